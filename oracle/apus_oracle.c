@@ -1,0 +1,966 @@
+/*
+ * apus_oracle.c -- CPU restatement of the APUS/DARE consensus hot path.
+ * TEST INFRASTRUCTURE ONLY (see apus_oracle.h for the rules and the parity pin).
+ *
+ * Part 1 restates src/include/dare/dare_log.h function by function.
+ * Part 2 restates the loops of src/dare/dare_server.c and
+ * src/dare/dare_ibv_rc.c over N in-process replicas; an RDMA WRITE is a
+ * memcpy to the same offset of the peer's structure, an RDMA READ a load.
+ *
+ * Schedule (the reference is timing dependent, the oracle is not): every
+ * posted WRITE/READ completes before the leader's next loop iteration, and a
+ * follower runs one polling() pass right after each doorbell (end / commit)
+ * lands in its memory.  Log bytes, offsets and the order of apply callbacks
+ * at every quiescent point do not depend on that choice.
+ */
+#include "apus_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+/* ================================================================== */
+/* Part 1: the log (dare_log.h)                                        */
+
+/* dare_log_entry_t, dare_log.h:33-47; offsets probed in SURVEY.md section 10 */
+typedef struct {
+    uint64_t idx;                       /*  0 */
+    uint64_t term;                      /*  8 */
+    uint64_t req_id;                    /* 16 */
+    uint16_t clt_id;                    /* 24 */
+    uint8_t  type;                      /* 26 */
+    uint8_t  sender;                    /* 27 */
+    uint8_t  reply[ORC_MAX_SERVERS];    /* 28 */
+    union {
+        struct { uint16_t len; uint8_t cmd[]; } cmd;   /* 48 ; payload @50 */
+        orc_cid_t cid;
+        uint64_t  head;
+    } data;
+} orc_entry_t;
+
+_Static_assert(sizeof(orc_entry_t) == ORC_HDR_BYTES, "entry header must be 64 bytes");
+_Static_assert(offsetof(orc_entry_t, clt_id) == 24, "clt_id@24");
+_Static_assert(offsetof(orc_entry_t, reply) == 28, "reply@28");
+_Static_assert(offsetof(orc_entry_t, data) == 48, "data@48");
+_Static_assert(sizeof(orc_cid_t) == 16, "cid is 16 bytes");
+
+/* dare_log_t, dare_log.h:77-102 (same field order; entries kept out of line) */
+struct orc_log {
+    uint64_t head, apply, commit, end, tail, old_end, old_commit, len;
+    orc_ncbuf_t nc_buf[ORC_MAX_SERVERS];
+    int prev_head;          /* the global prev_log_entry_head, dare_server.c:71 */
+    uint8_t *entries;
+};
+
+orc_log_t *orc_log_new(uint64_t len)           /* log_new, dare_log.h:120-136 */
+{
+    orc_log_t *log = calloc(1, sizeof *log);
+    if (!log) return NULL;
+    log->entries = calloc(1, len + ORC_HDR_BYTES);
+    if (!log->entries) { free(log); return NULL; }
+    log->len = len;
+    log->end = len;
+    log->tail = len;
+    log->old_end = len;
+    return log;
+}
+
+void orc_log_free(orc_log_t *log)
+{
+    if (!log) return;
+    free(log->entries);
+    free(log);
+}
+
+void orc_log_offsets(const orc_log_t *log, uint64_t out[8])
+{
+    out[0] = log->head; out[1] = log->apply; out[2] = log->commit; out[3] = log->end;
+    out[4] = log->tail; out[5] = log->old_end; out[6] = log->old_commit; out[7] = log->len;
+}
+
+void orc_log_set_offsets(orc_log_t *log, const uint64_t in[8])
+{
+    log->head = in[0]; log->apply = in[1]; log->commit = in[2]; log->end = in[3];
+    log->tail = in[4]; log->old_end = in[5]; log->old_commit = in[6];
+    /* len is fixed at creation */
+}
+
+uint8_t *orc_log_entries(orc_log_t *log) { return log->entries; }
+int orc_log_prev_head(const orc_log_t *log) { return log->prev_head; }
+void orc_log_set_prev_head(orc_log_t *log, int v) { log->prev_head = v; }
+
+static inline int log_empty(const orc_log_t *log) { return log->end == log->len; }   /* :158 */
+static inline int log_full(const orc_log_t *log)  { return log->end == log->head; }  /* :168 */
+static inline int fits_header(const orc_log_t *log, uint64_t off)                    /* :201 */
+{ return log->len - off >= ORC_HDR_BYTES; }
+
+static inline orc_entry_t *entry_at(const orc_log_t *log, uint64_t off)
+{ return (orc_entry_t *)(log->entries + off); }
+
+static inline uint32_t entry_len(const orc_entry_t *e)                               /* :228 */
+{
+    if (e->type == ORC_NOOP || e->type == ORC_CONFIG || e->type == ORC_HEAD)
+        return ORC_HDR_BYTES;
+    return ORC_HDR_BYTES + e->data.cmd.len;
+}
+
+static inline int fits_entry(const orc_log_t *log, uint64_t off, const orc_entry_t *e) /* :241 */
+{ return log->len - off >= entry_len(e); }
+
+uint64_t orc_log_end_distance(const orc_log_t *log, uint64_t off)                    /* :255 */
+{
+    uint64_t end = log->end;
+    if (end == log->len) return 0;
+    if (end >= off) return end - off;
+    return log->len - (off - end);
+}
+
+int orc_log_is_larger(const orc_log_t *log, uint64_t l, uint64_t r)                  /* :269 */
+{
+    /* "larger" means closer to end */
+    return orc_log_end_distance(log, l) < orc_log_end_distance(log, r);
+}
+
+/* log_get_entry :316-331; *off may be redirected to 0 */
+static orc_entry_t *get_entry(const orc_log_t *log, uint64_t *off)
+{
+    if (log_empty(log)) return NULL;
+    if (orc_log_end_distance(log, *off) == 0) return NULL;
+    if (!fits_header(log, *off)) *off = 0;
+    return entry_at(log, *off);
+}
+
+uint64_t orc_log_get_entry(const orc_log_t *log, uint64_t off)
+{
+    orc_entry_t *e = get_entry(log, &off);
+    return e ? off : UINT64_MAX;
+}
+
+uint32_t orc_log_entry_len_at(const orc_log_t *log, uint64_t off)
+{ return entry_len(entry_at(log, off)); }
+
+/* the walk shared by log_entries_to_nc_buf, log_get_tail and all the readers:
+ * step over one entry, honouring the "does not fit -> continues at 0" rule */
+static inline void step_over(const orc_log_t *log, uint64_t *off, const orc_entry_t *e)
+{
+    if (!fits_entry(log, *off, e)) *off = 0;
+    *off += entry_len(e);
+}
+
+void orc_log_to_ncbuf(const orc_log_t *log, orc_ncbuf_t *nc)                          /* :339-361 */
+{
+    uint64_t off = log->commit, n = 0;
+    orc_entry_t *e;
+    while ((e = get_entry(log, &off)) != NULL) {
+        nc->entries[n].idx = e->idx;
+        nc->entries[n].term = e->term;
+        nc->entries[n].offset = off;
+        n++;
+        step_over(log, &off, e);
+    }
+    nc->len = n;
+}
+
+uint64_t orc_log_find_remote_end(const orc_log_t *log, const orc_ncbuf_t *nc)         /* :367-395 */
+{
+    uint64_t off = 0;
+    for (uint64_t i = 0; i < nc->len; i++) {
+        off = nc->entries[i].offset;
+        orc_entry_t *e = get_entry(log, &off);
+        if (!e) return off;
+        if (e->idx != nc->entries[i].idx || e->term != nc->entries[i].term) return off;
+        step_over(log, &off, e);
+    }
+    return off;
+}
+
+static uint64_t scan_for_tail(const orc_log_t *log, uint64_t from)
+{
+    uint64_t off = from, tail = log->len;
+    orc_entry_t *e;
+    while ((e = get_entry(log, &off)) != NULL) {
+        tail = off;
+        step_over(log, &off, e);
+    }
+    return tail;
+}
+
+uint64_t orc_log_get_tail(const orc_log_t *log)                                       /* :402-457 */
+{
+    if (log->tail != log->len) return log->tail;
+    if (log_empty(log)) return log->len;
+    uint64_t t = scan_for_tail(log, log->commit);
+    if (t != log->len) return t;
+    t = scan_for_tail(log, log->apply);
+    if (t != log->len) return t;
+    return scan_for_tail(log, log->head);
+}
+
+/* log_add_new_entry :213-221 */
+static orc_entry_t *new_entry_slot(const orc_log_t *log)
+{
+    if (log_full(log)) return NULL;
+    if (log_empty(log) || !fits_header(log, log->end)) return entry_at(log, 0);
+    return entry_at(log, log->end);
+}
+
+static void fill_header(orc_entry_t *e, uint64_t idx, uint64_t term, uint64_t req_id,
+                        uint16_t clt_id, uint8_t type)
+{
+    e->idx = idx; e->term = term; e->req_id = req_id;
+    e->clt_id = clt_id; e->type = type;
+    memset(e->reply, 0, ORC_MAX_SERVERS);
+}
+
+uint64_t orc_log_append(orc_log_t *log, uint64_t term, uint64_t req_id,
+                        uint16_t clt_id, uint8_t type,
+                        const void *data, uint16_t data_len)                          /* :466-558 */
+{
+    if (type != ORC_HEAD) log->prev_head = 0;                     /* :477-480 */
+
+    if (log->tail == log->len) log->tail = orc_log_get_tail(log); /* :483-485 */
+    uint64_t off = log->tail;
+    orc_entry_t *last = get_entry(log, &off);
+    uint64_t idx = last ? last->idx + 1 : 1;                       /* :486-488 */
+
+    orc_entry_t *e = new_entry_slot(log);
+    if (!e) return 0;                                              /* log full, :492-495 */
+    fill_header(e, idx, term, req_id, clt_id, type);
+    if (!fits_header(log, log->end)) log->end = 0;                 /* :502-504 */
+
+    switch (type) {
+    case ORC_CONFIG: memcpy(&e->data.cid, data, sizeof(orc_cid_t)); break;
+    case ORC_HEAD:   memcpy(&e->data.head, data, sizeof(uint64_t)); break;
+    case ORC_NOOP:   break;
+    default:
+        e->data.cmd.len = data_len;
+        if (!fits_entry(log, log->end, e)) {                       /* :521-537 */
+            /* the header just written stays behind as a stale header */
+            log->end = 0;
+            e = new_entry_slot(log);
+            if (!e) return 0;
+            fill_header(e, idx, term, req_id, clt_id, type);
+            e->data.cmd.len = data_len;
+        }
+        if (data_len) memcpy(e->data.cmd.cmd, data, data_len);
+        break;
+    }
+    log->tail = log->end;                                          /* :547 */
+    log->end += entry_len(e);                                      /* :549 */
+    return idx;
+}
+
+/* ================================================================== */
+/* Part 2: the replicated state machine loops                          */
+
+/* SID word, src/include/dare/dare_server.h:47-66 */
+#define SID_IDX(s)    ((uint8_t)((s) & 0xFF))
+#define SID_L(s)      ((s) & (1ull << 8))
+#define SID_TERM(s)   ((s) >> 9)
+#define SID_MAKE(t, l, i) (((uint64_t)(t) << 9) | ((l) ? (1ull << 8) : 0) | (uint64_t)(i))
+
+/* log replication steps, dare_server.h:78-84 */
+enum { LR_GET_WRITE = 1, LR_GET_NCE_LEN, LR_GET_NCE, LR_SET_END, LR_UPDATE_LOG, LR_UPDATE_END };
+
+enum { PEND_NONE = 0, PEND_LOG, PEND_END, PEND_ADJ };
+
+typedef struct {
+    orc_log_t *log;
+    uint64_t sid;                               /* ctrl_data->sid */
+    orc_cid_t cid;                              /* config.cid     */
+    uint64_t cid_offset, cid_idx;               /* server_config_t */
+    uint8_t  idx;
+    int alive, held;
+    /* leader-side view of the peers (ctrl_data_t / server_t) */
+    uint64_t rem_end[ORC_MAX_SERVERS];          /* log_offsets[i].end    */
+    uint64_t rem_commit[ORC_MAX_SERVERS];       /* log_offsets[i].commit */
+    uint64_t apply_offsets[ORC_MAX_SERVERS];
+    uint64_t vote_ack[ORC_MAX_SERVERS];
+    uint64_t cached_end[ORC_MAX_SERVERS];       /* server_t.cached_end_offset */
+    uint8_t  lr_step[ORC_MAX_SERVERS];
+    uint8_t  send_flag[ORC_MAX_SERVERS];
+    uint8_t  pending[ORC_MAX_SERVERS];          /* what the outstanding WR was */
+    /* upcall bookkeeping (what the proxy callbacks would observe) */
+    uint64_t highest_rec;                       /* proxy.c:263 */
+    uint64_t store_count;                       /* proxy_store_cmd calls */
+    uint64_t apply_count, apply_hash;
+    orc_apply_t *apply_log; uint64_t apply_cap;
+    orc_det_t last_applied;                     /* dare_server.c:73 */
+} replica_t;
+
+struct orc_cluster {
+    int n;
+    uint64_t log_len;
+    int leader;                                  /* -1 when none */
+    int record_apply;
+    int allow_exact_fit;                         /* let SURVEY.md Q13 happen instead of failing */
+    int committed_flag;                          /* `committed`, dare_ibv_rc.c:1461 */
+    replica_t r[ORC_MAX_SERVERS];
+    uint64_t *round_commit, *round_end; uint64_t n_rounds, rounds_cap;
+};
+
+static inline int is_leader_r(const replica_t *p)                /* IS_LEADER, dare_server.c:42-46 */
+{ return SID_L(p->sid) && SID_IDX(p->sid) == p->idx; }
+
+static inline int cid_on(const orc_cid_t *cid, int i) { return (cid->bitmask >> i) & 1; }
+
+uint64_t orc_apply_mix(uint64_t h, uint64_t off, uint64_t idx, uint32_t len,
+                       uint16_t clt_id, uint8_t type, uint8_t kind)
+{
+    uint64_t v = off * 0x9E3779B97F4A7C15ull ^ idx * 0xC2B2AE3D27D4EB4Full
+               ^ ((uint64_t)len << 32 | (uint64_t)clt_id << 16 | (uint64_t)type << 8 | kind);
+    h ^= v;
+    h *= 0x100000001B3ull;
+    h ^= h >> 29;
+    return h;
+}
+
+static void record_apply(orc_cluster_t *c, replica_t *p, uint64_t off, const orc_entry_t *e, uint8_t kind)
+{
+    p->apply_hash = orc_apply_mix(p->apply_hash, off, e->idx, e->data.cmd.len, e->clt_id, e->type, kind);
+    if (c->record_apply) {
+        if (p->apply_count == p->apply_cap) {
+            p->apply_cap = p->apply_cap ? p->apply_cap * 2 : 1024;
+            p->apply_log = realloc(p->apply_log, p->apply_cap * sizeof(orc_apply_t));
+        }
+        orc_apply_t *a = &p->apply_log[p->apply_count];
+        a->off = off; a->idx = e->idx; a->len = e->data.cmd.len;
+        a->clt_id = e->clt_id; a->type = e->type; a->kind = kind;
+    }
+    p->apply_count++;
+}
+
+orc_cluster_t *orc_cluster_new(int group_size, uint64_t log_len)
+{
+    if (group_size < 1 || group_size > ORC_MAX_SERVERS) return NULL;
+    orc_cluster_t *c = calloc(1, sizeof *c);
+    if (!c) return NULL;
+    c->n = group_size;
+    c->log_len = log_len;
+    c->leader = -1;
+    for (int i = 0; i < group_size; i++) {
+        replica_t *p = &c->r[i];
+        p->log = orc_log_new(log_len);
+        p->idx = (uint8_t)i;
+        p->alive = 1;
+        /* init_server_data, dare_server.c:283-296: stable cid of group_size, all ON */
+        p->cid.epoch = 0; p->cid.size[0] = (uint8_t)group_size; p->cid.size[1] = 0;
+        p->cid.state = 0; p->cid.bitmask = (1u << group_size) - 1;
+        p->sid = SID_MAKE(0, 0, i);
+        for (int j = 0; j < ORC_MAX_SERVERS; j++) {
+            p->vote_ack[j] = log_len;
+            p->lr_step[j] = LR_GET_WRITE;
+            p->send_flag[j] = 1;
+        }
+    }
+    return c;
+}
+
+void orc_cluster_free(orc_cluster_t *c)
+{
+    if (!c) return;
+    for (int i = 0; i < c->n; i++) { orc_log_free(c->r[i].log); free(c->r[i].apply_log); }
+    free(c->round_commit); free(c->round_end);
+    free(c);
+}
+
+void orc_cluster_record_apply(orc_cluster_t *c, int on) { c->record_apply = on; }
+void orc_cluster_allow_exact_fit(orc_cluster_t *c, int on) { c->allow_exact_fit = on; }
+int orc_leader(const orc_cluster_t *c) { return c->leader; }
+int orc_group_size(const orc_cluster_t *c) { return c->n; }
+orc_log_t *orc_replica_log(orc_cluster_t *c, int r) { return c->r[r].log; }
+uint64_t orc_replica_sid(const orc_cluster_t *c, int r) { return c->r[r].sid; }
+uint64_t orc_replica_highest_rec(const orc_cluster_t *c, int r) { return c->r[r].highest_rec; }
+uint64_t orc_replica_apply_count(const orc_cluster_t *c, int r) { return c->r[r].apply_count; }
+uint64_t orc_replica_apply_hash(const orc_cluster_t *c, int r) { return c->r[r].apply_hash; }
+uint64_t orc_replica_store_count(const orc_cluster_t *c, int r) { return c->r[r].store_count; }
+const orc_apply_t *orc_replica_apply_log(const orc_cluster_t *c, int r, uint64_t *n)
+{ *n = c->record_apply ? c->r[r].apply_count : 0; return c->r[r].apply_log; }
+uint64_t orc_round_count(const orc_cluster_t *c) { return c->n_rounds; }
+const uint64_t *orc_round_commit(const orc_cluster_t *c) { return c->round_commit; }
+const uint64_t *orc_round_end(const orc_cluster_t *c) { return c->round_end; }
+
+/* --- persist_new_entries, dare_server.c:1792-1810 ------------------- */
+/* the follower ACK inside it is rc_send_entries_reply, dare_ibv_rc.c:1828-1863:
+ * reply[my_idx]=1 locally and, by a 1-byte WRITE, at the same offset of the
+ * log of entry->sender */
+static void persist_new_entries(orc_cluster_t *c, replica_t *p)
+{
+    orc_log_t *log = p->log;
+    while (orc_log_is_larger(log, log->end, log->old_end)) {
+        orc_entry_t *e = get_entry(log, &log->old_end);
+        if (!fits_entry(log, log->old_end, e)) { log->old_end = 0; continue; }
+        p->store_count++;                                   /* proxy_store_cmd(&entry->clt_id) */
+        if (is_leader_r(p)) {
+            e->sender = p->idx;
+        } else {
+            e->reply[p->idx] = 1;
+            replica_t *dst = &c->r[e->sender];
+            if (e->sender < c->n && dst->alive)              /* ep->rc_connected */
+                entry_at(dst->log, log->old_end)->reply[p->idx] = 1;
+        }
+        log->old_end += entry_len(e);
+    }
+}
+
+/* --- update_cid, dare_server.c:2192-2227 (connection side effects dropped) */
+static int cid_equal(const orc_cid_t *a, const orc_cid_t *b)
+{
+    return a->epoch == b->epoch && a->state == b->state && a->size[0] == b->size[0] &&
+           a->size[1] == b->size[1] && a->bitmask == b->bitmask;
+}
+static int update_cid(replica_t *p, const orc_cid_t *cid)
+{
+    if (cid_equal(&p->cid, cid)) return 1;
+    p->cid = *cid;
+    return 0;
+}
+
+/* --- poll_config_entries, dare_server.c:2133-2187 ------------------- */
+static void poll_config_entries(replica_t *p)
+{
+    orc_log_t *log = p->log;
+    uint64_t head_offset = log->head, off = p->cid_offset, commit = log->commit;
+    while (orc_log_end_distance(log, off)) {
+        orc_entry_t *e = get_entry(log, &off);
+        if (!fits_entry(log, off, e)) { off = 0; continue; }
+        if (e->type == ORC_CONFIG) {
+            if (e->idx > p->cid_idx) update_cid(p, &e->data.cid);
+        } else if (e->type == ORC_HEAD) {
+            if (!orc_log_is_larger(log, off, commit))       /* committed HEAD entries only */
+                head_offset = e->data.head;
+        }
+        off += entry_len(e);
+    }
+    p->cid_offset = orc_log_is_larger(log, off, commit) ? commit : off;
+    if (orc_log_is_larger(log, head_offset, log->head)) log->head = head_offset;
+}
+
+/* --- apply_committed_entries, dare_server.c:1815-1974 --------------- */
+/* stable configurations only: the 3-phase resize branches (:1883-1937) are
+ * outside the hot-path scope */
+static void apply_committed_entries(orc_cluster_t *c, replica_t *p)
+{
+    orc_log_t *log = p->log;
+    int leader = is_leader_r(p);
+    while (orc_log_is_larger(log, log->commit, log->apply)) {
+        orc_entry_t *e = get_entry(log, &log->apply);
+        if (!fits_entry(log, log->apply, e)) { log->apply = 0; continue; }
+        int client = (e->type != ORC_CONFIG && e->type != ORC_NOOP && e->type != ORC_HEAD);
+        if (client) {
+            if (leader) { p->highest_rec++; record_apply(c, p, log->apply, e, 1); }
+            else        { record_apply(c, p, log->apply, e, 2); }
+            p->last_applied.idx = e->idx;
+            p->last_applied.term = e->term;
+            p->last_applied.offset = log->apply + entry_len(e);
+        }
+        log->apply += entry_len(e);
+    }
+}
+
+/* one follower polling() pass, dare_server.c:1012-1125 (non-leader branch) */
+static void follower_poll(orc_cluster_t *c, replica_t *p)
+{
+    if (!p->alive) return;
+    persist_new_entries(c, p);
+    poll_config_entries(p);
+    apply_committed_entries(c, p);
+}
+
+/* --- handle_lr_work_completion, dare_ibv_rc.c:3126-3196 (success path) */
+static void complete_pending(orc_cluster_t *c, replica_t *L)
+{
+    for (int i = 0; i < c->n; i++) {
+        switch (L->pending[i]) {
+        case PEND_LOG: L->lr_step[i] = LR_UPDATE_END; L->send_flag[i] = 1; break;
+        case PEND_END: L->lr_step[i] = LR_UPDATE_LOG; L->send_flag[i] = 1; break;
+        case PEND_ADJ: L->lr_step[i]++;               L->send_flag[i] = 1; break;
+        default: break;
+        }
+        L->pending[i] = PEND_NONE;
+    }
+}
+
+static inline int peer_reachable(const orc_cluster_t *c, const replica_t *L, int i)
+{
+    /* CID_IS_SERVER_ON && fail_count < PERMANENT_FAILURE && rc_connected;
+     * a held peer models a link the leader cannot currently post to */
+    return i != L->idx && cid_on(&L->cid, i) && c->r[i].alive && !c->r[i].held;
+}
+
+/* --- log_adjustment, dare_ibv_rc.c:1292-1451 ------------------------ */
+static void log_adjustment(orc_cluster_t *c, replica_t *L)
+{
+    orc_log_t *log = L->log;
+    for (int i = 0; i < c->n; i++) {
+        if (!peer_reachable(c, L, i) || !L->send_flag[i]) continue;
+        uint64_t remote_commit = L->vote_ack[i];
+        if (remote_commit == log->len) continue;             /* no vote ACK from this server */
+        replica_t *F = &c->r[i];
+        switch (L->lr_step[i]) {
+        case LR_GET_WRITE:
+            L->rem_commit[i] = remote_commit;
+            L->lr_step[i] = LR_GET_NCE_LEN;
+            __attribute__((fallthrough));    /* no break in the reference either, :1357 */
+        case LR_GET_NCE_LEN:
+            if (orc_log_is_larger(log, remote_commit, log->commit)) log->commit = remote_commit;
+            log->nc_buf[i].len = F->log->nc_buf[i].len;       /* READ 8 bytes */
+            break;
+        case LR_GET_NCE:
+            if (log->nc_buf[i].len == 0) {
+                L->rem_end[i] = L->rem_commit[i];
+                L->lr_step[i] = LR_UPDATE_LOG;
+                continue;
+            }
+            memcpy(log->nc_buf[i].entries, F->log->nc_buf[i].entries,
+                   log->nc_buf[i].len * sizeof(orc_det_t)); /* READ len*24 bytes */
+            break;
+        case LR_SET_END:
+            L->rem_end[i] = orc_log_find_remote_end(log, &log->nc_buf[i]);
+            F->log->end = L->rem_end[i];                      /* WRITE 8 bytes */
+            break;
+        default:
+            continue;
+        }
+        L->send_flag[i] = 0;
+        L->pending[i] = PEND_ADJ;
+    }
+}
+
+static void ring_write(orc_log_t *dst, const orc_log_t *src, uint64_t from, uint64_t to)
+{
+    memcpy(dst->entries + from, src->entries + from, to - from);
+}
+
+/* --- update_remote_logs, dare_ibv_rc.c:1465-1826 -------------------- */
+static void update_remote_logs(orc_cluster_t *c, replica_t *L)
+{
+    orc_log_t *log = L->log;
+    int size = L->cid.size[0];      /* stable cid: get_extended_group_size == size[0] */
+
+    for (int i = 0; i < size; i++) {
+        if (!peer_reachable(c, L, i) || !L->send_flag[i]) continue;
+        replica_t *F = &c->r[i];
+        if (L->lr_step[i] == LR_UPDATE_LOG) {                 /* :1507-1547 */
+            uint64_t rend = L->rem_end[i];
+            if (orc_log_end_distance(log, rend) == 0) continue;
+            L->cached_end[i] = log->end;
+            if (log->end > rend) {
+                ring_write(F->log, log, rend, log->end);
+            } else {                                          /* wrap: two WRs, :1538-1545 */
+                ring_write(F->log, log, rend, log->len);
+                ring_write(F->log, log, 0, log->end);
+            }
+            L->pending[i] = PEND_LOG;
+        } else if (L->lr_step[i] == LR_UPDATE_END) {          /* :1549-1573 */
+            L->rem_end[i] = L->cached_end[i];
+            F->log->end = L->rem_end[i];
+            L->pending[i] = PEND_END;
+            follower_poll(c, F);                              /* doorbell seen: persist + ACK */
+        } else {
+            continue;
+        }
+        L->send_flag[i] = 0;
+    }
+
+    /* commit scan over the ACK bytes, :1725-1758 (the offset-median code above
+     * it is dead: its result is overwritten at :1725) */
+    uint64_t min_offset = log->commit;
+    while (orc_log_end_distance(log, min_offset)) {
+        orc_entry_t *e = get_entry(log, &min_offset);
+        if (!fits_entry(log, min_offset, e)) { min_offset = 0; continue; }
+        int replies = 0;
+        for (int i = 0; i < size; i++)
+            if (i == L->idx || e->reply[i] == 1) replies++;
+        if (replies < size / 2 + 1) break;
+        min_offset += entry_len(e);
+    }
+    if (orc_log_is_larger(log, min_offset, log->commit)) {
+        log->commit = min_offset;
+        L->cid_offset = log->commit;
+        c->committed_flag = 1;
+    }
+
+    /* lazy commit propagation, :1761-1819 */
+    for (int i = 0; i < size; i++) {
+        if (!peer_reachable(c, L, i) || L->lr_step[i] != LR_UPDATE_LOG) continue;
+        uint64_t *rc = &L->rem_commit[i], *re = &L->rem_end[i];
+        if (*rc == *re || *rc == log->commit) continue;
+        *rc = log->commit;
+        if (orc_log_is_larger(log, *rc, *re)) *rc = *re;
+        replica_t *F = &c->r[i];
+        F->log->commit = *rc;                                 /* WRITE 8 bytes */
+        follower_poll(c, F);
+    }
+}
+
+/* --- rc_write_remote_logs, dare_ibv_rc.c:1870-1948 ------------------ */
+static void write_remote_logs(orc_cluster_t *c, replica_t *L, int wait_for_commit)
+{
+    int threshold = 0;
+    if (wait_for_commit) c->committed_flag = 0;
+    for (;;) {
+        complete_pending(c, L);          /* empty_completion_queue(LOG_QP) */
+        threshold++;
+        log_adjustment(c, L);
+        update_remote_logs(c, L);
+        if (wait_for_commit && c->committed_flag) return;
+        if (threshold == 1000) return;
+        if (!wait_for_commit) return;
+    }
+}
+
+/* --- commit_new_entries, dare_server.c:1751-1789 -------------------- */
+static void commit_new_entries(orc_cluster_t *c, replica_t *L)
+{
+    orc_log_t *log = L->log;
+    if (orc_log_end_distance(log, log->commit)) {
+        write_remote_logs(c, L, 1);
+    } else if (!log_empty(log)) {
+        for (int i = 0; i < L->cid.size[0]; i++) {
+            if (!peer_reachable(c, L, i)) continue;
+            if (L->vote_ack[i] == log->len) continue;
+            if (L->lr_step[i] != LR_UPDATE_LOG || L->rem_end[i] != log->end) {
+                write_remote_logs(c, L, 0);
+                break;
+            }
+        }
+    }
+}
+
+/* leader polling() pass after the tailq was drained, dare_server.c:1095-1124 */
+static void leader_poll(orc_cluster_t *c, replica_t *L)
+{
+    persist_new_entries(c, L);
+    commit_new_entries(c, L);
+    apply_committed_entries(c, L);
+}
+
+static void note_round(orc_cluster_t *c, replica_t *L)
+{
+    if (c->n_rounds == c->rounds_cap) {
+        c->rounds_cap = c->rounds_cap ? c->rounds_cap * 2 : 1024;
+        c->round_commit = realloc(c->round_commit, c->rounds_cap * sizeof(uint64_t));
+        c->round_end = realloc(c->round_end, c->rounds_cap * sizeof(uint64_t));
+    }
+    c->round_commit[c->n_rounds] = L->log->commit;
+    c->round_end[c->n_rounds] = L->log->end;
+    c->n_rounds++;
+}
+
+int orc_round(orc_cluster_t *c, const orc_req_t *reqs, int n, const uint8_t *arena)
+{
+    if (c->leader < 0) return -1;
+    replica_t *L = &c->r[c->leader];
+    /* get_tailq_message, dare_ibv_ud.c:780-790 */
+    for (int k = 0; k < n; k++) {
+        uint64_t idx = orc_log_append(L->log, SID_TERM(L->sid), reqs[k].req_id, reqs[k].clt_id,
+                                      reqs[k].type, arena ? arena + reqs[k].payload_off : NULL,
+                                      reqs[k].len);
+        if (idx == 0) return -2;        /* log full: the reference drops the request (Q6) */
+        if (L->log->end == L->log->len && !c->allow_exact_fit) return -3;   /* exact-fit wrap, SURVEY.md Q13 */
+    }
+    leader_poll(c, L);
+    note_round(c, L);
+    return 0;
+}
+
+int orc_quiesce(orc_cluster_t *c)
+{
+    if (c->leader < 0) return -1;
+    replica_t *L = &c->r[c->leader];
+    /* poll until nothing moves any more */
+    for (int it = 0; it < 64; it++) {
+        uint64_t before[ORC_MAX_SERVERS][4];
+        for (int i = 0; i < c->n; i++) {
+            before[i][0] = c->r[i].log->end; before[i][1] = c->r[i].log->commit;
+            before[i][2] = c->r[i].log->apply; before[i][3] = c->r[i].log->old_end;
+        }
+        uint8_t steps[ORC_MAX_SERVERS];
+        memcpy(steps, L->lr_step, sizeof steps);
+        leader_poll(c, L);
+        for (int i = 0; i < c->n; i++) if (i != c->leader) follower_poll(c, &c->r[i]);
+        int moved = memcmp(steps, L->lr_step, sizeof steps) != 0;
+        for (int i = 0; i < c->n; i++) {
+            moved |= before[i][0] != c->r[i].log->end || before[i][1] != c->r[i].log->commit ||
+                     before[i][2] != c->r[i].log->apply || before[i][3] != c->r[i].log->old_end;
+        }
+        for (int i = 0; i < c->n; i++) moved |= L->pending[i] != PEND_NONE;
+        if (!moved) return 0;
+    }
+    return 1;
+}
+
+/* --- log_pruning, dare_server.c:1996-2067 + rc_get_remote_apply_offsets,
+ *     dare_ibv_rc.c:1970-2034 ------------------------------------------- */
+int orc_tick_prune(orc_cluster_t *c)
+{
+    if (c->leader < 0) return -1;
+    replica_t *L = &c->r[c->leader];
+    orc_log_t *log = L->log;
+    int size = L->cid.size[0];
+    /* Trace semantics: the prune timer fires between polling() passes once every
+     * follower has caught up (ms-scale timer vs us-scale rounds), so the apply
+     * offsets sampled by R8 below do not depend on the lazy commit lag. */
+    orc_quiesce(c);
+    uint64_t min_offset = log->apply;
+    for (int i = 0; i < size; i++) {
+        if (!cid_on(&L->cid, i)) L->apply_offsets[i] = log->apply;
+        if (orc_log_is_larger(log, min_offset, L->apply_offsets[i])) min_offset = L->apply_offsets[i];
+    }
+    if (!orc_log_end_distance(log, min_offset)) min_offset = orc_log_get_tail(log);
+    int appended = 0;
+    if (orc_log_is_larger(log, min_offset, log->head) && !log->prev_head) {
+        log->head = min_offset;
+        uint64_t idx = orc_log_append(log, SID_TERM(L->sid), 0, 0, ORC_HEAD, &log->head, 0);
+        if (idx == 0) return -2;
+        log->prev_head = 1;
+        appended = 1;
+    }
+    /* READ every reachable peer's apply offset for the next tick */
+    for (int i = 0; i < size; i++) {
+        if (i == L->idx || !cid_on(&L->cid, i)) { L->apply_offsets[i] = log->apply; continue; }
+        if (!c->r[i].alive || c->r[i].held) continue;
+        if (L->vote_ack[i] == log->len) continue;
+        L->apply_offsets[i] = c->r[i].log->apply;
+    }
+    if (appended) { leader_poll(c, L); note_round(c, L); }
+    return appended;
+}
+
+int orc_kill(orc_cluster_t *c, int r)
+{
+    if (r < 0 || r >= c->n) return -1;
+    c->r[r].alive = 0;
+    if (c->leader == r) c->leader = -1;
+    else if (c->leader >= 0) {
+        /* check_failure_count, dare_server.c:1189-1230: the leader drops the peer
+         * from the bitmask and logs a CONFIG entry */
+        replica_t *L = &c->r[c->leader];
+        if (cid_on(&L->cid, r)) {
+            L->cid.bitmask &= ~(1u << r);
+            uint64_t idx = orc_log_append(L->log, SID_TERM(L->sid), 0, 0, ORC_CONFIG, &L->cid, 0);
+            if (idx == 0) return -2;
+            leader_poll(c, L);
+            note_round(c, L);
+        }
+    }
+    return 0;
+}
+
+int orc_hold(orc_cluster_t *c, int r)    { if (r < 0 || r >= c->n) return -1; c->r[r].held = 1; return 0; }
+int orc_release(orc_cluster_t *c, int r) { if (r < 0 || r >= c->n) return -1; c->r[r].held = 0; return 0; }
+
+/* --- election: start_election dare_server.c:1264-1322, poll_vote_requests
+ *     :1526-1743, poll_vote_count :1327-1518, vote request / ack
+ *     dare_ibv_rc.c:969-1045 / :1116-1180 -------------------------------- */
+static void last_entry_of(const orc_log_t *log, uint64_t *idx, uint64_t *term)
+{
+    *idx = 0; *term = 0;
+    if (log_empty(log)) return;
+    uint64_t tail = orc_log_get_tail(log);
+    if (tail == log->len) return;
+    orc_entry_t *e = get_entry(log, &tail);
+    if (e) { *idx = e->idx; *term = e->term; }
+}
+
+static void start_election(orc_cluster_t *c, replica_t *p)
+{
+    p->sid = SID_MAKE(SID_TERM(p->sid) + 1, 0, p->idx);
+    for (int i = 0; i < c->n; i++) {
+        p->vote_ack[i] = p->log->len;
+        p->lr_step[i] = LR_GET_WRITE;
+        p->send_flag[i] = 1;
+        p->pending[i] = PEND_NONE;
+    }
+}
+
+/* returns 1 when voter v grants its vote to candidate w */
+static int vote_for(orc_cluster_t *c, replica_t *v, replica_t *w,
+                    uint64_t req_sid, uint64_t req_idx, uint64_t req_term)
+{
+    if (SID_L(v->sid)) return 0;                          /* :1536-1541 */
+    uint64_t old_sid = v->sid | (1ull << 8);              /* :1560 */
+    if (old_sid >= req_sid) return 0;
+    /* exclusive access to the local log; not-committed buffer, :1603-1626 */
+    orc_ncbuf_t *nc = &v->log->nc_buf[v->idx];
+    orc_log_to_ncbuf(v->log, nc);
+    uint64_t my_idx, my_term;
+    if (nc->len == 0) last_entry_of(v->log, &my_idx, &my_term);
+    else { my_idx = nc->entries[nc->len - 1].idx; my_term = nc->entries[nc->len - 1].term; }
+    if (my_term > req_term || (my_term == req_term && my_idx > req_idx)) {
+        /* candidate's log is not good enough: raise own term, no vote, :1661-1673 */
+        v->sid = SID_MAKE(SID_TERM(req_sid), 0, v->idx);
+        return 0;
+    }
+    v->sid = req_sid;                                     /* :1690 */
+    update_cid(v, &w->cid);                               /* :1697 */
+    w->vote_ack[v->idx] = v->log->commit;                 /* rc_send_vote_ack */
+    (void)c;
+    return 1;
+}
+
+int orc_elect(orc_cluster_t *c, int winner)
+{
+    if (winner < 0 || winner >= c->n || !c->r[winner].alive) return -1;
+    replica_t *w = &c->r[winner];
+    if (c->leader >= 0 && c->leader != winner) {
+        /* a live leader steps down only when it sees a higher term; the trace
+         * must KILL it first */
+        return -1;
+    }
+    /* Step 1: every live server misses the leader's heartbeat (or, at start-up,
+     * reaches RC_ESTABLISHED, dare_server.c:1169) and becomes a candidate of
+     * term t+1; same-term requests are mutually dropped (:1568). */
+    for (int i = 0; i < c->n; i++) if (c->r[i].alive) start_election(c, &c->r[i]);
+    /* Step 2: the winner's election timeout fires first: term t+2 */
+    start_election(c, w);
+    uint64_t req_idx, req_term;
+    last_entry_of(w->log, &req_idx, &req_term);            /* rc_send_vote_request */
+    uint64_t req_sid = w->sid;
+    int votes = 1;
+    for (int i = 0; i < c->n; i++) {
+        if (i == winner || !c->r[i].alive || c->r[i].held) continue;
+        if (!cid_on(&w->cid, i)) continue;
+        votes += vote_for(c, &c->r[i], w, req_sid, req_idx, req_term);
+    }
+    /* poll_vote_count, :1327-1518 */
+    for (int i = 0; i < c->n; i++) {
+        if (i == winner) continue;
+        uint64_t rc = w->vote_ack[i];
+        if (rc == w->log->len) continue;
+        w->rem_commit[i] = rc;
+        w->lr_step[i] = LR_GET_NCE_LEN;
+        if (orc_log_is_larger(w->log, rc, w->log->commit)) w->log->commit = rc;
+    }
+    if (votes < w->cid.size[0] / 2 + 1) return -1;
+    w->sid |= (1ull << 8);
+    c->leader = winner;
+    poll_config_entries(w);
+    apply_committed_entries(c, w);
+    /* blank CONFIG entry, :1411-1421 */
+    if (orc_log_append(w->log, SID_TERM(w->sid), 0, 0, ORC_CONFIG, &w->cid, 0) == 0) return -2;
+    for (int i = 0; i < w->cid.size[0]; i++) w->apply_offsets[i] = w->log->head;   /* :1504-1507 */
+    /* heartbeats reach everybody: hb_receive_cb :822-920 resets tail and adopts
+     * the leader's SID; servers that did not vote run server_to_follower :2238 */
+    for (int i = 0; i < c->n; i++) {
+        replica_t *p = &c->r[i];
+        if (i == winner || !p->alive || p->held) continue;
+        p->log->tail = p->log->len;
+        if (SID_TERM(p->sid) != SID_TERM(w->sid) || w->vote_ack[i] == w->log->len) {
+            orc_log_to_ncbuf(p->log, &p->log->nc_buf[p->idx]);
+            w->vote_ack[i] = p->log->commit;
+        }
+        p->sid = w->sid;
+    }
+    leader_poll(c, w);
+    note_round(c, w);
+    return 0;
+}
+
+int orc_run_rounds(orc_cluster_t *c, const orc_req_t *reqs, const uint32_t *round_n,
+                   uint64_t n_rounds, const uint8_t *arena, uint64_t prune_bytes)
+{
+    uint64_t since = 0, g = 0;
+    for (uint64_t r = 0; r < n_rounds; r++) {
+        uint32_t n = round_n[r];
+        int rc = orc_round(c, reqs + g, (int)n, arena);
+        if (rc) return rc;
+        for (uint32_t k = 0; k < n; k++) {
+            uint8_t t = reqs[g + k].type;
+            since += ORC_HDR_BYTES + ((t == ORC_NOOP || t == ORC_CONFIG || t == ORC_HEAD) ? 0 : reqs[g + k].len);
+        }
+        g += n;
+        if (prune_bytes && since >= prune_bytes) {
+            rc = orc_tick_prune(c);
+            if (rc < 0) return rc;
+            since = 0;
+        }
+    }
+    return 0;
+}
+
+/* ================================================================== */
+/* helpers: payload stream, canonical digest                           */
+
+uint64_t orc_splitmix64(uint64_t *state)
+{
+    uint64_t z = (*state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+void orc_fill_payload(uint64_t seed, uint8_t *dst, uint32_t len)
+{
+    uint64_t s = seed;
+    uint32_t i = 0;
+    while (i < len) {
+        uint64_t v = orc_splitmix64(&s);
+        for (int b = 0; b < 8 && i < len; b++, i++) dst[i] = (uint8_t)(v >> (8 * b));
+    }
+}
+
+typedef struct { uint8_t *out; uint64_t cap, n, hash; int hashing; } sink_t;
+
+static void sink_put(sink_t *s, const void *p, uint64_t n)
+{
+    const uint8_t *b = p;
+    if (s->hashing) {
+        uint64_t h = s->hash;
+        for (uint64_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001B3ull; }
+        s->hash = h;
+    } else {
+        for (uint64_t i = 0; i < n; i++) if (s->n + i < s->cap) s->out[s->n + i] = b[i];
+    }
+    s->n += n;
+}
+
+static uint64_t canon_walk(const uint8_t *ring, uint64_t len, uint64_t end,
+                           uint64_t from, uint64_t to, sink_t *s)
+{
+    /* the same reader rule as log_get_entry / log_fit_entry, on a bare ring */
+    uint64_t count = 0, off = from;
+    if (end == len) return 0;
+    while (off != to) {
+        if (len - off < ORC_HDR_BYTES) { off = 0; if (off == to) break; }
+        const orc_entry_t *e = (const orc_entry_t *)(ring + off);
+        uint32_t elen = entry_len(e);
+        if (len - off < elen) { off = 0; continue; }
+        uint8_t zero = 0;
+        uint32_t dlen;
+        const void *data;
+        switch (e->type) {
+        case ORC_CONFIG: dlen = 16; data = &e->data.cid; break;
+        case ORC_HEAD:   dlen = 8;  data = &e->data.head; break;
+        case ORC_NOOP:   dlen = 0;  data = NULL; break;
+        default:         dlen = e->data.cmd.len; data = e->data.cmd.cmd; break;
+        }
+        sink_put(s, &off, 8); sink_put(s, &e->idx, 8); sink_put(s, &e->term, 8);
+        sink_put(s, &e->req_id, 8); sink_put(s, &e->clt_id, 2); sink_put(s, &e->type, 1);
+        sink_put(s, &zero, 1); sink_put(s, &dlen, 4);
+        if (dlen) sink_put(s, data, dlen);
+        off += elen;
+        count++;
+        if (count > (1ull << 32)) break;        /* corrupt ring guard */
+    }
+    return count;
+}
+
+uint64_t orc_canon(const uint8_t *ring, uint64_t len, uint64_t end, uint64_t from, uint64_t to,
+                   uint8_t *out, uint64_t cap, uint64_t *n_entries)
+{
+    sink_t s = { out, cap, 0, 0, 0 };
+    uint64_t n = canon_walk(ring, len, end, from, to, &s);
+    if (n_entries) *n_entries = n;
+    return s.n;
+}
+
+uint64_t orc_canon_hash(const uint8_t *ring, uint64_t len, uint64_t end, uint64_t from, uint64_t to,
+                        uint64_t *n_entries)
+{
+    sink_t s = { NULL, 0, 0, 0xCBF29CE484222325ull, 1 };
+    uint64_t n = canon_walk(ring, len, end, from, to, &s);
+    if (n_entries) *n_entries = n;
+    return s.hash;
+}
