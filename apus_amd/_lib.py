@@ -1,0 +1,72 @@
+"""ctypes loader of libapus_gpu.so.  Fails loudly: there is no CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+u64, u32, u16, u8 = C.c_uint64, C.c_uint32, C.c_uint16, C.c_uint8
+vp = C.c_void_p
+
+
+class Cfg(C.Structure):
+    _fields_ = [("group_size", u32), ("n_local", u32), ("local_ids", u8 * 13), ("pad", u8 * 3),
+                ("log_len", u64), ("device", C.c_int32), ("flags", u32), ("stream", vp)]
+
+
+_lib = None
+
+SIGNATURES = {
+    "apus_gpu_create": (C.c_int, [C.POINTER(Cfg), C.POINTER(vp)]),
+    "apus_gpu_destroy": (None, [vp]),
+    "apus_gpu_reset": (C.c_int, [vp]),
+    "apus_gpu_sync": (C.c_int, [vp]),
+    "apus_gpu_stage": (C.c_int, [vp, vp, u64, vp, u64, vp, u64]),
+    "apus_gpu_become_leader": (C.c_int, [vp, u32, u64, u32]),
+    "apus_gpu_set_reachable": (C.c_int, [vp, u32]),
+    "apus_gpu_append_control": (C.c_int, [vp, u8, vp]),
+    "apus_gpu_run_rounds": (C.c_int, [vp, u64, u64]),
+    "apus_gpu_tick_prune": (C.c_int, [vp]),
+    "apus_gpu_quiesce": (C.c_int, [vp]),
+    "apus_gpu_capture_begin": (C.c_int, [vp]),
+    "apus_gpu_capture_end": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "apus_gpu_graph_launch": (C.c_int, [vp, C.c_int]),
+    "apus_gpu_offsets": (C.c_int, [vp, u32, C.POINTER(u64)]),
+    "apus_gpu_counters": (C.c_int, [vp, u32, C.POINTER(u64)]),
+    "apus_gpu_hdr_words": (C.c_int, [vp, u32, C.POINTER(u64), u32]),
+    "apus_gpu_read_ring": (C.c_int, [vp, u32, u64, u64, vp]),
+    "apus_gpu_round_record": (C.c_int, [vp, u64, u64, vp, vp]),
+    "apus_gpu_round_count": (u64, [vp]),
+    "apus_gpu_apply_records": (C.c_int, [vp, u32, u64, u64, vp]),
+    "apus_gpu_status": (u32, [vp]),
+    "apus_gpu_clear_status": (None, [vp]),
+    "apus_gpu_device_ptr": (vp, [vp, u32, C.c_int, C.POINTER(u64)]),
+    "apus_gpu_set_timing": (C.c_int, [vp, C.c_int]),
+    "apus_gpu_kernel_time": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(u64)]),
+    "apus_gpu_stream": (vp, [vp]),
+    "apus_gpu_bind_global": (C.c_int, [vp]),
+}
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load the HIP extension; raise if it cannot be built/loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError(f"{path} is missing: run python -m apus_amd.build (no CPU fallback exists)")
+        _build.build()
+    L = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)          # AttributeError if the ABI symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L

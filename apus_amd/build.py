@@ -1,0 +1,53 @@
+"""Build libapus_gpu.so (hand-written HIP for gfx950 + the C host layer) in-tree."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(PKG, "host")
+LIB = os.path.join(PKG, "libapus_gpu.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+SOURCES = [os.path.join(CSRC, "apus_engine.hip")]
+DEPS = [os.path.join(CSRC, "apus_kernels.h"), os.path.join(CSRC, "apus_device.h"),
+        os.path.join(CSRC, "apus_persistent.h"), os.path.join(ROOT, "include", "apus_gpu.h")]
+
+
+def _host_c_sources():
+    if not os.path.isdir(HOST):
+        return []
+    return sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".c") and not f.startswith("hook_"))
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SOURCES + DEPS + _host_c_sources())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not stale():
+        return LIB
+    objs = []
+    for c in _host_c_sources():
+        o = c[:-2] + ".o"
+        cmd = ["gcc", "-O2", "-g", "-fPIC", "-std=gnu11", "-Wall", "-I", os.path.join(ROOT, "include"), "-c", c, "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        objs.append(o)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", LIB] + SOURCES + objs + ["-lpthread"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,656 @@
+/*
+ * apus_engine.hip -- host side of libapus_gpu.so: owns the HBM-resident state of
+ * the local replicas and turns the C ABI of include/apus_gpu.h into kernel
+ * launches on one HIP stream.  Every hot-path call is asynchronous and free of
+ * host read-backs, so a sequence of calls can be captured into a hipGraph.
+ *
+ * There is no CPU fallback: every entry point needs a gfx950 device.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/apus_gpu.h"
+#include "apus_kernels.h"
+
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { \
+    fprintf(stderr, "[apus_gpu] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+    return APUS_E_HIP; } } while (0)
+
+static_assert(sizeof(apus_apply_t) == 32 && sizeof(apus_apply_rec) == 32, "apply record is 32 bytes");
+static_assert(sizeof(apus_req_t) == 24, "request record is 24 bytes");
+static_assert(sizeof(ReqDev) == 16, "device request descriptor is 16 bytes");
+static_assert(sizeof(EngDev) <= 3072, "EngDev travels as a kernel argument");
+
+struct TimedLaunch { hipEvent_t a, b; };
+
+struct apus_engine {
+    apus_cfg_t cfg;
+    EngDev d;                       /* host mirror, passed by value to every kernel */
+    hipStream_t stream;
+    bool own_stream;
+    uint32_t dir_cap;
+    uint32_t local_mask;            /* replicas hosted here */
+    uint32_t reachable;             /* peers the leader can post to (trace KILL/HOLD/RELEASE) */
+    uint64_t max_rounds;
+    /* staging */
+    void *d_req, *d_req_len, *d_arena, *d_round_first;
+    uint64_t n_reqs, n_rounds_staged;
+    std::vector<uint32_t> h_round_first;
+    /* graphs */
+    std::vector<hipGraphExec_t> graphs;
+    bool capturing;
+    /* timing of the dominant kernel (k_append_push) */
+    bool timing;
+    std::vector<TimedLaunch> timed;
+    size_t timed_used;
+    std::vector<void *> allocs;
+    /* live submission path (apus_gpu_submit): pinned host staging + device buffers */
+    uint8_t *h_live;                /* pinned: [ReqDev x LIVE_REQS][u16 x LIVE_REQS][u32 x (LIVE_REQS+1)][arena] */
+    uint8_t *d_live;
+    hipEvent_t live_copied;
+    bool live_pending;
+    uint64_t live_r0, live_R, live_n;   /* rounds appended by apus_gpu_append_live, not yet committed */
+};
+
+#define LIVE_REQS   4096u
+#define LIVE_ARENA  (16u << 20)
+#define LIVE_OFF_LEN    (sizeof(ReqDev) * LIVE_REQS)
+#define LIVE_OFF_RF     (LIVE_OFF_LEN + sizeof(uint16_t) * LIVE_REQS)
+#define LIVE_OFF_ARENA  (LIVE_OFF_RF + sizeof(uint32_t) * (LIVE_REQS + 1) + 16)
+#define LIVE_BYTES      (LIVE_OFF_ARENA + LIVE_ARENA + 64)
+
+static apus_engine *g_engine = nullptr;
+
+template <typename T>
+static int dev_alloc(apus_engine *e, T **out, size_t bytes, bool zero = true)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return APUS_E_NOMEM;
+    if (zero && hipMemset(p, 0, bytes) != hipSuccess) return APUS_E_HIP;
+    e->allocs.push_back(p);
+    *out = (T *)p;
+    return 0;
+}
+
+static uint32_t pow2_at_least(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+static inline uint32_t sync_mask(const apus_engine *e)
+{
+    /* local followers the leader can currently post to */
+    if (e->d.leader >= APUS_MAX_SERVERS) return 0;
+    return e->local_mask & e->reachable & ~(1u << e->d.leader);
+}
+static inline int popc(uint32_t v) { return __builtin_popcount(v); }
+
+extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
+{
+    if (!cfg || !out || cfg->group_size < 1 || cfg->group_size > APUS_MAX_SERVERS ||
+        cfg->n_local < 1 || cfg->n_local > cfg->group_size) return APUS_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "[apus_gpu] no HIP device: the consensus engine has no CPU path\n");
+        return APUS_E_HIP;
+    }
+    HIPCHK(hipSetDevice(cfg->device));
+    apus_engine *e = new apus_engine();
+    e->cfg = *cfg;
+    memset(&e->d, 0, sizeof e->d);
+    e->capturing = false; e->timing = false; e->timed_used = 0;
+    e->n_reqs = 0; e->n_rounds_staged = 0;
+    e->d_req = e->d_req_len = e->d_arena = e->d_round_first = nullptr;
+    e->h_live = nullptr; e->d_live = nullptr; e->live_pending = false; e->live_copied = nullptr;
+    e->live_r0 = e->live_R = e->live_n = 0;
+    if (cfg->stream) { e->stream = (hipStream_t)cfg->stream; e->own_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
+
+    const uint64_t L = cfg->log_len ? cfg->log_len : APUS_LOG_SIZE;
+    if (L < 1024 || (L % 64)) { delete e; return APUS_E_ARG; }
+    e->d.log_len = L;
+    e->d.group_size = cfg->group_size;
+    e->d.leader = 0xFFFFFFFFu;
+    e->dir_cap = pow2_at_least(L / APUS_ENTRY_HDR < 4096 ? 4096 : L / APUS_ENTRY_HDR);
+    e->d.dir_mask = e->dir_cap - 1;
+    e->local_mask = 0;
+    e->reachable = (1u << cfg->group_size) - 1;
+    e->d.reachable = e->reachable;
+    int rc = 0;
+    for (uint32_t k = 0; k < cfg->n_local; k++) {
+        const uint32_t i = cfg->local_ids[k];
+        if (i >= cfg->group_size || (e->local_mask >> i) & 1u) { rc = APUS_E_ARG; break; }
+        e->local_mask |= 1u << i;
+        RepDev &r = e->d.rep[i];
+        r.idx = i;
+        if ((rc = dev_alloc(e, &r.ring, L + 4096))) break;
+        if ((rc = dev_alloc(e, &r.hdr, sizeof(uint64_t) * 64))) break;
+        if ((rc = dev_alloc(e, &r.dir_off, sizeof(uint64_t) * e->dir_cap))) break;
+        if ((rc = dev_alloc(e, &r.dir_len, sizeof(uint32_t) * e->dir_cap))) break;
+        if ((rc = dev_alloc(e, &r.ack, sizeof(uint32_t) * e->dir_cap))) break;
+        if ((rc = dev_alloc(e, &r.apply, sizeof(apus_apply_rec) * (size_t)e->dir_cap))) break;
+    }
+    e->max_rounds = 1u << 16;
+    e->d.rec_cap = 1ull << 22;
+    if (!rc) rc = dev_alloc(e, &e->d.status, 64);
+    if (!rc) rc = dev_alloc(e, &e->d.seq, sizeof(SeqOut));
+    if (!rc) rc = dev_alloc(e, &e->d.round_virt, sizeof(uint64_t) * (e->max_rounds + 1));
+    if (!rc) rc = dev_alloc(e, &e->d.rec_end, sizeof(uint64_t) * e->d.rec_cap);
+    if (!rc) rc = dev_alloc(e, &e->d.rec_commit, sizeof(uint64_t) * e->d.rec_cap);
+    if (!rc) rc = dev_alloc(e, &e->d.rec_count, 64);
+    if (rc) { apus_gpu_destroy(e); return rc; }
+    *out = e;
+    rc = apus_gpu_reset(e);
+    if (rc) { apus_gpu_destroy(e); *out = nullptr; return rc; }
+    return apus_gpu_sync(e);
+}
+
+extern "C" void apus_gpu_destroy(apus_engine_t *e)
+{
+    if (!e) return;
+    hipStreamSynchronize(e->stream);
+    for (auto g : e->graphs) hipGraphExecDestroy(g);
+    for (auto &t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    for (void *p : e->allocs) hipFree(p);
+    if (e->d_req) hipFree(e->d_req);
+    if (e->d_req_len) hipFree(e->d_req_len);
+    if (e->d_arena) hipFree(e->d_arena);
+    if (e->d_round_first) hipFree(e->d_round_first);
+    if (e->h_live) hipHostFree(e->h_live);
+    if (e->d_live) hipFree(e->d_live);
+    if (e->live_copied) hipEventDestroy(e->live_copied);
+    if (e->own_stream) hipStreamDestroy(e->stream);
+    if (g_engine == e) g_engine = nullptr;
+    delete e;
+}
+
+extern "C" int apus_gpu_sync(apus_engine_t *e)
+{
+    if (!e) return APUS_E_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int apus_gpu_reset(apus_engine_t *e)
+{
+    if (!e) return APUS_E_ARG;
+    for (uint32_t i = 0; i < e->d.group_size; i++)
+        if (e->d.rep[i].ring) {
+            /* log_new() zeroes the whole log (dare_log.h:128) */
+            HIPCHK(hipMemsetAsync(e->d.rep[i].ring, 0, e->d.log_len + 4096, e->stream));
+            HIPCHK(hipMemsetAsync(e->d.rep[i].ack, 0, sizeof(uint32_t) * e->dir_cap, e->stream));
+        }
+    e->d.leader = 0xFFFFFFFFu;
+    e->reachable = (1u << e->d.group_size) - 1;
+    e->d.reachable = e->reachable;
+    hipLaunchKernelGGL(k_reset, dim3(e->d.group_size), dim3(64), 0, e->stream, e->d);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int apus_gpu_stage(apus_engine_t *e, const apus_req_t *reqs, uint64_t n,
+                              const uint8_t *arena, uint64_t arena_bytes,
+                              const uint32_t *round_n, uint64_t n_rounds)
+{
+    if (!e || (n && !reqs) || (n_rounds && !round_n)) return APUS_E_ARG;
+    if (n >= (1ull << 32) || arena_bytes >= (1ull << 32)) return APUS_E_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    std::vector<ReqDev> hd(n);
+    std::vector<uint16_t> hl(n);
+    for (uint64_t g = 0; g < n; g++) {
+        const apus_req_t &q = reqs[g];
+        if (q.payload_off % 16 || q.payload_off + q.len > arena_bytes) return APUS_E_ARG;
+        if (q.type == APUS_NOOP || q.type == APUS_CONFIG || q.type == APUS_HEAD || q.type > 15) return APUS_E_ARG;
+        if (q.len && q.payload_off < 16) return APUS_E_ARG;     /* the copy reads 2 bytes in front */
+        hd[g].req_id = q.req_id;
+        hd[g].pay16_type = (uint32_t)(q.payload_off / 16) | ((uint32_t)q.type << 28);
+        hd[g].len = q.len;
+        hd[g].clt_id = q.clt_id;
+        hl[g] = q.len;
+    }
+    e->h_round_first.assign(n_rounds + 1, 0);
+    uint64_t acc = 0;
+    for (uint64_t r = 0; r < n_rounds; r++) {
+        if (round_n[r] < 1 || round_n[r] > APUS_MAX_ROUND) return APUS_E_ARG;
+        e->h_round_first[r] = (uint32_t)acc;
+        acc += round_n[r];
+    }
+    if (acc != n) return APUS_E_ARG;
+    e->h_round_first[n_rounds] = (uint32_t)acc;
+    auto renew = [&](void **p, size_t bytes) -> int {
+        if (*p) { hipFree(*p); *p = nullptr; }
+        if (hipMalloc(p, bytes ? bytes : 16) != hipSuccess) return APUS_E_NOMEM;
+        return 0;
+    };
+    int rc;
+    if ((rc = renew(&e->d_req, sizeof(ReqDev) * n))) return rc;
+    if ((rc = renew(&e->d_req_len, sizeof(uint16_t) * n + 64))) return rc;
+    if ((rc = renew(&e->d_arena, arena_bytes + 64))) return rc;
+    if ((rc = renew(&e->d_round_first, sizeof(uint32_t) * (n_rounds + 1)))) return rc;
+    if (n) {
+        HIPCHK(hipMemcpy(e->d_req, hd.data(), sizeof(ReqDev) * n, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_req_len, hl.data(), sizeof(uint16_t) * n, hipMemcpyHostToDevice));
+    }
+    if (arena_bytes) HIPCHK(hipMemcpy(e->d_arena, arena, arena_bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_round_first, e->h_round_first.data(), sizeof(uint32_t) * (n_rounds + 1), hipMemcpyHostToDevice));
+    e->d.req = (const ReqDev *)e->d_req;
+    e->d.req_len = (const uint16_t *)e->d_req_len;
+    e->d.arena = (const uint8_t *)e->d_arena;
+    e->d.round_first = (const uint32_t *)e->d_round_first;
+    e->n_reqs = n;
+    e->n_rounds_staged = n_rounds;
+    return 0;
+}
+
+/* ---- launch helpers -------------------------------------------------------- */
+static inline uint32_t cap_grid(uint64_t n, uint32_t per_block, uint32_t cap)
+{
+    uint64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (uint32_t)g;
+}
+
+/* persist + ACK scan + apply + bookkeeping for whatever is new (mode: see k_finish) */
+static int launch_tail_view(apus_engine *e, const EngDev &view, uint64_t r0, uint32_t R, int mode, uint64_t n_hint)
+{
+    const uint32_t fm = sync_mask(e);
+    const uint32_t rm = fm | ((e->local_mask >> e->d.leader) & 1u ? (1u << e->d.leader) : 0);
+    const uint64_t n = n_hint ? n_hint : 1;
+    if (fm)
+        hipLaunchKernelGGL(k_persist_ack, dim3(cap_grid(n, 256, 1024), popc(fm)), dim3(256), 0, e->stream,
+                           view, r0, R, fm);
+    hipLaunchKernelGGL(k_commit, dim3(cap_grid(n, 1024, 512)), dim3(1024), 0, e->stream, view, r0, R);
+    hipLaunchKernelGGL(k_apply, dim3(cap_grid(n, 256, 1024), popc(rm)), dim3(256), 0, e->stream, view, r0, R, rm);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, e->stream, view, r0, R, mode, fm);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int launch_tail(apus_engine *e, uint64_t r0, uint32_t R, int mode, uint64_t n_hint)
+{
+    return launch_tail_view(e, e->d, r0, R, mode, n_hint);
+}
+
+static int launch_catchup(apus_engine *e)
+{
+    const uint32_t fm = sync_mask(e);
+    if (!fm) return 0;
+    hipLaunchKernelGGL(k_catchup, dim3(64, popc(fm)), dim3(256), 0, e->stream, e->d, fm);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int need_leader(apus_engine *e)
+{
+    if (!e) return APUS_E_ARG;
+    if (e->d.leader >= e->d.group_size || !((e->local_mask >> e->d.leader) & 1u)) return APUS_E_STATE;
+    return 0;
+}
+
+/* get_tailq_message + log_append_entry + R1: catch-up, sequence, append+push */
+static int launch_append(apus_engine *e, const EngDev &view, uint64_t r0, uint32_t R)
+{
+    int rc;
+    const uint32_t fm = sync_mask(e);
+    if ((rc = launch_catchup(e))) return rc;
+    hipLaunchKernelGGL(k_sequence, dim3(1), dim3(1024), 0, e->stream, view, r0, R, fm);
+    hipLaunchKernelGGL(k_append_push, dim3((R + 3) / 4), dim3(256), 0, e->stream, view, r0, R, fm);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rounds)
+{
+    int rc = need_leader(e);
+    if (rc) return rc;
+    if (r0 + n_rounds > e->n_rounds_staged || n_rounds > e->max_rounds) return APUS_E_ARG;
+    if (n_rounds == 0) return 0;
+    const uint32_t R = (uint32_t)n_rounds;
+    const uint64_t n = e->h_round_first[r0 + R] - e->h_round_first[r0];
+    const uint32_t fm = sync_mask(e);
+    if ((rc = launch_catchup(e))) return rc;
+    hipLaunchKernelGGL(k_sequence, dim3(1), dim3(1024), 0, e->stream, e->d, r0, R, fm);
+    TimedLaunch *tl = nullptr;
+    if (e->timing && !e->capturing) {
+        if (e->timed_used == e->timed.size()) {
+            TimedLaunch t;
+            HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b));
+            e->timed.push_back(t);
+        }
+        tl = &e->timed[e->timed_used++];
+        HIPCHK(hipEventRecord(tl->a, e->stream));
+    }
+    hipLaunchKernelGGL(k_append_push, dim3((R + 3) / 4), dim3(256), 0, e->stream, e->d, r0, R, fm);
+    if (tl) HIPCHK(hipEventRecord(tl->b, e->stream));
+    HIPCHK(hipGetLastError());
+    return launch_tail(e, r0, R, 0, n);
+}
+
+/* ---- live submission: what the proxy's DARE thread does every polling() pass ---- */
+static int live_view(apus_engine *e, EngDev *view)
+{
+    if (!e->h_live) {
+        HIPCHK(hipHostMalloc((void **)&e->h_live, LIVE_BYTES, hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&e->d_live, LIVE_BYTES));
+        HIPCHK(hipEventCreateWithFlags(&e->live_copied, hipEventDisableTiming));
+    }
+    *view = e->d;
+    view->req = (const ReqDev *)e->d_live;
+    view->req_len = (const uint16_t *)(e->d_live + LIVE_OFF_LEN);
+    view->round_first = (const uint32_t *)(e->d_live + LIVE_OFF_RF);
+    view->arena = e->d_live + LIVE_OFF_ARENA;
+    return 0;
+}
+
+/* dare_ib_poll_tailq: n queued requests become log entries (rounds of <= 64) */
+extern "C" int apus_gpu_append_live(apus_engine_t *e, const apus_req_t *reqs, uint32_t n,
+                                    const uint8_t *arena, uint64_t arena_bytes)
+{
+    int rc = need_leader(e);
+    if (rc) return rc;
+    if (!reqs || n == 0 || n > LIVE_REQS || arena_bytes + 16 > LIVE_ARENA) return APUS_E_ARG;
+    if (e->live_R) return APUS_E_STATE;             /* previous batch not committed yet */
+    EngDev view;
+    if ((rc = live_view(e, &view))) return rc;
+    if (e->live_pending) { HIPCHK(hipEventSynchronize(e->live_copied)); e->live_pending = false; }
+    ReqDev *hd = (ReqDev *)e->h_live;
+    uint16_t *hl = (uint16_t *)(e->h_live + LIVE_OFF_LEN);
+    uint32_t *rf = (uint32_t *)(e->h_live + LIVE_OFF_RF);
+    uint8_t *ha = e->h_live + LIVE_OFF_ARENA;
+    /* the live arena keeps the caller's offsets, shifted by 16 so that byte -2 exists */
+    for (uint32_t g = 0; g < n; g++) {
+        const apus_req_t &q = reqs[g];
+        if (q.payload_off % 16 || q.payload_off + q.len > arena_bytes) return APUS_E_ARG;
+        if (q.type == APUS_NOOP || q.type == APUS_CONFIG || q.type == APUS_HEAD || q.type > 15) return APUS_E_ARG;
+        hd[g].req_id = q.req_id;
+        hd[g].pay16_type = (uint32_t)(q.payload_off / 16 + 1) | ((uint32_t)q.type << 28);
+        hd[g].len = q.len; hd[g].clt_id = q.clt_id; hl[g] = q.len;
+    }
+    uint32_t R = 0;
+    for (uint32_t g = 0; g < n; g += APUS_MAX_ROUND) rf[R++] = g;
+    rf[R] = n;
+    if (arena_bytes) memcpy(ha + 16, arena, arena_bytes);
+    HIPCHK(hipMemcpyAsync(e->d_live, e->h_live, LIVE_OFF_ARENA + 16 + arena_bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipEventRecord(e->live_copied, e->stream));
+    e->live_pending = true;
+    if ((rc = launch_append(e, view, 0, R))) return rc;
+    e->live_r0 = 0; e->live_R = R; e->live_n = n;
+    return 0;
+}
+
+/* dare_ib_write_remote_logs: follower ACKs, ACK scan, commit, apply for the appended batch */
+extern "C" int apus_gpu_commit_live(apus_engine_t *e, int wait_for_commit)
+{
+    int rc = need_leader(e);
+    if (rc) return rc;
+    EngDev view;
+    if ((rc = live_view(e, &view))) return rc;
+    if (e->live_R) {
+        rc = launch_tail_view(e, view, e->live_r0, (uint32_t)e->live_R, 0, e->live_n);
+        e->live_R = 0;
+    } else {
+        rc = apus_gpu_quiesce(e);
+    }
+    if (rc) return rc;
+    if (wait_for_commit) HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int apus_gpu_submit(apus_engine_t *e, const apus_req_t *reqs, uint32_t n,
+                               const uint8_t *arena, uint64_t arena_bytes)
+{
+    int rc = apus_gpu_append_live(e, reqs, n, arena, arena_bytes);
+    if (rc) return rc;
+    return apus_gpu_commit_live(e, 0);
+}
+
+extern "C" int apus_gpu_quiesce(apus_engine_t *e)
+{
+    int rc = need_leader(e);
+    if (rc) return rc;
+    if ((rc = launch_catchup(e))) return rc;
+    hipLaunchKernelGGL(k_sequence, dim3(1), dim3(1024), 0, e->stream, e->d, (uint64_t)0, 0u, sync_mask(e));
+    HIPCHK(hipGetLastError());
+    return launch_tail(e, 0, 0, 2, 4096);
+}
+
+extern "C" int apus_gpu_append_control(apus_engine_t *e, uint8_t type, const void *data)
+{
+    int rc = need_leader(e);
+    if (rc) return rc;
+    uint64_t d0 = 0, d1 = 0;
+    if (type == APUS_CONFIG) { if (!data) return APUS_E_ARG; memcpy(&d0, data, 8); memcpy(&d1, (const uint8_t *)data + 8, 8); }
+    else if (type == APUS_HEAD) { if (!data) return APUS_E_ARG; memcpy(&d0, data, 8); }
+    else if (type != APUS_NOOP) return APUS_E_ARG;
+    if ((rc = launch_catchup(e))) return rc;
+    hipLaunchKernelGGL(k_control_append, dim3(1), dim3(64), 0, e->stream, e->d, 0, (uint32_t)type, d0, d1,
+                       sync_mask(e), 0u);
+    HIPCHK(hipGetLastError());
+    return launch_tail(e, 0, 0, 1, 1);
+}
+
+extern "C" int apus_gpu_tick_prune(apus_engine_t *e)
+{
+    int rc = apus_gpu_quiesce(e);       /* the timer fires between polling() passes */
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_control_append, dim3(1), dim3(64), 0, e->stream, e->d, 1, (uint32_t)APUS_HEAD,
+                       (uint64_t)0, (uint64_t)0, sync_mask(e), sync_mask(e));
+    HIPCHK(hipGetLastError());
+    return launch_tail(e, 0, 0, 1, 1);
+}
+
+__global__ void k_set_roles(const EngDev E, uint64_t sid, uint32_t bitmask, uint32_t follow_mask)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint64_t *lh = E.rep[E.leader].hdr;
+    lh[H_SID] = sid;
+    lh[H_CID_BITMASK] = bitmask;
+    for (uint32_t i = 0; i < E.group_size; i++) lh[H_APPLY_OFFSETS + i] = lh[H_HEAD];  /* dare_server.c:1504-1507 */
+    for (uint32_t i = 0; i < E.group_size; i++) {
+        if (i == E.leader || !((follow_mask >> i) & 1u) || !E.rep[i].ring) continue;
+        uint64_t *fh = E.rep[i].hdr;
+        fh[H_SID] = sid;                       /* heartbeat from the new leader, dare_server.c:822-920 */
+        fh[H_TAIL] = E.log_len;
+        fh[H_CID_BITMASK] = bitmask;
+    }
+}
+
+extern "C" int apus_gpu_become_leader(apus_engine_t *e, uint32_t leader, uint64_t term, uint32_t bitmask)
+{
+    if (!e || leader >= e->d.group_size) return APUS_E_ARG;
+    if (!((e->local_mask >> leader) & 1u)) return APUS_E_STATE;
+    e->d.leader = leader;
+    const uint64_t sid = (term << 9) | (1ull << 8) | leader;
+    hipLaunchKernelGGL(k_set_roles, dim3(1), dim3(64), 0, e->stream, e->d, sid, bitmask, e->reachable);
+    HIPCHK(hipGetLastError());
+    /* blank CONFIG entry: dare_cid_t {epoch, size[2], state, pad, bitmask} */
+    uint8_t cid[16] = {0};
+    cid[8] = (uint8_t)e->d.group_size;
+    memcpy(cid + 12, &bitmask, 4);
+    return apus_gpu_append_control(e, APUS_CONFIG, cid);
+}
+
+extern "C" int apus_gpu_set_reachable(apus_engine_t *e, uint32_t mask)
+{
+    if (!e) return APUS_E_ARG;
+    e->reachable = mask;
+    e->d.reachable = mask;
+    return 0;
+}
+
+/* ---- graphs ----------------------------------------------------------------- */
+extern "C" int apus_gpu_capture_begin(apus_engine_t *e)
+{
+    if (!e || e->capturing) return APUS_E_STATE;
+    HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    e->capturing = true;
+    return 0;
+}
+
+extern "C" int apus_gpu_capture_end(apus_engine_t *e, int *graph_id)
+{
+    if (!e || !e->capturing || !graph_id) return APUS_E_STATE;
+    hipGraph_t g = nullptr;
+    e->capturing = false;
+    HIPCHK(hipStreamEndCapture(e->stream, &g));
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    hipGraphDestroy(g);
+    e->graphs.push_back(ge);
+    *graph_id = (int)e->graphs.size() - 1;
+    return 0;
+}
+
+extern "C" int apus_gpu_graph_launch(apus_engine_t *e, int graph_id)
+{
+    if (!e || graph_id < 0 || graph_id >= (int)e->graphs.size()) return APUS_E_ARG;
+    HIPCHK(hipGraphLaunch(e->graphs[graph_id], e->stream));
+    return 0;
+}
+
+/* ---- observation ------------------------------------------------------------ */
+static int local_rep(apus_engine *e, uint32_t r)
+{
+    if (!e || r >= e->d.group_size || !e->d.rep[r].ring) return APUS_E_STATE;
+    return 0;
+}
+
+extern "C" int apus_gpu_offsets(apus_engine_t *e, uint32_t replica, uint64_t out[8])
+{
+    int rc = local_rep(e, replica);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(out, e->d.rep[replica].hdr, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int apus_gpu_counters(apus_engine_t *e, uint32_t replica, uint64_t out[8])
+{
+    int rc = local_rep(e, replica);
+    if (rc) return rc;
+    uint64_t h[64];
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(h, e->d.rep[replica].hdr, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = h[H_N_END]; out[1] = h[H_N_PERSIST]; out[2] = h[H_N_COMMIT]; out[3] = h[H_N_APPLY];
+    out[4] = h[H_LAST_IDX]; out[5] = h[H_SID]; out[6] = h[H_HIGHEST_REC]; out[7] = h[H_APPLY_HASH];
+    return 0;
+}
+
+extern "C" int apus_gpu_hdr_words(apus_engine_t *e, uint32_t replica, uint64_t *out, uint32_t n_words)
+{
+    int rc = local_rep(e, replica);
+    if (rc) return rc;
+    if (n_words > 64) n_words = 64;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(out, e->d.rep[replica].hdr, n_words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int apus_gpu_read_ring(apus_engine_t *e, uint32_t replica, uint64_t off, uint64_t n, void *dst)
+{
+    int rc = local_rep(e, replica);
+    if (rc) return rc;
+    if (off + n > e->d.log_len) return APUS_E_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(dst, e->d.rep[replica].ring + off, n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" uint64_t apus_gpu_round_count(apus_engine_t *e)
+{
+    if (!e) return 0;
+    uint64_t n = 0;
+    hipStreamSynchronize(e->stream);
+    hipMemcpy(&n, e->d.rec_count, sizeof n, hipMemcpyDeviceToHost);
+    return n;
+}
+
+extern "C" int apus_gpu_round_record(apus_engine_t *e, uint64_t first, uint64_t n, uint64_t *end_out, uint64_t *commit_out)
+{
+    if (!e || first + n > e->d.rec_cap) return APUS_E_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (end_out) HIPCHK(hipMemcpy(end_out, e->d.rec_end + first, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (commit_out) HIPCHK(hipMemcpy(commit_out, e->d.rec_commit + first, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int apus_gpu_apply_records(apus_engine_t *e, uint32_t replica, uint64_t first, uint64_t n, apus_apply_t *out)
+{
+    int rc = local_rep(e, replica);
+    if (rc) return rc;
+    if (n > e->dir_cap) return APUS_E_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const apus_apply_rec *base = e->d.rep[replica].apply;
+    for (uint64_t done = 0; done < n;) {
+        const uint64_t i = (first + done) & e->d.dir_mask;
+        const uint64_t chunk = (n - done < e->dir_cap - i) ? n - done : e->dir_cap - i;
+        HIPCHK(hipMemcpy(out + done, base + i, chunk * sizeof(apus_apply_rec), hipMemcpyDeviceToHost));
+        done += chunk;
+    }
+    return 0;
+}
+
+extern "C" uint32_t apus_gpu_status(apus_engine_t *e)
+{
+    if (!e) return 0xFFFFFFFFu;
+    uint32_t s = 0;
+    hipStreamSynchronize(e->stream);
+    hipMemcpy(&s, e->d.status, sizeof s, hipMemcpyDeviceToHost);
+    return s;
+}
+
+extern "C" void apus_gpu_clear_status(apus_engine_t *e)
+{
+    if (!e) return;
+    hipStreamSynchronize(e->stream);
+    hipMemset(e->d.status, 0, sizeof(uint32_t));
+}
+
+extern "C" void *apus_gpu_device_ptr(apus_engine_t *e, uint32_t replica, int which, uint64_t *bytes)
+{
+    if (local_rep(e, replica)) return nullptr;
+    RepDev &r = e->d.rep[replica];
+    uint64_t b = 0; void *p = nullptr;
+    switch (which) {
+    case 0: p = r.ring; b = e->d.log_len; break;
+    case 1: p = r.hdr; b = 64 * sizeof(uint64_t); break;
+    case 2: p = r.dir_off; b = sizeof(uint64_t) * e->dir_cap; break;
+    case 3: p = r.dir_len; b = sizeof(uint32_t) * e->dir_cap; break;
+    case 4: p = r.ack; b = sizeof(uint32_t) * e->dir_cap; break;
+    case 5: p = r.apply; b = sizeof(apus_apply_rec) * (uint64_t)e->dir_cap; break;
+    default: break;
+    }
+    if (bytes) *bytes = b;
+    return p;
+}
+
+extern "C" int apus_gpu_set_timing(apus_engine_t *e, int on)
+{
+    if (!e) return APUS_E_ARG;
+    e->timing = on != 0;
+    e->timed_used = 0;
+    return 0;
+}
+
+extern "C" int apus_gpu_kernel_time(apus_engine_t *e, int which, float *total_ms, uint64_t *launches)
+{
+    if (!e || which != 0) return APUS_E_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    float tot = 0.f;
+    for (size_t i = 0; i < e->timed_used; i++) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e->timed[i].a, e->timed[i].b));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = e->timed_used;
+    e->timed_used = 0;
+    return 0;
+}
+
+extern "C" void *apus_gpu_stream(apus_engine_t *e) { return e ? (void *)e->stream : nullptr; }
+
+extern "C" int apus_gpu_bind_global(apus_engine_t *e) { g_engine = e; return 0; }
+extern "C" apus_engine_t *apus_gpu_global(void) { return g_engine; }

@@ -1,0 +1,661 @@
+/*
+ * apus_kernels.h -- the HIP kernels of the consensus hot path (gfx950, wave64).
+ *
+ * One leader polling() pass of the reference (dare_server.c:1012-1125) over a
+ * batch of R rounds becomes six launches; every launch is wide (one wavefront
+ * per round / one lane per entry) and the launches are the only global syncs:
+ *
+ *   k_catchup       update_remote_logs step I for lagging followers
+ *                   (dare_ibv_rc.c:1507-1547): copy [remote_end, end)
+ *   k_sequence      get_tailq_message -> log_append_entry offsets
+ *                   (dare_ibv_ud.c:780, dare_log.h:466-558): where every
+ *                   entry of the batch goes, incl. both wrap rules and the
+ *                   end == len "empty" encoding; leader persist bookkeeping
+ *   k_append_push   writes the entries into the leader ring (log_append_entry
+ *                   body + persist_new_entries' sender stamp,
+ *                   dare_server.c:1803) AND into every in-sync follower ring
+ *                   at the same offsets (R1 of update_remote_logs, fused so
+ *                   the payload is read once)
+ *   k_persist_ack   follower persist_new_entries + rc_send_entries_reply
+ *                   (dare_server.c:1792, dare_ibv_rc.c:1828): reply byte in
+ *                   both logs + ACK bit in the leader's slot word
+ *   k_commit        the ACK scan of update_remote_logs (dare_ibv_rc.c:1725-1758):
+ *                   popcount(ack | self) >= size/2+1 per lane, wave ballot,
+ *                   first slot without a majority
+ *   k_apply         apply_committed_entries on every replica
+ *                   (dare_server.c:1815-1974): apply-stream records, HEAD adoption
+ *   k_finish        scalar bookkeeping: commit/apply offsets, R2/R4 doorbells,
+ *                   per-round end/commit record
+ *
+ * All arithmetic is integer / byte work; the binding roofline is HBM.
+ */
+#pragma once
+#include "apus_device.h"
+
+#define WAVE 64
+
+__device__ static inline uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
+
+/* inclusive scan across the 64 lanes of a wavefront */
+template <typename T>
+__device__ static inline T wave_incl_scan(T v)
+{
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        T o = __shfl_up(v, d, WAVE);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+
+template <typename T>
+__device__ static inline T wave_sum(T v)
+{
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
+    return v;
+}
+
+__device__ static inline void set_status(const EngDev &E, uint32_t bit) { atomicOr(E.status, bit); }
+
+/* bytes [b0, b1) of a little-endian u64 set to 0xFF (0 <= b0, b1 <= 8) */
+__device__ static inline uint64_t byte_mask64(int b0, int b1)
+{
+    if (b0 < 0) b0 = 0;
+    if (b1 > 8) b1 = 8;
+    if (b1 <= b0) return 0;
+    const uint64_t hi = (b1 == 8) ? ~0ull : ((1ull << (8 * b1)) - 1);
+    const uint64_t lo = (b0 == 0) ? 0ull : ((1ull << (8 * b0)) - 1);
+    return hi & ~lo;
+}
+
+/* 16 bytes [so, so+16) of the byte stream of a client entry, so >= 48:
+ *   [48,50) cmd.len   [50,50+P) payload   [50+P, 64+P) unused (written as 0)
+ * src points at payload byte 0 (readable from src-2 to src+P+14). */
+__device__ static inline uint4 payload_unit(const uint8_t *src, uint32_t so, uint32_t P, uint32_t len16)
+{
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (P == 0 && so >= 50) return v;
+    uint64_t lo = 0, hi = 0;
+    if (P != 0) {
+        v = ld16u(src + (int64_t)so - 50);
+        lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        const int vb = so < 50 ? (int)(50 - so) : 0;
+        const int ve = (int)min(16u, 50u + P - so);
+        lo &= byte_mask64(vb, ve);
+        hi &= byte_mask64(vb - 8, ve - 8);
+    }
+    if (so == 48)      lo |= (uint64_t)(len16 & 0xFFFFu);
+    else if (so == 49) lo |= (uint64_t)((len16 >> 8) & 0xFFu);
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_catchup: followers whose log is behind the leader's (released after a HOLD,
+ * or left one round behind by an exact-fit wrap) get [end_f, end_L) and the
+ * matching directory slots.  grid.y = follower ordinal in fmask.             */
+__global__ __launch_bounds__(256) void k_catchup(const EngDev E, uint32_t fmask)
+{
+    /* pick the follower of this grid row */
+    int f = -1;
+    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
+        if (fmask & (1u << i)) { if (k == (int)blockIdx.y) { f = i; break; } k++; }
+    if (f < 0) return;
+    const RepDev &Ld = E.rep[E.leader];
+    const RepDev &Fd = E.rep[f];
+    const uint64_t L = E.log_len;
+    const uint64_t end_l = Ld.hdr[H_END], end_f = Fd.hdr[H_END];
+    const uint64_t n_l = Ld.hdr[H_N_END], n_f = Fd.hdr[H_N_END];
+    if (n_f >= n_l || end_l == L) return;            /* in sync, or nothing visible yet */
+    /* directory slots */
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = n_f + tid; s < n_l; s += nth) {
+        const uint32_t i = (uint32_t)s & E.dir_mask;
+        Fd.dir_off[i] = Ld.dir_off[i];
+        Fd.dir_len[i] = Ld.dir_len[i];
+    }
+    /* ring bytes, at the same offsets; a wrapped range is two pieces (dare_ibv_rc.c:1538-1545) */
+    uint64_t from = (end_f == L) ? 0 : end_f;
+    uint64_t seg0_from = from, seg0_to, seg1_to = 0;
+    if (end_l > from || (end_f == L)) { seg0_to = end_l; }
+    else { seg0_to = L; seg1_to = end_l; }
+    for (int seg = 0; seg < 2; seg++) {
+        const uint64_t a = seg ? 0 : seg0_from, b = seg ? seg1_to : seg0_to;
+        if (b <= a) continue;
+        /* 16-byte units on the destination alignment of `a`; the tail is byte-wise */
+        const uint64_t nunit = (b - a) / 16;
+        for (uint64_t u = tid; u < nunit; u += nth) st16u(Fd.ring + a + 16 * u, ld16u(Ld.ring + a + 16 * u));
+        for (uint64_t x = a + 16 * nunit + tid; x < b; x += nth) Fd.ring[x] = Ld.ring[x];
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_sequence: one workgroup.  Computes where every entry of rounds
+ * [r0, r0+R) goes.  Round sizes come from the staged partition.             */
+__global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask)
+{
+    __shared__ uint64_t s_wave_tot[16];
+    __shared__ uint64_t s_carry;
+    __shared__ unsigned int s_rstar;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const RepDev &Ld = E.rep[E.leader];
+    uint64_t *hdr = Ld.hdr;
+    const uint64_t L = E.log_len;
+    const uint64_t e0 = hdr[H_END];
+    const uint32_t *rf = E.round_first + r0;
+    const uint32_t g0 = rf[0];
+    const uint32_t n = rf[R] - g0;
+    if (tid == 0) { s_carry = 0; s_rstar = 0xFFFFFFFFu; }
+    __syncthreads();
+
+    /* pass 1: bytes per round, exclusive scan into round_virt[0..R] */
+    for (uint32_t base = 0; base < R; base += 1024) {
+        const uint32_t r = base + tid;
+        uint64_t bytes = 0;
+        if (r < R) {
+            const uint32_t a = rf[r], b = rf[r + 1];
+            for (uint32_t g = a; g < b; g++) bytes += APUS_HDR + E.req_len[g];
+        }
+        uint64_t incl = wave_incl_scan(bytes);
+        if (lane == 63) s_wave_tot[wv] = incl;
+        __syncthreads();
+        uint64_t wbase = 0;
+        for (uint32_t w = 0; w < wv; w++) wbase += s_wave_tot[w];
+        const uint64_t carry = s_carry;
+        if (r < R) E.round_virt[r] = carry + wbase + incl - bytes;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + wbase + incl;
+        __syncthreads();
+    }
+    if (tid == 0) E.round_virt[R] = s_carry;
+    __syncthreads();
+    const uint64_t vtot = s_carry;
+
+    /* pass 2: the first round that does not fit before len */
+    for (uint32_t r = tid; r < R; r += 1024)
+        if (e0 + E.round_virt[r + 1] > L) atomicMin(&s_rstar, r);
+    __syncthreads();
+    const uint32_t rstar = s_rstar;
+
+    __shared__ int64_t s_kstar, s_estar;
+    __shared__ uint64_t s_w, s_end_new;
+    if (tid == 0) {
+        int64_t kstar = -1, estar = -1;
+        uint64_t w = 0;
+        uint32_t stale = 0;
+        if (rstar < R) {
+            uint64_t a = e0 + E.round_virt[rstar];
+            for (uint32_t g = rf[rstar]; g < rf[rstar + 1]; g++) {
+                const uint64_t T = APUS_HDR + E.req_len[g];
+                if (a + T > L) {
+                    kstar = (int64_t)(g - g0);
+                    w = a;
+                    if (a == L) estar = kstar;              /* empty encoding: idx restarts, dare_log.h:486-488 */
+                    else if (L - a >= APUS_HDR) stale = 1;  /* header fitted, payload did not, dare_log.h:521-537 */
+                    break;
+                }
+                a += T;
+            }
+        }
+        const uint64_t end_new = (kstar < 0) ? e0 + vtot : e0 + vtot - w;
+        if (kstar >= 0 && end_new > L) set_status(E, 1u << 0);      /* second wrap */
+        /* free space: the reference only notices end == head exactly (dare_log.h:168) */
+        {
+            const uint64_t head = hdr[H_HEAD];
+            const uint64_t used = (e0 == L) ? 0 : (e0 >= head ? e0 - head : L - (head - e0));
+            const uint64_t waste = (kstar >= 0) ? L - w : 0;
+            if (n && vtot + waste >= L - used && !(e0 == L)) set_status(E, 1u << 1);
+            if (n && e0 == L && vtot > L) set_status(E, 1u << 1);
+        }
+        const uint64_t n_end0 = hdr[H_N_END];
+        const uint64_t idx0 = hdr[H_LAST_IDX] + 1;
+        SeqOut s;
+        s.e0 = e0; s.idx0 = idx0; s.w = w; s.n_end0 = n_end0;
+        s.term = hdr[H_SID] >> 9;
+        s.kstar = kstar; s.estar = estar; s.stale = stale; s.n = n;
+        s.first_fail = ~0ull;
+        s.commit_before = hdr[H_COMMIT];
+        s.n_commit_before = hdr[H_N_COMMIT];
+        *E.seq = s;
+        if (n) {
+            const uint64_t t_last = APUS_HDR + E.req_len[g0 + n - 1];
+            hdr[H_END] = end_new;
+            hdr[H_TAIL] = end_new - t_last;
+            hdr[H_N_END] = n_end0 + n;
+            hdr[H_LAST_IDX] = (estar < 0) ? idx0 + n - 1 : 1 + (uint64_t)(n - 1 - estar);
+            hdr[H_PREV_HEAD] = 0;
+            /* leader side of persist_new_entries (dare_server.c:1792-1810) */
+            hdr[H_OLD_END] = end_new;
+            hdr[H_N_PERSIST] = n_end0 + n;
+            hdr[H_STORE_COUNT] += n;
+        }
+        s_kstar = kstar; s_estar = estar; s_w = w; s_end_new = end_new;
+        /* followers in push_mask are in sync with the pre-batch leader state by now
+         * (k_catchup ran before us) */
+        for (int f = 0; f < APUS_DEV_MAX_SERVERS; f++)
+            if ((push_mask >> f) & 1u) {
+                uint64_t *fh = E.rep[f].hdr;
+                if (fh[H_N_END] < n_end0 && e0 != L) { fh[H_END] = e0; fh[H_N_END] = n_end0; }
+            }
+    }
+    __syncthreads();
+
+    /* pass 3: end offset after every round (the leader's per-round record) */
+    const uint64_t rec_base = *E.rec_count;
+    const int64_t kstar = s_kstar;
+    const uint64_t w = s_w;
+    for (uint32_t r = tid; r < R; r += 1024) {
+        const uint64_t a_end = e0 + E.round_virt[r + 1];
+        const int64_t last = (int64_t)(rf[r + 1] - g0) - 1;   /* batch index of the round's last entry */
+        const uint64_t end_r = (kstar < 0 || last < kstar) ? a_end : a_end - w;
+        if (rec_base + r < E.rec_cap) E.rec_end[rec_base + r] = end_r;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_append_push: one wavefront per round, one lane per entry for the header /
+ * offset work, all 64 lanes over the round's 16-byte units for the copy.     */
+struct AppendLds {
+    uint64_t pos[WAVE];
+    uint64_t src[WAVE];
+    uint32_t T[WAVE];
+    uint32_t ubase[WAVE + 1];
+    uint4    h0[WAVE];
+    uint4    h1[WAVE];
+};
+
+__global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask)
+{
+    __shared__ AppendLds lds_all[4];
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t r = blockIdx.x * 4 + wv;
+    if (r >= R) return;
+    AppendLds &lds = lds_all[wv];
+    const SeqOut s = *E.seq;
+    const RepDev &Ld = E.rep[E.leader];
+    const uint32_t *rf = E.round_first + r0;
+    const uint32_t g0 = rf[0];
+    const uint32_t first = rf[r] - g0, nr = rf[r + 1] - rf[r];
+    const bool active = lane < nr;
+    const uint32_t g = g0 + first + lane;
+
+    ReqDev d; d.req_id = 0; d.pay16_type = 0; d.len = 0; d.clt_id = 0;
+    if (active) d = E.req[g];
+    const uint32_t T = active ? APUS_HDR + d.len : 0;
+    const uint64_t incl = wave_incl_scan((uint64_t)T);
+    const uint64_t a = s.e0 + E.round_virt[r] + incl - T;
+    const int64_t gk = (int64_t)first + lane;
+    const uint64_t pos = apus_place(s, gk, a);
+    const uint64_t idx = apus_entry_idx(s, gk);
+    const uint64_t slot = s.n_end0 + (uint64_t)gk;
+    const uint32_t nu = active ? (T + 15) / 16 : 0;
+    const uint32_t uincl = wave_incl_scan(nu);
+    const uint32_t utotal = __shfl(uincl, WAVE - 1, WAVE);
+    const uint32_t type = d.pay16_type >> 28;
+
+    const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)s.term, (uint32_t)(s.term >> 32));
+    /* bytes 16..31: req_id, clt_id, type, sender (= leader: persist_new_entries), reply[0..3] = 0 */
+    const uint4 h1 = make_uint4((uint32_t)d.req_id, (uint32_t)(d.req_id >> 32),
+                                (uint32_t)d.clt_id | (type << 16) | ((uint32_t)E.leader << 24), 0);
+    lds.pos[lane] = pos;
+    lds.src[lane] = (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
+    lds.T[lane] = T;
+    lds.ubase[lane] = uincl - nu;
+    if (lane == WAVE - 1) lds.ubase[WAVE] = uincl;
+    lds.h0[lane] = h0;
+    lds.h1[lane] = h1;
+
+    /* targets: the leader ring, then every in-sync follower ring (R1, same offsets) */
+    if (active) {
+        const uint32_t di = (uint32_t)slot & E.dir_mask;
+        Ld.dir_off[di] = pos; Ld.dir_len[di] = T; Ld.ack[di] = 0;
+        for (uint32_t m = push_mask; m; m &= m - 1) {
+            const RepDev &Fd = E.rep[__builtin_ctz(m)];
+            Fd.dir_off[di] = pos; Fd.dir_len[di] = T;
+        }
+        if (s.stale && gk == s.kstar) {
+            /* the header that log_append_entry wrote before it found out that the
+             * payload does not fit (dare_log.h:497-504, 521-523); readers use it to
+             * detect the wrap (log_fit_entry) */
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            const uint4 l = make_uint4((uint32_t)d.len, 0, 0, 0);
+            for (uint32_t m = push_mask | (1u << E.leader); m; m &= m - 1) {
+                uint8_t *rg = E.rep[__builtin_ctz(m)].ring;
+                st16u(rg + a, h0); st16u(rg + a + 16, h1);
+                st16u(rg + a + 32, z); st16u(rg + a + 48, l);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    for (uint32_t u = lane; u < utotal; u += WAVE) {
+        /* which entry owns unit u: largest e with ubase[e] <= u */
+        uint32_t lo = 0, hi = nr - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (lds.ubase[mid] <= u) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t e = lo;
+        const uint32_t Te = lds.T[e];
+        const uint32_t j = u - lds.ubase[e];
+        const uint32_t so = min(16u * j, Te - 16u);
+        uint4 v;
+        if (so == 0) v = lds.h0[e];
+        else if (so == 16) v = lds.h1[e];
+        else if (so == 32) v = make_uint4(0, 0, 0, 0);
+        else v = payload_unit(E.arena + lds.src[e], so, Te - APUS_HDR, Te - APUS_HDR);
+        const uint64_t p = lds.pos[e] + so;
+        st16u(Ld.ring + p, v);
+        for (uint32_t m = push_mask; m; m &= m - 1) st16u(E.rep[__builtin_ctz(m)].ring + p, v);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_control_append: the leader appends one CONFIG / HEAD / NOOP entry
+ * (log_append_entry, dare_log.h:466-558, 64-byte entries never hit case 2).
+ * mode 0: unconditional append of (type, d0, d1).
+ * mode 1: log_pruning (dare_server.c:1996-2067): decide from the apply offsets
+ *         whether the head moves, append <HEAD, head> if so, then refresh the
+ *         apply offsets (rc_get_remote_apply_offsets, dare_ibv_rc.c:1970).     */
+__global__ __launch_bounds__(64) void k_control_append(const EngDev E, int mode, uint32_t type,
+                                                       uint64_t d0, uint64_t d1, uint32_t push_mask,
+                                                       uint32_t sample_mask)
+{
+    if (threadIdx.x != 0) return;
+    const RepDev &Ld = E.rep[E.leader];
+    uint64_t *hdr = Ld.hdr;
+    const uint64_t L = E.log_len;
+    uint64_t end = hdr[H_END];
+    bool do_append = true;
+
+    if (mode == 1) {
+        const uint32_t size = E.group_size;
+        const uint32_t bitmask = (uint32_t)hdr[H_CID_BITMASK];
+        uint64_t min_off = hdr[H_APPLY];
+        for (uint32_t i = 0; i < size; i++) {
+            if (!((bitmask >> i) & 1u)) hdr[H_APPLY_OFFSETS + i] = hdr[H_APPLY];
+            if (apus_is_larger(end, L, min_off, hdr[H_APPLY_OFFSETS + i])) min_off = hdr[H_APPLY_OFFSETS + i];
+        }
+        if (apus_end_distance(end, L, min_off) == 0) min_off = hdr[H_TAIL];   /* leave one entry, :2038-2041 */
+        do_append = apus_is_larger(end, L, min_off, hdr[H_HEAD]) && !hdr[H_PREV_HEAD];
+        if (do_append) { hdr[H_HEAD] = min_off; d0 = min_off; type = 3; }
+    }
+
+    SeqOut s;
+    s.e0 = end; s.idx0 = hdr[H_LAST_IDX] + 1; s.w = 0; s.n_end0 = hdr[H_N_END];
+    s.term = hdr[H_SID] >> 9; s.kstar = -1; s.estar = -1; s.stale = 0; s.n = 0;
+    s.first_fail = ~0ull; s.commit_before = hdr[H_COMMIT]; s.n_commit_before = hdr[H_N_COMMIT];
+
+    if (do_append) {
+        if (end == hdr[H_HEAD] && end != L) { set_status(E, 1u << 1); do_append = false; }
+    }
+    if (do_append) {
+        uint64_t idx = (end == L) ? 1 : hdr[H_LAST_IDX] + 1;          /* dare_log.h:486-488 */
+        uint64_t pos = (end == L || L - end < APUS_HDR) ? 0 : end;   /* log_add_new_entry, :213-221 */
+        if (type != 3) hdr[H_PREV_HEAD] = 0; else if (mode == 1) hdr[H_PREV_HEAD] = 1;
+        const uint64_t term = s.term;
+        const uint64_t slot = s.n_end0;
+        const uint32_t di = (uint32_t)slot & E.dir_mask;
+        const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)term, (uint32_t)(term >> 32));
+        const uint4 h1 = make_uint4(0, 0, (type << 16) | ((uint32_t)E.leader << 24), 0);  /* req_id = clt_id = 0 */
+        const uint4 h2 = make_uint4(0, 0, 0, 0);
+        const uint4 h3 = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
+        for (int t = -1; t < APUS_DEV_MAX_SERVERS; t++) {
+            const RepDev *R = nullptr;
+            if (t < 0) R = &Ld; else if ((push_mask >> t) & 1u) R = &E.rep[t];
+            if (!R) continue;
+            st16u(R->ring + pos, h0); st16u(R->ring + pos + 16, h1);
+            st16u(R->ring + pos + 32, h2); st16u(R->ring + pos + 48, h3);
+            R->dir_off[di] = pos; R->dir_len[di] = APUS_HDR;
+            if (t < 0) R->ack[di] = 0;
+        }
+        hdr[H_TAIL] = pos;
+        hdr[H_END] = pos + APUS_HDR;
+        hdr[H_N_END] = slot + 1;
+        hdr[H_LAST_IDX] = idx;
+        hdr[H_OLD_END] = pos + APUS_HDR;
+        hdr[H_N_PERSIST] = slot + 1;
+        hdr[H_STORE_COUNT] += 1;
+        s.n = 1;
+        for (int f = 0; f < APUS_DEV_MAX_SERVERS; f++)
+            if ((push_mask >> f) & 1u) {
+                uint64_t *fh = E.rep[f].hdr;
+                if (fh[H_N_END] < slot && end != L) { fh[H_END] = end; fh[H_N_END] = slot; }
+            }
+        const uint64_t rec_base = *E.rec_count;
+        if (rec_base < E.rec_cap) E.rec_end[rec_base] = pos + APUS_HDR;
+    }
+    *E.seq = s;
+
+    if (mode == 1) {
+        /* READ the apply offset of every reachable peer for the next tick */
+        const uint32_t bitmask = (uint32_t)hdr[H_CID_BITMASK];
+        for (uint32_t i = 0; i < E.group_size; i++) {
+            if (i == E.leader || !((bitmask >> i) & 1u)) { hdr[H_APPLY_OFFSETS + i] = hdr[H_APPLY]; continue; }
+            if (!((sample_mask >> i) & 1u)) continue;
+            hdr[H_APPLY_OFFSETS + i] = E.rep[i].hdr[H_APPLY];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* the slot up to which the batch is visible to followers / committable: when
+ * the leader's end sits exactly on len the log reads as empty (dare_log.h:158)
+ * and neither update_remote_logs nor the ACK scan touch the last round.       */
+__device__ static inline uint64_t visible_slots(const EngDev &E, const uint64_t *lhdr, uint64_t r0, uint32_t R)
+{
+    const uint64_t n_end = lhdr[H_N_END];
+    if (lhdr[H_END] != E.log_len) return n_end;
+    const SeqOut &s = *E.seq;
+    if (s.n == 0) return lhdr[H_N_VISIBLE];           /* nothing new: what was visible stays visible */
+    if (R == 0) return s.n_end0;                      /* a control entry landed on len */
+    /* everything before the round that landed on len is visible */
+    const uint32_t *rf = E.round_first + r0;
+    return s.n_end0 + (rf[R - 1] - rf[0]);
+}
+
+/* k_persist_ack: one lane per new entry of one follower (grid.y = follower). */
+__global__ __launch_bounds__(256) void k_persist_ack(const EngDev E, uint64_t r0, uint32_t R, uint32_t fmask)
+{
+    int f = -1;
+    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
+        if (fmask & (1u << i)) { if (k == (int)blockIdx.y) { f = i; break; } k++; }
+    if (f < 0) return;
+    const RepDev &Fd = E.rep[f];
+    const RepDev &Ld = E.rep[E.leader];
+    const uint64_t vis = visible_slots(E, Ld.hdr, r0, R);
+    const uint64_t from = Fd.hdr[H_N_PERSIST];
+    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < vis; s += nth) {
+        const uint32_t di = (uint32_t)s & E.dir_mask;
+        const uint64_t off = Fd.dir_off[di];
+        /* entry->sender says whose log gets the ACK (dare_server.c:1806) */
+        const uint32_t sender = Fd.ring[off + 27];
+        Fd.ring[off + 28 + f] = 1;                               /* local reply byte, dare_ibv_rc.c:1840 */
+        if (sender < APUS_DEV_MAX_SERVERS && E.rep[sender].ring) {
+            E.rep[sender].ring[off + 28 + f] = 1;                /* R3: 1-byte WRITE at the same offset */
+            atomicOr(&E.rep[sender].ack[di], 1u << f);           /* derived ACK word the scan reads */
+        }
+    }
+}
+
+/* k_commit: ACK words of [n_commit, visible) staged in LDS, one lane per entry. */
+__global__ __launch_bounds__(1024) void k_commit(const EngDev E, uint64_t r0, uint32_t R)
+{
+    __shared__ uint32_t s_ack[1024];
+    const RepDev &Ld = E.rep[E.leader];
+    const uint64_t vis = visible_slots(E, Ld.hdr, r0, R);
+    const uint64_t from = Ld.hdr[H_N_COMMIT];
+    const uint32_t size = E.group_size;                          /* cid.size[0], dare_ibv_rc.c:1656 */
+    const uint32_t size_mask = (1u << size) - 1;
+    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t tile = from + (uint64_t)blockIdx.x * blockDim.x; tile < vis; tile += nth) {
+        const uint64_t s = tile + threadIdx.x;
+        const bool in = s < vis;
+        __syncthreads();
+        s_ack[threadIdx.x] = in ? Ld.ack[(uint32_t)s & E.dir_mask] : 0xFFFFFFFFu;
+        __syncthreads();
+        const uint32_t m = (s_ack[threadIdx.x] | (1u << E.leader)) & size_mask;
+        const bool ok = !in || (uint32_t)__popc(m) >= size / 2 + 1;  /* replies >= size/2+1, :1738 */
+        const unsigned long long bal = __ballot(!ok);
+        if (bal && lane_id() == 0) {
+            const uint64_t first = s + (uint64_t)__builtin_ctzll(bal);
+            atomicMin((unsigned long long *)&E.seq->first_fail, (unsigned long long)first);
+        }
+    }
+}
+
+/* commit slot reached by this call on the leader */
+__device__ static inline uint64_t commit_slot(const EngDev &E, const uint64_t *lhdr, uint64_t r0, uint32_t R)
+{
+    const uint64_t vis = visible_slots(E, lhdr, r0, R);
+    uint64_t cs = min((uint64_t)E.seq->first_fail, vis);
+    if (cs < E.seq->n_commit_before) cs = E.seq->n_commit_before;
+    return cs;
+}
+
+/* k_apply: one lane per committed-and-not-applied entry (grid.y = replica).   */
+__global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint32_t R, uint32_t rmask)
+{
+    int p = -1;
+    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
+        if (rmask & (1u << i)) { if (k == (int)blockIdx.y) { p = i; break; } k++; }
+    if (p < 0) return;
+    const RepDev &Pd = E.rep[p];
+    const RepDev &Ld = E.rep[E.leader];
+    const bool leader = (uint32_t)p == E.leader;
+    const uint64_t cs = commit_slot(E, Ld.hdr, r0, R);
+    const uint64_t from = Pd.hdr[H_N_APPLY];
+    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t tile = from + (uint64_t)blockIdx.x * blockDim.x; tile < cs; tile += nth) {
+    const uint64_t s = tile + threadIdx.x;
+    const bool in = s < cs;
+    uint64_t mix = 0;
+    uint32_t client = 0;
+    if (in) {
+        const uint32_t di = (uint32_t)s & E.dir_mask;
+        const uint64_t off = Pd.dir_off[di];
+        const uint32_t T = Pd.dir_len[di];
+        const uint4 u0 = ld16u(Pd.ring + off);
+        const uint4 u1 = ld16u(Pd.ring + off + 16);
+        const uint64_t idx = (uint64_t)u0.x | ((uint64_t)u0.y << 32);
+        const uint32_t type = (u1.z >> 16) & 0xFF;
+        const uint16_t clt = (uint16_t)(u1.z & 0xFFFF);
+        client = (type != 0 && type != 2 && type != 3);
+        apus_apply_rec rec;
+        rec.slot = s; rec.off = off; rec.idx = idx; rec.len = T - APUS_HDR;
+        rec.clt_id = clt; rec.type = (uint8_t)type;
+        rec.kind = client ? (leader ? 1 : 2) : 0;
+        Pd.apply[di] = rec;
+        if (client) mix = apus_apply_mix(s, off, idx, T - APUS_HDR, clt, (uint8_t)type, rec.kind);
+        if (type == 3 && !leader)                      /* poll_config_entries: committed HEAD, dare_server.c:2164 */
+            atomicMax((unsigned long long *)&Pd.hdr[H_HEAD_SLOT], (unsigned long long)(s + 1));
+    }
+    const uint64_t wsum = wave_sum(mix);
+    const uint32_t wcnt = (uint32_t)__popcll(__ballot(client != 0));
+    if (lane_id() == 0 && wcnt) {
+        atomicAdd((unsigned long long *)&Pd.hdr[H_APPLY_HASH], (unsigned long long)wsum);
+        atomicAdd((unsigned long long *)&Pd.hdr[H_APPLY_COUNT], (unsigned long long)wcnt);
+        if (leader) atomicAdd((unsigned long long *)&Pd.hdr[H_HIGHEST_REC], (unsigned long long)wcnt);
+    }
+    }
+}
+
+/* k_finish: scalar bookkeeping of the call.  mode 0: R staged rounds; mode 1:
+ * one control-entry round (s.n tells whether it happened); mode 2: quiesce.   */
+__global__ __launch_bounds__(64) void k_finish(const EngDev E, uint64_t r0, uint32_t R, int mode, uint32_t fmask)
+{
+    const RepDev &Ld = E.rep[E.leader];
+    uint64_t *lh = Ld.hdr;
+    const uint64_t L = E.log_len;
+    const SeqOut s = *E.seq;
+    const uint64_t vis = visible_slots(E, lh, r0, R);
+    const uint64_t cs = commit_slot(E, lh, r0, R);
+    const uint64_t end_l = lh[H_END];
+    /* byte offset that corresponds to a slot boundary b (<= n_end) */
+    auto slot_off = [&](uint64_t b) -> uint64_t {
+        if (b == lh[H_N_END]) return end_l;
+        return Ld.dir_off[(uint32_t)b & E.dir_mask];
+    };
+    const uint64_t commit_off = (cs > s.n_commit_before) ? slot_off(cs) : s.commit_before;
+    const uint64_t vis_off = slot_off(vis);
+    const uint32_t lane = threadIdx.x;
+
+    /* per-round record */
+    const uint64_t rec_base = *E.rec_count;
+    if (mode == 0) {
+        const uint32_t *rf = E.round_first + r0;
+        for (uint32_t r = lane; r < R; r += WAVE) {
+            if (rec_base + r >= E.rec_cap) break;
+            const uint64_t slot_end_r = s.n_end0 + (rf[r + 1] - rf[0]);
+            const uint64_t c = min(cs, slot_end_r);
+            uint64_t cr;
+            if (c <= s.n_commit_before) cr = s.commit_before;
+            else if (c == slot_end_r) cr = E.rec_end[rec_base + r];
+            else cr = Ld.dir_off[(uint32_t)c & E.dir_mask];
+            E.rec_commit[rec_base + r] = cr;
+        }
+    }
+    __syncthreads();
+    if (mode == 0) {
+        /* a round that ended exactly on len could not commit: the log read as empty
+         * (dare_log.h:158), the leader's scan saw distance 0 (dare_ibv_rc.c:1726) */
+        for (uint32_t r = lane; r < R; r += WAVE) {
+            if (rec_base + r >= E.rec_cap) break;
+            if (E.rec_end[rec_base + r] == L)
+                E.rec_commit[rec_base + r] = r ? E.rec_commit[rec_base + r - 1] : s.commit_before;
+        }
+    }
+    if (lane == 0) {
+        if (mode == 0) {
+            *E.rec_count = rec_base + R;
+        } else if (mode == 1 && s.n) {
+            if (rec_base < E.rec_cap)
+                E.rec_commit[rec_base] = (end_l == L) ? s.commit_before : commit_off;
+            *E.rec_count = rec_base + 1;
+        }
+        /* leader: commit, cid offset, apply (update_remote_logs :1744-1758, apply_committed_entries) */
+        lh[H_N_VISIBLE] = vis;
+        if (cs > s.n_commit_before) { lh[H_COMMIT] = commit_off; lh[H_N_COMMIT] = cs; }
+        if (cs > lh[H_N_APPLY]) { lh[H_APPLY] = slot_off(cs); lh[H_N_APPLY] = cs; }
+    }
+    /* followers: R2 end doorbell, persist bookkeeping, R4 lazy commit, apply, HEAD adoption */
+    if (lane >= 1 && lane <= APUS_DEV_MAX_SERVERS) {
+        const int f = (int)lane - 1;
+        if ((fmask >> f) & 1u) {
+            uint64_t *fh = E.rep[f].hdr;
+            if (vis > fh[H_N_PERSIST]) {
+                fh[H_STORE_COUNT] += vis - fh[H_N_PERSIST];
+                fh[H_END] = vis_off; fh[H_OLD_END] = vis_off;
+                fh[H_N_END] = vis; fh[H_N_PERSIST] = vis;
+            }
+            if (cs > fh[H_N_COMMIT]) { fh[H_COMMIT] = (cs > s.n_commit_before) ? commit_off : lh[H_COMMIT]; fh[H_N_COMMIT] = cs; }
+            if (cs > fh[H_N_APPLY]) { fh[H_APPLY] = fh[H_COMMIT]; fh[H_N_APPLY] = cs; }
+            const uint64_t hs = fh[H_HEAD_SLOT];
+            if (hs) {
+                const uint64_t hoff = E.rep[f].dir_off[(uint32_t)(hs - 1) & E.dir_mask];
+                const uint64_t hv = ld8u(E.rep[f].ring + hoff + 48);
+                if (apus_is_larger(fh[H_END], L, hv, fh[H_HEAD])) fh[H_HEAD] = hv;
+                fh[H_HEAD_SLOT] = 0;
+            }
+        }
+    }
+}
+
+/* k_reset: log_new() (dare_log.h:120-136) without touching the ring bytes that
+ * were never made visible; the host memsets rings separately when asked to.   */
+__global__ void k_reset(const EngDev E)
+{
+    const int p = blockIdx.x;
+    if (threadIdx.x != 0 || !E.rep[p].ring) return;
+    uint64_t *h = E.rep[p].hdr;
+    for (int i = 0; i < H_WORDS; i++) h[i] = 0;
+    h[H_LEN] = E.log_len; h[H_END] = E.log_len; h[H_TAIL] = E.log_len; h[H_OLD_END] = E.log_len;
+    h[H_SID] = (uint64_t)p;
+    h[H_CID_BITMASK] = (1u << E.group_size) - 1;
+    if (p == 0) { *E.rec_count = 0; *E.status = 0; }
+}

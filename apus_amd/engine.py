@@ -1,0 +1,237 @@
+"""Host-side mirror of the engine C ABI (include/apus_gpu.h) plus the trace driver.
+
+Everything that computes runs in libapus_gpu.so on the GPU; this module only
+marshals arguments, keeps the host control-plane state (who is leader, which
+term, who is reachable) and maps trace events onto ABI calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .trace import DEFAULT_LOG, REQ_DTYPE, Trace
+
+APPLY_DTYPE = np.dtype([("slot", "<u8"), ("off", "<u8"), ("idx", "<u8"), ("len", "<u4"),
+                        ("clt_id", "<u2"), ("type", "u1"), ("kind", "u1")])
+OFFSET_NAMES = ("head", "apply", "commit", "end", "tail", "old_end", "old_commit", "len")
+COUNTER_NAMES = ("n_end", "n_persist", "n_commit", "n_apply", "last_idx", "sid", "highest_rec", "apply_hash")
+# hdr word indices (apus_device.h)
+H_APPLY_COUNT, H_PREV_HEAD, H_CID_BITMASK, H_STORE_COUNT = 16, 17, 18, 21
+
+ST_NAMES = {1: "SECOND_WRAP", 2: "LOG_FULL", 4: "TERM_FENCE", 8: "DIR_OVERRUN", 16: "SPIN_TIMEOUT"}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Engine:
+    """N logical replicas of one consensus group on one MI355X (or the local share
+    of a group that spans several processes)."""
+
+    def __init__(self, group_size: int, log_len: int = DEFAULT_LOG, local_ids=None,
+                 device: int = 0, stream: int | None = None):
+        self.L = _lib.load()
+        self.group_size = group_size
+        self.log_len = log_len
+        self.local_ids = list(range(group_size)) if local_ids is None else list(local_ids)
+        cfg = _lib.Cfg()
+        cfg.group_size = group_size
+        cfg.n_local = len(self.local_ids)
+        for k, i in enumerate(self.local_ids):
+            cfg.local_ids[k] = i
+        cfg.log_len = log_len
+        cfg.device = device
+        cfg.flags = 0
+        cfg.stream = stream
+        h = C.c_void_p()
+        rc = self.L.apus_gpu_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise EngineError(f"apus_gpu_create failed rc={rc} (a gfx950 device is required)")
+        self.h = h
+        self.leader = -1
+        self.term = 0
+        self.bitmask = (1 << group_size) - 1
+        self.reachable = (1 << group_size) - 1
+        self.round_of_g0 = {}
+        self._keep = []
+
+    # -- lifetime ---------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.apus_gpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise EngineError(f"{what} failed rc={rc} status={self.status_names()}")
+
+    def sync(self):
+        self._chk(self.L.apus_gpu_sync(self.h), "sync")
+
+    def reset(self):
+        self._chk(self.L.apus_gpu_reset(self.h), "reset")
+        self.leader, self.term = -1, 0
+        self.bitmask = self.reachable = (1 << self.group_size) - 1
+
+    # -- admission --------------------------------------------------------------
+    def stage(self, reqs: np.ndarray, arena: np.ndarray, round_n: np.ndarray):
+        reqs = np.ascontiguousarray(reqs, dtype=REQ_DTYPE)
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        round_n = np.ascontiguousarray(round_n, dtype=np.uint32)
+        self._chk(self.L.apus_gpu_stage(self.h, reqs.ctypes.data, len(reqs), arena.ctypes.data, len(arena),
+                                        round_n.ctypes.data, len(round_n)), "stage")
+        self.n_rounds = len(round_n)
+
+    def stage_trace(self, trace: Trace):
+        """Stage every ROUND of a trace; returns {g0: round index}."""
+        rounds = [(ev[1], ev[2]) for ev in trace.events if ev[0] == "ROUND"]
+        g = 0
+        for g0, n in rounds:
+            assert g0 == g, "rounds must cover the request stream in order"
+            g += n
+        assert g == len(trace.reqs)
+        self.stage(trace.reqs, trace.arena, np.array([n for _, n in rounds], dtype=np.uint32))
+        self.round_of_g0 = {g0: i for i, (g0, _) in enumerate(rounds)}
+        return self.round_of_g0
+
+    # -- control plane ------------------------------------------------------------
+    def elect(self, winner: int):
+        """ELECT(winner): every live server becomes a candidate of term t+1, the
+        winner's election timeout fires first and it wins term t+2 (the schedule of
+        oracle/apus_oracle.c:orc_elect, from dare_server.c:1264-1518)."""
+        self.term += 2
+        self.leader = winner
+        self._chk(self.L.apus_gpu_become_leader(self.h, winner, self.term, self.bitmask), "become_leader")
+
+    def set_reachable(self, mask: int):
+        self.reachable = mask
+        self._chk(self.L.apus_gpu_set_reachable(self.h, mask), "set_reachable")
+
+    def hold(self, r: int): self.set_reachable(self.reachable & ~(1 << r))
+    def release(self, r: int): self.set_reachable(self.reachable | (1 << r))
+
+    def append_control(self, type_: int, data: bytes | None = None):
+        buf = C.create_string_buffer(data, 16) if data is not None else None
+        self._chk(self.L.apus_gpu_append_control(self.h, type_, C.cast(buf, C.c_void_p) if buf else None),
+                  "append_control")
+
+    def run_rounds(self, r0: int, n: int):
+        self._chk(self.L.apus_gpu_run_rounds(self.h, r0, n), "run_rounds")
+
+    def tick_prune(self): self._chk(self.L.apus_gpu_tick_prune(self.h), "tick_prune")
+    def quiesce(self): self._chk(self.L.apus_gpu_quiesce(self.h), "quiesce")
+
+    def run_trace(self, trace: Trace, on_event=None, max_batch_rounds: int = 4096, check: bool = True):
+        """Drive the engine with a trace.  Consecutive ROUND events are coalesced
+        into one run_rounds call (batch boundaries never change results)."""
+        self.stage_trace(trace)
+        i, ev = 0, trace.events
+        while i < len(ev):
+            op = ev[i][0]
+            if op == "ROUND":
+                j = i
+                while j < len(ev) and ev[j][0] == "ROUND" and j - i < max_batch_rounds:
+                    j += 1
+                self.run_rounds(self.round_of_g0[ev[i][1]], j - i)
+                last = j - 1
+                i = j
+            else:
+                if op == "ELECT":
+                    self.elect(ev[i][1])
+                elif op == "PRUNE":
+                    self.tick_prune()
+                elif op == "QUIESCE":
+                    self.quiesce()
+                elif op == "HOLD":
+                    self.hold(ev[i][1])
+                elif op == "RELEASE":
+                    self.release(ev[i][1])
+                else:
+                    raise EngineError(f"trace event {ev[i]} is not supported by the engine yet")
+                last = i
+                i += 1
+            if on_event is not None:
+                on_event(last, ev[last], self)
+        if check:
+            self.check_status()
+
+    # -- graphs -------------------------------------------------------------------
+    def capture_begin(self): self._chk(self.L.apus_gpu_capture_begin(self.h), "capture_begin")
+
+    def capture_end(self) -> int:
+        gid = C.c_int(-1)
+        self._chk(self.L.apus_gpu_capture_end(self.h, C.byref(gid)), "capture_end")
+        return gid.value
+
+    def graph_launch(self, gid: int): self._chk(self.L.apus_gpu_graph_launch(self.h, gid), "graph_launch")
+
+    # -- observation --------------------------------------------------------------
+    def offsets(self, r: int) -> dict:
+        out = (C.c_uint64 * 8)()
+        self._chk(self.L.apus_gpu_offsets(self.h, r, out), "offsets")
+        return dict(zip(OFFSET_NAMES, [int(v) for v in out]))
+
+    def counters(self, r: int) -> dict:
+        out = (C.c_uint64 * 8)()
+        self._chk(self.L.apus_gpu_counters(self.h, r, out), "counters")
+        return dict(zip(COUNTER_NAMES, [int(v) for v in out]))
+
+    def hdr_words(self, r: int) -> np.ndarray:
+        out = (C.c_uint64 * 64)()
+        self._chk(self.L.apus_gpu_hdr_words(self.h, r, out, 64), "hdr_words")
+        return np.array(out[:], dtype=np.uint64)
+
+    def ring(self, r: int, off: int = 0, n: int | None = None) -> np.ndarray:
+        n = self.log_len - off if n is None else n
+        out = np.empty(n, dtype=np.uint8)
+        self._chk(self.L.apus_gpu_read_ring(self.h, r, off, n, out.ctypes.data), "read_ring")
+        return out
+
+    def round_record(self):
+        n = int(self.L.apus_gpu_round_count(self.h))
+        end = np.zeros(n, dtype=np.uint64)
+        com = np.zeros(n, dtype=np.uint64)
+        if n:
+            self._chk(self.L.apus_gpu_round_record(self.h, 0, n, end.ctypes.data, com.ctypes.data), "round_record")
+        return com, end
+
+    def apply_records(self, r: int, first: int, n: int) -> np.ndarray:
+        out = np.zeros(n, dtype=APPLY_DTYPE)
+        if n:
+            self._chk(self.L.apus_gpu_apply_records(self.h, r, first, n, out.ctypes.data), "apply_records")
+        return out
+
+    def status(self) -> int: return int(self.L.apus_gpu_status(self.h))
+
+    def status_names(self):
+        try:
+            s = self.status()
+        except Exception:
+            return "?"
+        return [v for k, v in ST_NAMES.items() if s & k] or "OK"
+
+    def check_status(self):
+        s = self.status()
+        if s:
+            raise EngineError(f"device status {self.status_names()}")
+
+    def set_timing(self, on: bool): self._chk(self.L.apus_gpu_set_timing(self.h, int(on)), "set_timing")
+
+    def kernel_time(self, which: int = 0):
+        ms, n = C.c_float(0), C.c_uint64(0)
+        self._chk(self.L.apus_gpu_kernel_time(self.h, which, C.byref(ms), C.byref(n)), "kernel_time")
+        return float(ms.value), int(n.value)
+
+    def device_ptr(self, r: int, which: int):
+        nb = C.c_uint64(0)
+        p = self.L.apus_gpu_device_ptr(self.h, r, which, C.byref(nb))
+        return p, int(nb.value)

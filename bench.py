@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- committed log entries/s of the MI355X consensus engine.
+
+Metric (BASELINE.json): committed entries/sec (+ p50 consensus latency) on the
+configuration the metric is quoted on, configs[1]: 3 replicas, synthetic 64-B
+entries (E = 128 B), 2^20 SEND entries in rounds of 64, prune tick every 8 MiB.
+
+One "step" = one pass of the hot path over the whole staged request stream
+(append -> replicate -> ACK -> commit -> apply on every replica, prune ticks
+included), continuing on the same 64 MiB rings.  Inputs are resident in HBM
+before the timed region.
+
+  --gpus 1 : the 3 replicas are logical replicas on the one device (gpurun
+             exposes one MI355X; replication is a same-device copy, the binding
+             roofline is HBM -- SURVEY.md section 8d).
+  --gpus N : N >= 2 replicas, one per GPU / process, log ranges and ACKs exchanged
+             with RCCL point-to-point (torch.distributed backend "nccl").
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_trace(args, group_size):
+    from apus_amd import trace as T
+    return T.steady_trace(group_size, args.entries, args.payload, 16, args.batch,
+                          log_len=T.DEFAULT_LOG, name="C2")
+
+
+def step_calls(tr, eng):
+    """The ABI calls of one step, in trace order (ELECT happens once, before)."""
+    calls = []
+    ev = tr.events
+    i = 0
+    while i < len(ev):
+        if ev[i][0] == "ROUND":
+            j = i
+            while j < len(ev) and ev[j][0] == "ROUND":
+                j += 1
+            calls.append(("rounds", eng.round_of_g0[ev[i][1]], j - i))
+            i = j
+            continue
+        if ev[i][0] == "PRUNE":
+            calls.append(("prune",))
+        i += 1
+    calls.append(("quiesce",))
+    return calls
+
+
+def issue(eng, calls):
+    for c in calls:
+        if c[0] == "rounds":
+            eng.run_rounds(c[1], c[2])
+        elif c[0] == "prune":
+            eng.tick_prune()
+        else:
+            eng.quiesce()
+
+
+def cpu_baseline(args, seconds=15.0):
+    """The CPU oracle (a single-threaded port of the reference's loops, -O2) on a
+    bounded sample of the same workload, timed on this box's host cores."""
+    from apus_amd import trace as T
+    from oracle import oracle as orc
+    sample = min(args.entries, 1 << 18)
+    tr = T.steady_trace(3, sample, args.payload, 16, args.batch, log_len=T.DEFAULT_LOG)
+    cl = orc.Cluster(3, tr.log_len, record_apply=False)
+    cl.elect(0)
+    round_n = np.array([ev[2] for ev in tr.events if ev[0] == "ROUND"], dtype=np.uint32)
+    done, t0 = 0, time.perf_counter()
+    passes = 0
+    while True:
+        cl.run_rounds(tr.reqs, round_n, tr.arena, prune_bytes=8 << 20)
+        done += len(tr.reqs)
+        passes += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or passes >= 4096:
+            break
+    cl.quiesce()
+    o = cl.log(0).offsets()
+    assert o["commit"] == o["end"]
+    return {"value": done / el, "unit": "committed entries/s", "cores": 1, "kind": "port",
+            "sample": f"{passes} x {len(tr.reqs)} entries of the same 3-replica stream "
+                      f"({el:.1f} s, oracle/liboracle.so -O2, nproc={os.cpu_count()})"}
+
+
+def bench_single(args):
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
+    from apus_amd.engine import Engine
+    n_rep = args.replicas
+    tr = build_trace(args, n_rep)
+    eng = Engine(n_rep, tr.log_len, device=0)
+    eng.stage_trace(tr)
+    eng.elect(0)
+    calls = step_calls(tr, eng)
+    n_entries = len(tr.reqs)
+
+    # one eager step first (pages everything in, validates), then capture the step
+    issue(eng, calls)
+    eng.sync()
+    eng.check_status()
+    use_graph = not args.eager
+    gid = None
+    if use_graph:
+        eng.capture_begin()
+        issue(eng, calls)
+        gid = eng.capture_end()
+
+    def run_step():
+        if use_graph:
+            eng.graph_launch(gid)
+        else:
+            issue(eng, calls)
+
+    for _ in range(args.warmup):
+        run_step()
+    eng.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step()
+    eng.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.check_status()
+
+    # the work really happened: every entry of every step is committed and applied everywhere
+    total_steps = 1 + args.warmup + args.steps
+    for r in range(n_rep):
+        o = eng.offsets(r)
+        assert o["commit"] == o["end"] == o["apply"], f"replica {r} not caught up: {o}"
+    assert eng.counters(0)["highest_rec"] == total_steps * n_entries, "leader did not apply every entry"
+    for r in range(1, n_rep):
+        assert int(eng.hdr_words(r)[16]) == total_steps * n_entries, "follower did not apply every entry"
+
+    # dominant kernel (k_append_push): HIP events around each launch, eager, same steps
+    eng.set_timing(True)
+    for _ in range(args.steps):
+        issue(eng, calls)
+    eng.sync()
+    k_ms, k_launches = eng.kernel_time(0)
+    eng.set_timing(False)
+
+    # p50 consensus-round latency: one round per call, host-observed (submit -> commit visible)
+    lat = []
+    r_idx = eng.round_of_g0[tr.events[-2][1]] if tr.events[-2][0] == "ROUND" else 0
+    for k in range(200):
+        t1 = time.perf_counter()
+        eng.run_rounds((r_idx + k) % eng.n_rounds, 1)
+        eng.sync()
+        lat.append((time.perf_counter() - t1) * 1e6)
+    p50 = float(np.percentile(lat[20:], 50))
+    eng.check_status()
+
+    E = 64 + args.payload
+    N = n_rep
+    entries_per_launch = n_entries * args.steps / max(k_launches, 1)
+    # algorithmic HBM bytes (single-device mode): (3N-1)E + 64 per
+    # committed entry for the whole path; the append+replicate kernel's share of it is
+    # E (leader append) + 2E(N-1) (replication)
+    path_bytes = (3 * N - 1) * E + 64
+    kern_bytes = (2 * N - 1) * E
+    k_avg_s = (k_ms / 1e3) / max(k_launches, 1)
+    achieved = kern_bytes * entries_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+    value = n_entries * args.steps / dt
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("k_append_push_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "committed entries/sec", "value": value, "unit": "entries/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: {N} replicas (logical, one MI355X), "
+                               f"{n_entries} entries/step ({args.entries} SEND of {args.payload} B + 16 CONNECT), "
+                               f"rounds of {args.batch}, prune tick every 8 MiB, 64 MiB rings",
+                   "mode": "hipGraph replay of one step" if use_graph else "eager launches",
+                   "replicas": N, "entry_bytes": E, "launches_per_step": len(calls)},
+        "p50_round_latency_us": p50,
+        "latency_note": "one 64-entry round per call, host submit -> commit visible after stream sync (phased kernels)",
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "k_append_push", "bytes_per_entry": kern_bytes,
+                     "avg_launch_us": k_avg_s * 1e6, "launches": k_launches,
+                     "entries_per_launch": entries_per_launch},
+        "whole_path": {"bytes_per_entry": path_bytes, "achieved": path_bytes * value / 1e9,
+                       "unit": "GB/s", "frac": path_bytes * value / 1e9 / HBM_PEAK_GBS},
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+    eng.close()
+    return out
+
+
+def bench_multi(args):
+    from apus_amd.distributed import bench_group
+    return bench_group(args)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--entries", type=int, default=1 << 20)
+    ap.add_argument("--payload", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--replicas", type=int, default=3)
+    ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+    if args.gpus <= 1:
+        out = bench_single(args)
+        print(json.dumps(out))
+    else:
+        out = bench_multi(args)
+        if out is not None:
+            print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,200 @@
+/*
+ * apus_gpu.h -- C ABI of the MI355X consensus engine (libapus_gpu.so).
+ *
+ * Drop-in boundary for ONE path of hku-systems/apus: the dare_server consensus
+ * loop (log append -> replicate -> ACK aggregation -> commit advance -> apply).
+ * Plain pointers and sizes only; no torch / HIP types in any signature (a
+ * hipStream_t travels as void*).  Citations are relative to /root/reference/.
+ *
+ * Three layers, outermost first:
+ *
+ *   B-outer  proxy_init / proxy_on_read / proxy_on_accept / proxy_on_close
+ *            (src/include/rsm-interface.h:12-15) and
+ *   B-inner  dare_server_init / is_leader / get_node_id
+ *            (src/include/dare/dare_server.h:197-203)
+ *            are implemented in apus_amd/host/ (plain C) on top of this header;
+ *            INTEGRATION.md shows the two-line change that makes the
+ *            reference's own interposer (src/spec_hooks.cpp) link against them.
+ *
+ *   B-transport  the hot subset of the dare_ib_* facade
+ *            (src/include/dare/dare_ibv.h:140-201) is exported below under the
+ *            reference's own names, so that dare_server.c's polling() loop can
+ *            call them unchanged.
+ *
+ *   engine   apus_gpu_*: what those wrappers are made of, also used directly by
+ *            the trace harness, the tests and bench.py.
+ *
+ * Error convention (same as the reference's rc_* functions,
+ * src/dare/dare_ibv_rc.c:27-29): 0 = success, 1 = error, -1 = retry later.
+ * apus_gpu_* additionally return negative APUS_E_* codes.
+ */
+#ifndef APUS_GPU_H
+#define APUS_GPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APUS_MAX_SERVERS  13                    /* MAX_SERVER_COUNT, src/include/dare/dare.h:26      */
+#define APUS_ENTRY_HDR    64                    /* sizeof(dare_log_entry_t), dare_log.h:33-47        */
+#define APUS_LOG_SIZE     (16384ull * 4096ull)  /* LOG_SIZE, src/include/dare/dare_log.h:76          */
+#define APUS_MAX_ROUND    64                    /* entries per device round = one wavefront          */
+
+/* entry types: dare_log.h:22-25 and src/include/proxy/proxy.h:10-12 */
+#define APUS_NOOP 0
+#define APUS_CSM 1
+#define APUS_CONFIG 2
+#define APUS_HEAD 3
+#define APUS_CONNECT 4
+#define APUS_SEND 5
+#define APUS_CLOSE 6
+
+/* negative engine error codes */
+#define APUS_E_ARG      (-2)
+#define APUS_E_HIP      (-3)
+#define APUS_E_NOMEM    (-4)
+#define APUS_E_STATE    (-5)   /* no leader / not staged / bad replica */
+#define APUS_E_DEVICE   (-6)   /* a device-side status bit is set: see apus_gpu_status */
+
+/* device status bits (sticky until apus_gpu_clear_status) */
+#define APUS_ST_SECOND_WRAP  (1u << 0)  /* one run_rounds batch wrapped the ring twice               */
+#define APUS_ST_LOG_FULL     (1u << 1)  /* an append met end == head (dare_log.h:168) or ran over it  */
+#define APUS_ST_TERM_FENCE   (1u << 2)  /* a follower saw an entry batch from a stale term            */
+#define APUS_ST_DIR_OVERRUN  (1u << 3)  /* more live entries than directory slots                     */
+#define APUS_ST_SPIN_TIMEOUT (1u << 4)  /* persistent kernel gave up waiting (bounded spin)           */
+
+/* one admitted client request = what a tailq_entry_t carries
+ * (src/include/dare/message.h:11-18), produced by leader_handle_submit_req
+ * (src/proxy/proxy.c:108-161).  24 bytes, little endian. */
+typedef struct {
+    uint64_t req_id;
+    uint64_t payload_off;   /* byte offset into the payload arena, 16-byte aligned */
+    uint16_t clt_id;        /* connection_id */
+    uint16_t len;           /* payload bytes (cmd.len) */
+    uint8_t  type;          /* APUS_CONNECT / APUS_SEND / APUS_CLOSE */
+    uint8_t  pad[3];
+} apus_req_t;
+
+/* one record of the apply stream: the upcall apply_committed_entries would make
+ * (src/dare/dare_server.c:1941-1955).  32 bytes. */
+typedef struct {
+    uint64_t slot;          /* position of the entry in the total order of the log */
+    uint64_t off;           /* byte offset of the entry in the ring */
+    uint64_t idx;           /* entry->idx */
+    uint32_t len;           /* entry->data.cmd.len */
+    uint16_t clt_id;
+    uint8_t  type;
+    uint8_t  kind;          /* 0 = none (control entry), 1 = proxy_update_state, 2 = proxy_do_action */
+} apus_apply_t;
+
+typedef struct {
+    uint32_t group_size;                 /* N = cid.size[0]                                       */
+    uint32_t n_local;                    /* logical replicas hosted by this process / device      */
+    uint8_t  local_ids[APUS_MAX_SERVERS];/* their indices in the group                            */
+    uint8_t  pad[3];
+    uint64_t log_len;                    /* ring bytes; 0 = APUS_LOG_SIZE                         */
+    int32_t  device;                     /* HIP device ordinal                                    */
+    uint32_t flags;                      /* reserved, 0                                           */
+    void    *stream;                     /* hipStream_t to launch on; NULL = engine-owned stream  */
+} apus_cfg_t;
+
+typedef struct apus_engine apus_engine_t;
+
+/* ---- lifetime ------------------------------------------------------------- */
+int  apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out);
+void apus_gpu_destroy(apus_engine_t *e);
+int  apus_gpu_reset(apus_engine_t *e);     /* back to log_new() state (dare_log.h:120) on every replica; async */
+int  apus_gpu_sync(apus_engine_t *e);      /* wait for everything queued on the engine stream */
+
+/* ---- request admission (replaces the malloc'd TAILQ, message.h:20-22) ------ */
+/* Copies n admitted requests, their payload arena and the round partition
+ * (round_n[r] = number of requests the leader's r-th polling() pass drains,
+ * each <= APUS_MAX_ROUND) into HBM. */
+int  apus_gpu_stage(apus_engine_t *e, const apus_req_t *reqs, uint64_t n,
+                    const uint8_t *arena, uint64_t arena_bytes,
+                    const uint32_t *round_n, uint64_t n_rounds);
+
+/* ---- control plane (host-driven, ms-scale in the reference) ---------------- */
+/* Role/term change: the caller (host election logic) decided that `leader` won
+ * term `term`; appends the blank CONFIG entry a new leader always writes
+ * (src/dare/dare_server.c:1411-1421).  bitmask = cid.bitmask. */
+int  apus_gpu_become_leader(apus_engine_t *e, uint32_t leader, uint64_t term, uint32_t bitmask);
+/* reachability of peers from the leader (KILL / HOLD / RELEASE of the trace;
+ * fail_count >= PERMANENT_FAILURE or rc_connected == 0 in the reference) */
+int  apus_gpu_set_reachable(apus_engine_t *e, uint32_t mask);
+/* leader appends one CONFIG / HEAD / NOOP entry (data: 16-B cid, 8-B head or NULL) */
+int  apus_gpu_append_control(apus_engine_t *e, uint8_t type, const void *data);
+
+/* ---- the hot path ----------------------------------------------------------- */
+/* Leader polling() passes r0 .. r0+n_rounds-1 over the staged requests:
+ * get_tailq_message -> log_append_entry (dare_ibv_ud.c:780, dare_log.h:466),
+ * persist_new_entries (dare_server.c:1792), update_remote_logs incl. the ACK
+ * scan (dare_ibv_rc.c:1465-1826), follower ACKs (rc_send_entries_reply :1828),
+ * apply_committed_entries (dare_server.c:1815).  Asynchronous on the engine
+ * stream; capturable into a hipGraph. */
+int  apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rounds);
+/* log_pruning() timer tick (dare_server.c:1996-2067) incl. the R8 apply-offset gather */
+int  apus_gpu_tick_prune(apus_engine_t *e);
+/* one more polling() pass everywhere: brings every reachable follower's end,
+ * commit and apply up to the leader's (update_remote_logs re-send + lazy commit) */
+int  apus_gpu_quiesce(apus_engine_t *e);
+
+/* Live submission (what the DARE thread does per polling() pass; replaces the
+ * malloc'd TAILQ drain of get_tailq_message, dare_ibv_ud.c:780-790):
+ *   apus_gpu_append_live  n queued requests become log entries on the leader and are
+ *                         pushed to the in-sync followers (payload_off relative to arena)
+ *   apus_gpu_commit_live  follower ACKs + ACK scan + commit + apply for that batch;
+ *                         wait_for_commit != 0 blocks until the device is done
+ *   apus_gpu_submit       both, asynchronous */
+int  apus_gpu_append_live(apus_engine_t *e, const apus_req_t *reqs, uint32_t n,
+                          const uint8_t *arena, uint64_t arena_bytes);
+int  apus_gpu_commit_live(apus_engine_t *e, int wait_for_commit);
+int  apus_gpu_submit(apus_engine_t *e, const apus_req_t *reqs, uint32_t n,
+                     const uint8_t *arena, uint64_t arena_bytes);
+
+/* hipGraph capture of a sequence of the asynchronous calls above */
+int  apus_gpu_capture_begin(apus_engine_t *e);
+int  apus_gpu_capture_end(apus_engine_t *e, int *graph_id);
+int  apus_gpu_graph_launch(apus_engine_t *e, int graph_id);
+
+/* ---- observation (synchronising) ------------------------------------------ */
+/* out[8] = head, apply, commit, end, tail, old_end, old_commit, len  (dare_log_t order) */
+int  apus_gpu_offsets(apus_engine_t *e, uint32_t replica, uint64_t out[8]);
+/* out[8] = n_end, n_persist, n_commit, n_apply (entry counts), last_idx, sid, highest_rec, apply_hash */
+int  apus_gpu_counters(apus_engine_t *e, uint32_t replica, uint64_t out[8]);
+int  apus_gpu_read_ring(apus_engine_t *e, uint32_t replica, uint64_t off, uint64_t n, void *dst);
+/* per-round record of the leader: end and commit offsets after every round since the last reset */
+int  apus_gpu_round_record(apus_engine_t *e, uint64_t first, uint64_t n, uint64_t *end_out, uint64_t *commit_out);
+uint64_t apus_gpu_round_count(apus_engine_t *e);
+/* apply stream records of slots [first, first+n) of one replica */
+int  apus_gpu_apply_records(apus_engine_t *e, uint32_t replica, uint64_t first, uint64_t n, apus_apply_t *out);
+uint32_t apus_gpu_status(apus_engine_t *e);
+void apus_gpu_clear_status(apus_engine_t *e);
+/* raw device pointers for zero-copy wrapping by the host transport (RCCL p2p):
+ * which: 0 ring, 1 hdr, 2 dir_off, 3 dir_len, 4 ack, 5 apply ring */
+void *apus_gpu_device_ptr(apus_engine_t *e, uint32_t replica, int which, uint64_t *bytes);
+/* HIP-event timing of the dominant kernel (which = 0: k_append_push): enable, run
+ * eagerly, then read the summed duration of its launches */
+int  apus_gpu_set_timing(apus_engine_t *e, int on);
+int  apus_gpu_kernel_time(apus_engine_t *e, int which, float *total_ms, uint64_t *launches);
+/* first n_words (<= 64) of a replica's control block (apus_device.h H_* words) */
+int  apus_gpu_hdr_words(apus_engine_t *e, uint32_t replica, uint64_t *out, uint32_t n_words);
+void *apus_gpu_stream(apus_engine_t *e);          /* the hipStream_t the engine launches on */
+apus_engine_t *apus_gpu_global(void);
+
+/* ---- B-transport: the reference's own names ------------------------------- */
+/* Bind the process-wide engine the dare_ib_* facade operates on (the reference
+ * keeps a global singleton too: dare_ib_device, src/dare/dare_ibv.c:33). */
+int  apus_gpu_bind_global(apus_engine_t *e);
+void dare_ib_poll_tailq(void);                       /* dare_ibv.h:154 -> get_tailq_message, dare_ibv_ud.c:780 */
+int  dare_ib_write_remote_logs(int wait_for_commit); /* dare_ibv.h:176 -> rc_write_remote_logs, dare_ibv_rc.c:1870 */
+int  dare_ib_send_entries_reply(uint8_t idx);        /* dare_ibv.h:177 -> rc_send_entries_reply, dare_ibv_rc.c:1828 */
+int  dare_ib_get_remote_apply_offsets(void);         /* dare_ibv.h:178 -> rc_get_remote_apply_offsets, dare_ibv_rc.c:1970 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APUS_GPU_H */

@@ -1,0 +1,85 @@
+/*
+ * apus_smr.h -- the reference's two host-side API surfaces, kept source- and
+ * ABI-compatible so that the engine drops in under an unmodified Redis/memcached:
+ *
+ *   B-outer  LD_PRELOAD hook <-> proxy   /root/reference/src/include/rsm-interface.h:12-15
+ *   B-inner  proxy <-> SMR core          /root/reference/src/include/dare/dare_server.h:142-160,197-203
+ *                                        /root/reference/src/include/dare/dare_sm.h:42-47
+ *                                        /root/reference/src/include/dare/message.h:5-22
+ *
+ * Implemented in apus_amd/host/apus_proxy.c (plain C) on top of include/apus_gpu.h.
+ * The structs below are laid out exactly like the reference's (sizes probed in
+ * sizeof(dare_server_input_t) == 216).
+ */
+#ifndef APUS_SMR_H
+#define APUS_SMR_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <unistd.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- B-outer: rsm-interface.h:12-15 ---------------------------------------- */
+struct proxy_node_t;
+struct proxy_node_t *proxy_init(const char *config_path, const char *proxy_log_path);
+void proxy_on_read(struct proxy_node_t *proxy, void *buf, ssize_t ret, int fd);
+void proxy_on_accept(struct proxy_node_t *proxy, int ret);
+void proxy_on_close(struct proxy_node_t *proxy, int fildes);
+
+/* ---- B-inner: callbacks, dare_sm.h:42-47 ----------------------------------- */
+typedef void     (*proxy_store_cmd_cb_t)(void *data, void *arg);
+typedef void     (*proxy_do_action_cb_t)(uint16_t clt_id, uint8_t type, size_t data_size, void *data, void *arg);
+typedef void     (*proxy_create_db_snapshot_cb_t)(void *snapshot, void *arg);
+typedef uint32_t (*proxy_get_db_size_cb_t)(void *arg);
+typedef int      (*proxy_apply_db_snapshot_cb_t)(void *snapshot, uint32_t size, void *arg);
+typedef void     (*proxy_update_state_cb_t)(void *arg);
+
+/* server types, dare_server.h:23-26 */
+#define SRV_TYPE_START 1
+#define SRV_TYPE_JOIN  2
+
+/* dare_server_input_t, dare_server.h:142-160 (field order and types unchanged) */
+struct dare_server_input_t {
+    FILE *log;
+    char *name;
+    char *output;
+    uint8_t srv_type;
+    uint8_t sm_type;
+    uint8_t group_size;
+    uint8_t server_idx;
+    proxy_do_action_cb_t do_action;
+    proxy_store_cmd_cb_t store_cmd;
+    proxy_create_db_snapshot_cb_t create_db_snapshot;
+    proxy_get_db_size_cb_t get_db_size;
+    proxy_apply_db_snapshot_cb_t apply_db_snapshot;
+    proxy_update_state_cb_t update_state;
+    char config_path[128];
+    void *up_para;
+};
+typedef struct dare_server_input_t dare_server_input_t;
+
+/* dare_server.h:197-203 */
+void   *dare_server_init(void *arg);     /* pthread entry; owns and frees *arg */
+void    dare_server_shutdown(void);
+int     is_leader(void);
+uint8_t get_node_id(void);
+
+/* ---- submission queue -------------------------------------------------------- */
+/* Replaces the global TAILQ of 87 KB malloc'd nodes + spinlock (message.h:5-22,
+ * proxy.c:147-158): one call enqueues an admitted request for the DARE thread.
+ * Thread-safe; copies `len` bytes.  Returns 0, or -1 when the queue is full. */
+int apus_tailq_push(uint8_t type, uint16_t connection_id, uint64_t req_id, const void *buf, uint16_t len);
+
+/* action codes carried in entry->type, proxy.h:10-12 */
+#define PROXY_CONNECT 4
+#define PROXY_SEND    5
+#define PROXY_CLOSE   6
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APUS_SMR_H */

@@ -284,6 +284,7 @@ typedef struct {
     uint64_t highest_rec;                       /* proxy.c:263 */
     uint64_t store_count;                       /* proxy_store_cmd calls */
     uint64_t apply_count, apply_hash;
+    uint64_t apply_slot;                        /* entries walked by apply_committed_entries */
     orc_apply_t *apply_log; uint64_t apply_cap;
     orc_det_t last_applied;                     /* dare_server.c:73 */
 } replica_t;
@@ -304,27 +305,28 @@ static inline int is_leader_r(const replica_t *p)                /* IS_LEADER, d
 
 static inline int cid_on(const orc_cid_t *cid, int i) { return (cid->bitmask >> i) & 1; }
 
-uint64_t orc_apply_mix(uint64_t h, uint64_t off, uint64_t idx, uint32_t len,
+uint64_t orc_apply_mix(uint64_t slot, uint64_t off, uint64_t idx, uint32_t len,
                        uint16_t clt_id, uint8_t type, uint8_t kind)
 {
-    uint64_t v = off * 0x9E3779B97F4A7C15ull ^ idx * 0xC2B2AE3D27D4EB4Full
+    uint64_t x = slot * 0x9E3779B97F4A7C15ull ^ off * 0xC2B2AE3D27D4EB4Full
+               ^ idx * 0x165667B19E3779F9ull
                ^ ((uint64_t)len << 32 | (uint64_t)clt_id << 16 | (uint64_t)type << 8 | kind);
-    h ^= v;
-    h *= 0x100000001B3ull;
-    h ^= h >> 29;
-    return h;
+    x ^= x >> 31;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 29;
+    return x;
 }
 
 static void record_apply(orc_cluster_t *c, replica_t *p, uint64_t off, const orc_entry_t *e, uint8_t kind)
 {
-    p->apply_hash = orc_apply_mix(p->apply_hash, off, e->idx, e->data.cmd.len, e->clt_id, e->type, kind);
+    p->apply_hash += orc_apply_mix(p->apply_slot, off, e->idx, e->data.cmd.len, e->clt_id, e->type, kind);
     if (c->record_apply) {
         if (p->apply_count == p->apply_cap) {
             p->apply_cap = p->apply_cap ? p->apply_cap * 2 : 1024;
             p->apply_log = realloc(p->apply_log, p->apply_cap * sizeof(orc_apply_t));
         }
         orc_apply_t *a = &p->apply_log[p->apply_count];
-        a->off = off; a->idx = e->idx; a->len = e->data.cmd.len;
+        a->slot = p->apply_slot; a->off = off; a->idx = e->idx; a->len = e->data.cmd.len;
         a->clt_id = e->clt_id; a->type = e->type; a->kind = kind;
     }
     p->apply_count++;
@@ -455,6 +457,7 @@ static void apply_committed_entries(orc_cluster_t *c, replica_t *p)
             p->last_applied.offset = log->apply + entry_len(e);
         }
         log->apply += entry_len(e);
+        p->apply_slot++;
     }
 }
 
@@ -963,4 +966,41 @@ uint64_t orc_canon_hash(const uint8_t *ring, uint64_t len, uint64_t end, uint64_
     uint64_t n = canon_walk(ring, len, end, from, to, &s);
     if (n_entries) *n_entries = n;
     return s.hash;
+}
+
+/* mask[i] = 1 for every byte of the ring that an entry in [from, to) DEFINES:
+ * header bytes 0..40, cmd.len + payload of client entries, the 16-B cid, the
+ * 8-B head, and the same fields of the stale header a case-2 wrap leaves behind.
+ * Struct padding (41..47) and the 14 bytes behind a payload are never written
+ * by log_append_entry (they keep whatever the previous lap left there) and are
+ * therefore not part of any parity claim. */
+uint64_t orc_defined_mask(const uint8_t *ring, uint64_t len, uint64_t end,
+                          uint64_t from, uint64_t to, uint8_t *mask)
+{
+    uint64_t count = 0, off = from;
+    if (end == len) return 0;
+    while (off != to) {
+        if (len - off < ORC_HDR_BYTES) { off = 0; if (off == to) break; }
+        const orc_entry_t *e = (const orc_entry_t *)(ring + off);
+        uint32_t elen = entry_len(e);
+        if (len - off < elen) {
+            /* stale header: log_append_entry never writes `sender` (only persist does,
+             * and only on the real entry), so byte 27 keeps the previous lap's value */
+            memset(mask + off, 1, 41);
+            mask[off + 27] = 0;
+            mask[off + 48] = mask[off + 49] = 1;
+            off = 0;
+            continue;
+        }
+        memset(mask + off, 1, 41);
+        switch (e->type) {
+        case ORC_CONFIG: memset(mask + off + 48, 1, 16); break;
+        case ORC_HEAD:   memset(mask + off + 48, 1, 8); break;
+        case ORC_NOOP:   break;
+        default:         memset(mask + off + 48, 1, 2 + (size_t)e->data.cmd.len); break;
+        }
+        off += elen;
+        if (++count > (1ull << 32)) break;
+    }
+    return count;
 }

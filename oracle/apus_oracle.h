@@ -92,6 +92,7 @@ typedef struct {
 
 /* one record of the apply stream (callbacks of apply_committed_entries) */
 typedef struct {
+    uint64_t slot;            /* number of entries this replica applied before this one */
     uint64_t off;             /* entry offset in the ring */
     uint64_t idx;
     uint32_t len;             /* cmd.len */
@@ -141,8 +142,9 @@ int      orc_run_rounds(orc_cluster_t *c, const orc_req_t *reqs, const uint32_t 
 uint64_t orc_splitmix64(uint64_t *state);
 void     orc_fill_payload(uint64_t seed, uint8_t *dst, uint32_t len);
 
-/* mixing step of the apply-stream hash (exported so the GPU side can be compared) */
-uint64_t orc_apply_mix(uint64_t h, uint64_t off, uint64_t idx, uint32_t len,
+/* apply-stream hash = sum (mod 2^64) over all upcalls of orc_apply_mix(record);
+ * position dependent through `slot`, so it can be accumulated in any order */
+uint64_t orc_apply_mix(uint64_t slot, uint64_t off, uint64_t idx, uint32_t len,
                        uint16_t clt_id, uint8_t type, uint8_t kind);
 
 /* Canonical serialisation of the entries in [from, to) of a ring whose end
@@ -157,6 +159,10 @@ uint64_t orc_canon(const uint8_t *ring, uint64_t len, uint64_t end,
 /* FNV-1a-64 of the canonical stream (no buffer needed) */
 uint64_t orc_canon_hash(const uint8_t *ring, uint64_t len, uint64_t end,
                         uint64_t from, uint64_t to, uint64_t *n_entries);
+
+/* mask of the bytes that entries in [from, to) define (see apus_oracle.c) */
+uint64_t orc_defined_mask(const uint8_t *ring, uint64_t len, uint64_t end,
+                          uint64_t from, uint64_t to, uint8_t *mask);
 
 #ifdef __cplusplus
 }

@@ -26,9 +26,9 @@ vp = C.c_void_p
 
 REQ_DTYPE = np.dtype([("req_id", "<u8"), ("payload_off", "<u8"), ("clt_id", "<u2"),
                       ("len", "<u2"), ("type", "u1"), ("pad", "u1", (3,))])
-APPLY_DTYPE = np.dtype([("off", "<u8"), ("idx", "<u8"), ("len", "<u4"),
+APPLY_DTYPE = np.dtype([("slot", "<u8"), ("off", "<u8"), ("idx", "<u8"), ("len", "<u4"),
                         ("clt_id", "<u2"), ("type", "u1"), ("kind", "u1")])
-assert REQ_DTYPE.itemsize == 24 and APPLY_DTYPE.itemsize == 24
+assert REQ_DTYPE.itemsize == 24 and APPLY_DTYPE.itemsize == 32
 
 
 def build(force: bool = False) -> None:
@@ -93,6 +93,7 @@ def lib() -> C.CDLL:
             "orc_apply_mix": (u64, [u64, u64, u64, u32, u16, u8, u8]),
             "orc_canon": (u64, [vp, u64, u64, u64, u64, vp, u64, C.POINTER(u64)]),
             "orc_canon_hash": (u64, [vp, u64, u64, u64, u64, C.POINTER(u64)]),
+            "orc_defined_mask": (u64, [vp, u64, u64, u64, u64, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -284,7 +285,7 @@ class Cluster:
     """N in-process replicas driven by trace events."""
 
     def __init__(self, group_size: int, log_len: int = DEFAULT_LOG, record_apply: bool = True,
-                 allow_exact_fit: bool = False):
+                 allow_exact_fit: bool = True):
         self.L = lib()
         self.h = self.L.orc_cluster_new(group_size, log_len)
         if not self.h:
@@ -375,3 +376,43 @@ def canon_hash(ring: np.ndarray, end: int, frm: int, to: int) -> tuple:
     n = u64(0)
     h = lib().orc_canon_hash(ring.ctypes.data, len(ring), end, frm, to, C.byref(n))
     return int(h), int(n.value)
+
+
+def run_trace(trace, record_apply: bool = True, allow_exact_fit: bool = True,
+              on_event=None) -> "Cluster":
+    """Drive a fresh oracle cluster with an apus_amd.trace.Trace (duck-typed).
+    on_event(i, event, cluster) is called after each event (used to snapshot
+    quiescent points)."""
+    c = Cluster(trace.group_size, trace.log_len, record_apply, allow_exact_fit)
+    reqs = np.ascontiguousarray(trace.reqs, dtype=REQ_DTYPE)
+    arena = np.ascontiguousarray(trace.arena, dtype=np.uint8)
+    for i, ev in enumerate(trace.events):
+        op = ev[0]
+        if op == "ROUND":
+            _, g0, n = ev
+            c.round(reqs[g0:g0 + n], arena)
+        elif op == "ELECT":
+            c.elect(ev[1])
+        elif op == "PRUNE":
+            c.tick_prune()
+        elif op == "QUIESCE":
+            c.quiesce()
+        elif op == "KILL":
+            c.kill(ev[1])
+        elif op == "HOLD":
+            c.hold(ev[1])
+        elif op == "RELEASE":
+            c.release(ev[1])
+        else:
+            raise ValueError(f"unknown trace event {ev}")
+        if on_event is not None:
+            on_event(i, ev, c)
+    return c
+
+
+def defined_mask(ring: np.ndarray, end: int, frm: int, to: int) -> np.ndarray:
+    """Boolean mask of the ring bytes that the entries in [frm, to) define."""
+    ring = np.ascontiguousarray(ring, dtype=np.uint8)
+    mask = np.zeros(len(ring), dtype=np.uint8)
+    lib().orc_defined_mask(ring.ctypes.data, len(ring), end, frm, to, mask.ctypes.data)
+    return mask.astype(bool)
