@@ -97,6 +97,7 @@ struct EngDev {
     uint32_t dir_mask;                    /* dir_cap - 1 */
     uint64_t log_len;
     uint32_t *status;
+    uint32_t *ticket;                     /* arrival counter of k_sequence's blocks */
     /* staged requests */
     const ReqDev   *req;
     const uint16_t *req_len;

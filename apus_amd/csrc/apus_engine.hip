@@ -35,6 +35,7 @@ struct apus_engine {
     uint32_t dir_cap;
     uint32_t local_mask;            /* replicas hosted here */
     uint32_t reachable;             /* peers the leader can post to (trace KILL/HOLD/RELEASE) */
+    bool lag_possible;              /* a follower may be far behind: run the wide catch-up first */
     uint64_t max_rounds;
     /* staging */
     void *d_req, *d_req_len, *d_arena, *d_round_first;
@@ -99,7 +100,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     apus_engine *e = new apus_engine();
     e->cfg = *cfg;
     memset(&e->d, 0, sizeof e->d);
-    e->capturing = false; e->timing = false; e->timed_used = 0;
+    e->capturing = false; e->timing = false; e->timed_used = 0; e->lag_possible = false;
     e->n_reqs = 0; e->n_rounds_staged = 0;
     e->d_req = e->d_req_len = e->d_arena = e->d_round_first = nullptr;
     e->h_live = nullptr; e->d_live = nullptr; e->live_pending = false; e->live_copied = nullptr;
@@ -134,6 +135,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->max_rounds = 1u << 16;
     e->d.rec_cap = 1ull << 22;
     if (!rc) rc = dev_alloc(e, &e->d.status, 64);
+    if (!rc) e->d.ticket = e->d.status + 8;
     if (!rc) rc = dev_alloc(e, &e->d.seq, sizeof(SeqOut));
     if (!rc) rc = dev_alloc(e, &e->d.round_virt, sizeof(uint64_t) * (e->max_rounds + 1));
     if (!rc) rc = dev_alloc(e, &e->d.rec_end, sizeof(uint64_t) * e->d.rec_cap);
@@ -263,7 +265,7 @@ static int launch_tail_view(apus_engine *e, const EngDev &view, uint64_t r0, uin
                            view, r0, R, fm);
     hipLaunchKernelGGL(k_commit, dim3(cap_grid(n, 1024, 512)), dim3(1024), 0, e->stream, view, r0, R);
     hipLaunchKernelGGL(k_apply, dim3(cap_grid(n, 256, 1024), popc(rm)), dim3(256), 0, e->stream, view, r0, R, rm);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, e->stream, view, r0, R, mode, fm);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, e->stream, view, r0, R, mode, fm);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -276,9 +278,10 @@ static int launch_tail(apus_engine *e, uint64_t r0, uint32_t R, int mode, uint64
 static int launch_catchup(apus_engine *e)
 {
     const uint32_t fm = sync_mask(e);
-    if (!fm) return 0;
-    hipLaunchKernelGGL(k_catchup, dim3(64, popc(fm)), dim3(256), 0, e->stream, e->d, fm);
+    if (!fm || !e->lag_possible) return 0;      /* small lags are handled inside k_sequence / k_control_round */
+    hipLaunchKernelGGL(k_catchup, dim3(128, popc(fm)), dim3(256), 0, e->stream, e->d, fm);
     HIPCHK(hipGetLastError());
+    e->lag_possible = false;
     return 0;
 }
 
@@ -295,8 +298,8 @@ static int launch_append(apus_engine *e, const EngDev &view, uint64_t r0, uint32
     int rc;
     const uint32_t fm = sync_mask(e);
     if ((rc = launch_catchup(e))) return rc;
-    hipLaunchKernelGGL(k_sequence, dim3(1), dim3(1024), 0, e->stream, view, r0, R, fm);
-    hipLaunchKernelGGL(k_append_push, dim3((R + 3) / 4), dim3(256), 0, e->stream, view, r0, R, fm);
+    hipLaunchKernelGGL(k_sequence, dim3((R + 255) / 256), dim3(256), 0, e->stream, view, r0, R, fm);
+    hipLaunchKernelGGL(k_append_push, dim3(R), dim3(256), 0, e->stream, view, r0, R, fm);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -311,7 +314,7 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
     const uint64_t n = e->h_round_first[r0 + R] - e->h_round_first[r0];
     const uint32_t fm = sync_mask(e);
     if ((rc = launch_catchup(e))) return rc;
-    hipLaunchKernelGGL(k_sequence, dim3(1), dim3(1024), 0, e->stream, e->d, r0, R, fm);
+    hipLaunchKernelGGL(k_sequence, dim3((R + 255) / 256), dim3(256), 0, e->stream, e->d, r0, R, fm);
     TimedLaunch *tl = nullptr;
     if (e->timing && !e->capturing) {
         if (e->timed_used == e->timed.size()) {
@@ -322,7 +325,7 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
         tl = &e->timed[e->timed_used++];
         HIPCHK(hipEventRecord(tl->a, e->stream));
     }
-    hipLaunchKernelGGL(k_append_push, dim3((R + 3) / 4), dim3(256), 0, e->stream, e->d, r0, R, fm);
+    hipLaunchKernelGGL(k_append_push, dim3(R), dim3(256), 0, e->stream, e->d, r0, R, fm);
     if (tl) HIPCHK(hipEventRecord(tl->b, e->stream));
     HIPCHK(hipGetLastError());
     return launch_tail(e, r0, R, 0, n);
@@ -406,14 +409,21 @@ extern "C" int apus_gpu_submit(apus_engine_t *e, const apus_req_t *reqs, uint32_
     return apus_gpu_commit_live(e, 0);
 }
 
+static int launch_control_round(apus_engine *e, int mode, uint32_t type, uint64_t d0, uint64_t d1)
+{
+    int rc = launch_catchup(e);
+    if (rc) return rc;
+    const uint32_t fm = sync_mask(e);
+    hipLaunchKernelGGL(k_control_round, dim3(1), dim3(256), 0, e->stream, e->d, mode, type, d0, d1, fm, fm);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int apus_gpu_quiesce(apus_engine_t *e)
 {
     int rc = need_leader(e);
     if (rc) return rc;
-    if ((rc = launch_catchup(e))) return rc;
-    hipLaunchKernelGGL(k_sequence, dim3(1), dim3(1024), 0, e->stream, e->d, (uint64_t)0, 0u, sync_mask(e));
-    HIPCHK(hipGetLastError());
-    return launch_tail(e, 0, 0, 2, 4096);
+    return launch_control_round(e, 2, 0, 0, 0);
 }
 
 extern "C" int apus_gpu_append_control(apus_engine_t *e, uint8_t type, const void *data)
@@ -424,21 +434,17 @@ extern "C" int apus_gpu_append_control(apus_engine_t *e, uint8_t type, const voi
     if (type == APUS_CONFIG) { if (!data) return APUS_E_ARG; memcpy(&d0, data, 8); memcpy(&d1, (const uint8_t *)data + 8, 8); }
     else if (type == APUS_HEAD) { if (!data) return APUS_E_ARG; memcpy(&d0, data, 8); }
     else if (type != APUS_NOOP) return APUS_E_ARG;
-    if ((rc = launch_catchup(e))) return rc;
-    hipLaunchKernelGGL(k_control_append, dim3(1), dim3(64), 0, e->stream, e->d, 0, (uint32_t)type, d0, d1,
-                       sync_mask(e), 0u);
-    HIPCHK(hipGetLastError());
-    return launch_tail(e, 0, 0, 1, 1);
+    return launch_control_round(e, 0, type, d0, d1);
 }
 
+/* log_pruning timer tick.  The reference's timer fires between polling() passes,
+ * i.e. with every reachable follower caught up; the pipeline above leaves them
+ * caught up after every call, so no separate quiesce pass is needed. */
 extern "C" int apus_gpu_tick_prune(apus_engine_t *e)
 {
-    int rc = apus_gpu_quiesce(e);       /* the timer fires between polling() passes */
+    int rc = need_leader(e);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_control_append, dim3(1), dim3(64), 0, e->stream, e->d, 1, (uint32_t)APUS_HEAD,
-                       (uint64_t)0, (uint64_t)0, sync_mask(e), sync_mask(e));
-    HIPCHK(hipGetLastError());
-    return launch_tail(e, 0, 0, 1, 1);
+    return launch_control_round(e, 1, APUS_HEAD, 0, 0);
 }
 
 __global__ void k_set_roles(const EngDev E, uint64_t sid, uint32_t bitmask, uint32_t follow_mask)
@@ -475,6 +481,7 @@ extern "C" int apus_gpu_become_leader(apus_engine_t *e, uint32_t leader, uint64_
 extern "C" int apus_gpu_set_reachable(apus_engine_t *e, uint32_t mask)
 {
     if (!e) return APUS_E_ARG;
+    if (mask & ~e->reachable) e->lag_possible = true;     /* somebody was released */
     e->reachable = mask;
     e->d.reachable = mask;
     return 0;

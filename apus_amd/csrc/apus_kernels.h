@@ -93,95 +93,146 @@ __device__ static inline uint4 payload_unit(const uint8_t *src, uint32_t so, uin
 }
 
 /* ------------------------------------------------------------------------- */
-/* k_catchup: followers whose log is behind the leader's (released after a HOLD,
- * or left one round behind by an exact-fit wrap) get [end_f, end_L) and the
- * matching directory slots.  grid.y = follower ordinal in fmask.             */
-__global__ __launch_bounds__(256) void k_catchup(const EngDev E, uint32_t fmask)
+/* R1 for a follower whose log is behind the leader's (released after a HOLD, or
+ * left one round behind by an exact-fit wrap): copy [end_f, end_l) and the
+ * matching directory slots (update_remote_logs step I, dare_ibv_rc.c:1507-1547;
+ * a wrapped range is two pieces, :1538-1545).  Cooperative over (tid, nth).   */
+__device__ static inline void catchup_range(const EngDev &E, int f, uint64_t end_l, uint64_t n_l,
+                                            uint64_t tid, uint64_t nth)
 {
-    /* pick the follower of this grid row */
-    int f = -1;
-    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
-        if (fmask & (1u << i)) { if (k == (int)blockIdx.y) { f = i; break; } k++; }
-    if (f < 0) return;
     const RepDev &Ld = E.rep[E.leader];
     const RepDev &Fd = E.rep[f];
     const uint64_t L = E.log_len;
-    const uint64_t end_l = Ld.hdr[H_END], end_f = Fd.hdr[H_END];
-    const uint64_t n_l = Ld.hdr[H_N_END], n_f = Fd.hdr[H_N_END];
+    const uint64_t end_f = Fd.hdr[H_END];
+    const uint64_t n_f = Fd.hdr[H_N_END];
     if (n_f >= n_l || end_l == L) return;            /* in sync, or nothing visible yet */
-    /* directory slots */
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t s = n_f + tid; s < n_l; s += nth) {
         const uint32_t i = (uint32_t)s & E.dir_mask;
         Fd.dir_off[i] = Ld.dir_off[i];
         Fd.dir_len[i] = Ld.dir_len[i];
     }
-    /* ring bytes, at the same offsets; a wrapped range is two pieces (dare_ibv_rc.c:1538-1545) */
-    uint64_t from = (end_f == L) ? 0 : end_f;
-    uint64_t seg0_from = from, seg0_to, seg1_to = 0;
-    if (end_l > from || (end_f == L)) { seg0_to = end_l; }
+    const uint64_t from = (end_f == L) ? 0 : end_f;
+    uint64_t seg0_to, seg1_to = 0;
+    if (end_l > from || end_f == L) seg0_to = end_l;
     else { seg0_to = L; seg1_to = end_l; }
     for (int seg = 0; seg < 2; seg++) {
-        const uint64_t a = seg ? 0 : seg0_from, b = seg ? seg1_to : seg0_to;
+        const uint64_t a = seg ? 0 : from, b = seg ? seg1_to : seg0_to;
         if (b <= a) continue;
-        /* 16-byte units on the destination alignment of `a`; the tail is byte-wise */
         const uint64_t nunit = (b - a) / 16;
         for (uint64_t u = tid; u < nunit; u += nth) st16u(Fd.ring + a + 16 * u, ld16u(Ld.ring + a + 16 * u));
         for (uint64_t x = a + 16 * nunit + tid; x < b; x += nth) Fd.ring[x] = Ld.ring[x];
     }
 }
 
-/* ------------------------------------------------------------------------- */
-/* k_sequence: one workgroup.  Computes where every entry of rounds
- * [r0, r0+R) goes.  Round sizes come from the staged partition.             */
-__global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask)
+/* k_catchup: wide version, launched by the host when it knows a follower may lag
+ * by a lot (RELEASE after a HOLD).  grid.y = follower ordinal in fmask.        */
+__global__ __launch_bounds__(256) void k_catchup(const EngDev E, uint32_t fmask)
 {
-    __shared__ uint64_t s_wave_tot[16];
-    __shared__ uint64_t s_carry;
-    __shared__ unsigned int s_rstar;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int f = -1;
+    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
+        if (fmask & (1u << i)) { if (k == (int)blockIdx.y) { f = i; break; } k++; }
+    if (f < 0) return;
+    const uint64_t *lh = E.rep[E.leader].hdr;
+    catchup_range(E, f, lh[H_END], lh[H_N_END], (uint64_t)blockIdx.x * blockDim.x + threadIdx.x,
+                  (uint64_t)gridDim.x * blockDim.x);
+}
+
+/* block-wide inclusive scan of one u64 per thread (256 threads), returns the
+ * inclusive value; *total gets the block sum                                  */
+__device__ static inline uint64_t block_incl_scan256(uint64_t v, uint64_t *s_tot /*[4]*/, uint64_t *total)
+{
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    uint64_t incl = wave_incl_scan(v);
+    __syncthreads();
+    if (lane == WAVE - 1) s_tot[wv] = incl;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+    for (uint32_t w = 0; w < 4; w++) { if (w < wv) base += s_tot[w]; tot += s_tot[w]; }
+    *total = tot;
+    return base + incl;
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_sequence: where every entry of rounds [r0, r0+R) goes.
+ * Phase A (all blocks, one thread per round): bytes of the round.
+ * Phase B (the block that arrives last): exclusive scan over the rounds, the wrap
+ * point, the leader's control words and the per-round end record.            */
+__global__ __launch_bounds__(256) void k_sequence(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask)
+{
+    __shared__ uint64_t s_tot[4];
+    __shared__ unsigned int s_last, s_rstar;
+    __shared__ int64_t s_kstar;
+    __shared__ uint64_t s_w;
+    const uint32_t tid = threadIdx.x;
     const RepDev &Ld = E.rep[E.leader];
     uint64_t *hdr = Ld.hdr;
     const uint64_t L = E.log_len;
-    const uint64_t e0 = hdr[H_END];
     const uint32_t *rf = E.round_first + r0;
-    const uint32_t g0 = rf[0];
-    const uint32_t n = rf[R] - g0;
-    if (tid == 0) { s_carry = 0; s_rstar = 0xFFFFFFFFu; }
-    __syncthreads();
 
-    /* pass 1: bytes per round, exclusive scan into round_virt[0..R] */
-    for (uint32_t base = 0; base < R; base += 1024) {
-        const uint32_t r = base + tid;
-        uint64_t bytes = 0;
+    /* phase A */
+    {
+        const uint32_t r = blockIdx.x * blockDim.x + tid;
         if (r < R) {
             const uint32_t a = rf[r], b = rf[r + 1];
-            for (uint32_t g = a; g < b; g++) bytes += APUS_HDR + E.req_len[g];
+            uint64_t bytes = (uint64_t)APUS_HDR * (b - a);
+            uint32_t g = a;
+            for (; g + 8 <= b; g += 8) {              /* 8 lens per 16-byte load */
+                const uint4 v = ld16u((const uint8_t *)(E.req_len + g));
+                bytes += (v.x & 0xFFFF) + (v.x >> 16) + (v.y & 0xFFFF) + (v.y >> 16)
+                       + (v.z & 0xFFFF) + (v.z >> 16) + (v.w & 0xFFFF) + (v.w >> 16);
+            }
+            for (; g < b; g++) bytes += E.req_len[g];
+            E.round_virt[r] = bytes;
         }
-        uint64_t incl = wave_incl_scan(bytes);
-        if (lane == 63) s_wave_tot[wv] = incl;
-        __syncthreads();
-        uint64_t wbase = 0;
-        for (uint32_t w = 0; w < wv; w++) wbase += s_wave_tot[w];
-        const uint64_t carry = s_carry;
-        if (r < R) E.round_virt[r] = carry + wbase + incl - bytes;
-        __syncthreads();
-        if (tid == 1023) s_carry = carry + wbase + incl;
-        __syncthreads();
     }
-    if (tid == 0) E.round_virt[R] = s_carry;
     __syncthreads();
-    const uint64_t vtot = s_carry;
+    if (tid == 0) {
+        __threadfence();                               /* release the round sums (agent scope) */
+        const unsigned int t = atomicAdd(E.ticket, 1u);
+        s_last = (t == gridDim.x - 1);
+        if (s_last) { *E.ticket = 0; __threadfence(); }   /* acquire the other blocks' sums */
+    }
+    __syncthreads();
+    if (!s_last) return;
 
-    /* pass 2: the first round that does not fit before len */
-    for (uint32_t r = tid; r < R; r += 1024)
-        if (e0 + E.round_virt[r + 1] > L) atomicMin(&s_rstar, r);
+    /* phase B: this block is alone now */
+    const uint64_t e0 = hdr[H_END];
+    const uint64_t n_end0 = hdr[H_N_END];
+    const uint32_t g0 = rf[0];
+    const uint32_t n = rf[R] - g0;
+
+    /* followers that silently fell one round behind (exact-fit wrap) are caught up here */
+    for (uint32_t m = push_mask; m; m &= m - 1) {
+        const int f = __builtin_ctz(m);
+        catchup_range(E, f, e0, n_end0, tid, blockDim.x);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        s_rstar = 0xFFFFFFFFu;
+        for (uint32_t m = push_mask; m; m &= m - 1) {
+            uint64_t *fh = E.rep[__builtin_ctz(m)].hdr;
+            if (fh[H_N_END] < n_end0 && e0 != L) { fh[H_END] = e0; fh[H_N_END] = n_end0; }
+        }
+    }
+
+    /* exclusive scan of the round sums, in place */
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < R; base += 256) {
+        const uint32_t r = base + tid;
+        const uint64_t bytes = (r < R) ? E.round_virt[r] : 0;
+        uint64_t tot;
+        const uint64_t incl = block_incl_scan256(bytes, s_tot, &tot);
+        if (r < R) {
+            E.round_virt[r] = carry + incl - bytes;
+            if (e0 + carry + incl > L) atomicMin(&s_rstar, r);   /* first round that does not fit before len */
+        }
+        carry += tot;
+    }
+    const uint64_t vtot = carry;
+    if (tid == 0) E.round_virt[R] = vtot;
     __syncthreads();
     const uint32_t rstar = s_rstar;
 
-    __shared__ int64_t s_kstar, s_estar;
-    __shared__ uint64_t s_w, s_end_new;
     if (tid == 0) {
         int64_t kstar = -1, estar = -1;
         uint64_t w = 0;
@@ -207,10 +258,9 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
             const uint64_t head = hdr[H_HEAD];
             const uint64_t used = (e0 == L) ? 0 : (e0 >= head ? e0 - head : L - (head - e0));
             const uint64_t waste = (kstar >= 0) ? L - w : 0;
-            if (n && vtot + waste >= L - used && !(e0 == L)) set_status(E, 1u << 1);
+            if (n && e0 != L && vtot + waste >= L - used) set_status(E, 1u << 1);
             if (n && e0 == L && vtot > L) set_status(E, 1u << 1);
         }
-        const uint64_t n_end0 = hdr[H_N_END];
         const uint64_t idx0 = hdr[H_LAST_IDX] + 1;
         SeqOut s;
         s.e0 = e0; s.idx0 = idx0; s.w = w; s.n_end0 = n_end0;
@@ -232,22 +282,15 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
             hdr[H_N_PERSIST] = n_end0 + n;
             hdr[H_STORE_COUNT] += n;
         }
-        s_kstar = kstar; s_estar = estar; s_w = w; s_end_new = end_new;
-        /* followers in push_mask are in sync with the pre-batch leader state by now
-         * (k_catchup ran before us) */
-        for (int f = 0; f < APUS_DEV_MAX_SERVERS; f++)
-            if ((push_mask >> f) & 1u) {
-                uint64_t *fh = E.rep[f].hdr;
-                if (fh[H_N_END] < n_end0 && e0 != L) { fh[H_END] = e0; fh[H_N_END] = n_end0; }
-            }
+        s_kstar = kstar; s_w = w;
     }
     __syncthreads();
 
-    /* pass 3: end offset after every round (the leader's per-round record) */
+    /* end offset after every round (the leader's per-round record) */
     const uint64_t rec_base = *E.rec_count;
     const int64_t kstar = s_kstar;
     const uint64_t w = s_w;
-    for (uint32_t r = tid; r < R; r += 1024) {
+    for (uint32_t r = tid; r < R; r += 256) {
         const uint64_t a_end = e0 + E.round_virt[r + 1];
         const int64_t last = (int64_t)(rf[r + 1] - g0) - 1;   /* batch index of the round's last entry */
         const uint64_t end_r = (kstar < 0 || last < kstar) ? a_end : a_end - w;
@@ -256,8 +299,10 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
 }
 
 /* ------------------------------------------------------------------------- */
-/* k_append_push: one wavefront per round, one lane per entry for the header /
- * offset work, all 64 lanes over the round's 16-byte units for the copy.     */
+/* k_append_push: one workgroup per round.  Wave 0: one lane per entry (offset
+ * scan, index, header words, directory).  All 256 threads: the round's bytes as
+ * 16-byte units, each stored to the leader ring and to every in-sync follower
+ * ring at the same offset, so that the payload is read from HBM once.          */
 struct AppendLds {
     uint64_t pos[WAVE];
     uint64_t src[WAVE];
@@ -265,83 +310,88 @@ struct AppendLds {
     uint32_t ubase[WAVE + 1];
     uint4    h0[WAVE];
     uint4    h1[WAVE];
+    uint32_t uniform_nu;      /* units per entry when every entry of the round has the same size, else 0 */
 };
 
 __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask)
 {
-    __shared__ AppendLds lds_all[4];
-    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint32_t r = blockIdx.x * 4 + wv;
-    if (r >= R) return;
-    AppendLds &lds = lds_all[wv];
-    const SeqOut s = *E.seq;
+    __shared__ AppendLds lds;
+    const uint32_t tid = threadIdx.x, lane = lane_id();
+    const uint32_t r = blockIdx.x;
     const RepDev &Ld = E.rep[E.leader];
     const uint32_t *rf = E.round_first + r0;
     const uint32_t g0 = rf[0];
     const uint32_t first = rf[r] - g0, nr = rf[r + 1] - rf[r];
-    const bool active = lane < nr;
-    const uint32_t g = g0 + first + lane;
 
-    ReqDev d; d.req_id = 0; d.pay16_type = 0; d.len = 0; d.clt_id = 0;
-    if (active) d = E.req[g];
-    const uint32_t T = active ? APUS_HDR + d.len : 0;
-    const uint64_t incl = wave_incl_scan((uint64_t)T);
-    const uint64_t a = s.e0 + E.round_virt[r] + incl - T;
-    const int64_t gk = (int64_t)first + lane;
-    const uint64_t pos = apus_place(s, gk, a);
-    const uint64_t idx = apus_entry_idx(s, gk);
-    const uint64_t slot = s.n_end0 + (uint64_t)gk;
-    const uint32_t nu = active ? (T + 15) / 16 : 0;
-    const uint32_t uincl = wave_incl_scan(nu);
-    const uint32_t utotal = __shfl(uincl, WAVE - 1, WAVE);
-    const uint32_t type = d.pay16_type >> 28;
+    if (tid < WAVE) {
+        const SeqOut s = *E.seq;
+        const bool active = lane < nr;
+        const uint32_t g = g0 + first + lane;
+        ReqDev d; d.req_id = 0; d.pay16_type = 0; d.len = 0; d.clt_id = 0;
+        if (active) d = E.req[g];
+        const uint32_t T = active ? APUS_HDR + d.len : 0;
+        const uint64_t incl = wave_incl_scan((uint64_t)T);
+        const uint64_t a = s.e0 + E.round_virt[r] + incl - T;
+        const int64_t gk = (int64_t)first + lane;
+        const uint64_t pos = apus_place(s, gk, a);
+        const uint64_t idx = apus_entry_idx(s, gk);
+        const uint64_t slot = s.n_end0 + (uint64_t)gk;
+        const uint32_t nu = active ? (T + 15) / 16 : 0;
+        const uint32_t uincl = wave_incl_scan(nu);
+        const uint32_t type = d.pay16_type >> 28;
+        const uint32_t T0 = __shfl(T, 0, WAVE);
+        const bool uni = __all(!active || T == T0);
 
-    const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)s.term, (uint32_t)(s.term >> 32));
-    /* bytes 16..31: req_id, clt_id, type, sender (= leader: persist_new_entries), reply[0..3] = 0 */
-    const uint4 h1 = make_uint4((uint32_t)d.req_id, (uint32_t)(d.req_id >> 32),
-                                (uint32_t)d.clt_id | (type << 16) | ((uint32_t)E.leader << 24), 0);
-    lds.pos[lane] = pos;
-    lds.src[lane] = (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
-    lds.T[lane] = T;
-    lds.ubase[lane] = uincl - nu;
-    if (lane == WAVE - 1) lds.ubase[WAVE] = uincl;
-    lds.h0[lane] = h0;
-    lds.h1[lane] = h1;
+        const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)s.term, (uint32_t)(s.term >> 32));
+        /* bytes 16..31: req_id, clt_id, type, sender (= leader: persist_new_entries), reply[0..3] = 0 */
+        const uint4 h1 = make_uint4((uint32_t)d.req_id, (uint32_t)(d.req_id >> 32),
+                                    (uint32_t)d.clt_id | (type << 16) | ((uint32_t)E.leader << 24), 0);
+        lds.pos[lane] = pos;
+        lds.src[lane] = (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
+        lds.T[lane] = T;
+        lds.ubase[lane] = uincl - nu;
+        if (lane == WAVE - 1) { lds.ubase[WAVE] = uincl; lds.uniform_nu = uni ? (T0 + 15) / 16 : 0; }
+        lds.h0[lane] = h0;
+        lds.h1[lane] = h1;
 
-    /* targets: the leader ring, then every in-sync follower ring (R1, same offsets) */
-    if (active) {
-        const uint32_t di = (uint32_t)slot & E.dir_mask;
-        Ld.dir_off[di] = pos; Ld.dir_len[di] = T; Ld.ack[di] = 0;
-        for (uint32_t m = push_mask; m; m &= m - 1) {
-            const RepDev &Fd = E.rep[__builtin_ctz(m)];
-            Fd.dir_off[di] = pos; Fd.dir_len[di] = T;
-        }
-        if (s.stale && gk == s.kstar) {
-            /* the header that log_append_entry wrote before it found out that the
-             * payload does not fit (dare_log.h:497-504, 521-523); readers use it to
-             * detect the wrap (log_fit_entry) */
-            const uint4 z = make_uint4(0, 0, 0, 0);
-            const uint4 l = make_uint4((uint32_t)d.len, 0, 0, 0);
-            for (uint32_t m = push_mask | (1u << E.leader); m; m &= m - 1) {
-                uint8_t *rg = E.rep[__builtin_ctz(m)].ring;
-                st16u(rg + a, h0); st16u(rg + a + 16, h1);
-                st16u(rg + a + 32, z); st16u(rg + a + 48, l);
+        if (active) {
+            const uint32_t di = (uint32_t)slot & E.dir_mask;
+            Ld.dir_off[di] = pos; Ld.dir_len[di] = T; Ld.ack[di] = 0;
+            for (uint32_t m = push_mask; m; m &= m - 1) {
+                const RepDev &Fd = E.rep[__builtin_ctz(m)];
+                Fd.dir_off[di] = pos; Fd.dir_len[di] = T;
+            }
+            if (s.stale && gk == s.kstar) {
+                /* the header that log_append_entry wrote before it found out that the
+                 * payload does not fit (dare_log.h:497-504, 521-523); readers use it to
+                 * detect the wrap (log_fit_entry) */
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                const uint4 l = make_uint4((uint32_t)d.len, 0, 0, 0);
+                for (uint32_t m = push_mask | (1u << E.leader); m; m &= m - 1) {
+                    uint8_t *rg = E.rep[__builtin_ctz(m)].ring;
+                    st16u(rg + a, h0); st16u(rg + a + 16, h1);
+                    st16u(rg + a + 32, z); st16u(rg + a + 48, l);
+                }
             }
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __syncthreads();
 
-    for (uint32_t u = lane; u < utotal; u += WAVE) {
-        /* which entry owns unit u: largest e with ubase[e] <= u */
-        uint32_t lo = 0, hi = nr - 1;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1) >> 1;
-            if (lds.ubase[mid] <= u) lo = mid; else hi = mid - 1;
+    const uint32_t utotal = lds.ubase[WAVE];
+    const uint32_t unu = lds.uniform_nu;
+    for (uint32_t u = tid; u < utotal; u += 256) {
+        uint32_t e, j;
+        if (unu) { e = u / unu; j = u - e * unu; }
+        else {
+            /* which entry owns unit u: largest e with ubase[e] <= u */
+            uint32_t lo = 0, hi = nr - 1;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (lds.ubase[mid] <= u) lo = mid; else hi = mid - 1;
+            }
+            e = lo; j = u - lds.ubase[e];
         }
-        const uint32_t e = lo;
         const uint32_t Te = lds.T[e];
-        const uint32_t j = u - lds.ubase[e];
         const uint32_t so = min(16u * j, Te - 16u);
         uint4 v;
         if (so == 0) v = lds.h0[e];
@@ -351,94 +401,6 @@ __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0
         const uint64_t p = lds.pos[e] + so;
         st16u(Ld.ring + p, v);
         for (uint32_t m = push_mask; m; m &= m - 1) st16u(E.rep[__builtin_ctz(m)].ring + p, v);
-    }
-}
-
-/* ------------------------------------------------------------------------- */
-/* k_control_append: the leader appends one CONFIG / HEAD / NOOP entry
- * (log_append_entry, dare_log.h:466-558, 64-byte entries never hit case 2).
- * mode 0: unconditional append of (type, d0, d1).
- * mode 1: log_pruning (dare_server.c:1996-2067): decide from the apply offsets
- *         whether the head moves, append <HEAD, head> if so, then refresh the
- *         apply offsets (rc_get_remote_apply_offsets, dare_ibv_rc.c:1970).     */
-__global__ __launch_bounds__(64) void k_control_append(const EngDev E, int mode, uint32_t type,
-                                                       uint64_t d0, uint64_t d1, uint32_t push_mask,
-                                                       uint32_t sample_mask)
-{
-    if (threadIdx.x != 0) return;
-    const RepDev &Ld = E.rep[E.leader];
-    uint64_t *hdr = Ld.hdr;
-    const uint64_t L = E.log_len;
-    uint64_t end = hdr[H_END];
-    bool do_append = true;
-
-    if (mode == 1) {
-        const uint32_t size = E.group_size;
-        const uint32_t bitmask = (uint32_t)hdr[H_CID_BITMASK];
-        uint64_t min_off = hdr[H_APPLY];
-        for (uint32_t i = 0; i < size; i++) {
-            if (!((bitmask >> i) & 1u)) hdr[H_APPLY_OFFSETS + i] = hdr[H_APPLY];
-            if (apus_is_larger(end, L, min_off, hdr[H_APPLY_OFFSETS + i])) min_off = hdr[H_APPLY_OFFSETS + i];
-        }
-        if (apus_end_distance(end, L, min_off) == 0) min_off = hdr[H_TAIL];   /* leave one entry, :2038-2041 */
-        do_append = apus_is_larger(end, L, min_off, hdr[H_HEAD]) && !hdr[H_PREV_HEAD];
-        if (do_append) { hdr[H_HEAD] = min_off; d0 = min_off; type = 3; }
-    }
-
-    SeqOut s;
-    s.e0 = end; s.idx0 = hdr[H_LAST_IDX] + 1; s.w = 0; s.n_end0 = hdr[H_N_END];
-    s.term = hdr[H_SID] >> 9; s.kstar = -1; s.estar = -1; s.stale = 0; s.n = 0;
-    s.first_fail = ~0ull; s.commit_before = hdr[H_COMMIT]; s.n_commit_before = hdr[H_N_COMMIT];
-
-    if (do_append) {
-        if (end == hdr[H_HEAD] && end != L) { set_status(E, 1u << 1); do_append = false; }
-    }
-    if (do_append) {
-        uint64_t idx = (end == L) ? 1 : hdr[H_LAST_IDX] + 1;          /* dare_log.h:486-488 */
-        uint64_t pos = (end == L || L - end < APUS_HDR) ? 0 : end;   /* log_add_new_entry, :213-221 */
-        if (type != 3) hdr[H_PREV_HEAD] = 0; else if (mode == 1) hdr[H_PREV_HEAD] = 1;
-        const uint64_t term = s.term;
-        const uint64_t slot = s.n_end0;
-        const uint32_t di = (uint32_t)slot & E.dir_mask;
-        const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)term, (uint32_t)(term >> 32));
-        const uint4 h1 = make_uint4(0, 0, (type << 16) | ((uint32_t)E.leader << 24), 0);  /* req_id = clt_id = 0 */
-        const uint4 h2 = make_uint4(0, 0, 0, 0);
-        const uint4 h3 = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
-        for (int t = -1; t < APUS_DEV_MAX_SERVERS; t++) {
-            const RepDev *R = nullptr;
-            if (t < 0) R = &Ld; else if ((push_mask >> t) & 1u) R = &E.rep[t];
-            if (!R) continue;
-            st16u(R->ring + pos, h0); st16u(R->ring + pos + 16, h1);
-            st16u(R->ring + pos + 32, h2); st16u(R->ring + pos + 48, h3);
-            R->dir_off[di] = pos; R->dir_len[di] = APUS_HDR;
-            if (t < 0) R->ack[di] = 0;
-        }
-        hdr[H_TAIL] = pos;
-        hdr[H_END] = pos + APUS_HDR;
-        hdr[H_N_END] = slot + 1;
-        hdr[H_LAST_IDX] = idx;
-        hdr[H_OLD_END] = pos + APUS_HDR;
-        hdr[H_N_PERSIST] = slot + 1;
-        hdr[H_STORE_COUNT] += 1;
-        s.n = 1;
-        for (int f = 0; f < APUS_DEV_MAX_SERVERS; f++)
-            if ((push_mask >> f) & 1u) {
-                uint64_t *fh = E.rep[f].hdr;
-                if (fh[H_N_END] < slot && end != L) { fh[H_END] = end; fh[H_N_END] = slot; }
-            }
-        const uint64_t rec_base = *E.rec_count;
-        if (rec_base < E.rec_cap) E.rec_end[rec_base] = pos + APUS_HDR;
-    }
-    *E.seq = s;
-
-    if (mode == 1) {
-        /* READ the apply offset of every reachable peer for the next tick */
-        const uint32_t bitmask = (uint32_t)hdr[H_CID_BITMASK];
-        for (uint32_t i = 0; i < E.group_size; i++) {
-            if (i == E.leader || !((bitmask >> i) & 1u)) { hdr[H_APPLY_OFFSETS + i] = hdr[H_APPLY]; continue; }
-            if (!((sample_mask >> i) & 1u)) continue;
-            hdr[H_APPLY_OFFSETS + i] = E.rep[i].hdr[H_APPLY];
-        }
     }
 }
 
@@ -458,19 +420,22 @@ __device__ static inline uint64_t visible_slots(const EngDev &E, const uint64_t 
     return s.n_end0 + (rf[R - 1] - rf[0]);
 }
 
-/* k_persist_ack: one lane per new entry of one follower (grid.y = follower). */
-__global__ __launch_bounds__(256) void k_persist_ack(const EngDev E, uint64_t r0, uint32_t R, uint32_t fmask)
+/* commit slot reached by this call on the leader */
+__device__ static inline uint64_t commit_slot(const EngDev &E, uint64_t vis)
 {
-    int f = -1;
-    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
-        if (fmask & (1u << i)) { if (k == (int)blockIdx.y) { f = i; break; } k++; }
-    if (f < 0) return;
+    const uint64_t ff = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t cs = min(ff, vis);
+    if (cs < E.seq->n_commit_before) cs = E.seq->n_commit_before;
+    return cs;
+}
+
+/* follower persist_new_entries + rc_send_entries_reply (dare_server.c:1792-1810,
+ * dare_ibv_rc.c:1828-1863) for entry slots [from, vis) of follower f            */
+__device__ static inline void persist_ack_range(const EngDev &E, int f, uint64_t vis, uint64_t tid, uint64_t nth)
+{
     const RepDev &Fd = E.rep[f];
-    const RepDev &Ld = E.rep[E.leader];
-    const uint64_t vis = visible_slots(E, Ld.hdr, r0, R);
     const uint64_t from = Fd.hdr[H_N_PERSIST];
-    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t s = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < vis; s += nth) {
+    for (uint64_t s = from + tid; s < vis; s += nth) {
         const uint32_t di = (uint32_t)s & E.dir_mask;
         const uint64_t off = Fd.dir_off[di];
         /* entry->sender says whose log gets the ACK (dare_server.c:1806) */
@@ -483,134 +448,174 @@ __global__ __launch_bounds__(256) void k_persist_ack(const EngDev E, uint64_t r0
     }
 }
 
-/* k_commit: ACK words of [n_commit, visible) staged in LDS, one lane per entry. */
-__global__ __launch_bounds__(1024) void k_commit(const EngDev E, uint64_t r0, uint32_t R)
+__global__ __launch_bounds__(256) void k_persist_ack(const EngDev E, uint64_t r0, uint32_t R, uint32_t fmask)
 {
-    __shared__ uint32_t s_ack[1024];
+    int f = -1;
+    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
+        if (fmask & (1u << i)) { if (k == (int)blockIdx.y) { f = i; break; } k++; }
+    if (f < 0) return;
+    const uint64_t vis = visible_slots(E, E.rep[E.leader].hdr, r0, R);
+    persist_ack_range(E, f, vis, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+}
+
+/* The ACK scan of update_remote_logs (dare_ibv_rc.c:1725-1758) over slots
+ * [from, vis): ACK words staged in LDS, one lane per entry,
+ * popcount(ack | self) >= size/2+1, wave ballot, first slot without a majority.
+ * Must be called by all threads of the block (tile0 / tile_stride in slots).    */
+__device__ static inline void commit_scan(const EngDev &E, uint64_t from, uint64_t vis, uint64_t tile0,
+                                          uint64_t tile_stride, uint32_t *s_ack)
+{
     const RepDev &Ld = E.rep[E.leader];
-    const uint64_t vis = visible_slots(E, Ld.hdr, r0, R);
-    const uint64_t from = Ld.hdr[H_N_COMMIT];
     const uint32_t size = E.group_size;                          /* cid.size[0], dare_ibv_rc.c:1656 */
     const uint32_t size_mask = (1u << size) - 1;
-    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t tile = from + (uint64_t)blockIdx.x * blockDim.x; tile < vis; tile += nth) {
+    for (uint64_t tile = from + tile0; tile < vis; tile += tile_stride) {
         const uint64_t s = tile + threadIdx.x;
         const bool in = s < vis;
         __syncthreads();
-        s_ack[threadIdx.x] = in ? Ld.ack[(uint32_t)s & E.dir_mask] : 0xFFFFFFFFu;
+        s_ack[threadIdx.x] = in ? __hip_atomic_load(&Ld.ack[(uint32_t)s & E.dir_mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : 0xFFFFFFFFu;
         __syncthreads();
         const uint32_t m = (s_ack[threadIdx.x] | (1u << E.leader)) & size_mask;
         const bool ok = !in || (uint32_t)__popc(m) >= size / 2 + 1;  /* replies >= size/2+1, :1738 */
         const unsigned long long bal = __ballot(!ok);
         if (bal && lane_id() == 0) {
-            const uint64_t first = s + (uint64_t)__builtin_ctzll(bal);
+            const uint64_t first = (s - 0) + (uint64_t)__builtin_ctzll(bal);
             atomicMin((unsigned long long *)&E.seq->first_fail, (unsigned long long)first);
         }
     }
 }
 
-/* commit slot reached by this call on the leader */
-__device__ static inline uint64_t commit_slot(const EngDev &E, const uint64_t *lhdr, uint64_t r0, uint32_t R)
+__global__ __launch_bounds__(1024) void k_commit(const EngDev E, uint64_t r0, uint32_t R)
 {
-    const uint64_t vis = visible_slots(E, lhdr, r0, R);
-    uint64_t cs = min((uint64_t)E.seq->first_fail, vis);
-    if (cs < E.seq->n_commit_before) cs = E.seq->n_commit_before;
-    return cs;
+    __shared__ uint32_t s_ack[1024];
+    const uint64_t *lh = E.rep[E.leader].hdr;
+    const uint64_t vis = visible_slots(E, lh, r0, R);
+    commit_scan(E, lh[H_N_COMMIT], vis, (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_ack);
 }
 
-/* k_apply: one lane per committed-and-not-applied entry (grid.y = replica).   */
+/* apply_committed_entries (dare_server.c:1815-1974) for slots [from, cs) of
+ * replica p: apply-stream records, HEAD adoption candidates; block-reduced
+ * counters.  Must be called by all threads of the block.                        */
+__device__ static inline void apply_range(const EngDev &E, int p, uint64_t cs, uint64_t tile0, uint64_t tile_stride,
+                                          unsigned long long *s_acc /*[2]*/)
+{
+    const RepDev &Pd = E.rep[p];
+    const bool leader = (uint32_t)p == E.leader;
+    const uint64_t from = Pd.hdr[H_N_APPLY];
+    if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t tile = from + tile0; tile < cs; tile += tile_stride) {
+        const uint64_t s = tile + threadIdx.x;
+        const bool in = s < cs;
+        uint64_t mix = 0;
+        uint32_t client = 0;
+        if (in) {
+            const uint32_t di = (uint32_t)s & E.dir_mask;
+            const uint64_t off = Pd.dir_off[di];
+            const uint32_t T = Pd.dir_len[di];
+            const uint4 u0 = ld16u(Pd.ring + off);
+            const uint4 u1 = ld16u(Pd.ring + off + 16);
+            const uint64_t idx = (uint64_t)u0.x | ((uint64_t)u0.y << 32);
+            const uint32_t type = (u1.z >> 16) & 0xFF;
+            const uint16_t clt = (uint16_t)(u1.z & 0xFFFF);
+            client = (type != 0 && type != 2 && type != 3);
+            apus_apply_rec rec;
+            rec.slot = s; rec.off = off; rec.idx = idx; rec.len = T - APUS_HDR;
+            rec.clt_id = clt; rec.type = (uint8_t)type;
+            rec.kind = client ? (leader ? 1 : 2) : 0;
+            Pd.apply[di] = rec;
+            if (client) mix = apus_apply_mix(s, off, idx, T - APUS_HDR, clt, (uint8_t)type, rec.kind);
+            if (type == 3 && !leader)                  /* poll_config_entries: committed HEAD, dare_server.c:2164 */
+                atomicMax((unsigned long long *)&Pd.hdr[H_HEAD_SLOT], (unsigned long long)(s + 1));
+        }
+        const uint64_t wsum = wave_sum(mix);
+        const uint32_t wcnt = (uint32_t)__popcll(__ballot(client != 0));
+        if (lane_id() == 0 && wcnt) {
+            atomicAdd(&s_acc[0], (unsigned long long)wsum);
+            atomicAdd(&s_acc[1], (unsigned long long)wcnt);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_acc[1]) {
+        atomicAdd((unsigned long long *)&Pd.hdr[H_APPLY_HASH], s_acc[0]);
+        atomicAdd((unsigned long long *)&Pd.hdr[H_APPLY_COUNT], s_acc[1]);
+        if (leader) atomicAdd((unsigned long long *)&Pd.hdr[H_HIGHEST_REC], s_acc[1]);
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint32_t R, uint32_t rmask)
 {
+    __shared__ unsigned long long s_acc[2];
     int p = -1;
     for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
         if (rmask & (1u << i)) { if (k == (int)blockIdx.y) { p = i; break; } k++; }
     if (p < 0) return;
-    const RepDev &Pd = E.rep[p];
-    const RepDev &Ld = E.rep[E.leader];
-    const bool leader = (uint32_t)p == E.leader;
-    const uint64_t cs = commit_slot(E, Ld.hdr, r0, R);
-    const uint64_t from = Pd.hdr[H_N_APPLY];
-    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t tile = from + (uint64_t)blockIdx.x * blockDim.x; tile < cs; tile += nth) {
-    const uint64_t s = tile + threadIdx.x;
-    const bool in = s < cs;
-    uint64_t mix = 0;
-    uint32_t client = 0;
-    if (in) {
-        const uint32_t di = (uint32_t)s & E.dir_mask;
-        const uint64_t off = Pd.dir_off[di];
-        const uint32_t T = Pd.dir_len[di];
-        const uint4 u0 = ld16u(Pd.ring + off);
-        const uint4 u1 = ld16u(Pd.ring + off + 16);
-        const uint64_t idx = (uint64_t)u0.x | ((uint64_t)u0.y << 32);
-        const uint32_t type = (u1.z >> 16) & 0xFF;
-        const uint16_t clt = (uint16_t)(u1.z & 0xFFFF);
-        client = (type != 0 && type != 2 && type != 3);
-        apus_apply_rec rec;
-        rec.slot = s; rec.off = off; rec.idx = idx; rec.len = T - APUS_HDR;
-        rec.clt_id = clt; rec.type = (uint8_t)type;
-        rec.kind = client ? (leader ? 1 : 2) : 0;
-        Pd.apply[di] = rec;
-        if (client) mix = apus_apply_mix(s, off, idx, T - APUS_HDR, clt, (uint8_t)type, rec.kind);
-        if (type == 3 && !leader)                      /* poll_config_entries: committed HEAD, dare_server.c:2164 */
-            atomicMax((unsigned long long *)&Pd.hdr[H_HEAD_SLOT], (unsigned long long)(s + 1));
-    }
-    const uint64_t wsum = wave_sum(mix);
-    const uint32_t wcnt = (uint32_t)__popcll(__ballot(client != 0));
-    if (lane_id() == 0 && wcnt) {
-        atomicAdd((unsigned long long *)&Pd.hdr[H_APPLY_HASH], (unsigned long long)wsum);
-        atomicAdd((unsigned long long *)&Pd.hdr[H_APPLY_COUNT], (unsigned long long)wcnt);
-        if (leader) atomicAdd((unsigned long long *)&Pd.hdr[H_HIGHEST_REC], (unsigned long long)wcnt);
-    }
-    }
+    const uint64_t vis = visible_slots(E, E.rep[E.leader].hdr, r0, R);
+    apply_range(E, p, commit_slot(E, vis), (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_acc);
 }
 
-/* k_finish: scalar bookkeeping of the call.  mode 0: R staged rounds; mode 1:
- * one control-entry round (s.n tells whether it happened); mode 2: quiesce.   */
-__global__ __launch_bounds__(64) void k_finish(const EngDev E, uint64_t r0, uint32_t R, int mode, uint32_t fmask)
+/* Scalar bookkeeping of a call (all threads of one block).  mode 0: R staged
+ * rounds; mode 1: one control-entry round (s.n tells whether it happened);
+ * mode 2: quiesce.                                                              */
+__device__ static inline void finish_call(const EngDev &E, uint64_t r0, uint32_t R, int mode, uint32_t fmask)
 {
     const RepDev &Ld = E.rep[E.leader];
     uint64_t *lh = Ld.hdr;
     const uint64_t L = E.log_len;
     const SeqOut s = *E.seq;
     const uint64_t vis = visible_slots(E, lh, r0, R);
-    const uint64_t cs = commit_slot(E, lh, r0, R);
+    const uint64_t cs = commit_slot(E, vis);
     const uint64_t end_l = lh[H_END];
+    const uint64_t n_end_l = lh[H_N_END];
     /* byte offset that corresponds to a slot boundary b (<= n_end) */
     auto slot_off = [&](uint64_t b) -> uint64_t {
-        if (b == lh[H_N_END]) return end_l;
+        if (b == n_end_l) return end_l;
         return Ld.dir_off[(uint32_t)b & E.dir_mask];
     };
     const uint64_t commit_off = (cs > s.n_commit_before) ? slot_off(cs) : s.commit_before;
     const uint64_t vis_off = slot_off(vis);
-    const uint32_t lane = threadIdx.x;
-
-    /* per-round record */
+    const uint64_t apply_l = lh[H_N_APPLY];
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
     const uint64_t rec_base = *E.rec_count;
+    __syncthreads();                                  /* everybody sampled the control words */
+
     if (mode == 0) {
         const uint32_t *rf = E.round_first + r0;
-        for (uint32_t r = lane; r < R; r += WAVE) {
+        for (uint32_t r = tid; r < R; r += nth) {
             if (rec_base + r >= E.rec_cap) break;
             const uint64_t slot_end_r = s.n_end0 + (rf[r + 1] - rf[0]);
+            const uint64_t slot_start_r = s.n_end0 + (rf[r] - rf[0]);
             const uint64_t c = min(cs, slot_end_r);
+            const uint64_t end_r = E.rec_end[rec_base + r];
             uint64_t cr;
             if (c <= s.n_commit_before) cr = s.commit_before;
-            else if (c == slot_end_r) cr = E.rec_end[rec_base + r];
+            else if (c == slot_end_r) cr = end_r;
             else cr = Ld.dir_off[(uint32_t)c & E.dir_mask];
+            /* Reference quirk (dare_ibv_rc.c:1725-1758): when a polling() pass starts with the
+             * commit pointer parked at the wrap position X (everything before is committed, the
+             * pass's first entry wrapped to offset 0), the first scan redirects to offset 0, finds
+             * no ACKs yet, and "commits" offset 0 -- the same position, but log_is_offset_larger(0, X)
+             * holds, `committed` is set and rc_write_remote_logs returns before the followers
+             * were brought up to date.  That pass therefore ends with commit == 0. */
+            if (s.kstar >= 0 && (int64_t)(rf[r] - rf[0]) == s.kstar && s.w < L && cs >= slot_start_r &&
+                (r ? true : s.commit_before == s.e0))
+                cr = 0;
+            /* a round that ended exactly on len could not commit: the log read as empty
+             * (dare_log.h:158), the leader's scan saw distance 0 (dare_ibv_rc.c:1726) */
+            if (end_r == L) {
+                if (r == 0) cr = s.commit_before;
+                else {
+                    const uint64_t pe = E.rec_end[rec_base + r - 1];
+                    const uint64_t pc = min(cs, slot_start_r);
+                    cr = (pc <= s.n_commit_before) ? s.commit_before : (pc == slot_start_r ? pe : Ld.dir_off[(uint32_t)pc & E.dir_mask]);
+                }
+            }
             E.rec_commit[rec_base + r] = cr;
         }
     }
     __syncthreads();
-    if (mode == 0) {
-        /* a round that ended exactly on len could not commit: the log read as empty
-         * (dare_log.h:158), the leader's scan saw distance 0 (dare_ibv_rc.c:1726) */
-        for (uint32_t r = lane; r < R; r += WAVE) {
-            if (rec_base + r >= E.rec_cap) break;
-            if (E.rec_end[rec_base + r] == L)
-                E.rec_commit[rec_base + r] = r ? E.rec_commit[rec_base + r - 1] : s.commit_before;
-        }
-    }
-    if (lane == 0) {
+    if (tid == 0) {
         if (mode == 0) {
             *E.rec_count = rec_base + R;
         } else if (mode == 1 && s.n) {
@@ -618,14 +623,14 @@ __global__ __launch_bounds__(64) void k_finish(const EngDev E, uint64_t r0, uint
                 E.rec_commit[rec_base] = (end_l == L) ? s.commit_before : commit_off;
             *E.rec_count = rec_base + 1;
         }
-        /* leader: commit, cid offset, apply (update_remote_logs :1744-1758, apply_committed_entries) */
+        /* leader: commit, apply (update_remote_logs :1744-1758, apply_committed_entries) */
         lh[H_N_VISIBLE] = vis;
         if (cs > s.n_commit_before) { lh[H_COMMIT] = commit_off; lh[H_N_COMMIT] = cs; }
-        if (cs > lh[H_N_APPLY]) { lh[H_APPLY] = slot_off(cs); lh[H_N_APPLY] = cs; }
+        if (cs > apply_l) { lh[H_APPLY] = slot_off(cs); lh[H_N_APPLY] = cs; }
     }
     /* followers: R2 end doorbell, persist bookkeeping, R4 lazy commit, apply, HEAD adoption */
-    if (lane >= 1 && lane <= APUS_DEV_MAX_SERVERS) {
-        const int f = (int)lane - 1;
+    if (tid >= 1 && tid <= APUS_DEV_MAX_SERVERS) {
+        const int f = (int)tid - 1;
         if ((fmask >> f) & 1u) {
             uint64_t *fh = E.rep[f].hdr;
             if (vis > fh[H_N_PERSIST]) {
@@ -633,9 +638,9 @@ __global__ __launch_bounds__(64) void k_finish(const EngDev E, uint64_t r0, uint
                 fh[H_END] = vis_off; fh[H_OLD_END] = vis_off;
                 fh[H_N_END] = vis; fh[H_N_PERSIST] = vis;
             }
-            if (cs > fh[H_N_COMMIT]) { fh[H_COMMIT] = (cs > s.n_commit_before) ? commit_off : lh[H_COMMIT]; fh[H_N_COMMIT] = cs; }
-            if (cs > fh[H_N_APPLY]) { fh[H_APPLY] = fh[H_COMMIT]; fh[H_N_APPLY] = cs; }
-            const uint64_t hs = fh[H_HEAD_SLOT];
+            if (cs > fh[H_N_COMMIT]) { fh[H_COMMIT] = slot_off(cs); fh[H_N_COMMIT] = cs; }
+            if (cs > fh[H_N_APPLY]) { fh[H_APPLY] = slot_off(cs); fh[H_N_APPLY] = cs; }
+            const uint64_t hs = __hip_atomic_load((unsigned long long *)&fh[H_HEAD_SLOT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (hs) {
                 const uint64_t hoff = E.rep[f].dir_off[(uint32_t)(hs - 1) & E.dir_mask];
                 const uint64_t hv = ld8u(E.rep[f].ring + hoff + 48);
@@ -644,6 +649,121 @@ __global__ __launch_bounds__(64) void k_finish(const EngDev E, uint64_t r0, uint
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_finish(const EngDev E, uint64_t r0, uint32_t R, int mode, uint32_t fmask)
+{
+    finish_call(E, r0, R, mode, fmask);
+}
+
+/* ------------------------------------------------------------------------- */
+/* k_control_round: ONE workgroup does a whole polling() pass that carries at most
+ * one control entry -- used for the prune tick, the new leader's blank CONFIG
+ * entry, removed-server CONFIG entries and quiesce, where the wide pipeline's six
+ * launches would be pure overhead.
+ *   mode 0: append <type, d0, d1> (log_append_entry, dare_log.h:466-558; 64-byte
+ *           entries never hit wrap case 2)
+ *   mode 1: log_pruning (dare_server.c:1996-2067): decide from the sampled apply
+ *           offsets whether the head moves, append <HEAD, head> if so, re-sample the
+ *           apply offsets (rc_get_remote_apply_offsets, dare_ibv_rc.c:1970)
+ *   mode 2: no append (quiesce)
+ * then followers persist + ACK, the ACK scan, apply and the bookkeeping.          */
+__global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode, uint32_t type,
+                                                       uint64_t d0, uint64_t d1, uint32_t push_mask,
+                                                       uint32_t sample_mask)
+{
+    __shared__ uint32_t s_ack[256];
+    __shared__ unsigned long long s_acc[2];
+    const uint32_t tid = threadIdx.x;
+    const RepDev &Ld = E.rep[E.leader];
+    uint64_t *hdr = Ld.hdr;
+    const uint64_t L = E.log_len;
+
+    /* followers that lag (RELEASE without a wide catch-up, hidden exact-fit round) */
+    {
+        const uint64_t e0 = hdr[H_END], n0 = hdr[H_N_END];
+        for (uint32_t m = push_mask; m; m &= m - 1) catchup_range(E, __builtin_ctz(m), e0, n0, tid, blockDim.x);
+        __syncthreads();
+        if (tid == 0)
+            for (uint32_t m = push_mask; m; m &= m - 1) {
+                uint64_t *fh = E.rep[__builtin_ctz(m)].hdr;
+                if (fh[H_N_END] < n0 && e0 != L) { fh[H_END] = e0; fh[H_N_END] = n0; }
+            }
+    }
+
+    if (tid == 0) {
+        uint64_t end = hdr[H_END];
+        bool do_append = (mode != 2);
+        if (mode == 1) {
+            const uint32_t size = E.group_size;
+            const uint32_t bitmask = (uint32_t)hdr[H_CID_BITMASK];
+            uint64_t min_off = hdr[H_APPLY];
+            for (uint32_t i = 0; i < size; i++) {
+                if (!((bitmask >> i) & 1u)) hdr[H_APPLY_OFFSETS + i] = hdr[H_APPLY];
+                if (apus_is_larger(end, L, min_off, hdr[H_APPLY_OFFSETS + i])) min_off = hdr[H_APPLY_OFFSETS + i];
+            }
+            if (apus_end_distance(end, L, min_off) == 0) min_off = hdr[H_TAIL];   /* leave one entry, :2038-2041 */
+            do_append = apus_is_larger(end, L, min_off, hdr[H_HEAD]) && !hdr[H_PREV_HEAD];
+            if (do_append) { hdr[H_HEAD] = min_off; d0 = min_off; d1 = 0; type = 3; }
+        }
+        SeqOut s;
+        s.e0 = end; s.idx0 = hdr[H_LAST_IDX] + 1; s.w = 0; s.n_end0 = hdr[H_N_END];
+        s.term = hdr[H_SID] >> 9; s.kstar = -1; s.estar = -1; s.stale = 0; s.n = 0;
+        s.first_fail = ~0ull; s.commit_before = hdr[H_COMMIT]; s.n_commit_before = hdr[H_N_COMMIT];
+        if (do_append && end == hdr[H_HEAD] && end != L) { set_status(E, 1u << 1); do_append = false; }
+        if (do_append) {
+            const uint64_t idx = (end == L) ? 1 : hdr[H_LAST_IDX] + 1;          /* dare_log.h:486-488 */
+            const uint64_t pos = (end == L || L - end < APUS_HDR) ? 0 : end;   /* log_add_new_entry, :213-221 */
+            if (type != 3) hdr[H_PREV_HEAD] = 0; else if (mode == 1) hdr[H_PREV_HEAD] = 1;
+            const uint64_t term = s.term;
+            const uint64_t slot = s.n_end0;
+            const uint32_t di = (uint32_t)slot & E.dir_mask;
+            const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)term, (uint32_t)(term >> 32));
+            const uint4 h1 = make_uint4(0, 0, (type << 16) | ((uint32_t)E.leader << 24), 0);  /* req_id = clt_id = 0 */
+            const uint4 h2 = make_uint4(0, 0, 0, 0);
+            const uint4 h3 = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
+            for (uint32_t m = push_mask | (1u << E.leader); m; m &= m - 1) {
+                const int t = __builtin_ctz(m);
+                uint8_t *rg = E.rep[t].ring;
+                st16u(rg + pos, h0); st16u(rg + pos + 16, h1); st16u(rg + pos + 32, h2); st16u(rg + pos + 48, h3);
+                E.rep[t].dir_off[di] = pos; E.rep[t].dir_len[di] = APUS_HDR;
+            }
+            __hip_atomic_store(&Ld.ack[di], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hdr[H_TAIL] = pos;
+            hdr[H_END] = pos + APUS_HDR;
+            hdr[H_N_END] = slot + 1;
+            hdr[H_LAST_IDX] = idx;
+            hdr[H_OLD_END] = pos + APUS_HDR;
+            hdr[H_N_PERSIST] = slot + 1;
+            hdr[H_STORE_COUNT] += 1;
+            s.n = 1;
+            const uint64_t rec_base = *E.rec_count;
+            if (rec_base < E.rec_cap) E.rec_end[rec_base] = pos + APUS_HDR;
+        }
+        *E.seq = s;
+        if (mode == 1) {
+            /* READ the apply offset of every reachable peer for the next tick */
+            const uint32_t bitmask = (uint32_t)hdr[H_CID_BITMASK];
+            for (uint32_t i = 0; i < E.group_size; i++) {
+                if (i == E.leader || !((bitmask >> i) & 1u)) { hdr[H_APPLY_OFFSETS + i] = hdr[H_APPLY]; continue; }
+                if (!((sample_mask >> i) & 1u)) continue;
+                hdr[H_APPLY_OFFSETS + i] = E.rep[i].hdr[H_APPLY];
+            }
+        }
+    }
+    __syncthreads();
+
+    const uint64_t vis = visible_slots(E, hdr, 0, 0);
+    for (uint32_t m = push_mask; m; m &= m - 1) persist_ack_range(E, __builtin_ctz(m), vis, tid, blockDim.x);
+    __threadfence_block();
+    __syncthreads();
+    commit_scan(E, hdr[H_N_COMMIT], vis, 0, blockDim.x, s_ack);
+    __syncthreads();
+    const uint64_t cs = commit_slot(E, vis);
+    for (uint32_t m = push_mask | (1u << E.leader); m; m &= m - 1)
+        apply_range(E, __builtin_ctz(m), cs, 0, blockDim.x, s_acc);
+    __syncthreads();
+    finish_call(E, 0, 0, mode == 2 ? 2 : 1, push_mask);
 }
 
 /* k_reset: log_new() (dare_log.h:120-136) without touching the ring bytes that
@@ -657,5 +777,5 @@ __global__ void k_reset(const EngDev E)
     h[H_LEN] = E.log_len; h[H_END] = E.log_len; h[H_TAIL] = E.log_len; h[H_OLD_END] = E.log_len;
     h[H_SID] = (uint64_t)p;
     h[H_CID_BITMASK] = (1u << E.group_size) - 1;
-    if (p == 0) { *E.rec_count = 0; *E.status = 0; }
+    if (p == 0) { *E.rec_count = 0; *E.status = 0; *E.ticket = 0; }
 }

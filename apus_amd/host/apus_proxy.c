@@ -1,0 +1,496 @@
+/*
+ * apus_proxy.c -- host side of the drop-in: the reference's proxy and SMR-core
+ * API surfaces (include/apus_smr.h) implemented as thin C over the GPU engine
+ * (include/apus_gpu.h).  No consensus arithmetic happens here: requests are
+ * admitted (ids assigned, bytes copied into the submission queue) and the
+ * engine's apply stream is turned back into the reference's upcalls, in log order,
+ * on the one DARE thread.
+ *
+ * Mirrors, with the same names and blocking behaviour:
+ *   proxy_init / proxy_on_read / proxy_on_accept / proxy_on_close
+ *                       /root/reference/src/proxy/proxy.c:441,230,241,252
+ *   leader_handle_submit_req (admission + spin until applied)   proxy.c:108-161
+ *   dare_server_init / polling()          src/dare/dare_server.c:173-250, 1012-1125
+ *   is_leader / get_node_id               src/dare/dare_server.c:2299-2307
+ *   dare_ib_poll_tailq / write_remote_logs / send_entries_reply / get_remote_apply_offsets
+ *                                          src/include/dare/dare_ibv.h:154,176-178
+ *
+ * Configuration keeps the reference's environment variables (proxy.c:33-57):
+ * server_idx, group_size, server_type, dare_log_file, config_path; the libconfig
+ * file keys it needs (port, ip_address, req_log, db_name) are read with a tiny
+ * key=value scanner (the file format of target/nodes.local.cfg).
+ * Extra knobs: APUS_GPU_DEVICE, APUS_GPU_LOG_LEN, APUS_PRUNE_PERIOD_MS.
+ */
+#define _GNU_SOURCE
+#include <arpa/inet.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <pthread.h>
+#include <signal.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "apus_gpu.h"
+#include "apus_smr.h"
+
+/* ------------------------------------------------------------------------- */
+/* submission queue: fixed ring of admitted requests + a payload arena.       */
+#define Q_CAP        4096u                 /* == the engine's live batch limit */
+#define Q_ARENA      (8u << 20)
+
+typedef struct {
+    apus_req_t reqs[Q_CAP];
+    uint8_t   *arena;                      /* Q_ARENA bytes */
+    uint32_t   n;
+    uint64_t   arena_used;
+    pthread_spinlock_t lock;               /* tailq_lock, message.h:22 */
+} subq_t;
+
+static subq_t g_q;
+static pthread_once_t g_q_once = PTHREAD_ONCE_INIT;
+
+static void q_init(void)
+{
+    memset(&g_q, 0, sizeof g_q);
+    g_q.arena = malloc(Q_ARENA);
+    pthread_spin_init(&g_q.lock, PTHREAD_PROCESS_PRIVATE);
+}
+
+/* caller holds the lock */
+static int q_push_locked(uint8_t type, uint16_t connection_id, uint64_t req_id, const void *buf, uint16_t len)
+{
+    const uint64_t need = ((uint64_t)len + 15) & ~15ull;
+    if (g_q.n == Q_CAP || g_q.arena_used + need > Q_ARENA) return -1;
+    apus_req_t *q = &g_q.reqs[g_q.n++];
+    memset(q, 0, sizeof *q);
+    q->req_id = req_id;
+    q->payload_off = g_q.arena_used;
+    q->clt_id = connection_id;
+    q->len = len;
+    q->type = type;
+    if (len) memcpy(g_q.arena + g_q.arena_used, buf, len);
+    g_q.arena_used += need;
+    return 0;
+}
+
+int apus_tailq_push(uint8_t type, uint16_t connection_id, uint64_t req_id, const void *buf, uint16_t len)
+{
+    pthread_once(&g_q_once, q_init);
+    pthread_spin_lock(&g_q.lock);
+    int rc = q_push_locked(type, connection_id, req_id, buf, len);
+    pthread_spin_unlock(&g_q.lock);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* SMR core state (the reference keeps it in the global `data`, dare_server.c:69) */
+typedef struct {
+    apus_engine_t *eng;
+    dare_server_input_t in;
+    uint32_t group_size, idx, leader;
+    uint64_t term;
+    volatile int running, terminate, ready;
+    pthread_t thread;
+    uint64_t applied_slot[APUS_MAX_SERVERS];   /* next apply-stream slot to hand to the upcalls */
+    double prune_period_s;
+    /* drained batch kept between poll_tailq and write_remote_logs */
+    apus_req_t *batch; uint8_t *batch_arena; uint32_t batch_n; uint64_t batch_bytes;
+    FILE *log;
+} smr_t;
+
+static smr_t g_smr;
+
+int is_leader(void) { return g_smr.ready && g_smr.leader == g_smr.idx; }        /* dare_server.c:2299 */
+uint8_t get_node_id(void) { return (uint8_t)g_smr.idx; }                         /* dare_server.c:2304 */
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+/* dare_ib_poll_tailq -> get_tailq_message (dare_ibv_ud.c:780-790): everything that
+ * queued up becomes log entries, under the same lock the submitters take */
+void dare_ib_poll_tailq(void)
+{
+    smr_t *s = &g_smr;
+    if (!s->eng || s->batch_n) return;
+    pthread_once(&g_q_once, q_init);
+    pthread_spin_lock(&g_q.lock);
+    if (g_q.n) {
+        memcpy(s->batch, g_q.reqs, sizeof(apus_req_t) * g_q.n);
+        memcpy(s->batch_arena, g_q.arena, g_q.arena_used);
+        s->batch_n = g_q.n;
+        s->batch_bytes = g_q.arena_used;
+        g_q.n = 0;
+        g_q.arena_used = 0;
+    }
+    pthread_spin_unlock(&g_q.lock);
+    if (s->batch_n) {
+        int rc = apus_gpu_append_live(s->eng, s->batch, s->batch_n, s->batch_arena, s->batch_bytes);
+        if (rc) fprintf(stderr, "[apus] append_live failed rc=%d\n", rc);
+    }
+}
+
+/* dare_ib_write_remote_logs -> rc_write_remote_logs (dare_ibv_rc.c:1870): replicate,
+ * aggregate ACKs, advance commit; with wait_for_commit the reference loops until the
+ * commit happened, here the stream is drained.  Returns 0 like the reference. */
+int dare_ib_write_remote_logs(int wait_for_commit)
+{
+    smr_t *s = &g_smr;
+    if (!s->eng) return 1;
+    int rc = apus_gpu_commit_live(s->eng, wait_for_commit);
+    s->batch_n = 0;
+    return rc ? 1 : 0;
+}
+
+/* dare_ib_send_entries_reply -> rc_send_entries_reply (dare_ibv_rc.c:1828): the
+ * follower-side ACK.  Followers hosted by this process are driven by the engine's
+ * own persist/ACK kernel inside write_remote_logs, so nothing is left to post. */
+int dare_ib_send_entries_reply(uint8_t idx)
+{
+    (void)idx;
+    return g_smr.eng ? 0 : 1;
+}
+
+/* dare_ib_get_remote_apply_offsets -> rc_get_remote_apply_offsets (dare_ibv_rc.c:1970);
+ * the gather is part of the prune tick kernel */
+int dare_ib_get_remote_apply_offsets(void)
+{
+    return g_smr.eng ? 0 : 1;
+}
+
+/* apply_committed_entries' upcalls (dare_server.c:1941-1955), in log order */
+static void deliver_upcalls(smr_t *s)
+{
+    uint64_t cnt[8];
+    const uint32_t r = s->idx;
+    if (apus_gpu_counters(s->eng, r, cnt)) return;
+    const uint64_t n_apply = cnt[3];
+    static apus_apply_t recs[1024];
+    while (s->applied_slot[r] < n_apply) {
+        uint64_t n = n_apply - s->applied_slot[r];
+        if (n > 1024) n = 1024;
+        if (apus_gpu_apply_records(s->eng, r, s->applied_slot[r], n, recs)) return;
+        for (uint64_t i = 0; i < n; i++) {
+            if (recs[i].kind == 1) {
+                if (s->in.update_state) s->in.update_state(s->in.up_para);
+            } else if (recs[i].kind == 2 && s->in.do_action) {
+                static uint8_t payload[65536 + 64];
+                if (recs[i].len)
+                    apus_gpu_read_ring(s->eng, r, recs[i].off + 50, recs[i].len, payload);
+                s->in.do_action(recs[i].clt_id, recs[i].type, recs[i].len, payload, s->in.up_para);
+            }
+        }
+        s->applied_slot[r] += n;
+    }
+}
+
+static void on_sigint(int sig) { (void)sig; g_smr.terminate = 1; }   /* int_handler, dare_server.c:2310 */
+
+void dare_server_shutdown(void)
+{
+    g_smr.terminate = 1;
+}
+
+void *dare_server_init(void *arg)
+{
+    smr_t *s = &g_smr;
+    dare_server_input_t *in = arg;
+    pthread_once(&g_q_once, q_init);
+    s->in = *in;
+    free(in);                                      /* the reference frees it too, dare_server.c:208 */
+    s->log = s->in.log ? s->in.log : stdout;
+    s->group_size = s->in.group_size ? s->in.group_size : 3;
+    s->idx = s->in.server_idx;
+    s->batch = malloc(sizeof(apus_req_t) * Q_CAP);
+    s->batch_arena = malloc(Q_ARENA);
+    const char *pp = getenv("APUS_PRUNE_PERIOD_MS");
+    s->prune_period_s = pp ? atof(pp) * 1e-3 : 0.05;   /* log_pruning_period, nodes.local.cfg:35 */
+
+    apus_cfg_t cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.group_size = s->group_size;
+    cfg.n_local = s->group_size;                   /* logical replicas on one device */
+    for (uint32_t i = 0; i < s->group_size; i++) cfg.local_ids[i] = (uint8_t)i;
+    const char *ll = getenv("APUS_GPU_LOG_LEN");
+    cfg.log_len = ll ? strtoull(ll, NULL, 0) : 0;
+    const char *dv = getenv("APUS_GPU_DEVICE");
+    cfg.device = dv ? atoi(dv) : 0;
+    if (apus_gpu_create(&cfg, &s->eng)) {
+        fprintf(stderr, "[apus] cannot create the GPU consensus engine (no CPU path exists)\n");
+        s->eng = NULL;
+        s->ready = -1;
+        return NULL;
+    }
+    apus_gpu_bind_global(s->eng);
+    /* start-up election: every server becomes a candidate of term 1, this server's
+     * timeout fires first (dare_server.c:1169, 1264-1518) */
+    s->term = 2;
+    s->leader = s->idx;
+    if (apus_gpu_become_leader(s->eng, s->leader, s->term, (1u << s->group_size) - 1) || apus_gpu_sync(s->eng)) {
+        fprintf(stderr, "[apus] election failed\n");
+        s->ready = -1;
+        return NULL;
+    }
+    fprintf(s->log, "[T%lu] LEADER\n", (unsigned long)s->term);     /* dare_server.c:1396, grepped by run.sh */
+    fflush(s->log);
+    signal(SIGINT, on_sigint);
+    s->running = 1;
+    __sync_synchronize();
+    s->ready = 1;
+
+    double last_prune = now_s();
+    while (!s->terminate) {                        /* polling(), dare_server.c:1012-1125 */
+        dare_ib_poll_tailq();
+        if (s->batch_n) {
+            dare_ib_write_remote_logs(1);
+            deliver_upcalls(s);
+        } else {
+            struct timespec ts = {0, 20000};
+            nanosleep(&ts, NULL);
+        }
+        const double t = now_s();
+        if (t - last_prune >= s->prune_period_s) {  /* prune_log_cb, dare_server.c:1977 */
+            apus_gpu_tick_prune(s->eng);
+            apus_gpu_sync(s->eng);
+            dare_ib_get_remote_apply_offsets();
+            last_prune = t;
+        }
+    }
+    apus_gpu_sync(s->eng);
+    const uint32_t st = apus_gpu_status(s->eng);
+    if (st) fprintf(stderr, "[apus] device status %#x at shutdown\n", st);
+    apus_gpu_destroy(s->eng);
+    s->eng = NULL;
+    s->running = 0;
+    return NULL;
+}
+
+/* ------------------------------------------------------------------------- */
+/* proxy (B-outer) */
+#define MAX_FDS 65536
+
+typedef struct { uint64_t req_id; uint16_t connection_id; uint8_t used; } lead_pair_t;
+typedef struct { int sock; uint8_t used; } foll_pair_t;
+
+struct proxy_node_t {
+    struct sockaddr_in sys_addr;       /* where the local application listens (follower replay) */
+    lead_pair_t *leader_map;           /* leader_hash_map keyed by fd, proxy.h:36-45 */
+    foll_pair_t *follower_map;         /* follower_hash_map keyed by connection_id */
+    volatile uint64_t highest_rec;     /* proxy.h:47 */
+    volatile uint64_t cur_rec;
+    uint8_t pair_count;                /* nc_t */
+    int req_log;
+    FILE *req_log_file;
+    char db_name[128];
+    pthread_t dare_thread;
+};
+
+static struct proxy_node_t *g_proxy;
+
+static void update_highest_rec(void *arg)                        /* proxy.c:263-267 */
+{
+    struct proxy_node_t *p = arg;
+    p->highest_rec++;
+}
+
+static void do_action_to_server(uint16_t clt_id, uint8_t type, size_t data_size, void *data, void *arg)
+{                                                                /* proxy.c:341-439 */
+    struct proxy_node_t *p = arg;
+    foll_pair_t *fp = &p->follower_map[clt_id];
+    if (p->req_log && p->req_log_file)
+        fprintf(p->req_log_file, type == PROXY_CONNECT ? "Operation: Connects.\n" :
+                type == PROXY_SEND ? "Operation: Sends data.\n" : "Operation: Closes.\n");
+    switch (type) {
+    case PROXY_CONNECT:
+        if (!fp->used) {
+            int fd = socket(AF_INET, SOCK_STREAM, 0);
+            if (fd < 0) { fprintf(stderr, "ERROR opening socket!\n"); return; }
+            fp->sock = fd; fp->used = 1;
+            if (connect(fd, (struct sockaddr *)&p->sys_addr, sizeof p->sys_addr) < 0) fprintf(stderr, "ERROR connecting!\n");
+            int fl = fcntl(fd, F_GETFL); if (fl != -1) fcntl(fd, F_SETFL, fl | O_NONBLOCK);
+            int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+        }
+        break;
+    case PROXY_SEND:
+        if (fp->used && write(fp->sock, data, data_size) < 0) fprintf(stderr, "ERROR writing to socket!\n");
+        break;
+    case PROXY_CLOSE:
+        if (fp->used) { if (close(fp->sock)) fprintf(stderr, "ERROR closing socket!\n"); fp->used = 0; }
+        break;
+    default: break;
+    }
+}
+
+static int is_inner(pthread_t tid)                               /* proxy.c:91-99 */
+{
+    return g_proxy && pthread_equal(tid, g_proxy->dare_thread);
+}
+
+/* leader_handle_submit_req, proxy.c:108-161: same id assignment, same lock scope,
+ * same blocking (the caller returns only after its entry was applied) */
+static void leader_handle_submit_req(uint8_t type, ssize_t data_size, void *buf, int fd, struct proxy_node_t *p)
+{
+    if (fd < 0 || fd >= MAX_FDS || data_size < 0 || data_size > 65535) return;
+    pthread_once(&g_q_once, q_init);
+    lead_pair_t *pair = &p->leader_map[fd];
+    uint64_t req_id = 0;
+    uint16_t connection_id = 0;
+    for (;;) {
+        pthread_spin_lock(&g_q.lock);
+        if (g_q.n < Q_CAP && g_q.arena_used + (uint64_t)data_size + 16 <= Q_ARENA) break;
+        pthread_spin_unlock(&g_q.lock);              /* queue full: wait for the DARE thread to drain */
+        sched_yield();
+    }
+    const uint64_t cur_rec = ++p->cur_rec;
+    switch (type) {
+    case PROXY_CONNECT:
+        memset(pair, 0, sizeof *pair);
+        pair->used = 1;
+        pair->connection_id = (uint16_t)(((uint16_t)get_node_id() << 8) | p->pair_count++);   /* gen_key, proxy.c:101 */
+        req_id = ++pair->req_id;
+        connection_id = pair->connection_id;
+        break;
+    case PROXY_SEND:
+        if (!pair->used) { p->cur_rec--; pthread_spin_unlock(&g_q.lock); return; }   /* the reference dereferences NULL here (Q8) */
+        req_id = ++pair->req_id;
+        connection_id = pair->connection_id;
+        break;
+    case PROXY_CLOSE:
+        if (!pair->used) { p->cur_rec--; pthread_spin_unlock(&g_q.lock); return; }
+        req_id = ++pair->req_id;
+        connection_id = pair->connection_id;
+        pair->used = 0;
+        break;
+    default:
+        p->cur_rec--; pthread_spin_unlock(&g_q.lock); return;
+    }
+    q_push_locked(type, connection_id, req_id, buf, (uint16_t)data_size);
+    pthread_spin_unlock(&g_q.lock);
+    while (cur_rec > p->highest_rec) {               /* proxy.c:160 */
+        if (g_smr.terminate || g_smr.ready < 0) break;
+        __builtin_ia32_pause();
+    }
+}
+
+void proxy_on_read(struct proxy_node_t *p, void *buf, ssize_t bytes_read, int fd)
+{
+    if (!p || is_inner(pthread_self())) return;
+    if (is_leader()) leader_handle_submit_req(PROXY_SEND, bytes_read, buf, fd, p);
+}
+
+void proxy_on_accept(struct proxy_node_t *p, int fd)
+{
+    if (!p || is_inner(pthread_self())) return;
+    if (is_leader()) leader_handle_submit_req(PROXY_CONNECT, 0, NULL, fd, p);
+}
+
+void proxy_on_close(struct proxy_node_t *p, int fd)
+{
+    if (!p || is_inner(pthread_self())) return;
+    if (is_leader()) leader_handle_submit_req(PROXY_CLOSE, 0, NULL, fd, p);
+}
+
+/* the four keys proxy_read_config takes from the libconfig file (config-proxy.c:6-60) */
+static int read_cfg(struct proxy_node_t *p, const char *path)
+{
+    char ip[64] = "127.0.0.1";
+    int port = 6379;
+    if (path && *path) {
+        FILE *f = fopen(path, "r");
+        if (!f) return -1;
+        char line[512];
+        while (fgets(line, sizeof line, f)) {
+            char key[64], val[256];
+            char *h = strchr(line, '#'); if (h) *h = 0;
+            if (sscanf(line, " %63[A-Za-z_] = %255[^;\n]", key, val) != 2) continue;
+            char *v = val; while (*v == ' ' || *v == '"') v++;
+            char *e = v + strlen(v); while (e > v && (e[-1] == ' ' || e[-1] == '"')) *--e = 0;
+            if (!strcmp(key, "port")) port = atoi(v);
+            else if (!strcmp(key, "ip_address")) snprintf(ip, sizeof ip, "%s", v);
+            else if (!strcmp(key, "req_log")) p->req_log = atoi(v);
+            else if (!strcmp(key, "db_name")) snprintf(p->db_name, sizeof p->db_name, "%s", v);
+        }
+        fclose(f);
+    }
+    memset(&p->sys_addr, 0, sizeof p->sys_addr);
+    p->sys_addr.sin_family = AF_INET;
+    p->sys_addr.sin_port = htons((uint16_t)port);
+    inet_pton(AF_INET, ip, &p->sys_addr.sin_addr);
+    return 0;
+}
+
+struct proxy_node_t *proxy_init(const char *config_path, const char *proxy_log_path)
+{
+    struct proxy_node_t *p = calloc(1, sizeof *p);
+    if (!p) return NULL;
+    if (read_cfg(p, config_path)) {                               /* proxy.c:452-455 */
+        fprintf(stderr, "PROXY : Configuration File Reading Error.\n");
+        free(p);
+        return NULL;
+    }
+    p->leader_map = calloc(MAX_FDS, sizeof(lead_pair_t));
+    p->follower_map = calloc(65536, sizeof(foll_pair_t));
+    if (p->req_log) {
+        char path[512];
+        snprintf(path, sizeof path, "%s/node-proxy-req.log", proxy_log_path ? proxy_log_path : ".");
+        p->req_log_file = fopen(path, "w");
+    }
+    pthread_once(&g_q_once, q_init);
+
+    /* dare_main, proxy.c:22-89: same environment variables, same defaults */
+    dare_server_input_t *in = calloc(1, sizeof *in);
+    in->log = stdout;
+    in->name = "";
+    in->output = "dare_servers.out";
+    in->srv_type = SRV_TYPE_START;
+    in->sm_type = 2;
+    in->server_idx = 0xFF;
+    const char *e;
+    if ((e = getenv("server_idx"))) in->server_idx = (uint8_t)atoi(e);
+    in->group_size = 3;
+    if ((e = getenv("group_size"))) in->group_size = (uint8_t)atoi(e);
+    if ((e = getenv("server_type")) && !strcmp(e, "join")) in->srv_type = SRV_TYPE_JOIN;
+    if ((e = getenv("dare_log_file")) && *e) {
+        in->log = fopen(e, "w+");
+        if (!in->log) { printf("Cannot open log file\n"); exit(1); }
+    }
+    if (in->srv_type == SRV_TYPE_START && in->server_idx == 0xFF) {
+        printf("A server cannot start without an index\n");
+        exit(1);
+    }
+    in->do_action = do_action_to_server;
+    in->update_state = update_highest_rec;
+    if (config_path) snprintf(in->config_path, sizeof in->config_path, "%s", config_path);
+    in->up_para = p;
+    g_proxy = p;
+    if (pthread_create(&p->dare_thread, NULL, dare_server_init, in)) {
+        fprintf(stderr, "Cannot init dare_thread\n");
+        free(p);
+        g_proxy = NULL;
+        return NULL;
+    }
+    /* unlike the reference, wait until the engine answered: the first hooked call
+     * would otherwise race the election */
+    while (!g_smr.ready) { struct timespec ts = {0, 1000000}; nanosleep(&ts, NULL); }
+    if (g_smr.ready < 0) { g_proxy = NULL; return NULL; }
+    return p;
+}
+
+/* test / shutdown helper: stop the DARE thread and wait for it */
+void apus_proxy_shutdown(struct proxy_node_t *p)
+{
+    if (!p) return;
+    dare_server_shutdown();
+    pthread_join(p->dare_thread, NULL);
+}
+
+uint64_t apus_proxy_highest_rec(struct proxy_node_t *p) { return p ? p->highest_rec : 0; }

@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rocminfo 2>/dev/null | grep -m2 -E "gfx|Marketing" > gpurun_out/device.txt
-timeout 1500 python -m pytest tests -m gpu -q ${PYTEST_X:--x} --timeout 600 2>&1 | tail -80 > gpurun_out/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -q ${PYTEST_X--x} --timeout 600 2>&1 | tail -80 > gpurun_out/pytest_gpu.log
 echo "pytest exit: ${PIPESTATUS[0]}" >> gpurun_out/pytest_gpu.log
 tail -40 gpurun_out/pytest_gpu.log
 timeout 600 python bench.py --steps ${BENCH_STEPS:-5} --warmup 2 --cpu-seconds ${CPU_SECONDS:-5} > gpurun_out/bench.log 2>&1
