@@ -46,6 +46,10 @@ SIGNATURES = {
     "apus_gpu_kernel_time": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(u64)]),
     "apus_gpu_stream": (vp, [vp]),
     "apus_gpu_bind_global": (C.c_int, [vp]),
+    "apus_gpu_global": (vp, []),
+    "apus_gpu_submit": (C.c_int, [vp, vp, u32, vp, u64]),
+    "apus_gpu_append_live": (C.c_int, [vp, vp, u32, vp, u64]),
+    "apus_gpu_commit_live": (C.c_int, [vp, C.c_int]),
 }
 
 

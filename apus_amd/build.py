@@ -10,6 +10,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 HOST = os.path.join(PKG, "host")
 LIB = os.path.join(PKG, "libapus_gpu.so")
+HOOK_LIB = os.path.join(PKG, "libapus_interpose.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = [os.path.join(CSRC, "apus_engine.hip")]
@@ -27,7 +28,8 @@ def stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SOURCES + DEPS + _host_c_sources())
+    hook = os.path.join(HOST, "hook_interpose.c")
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SOURCES + DEPS + _host_c_sources() + [hook])
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -52,6 +54,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    # the LD_PRELOAD interposer (plain C), linked against the engine library
+    hook = os.path.join(HOST, "hook_interpose.c")
+    if os.path.exists(hook):
+        cmd = ["gcc", "-O2", "-g", "-fPIC", "-shared", "-std=gnu11", "-Wall", "-I", os.path.join(ROOT, "include"),
+               hook, "-o", HOOK_LIB, "-L", PKG, "-lapus_gpu", "-ldl", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
     return LIB
 
 

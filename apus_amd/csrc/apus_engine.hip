@@ -264,8 +264,7 @@ static int launch_tail_view(apus_engine *e, const EngDev &view, uint64_t r0, uin
         hipLaunchKernelGGL(k_persist_ack, dim3(cap_grid(n, 256, 1024), popc(fm)), dim3(256), 0, e->stream,
                            view, r0, R, fm);
     hipLaunchKernelGGL(k_commit, dim3(cap_grid(n, 1024, 512)), dim3(1024), 0, e->stream, view, r0, R);
-    hipLaunchKernelGGL(k_apply, dim3(cap_grid(n, 256, 1024), popc(rm)), dim3(256), 0, e->stream, view, r0, R, rm);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, e->stream, view, r0, R, mode, fm);
+    hipLaunchKernelGGL(k_apply, dim3(cap_grid(n, 256, 1024), popc(rm)), dim3(256), 0, e->stream, view, r0, R, rm, mode, fm);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -298,7 +297,7 @@ static int launch_append(apus_engine *e, const EngDev &view, uint64_t r0, uint32
     int rc;
     const uint32_t fm = sync_mask(e);
     if ((rc = launch_catchup(e))) return rc;
-    hipLaunchKernelGGL(k_sequence, dim3((R + 255) / 256), dim3(256), 0, e->stream, view, r0, R, fm);
+    hipLaunchKernelGGL(k_sequence, dim3((R + 1023) / 1024), dim3(1024), 0, e->stream, view, r0, R, fm);
     hipLaunchKernelGGL(k_append_push, dim3(R), dim3(256), 0, e->stream, view, r0, R, fm);
     HIPCHK(hipGetLastError());
     return 0;
@@ -314,7 +313,7 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
     const uint64_t n = e->h_round_first[r0 + R] - e->h_round_first[r0];
     const uint32_t fm = sync_mask(e);
     if ((rc = launch_catchup(e))) return rc;
-    hipLaunchKernelGGL(k_sequence, dim3((R + 255) / 256), dim3(256), 0, e->stream, e->d, r0, R, fm);
+    hipLaunchKernelGGL(k_sequence, dim3((R + 1023) / 1024), dim3(1024), 0, e->stream, e->d, r0, R, fm);
     TimedLaunch *tl = nullptr;
     if (e->timing && !e->capturing) {
         if (e->timed_used == e->timed.size()) {

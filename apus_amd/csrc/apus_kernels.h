@@ -137,17 +137,17 @@ __global__ __launch_bounds__(256) void k_catchup(const EngDev E, uint32_t fmask)
                   (uint64_t)gridDim.x * blockDim.x);
 }
 
-/* block-wide inclusive scan of one u64 per thread (256 threads), returns the
- * inclusive value; *total gets the block sum                                  */
-__device__ static inline uint64_t block_incl_scan256(uint64_t v, uint64_t *s_tot /*[4]*/, uint64_t *total)
+/* block-wide inclusive scan of one u64 per thread (blockDim.x <= 1024), returns
+ * the inclusive value; *total gets the block sum                              */
+__device__ static inline uint64_t block_incl_scan(uint64_t v, uint64_t *s_tot /*[16]*/, uint64_t *total)
 {
-    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     uint64_t incl = wave_incl_scan(v);
     __syncthreads();
     if (lane == WAVE - 1) s_tot[wv] = incl;
     __syncthreads();
     uint64_t base = 0, tot = 0;
-    for (uint32_t w = 0; w < 4; w++) { if (w < wv) base += s_tot[w]; tot += s_tot[w]; }
+    for (uint32_t w = 0; w < nw; w++) { if (w < wv) base += s_tot[w]; tot += s_tot[w]; }
     *total = tot;
     return base + incl;
 }
@@ -157,9 +157,9 @@ __device__ static inline uint64_t block_incl_scan256(uint64_t v, uint64_t *s_tot
  * Phase A (all blocks, one thread per round): bytes of the round.
  * Phase B (the block that arrives last): exclusive scan over the rounds, the wrap
  * point, the leader's control words and the per-round end record.            */
-__global__ __launch_bounds__(256) void k_sequence(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask)
+__global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask)
 {
-    __shared__ uint64_t s_tot[4];
+    __shared__ uint64_t s_tot[16];
     __shared__ unsigned int s_last, s_rstar;
     __shared__ int64_t s_kstar;
     __shared__ uint64_t s_w;
@@ -186,14 +186,16 @@ __global__ __launch_bounds__(256) void k_sequence(const EngDev E, uint64_t r0, u
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        __threadfence();                               /* release the round sums (agent scope) */
-        const unsigned int t = atomicAdd(E.ticket, 1u);
-        s_last = (t == gridDim.x - 1);
-        if (s_last) { *E.ticket = 0; __threadfence(); }   /* acquire the other blocks' sums */
+    if (gridDim.x > 1) {
+        if (tid == 0) {
+            __threadfence();                               /* release the round sums (agent scope) */
+            const unsigned int t = atomicAdd(E.ticket, 1u);
+            s_last = (t == gridDim.x - 1);
+            if (s_last) { *E.ticket = 0; __threadfence(); }   /* acquire the other blocks' sums */
+        }
+        __syncthreads();
+        if (!s_last) return;
     }
-    __syncthreads();
-    if (!s_last) return;
 
     /* phase B: this block is alone now */
     const uint64_t e0 = hdr[H_END];
@@ -217,11 +219,11 @@ __global__ __launch_bounds__(256) void k_sequence(const EngDev E, uint64_t r0, u
 
     /* exclusive scan of the round sums, in place */
     uint64_t carry = 0;
-    for (uint32_t base = 0; base < R; base += 256) {
+    for (uint32_t base = 0; base < R; base += 1024) {
         const uint32_t r = base + tid;
         const uint64_t bytes = (r < R) ? E.round_virt[r] : 0;
         uint64_t tot;
-        const uint64_t incl = block_incl_scan256(bytes, s_tot, &tot);
+        const uint64_t incl = block_incl_scan(bytes, s_tot, &tot);
         if (r < R) {
             E.round_virt[r] = carry + incl - bytes;
             if (e0 + carry + incl > L) atomicMin(&s_rstar, r);   /* first round that does not fit before len */
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256) void k_sequence(const EngDev E, uint64_t r0, u
     const uint64_t rec_base = *E.rec_count;
     const int64_t kstar = s_kstar;
     const uint64_t w = s_w;
-    for (uint32_t r = tid; r < R; r += 256) {
+    for (uint32_t r = tid; r < R; r += 1024) {
         const uint64_t a_end = e0 + E.round_virt[r + 1];
         const int64_t last = (int64_t)(rf[r + 1] - g0) - 1;   /* batch index of the round's last entry */
         const uint64_t end_r = (kstar < 0 || last < kstar) ? a_end : a_end - w;
@@ -356,10 +358,11 @@ __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0
 
         if (active) {
             const uint32_t di = (uint32_t)slot & E.dir_mask;
-            Ld.dir_off[di] = pos; Ld.dir_len[di] = T; Ld.ack[di] = 0;
+            const uint32_t dl = T | ((uint32_t)E.leader << 24);     /* derived: total bytes | sender << 24 */
+            Ld.dir_off[di] = pos; Ld.dir_len[di] = dl; Ld.ack[di] = 0;
             for (uint32_t m = push_mask; m; m &= m - 1) {
                 const RepDev &Fd = E.rep[__builtin_ctz(m)];
-                Fd.dir_off[di] = pos; Fd.dir_len[di] = T;
+                Fd.dir_off[di] = pos; Fd.dir_len[di] = dl;
             }
             if (s.stale && gk == s.kstar) {
                 /* the header that log_append_entry wrote before it found out that the
@@ -438,8 +441,9 @@ __device__ static inline void persist_ack_range(const EngDev &E, int f, uint64_t
     for (uint64_t s = from + tid; s < vis; s += nth) {
         const uint32_t di = (uint32_t)s & E.dir_mask;
         const uint64_t off = Fd.dir_off[di];
-        /* entry->sender says whose log gets the ACK (dare_server.c:1806) */
-        const uint32_t sender = Fd.ring[off + 27];
+        /* entry->sender says whose log gets the ACK (dare_server.c:1806); the directory
+         * carries a copy of that byte so that the ring line is only written, not read */
+        const uint32_t sender = Fd.dir_len[di] >> 24;
         Fd.ring[off + 28 + f] = 1;                               /* local reply byte, dare_ibv_rc.c:1840 */
         if (sender < APUS_DEV_MAX_SERVERS && E.rep[sender].ring) {
             E.rep[sender].ring[off + 28 + f] = 1;                /* R3: 1-byte WRITE at the same offset */
@@ -512,7 +516,7 @@ __device__ static inline void apply_range(const EngDev &E, int p, uint64_t cs, u
         if (in) {
             const uint32_t di = (uint32_t)s & E.dir_mask;
             const uint64_t off = Pd.dir_off[di];
-            const uint32_t T = Pd.dir_len[di];
+            const uint32_t T = Pd.dir_len[di] & 0xFFFFFFu;
             const uint4 u0 = ld16u(Pd.ring + off);
             const uint4 u1 = ld16u(Pd.ring + off + 16);
             const uint64_t idx = (uint64_t)u0.x | ((uint64_t)u0.y << 32);
@@ -544,16 +548,6 @@ __device__ static inline void apply_range(const EngDev &E, int p, uint64_t cs, u
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint32_t R, uint32_t rmask)
-{
-    __shared__ unsigned long long s_acc[2];
-    int p = -1;
-    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
-        if (rmask & (1u << i)) { if (k == (int)blockIdx.y) { p = i; break; } k++; }
-    if (p < 0) return;
-    const uint64_t vis = visible_slots(E, E.rep[E.leader].hdr, r0, R);
-    apply_range(E, p, commit_slot(E, vis), (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_acc);
-}
 
 /* Scalar bookkeeping of a call (all threads of one block).  mode 0: R staged
  * rounds; mode 1: one control-entry round (s.n tells whether it happened);
@@ -651,9 +645,29 @@ __device__ static inline void finish_call(const EngDev &E, uint64_t r0, uint32_t
     }
 }
 
-__global__ __launch_bounds__(256) void k_finish(const EngDev E, uint64_t r0, uint32_t R, int mode, uint32_t fmask)
+/* k_apply: apply on every replica in rmask (grid.y), then the block that finishes
+ * last does the call's scalar bookkeeping (finish_call).                          */
+__global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint32_t R, uint32_t rmask,
+                                               int mode, uint32_t fmask)
 {
-    finish_call(E, r0, R, mode, fmask);
+    __shared__ unsigned long long s_acc[2];
+    __shared__ unsigned int s_last;
+    int p = -1;
+    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
+        if (rmask & (1u << i)) { if (k == (int)blockIdx.y) { p = i; break; } k++; }
+    if (p >= 0) {
+        const uint64_t vis = visible_slots(E, E.rep[E.leader].hdr, r0, R);
+        apply_range(E, p, commit_slot(E, vis), (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_acc);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int t = atomicAdd(E.ticket + 1, 1u);
+        s_last = (t == gridDim.x * gridDim.y - 1);
+        if (s_last) { E.ticket[1] = 0; __threadfence(); }
+    }
+    __syncthreads();
+    if (s_last) finish_call(E, r0, R, mode, fmask);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -726,7 +740,7 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode,
                 const int t = __builtin_ctz(m);
                 uint8_t *rg = E.rep[t].ring;
                 st16u(rg + pos, h0); st16u(rg + pos + 16, h1); st16u(rg + pos + 32, h2); st16u(rg + pos + 48, h3);
-                E.rep[t].dir_off[di] = pos; E.rep[t].dir_len[di] = APUS_HDR;
+                E.rep[t].dir_off[di] = pos; E.rep[t].dir_len[di] = APUS_HDR | ((uint32_t)E.leader << 24);
             }
             __hip_atomic_store(&Ld.ack[di], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             hdr[H_TAIL] = pos;

@@ -58,10 +58,25 @@ class Engine:
         self.round_of_g0 = {}
         self._keep = []
 
+    @classmethod
+    def from_handle(cls, handle, group_size: int, log_len: int = DEFAULT_LOG) -> "Engine":
+        """Observation-only wrapper around an engine owned by somebody else (the host C layer)."""
+        self = cls.__new__(cls)
+        self.L = _lib.load()
+        self.h = C.c_void_p(handle)
+        self.owned = False
+        self.group_size, self.log_len = group_size, log_len
+        self.local_ids = list(range(group_size))
+        self.leader, self.term = -1, 0
+        self.bitmask = self.reachable = (1 << group_size) - 1
+        self.round_of_g0 = {}
+        return self
+
     # -- lifetime ---------------------------------------------------------------
     def close(self):
         if getattr(self, "h", None):
-            self.L.apus_gpu_destroy(self.h)
+            if getattr(self, "owned", True):
+                self.L.apus_gpu_destroy(self.h)
             self.h = None
 
     def __del__(self):

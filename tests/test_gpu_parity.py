@@ -84,7 +84,7 @@ def test_1KiB_entries_five_replicas(eng_factory):
 
 def test_hold_and_release_catch_up(eng_factory):
     from tests.parity import lockstep
-    n, L = 5, 1 << 17
+    n, L = 5, 1 << 19
     base = T.steady_trace(n, 2000, 64, 8, 32, log_len=L)
     ev = []
     k = 0
