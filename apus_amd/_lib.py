@@ -47,6 +47,14 @@ SIGNATURES = {
     "apus_gpu_stream": (vp, [vp]),
     "apus_gpu_bind_global": (C.c_int, [vp]),
     "apus_gpu_global": (vp, []),
+    "apus_gpu_device_arch": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "apus_gpu_persist_start": (C.c_int, [vp, u32, u32]),
+    "apus_gpu_persist_submit": (C.c_int, [vp, vp, u32, vp, u64]),
+    "apus_gpu_persist_prune": (C.c_int, [vp]),
+    "apus_gpu_persist_drain": (C.c_int, [vp, u32]),
+    "apus_gpu_persist_highest_rec": (u64, [vp]),
+    "apus_gpu_persist_stop": (C.c_int, [vp]),
+    "apus_gpu_persist_latency": (C.c_int, [vp, vp, u32, C.POINTER(u32)]),
     "apus_gpu_submit": (C.c_int, [vp, vp, u32, vp, u64]),
     "apus_gpu_append_live": (C.c_int, [vp, vp, u32, vp, u64]),
     "apus_gpu_commit_live": (C.c_int, [vp, C.c_int]),

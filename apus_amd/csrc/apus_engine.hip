@@ -15,6 +15,8 @@
 
 #include "../../include/apus_gpu.h"
 #include "apus_kernels.h"
+#include "apus_persistent.h"
+#include <time.h>
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { \
     fprintf(stderr, "[apus_gpu] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
@@ -55,6 +57,14 @@ struct apus_engine {
     hipEvent_t live_copied;
     bool live_pending;
     uint64_t live_r0, live_R, live_n;   /* rounds appended by apus_gpu_append_live, not yet committed */
+    /* persistent consensus kernel (live / latency path) */
+    PersistHost *ph;                /* pinned, coherent */
+    PersistHost *ph_dev;            /* device view of the same memory */
+    PersistDev *pd;
+    hipStream_t pstream;
+    bool p_running;
+    uint64_t p_ev_tail, p_req_tail, p_arena_pos;
+    uint64_t p_req_end[P_EV_CAP];   /* cumulative request count after each published event */
 };
 
 #define LIVE_REQS   4096u
@@ -65,6 +75,7 @@ struct apus_engine {
 #define LIVE_BYTES      (LIVE_OFF_ARENA + LIVE_ARENA + 64)
 
 static apus_engine *g_engine = nullptr;
+extern "C" int apus_gpu_persist_stop(apus_engine_t *e);
 
 template <typename T>
 static int dev_alloc(apus_engine *e, T **out, size_t bytes, bool zero = true)
@@ -105,6 +116,8 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->d_req = e->d_req_len = e->d_arena = e->d_round_first = nullptr;
     e->h_live = nullptr; e->d_live = nullptr; e->live_pending = false; e->live_copied = nullptr;
     e->live_r0 = e->live_R = e->live_n = 0;
+    e->ph = e->ph_dev = nullptr; e->pd = nullptr; e->pstream = nullptr; e->p_running = false;
+    e->p_ev_tail = e->p_req_tail = e->p_arena_pos = 0;
     if (cfg->stream) { e->stream = (hipStream_t)cfg->stream; e->own_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
 
@@ -159,6 +172,10 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
     if (e->d_req_len) hipFree(e->d_req_len);
     if (e->d_arena) hipFree(e->d_arena);
     if (e->d_round_first) hipFree(e->d_round_first);
+    if (e->p_running) apus_gpu_persist_stop(e);
+    if (e->ph) hipHostFree(e->ph);
+    if (e->pd) hipFree(e->pd);
+    if (e->pstream) hipStreamDestroy(e->pstream);
     if (e->h_live) hipHostFree(e->h_live);
     if (e->d_live) hipFree(e->d_live);
     if (e->live_copied) hipEventDestroy(e->live_copied);
@@ -660,3 +677,174 @@ extern "C" void *apus_gpu_stream(apus_engine_t *e) { return e ? (void *)e->strea
 
 extern "C" int apus_gpu_bind_global(apus_engine_t *e) { g_engine = e; return 0; }
 extern "C" apus_engine_t *apus_gpu_global(void) { return g_engine; }
+
+
+/* ---- persistent consensus kernel ---------------------------------------------- */
+__global__ void k_persist_init(const EngDev E, PersistDev *D)
+{
+    const int i = threadIdx.x;
+    if (i >= APUS_DEV_MAX_SERVERS) return;
+    if (i == 0) { D->quit = 0; D->lat_n = 0; }
+    if (i < (int)E.group_size && E.rep[i].ring) {
+        D->end_bell[i] = E.rep[i].hdr[H_N_PERSIST];
+        D->commit_bell[i] = E.rep[i].hdr[H_N_APPLY];
+        D->applied_bell[i] = E.rep[i].hdr[H_N_APPLY];
+    }
+}
+
+static double mono_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+extern "C" int apus_gpu_persist_start(apus_engine_t *e, uint32_t idle_ms, uint32_t peer_ms)
+{
+    int rc = need_leader(e);
+    if (rc) return rc;
+    if (e->p_running) return APUS_E_STATE;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (!e->ph) {
+        HIPCHK(hipHostMalloc((void **)&e->ph, sizeof(PersistHost), hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(hipHostGetDevicePointer((void **)&e->ph_dev, e->ph, 0));
+        HIPCHK(hipMalloc((void **)&e->pd, sizeof(PersistDev)));
+        HIPCHK(hipStreamCreateWithFlags(&e->pstream, hipStreamNonBlocking));
+    }
+    memset((void *)e->ph, 0, offsetof(PersistHost, ev));
+    HIPCHK(hipMemset(e->pd, 0, sizeof(PersistDev)));
+    e->p_ev_tail = e->p_req_tail = 0; e->p_arena_pos = 0;
+    uint64_t h[64];
+    HIPCHK(hipMemcpy(h, e->d.rep[e->d.leader].hdr, sizeof h, hipMemcpyDeviceToHost));
+    e->ph->highest_rec = h[H_HIGHEST_REC];
+    e->ph->commit_slot = h[H_N_COMMIT];
+    hipLaunchKernelGGL(k_persist_init, dim3(1), dim3(64), 0, e->pstream, e->d, e->pd);
+    /* one poll costs roughly 1 us (s_sleep + an uncached load) */
+    const uint64_t idle_polls = (uint64_t)idle_ms * 1000ull;
+    const uint64_t peer_polls = (uint64_t)peer_ms * 1000ull;
+    const uint32_t fm = sync_mask(e);
+    hipLaunchKernelGGL(k_consensus_persistent, dim3(popc(e->local_mask)), dim3(256), 0, e->pstream,
+                       e->d, e->ph_dev, e->pd, e->local_mask, fm, idle_polls, peer_polls);
+    HIPCHK(hipGetLastError());
+    const double t0 = mono_s();
+    while (e->ph->alive == 0) {
+        if (mono_s() - t0 > 5.0) { fprintf(stderr, "[apus_gpu] persistent kernel did not start\n"); return APUS_E_HIP; }
+    }
+    e->p_running = true;
+    return 0;
+}
+
+static int persist_push_event(apus_engine *e, uint32_t op, uint32_t n, uint64_t req_first, uint64_t req_end)
+{
+    const double t0 = mono_s();
+    while (e->p_ev_tail - e->ph->ev_head >= P_EV_CAP - 1) {
+        if (e->ph->alive == 2 || mono_s() - t0 > 5.0) return APUS_E_STATE;
+    }
+    PEvent &ev = e->ph->ev[e->p_ev_tail % P_EV_CAP];
+    ev.op = op; ev.n = n; ev.req_first = req_first;
+    e->p_req_end[e->p_ev_tail % P_EV_CAP] = req_end;
+    e->p_ev_tail++;
+    __atomic_store_n((uint64_t *)&e->ph->ev_tail, e->p_ev_tail, __ATOMIC_RELEASE);
+    return 0;
+}
+
+/* requests consumed by the kernel so far */
+static uint64_t persist_req_consumed(apus_engine *e)
+{
+    const uint64_t head = e->ph->ev_head;
+    return head ? e->p_req_end[(head - 1) % P_EV_CAP] : 0;
+}
+
+extern "C" int apus_gpu_persist_submit(apus_engine_t *e, const apus_req_t *reqs, uint32_t n,
+                                       const uint8_t *arena, uint64_t arena_bytes)
+{
+    if (!e || !e->p_running || !reqs) return APUS_E_STATE;
+    (void)arena_bytes;
+    for (uint32_t g0 = 0; g0 < n; g0 += APUS_MAX_ROUND) {
+        const uint32_t nr = (n - g0 < APUS_MAX_ROUND) ? n - g0 : APUS_MAX_ROUND;
+        uint64_t need = 0;
+        for (uint32_t k = 0; k < nr; k++) need += ((uint64_t)reqs[g0 + k].len + 15) & ~15ull;
+        const double t0 = mono_s();
+        /* payload ring: restart at 0 when the batch does not fit, once everything before was consumed */
+        if (e->p_arena_pos + need + 32 > P_ARENA_CAP) {
+            while (e->ph->ev_head < e->p_ev_tail) if (e->ph->alive == 2 || mono_s() - t0 > 5.0) return APUS_E_STATE;
+            e->p_arena_pos = 0;
+        }
+        while (e->p_req_tail + nr - persist_req_consumed(e) > P_REQ_CAP)
+            if (e->ph->alive == 2 || mono_s() - t0 > 5.0) return APUS_E_STATE;
+        for (uint32_t k = 0; k < nr; k++) {
+            const apus_req_t &q = reqs[g0 + k];
+            if (q.type == APUS_NOOP || q.type == APUS_CONFIG || q.type == APUS_HEAD || q.type > 15) return APUS_E_ARG;
+            const uint64_t slot = (e->p_req_tail + k) % P_REQ_CAP;
+            const uint64_t pos = 16 + e->p_arena_pos;                 /* byte -2 of a payload must exist */
+            if (q.len) memcpy((void *)(e->ph->arena + pos), arena + q.payload_off, q.len);
+            ReqDev d;
+            d.req_id = q.req_id;
+            d.pay16_type = (uint32_t)(pos / 16) | ((uint32_t)q.type << 28);
+            d.len = q.len; d.clt_id = q.clt_id;
+            e->ph->req[slot] = d;
+            e->ph->req_len[slot] = q.len;
+            e->p_arena_pos += ((uint64_t)q.len + 15) & ~15ull;
+        }
+        const uint64_t first = e->p_req_tail % P_REQ_CAP;
+        e->p_req_tail += nr;
+        int rc = persist_push_event(e, P_OP_ROUND, nr, first, e->p_req_tail);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int apus_gpu_persist_prune(apus_engine_t *e)
+{
+    if (!e || !e->p_running) return APUS_E_STATE;
+    return persist_push_event(e, P_OP_PRUNE, 0, 0, e->p_req_tail);
+}
+
+/* block until the kernel consumed every published event (or timeout_ms) */
+extern "C" int apus_gpu_persist_drain(apus_engine_t *e, uint32_t timeout_ms)
+{
+    if (!e || !e->p_running) return APUS_E_STATE;
+    const double t0 = mono_s();
+    while (e->ph->ev_head < e->p_ev_tail) {
+        if (e->ph->alive == 2) return APUS_E_STATE;
+        if ((mono_s() - t0) * 1e3 > timeout_ms) return -1;
+    }
+    return 0;
+}
+
+extern "C" uint64_t apus_gpu_persist_highest_rec(apus_engine_t *e) { return (e && e->ph) ? e->ph->highest_rec : 0; }
+extern "C" const volatile uint64_t *apus_gpu_persist_highest_rec_ptr(apus_engine_t *e) { return (e && e->ph) ? &e->ph->highest_rec : nullptr; }
+
+extern "C" int apus_gpu_persist_stop(apus_engine_t *e)
+{
+    if (!e || !e->p_running) return APUS_E_STATE;
+    __atomic_store_n((uint64_t *)&e->ph->stop, 1ull, __ATOMIC_RELEASE);
+    HIPCHK(hipStreamSynchronize(e->pstream));
+    e->p_running = false;
+    return (int)e->ph->exit_code;
+}
+
+/* append -> commit latency samples of the persistent kernel, in nanoseconds */
+extern "C" int apus_gpu_persist_latency(apus_engine_t *e, uint32_t *out_ns, uint32_t cap, uint32_t *n_out)
+{
+    if (!e || !e->pd) return APUS_E_STATE;
+    if (e->p_running) return APUS_E_STATE;
+    uint32_t n = 0;
+    HIPCHK(hipMemcpy(&n, &e->pd->lat_n, sizeof n, hipMemcpyDeviceToHost));
+    if (n > cap) n = cap;
+    if (n) HIPCHK(hipMemcpy(out_ns, e->pd->lat_ticks, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    int khz = 100000;
+    hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device);
+    if (khz <= 0) khz = 100000;
+    for (uint32_t i = 0; i < n; i++) out_ns[i] = (uint32_t)((uint64_t)out_ns[i] * 1000000ull / (uint64_t)khz);
+    if (n_out) *n_out = n;
+    return 0;
+}
+
+extern "C" int apus_gpu_device_arch(int device, char *out, int cap)
+{
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return APUS_E_HIP;
+    snprintf(out, cap, "%s", p.gcnArchName);
+    return 0;
+}

@@ -661,10 +661,11 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
+        /* no fence: finish_call only consumes words the other blocks updated with
+         * device-scope atomics (first_fail, HEAD slot) and control words nobody else writes */
         const unsigned int t = atomicAdd(E.ticket + 1, 1u);
         s_last = (t == gridDim.x * gridDim.y - 1);
-        if (s_last) { E.ticket[1] = 0; __threadfence(); }
+        if (s_last) __hip_atomic_store(E.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (s_last) finish_call(E, r0, R, mode, fmask);

@@ -179,6 +179,78 @@ class Engine:
         if check:
             self.check_status()
 
+    # -- persistent consensus kernel (live / latency path) --------------------------
+    def persist_start(self, idle_ms: int = 2000, peer_ms: int = 200):
+        self._chk(self.L.apus_gpu_persist_start(self.h, idle_ms, peer_ms), "persist_start")
+
+    def persist_submit(self, reqs: np.ndarray, arena: np.ndarray):
+        reqs = np.ascontiguousarray(reqs, dtype=REQ_DTYPE)
+        self._chk(self.L.apus_gpu_persist_submit(self.h, reqs.ctypes.data, len(reqs), arena.ctypes.data, len(arena)),
+                  "persist_submit")
+
+    def persist_prune(self): self._chk(self.L.apus_gpu_persist_prune(self.h), "persist_prune")
+
+    def persist_drain(self, timeout_ms: int = 5000):
+        rc = self.L.apus_gpu_persist_drain(self.h, timeout_ms)
+        if rc != 0:
+            raise EngineError(f"persistent kernel did not drain rc={rc}")
+
+    def persist_highest_rec(self) -> int: return int(self.L.apus_gpu_persist_highest_rec(self.h))
+
+    def persist_stop(self) -> int: return int(self.L.apus_gpu_persist_stop(self.h))
+
+    def persist_latency_ns(self) -> np.ndarray:
+        out = np.zeros(1 << 16, dtype=np.uint32)
+        n = C.c_uint32(0)
+        self._chk(self.L.apus_gpu_persist_latency(self.h, out.ctypes.data, len(out), C.byref(n)), "persist_latency")
+        return out[:n.value].copy()
+
+    def run_trace_persistent(self, trace: Trace, idle_ms: int = 2000, peer_ms: int = 200):
+        """Same events, but the ROUND / PRUNE events go through the persistent kernel's
+        command ring (ELECT, HOLD/RELEASE and QUIESCE stop it and use the phased path)."""
+        reqs = np.ascontiguousarray(trace.reqs, dtype=REQ_DTYPE)
+        arena = np.ascontiguousarray(trace.arena, dtype=np.uint8)
+        running = False
+
+        def stop():
+            nonlocal running
+            if running:
+                self.persist_drain()
+                code = self.persist_stop()
+                running = False
+                if code not in (0,):
+                    raise EngineError(f"persistent kernel exited with code {code}")
+        try:
+            for ev in trace.events:
+                op = ev[0]
+                if op in ("ROUND", "PRUNE"):
+                    if not running:
+                        self.persist_start(idle_ms, peer_ms)
+                        running = True
+                    if op == "ROUND":
+                        self.persist_submit(reqs[ev[1]:ev[1] + ev[2]], arena)
+                    else:
+                        self.persist_prune()
+                    continue
+                stop()
+                if op == "ELECT":
+                    self.elect(ev[1])
+                elif op == "QUIESCE":
+                    self.quiesce()
+                elif op == "HOLD":
+                    self.hold(ev[1])
+                elif op == "RELEASE":
+                    self.release(ev[1])
+                else:
+                    raise EngineError(f"trace event {ev} is not supported")
+        finally:
+            if running:
+                try:
+                    self.persist_stop()
+                except Exception:
+                    pass
+        self.check_status()
+
     # -- graphs -------------------------------------------------------------------
     def capture_begin(self): self._chk(self.L.apus_gpu_capture_begin(self.h), "capture_begin")
 

@@ -155,6 +155,24 @@ int  apus_gpu_commit_live(apus_engine_t *e, int wait_for_commit);
 int  apus_gpu_submit(apus_engine_t *e, const apus_req_t *reqs, uint32_t n,
                      const uint8_t *arena, uint64_t arena_bytes);
 
+/* ---- persistent consensus kernel (the live / latency path) ------------------------
+ * One resident kernel, one workgroup per local replica, runs the dare_server
+ * polling() loop on the device; the host only publishes events into a pinned command
+ * ring and spins on a host-visible highest_rec word (what proxy.c:160 spins on).
+ * While it runs, the phased calls above must not be used.
+ *   idle_ms : the kernel exits by itself after this long without an event
+ *   peer_ms : bound of every device-side wait (ACKs, follower progress)            */
+int  apus_gpu_persist_start(apus_engine_t *e, uint32_t idle_ms, uint32_t peer_ms);
+int  apus_gpu_persist_submit(apus_engine_t *e, const apus_req_t *reqs, uint32_t n,
+                             const uint8_t *arena, uint64_t arena_bytes);   /* rounds of <= 64 */
+int  apus_gpu_persist_prune(apus_engine_t *e);                              /* log_pruning tick */
+int  apus_gpu_persist_drain(apus_engine_t *e, uint32_t timeout_ms);         /* all events consumed */
+uint64_t apus_gpu_persist_highest_rec(apus_engine_t *e);
+const volatile uint64_t *apus_gpu_persist_highest_rec_ptr(apus_engine_t *e);
+int  apus_gpu_persist_stop(apus_engine_t *e);            /* returns the kernel's exit code: 0 stop, 1 idle, 2 timeout */
+int  apus_gpu_persist_latency(apus_engine_t *e, uint32_t *out_ns, uint32_t cap, uint32_t *n_out);
+int  apus_gpu_device_arch(int device, char *out, int cap);
+
 /* hipGraph capture of a sequence of the asynchronous calls above */
 int  apus_gpu_capture_begin(apus_engine_t *e);
 int  apus_gpu_capture_end(apus_engine_t *e, int *graph_id);

@@ -19,7 +19,7 @@ def test_proxy_api_single_app_thread_matches_oracle():
     from oracle import oracle as orc
     from tests.parity import compare_replica
     L = _lib.load(build_if_missing=False)
-    LOG = 1 << 17
+    LOG = 1 << 20
     os.environ.update(server_idx="0", group_size="3", APUS_GPU_LOG_LEN=str(LOG), APUS_PRUNE_PERIOD_MS="100000000")
     L.proxy_init.restype = C.c_void_p
     L.proxy_init.argtypes = [C.c_char_p, C.c_char_p]

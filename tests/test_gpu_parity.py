@@ -24,12 +24,12 @@ def eng_factory():
 
 
 def test_extension_is_loaded_and_device_is_gfx950():
-    import torch
+    import ctypes
     from apus_amd import _lib
-    assert torch.cuda.is_available()
     L = _lib.load(build_if_missing=False)
-    assert L is not None
-    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+    buf = ctypes.create_string_buffer(256)
+    assert L.apus_gpu_device_arch(0, buf, 256) == 0, "no HIP device"
+    assert b"gfx950" in buf.value
 
 
 def test_election_only(eng_factory):
