@@ -169,6 +169,16 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
     const uint64_t L = E.log_len;
     const uint32_t *rf = E.round_first + r0;
 
+    /* control words thread 0 needs later: loaded now so the latency hides behind phase A */
+    uint64_t p_head = 0, p_last_idx = 0, p_sid = 0, p_commit = 0, p_n_commit = 0, p_store = 0;
+    uint32_t p_tlast = 0;
+    const bool pre = gridDim.x == 1;                 /* with several blocks the last one is not known yet */
+    if (tid == 0 && pre) {
+        p_head = hdr[H_HEAD]; p_last_idx = hdr[H_LAST_IDX]; p_sid = hdr[H_SID];
+        p_commit = hdr[H_COMMIT]; p_n_commit = hdr[H_N_COMMIT]; p_store = hdr[H_STORE_COUNT];
+        if (rf[R] > rf[0]) p_tlast = E.req_len[rf[R] - 1];
+    }
+
     /* phase A */
     {
         const uint32_t r = blockIdx.x * blockDim.x + tid;
@@ -257,23 +267,23 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
         if (kstar >= 0 && end_new > L) set_status(E, 1u << 0);      /* second wrap */
         /* free space: the reference only notices end == head exactly (dare_log.h:168) */
         {
-            const uint64_t head = hdr[H_HEAD];
+            const uint64_t head = pre ? p_head : hdr[H_HEAD];
             const uint64_t used = (e0 == L) ? 0 : (e0 >= head ? e0 - head : L - (head - e0));
             const uint64_t waste = (kstar >= 0) ? L - w : 0;
             if (n && e0 != L && vtot + waste >= L - used) set_status(E, 1u << 1);
             if (n && e0 == L && vtot > L) set_status(E, 1u << 1);
         }
-        const uint64_t idx0 = hdr[H_LAST_IDX] + 1;
+        const uint64_t idx0 = (pre ? p_last_idx : hdr[H_LAST_IDX]) + 1;
         SeqOut s;
         s.e0 = e0; s.idx0 = idx0; s.w = w; s.n_end0 = n_end0;
-        s.term = hdr[H_SID] >> 9;
+        s.term = (pre ? p_sid : hdr[H_SID]) >> 9;
         s.kstar = kstar; s.estar = estar; s.stale = stale; s.n = n;
         s.first_fail = ~0ull;
-        s.commit_before = hdr[H_COMMIT];
-        s.n_commit_before = hdr[H_N_COMMIT];
+        s.commit_before = pre ? p_commit : hdr[H_COMMIT];
+        s.n_commit_before = pre ? p_n_commit : hdr[H_N_COMMIT];
         *E.seq = s;
         if (n) {
-            const uint64_t t_last = APUS_HDR + E.req_len[g0 + n - 1];
+            const uint64_t t_last = APUS_HDR + (pre ? p_tlast : E.req_len[g0 + n - 1]);
             hdr[H_END] = end_new;
             hdr[H_TAIL] = end_new - t_last;
             hdr[H_N_END] = n_end0 + n;
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
             /* leader side of persist_new_entries (dare_server.c:1792-1810) */
             hdr[H_OLD_END] = end_new;
             hdr[H_N_PERSIST] = n_end0 + n;
-            hdr[H_STORE_COUNT] += n;
+            hdr[H_STORE_COUNT] = (pre ? p_store : hdr[H_STORE_COUNT]) + n;
         }
         s_kstar = kstar; s_w = w;
     }
@@ -413,14 +423,16 @@ __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0
  * and neither update_remote_logs nor the ACK scan touch the last round.       */
 __device__ static inline uint64_t visible_slots(const EngDev &E, const uint64_t *lhdr, uint64_t r0, uint32_t R)
 {
-    const uint64_t n_end = lhdr[H_N_END];
-    if (lhdr[H_END] != E.log_len) return n_end;
-    const SeqOut &s = *E.seq;
-    if (s.n == 0) return lhdr[H_N_VISIBLE];           /* nothing new: what was visible stays visible */
-    if (R == 0) return s.n_end0;                      /* a control entry landed on len */
-    /* everything before the round that landed on len is visible */
-    const uint32_t *rf = E.round_first + r0;
-    return s.n_end0 + (rf[R - 1] - rf[0]);
+    /* all loads are issued before the first use so that they overlap */
+    const uint64_t n_end = lhdr[H_N_END], end = lhdr[H_END], nvis = lhdr[H_N_VISIBLE];
+    const uint32_t sn = E.seq->n;
+    const uint64_t n_end0 = E.seq->n_end0;
+    uint32_t rfa = 0, rfb = 0;
+    if (R) { rfa = E.round_first[r0]; rfb = E.round_first[r0 + R - 1]; }
+    if (end != E.log_len) return n_end;
+    if (sn == 0) return nvis;                         /* nothing new: what was visible stays visible */
+    if (R == 0) return n_end0;                        /* a control entry landed on len */
+    return n_end0 + (rfb - rfa);                      /* everything before the round that landed on len */
 }
 
 /* commit slot reached by this call on the leader */
@@ -627,18 +639,24 @@ __device__ static inline void finish_call(const EngDev &E, uint64_t r0, uint32_t
         const int f = (int)tid - 1;
         if ((fmask >> f) & 1u) {
             uint64_t *fh = E.rep[f].hdr;
-            if (vis > fh[H_N_PERSIST]) {
-                fh[H_STORE_COUNT] += vis - fh[H_N_PERSIST];
+            /* load first, store afterwards: the loads overlap instead of queueing behind stores */
+            const uint64_t f_np = fh[H_N_PERSIST], f_nc = fh[H_N_COMMIT], f_na = fh[H_N_APPLY];
+            const uint64_t f_sc = fh[H_STORE_COUNT], f_head = fh[H_HEAD], f_end = fh[H_END];
+            const uint64_t hs = __hip_atomic_load((unsigned long long *)&fh[H_HEAD_SLOT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t cs_off = slot_off(cs);
+            uint64_t end_now = f_end;
+            if (vis > f_np) {
+                fh[H_STORE_COUNT] = f_sc + (vis - f_np);
                 fh[H_END] = vis_off; fh[H_OLD_END] = vis_off;
                 fh[H_N_END] = vis; fh[H_N_PERSIST] = vis;
+                end_now = vis_off;
             }
-            if (cs > fh[H_N_COMMIT]) { fh[H_COMMIT] = slot_off(cs); fh[H_N_COMMIT] = cs; }
-            if (cs > fh[H_N_APPLY]) { fh[H_APPLY] = slot_off(cs); fh[H_N_APPLY] = cs; }
-            const uint64_t hs = __hip_atomic_load((unsigned long long *)&fh[H_HEAD_SLOT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cs > f_nc) { fh[H_COMMIT] = cs_off; fh[H_N_COMMIT] = cs; }
+            if (cs > f_na) { fh[H_APPLY] = cs_off; fh[H_N_APPLY] = cs; }
             if (hs) {
                 const uint64_t hoff = E.rep[f].dir_off[(uint32_t)(hs - 1) & E.dir_mask];
                 const uint64_t hv = ld8u(E.rep[f].ring + hoff + 48);
-                if (apus_is_larger(fh[H_END], L, hv, fh[H_HEAD])) fh[H_HEAD] = hv;
+                if (apus_is_larger(end_now, L, hv, f_head)) fh[H_HEAD] = hv;
                 fh[H_HEAD_SLOT] = 0;
             }
         }
@@ -706,28 +724,33 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode,
             }
     }
 
+    /* the leader's control block goes through LDS: one round trip instead of a chain */
+    __shared__ uint64_t s_lh[64];
+    if (tid < 64) s_lh[tid] = hdr[tid];
+    __syncthreads();
     if (tid == 0) {
-        uint64_t end = hdr[H_END];
+        const uint64_t end = s_lh[H_END];
+        uint64_t head = s_lh[H_HEAD];
         bool do_append = (mode != 2);
         if (mode == 1) {
             const uint32_t size = E.group_size;
-            const uint32_t bitmask = (uint32_t)hdr[H_CID_BITMASK];
-            uint64_t min_off = hdr[H_APPLY];
+            const uint32_t bitmask = (uint32_t)s_lh[H_CID_BITMASK];
+            uint64_t min_off = s_lh[H_APPLY];
             for (uint32_t i = 0; i < size; i++) {
-                if (!((bitmask >> i) & 1u)) hdr[H_APPLY_OFFSETS + i] = hdr[H_APPLY];
-                if (apus_is_larger(end, L, min_off, hdr[H_APPLY_OFFSETS + i])) min_off = hdr[H_APPLY_OFFSETS + i];
+                if (!((bitmask >> i) & 1u)) { s_lh[H_APPLY_OFFSETS + i] = s_lh[H_APPLY]; hdr[H_APPLY_OFFSETS + i] = s_lh[H_APPLY]; }
+                if (apus_is_larger(end, L, min_off, s_lh[H_APPLY_OFFSETS + i])) min_off = s_lh[H_APPLY_OFFSETS + i];
             }
-            if (apus_end_distance(end, L, min_off) == 0) min_off = hdr[H_TAIL];   /* leave one entry, :2038-2041 */
-            do_append = apus_is_larger(end, L, min_off, hdr[H_HEAD]) && !hdr[H_PREV_HEAD];
-            if (do_append) { hdr[H_HEAD] = min_off; d0 = min_off; d1 = 0; type = 3; }
+            if (apus_end_distance(end, L, min_off) == 0) min_off = s_lh[H_TAIL];   /* leave one entry, :2038-2041 */
+            do_append = apus_is_larger(end, L, min_off, head) && !s_lh[H_PREV_HEAD];
+            if (do_append) { hdr[H_HEAD] = min_off; head = min_off; d0 = min_off; d1 = 0; type = 3; }
         }
         SeqOut s;
-        s.e0 = end; s.idx0 = hdr[H_LAST_IDX] + 1; s.w = 0; s.n_end0 = hdr[H_N_END];
-        s.term = hdr[H_SID] >> 9; s.kstar = -1; s.estar = -1; s.stale = 0; s.n = 0;
-        s.first_fail = ~0ull; s.commit_before = hdr[H_COMMIT]; s.n_commit_before = hdr[H_N_COMMIT];
-        if (do_append && end == hdr[H_HEAD] && end != L) { set_status(E, 1u << 1); do_append = false; }
+        s.e0 = end; s.idx0 = s_lh[H_LAST_IDX] + 1; s.w = 0; s.n_end0 = s_lh[H_N_END];
+        s.term = s_lh[H_SID] >> 9; s.kstar = -1; s.estar = -1; s.stale = 0; s.n = 0;
+        s.first_fail = ~0ull; s.commit_before = s_lh[H_COMMIT]; s.n_commit_before = s_lh[H_N_COMMIT];
+        if (do_append && end == head && end != L) { set_status(E, 1u << 1); do_append = false; }
         if (do_append) {
-            const uint64_t idx = (end == L) ? 1 : hdr[H_LAST_IDX] + 1;          /* dare_log.h:486-488 */
+            const uint64_t idx = (end == L) ? 1 : s_lh[H_LAST_IDX] + 1;         /* dare_log.h:486-488 */
             const uint64_t pos = (end == L || L - end < APUS_HDR) ? 0 : end;   /* log_add_new_entry, :213-221 */
             if (type != 3) hdr[H_PREV_HEAD] = 0; else if (mode == 1) hdr[H_PREV_HEAD] = 1;
             const uint64_t term = s.term;
@@ -750,20 +773,21 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode,
             hdr[H_LAST_IDX] = idx;
             hdr[H_OLD_END] = pos + APUS_HDR;
             hdr[H_N_PERSIST] = slot + 1;
-            hdr[H_STORE_COUNT] += 1;
+            hdr[H_STORE_COUNT] = s_lh[H_STORE_COUNT] + 1;
             s.n = 1;
             const uint64_t rec_base = *E.rec_count;
             if (rec_base < E.rec_cap) E.rec_end[rec_base] = pos + APUS_HDR;
         }
         *E.seq = s;
-        if (mode == 1) {
-            /* READ the apply offset of every reachable peer for the next tick */
-            const uint32_t bitmask = (uint32_t)hdr[H_CID_BITMASK];
-            for (uint32_t i = 0; i < E.group_size; i++) {
-                if (i == E.leader || !((bitmask >> i) & 1u)) { hdr[H_APPLY_OFFSETS + i] = hdr[H_APPLY]; continue; }
-                if (!((sample_mask >> i) & 1u)) continue;
-                hdr[H_APPLY_OFFSETS + i] = E.rep[i].hdr[H_APPLY];
-            }
+    }
+    if (mode == 1 && tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS) {
+        /* READ the apply offset of every reachable peer for the next tick
+         * (rc_get_remote_apply_offsets, dare_ibv_rc.c:1970-2034), one lane per peer */
+        const uint32_t i = tid - 64;
+        const uint32_t bitmask = (uint32_t)s_lh[H_CID_BITMASK];
+        if (i < E.group_size) {
+            if (i == E.leader || !((bitmask >> i) & 1u)) hdr[H_APPLY_OFFSETS + i] = s_lh[H_APPLY];
+            else if ((sample_mask >> i) & 1u) hdr[H_APPLY_OFFSETS + i] = E.rep[i].hdr[H_APPLY];
         }
     }
     __syncthreads();
