@@ -48,6 +48,13 @@ SIGNATURES = {
     "apus_gpu_bind_global": (C.c_int, [vp]),
     "apus_gpu_global": (vp, []),
     "apus_gpu_device_arch": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "apus_gpu_follow": (C.c_int, [vp, u32, u32, u64, u32]),
+    "apus_gpu_append_rounds": (C.c_int, [vp, u64, u64]),
+    "apus_gpu_commit_rounds": (C.c_int, [vp, u64, u64]),
+    "apus_gpu_ship_info": (C.c_int, [vp, C.POINTER(u64)]),
+    "apus_gpu_ingest": (C.c_int, [vp, u32, u64, u64]),
+    "apus_gpu_ack_merge": (C.c_int, [vp, u32, u64, u64]),
+    "apus_gpu_follower_commit": (C.c_int, [vp, u32, u64, u64]),
     "apus_gpu_persist_start": (C.c_int, [vp, u32, u32]),
     "apus_gpu_persist_submit": (C.c_int, [vp, vp, u32, vp, u64]),
     "apus_gpu_persist_prune": (C.c_int, [vp]),

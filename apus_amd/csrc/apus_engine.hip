@@ -848,3 +848,94 @@ extern "C" int apus_gpu_device_arch(int device, char *out, int cap)
     snprintf(out, cap, "%s", p.gcnArchName);
     return 0;
 }
+
+
+/* ---- multi-process groups: one replica per GPU / process ------------------------ */
+/* follower process: adopt the leader's SID (heartbeat, dare_server.c:822-920) */
+__global__ void k_follow(const EngDev E, uint32_t f, uint64_t sid, uint32_t bitmask)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    uint64_t *fh = E.rep[f].hdr;
+    fh[H_SID] = sid; fh[H_TAIL] = E.log_len; fh[H_CID_BITMASK] = bitmask;
+}
+
+extern "C" int apus_gpu_follow(apus_engine_t *e, uint32_t replica, uint32_t leader, uint64_t term, uint32_t bitmask)
+{
+    int rc = local_rep(e, replica);
+    if (rc) return rc;
+    if (leader >= e->d.group_size || leader == replica) return APUS_E_ARG;
+    e->d.leader = leader;
+    hipLaunchKernelGGL(k_follow, dim3(1), dim3(64), 0, e->stream, e->d, replica,
+                       (term << 9) | (1ull << 8) | leader, bitmask);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+/* leader: get_tailq_message + log_append_entry only (the tail follows after the ACKs came back) */
+extern "C" int apus_gpu_append_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rounds)
+{
+    int rc = need_leader(e);
+    if (rc) return rc;
+    if (r0 + n_rounds > e->n_rounds_staged || n_rounds > e->max_rounds || n_rounds == 0) return APUS_E_ARG;
+    return launch_append(e, e->d, r0, (uint32_t)n_rounds);
+}
+
+extern "C" int apus_gpu_commit_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rounds)
+{
+    int rc = need_leader(e);
+    if (rc) return rc;
+    if (r0 + n_rounds > e->n_rounds_staged || n_rounds == 0) return APUS_E_ARG;
+    const uint64_t n = e->h_round_first[r0 + n_rounds] - e->h_round_first[r0];
+    return launch_tail(e, r0, (uint32_t)n_rounds, 0, n);
+}
+
+/* out[8] = end offset before the append, end after, slot before, slot after,
+ *          visible slot (== slot after unless the batch ended exactly on len), kstar >= 0,
+ *          leader commit slot, leader commit offset   (synchronises) */
+extern "C" int apus_gpu_ship_info(apus_engine_t *e, uint64_t out[8])
+{
+    int rc = need_leader(e);
+    if (rc) return rc;
+    SeqOut s;
+    uint64_t h[64];
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(&s, e->d.seq, sizeof s, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h, e->d.rep[e->d.leader].hdr, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = s.e0; out[1] = h[H_END]; out[2] = s.n_end0; out[3] = h[H_N_END];
+    out[4] = (h[H_END] == e->d.log_len) ? s.n_end0 : h[H_N_END];
+    out[5] = s.kstar >= 0 ? 1 : 0;
+    out[6] = h[H_N_COMMIT]; out[7] = h[H_COMMIT];
+    return 0;
+}
+
+extern "C" int apus_gpu_ingest(apus_engine_t *e, uint32_t replica, uint64_t vis_slot, uint64_t n_hint)
+{
+    int rc = local_rep(e, replica);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mp_ingest, dim3(cap_grid(n_hint ? n_hint : 1, 256, 1024)), dim3(256), 0, e->stream, e->d, replica, vis_slot);
+    hipLaunchKernelGGL(k_mp_ingest_fin, dim3(1), dim3(64), 0, e->stream, e->d, replica, vis_slot);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int apus_gpu_ack_merge(apus_engine_t *e, uint32_t follower, uint64_t from_slot, uint64_t upto_slot)
+{
+    int rc = need_leader(e);
+    if (rc) return rc;
+    if (follower >= e->d.group_size || upto_slot < from_slot) return APUS_E_ARG;
+    if (upto_slot == from_slot) return 0;
+    hipLaunchKernelGGL(k_mp_ack_merge, dim3(cap_grid(upto_slot - from_slot, 256, 1024)), dim3(256), 0, e->stream,
+                       e->d, follower, from_slot, upto_slot);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int apus_gpu_follower_commit(apus_engine_t *e, uint32_t replica, uint64_t commit_slot, uint64_t n_hint)
+{
+    int rc = local_rep(e, replica);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mp_apply, dim3(cap_grid(n_hint ? n_hint : 1, 256, 1024)), dim3(256), 0, e->stream, e->d, replica, commit_slot);
+    hipLaunchKernelGGL(k_mp_apply_fin, dim3(1), dim3(64), 0, e->stream, e->d, replica, commit_slot);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

@@ -805,6 +805,74 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode,
     finish_call(E, 0, 0, mode == 2 ? 2 : 1, push_mask);
 }
 
+/* ------------------------------------------------------------------------- */
+/* Multi-process groups (one replica per GPU): the byte range and the directory
+ * slots travel by RCCL point-to-point between processes (apus_amd/distributed.py);
+ * these kernels are the device halves on either side of that exchange.           */
+
+/* follower: the entries of slots [n_persist, vis) have landed in ring + directory:
+ * persist_new_entries + the local half of rc_send_entries_reply (own reply byte);
+ * the ACK itself goes back to the leader as one cumulative slot number.           */
+__global__ __launch_bounds__(256) void k_mp_ingest(const EngDev E, uint32_t f, uint64_t vis)
+{
+    const RepDev &Fd = E.rep[f];
+    const uint64_t from = Fd.hdr[H_N_PERSIST];
+    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < vis; s += nth) {
+        const uint32_t di = (uint32_t)s & E.dir_mask;
+        Fd.ring[Fd.dir_off[di] + 28 + f] = 1;
+    }
+}
+
+__global__ void k_mp_ingest_fin(const EngDev E, uint32_t f, uint64_t vis)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    uint64_t *fh = E.rep[f].hdr;
+    const uint64_t np = fh[H_N_PERSIST];
+    if (vis <= np) return;
+    const uint32_t dl = (uint32_t)(vis - 1) & E.dir_mask;
+    const uint64_t end = E.rep[f].dir_off[dl] + (E.rep[f].dir_len[dl] & 0xFFFFFFu);
+    fh[H_STORE_COUNT] += vis - np;
+    fh[H_END] = end; fh[H_OLD_END] = end; fh[H_N_END] = vis; fh[H_N_PERSIST] = vis;
+}
+
+/* leader: follower f acknowledged every entry below `upto` (R3 for a whole range):
+ * reply byte in the leader's ring + ACK bit in the slot word                       */
+__global__ __launch_bounds__(256) void k_mp_ack_merge(const EngDev E, uint32_t f, uint64_t from, uint64_t upto)
+{
+    const RepDev &Ld = E.rep[E.leader];
+    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < upto; s += nth) {
+        const uint32_t di = (uint32_t)s & E.dir_mask;
+        Ld.ring[Ld.dir_off[di] + 28 + f] = 1;
+        atomicOr(&Ld.ack[di], 1u << f);
+    }
+}
+
+/* follower: the leader's commit (R4) reached slot cs: apply_committed_entries */
+__global__ __launch_bounds__(256) void k_mp_apply(const EngDev E, uint32_t f, uint64_t cs)
+{
+    __shared__ unsigned long long s_acc[2];
+    apply_range(E, (int)f, cs, (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_acc);
+}
+
+__global__ void k_mp_apply_fin(const EngDev E, uint32_t f, uint64_t cs)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const RepDev &Fd = E.rep[f];
+    uint64_t *fh = Fd.hdr;
+    if (cs > fh[H_N_PERSIST]) cs = fh[H_N_PERSIST];
+    const uint64_t coff = (cs == fh[H_N_END]) ? fh[H_END] : Fd.dir_off[(uint32_t)cs & E.dir_mask];
+    if (cs > fh[H_N_COMMIT]) { fh[H_COMMIT] = coff; fh[H_N_COMMIT] = cs; }
+    if (cs > fh[H_N_APPLY]) { fh[H_APPLY] = coff; fh[H_N_APPLY] = cs; }
+    const uint64_t hs = fh[H_HEAD_SLOT];
+    if (hs) {
+        const uint64_t hv = ld8u(Fd.ring + Fd.dir_off[(uint32_t)(hs - 1) & E.dir_mask] + 48);
+        if (apus_is_larger(fh[H_END], E.log_len, hv, fh[H_HEAD])) fh[H_HEAD] = hv;
+        fh[H_HEAD_SLOT] = 0;
+    }
+}
+
 /* k_reset: log_new() (dare_log.h:120-136) without touching the ring bytes that
  * were never made visible; the host memsets rings separately when asked to.   */
 __global__ void k_reset(const EngDev E)

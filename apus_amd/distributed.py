@@ -1,0 +1,365 @@
+"""One replica per GPU / process: the quorum round over RCCL point-to-point.
+
+Replaces the reference's RDMA data plane (src/dare/dare_ibv_rc.c) between
+processes.  Rank r hosts replica r on its own GPU; rank `leader` runs the leader
+half of the engine, every other rank a follower half.  Per leader batch:
+
+    R1  WRITE log bytes  [follower end, leader end)  -> send of the ring range
+        (a wrapped range is two pieces, like the two WRs of dare_ibv_rc.c:1538-1545)
+        plus the matching directory slots (derived data, 12 B per entry)
+    R2  WRITE end                                     -> the header of that message
+    R3  1-byte ACK per entry (rc_send_entries_reply)  -> ONE cumulative slot number
+        per follower and batch; the leader expands it into reply bytes + ACK bits
+        (apus_gpu_ack_merge) so that the ACK scan reads the same words as always
+    R4  lazy WRITE commit (dare_ibv_rc.c:1761-1819)   -> piggy-backed on the next header
+    R8  READ apply offset (rc_get_remote_apply_offsets) -> rides on the ACK reply
+
+`backend="nccl"` is RCCL: device tensors that alias the HBM rings are sent
+directly (xGMI peer-to-peer, no staging).  `backend="gloo"` stages through host
+memory and exists for the CPU/one-GPU tests.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .engine import Engine, EngineError
+from .trace import DEFAULT_LOG
+
+OP_DATA, OP_STOP = 1, 2
+HDR_WORDS, REPLY_WORDS = 16, 4
+H_APPLY_OFFSETS = 23          # apus_device.h
+
+
+class _DevMem:
+    """Zero-copy torch view of engine-owned device memory."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def device_view(eng: Engine, replica: int, which: int, device) -> torch.Tensor:
+    ptr, nb = eng.device_ptr(replica, which)
+    return torch.as_tensor(_DevMem(ptr, nb), device=device)
+
+
+def ring_pieces(frm: int, to: int, length: int):
+    """Byte pieces of the circular range [frm, to) of a ring of `length` bytes."""
+    if frm == length:
+        frm = 0
+    if to == frm:
+        return []
+    if to > frm:
+        return [(frm, to)]
+    return [(frm, length), (0, to)] if to > 0 else [(frm, length)]
+
+
+def slot_pieces(s0: int, s1: int, cap: int):
+    """Index pieces of directory slots [s0, s1) in a directory ring of `cap` slots."""
+    out = []
+    while s0 < s1:
+        i = s0 % cap
+        n = min(s1 - s0, cap - i)
+        out.append((i, i + n))
+        s0 += n
+    return out
+
+
+class Transport:
+    """send/recv of byte tensors that may live on the GPU."""
+
+    def __init__(self, backend: str, device):
+        self.backend = backend
+        self.device = device
+        self.direct = backend == "nccl"
+
+    def _meta(self, words):
+        t = torch.tensor(words, dtype=torch.int64)
+        return t.to(self.device) if self.direct else t
+
+    def send_words(self, words, dst):
+        dist.send(self._meta(words), dst)
+
+    def recv_words(self, n, src):
+        t = torch.zeros(n, dtype=torch.int64, device=self.device if self.direct else "cpu")
+        dist.recv(t, src)
+        return [int(v) for v in t.cpu().tolist()]
+
+    def send_bytes(self, t: torch.Tensor, dst):
+        dist.send(t if self.direct else t.cpu(), dst)
+
+    def recv_bytes(self, view: torch.Tensor, src):
+        if self.direct or view.device.type == "cpu":
+            dist.recv(view, src)
+        else:
+            tmp = torch.empty(view.shape, dtype=view.dtype)
+            dist.recv(tmp, src)
+            view.copy_(tmp)
+
+
+def ship_range(tp: Transport, dst: int, ring, dir_off, dir_len, o0: int, o1: int, s0: int, s1: int,
+               log_len: int, dir_cap: int, commit_slot: int, term: int):
+    """Leader side of R1+R2 for one follower: header, ring pieces, directory pieces.
+    ring / dir_off / dir_len are byte tensors (device or host)."""
+    pieces = ring_pieces(o0, o1, log_len) if s1 > s0 else []
+    tp.send_words([OP_DATA, o0, o1, s0, s1 if s1 > s0 else s0, commit_slot, term, len(pieces)] + [0] * 8, dst)
+    for a, b in pieces:
+        tp.send_bytes(ring[a:b], dst)
+    if s1 > s0:
+        for a, b in slot_pieces(s0, s1, dir_cap):
+            tp.send_bytes(dir_off[8 * a:8 * b], dst)
+            tp.send_bytes(dir_len[4 * a:4 * b], dst)
+
+
+def recv_range(tp: Transport, src: int, ring, dir_off, dir_len, o0: int, o1: int, s0: int, s1: int,
+               log_len: int, dir_cap: int):
+    """Follower side: the bytes land at the same offsets of the local ring / directory."""
+    for a, b in ring_pieces(o0, o1, log_len):
+        tp.recv_bytes(ring[a:b], src)
+    for a, b in slot_pieces(s0, s1, dir_cap):
+        tp.recv_bytes(dir_off[8 * a:8 * b], src)
+        tp.recv_bytes(dir_len[4 * a:4 * b], src)
+
+
+class GroupMember:
+    """The replica hosted by this rank, plus its share of the exchange."""
+
+    def __init__(self, group_size: int, rank: int, leader: int, device_index: int, backend: str,
+                 log_len: int = DEFAULT_LOG):
+        self.n, self.rank, self.leader = group_size, rank, leader
+        self.device = torch.device("cuda", device_index)
+        self.eng = Engine(group_size, log_len, local_ids=[rank], device=device_index)
+        self.log_len = log_len
+        self.tp = Transport(backend, self.device)
+        self.ring = device_view(self.eng, rank, 0, self.device)
+        self.dir_off = device_view(self.eng, rank, 2, self.device)
+        self.dir_len = device_view(self.eng, rank, 3, self.device)
+        self.dir_cap = self.dir_len.numel() // 4
+        self.is_leader = rank == leader
+        self.followers = [r for r in range(group_size) if r != leader]
+        # leader-side view of every follower
+        self.shipped_slot = {f: 0 for f in self.followers}
+        self.shipped_off = {f: log_len for f in self.followers}     # log_len == empty
+        self.acked = {f: 0 for f in self.followers}
+        self.term = 0
+
+    # ---------------------------------------------------------------- leader
+    def elect(self):
+        self.term += 2
+        mask = (1 << self.n) - 1
+        if self.is_leader:
+            self.eng.elect(self.leader)            # sets term, blank CONFIG entry
+        else:
+            self.eng.term = self.term
+            self.eng._chk(self.eng.L.apus_gpu_follow(self.eng.h, self.rank, self.leader, self.term, mask), "follow")
+
+    def _leader_state(self):
+        out = (C.c_uint64 * 8)()
+        self.eng._chk(self.eng.L.apus_gpu_ship_info(self.eng.h, out), "ship_info")
+        end, n_end, vis = int(out[1]), int(out[3]), int(out[4])
+        o = self.eng.offsets(self.rank)
+        c = self.eng.counters(self.rank)
+        if o["end"] == self.log_len:
+            vis = int(self.eng.hdr_words(self.rank)[22])      # H_N_VISIBLE: nothing new is visible
+        else:
+            vis = c["n_end"]
+        if vis == c["n_end"]:
+            vis_off = o["end"]
+        else:
+            i = vis % self.dir_cap
+            vis_off = int(self.dir_off.view(torch.int64)[i].item())
+        return vis, vis_off, c["n_commit"], o
+
+    def sync_followers(self):
+        """Ship what the followers lack (R1+R2), collect the ACKs (R3), merge them."""
+        vis, vis_off, n_commit, _ = self._leader_state()
+        for f in self.followers:
+            s0, o0 = self.shipped_slot[f], self.shipped_off[f]
+            ship_range(self.tp, f, self.ring, self.dir_off, self.dir_len, o0, vis_off, s0, vis,
+                       self.log_len, self.dir_cap, n_commit, self.term)
+            if vis > s0:
+                self.shipped_slot[f], self.shipped_off[f] = vis, vis_off
+        replies = {}
+        for f in self.followers:
+            r = self.tp.recv_words(REPLY_WORDS, f)
+            replies[f] = r
+            if r[0] > self.acked[f]:
+                self.eng._chk(self.eng.L.apus_gpu_ack_merge(self.eng.h, f, self.acked[f], r[0]), "ack_merge")
+                self.acked[f] = r[0]
+        return replies
+
+    def leader_rounds(self, r0: int, n_rounds: int):
+        self.eng._chk(self.eng.L.apus_gpu_append_rounds(self.eng.h, r0, n_rounds), "append_rounds")
+        self.sync_followers()
+        self.eng._chk(self.eng.L.apus_gpu_commit_rounds(self.eng.h, r0, n_rounds), "commit_rounds")
+
+    def leader_quiesce(self):
+        """Followers learn the newest commit and apply it (the lazy R4 made eager)."""
+        self.sync_followers()
+        self.eng.quiesce()
+        return self.sync_followers()
+
+    def leader_prune(self):
+        replies = self.leader_quiesce()
+        self.eng.tick_prune()                                  # decision + maybe a HEAD entry
+        # R8: the apply offsets just read become the input of the next tick
+        hdr_ptr, _ = self.eng.device_ptr(self.rank, 1)
+        hdr = torch.as_tensor(_DevMem(hdr_ptr, 64 * 8), device=self.device).view(torch.int64)
+        for f, r in replies.items():
+            hdr[H_APPLY_OFFSETS + f] = r[2]
+        self.sync_followers()                                  # ship the HEAD entry, if any
+        self.eng.quiesce()
+
+    def leader_stop(self):
+        for f in self.followers:
+            self.tp.send_words([OP_STOP] + [0] * (HDR_WORDS - 1), f)
+
+    # -------------------------------------------------------------- follower
+    def follower_serve(self):
+        """Serve the leader until it says stop."""
+        eng, L = self.eng, self.eng.L
+        while True:
+            h = self.tp.recv_words(HDR_WORDS, self.leader)
+            if h[0] == OP_STOP:
+                return
+            _, o0, o1, s0, s1, commit, term, npieces = h[:8]
+            if s1 > s0:
+                recv_range(self.tp, self.leader, self.ring, self.dir_off, self.dir_len, o0, o1, s0, s1,
+                           self.log_len, self.dir_cap)
+                eng._chk(L.apus_gpu_ingest(eng.h, self.rank, s1, s1 - s0), "ingest")
+            eng._chk(L.apus_gpu_follower_commit(eng.h, self.rank, commit, max(s1 - s0, 1)), "follower_commit")
+            o = eng.offsets(self.rank)                 # synchronises: the ACK means "persisted"
+            c = eng.counters(self.rank)
+            self.tp.send_words([c["n_persist"], c["n_apply"], o["apply"], eng.status()], self.leader)
+
+    def close(self):
+        self.eng.close()
+
+
+# ------------------------------------------------------------------------------------
+def run_trace_group(member: GroupMember, trace):
+    """Drive one trace through a multi-process group (steady-state events)."""
+    if member.is_leader:
+        member.eng.stage_trace(trace)
+    member.elect()
+    if not member.is_leader:
+        member.follower_serve()
+        return
+    member.sync_followers()            # the blank CONFIG entry
+    member.eng.quiesce()
+    ev, i = trace.events, 0
+    while i < len(ev):
+        if ev[i][0] == "ROUND":
+            j = i
+            while j < len(ev) and ev[j][0] == "ROUND":
+                j += 1
+            member.leader_rounds(member.eng.round_of_g0[ev[i][1]], j - i)
+            i = j
+            continue
+        if ev[i][0] == "PRUNE":
+            member.leader_prune()
+        elif ev[i][0] == "QUIESCE":
+            member.leader_quiesce()
+        elif ev[i][0] != "ELECT":
+            raise EngineError(f"{ev[i]} is not supported in multi-process groups yet")
+        i += 1
+    member.leader_quiesce()
+    member.leader_stop()
+
+
+def bench_group(args):
+    """bench.py --gpus N (N >= 2): N replicas, one per GPU, over RCCL p2p."""
+    from . import trace as T
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    n = world
+    tr = T.steady_trace(n, args.entries, args.payload, 16, args.batch, log_len=T.DEFAULT_LOG, name="C2")
+    m = GroupMember(n, rank, 0, local, "nccl", tr.log_len)
+    calls = None
+    if m.is_leader:
+        m.eng.stage_trace(tr)
+        ev, i, calls = tr.events, 0, []
+        while i < len(ev):
+            if ev[i][0] == "ROUND":
+                j = i
+                while j < len(ev) and ev[j][0] == "ROUND":
+                    j += 1
+                calls.append(("rounds", m.eng.round_of_g0[ev[i][1]], j - i))
+                i = j
+                continue
+            if ev[i][0] == "PRUNE":
+                calls.append(("prune",))
+            i += 1
+    m.elect()
+
+    def leader_step():
+        for c in calls:
+            if c[0] == "rounds":
+                m.leader_rounds(c[1], c[2])
+            else:
+                m.leader_prune()
+        m.leader_quiesce()
+
+    sync_t = torch.zeros(1, device=m.device)
+    if m.is_leader:
+        m.sync_followers()
+        m.eng.quiesce()
+        for _ in range(args.warmup):
+            leader_step()
+        m.eng.sync()
+        # followers are in follower_serve(); the timed region is bracketed on the leader,
+        # whose every step ends with a quiesce that waits for all followers' replies
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            leader_step()
+        m.eng.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        m.leader_stop()
+    else:
+        m.follower_serve()
+        m.eng.sync()
+        dt = 0.0
+    # barrier + max over ranks (followers finish when the leader's last quiesce returned)
+    t = torch.tensor([dt], dtype=torch.float64, device=m.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    n_entries = len(tr.reqs)
+    ok = torch.ones(1, device=m.device)
+    o = m.eng.offsets(rank)
+    total = (args.warmup + args.steps) * n_entries
+    applied = m.eng.counters(rank)["highest_rec"] if m.is_leader else int(m.eng.hdr_words(rank)[16])
+    if not (o["commit"] == o["end"] == o["apply"]) or applied != total or m.eng.status():
+        ok.zero_()
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    out = None
+    if rank == 0:
+        E = 64 + args.payload
+        value = n_entries * args.steps / dt
+        out = {
+            "metric": "committed entries/sec", "value": value, "unit": "entries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{n} replicas, one per GPU (RCCL p2p over xGMI), {n_entries} entries/step "
+                                   f"of {args.payload} B, rounds of {args.batch}, prune tick every 8 MiB",
+                       "mode": "one process per replica GPU", "replicas": n, "entry_bytes": E},
+            "verified": bool(ok.item() == 1),
+            "roofline": {"bound": "xgmi", "achieved": value * E / 1e9, "peak": 153.0, "unit": "GB/s",
+                         "frac": value * E / 1e9 / 153.0, "traffic": None,
+                         "note": "per leader->follower link: entries/s x E against one xGMI link (SURVEY.md 8d)"},
+        }
+    m.close()
+    dist.destroy_process_group()
+    return out

@@ -173,6 +173,19 @@ int  apus_gpu_persist_stop(apus_engine_t *e);            /* returns the kernel's
 int  apus_gpu_persist_latency(apus_engine_t *e, uint32_t *out_ns, uint32_t cap, uint32_t *n_out);
 int  apus_gpu_device_arch(int device, char *out, int cap);
 
+/* ---- multi-process groups: one replica per GPU / process --------------------------
+ * The leader's new log range [end before, end after) and the matching directory
+ * slots travel between processes by RCCL point-to-point (apus_amd/distributed.py);
+ * these are the device halves on either side (R1/R2: ingest, R3: ack_merge,
+ * R4: follower_commit). */
+int  apus_gpu_follow(apus_engine_t *e, uint32_t replica, uint32_t leader, uint64_t term, uint32_t bitmask);
+int  apus_gpu_append_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rounds);   /* leader: append only */
+int  apus_gpu_commit_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rounds);   /* leader: ACK scan, commit, apply */
+int  apus_gpu_ship_info(apus_engine_t *e, uint64_t out[8]);
+int  apus_gpu_ingest(apus_engine_t *e, uint32_t replica, uint64_t vis_slot, uint64_t n_hint);
+int  apus_gpu_ack_merge(apus_engine_t *e, uint32_t follower, uint64_t from_slot, uint64_t upto_slot);
+int  apus_gpu_follower_commit(apus_engine_t *e, uint32_t replica, uint64_t commit_slot, uint64_t n_hint);
+
 /* hipGraph capture of a sequence of the asynchronous calls above */
 int  apus_gpu_capture_begin(apus_engine_t *e);
 int  apus_gpu_capture_end(apus_engine_t *e, int *graph_id);
