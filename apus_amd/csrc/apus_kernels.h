@@ -474,6 +474,52 @@ __global__ __launch_bounds__(256) void k_persist_ack(const EngDev E, uint64_t r0
     persist_ack_range(E, f, vis, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
 }
 
+/* k_persist_commit: when the followers live on this device, one lane handles one
+ * entry slot for ALL of them -- follower persist + ACK (reply byte in both rings, ACK
+ * bit) -- and, since the lane then holds the slot's complete ACK word, the quorum test
+ * of update_remote_logs (dare_ibv_rc.c:1725-1758) right away:
+ * popcount(ack | self) >= size/2+1 per lane, wave ballot, first slot without a majority. */
+__global__ __launch_bounds__(256) void k_persist_commit(const EngDev E, uint64_t r0, uint32_t R, uint32_t fmask)
+{
+    const RepDev &Ld = E.rep[E.leader];
+    const uint64_t *lh = Ld.hdr;
+    const uint64_t vis = visible_slots(E, lh, r0, R);
+    uint64_t lo = lh[H_N_COMMIT];
+    for (uint32_t m = fmask; m; m &= m - 1) lo = min(lo, E.rep[__builtin_ctz(m)].hdr[H_N_PERSIST]);
+    const uint32_t size = E.group_size, size_mask = (1u << size) - 1, quorum = size / 2 + 1;
+    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t tile = lo + (uint64_t)blockIdx.x * blockDim.x; tile < vis; tile += nth) {
+        const uint64_t s = tile + threadIdx.x;
+        const bool in = s < vis;
+        bool ok = true;
+        if (in) {
+            const uint32_t di = (uint32_t)s & E.dir_mask;
+            uint32_t bits = 0, sender = E.leader;
+            for (uint32_t m = fmask; m; m &= m - 1) {
+                const int f = __builtin_ctz(m);
+                const RepDev &Fd = E.rep[f];
+                if (s < Fd.hdr[H_N_PERSIST]) continue;               /* this follower persisted it earlier */
+                const uint64_t off = Fd.dir_off[di];                 /* the follower reads its own log */
+                sender = Fd.dir_len[di] >> 24;                       /* entry->sender, dare_server.c:1806 */
+                Fd.ring[off + 28 + f] = 1;                           /* local reply byte, dare_ibv_rc.c:1840 */
+                if (sender < APUS_DEV_MAX_SERVERS && E.rep[sender].ring)
+                    E.rep[sender].ring[off + 28 + f] = 1;            /* R3: 1-byte WRITE at the same offset */
+                bits |= 1u << f;
+            }
+            uint32_t word;
+            if (bits && sender == E.leader) word = atomicOr(&Ld.ack[di], bits) | bits;
+            else word = __hip_atomic_load(&Ld.ack[di], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t mm = (word | (1u << E.leader)) & size_mask;
+            ok = (s < lh[H_N_COMMIT]) || (uint32_t)__popc(mm) >= quorum;   /* replies >= size/2+1, :1738 */
+        }
+        const unsigned long long bal = __ballot(!ok);
+        if (bal && lane_id() == 0) {
+            const uint64_t first = s + (uint64_t)__builtin_ctzll(bal);
+            atomicMin((unsigned long long *)&E.seq->first_fail, (unsigned long long)first);
+        }
+    }
+}
+
 /* The ACK scan of update_remote_logs (dare_ibv_rc.c:1725-1758) over slots
  * [from, vis): ACK words staged in LDS, one lane per entry,
  * popcount(ack | self) >= size/2+1, wave ballot, first slot without a majority.
@@ -561,6 +607,49 @@ __device__ static inline void apply_range(const EngDev &E, int p, uint64_t cs, u
 }
 
 
+/* per-round commit record of rounds [r0, r0+R) of this call, one thread per round;
+ * every block of k_apply takes a slice (gtid over gthreads)                        */
+__device__ static inline void finish_records(const EngDev &E, uint64_t r0, uint32_t R, uint64_t cs,
+                                             uint64_t gtid, uint64_t gthreads)
+{
+    const RepDev &Ld = E.rep[E.leader];
+    const uint64_t L = E.log_len;
+    const SeqOut s = *E.seq;
+    const uint64_t rec_base = *E.rec_count;
+    const uint32_t *rf = E.round_first + r0;
+    for (uint64_t r = gtid; r < R; r += gthreads) {
+        if (rec_base + r >= E.rec_cap) break;
+        const uint64_t slot_end_r = s.n_end0 + (rf[r + 1] - rf[0]);
+        const uint64_t slot_start_r = s.n_end0 + (rf[r] - rf[0]);
+        const uint64_t c = min(cs, slot_end_r);
+        const uint64_t end_r = E.rec_end[rec_base + r];
+        uint64_t cr;
+        if (c <= s.n_commit_before) cr = s.commit_before;
+        else if (c == slot_end_r) cr = end_r;
+        else cr = Ld.dir_off[(uint32_t)c & E.dir_mask];
+        /* Reference quirk (dare_ibv_rc.c:1725-1758): when a polling() pass starts with the
+         * commit pointer parked at the wrap position X (everything before is committed, the
+         * pass's first entry wrapped to offset 0), the first scan redirects to offset 0, finds
+         * no ACKs yet, and "commits" offset 0 -- the same position, but log_is_offset_larger(0, X)
+         * holds, `committed` is set and rc_write_remote_logs returns before the followers
+         * were brought up to date.  That pass therefore ends with commit == 0. */
+        if (s.kstar >= 0 && (int64_t)(rf[r] - rf[0]) == s.kstar && s.w < L && cs >= slot_start_r &&
+            (r ? true : s.commit_before == s.e0))
+            cr = 0;
+        /* a round that ended exactly on len could not commit: the log read as empty
+         * (dare_log.h:158), the leader's scan saw distance 0 (dare_ibv_rc.c:1726) */
+        if (end_r == L) {
+            if (r == 0) cr = s.commit_before;
+            else {
+                const uint64_t pe = E.rec_end[rec_base + r - 1];
+                const uint64_t pc = min(cs, slot_start_r);
+                cr = (pc <= s.n_commit_before) ? s.commit_before : (pc == slot_start_r ? pe : Ld.dir_off[(uint32_t)pc & E.dir_mask]);
+            }
+        }
+        E.rec_commit[rec_base + r] = cr;
+    }
+}
+
 /* Scalar bookkeeping of a call (all threads of one block).  mode 0: R staged
  * rounds; mode 1: one control-entry round (s.n tells whether it happened);
  * mode 2: quiesce.                                                              */
@@ -586,40 +675,6 @@ __device__ static inline void finish_call(const EngDev &E, uint64_t r0, uint32_t
     const uint64_t rec_base = *E.rec_count;
     __syncthreads();                                  /* everybody sampled the control words */
 
-    if (mode == 0) {
-        const uint32_t *rf = E.round_first + r0;
-        for (uint32_t r = tid; r < R; r += nth) {
-            if (rec_base + r >= E.rec_cap) break;
-            const uint64_t slot_end_r = s.n_end0 + (rf[r + 1] - rf[0]);
-            const uint64_t slot_start_r = s.n_end0 + (rf[r] - rf[0]);
-            const uint64_t c = min(cs, slot_end_r);
-            const uint64_t end_r = E.rec_end[rec_base + r];
-            uint64_t cr;
-            if (c <= s.n_commit_before) cr = s.commit_before;
-            else if (c == slot_end_r) cr = end_r;
-            else cr = Ld.dir_off[(uint32_t)c & E.dir_mask];
-            /* Reference quirk (dare_ibv_rc.c:1725-1758): when a polling() pass starts with the
-             * commit pointer parked at the wrap position X (everything before is committed, the
-             * pass's first entry wrapped to offset 0), the first scan redirects to offset 0, finds
-             * no ACKs yet, and "commits" offset 0 -- the same position, but log_is_offset_larger(0, X)
-             * holds, `committed` is set and rc_write_remote_logs returns before the followers
-             * were brought up to date.  That pass therefore ends with commit == 0. */
-            if (s.kstar >= 0 && (int64_t)(rf[r] - rf[0]) == s.kstar && s.w < L && cs >= slot_start_r &&
-                (r ? true : s.commit_before == s.e0))
-                cr = 0;
-            /* a round that ended exactly on len could not commit: the log read as empty
-             * (dare_log.h:158), the leader's scan saw distance 0 (dare_ibv_rc.c:1726) */
-            if (end_r == L) {
-                if (r == 0) cr = s.commit_before;
-                else {
-                    const uint64_t pe = E.rec_end[rec_base + r - 1];
-                    const uint64_t pc = min(cs, slot_start_r);
-                    cr = (pc <= s.n_commit_before) ? s.commit_before : (pc == slot_start_r ? pe : Ld.dir_off[(uint32_t)pc & E.dir_mask]);
-                }
-            }
-            E.rec_commit[rec_base + r] = cr;
-        }
-    }
     __syncthreads();
     if (tid == 0) {
         if (mode == 0) {
@@ -673,9 +728,13 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
     int p = -1;
     for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
         if (rmask & (1u << i)) { if (k == (int)blockIdx.y) { p = i; break; } k++; }
-    if (p >= 0) {
+    {
         const uint64_t vis = visible_slots(E, E.rep[E.leader].hdr, r0, R);
-        apply_range(E, p, commit_slot(E, vis), (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_acc);
+        const uint64_t cs = commit_slot(E, vis);
+        if (mode == 0)
+            finish_records(E, r0, R, cs, ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x,
+                           (uint64_t)gridDim.x * gridDim.y * blockDim.x);
+        if (p >= 0) apply_range(E, p, cs, (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_acc);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
