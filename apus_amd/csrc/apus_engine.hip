@@ -466,9 +466,22 @@ extern "C" int apus_gpu_tick_prune(apus_engine_t *e)
 __global__ void k_set_roles(const EngDev E, uint64_t sid, uint32_t bitmask, uint32_t follow_mask)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint64_t *lh = E.rep[E.leader].hdr;
+    const RepDev &Ld = E.rep[E.leader];
+    uint64_t *lh = Ld.hdr;
     lh[H_SID] = sid;
     lh[H_CID_BITMASK] = bitmask;
+    /* a former follower has no tail (hb_receive_cb resets it): log_get_tail, dare_log.h:402-457 */
+    const uint64_t n_end = lh[H_N_END];
+    if (n_end > 0 && lh[H_END] != E.log_len) {
+        const uint64_t t = Ld.dir_off[(uint32_t)(n_end - 1) & E.dir_mask];
+        lh[H_TAIL] = t;
+        lh[H_LAST_IDX] = ld8u(Ld.ring + t);
+    }
+    lh[H_N_VISIBLE] = n_end;
+    lh[H_OLD_END] = lh[H_END];
+    lh[H_N_PERSIST] = n_end;
+    /* ACK words of entries this server did not append itself start empty */
+    for (uint64_t s2 = lh[H_N_COMMIT]; s2 < n_end; s2++) Ld.ack[(uint32_t)s2 & E.dir_mask] = 0;
     for (uint32_t i = 0; i < E.group_size; i++) lh[H_APPLY_OFFSETS + i] = lh[H_HEAD];  /* dare_server.c:1504-1507 */
     for (uint32_t i = 0; i < E.group_size; i++) {
         if (i == E.leader || !((follow_mask >> i) & 1u) || !E.rep[i].ring) continue;

@@ -812,6 +812,7 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode,
             const uint64_t idx = (end == L) ? 1 : s_lh[H_LAST_IDX] + 1;         /* dare_log.h:486-488 */
             const uint64_t pos = (end == L || L - end < APUS_HDR) ? 0 : end;   /* log_add_new_entry, :213-221 */
             if (type != 3) hdr[H_PREV_HEAD] = 0; else if (mode == 1) hdr[H_PREV_HEAD] = 1;
+            if (type == 2) hdr[H_CID_BITMASK] = (uint32_t)(d1 >> 32);     /* the leader's own cid follows its CONFIG entries */
             const uint64_t term = s.term;
             const uint64_t slot = s.n_end0;
             const uint32_t di = (uint32_t)slot & E.dir_mask;

@@ -123,9 +123,30 @@ class Engine:
         """ELECT(winner): every live server becomes a candidate of term t+1, the
         winner's election timeout fires first and it wins term t+2 (the schedule of
         oracle/apus_oracle.c:orc_elect, from dare_server.c:1264-1518)."""
+        if not (self.reachable >> winner) & 1:
+            raise EngineError("the winner of an election must be alive")
         self.term += 2
         self.leader = winner
         self._chk(self.L.apus_gpu_become_leader(self.h, winner, self.term, self.bitmask), "become_leader")
+        # check_failure_count (dare_server.c:1189-1230): the new leader drops configured
+        # servers that do not answer and logs the new configuration
+        dead = self.bitmask & ~self.reachable & ~(1 << winner)
+        if dead:
+            self.bitmask &= ~dead
+            self.append_control(2, self._cid_bytes())
+
+    def _cid_bytes(self) -> bytes:
+        import struct
+        return struct.pack("<QBBBBI", 0, self.group_size, 0, 0, 0, self.bitmask)
+
+    def kill(self, r: int):
+        """KILL(r) of the trace: the server stops answering."""
+        self.set_reachable(self.reachable & ~(1 << r))
+        if r == self.leader:
+            self.leader = -1
+        elif self.leader >= 0 and (self.bitmask >> r) & 1:
+            self.bitmask &= ~(1 << r)
+            self.append_control(2, self._cid_bytes())
 
     def set_reachable(self, mask: int):
         self.reachable = mask
@@ -170,6 +191,8 @@ class Engine:
                     self.hold(ev[i][1])
                 elif op == "RELEASE":
                     self.release(ev[i][1])
+                elif op == "KILL":
+                    self.kill(ev[i][1])
                 else:
                     raise EngineError(f"trace event {ev[i]} is not supported by the engine yet")
                 last = i

@@ -158,19 +158,22 @@ def bench_single(args):
 
     # p50 consensus-round latency: one round per call, host-observed (submit -> commit visible)
     lat = []
+    n_lat = 0 if args.no_latency else 200
     r_idx = eng.round_of_g0[tr.events[-2][1]] if tr.events[-2][0] == "ROUND" else 0
-    for k in range(200):
+    for k in range(n_lat):
         t1 = time.perf_counter()
         eng.run_rounds((r_idx + k) % eng.n_rounds, 1)
         eng.sync()
         lat.append((time.perf_counter() - t1) * 1e6)
-    p50 = float(np.percentile(lat[20:], 50))
+    p50 = float(np.percentile(lat[20:], 50)) if len(lat) > 20 else None
     eng.check_status()
 
     # the persistent consensus kernel (live path): one 64-entry round at a time through the
     # pinned command ring; host-observed submit -> highest_rec, and device append -> commit
     plat_host, plat_dev = None, None
     try:
+        if args.no_latency:
+            raise RuntimeError('skipped (--no-latency)')
         reqs64 = np.ascontiguousarray(tr.reqs[16:16 + 64 * 64])
         base = eng.counters(0)["highest_rec"]
         eng.persist_start(idle_ms=2000, peer_ms=200)
@@ -258,6 +261,7 @@ def main():
     ap.add_argument("--replicas", type=int, default=3)
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
     if args.gpus <= 1:

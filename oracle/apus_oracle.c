@@ -858,6 +858,19 @@ int orc_elect(orc_cluster_t *c, int winner)
     }
     leader_poll(c, w);
     note_round(c, w);
+    /* check_failure_count (dare_server.c:1189-1230), first pass of the new leader: servers
+     * that are ON in the configuration but do not answer are removed with a CONFIG entry */
+    {
+        uint32_t dead = 0;
+        for (int i = 0; i < c->n; i++)
+            if (i != winner && cid_on(&w->cid, i) && !c->r[i].alive) dead |= 1u << i;
+        if (dead) {
+            w->cid.bitmask &= ~dead;
+            if (orc_log_append(w->log, SID_TERM(w->sid), 0, 0, ORC_CONFIG, &w->cid, 0) == 0) return -2;
+            leader_poll(c, w);
+            note_round(c, w);
+        }
+    }
     return 0;
 }
 

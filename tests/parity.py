@@ -90,6 +90,8 @@ def lockstep(trace, eng, check_at=("PRUNE", "QUIESCE"), coalesce=True, allow_exa
             cl.hold(ev[i][1]); eng.hold(ev[i][1])
         elif op == "RELEASE":
             cl.release(ev[i][1]); eng.release(ev[i][1])
+        elif op == "KILL":
+            cl.kill(ev[i][1]); eng.kill(ev[i][1])
         else:
             raise ValueError(ev[i])
         if op in check_at:

@@ -181,3 +181,15 @@ def test_graph_replay_equals_eager(eng_factory):
     eng.graph_launch(gid)
     eng.check_status()
     compare_all(eng, cl, tag="graph replay")
+
+
+def test_failover_reconf_bench_shape(eng_factory):
+    """BASELINE config 5: bench, kill the leader, elect, bench, kill a follower, bench
+    (benchmarks/reconf_bench.sh:249-343), 107/40-byte requests, 5 replicas."""
+    from tests.parity import lockstep
+    L = 1 << 19
+    tr = T.config_c5(per_phase=1500, log_len=L, batch=16)
+    eng = eng_factory(5, L)
+    cl = lockstep(tr, eng)
+    assert cl.leader == 1 and cl.term(1) == 4
+    assert eng.counters(1)["sid"] == cl.sid(1)

@@ -18,3 +18,11 @@ if [ -n "$PROFILE" ]; then
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && head -20 "$f"
 fi
+if [ -n "$PMC" ]; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf gpurun_out/pmc_$c
+    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/gpurun_out/pmc_$c -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu --eager --no-latency > $OLDPWD/gpurun_out/pmc_$c.log 2>&1)
+    echo "pmc $c exit: $?"
+    ls gpurun_out/pmc_$c | head
+  done
+fi
