@@ -83,6 +83,8 @@ struct SeqOut {
     int64_t  estar;        /* batch index where idx restarts at 1 (empty log), -1 if none*/
     uint32_t stale;        /* 1: the wrapped entry left a stale header at e0+virt(kstar) */
     uint32_t n;            /* entries in the batch                                       */
+    uint32_t head_round;   /* 1: a fused prune tick appended a <HEAD> entry right before  */
+    uint32_t pad0;
     uint64_t first_fail;   /* commit scan: first slot without a majority                 */
     uint64_t commit_before;/* leader commit offset before this call                      */
     uint64_t n_commit_before;

@@ -38,6 +38,7 @@ struct apus_engine {
     uint32_t local_mask;            /* replicas hosted here */
     uint32_t reachable;             /* peers the leader can post to (trace KILL/HOLD/RELEASE) */
     bool lag_possible;              /* a follower may be far behind: run the wide catch-up first */
+    bool tick_pending;              /* a prune tick waits to be fused into the next batch's sequencer */
     uint64_t max_rounds;
     /* staging */
     void *d_req, *d_req_len, *d_arena, *d_round_first;
@@ -75,6 +76,7 @@ struct apus_engine {
 #define LIVE_BYTES      (LIVE_OFF_ARENA + LIVE_ARENA + 64)
 
 static apus_engine *g_engine = nullptr;
+static int flush_tick(apus_engine *e);
 extern "C" int apus_gpu_persist_stop(apus_engine_t *e);
 
 template <typename T>
@@ -111,7 +113,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     apus_engine *e = new apus_engine();
     e->cfg = *cfg;
     memset(&e->d, 0, sizeof e->d);
-    e->capturing = false; e->timing = false; e->timed_used = 0; e->lag_possible = false;
+    e->capturing = false; e->timing = false; e->timed_used = 0; e->lag_possible = false; e->tick_pending = false;
     e->n_reqs = 0; e->n_rounds_staged = 0;
     e->d_req = e->d_req_len = e->d_arena = e->d_round_first = nullptr;
     e->h_live = nullptr; e->d_live = nullptr; e->live_pending = false; e->live_copied = nullptr;
@@ -187,6 +189,7 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
 extern "C" int apus_gpu_sync(apus_engine_t *e)
 {
     if (!e) return APUS_E_ARG;
+    { int frc = flush_tick(e); if (frc) return frc; }
     HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
@@ -201,6 +204,7 @@ extern "C" int apus_gpu_reset(apus_engine_t *e)
             HIPCHK(hipMemsetAsync(e->d.rep[i].ack, 0, sizeof(uint32_t) * e->dir_cap, e->stream));
         }
     e->d.leader = 0xFFFFFFFFu;
+    e->tick_pending = false;
     e->reachable = (1u << e->d.group_size) - 1;
     e->d.reachable = e->reachable;
     hipLaunchKernelGGL(k_reset, dim3(e->d.group_size), dim3(64), 0, e->stream, e->d);
@@ -314,7 +318,9 @@ static int launch_append(apus_engine *e, const EngDev &view, uint64_t r0, uint32
     int rc;
     const uint32_t fm = sync_mask(e);
     if ((rc = launch_catchup(e))) return rc;
-    hipLaunchKernelGGL(k_sequence, dim3((R + 1023) / 1024), dim3(1024), 0, e->stream, view, r0, R, fm);
+    const uint32_t tick = e->tick_pending ? 1u : 0u;
+    e->tick_pending = false;
+    hipLaunchKernelGGL(k_sequence, dim3((R + 1023) / 1024), dim3(1024), 0, e->stream, view, r0, R, fm, tick, fm);
     hipLaunchKernelGGL(k_append_push, dim3(R), dim3(256), 0, e->stream, view, r0, R, fm);
     HIPCHK(hipGetLastError());
     return 0;
@@ -330,7 +336,9 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
     const uint64_t n = e->h_round_first[r0 + R] - e->h_round_first[r0];
     const uint32_t fm = sync_mask(e);
     if ((rc = launch_catchup(e))) return rc;
-    hipLaunchKernelGGL(k_sequence, dim3((R + 1023) / 1024), dim3(1024), 0, e->stream, e->d, r0, R, fm);
+    const uint32_t tick = e->tick_pending ? 1u : 0u;
+    e->tick_pending = false;
+    hipLaunchKernelGGL(k_sequence, dim3((R + 1023) / 1024), dim3(1024), 0, e->stream, e->d, r0, R, fm, tick, fm);
     TimedLaunch *tl = nullptr;
     if (e->timing && !e->capturing) {
         if (e->timed_used == e->timed.size()) {
@@ -425,6 +433,14 @@ extern "C" int apus_gpu_submit(apus_engine_t *e, const apus_req_t *reqs, uint32_
     return apus_gpu_commit_live(e, 0);
 }
 
+static int launch_control_round(apus_engine *e, int mode, uint32_t type, uint64_t d0, uint64_t d1);
+static int flush_tick(apus_engine *e)
+{
+    if (!e->tick_pending) return 0;
+    e->tick_pending = false;
+    return launch_control_round(e, 1, APUS_HEAD, 0, 0);
+}
+
 static int launch_control_round(apus_engine *e, int mode, uint32_t type, uint64_t d0, uint64_t d1)
 {
     int rc = launch_catchup(e);
@@ -439,6 +455,7 @@ extern "C" int apus_gpu_quiesce(apus_engine_t *e)
 {
     int rc = need_leader(e);
     if (rc) return rc;
+    { int frc = flush_tick(e); if (frc) return frc; }
     return launch_control_round(e, 2, 0, 0, 0);
 }
 
@@ -446,6 +463,7 @@ extern "C" int apus_gpu_append_control(apus_engine_t *e, uint8_t type, const voi
 {
     int rc = need_leader(e);
     if (rc) return rc;
+    { int frc = flush_tick(e); if (frc) return frc; }
     uint64_t d0 = 0, d1 = 0;
     if (type == APUS_CONFIG) { if (!data) return APUS_E_ARG; memcpy(&d0, data, 8); memcpy(&d1, (const uint8_t *)data + 8, 8); }
     else if (type == APUS_HEAD) { if (!data) return APUS_E_ARG; memcpy(&d0, data, 8); }
@@ -460,6 +478,11 @@ extern "C" int apus_gpu_tick_prune(apus_engine_t *e)
 {
     int rc = need_leader(e);
     if (rc) return rc;
+    if ((rc = flush_tick(e))) return rc;            /* two ticks in a row: the first one runs now */
+    /* When every replica lives on this device the tick is deferred and fused into the
+     * sequencer of the next batch (same position in the order of events, one launch less);
+     * any other call flushes it first. */
+    if (e->local_mask == (1u << e->d.group_size) - 1) { e->tick_pending = true; return 0; }
     return launch_control_round(e, 1, APUS_HEAD, 0, 0);
 }
 
@@ -496,6 +519,8 @@ extern "C" int apus_gpu_become_leader(apus_engine_t *e, uint32_t leader, uint64_
 {
     if (!e || leader >= e->d.group_size) return APUS_E_ARG;
     if (!((e->local_mask >> leader) & 1u)) return APUS_E_STATE;
+    if (e->d.leader < e->d.group_size) { int frc = flush_tick(e); if (frc) return frc; }
+    e->tick_pending = false;
     e->d.leader = leader;
     const uint64_t sid = (term << 9) | (1ull << 8) | leader;
     hipLaunchKernelGGL(k_set_roles, dim3(1), dim3(64), 0, e->stream, e->d, sid, bitmask, e->reachable);
@@ -510,6 +535,7 @@ extern "C" int apus_gpu_become_leader(apus_engine_t *e, uint32_t leader, uint64_
 extern "C" int apus_gpu_set_reachable(apus_engine_t *e, uint32_t mask)
 {
     if (!e) return APUS_E_ARG;
+    { int frc = flush_tick(e); if (frc) return frc; }
     if (mask & ~e->reachable) e->lag_possible = true;     /* somebody was released */
     e->reachable = mask;
     e->d.reachable = mask;
@@ -520,6 +546,7 @@ extern "C" int apus_gpu_set_reachable(apus_engine_t *e, uint32_t mask)
 extern "C" int apus_gpu_capture_begin(apus_engine_t *e)
 {
     if (!e || e->capturing) return APUS_E_STATE;
+    { int frc = flush_tick(e); if (frc) return frc; }
     HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
     e->capturing = true;
     return 0;
@@ -528,6 +555,7 @@ extern "C" int apus_gpu_capture_begin(apus_engine_t *e)
 extern "C" int apus_gpu_capture_end(apus_engine_t *e, int *graph_id)
 {
     if (!e || !e->capturing || !graph_id) return APUS_E_STATE;
+    { int frc = flush_tick(e); if (frc) return frc; }
     hipGraph_t g = nullptr;
     e->capturing = false;
     HIPCHK(hipStreamEndCapture(e->stream, &g));
@@ -557,6 +585,7 @@ extern "C" int apus_gpu_offsets(apus_engine_t *e, uint32_t replica, uint64_t out
 {
     int rc = local_rep(e, replica);
     if (rc) return rc;
+    { int frc = flush_tick(e); if (frc) return frc; }
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(out, e->d.rep[replica].hdr, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
@@ -566,6 +595,7 @@ extern "C" int apus_gpu_counters(apus_engine_t *e, uint32_t replica, uint64_t ou
 {
     int rc = local_rep(e, replica);
     if (rc) return rc;
+    { int frc = flush_tick(e); if (frc) return frc; }
     uint64_t h[64];
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(h, e->d.rep[replica].hdr, sizeof h, hipMemcpyDeviceToHost));
@@ -578,6 +608,7 @@ extern "C" int apus_gpu_hdr_words(apus_engine_t *e, uint32_t replica, uint64_t *
 {
     int rc = local_rep(e, replica);
     if (rc) return rc;
+    { int frc = flush_tick(e); if (frc) return frc; }
     if (n_words > 64) n_words = 64;
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(out, e->d.rep[replica].hdr, n_words * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -588,6 +619,7 @@ extern "C" int apus_gpu_read_ring(apus_engine_t *e, uint32_t replica, uint64_t o
 {
     int rc = local_rep(e, replica);
     if (rc) return rc;
+    { int frc = flush_tick(e); if (frc) return frc; }
     if (off + n > e->d.log_len) return APUS_E_ARG;
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(dst, e->d.rep[replica].ring + off, n, hipMemcpyDeviceToHost));
@@ -597,6 +629,7 @@ extern "C" int apus_gpu_read_ring(apus_engine_t *e, uint32_t replica, uint64_t o
 extern "C" uint64_t apus_gpu_round_count(apus_engine_t *e)
 {
     if (!e) return 0;
+    flush_tick(e);
     uint64_t n = 0;
     hipStreamSynchronize(e->stream);
     hipMemcpy(&n, e->d.rec_count, sizeof n, hipMemcpyDeviceToHost);
@@ -606,6 +639,7 @@ extern "C" uint64_t apus_gpu_round_count(apus_engine_t *e)
 extern "C" int apus_gpu_round_record(apus_engine_t *e, uint64_t first, uint64_t n, uint64_t *end_out, uint64_t *commit_out)
 {
     if (!e || first + n > e->d.rec_cap) return APUS_E_ARG;
+    { int frc = flush_tick(e); if (frc) return frc; }
     HIPCHK(hipStreamSynchronize(e->stream));
     if (end_out) HIPCHK(hipMemcpy(end_out, e->d.rec_end + first, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (commit_out) HIPCHK(hipMemcpy(commit_out, e->d.rec_commit + first, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -616,6 +650,7 @@ extern "C" int apus_gpu_apply_records(apus_engine_t *e, uint32_t replica, uint64
 {
     int rc = local_rep(e, replica);
     if (rc) return rc;
+    { int frc = flush_tick(e); if (frc) return frc; }
     if (n > e->dir_cap) return APUS_E_ARG;
     HIPCHK(hipStreamSynchronize(e->stream));
     const apus_apply_rec *base = e->d.rep[replica].apply;
@@ -631,6 +666,7 @@ extern "C" int apus_gpu_apply_records(apus_engine_t *e, uint32_t replica, uint64
 extern "C" uint32_t apus_gpu_status(apus_engine_t *e)
 {
     if (!e) return 0xFFFFFFFFu;
+    flush_tick(e);
     uint32_t s = 0;
     hipStreamSynchronize(e->stream);
     hipMemcpy(&s, e->d.status, sizeof s, hipMemcpyDeviceToHost);
@@ -716,6 +752,7 @@ extern "C" int apus_gpu_persist_start(apus_engine_t *e, uint32_t idle_ms, uint32
 {
     int rc = need_leader(e);
     if (rc) return rc;
+    { int frc = flush_tick(e); if (frc) return frc; }
     if (e->p_running) return APUS_E_STATE;
     HIPCHK(hipStreamSynchronize(e->stream));
     if (!e->ph) {

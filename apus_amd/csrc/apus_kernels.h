@@ -137,6 +137,10 @@ __global__ __launch_bounds__(256) void k_catchup(const EngDev E, uint32_t fmask)
                   (uint64_t)gridDim.x * blockDim.x);
 }
 
+__device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32_t type, uint64_t d0, uint64_t d1,
+                                               uint32_t push_mask, uint64_t *s_lh);
+__device__ static inline void sample_apply_offsets(const EngDev &E, const uint64_t *s_lh, uint32_t sample_mask, uint32_t i);
+
 /* block-wide inclusive scan of one u64 per thread (blockDim.x <= 1024), returns
  * the inclusive value; *total gets the block sum                              */
 __device__ static inline uint64_t block_incl_scan(uint64_t v, uint64_t *s_tot /*[16]*/, uint64_t *total)
@@ -157,8 +161,11 @@ __device__ static inline uint64_t block_incl_scan(uint64_t v, uint64_t *s_tot /*
  * Phase A (all blocks, one thread per round): bytes of the round.
  * Phase B (the block that arrives last): exclusive scan over the rounds, the wrap
  * point, the leader's control words and the per-round end record.            */
-__global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask)
+__global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask,
+                                                    uint32_t tick, uint32_t sample_mask)
 {
+    __shared__ uint64_t s_lh[64];
+    __shared__ uint32_t s_head_round;
     __shared__ uint64_t s_tot[16];
     __shared__ unsigned int s_last, s_rstar;
     __shared__ int64_t s_kstar;
@@ -172,7 +179,8 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
     /* control words thread 0 needs later: loaded now so the latency hides behind phase A */
     uint64_t p_head = 0, p_last_idx = 0, p_sid = 0, p_commit = 0, p_n_commit = 0, p_store = 0;
     uint32_t p_tlast = 0;
-    const bool pre = gridDim.x == 1;                 /* with several blocks the last one is not known yet */
+    const bool pre = gridDim.x == 1 && !tick;        /* with several blocks the last one is not known yet;
+                                                        a fused prune tick rewrites the words */
     if (tid == 0 && pre) {
         p_head = hdr[H_HEAD]; p_last_idx = hdr[H_LAST_IDX]; p_sid = hdr[H_SID];
         p_commit = hdr[H_COMMIT]; p_n_commit = hdr[H_N_COMMIT]; p_store = hdr[H_STORE_COUNT];
@@ -208,24 +216,32 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
     }
 
     /* phase B: this block is alone now */
-    const uint64_t e0 = hdr[H_END];
-    const uint64_t n_end0 = hdr[H_N_END];
     const uint32_t g0 = rf[0];
     const uint32_t n = rf[R] - g0;
-
-    /* followers that silently fell one round behind (exact-fit wrap) are caught up here */
-    for (uint32_t m = push_mask; m; m &= m - 1) {
-        const int f = __builtin_ctz(m);
-        catchup_range(E, f, e0, n_end0, tid, blockDim.x);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        s_rstar = 0xFFFFFFFFu;
-        for (uint32_t m = push_mask; m; m &= m - 1) {
-            uint64_t *fh = E.rep[__builtin_ctz(m)].hdr;
-            if (fh[H_N_END] < n_end0 && e0 != L) { fh[H_END] = e0; fh[H_N_END] = n_end0; }
+    {
+        /* followers that silently fell one round behind (exact-fit wrap) are caught up here */
+        const uint64_t e_pre = hdr[H_END], n_pre = hdr[H_N_END];
+        if (tick && tid < 64) s_lh[tid] = hdr[tid];
+        for (uint32_t m = push_mask; m; m &= m - 1) catchup_range(E, __builtin_ctz(m), e_pre, n_pre, tid, blockDim.x);
+        __syncthreads();
+        if (tid == 0) {
+            s_rstar = 0xFFFFFFFFu;
+            s_head_round = 0;
+            for (uint32_t m = push_mask; m; m &= m - 1) {
+                uint64_t *fh = E.rep[__builtin_ctz(m)].hdr;
+                if (fh[H_N_END] < n_pre && e_pre != L) { fh[H_END] = e_pre; fh[H_N_END] = n_pre; }
+            }
+            /* a log_pruning tick that was due right before this batch (the timer fired between
+             * two polling() passes): decision + <HEAD> entry happen here, its persist / ACK /
+             * commit / apply ride with the batch's own tail kernels */
+            if (tick) s_head_round = control_append(E, 1, 3, 0, 0, push_mask, s_lh).n;
         }
+        if (tick && tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS) sample_apply_offsets(E, s_lh, sample_mask, tid - 64);
+        __syncthreads();
     }
+    const uint32_t head_round = s_head_round;
+    const uint64_t e0 = hdr[H_END];
+    const uint64_t n_end0 = hdr[H_N_END];
 
     /* exclusive scan of the round sums, in place */
     uint64_t carry = 0;
@@ -278,6 +294,7 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
         s.e0 = e0; s.idx0 = idx0; s.w = w; s.n_end0 = n_end0;
         s.term = (pre ? p_sid : hdr[H_SID]) >> 9;
         s.kstar = kstar; s.estar = estar; s.stale = stale; s.n = n;
+        s.head_round = head_round;
         s.first_fail = ~0ull;
         s.commit_before = pre ? p_commit : hdr[H_COMMIT];
         s.n_commit_before = pre ? p_n_commit : hdr[H_N_COMMIT];
@@ -306,7 +323,7 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
         const uint64_t a_end = e0 + E.round_virt[r + 1];
         const int64_t last = (int64_t)(rf[r + 1] - g0) - 1;   /* batch index of the round's last entry */
         const uint64_t end_r = (kstar < 0 || last < kstar) ? a_end : a_end - w;
-        if (rec_base + r < E.rec_cap) E.rec_end[rec_base + r] = end_r;
+        if (rec_base + head_round + r < E.rec_cap) E.rec_end[rec_base + head_round + r] = end_r;
     }
 }
 
@@ -615,8 +632,17 @@ __device__ static inline void finish_records(const EngDev &E, uint64_t r0, uint3
     const RepDev &Ld = E.rep[E.leader];
     const uint64_t L = E.log_len;
     const SeqOut s = *E.seq;
-    const uint64_t rec_base = *E.rec_count;
+    const uint64_t rec_base0 = *E.rec_count;
+    const uint32_t hr = s.head_round;
+    const uint64_t rec_base = rec_base0 + hr;
     const uint32_t *rf = E.round_first + r0;
+    /* the <HEAD> round of a fused prune tick committed (or not) on its own, before the batch */
+    uint64_t base_commit = s.commit_before;
+    if (hr) {
+        const uint64_t he = E.rec_end[rec_base0];
+        if (cs >= s.n_end0 && cs > s.n_commit_before && he != L) base_commit = he;
+        if (gtid == 0 && rec_base0 < E.rec_cap) E.rec_commit[rec_base0] = base_commit;
+    }
     for (uint64_t r = gtid; r < R; r += gthreads) {
         if (rec_base + r >= E.rec_cap) break;
         const uint64_t slot_end_r = s.n_end0 + (rf[r + 1] - rf[0]);
@@ -625,6 +651,7 @@ __device__ static inline void finish_records(const EngDev &E, uint64_t r0, uint3
         const uint64_t end_r = E.rec_end[rec_base + r];
         uint64_t cr;
         if (c <= s.n_commit_before) cr = s.commit_before;
+        else if (c <= s.n_end0) cr = base_commit;
         else if (c == slot_end_r) cr = end_r;
         else cr = Ld.dir_off[(uint32_t)c & E.dir_mask];
         /* Reference quirk (dare_ibv_rc.c:1725-1758): when a polling() pass starts with the
@@ -634,16 +661,17 @@ __device__ static inline void finish_records(const EngDev &E, uint64_t r0, uint3
          * holds, `committed` is set and rc_write_remote_logs returns before the followers
          * were brought up to date.  That pass therefore ends with commit == 0. */
         if (s.kstar >= 0 && (int64_t)(rf[r] - rf[0]) == s.kstar && s.w < L && cs >= slot_start_r &&
-            (r ? true : s.commit_before == s.e0))
+            (r ? true : base_commit == s.e0))
             cr = 0;
         /* a round that ended exactly on len could not commit: the log read as empty
          * (dare_log.h:158), the leader's scan saw distance 0 (dare_ibv_rc.c:1726) */
         if (end_r == L) {
-            if (r == 0) cr = s.commit_before;
+            if (r == 0) cr = base_commit;
             else {
                 const uint64_t pe = E.rec_end[rec_base + r - 1];
                 const uint64_t pc = min(cs, slot_start_r);
-                cr = (pc <= s.n_commit_before) ? s.commit_before : (pc == slot_start_r ? pe : Ld.dir_off[(uint32_t)pc & E.dir_mask]);
+                cr = (pc <= s.n_commit_before) ? s.commit_before
+                   : (pc <= s.n_end0 ? base_commit : (pc == slot_start_r ? pe : Ld.dir_off[(uint32_t)pc & E.dir_mask]));
             }
         }
         E.rec_commit[rec_base + r] = cr;
@@ -678,7 +706,7 @@ __device__ static inline void finish_call(const EngDev &E, uint64_t r0, uint32_t
     __syncthreads();
     if (tid == 0) {
         if (mode == 0) {
-            *E.rec_count = rec_base + R;
+            *E.rec_count = rec_base + R + s.head_round;
         } else if (mode == 1 && s.n) {
             if (rec_base < E.rec_cap)
                 E.rec_commit[rec_base] = (end_l == L) ? s.commit_before : commit_off;
@@ -748,6 +776,83 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
     if (s_last) finish_call(E, r0, R, mode, fmask);
 }
 
+/* READ the apply offset of peer i for the next prune tick (rc_get_remote_apply_offsets,
+ * dare_ibv_rc.c:1970-2034); one lane per peer, s_lh = the leader's control block
+ * as it was before the tick */
+__device__ static inline void sample_apply_offsets(const EngDev &E, const uint64_t *s_lh, uint32_t sample_mask, uint32_t i)
+{
+    uint64_t *hdr = E.rep[E.leader].hdr;
+    const uint32_t bitmask = (uint32_t)s_lh[H_CID_BITMASK];
+    if (i >= E.group_size) return;
+    if (i == E.leader || !((bitmask >> i) & 1u)) hdr[H_APPLY_OFFSETS + i] = s_lh[H_APPLY];
+    else if ((sample_mask >> i) & 1u) hdr[H_APPLY_OFFSETS + i] = E.rep[i].hdr[H_APPLY];
+}
+
+/* One thread: the leader appends at most one control entry (log_append_entry,
+ * dare_log.h:466-558; a 64-byte entry never hits wrap case 2).
+ *   mode 0: <type, d0, d1>       mode 2: nothing
+ *   mode 1: log_pruning (dare_server.c:1996-2067): decide from the sampled apply offsets
+ *           whether the head moves and append <HEAD, head> if so
+ * s_lh is an LDS copy of the leader's control block; returns the call's SeqOut. */
+__device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32_t type, uint64_t d0, uint64_t d1,
+                                               uint32_t push_mask, uint64_t *s_lh)
+{
+    const RepDev &Ld = E.rep[E.leader];
+    uint64_t *hdr = Ld.hdr;
+    const uint64_t L = E.log_len;
+    const uint64_t end = s_lh[H_END];
+    uint64_t head = s_lh[H_HEAD];
+    bool do_append = (mode != 2);
+    if (mode == 1) {
+        const uint32_t size = E.group_size;
+        const uint32_t bitmask = (uint32_t)s_lh[H_CID_BITMASK];
+        uint64_t min_off = s_lh[H_APPLY];
+        for (uint32_t i = 0; i < size; i++) {
+            if (!((bitmask >> i) & 1u)) { s_lh[H_APPLY_OFFSETS + i] = s_lh[H_APPLY]; hdr[H_APPLY_OFFSETS + i] = s_lh[H_APPLY]; }
+            if (apus_is_larger(end, L, min_off, s_lh[H_APPLY_OFFSETS + i])) min_off = s_lh[H_APPLY_OFFSETS + i];
+        }
+        if (apus_end_distance(end, L, min_off) == 0) min_off = s_lh[H_TAIL];   /* leave one entry, :2038-2041 */
+        do_append = apus_is_larger(end, L, min_off, head) && !s_lh[H_PREV_HEAD];
+        if (do_append) { hdr[H_HEAD] = min_off; head = min_off; d0 = min_off; d1 = 0; type = 3; }
+    }
+    SeqOut s;
+    s.e0 = end; s.idx0 = s_lh[H_LAST_IDX] + 1; s.w = 0; s.n_end0 = s_lh[H_N_END];
+    s.term = s_lh[H_SID] >> 9; s.kstar = -1; s.estar = -1; s.stale = 0; s.n = 0; s.head_round = 0;
+    s.first_fail = ~0ull; s.commit_before = s_lh[H_COMMIT]; s.n_commit_before = s_lh[H_N_COMMIT];
+    if (do_append && end == head && end != L) { set_status(E, 1u << 1); do_append = false; }
+    if (do_append) {
+        const uint64_t idx = (end == L) ? 1 : s_lh[H_LAST_IDX] + 1;         /* dare_log.h:486-488 */
+        const uint64_t pos = (end == L || L - end < APUS_HDR) ? 0 : end;   /* log_add_new_entry, :213-221 */
+        if (type != 3) hdr[H_PREV_HEAD] = 0; else if (mode == 1) hdr[H_PREV_HEAD] = 1;
+        if (type == 2) hdr[H_CID_BITMASK] = (uint32_t)(d1 >> 32);     /* the leader's own cid follows its CONFIG entries */
+        const uint64_t term = s.term;
+        const uint64_t slot = s.n_end0;
+        const uint32_t di = (uint32_t)slot & E.dir_mask;
+        const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)term, (uint32_t)(term >> 32));
+        const uint4 h1 = make_uint4(0, 0, (type << 16) | ((uint32_t)E.leader << 24), 0);  /* req_id = clt_id = 0 */
+        const uint4 h2 = make_uint4(0, 0, 0, 0);
+        const uint4 h3 = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
+        for (uint32_t m = push_mask | (1u << E.leader); m; m &= m - 1) {
+            const int t = __builtin_ctz(m);
+            uint8_t *rg = E.rep[t].ring;
+            st16u(rg + pos, h0); st16u(rg + pos + 16, h1); st16u(rg + pos + 32, h2); st16u(rg + pos + 48, h3);
+            E.rep[t].dir_off[di] = pos; E.rep[t].dir_len[di] = APUS_HDR | ((uint32_t)E.leader << 24);
+        }
+        __hip_atomic_store(&Ld.ack[di], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hdr[H_TAIL] = pos;
+        hdr[H_END] = pos + APUS_HDR;
+        hdr[H_N_END] = slot + 1;
+        hdr[H_LAST_IDX] = idx;
+        hdr[H_OLD_END] = pos + APUS_HDR;
+        hdr[H_N_PERSIST] = slot + 1;
+        hdr[H_STORE_COUNT] = s_lh[H_STORE_COUNT] + 1;
+        s.n = 1;
+        const uint64_t rec_base = *E.rec_count;
+        if (rec_base < E.rec_cap) E.rec_end[rec_base] = pos + APUS_HDR;
+    }
+    return s;
+}
+
 /* ------------------------------------------------------------------------- */
 /* k_control_round: ONE workgroup does a whole polling() pass that carries at most
  * one control entry -- used for the prune tick, the new leader's blank CONFIG
@@ -787,69 +892,8 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode,
     __shared__ uint64_t s_lh[64];
     if (tid < 64) s_lh[tid] = hdr[tid];
     __syncthreads();
-    if (tid == 0) {
-        const uint64_t end = s_lh[H_END];
-        uint64_t head = s_lh[H_HEAD];
-        bool do_append = (mode != 2);
-        if (mode == 1) {
-            const uint32_t size = E.group_size;
-            const uint32_t bitmask = (uint32_t)s_lh[H_CID_BITMASK];
-            uint64_t min_off = s_lh[H_APPLY];
-            for (uint32_t i = 0; i < size; i++) {
-                if (!((bitmask >> i) & 1u)) { s_lh[H_APPLY_OFFSETS + i] = s_lh[H_APPLY]; hdr[H_APPLY_OFFSETS + i] = s_lh[H_APPLY]; }
-                if (apus_is_larger(end, L, min_off, s_lh[H_APPLY_OFFSETS + i])) min_off = s_lh[H_APPLY_OFFSETS + i];
-            }
-            if (apus_end_distance(end, L, min_off) == 0) min_off = s_lh[H_TAIL];   /* leave one entry, :2038-2041 */
-            do_append = apus_is_larger(end, L, min_off, head) && !s_lh[H_PREV_HEAD];
-            if (do_append) { hdr[H_HEAD] = min_off; head = min_off; d0 = min_off; d1 = 0; type = 3; }
-        }
-        SeqOut s;
-        s.e0 = end; s.idx0 = s_lh[H_LAST_IDX] + 1; s.w = 0; s.n_end0 = s_lh[H_N_END];
-        s.term = s_lh[H_SID] >> 9; s.kstar = -1; s.estar = -1; s.stale = 0; s.n = 0;
-        s.first_fail = ~0ull; s.commit_before = s_lh[H_COMMIT]; s.n_commit_before = s_lh[H_N_COMMIT];
-        if (do_append && end == head && end != L) { set_status(E, 1u << 1); do_append = false; }
-        if (do_append) {
-            const uint64_t idx = (end == L) ? 1 : s_lh[H_LAST_IDX] + 1;         /* dare_log.h:486-488 */
-            const uint64_t pos = (end == L || L - end < APUS_HDR) ? 0 : end;   /* log_add_new_entry, :213-221 */
-            if (type != 3) hdr[H_PREV_HEAD] = 0; else if (mode == 1) hdr[H_PREV_HEAD] = 1;
-            if (type == 2) hdr[H_CID_BITMASK] = (uint32_t)(d1 >> 32);     /* the leader's own cid follows its CONFIG entries */
-            const uint64_t term = s.term;
-            const uint64_t slot = s.n_end0;
-            const uint32_t di = (uint32_t)slot & E.dir_mask;
-            const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)term, (uint32_t)(term >> 32));
-            const uint4 h1 = make_uint4(0, 0, (type << 16) | ((uint32_t)E.leader << 24), 0);  /* req_id = clt_id = 0 */
-            const uint4 h2 = make_uint4(0, 0, 0, 0);
-            const uint4 h3 = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
-            for (uint32_t m = push_mask | (1u << E.leader); m; m &= m - 1) {
-                const int t = __builtin_ctz(m);
-                uint8_t *rg = E.rep[t].ring;
-                st16u(rg + pos, h0); st16u(rg + pos + 16, h1); st16u(rg + pos + 32, h2); st16u(rg + pos + 48, h3);
-                E.rep[t].dir_off[di] = pos; E.rep[t].dir_len[di] = APUS_HDR | ((uint32_t)E.leader << 24);
-            }
-            __hip_atomic_store(&Ld.ack[di], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hdr[H_TAIL] = pos;
-            hdr[H_END] = pos + APUS_HDR;
-            hdr[H_N_END] = slot + 1;
-            hdr[H_LAST_IDX] = idx;
-            hdr[H_OLD_END] = pos + APUS_HDR;
-            hdr[H_N_PERSIST] = slot + 1;
-            hdr[H_STORE_COUNT] = s_lh[H_STORE_COUNT] + 1;
-            s.n = 1;
-            const uint64_t rec_base = *E.rec_count;
-            if (rec_base < E.rec_cap) E.rec_end[rec_base] = pos + APUS_HDR;
-        }
-        *E.seq = s;
-    }
-    if (mode == 1 && tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS) {
-        /* READ the apply offset of every reachable peer for the next tick
-         * (rc_get_remote_apply_offsets, dare_ibv_rc.c:1970-2034), one lane per peer */
-        const uint32_t i = tid - 64;
-        const uint32_t bitmask = (uint32_t)s_lh[H_CID_BITMASK];
-        if (i < E.group_size) {
-            if (i == E.leader || !((bitmask >> i) & 1u)) hdr[H_APPLY_OFFSETS + i] = s_lh[H_APPLY];
-            else if ((sample_mask >> i) & 1u) hdr[H_APPLY_OFFSETS + i] = E.rep[i].hdr[H_APPLY];
-        }
-    }
+    if (tid == 0) *E.seq = control_append(E, mode, type, d0, d1, push_mask, s_lh);
+    if (mode == 1 && tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS) sample_apply_offsets(E, s_lh, sample_mask, tid - 64);
     __syncthreads();
 
     const uint64_t vis = visible_slots(E, hdr, 0, 0);
