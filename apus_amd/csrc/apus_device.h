@@ -59,8 +59,6 @@ struct RepDev {
     uint64_t *dir_off;     /* [dir_cap]  byte offset of entry slot s                     */
     uint32_t *dir_len;     /* [dir_cap]  total bytes of entry slot s (64 + cmd.len)      */
     uint32_t *ack;         /* [dir_cap]  ACK bitmask (meaningful on the leader)          */
-    uint4    *dir_meta;    /* [dir_cap]  {idx lo, idx hi, clt_id | type << 16, 0}: what apply needs of the
-                              header, so that it streams 16 B per entry instead of a 128-B line */
     apus_apply_rec *apply; /* [dir_cap]  apply stream, indexed by slot                   */
     uint32_t idx;          /* index in the group                                         */
     uint32_t pad;

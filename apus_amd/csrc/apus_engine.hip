@@ -145,7 +145,6 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
         if ((rc = dev_alloc(e, &r.dir_off, sizeof(uint64_t) * e->dir_cap))) break;
         if ((rc = dev_alloc(e, &r.dir_len, sizeof(uint32_t) * e->dir_cap))) break;
         if ((rc = dev_alloc(e, &r.ack, sizeof(uint32_t) * e->dir_cap))) break;
-        if ((rc = dev_alloc(e, &r.dir_meta, sizeof(uint4) * (size_t)e->dir_cap))) break;
         if ((rc = dev_alloc(e, &r.apply, sizeof(apus_apply_rec) * (size_t)e->dir_cap))) break;
     }
     e->max_rounds = 1u << 16;
@@ -693,7 +692,6 @@ extern "C" void *apus_gpu_device_ptr(apus_engine_t *e, uint32_t replica, int whi
     case 3: p = r.dir_len; b = sizeof(uint32_t) * e->dir_cap; break;
     case 4: p = r.ack; b = sizeof(uint32_t) * e->dir_cap; break;
     case 5: p = r.apply; b = sizeof(apus_apply_rec) * (uint64_t)e->dir_cap; break;
-    case 6: p = r.dir_meta; b = sizeof(uint4) * (uint64_t)e->dir_cap; break;
     default: break;
     }
     if (bytes) *bytes = b;

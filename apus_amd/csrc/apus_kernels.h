@@ -110,7 +110,6 @@ __device__ static inline void catchup_range(const EngDev &E, int f, uint64_t end
         const uint32_t i = (uint32_t)s & E.dir_mask;
         Fd.dir_off[i] = Ld.dir_off[i];
         Fd.dir_len[i] = Ld.dir_len[i];
-        Fd.dir_meta[i] = Ld.dir_meta[i];
     }
     const uint64_t from = (end_f == L) ? 0 : end_f;
     uint64_t seg0_to, seg1_to = 0;
@@ -387,11 +386,10 @@ __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0
         if (active) {
             const uint32_t di = (uint32_t)slot & E.dir_mask;
             const uint32_t dl = T | ((uint32_t)E.leader << 24);     /* derived: total bytes | sender << 24 */
-            const uint4 meta = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)d.clt_id | (type << 16), 0);
-            Ld.dir_off[di] = pos; Ld.dir_len[di] = dl; Ld.ack[di] = 0; Ld.dir_meta[di] = meta;
+            Ld.dir_off[di] = pos; Ld.dir_len[di] = dl; Ld.ack[di] = 0;
             for (uint32_t m = push_mask; m; m &= m - 1) {
                 const RepDev &Fd = E.rep[__builtin_ctz(m)];
-                Fd.dir_off[di] = pos; Fd.dir_len[di] = dl; Fd.dir_meta[di] = meta;
+                Fd.dir_off[di] = pos; Fd.dir_len[di] = dl;
             }
             if (s.stale && gk == s.kstar) {
                 /* the header that log_append_entry wrote before it found out that the
@@ -577,7 +575,6 @@ __global__ __launch_bounds__(1024) void k_commit(const EngDev E, uint64_t r0, ui
 /* apply_committed_entries (dare_server.c:1815-1974) for slots [from, cs) of
  * replica p: apply-stream records, HEAD adoption candidates; block-reduced
  * counters.  Must be called by all threads of the block.                        */
-template <bool FROM_META>
 __device__ static inline void apply_range(const EngDev &E, int p, uint64_t cs, uint64_t tile0, uint64_t tile_stride,
                                           unsigned long long *s_acc /*[2]*/)
 {
@@ -595,18 +592,11 @@ __device__ static inline void apply_range(const EngDev &E, int p, uint64_t cs, u
             const uint32_t di = (uint32_t)s & E.dir_mask;
             const uint64_t off = Pd.dir_off[di];
             const uint32_t T = Pd.dir_len[di] & 0xFFFFFFu;
-            uint64_t idx; uint32_t type; uint16_t clt;
-            if (FROM_META) {
-                /* the directory carries a copy of the three header fields an upcall needs */
-                const uint4 mt = Pd.dir_meta[di];
-                idx = (uint64_t)mt.x | ((uint64_t)mt.y << 32);
-                type = (mt.z >> 16) & 0xFF; clt = (uint16_t)(mt.z & 0xFFFF);
-            } else {
-                const uint4 u0 = ld16u(Pd.ring + off);
-                const uint4 u1 = ld16u(Pd.ring + off + 16);
-                idx = (uint64_t)u0.x | ((uint64_t)u0.y << 32);
-                type = (u1.z >> 16) & 0xFF; clt = (uint16_t)(u1.z & 0xFFFF);
-            }
+            const uint4 u0 = ld16u(Pd.ring + off);
+            const uint4 u1 = ld16u(Pd.ring + off + 16);
+            const uint64_t idx = (uint64_t)u0.x | ((uint64_t)u0.y << 32);
+            const uint32_t type = (u1.z >> 16) & 0xFF;
+            const uint16_t clt = (uint16_t)(u1.z & 0xFFFF);
             client = (type != 0 && type != 2 && type != 3);
             apus_apply_rec rec;
             rec.slot = s; rec.off = off; rec.idx = idx; rec.len = T - APUS_HDR;
@@ -772,7 +762,7 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
         if (mode == 0)
             finish_records(E, r0, R, cs, ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x,
                            (uint64_t)gridDim.x * gridDim.y * blockDim.x);
-        if (p >= 0) apply_range<true>(E, p, cs, (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_acc);
+        if (p >= 0) apply_range(E, p, cs, (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_acc);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -847,7 +837,6 @@ __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32
             uint8_t *rg = E.rep[t].ring;
             st16u(rg + pos, h0); st16u(rg + pos + 16, h1); st16u(rg + pos + 32, h2); st16u(rg + pos + 48, h3);
             E.rep[t].dir_off[di] = pos; E.rep[t].dir_len[di] = APUS_HDR | ((uint32_t)E.leader << 24);
-            E.rep[t].dir_meta[di] = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), type << 16, 0);
         }
         __hip_atomic_store(&Ld.ack[di], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         hdr[H_TAIL] = pos;
@@ -915,7 +904,7 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode,
     __syncthreads();
     const uint64_t cs = commit_slot(E, vis);
     for (uint32_t m = push_mask | (1u << E.leader); m; m &= m - 1)
-        apply_range<true>(E, __builtin_ctz(m), cs, 0, blockDim.x, s_acc);
+        apply_range(E, __builtin_ctz(m), cs, 0, blockDim.x, s_acc);
     __syncthreads();
     finish_call(E, 0, 0, mode == 2 ? 2 : 1, push_mask);
 }
@@ -968,7 +957,7 @@ __global__ __launch_bounds__(256) void k_mp_ack_merge(const EngDev E, uint32_t f
 __global__ __launch_bounds__(256) void k_mp_apply(const EngDev E, uint32_t f, uint64_t cs)
 {
     __shared__ unsigned long long s_acc[2];
-    apply_range<false>(E, (int)f, cs, (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_acc);
+    apply_range(E, (int)f, cs, (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_acc);
 }
 
 __global__ void k_mp_apply_fin(const EngDev E, uint32_t f, uint64_t cs)

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
             }
             if (com > n_persist) com = n_persist;
             if (com > n_apply) {
-                apply_range<false>(E, me, com, 0, blockDim.x, s_acc);
+                apply_range(E, me, com, 0, blockDim.x, s_acc);
                 if (tid == 0) {
                     const uint64_t coff = (com == mh[H_N_END]) ? mh[H_END] : Md.dir_off[(uint32_t)com & E.dir_mask];
                     mh[H_COMMIT] = coff; mh[H_N_COMMIT] = com; mh[H_N_APPLY] = com;
@@ -270,8 +270,6 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
                         const RepDev &Fd = E.rep[__builtin_ctz(m)];
                         st_agent(&Fd.dir_off[di], pos);
                         __hip_atomic_store(&Fd.dir_len[di], dl, RLX_AGENT);
-                        st_agent((uint64_t *)&Fd.dir_meta[di], idx);
-                        st_agent((uint64_t *)&Fd.dir_meta[di] + 1, (uint64_t)((uint32_t)d.clt_id | (type << 16)));
                     }
                     __hip_atomic_store(&Md.ack[di], 0u, RLX_AGENT);
                     if (s.stale && gk == s.kstar) {
@@ -347,8 +345,6 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
                         st16_agent(Fd.ring + pos + 32, make_uint4(0, 0, 0, 0)); st16_agent(Fd.ring + pos + 48, h3);
                         st_agent(&Fd.dir_off[di], pos);
                         __hip_atomic_store(&Fd.dir_len[di], APUS_HDR | ((uint32_t)E.leader << 24), RLX_AGENT);
-                        st_agent((uint64_t *)&Fd.dir_meta[di], idx);
-                        st_agent((uint64_t *)&Fd.dir_meta[di] + 1, (uint64_t)(3u << 16));
                     }
                     __hip_atomic_store(&Md.ack[di], 0u, RLX_AGENT);
                     mh[H_PREV_HEAD] = 1;
@@ -413,7 +409,7 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
                     if (appended && k < P_LAT_CAP) { D->lat_ticks[k] = (uint32_t)(wall_clock64() - t_start); D->lat_n = k + 1; }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                apply_range<false>(E, me, cs, 0, blockDim.x, s_acc);
+                apply_range(E, me, cs, 0, blockDim.x, s_acc);
                 if (tid == 0) {
                     const uint64_t coff = mh[H_COMMIT];
                     mh[H_APPLY] = coff; mh[H_N_APPLY] = cs;
