@@ -504,35 +504,57 @@ __global__ __launch_bounds__(256) void k_persist_commit(const EngDev E, uint64_t
     uint64_t lo = lh[H_N_COMMIT];
     for (uint32_t m = fmask; m; m &= m - 1) lo = min(lo, E.rep[__builtin_ctz(m)].hdr[H_N_PERSIST]);
     const uint32_t size = E.group_size, size_mask = (1u << size) - 1, quorum = size / 2 + 1;
-    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t tile = lo + (uint64_t)blockIdx.x * blockDim.x; tile < vis; tile += nth) {
-        const uint64_t s = tile + threadIdx.x;
-        const bool in = s < vis;
-        bool ok = true;
-        if (in) {
-            const uint32_t di = (uint32_t)s & E.dir_mask;
-            uint32_t bits = 0, sender = E.leader;
-            for (uint32_t m = fmask; m; m &= m - 1) {
-                const int f = __builtin_ctz(m);
-                const RepDev &Fd = E.rep[f];
-                if (s < Fd.hdr[H_N_PERSIST]) continue;               /* this follower persisted it earlier */
-                const uint64_t off = Fd.dir_off[di];                 /* the follower reads its own log */
-                sender = Fd.dir_len[di] >> 24;                       /* entry->sender, dare_server.c:1806 */
-                Fd.ring[off + 28 + f] = 1;                           /* local reply byte, dare_ibv_rc.c:1840 */
-                if (sender < APUS_DEV_MAX_SERVERS && E.rep[sender].ring)
-                    E.rep[sender].ring[off + 28 + f] = 1;            /* R3: 1-byte WRITE at the same offset */
-                bits |= 1u << f;
-            }
-            uint32_t word;
-            if (bits && sender == E.leader) word = atomicOr(&Ld.ack[di], bits) | bits;
-            else word = __hip_atomic_load(&Ld.ack[di], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t mm = (word | (1u << E.leader)) & size_mask;
-            ok = (s < lh[H_N_COMMIT]) || (uint32_t)__popc(mm) >= quorum;   /* replies >= size/2+1, :1738 */
+    constexpr int ILP = 4;                       /* slots per thread and pass, loads issued together */
+    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x * ILP;
+    const uint64_t n_commit = lh[H_N_COMMIT];
+    for (uint64_t tile = lo + (uint64_t)blockIdx.x * blockDim.x * ILP; tile < vis; tile += nth) {
+        uint64_t sl[ILP];
+        uint32_t bits[ILP], sender[ILP];
+        bool in[ILP];
+#pragma unroll
+        for (int k = 0; k < ILP; k++) {
+            sl[k] = tile + (uint64_t)k * blockDim.x + threadIdx.x;
+            in[k] = sl[k] < vis;
+            bits[k] = 0; sender[k] = E.leader;
         }
-        const unsigned long long bal = __ballot(!ok);
-        if (bal && lane_id() == 0) {
-            const uint64_t first = s + (uint64_t)__builtin_ctzll(bal);
-            atomicMin((unsigned long long *)&E.seq->first_fail, (unsigned long long)first);
+        for (uint32_t m = fmask; m; m &= m - 1) {
+            const int f = __builtin_ctz(m);
+            const RepDev &Fd = E.rep[f];
+            const uint64_t f_np = Fd.hdr[H_N_PERSIST];
+            uint64_t off[ILP]; uint32_t dl[ILP]; bool todo[ILP];
+#pragma unroll
+            for (int k = 0; k < ILP; k++) {
+                todo[k] = in[k] && sl[k] >= f_np;                    /* else: this follower persisted it earlier */
+                const uint32_t di = (uint32_t)sl[k] & E.dir_mask;
+                off[k] = todo[k] ? Fd.dir_off[di] : 0;               /* the follower reads its own log */
+                dl[k] = todo[k] ? Fd.dir_len[di] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < ILP; k++) {
+                if (!todo[k]) continue;
+                sender[k] = dl[k] >> 24;                             /* entry->sender, dare_server.c:1806 */
+                Fd.ring[off[k] + 28 + f] = 1;                        /* local reply byte, dare_ibv_rc.c:1840 */
+                if (sender[k] < APUS_DEV_MAX_SERVERS && E.rep[sender[k]].ring)
+                    E.rep[sender[k]].ring[off[k] + 28 + f] = 1;      /* R3: 1-byte WRITE at the same offset */
+                bits[k] |= 1u << f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ILP; k++) {
+            bool ok = true;
+            if (in[k]) {
+                const uint32_t di = (uint32_t)sl[k] & E.dir_mask;
+                uint32_t word;
+                if (bits[k] && sender[k] == E.leader) word = atomicOr(&Ld.ack[di], bits[k]) | bits[k];
+                else word = __hip_atomic_load(&Ld.ack[di], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t mm = (word | (1u << E.leader)) & size_mask;
+                ok = (sl[k] < n_commit) || (uint32_t)__popc(mm) >= quorum;   /* replies >= size/2+1, :1738 */
+            }
+            const unsigned long long bal = __ballot(!ok);
+            if (bal && lane_id() == 0) {
+                const uint64_t first = sl[k] + (uint64_t)__builtin_ctzll(bal);
+                atomicMin((unsigned long long *)&E.seq->first_fail, (unsigned long long)first);
+            }
         }
     }
 }
@@ -583,32 +605,47 @@ __device__ static inline void apply_range(const EngDev &E, int p, uint64_t cs, u
     const uint64_t from = Pd.hdr[H_N_APPLY];
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
     __syncthreads();
-    for (uint64_t tile = from + tile0; tile < cs; tile += tile_stride) {
-        const uint64_t s = tile + threadIdx.x;
-        const bool in = s < cs;
+    /* APPLY_ILP slots per thread and pass: the three dependent memory steps (directory ->
+     * header -> record) are issued for all of them before the first result is needed */
+    constexpr int APPLY_ILP = 4;
+    for (uint64_t tile = from + tile0 * APPLY_ILP; tile < cs; tile += tile_stride * APPLY_ILP) {
+        uint64_t sl[APPLY_ILP], off[APPLY_ILP];
+        uint32_t T[APPLY_ILP];
+        bool in[APPLY_ILP];
+#pragma unroll
+        for (int k = 0; k < APPLY_ILP; k++) {
+            sl[k] = tile + (uint64_t)k * blockDim.x + threadIdx.x;
+            in[k] = sl[k] < cs;
+            const uint32_t di = (uint32_t)sl[k] & E.dir_mask;
+            off[k] = in[k] ? Pd.dir_off[di] : 0;
+            T[k] = in[k] ? (Pd.dir_len[di] & 0xFFFFFFu) : APUS_HDR;
+        }
+        uint4 u0[APPLY_ILP], u1[APPLY_ILP];
+#pragma unroll
+        for (int k = 0; k < APPLY_ILP; k++) {
+            u0[k] = in[k] ? ld16u(Pd.ring + off[k]) : make_uint4(0, 0, 0, 0);
+            u1[k] = in[k] ? ld16u(Pd.ring + off[k] + 16) : make_uint4(0, 0, 0, 0);
+        }
         uint64_t mix = 0;
-        uint32_t client = 0;
-        if (in) {
-            const uint32_t di = (uint32_t)s & E.dir_mask;
-            const uint64_t off = Pd.dir_off[di];
-            const uint32_t T = Pd.dir_len[di] & 0xFFFFFFu;
-            const uint4 u0 = ld16u(Pd.ring + off);
-            const uint4 u1 = ld16u(Pd.ring + off + 16);
-            const uint64_t idx = (uint64_t)u0.x | ((uint64_t)u0.y << 32);
-            const uint32_t type = (u1.z >> 16) & 0xFF;
-            const uint16_t clt = (uint16_t)(u1.z & 0xFFFF);
-            client = (type != 0 && type != 2 && type != 3);
+        uint32_t nclient = 0;
+#pragma unroll
+        for (int k = 0; k < APPLY_ILP; k++) {
+            if (!in[k]) continue;
+            const uint64_t idx = (uint64_t)u0[k].x | ((uint64_t)u0[k].y << 32);
+            const uint32_t type = (u1[k].z >> 16) & 0xFF;
+            const uint16_t clt = (uint16_t)(u1[k].z & 0xFFFF);
+            const uint32_t client = (type != 0 && type != 2 && type != 3);
             apus_apply_rec rec;
-            rec.slot = s; rec.off = off; rec.idx = idx; rec.len = T - APUS_HDR;
+            rec.slot = sl[k]; rec.off = off[k]; rec.idx = idx; rec.len = T[k] - APUS_HDR;
             rec.clt_id = clt; rec.type = (uint8_t)type;
             rec.kind = client ? (leader ? 1 : 2) : 0;
-            Pd.apply[di] = rec;
-            if (client) mix = apus_apply_mix(s, off, idx, T - APUS_HDR, clt, (uint8_t)type, rec.kind);
+            Pd.apply[(uint32_t)sl[k] & E.dir_mask] = rec;
+            if (client) { mix += apus_apply_mix(sl[k], off[k], idx, T[k] - APUS_HDR, clt, (uint8_t)type, rec.kind); nclient++; }
             if (type == 3 && !leader)                  /* poll_config_entries: committed HEAD, dare_server.c:2164 */
-                atomicMax((unsigned long long *)&Pd.hdr[H_HEAD_SLOT], (unsigned long long)(s + 1));
+                atomicMax((unsigned long long *)&Pd.hdr[H_HEAD_SLOT], (unsigned long long)(sl[k] + 1));
         }
         const uint64_t wsum = wave_sum(mix);
-        const uint32_t wcnt = (uint32_t)__popcll(__ballot(client != 0));
+        const uint32_t wcnt = wave_sum(nclient);
         if (lane_id() == 0 && wcnt) {
             atomicAdd(&s_acc[0], (unsigned long long)wsum);
             atomicAdd(&s_acc[1], (unsigned long long)wcnt);
