@@ -282,7 +282,7 @@ static int launch_tail_view(apus_engine *e, const EngDev &view, uint64_t r0, uin
     const uint32_t rm = fm | ((e->local_mask >> e->d.leader) & 1u ? (1u << e->d.leader) : 0);
     const uint64_t n = n_hint ? n_hint : 1;
     if (fm)     /* followers on this device: persist + ACK + quorum test in one pass */
-        hipLaunchKernelGGL(k_persist_commit, dim3(cap_grid(n, 1024, 2048)), dim3(256), 0, e->stream, view, r0, R, fm);
+        hipLaunchKernelGGL(k_persist_commit, dim3(cap_grid(n, 256, 2048)), dim3(256), 0, e->stream, view, r0, R, fm);
     else        /* ACK bits were merged from remote followers (k_mp_ack_merge) */
         hipLaunchKernelGGL(k_commit, dim3(cap_grid(n, 1024, 512)), dim3(1024), 0, e->stream, view, r0, R);
     hipLaunchKernelGGL(k_apply, dim3(cap_grid(n, 1024, 1024), popc(rm)), dim3(256), 0, e->stream, view, r0, R, rm, mode, fm);

@@ -504,57 +504,35 @@ __global__ __launch_bounds__(256) void k_persist_commit(const EngDev E, uint64_t
     uint64_t lo = lh[H_N_COMMIT];
     for (uint32_t m = fmask; m; m &= m - 1) lo = min(lo, E.rep[__builtin_ctz(m)].hdr[H_N_PERSIST]);
     const uint32_t size = E.group_size, size_mask = (1u << size) - 1, quorum = size / 2 + 1;
-    constexpr int ILP = 4;                       /* slots per thread and pass, loads issued together */
-    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x * ILP;
-    const uint64_t n_commit = lh[H_N_COMMIT];
-    for (uint64_t tile = lo + (uint64_t)blockIdx.x * blockDim.x * ILP; tile < vis; tile += nth) {
-        uint64_t sl[ILP];
-        uint32_t bits[ILP], sender[ILP];
-        bool in[ILP];
-#pragma unroll
-        for (int k = 0; k < ILP; k++) {
-            sl[k] = tile + (uint64_t)k * blockDim.x + threadIdx.x;
-            in[k] = sl[k] < vis;
-            bits[k] = 0; sender[k] = E.leader;
+    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t tile = lo + (uint64_t)blockIdx.x * blockDim.x; tile < vis; tile += nth) {
+        const uint64_t s = tile + threadIdx.x;
+        const bool in = s < vis;
+        bool ok = true;
+        if (in) {
+            const uint32_t di = (uint32_t)s & E.dir_mask;
+            uint32_t bits = 0, sender = E.leader;
+            for (uint32_t m = fmask; m; m &= m - 1) {
+                const int f = __builtin_ctz(m);
+                const RepDev &Fd = E.rep[f];
+                if (s < Fd.hdr[H_N_PERSIST]) continue;               /* this follower persisted it earlier */
+                const uint64_t off = Fd.dir_off[di];                 /* the follower reads its own log */
+                sender = Fd.dir_len[di] >> 24;                       /* entry->sender, dare_server.c:1806 */
+                Fd.ring[off + 28 + f] = 1;                           /* local reply byte, dare_ibv_rc.c:1840 */
+                if (sender < APUS_DEV_MAX_SERVERS && E.rep[sender].ring)
+                    E.rep[sender].ring[off + 28 + f] = 1;            /* R3: 1-byte WRITE at the same offset */
+                bits |= 1u << f;
+            }
+            uint32_t word;
+            if (bits && sender == E.leader) word = atomicOr(&Ld.ack[di], bits) | bits;
+            else word = __hip_atomic_load(&Ld.ack[di], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t mm = (word | (1u << E.leader)) & size_mask;
+            ok = (s < lh[H_N_COMMIT]) || (uint32_t)__popc(mm) >= quorum;   /* replies >= size/2+1, :1738 */
         }
-        for (uint32_t m = fmask; m; m &= m - 1) {
-            const int f = __builtin_ctz(m);
-            const RepDev &Fd = E.rep[f];
-            const uint64_t f_np = Fd.hdr[H_N_PERSIST];
-            uint64_t off[ILP]; uint32_t dl[ILP]; bool todo[ILP];
-#pragma unroll
-            for (int k = 0; k < ILP; k++) {
-                todo[k] = in[k] && sl[k] >= f_np;                    /* else: this follower persisted it earlier */
-                const uint32_t di = (uint32_t)sl[k] & E.dir_mask;
-                off[k] = todo[k] ? Fd.dir_off[di] : 0;               /* the follower reads its own log */
-                dl[k] = todo[k] ? Fd.dir_len[di] : 0;
-            }
-#pragma unroll
-            for (int k = 0; k < ILP; k++) {
-                if (!todo[k]) continue;
-                sender[k] = dl[k] >> 24;                             /* entry->sender, dare_server.c:1806 */
-                Fd.ring[off[k] + 28 + f] = 1;                        /* local reply byte, dare_ibv_rc.c:1840 */
-                if (sender[k] < APUS_DEV_MAX_SERVERS && E.rep[sender[k]].ring)
-                    E.rep[sender[k]].ring[off[k] + 28 + f] = 1;      /* R3: 1-byte WRITE at the same offset */
-                bits[k] |= 1u << f;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < ILP; k++) {
-            bool ok = true;
-            if (in[k]) {
-                const uint32_t di = (uint32_t)sl[k] & E.dir_mask;
-                uint32_t word;
-                if (bits[k] && sender[k] == E.leader) word = atomicOr(&Ld.ack[di], bits[k]) | bits[k];
-                else word = __hip_atomic_load(&Ld.ack[di], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t mm = (word | (1u << E.leader)) & size_mask;
-                ok = (sl[k] < n_commit) || (uint32_t)__popc(mm) >= quorum;   /* replies >= size/2+1, :1738 */
-            }
-            const unsigned long long bal = __ballot(!ok);
-            if (bal && lane_id() == 0) {
-                const uint64_t first = sl[k] + (uint64_t)__builtin_ctzll(bal);
-                atomicMin((unsigned long long *)&E.seq->first_fail, (unsigned long long)first);
-            }
+        const unsigned long long bal = __ballot(!ok);
+        if (bal && lane_id() == 0) {
+            const uint64_t first = s + (uint64_t)__builtin_ctzll(bal);
+            atomicMin((unsigned long long *)&E.seq->first_fail, (unsigned long long)first);
         }
     }
 }
