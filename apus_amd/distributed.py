@@ -31,7 +31,7 @@ import torch.distributed as dist
 from .engine import Engine, EngineError
 from .trace import DEFAULT_LOG
 
-OP_DATA, OP_STOP = 1, 2
+OP_DATA, OP_STOP, OP_MARK = 1, 2, 3
 HDR_WORDS, REPLY_WORDS = 16, 4
 H_APPLY_OFFSETS = 23          # apus_device.h
 
@@ -101,6 +101,12 @@ class Transport:
             dist.recv(tmp, src)
             view.copy_(tmp)
 
+    def fence(self):
+        """Received bytes are in HBM before the engine's own stream touches them: RCCL
+        completes on torch's stream, the engine launches on its own non-blocking one."""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
 
 def ship_range(tp: Transport, dst: int, ring, dir_off, dir_len, o0: int, o1: int, s0: int, s1: int,
                log_len: int, dir_cap: int, commit_slot: int, term: int):
@@ -124,6 +130,7 @@ def recv_range(tp: Transport, src: int, ring, dir_off, dir_len, o0: int, o1: int
     for a, b in slot_pieces(s0, s1, dir_cap):
         tp.recv_bytes(dir_off[8 * a:8 * b], src)
         tp.recv_bytes(dir_len[4 * a:4 * b], src)
+    tp.fence()
 
 
 class GroupMember:
@@ -147,6 +154,7 @@ class GroupMember:
         self.shipped_off = {f: log_len for f in self.followers}     # log_len == empty
         self.acked = {f: 0 for f in self.followers}
         self.term = 0
+        self.marks = []
 
     # ---------------------------------------------------------------- leader
     def elect(self):
@@ -219,6 +227,16 @@ class GroupMember:
         for f in self.followers:
             self.tp.send_words([OP_STOP] + [0] * (HDR_WORDS - 1), f)
 
+    def mark(self):
+        """Timing mark on every rank: device sync + barrier, then a timestamp."""
+        if self.is_leader:
+            for f in self.followers:
+                self.tp.send_words([OP_MARK] + [0] * (HDR_WORDS - 1), f)
+        self.eng.sync()
+        torch.cuda.synchronize(self.device)
+        dist.barrier()
+        self.marks.append(time.perf_counter())
+
     # -------------------------------------------------------------- follower
     def follower_serve(self):
         """Serve the leader until it says stop."""
@@ -227,6 +245,9 @@ class GroupMember:
             h = self.tp.recv_words(HDR_WORDS, self.leader)
             if h[0] == OP_STOP:
                 return
+            if h[0] == OP_MARK:
+                self.mark()
+                continue
             _, o0, o1, s0, s1, commit, term, npieces = h[:8]
             if s1 > s0:
                 recv_range(self.tp, self.leader, self.ring, self.dir_off, self.dir_len, o0, o1, s0, s1,
@@ -280,11 +301,18 @@ def bench_group(args):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    # test hooks for a one-GPU box: every rank on device 0, exchange staged through gloo
+    backend = os.environ.get("APUS_DIST_BACKEND", "nccl")
+    if os.environ.get("APUS_DIST_ONE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     n = world
     tr = T.steady_trace(n, args.entries, args.payload, 16, args.batch, log_len=T.DEFAULT_LOG, name="C2")
-    m = GroupMember(n, rank, 0, local, "nccl", tr.log_len)
+    m = GroupMember(n, rank, 0, local, backend, tr.log_len)
     calls = None
     if m.is_leader:
         m.eng.stage_trace(tr)
@@ -310,33 +338,27 @@ def bench_group(args):
                 m.leader_prune()
         m.leader_quiesce()
 
-    sync_t = torch.zeros(1, device=m.device)
     if m.is_leader:
         m.sync_followers()
         m.eng.quiesce()
         for _ in range(args.warmup):
             leader_step()
-        m.eng.sync()
-        # followers are in follower_serve(); the timed region is bracketed on the leader,
-        # whose every step ends with a quiesce that waits for all followers' replies
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        # exactly K steps between two marks; a mark = device sync + barrier on every rank
+        m.mark()
         for _ in range(args.steps):
             leader_step()
-        m.eng.sync()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        m.mark()
         m.leader_stop()
     else:
         m.follower_serve()
-        m.eng.sync()
-        dt = 0.0
-    # barrier + max over ranks (followers finish when the leader's last quiesce returned)
-    t = torch.tensor([dt], dtype=torch.float64, device=m.device)
+    dt = m.marks[1] - m.marks[0]
+    # max over ranks
+    red_dev = m.device if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     n_entries = len(tr.reqs)
-    ok = torch.ones(1, device=m.device)
+    ok = torch.ones(1, device=red_dev)
     o = m.eng.offsets(rank)
     total = (args.warmup + args.steps) * n_entries
     applied = m.eng.counters(rank)["highest_rec"] if m.is_leader else int(m.eng.hdr_words(rank)[16])
@@ -352,7 +374,7 @@ def bench_group(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{n} replicas, one per GPU (RCCL p2p over xGMI), {n_entries} entries/step "
+            "config": {"workload": f"{n} replicas, one per GPU ({'RCCL p2p over xGMI' if backend == 'nccl' else backend + ' staging (test mode)'}), {n_entries} entries/step "
                                    f"of {args.payload} B, rounds of {args.batch}, prune tick every 8 MiB",
                        "mode": "one process per replica GPU", "replicas": n, "entry_bytes": E},
             "verified": bool(ok.item() == 1),

@@ -26,3 +26,7 @@ if [ -n "$PMC" ]; then
     ls gpurun_out/pmc_$c | head
   done
 fi
+if [ -n "$GROUP" ]; then
+  APUS_DIST_BACKEND=gloo APUS_DIST_ONE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 3 --steps 2 --warmup 1 --entries 262144 > gpurun_out/bench_group.log 2>&1
+  echo "group bench exit: $?"; tail -3 gpurun_out/bench_group.log | cut -c1-600
+fi
