@@ -891,6 +891,27 @@ extern "C" int apus_gpu_persist_latency(apus_engine_t *e, uint32_t *out_ns, uint
     return 0;
 }
 
+/* App-visible latency of the live path, measured in C: `iters` times, submit one round of
+ * n <= 64 requests and spin on highest_rec (exactly what proxy.c:160 does); out_ns[i] =
+ * submit -> released */
+extern "C" int apus_gpu_persist_roundtrip(apus_engine_t *e, const apus_req_t *reqs, uint32_t n,
+                                          const uint8_t *arena, uint64_t arena_bytes,
+                                          uint32_t iters, uint32_t *out_ns)
+{
+    if (!e || !e->p_running || n == 0 || n > APUS_MAX_ROUND) return APUS_E_STATE;
+    for (uint32_t i = 0; i < iters; i++) {
+        const uint64_t target = e->ph->highest_rec + n;
+        const double t0 = mono_s();
+        int rc = apus_gpu_persist_submit(e, reqs, n, arena, arena_bytes);
+        if (rc) return rc;
+        while (e->ph->highest_rec < target) {
+            if (e->ph->alive == 2 || mono_s() - t0 > 2.0) return -1;
+        }
+        out_ns[i] = (uint32_t)((mono_s() - t0) * 1e9);
+    }
+    return 0;
+}
+
 extern "C" int apus_gpu_device_arch(int device, char *out, int cap)
 {
     hipDeviceProp_t p;

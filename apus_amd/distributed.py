@@ -101,6 +101,29 @@ class Transport:
             dist.recv(tmp, src)
             view.copy_(tmp)
 
+    # ---- batched point-to-point (one ncclGroup per call on RCCL: all links at once) ----
+    def batch_send(self, items):
+        """items: [(tensor, dst)]"""
+        if not items:
+            return
+        keep = [(t if self.direct else t.cpu().contiguous(), d) for t, d in items]
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, d) for t, d in keep]):
+            w.wait()
+
+    def batch_recv(self, items):
+        """items: [(view, src)]; data lands in the views"""
+        if not items:
+            return
+        if self.direct:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, v, s_) for v, s_ in items]):
+                w.wait()
+            return
+        tmps = [(torch.empty(v.shape, dtype=v.dtype), v, s_) for v, s_ in items]
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, t, s_) for t, _, s_ in tmps]):
+            w.wait()
+        for t, v, _ in tmps:
+            v.copy_(t)
+
     def fence(self):
         """Received bytes are in HBM before the engine's own stream touches them: RCCL
         completes on torch's stream, the engine launches on its own non-blocking one."""
@@ -108,28 +131,33 @@ class Transport:
             torch.cuda.synchronize(self.device)
 
 
+def range_items(ring, dir_off, dir_len, o0: int, o1: int, s0: int, s1: int, log_len: int, dir_cap: int):
+    """The tensors that make up R1 for slots [s0, s1): ring pieces, then directory pieces."""
+    if s1 <= s0:
+        return []
+    out = [ring[a:b] for a, b in ring_pieces(o0, o1, log_len)]
+    for a, b in slot_pieces(s0, s1, dir_cap):
+        out.append(dir_off[8 * a:8 * b])
+        out.append(dir_len[4 * a:4 * b])
+    return out
+
+
+def header_words(o0, o1, s0, s1, commit_slot, term):
+    return [OP_DATA, o0, o1, s0, max(s1, s0), commit_slot, term, 0] + [0] * 8
+
+
 def ship_range(tp: Transport, dst: int, ring, dir_off, dir_len, o0: int, o1: int, s0: int, s1: int,
                log_len: int, dir_cap: int, commit_slot: int, term: int):
     """Leader side of R1+R2 for one follower: header, ring pieces, directory pieces.
     ring / dir_off / dir_len are byte tensors (device or host)."""
-    pieces = ring_pieces(o0, o1, log_len) if s1 > s0 else []
-    tp.send_words([OP_DATA, o0, o1, s0, s1 if s1 > s0 else s0, commit_slot, term, len(pieces)] + [0] * 8, dst)
-    for a, b in pieces:
-        tp.send_bytes(ring[a:b], dst)
-    if s1 > s0:
-        for a, b in slot_pieces(s0, s1, dir_cap):
-            tp.send_bytes(dir_off[8 * a:8 * b], dst)
-            tp.send_bytes(dir_len[4 * a:4 * b], dst)
+    tp.send_words(header_words(o0, o1, s0, s1, commit_slot, term), dst)
+    tp.batch_send([(t, dst) for t in range_items(ring, dir_off, dir_len, o0, o1, s0, s1, log_len, dir_cap)])
 
 
 def recv_range(tp: Transport, src: int, ring, dir_off, dir_len, o0: int, o1: int, s0: int, s1: int,
                log_len: int, dir_cap: int):
     """Follower side: the bytes land at the same offsets of the local ring / directory."""
-    for a, b in ring_pieces(o0, o1, log_len):
-        tp.recv_bytes(ring[a:b], src)
-    for a, b in slot_pieces(s0, s1, dir_cap):
-        tp.recv_bytes(dir_off[8 * a:8 * b], src)
-        tp.recv_bytes(dir_len[4 * a:4 * b], src)
+    tp.batch_recv([(t, src) for t in range_items(ring, dir_off, dir_len, o0, o1, s0, s1, log_len, dir_cap)])
     tp.fence()
 
 
@@ -167,35 +195,39 @@ class GroupMember:
             self.eng._chk(self.eng.L.apus_gpu_follow(self.eng.h, self.rank, self.leader, self.term, mask), "follow")
 
     def _leader_state(self):
-        out = (C.c_uint64 * 8)()
-        self.eng._chk(self.eng.L.apus_gpu_ship_info(self.eng.h, out), "ship_info")
-        end, n_end, vis = int(out[1]), int(out[3]), int(out[4])
-        o = self.eng.offsets(self.rank)
-        c = self.eng.counters(self.rank)
-        if o["end"] == self.log_len:
-            vis = int(self.eng.hdr_words(self.rank)[22])      # H_N_VISIBLE: nothing new is visible
+        """(visible slot, its byte offset, commit slot) of the leader: one read-back."""
+        w = self.eng.hdr_words(self.rank)
+        end, n_end, n_commit, n_vis = int(w[3]), int(w[8]), int(w[10]), int(w[22])
+        vis = n_vis if end == self.log_len else n_end          # end == len: the log reads as empty
+        if vis == n_end:
+            vis_off = end
         else:
-            vis = c["n_end"]
-        if vis == c["n_end"]:
-            vis_off = o["end"]
-        else:
-            i = vis % self.dir_cap
-            vis_off = int(self.dir_off.view(torch.int64)[i].item())
-        return vis, vis_off, c["n_commit"], o
+            vis_off = int(self.dir_off.view(torch.int64)[vis % self.dir_cap].item())
+        return vis, vis_off, n_commit
 
     def sync_followers(self):
-        """Ship what the followers lack (R1+R2), collect the ACKs (R3), merge them."""
-        vis, vis_off, n_commit, _ = self._leader_state()
+        """Ship what the followers lack (R1+R2), collect the ACKs (R3), merge them.
+        Every follower is served in the same batch (one link each on xGMI)."""
+        vis, vis_off, n_commit = self._leader_state()
+        hdrs, data = [], []
         for f in self.followers:
             s0, o0 = self.shipped_slot[f], self.shipped_off[f]
-            ship_range(self.tp, f, self.ring, self.dir_off, self.dir_len, o0, vis_off, s0, vis,
-                       self.log_len, self.dir_cap, n_commit, self.term)
+            hdrs.append((self.tp._meta(header_words(o0, vis_off, s0, vis, n_commit, self.term)), f))
+            data += [(t, f) for t in range_items(self.ring, self.dir_off, self.dir_len, o0, vis_off, s0, vis,
+                                                 self.log_len, self.dir_cap)]
             if vis > s0:
                 self.shipped_slot[f], self.shipped_off[f] = vis, vis_off
+        self.tp.batch_send(hdrs)
+        self.tp.batch_send(data)
+        rep = {f: torch.zeros(REPLY_WORDS, dtype=torch.int64, device=self.device if self.tp.direct else "cpu")
+               for f in self.followers}
+        self.tp.batch_recv([(rep[f], f) for f in self.followers])
         replies = {}
         for f in self.followers:
-            r = self.tp.recv_words(REPLY_WORDS, f)
+            r = [int(v) for v in rep[f].cpu().tolist()]
             replies[f] = r
+            if r[3]:
+                raise EngineError(f"follower {f} reports device status {r[3]:#x}")
             if r[0] > self.acked[f]:
                 self.eng._chk(self.eng.L.apus_gpu_ack_merge(self.eng.h, f, self.acked[f], r[0]), "ack_merge")
                 self.acked[f] = r[0]
@@ -254,9 +286,8 @@ class GroupMember:
                            self.log_len, self.dir_cap)
                 eng._chk(L.apus_gpu_ingest(eng.h, self.rank, s1, s1 - s0), "ingest")
             eng._chk(L.apus_gpu_follower_commit(eng.h, self.rank, commit, max(s1 - s0, 1)), "follower_commit")
-            o = eng.offsets(self.rank)                 # synchronises: the ACK means "persisted"
-            c = eng.counters(self.rank)
-            self.tp.send_words([c["n_persist"], c["n_apply"], o["apply"], eng.status()], self.leader)
+            w = eng.hdr_words(self.rank)               # synchronises: the ACK means "persisted"
+            self.tp.send_words([int(w[9]), int(w[11]), int(w[1]), eng.status()], self.leader)
 
     def close(self):
         self.eng.close()

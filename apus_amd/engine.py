@@ -222,6 +222,13 @@ class Engine:
 
     def persist_stop(self) -> int: return int(self.L.apus_gpu_persist_stop(self.h))
 
+    def persist_roundtrip_ns(self, reqs: np.ndarray, arena: np.ndarray, iters: int) -> np.ndarray:
+        reqs = np.ascontiguousarray(reqs, dtype=REQ_DTYPE)
+        out = np.zeros(iters, dtype=np.uint32)
+        self._chk(self.L.apus_gpu_persist_roundtrip(self.h, reqs.ctypes.data, len(reqs), arena.ctypes.data,
+                                                    len(arena), iters, out.ctypes.data), "persist_roundtrip")
+        return out
+
     def persist_latency_ns(self) -> np.ndarray:
         out = np.zeros(1 << 16, dtype=np.uint32)
         n = C.c_uint32(0)

@@ -177,20 +177,12 @@ def bench_single(args):
         reqs64 = np.ascontiguousarray(tr.reqs[16:16 + 64 * 64])
         base = eng.counters(0)["highest_rec"]
         eng.persist_start(idle_ms=2000, peer_ms=200)
-        hl = []
-        for k in range(300):
-            blk = reqs64[(k % 64) * 64:(k % 64) * 64 + 64]
-            t1 = time.perf_counter()
-            eng.persist_submit(blk, tr.arena)
-            base += 64
-            while eng.persist_highest_rec() < base:
-                if time.perf_counter() - t1 > 2.0:
-                    raise RuntimeError("persistent kernel did not commit")
-            hl.append((time.perf_counter() - t1) * 1e6)
+        blk = reqs64[:64]
+        hl = eng.persist_roundtrip_ns(blk, tr.arena, 400) / 1e3       # C loop: submit -> highest_rec
         eng.persist_drain()
         code = eng.persist_stop()
         dl = eng.persist_latency_ns()
-        plat_host = float(np.percentile(hl[20:], 50))
+        plat_host = float(np.percentile(hl[40:], 50))
         plat_dev = float(np.percentile(dl[20:], 50)) / 1e3 if len(dl) > 20 else None
         eng.quiesce()
         eng.check_status()
