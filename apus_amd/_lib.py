@@ -61,6 +61,7 @@ SIGNATURES = {
     "apus_gpu_persist_drain": (C.c_int, [vp, u32]),
     "apus_gpu_persist_highest_rec": (u64, [vp]),
     "apus_gpu_persist_stop": (C.c_int, [vp]),
+    "apus_gpu_persist_latency_phase": (C.c_int, [vp, C.c_int, vp, u32, C.POINTER(u32)]),
     "apus_gpu_persist_roundtrip": (C.c_int, [vp, vp, u32, vp, u64, u32, vp]),
     "apus_gpu_persist_latency": (C.c_int, [vp, vp, u32, C.POINTER(u32)]),
     "apus_gpu_submit": (C.c_int, [vp, vp, u32, vp, u64]),

@@ -784,14 +784,15 @@ extern "C" int apus_gpu_persist_start(apus_engine_t *e, uint32_t idle_ms, uint32
     return 0;
 }
 
-static int persist_push_event(apus_engine *e, uint32_t op, uint32_t n, uint64_t req_first, uint64_t req_end)
+static int persist_push_event(apus_engine *e, uint32_t op, uint32_t n, uint64_t req_first, uint64_t req_end,
+                              uint32_t arena_off = 0, uint32_t arena_bytes = 0)
 {
     const double t0 = mono_s();
     while (e->p_ev_tail - e->ph->ev_head >= P_EV_CAP - 1) {
         if (e->ph->alive == 2 || mono_s() - t0 > 5.0) return APUS_E_STATE;
     }
     PEvent &ev = e->ph->ev[e->p_ev_tail % P_EV_CAP];
-    ev.op = op; ev.n = n; ev.req_first = req_first;
+    ev.op = op; ev.n = n; ev.req_first = req_first; ev.arena_off = arena_off; ev.arena_bytes = arena_bytes;
     e->p_req_end[e->p_ev_tail % P_EV_CAP] = req_end;
     e->p_ev_tail++;
     __atomic_store_n((uint64_t *)&e->ph->ev_tail, e->p_ev_tail, __ATOMIC_RELEASE);
@@ -822,6 +823,7 @@ extern "C" int apus_gpu_persist_submit(apus_engine_t *e, const apus_req_t *reqs,
         }
         while (e->p_req_tail + nr - persist_req_consumed(e) > P_REQ_CAP)
             if (e->ph->alive == 2 || mono_s() - t0 > 5.0) return APUS_E_STATE;
+        const uint64_t batch_pos = 16 + e->p_arena_pos;
         for (uint32_t k = 0; k < nr; k++) {
             const apus_req_t &q = reqs[g0 + k];
             if (q.type == APUS_NOOP || q.type == APUS_CONFIG || q.type == APUS_HEAD || q.type > 15) return APUS_E_ARG;
@@ -838,7 +840,8 @@ extern "C" int apus_gpu_persist_submit(apus_engine_t *e, const apus_req_t *reqs,
         }
         const uint64_t first = e->p_req_tail % P_REQ_CAP;
         e->p_req_tail += nr;
-        int rc = persist_push_event(e, P_OP_ROUND, nr, first, e->p_req_tail);
+        int rc = persist_push_event(e, P_OP_ROUND, nr, first, e->p_req_tail, (uint32_t)batch_pos,
+                                    (uint32_t)(16 + e->p_arena_pos - batch_pos));
         if (rc) return rc;
     }
     return 0;
@@ -909,6 +912,23 @@ extern "C" int apus_gpu_persist_roundtrip(apus_engine_t *e, const apus_req_t *re
         }
         out_ns[i] = (uint32_t)((mono_s() - t0) * 1e9);
     }
+    return 0;
+}
+
+/* phase breakdown of the same samples: which = 1: event seen -> sequenced, 2: -> pushed + doorbell */
+extern "C" int apus_gpu_persist_latency_phase(apus_engine_t *e, int which, uint32_t *out_ns, uint32_t cap, uint32_t *n_out)
+{
+    if (!e || !e->pd || e->p_running || (which != 1 && which != 2)) return APUS_E_STATE;
+    uint32_t n = 0;
+    HIPCHK(hipMemcpy(&n, &e->pd->lat_n, sizeof n, hipMemcpyDeviceToHost));
+    if (n > cap) n = cap;
+    const uint32_t *src = which == 1 ? e->pd->lat_seq : e->pd->lat_push;
+    if (n) HIPCHK(hipMemcpy(out_ns, src, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    int khz = 100000;
+    hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device);
+    if (khz <= 0) khz = 100000;
+    for (uint32_t i = 0; i < n; i++) out_ns[i] = (uint32_t)((uint64_t)out_ns[i] * 1000000ull / (uint64_t)khz);
+    if (n_out) *n_out = n;
     return 0;
 }
 

@@ -35,7 +35,10 @@
 
 enum { P_OP_ROUND = 1, P_OP_PRUNE = 2, P_OP_STOP = 3 };
 
-struct PEvent { uint32_t op; uint32_t n; uint64_t req_first; };
+struct PEvent { uint32_t op; uint32_t n; uint64_t req_first;
+                uint32_t arena_off;      /* the round's payloads are contiguous in the pinned arena: [off, off+bytes) */
+                uint32_t arena_bytes; };
+#define P_PREFETCH_BYTES (32u << 10)    /* rounds whose payloads fit are prefetched into LDS in one PCIe round trip */
 
 /* host-coherent control block (hipHostMalloc, mapped) */
 struct PersistHost {
@@ -62,6 +65,8 @@ struct PersistDev {
     uint32_t lat_n;
     uint32_t pad;
     uint32_t lat_ticks[P_LAT_CAP];               /* append -> commit, wall_clock64 ticks */
+    uint32_t lat_seq[P_LAT_CAP];                 /* event seen -> offsets/headers computed   */
+    uint32_t lat_push[P_LAT_CAP];                /* ... -> bytes pushed + end doorbell rung   */
 };
 
 #define RLX_AGENT  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -72,17 +77,50 @@ __device__ static inline void st_agent(uint64_t *p, uint64_t v) { __hip_atomic_s
 __device__ static inline uint64_t ld_sys(const volatile uint64_t *p) { return __hip_atomic_load((const uint64_t *)p, RLX_SYSTEM); }
 __device__ static inline void st_sys(volatile uint64_t *p, uint64_t v) { __hip_atomic_store((uint64_t *)p, v, RLX_SYSTEM); }
 
-/* 16 bytes to another workgroup's view of memory: write-through stores */
+/* 16 bytes to another workgroup's view of memory: ONE write-through store
+ * (global_store_dwordx4 sc0 sc1 = the R1 store of cdna_hip_programming.md G16); byte-wise
+ * agent-scope stores when the address is not dword aligned (unaligned entries) */
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
 __device__ static inline void st16_agent(uint8_t *p, uint4 v)
 {
-    if ((((uintptr_t)p) & 7) == 0) {
-        st_agent((uint64_t *)p, (uint64_t)v.x | ((uint64_t)v.y << 32));
-        st_agent((uint64_t *)(p + 8), (uint64_t)v.z | ((uint64_t)v.w << 32));
+    if ((((uintptr_t)p) & 3) == 0) {
+        v4u_t d = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(d) : "memory");
     } else {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         for (int i = 0; i < 16; i++)
             __hip_atomic_store(p + i, (uint8_t)(w[i >> 2] >> (8 * (i & 3))), RLX_AGENT);
     }
+}
+
+/* 16 bytes at an arbitrary byte offset of an LDS buffer (dword reads + funnel shift) */
+__device__ static inline uint4 lds_ld16u(const uint32_t *buf, uint32_t byte_off)
+{
+    const uint32_t i = byte_off >> 2, sh = (byte_off & 3) * 8;
+    const uint32_t d0 = buf[i], d1 = buf[i + 1], d2 = buf[i + 2], d3 = buf[i + 3], d4 = buf[i + 4];
+    if (sh == 0) return make_uint4(d0, d1, d2, d3);
+    return make_uint4((d0 >> sh) | (d1 << (32 - sh)), (d1 >> sh) | (d2 << (32 - sh)),
+                      (d2 >> sh) | (d3 << (32 - sh)), (d3 >> sh) | (d4 << (32 - sh)));
+}
+
+/* payload_unit() on a payload that sits in LDS at byte offset `src` (bytes src-2 .. readable) */
+__device__ static inline uint4 payload_unit_lds(const uint32_t *buf, uint32_t src, uint32_t so, uint32_t P, uint32_t len16)
+{
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (P == 0 && so >= 50) return v;
+    uint64_t lo = 0, hi = 0;
+    if (P != 0) {
+        v = lds_ld16u(buf, src + so - 50);
+        lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        const int vb = so < 50 ? (int)(50 - so) : 0;
+        const int ve = (int)min(16u, 50u + P - so);
+        lo &= byte_mask64(vb, ve);
+        hi &= byte_mask64(vb - 8, ve - 8);
+    }
+    if (so == 48)      lo |= (uint64_t)(len16 & 0xFFFFu);
+    else if (so == 49) lo |= (uint64_t)((len16 >> 8) & 0xFFu);
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
 
 /* bounded wait until *p (agent scope) reaches `want`; lane 0 of wave 0 polls */
@@ -110,6 +148,7 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
     __shared__ uint32_t s_ack[WAVE];                  /* ACK bitmaps of the window               */
     __shared__ uint64_t s_sid[APUS_DEV_MAX_SERVERS];  /* ballot numbers (SIDs) of the group      */
     __shared__ unsigned long long s_acc[2];
+    __shared__ uint32_t s_pay[(P_PREFETCH_BYTES + 64) / 4];   /* the round's payload bytes (leader) */
     const uint32_t tid = threadIdx.x, lane = lane_id();
     const uint64_t L = E.log_len;
 
@@ -134,11 +173,10 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
                     com = ld_agent(&D->commit_bell[me]);
                     if (vis > n_persist || com > n_apply) break;
                     if (ld_agent(&D->quit)) { code = 1; break; }
-                    if (i >= idle_polls + peer_polls) { code = 2; break; }
-                    __builtin_amdgcn_s_sleep(4);
+                    if (i >= 16 * (idle_polls + peer_polls)) { code = 2; break; }   /* safety net only: the leader's quit bell ends us */
+                    __builtin_amdgcn_s_sleep(1);
                 }
                 s_word[0] = code; s_word[1] = vis; s_word[2] = com;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       /* ONE acquire after the poll */
             }
             __syncthreads();
             const uint64_t code = s_word[0], vis = s_word[1];
@@ -146,10 +184,12 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
             if (code) break;
             if (vis > n_persist) {
                 /* persist_new_entries + rc_send_entries_reply for slots [n_persist, vis) */
+                /* the directory words were published with write-through stores: L1-bypassing
+                 * loads read them without an acquire fence (G16: sc1 loads pair with sc1 stores) */
                 for (uint64_t s = n_persist + tid; s < vis; s += blockDim.x) {
                     const uint32_t di = (uint32_t)s & E.dir_mask;
-                    const uint64_t off = Md.dir_off[di];
-                    const uint32_t sender = Md.dir_len[di] >> 24;
+                    const uint64_t off = ld_agent(&Md.dir_off[di]);
+                    const uint32_t sender = __hip_atomic_load(&Md.dir_len[di], RLX_AGENT) >> 24;
                     __hip_atomic_store(Md.ring + off + 28 + me, (uint8_t)1, RLX_AGENT);
                     if (sender < APUS_DEV_MAX_SERVERS && E.rep[sender].ring) {
                         __hip_atomic_store(E.rep[sender].ring + off + 28 + me, (uint8_t)1, RLX_AGENT);   /* R3 */
@@ -159,7 +199,7 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
                 if (tid == 0) {
                     /* R2: the new end = the byte after the last visible entry (own directory) */
                     const uint32_t dl = (uint32_t)(vis - 1) & E.dir_mask;
-                    const uint64_t lend = Md.dir_off[dl] + (Md.dir_len[dl] & 0xFFFFFFu);
+                    const uint64_t lend = ld_agent(&Md.dir_off[dl]) + (__hip_atomic_load(&Md.dir_len[dl], RLX_AGENT) & 0xFFFFFFu);
                     mh[H_STORE_COUNT] += vis - n_persist;
                     mh[H_END] = lend; mh[H_OLD_END] = lend; mh[H_N_END] = vis; mh[H_N_PERSIST] = vis;
                 }
@@ -167,6 +207,7 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
             }
             if (com > n_persist) com = n_persist;
             if (com > n_apply) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       /* ring headers were written by the leader WG */
                 apply_range(E, me, com, 0, blockDim.x, s_acc);
                 if (tid == 0) {
                     const uint64_t coff = (com == mh[H_N_END]) ? mh[H_END] : Md.dir_off[(uint32_t)com & E.dir_mask];
@@ -211,6 +252,7 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");       /* system scope: the event and its requests */
                 const PEvent ev = H->ev[ev_head % P_EV_CAP];
                 s_word[1] = ev.op; s_word[2] = ev.n; s_word[3] = ev.req_first;
+                s_word[5] = ev.arena_off; s_word[6] = ev.arena_bytes;
             }
         }
         __syncthreads();
@@ -218,6 +260,7 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
         const uint32_t op = (uint32_t)s_word[1];
         const uint32_t nr = (uint32_t)s_word[2];
         const uint64_t req_first = s_word[3];
+        const uint32_t ar_off = (uint32_t)s_word[5], ar_bytes = (uint32_t)s_word[6];
         __syncthreads();
         if (op == P_OP_STOP) { exit_code = 0; ev_head++; break; }
 
@@ -226,6 +269,19 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
         bool appended = false;
 
         if (op == P_OP_ROUND && nr > 0 && nr <= WAVE) {
+            /* the round's payload bytes start their way across PCIe now, in parallel with the
+             * descriptors: [ar_off - 16, ar_off + ar_bytes + 16) of the pinned arena -> LDS */
+            const bool pre = ar_bytes != 0 && ar_bytes <= P_PREFETCH_BYTES;
+            constexpr int PRE_PER_THREAD = (P_PREFETCH_BYTES + 32) / 16 / 256 + 1;
+            uint4 pf[PRE_PER_THREAD];
+            const uint32_t pre_units = pre ? (ar_bytes + 32 + 15) / 16 : 0;
+            if (pre) {
+#pragma unroll
+                for (int k = 0; k < PRE_PER_THREAD; k++) {
+                    const uint32_t u = tid + k * 256;
+                    if (u < pre_units) pf[k] = *(const uint4 *)(H->arena + (ar_off - 16) + 16 * u);
+                }
+            }
             /* ---- get_tailq_message + log_append_entry: one lane per entry ---- */
             if (tid < WAVE) {
                 const bool active = lane < nr;
@@ -291,24 +347,46 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
                 }
                 if (lane == 0) s_seq = s;
             }
+            if (pre) {
+#pragma unroll
+                for (int k = 0; k < PRE_PER_THREAD; k++) {
+                    const uint32_t u = tid + k * 256;
+                    if (u < pre_units) ((uint4 *)s_pay)[u] = pf[k];
+                }
+            }
             __syncthreads();
+            if (tid == 0) s_word[7] = wall_clock64();
             /* ---- the round's bytes: own ring + R1 to every in-sync follower ---- */
             const uint32_t utotal = lds.ubase[WAVE];
-            for (uint32_t u = tid; u < utotal; u += blockDim.x) {
-                uint32_t lo = 0, hi = nr - 1;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi + 1) >> 1;
-                    if (lds.ubase[mid] <= u) lo = mid; else hi = mid - 1;
+            constexpr int PUSH_ILP = 4;           /* units per thread and pass: the PCIe payload reads overlap */
+            for (uint32_t u0 = tid; u0 < utotal; u0 += blockDim.x * PUSH_ILP) {
+                uint4 v[PUSH_ILP];
+                uint64_t p[PUSH_ILP];
+                bool on[PUSH_ILP];
+#pragma unroll
+                for (int k = 0; k < PUSH_ILP; k++) {
+                    const uint32_t u = u0 + k * blockDim.x;
+                    on[k] = u < utotal;
+                    v[k] = make_uint4(0, 0, 0, 0); p[k] = 0;
+                    if (!on[k]) continue;
+                    uint32_t lo = 0, hi = nr - 1;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi + 1) >> 1;
+                        if (lds.ubase[mid] <= u) lo = mid; else hi = mid - 1;
+                    }
+                    const uint32_t e = lo, Te = lds.T[e], j = u - lds.ubase[e];
+                    const uint32_t so = min(16u * j, Te - 16u);
+                    if (so == 0) v[k] = lds.h0[e];
+                    else if (so == 16) v[k] = lds.h1[e];
+                    else if (so == 32) v[k] = make_uint4(0, 0, 0, 0);
+                    else if (pre) v[k] = payload_unit_lds(s_pay, (uint32_t)(lds.src[e] - (ar_off - 16)), so, Te - APUS_HDR, Te - APUS_HDR);
+                    else v[k] = payload_unit(H->arena + lds.src[e], so, Te - APUS_HDR, Te - APUS_HDR);
+                    p[k] = lds.pos[e] + so;
                 }
-                const uint32_t e = lo, Te = lds.T[e], j = u - lds.ubase[e];
-                const uint32_t so = min(16u * j, Te - 16u);
-                uint4 v;
-                if (so == 0) v = lds.h0[e];
-                else if (so == 16) v = lds.h1[e];
-                else if (so == 32) v = make_uint4(0, 0, 0, 0);
-                else v = payload_unit(H->arena + lds.src[e], so, Te - APUS_HDR, Te - APUS_HDR);
-                const uint64_t p = lds.pos[e] + so;
-                for (uint32_t m = push_mask | (1u << me); m; m &= m - 1) st16_agent(E.rep[__builtin_ctz(m)].ring + p, v);
+#pragma unroll
+                for (int k = 0; k < PUSH_ILP; k++)
+                    if (on[k])
+                        for (uint32_t m = push_mask | (1u << me); m; m &= m - 1) st16_agent(E.rep[__builtin_ctz(m)].ring + p[k], v[k]);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          /* every storing wave drains */
             __syncthreads();
@@ -372,8 +450,11 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
 
         if (vis > mh[H_N_COMMIT]) {
             /* ---- R2: end doorbell to every in-sync follower ---- */
-            if (tid == 0)
+            uint64_t t_bell = 0;
+            if (tid == 0) {
                 for (uint32_t m = push_mask; m; m &= m - 1) st_agent(&D->end_bell[__builtin_ctz(m)], vis);
+                t_bell = wall_clock64();
+            }
 
             /* ---- ACK aggregation: window of <= 64 entries per pass, bitmaps in LDS ---- */
             uint64_t cs = mh[H_N_COMMIT];
@@ -406,7 +487,12 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
                     mh[H_COMMIT] = coff; mh[H_N_COMMIT] = cs; mh[H_N_VISIBLE] = vis;
                     for (uint32_t m = push_mask; m; m &= m - 1) st_agent(&D->commit_bell[__builtin_ctz(m)], cs);
                     const uint32_t k = D->lat_n;
-                    if (appended && k < P_LAT_CAP) { D->lat_ticks[k] = (uint32_t)(wall_clock64() - t_start); D->lat_n = k + 1; }
+                    if (appended && k < P_LAT_CAP) {
+                        D->lat_ticks[k] = (uint32_t)(wall_clock64() - t_start);
+                        D->lat_seq[k] = (op == P_OP_ROUND) ? (uint32_t)(s_word[7] - t_start) : 0;
+                        D->lat_push[k] = (uint32_t)(t_bell - t_start);
+                        D->lat_n = k + 1;
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 apply_range(E, me, cs, 0, blockDim.x, s_acc);

@@ -235,6 +235,13 @@ class Engine:
         self._chk(self.L.apus_gpu_persist_latency(self.h, out.ctypes.data, len(out), C.byref(n)), "persist_latency")
         return out[:n.value].copy()
 
+    def persist_latency_phase_ns(self, which: int) -> np.ndarray:
+        out = np.zeros(1 << 16, dtype=np.uint32)
+        n = C.c_uint32(0)
+        self._chk(self.L.apus_gpu_persist_latency_phase(self.h, which, out.ctypes.data, len(out), C.byref(n)),
+                  "persist_latency_phase")
+        return out[:n.value].copy()
+
     def run_trace_persistent(self, trace: Trace, idle_ms: int = 2000, peer_ms: int = 200):
         """Same events, but the ROUND / PRUNE events go through the persistent kernel's
         command ring (ELECT, HOLD/RELEASE and QUIESCE stop it and use the phased path)."""

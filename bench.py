@@ -170,7 +170,7 @@ def bench_single(args):
 
     # the persistent consensus kernel (live path): one 64-entry round at a time through the
     # pinned command ring; host-observed submit -> highest_rec, and device append -> commit
-    plat_host, plat_dev = None, None
+    plat_host, plat_dev, plat_phases = None, None, None
     try:
         if args.no_latency:
             raise RuntimeError('skipped (--no-latency)')
@@ -182,6 +182,8 @@ def bench_single(args):
         eng.persist_drain()
         code = eng.persist_stop()
         dl = eng.persist_latency_ns()
+        ph1, ph2 = eng.persist_latency_phase_ns(1), eng.persist_latency_phase_ns(2)
+        plat_phases = {"sequenced_us_p50": float(np.percentile(ph1[20:], 50)) / 1e3, "pushed_and_doorbell_us_p50": float(np.percentile(ph2[20:], 50)) / 1e3} if len(ph1) > 20 else None
         plat_host = float(np.percentile(hl[40:], 50))
         plat_dev = float(np.percentile(dl[20:], 50)) / 1e3 if len(dl) > 20 else None
         eng.quiesce()
@@ -220,6 +222,7 @@ def bench_single(args):
         "p50_round_latency_us": plat_dev if plat_dev is not None else p50,
         "latency": {"persistent_kernel_append_to_commit_us_p50": plat_dev,
                     "persistent_kernel_host_submit_to_highest_rec_us_p50": plat_host,
+                    "persistent_kernel_phase_breakdown": plat_phases,
                     "phased_kernels_host_round_trip_us_p50": p50,
                     "note": "one 64-entry round per measurement, 3 logical replicas on one MI355X; "
                             "device latency from wall_clock64 inside the persistent kernel"},

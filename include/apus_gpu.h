@@ -171,6 +171,7 @@ uint64_t apus_gpu_persist_highest_rec(apus_engine_t *e);
 const volatile uint64_t *apus_gpu_persist_highest_rec_ptr(apus_engine_t *e);
 int  apus_gpu_persist_stop(apus_engine_t *e);            /* returns the kernel's exit code: 0 stop, 1 idle, 2 timeout */
 int  apus_gpu_persist_latency(apus_engine_t *e, uint32_t *out_ns, uint32_t cap, uint32_t *n_out);
+int  apus_gpu_persist_latency_phase(apus_engine_t *e, int which, uint32_t *out_ns, uint32_t cap, uint32_t *n_out);
 /* submit one round of n <= 64 requests and spin on highest_rec, `iters` times (C-level timing) */
 int  apus_gpu_persist_roundtrip(apus_engine_t *e, const apus_req_t *reqs, uint32_t n,
                                 const uint8_t *arena, uint64_t arena_bytes, uint32_t iters, uint32_t *out_ns);
