@@ -37,6 +37,12 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0
 
 def build_trace(args, group_size):
     from apus_amd import trace as T
+    if args.config == "c3":      # BASELINE configs[2]: 1 KiB entries, batch 32
+        args.payload, args.batch = 1024, 32
+        return T.config_c3(n_send=args.entries if args.entries != (1 << 20) else (1 << 18), group_size=group_size)
+    if args.config == "c4":      # BASELINE configs[3]: 64 B .. 4 KiB, batches of 1..64
+        args.payload, args.batch = 1161, 0        # mean payload of the mix, for the byte accounting only
+        return T.config_c4(n_send=args.entries if args.entries != (1 << 20) else (1 << 18), group_size=group_size)
     return T.steady_trace(group_size, args.entries, args.payload, 16, args.batch,
                           log_len=T.DEFAULT_LOG, name="C2")
 
@@ -214,9 +220,11 @@ def bench_single(args):
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: {N} replicas (logical, one MI355X), "
-                               f"{n_entries} entries/step ({args.entries} SEND of {args.payload} B + 16 CONNECT), "
-                               f"rounds of {args.batch}, prune tick every 8 MiB, 64 MiB rings",
+        "config": {"workload": (f"BASELINE configs[1]: {N} replicas (logical, one MI355X), "
+                                f"{n_entries} entries/step ({args.entries} SEND of {args.payload} B + 16 CONNECT), "
+                                f"rounds of {args.batch}, prune tick every 8 MiB, 64 MiB rings") if args.config == "c2" else
+                               f"BASELINE {args.config}: {N} replicas (logical, one MI355X), {n_entries} entries/step, "
+                               f"mean payload {args.payload} B, 64 MiB rings",
                    "mode": "hipGraph replay of one step" if use_graph else "eager launches",
                    "replicas": N, "entry_bytes": E, "launches_per_step": len(calls)},
         "p50_round_latency_us": plat_dev if plat_dev is not None else p50,
@@ -254,11 +262,17 @@ def main():
     ap.add_argument("--payload", type=int, default=64)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--replicas", type=int, default=3)
+    ap.add_argument("--config", choices=["c2", "c3", "c4"], default="c2",
+                    help="c2 = BASELINE configs[1] (the metric's configuration); c3/c4 = configs[2]/[3] as extra measurements")
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+    if args.config == "c3" and args.replicas == 3:
+        args.replicas = 5
+    if args.config == "c4" and args.replicas == 3:
+        args.replicas = 7
     if args.gpus <= 1:
         out = bench_single(args)
         print(json.dumps(out))

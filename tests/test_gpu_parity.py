@@ -193,3 +193,36 @@ def test_failover_reconf_bench_shape(eng_factory):
     cl = lockstep(tr, eng)
     assert cl.leader == 1 and cl.term(1) == 4
     assert eng.counters(1)["sid"] == cl.sid(1)
+
+
+def test_full_size_c3_against_oracle(eng_factory):
+    """BASELINE config 3: 5 replicas, 2^18 SEND entries of 1 KiB (272 MiB through the
+    64 MiB ring, >= 4 wraps), batch 32."""
+    from tests.parity import lockstep
+    tr = T.config_c3()
+    eng = eng_factory(5, T.DEFAULT_LOG)
+    lockstep(tr, eng, check_at=("QUIESCE",))
+    o = eng.offsets(0)
+    assert o["commit"] == o["end"] == o["apply"]
+    assert eng.counters(0)["highest_rec"] == (1 << 18) + 16
+
+
+def test_full_size_c4_against_oracle(eng_factory):
+    """BASELINE config 4: 7 replicas, 2^18 SEND entries of 64 B .. 4 KiB, batches of 1..64."""
+    from tests.parity import lockstep
+    tr = T.config_c4()
+    eng = eng_factory(7, T.DEFAULT_LOG)
+    lockstep(tr, eng, check_at=("QUIESCE",))
+    o = eng.offsets(0)
+    assert o["commit"] == o["end"] == o["apply"]
+    assert eng.counters(3)["n_apply"] == eng.counters(0)["n_apply"]
+
+
+def test_single_replica_group(eng_factory):
+    """N = 1 point of the metric: commit == end after every round (quorum of one)."""
+    from tests.parity import lockstep
+    tr = T.steady_trace(1, 20000, 64, 16, 64, log_len=1 << 20)
+    eng = eng_factory(1, 1 << 20)
+    lockstep(tr, eng)
+    gc, ge = eng.round_record()
+    assert ((gc == ge) | (gc == 0)).all()      # 0 = the wrap-position pass (DESIGN.md section 6)

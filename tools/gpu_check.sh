@@ -30,3 +30,9 @@ if [ -n "$GROUP" ]; then
   APUS_DIST_BACKEND=gloo APUS_DIST_ONE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 3 --steps 2 --warmup 1 --entries 262144 > gpurun_out/bench_group.log 2>&1
   echo "group bench exit: $?"; tail -3 gpurun_out/bench_group.log | cut -c1-600
 fi
+if [ -n "$EXTRA_CONFIGS" ]; then
+  for c in c3 c4; do
+    timeout 600 python bench.py --config $c --steps 5 --warmup 2 --no-cpu --no-latency > gpurun_out/bench_$c.log 2>&1
+    echo "bench $c exit: $?"; tail -1 gpurun_out/bench_$c.log | cut -c1-400
+  done
+fi
