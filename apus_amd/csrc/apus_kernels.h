@@ -2,30 +2,36 @@
  * apus_kernels.h -- the HIP kernels of the consensus hot path (gfx950, wave64).
  *
  * One leader polling() pass of the reference (dare_server.c:1012-1125) over a
- * batch of R rounds becomes six launches; every launch is wide (one wavefront
- * per round / one lane per entry) and the launches are the only global syncs:
+ * batch of R rounds is four launches; every launch is wide (one workgroup per
+ * round / one lane per entry) and the launches are the only global syncs:
  *
- *   k_catchup       update_remote_logs step I for lagging followers
- *                   (dare_ibv_rc.c:1507-1547): copy [remote_end, end)
- *   k_sequence      get_tailq_message -> log_append_entry offsets
- *                   (dare_ibv_ud.c:780, dare_log.h:466-558): where every
- *                   entry of the batch goes, incl. both wrap rules and the
- *                   end == len "empty" encoding; leader persist bookkeeping
- *   k_append_push   writes the entries into the leader ring (log_append_entry
- *                   body + persist_new_entries' sender stamp,
- *                   dare_server.c:1803) AND into every in-sync follower ring
- *                   at the same offsets (R1 of update_remote_logs, fused so
- *                   the payload is read once)
- *   k_persist_ack   follower persist_new_entries + rc_send_entries_reply
- *                   (dare_server.c:1792, dare_ibv_rc.c:1828): reply byte in
- *                   both logs + ACK bit in the leader's slot word
- *   k_commit        the ACK scan of update_remote_logs (dare_ibv_rc.c:1725-1758):
- *                   popcount(ack | self) >= size/2+1 per lane, wave ballot,
- *                   first slot without a majority
- *   k_apply         apply_committed_entries on every replica
- *                   (dare_server.c:1815-1974): apply-stream records, HEAD adoption
- *   k_finish        scalar bookkeeping: commit/apply offsets, R2/R4 doorbells,
- *                   per-round end/commit record
+ *   k_sequence        get_tailq_message -> log_append_entry offsets
+ *                     (dare_ibv_ud.c:780, dare_log.h:466-558): where every entry of
+ *                     the batch goes, incl. both wrap rules and the end == len
+ *                     "empty" encoding; leader persist bookkeeping; a log_pruning
+ *                     tick that was due right before the batch is fused in
+ *   k_append_push     writes the entries into the leader ring (log_append_entry
+ *                     body + persist_new_entries' sender stamp, dare_server.c:1803)
+ *                     AND into every in-sync follower ring at the same offsets
+ *                     (R1 of update_remote_logs, fused so the payload is read once)
+ *   k_persist_commit  follower persist_new_entries + rc_send_entries_reply
+ *                     (dare_server.c:1792, dare_ibv_rc.c:1828): reply byte in both
+ *                     logs + ACK bit in the leader's slot word, and the ACK scan of
+ *                     update_remote_logs (dare_ibv_rc.c:1725-1758):
+ *                     popcount(ack | self) >= size/2+1 per lane, wave ballot, first
+ *                     slot without a majority   (k_commit: the scan alone, used when
+ *                     the ACK bits were merged from followers in other processes)
+ *   k_apply           apply_committed_entries on every replica
+ *                     (dare_server.c:1815-1974): apply-stream records, HEAD adoption;
+ *                     every block computes a slice of the per-round commit record,
+ *                     the block that finishes last does the scalar bookkeeping
+ *                     (commit/apply offsets, R2/R4 doorbells)
+ *
+ *   k_control_round   one workgroup: a whole pass that carries at most one control
+ *                     entry (CONFIG / HEAD / NOOP, prune tick, quiesce)
+ *   k_catchup         update_remote_logs step I for followers that lag by a lot
+ *                     (dare_ibv_rc.c:1507-1547): copy [remote_end, end)
+ *   k_mp_*            device halves of the multi-process (one replica per GPU) exchange
  *
  * All arithmetic is integer / byte work; the binding roofline is HBM.
  */
@@ -479,16 +485,6 @@ __device__ static inline void persist_ack_range(const EngDev &E, int f, uint64_t
             atomicOr(&E.rep[sender].ack[di], 1u << f);           /* derived ACK word the scan reads */
         }
     }
-}
-
-__global__ __launch_bounds__(256) void k_persist_ack(const EngDev E, uint64_t r0, uint32_t R, uint32_t fmask)
-{
-    int f = -1;
-    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
-        if (fmask & (1u << i)) { if (k == (int)blockIdx.y) { f = i; break; } k++; }
-    if (f < 0) return;
-    const uint64_t vis = visible_slots(E, E.rep[E.leader].hdr, r0, R);
-    persist_ack_range(E, f, vis, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
 }
 
 /* k_persist_commit: when the followers live on this device, one lane handles one
