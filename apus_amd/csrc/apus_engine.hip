@@ -285,7 +285,8 @@ static int launch_tail_view(apus_engine *e, const EngDev &view, uint64_t r0, uin
         hipLaunchKernelGGL(k_persist_commit, dim3(cap_grid(n, 256, 2048)), dim3(256), 0, e->stream, view, r0, R, fm);
     else        /* ACK bits were merged from remote followers (k_mp_ack_merge) */
         hipLaunchKernelGGL(k_commit, dim3(cap_grid(n, 1024, 512)), dim3(1024), 0, e->stream, view, r0, R);
-    hipLaunchKernelGGL(k_apply, dim3(cap_grid(n, 1024, 1024), popc(rm)), dim3(256), 0, e->stream, view, r0, R, rm, mode, fm);
+    /* + 1: the bookkeeping block */
+    hipLaunchKernelGGL(k_apply, dim3(cap_grid(n, 1024, 1024) + 1, popc(rm)), dim3(256), 0, e->stream, view, r0, R, rm, mode, fm);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -144,8 +144,9 @@ __global__ __launch_bounds__(256) void k_catchup(const EngDev E, uint32_t fmask)
 }
 
 __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32_t type, uint64_t d0, uint64_t d1,
-                                               uint32_t push_mask, uint64_t *s_lh);
-__device__ static inline void sample_apply_offsets(const EngDev &E, const uint64_t *s_lh, uint32_t sample_mask, uint32_t i);
+                                               uint32_t push_mask, uint64_t *s_lh, uint64_t rec_base);
+__device__ static inline void sample_apply_offsets(const EngDev &E, const uint64_t *s_lh, uint32_t sample_mask, uint32_t i,
+                                                   const uint64_t *staged_apply);
 
 /* block-wide inclusive scan of one u64 per thread (blockDim.x <= 1024), returns
  * the inclusive value; *total gets the block sum                              */
@@ -170,7 +171,9 @@ __device__ static inline uint64_t block_incl_scan(uint64_t v, uint64_t *s_tot /*
 __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask,
                                                     uint32_t tick, uint32_t sample_mask)
 {
-    __shared__ uint64_t s_lh[64];
+    __shared__ uint64_t s_lh[64];                      /* the leader's control block, kept current */
+    __shared__ uint64_t s_fw[APUS_DEV_MAX_SERVERS][3]; /* followers: end, n_end, apply */
+    __shared__ uint64_t s_misc[2];                     /* rec_count, len of the batch's last request */
     __shared__ uint32_t s_head_round;
     __shared__ uint64_t s_tot[16];
     __shared__ unsigned int s_last, s_rstar;
@@ -182,18 +185,29 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
     const uint64_t L = E.log_len;
     const uint32_t *rf = E.round_first + r0;
 
-    /* control words thread 0 needs later: loaded now so the latency hides behind phase A */
-    uint64_t p_head = 0, p_last_idx = 0, p_sid = 0, p_commit = 0, p_n_commit = 0, p_store = 0;
-    uint32_t p_tlast = 0;
-    const bool pre = gridDim.x == 1 && !tick;        /* with several blocks the last one is not known yet;
-                                                        a fused prune tick rewrites the words */
-    if (tid == 0 && pre) {
-        p_head = hdr[H_HEAD]; p_last_idx = hdr[H_LAST_IDX]; p_sid = hdr[H_SID];
-        p_commit = hdr[H_COMMIT]; p_n_commit = hdr[H_N_COMMIT]; p_store = hdr[H_STORE_COUNT];
-        if (rf[R] > rf[0]) p_tlast = E.req_len[rf[R] - 1];
-    }
+    /* Everything phase B needs from HBM is requested NOW, by different lanes, so that it is
+     * one round trip that overlaps phase A instead of a chain of dependent loads later. */
+    uint64_t st0 = 0, st1 = 0, st2 = 0;
+    auto stage_load = [&]() {
+        if (tid < 64) st0 = hdr[tid];
+        else if (tid < 64 + APUS_DEV_MAX_SERVERS) {
+            const uint32_t f = tid - 64;
+            if (((push_mask | sample_mask) >> f) & 1u) {
+                const uint64_t *fh = E.rep[f].hdr;
+                st0 = fh[H_END]; st1 = fh[H_N_END]; st2 = fh[H_APPLY];
+            }
+        } else if (tid == 96) st0 = *E.rec_count;
+        else if (tid == 97) st0 = (rf[R] > rf[0]) ? E.req_len[rf[R] - 1] : 0;
+    };
+    auto stage_store = [&]() {
+        if (tid < 64) s_lh[tid] = st0;
+        else if (tid < 64 + APUS_DEV_MAX_SERVERS) { s_fw[tid - 64][0] = st0; s_fw[tid - 64][1] = st1; s_fw[tid - 64][2] = st2; }
+        else if (tid == 96) s_misc[0] = st0;
+        else if (tid == 97) s_misc[1] = st0;
+    };
+    if (gridDim.x == 1) stage_load();
 
-    /* phase A */
+    /* phase A: bytes of every round, one thread per round */
     {
         const uint32_t r = blockIdx.x * blockDim.x + tid;
         if (r < R) {
@@ -219,35 +233,43 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
         }
         __syncthreads();
         if (!s_last) return;
+        stage_load();                                     /* only the finishing block needs the context */
     }
+    stage_store();
+    if (tid == 0) { s_rstar = 0xFFFFFFFFu; s_head_round = 0; }
+    __syncthreads();
 
-    /* phase B: this block is alone now */
+    /* phase B: this block is alone now; it works on the staged copies */
     const uint32_t g0 = rf[0];
     const uint32_t n = rf[R] - g0;
     {
-        /* followers that silently fell one round behind (exact-fit wrap) are caught up here */
-        const uint64_t e_pre = hdr[H_END], n_pre = hdr[H_N_END];
-        if (tick && tid < 64) s_lh[tid] = hdr[tid];
-        for (uint32_t m = push_mask; m; m &= m - 1) catchup_range(E, __builtin_ctz(m), e_pre, n_pre, tid, blockDim.x);
-        __syncthreads();
-        if (tid == 0) {
-            s_rstar = 0xFFFFFFFFu;
-            s_head_round = 0;
-            for (uint32_t m = push_mask; m; m &= m - 1) {
-                uint64_t *fh = E.rep[__builtin_ctz(m)].hdr;
-                if (fh[H_N_END] < n_pre && e_pre != L) { fh[H_END] = e_pre; fh[H_N_END] = n_pre; }
-            }
-            /* a log_pruning tick that was due right before this batch (the timer fired between
-             * two polling() passes): decision + <HEAD> entry happen here, its persist / ACK /
-             * commit / apply ride with the batch's own tail kernels */
-            if (tick) s_head_round = control_append(E, 1, 3, 0, 0, push_mask, s_lh).n;
+        const uint64_t e_pre = s_lh[H_END], n_pre = s_lh[H_N_END];
+        /* followers that silently fell behind (hidden exact-fit round) are caught up here */
+        bool any_lag = false;
+        for (uint32_t m = push_mask; m; m &= m - 1) any_lag |= (s_fw[__builtin_ctz(m)][1] < n_pre) && e_pre != L;
+        if (any_lag) {
+            for (uint32_t m = push_mask; m; m &= m - 1) catchup_range(E, __builtin_ctz(m), e_pre, n_pre, tid, blockDim.x);
+            __syncthreads();
+            if (tid == 0)
+                for (uint32_t m = push_mask; m; m &= m - 1) {
+                    const int f = __builtin_ctz(m);
+                    if (s_fw[f][1] < n_pre) { uint64_t *fh = E.rep[f].hdr; fh[H_END] = e_pre; fh[H_N_END] = n_pre; }
+                }
         }
-        if (tick && tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS) sample_apply_offsets(E, s_lh, sample_mask, tid - 64);
-        __syncthreads();
+        /* a log_pruning tick that was due right before this batch (the timer fired between two
+         * polling() passes): decision + <HEAD> entry happen here, its persist / ACK / commit /
+         * apply ride with the batch's own tail kernels */
+        if (tick) {
+            if (tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS)
+                sample_apply_offsets(E, s_lh, sample_mask, tid - 64, &s_fw[tid - 64][2]);
+            __syncthreads();                             /* the sampling lanes read the pre-tick block */
+            if (tid == 0) s_head_round = control_append(E, 1, 3, 0, 0, push_mask, s_lh, s_misc[0]).n;
+            __syncthreads();
+        }
     }
     const uint32_t head_round = s_head_round;
-    const uint64_t e0 = hdr[H_END];
-    const uint64_t n_end0 = hdr[H_N_END];
+    const uint64_t e0 = s_lh[H_END];
+    const uint64_t n_end0 = s_lh[H_N_END];
 
     /* exclusive scan of the round sums, in place */
     uint64_t carry = 0;
@@ -289,24 +311,24 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
         if (kstar >= 0 && end_new > L) set_status(E, 1u << 0);      /* second wrap */
         /* free space: the reference only notices end == head exactly (dare_log.h:168) */
         {
-            const uint64_t head = pre ? p_head : hdr[H_HEAD];
+            const uint64_t head = s_lh[H_HEAD];
             const uint64_t used = (e0 == L) ? 0 : (e0 >= head ? e0 - head : L - (head - e0));
             const uint64_t waste = (kstar >= 0) ? L - w : 0;
             if (n && e0 != L && vtot + waste >= L - used) set_status(E, 1u << 1);
             if (n && e0 == L && vtot > L) set_status(E, 1u << 1);
         }
-        const uint64_t idx0 = (pre ? p_last_idx : hdr[H_LAST_IDX]) + 1;
+        const uint64_t idx0 = s_lh[H_LAST_IDX] + 1;
         SeqOut s;
         s.e0 = e0; s.idx0 = idx0; s.w = w; s.n_end0 = n_end0;
-        s.term = (pre ? p_sid : hdr[H_SID]) >> 9;
+        s.term = s_lh[H_SID] >> 9;
         s.kstar = kstar; s.estar = estar; s.stale = stale; s.n = n;
         s.head_round = head_round;
         s.first_fail = ~0ull;
-        s.commit_before = pre ? p_commit : hdr[H_COMMIT];
-        s.n_commit_before = pre ? p_n_commit : hdr[H_N_COMMIT];
+        s.commit_before = s_lh[H_COMMIT];
+        s.n_commit_before = s_lh[H_N_COMMIT];
         *E.seq = s;
         if (n) {
-            const uint64_t t_last = APUS_HDR + (pre ? p_tlast : E.req_len[g0 + n - 1]);
+            const uint64_t t_last = APUS_HDR + s_misc[1];
             hdr[H_END] = end_new;
             hdr[H_TAIL] = end_new - t_last;
             hdr[H_N_END] = n_end0 + n;
@@ -315,14 +337,14 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
             /* leader side of persist_new_entries (dare_server.c:1792-1810) */
             hdr[H_OLD_END] = end_new;
             hdr[H_N_PERSIST] = n_end0 + n;
-            hdr[H_STORE_COUNT] = (pre ? p_store : hdr[H_STORE_COUNT]) + n;
+            hdr[H_STORE_COUNT] = s_lh[H_STORE_COUNT] + n;
         }
         s_kstar = kstar; s_w = w;
     }
     __syncthreads();
 
     /* end offset after every round (the leader's per-round record) */
-    const uint64_t rec_base = *E.rec_count;
+    const uint64_t rec_base = s_misc[0];
     const int64_t kstar = s_kstar;
     const uint64_t w = s_w;
     for (uint32_t r = tid; r < R; r += 1024) {
@@ -571,12 +593,11 @@ __global__ __launch_bounds__(1024) void k_commit(const EngDev E, uint64_t r0, ui
 /* apply_committed_entries (dare_server.c:1815-1974) for slots [from, cs) of
  * replica p: apply-stream records, HEAD adoption candidates; block-reduced
  * counters.  Must be called by all threads of the block.                        */
-__device__ static inline void apply_range(const EngDev &E, int p, uint64_t cs, uint64_t tile0, uint64_t tile_stride,
-                                          unsigned long long *s_acc /*[2]*/)
+__device__ static inline void apply_range(const EngDev &E, int p, uint64_t from, uint64_t cs, uint64_t tile0,
+                                          uint64_t tile_stride, unsigned long long *s_acc /*[2]*/)
 {
     const RepDev &Pd = E.rep[p];
     const bool leader = (uint32_t)p == E.leader;
-    const uint64_t from = Pd.hdr[H_N_APPLY];
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
     __syncthreads();
     /* APPLY_ILP slots per thread and pass: the three dependent memory steps (directory ->
@@ -638,12 +659,10 @@ __device__ static inline void apply_range(const EngDev &E, int p, uint64_t cs, u
 /* per-round commit record of rounds [r0, r0+R) of this call, one thread per round;
  * every block of k_apply takes a slice (gtid over gthreads)                        */
 __device__ static inline void finish_records(const EngDev &E, uint64_t r0, uint32_t R, uint64_t cs,
-                                             uint64_t gtid, uint64_t gthreads)
+                                             uint64_t gtid, uint64_t gthreads, const SeqOut &s, uint64_t rec_base0)
 {
     const RepDev &Ld = E.rep[E.leader];
     const uint64_t L = E.log_len;
-    const SeqOut s = *E.seq;
-    const uint64_t rec_base0 = *E.rec_count;
     const uint32_t hr = s.head_round;
     const uint64_t rec_base = rec_base0 + hr;
     const uint32_t *rf = E.round_first + r0;
@@ -759,44 +778,141 @@ __device__ static inline void finish_call(const EngDev &E, uint64_t r0, uint32_t
 
 /* k_apply: apply on every replica in rmask (grid.y), then the block that finishes
  * last does the call's scalar bookkeeping (finish_call).                          */
+/* what every block of k_apply needs before it can start, fetched in ONE round trip
+ * (different lanes load different words) */
+struct ApplyCtx {
+    uint64_t lh[64];          /* leader control block */
+    SeqOut   seq;
+    uint64_t rec_base, n_apply_p;
+    uint32_t rfa, rfb;
+    uint64_t fw[APUS_DEV_MAX_SERVERS][8];   /* bookkeeping block: followers' control words */
+    uint64_t off_cs, off_vis;
+};
+
+__device__ static inline uint64_t ctx_visible(const EngDev &E, const ApplyCtx &c, uint32_t R)
+{
+    if (c.lh[H_END] != E.log_len) return c.lh[H_N_END];
+    if (c.seq.n == 0) return c.lh[H_N_VISIBLE];
+    if (R == 0) return c.seq.n_end0;
+    return c.seq.n_end0 + (c.rfb - c.rfa);
+}
+
+/* k_apply: apply_committed_entries on every replica in rmask (grid.y).  Blocks
+ * 0 .. gridDim.x-2 apply (and compute slices of the per-round commit record); block
+ * (gridDim.x-1, 0) is the call's bookkeeper: it fetches everything finish needs while the
+ * others work, waits for their arrival tickets, then publishes commit/apply offsets and the
+ * R2/R4 doorbell words.  The appliers never wait for it, so the wait cannot deadlock. */
 __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint32_t R, uint32_t rmask,
                                                int mode, uint32_t fmask)
 {
     __shared__ unsigned long long s_acc[2];
-    __shared__ unsigned int s_last;
+    __shared__ ApplyCtx c;
+    const uint32_t tid = threadIdx.x;
+    const bool keeper = blockIdx.x == gridDim.x - 1;
+    if (keeper && blockIdx.y != 0) return;
     int p = -1;
     for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
         if (rmask & (1u << i)) { if (k == (int)blockIdx.y) { p = i; break; } k++; }
-    {
-        const uint64_t vis = visible_slots(E, E.rep[E.leader].hdr, r0, R);
-        const uint64_t cs = commit_slot(E, vis);
+    const RepDev &Ld = E.rep[E.leader];
+    uint64_t *lh = Ld.hdr;
+
+    /* ---- context: one round trip ---- */
+    if (tid < 64) c.lh[tid] = lh[tid];
+    else if (tid < 64 + sizeof(SeqOut) / 8) ((uint64_t *)&c.seq)[tid - 64] = ((const uint64_t *)E.seq)[tid - 64];
+    else if (tid == 96) c.rec_base = *E.rec_count;
+    else if (tid == 97) c.n_apply_p = (p >= 0) ? E.rep[p].hdr[H_N_APPLY] : 0;
+    else if (tid == 98) { c.rfa = R ? E.round_first[r0] : 0; c.rfb = R ? E.round_first[r0 + R - 1] : 0; }
+    else if (keeper && tid >= 128 && tid < 128 + 8 * APUS_DEV_MAX_SERVERS) {
+        const uint32_t f = (tid - 128) >> 3, j = (tid - 128) & 7;
+        static const int words[8] = {H_N_PERSIST, H_N_COMMIT, H_N_APPLY, H_STORE_COUNT, H_HEAD, H_END, H_N_END, H_HEAD_SLOT};
+        c.fw[f][j] = ((fmask >> f) & 1u) ? E.rep[f].hdr[words[j]] : 0;
+    }
+    __syncthreads();
+    const uint64_t L = E.log_len;
+    const uint64_t vis = ctx_visible(E, c, R);
+    uint64_t cs = min((uint64_t)c.seq.first_fail, vis);
+    if (cs < c.seq.n_commit_before) cs = c.seq.n_commit_before;
+
+    if (!keeper) {
         if (mode == 0)
-            finish_records(E, r0, R, cs, ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x,
-                           (uint64_t)gridDim.x * gridDim.y * blockDim.x);
-        if (p >= 0) apply_range(E, p, cs, (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_acc);
+            finish_records(E, r0, R, cs, ((uint64_t)blockIdx.y * (gridDim.x - 1) + blockIdx.x) * blockDim.x + tid,
+                           (uint64_t)(gridDim.x - 1) * gridDim.y * blockDim.x, c.seq, c.rec_base);
+        if (p >= 0) apply_range(E, p, c.n_apply_p, cs, (uint64_t)blockIdx.x * blockDim.x,
+                                (uint64_t)(gridDim.x - 1) * blockDim.x, s_acc);
+        __syncthreads();
+        if (tid == 0) atomicAdd(E.ticket + 1, 1u);          /* arrival ticket; no fence needed (see below) */
+        return;
+    }
+
+    /* ---- the bookkeeper ---- */
+    const uint64_t end_l = c.lh[H_END], n_end_l = c.lh[H_N_END];
+    if (tid == 0) c.off_cs = (cs == n_end_l) ? end_l : Ld.dir_off[(uint32_t)cs & E.dir_mask];
+    if (tid == 1) c.off_vis = (vis == n_end_l) ? end_l : Ld.dir_off[(uint32_t)vis & E.dir_mask];
+    /* wait for every applier: it only consumes words they updated with device-scope atomics
+     * (HEAD slot) plus control words nobody else writes, so the ticket needs no fence */
+    if (tid == 0) {
+        const unsigned int want = (gridDim.x - 1) * gridDim.y;
+        unsigned long long spins = 0;
+        while (__hip_atomic_load(E.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1ull << 24)) { set_status(E, 1u << 4); break; }     /* bounded */
+        }
+        __hip_atomic_store(E.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        /* no fence: finish_call only consumes words the other blocks updated with
-         * device-scope atomics (first_fail, HEAD slot) and control words nobody else writes */
-        const unsigned int t = atomicAdd(E.ticket + 1, 1u);
-        s_last = (t == gridDim.x * gridDim.y - 1);
-        if (s_last) __hip_atomic_store(E.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const SeqOut &s = c.seq;
+    const uint64_t commit_off = (cs > s.n_commit_before) ? c.off_cs : s.commit_before;
+    if (tid == 0) {
+        if (mode == 0) {
+            *E.rec_count = c.rec_base + R + s.head_round;
+        } else if (mode == 1 && s.n) {
+            if (c.rec_base < E.rec_cap) E.rec_commit[c.rec_base] = (end_l == L) ? s.commit_before : commit_off;
+            *E.rec_count = c.rec_base + 1;
+        }
+        /* leader: commit, apply (update_remote_logs :1744-1758, apply_committed_entries) */
+        lh[H_N_VISIBLE] = vis;
+        if (cs > s.n_commit_before) { lh[H_COMMIT] = commit_off; lh[H_N_COMMIT] = cs; }
+        if (cs > c.lh[H_N_APPLY]) { lh[H_APPLY] = c.off_cs; lh[H_N_APPLY] = cs; }
     }
-    __syncthreads();
-    if (s_last) finish_call(E, r0, R, mode, fmask);
+    /* followers: R2 end doorbell, persist bookkeeping, R4 lazy commit, apply, HEAD adoption */
+    if (tid >= 1 && tid <= APUS_DEV_MAX_SERVERS) {
+        const int f = (int)tid - 1;
+        if ((fmask >> f) & 1u) {
+            uint64_t *fh = E.rep[f].hdr;
+            const uint64_t f_np = c.fw[f][0], f_nc = c.fw[f][1], f_na = c.fw[f][2], f_sc = c.fw[f][3];
+            const uint64_t f_head = c.fw[f][4], f_end = c.fw[f][5];
+            /* the appliers of this launch may have raised the HEAD slot: read it now */
+            const uint64_t hs = __hip_atomic_load((unsigned long long *)&fh[H_HEAD_SLOT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint64_t end_now = f_end;
+            if (vis > f_np) {
+                fh[H_STORE_COUNT] = f_sc + (vis - f_np);
+                fh[H_END] = c.off_vis; fh[H_OLD_END] = c.off_vis;
+                fh[H_N_END] = vis; fh[H_N_PERSIST] = vis;
+                end_now = c.off_vis;
+            }
+            if (cs > f_nc) { fh[H_COMMIT] = c.off_cs; fh[H_N_COMMIT] = cs; }
+            if (cs > f_na) { fh[H_APPLY] = c.off_cs; fh[H_N_APPLY] = cs; }
+            if (hs) {
+                const uint64_t hoff = E.rep[f].dir_off[(uint32_t)(hs - 1) & E.dir_mask];
+                const uint64_t hv = ld8u(E.rep[f].ring + hoff + 48);
+                if (apus_is_larger(end_now, L, hv, f_head)) fh[H_HEAD] = hv;
+                fh[H_HEAD_SLOT] = 0;
+            }
+        }
+    }
 }
 
 /* READ the apply offset of peer i for the next prune tick (rc_get_remote_apply_offsets,
  * dare_ibv_rc.c:1970-2034); one lane per peer, s_lh = the leader's control block
  * as it was before the tick */
-__device__ static inline void sample_apply_offsets(const EngDev &E, const uint64_t *s_lh, uint32_t sample_mask, uint32_t i)
+__device__ static inline void sample_apply_offsets(const EngDev &E, const uint64_t *s_lh, uint32_t sample_mask, uint32_t i,
+                                                   const uint64_t *staged_apply)
 {
     uint64_t *hdr = E.rep[E.leader].hdr;
     const uint32_t bitmask = (uint32_t)s_lh[H_CID_BITMASK];
     if (i >= E.group_size) return;
     if (i == E.leader || !((bitmask >> i) & 1u)) hdr[H_APPLY_OFFSETS + i] = s_lh[H_APPLY];
-    else if ((sample_mask >> i) & 1u) hdr[H_APPLY_OFFSETS + i] = E.rep[i].hdr[H_APPLY];
+    else if ((sample_mask >> i) & 1u) hdr[H_APPLY_OFFSETS + i] = staged_apply ? *staged_apply : E.rep[i].hdr[H_APPLY];
 }
 
 /* One thread: the leader appends at most one control entry (log_append_entry,
@@ -806,7 +922,7 @@ __device__ static inline void sample_apply_offsets(const EngDev &E, const uint64
  *           whether the head moves and append <HEAD, head> if so
  * s_lh is an LDS copy of the leader's control block; returns the call's SeqOut. */
 __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32_t type, uint64_t d0, uint64_t d1,
-                                               uint32_t push_mask, uint64_t *s_lh)
+                                               uint32_t push_mask, uint64_t *s_lh, uint64_t rec_base)
 {
     const RepDev &Ld = E.rep[E.leader];
     uint64_t *hdr = Ld.hdr;
@@ -824,7 +940,7 @@ __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32
         }
         if (apus_end_distance(end, L, min_off) == 0) min_off = s_lh[H_TAIL];   /* leave one entry, :2038-2041 */
         do_append = apus_is_larger(end, L, min_off, head) && !s_lh[H_PREV_HEAD];
-        if (do_append) { hdr[H_HEAD] = min_off; head = min_off; d0 = min_off; d1 = 0; type = 3; }
+        if (do_append) { hdr[H_HEAD] = min_off; s_lh[H_HEAD] = min_off; head = min_off; d0 = min_off; d1 = 0; type = 3; }
     }
     SeqOut s;
     s.e0 = end; s.idx0 = s_lh[H_LAST_IDX] + 1; s.w = 0; s.n_end0 = s_lh[H_N_END];
@@ -834,7 +950,7 @@ __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32
     if (do_append) {
         const uint64_t idx = (end == L) ? 1 : s_lh[H_LAST_IDX] + 1;         /* dare_log.h:486-488 */
         const uint64_t pos = (end == L || L - end < APUS_HDR) ? 0 : end;   /* log_add_new_entry, :213-221 */
-        if (type != 3) hdr[H_PREV_HEAD] = 0; else if (mode == 1) hdr[H_PREV_HEAD] = 1;
+        if (type != 3) { hdr[H_PREV_HEAD] = 0; s_lh[H_PREV_HEAD] = 0; } else if (mode == 1) { hdr[H_PREV_HEAD] = 1; s_lh[H_PREV_HEAD] = 1; }
         if (type == 2) hdr[H_CID_BITMASK] = (uint32_t)(d1 >> 32);     /* the leader's own cid follows its CONFIG entries */
         const uint64_t term = s.term;
         const uint64_t slot = s.n_end0;
@@ -850,15 +966,14 @@ __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32
             E.rep[t].dir_off[di] = pos; E.rep[t].dir_len[di] = APUS_HDR | ((uint32_t)E.leader << 24);
         }
         __hip_atomic_store(&Ld.ack[di], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        hdr[H_TAIL] = pos;
-        hdr[H_END] = pos + APUS_HDR;
-        hdr[H_N_END] = slot + 1;
-        hdr[H_LAST_IDX] = idx;
-        hdr[H_OLD_END] = pos + APUS_HDR;
-        hdr[H_N_PERSIST] = slot + 1;
-        hdr[H_STORE_COUNT] = s_lh[H_STORE_COUNT] + 1;
+        hdr[H_TAIL] = pos;               s_lh[H_TAIL] = pos;
+        hdr[H_END] = pos + APUS_HDR;     s_lh[H_END] = pos + APUS_HDR;
+        hdr[H_N_END] = slot + 1;         s_lh[H_N_END] = slot + 1;
+        hdr[H_LAST_IDX] = idx;           s_lh[H_LAST_IDX] = idx;
+        hdr[H_OLD_END] = pos + APUS_HDR; s_lh[H_OLD_END] = pos + APUS_HDR;
+        hdr[H_N_PERSIST] = slot + 1;     s_lh[H_N_PERSIST] = slot + 1;
+        hdr[H_STORE_COUNT] = s_lh[H_STORE_COUNT] + 1; s_lh[H_STORE_COUNT] += 1;
         s.n = 1;
-        const uint64_t rec_base = *E.rec_count;
         if (rec_base < E.rec_cap) E.rec_end[rec_base] = pos + APUS_HDR;
     }
     return s;
@@ -903,8 +1018,8 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode,
     __shared__ uint64_t s_lh[64];
     if (tid < 64) s_lh[tid] = hdr[tid];
     __syncthreads();
-    if (tid == 0) *E.seq = control_append(E, mode, type, d0, d1, push_mask, s_lh);
-    if (mode == 1 && tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS) sample_apply_offsets(E, s_lh, sample_mask, tid - 64);
+    if (tid == 0) *E.seq = control_append(E, mode, type, d0, d1, push_mask, s_lh, *E.rec_count);
+    if (mode == 1 && tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS) sample_apply_offsets(E, s_lh, sample_mask, tid - 64, nullptr);
     __syncthreads();
 
     const uint64_t vis = visible_slots(E, hdr, 0, 0);
@@ -915,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode,
     __syncthreads();
     const uint64_t cs = commit_slot(E, vis);
     for (uint32_t m = push_mask | (1u << E.leader); m; m &= m - 1)
-        apply_range(E, __builtin_ctz(m), cs, 0, blockDim.x, s_acc);
+        apply_range(E, __builtin_ctz(m), E.rep[__builtin_ctz(m)].hdr[H_N_APPLY], cs, 0, blockDim.x, s_acc);
     __syncthreads();
     finish_call(E, 0, 0, mode == 2 ? 2 : 1, push_mask);
 }
@@ -968,7 +1083,7 @@ __global__ __launch_bounds__(256) void k_mp_ack_merge(const EngDev E, uint32_t f
 __global__ __launch_bounds__(256) void k_mp_apply(const EngDev E, uint32_t f, uint64_t cs)
 {
     __shared__ unsigned long long s_acc[2];
-    apply_range(E, (int)f, cs, (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_acc);
+    apply_range(E, (int)f, E.rep[f].hdr[H_N_APPLY], cs, (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_acc);
 }
 
 __global__ void k_mp_apply_fin(const EngDev E, uint32_t f, uint64_t cs)
@@ -999,5 +1114,5 @@ __global__ void k_reset(const EngDev E)
     h[H_LEN] = E.log_len; h[H_END] = E.log_len; h[H_TAIL] = E.log_len; h[H_OLD_END] = E.log_len;
     h[H_SID] = (uint64_t)p;
     h[H_CID_BITMASK] = (1u << E.group_size) - 1;
-    if (p == 0) { *E.rec_count = 0; *E.status = 0; *E.ticket = 0; }
+    if (p == 0) { *E.rec_count = 0; *E.status = 0; E.ticket[0] = 0; E.ticket[1] = 0; }
 }

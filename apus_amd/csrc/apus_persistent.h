@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
             if (com > n_persist) com = n_persist;
             if (com > n_apply) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       /* ring headers were written by the leader WG */
-                apply_range(E, me, com, 0, blockDim.x, s_acc);
+                apply_range(E, me, n_apply, com, 0, blockDim.x, s_acc);
                 if (tid == 0) {
                     const uint64_t coff = (com == mh[H_N_END]) ? mh[H_END] : Md.dir_off[(uint32_t)com & E.dir_mask];
                     mh[H_COMMIT] = coff; mh[H_N_COMMIT] = com; mh[H_N_APPLY] = com;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                apply_range(E, me, cs, 0, blockDim.x, s_acc);
+                apply_range(E, me, mh[H_N_APPLY], cs, 0, blockDim.x, s_acc);
                 if (tid == 0) {
                     const uint64_t coff = mh[H_COMMIT];
                     mh[H_APPLY] = coff; mh[H_N_APPLY] = cs;
