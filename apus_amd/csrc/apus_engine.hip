@@ -281,19 +281,12 @@ static int launch_tail_view(apus_engine *e, const EngDev &view, uint64_t r0, uin
     const uint32_t fm = sync_mask(e);
     const uint32_t rm = fm | ((e->local_mask >> e->d.leader) & 1u ? (1u << e->d.leader) : 0);
     const uint64_t n = n_hint ? n_hint : 1;
-    if (fm) {
-        /* followers on this device: persist + ACK + quorum test, apply and bookkeeping in one
-         * launch; the grid stays small enough to be resident (roles wait for each other) */
-        const uint32_t nrep = (uint32_t)popc(rm);
-        const uint32_t np = cap_grid(n, 256, 256);
-        uint32_t na = cap_grid(n, 1024, 512 / nrep ? 512 / nrep : 1);
-        hipLaunchKernelGGL(k_tail, dim3(np + na * nrep + 1), dim3(256), 0, e->stream, view, r0, R, rm, mode, fm, np, na, nrep);
-    } else {
-        /* ACK bits were merged from remote followers (k_mp_ack_merge) */
+    if (fm)     /* followers on this device: persist + ACK + quorum test in one pass */
+        hipLaunchKernelGGL(k_persist_commit, dim3(cap_grid(n, 256, 2048)), dim3(256), 0, e->stream, view, r0, R, fm);
+    else        /* ACK bits were merged from remote followers (k_mp_ack_merge) */
         hipLaunchKernelGGL(k_commit, dim3(cap_grid(n, 1024, 512)), dim3(1024), 0, e->stream, view, r0, R);
-        /* + 1: the bookkeeping block */
-        hipLaunchKernelGGL(k_apply, dim3(cap_grid(n, 1024, 1024) + 1, popc(rm)), dim3(256), 0, e->stream, view, r0, R, rm, mode, fm);
-    }
+    /* + 1: the bookkeeping block */
+    hipLaunchKernelGGL(k_apply, dim3(cap_grid(n, 1024, 1024) + 1, popc(rm)), dim3(256), 0, e->stream, view, r0, R, rm, mode, fm);
     HIPCHK(hipGetLastError());
     return 0;
 }

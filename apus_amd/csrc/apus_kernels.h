@@ -514,8 +514,7 @@ __device__ static inline void persist_ack_range(const EngDev &E, int f, uint64_t
  * bit) -- and, since the lane then holds the slot's complete ACK word, the quorum test
  * of update_remote_logs (dare_ibv_rc.c:1725-1758) right away:
  * popcount(ack | self) >= size/2+1 per lane, wave ballot, first slot without a majority. */
-__device__ static inline void persist_commit_blocks(const EngDev &E, uint64_t r0, uint32_t R, uint32_t fmask,
-                                                    uint32_t bx, uint32_t nb)
+__global__ __launch_bounds__(256) void k_persist_commit(const EngDev E, uint64_t r0, uint32_t R, uint32_t fmask)
 {
     const RepDev &Ld = E.rep[E.leader];
     const uint64_t *lh = Ld.hdr;
@@ -523,8 +522,8 @@ __device__ static inline void persist_commit_blocks(const EngDev &E, uint64_t r0
     uint64_t lo = lh[H_N_COMMIT];
     for (uint32_t m = fmask; m; m &= m - 1) lo = min(lo, E.rep[__builtin_ctz(m)].hdr[H_N_PERSIST]);
     const uint32_t size = E.group_size, size_mask = (1u << size) - 1, quorum = size / 2 + 1;
-    const uint64_t nth = (uint64_t)nb * blockDim.x;
-    for (uint64_t tile = lo + (uint64_t)bx * blockDim.x; tile < vis; tile += nth) {
+    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t tile = lo + (uint64_t)blockIdx.x * blockDim.x; tile < vis; tile += nth) {
         const uint64_t s = tile + threadIdx.x;
         const bool in = s < vis;
         bool ok = true;
@@ -554,11 +553,6 @@ __device__ static inline void persist_commit_blocks(const EngDev &E, uint64_t r0
             atomicMin((unsigned long long *)&E.seq->first_fail, (unsigned long long)first);
         }
     }
-}
-
-__global__ __launch_bounds__(256) void k_persist_commit(const EngDev E, uint64_t r0, uint32_t R, uint32_t fmask)
-{
-    persist_commit_blocks(E, r0, R, fmask, blockIdx.x, gridDim.x);
 }
 
 /* The ACK scan of update_remote_logs (dare_ibv_rc.c:1725-1758) over slots
@@ -808,19 +802,17 @@ __device__ static inline uint64_t ctx_visible(const EngDev &E, const ApplyCtx &c
  * (gridDim.x-1, 0) is the call's bookkeeper: it fetches everything finish needs while the
  * others work, waits for their arrival tickets, then publishes commit/apply offsets and the
  * R2/R4 doorbell words.  The appliers never wait for it, so the wait cannot deadlock. */
-/* bx / by / nbx / nby: this block's place among the appliers (nbx per replica, nby replicas)
- * or keeper = true for the bookkeeper.  wait_persist: number of persist tickets (ticket[2])
- * to wait for before the commit slot is final (fused tail), 0 when a kernel boundary already
- * separates us from the ACK scan. */
-__device__ static inline void apply_blocks(const EngDev &E, uint64_t r0, uint32_t R, uint32_t rmask, int mode, uint32_t fmask,
-                                           uint32_t bx, uint32_t by, uint32_t nbx, uint32_t nby, bool keeper,
-                                           uint32_t wait_persist, unsigned long long *s_acc, ApplyCtx &c)
+__global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint32_t R, uint32_t rmask,
+                                               int mode, uint32_t fmask)
 {
+    __shared__ unsigned long long s_acc[2];
+    __shared__ ApplyCtx c;
     const uint32_t tid = threadIdx.x;
+    const bool keeper = blockIdx.x == gridDim.x - 1;
+    if (keeper && blockIdx.y != 0) return;
     int p = -1;
-    if (!keeper)
-        for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
-            if (rmask & (1u << i)) { if (k == (int)by) { p = i; break; } k++; }
+    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
+        if (rmask & (1u << i)) { if (k == (int)blockIdx.y) { p = i; break; } k++; }
     const RepDev &Ld = E.rep[E.leader];
     uint64_t *lh = Ld.hdr;
 
@@ -836,20 +828,6 @@ __device__ static inline void apply_blocks(const EngDev &E, uint64_t r0, uint32_
         c.fw[f][j] = ((fmask >> f) & 1u) ? E.rep[f].hdr[words[j]] : 0;
     }
     __syncthreads();
-    if (wait_persist) {
-        /* fused tail: the persist blocks of this very launch decide first_fail; they never wait
-         * for anybody, so waiting for their tickets cannot deadlock; bounded anyway.  What flows
-         * from them to us is only first_fail (device-scope atomic): no fence needed. */
-        if (tid == 0) {
-            unsigned long long spins = 0;
-            while (__hip_atomic_load(E.ticket + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_persist) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1ull << 24)) { set_status(E, 1u << 4); break; }
-            }
-            c.seq.first_fail = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-    }
     const uint64_t L = E.log_len;
     const uint64_t vis = ctx_visible(E, c, R);
     uint64_t cs = min((uint64_t)c.seq.first_fail, vis);
@@ -857,9 +835,10 @@ __device__ static inline void apply_blocks(const EngDev &E, uint64_t r0, uint32_
 
     if (!keeper) {
         if (mode == 0)
-            finish_records(E, r0, R, cs, ((uint64_t)by * nbx + bx) * blockDim.x + tid,
-                           (uint64_t)nbx * nby * blockDim.x, c.seq, c.rec_base);
-        if (p >= 0) apply_range(E, p, c.n_apply_p, cs, (uint64_t)bx * blockDim.x, (uint64_t)nbx * blockDim.x, s_acc);
+            finish_records(E, r0, R, cs, ((uint64_t)blockIdx.y * (gridDim.x - 1) + blockIdx.x) * blockDim.x + tid,
+                           (uint64_t)(gridDim.x - 1) * gridDim.y * blockDim.x, c.seq, c.rec_base);
+        if (p >= 0) apply_range(E, p, c.n_apply_p, cs, (uint64_t)blockIdx.x * blockDim.x,
+                                (uint64_t)(gridDim.x - 1) * blockDim.x, s_acc);
         __syncthreads();
         if (tid == 0) atomicAdd(E.ticket + 1, 1u);          /* arrival ticket; no fence needed (see below) */
         return;
@@ -872,14 +851,13 @@ __device__ static inline void apply_blocks(const EngDev &E, uint64_t r0, uint32_
     /* wait for every applier: it only consumes words they updated with device-scope atomics
      * (HEAD slot) plus control words nobody else writes, so the ticket needs no fence */
     if (tid == 0) {
-        const unsigned int want = nbx * nby;
+        const unsigned int want = (gridDim.x - 1) * gridDim.y;
         unsigned long long spins = 0;
         while (__hip_atomic_load(E.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             __builtin_amdgcn_s_sleep(2);
             if (++spins > (1ull << 24)) { set_status(E, 1u << 4); break; }     /* bounded */
         }
         __hip_atomic_store(E.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (wait_persist) __hip_atomic_store(E.ticket + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const SeqOut &s = c.seq;
@@ -922,38 +900,6 @@ __device__ static inline void apply_blocks(const EngDev &E, uint64_t r0, uint32_
             }
         }
     }
-}
-
-__global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint32_t R, uint32_t rmask,
-                                               int mode, uint32_t fmask)
-{
-    __shared__ unsigned long long s_acc[2];
-    __shared__ ApplyCtx c;
-    const bool keeper = blockIdx.x == gridDim.x - 1;
-    if (keeper && blockIdx.y != 0) return;
-    apply_blocks(E, r0, R, rmask, mode, fmask, blockIdx.x, blockIdx.y, gridDim.x - 1, gridDim.y, keeper, 0, s_acc, c);
-}
-
-/* k_tail: persist + ACK + quorum test, apply and the bookkeeping of one call in ONE launch
- * (single-device groups).  Block roles by index: [0, np) persist/quorum blocks, then
- * na * nrep appliers, then the bookkeeper.  Data flows between the roles only through
- * device-scope atomics (ACK words, first_fail, HEAD slot) and arrival tickets; the grid is
- * sized by the host to stay resident (<= 1024 blocks of 256 threads), every wait is bounded. */
-__global__ __launch_bounds__(256) void k_tail(const EngDev E, uint64_t r0, uint32_t R, uint32_t rmask, int mode,
-                                              uint32_t fmask, uint32_t np, uint32_t na, uint32_t nrep)
-{
-    __shared__ unsigned long long s_acc[2];
-    __shared__ ApplyCtx c;
-    const uint32_t b = blockIdx.x;
-    if (b < np) {
-        persist_commit_blocks(E, r0, R, fmask, b, np);
-        __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(E.ticket + 2, 1u);
-        return;
-    }
-    const uint32_t a = b - np;
-    const bool keeper = a == na * nrep;
-    apply_blocks(E, r0, R, rmask, mode, fmask, keeper ? 0 : a % na, keeper ? 0 : a / na, na, nrep, keeper, np, s_acc, c);
 }
 
 /* READ the apply offset of peer i for the next prune tick (rc_get_remote_apply_offsets,
@@ -1168,5 +1114,5 @@ __global__ void k_reset(const EngDev E)
     h[H_LEN] = E.log_len; h[H_END] = E.log_len; h[H_TAIL] = E.log_len; h[H_OLD_END] = E.log_len;
     h[H_SID] = (uint64_t)p;
     h[H_CID_BITMASK] = (1u << E.group_size) - 1;
-    if (p == 0) { *E.rec_count = 0; *E.status = 0; E.ticket[0] = 0; E.ticket[1] = 0; E.ticket[2] = 0; }
+    if (p == 0) { *E.rec_count = 0; *E.status = 0; E.ticket[0] = 0; E.ticket[1] = 0; }
 }
