@@ -8,9 +8,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "apus_gpu.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    names = re.findall(r"\b((?:apus_gpu|dare_ib|dare_server|proxy|is_leader|get_node_id)\w*)\s*\(", txt)
+    names = []
+    for hdr in ("apus_gpu.h", "apus_smr.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        txt = re.sub(r"typedef[^;]*;", "", txt)
+        names += re.findall(r"\b((?:apus_gpu_|apus_tailq_|dare_ib_|dare_server_|proxy_(?:init|on_)|is_leader|get_node_id)\w*)\s*\(", txt)
     return sorted(set(names))
 
 
