@@ -186,26 +186,23 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
     const uint32_t *rf = E.round_first + r0;
 
     /* Everything phase B needs from HBM is requested NOW, by different lanes, so that it is
-     * one round trip that overlaps phase A instead of a chain of dependent loads later. */
+     * one round trip that overlaps phase A instead of a chain of dependent loads later.
+     * (plain code, no lambdas: captured locals would live in scratch and a kernel with a
+     * private segment pays for it at every dispatch) */
     uint64_t st0 = 0, st1 = 0, st2 = 0;
-    auto stage_load = [&]() {
-        if (tid < 64) st0 = hdr[tid];
-        else if (tid < 64 + APUS_DEV_MAX_SERVERS) {
-            const uint32_t f = tid - 64;
-            if (((push_mask | sample_mask) >> f) & 1u) {
-                const uint64_t *fh = E.rep[f].hdr;
-                st0 = fh[H_END]; st1 = fh[H_N_END]; st2 = fh[H_APPLY];
-            }
-        } else if (tid == 96) st0 = *E.rec_count;
-        else if (tid == 97) st0 = (rf[R] > rf[0]) ? E.req_len[rf[R] - 1] : 0;
-    };
-    auto stage_store = [&]() {
-        if (tid < 64) s_lh[tid] = st0;
-        else if (tid < 64 + APUS_DEV_MAX_SERVERS) { s_fw[tid - 64][0] = st0; s_fw[tid - 64][1] = st1; s_fw[tid - 64][2] = st2; }
-        else if (tid == 96) s_misc[0] = st0;
-        else if (tid == 97) s_misc[1] = st0;
-    };
-    if (gridDim.x == 1) stage_load();
+#define APUS_SEQ_STAGE_LOAD()                                                                  \
+    do {                                                                                       \
+        if (tid < 64) st0 = hdr[tid];                                                          \
+        else if (tid < 64 + APUS_DEV_MAX_SERVERS) {                                            \
+            const uint32_t f_ = tid - 64;                                                      \
+            if (((push_mask | sample_mask) >> f_) & 1u) {                                      \
+                const uint64_t *fh_ = E.rep[f_].hdr;                                           \
+                st0 = fh_[H_END]; st1 = fh_[H_N_END]; st2 = fh_[H_APPLY];                      \
+            }                                                                                  \
+        } else if (tid == 96) st0 = *E.rec_count;                                              \
+        else if (tid == 97) st0 = (rf[R] > rf[0]) ? E.req_len[rf[R] - 1] : 0;                  \
+    } while (0)
+    if (gridDim.x == 1) APUS_SEQ_STAGE_LOAD();
 
     /* phase A: bytes of every round, one thread per round */
     {
@@ -233,9 +230,13 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
         }
         __syncthreads();
         if (!s_last) return;
-        stage_load();                                     /* only the finishing block needs the context */
+        APUS_SEQ_STAGE_LOAD();                            /* only the finishing block needs the context */
     }
-    stage_store();
+#undef APUS_SEQ_STAGE_LOAD
+    if (tid < 64) s_lh[tid] = st0;
+    else if (tid < 64 + APUS_DEV_MAX_SERVERS) { s_fw[tid - 64][0] = st0; s_fw[tid - 64][1] = st1; s_fw[tid - 64][2] = st2; }
+    else if (tid == 96) s_misc[0] = st0;
+    else if (tid == 97) s_misc[1] = st0;
     if (tid == 0) { s_rstar = 0xFFFFFFFFu; s_head_round = 0; }
     __syncthreads();
 
@@ -271,7 +272,8 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
     const uint64_t e0 = s_lh[H_END];
     const uint64_t n_end0 = s_lh[H_N_END];
 
-    /* exclusive scan of the round sums, in place */
+    /* exclusive scan of the round sums; up to 1024 rounds stay in LDS for the passes below */
+    __shared__ uint64_t s_virt[1025];
     uint64_t carry = 0;
     for (uint32_t base = 0; base < R; base += 1024) {
         const uint32_t r = base + tid;
@@ -279,13 +281,15 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
         uint64_t tot;
         const uint64_t incl = block_incl_scan(bytes, s_tot, &tot);
         if (r < R) {
-            E.round_virt[r] = carry + incl - bytes;
+            const uint64_t v = carry + incl - bytes;
+            E.round_virt[r] = v;
+            if (R <= 1024) s_virt[r] = v;
             if (e0 + carry + incl > L) atomicMin(&s_rstar, r);   /* first round that does not fit before len */
         }
         carry += tot;
     }
     const uint64_t vtot = carry;
-    if (tid == 0) E.round_virt[R] = vtot;
+    if (tid == 0) { E.round_virt[R] = vtot; if (R <= 1024) s_virt[R] = vtot; }
     __syncthreads();
     const uint32_t rstar = s_rstar;
 
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
         uint64_t w = 0;
         uint32_t stale = 0;
         if (rstar < R) {
-            uint64_t a = e0 + E.round_virt[rstar];
+            uint64_t a = e0 + (R <= 1024 ? s_virt[rstar] : E.round_virt[rstar]);
             for (uint32_t g = rf[rstar]; g < rf[rstar + 1]; g++) {
                 const uint64_t T = APUS_HDR + E.req_len[g];
                 if (a + T > L) {
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
     const int64_t kstar = s_kstar;
     const uint64_t w = s_w;
     for (uint32_t r = tid; r < R; r += 1024) {
-        const uint64_t a_end = e0 + E.round_virt[r + 1];
+        const uint64_t a_end = e0 + (R <= 1024 ? s_virt[r + 1] : E.round_virt[r + 1]);
         const int64_t last = (int64_t)(rf[r + 1] - g0) - 1;   /* batch index of the round's last entry */
         const uint64_t end_r = (kstar < 0 || last < kstar) ? a_end : a_end - w;
         if (rec_base + head_round + r < E.rec_cap) E.rec_end[rec_base + head_round + r] = end_r;
