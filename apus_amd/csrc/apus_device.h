@@ -88,6 +88,11 @@ struct SeqOut {
     uint64_t first_fail;   /* commit scan: first slot without a majority                 */
     uint64_t commit_before;/* leader commit offset before this call                      */
     uint64_t n_commit_before;
+    /* context of the call's tail kernels (persist + ACK scan, apply), filled by k_sequence
+     * so that each of them starts with ONE load round trip instead of a chain */
+    uint64_t vis;          /* slots visible to followers / committable once the batch is appended */
+    uint64_t scan_lo;      /* first slot the persist + ACK pass has to look at                   */
+    uint64_t np[APUS_DEV_MAX_SERVERS];   /* followers' persisted slot count (~0: not pushed to)  */
 };
 
 /* engine-wide device state */
@@ -99,12 +104,13 @@ struct EngDev {
     uint32_t dir_mask;                    /* dir_cap - 1 */
     uint64_t log_len;
     uint32_t *status;
-    uint32_t *ticket;                     /* arrival counter of k_sequence's blocks */
+    uint32_t *ticket;                     /* [1]: arrival counter of k_apply's blocks */
     /* staged requests */
     const ReqDev   *req;
     const uint16_t *req_len;
     const uint8_t  *arena;
     const uint32_t *round_first;          /* prefix of round sizes, n_rounds + 1 entries */
+    const uint32_t *round_bytes;          /* bytes each round appends (64 + len per request), n_rounds entries */
     /* per-call scratch */
     SeqOut   *seq;
     uint64_t *round_virt;                 /* [max_rounds + 1] exclusive scan of round bytes */

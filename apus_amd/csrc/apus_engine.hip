@@ -53,7 +53,7 @@ struct apus_engine {
     size_t timed_used;
     std::vector<void *> allocs;
     /* live submission path (apus_gpu_submit): pinned host staging + device buffers */
-    uint8_t *h_live;                /* pinned: [ReqDev x LIVE_REQS][u16 x LIVE_REQS][u32 x (LIVE_REQS+1)][arena] */
+    uint8_t *h_live;                /* pinned: [ReqDev x LIVE_REQS][u16 x LIVE_REQS][u32 x (LIVE_REQS+1)][u32 x LIVE_REQS][arena] */
     uint8_t *d_live;
     hipEvent_t live_copied;
     bool live_pending;
@@ -72,7 +72,8 @@ struct apus_engine {
 #define LIVE_ARENA  (16u << 20)
 #define LIVE_OFF_LEN    (sizeof(ReqDev) * LIVE_REQS)
 #define LIVE_OFF_RF     (LIVE_OFF_LEN + sizeof(uint16_t) * LIVE_REQS)
-#define LIVE_OFF_ARENA  (LIVE_OFF_RF + sizeof(uint32_t) * (LIVE_REQS + 1) + 16)
+#define LIVE_OFF_RB     (LIVE_OFF_RF + sizeof(uint32_t) * (LIVE_REQS + 1))
+#define LIVE_OFF_ARENA  (LIVE_OFF_RB + sizeof(uint32_t) * LIVE_REQS + 16)
 #define LIVE_BYTES      (LIVE_OFF_ARENA + LIVE_ARENA + 64)
 
 static apus_engine *g_engine = nullptr;
@@ -232,11 +233,15 @@ extern "C" int apus_gpu_stage(apus_engine_t *e, const apus_req_t *reqs, uint64_t
         hd[g].clt_id = q.clt_id;
         hl[g] = q.len;
     }
-    e->h_round_first.assign(n_rounds + 1, 0);
+    /* round descriptors: [first request of round r : n_rounds + 1][bytes round r appends : n_rounds] */
+    e->h_round_first.assign(2 * n_rounds + 1, 0);
     uint64_t acc = 0;
     for (uint64_t r = 0; r < n_rounds; r++) {
-        if (round_n[r] < 1 || round_n[r] > APUS_MAX_ROUND) return APUS_E_ARG;
+        if (round_n[r] < 1 || round_n[r] > APUS_MAX_ROUND || acc + round_n[r] > n) return APUS_E_ARG;
         e->h_round_first[r] = (uint32_t)acc;
+        uint32_t bytes = 0;
+        for (uint64_t g = acc; g < acc + round_n[r]; g++) bytes += APUS_HDR + (uint32_t)hl[g];
+        e->h_round_first[n_rounds + 1 + r] = bytes;
         acc += round_n[r];
     }
     if (acc != n) return APUS_E_ARG;
@@ -250,17 +255,18 @@ extern "C" int apus_gpu_stage(apus_engine_t *e, const apus_req_t *reqs, uint64_t
     if ((rc = renew(&e->d_req, sizeof(ReqDev) * n))) return rc;
     if ((rc = renew(&e->d_req_len, sizeof(uint16_t) * n + 64))) return rc;
     if ((rc = renew(&e->d_arena, arena_bytes + 64))) return rc;
-    if ((rc = renew(&e->d_round_first, sizeof(uint32_t) * (n_rounds + 1)))) return rc;
+    if ((rc = renew(&e->d_round_first, sizeof(uint32_t) * (2 * n_rounds + 1)))) return rc;
     if (n) {
         HIPCHK(hipMemcpy(e->d_req, hd.data(), sizeof(ReqDev) * n, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_req_len, hl.data(), sizeof(uint16_t) * n, hipMemcpyHostToDevice));
     }
     if (arena_bytes) HIPCHK(hipMemcpy(e->d_arena, arena, arena_bytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_round_first, e->h_round_first.data(), sizeof(uint32_t) * (n_rounds + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_round_first, e->h_round_first.data(), sizeof(uint32_t) * (2 * n_rounds + 1), hipMemcpyHostToDevice));
     e->d.req = (const ReqDev *)e->d_req;
     e->d.req_len = (const uint16_t *)e->d_req_len;
     e->d.arena = (const uint8_t *)e->d_arena;
     e->d.round_first = (const uint32_t *)e->d_round_first;
+    e->d.round_bytes = e->d.round_first + n_rounds + 1;
     e->n_reqs = n;
     e->n_rounds_staged = n_rounds;
     return 0;
@@ -285,8 +291,10 @@ static int launch_tail_view(apus_engine *e, const EngDev &view, uint64_t r0, uin
         hipLaunchKernelGGL(k_persist_commit, dim3(cap_grid(n, 256, 2048)), dim3(256), 0, e->stream, view, r0, R, fm);
     else        /* ACK bits were merged from remote followers (k_mp_ack_merge) */
         hipLaunchKernelGGL(k_commit, dim3(cap_grid(n, 1024, 512)), dim3(1024), 0, e->stream, view, r0, R);
-    /* + 1: the bookkeeping block */
-    hipLaunchKernelGGL(k_apply, dim3(cap_grid(n, 1024, 1024) + 1, popc(rm)), dim3(256), 0, e->stream, view, r0, R, rm, mode, fm);
+    /* appliers + per-round record blocks + the bookkeeping block */
+    const uint32_t nR = (mode == 0 && R) ? cap_grid(R, 256, 8) : 0;
+    hipLaunchKernelGGL(k_apply, dim3(cap_grid(n, 1024, 1024) + nR + 1, popc(rm)), dim3(256), 0, e->stream, view, r0, R, rm, mode,
+                       fm, nR);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -321,7 +329,7 @@ static int launch_append(apus_engine *e, const EngDev &view, uint64_t r0, uint32
     if ((rc = launch_catchup(e))) return rc;
     const uint32_t tick = e->tick_pending ? 1u : 0u;
     e->tick_pending = false;
-    hipLaunchKernelGGL(k_sequence, dim3((R + 1023) / 1024), dim3(1024), 0, e->stream, view, r0, R, fm, tick, fm);
+    hipLaunchKernelGGL(k_sequence, dim3(1), dim3(1024), 0, e->stream, view, r0, R, fm, tick, fm);
     hipLaunchKernelGGL(k_append_push, dim3(R), dim3(256), 0, e->stream, view, r0, R, fm);
     HIPCHK(hipGetLastError());
     return 0;
@@ -339,7 +347,7 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
     if ((rc = launch_catchup(e))) return rc;
     const uint32_t tick = e->tick_pending ? 1u : 0u;
     e->tick_pending = false;
-    hipLaunchKernelGGL(k_sequence, dim3((R + 1023) / 1024), dim3(1024), 0, e->stream, e->d, r0, R, fm, tick, fm);
+    hipLaunchKernelGGL(k_sequence, dim3(1), dim3(1024), 0, e->stream, e->d, r0, R, fm, tick, fm);
     TimedLaunch *tl = nullptr;
     if (e->timing && !e->capturing) {
         if (e->timed_used == e->timed.size()) {
@@ -368,6 +376,7 @@ static int live_view(apus_engine *e, EngDev *view)
     view->req = (const ReqDev *)e->d_live;
     view->req_len = (const uint16_t *)(e->d_live + LIVE_OFF_LEN);
     view->round_first = (const uint32_t *)(e->d_live + LIVE_OFF_RF);
+    view->round_bytes = (const uint32_t *)(e->d_live + LIVE_OFF_RB);
     view->arena = e->d_live + LIVE_OFF_ARENA;
     return 0;
 }
@@ -396,8 +405,14 @@ extern "C" int apus_gpu_append_live(apus_engine_t *e, const apus_req_t *reqs, ui
         hd[g].pay16_type = (uint32_t)(q.payload_off / 16 + 1) | ((uint32_t)q.type << 28);
         hd[g].len = q.len; hd[g].clt_id = q.clt_id; hl[g] = q.len;
     }
+    uint32_t *rb = (uint32_t *)(e->h_live + LIVE_OFF_RB);
     uint32_t R = 0;
-    for (uint32_t g = 0; g < n; g += APUS_MAX_ROUND) rf[R++] = g;
+    for (uint32_t g = 0; g < n; g += APUS_MAX_ROUND) {
+        uint32_t bytes = 0;
+        for (uint32_t k = g; k < n && k < g + APUS_MAX_ROUND; k++) bytes += APUS_HDR + (uint32_t)hl[k];
+        rb[R] = bytes;
+        rf[R++] = g;
+    }
     rf[R] = n;
     if (arena_bytes) memcpy(ha + 16, arena, arena_bytes);
     HIPCHK(hipMemcpyAsync(e->d_live, e->h_live, LIVE_OFF_ARENA + 16 + arena_bytes, hipMemcpyHostToDevice, e->stream));

@@ -164,19 +164,19 @@ __device__ static inline uint64_t block_incl_scan(uint64_t v, uint64_t *s_tot /*
 }
 
 /* ------------------------------------------------------------------------- */
-/* k_sequence: where every entry of rounds [r0, r0+R) goes.
- * Phase A (all blocks, one thread per round): bytes of the round.
- * Phase B (the block that arrives last): exclusive scan over the rounds, the wrap
- * point, the leader's control words and the per-round end record.            */
+/* k_sequence: where every entry of rounds [r0, r0+R) goes -- one workgroup: exclusive
+ * scan over the rounds' byte totals (staged with the batch: the admission side knows every
+ * request's size, so a round arrives with its total), the wrap point, the leader's
+ * control words and the per-round end record.                                  */
 __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask,
                                                     uint32_t tick, uint32_t sample_mask)
 {
     __shared__ uint64_t s_lh[64];                      /* the leader's control block, kept current */
-    __shared__ uint64_t s_fw[APUS_DEV_MAX_SERVERS][3]; /* followers: end, n_end, apply */
+    __shared__ uint64_t s_fw[APUS_DEV_MAX_SERVERS][4]; /* followers: end, n_end, apply, n_persist */
     __shared__ uint64_t s_misc[2];                     /* rec_count, len of the batch's last request */
     __shared__ uint32_t s_head_round;
     __shared__ uint64_t s_tot[16];
-    __shared__ unsigned int s_last, s_rstar;
+    __shared__ unsigned int s_rstar;
     __shared__ int64_t s_kstar;
     __shared__ uint64_t s_w;
     const uint32_t tid = threadIdx.x;
@@ -184,63 +184,29 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
     uint64_t *hdr = Ld.hdr;
     const uint64_t L = E.log_len;
     const uint32_t *rf = E.round_first + r0;
+    const uint32_t *rb = E.round_bytes + r0;
 
-    /* Everything phase B needs from HBM is requested NOW, by different lanes, so that it is
-     * one round trip that overlaps phase A instead of a chain of dependent loads later.
-     * (plain code, no lambdas: captured locals would live in scratch and a kernel with a
-     * private segment pays for it at every dispatch) */
-    uint64_t st0 = 0, st1 = 0, st2 = 0;
-#define APUS_SEQ_STAGE_LOAD()                                                                  \
-    do {                                                                                       \
-        if (tid < 64) st0 = hdr[tid];                                                          \
-        else if (tid < 64 + APUS_DEV_MAX_SERVERS) {                                            \
-            const uint32_t f_ = tid - 64;                                                      \
-            if (((push_mask | sample_mask) >> f_) & 1u) {                                      \
-                const uint64_t *fh_ = E.rep[f_].hdr;                                           \
-                st0 = fh_[H_END]; st1 = fh_[H_N_END]; st2 = fh_[H_APPLY];                      \
-            }                                                                                  \
-        } else if (tid == 96) st0 = *E.rec_count;                                              \
-        else if (tid == 97) st0 = (rf[R] > rf[0]) ? E.req_len[rf[R] - 1] : 0;                  \
-    } while (0)
-    if (gridDim.x == 1) APUS_SEQ_STAGE_LOAD();
-
-    /* phase A: bytes of every round, one thread per round */
-    {
-        const uint32_t r = blockIdx.x * blockDim.x + tid;
-        if (r < R) {
-            const uint32_t a = rf[r], b = rf[r + 1];
-            uint64_t bytes = (uint64_t)APUS_HDR * (b - a);
-            uint32_t g = a;
-            for (; g + 8 <= b; g += 8) {              /* 8 lens per 16-byte load */
-                const uint4 v = ld16u((const uint8_t *)(E.req_len + g));
-                bytes += (v.x & 0xFFFF) + (v.x >> 16) + (v.y & 0xFFFF) + (v.y >> 16)
-                       + (v.z & 0xFFFF) + (v.z >> 16) + (v.w & 0xFFFF) + (v.w >> 16);
-            }
-            for (; g < b; g++) bytes += E.req_len[g];
-            E.round_virt[r] = bytes;
+    /* Everything the block needs from HBM is requested NOW, by different lanes: one round
+     * trip instead of a chain of dependent loads later. */
+    uint64_t st0 = 0, st1 = 0, st2 = 0, st3 = ~0ull;
+    const uint32_t bytes0 = (tid < R) ? rb[tid] : 0;   /* first tile of the scan */
+    if (tid < 64) st0 = hdr[tid];
+    else if (tid < 64 + APUS_DEV_MAX_SERVERS) {
+        const uint32_t f_ = tid - 64;
+        if (((push_mask | sample_mask) >> f_) & 1u) {
+            const uint64_t *fh_ = E.rep[f_].hdr;
+            st0 = fh_[H_END]; st1 = fh_[H_N_END]; st2 = fh_[H_APPLY];
+            if ((push_mask >> f_) & 1u) st3 = fh_[H_N_PERSIST];
         }
-    }
-    __syncthreads();
-    if (gridDim.x > 1) {
-        if (tid == 0) {
-            __threadfence();                               /* release the round sums (agent scope) */
-            const unsigned int t = atomicAdd(E.ticket, 1u);
-            s_last = (t == gridDim.x - 1);
-            if (s_last) { *E.ticket = 0; __threadfence(); }   /* acquire the other blocks' sums */
-        }
-        __syncthreads();
-        if (!s_last) return;
-        APUS_SEQ_STAGE_LOAD();                            /* only the finishing block needs the context */
-    }
-#undef APUS_SEQ_STAGE_LOAD
+    } else if (tid == 96) st0 = *E.rec_count;
+    else if (tid == 97) st0 = (rf[R] > rf[0]) ? E.req_len[rf[R] - 1] : 0;
     if (tid < 64) s_lh[tid] = st0;
-    else if (tid < 64 + APUS_DEV_MAX_SERVERS) { s_fw[tid - 64][0] = st0; s_fw[tid - 64][1] = st1; s_fw[tid - 64][2] = st2; }
+    else if (tid < 64 + APUS_DEV_MAX_SERVERS) { s_fw[tid - 64][0] = st0; s_fw[tid - 64][1] = st1; s_fw[tid - 64][2] = st2; s_fw[tid - 64][3] = st3; }
     else if (tid == 96) s_misc[0] = st0;
     else if (tid == 97) s_misc[1] = st0;
     if (tid == 0) { s_rstar = 0xFFFFFFFFu; s_head_round = 0; }
     __syncthreads();
 
-    /* phase B: this block is alone now; it works on the staged copies */
     const uint32_t g0 = rf[0];
     const uint32_t n = rf[R] - g0;
     {
@@ -277,7 +243,7 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
     uint64_t carry = 0;
     for (uint32_t base = 0; base < R; base += 1024) {
         const uint32_t r = base + tid;
-        const uint64_t bytes = (r < R) ? E.round_virt[r] : 0;
+        const uint64_t bytes = base ? ((r < R) ? rb[r] : 0) : bytes0;
         uint64_t tot;
         const uint64_t incl = block_incl_scan(bytes, s_tot, &tot);
         if (r < R) {
@@ -330,6 +296,16 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
         s.first_fail = ~0ull;
         s.commit_before = s_lh[H_COMMIT];
         s.n_commit_before = s_lh[H_N_COMMIT];
+        /* what the followers may see / the scan may commit (visible_slots): a batch that ends
+         * exactly on len reads as empty, its last round stays hidden */
+        {
+            const uint64_t end_after = n ? end_new : e0, n_end_after = n_end0 + n;
+            s.vis = (end_after != L) ? n_end_after
+                  : (n == 0 ? s_lh[H_N_VISIBLE] : n_end0 + (rf[R - 1] - g0));
+            uint64_t lo = s.n_commit_before;
+            for (uint32_t f = 0; f < APUS_DEV_MAX_SERVERS; f++) { s.np[f] = s_fw[f][3]; lo = min(lo, s_fw[f][3]); }
+            s.scan_lo = lo;
+        }
         *E.seq = s;
         if (n) {
             const uint64_t t_last = APUS_HDR + s_misc[1];
@@ -515,41 +491,59 @@ __device__ static inline void persist_ack_range(const EngDev &E, int f, uint64_t
 
 /* k_persist_commit: when the followers live on this device, one lane handles one
  * entry slot for ALL of them -- follower persist + ACK (reply byte in both rings, ACK
- * bit) -- and, since the lane then holds the slot's complete ACK word, the quorum test
- * of update_remote_logs (dare_ibv_rc.c:1725-1758) right away:
- * popcount(ack | self) >= size/2+1 per lane, wave ballot, first slot without a majority. */
+ * bit) -- and, since the lane then holds the slot's ACK bits, the quorum test of
+ * update_remote_logs (dare_ibv_rc.c:1725-1758) right away:
+ * popcount(ack | self) >= size/2+1 per lane, wave ballot, first slot without a majority.
+ * Latency shape: one load round trip for the call context (k_sequence left it in SeqOut),
+ * one for the slot's directory entry, then only stores.  Followers in the mask hold the
+ * same entries at the same offsets as the leader (that is what R1 pushed), so the lane
+ * reads the leader's directory entry once instead of one copy per follower.        */
 __global__ __launch_bounds__(256) void k_persist_commit(const EngDev E, uint64_t r0, uint32_t R, uint32_t fmask)
 {
+    __shared__ uint64_t s_np[APUS_DEV_MAX_SERVERS];
+    __shared__ uint64_t s_c[3];
+    const uint32_t tid = threadIdx.x;
+    if (tid < APUS_DEV_MAX_SERVERS) s_np[tid] = E.seq->np[tid];
+    else if (tid == 16) s_c[0] = E.seq->vis;
+    else if (tid == 17) s_c[1] = E.seq->scan_lo;
+    else if (tid == 18) s_c[2] = E.seq->n_commit_before;
+    __syncthreads();
     const RepDev &Ld = E.rep[E.leader];
-    const uint64_t *lh = Ld.hdr;
-    const uint64_t vis = visible_slots(E, lh, r0, R);
-    uint64_t lo = lh[H_N_COMMIT];
-    for (uint32_t m = fmask; m; m &= m - 1) lo = min(lo, E.rep[__builtin_ctz(m)].hdr[H_N_PERSIST]);
+    const uint64_t vis = s_c[0], lo = s_c[1], n_commit = s_c[2];
     const uint32_t size = E.group_size, size_mask = (1u << size) - 1, quorum = size / 2 + 1;
+    const uint32_t self = 1u << E.leader;
     const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t tile = lo + (uint64_t)blockIdx.x * blockDim.x; tile < vis; tile += nth) {
-        const uint64_t s = tile + threadIdx.x;
+        const uint64_t s = tile + tid;
         const bool in = s < vis;
+        const uint32_t di = (uint32_t)(in ? s : vis - 1) & E.dir_mask;     /* clamped: the loads are unconditional */
+        const uint64_t off = Ld.dir_off[di];
+        const uint32_t sender = Ld.dir_len[di] >> 24;                      /* entry->sender, dare_server.c:1806 */
         bool ok = true;
         if (in) {
-            const uint32_t di = (uint32_t)s & E.dir_mask;
-            uint32_t bits = 0, sender = E.leader;
+            uint8_t *sring = (sender == E.leader) ? Ld.ring
+                           : (sender < APUS_DEV_MAX_SERVERS ? E.rep[sender].ring : nullptr);
+            uint32_t bits = 0;
             for (uint32_t m = fmask; m; m &= m - 1) {
                 const int f = __builtin_ctz(m);
-                const RepDev &Fd = E.rep[f];
-                if (s < Fd.hdr[H_N_PERSIST]) continue;               /* this follower persisted it earlier */
-                const uint64_t off = Fd.dir_off[di];                 /* the follower reads its own log */
-                sender = Fd.dir_len[di] >> 24;                       /* entry->sender, dare_server.c:1806 */
-                Fd.ring[off + 28 + f] = 1;                           /* local reply byte, dare_ibv_rc.c:1840 */
-                if (sender < APUS_DEV_MAX_SERVERS && E.rep[sender].ring)
-                    E.rep[sender].ring[off + 28 + f] = 1;            /* R3: 1-byte WRITE at the same offset */
+                if (s < s_np[f]) continue;                               /* this follower persisted it earlier */
+                E.rep[f].ring[off + 28 + f] = 1;                         /* local reply byte, dare_ibv_rc.c:1840 */
+                if (sring) sring[off + 28 + f] = 1;                      /* R3: 1-byte WRITE at the same offset */
                 bits |= 1u << f;
             }
-            uint32_t word;
-            if (bits && sender == E.leader) word = atomicOr(&Ld.ack[di], bits) | bits;
-            else word = __hip_atomic_load(&Ld.ack[di], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t mm = (word | (1u << E.leader)) & size_mask;
-            ok = (s < lh[H_N_COMMIT]) || (uint32_t)__popc(mm) >= quorum;   /* replies >= size/2+1, :1738 */
+            if (s >= n_commit) {
+                uint32_t word = bits;
+                if (sender == E.leader && (uint32_t)__popc((bits | self) & size_mask) >= quorum) {
+                    if (bits) __hip_atomic_fetch_or(&Ld.ack[di], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    /* not decided by the local followers alone: the word may hold remote ACK bits */
+                    if (bits && sender == E.leader) word = atomicOr(&Ld.ack[di], bits) | bits;
+                    else word = __hip_atomic_load(&Ld.ack[di], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (uint32_t)__popc((word | self) & size_mask) >= quorum;   /* replies >= size/2+1, :1738 */
+                }
+            } else if (bits && sender == E.leader) {
+                __hip_atomic_fetch_or(&Ld.ack[di], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         const unsigned long long bal = __ballot(!ok);
         if (bal && lane_id() == 0) {
@@ -589,9 +583,8 @@ __device__ static inline void commit_scan(const EngDev &E, uint64_t from, uint64
 __global__ __launch_bounds__(1024) void k_commit(const EngDev E, uint64_t r0, uint32_t R)
 {
     __shared__ uint32_t s_ack[1024];
-    const uint64_t *lh = E.rep[E.leader].hdr;
-    const uint64_t vis = visible_slots(E, lh, r0, R);
-    commit_scan(E, lh[H_N_COMMIT], vis, (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_ack);
+    const uint64_t from = E.seq->n_commit_before, vis = E.seq->vis;      /* left there by k_sequence */
+    commit_scan(E, from, vis, (uint64_t)blockIdx.x * blockDim.x, (uint64_t)gridDim.x * blockDim.x, s_ack);
 }
 
 /* apply_committed_entries (dare_server.c:1815-1974) for slots [from, cs) of
@@ -611,20 +604,24 @@ __device__ static inline void apply_range(const EngDev &E, int p, uint64_t from,
         uint64_t sl[APPLY_ILP], off[APPLY_ILP];
         uint32_t T[APPLY_ILP];
         bool in[APPLY_ILP];
+        /* loads are unconditional (lanes past the end re-read slot cs-1): a load inside a
+         * divergent branch makes the compiler wait for it before the next one is issued */
 #pragma unroll
         for (int k = 0; k < APPLY_ILP; k++) {
             sl[k] = tile + (uint64_t)k * blockDim.x + threadIdx.x;
             in[k] = sl[k] < cs;
-            const uint32_t di = (uint32_t)sl[k] & E.dir_mask;
-            off[k] = in[k] ? Pd.dir_off[di] : 0;
-            T[k] = in[k] ? (Pd.dir_len[di] & 0xFFFFFFu) : APUS_HDR;
+            const uint32_t di = (uint32_t)(in[k] ? sl[k] : cs - 1) & E.dir_mask;
+            off[k] = Pd.dir_off[di];
+            T[k] = Pd.dir_len[di];
         }
         uint4 u0[APPLY_ILP], u1[APPLY_ILP];
 #pragma unroll
         for (int k = 0; k < APPLY_ILP; k++) {
-            u0[k] = in[k] ? ld16u(Pd.ring + off[k]) : make_uint4(0, 0, 0, 0);
-            u1[k] = in[k] ? ld16u(Pd.ring + off[k] + 16) : make_uint4(0, 0, 0, 0);
+            u0[k] = ld16u(Pd.ring + off[k]);
+            u1[k] = ld16u(Pd.ring + off[k] + 16);
         }
+#pragma unroll
+        for (int k = 0; k < APPLY_ILP; k++) T[k] &= 0xFFFFFFu;
         uint64_t mix = 0;
         uint32_t nclient = 0;
 #pragma unroll
@@ -785,35 +782,32 @@ __device__ static inline void finish_call(const EngDev &E, uint64_t r0, uint32_t
 /* what every block of k_apply needs before it can start, fetched in ONE round trip
  * (different lanes load different words) */
 struct ApplyCtx {
-    uint64_t lh[64];          /* leader control block */
+    uint64_t lh[64];          /* leader control block (bookkeeper only) */
     SeqOut   seq;
     uint64_t rec_base, n_apply_p;
-    uint32_t rfa, rfb;
     uint64_t fw[APUS_DEV_MAX_SERVERS][8];   /* bookkeeping block: followers' control words */
     uint64_t off_cs, off_vis;
 };
+static_assert(sizeof(SeqOut) / 8 <= 32, "k_apply stages SeqOut with lanes 64..95");
 
-__device__ static inline uint64_t ctx_visible(const EngDev &E, const ApplyCtx &c, uint32_t R)
-{
-    if (c.lh[H_END] != E.log_len) return c.lh[H_N_END];
-    if (c.seq.n == 0) return c.lh[H_N_VISIBLE];
-    if (R == 0) return c.seq.n_end0;
-    return c.seq.n_end0 + (c.rfb - c.rfa);
-}
-
-/* k_apply: apply_committed_entries on every replica in rmask (grid.y).  Blocks
- * 0 .. gridDim.x-2 apply (and compute slices of the per-round commit record); block
- * (gridDim.x-1, 0) is the call's bookkeeper: it fetches everything finish needs while the
- * others work, waits for their arrival tickets, then publishes commit/apply offsets and the
- * R2/R4 doorbell words.  The appliers never wait for it, so the wait cannot deadlock. */
+/* k_apply: apply_committed_entries on every replica in rmask (grid.y).  Block roles along x:
+ *   [0, nA)        appliers (grid.y = replica)
+ *   [nA, nA + nR)  the leader's per-round commit record (y == 0 only)
+ *   nA + nR        the call's bookkeeper (y == 0 only): it fetches everything finish needs
+ *                  while the others work, waits for their arrival tickets, then publishes
+ *                  commit/apply offsets and the R2/R4 doorbell words.
+ * Nobody waits for the bookkeeper, so its wait cannot deadlock.  Every role starts with ONE
+ * load round trip (the context k_sequence left in SeqOut + a few control words). */
 __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint32_t R, uint32_t rmask,
-                                               int mode, uint32_t fmask)
+                                               int mode, uint32_t fmask, uint32_t nR)
 {
     __shared__ unsigned long long s_acc[2];
     __shared__ ApplyCtx c;
     const uint32_t tid = threadIdx.x;
+    const uint32_t nA = gridDim.x - 1 - nR;
     const bool keeper = blockIdx.x == gridDim.x - 1;
-    if (keeper && blockIdx.y != 0) return;
+    const bool recorder = !keeper && blockIdx.x >= nA;
+    if ((keeper || recorder) && blockIdx.y != 0) return;
     int p = -1;
     for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
         if (rmask & (1u << i)) { if (k == (int)blockIdx.y) { p = i; break; } k++; }
@@ -821,11 +815,10 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
     uint64_t *lh = Ld.hdr;
 
     /* ---- context: one round trip ---- */
-    if (tid < 64) c.lh[tid] = lh[tid];
+    if (tid < 64) { if (keeper) c.lh[tid] = lh[tid]; }
     else if (tid < 64 + sizeof(SeqOut) / 8) ((uint64_t *)&c.seq)[tid - 64] = ((const uint64_t *)E.seq)[tid - 64];
     else if (tid == 96) c.rec_base = *E.rec_count;
     else if (tid == 97) c.n_apply_p = (p >= 0) ? E.rep[p].hdr[H_N_APPLY] : 0;
-    else if (tid == 98) { c.rfa = R ? E.round_first[r0] : 0; c.rfb = R ? E.round_first[r0 + R - 1] : 0; }
     else if (keeper && tid >= 128 && tid < 128 + 8 * APUS_DEV_MAX_SERVERS) {
         const uint32_t f = (tid - 128) >> 3, j = (tid - 128) & 7;
         static const int words[8] = {H_N_PERSIST, H_N_COMMIT, H_N_APPLY, H_STORE_COUNT, H_HEAD, H_END, H_N_END, H_HEAD_SLOT};
@@ -833,16 +826,21 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
     }
     __syncthreads();
     const uint64_t L = E.log_len;
-    const uint64_t vis = ctx_visible(E, c, R);
+    const uint64_t vis = c.seq.vis;
     uint64_t cs = min((uint64_t)c.seq.first_fail, vis);
     if (cs < c.seq.n_commit_before) cs = c.seq.n_commit_before;
 
-    if (!keeper) {
+    if (recorder) {
         if (mode == 0)
-            finish_records(E, r0, R, cs, ((uint64_t)blockIdx.y * (gridDim.x - 1) + blockIdx.x) * blockDim.x + tid,
-                           (uint64_t)(gridDim.x - 1) * gridDim.y * blockDim.x, c.seq, c.rec_base);
+            finish_records(E, r0, R, cs, (uint64_t)(blockIdx.x - nA) * blockDim.x + tid, (uint64_t)nR * blockDim.x,
+                           c.seq, c.rec_base);
+        __syncthreads();
+        if (tid == 0) atomicAdd(E.ticket + 1, 1u);
+        return;
+    }
+    if (!keeper) {
         if (p >= 0) apply_range(E, p, c.n_apply_p, cs, (uint64_t)blockIdx.x * blockDim.x,
-                                (uint64_t)(gridDim.x - 1) * blockDim.x, s_acc);
+                                (uint64_t)nA * blockDim.x, s_acc);
         __syncthreads();
         if (tid == 0) atomicAdd(E.ticket + 1, 1u);          /* arrival ticket; no fence needed (see below) */
         return;
@@ -855,7 +853,7 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
     /* wait for every applier: it only consumes words they updated with device-scope atomics
      * (HEAD slot) plus control words nobody else writes, so the ticket needs no fence */
     if (tid == 0) {
-        const unsigned int want = (gridDim.x - 1) * gridDim.y;
+        const unsigned int want = nA * gridDim.y + nR;
         unsigned long long spins = 0;
         while (__hip_atomic_load(E.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             __builtin_amdgcn_s_sleep(2);
