@@ -79,9 +79,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
+    path = os.environ.get("APUS_GPU_LIB") or _build.LIB     # APUS_GPU_LIB: e.g. the -DAPUS_TRACE diagnostics build
     if not os.path.exists(path):
-        if not build_if_missing:
+        if not build_if_missing or path != _build.LIB:
             raise RuntimeError(f"{path} is missing: run python -m apus_amd.build (no CPU fallback exists)")
         _build.build()
     L = C.CDLL(path)

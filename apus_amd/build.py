@@ -32,6 +32,28 @@ def stale() -> bool:
     return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SOURCES + DEPS + _host_c_sources() + [hook])
 
 
+TRACE_LIB = os.path.join(PKG, "libapus_gpu_trace.so")
+
+
+def build_trace(verbose: bool = False) -> str:
+    """Diagnostics build: the same engine with -DAPUS_TRACE (in-kernel wall-clock stamps,
+    apus_gpu_trace()); a separate library, the product library is never instrumented."""
+    objs = []
+    for c in _host_c_sources():
+        o = c[:-2] + ".trace.o"
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=gnu11", "-I", os.path.join(ROOT, "include"), "-c", c, "-o", o])
+        objs.append(o)
+    for src in SOURCES:
+        o = src.rsplit(".", 1)[0] + ".trace.o"
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-DAPUS_TRACE", "-c", src, "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        objs.append(o)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TRACE_LIB] + objs + ["-lpthread"])
+    return TRACE_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
@@ -66,4 +88,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--trace" in sys.argv:
+        print(build_trace(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

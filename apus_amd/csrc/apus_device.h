@@ -92,7 +92,18 @@ struct SeqOut {
      * so that each of them starts with ONE load round trip instead of a chain */
     uint64_t vis;          /* slots visible to followers / committable once the batch is appended */
     uint64_t scan_lo;      /* first slot the persist + ACK pass has to look at                   */
-    uint64_t np[APUS_DEV_MAX_SERVERS];   /* followers' persisted slot count (~0: not pushed to)  */
+    uint64_t np[APUS_DEV_MAX_SERVERS];   /* followers' persisted slot count (~0: nothing left to do) */
+    /* Followers on this device that had persisted everything before the call: their persist + ACK
+     * of the new entries (reply byte in their own ring and in the leader's, ACK bit) is written by
+     * k_append_push together with the entry, in the same 16-byte stores -- no extra HBM traffic. */
+    uint32_t fuse_mask;
+    uint32_t tail_needed;  /* 0: k_persist_commit has nothing to do (every pushed follower fused, quorum reached) */
+    /* 1: every replica on this device is in step (all pushed followers fused, a majority among them,
+     * no commit or apply backlog, the whole batch visible): each new entry is committed the moment
+     * it is written, so k_append_push also produces its apply records (apply_committed_entries) for
+     * the leader and the fused followers, from registers -- k_apply's appliers have nothing to do. */
+    uint32_t fast;
+    uint32_t pad1;
 };
 
 /* engine-wide device state */
@@ -114,11 +125,29 @@ struct EngDev {
     /* per-call scratch */
     SeqOut   *seq;
     uint64_t *round_virt;                 /* [max_rounds + 1] exclusive scan of round bytes */
+    uint64_t *round_hash;                 /* [2 * max_rounds] fast path: per-round apply-stream sums (leader kind, follower kind) */
     /* per-round record of the leader since the last reset */
     uint64_t *rec_end, *rec_commit;
     uint64_t *rec_count;
     uint64_t  rec_cap;
+    uint64_t *trace;                      /* -DAPUS_TRACE builds: [kernel][64] wall-clock stamps; else nullptr */
 };
+
+/* reply[] bytes of an entry (offsets 28..40, MAX_SERVER_COUNT = 13) for the ACK bits in `mask`:
+ * w28 = bytes 28..31 (last word of the second 16-byte unit), x32 / y36 / z40 = words of the third unit */
+struct ReplyWords { uint32_t w28, x32, y36, z40; };
+__host__ __device__ static inline ReplyWords apus_reply_words(uint32_t mask)
+{
+    ReplyWords r = {0, 0, 0, 0};
+    for (uint32_t m = mask & ((1u << APUS_DEV_MAX_SERVERS) - 1); m; m &= m - 1) {
+        const uint32_t f = (uint32_t)__builtin_ctz(m);
+        if (f < 4) r.w28 |= 1u << (8 * f);
+        else if (f < 8) r.x32 |= 1u << (8 * (f - 4));
+        else if (f < 12) r.y36 |= 1u << (8 * (f - 8));
+        else r.z40 |= 1u;
+    }
+    return r;
+}
 
 /* ---- log algebra (dare_log.h:255-283) ----------------------------------- */
 __host__ __device__ static inline uint64_t apus_end_distance(uint64_t end, uint64_t len, uint64_t off)

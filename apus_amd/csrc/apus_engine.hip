@@ -153,7 +153,13 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     if (!rc) rc = dev_alloc(e, &e->d.status, 64);
     if (!rc) e->d.ticket = e->d.status + 8;
     if (!rc) rc = dev_alloc(e, &e->d.seq, sizeof(SeqOut));
+#ifdef APUS_TRACE
+    if (!rc) rc = dev_alloc(e, &e->d.trace, 8 * 16 * 64);
+#else
+    e->d.trace = nullptr;
+#endif
     if (!rc) rc = dev_alloc(e, &e->d.round_virt, sizeof(uint64_t) * (e->max_rounds + 1));
+    if (!rc) rc = dev_alloc(e, &e->d.round_hash, sizeof(uint64_t) * 2 * e->max_rounds);
     if (!rc) rc = dev_alloc(e, &e->d.rec_end, sizeof(uint64_t) * e->d.rec_cap);
     if (!rc) rc = dev_alloc(e, &e->d.rec_commit, sizeof(uint64_t) * e->d.rec_cap);
     if (!rc) rc = dev_alloc(e, &e->d.rec_count, 64);
@@ -1046,3 +1052,14 @@ extern "C" int apus_gpu_follower_commit(apus_engine_t *e, uint32_t replica, uint
     HIPCHK(hipGetLastError());
     return 0;
 }
+
+#ifdef APUS_TRACE
+/* diagnostics build only: copy out the in-kernel stamps ([16 kernels][64] u64) */
+extern "C" int apus_gpu_trace(apus_engine_t *e, uint64_t *out, uint32_t n)
+{
+    if (!e || !out || n > 16 * 64) return APUS_E_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(out, e->d.trace, n * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif

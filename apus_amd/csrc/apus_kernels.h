@@ -40,6 +40,17 @@
 
 #define WAVE 64
 
+/* Diagnostics (python -m apus_amd.build --trace): thread 0 of the calling block drains its
+ * memory queue and records the 100 MHz wall clock; tools/trace_probe.py prints the deltas.
+ * Compiles to nothing in the product library. */
+#ifdef APUS_TRACE
+#define STAMP(K, k) do { if (threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); E.trace[(K) * 64 + (k)] = wall_clock64(); } } while (0)
+#define STAMPW(K, k, T) do { if (threadIdx.x == (T)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); E.trace[(K) * 64 + (k)] = wall_clock64(); } } while (0)
+#else
+#define STAMP(K, k) do { } while (0)
+#define STAMPW(K, k, T) do { } while (0)
+#endif
+
 __device__ static inline uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
 
 /* inclusive scan across the 64 lanes of a wavefront */
@@ -144,7 +155,8 @@ __global__ __launch_bounds__(256) void k_catchup(const EngDev E, uint32_t fmask)
 }
 
 __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32_t type, uint64_t d0, uint64_t d1,
-                                               uint32_t push_mask, uint64_t *s_lh, uint64_t rec_base);
+                                               uint32_t push_mask, uint64_t *s_lh, uint64_t rec_base, uint32_t ack_mask,
+                                               bool apply_now);
 __device__ static inline void sample_apply_offsets(const EngDev &E, const uint64_t *s_lh, uint32_t sample_mask, uint32_t i,
                                                    const uint64_t *staged_apply);
 
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
                                                     uint32_t tick, uint32_t sample_mask)
 {
     __shared__ uint64_t s_lh[64];                      /* the leader's control block, kept current */
-    __shared__ uint64_t s_fw[APUS_DEV_MAX_SERVERS][4]; /* followers: end, n_end, apply, n_persist */
+    __shared__ uint64_t s_fw[APUS_DEV_MAX_SERVERS][5]; /* followers: end, n_end, apply, n_persist, n_apply */
     __shared__ uint64_t s_misc[2];                     /* rec_count, len of the batch's last request */
     __shared__ uint32_t s_head_round;
     __shared__ uint64_t s_tot[16];
@@ -188,7 +200,8 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
 
     /* Everything the block needs from HBM is requested NOW, by different lanes: one round
      * trip instead of a chain of dependent loads later. */
-    uint64_t st0 = 0, st1 = 0, st2 = 0, st3 = ~0ull;
+    STAMP(0, 0);
+    uint64_t st0 = 0, st1 = 0, st2 = 0, st3 = ~0ull, st4 = 0;
     const uint32_t bytes0 = (tid < R) ? rb[tid] : 0;   /* first tile of the scan */
     if (tid < 64) st0 = hdr[tid];
     else if (tid < 64 + APUS_DEV_MAX_SERVERS) {
@@ -196,21 +209,34 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
         if (((push_mask | sample_mask) >> f_) & 1u) {
             const uint64_t *fh_ = E.rep[f_].hdr;
             st0 = fh_[H_END]; st1 = fh_[H_N_END]; st2 = fh_[H_APPLY];
-            if ((push_mask >> f_) & 1u) st3 = fh_[H_N_PERSIST];
+            if ((push_mask >> f_) & 1u) { st3 = fh_[H_N_PERSIST]; st4 = fh_[H_N_APPLY]; }
         }
     } else if (tid == 96) st0 = *E.rec_count;
     else if (tid == 97) st0 = (rf[R] > rf[0]) ? E.req_len[rf[R] - 1] : 0;
     if (tid < 64) s_lh[tid] = st0;
-    else if (tid < 64 + APUS_DEV_MAX_SERVERS) { s_fw[tid - 64][0] = st0; s_fw[tid - 64][1] = st1; s_fw[tid - 64][2] = st2; s_fw[tid - 64][3] = st3; }
+    else if (tid < 64 + APUS_DEV_MAX_SERVERS) { s_fw[tid - 64][0] = st0; s_fw[tid - 64][1] = st1; s_fw[tid - 64][2] = st2; s_fw[tid - 64][3] = st3; s_fw[tid - 64][4] = st4; }
     else if (tid == 96) s_misc[0] = st0;
     else if (tid == 97) s_misc[1] = st0;
     if (tid == 0) { s_rstar = 0xFFFFFFFFu; s_head_round = 0; }
     __syncthreads();
+    STAMP(0, 1);
 
     const uint32_t g0 = rf[0];
     const uint32_t n = rf[R] - g0;
+    uint32_t fuse_mask = 0;
+    bool in_step = false;       /* every replica on the device has persisted, committed and applied everything so far */
     {
         const uint64_t e_pre = s_lh[H_END], n_pre = s_lh[H_N_END];
+        /* pushed followers that have persisted everything so far: they persist + ACK this
+         * call's entries as part of the push itself (SeqOut::fuse_mask) */
+        for (uint32_t m = push_mask; m; m &= m - 1)
+            if (s_fw[__builtin_ctz(m)][3] == n_pre && e_pre != L) fuse_mask |= 1u << __builtin_ctz(m);
+        {
+            const uint32_t size = E.group_size, size_mask = (1u << size) - 1;
+            in_step = fuse_mask == push_mask && (uint32_t)__popc((fuse_mask | (1u << E.leader)) & size_mask) >= size / 2 + 1
+                   && s_lh[H_N_COMMIT] == n_pre && s_lh[H_N_APPLY] == n_pre;
+            for (uint32_t m = push_mask; m; m &= m - 1) in_step = in_step && s_fw[__builtin_ctz(m)][4] == n_pre;
+        }
         /* followers that silently fell behind (hidden exact-fit round) are caught up here */
         bool any_lag = false;
         for (uint32_t m = push_mask; m; m &= m - 1) any_lag |= (s_fw[__builtin_ctz(m)][1] < n_pre) && e_pre != L;
@@ -230,10 +256,11 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
             if (tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS)
                 sample_apply_offsets(E, s_lh, sample_mask, tid - 64, &s_fw[tid - 64][2]);
             __syncthreads();                             /* the sampling lanes read the pre-tick block */
-            if (tid == 0) s_head_round = control_append(E, 1, 3, 0, 0, push_mask, s_lh, s_misc[0]).n;
+            if (tid == 0) s_head_round = control_append(E, 1, 3, 0, 0, push_mask, s_lh, s_misc[0], fuse_mask, in_step).n;
             __syncthreads();
         }
     }
+    STAMP(0, 2);
     const uint32_t head_round = s_head_round;
     const uint64_t e0 = s_lh[H_END];
     const uint64_t n_end0 = s_lh[H_N_END];
@@ -258,6 +285,7 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
     if (tid == 0) { E.round_virt[R] = vtot; if (R <= 1024) s_virt[R] = vtot; }
     __syncthreads();
     const uint32_t rstar = s_rstar;
+    STAMP(0, 3);
 
     if (tid == 0) {
         int64_t kstar = -1, estar = -1;
@@ -302,9 +330,22 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
             const uint64_t end_after = n ? end_new : e0, n_end_after = n_end0 + n;
             s.vis = (end_after != L) ? n_end_after
                   : (n == 0 ? s_lh[H_N_VISIBLE] : n_end0 + (rf[R - 1] - g0));
+            /* a batch whose last round stays hidden (end on len) is not pushed as acknowledged */
+            const uint32_t fuse_batch = (end_after != L) ? fuse_mask : 0u;
+            const uint32_t size = E.group_size, size_mask = (1u << size) - 1;
+            const bool quorum_fused = (uint32_t)__popc((fuse_batch | (1u << E.leader)) & size_mask) >= size / 2 + 1;
             uint64_t lo = s.n_commit_before;
-            for (uint32_t f = 0; f < APUS_DEV_MAX_SERVERS; f++) { s.np[f] = s_fw[f][3]; lo = min(lo, s_fw[f][3]); }
+            for (uint32_t f = 0; f < APUS_DEV_MAX_SERVERS; f++) {
+                uint64_t npf = s_fw[f][3];                              /* ~0 for servers not pushed to */
+                if ((fuse_mask >> f) & 1u) npf = ((fuse_batch >> f) & 1u) ? ~0ull : npf + head_round;
+                s.np[f] = npf;
+                lo = min(lo, npf);
+            }
             s.scan_lo = lo;
+            s.fuse_mask = fuse_batch;
+            s.tail_needed = ((push_mask & ~fuse_batch) != 0 || !quorum_fused || s.n_commit_before < n_end0 - head_round) ? 1u : 0u;
+            s.fast = (in_step && !s.tail_needed && end_after != L && n) ? 1u : 0u;
+            s.pad1 = 0;
         }
         *E.seq = s;
         if (n) {
@@ -323,6 +364,7 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
     }
     __syncthreads();
 
+    STAMP(0, 4);
     /* end offset after every round (the leader's per-round record) */
     const uint64_t rec_base = s_misc[0];
     const int64_t kstar = s_kstar;
@@ -333,6 +375,7 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
         const uint64_t end_r = (kstar < 0 || last < kstar) ? a_end : a_end - w;
         if (rec_base + head_round + r < E.rec_cap) E.rec_end[rec_base + head_round + r] = end_r;
     }
+    STAMP(0, 5);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -348,6 +391,7 @@ struct AppendLds {
     uint4    h0[WAVE];
     uint4    h1[WAVE];
     uint32_t uniform_nu;      /* units per entry when every entry of the round has the same size, else 0 */
+    uint32_t fuse_mask;       /* SeqOut::fuse_mask */
 };
 
 __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask)
@@ -358,6 +402,7 @@ __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0
     const RepDev &Ld = E.rep[E.leader];
     const uint32_t *rf = E.round_first + r0;
     const uint32_t g0 = rf[0];
+    if (r == 0) STAMP(1, 0);
     const uint32_t first = rf[r] - g0, nr = rf[r + 1] - rf[r];
 
     if (tid < WAVE) {
@@ -387,14 +432,40 @@ __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0
         lds.src[lane] = (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
         lds.T[lane] = T;
         lds.ubase[lane] = uincl - nu;
-        if (lane == WAVE - 1) { lds.ubase[WAVE] = uincl; lds.uniform_nu = uni ? (T0 + 15) / 16 : 0; }
+        if (lane == WAVE - 1) { lds.ubase[WAVE] = uincl; lds.uniform_nu = uni ? (T0 + 15) / 16 : 0; lds.fuse_mask = s.fuse_mask; }
         lds.h0[lane] = h0;
         lds.h1[lane] = h1;
+
+        if (s.fast) {
+            /* apply_committed_entries (dare_server.c:1815-1974) for the round, straight from the
+             * registers that built the entries: record + stream hash for the leader (kind 1:
+             * proxy_update_state) and every fused follower (kind 2: proxy_do_action) */
+            const uint32_t len = T - APUS_HDR;
+            uint64_t mix1 = 0, mix2 = 0;
+            if (active) {
+                const uint32_t di = (uint32_t)slot & E.dir_mask;
+                const uint4 r0v = make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32));
+                const uint32_t tail = (uint32_t)d.clt_id | (type << 16);
+                uint4 *rp = (uint4 *)&Ld.apply[di];
+                rp[0] = r0v; rp[1] = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), len, tail | (1u << 24));
+                for (uint32_t m = s.fuse_mask; m; m &= m - 1) {
+                    uint4 *fp = (uint4 *)&E.rep[__builtin_ctz(m)].apply[di];
+                    fp[0] = r0v; fp[1] = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), len, tail | (2u << 24));
+                }
+                mix1 = apus_apply_mix(slot, pos, idx, len, d.clt_id, (uint8_t)type, 1);
+                mix2 = apus_apply_mix(slot, pos, idx, len, d.clt_id, (uint8_t)type, 2);
+            }
+            /* the round's contribution to the stream hashes; k_apply's record blocks fold them
+             * into the control blocks (a thousand workgroups adding to the same words would queue
+             * up in one L2 channel), the upcall counters advance by the batch size there too */
+            const uint64_t sum1 = wave_sum(mix1), sum2 = wave_sum(mix2);
+            if (lane == 0) { E.round_hash[2 * r] = sum1; E.round_hash[2 * r + 1] = sum2; }
+        }
 
         if (active) {
             const uint32_t di = (uint32_t)slot & E.dir_mask;
             const uint32_t dl = T | ((uint32_t)E.leader << 24);     /* derived: total bytes | sender << 24 */
-            Ld.dir_off[di] = pos; Ld.dir_len[di] = dl; Ld.ack[di] = 0;
+            Ld.dir_off[di] = pos; Ld.dir_len[di] = dl; Ld.ack[di] = s.fuse_mask;     /* ACK bits of the fused followers */
             for (uint32_t m = push_mask; m; m &= m - 1) {
                 const RepDev &Fd = E.rep[__builtin_ctz(m)];
                 Fd.dir_off[di] = pos; Fd.dir_len[di] = dl;
@@ -415,8 +486,13 @@ __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0
     }
     __syncthreads();
 
+    if (r == 0) STAMP(1, 1);
     const uint32_t utotal = lds.ubase[WAVE];
     const uint32_t unu = lds.uniform_nu;
+    /* reply bytes that ride with the entry: fused followers persist + ACK as part of the push
+     * (their own byte in their ring, every fused follower's byte in the leader's ring) */
+    const uint32_t fuse = lds.fuse_mask;
+    const ReplyWords rwl = apus_reply_words(fuse);
     for (uint32_t u = tid; u < utotal; u += 256) {
         uint32_t e, j;
         if (unu) { e = u / unu; j = u - e * unu; }
@@ -437,9 +513,20 @@ __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0
         else if (so == 32) v = make_uint4(0, 0, 0, 0);
         else v = payload_unit(E.arena + lds.src[e], so, Te - APUS_HDR, Te - APUS_HDR);
         const uint64_t p = lds.pos[e] + so;
-        st16u(Ld.ring + p, v);
-        for (uint32_t m = push_mask; m; m &= m - 1) st16u(E.rep[__builtin_ctz(m)].ring + p, v);
+        if (fuse && so - 16u <= 16u) {                 /* the two units that hold reply[0..12] */
+            const bool second = so == 16;
+            st16u(Ld.ring + p, second ? make_uint4(v.x, v.y, v.z, rwl.w28) : make_uint4(rwl.x32, rwl.y36, rwl.z40, 0));
+            for (uint32_t m = push_mask; m; m &= m - 1) {
+                const int f = __builtin_ctz(m);
+                const ReplyWords rwf = apus_reply_words(fuse & (1u << f));
+                st16u(E.rep[f].ring + p, second ? make_uint4(v.x, v.y, v.z, rwf.w28) : make_uint4(rwf.x32, rwf.y36, rwf.z40, 0));
+            }
+        } else {
+            st16u(Ld.ring + p, v);
+            for (uint32_t m = push_mask; m; m &= m - 1) st16u(E.rep[__builtin_ctz(m)].ring + p, v);
+        }
     }
+    if (r == 0) STAMP(1, 2);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -501,15 +588,19 @@ __device__ static inline void persist_ack_range(const EngDev &E, int f, uint64_t
 __global__ __launch_bounds__(256) void k_persist_commit(const EngDev E, uint64_t r0, uint32_t R, uint32_t fmask)
 {
     __shared__ uint64_t s_np[APUS_DEV_MAX_SERVERS];
-    __shared__ uint64_t s_c[3];
+    __shared__ uint64_t s_c[4];
     const uint32_t tid = threadIdx.x;
+    if (blockIdx.x == 0) STAMP(4, 0);
     if (tid < APUS_DEV_MAX_SERVERS) s_np[tid] = E.seq->np[tid];
     else if (tid == 16) s_c[0] = E.seq->vis;
     else if (tid == 17) s_c[1] = E.seq->scan_lo;
     else if (tid == 18) s_c[2] = E.seq->n_commit_before;
+    else if (tid == 19) s_c[3] = E.seq->tail_needed;
     __syncthreads();
+    if (!s_c[3]) return;          /* every pushed follower acknowledged with the push and a majority was reached */
     const RepDev &Ld = E.rep[E.leader];
     const uint64_t vis = s_c[0], lo = s_c[1], n_commit = s_c[2];
+    if (blockIdx.x == 0) STAMP(4, 1);
     const uint32_t size = E.group_size, size_mask = (1u << size) - 1, quorum = size / 2 + 1;
     const uint32_t self = 1u << E.leader;
     const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
@@ -519,6 +610,7 @@ __global__ __launch_bounds__(256) void k_persist_commit(const EngDev E, uint64_t
         const uint32_t di = (uint32_t)(in ? s : vis - 1) & E.dir_mask;     /* clamped: the loads are unconditional */
         const uint64_t off = Ld.dir_off[di];
         const uint32_t sender = Ld.dir_len[di] >> 24;                      /* entry->sender, dare_server.c:1806 */
+        if (blockIdx.x == 0) STAMP(4, 2);
         bool ok = true;
         if (in) {
             uint8_t *sring = (sender == E.leader) ? Ld.ring
@@ -545,6 +637,7 @@ __global__ __launch_bounds__(256) void k_persist_commit(const EngDev E, uint64_t
                 __hip_atomic_fetch_or(&Ld.ack[di], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        if (blockIdx.x == 0) STAMP(4, 3);
         const unsigned long long bal = __ballot(!ok);
         if (bal && lane_id() == 0) {
             const uint64_t first = s + (uint64_t)__builtin_ctzll(bal);
@@ -614,6 +707,7 @@ __device__ static inline void apply_range(const EngDev &E, int p, uint64_t from,
             off[k] = Pd.dir_off[di];
             T[k] = Pd.dir_len[di];
         }
+        if (blockIdx.x == 0 && blockIdx.y == 0) STAMP(2, 2);
         uint4 u0[APPLY_ILP], u1[APPLY_ILP];
 #pragma unroll
         for (int k = 0; k < APPLY_ILP; k++) {
@@ -622,6 +716,7 @@ __device__ static inline void apply_range(const EngDev &E, int p, uint64_t from,
         }
 #pragma unroll
         for (int k = 0; k < APPLY_ILP; k++) T[k] &= 0xFFFFFFu;
+        if (blockIdx.x == 0 && blockIdx.y == 0) STAMP(2, 3);
         uint64_t mix = 0;
         uint32_t nclient = 0;
 #pragma unroll
@@ -631,15 +726,17 @@ __device__ static inline void apply_range(const EngDev &E, int p, uint64_t from,
             const uint32_t type = (u1[k].z >> 16) & 0xFF;
             const uint16_t clt = (uint16_t)(u1[k].z & 0xFFFF);
             const uint32_t client = (type != 0 && type != 2 && type != 3);
-            apus_apply_rec rec;
-            rec.slot = sl[k]; rec.off = off[k]; rec.idx = idx; rec.len = T[k] - APUS_HDR;
-            rec.clt_id = clt; rec.type = (uint8_t)type;
-            rec.kind = client ? (leader ? 1 : 2) : 0;
-            Pd.apply[(uint32_t)sl[k] & E.dir_mask] = rec;
-            if (client) { mix += apus_apply_mix(sl[k], off[k], idx, T[k] - APUS_HDR, clt, (uint8_t)type, rec.kind); nclient++; }
+            const uint32_t kind = client ? (leader ? 1u : 2u) : 0u;
+            /* the 32-byte record as two 16-byte stores (field by field it would be four
+             * partial writes per slot): slot, off | idx, len, clt_id | type << 16 | kind << 24 */
+            uint4 *rp = (uint4 *)&Pd.apply[(uint32_t)sl[k] & E.dir_mask];
+            rp[0] = make_uint4((uint32_t)sl[k], (uint32_t)(sl[k] >> 32), (uint32_t)off[k], (uint32_t)(off[k] >> 32));
+            rp[1] = make_uint4(u0[k].x, u0[k].y, T[k] - APUS_HDR, (uint32_t)clt | (type << 16) | (kind << 24));
+            if (client) { mix += apus_apply_mix(sl[k], off[k], idx, T[k] - APUS_HDR, clt, (uint8_t)type, (uint8_t)kind); nclient++; }
             if (type == 3 && !leader)                  /* poll_config_entries: committed HEAD, dare_server.c:2164 */
                 atomicMax((unsigned long long *)&Pd.hdr[H_HEAD_SLOT], (unsigned long long)(sl[k] + 1));
         }
+        if (blockIdx.x == 0 && blockIdx.y == 0) STAMP(2, 4);
         const uint64_t wsum = wave_sum(mix);
         const uint32_t wcnt = wave_sum(nclient);
         if (lane_id() == 0 && wcnt) {
@@ -647,6 +744,7 @@ __device__ static inline void apply_range(const EngDev &E, int p, uint64_t from,
             atomicAdd(&s_acc[1], (unsigned long long)wcnt);
         }
     }
+    if (blockIdx.x == 0 && blockIdx.y == 0) STAMP(2, 5);
     __syncthreads();
     if (threadIdx.x == 0 && s_acc[1]) {
         atomicAdd((unsigned long long *)&Pd.hdr[H_APPLY_HASH], s_acc[0]);
@@ -781,6 +879,10 @@ __device__ static inline void finish_call(const EngDev &E, uint64_t r0, uint32_t
  * last does the call's scalar bookkeeping (finish_call).                          */
 /* what every block of k_apply needs before it can start, fetched in ONE round trip
  * (different lanes load different words) */
+static_assert(sizeof(apus_apply_rec) == 32 && offsetof(apus_apply_rec, idx) == 16 && offsetof(apus_apply_rec, len) == 24 &&
+              offsetof(apus_apply_rec, clt_id) == 28 && offsetof(apus_apply_rec, type) == 30 && offsetof(apus_apply_rec, kind) == 31,
+              "apply_range stores the record as two uint4");
+
 struct ApplyCtx {
     uint64_t lh[64];          /* leader control block (bookkeeper only) */
     SeqOut   seq;
@@ -814,6 +916,10 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
     const RepDev &Ld = E.rep[E.leader];
     uint64_t *lh = Ld.hdr;
 
+    const bool B0 = blockIdx.x == 0 && blockIdx.y == 0;
+    if (B0) STAMP(2, 0);
+    if (keeper) STAMP(3, 0);
+    if (recorder && blockIdx.x == nA) STAMP(5, 0);
     /* ---- context: one round trip ---- */
     if (tid < 64) { if (keeper) c.lh[tid] = lh[tid]; }
     else if (tid < 64 + sizeof(SeqOut) / 8) ((uint64_t *)&c.seq)[tid - 64] = ((const uint64_t *)E.seq)[tid - 64];
@@ -830,18 +936,35 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
     uint64_t cs = min((uint64_t)c.seq.first_fail, vis);
     if (cs < c.seq.n_commit_before) cs = c.seq.n_commit_before;
 
+    if (B0) STAMP(2, 1);
     if (recorder) {
         if (mode == 0)
             finish_records(E, r0, R, cs, (uint64_t)(blockIdx.x - nA) * blockDim.x + tid, (uint64_t)nR * blockDim.x,
                            c.seq, c.rec_base);
+        if (mode == 0 && c.seq.fast) {
+            /* fold the per-round stream sums k_append_push left into the replicas' hashes */
+            uint64_t h1 = 0, h2 = 0;
+            for (uint64_t r = (uint64_t)(blockIdx.x - nA) * blockDim.x + tid; r < R; r += (uint64_t)nR * blockDim.x) {
+                h1 += E.round_hash[2 * r]; h2 += E.round_hash[2 * r + 1];
+            }
+            h1 = wave_sum(h1); h2 = wave_sum(h2);
+            if (lane_id() == 0 && (h1 | h2)) {
+                atomicAdd((unsigned long long *)&lh[H_APPLY_HASH], (unsigned long long)h1);
+                for (uint32_t m = c.seq.fuse_mask; m; m &= m - 1)
+                    atomicAdd((unsigned long long *)&E.rep[__builtin_ctz(m)].hdr[H_APPLY_HASH], (unsigned long long)h2);
+            }
+        }
         __syncthreads();
+        if (blockIdx.x == nA) STAMP(5, 1);
         if (tid == 0) atomicAdd(E.ticket + 1, 1u);
         return;
     }
     if (!keeper) {
-        if (p >= 0) apply_range(E, p, c.n_apply_p, cs, (uint64_t)blockIdx.x * blockDim.x,
-                                (uint64_t)nA * blockDim.x, s_acc);
+        /* in step (SeqOut::fast): k_append_push applied the batch as it wrote it */
+        if (p >= 0 && !c.seq.fast) apply_range(E, p, c.n_apply_p, cs, (uint64_t)blockIdx.x * blockDim.x,
+                                               (uint64_t)nA * blockDim.x, s_acc);
         __syncthreads();
+        if (B0) STAMP(2, 6);
         if (tid == 0) atomicAdd(E.ticket + 1, 1u);          /* arrival ticket; no fence needed (see below) */
         return;
     }
@@ -852,6 +975,7 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
     if (tid == 1) c.off_vis = (vis == n_end_l) ? end_l : Ld.dir_off[(uint32_t)vis & E.dir_mask];
     /* wait for every applier: it only consumes words they updated with device-scope atomics
      * (HEAD slot) plus control words nobody else writes, so the ticket needs no fence */
+    STAMP(3, 1);
     if (tid == 0) {
         const unsigned int want = nA * gridDim.y + nR;
         unsigned long long spins = 0;
@@ -862,6 +986,7 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
         __hip_atomic_store(E.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    STAMP(3, 2);
     const SeqOut &s = c.seq;
     const uint64_t commit_off = (cs > s.n_commit_before) ? c.off_cs : s.commit_before;
     if (tid == 0) {
@@ -875,6 +1000,13 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
         lh[H_N_VISIBLE] = vis;
         if (cs > s.n_commit_before) { lh[H_COMMIT] = commit_off; lh[H_N_COMMIT] = cs; }
         if (cs > c.lh[H_N_APPLY]) { lh[H_APPLY] = c.off_cs; lh[H_N_APPLY] = cs; }
+        if (mode == 0 && s.fast) {
+            /* k_append_push applied the batch (every entry a client entry): one upcall each */
+            atomicAdd((unsigned long long *)&lh[H_APPLY_COUNT], (unsigned long long)s.n);
+            atomicAdd((unsigned long long *)&lh[H_HIGHEST_REC], (unsigned long long)s.n);
+            for (uint32_t m = s.fuse_mask; m; m &= m - 1)
+                atomicAdd((unsigned long long *)&E.rep[__builtin_ctz(m)].hdr[H_APPLY_COUNT], (unsigned long long)s.n);
+        }
     }
     /* followers: R2 end doorbell, persist bookkeeping, R4 lazy commit, apply, HEAD adoption */
     if (tid >= 1 && tid <= APUS_DEV_MAX_SERVERS) {
@@ -902,6 +1034,7 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
             }
         }
     }
+    STAMP(3, 3);
 }
 
 /* READ the apply offset of peer i for the next prune tick (rc_get_remote_apply_offsets,
@@ -924,7 +1057,8 @@ __device__ static inline void sample_apply_offsets(const EngDev &E, const uint64
  *           whether the head moves and append <HEAD, head> if so
  * s_lh is an LDS copy of the leader's control block; returns the call's SeqOut. */
 __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32_t type, uint64_t d0, uint64_t d1,
-                                               uint32_t push_mask, uint64_t *s_lh, uint64_t rec_base)
+                                               uint32_t push_mask, uint64_t *s_lh, uint64_t rec_base, uint32_t ack_mask,
+                                               bool apply_now)
 {
     const RepDev &Ld = E.rep[E.leader];
     uint64_t *hdr = Ld.hdr;
@@ -948,6 +1082,8 @@ __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32
     s.e0 = end; s.idx0 = s_lh[H_LAST_IDX] + 1; s.w = 0; s.n_end0 = s_lh[H_N_END];
     s.term = s_lh[H_SID] >> 9; s.kstar = -1; s.estar = -1; s.stale = 0; s.n = 0; s.head_round = 0;
     s.first_fail = ~0ull; s.commit_before = s_lh[H_COMMIT]; s.n_commit_before = s_lh[H_N_COMMIT];
+    s.vis = 0; s.scan_lo = 0; s.fuse_mask = 0; s.tail_needed = 1; s.fast = 0; s.pad1 = 0;
+    for (uint32_t f = 0; f < APUS_DEV_MAX_SERVERS; f++) s.np[f] = ~0ull;
     if (do_append && end == head && end != L) { set_status(E, 1u << 1); do_append = false; }
     if (do_append) {
         const uint64_t idx = (end == L) ? 1 : s_lh[H_LAST_IDX] + 1;         /* dare_log.h:486-488 */
@@ -959,15 +1095,26 @@ __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32
         const uint32_t di = (uint32_t)slot & E.dir_mask;
         const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)term, (uint32_t)(term >> 32));
         const uint4 h1 = make_uint4(0, 0, (type << 16) | ((uint32_t)E.leader << 24), 0);  /* req_id = clt_id = 0 */
-        const uint4 h2 = make_uint4(0, 0, 0, 0);
         const uint4 h3 = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
         for (uint32_t m = push_mask | (1u << E.leader); m; m &= m - 1) {
             const int t = __builtin_ctz(m);
             uint8_t *rg = E.rep[t].ring;
-            st16u(rg + pos, h0); st16u(rg + pos + 16, h1); st16u(rg + pos + 32, h2); st16u(rg + pos + 48, h3);
+            /* followers in ack_mask persist + ACK with the push: own reply byte in their ring, all of them in the leader's */
+            const ReplyWords rw = apus_reply_words((uint32_t)t == E.leader ? ack_mask : (ack_mask & (1u << t)));
+            st16u(rg + pos, h0); st16u(rg + pos + 16, make_uint4(h1.x, h1.y, h1.z, rw.w28));
+            st16u(rg + pos + 32, make_uint4(rw.x32, rw.y36, rw.z40, 0)); st16u(rg + pos + 48, h3);
             E.rep[t].dir_off[di] = pos; E.rep[t].dir_len[di] = APUS_HDR | ((uint32_t)E.leader << 24);
+            if (apply_now) {
+                /* everybody is in step: the entry is committed as it lands, the replicas apply it
+                 * right away (a control entry: no upcall; a follower notes a committed <HEAD>) */
+                uint4 *rp = (uint4 *)&E.rep[t].apply[di];
+                rp[0] = make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32));
+                rp[1] = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), 0, type << 16);
+                if (type == 3 && (uint32_t)t != E.leader)
+                    atomicMax((unsigned long long *)&E.rep[t].hdr[H_HEAD_SLOT], (unsigned long long)(slot + 1));
+            }
         }
-        __hip_atomic_store(&Ld.ack[di], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&Ld.ack[di], ack_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         hdr[H_TAIL] = pos;               s_lh[H_TAIL] = pos;
         hdr[H_END] = pos + APUS_HDR;     s_lh[H_END] = pos + APUS_HDR;
         hdr[H_N_END] = slot + 1;         s_lh[H_N_END] = slot + 1;
@@ -1020,7 +1167,7 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode,
     __shared__ uint64_t s_lh[64];
     if (tid < 64) s_lh[tid] = hdr[tid];
     __syncthreads();
-    if (tid == 0) *E.seq = control_append(E, mode, type, d0, d1, push_mask, s_lh, *E.rec_count);
+    if (tid == 0) *E.seq = control_append(E, mode, type, d0, d1, push_mask, s_lh, *E.rec_count, 0, false);
     if (mode == 1 && tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS) sample_apply_offsets(E, s_lh, sample_mask, tid - 64, nullptr);
     __syncthreads();
 

@@ -1,5 +1,8 @@
-import sys, ctypes as C, numpy as np
+"""In-kernel timing probe.  Build the diagnostics library first (python -m apus_amd.build --trace),
+then: APUS_GPU_LIB=apus_amd/libapus_gpu_trace.so python tools/trace_probe.py"""
+import os, sys, ctypes as C, numpy as np
 sys.path.insert(0, '.')
+os.environ.setdefault('APUS_GPU_LIB', os.path.join('apus_amd', 'libapus_gpu_trace.so'))
 from apus_amd import trace as T
 from apus_amd.engine import Engine
 tr = T.config_c2()
@@ -20,11 +23,18 @@ for rep in range(2):
 eng.sync()
 L = eng.L
 L.apus_gpu_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
-buf = np.zeros(64 * 8, dtype=np.uint64)
+buf = np.zeros(64 * 16, dtype=np.uint64)
 L.apus_gpu_trace(eng.h, buf.ctypes.data, len(buf))
-names = {0: "k_sequence", 2: "k_apply b00", 4: "k_persist_commit b0"}
+names = {0: "k_sequence", 1: "k_append_push b0", 4: "k_persist_commit b0", 2: "k_apply applier(0,0)", 5: "k_apply recorder", 3: "k_apply keeper"}
 base = int(buf[0])
-for k in (0, 2, 4):
+base2 = int(buf[2*64])
+for w, k in ((0, 2), (1, 6), (3, 7)):
+    idx = [0, 1, 9, 10] if k == 2 else [0, 1, 2, 3]
+    print("  applier wave", w, "abs us:", [round((int(buf[k*64+i]) - base2) / 100.0, 2) for i in idx])
+print("  wave1: pre-barrier, post-barrier, +dir_mask, +rep[p] abs us:", [round((int(buf[6*64+i]) - base2) / 100.0, 2) for i in (8, 9, 10, 11)])
+for k in (0, 1, 4, 2, 5, 3):
     row = buf[k * 64:k * 64 + 8].astype(np.int64)
+    if k == 2: print("   applier probes:", [round((int(b) - int(a)) / 100.0, 2) for a, b in zip(buf[k*64+10:k*64+13], buf[k*64+11:k*64+14])], "barrier+setup:", round((int(buf[k*64+10]) - int(buf[k*64+1])) / 100.0, 2))
     st = [int(v) for v in row if v]
-    print(names[k], "start@%.2f" % ((st[0] - base) / 100.0), "deltas(us):", [round((b - a) / 100.0, 2) for a, b in zip(st, st[1:])])
+    if not st: continue
+    print("%-22s" % names[k], "start@%.2f" % ((st[0] - base) / 100.0), "deltas(us):", [round((b - a) / 100.0, 2) for a, b in zip(st, st[1:])])
