@@ -104,6 +104,7 @@ struct SeqOut {
      * the leader and the fused followers, from registers -- k_apply's appliers have nothing to do. */
     uint32_t fast;
     uint32_t pad1;
+    uint64_t rec_base;     /* *rec_count when the call started (index of its first per-round record) */
 };
 
 /* engine-wide device state */
@@ -115,7 +116,8 @@ struct EngDev {
     uint32_t dir_mask;                    /* dir_cap - 1 */
     uint64_t log_len;
     uint32_t *status;
-    uint32_t *ticket;                     /* [1]: arrival counter of k_apply's blocks */
+    uint32_t *ticket;                     /* [8] arrival counters (k_apply: [1]; k_round: scan [3], done [4]) */
+    uint32_t *tick_lines;                 /* [32 lines x 32 words] k_round's append arrivals, spread over 32 cache lines */
     /* staged requests */
     const ReqDev   *req;
     const uint16_t *req_len;

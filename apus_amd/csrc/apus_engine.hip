@@ -152,6 +152,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->d.rec_cap = 1ull << 22;
     if (!rc) rc = dev_alloc(e, &e->d.status, 64);
     if (!rc) e->d.ticket = e->d.status + 8;
+    if (!rc) rc = dev_alloc(e, &e->d.tick_lines, sizeof(uint32_t) * 32 * 32);
     if (!rc) rc = dev_alloc(e, &e->d.seq, sizeof(SeqOut));
 #ifdef APUS_TRACE
     if (!rc) rc = dev_alloc(e, &e->d.trace, 8 * 16 * 64);
@@ -364,10 +365,14 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
         tl = &e->timed[e->timed_used++];
         HIPCHK(hipEventRecord(tl->a, e->stream));
     }
-    hipLaunchKernelGGL(k_append_push, dim3(R), dim3(256), 0, e->stream, e->d, r0, R, fm);
+    /* everything after the sequencer in one launch: append + push, persist + ACK scan, apply,
+     * per-round records, bookkeeping (k_round's block roles) */
+    const uint32_t rm = fm | ((e->local_mask >> e->d.leader) & 1u ? (1u << e->d.leader) : 0);
+    const uint32_t nS = cap_grid(n, 256, 128), nA = cap_grid(n, 1024, 64), nR = cap_grid(R, 256, 8);
+    hipLaunchKernelGGL(k_round, dim3(R + nS + nA * popc(rm) + nR + 1), dim3(256), 0, e->stream, e->d, r0, R, fm, rm, nS, nA, nR);
     if (tl) HIPCHK(hipEventRecord(tl->b, e->stream));
     HIPCHK(hipGetLastError());
-    return launch_tail(e, r0, R, 0, n);
+    return 0;
 }
 
 /* ---- live submission: what the proxy's DARE thread does every polling() pass ---- */

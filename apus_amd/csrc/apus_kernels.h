@@ -51,6 +51,9 @@
 #define STAMPW(K, k, T) do { } while (0)
 #endif
 
+/* E.ticket words */
+enum { T_APPLY = 1, T_SCAN = 3, T_DONE = 4 };
+
 __device__ static inline uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
 
 /* inclusive scan across the 64 lanes of a wavefront */
@@ -218,6 +221,9 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
     else if (tid == 96) s_misc[0] = st0;
     else if (tid == 97) s_misc[1] = st0;
     if (tid == 0) { s_rstar = 0xFFFFFFFFu; s_head_round = 0; }
+    /* arrival counters of the k_round launch that follows (the previous one is long done) */
+    if (tid >= 128 && tid < 160) E.tick_lines[(tid - 128) * 32] = 0;
+    else if (tid == 160) { E.ticket[T_SCAN] = 0; E.ticket[T_DONE] = 0; }
     __syncthreads();
     STAMP(0, 1);
 
@@ -346,6 +352,7 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
             s.tail_needed = ((push_mask & ~fuse_batch) != 0 || !quorum_fused || s.n_commit_before < n_end0 - head_round) ? 1u : 0u;
             s.fast = (in_step && !s.tail_needed && end_after != L && n) ? 1u : 0u;
             s.pad1 = 0;
+            s.rec_base = s_misc[0];
         }
         *E.seq = s;
         if (n) {
@@ -392,13 +399,13 @@ struct AppendLds {
     uint4    h1[WAVE];
     uint32_t uniform_nu;      /* units per entry when every entry of the round has the same size, else 0 */
     uint32_t fuse_mask;       /* SeqOut::fuse_mask */
+    uint32_t fast;            /* SeqOut::fast */
 };
 
-__global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask)
+__device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t r,
+                                           AppendLds &lds)
 {
-    __shared__ AppendLds lds;
     const uint32_t tid = threadIdx.x, lane = lane_id();
-    const uint32_t r = blockIdx.x;
     const RepDev &Ld = E.rep[E.leader];
     const uint32_t *rf = E.round_first + r0;
     const uint32_t g0 = rf[0];
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0
         lds.src[lane] = (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
         lds.T[lane] = T;
         lds.ubase[lane] = uincl - nu;
-        if (lane == WAVE - 1) { lds.ubase[WAVE] = uincl; lds.uniform_nu = uni ? (T0 + 15) / 16 : 0; lds.fuse_mask = s.fuse_mask; }
+        if (lane == WAVE - 1) { lds.ubase[WAVE] = uincl; lds.uniform_nu = uni ? (T0 + 15) / 16 : 0; lds.fuse_mask = s.fuse_mask; lds.fast = s.fast; }
         lds.h0[lane] = h0;
         lds.h1[lane] = h1;
 
@@ -459,7 +466,10 @@ __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0
              * into the control blocks (a thousand workgroups adding to the same words would queue
              * up in one L2 channel), the upcall counters advance by the batch size there too */
             const uint64_t sum1 = wave_sum(mix1), sum2 = wave_sum(mix2);
-            if (lane == 0) { E.round_hash[2 * r] = sum1; E.round_hash[2 * r + 1] = sum2; }
+            if (lane == 0) {     /* write-through: a record block of the same launch may read them (k_round) */
+                __hip_atomic_store(&E.round_hash[2 * r], sum1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&E.round_hash[2 * r + 1], sum2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
 
         if (active) {
@@ -529,6 +539,12 @@ __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0
     if (r == 0) STAMP(1, 2);
 }
 
+__global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask)
+{
+    __shared__ AppendLds lds;
+    append_round(E, r0, R, push_mask, blockIdx.x, lds);
+}
+
 /* ------------------------------------------------------------------------- */
 /* the slot up to which the batch is visible to followers / committable: when
  * the leader's end sits exactly on len the log reads as empty (dare_log.h:158)
@@ -585,12 +601,11 @@ __device__ static inline void persist_ack_range(const EngDev &E, int f, uint64_t
  * one for the slot's directory entry, then only stores.  Followers in the mask hold the
  * same entries at the same offsets as the leader (that is what R1 pushed), so the lane
  * reads the leader's directory entry once instead of one copy per follower.        */
-__global__ __launch_bounds__(256) void k_persist_commit(const EngDev E, uint64_t r0, uint32_t R, uint32_t fmask)
+__device__ static inline void persist_commit_blocks(const EngDev &E, uint32_t fmask, uint32_t blk, uint32_t nblk,
+                                                    uint64_t *s_np /*[APUS_DEV_MAX_SERVERS]*/, uint64_t *s_c /*[4]*/)
 {
-    __shared__ uint64_t s_np[APUS_DEV_MAX_SERVERS];
-    __shared__ uint64_t s_c[4];
     const uint32_t tid = threadIdx.x;
-    if (blockIdx.x == 0) STAMP(4, 0);
+    if (blk == 0) STAMP(4, 0);
     if (tid < APUS_DEV_MAX_SERVERS) s_np[tid] = E.seq->np[tid];
     else if (tid == 16) s_c[0] = E.seq->vis;
     else if (tid == 17) s_c[1] = E.seq->scan_lo;
@@ -600,17 +615,17 @@ __global__ __launch_bounds__(256) void k_persist_commit(const EngDev E, uint64_t
     if (!s_c[3]) return;          /* every pushed follower acknowledged with the push and a majority was reached */
     const RepDev &Ld = E.rep[E.leader];
     const uint64_t vis = s_c[0], lo = s_c[1], n_commit = s_c[2];
-    if (blockIdx.x == 0) STAMP(4, 1);
+    if (blk == 0) STAMP(4, 1);
     const uint32_t size = E.group_size, size_mask = (1u << size) - 1, quorum = size / 2 + 1;
     const uint32_t self = 1u << E.leader;
-    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t tile = lo + (uint64_t)blockIdx.x * blockDim.x; tile < vis; tile += nth) {
+    const uint64_t nth = (uint64_t)nblk * blockDim.x;
+    for (uint64_t tile = lo + (uint64_t)blk * blockDim.x; tile < vis; tile += nth) {
         const uint64_t s = tile + tid;
         const bool in = s < vis;
         const uint32_t di = (uint32_t)(in ? s : vis - 1) & E.dir_mask;     /* clamped: the loads are unconditional */
         const uint64_t off = Ld.dir_off[di];
         const uint32_t sender = Ld.dir_len[di] >> 24;                      /* entry->sender, dare_server.c:1806 */
-        if (blockIdx.x == 0) STAMP(4, 2);
+        if (blk == 0) STAMP(4, 2);
         bool ok = true;
         if (in) {
             uint8_t *sring = (sender == E.leader) ? Ld.ring
@@ -637,13 +652,20 @@ __global__ __launch_bounds__(256) void k_persist_commit(const EngDev E, uint64_t
                 __hip_atomic_fetch_or(&Ld.ack[di], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (blockIdx.x == 0) STAMP(4, 3);
+        if (blk == 0) STAMP(4, 3);
         const unsigned long long bal = __ballot(!ok);
         if (bal && lane_id() == 0) {
             const uint64_t first = s + (uint64_t)__builtin_ctzll(bal);
             atomicMin((unsigned long long *)&E.seq->first_fail, (unsigned long long)first);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_persist_commit(const EngDev E, uint64_t r0, uint32_t R, uint32_t fmask)
+{
+    __shared__ uint64_t s_np[APUS_DEV_MAX_SERVERS];
+    __shared__ uint64_t s_c[4];
+    persist_commit_blocks(E, fmask, blockIdx.x, gridDim.x, s_np, s_c);
 }
 
 /* The ACK scan of update_remote_logs (dare_ibv_rc.c:1725-1758) over slots
@@ -892,6 +914,162 @@ struct ApplyCtx {
 };
 static_assert(sizeof(SeqOut) / 8 <= 32, "k_apply stages SeqOut with lanes 64..95");
 
+/* what a block of the call's tail needs before it can start, fetched in ONE round trip
+ * (different lanes load different words); p = replica an applier works on, -1 otherwise */
+__device__ static inline void stage_apply_ctx(const EngDev &E, ApplyCtx &c, int p, bool keeper, uint32_t fmask)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint64_t *lh = E.rep[E.leader].hdr;
+    if (tid < 64) { if (keeper) c.lh[tid] = lh[tid]; }
+    else if (tid < 64 + sizeof(SeqOut) / 8) ((uint64_t *)&c.seq)[tid - 64] = ((const uint64_t *)E.seq)[tid - 64];
+    else if (tid == 97) c.n_apply_p = (p >= 0) ? E.rep[p].hdr[H_N_APPLY] : 0;
+    else if (keeper && tid >= 128 && tid < 128 + 8 * APUS_DEV_MAX_SERVERS) {
+        const uint32_t f = (tid - 128) >> 3, j = (tid - 128) & 7;
+        static const int words[8] = {H_N_PERSIST, H_N_COMMIT, H_N_APPLY, H_STORE_COUNT, H_HEAD, H_END, H_N_END, H_HEAD_SLOT};
+        c.fw[f][j] = ((fmask >> f) & 1u) ? E.rep[f].hdr[words[j]] : 0;
+    }
+    __syncthreads();
+    if (tid == 0) c.rec_base = c.seq.rec_base;      /* k_sequence noted it; the bookkeeper advances *rec_count */
+    __syncthreads();
+}
+
+__device__ static inline uint64_t ctx_commit_slot(const ApplyCtx &c)
+{
+    uint64_t cs = min((uint64_t)c.seq.first_fail, c.seq.vis);
+    if (cs < c.seq.n_commit_before) cs = c.seq.n_commit_before;
+    return cs;
+}
+
+/* fast path: the per-round stream sums k_append_push left, folded into the replicas' hashes */
+__device__ static inline void fold_round_hashes(const EngDev &E, uint32_t R, uint32_t blk, uint32_t nblk, uint32_t fuse_mask)
+{
+    uint64_t h1 = 0, h2 = 0;
+    for (uint64_t r = (uint64_t)blk * blockDim.x + threadIdx.x; r < R; r += (uint64_t)nblk * blockDim.x) {
+        h1 += E.round_hash[2 * r]; h2 += E.round_hash[2 * r + 1];
+    }
+    h1 = wave_sum(h1); h2 = wave_sum(h2);
+    if (lane_id() == 0 && (h1 | h2)) {
+        atomicAdd((unsigned long long *)&E.rep[E.leader].hdr[H_APPLY_HASH], (unsigned long long)h1);
+        for (uint32_t m = fuse_mask; m; m &= m - 1)
+            atomicAdd((unsigned long long *)&E.rep[__builtin_ctz(m)].hdr[H_APPLY_HASH], (unsigned long long)h2);
+    }
+}
+
+/* record blocks: the leader's per-round commit record, and (fast path) the per-round stream
+ * sums k_append_push left folded into the replicas' hashes; blk of nblk, all threads */
+__device__ static inline void recorder_body(const EngDev &E, uint64_t r0, uint32_t R, int mode, uint64_t cs,
+                                            uint32_t blk, uint32_t nblk, const ApplyCtx &c)
+{
+    const uint32_t tid = threadIdx.x;
+    if (mode == 0)
+        finish_records(E, r0, R, cs, (uint64_t)blk * blockDim.x + tid, (uint64_t)nblk * blockDim.x, c.seq, c.rec_base);
+    if (mode == 0 && c.seq.fast) fold_round_hashes(E, R, blk, nblk, c.seq.fuse_mask);
+}
+
+/* the bookkeeper, once everybody else is done: per-call counters, the leader's commit / apply
+ * offsets (update_remote_logs :1744-1758), and for every follower the R2 end doorbell, persist
+ * bookkeeping, R4 lazy commit, apply offset and HEAD adoption.  c.off_cs / c.off_vis are set. */
+__device__ static inline void keeper_publish(const EngDev &E, const ApplyCtx &c, uint32_t R, int mode, uint32_t fmask,
+                                             uint64_t vis, uint64_t cs)
+{
+    const uint32_t tid = threadIdx.x;
+    uint64_t *lh = E.rep[E.leader].hdr;
+    const uint64_t L = E.log_len;
+    const uint64_t end_l = c.lh[H_END];
+    const SeqOut &s = c.seq;
+    const uint64_t commit_off = (cs > s.n_commit_before) ? c.off_cs : s.commit_before;
+    if (tid == 0) {
+        if (mode == 0) {
+            *E.rec_count = c.rec_base + R + s.head_round;
+        } else if (mode == 1 && s.n) {
+            if (c.rec_base < E.rec_cap) E.rec_commit[c.rec_base] = (end_l == L) ? s.commit_before : commit_off;
+            *E.rec_count = c.rec_base + 1;
+        }
+        lh[H_N_VISIBLE] = vis;
+        if (cs > s.n_commit_before) { lh[H_COMMIT] = commit_off; lh[H_N_COMMIT] = cs; }
+        if (cs > c.lh[H_N_APPLY]) { lh[H_APPLY] = c.off_cs; lh[H_N_APPLY] = cs; }
+        if (mode == 0 && s.fast) {
+            /* k_append_push applied the batch (every entry a client entry): one upcall each */
+            atomicAdd((unsigned long long *)&lh[H_APPLY_COUNT], (unsigned long long)s.n);
+            atomicAdd((unsigned long long *)&lh[H_HIGHEST_REC], (unsigned long long)s.n);
+            for (uint32_t m = s.fuse_mask; m; m &= m - 1)
+                atomicAdd((unsigned long long *)&E.rep[__builtin_ctz(m)].hdr[H_APPLY_COUNT], (unsigned long long)s.n);
+        }
+    }
+    if (tid >= 1 && tid <= APUS_DEV_MAX_SERVERS) {
+        const int f = (int)tid - 1;
+        if ((fmask >> f) & 1u) {
+            uint64_t *fh = E.rep[f].hdr;
+            const uint64_t f_np = c.fw[f][0], f_nc = c.fw[f][1], f_na = c.fw[f][2], f_sc = c.fw[f][3];
+            const uint64_t f_head = c.fw[f][4], f_end = c.fw[f][5];
+            /* the appliers of this call may have raised the HEAD slot: read it now */
+            const uint64_t hs = __hip_atomic_load((unsigned long long *)&fh[H_HEAD_SLOT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint64_t end_now = f_end;
+            if (vis > f_np) {
+                fh[H_STORE_COUNT] = f_sc + (vis - f_np);
+                fh[H_END] = c.off_vis; fh[H_OLD_END] = c.off_vis;
+                fh[H_N_END] = vis; fh[H_N_PERSIST] = vis;
+                end_now = c.off_vis;
+            }
+            if (cs > f_nc) { fh[H_COMMIT] = c.off_cs; fh[H_N_COMMIT] = cs; }
+            if (cs > f_na) { fh[H_APPLY] = c.off_cs; fh[H_N_APPLY] = cs; }
+            if (hs) {
+                const uint64_t hoff = E.rep[f].dir_off[(uint32_t)(hs - 1) & E.dir_mask];
+                const uint64_t hv = ld8u(E.rep[f].ring + hoff + 48);
+                if (apus_is_larger(end_now, L, hv, f_head)) fh[H_HEAD] = hv;
+                fh[H_HEAD_SLOT] = 0;
+            }
+        }
+    }
+}
+
+/* thread 0 spins until ticket `which` reaches `want` (bounded), then the whole block passes an
+ * agent-scope acquire: what the ticketing blocks released is visible to plain loads */
+__device__ static inline void wait_ticket(const EngDev &E, int which, uint32_t want)
+{
+    if (threadIdx.x == 0) {
+        unsigned long long spins = 0;
+        while (__hip_atomic_load(E.ticket + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1ull << 22)) { set_status(E, 1u << 4); break; }     /* bounded */
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+/* the append blocks' arrivals are spread over 32 counters in 32 cache lines (a thousand
+ * workgroups finishing together would queue up on one word): lane i < 32 waits for counter i */
+__device__ static inline void wait_append(const EngDev &E, uint32_t R)
+{
+    if (threadIdx.x < 32) {
+        const uint32_t quota = R / 32 + (threadIdx.x < (R & 31u) ? 1u : 0u);
+        unsigned long long spins = 0;
+        while (__hip_atomic_load(E.tick_lines + threadIdx.x * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < quota) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1ull << 22)) { set_status(E, 1u << 4); break; }     /* bounded */
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ static inline void post_append(const EngDev &E, uint32_t b, bool release)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(E.tick_lines + (b & 31u) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+/* all of the block's stores are done (barrier), optionally released to the device, then the ticket */
+__device__ static inline void post_ticket(const EngDev &E, int which, bool release)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(E.ticket + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 /* k_apply: apply_committed_entries on every replica in rmask (grid.y).  Block roles along x:
  *   [0, nA)        appliers (grid.y = replica)
  *   [nA, nA + nR)  the leader's per-round commit record (y == 0 only)
@@ -914,49 +1092,21 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
     for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
         if (rmask & (1u << i)) { if (k == (int)blockIdx.y) { p = i; break; } k++; }
     const RepDev &Ld = E.rep[E.leader];
-    uint64_t *lh = Ld.hdr;
 
     const bool B0 = blockIdx.x == 0 && blockIdx.y == 0;
     if (B0) STAMP(2, 0);
     if (keeper) STAMP(3, 0);
     if (recorder && blockIdx.x == nA) STAMP(5, 0);
-    /* ---- context: one round trip ---- */
-    if (tid < 64) { if (keeper) c.lh[tid] = lh[tid]; }
-    else if (tid < 64 + sizeof(SeqOut) / 8) ((uint64_t *)&c.seq)[tid - 64] = ((const uint64_t *)E.seq)[tid - 64];
-    else if (tid == 96) c.rec_base = *E.rec_count;
-    else if (tid == 97) c.n_apply_p = (p >= 0) ? E.rep[p].hdr[H_N_APPLY] : 0;
-    else if (keeper && tid >= 128 && tid < 128 + 8 * APUS_DEV_MAX_SERVERS) {
-        const uint32_t f = (tid - 128) >> 3, j = (tid - 128) & 7;
-        static const int words[8] = {H_N_PERSIST, H_N_COMMIT, H_N_APPLY, H_STORE_COUNT, H_HEAD, H_END, H_N_END, H_HEAD_SLOT};
-        c.fw[f][j] = ((fmask >> f) & 1u) ? E.rep[f].hdr[words[j]] : 0;
-    }
-    __syncthreads();
-    const uint64_t L = E.log_len;
+    stage_apply_ctx(E, c, p, keeper, fmask);
     const uint64_t vis = c.seq.vis;
-    uint64_t cs = min((uint64_t)c.seq.first_fail, vis);
-    if (cs < c.seq.n_commit_before) cs = c.seq.n_commit_before;
+    const uint64_t cs = ctx_commit_slot(c);
 
     if (B0) STAMP(2, 1);
     if (recorder) {
-        if (mode == 0)
-            finish_records(E, r0, R, cs, (uint64_t)(blockIdx.x - nA) * blockDim.x + tid, (uint64_t)nR * blockDim.x,
-                           c.seq, c.rec_base);
-        if (mode == 0 && c.seq.fast) {
-            /* fold the per-round stream sums k_append_push left into the replicas' hashes */
-            uint64_t h1 = 0, h2 = 0;
-            for (uint64_t r = (uint64_t)(blockIdx.x - nA) * blockDim.x + tid; r < R; r += (uint64_t)nR * blockDim.x) {
-                h1 += E.round_hash[2 * r]; h2 += E.round_hash[2 * r + 1];
-            }
-            h1 = wave_sum(h1); h2 = wave_sum(h2);
-            if (lane_id() == 0 && (h1 | h2)) {
-                atomicAdd((unsigned long long *)&lh[H_APPLY_HASH], (unsigned long long)h1);
-                for (uint32_t m = c.seq.fuse_mask; m; m &= m - 1)
-                    atomicAdd((unsigned long long *)&E.rep[__builtin_ctz(m)].hdr[H_APPLY_HASH], (unsigned long long)h2);
-            }
-        }
+        recorder_body(E, r0, R, mode, cs, blockIdx.x - nA, nR, c);
         __syncthreads();
         if (blockIdx.x == nA) STAMP(5, 1);
-        if (tid == 0) atomicAdd(E.ticket + 1, 1u);
+        if (tid == 0) atomicAdd(E.ticket + T_APPLY, 1u);
         return;
     }
     if (!keeper) {
@@ -965,7 +1115,7 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
                                                (uint64_t)nA * blockDim.x, s_acc);
         __syncthreads();
         if (B0) STAMP(2, 6);
-        if (tid == 0) atomicAdd(E.ticket + 1, 1u);          /* arrival ticket; no fence needed (see below) */
+        if (tid == 0) atomicAdd(E.ticket + T_APPLY, 1u);    /* arrival ticket; no fence needed (see below) */
         return;
     }
 
@@ -979,61 +1129,127 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
     if (tid == 0) {
         const unsigned int want = nA * gridDim.y + nR;
         unsigned long long spins = 0;
-        while (__hip_atomic_load(E.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        while (__hip_atomic_load(E.ticket + T_APPLY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             __builtin_amdgcn_s_sleep(2);
             if (++spins > (1ull << 24)) { set_status(E, 1u << 4); break; }     /* bounded */
         }
-        __hip_atomic_store(E.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(E.ticket + T_APPLY, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     STAMP(3, 2);
-    const SeqOut &s = c.seq;
-    const uint64_t commit_off = (cs > s.n_commit_before) ? c.off_cs : s.commit_before;
-    if (tid == 0) {
-        if (mode == 0) {
-            *E.rec_count = c.rec_base + R + s.head_round;
-        } else if (mode == 1 && s.n) {
-            if (c.rec_base < E.rec_cap) E.rec_commit[c.rec_base] = (end_l == L) ? s.commit_before : commit_off;
-            *E.rec_count = c.rec_base + 1;
-        }
-        /* leader: commit, apply (update_remote_logs :1744-1758, apply_committed_entries) */
-        lh[H_N_VISIBLE] = vis;
-        if (cs > s.n_commit_before) { lh[H_COMMIT] = commit_off; lh[H_N_COMMIT] = cs; }
-        if (cs > c.lh[H_N_APPLY]) { lh[H_APPLY] = c.off_cs; lh[H_N_APPLY] = cs; }
-        if (mode == 0 && s.fast) {
-            /* k_append_push applied the batch (every entry a client entry): one upcall each */
-            atomicAdd((unsigned long long *)&lh[H_APPLY_COUNT], (unsigned long long)s.n);
-            atomicAdd((unsigned long long *)&lh[H_HIGHEST_REC], (unsigned long long)s.n);
-            for (uint32_t m = s.fuse_mask; m; m &= m - 1)
-                atomicAdd((unsigned long long *)&E.rep[__builtin_ctz(m)].hdr[H_APPLY_COUNT], (unsigned long long)s.n);
-        }
+    keeper_publish(E, c, R, mode, fmask, vis, cs);
+    STAMP(3, 3);
+}
+
+/* k_round: everything of a call that follows the sequencer, in ONE launch -- the blocks take
+ * roles by index and hand over through arrival tickets (E.ticket) instead of kernel boundaries:
+ *   [0, R)                    one round each: append + push (+ fused persist/ACK, + apply when in step)
+ *   [R, R + nS)               follower persist + ACK + quorum scan (k_persist_commit's body); idle
+ *                             unless SeqOut::tail_needed; they wait for the append blocks
+ *   [.., + nA * replicas)     apply_committed_entries per replica; idle when in step (SeqOut::fast),
+ *                             else they wait for the scan
+ *   [.., + nR)                the leader's per-round commit record (+ fast-path hash fold)
+ *   last                      the bookkeeper
+ * A block only ever waits for blocks with a LOWER index; workgroups are dispatched in index order,
+ * so everything a waiting block needs is already running or done -- no co-residency assumption.
+ * Data that crosses blocks inside the launch is released (L2 write-back, agent scope) by the
+ * producer before its ticket and acquired by the consumer after it; on the fast path nothing
+ * but tickets and the per-round hash words crosses, and the append blocks skip the release. */
+__global__ __launch_bounds__(256) void k_round(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask,
+                                               uint32_t rmask, uint32_t nS, uint32_t nA, uint32_t nR)
+{
+    __shared__ union RoundLds {
+        AppendLds app;
+        struct { ApplyCtx c; unsigned long long acc[2]; uint64_t np[APUS_DEV_MAX_SERVERS]; uint64_t sc[4]; } t;
+    } l;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    const uint32_t ny = (uint32_t)__popc(rmask);
+    const uint32_t fmask = push_mask;
+
+    if (b < R) {                                               /* ---- append + push ---- */
+        if (b == R - 1) STAMP(6, 0);
+        append_round(E, r0, R, push_mask, b, l.app);
+        if (b == R - 1) STAMP(6, 1);
+        /* in step, the only data a later role reads are the round's hash words (written through);
+         * otherwise the scan and apply blocks read the entries: release them before the ticket */
+        post_append(E, b, l.app.fast == 0);                    /* .fast was written before append_round's barrier */
+        if (b == R - 1) STAMP(6, 2);
+        return;
     }
-    /* followers: R2 end doorbell, persist bookkeeping, R4 lazy commit, apply, HEAD adoption */
-    if (tid >= 1 && tid <= APUS_DEV_MAX_SERVERS) {
-        const int f = (int)tid - 1;
-        if ((fmask >> f) & 1u) {
-            uint64_t *fh = E.rep[f].hdr;
-            const uint64_t f_np = c.fw[f][0], f_nc = c.fw[f][1], f_na = c.fw[f][2], f_sc = c.fw[f][3];
-            const uint64_t f_head = c.fw[f][4], f_end = c.fw[f][5];
-            /* the appliers of this launch may have raised the HEAD slot: read it now */
-            const uint64_t hs = __hip_atomic_load((unsigned long long *)&fh[H_HEAD_SLOT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint64_t end_now = f_end;
-            if (vis > f_np) {
-                fh[H_STORE_COUNT] = f_sc + (vis - f_np);
-                fh[H_END] = c.off_vis; fh[H_OLD_END] = c.off_vis;
-                fh[H_N_END] = vis; fh[H_N_PERSIST] = vis;
-                end_now = c.off_vis;
-            }
-            if (cs > f_nc) { fh[H_COMMIT] = c.off_cs; fh[H_N_COMMIT] = cs; }
-            if (cs > f_na) { fh[H_APPLY] = c.off_cs; fh[H_N_APPLY] = cs; }
-            if (hs) {
-                const uint64_t hoff = E.rep[f].dir_off[(uint32_t)(hs - 1) & E.dir_mask];
-                const uint64_t hv = ld8u(E.rep[f].ring + hoff + 48);
-                if (apus_is_larger(end_now, L, hv, f_head)) fh[H_HEAD] = hv;
-                fh[H_HEAD_SLOT] = 0;
-            }
+    uint32_t q = b - R;
+    ApplyCtx &c = l.t.c;
+    if (q < nS) {                                              /* ---- persist + ACK + quorum scan ---- */
+        if (tid == 0) l.t.sc[3] = E.seq->tail_needed;
+        __syncthreads();
+        if (l.t.sc[3]) {
+            wait_append(E, R);
+            persist_commit_blocks(E, fmask, q, nS, l.t.np, l.t.sc);
         }
+        post_ticket(E, T_SCAN, l.t.sc[3] != 0);
+        return;
     }
+    q -= nS;
+    if (q < nA * ny) {                                         /* ---- apply ---- */
+        const uint32_t y = q / nA, x = q - y * nA;
+        int p = -1;
+        for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
+            if (rmask & (1u << i)) { if (k == (int)y) { p = i; break; } k++; }
+        if (tid == 0) l.t.sc[3] = E.seq->fast;
+        __syncthreads();
+        if (!l.t.sc[3]) {
+            wait_ticket(E, T_SCAN, nS);                        /* first_fail is final, the entries are visible */
+            stage_apply_ctx(E, c, p, false, fmask);
+            if (p >= 0) apply_range(E, p, c.n_apply_p, ctx_commit_slot(c), (uint64_t)x * blockDim.x,
+                                    (uint64_t)nA * blockDim.x, l.t.acc);
+        }
+        post_ticket(E, T_DONE, false);                         /* records and atomics only; visible at kernel end */
+        return;
+    }
+    q -= nA * ny;
+    if (q < nR) {                                              /* ---- per-round records ---- */
+        if (q == 0) STAMP(5, 0);
+        stage_apply_ctx(E, c, -1, false, fmask);               /* nothing here changes during the launch ... */
+        if (q == 0) STAMP(5, 1);
+        if (c.seq.fast) {
+            /* in step: the commit slot is known (everything visible commits), only the rounds'
+             * hash words have to be waited for */
+            finish_records(E, r0, R, c.seq.vis, (uint64_t)q * blockDim.x + tid, (uint64_t)nR * blockDim.x, c.seq, c.rec_base);
+            if (q == 0) STAMP(5, 2);
+            wait_append(E, R);
+            if (q == 0) STAMP(5, 3);
+            fold_round_hashes(E, R, q, nR, c.seq.fuse_mask);
+            if (q == 0) STAMP(5, 4);
+            return;
+        }
+        wait_append(E, R);
+        wait_ticket(E, T_SCAN, nS);
+        if (tid == 0)                                          /* ... except the scan's result */
+            c.seq.first_fail = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        recorder_body(E, r0, R, 0, ctx_commit_slot(c), q, nR, c);
+        post_ticket(E, T_DONE, false);
+        return;
+    }
+    /* ---- the bookkeeper ---- */
+    STAMP(3, 0);
+    stage_apply_ctx(E, c, -1, true, fmask);
+    STAMP(3, 1);
+    if (!c.seq.fast) {
+        wait_ticket(E, T_DONE, nA * ny + nR);
+        if (tid == 0)
+            c.seq.first_fail = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
+    /* in step nothing the bookkeeper writes is read by another block of this launch and the
+     * commit slot is known, so it publishes right away */
+    STAMP(3, 2);
+    const uint64_t vis = c.seq.vis, cs = ctx_commit_slot(c);
+    const uint64_t end_l = c.lh[H_END], n_end_l = c.lh[H_N_END];
+    if (tid == 0) c.off_cs = (cs == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)cs & E.dir_mask];
+    if (tid == 1) c.off_vis = (vis == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)vis & E.dir_mask];
+    __syncthreads();
+    keeper_publish(E, c, R, 0, fmask, vis, cs);
     STAMP(3, 3);
 }
 
@@ -1082,7 +1298,7 @@ __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32
     s.e0 = end; s.idx0 = s_lh[H_LAST_IDX] + 1; s.w = 0; s.n_end0 = s_lh[H_N_END];
     s.term = s_lh[H_SID] >> 9; s.kstar = -1; s.estar = -1; s.stale = 0; s.n = 0; s.head_round = 0;
     s.first_fail = ~0ull; s.commit_before = s_lh[H_COMMIT]; s.n_commit_before = s_lh[H_N_COMMIT];
-    s.vis = 0; s.scan_lo = 0; s.fuse_mask = 0; s.tail_needed = 1; s.fast = 0; s.pad1 = 0;
+    s.vis = 0; s.scan_lo = 0; s.fuse_mask = 0; s.tail_needed = 1; s.fast = 0; s.pad1 = 0; s.rec_base = rec_base;
     for (uint32_t f = 0; f < APUS_DEV_MAX_SERVERS; f++) s.np[f] = ~0ull;
     if (do_append && end == head && end != L) { set_status(E, 1u << 1); do_append = false; }
     if (do_append) {
@@ -1263,5 +1479,5 @@ __global__ void k_reset(const EngDev E)
     h[H_LEN] = E.log_len; h[H_END] = E.log_len; h[H_TAIL] = E.log_len; h[H_OLD_END] = E.log_len;
     h[H_SID] = (uint64_t)p;
     h[H_CID_BITMASK] = (1u << E.group_size) - 1;
-    if (p == 0) { *E.rec_count = 0; *E.status = 0; E.ticket[0] = 0; E.ticket[1] = 0; }
+    if (p == 0) { *E.rec_count = 0; *E.status = 0; for (int i = 0; i < 8; i++) E.ticket[i] = 0; }
 }

@@ -25,16 +25,11 @@ L = eng.L
 L.apus_gpu_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 buf = np.zeros(64 * 16, dtype=np.uint64)
 L.apus_gpu_trace(eng.h, buf.ctypes.data, len(buf))
-names = {0: "k_sequence", 1: "k_append_push b0", 4: "k_persist_commit b0", 2: "k_apply applier(0,0)", 5: "k_apply recorder", 3: "k_apply keeper"}
+names = {0: "k_sequence", 1: "append block 0", 6: "append block R-1", 4: "scan block 0", 2: "applier 0", 5: "recorder 0", 3: "keeper"}
 base = int(buf[0])
-base2 = int(buf[2*64])
-for w, k in ((0, 2), (1, 6), (3, 7)):
-    idx = [0, 1, 9, 10] if k == 2 else [0, 1, 2, 3]
-    print("  applier wave", w, "abs us:", [round((int(buf[k*64+i]) - base2) / 100.0, 2) for i in idx])
-print("  wave1: pre-barrier, post-barrier, +dir_mask, +rep[p] abs us:", [round((int(buf[6*64+i]) - base2) / 100.0, 2) for i in (8, 9, 10, 11)])
-for k in (0, 1, 4, 2, 5, 3):
+for k in (0, 1, 6, 4, 2, 5, 3):
     row = buf[k * 64:k * 64 + 8].astype(np.int64)
-    if k == 2: print("   applier probes:", [round((int(b) - int(a)) / 100.0, 2) for a, b in zip(buf[k*64+10:k*64+13], buf[k*64+11:k*64+14])], "barrier+setup:", round((int(buf[k*64+10]) - int(buf[k*64+1])) / 100.0, 2))
+    if False: print("   applier probes:", [round((int(b) - int(a)) / 100.0, 2) for a, b in zip(buf[k*64+10:k*64+13], buf[k*64+11:k*64+14])], "barrier+setup:", round((int(buf[k*64+10]) - int(buf[k*64+1])) / 100.0, 2))
     st = [int(v) for v in row if v]
     if not st: continue
     print("%-22s" % names[k], "start@%.2f" % ((st[0] - base) / 100.0), "deltas(us):", [round((b - a) / 100.0, 2) for a, b in zip(st, st[1:])])
