@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/apus_gpu.h"
 #include "apus_kernels.h"
@@ -342,35 +343,42 @@ static int launch_append(apus_engine *e, const EngDev &view, uint64_t r0, uint32
     return 0;
 }
 
+/* k_call sequences up to this many rounds per launch (their prefix stays in LDS) */
+#define APUS_CALL_ROUNDS 1024u
+
 extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rounds)
 {
     int rc = need_leader(e);
     if (rc) return rc;
     if (r0 + n_rounds > e->n_rounds_staged || n_rounds > e->max_rounds) return APUS_E_ARG;
     if (n_rounds == 0) return 0;
-    const uint32_t R = (uint32_t)n_rounds;
-    const uint64_t n = e->h_round_first[r0 + R] - e->h_round_first[r0];
     const uint32_t fm = sync_mask(e);
-    if ((rc = launch_catchup(e))) return rc;
-    const uint32_t tick = e->tick_pending ? 1u : 0u;
-    e->tick_pending = false;
-    hipLaunchKernelGGL(k_sequence, dim3(1), dim3(1024), 0, e->stream, e->d, r0, R, fm, tick, fm);
-    TimedLaunch *tl = nullptr;
-    if (e->timing && !e->capturing) {
-        if (e->timed_used == e->timed.size()) {
-            TimedLaunch t;
-            HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b));
-            e->timed.push_back(t);
-        }
-        tl = &e->timed[e->timed_used++];
-        HIPCHK(hipEventRecord(tl->a, e->stream));
-    }
-    /* everything after the sequencer in one launch: append + push, persist + ACK scan, apply,
-     * per-round records, bookkeeping (k_round's block roles) */
     const uint32_t rm = fm | ((e->local_mask >> e->d.leader) & 1u ? (1u << e->d.leader) : 0);
-    const uint32_t nS = cap_grid(n, 256, 128), nA = cap_grid(n, 1024, 64), nR = cap_grid(R, 256, 8);
-    hipLaunchKernelGGL(k_round, dim3(R + nS + nA * popc(rm) + nR + 1), dim3(256), 0, e->stream, e->d, r0, R, fm, rm, nS, nA, nR);
-    if (tl) HIPCHK(hipEventRecord(tl->b, e->stream));
+    if ((rc = launch_catchup(e))) return rc;
+    for (uint64_t done = 0; done < n_rounds; done += APUS_CALL_ROUNDS) {
+        const uint64_t c0 = r0 + done;
+        const uint32_t R = (uint32_t)std::min<uint64_t>(APUS_CALL_ROUNDS, n_rounds - done);
+        const uint64_t n = e->h_round_first[c0 + R] - e->h_round_first[c0];
+        const uint32_t tick = e->tick_pending ? 1u : 0u;
+        e->tick_pending = false;
+        TimedLaunch *tl = nullptr;
+        if (e->timing && !e->capturing) {
+            if (e->timed_used == e->timed.size()) {
+                TimedLaunch t;
+                HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b));
+                e->timed.push_back(t);
+            }
+            tl = &e->timed[e->timed_used++];
+            HIPCHK(hipEventRecord(tl->a, e->stream));
+        }
+        /* the whole call in one launch: sequencer + bookkeeper, append + push, persist + ACK scan,
+         * apply, per-round records (k_call's block roles) */
+        /* the scan / apply blocks only work when the replicas are not in step: a modest number, grid-stride */
+        const uint32_t nS = cap_grid(n, 256, 32), nA = cap_grid(n, 1024, 16), nR = cap_grid(R, 256, 8);
+        hipLaunchKernelGGL(k_call, dim3(1 + R + nS + nA * popc(rm) + nR), dim3(256), 0, e->stream, e->d, c0, R, fm, tick, rm,
+                           nS, nA, nR);
+        if (tl) HIPCHK(hipEventRecord(tl->b, e->stream));
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -52,7 +52,7 @@
 #endif
 
 /* E.ticket words */
-enum { T_APPLY = 1, T_SCAN = 3, T_DONE = 4 };
+enum { T_APPLY = 1, T_PASS = 2, T_SCAN = 3, T_DONE = 4 };
 
 __device__ static inline uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
 
@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256) void k_catchup(const EngDev E, uint32_t fmask)
                   (uint64_t)gridDim.x * blockDim.x);
 }
 
+template <bool FX>
 __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32_t type, uint64_t d0, uint64_t d1,
                                                uint32_t push_mask, uint64_t *s_lh, uint64_t rec_base, uint32_t ack_mask,
                                                bool apply_now);
@@ -183,29 +184,47 @@ __device__ static inline uint64_t block_incl_scan(uint64_t v, uint64_t *s_tot /*
  * scan over the rounds' byte totals (staged with the batch: the admission side knows every
  * request's size, so a round arrives with its total), the wrap point, the leader's
  * control words and the per-round end record.                                  */
-__global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask,
-                                                    uint32_t tick, uint32_t sample_mask)
+struct SeqLds {
+    uint64_t lh[64];                      /* the leader's control block, kept current */
+    uint64_t fw[APUS_DEV_MAX_SERVERS][5]; /* followers: end, n_end, apply, n_persist, n_apply */
+    uint64_t misc[2];                     /* rec_count, len of the batch's last request */
+    uint64_t tot[16];
+    uint64_t w;
+    int64_t  kstar;
+    uint32_t head_round;
+    unsigned int rstar;
+    uint64_t virt[1025];                  /* exclusive scan of the round totals when R <= 1024 */
+    uint32_t bytes0[1024];                /* byte totals of the first 1024 rounds */
+    uint64_t virt_rstar;                  /* exclusive prefix of the round that crosses len */
+    uint64_t my_virt;                     /* FX = false: where round my_r starts */
+    SeqOut   out;                         /* FX = false: the call's SeqOut */
+};
+
+/* The sequencer, for one workgroup of 256 .. 1024 threads, in two steps.
+ * seq_stage: everything it needs from HBM, requested by different lanes in one round trip.
+ * seq_body<FX>: FX = true is the sequencer proper (control words, SeqOut, round_virt, the
+ * per-round end record, a due prune tick's <HEAD> entry, catch-up of lagging followers).
+ * FX = false computes the same SeqOut from the same inputs with NO store to HBM: in k_call every
+ * append block does that for itself instead of waiting for the sequencer block (q.out, and
+ * q.my_virt = where round my_r starts). */
+__device__ static inline void seq_stage(const EngDev &E, uint64_t r0, uint32_t R, uint32_t push_mask,
+                                        uint32_t sample_mask, SeqLds &q)
 {
-    __shared__ uint64_t s_lh[64];                      /* the leader's control block, kept current */
-    __shared__ uint64_t s_fw[APUS_DEV_MAX_SERVERS][5]; /* followers: end, n_end, apply, n_persist, n_apply */
-    __shared__ uint64_t s_misc[2];                     /* rec_count, len of the batch's last request */
-    __shared__ uint32_t s_head_round;
-    __shared__ uint64_t s_tot[16];
-    __shared__ unsigned int s_rstar;
-    __shared__ int64_t s_kstar;
-    __shared__ uint64_t s_w;
+    uint64_t (&s_lh)[64] = q.lh;
+    uint64_t (&s_fw)[APUS_DEV_MAX_SERVERS][5] = q.fw;
+    uint64_t (&s_misc)[2] = q.misc;
+    uint32_t &s_head_round = q.head_round;
+    unsigned int &s_rstar = q.rstar;
     const uint32_t tid = threadIdx.x;
-    const RepDev &Ld = E.rep[E.leader];
-    uint64_t *hdr = Ld.hdr;
-    const uint64_t L = E.log_len;
+    const uint64_t *hdr = E.rep[E.leader].hdr;
     const uint32_t *rf = E.round_first + r0;
     const uint32_t *rb = E.round_bytes + r0;
 
     /* Everything the block needs from HBM is requested NOW, by different lanes: one round
      * trip instead of a chain of dependent loads later. */
-    STAMP(0, 0);
+    if (blockIdx.x == 0) STAMP(0, 0);
     uint64_t st0 = 0, st1 = 0, st2 = 0, st3 = ~0ull, st4 = 0;
-    const uint32_t bytes0 = (tid < R) ? rb[tid] : 0;   /* first tile of the scan */
+    for (uint32_t i = tid; i < R && i < 1024; i += blockDim.x) q.bytes0[i] = rb[i];   /* the rounds' byte totals */
     if (tid < 64) st0 = hdr[tid];
     else if (tid < 64 + APUS_DEV_MAX_SERVERS) {
         const uint32_t f_ = tid - 64;
@@ -221,11 +240,30 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
     else if (tid == 96) s_misc[0] = st0;
     else if (tid == 97) s_misc[1] = st0;
     if (tid == 0) { s_rstar = 0xFFFFFFFFu; s_head_round = 0; }
-    /* arrival counters of the k_round launch that follows (the previous one is long done) */
-    if (tid >= 128 && tid < 160) E.tick_lines[(tid - 128) * 32] = 0;
-    else if (tid == 160) { E.ticket[T_SCAN] = 0; E.ticket[T_DONE] = 0; }
     __syncthreads();
-    STAMP(0, 1);
+    if (blockIdx.x == 0) STAMP(0, 1);
+}
+
+template <bool FX>
+__device__ static inline void seq_body(const EngDev &E, uint64_t r0, uint32_t R, uint32_t push_mask,
+                                       uint32_t tick, uint32_t sample_mask, SeqLds &q, uint32_t my_r, bool write_rec = true)
+{
+    uint64_t (&s_lh)[64] = q.lh;
+    uint64_t (&s_fw)[APUS_DEV_MAX_SERVERS][5] = q.fw;
+    uint64_t (&s_misc)[2] = q.misc;
+    uint32_t &s_head_round = q.head_round;
+    uint64_t (&s_tot)[16] = q.tot;
+    unsigned int &s_rstar = q.rstar;
+    int64_t &s_kstar = q.kstar;
+    uint64_t &s_w = q.w;
+    uint64_t (&s_virt)[1025] = q.virt;
+    const uint32_t BD = blockDim.x;
+    const uint32_t tid = threadIdx.x;
+    const RepDev &Ld = E.rep[E.leader];
+    uint64_t *hdr = Ld.hdr;
+    const uint64_t L = E.log_len;
+    const uint32_t *rf = E.round_first + r0;
+    const uint32_t *rb = E.round_bytes + r0;
 
     const uint32_t g0 = rf[0];
     const uint32_t n = rf[R] - g0;
@@ -246,7 +284,7 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
         /* followers that silently fell behind (hidden exact-fit round) are caught up here */
         bool any_lag = false;
         for (uint32_t m = push_mask; m; m &= m - 1) any_lag |= (s_fw[__builtin_ctz(m)][1] < n_pre) && e_pre != L;
-        if (any_lag) {
+        if (FX && any_lag) {
             for (uint32_t m = push_mask; m; m &= m - 1) catchup_range(E, __builtin_ctz(m), e_pre, n_pre, tid, blockDim.x);
             __syncthreads();
             if (tid == 0)
@@ -259,46 +297,49 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
          * polling() passes): decision + <HEAD> entry happen here, its persist / ACK / commit /
          * apply ride with the batch's own tail kernels */
         if (tick) {
-            if (tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS)
+            if (FX && tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS)
                 sample_apply_offsets(E, s_lh, sample_mask, tid - 64, &s_fw[tid - 64][2]);
             __syncthreads();                             /* the sampling lanes read the pre-tick block */
-            if (tid == 0) s_head_round = control_append(E, 1, 3, 0, 0, push_mask, s_lh, s_misc[0], fuse_mask, in_step).n;
+            if (tid == 0) s_head_round = control_append<FX>(E, 1, 3, 0, 0, push_mask, s_lh, s_misc[0], fuse_mask, in_step).n;
             __syncthreads();
         }
     }
-    STAMP(0, 2);
+    if (blockIdx.x == 0) STAMP(0, 2);
     const uint32_t head_round = s_head_round;
     const uint64_t e0 = s_lh[H_END];
     const uint64_t n_end0 = s_lh[H_N_END];
 
-    /* exclusive scan of the round sums; up to 1024 rounds stay in LDS for the passes below */
-    __shared__ uint64_t s_virt[1025];
-    uint64_t carry = 0;
-    for (uint32_t base = 0; base < R; base += 1024) {
-        const uint32_t r = base + tid;
-        const uint64_t bytes = base ? ((r < R) ? rb[r] : 0) : bytes0;
-        uint64_t tot;
-        const uint64_t incl = block_incl_scan(bytes, s_tot, &tot);
-        if (r < R) {
-            const uint64_t v = carry + incl - bytes;
-            E.round_virt[r] = v;
+    /* exclusive scan of the round totals: every thread takes a run of consecutive rounds, one
+     * block scan over the runs; up to 1024 rounds stay in LDS for the passes below */
+    const uint32_t per = (R + BD - 1) / BD;
+    const uint32_t r_lo = min(R, tid * per), r_hi = min(R, r_lo + per);
+    uint64_t run = 0;
+    for (uint32_t r = r_lo; r < r_hi; r++) run += (r < 1024) ? q.bytes0[r] : rb[r];
+    uint64_t vtot;
+    {
+        const uint64_t incl = block_incl_scan(run, s_tot, &vtot);
+        uint64_t v = incl - run;
+        for (uint32_t r = r_lo; r < r_hi; r++) {
+            const uint64_t bytes = (r < 1024) ? q.bytes0[r] : rb[r];
+            if (FX) E.round_virt[r] = v;
             if (R <= 1024) s_virt[r] = v;
-            if (e0 + carry + incl > L) atomicMin(&s_rstar, r);   /* first round that does not fit before len */
+            if (!FX && r == my_r) q.my_virt = v;
+            /* the first round that does not fit before len (the totals are positive: exactly one) */
+            if (e0 + v + bytes > L && e0 + v <= L) { s_rstar = r; q.virt_rstar = v; }
+            v += bytes;
         }
-        carry += tot;
     }
-    const uint64_t vtot = carry;
-    if (tid == 0) { E.round_virt[R] = vtot; if (R <= 1024) s_virt[R] = vtot; }
+    if (tid == 0) { if (FX) E.round_virt[R] = vtot; if (R <= 1024) s_virt[R] = vtot; }
     __syncthreads();
     const uint32_t rstar = s_rstar;
-    STAMP(0, 3);
+    if (blockIdx.x == 0) STAMP(0, 3);
 
     if (tid == 0) {
         int64_t kstar = -1, estar = -1;
         uint64_t w = 0;
         uint32_t stale = 0;
         if (rstar < R) {
-            uint64_t a = e0 + (R <= 1024 ? s_virt[rstar] : E.round_virt[rstar]);
+            uint64_t a = e0 + q.virt_rstar;
             for (uint32_t g = rf[rstar]; g < rf[rstar + 1]; g++) {
                 const uint64_t T = APUS_HDR + E.req_len[g];
                 if (a + T > L) {
@@ -312,14 +353,14 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
             }
         }
         const uint64_t end_new = (kstar < 0) ? e0 + vtot : e0 + vtot - w;
-        if (kstar >= 0 && end_new > L) set_status(E, 1u << 0);      /* second wrap */
+        if (FX && kstar >= 0 && end_new > L) set_status(E, 1u << 0);      /* second wrap */
         /* free space: the reference only notices end == head exactly (dare_log.h:168) */
         {
             const uint64_t head = s_lh[H_HEAD];
             const uint64_t used = (e0 == L) ? 0 : (e0 >= head ? e0 - head : L - (head - e0));
             const uint64_t waste = (kstar >= 0) ? L - w : 0;
-            if (n && e0 != L && vtot + waste >= L - used) set_status(E, 1u << 1);
-            if (n && e0 == L && vtot > L) set_status(E, 1u << 1);
+            if (FX && n && e0 != L && vtot + waste >= L - used) set_status(E, 1u << 1);
+            if (FX && n && e0 == L && vtot > L) set_status(E, 1u << 1);
         }
         const uint64_t idx0 = s_lh[H_LAST_IDX] + 1;
         SeqOut s;
@@ -354,8 +395,9 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
             s.pad1 = 0;
             s.rec_base = s_misc[0];
         }
-        *E.seq = s;
-        if (n) {
+        q.out = s;
+        if (FX) *E.seq = s;
+        if (FX && n) {
             const uint64_t t_last = APUS_HDR + s_misc[1];
             hdr[H_END] = end_new;
             hdr[H_TAIL] = end_new - t_last;
@@ -371,18 +413,27 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
     }
     __syncthreads();
 
-    STAMP(0, 4);
+    if (blockIdx.x == 0) STAMP(0, 4);
+    if (!FX || !write_rec) return;
     /* end offset after every round (the leader's per-round record) */
     const uint64_t rec_base = s_misc[0];
     const int64_t kstar = s_kstar;
     const uint64_t w = s_w;
-    for (uint32_t r = tid; r < R; r += 1024) {
+    for (uint32_t r = tid; r < R; r += BD) {
         const uint64_t a_end = e0 + (R <= 1024 ? s_virt[r + 1] : E.round_virt[r + 1]);
         const int64_t last = (int64_t)(rf[r + 1] - g0) - 1;   /* batch index of the round's last entry */
         const uint64_t end_r = (kstar < 0 || last < kstar) ? a_end : a_end - w;
         if (rec_base + head_round + r < E.rec_cap) E.rec_end[rec_base + head_round + r] = end_r;
     }
-    STAMP(0, 5);
+    if (blockIdx.x == 0) STAMP(0, 5);
+}
+
+__global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask,
+                                                    uint32_t tick, uint32_t sample_mask)
+{
+    __shared__ SeqLds q;
+    seq_stage(E, r0, R, push_mask, sample_mask, q);
+    seq_body<true>(E, r0, R, push_mask, tick, sample_mask, q, 0);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -402,8 +453,45 @@ struct AppendLds {
     uint32_t fast;            /* SeqOut::fast */
 };
 
+/* which entry of the round owns 16-byte unit u, and which of its units it is */
+__device__ static inline void locate_unit(const AppendLds &lds, uint32_t u, uint32_t unu, uint32_t nr, uint32_t &e, uint32_t &j)
+{
+    if (unu) { e = u / unu; j = u - e * unu; return; }
+    uint32_t lo = 0, hi = nr - 1;                       /* largest e with ubase[e] <= u */
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (lds.ubase[mid] <= u) lo = mid; else hi = mid - 1;
+    }
+    e = lo; j = u - lds.ubase[e];
+}
+
+/* the sequencer of the same launch (k_call) has published SeqOut / round_virt: its flag is
+ * replicated on 32 cache lines (word 1 of every tick line) so that a thousand pollers do not
+ * queue up on one word; then an agent-scope acquire for the whole block */
+__device__ static inline uint32_t wait_sequenced(const EngDev &E, uint32_t b, uint32_t *s_flag)
+{
+    if (threadIdx.x == 0) {
+        unsigned long long spins = 0;
+        uint32_t f;
+        while ((f = __hip_atomic_load(E.tick_lines + (b & 31u) * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1ull << 22)) { set_status(E, 1u << 4); f = 1; break; }     /* bounded */
+        }
+        *s_flag = f;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return *s_flag;
+}
+
+/* One round by one workgroup of 256.  Everything that does not depend on the sequencer's
+ * result -- the request descriptors, sizes, unit layout, and the first payload units -- is
+ * fetched first; with IN_LAUNCH the block then waits for the sequencer block of the same launch
+ * (k_call), so that fetch overlaps the sequencing.  Then: positions, indices, header words,
+ * directory, (in step) the apply records, and the stores. */
+template <bool IN_LAUNCH>
 __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t r,
-                                           AppendLds &lds)
+                                           AppendLds &lds, SeqLds *sq, uint32_t tick)
 {
     const uint32_t tid = threadIdx.x, lane = lane_id();
     const RepDev &Ld = E.rep[E.leader];
@@ -412,34 +500,72 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
     if (r == 0) STAMP(1, 0);
     const uint32_t first = rf[r] - g0, nr = rf[r + 1] - rf[r];
 
+    /* ---- phase 1 (wave 0): descriptors, sizes, unit layout ---- */
+    const bool active = lane < nr;
+    ReqDev d; d.req_id = 0; d.pay16_type = 0; d.len = 0; d.clt_id = 0;
+    uint32_t T = 0;
+    uint64_t incl = 0;
+    if (tid < WAVE && active) d = E.req[g0 + first + lane];
+    if (IN_LAUNCH) {
+        /* the sequencer's inputs, in the same round trip as the descriptors; once they are in LDS
+         * the sequencer block may start changing the control words (it waits for these tickets) */
+        seq_stage(E, r0, R, push_mask, push_mask, *sq);
+        if (r == 0) STAMP(1, 3);
+        if (tid == 0) __hip_atomic_fetch_add(E.tick_lines + (r & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (tid < WAVE) {
-        const SeqOut s = *E.seq;
-        const bool active = lane < nr;
-        const uint32_t g = g0 + first + lane;
-        ReqDev d; d.req_id = 0; d.pay16_type = 0; d.len = 0; d.clt_id = 0;
-        if (active) d = E.req[g];
-        const uint32_t T = active ? APUS_HDR + d.len : 0;
-        const uint64_t incl = wave_incl_scan((uint64_t)T);
-        const uint64_t a = s.e0 + E.round_virt[r] + incl - T;
+        T = active ? APUS_HDR + d.len : 0;
+        incl = wave_incl_scan((uint64_t)T);
+        const uint32_t nu = active ? (T + 15) / 16 : 0;
+        const uint32_t uincl = wave_incl_scan(nu);
+        const uint32_t T0 = __shfl(T, 0, WAVE);
+        const bool uni = __all(!active || T == T0);
+        lds.src[lane] = (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
+        lds.T[lane] = T;
+        lds.ubase[lane] = uincl - nu;
+        if (lane == WAVE - 1) { lds.ubase[WAVE] = uincl; lds.uniform_nu = uni ? (T0 + 15) / 16 : 0; }
+    }
+    __syncthreads();
+
+    /* ---- phase 2 (all): the first payload units into registers ---- */
+    const uint32_t utotal = lds.ubase[WAVE];
+    const uint32_t unu = lds.uniform_nu;
+    constexpr int PF = 2;
+    uint4 pv[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        pv[k] = make_uint4(0, 0, 0, 0);
+        const uint32_t u = tid + (uint32_t)k * 256;
+        if (u < utotal) {
+            uint32_t e, j;
+            locate_unit(lds, u, unu, nr, e, j);
+            const uint32_t Te = lds.T[e];
+            const uint32_t so = min(16u * j, Te - 16u);
+            if (so >= 48) pv[k] = payload_unit(E.arena + lds.src[e], so, Te - APUS_HDR, Te - APUS_HDR);
+        }
+    }
+    /* the call's SeqOut: worked out here, from the same inputs by the same code as the sequencer
+     * block's, while the payload loads are in flight -- nobody waits for the sequencer */
+    if (r == 0) STAMP(1, 4);
+    if (IN_LAUNCH) seq_body<false>(E, r0, R, push_mask, tick, push_mask, *sq, r);
+    if (r == 0) STAMP(1, 1);
+
+    /* ---- phase 3 (wave 0): where the entries go ---- */
+    if (tid < WAVE) {
+        const SeqOut s = IN_LAUNCH ? sq->out : *E.seq;
+        const uint64_t a = s.e0 + (IN_LAUNCH ? sq->my_virt : E.round_virt[r]) + incl - T;
         const int64_t gk = (int64_t)first + lane;
         const uint64_t pos = apus_place(s, gk, a);
         const uint64_t idx = apus_entry_idx(s, gk);
         const uint64_t slot = s.n_end0 + (uint64_t)gk;
-        const uint32_t nu = active ? (T + 15) / 16 : 0;
-        const uint32_t uincl = wave_incl_scan(nu);
         const uint32_t type = d.pay16_type >> 28;
-        const uint32_t T0 = __shfl(T, 0, WAVE);
-        const bool uni = __all(!active || T == T0);
 
         const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)s.term, (uint32_t)(s.term >> 32));
         /* bytes 16..31: req_id, clt_id, type, sender (= leader: persist_new_entries), reply[0..3] = 0 */
         const uint4 h1 = make_uint4((uint32_t)d.req_id, (uint32_t)(d.req_id >> 32),
                                     (uint32_t)d.clt_id | (type << 16) | ((uint32_t)E.leader << 24), 0);
         lds.pos[lane] = pos;
-        lds.src[lane] = (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
-        lds.T[lane] = T;
-        lds.ubase[lane] = uincl - nu;
-        if (lane == WAVE - 1) { lds.ubase[WAVE] = uincl; lds.uniform_nu = uni ? (T0 + 15) / 16 : 0; lds.fuse_mask = s.fuse_mask; lds.fast = s.fast; }
+        if (lane == WAVE - 1) { lds.fuse_mask = s.fuse_mask; lds.fast = s.fast; }
         lds.h0[lane] = h0;
         lds.h1[lane] = h1;
 
@@ -462,11 +588,11 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
                 mix1 = apus_apply_mix(slot, pos, idx, len, d.clt_id, (uint8_t)type, 1);
                 mix2 = apus_apply_mix(slot, pos, idx, len, d.clt_id, (uint8_t)type, 2);
             }
-            /* the round's contribution to the stream hashes; k_apply's record blocks fold them
+            /* the round's contribution to the stream hashes; the call's record blocks fold them
              * into the control blocks (a thousand workgroups adding to the same words would queue
              * up in one L2 channel), the upcall counters advance by the batch size there too */
             const uint64_t sum1 = wave_sum(mix1), sum2 = wave_sum(mix2);
-            if (lane == 0) {     /* write-through: a record block of the same launch may read them (k_round) */
+            if (lane == 0) {     /* write-through: a record block of the same launch may read them */
                 __hip_atomic_store(&E.round_hash[2 * r], sum1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&E.round_hash[2 * r + 1], sum2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -495,33 +621,15 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
         }
     }
     __syncthreads();
+    if (r == 0) STAMP(1, 5);
 
-    if (r == 0) STAMP(1, 1);
-    const uint32_t utotal = lds.ubase[WAVE];
-    const uint32_t unu = lds.uniform_nu;
-    /* reply bytes that ride with the entry: fused followers persist + ACK as part of the push
-     * (their own byte in their ring, every fused follower's byte in the leader's ring) */
+    /* ---- phase 4 (all): the round's bytes as 16-byte units, to the leader ring and every
+     * pushed follower ring at the same offset.  Reply bytes ride with the entry: fused followers
+     * persist + ACK as part of the push (their own byte in their ring, every fused follower's
+     * byte in the leader's ring) ---- */
     const uint32_t fuse = lds.fuse_mask;
     const ReplyWords rwl = apus_reply_words(fuse);
-    for (uint32_t u = tid; u < utotal; u += 256) {
-        uint32_t e, j;
-        if (unu) { e = u / unu; j = u - e * unu; }
-        else {
-            /* which entry owns unit u: largest e with ubase[e] <= u */
-            uint32_t lo = 0, hi = nr - 1;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1) >> 1;
-                if (lds.ubase[mid] <= u) lo = mid; else hi = mid - 1;
-            }
-            e = lo; j = u - lds.ubase[e];
-        }
-        const uint32_t Te = lds.T[e];
-        const uint32_t so = min(16u * j, Te - 16u);
-        uint4 v;
-        if (so == 0) v = lds.h0[e];
-        else if (so == 16) v = lds.h1[e];
-        else if (so == 32) v = make_uint4(0, 0, 0, 0);
-        else v = payload_unit(E.arena + lds.src[e], so, Te - APUS_HDR, Te - APUS_HDR);
+    auto store_unit = [&](uint32_t e, uint32_t so, uint4 v) {
         const uint64_t p = lds.pos[e] + so;
         if (fuse && so - 16u <= 16u) {                 /* the two units that hold reply[0..12] */
             const bool second = so == 16;
@@ -535,6 +643,30 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
             st16u(Ld.ring + p, v);
             for (uint32_t m = push_mask; m; m &= m - 1) st16u(E.rep[__builtin_ctz(m)].ring + p, v);
         }
+    };
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        const uint32_t u = tid + (uint32_t)k * 256;
+        if (u < utotal) {
+            uint32_t e, j;
+            locate_unit(lds, u, unu, nr, e, j);
+            const uint32_t Te = lds.T[e];
+            const uint32_t so = min(16u * j, Te - 16u);
+            const uint4 v = so == 0 ? lds.h0[e] : so == 16 ? lds.h1[e] : so == 32 ? make_uint4(0, 0, 0, 0) : pv[k];
+            store_unit(e, so, v);
+        }
+    }
+    for (uint32_t u = tid + PF * 256; u < utotal; u += 256) {
+        uint32_t e, j;
+        locate_unit(lds, u, unu, nr, e, j);
+        const uint32_t Te = lds.T[e];
+        const uint32_t so = min(16u * j, Te - 16u);
+        uint4 v;
+        if (so == 0) v = lds.h0[e];
+        else if (so == 16) v = lds.h1[e];
+        else if (so == 32) v = make_uint4(0, 0, 0, 0);
+        else v = payload_unit(E.arena + lds.src[e], so, Te - APUS_HDR, Te - APUS_HDR);
+        store_unit(e, so, v);
     }
     if (r == 0) STAMP(1, 2);
 }
@@ -542,7 +674,7 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
 __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask)
 {
     __shared__ AppendLds lds;
-    append_round(E, r0, R, push_mask, blockIdx.x, lds);
+    append_round<false>(E, r0, R, push_mask, blockIdx.x, lds, nullptr, 0);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -705,6 +837,7 @@ __global__ __launch_bounds__(1024) void k_commit(const EngDev E, uint64_t r0, ui
 /* apply_committed_entries (dare_server.c:1815-1974) for slots [from, cs) of
  * replica p: apply-stream records, HEAD adoption candidates; block-reduced
  * counters.  Must be called by all threads of the block.                        */
+template <int APPLY_ILP = 4>
 __device__ static inline void apply_range(const EngDev &E, int p, uint64_t from, uint64_t cs, uint64_t tile0,
                                           uint64_t tile_stride, unsigned long long *s_acc /*[2]*/)
 {
@@ -714,7 +847,6 @@ __device__ static inline void apply_range(const EngDev &E, int p, uint64_t from,
     __syncthreads();
     /* APPLY_ILP slots per thread and pass: the three dependent memory steps (directory ->
      * header -> record) are issued for all of them before the first result is needed */
-    constexpr int APPLY_ILP = 4;
     for (uint64_t tile = from + tile0 * APPLY_ILP; tile < cs; tile += tile_stride * APPLY_ILP) {
         uint64_t sl[APPLY_ILP], off[APPLY_ILP];
         uint32_t T[APPLY_ILP];
@@ -779,8 +911,12 @@ __device__ static inline void apply_range(const EngDev &E, int p, uint64_t from,
 
 /* per-round commit record of rounds [r0, r0+R) of this call, one thread per round;
  * every block of k_apply takes a slice (gtid over gthreads)                        */
+/* virt = nullptr: the end offsets come from E.rec_end (written by k_sequence, an earlier launch);
+ * virt = the block's own exclusive scan of the round totals (k_call, R <= 1024): they are worked
+ * out here, the same way the sequencer does, and written to E.rec_end as well */
 __device__ static inline void finish_records(const EngDev &E, uint64_t r0, uint32_t R, uint64_t cs,
-                                             uint64_t gtid, uint64_t gthreads, const SeqOut &s, uint64_t rec_base0)
+                                             uint64_t gtid, uint64_t gthreads, const SeqOut &s, uint64_t rec_base0,
+                                             const uint64_t *virt = nullptr)
 {
     const RepDev &Ld = E.rep[E.leader];
     const uint64_t L = E.log_len;
@@ -790,7 +926,7 @@ __device__ static inline void finish_records(const EngDev &E, uint64_t r0, uint3
     /* the <HEAD> round of a fused prune tick committed (or not) on its own, before the batch */
     uint64_t base_commit = s.commit_before;
     if (hr) {
-        const uint64_t he = E.rec_end[rec_base0];
+        const uint64_t he = virt ? s.e0 : E.rec_end[rec_base0];       /* the <HEAD> entry ends where the batch starts */
         if (cs >= s.n_end0 && cs > s.n_commit_before && he != L) base_commit = he;
         if (gtid == 0 && rec_base0 < E.rec_cap) E.rec_commit[rec_base0] = base_commit;
     }
@@ -799,7 +935,19 @@ __device__ static inline void finish_records(const EngDev &E, uint64_t r0, uint3
         const uint64_t slot_end_r = s.n_end0 + (rf[r + 1] - rf[0]);
         const uint64_t slot_start_r = s.n_end0 + (rf[r] - rf[0]);
         const uint64_t c = min(cs, slot_end_r);
-        const uint64_t end_r = E.rec_end[rec_base + r];
+        uint64_t end_r, end_prev = 0;
+        if (virt) {
+            const int64_t g0 = (int64_t)rf[0];
+            const uint64_t a_end = s.e0 + virt[r + 1];
+            end_r = (s.kstar < 0 || (int64_t)rf[r + 1] - g0 - 1 < s.kstar) ? a_end : a_end - s.w;
+            if (r) {
+                const uint64_t p_end = s.e0 + virt[r];
+                end_prev = (s.kstar < 0 || (int64_t)rf[r] - g0 - 1 < s.kstar) ? p_end : p_end - s.w;
+            }
+            E.rec_end[rec_base + r] = end_r;
+        } else {
+            end_r = E.rec_end[rec_base + r];
+        }
         uint64_t cr;
         if (c <= s.n_commit_before) cr = s.commit_before;
         else if (c <= s.n_end0) cr = base_commit;
@@ -819,7 +967,7 @@ __device__ static inline void finish_records(const EngDev &E, uint64_t r0, uint3
         if (end_r == L) {
             if (r == 0) cr = base_commit;
             else {
-                const uint64_t pe = E.rec_end[rec_base + r - 1];
+                const uint64_t pe = virt ? end_prev : E.rec_end[rec_base + r - 1];
                 const uint64_t pc = min(cs, slot_start_r);
                 cr = (pc <= s.n_commit_before) ? s.commit_before
                    : (pc <= s.n_end0 ? base_commit : (pc == slot_start_r ? pe : Ld.dir_off[(uint32_t)pc & E.dir_mask]));
@@ -1141,116 +1289,155 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
     STAMP(3, 3);
 }
 
-/* k_round: everything of a call that follows the sequencer, in ONE launch -- the blocks take
- * roles by index and hand over through arrival tickets (E.ticket) instead of kernel boundaries:
- *   [0, R)                    one round each: append + push (+ fused persist/ACK, + apply when in step)
- *   [R, R + nS)               follower persist + ACK + quorum scan (k_persist_commit's body); idle
- *                             unless SeqOut::tail_needed; they wait for the append blocks
- *   [.., + nA * replicas)     apply_committed_entries per replica; idle when in step (SeqOut::fast),
- *                             else they wait for the scan
- *   [.., + nR)                the leader's per-round commit record (+ fast-path hash fold)
- *   last                      the bookkeeper
- * A block only ever waits for blocks with a LOWER index; workgroups are dispatched in index order,
- * so everything a waiting block needs is already running or done -- no co-residency assumption.
- * Data that crosses blocks inside the launch is released (L2 write-back, agent scope) by the
- * producer before its ticket and acquired by the consumer after it; on the fast path nothing
- * but tickets and the per-round hash words crosses, and the append blocks skip the release. */
-__global__ __launch_bounds__(256) void k_round(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask,
-                                               uint32_t rmask, uint32_t nS, uint32_t nA, uint32_t nR)
+/* k_call: a whole run_rounds call (R <= 1024 rounds) in ONE launch.  Block roles by index:
+ *   0                         sequencer + bookkeeper
+ *   [1, R]                    one round each: append + push (+ fused persist/ACK, + apply when in step)
+ *   [.., + nR)                the leader's per-round record (+ fast-path hash fold); recorder 0 is
+ *                             also the janitor: last to leave, it clears the call's counters
+ *   [.., + nS)                follower persist + ACK + quorum scan; idle unless SeqOut::tail_needed
+ *   [.., + nA * replicas)     apply_committed_entries per replica; idle when in step (SeqOut::fast)
+ * Nobody waits for the sequencer on the fast path: every append block (and record block) works
+ * the sequencing out for itself -- same inputs, same code (seq_stage + seq_body<false>), no
+ * stores -- while its descriptor / payload loads are in flight.  The sequencer block changes the
+ * control words only after every append block has fetched its copy of them (tick word 2), then
+ * does the effects (seq_body<true>) and, in step, the bookkeeping right away: nothing it writes
+ * is read by another block of the launch.  It raises the flag (tick word 1): 1 = in step, the idle
+ * roles just leave; 2 = not in step, its results are released (L2 write-back) first and the
+ * persist/scan -> apply -> records -> bookkeeping chain runs on arrival tickets, producers
+ * releasing and consumers acquiring at agent scope.
+ * A block only ever waits for blocks with a LOWER index (or, for the sequencer, for tickets the
+ * append blocks post before they wait for anything); workgroups are dispatched in index order per
+ * XCD, so what a waiting block needs is already running or done: no co-residency assumption. */
+__global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t tick,
+                                              uint32_t rmask, uint32_t nS, uint32_t nA, uint32_t nR)
 {
-    __shared__ union RoundLds {
+    __shared__ SeqLds sq;
+    __shared__ union CallLds {
         AppendLds app;
-        struct { ApplyCtx c; unsigned long long acc[2]; uint64_t np[APUS_DEV_MAX_SERVERS]; uint64_t sc[4]; } t;
+        struct { ApplyCtx c; unsigned long long acc[2]; uint64_t np[APUS_DEV_MAX_SERVERS]; uint64_t sc[4]; uint32_t flag; } t;
     } l;
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     const uint32_t ny = (uint32_t)__popc(rmask);
     const uint32_t fmask = push_mask;
-
-    if (b < R) {                                               /* ---- append + push ---- */
-        if (b == R - 1) STAMP(6, 0);
-        append_round(E, r0, R, push_mask, b, l.app);
-        if (b == R - 1) STAMP(6, 1);
-        /* in step, the only data a later role reads are the round's hash words (written through);
-         * otherwise the scan and apply blocks read the entries: release them before the ticket */
-        post_append(E, b, l.app.fast == 0);                    /* .fast was written before append_round's barrier */
-        if (b == R - 1) STAMP(6, 2);
-        return;
-    }
-    uint32_t q = b - R;
     ApplyCtx &c = l.t.c;
-    if (q < nS) {                                              /* ---- persist + ACK + quorum scan ---- */
-        if (tid == 0) l.t.sc[3] = E.seq->tail_needed;
-        __syncthreads();
-        if (l.t.sc[3]) {
-            wait_append(E, R);
-            persist_commit_blocks(E, fmask, q, nS, l.t.np, l.t.sc);
-        }
-        post_ticket(E, T_SCAN, l.t.sc[3] != 0);
+
+    if (b >= 1 && b <= R) {                                    /* ---- append + push ---- */
+        if (b == R) STAMP(6, 0);
+        append_round<true>(E, r0, R, push_mask, b - 1, l.app, &sq, tick);
+        if (b == R) STAMP(6, 1);
+        post_append(E, b - 1, l.app.fast == 0);
+        if (b == R) STAMP(6, 2);
         return;
     }
-    q -= nS;
-    if (q < nA * ny) {                                         /* ---- apply ---- */
-        const uint32_t y = q / nA, x = q - y * nA;
-        int p = -1;
-        for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
-            if (rmask & (1u << i)) { if (k == (int)y) { p = i; break; } k++; }
-        if (tid == 0) l.t.sc[3] = E.seq->fast;
-        __syncthreads();
-        if (!l.t.sc[3]) {
-            wait_ticket(E, T_SCAN, nS);                        /* first_fail is final, the entries are visible */
-            stage_apply_ctx(E, c, p, false, fmask);
-            if (p >= 0) apply_range(E, p, c.n_apply_p, ctx_commit_slot(c), (uint64_t)x * blockDim.x,
-                                    (uint64_t)nA * blockDim.x, l.t.acc);
+    if (b == 0) {                                              /* ---- sequencer + bookkeeper ---- */
+        seq_stage(E, r0, R, push_mask, push_mask, sq);
+        if (tid < 32) {                                        /* every append and record block has its copy of the inputs */
+            const uint32_t quota = (R + nR) / 32 + (tid < ((R + nR) & 31u) ? 1u : 0u);
+            unsigned long long spins = 0;
+            while (__hip_atomic_load(E.tick_lines + tid * 32 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < quota) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1ull << 22)) { set_status(E, 1u << 4); break; }     /* bounded */
+            }
         }
-        post_ticket(E, T_DONE, false);                         /* records and atomics only; visible at kernel end */
+        __syncthreads();
+        seq_body<true>(E, r0, R, push_mask, tick, push_mask, sq, 0, false);
+        __syncthreads();
+        const bool fast = sq.out.fast != 0;
+        if (!fast && tid == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   /* SeqOut, control words, <HEAD> entry */
+        __syncthreads();
+        if (tid < 32) __hip_atomic_store(E.tick_lines + tid * 32 + 1, fast ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        STAMP(3, 0);
+        stage_apply_ctx(E, c, -1, true, fmask);                /* own stores: same CU, same L2 */
+        STAMP(3, 1);
+        if (!fast) {
+            wait_ticket(E, T_DONE, nA * ny + nR);
+            if (tid == 0)
+                c.seq.first_fail = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+        }
+        STAMP(3, 2);
+        const uint64_t vis = c.seq.vis, cs = ctx_commit_slot(c);
+        const uint64_t end_l = c.lh[H_END], n_end_l = c.lh[H_N_END];
+        if (tid == 0) c.off_cs = (cs == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)cs & E.dir_mask];
+        if (tid == 1) c.off_vis = (vis == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)vis & E.dir_mask];
+        __syncthreads();
+        keeper_publish(E, c, R, 0, fmask, vis, cs);
+        STAMP(3, 3);
+        post_ticket(E, T_PASS, false);
         return;
     }
-    q -= nA * ny;
+    uint32_t q = b - 1 - R;
     if (q < nR) {                                              /* ---- per-round records ---- */
         if (q == 0) STAMP(5, 0);
-        stage_apply_ctx(E, c, -1, false, fmask);               /* nothing here changes during the launch ... */
+        /* the sequencing, worked out locally (SeqOut in sq.out, the rounds' prefix in sq.virt) */
+        seq_stage(E, r0, R, push_mask, push_mask, sq);
+        if (tid == 0) __hip_atomic_fetch_add(E.tick_lines + ((R + q) & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seq_body<false>(E, r0, R, push_mask, tick, push_mask, sq, 0);
         if (q == 0) STAMP(5, 1);
-        if (c.seq.fast) {
-            /* in step: the commit slot is known (everything visible commits), only the rounds'
+        if (sq.out.fast) {
+            /* in step: the commit slot is known (everything visible commits); only the rounds'
              * hash words have to be waited for */
-            finish_records(E, r0, R, c.seq.vis, (uint64_t)q * blockDim.x + tid, (uint64_t)nR * blockDim.x, c.seq, c.rec_base);
+            finish_records(E, r0, R, sq.out.vis, (uint64_t)q * blockDim.x + tid, (uint64_t)nR * blockDim.x, sq.out,
+                           sq.out.rec_base, sq.virt);
             if (q == 0) STAMP(5, 2);
             wait_append(E, R);
             if (q == 0) STAMP(5, 3);
-            fold_round_hashes(E, R, q, nR, c.seq.fuse_mask);
+            fold_round_hashes(E, R, q, nR, sq.out.fuse_mask);
             if (q == 0) STAMP(5, 4);
-            return;
+        } else {
+            wait_append(E, R);
+            wait_ticket(E, T_SCAN, nS);
+            if (tid == 0)
+                sq.out.first_fail = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            uint64_t cs = min((uint64_t)sq.out.first_fail, sq.out.vis);
+            if (cs < sq.out.n_commit_before) cs = sq.out.n_commit_before;
+            finish_records(E, r0, R, cs, (uint64_t)q * blockDim.x + tid, (uint64_t)nR * blockDim.x, sq.out, sq.out.rec_base, sq.virt);
+            post_ticket(E, T_DONE, false);
         }
-        wait_append(E, R);
-        wait_ticket(E, T_SCAN, nS);
-        if (tid == 0)                                          /* ... except the scan's result */
-            c.seq.first_fail = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        recorder_body(E, r0, R, 0, ctx_commit_slot(c), q, nR, c);
-        post_ticket(E, T_DONE, false);
+        if (q != 0) { post_ticket(E, T_PASS, false); return; }
+        /* the janitor: every append block is done (wait_append above), everybody else signs off
+         * with T_PASS; then the call's counters and the flag are cleared for the next call */
+        wait_ticket(E, T_PASS, nS + nA * ny + (nR - 1) + 1);
+        if (tid < 32) {
+            __hip_atomic_store(E.tick_lines + tid * 32 + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(E.tick_lines + tid * 32 + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(E.tick_lines + tid * 32 + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (tid == 32) {
+            __hip_atomic_store(E.ticket + T_PASS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(E.ticket + T_SCAN, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(E.ticket + T_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
-    /* ---- the bookkeeper ---- */
-    STAMP(3, 0);
-    stage_apply_ctx(E, c, -1, true, fmask);
-    STAMP(3, 1);
-    if (!c.seq.fast) {
-        wait_ticket(E, T_DONE, nA * ny + nR);
-        if (tid == 0)
-            c.seq.first_fail = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
+    /* ---- the roles that only work when the replicas are not in step ---- */
+    q -= nR;
+    const uint32_t flag = wait_sequenced(E, b, &l.t.flag);
+    if (flag == 2) {
+        if (q < nS) {                                          /* persist + ACK + quorum scan */
+            if (tid == 0) l.t.sc[3] = E.seq->tail_needed;
+            __syncthreads();
+            if (l.t.sc[3]) {
+                wait_append(E, R);
+                persist_commit_blocks(E, fmask, q, nS, l.t.np, l.t.sc);
+            }
+            post_ticket(E, T_SCAN, l.t.sc[3] != 0);
+        } else {                                               /* apply */
+            q -= nS;
+            const uint32_t y = q / nA, x = q - y * nA;
+            int p = -1;
+            for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
+                if (rmask & (1u << i)) { if (k == (int)y) { p = i; break; } k++; }
+            wait_ticket(E, T_SCAN, nS);                        /* first_fail is final, the entries are visible */
+            stage_apply_ctx(E, c, p, false, fmask);
+            /* (2 slots per lane and pass: keeps the whole kernel at 8 waves per SIMD) */
+            if (p >= 0 && !c.seq.fast) apply_range<2>(E, p, c.n_apply_p, ctx_commit_slot(c), (uint64_t)x * blockDim.x,
+                                                      (uint64_t)nA * blockDim.x, l.t.acc);
+            post_ticket(E, T_DONE, false);
+        }
     }
-    /* in step nothing the bookkeeper writes is read by another block of this launch and the
-     * commit slot is known, so it publishes right away */
-    STAMP(3, 2);
-    const uint64_t vis = c.seq.vis, cs = ctx_commit_slot(c);
-    const uint64_t end_l = c.lh[H_END], n_end_l = c.lh[H_N_END];
-    if (tid == 0) c.off_cs = (cs == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)cs & E.dir_mask];
-    if (tid == 1) c.off_vis = (vis == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)vis & E.dir_mask];
-    __syncthreads();
-    keeper_publish(E, c, R, 0, fmask, vis, cs);
-    STAMP(3, 3);
+    post_ticket(E, T_PASS, false);
 }
 
 /* READ the apply offset of peer i for the next prune tick (rc_get_remote_apply_offsets,
@@ -1272,6 +1459,9 @@ __device__ static inline void sample_apply_offsets(const EngDev &E, const uint64
  *   mode 1: log_pruning (dare_server.c:1996-2067): decide from the sampled apply offsets
  *           whether the head moves and append <HEAD, head> if so
  * s_lh is an LDS copy of the leader's control block; returns the call's SeqOut. */
+/* FX = false: decide and account only (the LDS copy s_lh is updated, nothing is stored to HBM) --
+ * what every append block of k_call computes for itself; FX = true: the sequencer, with all effects */
+template <bool FX>
 __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32_t type, uint64_t d0, uint64_t d1,
                                                uint32_t push_mask, uint64_t *s_lh, uint64_t rec_base, uint32_t ack_mask,
                                                bool apply_now)
@@ -1287,12 +1477,12 @@ __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32
         const uint32_t bitmask = (uint32_t)s_lh[H_CID_BITMASK];
         uint64_t min_off = s_lh[H_APPLY];
         for (uint32_t i = 0; i < size; i++) {
-            if (!((bitmask >> i) & 1u)) { s_lh[H_APPLY_OFFSETS + i] = s_lh[H_APPLY]; hdr[H_APPLY_OFFSETS + i] = s_lh[H_APPLY]; }
+            if (!((bitmask >> i) & 1u)) { s_lh[H_APPLY_OFFSETS + i] = s_lh[H_APPLY]; if (FX) hdr[H_APPLY_OFFSETS + i] = s_lh[H_APPLY]; }
             if (apus_is_larger(end, L, min_off, s_lh[H_APPLY_OFFSETS + i])) min_off = s_lh[H_APPLY_OFFSETS + i];
         }
         if (apus_end_distance(end, L, min_off) == 0) min_off = s_lh[H_TAIL];   /* leave one entry, :2038-2041 */
         do_append = apus_is_larger(end, L, min_off, head) && !s_lh[H_PREV_HEAD];
-        if (do_append) { hdr[H_HEAD] = min_off; s_lh[H_HEAD] = min_off; head = min_off; d0 = min_off; d1 = 0; type = 3; }
+        if (do_append) { if (FX) hdr[H_HEAD] = min_off; s_lh[H_HEAD] = min_off; head = min_off; d0 = min_off; d1 = 0; type = 3; }
     }
     SeqOut s;
     s.e0 = end; s.idx0 = s_lh[H_LAST_IDX] + 1; s.w = 0; s.n_end0 = s_lh[H_N_END];
@@ -1300,19 +1490,19 @@ __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32
     s.first_fail = ~0ull; s.commit_before = s_lh[H_COMMIT]; s.n_commit_before = s_lh[H_N_COMMIT];
     s.vis = 0; s.scan_lo = 0; s.fuse_mask = 0; s.tail_needed = 1; s.fast = 0; s.pad1 = 0; s.rec_base = rec_base;
     for (uint32_t f = 0; f < APUS_DEV_MAX_SERVERS; f++) s.np[f] = ~0ull;
-    if (do_append && end == head && end != L) { set_status(E, 1u << 1); do_append = false; }
+    if (do_append && end == head && end != L) { if (FX) set_status(E, 1u << 1); do_append = false; }
     if (do_append) {
         const uint64_t idx = (end == L) ? 1 : s_lh[H_LAST_IDX] + 1;         /* dare_log.h:486-488 */
         const uint64_t pos = (end == L || L - end < APUS_HDR) ? 0 : end;   /* log_add_new_entry, :213-221 */
-        if (type != 3) { hdr[H_PREV_HEAD] = 0; s_lh[H_PREV_HEAD] = 0; } else if (mode == 1) { hdr[H_PREV_HEAD] = 1; s_lh[H_PREV_HEAD] = 1; }
-        if (type == 2) hdr[H_CID_BITMASK] = (uint32_t)(d1 >> 32);     /* the leader's own cid follows its CONFIG entries */
+        if (type != 3) { if (FX) hdr[H_PREV_HEAD] = 0; s_lh[H_PREV_HEAD] = 0; } else if (mode == 1) { if (FX) hdr[H_PREV_HEAD] = 1; s_lh[H_PREV_HEAD] = 1; }
+        if (FX && type == 2) hdr[H_CID_BITMASK] = (uint32_t)(d1 >> 32);     /* the leader's own cid follows its CONFIG entries */
         const uint64_t term = s.term;
         const uint64_t slot = s.n_end0;
         const uint32_t di = (uint32_t)slot & E.dir_mask;
         const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)term, (uint32_t)(term >> 32));
         const uint4 h1 = make_uint4(0, 0, (type << 16) | ((uint32_t)E.leader << 24), 0);  /* req_id = clt_id = 0 */
         const uint4 h3 = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
-        for (uint32_t m = push_mask | (1u << E.leader); m; m &= m - 1) {
+        for (uint32_t m = FX ? (push_mask | (1u << E.leader)) : 0u; m; m &= m - 1) {
             const int t = __builtin_ctz(m);
             uint8_t *rg = E.rep[t].ring;
             /* followers in ack_mask persist + ACK with the push: own reply byte in their ring, all of them in the leader's */
@@ -1330,16 +1520,17 @@ __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32
                     atomicMax((unsigned long long *)&E.rep[t].hdr[H_HEAD_SLOT], (unsigned long long)(slot + 1));
             }
         }
-        __hip_atomic_store(&Ld.ack[di], ack_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        hdr[H_TAIL] = pos;               s_lh[H_TAIL] = pos;
-        hdr[H_END] = pos + APUS_HDR;     s_lh[H_END] = pos + APUS_HDR;
-        hdr[H_N_END] = slot + 1;         s_lh[H_N_END] = slot + 1;
-        hdr[H_LAST_IDX] = idx;           s_lh[H_LAST_IDX] = idx;
-        hdr[H_OLD_END] = pos + APUS_HDR; s_lh[H_OLD_END] = pos + APUS_HDR;
-        hdr[H_N_PERSIST] = slot + 1;     s_lh[H_N_PERSIST] = slot + 1;
-        hdr[H_STORE_COUNT] = s_lh[H_STORE_COUNT] + 1; s_lh[H_STORE_COUNT] += 1;
+        if (FX) __hip_atomic_store(&Ld.ack[di], ack_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (FX) hdr[H_TAIL] = pos;               s_lh[H_TAIL] = pos;
+        if (FX) hdr[H_END] = pos + APUS_HDR;     s_lh[H_END] = pos + APUS_HDR;
+        if (FX) hdr[H_N_END] = slot + 1;         s_lh[H_N_END] = slot + 1;
+        if (FX) hdr[H_LAST_IDX] = idx;           s_lh[H_LAST_IDX] = idx;
+        if (FX) hdr[H_OLD_END] = pos + APUS_HDR; s_lh[H_OLD_END] = pos + APUS_HDR;
+        if (FX) hdr[H_N_PERSIST] = slot + 1;     s_lh[H_N_PERSIST] = slot + 1;
+        if (FX) hdr[H_STORE_COUNT] = s_lh[H_STORE_COUNT] + 1;
+        s_lh[H_STORE_COUNT] += 1;
         s.n = 1;
-        if (rec_base < E.rec_cap) E.rec_end[rec_base] = pos + APUS_HDR;
+        if (FX && rec_base < E.rec_cap) E.rec_end[rec_base] = pos + APUS_HDR;
     }
     return s;
 }
@@ -1383,7 +1574,7 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode,
     __shared__ uint64_t s_lh[64];
     if (tid < 64) s_lh[tid] = hdr[tid];
     __syncthreads();
-    if (tid == 0) *E.seq = control_append(E, mode, type, d0, d1, push_mask, s_lh, *E.rec_count, 0, false);
+    if (tid == 0) *E.seq = control_append<true>(E, mode, type, d0, d1, push_mask, s_lh, *E.rec_count, 0, false);
     if (mode == 1 && tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS) sample_apply_offsets(E, s_lh, sample_mask, tid - 64, nullptr);
     __syncthreads();
 
@@ -1479,5 +1670,9 @@ __global__ void k_reset(const EngDev E)
     h[H_LEN] = E.log_len; h[H_END] = E.log_len; h[H_TAIL] = E.log_len; h[H_OLD_END] = E.log_len;
     h[H_SID] = (uint64_t)p;
     h[H_CID_BITMASK] = (1u << E.group_size) - 1;
-    if (p == 0) { *E.rec_count = 0; *E.status = 0; for (int i = 0; i < 8; i++) E.ticket[i] = 0; }
+    if (p == 0) {
+        *E.rec_count = 0; *E.status = 0;
+        for (int i = 0; i < 8; i++) E.ticket[i] = 0;
+        for (int i = 0; i < 32; i++) { E.tick_lines[i * 32] = 0; E.tick_lines[i * 32 + 1] = 0; E.tick_lines[i * 32 + 2] = 0; }
+    }
 }

@@ -32,4 +32,7 @@ for k in (0, 1, 6, 4, 2, 5, 3):
     if False: print("   applier probes:", [round((int(b) - int(a)) / 100.0, 2) for a, b in zip(buf[k*64+10:k*64+13], buf[k*64+11:k*64+14])], "barrier+setup:", round((int(buf[k*64+10]) - int(buf[k*64+1])) / 100.0, 2))
     st = [int(v) for v in row if v]
     if not st: continue
+    if k == 1:
+        o = [int(buf[64 + i]) for i in (0, 3, 4, 1, 5, 2)]
+        print("append block 0: start, staged, prefetch issued, sequenced, placed, stored (us):", [round((v - o[0]) / 100.0, 2) for v in o]); continue
     print("%-22s" % names[k], "start@%.2f" % ((st[0] - base) / 100.0), "deltas(us):", [round((b - a) / 100.0, 2) for a, b in zip(st, st[1:])])
