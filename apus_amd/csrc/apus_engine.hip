@@ -42,7 +42,7 @@ struct apus_engine {
     bool tick_pending;              /* a prune tick waits to be fused into the next batch's sequencer */
     uint64_t max_rounds;
     /* staging */
-    void *d_req, *d_req_len, *d_arena, *d_round_first;
+    void *d_req, *d_req_len, *d_arena, *d_round_first, *d_round_prefix;
     uint64_t n_reqs, n_rounds_staged;
     std::vector<uint32_t> h_round_first;
     /* graphs */
@@ -117,7 +117,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     memset(&e->d, 0, sizeof e->d);
     e->capturing = false; e->timing = false; e->timed_used = 0; e->lag_possible = false; e->tick_pending = false;
     e->n_reqs = 0; e->n_rounds_staged = 0;
-    e->d_req = e->d_req_len = e->d_arena = e->d_round_first = nullptr;
+    e->d_req = e->d_req_len = e->d_arena = e->d_round_first = e->d_round_prefix = nullptr;
     e->h_live = nullptr; e->d_live = nullptr; e->live_pending = false; e->live_copied = nullptr;
     e->live_r0 = e->live_R = e->live_n = 0;
     e->ph = e->ph_dev = nullptr; e->pd = nullptr; e->pstream = nullptr; e->p_running = false;
@@ -183,6 +183,7 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
     if (e->d_req_len) hipFree(e->d_req_len);
     if (e->d_arena) hipFree(e->d_arena);
     if (e->d_round_first) hipFree(e->d_round_first);
+    if (e->d_round_prefix) hipFree(e->d_round_prefix);
     if (e->p_running) apus_gpu_persist_stop(e);
     if (e->ph) hipHostFree(e->ph);
     if (e->pd) hipFree(e->pd);
@@ -270,11 +271,19 @@ extern "C" int apus_gpu_stage(apus_engine_t *e, const apus_req_t *reqs, uint64_t
     }
     if (arena_bytes) HIPCHK(hipMemcpy(e->d_arena, arena, arena_bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_round_first, e->h_round_first.data(), sizeof(uint32_t) * (2 * n_rounds + 1), hipMemcpyHostToDevice));
+    {
+        /* byte prefix of the rounds: lets an append block place its round without a scan */
+        std::vector<uint64_t> pfx(n_rounds + 1, 0);
+        for (uint64_t r = 0; r < n_rounds; r++) pfx[r + 1] = pfx[r] + e->h_round_first[n_rounds + 1 + r];
+        if ((rc = renew(&e->d_round_prefix, sizeof(uint64_t) * (n_rounds + 1)))) return rc;
+        HIPCHK(hipMemcpy(e->d_round_prefix, pfx.data(), sizeof(uint64_t) * (n_rounds + 1), hipMemcpyHostToDevice));
+    }
     e->d.req = (const ReqDev *)e->d_req;
     e->d.req_len = (const uint16_t *)e->d_req_len;
     e->d.arena = (const uint8_t *)e->d_arena;
     e->d.round_first = (const uint32_t *)e->d_round_first;
     e->d.round_bytes = e->d.round_first + n_rounds + 1;
+    e->d.round_prefix = (const uint64_t *)e->d_round_prefix;
     e->n_reqs = n;
     e->n_rounds_staged = n_rounds;
     return 0;

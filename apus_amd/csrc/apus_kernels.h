@@ -197,8 +197,42 @@ struct SeqLds {
     uint32_t bytes0[1024];                /* byte totals of the first 1024 rounds */
     uint64_t virt_rstar;                  /* exclusive prefix of the round that crosses len */
     uint64_t my_virt;                     /* FX = false: where round my_r starts */
+    uint64_t pfx[3];                      /* wave-0 variant: staged byte prefix at round 0, my_r, R of the call */
+    uint32_t rfx[2];                      /* wave-0 variant: first request of round 0 and of round R */
+    uint32_t ok;                          /* wave-0 variant: 1 = SeqOut worked out, 0 = take the block-wide path */
     SeqOut   out;                         /* FX = false: the call's SeqOut */
 };
+
+/* which pushed followers persist + ACK with the push itself (they have persisted everything so
+ * far), and whether every replica on the device has persisted, committed and applied everything */
+__device__ static inline void seq_in_step(const EngDev &E, const uint64_t *lh, const uint64_t (*fw)[5], uint32_t push_mask,
+                                          uint32_t &fuse_mask, bool &in_step)
+{
+    const uint64_t L = E.log_len;
+    const uint64_t e_pre = lh[H_END], n_pre = lh[H_N_END];
+    fuse_mask = 0;
+    for (uint32_t m = push_mask; m; m &= m - 1)
+        if (fw[__builtin_ctz(m)][3] == n_pre && e_pre != L) fuse_mask |= 1u << __builtin_ctz(m);
+    const uint32_t size = E.group_size, size_mask = (1u << size) - 1;
+    in_step = fuse_mask == push_mask && (uint32_t)__popc((fuse_mask | (1u << E.leader)) & size_mask) >= size / 2 + 1
+           && lh[H_N_COMMIT] == n_pre && lh[H_N_APPLY] == n_pre;
+    for (uint32_t m = push_mask; m; m &= m - 1) in_step = in_step && fw[__builtin_ctz(m)][4] == n_pre;
+}
+
+/* the batch-level switches of SeqOut; hidden = the batch ends exactly on len (its last round
+ * stays invisible and is not pushed as acknowledged) */
+struct SeqFlags { uint32_t fuse_batch, tail_needed, fast; };
+__device__ static inline SeqFlags seq_flags(const EngDev &E, uint32_t push_mask, uint32_t fuse_mask, bool in_step, bool hidden,
+                                            uint32_t n, uint64_t n_commit_before, uint64_t n_end0, uint32_t head_round)
+{
+    SeqFlags f;
+    f.fuse_batch = hidden ? 0u : fuse_mask;
+    const uint32_t size = E.group_size, size_mask = (1u << size) - 1;
+    const bool quorum_fused = (uint32_t)__popc((f.fuse_batch | (1u << E.leader)) & size_mask) >= size / 2 + 1;
+    f.tail_needed = ((push_mask & ~f.fuse_batch) != 0 || !quorum_fused || n_commit_before < n_end0 - head_round) ? 1u : 0u;
+    f.fast = (in_step && !f.tail_needed && !hidden && n) ? 1u : 0u;
+    return f;
+}
 
 /* The sequencer, for one workgroup of 256 .. 1024 threads, in two steps.
  * seq_stage: everything it needs from HBM, requested by different lanes in one round trip.
@@ -208,7 +242,7 @@ struct SeqLds {
  * append block does that for itself instead of waiting for the sequencer block (q.out, and
  * q.my_virt = where round my_r starts). */
 __device__ static inline void seq_stage(const EngDev &E, uint64_t r0, uint32_t R, uint32_t push_mask,
-                                        uint32_t sample_mask, SeqLds &q)
+                                        uint32_t sample_mask, SeqLds &q, bool need_tail = true)
 {
     uint64_t (&s_lh)[64] = q.lh;
     uint64_t (&s_fw)[APUS_DEV_MAX_SERVERS][5] = q.fw;
@@ -234,7 +268,7 @@ __device__ static inline void seq_stage(const EngDev &E, uint64_t r0, uint32_t R
             if ((push_mask >> f_) & 1u) { st3 = fh_[H_N_PERSIST]; st4 = fh_[H_N_APPLY]; }
         }
     } else if (tid == 96) st0 = *E.rec_count;
-    else if (tid == 97) st0 = (rf[R] > rf[0]) ? E.req_len[rf[R] - 1] : 0;
+    else if (tid == 97 && need_tail) st0 = (rf[R] > rf[0]) ? E.req_len[rf[R] - 1] : 0;   /* two dependent loads: only the real sequencer */
     if (tid < 64) s_lh[tid] = st0;
     else if (tid < 64 + APUS_DEV_MAX_SERVERS) { s_fw[tid - 64][0] = st0; s_fw[tid - 64][1] = st1; s_fw[tid - 64][2] = st2; s_fw[tid - 64][3] = st3; s_fw[tid - 64][4] = st4; }
     else if (tid == 96) s_misc[0] = st0;
@@ -271,16 +305,7 @@ __device__ static inline void seq_body(const EngDev &E, uint64_t r0, uint32_t R,
     bool in_step = false;       /* every replica on the device has persisted, committed and applied everything so far */
     {
         const uint64_t e_pre = s_lh[H_END], n_pre = s_lh[H_N_END];
-        /* pushed followers that have persisted everything so far: they persist + ACK this
-         * call's entries as part of the push itself (SeqOut::fuse_mask) */
-        for (uint32_t m = push_mask; m; m &= m - 1)
-            if (s_fw[__builtin_ctz(m)][3] == n_pre && e_pre != L) fuse_mask |= 1u << __builtin_ctz(m);
-        {
-            const uint32_t size = E.group_size, size_mask = (1u << size) - 1;
-            in_step = fuse_mask == push_mask && (uint32_t)__popc((fuse_mask | (1u << E.leader)) & size_mask) >= size / 2 + 1
-                   && s_lh[H_N_COMMIT] == n_pre && s_lh[H_N_APPLY] == n_pre;
-            for (uint32_t m = push_mask; m; m &= m - 1) in_step = in_step && s_fw[__builtin_ctz(m)][4] == n_pre;
-        }
+        seq_in_step(E, s_lh, s_fw, push_mask, fuse_mask, in_step);
         /* followers that silently fell behind (hidden exact-fit round) are caught up here */
         bool any_lag = false;
         for (uint32_t m = push_mask; m; m &= m - 1) any_lag |= (s_fw[__builtin_ctz(m)][1] < n_pre) && e_pre != L;
@@ -321,7 +346,7 @@ __device__ static inline void seq_body(const EngDev &E, uint64_t r0, uint32_t R,
         uint64_t v = incl - run;
         for (uint32_t r = r_lo; r < r_hi; r++) {
             const uint64_t bytes = (r < 1024) ? q.bytes0[r] : rb[r];
-            if (FX) E.round_virt[r] = v;
+            if (FX && write_rec) E.round_virt[r] = v;      /* k_append_push of a later launch reads it; k_call does not */
             if (R <= 1024) s_virt[r] = v;
             if (!FX && r == my_r) q.my_virt = v;
             /* the first round that does not fit before len (the totals are positive: exactly one) */
@@ -329,7 +354,7 @@ __device__ static inline void seq_body(const EngDev &E, uint64_t r0, uint32_t R,
             v += bytes;
         }
     }
-    if (tid == 0) { if (FX) E.round_virt[R] = vtot; if (R <= 1024) s_virt[R] = vtot; }
+    if (tid == 0) { if (FX && write_rec) E.round_virt[R] = vtot; if (R <= 1024) s_virt[R] = vtot; }
     __syncthreads();
     const uint32_t rstar = s_rstar;
     if (blockIdx.x == 0) STAMP(0, 3);
@@ -377,10 +402,8 @@ __device__ static inline void seq_body(const EngDev &E, uint64_t r0, uint32_t R,
             const uint64_t end_after = n ? end_new : e0, n_end_after = n_end0 + n;
             s.vis = (end_after != L) ? n_end_after
                   : (n == 0 ? s_lh[H_N_VISIBLE] : n_end0 + (rf[R - 1] - g0));
-            /* a batch whose last round stays hidden (end on len) is not pushed as acknowledged */
-            const uint32_t fuse_batch = (end_after != L) ? fuse_mask : 0u;
-            const uint32_t size = E.group_size, size_mask = (1u << size) - 1;
-            const bool quorum_fused = (uint32_t)__popc((fuse_batch | (1u << E.leader)) & size_mask) >= size / 2 + 1;
+            const SeqFlags fl = seq_flags(E, push_mask, fuse_mask, in_step, end_after == L, n, s.n_commit_before, n_end0, head_round);
+            const uint32_t fuse_batch = fl.fuse_batch;
             uint64_t lo = s.n_commit_before;
             for (uint32_t f = 0; f < APUS_DEV_MAX_SERVERS; f++) {
                 uint64_t npf = s_fw[f][3];                              /* ~0 for servers not pushed to */
@@ -390,8 +413,8 @@ __device__ static inline void seq_body(const EngDev &E, uint64_t r0, uint32_t R,
             }
             s.scan_lo = lo;
             s.fuse_mask = fuse_batch;
-            s.tail_needed = ((push_mask & ~fuse_batch) != 0 || !quorum_fused || s.n_commit_before < n_end0 - head_round) ? 1u : 0u;
-            s.fast = (in_step && !s.tail_needed && end_after != L && n) ? 1u : 0u;
+            s.tail_needed = fl.tail_needed;
+            s.fast = fl.fast;
             s.pad1 = 0;
             s.rec_base = s_misc[0];
         }
@@ -441,6 +464,65 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
  * scan, index, header words, directory).  All 256 threads: the round's bytes as
  * 16-byte units, each stored to the leader ring and to every in-sync follower
  * ring at the same offset, so that the payload is read from HBM once.          */
+/* k_call's append blocks, common case -- the batch stays clear of the end of the ring: wave 0
+ * alone works out the SeqOut fields an append block needs (no block-wide scan: the host staged
+ * the byte prefix of the rounds next to their totals), while the other waves fetch payload.
+ * seq_w0_stage: the inputs, one round trip, by the 64 lanes.  seq_w0_decide: one lane, the same
+ * decision code as the sequencer (seq_in_step, control_append<false>, seq_flags).  If the batch
+ * could reach len (q.ok = 0) the block falls back to seq_body<false> on the same staged inputs. */
+__device__ static inline void seq_w0_stage(const EngDev &E, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t my_r, SeqLds &q)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t *hdr = E.rep[E.leader].hdr;
+    auto fw_word = [&](uint32_t k) -> uint64_t {
+        const uint32_t f = k / 5, j = k - f * 5;
+        const int words[5] = {H_END, H_N_END, H_APPLY, H_N_PERSIST, H_N_APPLY};
+        if ((push_mask >> f) & 1u) return E.rep[f].hdr[words[j]];
+        return j == 3 ? ~0ull : 0ull;
+    };
+    const uint64_t v0 = hdr[lane];
+    const uint64_t f0 = fw_word(lane);
+    uint64_t x = 0;
+    if (lane == 0) x = fw_word(64);
+    else if (lane == 1) x = *E.rec_count;
+    else if (lane == 2) x = E.round_prefix[r0];
+    else if (lane == 3) x = E.round_prefix[r0 + my_r];
+    else if (lane == 4) x = E.round_prefix[r0 + R];
+    else if (lane == 5) x = E.round_first[r0];
+    else if (lane == 6) x = E.round_first[r0 + R];
+    q.lh[lane] = v0;
+    (&q.fw[0][0])[lane] = f0;
+    if (lane == 0) { (&q.fw[0][0])[64] = x; q.rstar = 0xFFFFFFFFu; q.head_round = 0; }
+    else if (lane == 1) q.misc[0] = x;
+    else if (lane >= 2 && lane <= 4) q.pfx[lane - 2] = x;
+    else if (lane == 5 || lane == 6) q.rfx[lane - 5] = (uint32_t)x;
+}
+
+__device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask, uint32_t tick, SeqLds &q)
+{
+    const uint64_t L = E.log_len;
+    const uint64_t vtot = q.pfx[2] - q.pfx[0];
+    const uint64_t e_pre = q.lh[H_END];
+    /* clear of len even if a <HEAD> entry (64 bytes) goes in front of the batch? */
+    if (e_pre == L || e_pre + APUS_HDR + vtot >= L) { q.ok = 0; return; }
+    uint32_t fuse_mask; bool in_step;
+    seq_in_step(E, q.lh, q.fw, push_mask, fuse_mask, in_step);
+    uint32_t head_round = 0;
+    if (tick) head_round = control_append<false>(E, 1, 3, 0, 0, push_mask, q.lh, q.misc[0], fuse_mask, in_step).n;
+    const uint32_t n = q.rfx[1] - q.rfx[0];
+    SeqOut s;
+    s.e0 = q.lh[H_END]; s.idx0 = q.lh[H_LAST_IDX] + 1; s.w = 0; s.n_end0 = q.lh[H_N_END];
+    s.term = q.lh[H_SID] >> 9; s.kstar = -1; s.estar = -1; s.stale = 0; s.n = n; s.head_round = head_round; s.pad0 = 0;
+    s.first_fail = ~0ull; s.commit_before = q.lh[H_COMMIT]; s.n_commit_before = q.lh[H_N_COMMIT];
+    const SeqFlags fl = seq_flags(E, push_mask, fuse_mask, in_step, false, n, s.n_commit_before, s.n_end0, head_round);
+    s.vis = s.n_end0 + n; s.scan_lo = 0;
+    for (uint32_t f = 0; f < APUS_DEV_MAX_SERVERS; f++) s.np[f] = ~0ull;       /* not used by an append block */
+    s.fuse_mask = fl.fuse_batch; s.tail_needed = fl.tail_needed; s.fast = fl.fast; s.pad1 = 0; s.rec_base = q.misc[0];
+    q.out = s;
+    q.my_virt = q.pfx[1] - q.pfx[0];
+    q.ok = 1;
+}
+
 struct AppendLds {
     uint64_t pos[WAVE];
     uint64_t src[WAVE];
@@ -506,10 +588,10 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
     uint32_t T = 0;
     uint64_t incl = 0;
     if (tid < WAVE && active) d = E.req[g0 + first + lane];
-    if (IN_LAUNCH) {
+    if (IN_LAUNCH && tid < WAVE) {
         /* the sequencer's inputs, in the same round trip as the descriptors; once they are in LDS
          * the sequencer block may start changing the control words (it waits for these tickets) */
-        seq_stage(E, r0, R, push_mask, push_mask, *sq);
+        seq_w0_stage(E, r0, R, push_mask, r, *sq);
         if (r == 0) STAMP(1, 3);
         if (tid == 0) __hip_atomic_fetch_add(E.tick_lines + (r & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -547,7 +629,16 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
     /* the call's SeqOut: worked out here, from the same inputs by the same code as the sequencer
      * block's, while the payload loads are in flight -- nobody waits for the sequencer */
     if (r == 0) STAMP(1, 4);
-    if (IN_LAUNCH) seq_body<false>(E, r0, R, push_mask, tick, push_mask, *sq, r);
+    if (IN_LAUNCH) {
+        if (tid == 0) seq_w0_decide(E, push_mask, tick, *sq);
+        __syncthreads();
+        if (!sq->ok) {                 /* the batch could reach len: the block-wide scan, on the inputs staged above */
+            const uint32_t *rb = E.round_bytes + r0;
+            for (uint32_t i = tid; i < R && i < 1024; i += blockDim.x) sq->bytes0[i] = rb[i];
+            __syncthreads();
+            seq_body<false>(E, r0, R, push_mask, tick, push_mask, *sq, r);
+        }
+    }
     if (r == 0) STAMP(1, 1);
 
     /* ---- phase 3 (wave 0): where the entries go ---- */
@@ -1371,7 +1462,7 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
     if (q < nR) {                                              /* ---- per-round records ---- */
         if (q == 0) STAMP(5, 0);
         /* the sequencing, worked out locally (SeqOut in sq.out, the rounds' prefix in sq.virt) */
-        seq_stage(E, r0, R, push_mask, push_mask, sq);
+        seq_stage(E, r0, R, push_mask, push_mask, sq, false);
         if (tid == 0) __hip_atomic_fetch_add(E.tick_lines + ((R + q) & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         seq_body<false>(E, r0, R, push_mask, tick, push_mask, sq, 0);
         if (q == 0) STAMP(5, 1);

@@ -154,7 +154,8 @@ def bench_single(args):
     for r in range(1, n_rep):
         assert int(eng.hdr_words(r)[16]) == total_steps * n_entries, "follower did not apply every entry"
 
-    # dominant kernel (k_append_push): HIP events around each launch, eager, same steps
+    # dominant kernel (k_call: the whole consensus pass of a run_rounds call in one launch):
+    # HIP events around each launch on the engine's stream, eager, same steps
     eng.set_timing(True)
     for _ in range(args.steps):
         issue(eng, calls)
@@ -201,10 +202,11 @@ def bench_single(args):
     N = n_rep
     entries_per_launch = n_entries * args.steps / max(k_launches, 1)
     # algorithmic HBM bytes (single-device mode): (3N-1)E + 64 per
-    # committed entry for the whole path; the append+replicate kernel's share of it is
-    # E (leader append) + 2E(N-1) (replication)
+    # committed entry -- E (leader append) + 2E(N-1) (replication) + N*E (apply-side read on every
+    # replica) + 64 (ACK scan).  k_call does all of it in one launch, so the dominant kernel's
+    # algorithmic bytes are the whole path's (it moves fewer: the apply side works from registers)
     path_bytes = (3 * N - 1) * E + 64
-    kern_bytes = (2 * N - 1) * E
+    kern_bytes = path_bytes
     k_avg_s = (k_ms / 1e3) / max(k_launches, 1)
     achieved = kern_bytes * entries_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
     value = n_entries * args.steps / dt
@@ -212,7 +214,7 @@ def bench_single(args):
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("k_append_push_bytes_per_launch")
+            traffic = json.load(open(pmc)).get("k_call_bytes_per_launch")
         except Exception:
             traffic = None
     out = {
@@ -236,7 +238,7 @@ def bench_single(args):
                             "device latency from wall_clock64 inside the persistent kernel"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_append_push", "bytes_per_entry": kern_bytes,
+                     "kernel": "k_call", "bytes_per_entry": kern_bytes,
                      "avg_launch_us": k_avg_s * 1e6, "launches": k_launches,
                      "entries_per_launch": entries_per_launch},
         "whole_path": {"bytes_per_entry": path_bytes, "achieved": path_bytes * value / 1e9,
