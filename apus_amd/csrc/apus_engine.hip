@@ -384,7 +384,7 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
          * apply, per-round records (k_call's block roles) */
         /* the scan / apply blocks only work when the replicas are not in step: a modest number, grid-stride */
         const uint32_t nS = cap_grid(n, 256, 32), nA = cap_grid(n, 1024, 16), nR = cap_grid(R, 256, 8);
-        hipLaunchKernelGGL(k_call, dim3(1 + R + nS + nA * popc(rm) + nR), dim3(256), 0, e->stream, e->d, c0, R, fm, tick, rm,
+        hipLaunchKernelGGL(k_call, dim3(1 + R + nR + 1 + nS + nA * popc(rm)), dim3(256), 0, e->stream, e->d, c0, R, fm, tick, rm,
                            nS, nA, nR);
         if (tl) HIPCHK(hipEventRecord(tl->b, e->stream));
     }

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_catchup(const EngDev E, uint32_t fmask)
 template <bool FX>
 __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32_t type, uint64_t d0, uint64_t d1,
                                                uint32_t push_mask, uint64_t *s_lh, uint64_t rec_base, uint32_t ack_mask,
-                                               bool apply_now);
+                                               bool apply_now, bool note_head_slot = true);
 __device__ static inline void sample_apply_offsets(const EngDev &E, const uint64_t *s_lh, uint32_t sample_mask, uint32_t i,
                                                    const uint64_t *staged_apply);
 
@@ -200,6 +200,7 @@ struct SeqLds {
     uint64_t pfx[3];                      /* wave-0 variant: staged byte prefix at round 0, my_r, R of the call */
     uint32_t rfx[2];                      /* wave-0 variant: first request of round 0 and of round R */
     uint32_t ok;                          /* wave-0 variant: 1 = SeqOut worked out, 0 = take the block-wide path */
+    uint64_t end_new;                     /* the leader's end offset after the batch */
     SeqOut   out;                         /* FX = false: the call's SeqOut */
 };
 
@@ -325,7 +326,7 @@ __device__ static inline void seq_body(const EngDev &E, uint64_t r0, uint32_t R,
             if (FX && tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS)
                 sample_apply_offsets(E, s_lh, sample_mask, tid - 64, &s_fw[tid - 64][2]);
             __syncthreads();                             /* the sampling lanes read the pre-tick block */
-            if (tid == 0) s_head_round = control_append<FX>(E, 1, 3, 0, 0, push_mask, s_lh, s_misc[0], fuse_mask, in_step).n;
+            if (tid == 0) s_head_round = control_append<FX>(E, 1, 3, 0, 0, push_mask, s_lh, s_misc[0], fuse_mask, in_step, write_rec).n;
             __syncthreads();
         }
     }
@@ -419,6 +420,7 @@ __device__ static inline void seq_body(const EngDev &E, uint64_t r0, uint32_t R,
             s.rec_base = s_misc[0];
         }
         q.out = s;
+        q.end_new = n ? end_new : e0;
         if (FX) *E.seq = s;
         if (FX && n) {
             const uint64_t t_last = APUS_HDR + s_misc[1];
@@ -519,8 +521,31 @@ __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask,
     for (uint32_t f = 0; f < APUS_DEV_MAX_SERVERS; f++) s.np[f] = ~0ull;       /* not used by an append block */
     s.fuse_mask = fl.fuse_batch; s.tail_needed = fl.tail_needed; s.fast = fl.fast; s.pad1 = 0; s.rec_base = q.misc[0];
     q.out = s;
+    q.end_new = n ? s.e0 + vtot : s.e0;
     q.my_virt = q.pfx[1] - q.pfx[0];
     q.ok = 1;
+}
+
+/* a block of k_call works the call's SeqOut out for itself: wave 0's variant, or the block-wide
+ * scan when the batch could reach len; posts its "inputs fetched" ticket on tick line read_line */
+__device__ static inline void seq_local(const EngDev &E, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t tick,
+                                        uint32_t my_r, uint32_t read_line, SeqLds &q)
+{
+    const uint32_t tid = threadIdx.x;
+    if (tid < WAVE) {
+        seq_w0_stage(E, r0, R, push_mask, my_r, q);
+        if (tid == 0) {
+            __hip_atomic_fetch_add(E.tick_lines + (read_line & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seq_w0_decide(E, push_mask, tick, q);
+        }
+    }
+    __syncthreads();
+    if (!q.ok) {
+        const uint32_t *rb = E.round_bytes + r0;
+        for (uint32_t i = tid; i < R && i < 1024; i += blockDim.x) q.bytes0[i] = rb[i];
+        __syncthreads();
+        seq_body<false>(E, r0, R, push_mask, tick, push_mask, q, my_r);
+    }
 }
 
 struct AppendLds {
@@ -1003,11 +1028,12 @@ __device__ static inline void apply_range(const EngDev &E, int p, uint64_t from,
 /* per-round commit record of rounds [r0, r0+R) of this call, one thread per round;
  * every block of k_apply takes a slice (gtid over gthreads)                        */
 /* virt = nullptr: the end offsets come from E.rec_end (written by k_sequence, an earlier launch);
- * virt = the block's own exclusive scan of the round totals (k_call, R <= 1024): they are worked
- * out here, the same way the sequencer does, and written to E.rec_end as well */
+ * virt = an exclusive prefix of the round totals, offset by vbase (k_call: the block's own scan in
+ * LDS, or the host-staged E.round_prefix): they are worked out here, the same way the sequencer
+ * does, and written to E.rec_end as well */
 __device__ static inline void finish_records(const EngDev &E, uint64_t r0, uint32_t R, uint64_t cs,
                                              uint64_t gtid, uint64_t gthreads, const SeqOut &s, uint64_t rec_base0,
-                                             const uint64_t *virt = nullptr)
+                                             const uint64_t *virt = nullptr, uint64_t vbase = 0)
 {
     const RepDev &Ld = E.rep[E.leader];
     const uint64_t L = E.log_len;
@@ -1029,10 +1055,10 @@ __device__ static inline void finish_records(const EngDev &E, uint64_t r0, uint3
         uint64_t end_r, end_prev = 0;
         if (virt) {
             const int64_t g0 = (int64_t)rf[0];
-            const uint64_t a_end = s.e0 + virt[r + 1];
+            const uint64_t a_end = s.e0 + (virt[r + 1] - vbase);
             end_r = (s.kstar < 0 || (int64_t)rf[r + 1] - g0 - 1 < s.kstar) ? a_end : a_end - s.w;
             if (r) {
-                const uint64_t p_end = s.e0 + virt[r];
+                const uint64_t p_end = s.e0 + (virt[r] - vbase);
                 end_prev = (s.kstar < 0 || (int64_t)rf[r] - g0 - 1 < s.kstar) ? p_end : p_end - s.w;
             }
             E.rec_end[rec_base + r] = end_r;
@@ -1208,8 +1234,11 @@ __device__ static inline void recorder_body(const EngDev &E, uint64_t r0, uint32
 /* the bookkeeper, once everybody else is done: per-call counters, the leader's commit / apply
  * offsets (update_remote_logs :1744-1758), and for every follower the R2 end doorbell, persist
  * bookkeeping, R4 lazy commit, apply offset and HEAD adoption.  c.off_cs / c.off_vis are set. */
+/* pure_head: k_call in step -- the followers applied the call's <HEAD> entry (if any) when the
+ * sequencer pushed it; slot + 1 and value are derived (head_slot1, head_value) instead of read */
 __device__ static inline void keeper_publish(const EngDev &E, const ApplyCtx &c, uint32_t R, int mode, uint32_t fmask,
-                                             uint64_t vis, uint64_t cs)
+                                             uint64_t vis, uint64_t cs, bool pure_head = false, uint64_t head_slot1 = 0,
+                                             uint64_t head_value = 0)
 {
     const uint32_t tid = threadIdx.x;
     uint64_t *lh = E.rep[E.leader].hdr;
@@ -1242,7 +1271,8 @@ __device__ static inline void keeper_publish(const EngDev &E, const ApplyCtx &c,
             const uint64_t f_np = c.fw[f][0], f_nc = c.fw[f][1], f_na = c.fw[f][2], f_sc = c.fw[f][3];
             const uint64_t f_head = c.fw[f][4], f_end = c.fw[f][5];
             /* the appliers of this call may have raised the HEAD slot: read it now */
-            const uint64_t hs = __hip_atomic_load((unsigned long long *)&fh[H_HEAD_SLOT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t hs = pure_head ? head_slot1
+                              : __hip_atomic_load((unsigned long long *)&fh[H_HEAD_SLOT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint64_t end_now = f_end;
             if (vis > f_np) {
                 fh[H_STORE_COUNT] = f_sc + (vis - f_np);
@@ -1253,10 +1283,13 @@ __device__ static inline void keeper_publish(const EngDev &E, const ApplyCtx &c,
             if (cs > f_nc) { fh[H_COMMIT] = c.off_cs; fh[H_N_COMMIT] = cs; }
             if (cs > f_na) { fh[H_APPLY] = c.off_cs; fh[H_N_APPLY] = cs; }
             if (hs) {
-                const uint64_t hoff = E.rep[f].dir_off[(uint32_t)(hs - 1) & E.dir_mask];
-                const uint64_t hv = ld8u(E.rep[f].ring + hoff + 48);
+                uint64_t hv = head_value;
+                if (!pure_head) {
+                    const uint64_t hoff = E.rep[f].dir_off[(uint32_t)(hs - 1) & E.dir_mask];
+                    hv = ld8u(E.rep[f].ring + hoff + 48);
+                }
                 if (apus_is_larger(end_now, L, hv, f_head)) fh[H_HEAD] = hv;
-                fh[H_HEAD_SLOT] = 0;
+                if (!pure_head) fh[H_HEAD_SLOT] = 0;
             }
         }
     }
@@ -1298,6 +1331,20 @@ __device__ static inline void post_append(const EngDev &E, uint32_t b, bool rele
         if (release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(E.tick_lines + (b & 31u) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+/* every block of k_call that works the sequencing out for itself has fetched its copy of the
+ * control words (tick word 2 of the 32 lines): only then may they be changed */
+__device__ static inline void wait_readers(const EngDev &E, uint32_t n_readers)
+{
+    if (threadIdx.x < 32) {
+        const uint32_t quota = n_readers / 32 + (threadIdx.x < (n_readers & 31u) ? 1u : 0u);
+        unsigned long long spins = 0;
+        while (__hip_atomic_load(E.tick_lines + threadIdx.x * 32 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < quota) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1ull << 22)) { set_status(E, 1u << 4); break; }     /* bounded */
+        }
+    }
+    __syncthreads();
 }
 /* all of the block's stores are done (barrier), optionally released to the device, then the ticket */
 __device__ static inline void post_ticket(const EngDev &E, int which, bool release)
@@ -1381,21 +1428,22 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
 }
 
 /* k_call: a whole run_rounds call (R <= 1024 rounds) in ONE launch.  Block roles by index:
- *   0                         sequencer + bookkeeper
+ *   0                         the sequencer
  *   [1, R]                    one round each: append + push (+ fused persist/ACK, + apply when in step)
  *   [.., + nR)                the leader's per-round record (+ fast-path hash fold); recorder 0 is
  *                             also the janitor: last to leave, it clears the call's counters
+ *   next                      the bookkeeper
  *   [.., + nS)                follower persist + ACK + quorum scan; idle unless SeqOut::tail_needed
  *   [.., + nA * replicas)     apply_committed_entries per replica; idle when in step (SeqOut::fast)
  * Nobody waits for the sequencer on the fast path: every append block (and record block) works
  * the sequencing out for itself -- same inputs, same code (seq_stage + seq_body<false>), no
- * stores -- while its descriptor / payload loads are in flight.  The sequencer block changes the
- * control words only after every append block has fetched its copy of them (tick word 2), then
- * does the effects (seq_body<true>) and, in step, the bookkeeping right away: nothing it writes
- * is read by another block of the launch.  It raises the flag (tick word 1): 1 = in step, the idle
- * roles just leave; 2 = not in step, its results are released (L2 write-back) first and the
- * persist/scan -> apply -> records -> bookkeeping chain runs on arrival tickets, producers
- * releasing and consumers acquiring at agent scope.
+ * stores -- while its descriptor / payload loads are in flight; so do the record blocks and the
+ * bookkeeper, which in step publishes right away (nothing it writes is read by another block of
+ * the launch).  The sequencer block changes the control words only after every such block has
+ * fetched its copy of them (tick word 2), then does the effects (seq_body<true>) and raises the
+ * flag (tick word 1): 1 = in step, the idle roles just leave; 2 = not in step, its results are
+ * released (L2 write-back) first and the persist/scan -> apply -> records -> bookkeeping chain
+ * runs on arrival tickets, producers releasing and consumers acquiring at agent scope.
  * A block only ever waits for blocks with a LOWER index (or, for the sequencer, for tickets the
  * append blocks post before they wait for anything); workgroups are dispatched in index order per
  * XCD, so what a waiting block needs is already running or done: no co-residency assumption. */
@@ -1412,6 +1460,10 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
     const uint32_t ny = (uint32_t)__popc(rmask);
     const uint32_t fmask = push_mask;
     ApplyCtx &c = l.t.c;
+    /* blocks that fetch the control words themselves: R append + nR record + 1 bookkeeper */
+    const uint32_t n_readers = R + nR + 1;
+    /* blocks that sign off with T_PASS: everybody but the append blocks and the janitor */
+    const uint32_t n_pass = 1 + (nR - 1) + 1 + nS + nA * ny;
 
     if (b >= 1 && b <= R) {                                    /* ---- append + push ---- */
         if (b == R) STAMP(6, 0);
@@ -1421,56 +1473,31 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
         if (b == R) STAMP(6, 2);
         return;
     }
-    if (b == 0) {                                              /* ---- sequencer + bookkeeper ---- */
+    if (b == 0) {                                              /* ---- the sequencer ---- */
         seq_stage(E, r0, R, push_mask, push_mask, sq);
-        if (tid < 32) {                                        /* every append and record block has its copy of the inputs */
-            const uint32_t quota = (R + nR) / 32 + (tid < ((R + nR) & 31u) ? 1u : 0u);
-            unsigned long long spins = 0;
-            while (__hip_atomic_load(E.tick_lines + tid * 32 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < quota) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1ull << 22)) { set_status(E, 1u << 4); break; }     /* bounded */
-            }
-        }
-        __syncthreads();
+        wait_readers(E, n_readers);                            /* every reader has its copy of the inputs */
         seq_body<true>(E, r0, R, push_mask, tick, push_mask, sq, 0, false);
         __syncthreads();
         const bool fast = sq.out.fast != 0;
         if (!fast && tid == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   /* SeqOut, control words, <HEAD> entry */
         __syncthreads();
         if (tid < 32) __hip_atomic_store(E.tick_lines + tid * 32 + 1, fast ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        STAMP(3, 0);
-        stage_apply_ctx(E, c, -1, true, fmask);                /* own stores: same CU, same L2 */
-        STAMP(3, 1);
-        if (!fast) {
-            wait_ticket(E, T_DONE, nA * ny + nR);
-            if (tid == 0)
-                c.seq.first_fail = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-        }
-        STAMP(3, 2);
-        const uint64_t vis = c.seq.vis, cs = ctx_commit_slot(c);
-        const uint64_t end_l = c.lh[H_END], n_end_l = c.lh[H_N_END];
-        if (tid == 0) c.off_cs = (cs == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)cs & E.dir_mask];
-        if (tid == 1) c.off_vis = (vis == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)vis & E.dir_mask];
-        __syncthreads();
-        keeper_publish(E, c, R, 0, fmask, vis, cs);
-        STAMP(3, 3);
         post_ticket(E, T_PASS, false);
         return;
     }
     uint32_t q = b - 1 - R;
     if (q < nR) {                                              /* ---- per-round records ---- */
         if (q == 0) STAMP(5, 0);
-        /* the sequencing, worked out locally (SeqOut in sq.out, the rounds' prefix in sq.virt) */
-        seq_stage(E, r0, R, push_mask, push_mask, sq, false);
-        if (tid == 0) __hip_atomic_fetch_add(E.tick_lines + ((R + q) & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        seq_body<false>(E, r0, R, push_mask, tick, push_mask, sq, 0);
+        seq_local(E, r0, R, push_mask, tick, 0, R + q, sq);
         if (q == 0) STAMP(5, 1);
+        /* the rounds' byte prefix: the host-staged one, or the block's own scan */
+        const uint64_t *virt = sq.ok ? E.round_prefix + r0 : sq.virt;
+        const uint64_t vbase = sq.ok ? sq.pfx[0] : 0;
         if (sq.out.fast) {
             /* in step: the commit slot is known (everything visible commits); only the rounds'
              * hash words have to be waited for */
             finish_records(E, r0, R, sq.out.vis, (uint64_t)q * blockDim.x + tid, (uint64_t)nR * blockDim.x, sq.out,
-                           sq.out.rec_base, sq.virt);
+                           sq.out.rec_base, virt, vbase);
             if (q == 0) STAMP(5, 2);
             wait_append(E, R);
             if (q == 0) STAMP(5, 3);
@@ -1484,13 +1511,13 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
             __syncthreads();
             uint64_t cs = min((uint64_t)sq.out.first_fail, sq.out.vis);
             if (cs < sq.out.n_commit_before) cs = sq.out.n_commit_before;
-            finish_records(E, r0, R, cs, (uint64_t)q * blockDim.x + tid, (uint64_t)nR * blockDim.x, sq.out, sq.out.rec_base, sq.virt);
+            finish_records(E, r0, R, cs, (uint64_t)q * blockDim.x + tid, (uint64_t)nR * blockDim.x, sq.out, sq.out.rec_base, virt, vbase);
             post_ticket(E, T_DONE, false);
         }
         if (q != 0) { post_ticket(E, T_PASS, false); return; }
         /* the janitor: every append block is done (wait_append above), everybody else signs off
          * with T_PASS; then the call's counters and the flag are cleared for the next call */
-        wait_ticket(E, T_PASS, nS + nA * ny + (nR - 1) + 1);
+        wait_ticket(E, T_PASS, n_pass);
         if (tid < 32) {
             __hip_atomic_store(E.tick_lines + tid * 32 + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(E.tick_lines + tid * 32 + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1502,8 +1529,53 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
         }
         return;
     }
-    /* ---- the roles that only work when the replicas are not in step ---- */
     q -= nR;
+    if (q == 0) {                                              /* ---- the bookkeeper ---- */
+        STAMP(3, 0);
+        /* followers' control words: nobody else writes them while the replicas are in step */
+        if (tid >= 128 && tid < 128 + 8 * APUS_DEV_MAX_SERVERS) {
+            const uint32_t f = (tid - 128) >> 3, j = (tid - 128) & 7;
+            static const int words[8] = {H_N_PERSIST, H_N_COMMIT, H_N_APPLY, H_STORE_COUNT, H_HEAD, H_END, H_N_END, H_HEAD_SLOT};
+            c.fw[f][j] = ((fmask >> f) & 1u) ? E.rep[f].hdr[words[j]] : 0;
+        }
+        seq_local(E, r0, R, push_mask, tick, 0, R + nR, sq);
+        STAMP(3, 1);
+        if (sq.out.fast) {
+            /* in step: everything the bookkeeping needs follows from the sequencing it just worked
+             * out; nothing it writes is read by another block of the launch: publish right away */
+            if (tid < 64) c.lh[tid] = sq.lh[tid];
+            else if (tid < 64 + sizeof(SeqOut) / 8) ((uint64_t *)&c.seq)[tid - 64] = ((const uint64_t *)&sq.out)[tid - 64];
+            __syncthreads();
+            const uint64_t vis = sq.out.vis, cs = vis;
+            if (tid == 0) {
+                c.rec_base = sq.out.rec_base;
+                c.lh[H_END] = sq.end_new; c.lh[H_N_END] = sq.out.n_end0 + sq.out.n;
+                c.off_cs = sq.end_new; c.off_vis = sq.end_new;       /* vis == n_end: the batch is fully visible */
+            }
+            __syncthreads();
+            wait_readers(E, n_readers);                        /* it changes words the other blocks sequence from */
+            STAMP(3, 2);
+            keeper_publish(E, c, R, 0, fmask, vis, cs, true, sq.out.head_round ? sq.out.n_end0 : 0, sq.lh[H_HEAD]);
+            STAMP(3, 3);
+        } else {
+            wait_sequenced(E, b, &l.t.flag);                   /* the sequencer's results, released */
+            stage_apply_ctx(E, c, -1, true, fmask);
+            wait_ticket(E, T_DONE, nA * ny + nR);
+            if (tid == 0)
+                c.seq.first_fail = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const uint64_t vis = c.seq.vis, cs = ctx_commit_slot(c);
+            const uint64_t end_l = c.lh[H_END], n_end_l = c.lh[H_N_END];
+            if (tid == 0) c.off_cs = (cs == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)cs & E.dir_mask];
+            if (tid == 1) c.off_vis = (vis == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)vis & E.dir_mask];
+            __syncthreads();
+            keeper_publish(E, c, R, 0, fmask, vis, cs);
+        }
+        post_ticket(E, T_PASS, false);
+        return;
+    }
+    q -= 1;
+    /* ---- the roles that only work when the replicas are not in step ---- */
     const uint32_t flag = wait_sequenced(E, b, &l.t.flag);
     if (flag == 2) {
         if (q < nS) {                                          /* persist + ACK + quorum scan */
@@ -1522,7 +1594,7 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
                 if (rmask & (1u << i)) { if (k == (int)y) { p = i; break; } k++; }
             wait_ticket(E, T_SCAN, nS);                        /* first_fail is final, the entries are visible */
             stage_apply_ctx(E, c, p, false, fmask);
-            /* (2 slots per lane and pass: keeps the whole kernel at 8 waves per SIMD) */
+            /* (2 slots per lane and pass: keeps the whole kernel's register count down) */
             if (p >= 0 && !c.seq.fast) apply_range<2>(E, p, c.n_apply_p, ctx_commit_slot(c), (uint64_t)x * blockDim.x,
                                                       (uint64_t)nA * blockDim.x, l.t.acc);
             post_ticket(E, T_DONE, false);
@@ -1555,7 +1627,7 @@ __device__ static inline void sample_apply_offsets(const EngDev &E, const uint64
 template <bool FX>
 __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32_t type, uint64_t d0, uint64_t d1,
                                                uint32_t push_mask, uint64_t *s_lh, uint64_t rec_base, uint32_t ack_mask,
-                                               bool apply_now)
+                                               bool apply_now, bool note_head_slot)
 {
     const RepDev &Ld = E.rep[E.leader];
     uint64_t *hdr = Ld.hdr;
@@ -1607,7 +1679,8 @@ __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32
                 uint4 *rp = (uint4 *)&E.rep[t].apply[di];
                 rp[0] = make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32));
                 rp[1] = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), 0, type << 16);
-                if (type == 3 && (uint32_t)t != E.leader)
+                /* (k_call's bookkeeper derives the adoption itself: note_head_slot = false) */
+                if (type == 3 && (uint32_t)t != E.leader && note_head_slot)
                     atomicMax((unsigned long long *)&E.rep[t].hdr[H_HEAD_SLOT], (unsigned long long)(slot + 1));
             }
         }

@@ -51,6 +51,17 @@ def test_small_fixed_64B(eng_factory, n):
         compare_apply_tail(eng, cl, r)
 
 
+def test_repeated_runs_stay_bit_exact(eng_factory):
+    """k_call's blocks hand over through tickets and work the sequencing out independently:
+    a protocol slip shows as an intermittent mismatch or a spin time-out, so run the small
+    5-replica stream (frequent wraps, prune ticks, both sequencing variants) many times."""
+    from tests.parity import lockstep
+    eng = eng_factory(5, 1 << 16)
+    tr = T.steady_trace(5, 3000, 64, 16, 64, log_len=1 << 16)
+    for _ in range(12):
+        lockstep(tr, eng)
+
+
 def test_rounds_one_by_one_match_coalesced(eng_factory):
     from tests.parity import lockstep
     eng = eng_factory(3, 1 << 16)
