@@ -116,8 +116,8 @@ struct EngDev {
     uint32_t dir_mask;                    /* dir_cap - 1 */
     uint64_t log_len;
     uint32_t *status;
-    uint32_t *ticket;                     /* [8] arrival counters (k_apply: [1]; k_round: scan [3], done [4]) */
-    uint32_t *tick_lines;                 /* [32 lines x 32 words] k_round's append arrivals, spread over 32 cache lines */
+    uint32_t *ticket;                     /* [8] arrival counters (k_apply: [1]; k_call: pass [2], scan [3], done [4]) */
+    uint32_t *tick_lines;                 /* [32 lines x 32 words] k_call: word 0 append arrivals, word 1 the sequencer's flag, word 2 "inputs fetched" */
     /* staged requests */
     const ReqDev   *req;
     const uint16_t *req_len;

@@ -298,7 +298,8 @@ static inline uint32_t cap_grid(uint64_t n, uint32_t per_block, uint32_t cap)
     return (uint32_t)g;
 }
 
-/* persist + ACK scan + apply + bookkeeping for whatever is new (mode: see k_finish) */
+/* persist + ACK scan + apply + bookkeeping for whatever is new (mode 0: staged rounds) -- the
+ * second half of the phased ABI (commit_live / commit_rounds); run_rounds uses k_call instead */
 static int launch_tail_view(apus_engine *e, const EngDev &view, uint64_t r0, uint32_t R, int mode, uint64_t n_hint)
 {
     const uint32_t fm = sync_mask(e);

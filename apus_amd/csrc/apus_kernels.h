@@ -558,6 +558,7 @@ struct AppendLds {
     uint32_t uniform_nu;      /* units per entry when every entry of the round has the same size, else 0 */
     uint32_t fuse_mask;       /* SeqOut::fuse_mask */
     uint32_t fast;            /* SeqOut::fast */
+    uint64_t slot0;           /* slot of the round's first entry */
 };
 
 /* which entry of the round owns 16-byte unit u, and which of its units it is */
@@ -613,12 +614,17 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
     uint32_t T = 0;
     uint64_t incl = 0;
     if (tid < WAVE && active) d = E.req[g0 + first + lane];
-    if (IN_LAUNCH && tid < WAVE) {
-        /* the sequencer's inputs, in the same round trip as the descriptors; once they are in LDS
-         * the sequencer block may start changing the control words (it waits for these tickets) */
-        seq_w0_stage(E, r0, R, push_mask, r, *sq);
-        if (r == 0) STAMP(1, 3);
-        if (tid == 0) __hip_atomic_fetch_add(E.tick_lines + (r & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (IN_LAUNCH) {
+        if (tid < WAVE) {
+            /* the sequencer's inputs, in the same round trip as the descriptors; once they are in LDS
+             * the sequencer block may start changing the control words (it waits for these tickets) */
+            seq_w0_stage(E, r0, R, push_mask, r, *sq);
+            if (r == 0) STAMP(1, 3);
+            if (tid == 0) __hip_atomic_fetch_add(E.tick_lines + (r & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        /* one lane of wave 1 works the call's SeqOut out while wave 0 lays the round out */
+        if (tid == WAVE) seq_w0_decide(E, push_mask, tick, *sq);
     }
     if (tid < WAVE) {
         T = active ? APUS_HDR + d.len : 0;
@@ -655,8 +661,6 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
      * block's, while the payload loads are in flight -- nobody waits for the sequencer */
     if (r == 0) STAMP(1, 4);
     if (IN_LAUNCH) {
-        if (tid == 0) seq_w0_decide(E, push_mask, tick, *sq);
-        __syncthreads();
         if (!sq->ok) {                 /* the batch could reach len: the block-wide scan, on the inputs staged above */
             const uint32_t *rb = E.round_bytes + r0;
             for (uint32_t i = tid; i < R && i < 1024; i += blockDim.x) sq->bytes0[i] = rb[i];
@@ -681,38 +685,9 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
         const uint4 h1 = make_uint4((uint32_t)d.req_id, (uint32_t)(d.req_id >> 32),
                                     (uint32_t)d.clt_id | (type << 16) | ((uint32_t)E.leader << 24), 0);
         lds.pos[lane] = pos;
-        if (lane == WAVE - 1) { lds.fuse_mask = s.fuse_mask; lds.fast = s.fast; }
+        if (lane == WAVE - 1) { lds.fuse_mask = s.fuse_mask; lds.fast = s.fast; lds.slot0 = s.n_end0 + first; }
         lds.h0[lane] = h0;
         lds.h1[lane] = h1;
-
-        if (s.fast) {
-            /* apply_committed_entries (dare_server.c:1815-1974) for the round, straight from the
-             * registers that built the entries: record + stream hash for the leader (kind 1:
-             * proxy_update_state) and every fused follower (kind 2: proxy_do_action) */
-            const uint32_t len = T - APUS_HDR;
-            uint64_t mix1 = 0, mix2 = 0;
-            if (active) {
-                const uint32_t di = (uint32_t)slot & E.dir_mask;
-                const uint4 r0v = make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32));
-                const uint32_t tail = (uint32_t)d.clt_id | (type << 16);
-                uint4 *rp = (uint4 *)&Ld.apply[di];
-                rp[0] = r0v; rp[1] = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), len, tail | (1u << 24));
-                for (uint32_t m = s.fuse_mask; m; m &= m - 1) {
-                    uint4 *fp = (uint4 *)&E.rep[__builtin_ctz(m)].apply[di];
-                    fp[0] = r0v; fp[1] = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), len, tail | (2u << 24));
-                }
-                mix1 = apus_apply_mix(slot, pos, idx, len, d.clt_id, (uint8_t)type, 1);
-                mix2 = apus_apply_mix(slot, pos, idx, len, d.clt_id, (uint8_t)type, 2);
-            }
-            /* the round's contribution to the stream hashes; the call's record blocks fold them
-             * into the control blocks (a thousand workgroups adding to the same words would queue
-             * up in one L2 channel), the upcall counters advance by the batch size there too */
-            const uint64_t sum1 = wave_sum(mix1), sum2 = wave_sum(mix2);
-            if (lane == 0) {     /* write-through: a record block of the same launch may read them */
-                __hip_atomic_store(&E.round_hash[2 * r], sum1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&E.round_hash[2 * r + 1], sum2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
 
         if (active) {
             const uint32_t di = (uint32_t)slot & E.dir_mask;
@@ -770,6 +745,39 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
             const uint32_t so = min(16u * j, Te - 16u);
             const uint4 v = so == 0 ? lds.h0[e] : so == 16 ? lds.h1[e] : so == 32 ? make_uint4(0, 0, 0, 0) : pv[k];
             store_unit(e, so, v);
+        }
+    }
+    if (lds.fast && tid >= 3 * WAVE) {
+        /* apply_committed_entries (dare_server.c:1815-1974) for the round, by the last wave while
+         * the first stores are in flight: what the replicas would read back from their logs is
+         * still on chip -- record + stream hash for the leader (kind 1: proxy_update_state) and
+         * every fused follower (kind 2: proxy_do_action) */
+        const bool act = lane < nr;
+        uint64_t mix1 = 0, mix2 = 0;
+        if (act) {
+            const uint64_t slot = lds.slot0 + lane, pos = lds.pos[lane];
+            const uint4 h0 = lds.h0[lane], h1 = lds.h1[lane];
+            const uint64_t idx = (uint64_t)h0.x | ((uint64_t)h0.y << 32);
+            const uint32_t len = lds.T[lane] - APUS_HDR;
+            const uint32_t tail = h1.z & 0x00FFFFFFu;                    /* clt_id | type << 16 */
+            const uint32_t di = (uint32_t)slot & E.dir_mask;
+            const uint4 r0v = make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32));
+            uint4 *rp = (uint4 *)&Ld.apply[di];
+            rp[0] = r0v; rp[1] = make_uint4(h0.x, h0.y, len, tail | (1u << 24));
+            for (uint32_t m = fuse; m; m &= m - 1) {
+                uint4 *fp = (uint4 *)&E.rep[__builtin_ctz(m)].apply[di];
+                fp[0] = r0v; fp[1] = make_uint4(h0.x, h0.y, len, tail | (2u << 24));
+            }
+            mix1 = apus_apply_mix(slot, pos, idx, len, (uint16_t)tail, (uint8_t)(tail >> 16), 1);
+            mix2 = apus_apply_mix(slot, pos, idx, len, (uint16_t)tail, (uint8_t)(tail >> 16), 2);
+        }
+        /* the round's contribution to the stream hashes; the call's record blocks fold them
+         * into the control blocks (a thousand workgroups adding to the same words would queue
+         * up in one L2 channel), the upcall counters advance by the batch size there too */
+        const uint64_t sum1 = wave_sum(mix1), sum2 = wave_sum(mix2);
+        if (lane == 0) {     /* write-through: a record block of the same launch may read them */
+            __hip_atomic_store(&E.round_hash[2 * r], sum1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&E.round_hash[2 * r + 1], sum2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     for (uint32_t u = tid + PF * 256; u < utotal; u += 256) {
