@@ -62,6 +62,27 @@ def test_repeated_runs_stay_bit_exact(eng_factory):
         lockstep(tr, eng)
 
 
+def test_call_longer_than_one_launch(eng_factory):
+    """A run of more than 1024 rounds between two prune ticks: apus_gpu_run_rounds splits it into
+    several k_call launches (only the first carries the deferred tick)."""
+    from tests.parity import lockstep, compare_apply_tail
+    eng = eng_factory(3, 8 << 20)
+    tr = T.steady_trace(3, 4 * 2600, (16, 40, 100), 8, 4, log_len=8 << 20, prune_bytes=512 << 10)
+    n_long = 0
+    ev = tr.events
+    i = 0
+    while i < len(ev):
+        j = i
+        while j < len(ev) and ev[j][0] == "ROUND":
+            j += 1
+        n_long += (j - i) > 1024
+        i = max(j, i + 1)
+    assert n_long >= 1, "the trace should hold a run of more than 1024 rounds"
+    cl = lockstep(tr, eng)
+    for r in range(3):
+        compare_apply_tail(eng, cl, r)
+
+
 def test_rounds_one_by_one_match_coalesced(eng_factory):
     from tests.parity import lockstep
     eng = eng_factory(3, 1 << 16)
