@@ -45,6 +45,7 @@ struct apus_engine {
     void *d_req, *d_req_len, *d_arena, *d_round_first, *d_round_prefix;
     uint64_t n_reqs, n_rounds_staged;
     std::vector<uint32_t> h_round_first;
+    std::vector<uint64_t> h_round_prefix;      /* byte prefix of the staged rounds */
     /* graphs */
     std::vector<hipGraphExec_t> graphs;
     bool capturing;
@@ -273,7 +274,8 @@ extern "C" int apus_gpu_stage(apus_engine_t *e, const apus_req_t *reqs, uint64_t
     HIPCHK(hipMemcpy(e->d_round_first, e->h_round_first.data(), sizeof(uint32_t) * (2 * n_rounds + 1), hipMemcpyHostToDevice));
     {
         /* byte prefix of the rounds: lets an append block place its round without a scan */
-        std::vector<uint64_t> pfx(n_rounds + 1, 0);
+        std::vector<uint64_t> &pfx = e->h_round_prefix;
+        pfx.assign(n_rounds + 1, 0);
         for (uint64_t r = 0; r < n_rounds; r++) pfx[r + 1] = pfx[r] + e->h_round_first[n_rounds + 1 + r];
         if ((rc = renew(&e->d_round_prefix, sizeof(uint64_t) * (n_rounds + 1)))) return rc;
         HIPCHK(hipMemcpy(e->d_round_prefix, pfx.data(), sizeof(uint64_t) * (n_rounds + 1), hipMemcpyHostToDevice));
@@ -385,8 +387,12 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
          * apply, per-round records (k_call's block roles) */
         /* the scan / apply blocks only work when the replicas are not in step: a modest number, grid-stride */
         const uint32_t nS = cap_grid(n, 256, 32), nA = cap_grid(n, 1024, 16), nR = cap_grid(R, 256, 8);
-        hipLaunchKernelGGL(k_call, dim3(1 + R + nR + 1 + nS + nA * popc(rm)), dim3(256), 0, e->stream, e->d, c0, R, fm, tick, rm,
-                           nS, nA, nR);
+        /* rounds with many 16-byte units are shared by SP workgroups each (a launch of a few hundred
+         * large rounds would leave most of the 256 CUs idle) */
+        const uint64_t units = (e->h_round_prefix[c0 + R] - e->h_round_prefix[c0]) / 16;
+        const uint32_t SP = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (units / R + 511) / 768));
+        hipLaunchKernelGGL(k_call, dim3(1 + R * SP + nR + 1 + nS + nA * popc(rm)), dim3(256), 0, e->stream, e->d, c0, R, fm, tick, rm,
+                           nS, nA, nR, SP);
         if (tl) HIPCHK(hipEventRecord(tl->b, e->stream));
     }
     HIPCHK(hipGetLastError());

@@ -599,7 +599,7 @@ __device__ static inline uint32_t wait_sequenced(const EngDev &E, uint32_t b, ui
  * directory, (in step) the apply records, and the stores. */
 template <bool IN_LAUNCH>
 __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t r,
-                                           AppendLds &lds, SeqLds *sq, uint32_t tick)
+                                           AppendLds &lds, SeqLds *sq, uint32_t tick, uint32_t slice = 0, uint32_t n_slices = 1)
 {
     const uint32_t tid = threadIdx.x, lane = lane_id();
     const RepDev &Ld = E.rep[E.leader];
@@ -620,7 +620,7 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
              * the sequencer block may start changing the control words (it waits for these tickets) */
             seq_w0_stage(E, r0, R, push_mask, r, *sq);
             if (r == 0) STAMP(1, 3);
-            if (tid == 0) __hip_atomic_fetch_add(E.tick_lines + (r & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_fetch_add(E.tick_lines + ((r * n_slices + slice) & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         /* one lane of wave 1 works the call's SeqOut out while wave 0 lays the round out */
@@ -641,14 +641,19 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
     __syncthreads();
 
     /* ---- phase 2 (all): the first payload units into registers ---- */
-    const uint32_t utotal = lds.ubase[WAVE];
+    /* a round with many units is shared by n_slices workgroups: each lays the round out for
+     * itself and copies a contiguous share of the units; slice 0 also writes the directory, the
+     * ACK words and (in step) the apply records */
+    const uint32_t uall = lds.ubase[WAVE];
+    const uint32_t ushare = ((uall + n_slices - 1) / n_slices + 255u) & ~255u;
+    const uint32_t ubeg = min(uall, slice * ushare), utotal = min(uall, ubeg + ushare);
     const uint32_t unu = lds.uniform_nu;
     constexpr int PF = 2;
     uint4 pv[PF];
 #pragma unroll
     for (int k = 0; k < PF; k++) {
         pv[k] = make_uint4(0, 0, 0, 0);
-        const uint32_t u = tid + (uint32_t)k * 256;
+        const uint32_t u = ubeg + tid + (uint32_t)k * 256;
         if (u < utotal) {
             uint32_t e, j;
             locate_unit(lds, u, unu, nr, e, j);
@@ -689,7 +694,7 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
         lds.h0[lane] = h0;
         lds.h1[lane] = h1;
 
-        if (active) {
+        if (active && slice == 0) {
             const uint32_t di = (uint32_t)slot & E.dir_mask;
             const uint32_t dl = T | ((uint32_t)E.leader << 24);     /* derived: total bytes | sender << 24 */
             Ld.dir_off[di] = pos; Ld.dir_len[di] = dl; Ld.ack[di] = s.fuse_mask;     /* ACK bits of the fused followers */
@@ -737,7 +742,7 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
     };
 #pragma unroll
     for (int k = 0; k < PF; k++) {
-        const uint32_t u = tid + (uint32_t)k * 256;
+        const uint32_t u = ubeg + tid + (uint32_t)k * 256;
         if (u < utotal) {
             uint32_t e, j;
             locate_unit(lds, u, unu, nr, e, j);
@@ -747,7 +752,7 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
             store_unit(e, so, v);
         }
     }
-    if (lds.fast && tid >= 3 * WAVE) {
+    if (lds.fast && slice == 0 && tid >= 3 * WAVE) {
         /* apply_committed_entries (dare_server.c:1815-1974) for the round, by the last wave while
          * the first stores are in flight: what the replicas would read back from their logs is
          * still on chip -- record + stream hash for the leader (kind 1: proxy_update_state) and
@@ -780,7 +785,7 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
             __hip_atomic_store(&E.round_hash[2 * r + 1], sum2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    for (uint32_t u = tid + PF * 256; u < utotal; u += 256) {
+    for (uint32_t u = ubeg + tid + PF * 256; u < utotal; u += 256) {
         uint32_t e, j;
         locate_unit(lds, u, unu, nr, e, j);
         const uint32_t Te = lds.T[e];
@@ -1319,10 +1324,10 @@ __device__ static inline void wait_ticket(const EngDev &E, int which, uint32_t w
 }
 /* the append blocks' arrivals are spread over 32 counters in 32 cache lines (a thousand
  * workgroups finishing together would queue up on one word): lane i < 32 waits for counter i */
-__device__ static inline void wait_append(const EngDev &E, uint32_t R)
+__device__ static inline void wait_append(const EngDev &E, uint32_t n_blocks)
 {
     if (threadIdx.x < 32) {
-        const uint32_t quota = R / 32 + (threadIdx.x < (R & 31u) ? 1u : 0u);
+        const uint32_t quota = n_blocks / 32 + (threadIdx.x < (n_blocks & 31u) ? 1u : 0u);
         unsigned long long spins = 0;
         while (__hip_atomic_load(E.tick_lines + threadIdx.x * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < quota) {
             __builtin_amdgcn_s_sleep(8);
@@ -1437,7 +1442,8 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
 
 /* k_call: a whole run_rounds call (R <= 1024 rounds) in ONE launch.  Block roles by index:
  *   0                         the sequencer
- *   [1, R]                    one round each: append + push (+ fused persist/ACK, + apply when in step)
+ *   [1, R * SP]               append + push (+ fused persist/ACK, + apply when in step): one round each,
+ *                             or SP workgroups per round when the rounds are large (host's choice)
  *   [.., + nR)                the leader's per-round record (+ fast-path hash fold); recorder 0 is
  *                             also the janitor: last to leave, it clears the call's counters
  *   next                      the bookkeeper
@@ -1456,7 +1462,7 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
  * append blocks post before they wait for anything); workgroups are dispatched in index order per
  * XCD, so what a waiting block needs is already running or done: no co-residency assumption. */
 __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t tick,
-                                              uint32_t rmask, uint32_t nS, uint32_t nA, uint32_t nR)
+                                              uint32_t rmask, uint32_t nS, uint32_t nA, uint32_t nR, uint32_t SP)
 {
     __shared__ SeqLds sq;
     __shared__ union CallLds {
@@ -1468,17 +1474,19 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
     const uint32_t ny = (uint32_t)__popc(rmask);
     const uint32_t fmask = push_mask;
     ApplyCtx &c = l.t.c;
-    /* blocks that fetch the control words themselves: R append + nR record + 1 bookkeeper */
-    const uint32_t n_readers = R + nR + 1;
+    const uint32_t nAB = R * SP;                               /* append blocks: SP per round */
+    /* blocks that fetch the control words themselves: append + nR record + 1 bookkeeper */
+    const uint32_t n_readers = nAB + nR + 1;
     /* blocks that sign off with T_PASS: everybody but the append blocks and the janitor */
     const uint32_t n_pass = 1 + (nR - 1) + 1 + nS + nA * ny;
 
-    if (b >= 1 && b <= R) {                                    /* ---- append + push ---- */
-        if (b == R) STAMP(6, 0);
-        append_round<true>(E, r0, R, push_mask, b - 1, l.app, &sq, tick);
-        if (b == R) STAMP(6, 1);
-        post_append(E, b - 1, l.app.fast == 0);
-        if (b == R) STAMP(6, 2);
+    if (b >= 1 && b <= nAB) {                                  /* ---- append + push ---- */
+        const uint32_t ab = b - 1, r = ab / SP, slice = ab - r * SP;
+        if (b == nAB) STAMP(6, 0);
+        append_round<true>(E, r0, R, push_mask, r, l.app, &sq, tick, slice, SP);
+        if (b == nAB) STAMP(6, 1);
+        post_append(E, ab, l.app.fast == 0);
+        if (b == nAB) STAMP(6, 2);
         return;
     }
     if (b == 0) {                                              /* ---- the sequencer ---- */
@@ -1493,10 +1501,10 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
         post_ticket(E, T_PASS, false);
         return;
     }
-    uint32_t q = b - 1 - R;
+    uint32_t q = b - 1 - nAB;
     if (q < nR) {                                              /* ---- per-round records ---- */
         if (q == 0) STAMP(5, 0);
-        seq_local(E, r0, R, push_mask, tick, 0, R + q, sq);
+        seq_local(E, r0, R, push_mask, tick, 0, nAB + q, sq);
         if (q == 0) STAMP(5, 1);
         /* the rounds' byte prefix: the host-staged one, or the block's own scan */
         const uint64_t *virt = sq.ok ? E.round_prefix + r0 : sq.virt;
@@ -1507,12 +1515,12 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
             finish_records(E, r0, R, sq.out.vis, (uint64_t)q * blockDim.x + tid, (uint64_t)nR * blockDim.x, sq.out,
                            sq.out.rec_base, virt, vbase);
             if (q == 0) STAMP(5, 2);
-            wait_append(E, R);
+            wait_append(E, nAB);
             if (q == 0) STAMP(5, 3);
             fold_round_hashes(E, R, q, nR, sq.out.fuse_mask);
             if (q == 0) STAMP(5, 4);
         } else {
-            wait_append(E, R);
+            wait_append(E, nAB);
             wait_ticket(E, T_SCAN, nS);
             if (tid == 0)
                 sq.out.first_fail = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1546,7 +1554,7 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
             static const int words[8] = {H_N_PERSIST, H_N_COMMIT, H_N_APPLY, H_STORE_COUNT, H_HEAD, H_END, H_N_END, H_HEAD_SLOT};
             c.fw[f][j] = ((fmask >> f) & 1u) ? E.rep[f].hdr[words[j]] : 0;
         }
-        seq_local(E, r0, R, push_mask, tick, 0, R + nR, sq);
+        seq_local(E, r0, R, push_mask, tick, 0, nAB + nR, sq);
         STAMP(3, 1);
         if (sq.out.fast) {
             /* in step: everything the bookkeeping needs follows from the sequencing it just worked
@@ -1590,7 +1598,7 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
             if (tid == 0) l.t.sc[3] = E.seq->tail_needed;
             __syncthreads();
             if (l.t.sc[3]) {
-                wait_append(E, R);
+                wait_append(E, nAB);
                 persist_commit_blocks(E, fmask, q, nS, l.t.np, l.t.sc);
             }
             post_ticket(E, T_SCAN, l.t.sc[3] != 0);
