@@ -390,7 +390,9 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
         /* rounds with many 16-byte units are shared by SP workgroups each (a launch of a few hundred
          * large rounds would leave most of the 256 CUs idle) */
         const uint64_t units = (e->h_round_prefix[c0 + R] - e->h_round_prefix[c0]) / 16;
-        const uint32_t SP = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (units / R + 511) / 768));
+        const char *sp_env = getenv("APUS_SP_UNITS");                        /* tuning knob: units per workgroup */
+        const uint64_t sp_units = sp_env ? (uint64_t)atoi(sp_env) : 768;
+        const uint32_t SP = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (units / R + sp_units * 2 / 3) / sp_units));
         hipLaunchKernelGGL(k_call, dim3(1 + R * SP + nR + 1 + nS + nA * popc(rm)), dim3(256), 0, e->stream, e->d, c0, R, fm, tick, rm,
                            nS, nA, nR, SP);
         if (tl) HIPCHK(hipEventRecord(tl->b, e->stream));
