@@ -83,10 +83,11 @@ static int flush_tick(apus_engine *e);
 extern "C" int apus_gpu_persist_stop(apus_engine_t *e);
 
 template <typename T>
-static int dev_alloc(apus_engine *e, T **out, size_t bytes, bool zero = true)
+static int dev_alloc(apus_engine *e, T **out, size_t bytes, bool zero = true, unsigned ext_flags = 0)
 {
     void *p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) return APUS_E_NOMEM;
+    if (ext_flags) { if (hipExtMallocWithFlags(&p, bytes, ext_flags) != hipSuccess) return APUS_E_NOMEM; }
+    else if (hipMalloc(&p, bytes) != hipSuccess) return APUS_E_NOMEM;
     if (zero && hipMemset(p, 0, bytes) != hipSuccess) return APUS_E_HIP;
     e->allocs.push_back(p);
     *out = (T *)p;
@@ -144,7 +145,9 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
         RepDev &r = e->d.rep[i];
         r.idx = i;
         if ((rc = dev_alloc(e, &r.ring, L + 4096))) break;
-        if ((rc = dev_alloc(e, &r.hdr, sizeof(uint64_t) * 64))) break;
+        /* control blocks live in uncached device memory: stores reach memory without a release, so
+         * that blocks of a LATER segment of the same launch (k_step) can read them with bypassing loads */
+        if ((rc = dev_alloc(e, &r.hdr, sizeof(uint64_t) * 64, true, hipDeviceMallocUncached))) break;
         if ((rc = dev_alloc(e, &r.dir_off, sizeof(uint64_t) * e->dir_cap))) break;
         if ((rc = dev_alloc(e, &r.dir_len, sizeof(uint32_t) * e->dir_cap))) break;
         if ((rc = dev_alloc(e, &r.ack, sizeof(uint32_t) * e->dir_cap))) break;
@@ -165,7 +168,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     if (!rc) rc = dev_alloc(e, &e->d.round_hash, sizeof(uint64_t) * 2 * e->max_rounds);
     if (!rc) rc = dev_alloc(e, &e->d.rec_end, sizeof(uint64_t) * e->d.rec_cap);
     if (!rc) rc = dev_alloc(e, &e->d.rec_commit, sizeof(uint64_t) * e->d.rec_cap);
-    if (!rc) rc = dev_alloc(e, &e->d.rec_count, 64);
+    if (!rc) rc = dev_alloc(e, &e->d.rec_count, 64, true, hipDeviceMallocUncached);
     if (rc) { apus_gpu_destroy(e); return rc; }
     *out = e;
     rc = apus_gpu_reset(e);

@@ -51,6 +51,13 @@
 #define STAMPW(K, k, T) do { } while (0)
 #endif
 
+/* a control word (uncached device memory) read past L1 / L2: blocks of one launch may read words
+ * an earlier part of the same launch wrote */
+__device__ static inline uint64_t ldw(const uint64_t *p)
+{
+    return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 /* E.ticket words */
 enum { T_APPLY = 1, T_PASS = 2, T_SCAN = 3, T_DONE = 4 };
 
@@ -260,15 +267,15 @@ __device__ static inline void seq_stage(const EngDev &E, uint64_t r0, uint32_t R
     if (blockIdx.x == 0) STAMP(0, 0);
     uint64_t st0 = 0, st1 = 0, st2 = 0, st3 = ~0ull, st4 = 0;
     for (uint32_t i = tid; i < R && i < 1024; i += blockDim.x) q.bytes0[i] = rb[i];   /* the rounds' byte totals */
-    if (tid < 64) st0 = hdr[tid];
+    if (tid < 64) st0 = ldw(&hdr[tid]);
     else if (tid < 64 + APUS_DEV_MAX_SERVERS) {
         const uint32_t f_ = tid - 64;
         if (((push_mask | sample_mask) >> f_) & 1u) {
             const uint64_t *fh_ = E.rep[f_].hdr;
-            st0 = fh_[H_END]; st1 = fh_[H_N_END]; st2 = fh_[H_APPLY];
-            if ((push_mask >> f_) & 1u) { st3 = fh_[H_N_PERSIST]; st4 = fh_[H_N_APPLY]; }
+            st0 = ldw(&fh_[H_END]); st1 = ldw(&fh_[H_N_END]); st2 = ldw(&fh_[H_APPLY]);
+            if ((push_mask >> f_) & 1u) { st3 = ldw(&fh_[H_N_PERSIST]); st4 = ldw(&fh_[H_N_APPLY]); }
         }
-    } else if (tid == 96) st0 = *E.rec_count;
+    } else if (tid == 96) st0 = ldw(E.rec_count);
     else if (tid == 97 && need_tail) st0 = (rf[R] > rf[0]) ? E.req_len[rf[R] - 1] : 0;   /* two dependent loads: only the real sequencer */
     if (tid < 64) s_lh[tid] = st0;
     else if (tid < 64 + APUS_DEV_MAX_SERVERS) { s_fw[tid - 64][0] = st0; s_fw[tid - 64][1] = st1; s_fw[tid - 64][2] = st2; s_fw[tid - 64][3] = st3; s_fw[tid - 64][4] = st4; }
@@ -479,14 +486,14 @@ __device__ static inline void seq_w0_stage(const EngDev &E, uint64_t r0, uint32_
     auto fw_word = [&](uint32_t k) -> uint64_t {
         const uint32_t f = k / 5, j = k - f * 5;
         const int words[5] = {H_END, H_N_END, H_APPLY, H_N_PERSIST, H_N_APPLY};
-        if ((push_mask >> f) & 1u) return E.rep[f].hdr[words[j]];
+        if ((push_mask >> f) & 1u) return ldw(&E.rep[f].hdr[words[j]]);
         return j == 3 ? ~0ull : 0ull;
     };
-    const uint64_t v0 = hdr[lane];
+    const uint64_t v0 = ldw(&hdr[lane]);
     const uint64_t f0 = fw_word(lane);
     uint64_t x = 0;
     if (lane == 0) x = fw_word(64);
-    else if (lane == 1) x = *E.rec_count;
+    else if (lane == 1) x = ldw(E.rec_count);
     else if (lane == 2) x = E.round_prefix[r0];
     else if (lane == 3) x = E.round_prefix[r0 + my_r];
     else if (lane == 4) x = E.round_prefix[r0 + R];
@@ -1552,7 +1559,7 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
         if (tid >= 128 && tid < 128 + 8 * APUS_DEV_MAX_SERVERS) {
             const uint32_t f = (tid - 128) >> 3, j = (tid - 128) & 7;
             static const int words[8] = {H_N_PERSIST, H_N_COMMIT, H_N_APPLY, H_STORE_COUNT, H_HEAD, H_END, H_N_END, H_HEAD_SLOT};
-            c.fw[f][j] = ((fmask >> f) & 1u) ? E.rep[f].hdr[words[j]] : 0;
+            c.fw[f][j] = ((fmask >> f) & 1u) ? ldw(&E.rep[f].hdr[words[j]]) : 0;
         }
         seq_local(E, r0, R, push_mask, tick, 0, nAB + nR, sq);
         STAMP(3, 1);
