@@ -191,6 +191,53 @@ __device__ static inline uint64_t block_incl_scan(uint64_t v, uint64_t *s_tot /*
  * scan over the rounds' byte totals (staged with the batch: the admission side knows every
  * request's size, so a round arrives with its total), the wrap point, the leader's
  * control words and the per-round end record.                                  */
+/* A control-state snapshot: everything a block stages before it sequences a call -- the leader's
+ * control block, eight words per follower, the record count.  In a multi-segment launch (k_step)
+ * the bookkeeper of segment k writes snapshot k+1 (write-once, uncached memory), so later
+ * segments never read words an earlier one is still changing. */
+#define SNAP_FW        64
+#define SNAP_REC       (SNAP_FW + 8 * APUS_DEV_MAX_SERVERS)
+#define SNAP_WORDS     (SNAP_REC + 1)
+#define SNAP_STRIDE    192            /* u64 words per snapshot */
+/* follower words in snapshot / bookkeeper order */
+enum { FW_END = 0, FW_N_END, FW_APPLY, FW_N_PERSIST, FW_N_APPLY, FW_N_COMMIT, FW_STORE_COUNT, FW_HEAD };
+__device__ static inline int fw_hdr_word(uint32_t j)
+{
+    switch (j) {
+    case FW_END: return H_END;            case FW_N_END: return H_N_END;        case FW_APPLY: return H_APPLY;
+    case FW_N_PERSIST: return H_N_PERSIST; case FW_N_APPLY: return H_N_APPLY;    case FW_N_COMMIT: return H_N_COMMIT;
+    case FW_STORE_COUNT: return H_STORE_COUNT; default: return H_HEAD;
+    }
+}
+/* a staged control word: from a snapshot, or (snap == nullptr) from the live control blocks */
+__device__ static inline uint64_t stage_leader_word(const EngDev &E, const uint64_t *snap, uint32_t i)
+{
+    return snap ? ldw(&snap[i]) : ldw(&E.rep[E.leader].hdr[i]);
+}
+__device__ static inline uint64_t stage_follower_word(const EngDev &E, const uint64_t *snap, uint32_t f, uint32_t j)
+{
+    return snap ? ldw(&snap[SNAP_FW + 8 * f + j]) : ldw(&E.rep[f].hdr[fw_hdr_word(j)]);
+}
+__device__ static inline uint64_t stage_rec_count(const EngDev &E, const uint64_t *snap)
+{
+    return snap ? ldw(&snap[SNAP_REC]) : ldw(E.rec_count);
+}
+
+/* what a batch of n entries does to the leader's control block (log_append_entry's offsets and
+ * the leader side of persist_new_entries, dare_server.c:1792-1810) */
+__device__ static inline void seq_apply_batch(uint64_t *lh, uint64_t end_new, uint64_t t_last, uint64_t n_end0, uint32_t n,
+                                              uint64_t idx0, int64_t estar)
+{
+    lh[H_END] = end_new;
+    lh[H_TAIL] = end_new - t_last;
+    lh[H_N_END] = n_end0 + n;
+    lh[H_LAST_IDX] = (estar < 0) ? idx0 + n - 1 : 1 + (uint64_t)(n - 1 - estar);
+    lh[H_PREV_HEAD] = 0;
+    lh[H_OLD_END] = end_new;
+    lh[H_N_PERSIST] = n_end0 + n;
+    lh[H_STORE_COUNT] += n;
+}
+
 struct SeqLds {
     uint64_t lh[64];                      /* the leader's control block, kept current */
     uint64_t fw[APUS_DEV_MAX_SERVERS][5]; /* followers: end, n_end, apply, n_persist, n_apply */
@@ -227,6 +274,16 @@ __device__ static inline void seq_in_step(const EngDev &E, const uint64_t *lh, c
     for (uint32_t m = push_mask; m; m &= m - 1) in_step = in_step && fw[__builtin_ctz(m)][4] == n_pre;
 }
 
+/* sample_apply_offsets, applied to an LDS copy of the leader's control block (the stores to
+ * the control block itself are the sequencer's) */
+__device__ static inline void sample_into_copy(const EngDev &E, uint64_t *lh, uint32_t sample_mask, uint32_t i, uint64_t staged_apply)
+{
+    const uint32_t bitmask = (uint32_t)lh[H_CID_BITMASK];
+    if (i >= E.group_size) return;
+    if (i == E.leader || !((bitmask >> i) & 1u)) lh[H_APPLY_OFFSETS + i] = lh[H_APPLY];
+    else if ((sample_mask >> i) & 1u) lh[H_APPLY_OFFSETS + i] = staged_apply;
+}
+
 /* the batch-level switches of SeqOut; hidden = the batch ends exactly on len (its last round
  * stays invisible and is not pushed as acknowledged) */
 struct SeqFlags { uint32_t fuse_batch, tail_needed, fast; };
@@ -250,7 +307,7 @@ __device__ static inline SeqFlags seq_flags(const EngDev &E, uint32_t push_mask,
  * append block does that for itself instead of waiting for the sequencer block (q.out, and
  * q.my_virt = where round my_r starts). */
 __device__ static inline void seq_stage(const EngDev &E, uint64_t r0, uint32_t R, uint32_t push_mask,
-                                        uint32_t sample_mask, SeqLds &q, bool need_tail = true)
+                                        uint32_t sample_mask, SeqLds &q, bool need_tail = true, const uint64_t *snap = nullptr)
 {
     uint64_t (&s_lh)[64] = q.lh;
     uint64_t (&s_fw)[APUS_DEV_MAX_SERVERS][5] = q.fw;
@@ -258,7 +315,6 @@ __device__ static inline void seq_stage(const EngDev &E, uint64_t r0, uint32_t R
     uint32_t &s_head_round = q.head_round;
     unsigned int &s_rstar = q.rstar;
     const uint32_t tid = threadIdx.x;
-    const uint64_t *hdr = E.rep[E.leader].hdr;
     const uint32_t *rf = E.round_first + r0;
     const uint32_t *rb = E.round_bytes + r0;
 
@@ -267,15 +323,15 @@ __device__ static inline void seq_stage(const EngDev &E, uint64_t r0, uint32_t R
     if (blockIdx.x == 0) STAMP(0, 0);
     uint64_t st0 = 0, st1 = 0, st2 = 0, st3 = ~0ull, st4 = 0;
     for (uint32_t i = tid; i < R && i < 1024; i += blockDim.x) q.bytes0[i] = rb[i];   /* the rounds' byte totals */
-    if (tid < 64) st0 = ldw(&hdr[tid]);
+    if (tid < 64) st0 = stage_leader_word(E, snap, tid);
     else if (tid < 64 + APUS_DEV_MAX_SERVERS) {
         const uint32_t f_ = tid - 64;
         if (((push_mask | sample_mask) >> f_) & 1u) {
-            const uint64_t *fh_ = E.rep[f_].hdr;
-            st0 = ldw(&fh_[H_END]); st1 = ldw(&fh_[H_N_END]); st2 = ldw(&fh_[H_APPLY]);
-            if ((push_mask >> f_) & 1u) { st3 = ldw(&fh_[H_N_PERSIST]); st4 = ldw(&fh_[H_N_APPLY]); }
+            st0 = stage_follower_word(E, snap, f_, FW_END); st1 = stage_follower_word(E, snap, f_, FW_N_END);
+            st2 = stage_follower_word(E, snap, f_, FW_APPLY);
+            if ((push_mask >> f_) & 1u) { st3 = stage_follower_word(E, snap, f_, FW_N_PERSIST); st4 = stage_follower_word(E, snap, f_, FW_N_APPLY); }
         }
-    } else if (tid == 96) st0 = ldw(E.rec_count);
+    } else if (tid == 96) st0 = stage_rec_count(E, snap);
     else if (tid == 97 && need_tail) st0 = (rf[R] > rf[0]) ? E.req_len[rf[R] - 1] : 0;   /* two dependent loads: only the real sequencer */
     if (tid < 64) s_lh[tid] = st0;
     else if (tid < 64 + APUS_DEV_MAX_SERVERS) { s_fw[tid - 64][0] = st0; s_fw[tid - 64][1] = st1; s_fw[tid - 64][2] = st2; s_fw[tid - 64][3] = st3; s_fw[tid - 64][4] = st4; }
@@ -334,6 +390,9 @@ __device__ static inline void seq_body(const EngDev &E, uint64_t r0, uint32_t R,
                 sample_apply_offsets(E, s_lh, sample_mask, tid - 64, &s_fw[tid - 64][2]);
             __syncthreads();                             /* the sampling lanes read the pre-tick block */
             if (tid == 0) s_head_round = control_append<FX>(E, 1, 3, 0, 0, push_mask, s_lh, s_misc[0], fuse_mask, in_step, write_rec).n;
+            __syncthreads();
+            /* the offsets sampled above are what the NEXT tick decides from: note them in the LDS copy too */
+            if (tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS) sample_into_copy(E, s_lh, sample_mask, tid - 64, s_fw[tid - 64][2]);
             __syncthreads();
         }
     }
@@ -429,17 +488,15 @@ __device__ static inline void seq_body(const EngDev &E, uint64_t r0, uint32_t R,
         q.out = s;
         q.end_new = n ? end_new : e0;
         if (FX) *E.seq = s;
-        if (FX && n) {
-            const uint64_t t_last = APUS_HDR + s_misc[1];
-            hdr[H_END] = end_new;
-            hdr[H_TAIL] = end_new - t_last;
-            hdr[H_N_END] = n_end0 + n;
-            hdr[H_LAST_IDX] = (estar < 0) ? idx0 + n - 1 : 1 + (uint64_t)(n - 1 - estar);
-            hdr[H_PREV_HEAD] = 0;
-            /* leader side of persist_new_entries (dare_server.c:1792-1810) */
-            hdr[H_OLD_END] = end_new;
-            hdr[H_N_PERSIST] = n_end0 + n;
-            hdr[H_STORE_COUNT] = s_lh[H_STORE_COUNT] + n;
+        if (n) {
+            /* the LDS copy becomes the control block as it is after the batch; the sequencer
+             * proper stores the words that changed */
+            seq_apply_batch(s_lh, end_new, APUS_HDR + s_misc[1], n_end0, n, idx0, estar);
+            if (FX) {
+                hdr[H_END] = s_lh[H_END]; hdr[H_TAIL] = s_lh[H_TAIL]; hdr[H_N_END] = s_lh[H_N_END];
+                hdr[H_LAST_IDX] = s_lh[H_LAST_IDX]; hdr[H_PREV_HEAD] = 0; hdr[H_OLD_END] = s_lh[H_OLD_END];
+                hdr[H_N_PERSIST] = s_lh[H_N_PERSIST]; hdr[H_STORE_COUNT] = s_lh[H_STORE_COUNT];
+            }
         }
         s_kstar = kstar; s_w = w;
     }
@@ -479,32 +536,36 @@ __global__ __launch_bounds__(1024) void k_sequence(const EngDev E, uint64_t r0, 
  * seq_w0_stage: the inputs, one round trip, by the 64 lanes.  seq_w0_decide: one lane, the same
  * decision code as the sequencer (seq_in_step, control_append<false>, seq_flags).  If the batch
  * could reach len (q.ok = 0) the block falls back to seq_body<false> on the same staged inputs. */
-__device__ static inline void seq_w0_stage(const EngDev &E, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t my_r, SeqLds &q)
+__device__ static inline void seq_w0_stage(const EngDev &E, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t my_r, SeqLds &q,
+                                           const uint64_t *snap = nullptr, bool need_tail = false)
 {
     const uint32_t lane = lane_id();
-    const uint64_t *hdr = E.rep[E.leader].hdr;
-    auto fw_word = [&](uint32_t k) -> uint64_t {
+    auto fw_word = [&](uint32_t k) -> uint64_t {                 /* q.fw[f][j], j = FW_END .. FW_N_APPLY */
         const uint32_t f = k / 5, j = k - f * 5;
-        const int words[5] = {H_END, H_N_END, H_APPLY, H_N_PERSIST, H_N_APPLY};
-        if ((push_mask >> f) & 1u) return ldw(&E.rep[f].hdr[words[j]]);
-        return j == 3 ? ~0ull : 0ull;
+        if ((push_mask >> f) & 1u) return stage_follower_word(E, snap, f, j);
+        return j == FW_N_PERSIST ? ~0ull : 0ull;
     };
-    const uint64_t v0 = ldw(&hdr[lane]);
+    const uint64_t v0 = stage_leader_word(E, snap, lane);
     const uint64_t f0 = fw_word(lane);
     uint64_t x = 0;
     if (lane == 0) x = fw_word(64);
-    else if (lane == 1) x = ldw(E.rec_count);
+    else if (lane == 1) x = stage_rec_count(E, snap);
     else if (lane == 2) x = E.round_prefix[r0];
     else if (lane == 3) x = E.round_prefix[r0 + my_r];
     else if (lane == 4) x = E.round_prefix[r0 + R];
     else if (lane == 5) x = E.round_first[r0];
     else if (lane == 6) x = E.round_first[r0 + R];
+    else if (lane == 7 && need_tail) {                              /* len of the batch's last request (for H_TAIL) */
+        const uint32_t a = E.round_first[r0], b = E.round_first[r0 + R];
+        x = (b > a) ? E.req_len[b - 1] : 0;
+    }
     q.lh[lane] = v0;
     (&q.fw[0][0])[lane] = f0;
     if (lane == 0) { (&q.fw[0][0])[64] = x; q.rstar = 0xFFFFFFFFu; q.head_round = 0; }
     else if (lane == 1) q.misc[0] = x;
     else if (lane >= 2 && lane <= 4) q.pfx[lane - 2] = x;
     else if (lane == 5 || lane == 6) q.rfx[lane - 5] = (uint32_t)x;
+    else if (lane == 7) q.misc[1] = x;
 }
 
 __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask, uint32_t tick, SeqLds &q)
@@ -517,7 +578,10 @@ __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask,
     uint32_t fuse_mask; bool in_step;
     seq_in_step(E, q.lh, q.fw, push_mask, fuse_mask, in_step);
     uint32_t head_round = 0;
-    if (tick) head_round = control_append<false>(E, 1, 3, 0, 0, push_mask, q.lh, q.misc[0], fuse_mask, in_step).n;
+    if (tick) {
+        head_round = control_append<false>(E, 1, 3, 0, 0, push_mask, q.lh, q.misc[0], fuse_mask, in_step).n;
+        for (uint32_t i = 0; i < APUS_DEV_MAX_SERVERS; i++) sample_into_copy(E, q.lh, push_mask, i, q.fw[i][2]);
+    }
     const uint32_t n = q.rfx[1] - q.rfx[0];
     SeqOut s;
     s.e0 = q.lh[H_END]; s.idx0 = q.lh[H_LAST_IDX] + 1; s.w = 0; s.n_end0 = q.lh[H_N_END];
@@ -529,6 +593,9 @@ __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask,
     s.fuse_mask = fl.fuse_batch; s.tail_needed = fl.tail_needed; s.fast = fl.fast; s.pad1 = 0; s.rec_base = q.misc[0];
     q.out = s;
     q.end_new = n ? s.e0 + vtot : s.e0;
+    /* q.lh becomes the control block as the sequencer leaves it (H_TAIL is only right when the
+     * length of the batch's last request was staged: the bookkeeper does) */
+    if (n) seq_apply_batch(q.lh, q.end_new, APUS_HDR + q.misc[1], s.n_end0, n, s.idx0, -1);
     q.my_virt = q.pfx[1] - q.pfx[0];
     q.ok = 1;
 }
@@ -536,11 +603,12 @@ __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask,
 /* a block of k_call works the call's SeqOut out for itself: wave 0's variant, or the block-wide
  * scan when the batch could reach len; posts its "inputs fetched" ticket on tick line read_line */
 __device__ static inline void seq_local(const EngDev &E, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t tick,
-                                        uint32_t my_r, uint32_t read_line, SeqLds &q)
+                                        uint32_t my_r, uint32_t read_line, SeqLds &q, const uint64_t *snap = nullptr,
+                                        bool need_tail = false)
 {
     const uint32_t tid = threadIdx.x;
     if (tid < WAVE) {
-        seq_w0_stage(E, r0, R, push_mask, my_r, q);
+        seq_w0_stage(E, r0, R, push_mask, my_r, q, snap, need_tail);
         if (tid == 0) {
             __hip_atomic_fetch_add(E.tick_lines + (read_line & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             seq_w0_decide(E, push_mask, tick, q);
@@ -1210,8 +1278,7 @@ __device__ static inline void stage_apply_ctx(const EngDev &E, ApplyCtx &c, int 
     else if (tid == 97) c.n_apply_p = (p >= 0) ? E.rep[p].hdr[H_N_APPLY] : 0;
     else if (keeper && tid >= 128 && tid < 128 + 8 * APUS_DEV_MAX_SERVERS) {
         const uint32_t f = (tid - 128) >> 3, j = (tid - 128) & 7;
-        static const int words[8] = {H_N_PERSIST, H_N_COMMIT, H_N_APPLY, H_STORE_COUNT, H_HEAD, H_END, H_N_END, H_HEAD_SLOT};
-        c.fw[f][j] = ((fmask >> f) & 1u) ? E.rep[f].hdr[words[j]] : 0;
+        c.fw[f][j] = ((fmask >> f) & 1u) ? ldw(&E.rep[f].hdr[fw_hdr_word(j)]) : 0;      /* FW_* order */
     }
     __syncthreads();
     if (tid == 0) c.rec_base = c.seq.rec_base;      /* k_sequence noted it; the bookkeeper advances *rec_count */
@@ -1256,9 +1323,9 @@ __device__ static inline void recorder_body(const EngDev &E, uint64_t r0, uint32
  * bookkeeping, R4 lazy commit, apply offset and HEAD adoption.  c.off_cs / c.off_vis are set. */
 /* pure_head: k_call in step -- the followers applied the call's <HEAD> entry (if any) when the
  * sequencer pushed it; slot + 1 and value are derived (head_slot1, head_value) instead of read */
-__device__ static inline void keeper_publish(const EngDev &E, const ApplyCtx &c, uint32_t R, int mode, uint32_t fmask,
+__device__ static inline void keeper_publish(const EngDev &E, ApplyCtx &c, uint32_t R, int mode, uint32_t fmask,
                                              uint64_t vis, uint64_t cs, bool pure_head = false, uint64_t head_slot1 = 0,
-                                             uint64_t head_value = 0)
+                                             uint64_t head_value = 0, uint64_t *snap_next = nullptr)
 {
     const uint32_t tid = threadIdx.x;
     uint64_t *lh = E.rep[E.leader].hdr;
@@ -1266,18 +1333,22 @@ __device__ static inline void keeper_publish(const EngDev &E, const ApplyCtx &c,
     const uint64_t end_l = c.lh[H_END];
     const SeqOut &s = c.seq;
     const uint64_t commit_off = (cs > s.n_commit_before) ? c.off_cs : s.commit_before;
+    /* every store is mirrored in the LDS copies (c.lh, c.fw, c.rec_base): they become the state
+     * after the call, which a multi-segment launch hands to the next segment as a snapshot */
     if (tid == 0) {
         if (mode == 0) {
-            *E.rec_count = c.rec_base + R + s.head_round;
+            c.rec_base = c.rec_base + R + s.head_round;
+            *E.rec_count = c.rec_base;
         } else if (mode == 1 && s.n) {
             if (c.rec_base < E.rec_cap) E.rec_commit[c.rec_base] = (end_l == L) ? s.commit_before : commit_off;
-            *E.rec_count = c.rec_base + 1;
+            c.rec_base = c.rec_base + 1;
+            *E.rec_count = c.rec_base;
         }
-        lh[H_N_VISIBLE] = vis;
-        if (cs > s.n_commit_before) { lh[H_COMMIT] = commit_off; lh[H_N_COMMIT] = cs; }
-        if (cs > c.lh[H_N_APPLY]) { lh[H_APPLY] = c.off_cs; lh[H_N_APPLY] = cs; }
+        lh[H_N_VISIBLE] = vis; c.lh[H_N_VISIBLE] = vis;
+        if (cs > s.n_commit_before) { lh[H_COMMIT] = commit_off; lh[H_N_COMMIT] = cs; c.lh[H_COMMIT] = commit_off; c.lh[H_N_COMMIT] = cs; }
+        if (cs > c.lh[H_N_APPLY]) { lh[H_APPLY] = c.off_cs; lh[H_N_APPLY] = cs; c.lh[H_APPLY] = c.off_cs; c.lh[H_N_APPLY] = cs; }
         if (mode == 0 && s.fast) {
-            /* k_append_push applied the batch (every entry a client entry): one upcall each */
+            /* the append blocks applied the batch (every entry a client entry): one upcall each */
             atomicAdd((unsigned long long *)&lh[H_APPLY_COUNT], (unsigned long long)s.n);
             atomicAdd((unsigned long long *)&lh[H_HIGHEST_REC], (unsigned long long)s.n);
             for (uint32_t m = s.fuse_mask; m; m &= m - 1)
@@ -1288,8 +1359,9 @@ __device__ static inline void keeper_publish(const EngDev &E, const ApplyCtx &c,
         const int f = (int)tid - 1;
         if ((fmask >> f) & 1u) {
             uint64_t *fh = E.rep[f].hdr;
-            const uint64_t f_np = c.fw[f][0], f_nc = c.fw[f][1], f_na = c.fw[f][2], f_sc = c.fw[f][3];
-            const uint64_t f_head = c.fw[f][4], f_end = c.fw[f][5];
+            uint64_t *w = c.fw[f];
+            const uint64_t f_np = w[FW_N_PERSIST], f_nc = w[FW_N_COMMIT], f_na = w[FW_N_APPLY], f_sc = w[FW_STORE_COUNT];
+            const uint64_t f_head = w[FW_HEAD], f_end = w[FW_END];
             /* the appliers of this call may have raised the HEAD slot: read it now */
             const uint64_t hs = pure_head ? head_slot1
                               : __hip_atomic_load((unsigned long long *)&fh[H_HEAD_SLOT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1298,20 +1370,28 @@ __device__ static inline void keeper_publish(const EngDev &E, const ApplyCtx &c,
                 fh[H_STORE_COUNT] = f_sc + (vis - f_np);
                 fh[H_END] = c.off_vis; fh[H_OLD_END] = c.off_vis;
                 fh[H_N_END] = vis; fh[H_N_PERSIST] = vis;
+                w[FW_STORE_COUNT] = f_sc + (vis - f_np); w[FW_END] = c.off_vis; w[FW_N_END] = vis; w[FW_N_PERSIST] = vis;
                 end_now = c.off_vis;
             }
-            if (cs > f_nc) { fh[H_COMMIT] = c.off_cs; fh[H_N_COMMIT] = cs; }
-            if (cs > f_na) { fh[H_APPLY] = c.off_cs; fh[H_N_APPLY] = cs; }
+            if (cs > f_nc) { fh[H_COMMIT] = c.off_cs; fh[H_N_COMMIT] = cs; w[FW_N_COMMIT] = cs; }
+            if (cs > f_na) { fh[H_APPLY] = c.off_cs; fh[H_N_APPLY] = cs; w[FW_APPLY] = c.off_cs; w[FW_N_APPLY] = cs; }
             if (hs) {
                 uint64_t hv = head_value;
                 if (!pure_head) {
                     const uint64_t hoff = E.rep[f].dir_off[(uint32_t)(hs - 1) & E.dir_mask];
                     hv = ld8u(E.rep[f].ring + hoff + 48);
                 }
-                if (apus_is_larger(end_now, L, hv, f_head)) fh[H_HEAD] = hv;
+                if (apus_is_larger(end_now, L, hv, f_head)) { fh[H_HEAD] = hv; w[FW_HEAD] = hv; }
                 if (!pure_head) fh[H_HEAD_SLOT] = 0;
             }
         }
+    }
+    if (snap_next) {
+        /* the state after this call, for the next segment of the launch (write-once, uncached) */
+        __syncthreads();
+        if (tid < 64) snap_next[tid] = c.lh[tid];
+        else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) snap_next[SNAP_FW + (tid - 64)] = (&c.fw[0][0])[tid - 64];
+        else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) snap_next[SNAP_REC] = c.rec_base;
     }
 }
 
@@ -1558,10 +1638,9 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
         /* followers' control words: nobody else writes them while the replicas are in step */
         if (tid >= 128 && tid < 128 + 8 * APUS_DEV_MAX_SERVERS) {
             const uint32_t f = (tid - 128) >> 3, j = (tid - 128) & 7;
-            static const int words[8] = {H_N_PERSIST, H_N_COMMIT, H_N_APPLY, H_STORE_COUNT, H_HEAD, H_END, H_N_END, H_HEAD_SLOT};
-            c.fw[f][j] = ((fmask >> f) & 1u) ? ldw(&E.rep[f].hdr[words[j]]) : 0;
+            c.fw[f][j] = ((fmask >> f) & 1u) ? stage_follower_word(E, nullptr, f, j) : 0;     /* FW_* order */
         }
-        seq_local(E, r0, R, push_mask, tick, 0, nAB + nR, sq);
+        seq_local(E, r0, R, push_mask, tick, 0, nAB + nR, sq, nullptr, true);
         STAMP(3, 1);
         if (sq.out.fast) {
             /* in step: everything the bookkeeping needs follows from the sequencing it just worked
@@ -1572,7 +1651,6 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
             const uint64_t vis = sq.out.vis, cs = vis;
             if (tid == 0) {
                 c.rec_base = sq.out.rec_base;
-                c.lh[H_END] = sq.end_new; c.lh[H_N_END] = sq.out.n_end0 + sq.out.n;
                 c.off_cs = sq.end_new; c.off_vis = sq.end_new;       /* vis == n_end: the batch is fully visible */
             }
             __syncthreads();
