@@ -67,6 +67,8 @@ SIGNATURES = {
     "apus_gpu_submit": (C.c_int, [vp, vp, u32, vp, u64]),
     "apus_gpu_append_live": (C.c_int, [vp, vp, u32, vp, u64]),
     "apus_gpu_commit_live": (C.c_int, [vp, C.c_int]),
+    "apus_gpu_batch_begin": (C.c_int, [vp]),
+    "apus_gpu_batch_end": (C.c_int, [vp]),
 }
 
 

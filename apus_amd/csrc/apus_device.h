@@ -133,6 +133,13 @@ struct EngDev {
     uint64_t *rec_end, *rec_commit;
     uint64_t *rec_count;
     uint64_t  rec_cap;
+    /* multi-segment launches (k_step): per-segment counters / hash scratch, state snapshots
+     * (uncached), and the two chain counts (32 replicas each, one per cache line) */
+    uint32_t *step_lines;                 /* [segs][32 x 32] */
+    uint32_t *step_tickets;               /* [segs][32] */
+    uint64_t *step_hash;                  /* [segs][2 x 1024] */
+    uint64_t *step_snap;                  /* [segs + 1][SNAP_STRIDE] */
+    uint32_t *step_epoch, *step_seq_done, *step_app_done; /* [32 x 32] each: bookkeeper / sequencer / append phase of segment k done */
     uint64_t *trace;                      /* -DAPUS_TRACE builds: [kernel][64] wall-clock stamps; else nullptr */
 };
 

@@ -46,6 +46,9 @@ struct apus_engine {
     uint64_t n_reqs, n_rounds_staged;
     std::vector<uint32_t> h_round_first;
     std::vector<uint64_t> h_round_prefix;      /* byte prefix of the staged rounds */
+    bool batching;                             /* apus_gpu_batch_begin .. _end */
+    struct BatchSeg { CallArgs a; uint32_t blocks; uint64_t bytes; };
+    std::vector<BatchSeg> batch;               /* recorded calls: arguments, blocks, bytes they append */
     /* graphs */
     std::vector<hipGraphExec_t> graphs;
     bool capturing;
@@ -118,6 +121,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->cfg = *cfg;
     memset(&e->d, 0, sizeof e->d);
     e->capturing = false; e->timing = false; e->timed_used = 0; e->lag_possible = false; e->tick_pending = false;
+    e->batching = false;
     e->n_reqs = 0; e->n_rounds_staged = 0;
     e->d_req = e->d_req_len = e->d_arena = e->d_round_first = e->d_round_prefix = nullptr;
     e->h_live = nullptr; e->d_live = nullptr; e->live_pending = false; e->live_copied = nullptr;
@@ -159,6 +163,13 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     if (!rc) e->d.ticket = e->d.status + 8;
     if (!rc) rc = dev_alloc(e, &e->d.tick_lines, sizeof(uint32_t) * 32 * 32);
     if (!rc) rc = dev_alloc(e, &e->d.seq, sizeof(SeqOut));
+    if (!rc) rc = dev_alloc(e, &e->d.step_lines, sizeof(uint32_t) * APUS_STEP_SEGS * 1024);
+    if (!rc) rc = dev_alloc(e, &e->d.step_tickets, sizeof(uint32_t) * APUS_STEP_SEGS * 32);
+    if (!rc) rc = dev_alloc(e, &e->d.step_hash, sizeof(uint64_t) * APUS_STEP_SEGS * 2 * 1024);
+    if (!rc) rc = dev_alloc(e, &e->d.step_snap, sizeof(uint64_t) * (APUS_STEP_SEGS + 1) * SNAP_STRIDE, true, hipDeviceMallocUncached);
+    if (!rc) rc = dev_alloc(e, &e->d.step_epoch, sizeof(uint32_t) * 32 * 32);
+    if (!rc) rc = dev_alloc(e, &e->d.step_seq_done, sizeof(uint32_t) * 32 * 32);
+    if (!rc) rc = dev_alloc(e, &e->d.step_app_done, sizeof(uint32_t) * 32 * 32);
 #ifdef APUS_TRACE
     if (!rc) rc = dev_alloc(e, &e->d.trace, 8 * 16 * 64);
 #else
@@ -202,6 +213,7 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
 
 extern "C" int apus_gpu_sync(apus_engine_t *e)
 {
+    if (e && e->batching) return APUS_E_STATE;      /* close the batch first (apus_gpu_batch_end) */
     if (!e) return APUS_E_ARG;
     { int frc = flush_tick(e); if (frc) return frc; }
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -361,21 +373,56 @@ static int launch_append(apus_engine *e, const EngDev &view, uint64_t r0, uint32
 /* k_call sequences up to this many rounds per launch (their prefix stays in LDS) */
 #define APUS_CALL_ROUNDS 1024u
 
-extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rounds)
+/* one call's launch parameters */
+static CallArgs call_args(apus_engine *e, uint64_t c0, uint32_t R, uint32_t tick, uint32_t *blocks)
 {
-    int rc = need_leader(e);
-    if (rc) return rc;
-    if (r0 + n_rounds > e->n_rounds_staged || n_rounds > e->max_rounds) return APUS_E_ARG;
-    if (n_rounds == 0) return 0;
     const uint32_t fm = sync_mask(e);
     const uint32_t rm = fm | ((e->local_mask >> e->d.leader) & 1u ? (1u << e->d.leader) : 0);
-    if ((rc = launch_catchup(e))) return rc;
-    for (uint64_t done = 0; done < n_rounds; done += APUS_CALL_ROUNDS) {
-        const uint64_t c0 = r0 + done;
-        const uint32_t R = (uint32_t)std::min<uint64_t>(APUS_CALL_ROUNDS, n_rounds - done);
-        const uint64_t n = e->h_round_first[c0 + R] - e->h_round_first[c0];
-        const uint32_t tick = e->tick_pending ? 1u : 0u;
-        e->tick_pending = false;
+    const uint64_t n = e->h_round_first[c0 + R] - e->h_round_first[c0];
+    CallArgs a;
+    a.r0 = c0; a.R = R; a.tick = tick;
+    /* the scan / apply blocks only work when the replicas are not in step: a modest number, grid-stride */
+    a.nS = cap_grid(n, 256, 32); a.nA = cap_grid(n, 1024, 16); a.nR = cap_grid(R, 256, 8);
+    /* rounds with many 16-byte units are shared by SP workgroups each (a launch of a few hundred
+     * large rounds would leave most of the 256 CUs idle) */
+    const uint64_t units = (e->h_round_prefix[c0 + R] - e->h_round_prefix[c0]) / 16;
+    const char *sp_env = getenv("APUS_SP_UNITS");                        /* tuning knob: units per workgroup */
+    const uint64_t sp_units = sp_env ? (uint64_t)atoi(sp_env) : 768;
+    a.SP = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (units / R + sp_units * 2 / 3) / sp_units));
+    *blocks = 1 + R * a.SP + a.nR + 1 + a.nS + a.nA * popc(rm);
+    return a;
+}
+
+/* launch the recorded segments of a batch (apus_gpu_batch_begin .. _end) as k_step launches */
+static int flush_batch(apus_engine *e)
+{
+    if (e->batch.empty()) return 0;
+    const uint32_t fm = sync_mask(e);
+    const uint32_t rm = fm | ((e->local_mask >> e->d.leader) & 1u ? (1u << e->d.leader) : 0);
+    /* One launch must not lap the ring: the XCDs' L2s are not coherent with each other, so two
+     * segments of one launch that store to the same ring line (one lap apart) could be written
+     * back in either order.  A kernel boundary writes everything back; so a launch takes
+     * segments while they append less than one ring (minus slack for <HEAD> entries and the bytes
+     * skipped at a wrap). */
+    const uint64_t lap = e->d.log_len - e->d.log_len / 8;
+    size_t i = 0;
+    while (i < e->batch.size()) {
+        StepTable T;
+        memset(&T, 0, sizeof T);
+        uint32_t blk = 0;
+        uint64_t bytes = 0;
+        uint32_t k = 0;
+        while (i + k < e->batch.size() && k < APUS_STEP_SEGS) {
+            const apus_engine::BatchSeg &g = e->batch[i + k];
+            if (k && bytes + g.bytes + APUS_HDR > lap) break;
+            T.seg[k] = g.a;
+            T.blk0[k] = blk;
+            blk += g.blocks;
+            bytes += g.bytes + APUS_HDR;
+            k++;
+        }
+        T.S = k;
+        T.blk0[k] = blk;
         TimedLaunch *tl = nullptr;
         if (e->timing && !e->capturing) {
             if (e->timed_used == e->timed.size()) {
@@ -386,22 +433,73 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
             tl = &e->timed[e->timed_used++];
             HIPCHK(hipEventRecord(tl->a, e->stream));
         }
-        /* the whole call in one launch: sequencer + bookkeeper, append + push, persist + ACK scan,
-         * apply, per-round records (k_call's block roles) */
-        /* the scan / apply blocks only work when the replicas are not in step: a modest number, grid-stride */
-        const uint32_t nS = cap_grid(n, 256, 32), nA = cap_grid(n, 1024, 16), nR = cap_grid(R, 256, 8);
-        /* rounds with many 16-byte units are shared by SP workgroups each (a launch of a few hundred
-         * large rounds would leave most of the 256 CUs idle) */
-        const uint64_t units = (e->h_round_prefix[c0 + R] - e->h_round_prefix[c0]) / 16;
-        const char *sp_env = getenv("APUS_SP_UNITS");                        /* tuning knob: units per workgroup */
-        const uint64_t sp_units = sp_env ? (uint64_t)atoi(sp_env) : 768;
-        const uint32_t SP = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (units / R + sp_units * 2 / 3) / sp_units));
-        hipLaunchKernelGGL(k_call, dim3(1 + R * SP + nR + 1 + nS + nA * popc(rm)), dim3(256), 0, e->stream, e->d, c0, R, fm, tick, rm,
-                           nS, nA, nR, SP);
+        hipLaunchKernelGGL(k_step, dim3(blk), dim3(256), 0, e->stream, e->d, T, fm, rm);
+        if (tl) HIPCHK(hipEventRecord(tl->b, e->stream));
+        i += k;
+    }
+    e->batch.clear();
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rounds)
+{
+    int rc = need_leader(e);
+    if (rc) return rc;
+    if (r0 + n_rounds > e->n_rounds_staged || n_rounds > e->max_rounds) return APUS_E_ARG;
+    if (n_rounds == 0) return 0;
+    const uint32_t fm = sync_mask(e);
+    const uint32_t rm = fm | ((e->local_mask >> e->d.leader) & 1u ? (1u << e->d.leader) : 0);
+    if (!e->batching || e->batch.empty()) { if ((rc = launch_catchup(e))) return rc; }
+    for (uint64_t done = 0; done < n_rounds; done += APUS_CALL_ROUNDS) {
+        const uint64_t c0 = r0 + done;
+        const uint32_t R = (uint32_t)std::min<uint64_t>(APUS_CALL_ROUNDS, n_rounds - done);
+        const uint32_t tick = e->tick_pending ? 1u : 0u;
+        e->tick_pending = false;
+        uint32_t blocks = 0;
+        const CallArgs a = call_args(e, c0, R, tick, &blocks);
+        if (e->batching) {                    /* recorded; apus_gpu_batch_end launches the lot as k_step */
+            e->batch.push_back(apus_engine::BatchSeg{a, blocks, e->h_round_prefix[c0 + R] - e->h_round_prefix[c0]});
+            continue;
+        }
+        TimedLaunch *tl = nullptr;
+        if (e->timing && !e->capturing) {
+            if (e->timed_used == e->timed.size()) {
+                TimedLaunch t;
+                HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b));
+                e->timed.push_back(t);
+            }
+            tl = &e->timed[e->timed_used++];
+            HIPCHK(hipEventRecord(tl->a, e->stream));
+        }
+        /* the whole call in one launch: sequencer, append + push, per-round records, bookkeeper,
+         * persist + ACK scan, apply (k_call's block roles) */
+        hipLaunchKernelGGL(k_call, dim3(blocks), dim3(256), 0, e->stream, e->d, a, fm, rm);
         if (tl) HIPCHK(hipEventRecord(tl->b, e->stream));
     }
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+/* Batching: between _begin and _end, apus_gpu_run_rounds calls (and the prune ticks deferred into
+ * them) are recorded and then issued as multi-segment launches (k_step, up to 32 calls each) --
+ * the same work, without a kernel boundary between consecutive calls.  Only run_rounds and
+ * tick_prune may be called while a batch is open. */
+extern "C" int apus_gpu_batch_begin(apus_engine_t *e)
+{
+    int rc = need_leader(e);
+    if (rc) return rc;
+    if (e->batching) return APUS_E_STATE;
+    e->batching = true;
+    e->batch.clear();
+    return 0;
+}
+
+extern "C" int apus_gpu_batch_end(apus_engine_t *e)
+{
+    if (!e || !e->batching) return APUS_E_STATE;
+    e->batching = false;
+    return flush_batch(e);
 }
 
 /* ---- live submission: what the proxy's DARE thread does every polling() pass ---- */
@@ -425,6 +523,7 @@ static int live_view(apus_engine *e, EngDev *view)
 extern "C" int apus_gpu_append_live(apus_engine_t *e, const apus_req_t *reqs, uint32_t n,
                                     const uint8_t *arena, uint64_t arena_bytes)
 {
+    if (e && e->batching) return APUS_E_STATE;      /* close the batch first (apus_gpu_batch_end) */
     int rc = need_leader(e);
     if (rc) return rc;
     if (!reqs || n == 0 || n > LIVE_REQS || arena_bytes + 16 > LIVE_ARENA) return APUS_E_ARG;
@@ -509,6 +608,7 @@ static int launch_control_round(apus_engine *e, int mode, uint32_t type, uint64_
 
 extern "C" int apus_gpu_quiesce(apus_engine_t *e)
 {
+    if (e && e->batching) return APUS_E_STATE;      /* close the batch first (apus_gpu_batch_end) */
     int rc = need_leader(e);
     if (rc) return rc;
     { int frc = flush_tick(e); if (frc) return frc; }
@@ -517,6 +617,7 @@ extern "C" int apus_gpu_quiesce(apus_engine_t *e)
 
 extern "C" int apus_gpu_append_control(apus_engine_t *e, uint8_t type, const void *data)
 {
+    if (e && e->batching) return APUS_E_STATE;      /* close the batch first (apus_gpu_batch_end) */
     int rc = need_leader(e);
     if (rc) return rc;
     { int frc = flush_tick(e); if (frc) return frc; }
@@ -534,6 +635,8 @@ extern "C" int apus_gpu_tick_prune(apus_engine_t *e)
 {
     int rc = need_leader(e);
     if (rc) return rc;
+    /* an open batch: anything that has to run now goes behind what was recorded so far */
+    if (e->batching && (e->tick_pending || e->local_mask != (1u << e->d.group_size) - 1) && (rc = flush_batch(e))) return rc;
     if ((rc = flush_tick(e))) return rc;            /* two ticks in a row: the first one runs now */
     /* When every replica lives on this device the tick is deferred and fused into the
      * sequencer of the next batch (same position in the order of events, one launch less);
@@ -610,6 +713,7 @@ extern "C" int apus_gpu_capture_begin(apus_engine_t *e)
 
 extern "C" int apus_gpu_capture_end(apus_engine_t *e, int *graph_id)
 {
+    if (e && e->batching) return APUS_E_STATE;      /* close the batch first (apus_gpu_batch_end) */
     if (!e || !e->capturing || !graph_id) return APUS_E_STATE;
     { int frc = flush_tick(e); if (frc) return frc; }
     hipGraph_t g = nullptr;
@@ -625,6 +729,7 @@ extern "C" int apus_gpu_capture_end(apus_engine_t *e, int *graph_id)
 
 extern "C" int apus_gpu_graph_launch(apus_engine_t *e, int graph_id)
 {
+    if (e && e->batching) return APUS_E_STATE;      /* close the batch first (apus_gpu_batch_end) */
     if (!e || graph_id < 0 || graph_id >= (int)e->graphs.size()) return APUS_E_ARG;
     HIPCHK(hipGraphLaunch(e->graphs[graph_id], e->stream));
     return 0;

@@ -58,6 +58,15 @@ __device__ static inline uint64_t ldw(const uint64_t *p)
     return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+/* where a call's blocks meet: arrival counters and the per-round hash scratch.  One set per
+ * engine for k_call / the phased kernels; one per segment in a multi-segment launch (k_step). */
+struct CallEnv {
+    uint32_t *lines;      /* [32 lines x 32 words] word 0 append arrivals, word 1 the sequencer's flag, word 2 "inputs fetched" */
+    uint32_t *ticket;     /* [8] T_PASS, T_SCAN, T_DONE */
+    uint64_t *hash;       /* [2 x rounds] fast path: per-round apply-stream sums */
+};
+#define APUS_ENV_OF(E) CallEnv{(E).tick_lines, (E).ticket, (E).round_hash}
+
 /* E.ticket words */
 enum { T_APPLY = 1, T_PASS = 2, T_SCAN = 3, T_DONE = 4 };
 
@@ -602,15 +611,15 @@ __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask,
 
 /* a block of k_call works the call's SeqOut out for itself: wave 0's variant, or the block-wide
  * scan when the batch could reach len; posts its "inputs fetched" ticket on tick line read_line */
-__device__ static inline void seq_local(const EngDev &E, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t tick,
+__device__ static inline void seq_local(const EngDev &E, const CallEnv &X, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t tick,
                                         uint32_t my_r, uint32_t read_line, SeqLds &q, const uint64_t *snap = nullptr,
-                                        bool need_tail = false)
+                                        bool need_tail = false, bool post_read = true)
 {
     const uint32_t tid = threadIdx.x;
     if (tid < WAVE) {
         seq_w0_stage(E, r0, R, push_mask, my_r, q, snap, need_tail);
         if (tid == 0) {
-            __hip_atomic_fetch_add(E.tick_lines + (read_line & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (post_read) __hip_atomic_fetch_add(X.lines + (read_line & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             seq_w0_decide(E, push_mask, tick, q);
         }
     }
@@ -651,12 +660,12 @@ __device__ static inline void locate_unit(const AppendLds &lds, uint32_t u, uint
 /* the sequencer of the same launch (k_call) has published SeqOut / round_virt: its flag is
  * replicated on 32 cache lines (word 1 of every tick line) so that a thousand pollers do not
  * queue up on one word; then an agent-scope acquire for the whole block */
-__device__ static inline uint32_t wait_sequenced(const EngDev &E, uint32_t b, uint32_t *s_flag)
+__device__ static inline uint32_t wait_sequenced(const EngDev &E, const CallEnv &X, uint32_t b, uint32_t *s_flag)
 {
     if (threadIdx.x == 0) {
         unsigned long long spins = 0;
         uint32_t f;
-        while ((f = __hip_atomic_load(E.tick_lines + (b & 31u) * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+        while ((f = __hip_atomic_load(X.lines + (b & 31u) * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
             __builtin_amdgcn_s_sleep(32);
             if (++spins > (1ull << 22)) { set_status(E, 1u << 4); f = 1; break; }     /* bounded */
         }
@@ -673,8 +682,9 @@ __device__ static inline uint32_t wait_sequenced(const EngDev &E, uint32_t b, ui
  * (k_call), so that fetch overlaps the sequencing.  Then: positions, indices, header words,
  * directory, (in step) the apply records, and the stores. */
 template <bool IN_LAUNCH>
-__device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t r,
-                                           AppendLds &lds, SeqLds *sq, uint32_t tick, uint32_t slice = 0, uint32_t n_slices = 1)
+__device__ static inline void append_round(const EngDev &E, const CallEnv &X, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t r,
+                                           AppendLds &lds, SeqLds *sq, uint32_t tick, uint32_t slice = 0, uint32_t n_slices = 1,
+                                           const uint64_t *snap = nullptr, bool post_read = true)
 {
     const uint32_t tid = threadIdx.x, lane = lane_id();
     const RepDev &Ld = E.rep[E.leader];
@@ -693,9 +703,9 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
         if (tid < WAVE) {
             /* the sequencer's inputs, in the same round trip as the descriptors; once they are in LDS
              * the sequencer block may start changing the control words (it waits for these tickets) */
-            seq_w0_stage(E, r0, R, push_mask, r, *sq);
+            seq_w0_stage(E, r0, R, push_mask, r, *sq, snap);
             if (r == 0) STAMP(1, 3);
-            if (tid == 0) __hip_atomic_fetch_add(E.tick_lines + ((r * n_slices + slice) & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && post_read) __hip_atomic_fetch_add(X.lines + ((r * n_slices + slice) & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         /* one lane of wave 1 works the call's SeqOut out while wave 0 lays the round out */
@@ -856,8 +866,8 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
          * up in one L2 channel), the upcall counters advance by the batch size there too */
         const uint64_t sum1 = wave_sum(mix1), sum2 = wave_sum(mix2);
         if (lane == 0) {     /* write-through: a record block of the same launch may read them */
-            __hip_atomic_store(&E.round_hash[2 * r], sum1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&E.round_hash[2 * r + 1], sum2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&X.hash[2 * r], sum1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&X.hash[2 * r + 1], sum2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     for (uint32_t u = ubeg + tid + PF * 256; u < utotal; u += 256) {
@@ -878,7 +888,8 @@ __device__ static inline void append_round(const EngDev &E, uint64_t r0, uint32_
 __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask)
 {
     __shared__ AppendLds lds;
-    append_round<false>(E, r0, R, push_mask, blockIdx.x, lds, nullptr, 0);
+    const CallEnv X = APUS_ENV_OF(E);
+    append_round<false>(E, X, r0, R, push_mask, blockIdx.x, lds, nullptr, 0);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1293,11 +1304,11 @@ __device__ static inline uint64_t ctx_commit_slot(const ApplyCtx &c)
 }
 
 /* fast path: the per-round stream sums k_append_push left, folded into the replicas' hashes */
-__device__ static inline void fold_round_hashes(const EngDev &E, uint32_t R, uint32_t blk, uint32_t nblk, uint32_t fuse_mask)
+__device__ static inline void fold_round_hashes(const EngDev &E, const CallEnv &X, uint32_t R, uint32_t blk, uint32_t nblk, uint32_t fuse_mask)
 {
     uint64_t h1 = 0, h2 = 0;
     for (uint64_t r = (uint64_t)blk * blockDim.x + threadIdx.x; r < R; r += (uint64_t)nblk * blockDim.x) {
-        h1 += E.round_hash[2 * r]; h2 += E.round_hash[2 * r + 1];
+        h1 += X.hash[2 * r]; h2 += X.hash[2 * r + 1];
     }
     h1 = wave_sum(h1); h2 = wave_sum(h2);
     if (lane_id() == 0 && (h1 | h2)) {
@@ -1315,7 +1326,7 @@ __device__ static inline void recorder_body(const EngDev &E, uint64_t r0, uint32
     const uint32_t tid = threadIdx.x;
     if (mode == 0)
         finish_records(E, r0, R, cs, (uint64_t)blk * blockDim.x + tid, (uint64_t)nblk * blockDim.x, c.seq, c.rec_base);
-    if (mode == 0 && c.seq.fast) fold_round_hashes(E, R, blk, nblk, c.seq.fuse_mask);
+    if (mode == 0 && c.seq.fast) { const CallEnv X = APUS_ENV_OF(E); fold_round_hashes(E, X, R, blk, nblk, c.seq.fuse_mask); }
 }
 
 /* the bookkeeper, once everybody else is done: per-call counters, the leader's commit / apply
@@ -1397,11 +1408,11 @@ __device__ static inline void keeper_publish(const EngDev &E, ApplyCtx &c, uint3
 
 /* thread 0 spins until ticket `which` reaches `want` (bounded), then the whole block passes an
  * agent-scope acquire: what the ticketing blocks released is visible to plain loads */
-__device__ static inline void wait_ticket(const EngDev &E, int which, uint32_t want)
+__device__ static inline void wait_ticket(const EngDev &E, const CallEnv &X, int which, uint32_t want)
 {
     if (threadIdx.x == 0) {
         unsigned long long spins = 0;
-        while (__hip_atomic_load(E.ticket + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        while (__hip_atomic_load(X.ticket + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             __builtin_amdgcn_s_sleep(8);
             if (++spins > (1ull << 22)) { set_status(E, 1u << 4); break; }     /* bounded */
         }
@@ -1411,12 +1422,12 @@ __device__ static inline void wait_ticket(const EngDev &E, int which, uint32_t w
 }
 /* the append blocks' arrivals are spread over 32 counters in 32 cache lines (a thousand
  * workgroups finishing together would queue up on one word): lane i < 32 waits for counter i */
-__device__ static inline void wait_append(const EngDev &E, uint32_t n_blocks)
+__device__ static inline void wait_append(const EngDev &E, const CallEnv &X, uint32_t n_blocks)
 {
     if (threadIdx.x < 32) {
         const uint32_t quota = n_blocks / 32 + (threadIdx.x < (n_blocks & 31u) ? 1u : 0u);
         unsigned long long spins = 0;
-        while (__hip_atomic_load(E.tick_lines + threadIdx.x * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < quota) {
+        while (__hip_atomic_load(X.lines + threadIdx.x * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < quota) {
             __builtin_amdgcn_s_sleep(8);
             if (++spins > (1ull << 22)) { set_status(E, 1u << 4); break; }     /* bounded */
         }
@@ -1424,22 +1435,22 @@ __device__ static inline void wait_append(const EngDev &E, uint32_t n_blocks)
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
-__device__ static inline void post_append(const EngDev &E, uint32_t b, bool release)
+__device__ static inline void post_append(const EngDev &E, const CallEnv &X, uint32_t b, bool release)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
         if (release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_fetch_add(E.tick_lines + (b & 31u) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(X.lines + (b & 31u) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 /* every block of k_call that works the sequencing out for itself has fetched its copy of the
  * control words (tick word 2 of the 32 lines): only then may they be changed */
-__device__ static inline void wait_readers(const EngDev &E, uint32_t n_readers)
+__device__ static inline void wait_readers(const EngDev &E, const CallEnv &X, uint32_t n_readers)
 {
     if (threadIdx.x < 32) {
         const uint32_t quota = n_readers / 32 + (threadIdx.x < (n_readers & 31u) ? 1u : 0u);
         unsigned long long spins = 0;
-        while (__hip_atomic_load(E.tick_lines + threadIdx.x * 32 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < quota) {
+        while (__hip_atomic_load(X.lines + threadIdx.x * 32 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < quota) {
             __builtin_amdgcn_s_sleep(4);
             if (++spins > (1ull << 22)) { set_status(E, 1u << 4); break; }     /* bounded */
         }
@@ -1447,12 +1458,12 @@ __device__ static inline void wait_readers(const EngDev &E, uint32_t n_readers)
     __syncthreads();
 }
 /* all of the block's stores are done (barrier), optionally released to the device, then the ticket */
-__device__ static inline void post_ticket(const EngDev &E, int which, bool release)
+__device__ static inline void post_ticket(const EngDev &E, const CallEnv &X, int which, bool release)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
         if (release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_fetch_add(E.ticket + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(X.ticket + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1548,16 +1559,48 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
  * A block only ever waits for blocks with a LOWER index (or, for the sequencer, for tickets the
  * append blocks post before they wait for anything); workgroups are dispatched in index order per
  * XCD, so what a waiting block needs is already running or done: no co-residency assumption. */
-__global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t tick,
-                                              uint32_t rmask, uint32_t nS, uint32_t nA, uint32_t nR, uint32_t SP)
+/* one call's parameters (k_call's arguments; one entry per segment in k_step's table) */
+struct CallArgs {
+    uint64_t r0;
+    uint32_t R, tick, SP, nR, nS, nA;
+};
+union CallLds {
+    AppendLds app;
+    struct { ApplyCtx c; unsigned long long acc[2]; uint64_t np[APUS_DEV_MAX_SERVERS]; uint64_t sc[4]; uint32_t flag; } t;
+};
+
+/* multi-segment launches: segment k waits until epoch >= k (the bookkeeper of segment k-1 has
+ * written snapshot k) / until the sequencer of segment k-1 is done; 32 replicas, one per cache line */
+__device__ static inline void wait_count(const EngDev &E, const uint32_t *lines32, uint32_t b, uint32_t want)
 {
-    __shared__ SeqLds sq;
-    __shared__ union CallLds {
-        AppendLds app;
-        struct { ApplyCtx c; unsigned long long acc[2]; uint64_t np[APUS_DEV_MAX_SERVERS]; uint64_t sc[4]; uint32_t flag; } t;
-    } l;
+    if (threadIdx.x == 0) {
+        unsigned long long spins = 0;
+        while (__hip_atomic_load(lines32 + (b & 31u) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1ull << 22)) { set_status(E, 1u << 4); break; }     /* bounded */
+        }
+    }
+    __syncthreads();
+}
+/* all of the block's stores (uncached control words, snapshot) have reached memory, then the count */
+__device__ static inline void bump_count(uint32_t *lines32, uint32_t value)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < 32) __hip_atomic_store(lines32 + threadIdx.x * 32, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* The body of a call for block b of its grid.  STEP = false: k_call (one call per launch, inputs =
+ * the live control blocks).  STEP = true: segment seg of S in a k_step launch: inputs = snapshot
+ * seg (seg > 0), the bookkeeper writes snapshot seg + 1 and raises the epoch, the sequencers'
+ * effects are chained by their own count. */
+template <bool STEP>
+__device__ static inline void call_block(const EngDev &E, const CallEnv &X, const CallArgs &A, uint32_t push_mask, uint32_t rmask,
+                                         uint32_t b, SeqLds &sq, CallLds &l, uint32_t seg, uint32_t S)
+{
+    const uint64_t r0 = A.r0;
+    const uint32_t R = A.R, tick = A.tick, SP = A.SP, nR = A.nR, nS = A.nS, nA = A.nA;
     const uint32_t tid = threadIdx.x;
-    const uint32_t b = blockIdx.x;
     const uint32_t ny = (uint32_t)__popc(rmask);
     const uint32_t fmask = push_mask;
     ApplyCtx &c = l.t.c;
@@ -1566,32 +1609,47 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
     const uint32_t n_readers = nAB + nR + 1;
     /* blocks that sign off with T_PASS: everybody but the append blocks and the janitor */
     const uint32_t n_pass = 1 + (nR - 1) + 1 + nS + nA * ny;
+    /* inputs: the live control blocks, or (later segments of a launch) the previous bookkeeper's
+     * snapshot -- then nobody has to wait before changing the live words */
+    const bool live = !STEP || seg == 0;
+    const uint64_t *snap = live ? nullptr : E.step_snap + (size_t)seg * SNAP_STRIDE;
+    uint64_t *snap_next = STEP ? E.step_snap + (size_t)(seg + 1) * SNAP_STRIDE : nullptr;
 
     if (b >= 1 && b <= nAB) {                                  /* ---- append + push ---- */
         const uint32_t ab = b - 1, r = ab / SP, slice = ab - r * SP;
+        if (!live) wait_count(E, E.step_epoch, b, seg);
+        /* at most two segments append at a time: a later lap of the ring must not be overtaken by
+         * stores of the lap it overwrites (segment seg - 2 and everything before it is complete) */
+        if (STEP && seg >= 2) wait_count(E, E.step_app_done, b, seg - 1);
         if (b == nAB) STAMP(6, 0);
-        append_round<true>(E, r0, R, push_mask, r, l.app, &sq, tick, slice, SP);
+        append_round<true>(E, X, r0, R, push_mask, r, l.app, &sq, tick, slice, SP, snap, live);
         if (b == nAB) STAMP(6, 1);
-        post_append(E, ab, l.app.fast == 0);
+        post_append(E, X, ab, l.app.fast == 0);
         if (b == nAB) STAMP(6, 2);
         return;
     }
     if (b == 0) {                                              /* ---- the sequencer ---- */
-        seq_stage(E, r0, R, push_mask, push_mask, sq);
-        wait_readers(E, n_readers);                            /* every reader has its copy of the inputs */
+        if (!live) wait_count(E, E.step_epoch, b, seg);
+        seq_stage(E, r0, R, push_mask, push_mask, sq, true, snap);
+        if (live) wait_readers(E, X, n_readers);               /* every reader has its copy of the inputs */
+        if (STEP && seg) wait_count(E, E.step_seq_done, b, seg);   /* the previous segment's sequencer is done */
+        if (STEP && seg >= 2) wait_count(E, E.step_app_done, b, seg - 1);   /* its <HEAD> entry goes into the ring too */
         seq_body<true>(E, r0, R, push_mask, tick, push_mask, sq, 0, false);
         __syncthreads();
         const bool fast = sq.out.fast != 0;
         if (!fast && tid == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   /* SeqOut, control words, <HEAD> entry */
         __syncthreads();
-        if (tid < 32) __hip_atomic_store(E.tick_lines + tid * 32 + 1, fast ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        post_ticket(E, T_PASS, false);
+        if (tid < 32) __hip_atomic_store(X.lines + tid * 32 + 1, fast ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (STEP) bump_count(E.step_seq_done, seg + 1);
+        post_ticket(E, X, T_PASS, false);
         return;
     }
     uint32_t q = b - 1 - nAB;
     if (q < nR) {                                              /* ---- per-round records ---- */
         if (q == 0) STAMP(5, 0);
-        seq_local(E, r0, R, push_mask, tick, 0, nAB + q, sq);
+        if (!live) wait_count(E, E.step_epoch, b, seg);
+        /* the sequencing, worked out locally (SeqOut in sq.out) */
+        seq_local(E, X, r0, R, push_mask, tick, 0, nAB + q, sq, snap, false, live);
         if (q == 0) STAMP(5, 1);
         /* the rounds' byte prefix: the host-staged one, or the block's own scan */
         const uint64_t *virt = sq.ok ? E.round_prefix + r0 : sq.virt;
@@ -1602,45 +1660,58 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
             finish_records(E, r0, R, sq.out.vis, (uint64_t)q * blockDim.x + tid, (uint64_t)nR * blockDim.x, sq.out,
                            sq.out.rec_base, virt, vbase);
             if (q == 0) STAMP(5, 2);
-            wait_append(E, nAB);
+            wait_append(E, X, nAB);
             if (q == 0) STAMP(5, 3);
-            fold_round_hashes(E, R, q, nR, sq.out.fuse_mask);
+            fold_round_hashes(E, X, R, q, nR, sq.out.fuse_mask);
             if (q == 0) STAMP(5, 4);
         } else {
-            wait_append(E, nAB);
-            wait_ticket(E, T_SCAN, nS);
+            wait_append(E, X, nAB);
+            wait_ticket(E, X, T_SCAN, nS);
             if (tid == 0)
                 sq.out.first_fail = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             uint64_t cs = min((uint64_t)sq.out.first_fail, sq.out.vis);
             if (cs < sq.out.n_commit_before) cs = sq.out.n_commit_before;
             finish_records(E, r0, R, cs, (uint64_t)q * blockDim.x + tid, (uint64_t)nR * blockDim.x, sq.out, sq.out.rec_base, virt, vbase);
-            post_ticket(E, T_DONE, false);
+            post_ticket(E, X, T_DONE, false);
         }
-        if (q != 0) { post_ticket(E, T_PASS, false); return; }
-        /* the janitor: every append block is done (wait_append above), everybody else signs off
-         * with T_PASS; then the call's counters and the flag are cleared for the next call */
-        wait_ticket(E, T_PASS, n_pass);
+        if (q != 0) { post_ticket(E, X, T_PASS, false); return; }
+        /* the janitor: every append block is done (wait_append above), everybody else -- the
+         * sequencer with its <HEAD> entry too -- signs off with T_PASS */
+        wait_ticket(E, X, T_PASS, n_pass);
+        if (STEP) {
+            /* the segment is complete: nothing of it will be stored into the ring any more, which
+             * is what the segment after next waits for before it appends (in order) */
+            if (seg) wait_count(E, E.step_app_done, b, seg);
+            bump_count(E.step_app_done, seg + 1);
+        }
+        /* then the call's counters and the flag are cleared for the next call */
         if (tid < 32) {
-            __hip_atomic_store(E.tick_lines + tid * 32 + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(E.tick_lines + tid * 32 + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(E.tick_lines + tid * 32 + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(X.lines + tid * 32 + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(X.lines + tid * 32 + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(X.lines + tid * 32 + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (STEP && seg + 1 == S) {                        /* the launch's last segment: its chain counts too */
+                __hip_atomic_store(E.step_epoch + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(E.step_seq_done + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(E.step_app_done + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else if (tid == 32) {
-            __hip_atomic_store(E.ticket + T_PASS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(E.ticket + T_SCAN, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(E.ticket + T_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(X.ticket + T_PASS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(X.ticket + T_SCAN, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(X.ticket + T_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
     q -= nR;
     if (q == 0) {                                              /* ---- the bookkeeper ---- */
         STAMP(3, 0);
+        if (!live) wait_count(E, E.step_epoch, b, seg);
         /* followers' control words: nobody else writes them while the replicas are in step */
         if (tid >= 128 && tid < 128 + 8 * APUS_DEV_MAX_SERVERS) {
             const uint32_t f = (tid - 128) >> 3, j = (tid - 128) & 7;
-            c.fw[f][j] = ((fmask >> f) & 1u) ? stage_follower_word(E, nullptr, f, j) : 0;     /* FW_* order */
+            c.fw[f][j] = ((fmask >> f) & 1u) ? stage_follower_word(E, snap, f, j) : 0;     /* FW_* order */
         }
-        seq_local(E, r0, R, push_mask, tick, 0, nAB + nR, sq, nullptr, true);
+        seq_local(E, X, r0, R, push_mask, tick, 0, nAB + nR, sq, snap, true, live);
         STAMP(3, 1);
         if (sq.out.fast) {
             /* in step: everything the bookkeeping needs follows from the sequencing it just worked
@@ -1654,14 +1725,14 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
                 c.off_cs = sq.end_new; c.off_vis = sq.end_new;       /* vis == n_end: the batch is fully visible */
             }
             __syncthreads();
-            wait_readers(E, n_readers);                        /* it changes words the other blocks sequence from */
+            if (live) wait_readers(E, X, n_readers);           /* it changes words the other blocks sequence from */
             STAMP(3, 2);
-            keeper_publish(E, c, R, 0, fmask, vis, cs, true, sq.out.head_round ? sq.out.n_end0 : 0, sq.lh[H_HEAD]);
+            keeper_publish(E, c, R, 0, fmask, vis, cs, true, sq.out.head_round ? sq.out.n_end0 : 0, sq.lh[H_HEAD], snap_next);
             STAMP(3, 3);
         } else {
-            wait_sequenced(E, b, &l.t.flag);                   /* the sequencer's results, released */
+            wait_sequenced(E, X, b, &l.t.flag);                /* the sequencer's results, released */
             stage_apply_ctx(E, c, -1, true, fmask);
-            wait_ticket(E, T_DONE, nA * ny + nR);
+            wait_ticket(E, X, T_DONE, nA * ny + nR);
             if (tid == 0)
                 c.seq.first_fail = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
@@ -1670,38 +1741,71 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, uint64_t r0, uint3
             if (tid == 0) c.off_cs = (cs == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)cs & E.dir_mask];
             if (tid == 1) c.off_vis = (vis == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)vis & E.dir_mask];
             __syncthreads();
-            keeper_publish(E, c, R, 0, fmask, vis, cs);
+            keeper_publish(E, c, R, 0, fmask, vis, cs, false, 0, 0, snap_next);
         }
-        post_ticket(E, T_PASS, false);
+        if (STEP) bump_count(E.step_epoch, seg + 1);           /* snapshot seg + 1 is complete */
+        post_ticket(E, X, T_PASS, false);
         return;
     }
     q -= 1;
     /* ---- the roles that only work when the replicas are not in step ---- */
-    const uint32_t flag = wait_sequenced(E, b, &l.t.flag);
+    const uint32_t flag = wait_sequenced(E, X, b, &l.t.flag);
     if (flag == 2) {
         if (q < nS) {                                          /* persist + ACK + quorum scan */
             if (tid == 0) l.t.sc[3] = E.seq->tail_needed;
             __syncthreads();
             if (l.t.sc[3]) {
-                wait_append(E, nAB);
+                wait_append(E, X, nAB);
                 persist_commit_blocks(E, fmask, q, nS, l.t.np, l.t.sc);
             }
-            post_ticket(E, T_SCAN, l.t.sc[3] != 0);
+            post_ticket(E, X, T_SCAN, l.t.sc[3] != 0);
         } else {                                               /* apply */
             q -= nS;
             const uint32_t y = q / nA, x = q - y * nA;
             int p = -1;
             for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
                 if (rmask & (1u << i)) { if (k == (int)y) { p = i; break; } k++; }
-            wait_ticket(E, T_SCAN, nS);                        /* first_fail is final, the entries are visible */
+            wait_ticket(E, X, T_SCAN, nS);                     /* first_fail is final, the entries are visible */
             stage_apply_ctx(E, c, p, false, fmask);
             /* (2 slots per lane and pass: keeps the whole kernel's register count down) */
             if (p >= 0 && !c.seq.fast) apply_range<2>(E, p, c.n_apply_p, ctx_commit_slot(c), (uint64_t)x * blockDim.x,
                                                       (uint64_t)nA * blockDim.x, l.t.acc);
-            post_ticket(E, T_DONE, false);
+            post_ticket(E, X, T_DONE, false);
         }
     }
-    post_ticket(E, T_PASS, false);
+    post_ticket(E, X, T_PASS, false);
+}
+
+__global__ __launch_bounds__(256) void k_call(const EngDev E, const CallArgs A, uint32_t push_mask, uint32_t rmask)
+{
+    __shared__ SeqLds sq;
+    __shared__ CallLds l;
+    const CallEnv X = APUS_ENV_OF(E);
+    call_block<false>(E, X, A, push_mask, rmask, blockIdx.x, sq, l, 0, 1);
+}
+
+/* k_step: several consecutive calls (segments) in ONE launch.  The blocks of segment k sit behind
+ * those of segment k-1 in the grid and run k_call's roles on segment-private counters; what
+ * replaces the kernel boundary between two calls is a state snapshot: the bookkeeper of segment
+ * k-1 writes the control state after its call (write-once, uncached memory) and raises the epoch,
+ * and segment k sequences from that snapshot -- its append blocks start as soon as that
+ * bookkeeper is done (which in step is early: it needs nothing but its own copy of the
+ * sequencing), while segment k-1's stores are still draining.  No end-of-kernel write-back, no
+ * dispatch ramp, no graph gap between segments. */
+#define APUS_STEP_SEGS 32
+struct StepTable {
+    CallArgs seg[APUS_STEP_SEGS];
+    uint32_t blk0[APUS_STEP_SEGS + 1];        /* first block of every segment; blk0[S] = grid size */
+    uint32_t S;
+};
+__global__ __launch_bounds__(256) void k_step(const EngDev E, const StepTable T, uint32_t push_mask, uint32_t rmask)
+{
+    __shared__ SeqLds sq;
+    __shared__ CallLds l;
+    uint32_t seg = 0;
+    for (uint32_t k = 1; k < T.S; k++) if (blockIdx.x >= T.blk0[k]) seg = k;
+    const CallEnv X{E.step_lines + (size_t)seg * 1024, E.step_tickets + (size_t)seg * 32, E.step_hash + (size_t)seg * 2 * 1024};
+    call_block<true>(E, X, T.seg[seg], push_mask, rmask, blockIdx.x - T.blk0[seg], sq, l, seg, T.S);
 }
 
 /* READ the apply offset of peer i for the next prune tick (rc_get_remote_apply_offsets,
@@ -1939,5 +2043,8 @@ __global__ void k_reset(const EngDev E)
         *E.rec_count = 0; *E.status = 0;
         for (int i = 0; i < 8; i++) E.ticket[i] = 0;
         for (int i = 0; i < 32; i++) { E.tick_lines[i * 32] = 0; E.tick_lines[i * 32 + 1] = 0; E.tick_lines[i * 32 + 2] = 0; }
+        for (int i = 0; i < 32; i++) { E.step_epoch[i * 32] = 0; E.step_seq_done[i * 32] = 0; E.step_app_done[i * 32] = 0; }
+        for (int i = 0; i < APUS_STEP_SEGS * 1024; i++) E.step_lines[i] = 0;
+        for (int i = 0; i < APUS_STEP_SEGS * 32; i++) E.step_tickets[i] = 0;
     }
 }

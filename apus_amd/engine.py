@@ -164,6 +164,9 @@ class Engine:
         self._chk(self.L.apus_gpu_run_rounds(self.h, r0, n), "run_rounds")
 
     def tick_prune(self): self._chk(self.L.apus_gpu_tick_prune(self.h), "tick_prune")
+
+    def batch_begin(self): self._chk(self.L.apus_gpu_batch_begin(self.h), "batch_begin")
+    def batch_end(self): self._chk(self.L.apus_gpu_batch_end(self.h), "batch_end")
     def quiesce(self): self._chk(self.L.apus_gpu_quiesce(self.h), "quiesce")
 
     def run_trace(self, trace: Trace, on_event=None, max_batch_rounds: int = 4096, check: bool = True):

@@ -67,14 +67,25 @@ def step_calls(tr, eng):
     return calls
 
 
+BATCH = True      # submit a step's calls as batches (multi-segment launches, k_step); --no-batch: one launch per call
+
+
 def issue(eng, calls):
+    opened = False
     for c in calls:
-        if c[0] == "rounds":
-            eng.run_rounds(c[1], c[2])
-        elif c[0] == "prune":
-            eng.tick_prune()
+        if c[0] in ("rounds", "prune"):
+            if BATCH and not opened:
+                eng.batch_begin(); opened = True
+            if c[0] == "rounds":
+                eng.run_rounds(c[1], c[2])
+            else:
+                eng.tick_prune()
         else:
+            if opened:
+                eng.batch_end(); opened = False
             eng.quiesce()
+    if opened:
+        eng.batch_end()
 
 
 def cpu_baseline(args, seconds=15.0):
@@ -214,7 +225,11 @@ def bench_single(args):
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("k_call_bytes_per_launch")
+            pj = json.load(open(pmc))
+            if BATCH and pj.get("k_step_bytes_per_entry"):
+                traffic = int(pj["k_step_bytes_per_entry"] * entries_per_launch)
+            else:
+                traffic = pj.get("k_call_bytes_per_launch")
         except Exception:
             traffic = None
     out = {
@@ -227,7 +242,7 @@ def bench_single(args):
                                 f"rounds of {args.batch}, prune tick every 8 MiB, 64 MiB rings") if args.config == "c2" else
                                f"BASELINE {args.config}: {N} replicas (logical, one MI355X), {n_entries} entries/step, "
                                f"mean payload {args.payload} B, 64 MiB rings",
-                   "mode": "hipGraph replay of one step" if use_graph else "eager launches",
+                   "mode": ("hipGraph replay of one step" if use_graph else "eager launches") + (", calls batched into multi-segment launches" if BATCH else ""),
                    "replicas": N, "entry_bytes": E, "launches_per_step": len(calls)},
         "p50_round_latency_us": plat_dev if plat_dev is not None else p50,
         "latency": {"persistent_kernel_append_to_commit_us_p50": plat_dev,
@@ -238,7 +253,7 @@ def bench_single(args):
                             "device latency from wall_clock64 inside the persistent kernel"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_call", "bytes_per_entry": kern_bytes,
+                     "kernel": "k_step" if BATCH else "k_call", "bytes_per_entry": kern_bytes,
                      "avg_launch_us": k_avg_s * 1e6, "launches": k_launches,
                      "entries_per_launch": entries_per_launch},
         "whole_path": {"bytes_per_entry": path_bytes, "achieved": path_bytes * value / 1e9,
@@ -269,8 +284,11 @@ def main():
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="one launch per run_rounds call (k_call) instead of batches (k_step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+    global BATCH
+    BATCH = not args.no_batch
     if args.config == "c3" and args.replicas == 3:
         args.replicas = 5
     if args.config == "c4" and args.replicas == 3:

@@ -138,6 +138,14 @@ int  apus_gpu_append_control(apus_engine_t *e, uint8_t type, const void *data);
 int  apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rounds);
 /* log_pruning() timer tick (dare_server.c:1996-2067) incl. the R8 apply-offset gather */
 int  apus_gpu_tick_prune(apus_engine_t *e);
+/* Batching: between _begin and _end, apus_gpu_run_rounds calls (and the prune ticks that
+ * fall between them, which the engine defers into the next call's sequencer) are recorded and
+ * then issued as multi-segment launches -- the same polling() passes in the same order, without a
+ * kernel boundary between consecutive calls.  While a batch is open only run_rounds and
+ * tick_prune may be called.  No reference counterpart: polling() is a loop, a batch is a stretch
+ * of its iterations submitted at once. */
+int  apus_gpu_batch_begin(apus_engine_t *e);
+int  apus_gpu_batch_end(apus_engine_t *e);
 /* one more polling() pass everywhere: brings every reachable follower's end,
  * commit and apply up to the leader's (update_remote_logs re-send + lazy commit) */
 int  apus_gpu_quiesce(apus_engine_t *e);

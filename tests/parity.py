@@ -61,15 +61,29 @@ def compare_apply_tail(eng, cl, r, last=512):
         assert np.array_equal(ga[name], oa[name]), f"replica {r}: apply field {name} differs"
 
 
-def lockstep(trace, eng, check_at=("PRUNE", "QUIESCE"), coalesce=True, allow_exact_fit=True):
+def lockstep(trace, eng, check_at=("PRUNE", "QUIESCE"), coalesce=True, allow_exact_fit=True, batch=False):
     """Feed the same events to the engine and to a fresh oracle cluster; compare
-    at every quiescent event.  Returns the oracle cluster."""
+    at every quiescent event.  Returns the oracle cluster.
+    batch=True: stretches of ROUND / PRUNE events go through apus_gpu_batch_begin/_end
+    (multi-segment launches); use check_at=("QUIESCE",) so that stretches span prune ticks."""
     cl = orc.Cluster(trace.group_size, trace.log_len, record_apply=True, allow_exact_fit=allow_exact_fit)
     eng.reset()
     eng.stage_trace(trace)
     reqs = np.ascontiguousarray(trace.reqs, dtype=orc.REQ_DTYPE)
     ev = trace.events
     i = 0
+    opened = False
+
+    def batch_open():
+        nonlocal opened
+        if batch and not opened:
+            eng.batch_begin(); opened = True
+
+    def batch_close():
+        nonlocal opened
+        if opened:
+            eng.batch_end(); opened = False
+
     while i < len(ev):
         op = ev[i][0]
         if op == "ROUND":
@@ -77,9 +91,14 @@ def lockstep(trace, eng, check_at=("PRUNE", "QUIESCE"), coalesce=True, allow_exa
             while j < len(ev) and ev[j][0] == "ROUND" and (coalesce or j == i):
                 cl.round(reqs[ev[j][1]:ev[j][1] + ev[j][2]], trace.arena)
                 j += 1
+            batch_open()
             eng.run_rounds(eng.round_of_g0[ev[i][1]], j - i)
             i = j
             continue
+        if op == "PRUNE" and op not in check_at:
+            batch_open()
+        else:
+            batch_close()
         if op == "ELECT":
             cl.elect(ev[i][1]); eng.elect(ev[i][1])
         elif op == "PRUNE":
@@ -104,5 +123,6 @@ def lockstep(trace, eng, check_at=("PRUNE", "QUIESCE"), coalesce=True, allow_exa
             compare_all(eng, cl, tag=f"event {i} {ev[i]}",
                         replicas=[r for r in range(trace.group_size) if r not in held])
         i += 1
+    batch_close()
     eng.check_status()
     return cl

@@ -83,6 +83,36 @@ def test_call_longer_than_one_launch(eng_factory):
         compare_apply_tail(eng, cl, r)
 
 
+@pytest.mark.parametrize("n", [1, 3, 5])
+def test_batched_segments_small_ring(eng_factory, n):
+    """apus_gpu_batch_begin/_end: stretches of calls and prune ticks as multi-segment launches
+    (k_step); a small ring so that wraps, exact fits and both sequencing variants occur."""
+    from tests.parity import lockstep, compare_apply_tail
+    eng = eng_factory(n, 1 << 16)
+    tr = T.steady_trace(n, 3000, 64, 16, 64, log_len=1 << 16)
+    for _ in range(4):
+        cl = lockstep(tr, eng, check_at=("QUIESCE",), batch=True)
+    for r in range(n):
+        compare_apply_tail(eng, cl, r)
+
+
+def test_batched_segments_mixed_sizes(eng_factory):
+    from tests.parity import lockstep, compare_apply_tail
+    eng = eng_factory(3, 8 << 20)
+    tr = T.steady_trace(3, 4 * 2600, (16, 40, 100, 900), 8, (1, 64), log_len=8 << 20, prune_bytes=256 << 10)
+    cl = lockstep(tr, eng, check_at=("QUIESCE",), batch=True)
+    for r in range(3):
+        compare_apply_tail(eng, cl, r)
+
+
+def test_batched_step_at_full_size(eng_factory):
+    """BASELINE configs[1] as one batch per pass: 17 segments, 16 fused prune ticks."""
+    from tests.parity import lockstep
+    eng = eng_factory(3, T.DEFAULT_LOG)
+    tr = T.config_c2()
+    lockstep(tr, eng, check_at=("QUIESCE",), batch=True)
+
+
 def test_rounds_one_by_one_match_coalesced(eng_factory):
     from tests.parity import lockstep
     eng = eng_factory(3, 1 << 16)

@@ -23,10 +23,10 @@ __global__ void coh(uint64_t* words, uint32_t* flag, uint32_t* stale, uint64_t* 
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1ull << 22)) __builtin_amdgcn_s_sleep(4);
     }
     __syncthreads();
-    if (acq) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");               // reader side: drop L1 / non-coherent L2 lines
+    if (acq == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");               // reader side: drop L1 / non-coherent L2 lines
     if (threadIdx.x < 64) {
         const uint64_t t0 = wall_clock64();
-        const uint64_t v = words[threadIdx.x];                                 // plain load
+        const uint64_t v = (acq == 2) ? __hip_atomic_load((unsigned long long*)&words[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : words[threadIdx.x];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint64_t t1 = wall_clock64();
         if (v != threadIdx.x + 1) atomicAdd(stale, 1u);
@@ -37,7 +37,7 @@ __global__ void coh(uint64_t* words, uint32_t* flag, uint32_t* stale, uint64_t* 
 int main() {
     const char* names[3] = {"hipMalloc (coarse-grained)", "hipExtMallocWithFlags(Finegrained)", "hipExtMallocWithFlags(Uncached)"};
     unsigned flags[3] = {0, hipDeviceMallocFinegrained, hipDeviceMallocUncached};
-    for (int acq = 0; acq < 2; acq++) for (int m = 0; m < 3; m++) for (int rep = 0; rep < 2; rep++) {
+    for (int acq = 0; acq < 3; acq++) for (int m = 0; m < 3; m++) for (int rep = 0; rep < 2; rep++) {
         uint64_t* w; uint32_t *flag, *stale; uint64_t* lat;
         if (flags[m]) { if (hipExtMallocWithFlags((void**)&w, 4096, flags[m]) != hipSuccess) { printf("%s: alloc failed\n", names[m]); break; } }
         else hipMalloc(&w, 4096);
@@ -47,7 +47,7 @@ int main() {
         uint32_t s[2]; uint64_t l[1024]; hipMemcpy(s, stale, 8, hipMemcpyDeviceToHost); hipMemcpy(l, lat, 8 * 1024, hipMemcpyDeviceToHost);
         double a = 0; for (int i = 1; i < 1024; i++) a += l[i];
         printf("%s %-36s run %d: stale words after the flag: %u of %d (pre-read nonzero: %u), plain re-read latency avg %.2f us\n",
-               acq ? "[reader acquires]" : "[plain re-read]  ", names[m], rep, s[0], 1023 * 64, s[1], a / 1023 / 100.0);
+               acq == 2 ? "[atomic re-read] " : acq ? "[reader acquires]" : "[plain re-read]  ", names[m], rep, s[0], 1023 * 64, s[1], a / 1023 / 100.0);
         hipFree(w); hipFree(flag); hipFree(stale); hipFree(lat);
     }
     return 0;
