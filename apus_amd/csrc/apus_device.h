@@ -139,7 +139,7 @@ struct EngDev {
     uint32_t *step_tickets;               /* [segs][32] */
     uint64_t *step_hash;                  /* [segs][2 x 1024] */
     uint64_t *step_snap;                  /* [segs + 1][SNAP_STRIDE] */
-    uint32_t *step_epoch, *step_seq_done, *step_app_done; /* [32 x 32] each: bookkeeper / sequencer / append phase of segment k done */
+    uint32_t *step_epoch, *step_seq_done; /* [32 x 32] each: bookkeeper / sequencer of segment k done */
     uint64_t *trace;                      /* -DAPUS_TRACE builds: [kernel][64] wall-clock stamps; else nullptr */
 };
 

@@ -169,7 +169,6 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     if (!rc) rc = dev_alloc(e, &e->d.step_snap, sizeof(uint64_t) * (APUS_STEP_SEGS + 1) * SNAP_STRIDE, true, hipDeviceMallocUncached);
     if (!rc) rc = dev_alloc(e, &e->d.step_epoch, sizeof(uint32_t) * 32 * 32);
     if (!rc) rc = dev_alloc(e, &e->d.step_seq_done, sizeof(uint32_t) * 32 * 32);
-    if (!rc) rc = dev_alloc(e, &e->d.step_app_done, sizeof(uint32_t) * 32 * 32);
 #ifdef APUS_TRACE
     if (!rc) rc = dev_alloc(e, &e->d.trace, 8 * 16 * 64);
 #else

@@ -346,6 +346,9 @@ __device__ static inline void seq_stage(const EngDev &E, uint64_t r0, uint32_t R
     else if (tid < 64 + APUS_DEV_MAX_SERVERS) { s_fw[tid - 64][0] = st0; s_fw[tid - 64][1] = st1; s_fw[tid - 64][2] = st2; s_fw[tid - 64][3] = st3; s_fw[tid - 64][4] = st4; }
     else if (tid == 96) s_misc[0] = st0;
     else if (tid == 97) s_misc[1] = st0;
+    else if (tid == 98) { q.pfx[0] = E.round_prefix ? E.round_prefix[r0] : 0; q.pfx[1] = q.pfx[0]; }      /* for seq_w0_decide */
+    else if (tid == 99) q.pfx[2] = E.round_prefix ? E.round_prefix[r0 + R] : ~0ull;
+    else if (tid == 100) { q.rfx[0] = rf[0]; q.rfx[1] = rf[R]; }
     if (tid == 0) { s_rstar = 0xFFFFFFFFu; s_head_round = 0; }
     __syncthreads();
     if (blockIdx.x == 0) STAMP(0, 1);
@@ -549,15 +552,15 @@ __device__ static inline void seq_w0_stage(const EngDev &E, uint64_t r0, uint32_
                                            const uint64_t *snap = nullptr, bool need_tail = false)
 {
     const uint32_t lane = lane_id();
-    auto fw_word = [&](uint32_t k) -> uint64_t {                 /* q.fw[f][j], j = FW_END .. FW_N_APPLY */
-        const uint32_t f = k / 5, j = k - f * 5;
-        if ((push_mask >> f) & 1u) return stage_follower_word(E, snap, f, j);
-        return j == FW_N_PERSIST ? ~0ull : 0ull;
-    };
+    /* q.fw[f][j], j = FW_END .. FW_N_APPLY: word k = 5 f + j by lane k (and word 64 by lane 0).  The
+     * follower's control block is addressed through the pointer table in HBM-resident kernarg
+     * memory, never through a private copy of E */
+    const uint32_t kf = lane / 5, kj = lane - kf * 5;
     const uint64_t v0 = stage_leader_word(E, snap, lane);
-    const uint64_t f0 = fw_word(lane);
+    uint64_t f0 = kj == FW_N_PERSIST ? ~0ull : 0ull;
+    if ((push_mask >> kf) & 1u) f0 = stage_follower_word(E, snap, kf, kj);
     uint64_t x = 0;
-    if (lane == 0) x = fw_word(64);
+    if (lane == 0) { x = 0; if ((push_mask >> 12) & 1u) x = stage_follower_word(E, snap, 12, FW_N_APPLY); }
     else if (lane == 1) x = stage_rec_count(E, snap);
     else if (lane == 2) x = E.round_prefix[r0];
     else if (lane == 3) x = E.round_prefix[r0 + my_r];
@@ -577,6 +580,11 @@ __device__ static inline void seq_w0_stage(const EngDev &E, uint64_t r0, uint32_
     else if (lane == 7) q.misc[1] = x;
 }
 
+/* FX = true: the sequencer block's own use of it -- the same decisions, plus every effect
+ * (the tick's <HEAD> entry, the sampled apply offsets, the control words, SeqOut); it declines
+ * (q.ok = 0, nothing stored) whenever the block-wide sequencer is needed: a possible wrap, or a
+ * pushed follower that lags. */
+template <bool FX>
 __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask, uint32_t tick, SeqLds &q)
 {
     const uint64_t L = E.log_len;
@@ -584,27 +592,56 @@ __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask,
     const uint64_t e_pre = q.lh[H_END];
     /* clear of len even if a <HEAD> entry (64 bytes) goes in front of the batch? */
     if (e_pre == L || e_pre + APUS_HDR + vtot >= L) { q.ok = 0; return; }
+    if (FX) {
+        const uint64_t n_pre = q.lh[H_N_END];
+        for (uint32_t m = push_mask; m; m &= m - 1)
+            if (q.fw[__builtin_ctz(m)][1] < n_pre) { q.ok = 0; return; }       /* catch-up first: the block-wide path */
+    }
+    uint64_t *hdr = E.rep[E.leader].hdr;
     uint32_t fuse_mask; bool in_step;
     seq_in_step(E, q.lh, q.fw, push_mask, fuse_mask, in_step);
     uint32_t head_round = 0;
     if (tick) {
-        head_round = control_append<false>(E, 1, 3, 0, 0, push_mask, q.lh, q.misc[0], fuse_mask, in_step).n;
+        if (FX) for (uint32_t i = 0; i < APUS_DEV_MAX_SERVERS; i++) sample_apply_offsets(E, q.lh, push_mask, i, &q.fw[i][2]);
+        head_round = control_append<FX>(E, 1, 3, 0, 0, push_mask, q.lh, q.misc[0], fuse_mask, in_step, false).n;
         for (uint32_t i = 0; i < APUS_DEV_MAX_SERVERS; i++) sample_into_copy(E, q.lh, push_mask, i, q.fw[i][2]);
     }
     const uint32_t n = q.rfx[1] - q.rfx[0];
-    SeqOut s;
+    SeqOut &s = q.out;              /* built in LDS: 31 words of it in registers cost occupancy */
     s.e0 = q.lh[H_END]; s.idx0 = q.lh[H_LAST_IDX] + 1; s.w = 0; s.n_end0 = q.lh[H_N_END];
     s.term = q.lh[H_SID] >> 9; s.kstar = -1; s.estar = -1; s.stale = 0; s.n = n; s.head_round = head_round; s.pad0 = 0;
     s.first_fail = ~0ull; s.commit_before = q.lh[H_COMMIT]; s.n_commit_before = q.lh[H_N_COMMIT];
     const SeqFlags fl = seq_flags(E, push_mask, fuse_mask, in_step, false, n, s.n_commit_before, s.n_end0, head_round);
-    s.vis = s.n_end0 + n; s.scan_lo = 0;
-    for (uint32_t f = 0; f < APUS_DEV_MAX_SERVERS; f++) s.np[f] = ~0ull;       /* not used by an append block */
+    s.vis = s.n_end0 + n;
+    {
+        uint64_t lo = s.n_commit_before;
+        for (uint32_t f = 0; f < APUS_DEV_MAX_SERVERS; f++) {
+            uint64_t npf = q.fw[f][3];                                  /* ~0 for servers not pushed to */
+            if ((fuse_mask >> f) & 1u) npf = ((fl.fuse_batch >> f) & 1u) ? ~0ull : npf + head_round;
+            s.np[f] = npf;
+            lo = min(lo, npf);
+        }
+        s.scan_lo = lo;
+    }
     s.fuse_mask = fl.fuse_batch; s.tail_needed = fl.tail_needed; s.fast = fl.fast; s.pad1 = 0; s.rec_base = q.misc[0];
-    q.out = s;
     q.end_new = n ? s.e0 + vtot : s.e0;
+    if (FX) {
+        /* free space: the reference only notices end == head exactly (dare_log.h:168) */
+        const uint64_t head = q.lh[H_HEAD], e0 = s.e0;
+        const uint64_t used = e0 >= head ? e0 - head : L - (head - e0);
+        if (n && vtot >= L - used) set_status(E, 1u << 1);
+        /* (the caller copies q.out to E.seq with a wave) */
+    }
     /* q.lh becomes the control block as the sequencer leaves it (H_TAIL is only right when the
-     * length of the batch's last request was staged: the bookkeeper does) */
-    if (n) seq_apply_batch(q.lh, q.end_new, APUS_HDR + q.misc[1], s.n_end0, n, s.idx0, -1);
+     * length of the batch's last request was staged: the bookkeeper and the sequencer do) */
+    if (n) {
+        seq_apply_batch(q.lh, q.end_new, APUS_HDR + q.misc[1], s.n_end0, n, s.idx0, -1);
+        if (FX) {
+            hdr[H_END] = q.lh[H_END]; hdr[H_TAIL] = q.lh[H_TAIL]; hdr[H_N_END] = q.lh[H_N_END];
+            hdr[H_LAST_IDX] = q.lh[H_LAST_IDX]; hdr[H_PREV_HEAD] = 0; hdr[H_OLD_END] = q.lh[H_OLD_END];
+            hdr[H_N_PERSIST] = q.lh[H_N_PERSIST]; hdr[H_STORE_COUNT] = q.lh[H_STORE_COUNT];
+        }
+    }
     q.my_virt = q.pfx[1] - q.pfx[0];
     q.ok = 1;
 }
@@ -620,7 +657,7 @@ __device__ static inline void seq_local(const EngDev &E, const CallEnv &X, uint6
         seq_w0_stage(E, r0, R, push_mask, my_r, q, snap, need_tail);
         if (tid == 0) {
             if (post_read) __hip_atomic_fetch_add(X.lines + (read_line & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            seq_w0_decide(E, push_mask, tick, q);
+            seq_w0_decide<false>(E, push_mask, tick, q);
         }
     }
     __syncthreads();
@@ -709,7 +746,7 @@ __device__ static inline void append_round(const EngDev &E, const CallEnv &X, ui
         }
         __syncthreads();
         /* one lane of wave 1 works the call's SeqOut out while wave 0 lays the round out */
-        if (tid == WAVE) seq_w0_decide(E, push_mask, tick, *sq);
+        if (tid == WAVE) seq_w0_decide<false>(E, push_mask, tick, *sq);
     }
     if (tid < WAVE) {
         T = active ? APUS_HDR + d.len : 0;
@@ -1618,9 +1655,6 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
     if (b >= 1 && b <= nAB) {                                  /* ---- append + push ---- */
         const uint32_t ab = b - 1, r = ab / SP, slice = ab - r * SP;
         if (!live) wait_count(E, E.step_epoch, b, seg);
-        /* at most two segments append at a time: a later lap of the ring must not be overtaken by
-         * stores of the lap it overwrites (segment seg - 2 and everything before it is complete) */
-        if (STEP && seg >= 2) wait_count(E, E.step_app_done, b, seg - 1);
         if (b == nAB) STAMP(6, 0);
         append_round<true>(E, X, r0, R, push_mask, r, l.app, &sq, tick, slice, SP, snap, live);
         if (b == nAB) STAMP(6, 1);
@@ -1633,8 +1667,14 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
         seq_stage(E, r0, R, push_mask, push_mask, sq, true, snap);
         if (live) wait_readers(E, X, n_readers);               /* every reader has its copy of the inputs */
         if (STEP && seg) wait_count(E, E.step_seq_done, b, seg);   /* the previous segment's sequencer is done */
-        if (STEP && seg >= 2) wait_count(E, E.step_app_done, b, seg - 1);   /* its <HEAD> entry goes into the ring too */
-        seq_body<true>(E, r0, R, push_mask, tick, push_mask, sq, 0, false);
+        /* the common case needs no block-wide scan: one lane decides and does the effects */
+        if (tid == 0) seq_w0_decide<true>(E, push_mask, tick, sq);
+        __syncthreads();
+        if (sq.ok) {
+            if (tid < sizeof(SeqOut) / 8) ((uint64_t *)E.seq)[tid] = ((const uint64_t *)&sq.out)[tid];
+        } else {                                               /* possible wrap / lagging follower: the full sequencer */
+            seq_body<true>(E, r0, R, push_mask, tick, push_mask, sq, 0, false);
+        }
         __syncthreads();
         const bool fast = sq.out.fast != 0;
         if (!fast && tid == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   /* SeqOut, control words, <HEAD> entry */
@@ -1679,12 +1719,6 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
         /* the janitor: every append block is done (wait_append above), everybody else -- the
          * sequencer with its <HEAD> entry too -- signs off with T_PASS */
         wait_ticket(E, X, T_PASS, n_pass);
-        if (STEP) {
-            /* the segment is complete: nothing of it will be stored into the ring any more, which
-             * is what the segment after next waits for before it appends (in order) */
-            if (seg) wait_count(E, E.step_app_done, b, seg);
-            bump_count(E.step_app_done, seg + 1);
-        }
         /* then the call's counters and the flag are cleared for the next call */
         if (tid < 32) {
             __hip_atomic_store(X.lines + tid * 32 + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1693,7 +1727,6 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
             if (STEP && seg + 1 == S) {                        /* the launch's last segment: its chain counts too */
                 __hip_atomic_store(E.step_epoch + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(E.step_seq_done + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(E.step_app_done + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else if (tid == 32) {
             __hip_atomic_store(X.ticket + T_PASS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1798,8 +1831,12 @@ struct StepTable {
     uint32_t blk0[APUS_STEP_SEGS + 1];        /* first block of every segment; blk0[S] = grid size */
     uint32_t S;
 };
-__global__ __launch_bounds__(256) void k_step(const EngDev E, const StepTable T, uint32_t push_mask, uint32_t rmask)
+__global__ __launch_bounds__(256) void k_step(const EngDev E_arg, const StepTable T, uint32_t push_mask, uint32_t rmask)
 {
+    /* E is used where it lies in the kernarg segment (first argument): with this much code behind
+     * it the compiler otherwise copies the 950-byte struct into scratch for per-lane indexing */
+    const EngDev &E = *(const EngDev *)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)E_arg;
     __shared__ SeqLds sq;
     __shared__ CallLds l;
     uint32_t seg = 0;
@@ -2043,7 +2080,7 @@ __global__ void k_reset(const EngDev E)
         *E.rec_count = 0; *E.status = 0;
         for (int i = 0; i < 8; i++) E.ticket[i] = 0;
         for (int i = 0; i < 32; i++) { E.tick_lines[i * 32] = 0; E.tick_lines[i * 32 + 1] = 0; E.tick_lines[i * 32 + 2] = 0; }
-        for (int i = 0; i < 32; i++) { E.step_epoch[i * 32] = 0; E.step_seq_done[i * 32] = 0; E.step_app_done[i * 32] = 0; }
+        for (int i = 0; i < 32; i++) { E.step_epoch[i * 32] = 0; E.step_seq_done[i * 32] = 0; }
         for (int i = 0; i < APUS_STEP_SEGS * 1024; i++) E.step_lines[i] = 0;
         for (int i = 0; i < APUS_STEP_SEGS * 32; i++) E.step_tickets[i] = 0;
     }

@@ -96,6 +96,16 @@ def test_batched_segments_small_ring(eng_factory, n):
         compare_apply_tail(eng, cl, r)
 
 
+def test_batched_repeated_runs_stay_bit_exact(eng_factory):
+    """The multi-segment launch hands control state from segment to segment through snapshots
+    and chain counts: run the small 5-replica stream many times as batches."""
+    from tests.parity import lockstep
+    eng = eng_factory(5, 1 << 16)
+    tr = T.steady_trace(5, 3000, 64, 16, 64, log_len=1 << 16)
+    for _ in range(12):
+        lockstep(tr, eng, check_at=("QUIESCE",), batch=True)
+
+
 def test_batched_segments_mixed_sizes(eng_factory):
     from tests.parity import lockstep, compare_apply_tail
     eng = eng_factory(3, 8 << 20)
