@@ -115,11 +115,13 @@ def test_batched_segments_mixed_sizes(eng_factory):
         compare_apply_tail(eng, cl, r)
 
 
-def test_batched_step_at_full_size(eng_factory):
-    """BASELINE configs[1] as one batch per pass: 17 segments, 16 fused prune ticks."""
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
+def test_batched_step_at_full_size(eng_factory, cfg):
+    """BASELINE configs[1..3] with every pass submitted as batches (c2: 17 segments, 16 fused
+    prune ticks, three launches because a launch never laps the 64 MiB ring)."""
     from tests.parity import lockstep
-    eng = eng_factory(3, T.DEFAULT_LOG)
-    tr = T.config_c2()
+    tr = {"c2": T.config_c2, "c3": T.config_c3, "c4": T.config_c4}[cfg]()
+    eng = eng_factory(tr.group_size, T.DEFAULT_LOG)
     lockstep(tr, eng, check_at=("QUIESCE",), batch=True)
 
 
