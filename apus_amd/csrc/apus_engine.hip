@@ -62,7 +62,7 @@ struct apus_engine {
     uint8_t *d_live;
     hipEvent_t live_copied;
     bool live_pending;
-    uint64_t live_r0, live_R, live_n;   /* rounds appended by apus_gpu_append_live, not yet committed */
+    uint64_t live_r0, live_R, live_n, live_bytes;   /* rounds appended by apus_gpu_append_live, not yet committed */
     /* persistent consensus kernel (live / latency path) */
     PersistHost *ph;                /* pinned, coherent */
     PersistHost *ph_dev;            /* device view of the same memory */
@@ -78,12 +78,15 @@ struct apus_engine {
 #define LIVE_OFF_LEN    (sizeof(ReqDev) * LIVE_REQS)
 #define LIVE_OFF_RF     (LIVE_OFF_LEN + sizeof(uint16_t) * LIVE_REQS)
 #define LIVE_OFF_RB     (LIVE_OFF_RF + sizeof(uint32_t) * (LIVE_REQS + 1))
-#define LIVE_OFF_ARENA  (LIVE_OFF_RB + sizeof(uint32_t) * LIVE_REQS + 16)
+#define LIVE_OFF_PFX    ((LIVE_OFF_RB + sizeof(uint32_t) * LIVE_REQS + 7) & ~(size_t)7)
+#define LIVE_OFF_ARENA  ((LIVE_OFF_PFX + sizeof(uint64_t) * (LIVE_REQS + 1) + 31) & ~(size_t)15)
 #define LIVE_BYTES      (LIVE_OFF_ARENA + LIVE_ARENA + 64)
 
 static apus_engine *g_engine = nullptr;
 static int flush_tick(apus_engine *e);
 extern "C" int apus_gpu_persist_stop(apus_engine_t *e);
+
+static int flush_live(apus_engine *e);        /* a staged live batch runs before anything else touches the engine */
 
 template <typename T>
 static int dev_alloc(apus_engine *e, T **out, size_t bytes, bool zero = true, unsigned ext_flags = 0)
@@ -212,6 +215,7 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
 
 extern "C" int apus_gpu_sync(apus_engine_t *e)
 {
+    if (e && e->live_R) { int rc_ = flush_live(e); if (rc_) return rc_; }
     if (e && e->batching) return APUS_E_STATE;      /* close the batch first (apus_gpu_batch_end) */
     if (!e) return APUS_E_ARG;
     { int frc = flush_tick(e); if (frc) return frc; }
@@ -443,6 +447,7 @@ static int flush_batch(apus_engine *e)
 
 extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rounds)
 {
+    if (e && e->live_R) { int rc_ = flush_live(e); if (rc_) return rc_; }
     int rc = need_leader(e);
     if (rc) return rc;
     if (r0 + n_rounds > e->n_rounds_staged || n_rounds > e->max_rounds) return APUS_E_ARG;
@@ -486,6 +491,7 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
  * tick_prune may be called while a batch is open. */
 extern "C" int apus_gpu_batch_begin(apus_engine_t *e)
 {
+    if (e && e->live_R) { int rc_ = flush_live(e); if (rc_) return rc_; }
     int rc = need_leader(e);
     if (rc) return rc;
     if (e->batching) return APUS_E_STATE;
@@ -514,6 +520,7 @@ static int live_view(apus_engine *e, EngDev *view)
     view->req_len = (const uint16_t *)(e->d_live + LIVE_OFF_LEN);
     view->round_first = (const uint32_t *)(e->d_live + LIVE_OFF_RF);
     view->round_bytes = (const uint32_t *)(e->d_live + LIVE_OFF_RB);
+    view->round_prefix = (const uint64_t *)(e->d_live + LIVE_OFF_PFX);
     view->arena = e->d_live + LIVE_OFF_ARENA;
     return 0;
 }
@@ -544,11 +551,14 @@ extern "C" int apus_gpu_append_live(apus_engine_t *e, const apus_req_t *reqs, ui
         hd[g].len = q.len; hd[g].clt_id = q.clt_id; hl[g] = q.len;
     }
     uint32_t *rb = (uint32_t *)(e->h_live + LIVE_OFF_RB);
+    uint64_t *pf = (uint64_t *)(e->h_live + LIVE_OFF_PFX);
     uint32_t R = 0;
+    pf[0] = 0;
     for (uint32_t g = 0; g < n; g += APUS_MAX_ROUND) {
         uint32_t bytes = 0;
         for (uint32_t k = g; k < n && k < g + APUS_MAX_ROUND; k++) bytes += APUS_HDR + (uint32_t)hl[k];
         rb[R] = bytes;
+        pf[R + 1] = pf[R] + bytes;
         rf[R++] = g;
     }
     rf[R] = n;
@@ -556,8 +566,32 @@ extern "C" int apus_gpu_append_live(apus_engine_t *e, const apus_req_t *reqs, ui
     HIPCHK(hipMemcpyAsync(e->d_live, e->h_live, LIVE_OFF_ARENA + 16 + arena_bytes, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipEventRecord(e->live_copied, e->stream));
     e->live_pending = true;
-    if ((rc = launch_append(e, view, 0, R))) return rc;
-    e->live_r0 = 0; e->live_R = R; e->live_n = n;
+    /* The entries are staged; the consensus pass over them -- append, replication, ACKs, commit,
+     * apply -- is ONE launch (k_call), issued by apus_gpu_commit_live (dare_ib_write_remote_logs,
+     * which polling() calls right after dare_ib_poll_tailq) or by whatever engine call comes next. */
+    e->live_r0 = 0; e->live_R = R; e->live_n = n; e->live_bytes = pf[R];
+    return 0;
+}
+
+/* the staged live batch as one k_call launch over the live view */
+static int flush_live(apus_engine *e)
+{
+    if (!e->live_R) return 0;
+    int rc;
+    EngDev view;
+    if ((rc = live_view(e, &view))) return rc;
+    if ((rc = launch_catchup(e))) return rc;
+    const uint32_t fm = sync_mask(e);
+    const uint32_t rm = fm | ((e->local_mask >> e->d.leader) & 1u ? (1u << e->d.leader) : 0);
+    const uint32_t R = (uint32_t)e->live_R;
+    CallArgs a;
+    a.r0 = 0; a.R = R; a.tick = e->tick_pending ? 1u : 0u;
+    e->tick_pending = false;
+    a.nS = cap_grid(e->live_n, 256, 32); a.nA = cap_grid(e->live_n, 1024, 16); a.nR = cap_grid(R, 256, 8);
+    a.SP = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (e->live_bytes / 16 / R + 512) / 768));
+    hipLaunchKernelGGL(k_call, dim3(1 + R * a.SP + a.nR + 1 + a.nS + a.nA * popc(rm)), dim3(256), 0, e->stream, view, a, fm, rm);
+    e->live_R = 0;
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -568,12 +602,8 @@ extern "C" int apus_gpu_commit_live(apus_engine_t *e, int wait_for_commit)
     if (rc) return rc;
     EngDev view;
     if ((rc = live_view(e, &view))) return rc;
-    if (e->live_R) {
-        rc = launch_tail_view(e, view, e->live_r0, (uint32_t)e->live_R, 0, e->live_n);
-        e->live_R = 0;
-    } else {
-        rc = apus_gpu_quiesce(e);
-    }
+    if (e->live_R) rc = flush_live(e);
+    else rc = apus_gpu_quiesce(e);
     if (rc) return rc;
     if (wait_for_commit) HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
@@ -607,6 +637,7 @@ static int launch_control_round(apus_engine *e, int mode, uint32_t type, uint64_
 
 extern "C" int apus_gpu_quiesce(apus_engine_t *e)
 {
+    if (e && e->live_R) { int rc_ = flush_live(e); if (rc_) return rc_; }
     if (e && e->batching) return APUS_E_STATE;      /* close the batch first (apus_gpu_batch_end) */
     int rc = need_leader(e);
     if (rc) return rc;
@@ -616,6 +647,7 @@ extern "C" int apus_gpu_quiesce(apus_engine_t *e)
 
 extern "C" int apus_gpu_append_control(apus_engine_t *e, uint8_t type, const void *data)
 {
+    if (e && e->live_R) { int rc_ = flush_live(e); if (rc_) return rc_; }
     if (e && e->batching) return APUS_E_STATE;      /* close the batch first (apus_gpu_batch_end) */
     int rc = need_leader(e);
     if (rc) return rc;
@@ -632,6 +664,7 @@ extern "C" int apus_gpu_append_control(apus_engine_t *e, uint8_t type, const voi
  * caught up after every call, so no separate quiesce pass is needed. */
 extern "C" int apus_gpu_tick_prune(apus_engine_t *e)
 {
+    if (e && e->live_R) { int rc_ = flush_live(e); if (rc_) return rc_; }
     int rc = need_leader(e);
     if (rc) return rc;
     /* an open batch: anything that has to run now goes behind what was recorded so far */
