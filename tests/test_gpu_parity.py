@@ -156,7 +156,11 @@ def test_1KiB_entries_five_replicas(eng_factory):
     lockstep(tr, eng)
 
 
-def test_hold_and_release_catch_up(eng_factory):
+BATCH_MODES = [pytest.param({}, id="per-call"), pytest.param({"batch": True, "check_at": ("QUIESCE",)}, id="batched")]
+
+
+@pytest.mark.parametrize("mode", BATCH_MODES)
+def test_hold_and_release_catch_up(eng_factory, mode):
     from tests.parity import lockstep
     n, L = 5, 1 << 19
     base = T.steady_trace(n, 2000, 64, 8, 32, log_len=L)
@@ -175,10 +179,11 @@ def test_hold_and_release_catch_up(eng_factory):
             if k == 36:
                 ev.append(("RELEASE", 4)); ev.append(("RELEASE", 1)); ev.append(("QUIESCE",))
     base.events = [e for e in ev if e[0] != "PRUNE"]
-    lockstep(base, eng_factory(n, L))
+    lockstep(base, eng_factory(n, L), **mode)
 
 
-def test_no_quorum_no_commit(eng_factory):
+@pytest.mark.parametrize("mode", BATCH_MODES)
+def test_no_quorum_no_commit(eng_factory, mode):
     """With a majority unreachable nothing commits; it all commits on release."""
     from tests.parity import lockstep
     n, L = 3, 1 << 16
@@ -197,19 +202,20 @@ def test_no_quorum_no_commit(eng_factory):
                 ev += [("RELEASE", 1), ("QUIESCE",)]
     base.events = ev
     eng = eng_factory(n, L)
-    cl = lockstep(base, eng)
+    cl = lockstep(base, eng, **mode)
     gc, ge = eng.round_record()
     assert (gc != ge).any()          # some rounds ended without a commit
 
 
-def test_exact_fit_wrap_restarts_index(eng_factory):
+@pytest.mark.parametrize("mode", BATCH_MODES)
+def test_exact_fit_wrap_restarts_index(eng_factory, mode):
     """an append that lands exactly on len makes the log read as
     empty; the next entry gets idx 1.  128-byte entries on a 2^k ring hit it."""
     from tests.parity import lockstep
     L = 1 << 14
     tr = T.steady_trace(3, 1024, 64, 1, 8, log_len=L, prune_bytes=L // 4)
     eng = eng_factory(3, L)
-    cl = lockstep(tr, eng)
+    cl = lockstep(tr, eng, **mode)
     # the index restarted at least once: last idx is far smaller than the entry count
     assert eng.counters(0)["last_idx"] < 1024
 
@@ -257,14 +263,15 @@ def test_graph_replay_equals_eager(eng_factory):
     compare_all(eng, cl, tag="graph replay")
 
 
-def test_failover_reconf_bench_shape(eng_factory):
+@pytest.mark.parametrize("mode", BATCH_MODES)
+def test_failover_reconf_bench_shape(eng_factory, mode):
     """BASELINE config 5: bench, kill the leader, elect, bench, kill a follower, bench
     (benchmarks/reconf_bench.sh:249-343), 107/40-byte requests, 5 replicas."""
     from tests.parity import lockstep
     L = 1 << 19
     tr = T.config_c5(per_phase=1500, log_len=L, batch=16)
     eng = eng_factory(5, L)
-    cl = lockstep(tr, eng)
+    cl = lockstep(tr, eng, **mode)
     assert cl.leader == 1 and cl.term(1) == 4
     assert eng.counters(1)["sid"] == cl.sid(1)
 
