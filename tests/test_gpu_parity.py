@@ -208,6 +208,28 @@ def test_no_quorum_no_commit(eng_factory, mode):
 
 
 @pytest.mark.parametrize("mode", BATCH_MODES)
+def test_no_quorum_across_prune_ticks(eng_factory, mode):
+    """A majority unreachable over several calls and prune ticks (in batched mode: consecutive
+    not-in-step segments of one launch, a commit backlog that spans segments), then release."""
+    from tests.parity import lockstep
+    n, L = 3, 1 << 18
+    base = T.steady_trace(n, 1200, 64, 4, 16, log_len=L, prune_bytes=8 << 10)
+    ev = []
+    k = 0
+    for e in base.events:
+        ev.append(e)
+        if e[0] == "ROUND":
+            k += 1
+            if k == 6:
+                ev += [("HOLD", 1), ("HOLD", 2)]
+            if k == 40:
+                ev += [("RELEASE", 1), ("RELEASE", 2), ("QUIESCE",)]
+    base.events = ev
+    eng = eng_factory(n, L)
+    lockstep(base, eng, **mode)
+
+
+@pytest.mark.parametrize("mode", BATCH_MODES)
 def test_exact_fit_wrap_restarts_index(eng_factory, mode):
     """an append that lands exactly on len makes the log read as
     empty; the next entry gets idx 1.  128-byte entries on a 2^k ring hit it."""
