@@ -1575,13 +1575,13 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
     STAMP(3, 3);
 }
 
-/* k_call: a whole run_rounds call (R <= 1024 rounds) in ONE launch.  Block roles by index:
- *   0                         the sequencer
- *   [1, R * SP]               append + push (+ fused persist/ACK, + apply when in step): one round each,
+/* k_call: a whole run_rounds call (R <= 1024 rounds) in ONE launch.  Block roles by grid index:
+ *   0                         the bookkeeper
+ *   1                         the sequencer
+ *   [2, 2 + R * SP)           append + push (+ fused persist/ACK, + apply when in step): one round each,
  *                             or SP workgroups per round when the rounds are large (host's choice)
  *   [.., + nR)                the leader's per-round record (+ fast-path hash fold); recorder 0 is
  *                             also the janitor: last to leave, it clears the call's counters
- *   next                      the bookkeeper
  *   [.., + nS)                follower persist + ACK + quorum scan; idle unless SeqOut::tail_needed
  *   [.., + nA * replicas)     apply_committed_entries per replica; idle when in step (SeqOut::fast)
  * Nobody waits for the sequencer on the fast path: every append block (and record block) works
@@ -1633,10 +1633,23 @@ __device__ static inline void bump_count(uint32_t *lines32, uint32_t value)
  * effects are chained by their own count. */
 template <bool STEP>
 __device__ static inline void call_block(const EngDev &E, const CallEnv &X, const CallArgs &A, uint32_t push_mask, uint32_t rmask,
-                                         uint32_t b, SeqLds &sq, CallLds &l, uint32_t seg, uint32_t S)
+                                         uint32_t b_grid, SeqLds &sq, CallLds &l, uint32_t seg, uint32_t S)
 {
     const uint64_t r0 = A.r0;
     const uint32_t R = A.R, tick = A.tick, SP = A.SP, nR = A.nR, nS = A.nS, nA = A.nA;
+    /* Order in the grid: bookkeeper, sequencer, append blocks, record blocks, scan, apply.  The two
+     * single blocks come FIRST: workgroups are dispatched in index order, and in a multi-segment
+     * launch the next segment's append blocks wait for this segment's bookkeeper -- it must not
+     * queue behind a thousand append blocks of its own segment.  (b below is the role index the
+     * rest of the function was written in: sequencer 0, append 1 .. nAB, records, bookkeeper, ...) */
+    uint32_t b;
+    {
+        const uint32_t nAB_ = R * SP;
+        if (b_grid == 0) b = 1 + nAB_ + nR;                    /* the bookkeeper */
+        else if (b_grid == 1) b = 0;                           /* the sequencer */
+        else if (b_grid < 2 + nAB_ + nR) b = b_grid - 1;       /* append and record blocks */
+        else b = b_grid;                                       /* scan and apply blocks */
+    }
     const uint32_t tid = threadIdx.x;
     const uint32_t ny = (uint32_t)__popc(rmask);
     const uint32_t fmask = push_mask;

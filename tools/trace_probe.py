@@ -16,10 +16,13 @@ while i < len(ev):
         calls.append((eng.round_of_g0[ev[i][1]], j - i)); i = j; continue
     if ev[i][0] == "PRUNE": calls.append(None)
     i += 1
+batch = "--batch" in sys.argv        # the calls as one multi-segment launch (k_step): stamps of its last segment
 for rep in range(2):
+    if batch: eng.batch_begin()
     for c in calls[:9]:
         if c is None: eng.tick_prune()
         else: eng.run_rounds(*c)
+    if batch: eng.batch_end()
 eng.sync()
 L = eng.L
 L.apus_gpu_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
