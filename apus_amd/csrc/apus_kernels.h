@@ -584,7 +584,9 @@ __device__ static inline void seq_w0_stage(const EngDev &E, uint64_t r0, uint32_
  * (the tick's <HEAD> entry, the sampled apply offsets, the control words, SeqOut); it declines
  * (q.ok = 0, nothing stored) whenever the block-wide sequencer is needed: a possible wrap, or a
  * pushed follower that lags. */
-template <bool FX>
+/* LEAN: only what an append / record block needs of SeqOut (no follower table, no post-call
+ * control block): this lane's work sits on every append block's critical path */
+template <bool FX, bool LEAN = false>
 __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask, uint32_t tick, SeqLds &q)
 {
     const uint64_t L = E.log_len;
@@ -604,7 +606,7 @@ __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask,
     if (tick) {
         if (FX) for (uint32_t i = 0; i < APUS_DEV_MAX_SERVERS; i++) sample_apply_offsets(E, q.lh, push_mask, i, &q.fw[i][2]);
         head_round = control_append<FX>(E, 1, 3, 0, 0, push_mask, q.lh, q.misc[0], fuse_mask, in_step, false).n;
-        for (uint32_t i = 0; i < APUS_DEV_MAX_SERVERS; i++) sample_into_copy(E, q.lh, push_mask, i, q.fw[i][2]);
+        if (!LEAN) for (uint32_t i = 0; i < APUS_DEV_MAX_SERVERS; i++) sample_into_copy(E, q.lh, push_mask, i, q.fw[i][2]);
     }
     const uint32_t n = q.rfx[1] - q.rfx[0];
     SeqOut &s = q.out;              /* built in LDS: 31 words of it in registers cost occupancy */
@@ -613,7 +615,7 @@ __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask,
     s.first_fail = ~0ull; s.commit_before = q.lh[H_COMMIT]; s.n_commit_before = q.lh[H_N_COMMIT];
     const SeqFlags fl = seq_flags(E, push_mask, fuse_mask, in_step, false, n, s.n_commit_before, s.n_end0, head_round);
     s.vis = s.n_end0 + n;
-    {
+    if (!LEAN) {
         uint64_t lo = s.n_commit_before;
         for (uint32_t f = 0; f < APUS_DEV_MAX_SERVERS; f++) {
             uint64_t npf = q.fw[f][3];                                  /* ~0 for servers not pushed to */
@@ -634,7 +636,7 @@ __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask,
     }
     /* q.lh becomes the control block as the sequencer leaves it (H_TAIL is only right when the
      * length of the batch's last request was staged: the bookkeeper and the sequencer do) */
-    if (n) {
+    if (n && !LEAN) {
         seq_apply_batch(q.lh, q.end_new, APUS_HDR + q.misc[1], s.n_end0, n, s.idx0, -1);
         if (FX) {
             hdr[H_END] = q.lh[H_END]; hdr[H_TAIL] = q.lh[H_TAIL]; hdr[H_N_END] = q.lh[H_N_END];
@@ -746,7 +748,7 @@ __device__ static inline void append_round(const EngDev &E, const CallEnv &X, ui
         }
         __syncthreads();
         /* one lane of wave 1 works the call's SeqOut out while wave 0 lays the round out */
-        if (tid == WAVE) seq_w0_decide<false>(E, push_mask, tick, *sq);
+        if (tid == WAVE) seq_w0_decide<false, true>(E, push_mask, tick, *sq);
     }
     if (tid < WAVE) {
         T = active ? APUS_HDR + d.len : 0;
