@@ -1739,7 +1739,12 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
             __hip_atomic_store(X.lines + tid * 32 + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(X.lines + tid * 32 + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(X.lines + tid * 32 + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (STEP && seg + 1 == S) {                        /* the launch's last segment: its chain counts too */
+            /* the launch's last segment: its chain counts too.  Every block that reads them belongs
+             * to this or an earlier segment; this segment's have all signed off (above), earlier
+             * segments' were dispatched before any block of this one and read the counts first thing
+             * -- a block that had not got that far by now would have stalled for a whole segment and
+             * runs into its bounded spin (status bit 4), it cannot hang */
+            if (STEP && seg + 1 == S) {
                 __hip_atomic_store(E.step_epoch + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(E.step_seq_done + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
