@@ -1253,7 +1253,7 @@ __device__ static inline void finish_call(const EngDev &E, uint64_t r0, uint32_t
     const uint64_t commit_off = (cs > s.n_commit_before) ? slot_off(cs) : s.commit_before;
     const uint64_t vis_off = slot_off(vis);
     const uint64_t apply_l = lh[H_N_APPLY];
-    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    const uint32_t tid = threadIdx.x;
     const uint64_t rec_base = *E.rec_count;
     __syncthreads();                                  /* everybody sampled the control words */
 
