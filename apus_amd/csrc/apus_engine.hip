@@ -47,6 +47,7 @@ struct apus_engine {
     std::vector<uint32_t> h_round_first;
     std::vector<uint64_t> h_round_prefix;      /* byte prefix of the staged rounds */
     bool batching;                             /* apus_gpu_batch_begin .. _end */
+    uint64_t sp_units;                         /* APUS_SP_UNITS (default 768), see call_args */
     struct BatchSeg { CallArgs a; uint32_t blocks; uint64_t bytes; };
     std::vector<BatchSeg> batch;               /* recorded calls: arguments, blocks, bytes they append */
     /* graphs */
@@ -125,6 +126,10 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     memset(&e->d, 0, sizeof e->d);
     e->capturing = false; e->timing = false; e->timed_used = 0; e->lag_possible = false; e->tick_pending = false;
     e->batching = false;
+    {   /* tuning knob, read once: 16-byte units of a round one append workgroup takes */
+        const char *sp_env = getenv("APUS_SP_UNITS");
+        e->sp_units = (sp_env && atoi(sp_env) > 0) ? (uint64_t)atoi(sp_env) : 768;
+    }
     e->n_reqs = 0; e->n_rounds_staged = 0;
     e->d_req = e->d_req_len = e->d_arena = e->d_round_first = e->d_round_prefix = nullptr;
     e->h_live = nullptr; e->d_live = nullptr; e->live_pending = false; e->live_copied = nullptr;
@@ -389,8 +394,7 @@ static CallArgs call_args(apus_engine *e, uint64_t c0, uint32_t R, uint32_t tick
     /* rounds with many 16-byte units are shared by SP workgroups each (a launch of a few hundred
      * large rounds would leave most of the 256 CUs idle) */
     const uint64_t units = (e->h_round_prefix[c0 + R] - e->h_round_prefix[c0]) / 16;
-    const char *sp_env = getenv("APUS_SP_UNITS");                        /* tuning knob: units per workgroup */
-    const uint64_t sp_units = sp_env ? (uint64_t)atoi(sp_env) : 768;
+    const uint64_t sp_units = e->sp_units;
     a.SP = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (units / R + sp_units * 2 / 3) / sp_units));
     *blocks = 1 + R * a.SP + a.nR + 1 + a.nS + a.nA * popc(rm);
     return a;
@@ -588,7 +592,7 @@ static int flush_live(apus_engine *e)
     a.r0 = 0; a.R = R; a.tick = e->tick_pending ? 1u : 0u;
     e->tick_pending = false;
     a.nS = cap_grid(e->live_n, 256, 32); a.nA = cap_grid(e->live_n, 1024, 16); a.nR = cap_grid(R, 256, 8);
-    a.SP = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (e->live_bytes / 16 / R + 512) / 768));
+    a.SP = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (e->live_bytes / 16 / R + e->sp_units * 2 / 3) / e->sp_units));
     hipLaunchKernelGGL(k_call, dim3(1 + R * a.SP + a.nR + 1 + a.nS + a.nA * popc(rm)), dim3(256), 0, e->stream, view, a, fm, rm);
     e->live_R = 0;
     HIPCHK(hipGetLastError());
