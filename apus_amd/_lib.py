@@ -24,6 +24,7 @@ SIGNATURES = {
     "apus_gpu_sync": (C.c_int, [vp]),
     "apus_gpu_stage": (C.c_int, [vp, vp, u64, vp, u64, vp, u64]),
     "apus_gpu_become_leader": (C.c_int, [vp, u32, u64, u32]),
+    "apus_gpu_become_leader_ex": (C.c_int, [vp, u32, u64, u32, u32]),
     "apus_gpu_set_reachable": (C.c_int, [vp, u32]),
     "apus_gpu_append_control": (C.c_int, [vp, u8, vp]),
     "apus_gpu_run_rounds": (C.c_int, [vp, u64, u64]),

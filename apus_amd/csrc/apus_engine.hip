@@ -710,9 +710,18 @@ __global__ void k_set_roles(const EngDev E, uint64_t sid, uint32_t bitmask, uint
     }
 }
 
-extern "C" int apus_gpu_become_leader(apus_engine_t *e, uint32_t leader, uint64_t term, uint32_t bitmask)
+/* The election itself (who wins which term) is the trace's ELECT event; this is what the winner
+ * does in poll_vote_count (dare_server.c:1389-1421) and in the pass that follows.  `removed` =
+ * servers that are ON in `bitmask` but have reached PERMANENT_FAILURE during the election (both
+ * vote requests to a dead server fail, dare_ibv_rc.c:2747): check_failure_count (:1189-1227)
+ * opens the new leader's first pass and appends their removal as a second CONFIG entry BEFORE
+ * persist/commit run, so both entries commit in ONE pass (pinned on the reference itself,
+ * tests/test_oracle_vs_refloops.py). */
+extern "C" int apus_gpu_become_leader_ex(apus_engine_t *e, uint32_t leader, uint64_t term, uint32_t bitmask,
+                                         uint32_t removed)
 {
     if (!e || leader >= e->d.group_size) return APUS_E_ARG;
+    if (e->batching) return APUS_E_STATE;           /* close the batch first (apus_gpu_batch_end) */
     if (!((e->local_mask >> leader) & 1u)) return APUS_E_STATE;
     if (e->d.leader < e->d.group_size) { int frc = flush_tick(e); if (frc) return frc; }
     e->tick_pending = false;
@@ -724,7 +733,20 @@ extern "C" int apus_gpu_become_leader(apus_engine_t *e, uint32_t leader, uint64_
     uint8_t cid[16] = {0};
     cid[8] = (uint8_t)e->d.group_size;
     memcpy(cid + 12, &bitmask, 4);
-    return apus_gpu_append_control(e, APUS_CONFIG, cid);
+    removed &= bitmask & ~(1u << leader);
+    if (!removed) return apus_gpu_append_control(e, APUS_CONFIG, cid);
+    uint64_t d0, d1;
+    memcpy(&d0, cid, 8); memcpy(&d1, cid + 8, 8);
+    int rc = launch_control_round(e, 3, APUS_CONFIG, d0, d1);        /* append only */
+    if (rc) return rc;
+    const uint32_t left = bitmask & ~removed;
+    memcpy(cid + 12, &left, 4);
+    return apus_gpu_append_control(e, APUS_CONFIG, cid);            /* second entry + the pass */
+}
+
+extern "C" int apus_gpu_become_leader(apus_engine_t *e, uint32_t leader, uint64_t term, uint32_t bitmask)
+{
+    return apus_gpu_become_leader_ex(e, leader, term, bitmask, 0);
 }
 
 extern "C" int apus_gpu_set_reachable(apus_engine_t *e, uint32_t mask)

@@ -1972,6 +1972,8 @@ __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32
  *           offsets whether the head moves, append <HEAD, head> if so, re-sample the
  *           apply offsets (rc_get_remote_apply_offsets, dare_ibv_rc.c:1970)
  *   mode 2: no append (quiesce)
+ *   mode 3: append <type, d0, d1> and stop: the entry joins the next pass (the new leader's
+ *           blank CONFIG when check_failure_count appends a removal behind it)
  * then followers persist + ACK, the ACK scan, apply and the bookkeeping.          */
 __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode, uint32_t type,
                                                        uint64_t d0, uint64_t d1, uint32_t push_mask,
@@ -2003,6 +2005,7 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode,
     if (tid == 0) *E.seq = control_append<true>(E, mode, type, d0, d1, push_mask, s_lh, *E.rec_count, 0, false);
     if (mode == 1 && tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS) sample_apply_offsets(E, s_lh, sample_mask, tid - 64, nullptr);
     __syncthreads();
+    if (mode == 3) return;     /* the followers' end words follow in the next pass's catch-up prelude */
 
     const uint64_t vis = visible_slots(E, hdr, 0, 0);
     for (uint32_t m = push_mask; m; m &= m - 1) persist_ack_range(E, __builtin_ctz(m), vis, tid, blockDim.x);

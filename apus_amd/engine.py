@@ -127,13 +127,12 @@ class Engine:
             raise EngineError("the winner of an election must be alive")
         self.term += 2
         self.leader = winner
-        self._chk(self.L.apus_gpu_become_leader(self.h, winner, self.term, self.bitmask), "become_leader")
-        # check_failure_count (dare_server.c:1189-1230): the new leader drops configured
-        # servers that do not answer and logs the new configuration
+        # check_failure_count (dare_server.c:1189-1230) opens the new leader's first pass: configured
+        # servers that did not answer the two vote requests are removed with a second CONFIG entry
+        # that commits in the same pass as the blank one
         dead = self.bitmask & ~self.reachable & ~(1 << winner)
-        if dead:
-            self.bitmask &= ~dead
-            self.append_control(2, self._cid_bytes())
+        self._chk(self.L.apus_gpu_become_leader_ex(self.h, winner, self.term, self.bitmask, dead), "become_leader")
+        self.bitmask &= ~dead
 
     def _cid_bytes(self) -> bytes:
         import struct

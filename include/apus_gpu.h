@@ -122,6 +122,10 @@ int  apus_gpu_stage(apus_engine_t *e, const apus_req_t *reqs, uint64_t n,
  * term `term`; appends the blank CONFIG entry a new leader always writes
  * (src/dare/dare_server.c:1411-1421).  bitmask = cid.bitmask. */
 int  apus_gpu_become_leader(apus_engine_t *e, uint32_t leader, uint64_t term, uint32_t bitmask);
+/* same, with the servers check_failure_count (dare_server.c:1189-1227) removes in the new
+ * leader's first pass: blank CONFIG <bitmask> + CONFIG <bitmask & ~removed> commit in one pass */
+int  apus_gpu_become_leader_ex(apus_engine_t *e, uint32_t leader, uint64_t term, uint32_t bitmask,
+                               uint32_t removed);
 /* reachability of peers from the leader (KILL / HOLD / RELEASE of the trace;
  * fail_count >= PERMANENT_FAILURE or rc_connected == 0 in the reference) */
 int  apus_gpu_set_reachable(apus_engine_t *e, uint32_t mask);

@@ -296,6 +296,8 @@ struct orc_cluster {
     int record_apply;
     int allow_exact_fit;                         /* let SURVEY.md Q13 happen instead of failing */
     int committed_flag;                          /* `committed`, dare_ibv_rc.c:1461 */
+    int completion_delay;                        /* see posted() */
+    uint64_t force_prunes;                       /* times force_log_pruning found the log >= 75 % full */
     replica_t r[ORC_MAX_SERVERS];
     uint64_t *round_commit, *round_end; uint64_t n_rounds, rounds_cap;
 };
@@ -368,6 +370,8 @@ void orc_cluster_free(orc_cluster_t *c)
 
 void orc_cluster_record_apply(orc_cluster_t *c, int on) { c->record_apply = on; }
 void orc_cluster_allow_exact_fit(orc_cluster_t *c, int on) { c->allow_exact_fit = on; }
+void orc_cluster_completion_delay(orc_cluster_t *c, int on) { c->completion_delay = on; }
+uint64_t orc_force_prune_count(const orc_cluster_t *c) { return c->force_prunes; }
 int orc_leader(const orc_cluster_t *c) { return c->leader; }
 int orc_group_size(const orc_cluster_t *c) { return c->n; }
 orc_log_t *orc_replica_log(orc_cluster_t *c, int r) { return c->r[r].log; }
@@ -471,17 +475,31 @@ static void follower_poll(orc_cluster_t *c, replica_t *p)
 }
 
 /* --- handle_lr_work_completion, dare_ibv_rc.c:3126-3196 (success path) */
+static void complete_one(replica_t *L, int i)
+{
+    switch (L->pending[i]) {
+    case PEND_LOG: L->lr_step[i] = LR_UPDATE_END; L->send_flag[i] = 1; break;
+    case PEND_END: L->lr_step[i] = LR_UPDATE_LOG; L->send_flag[i] = 1; break;
+    case PEND_ADJ: L->lr_step[i]++;               L->send_flag[i] = 1; break;
+    default: break;
+    }
+    L->pending[i] = PEND_NONE;
+}
+
 static void complete_pending(orc_cluster_t *c, replica_t *L)
 {
-    for (int i = 0; i < c->n; i++) {
-        switch (L->pending[i]) {
-        case PEND_LOG: L->lr_step[i] = LR_UPDATE_END; L->send_flag[i] = 1; break;
-        case PEND_END: L->lr_step[i] = LR_UPDATE_LOG; L->send_flag[i] = 1; break;
-        case PEND_ADJ: L->lr_step[i]++;               L->send_flag[i] = 1; break;
-        default: break;
-        }
-        L->pending[i] = PEND_NONE;
-    }
+    for (int i = 0; i < c->n; i++) complete_one(L, i);
+}
+
+/* Completion timing.  post_send drains the LOG CQ right behind every post
+ * (empty_completion_queue, dare_ibv_rc.c:2590).  Default schedule (the one the
+ * reference-as-is harness oracle/refshim/fabric.c produces, and the one the loops are
+ * pinned on): the completion of the WR just posted is already there, so the step machine
+ * advances at once.  completion_delay = 1 gives the other legal schedule (the completion
+ * is seen by the poll at the top of the next loop pass, :1890). */
+static inline void posted(orc_cluster_t *c, replica_t *L, int i)
+{
+    if (!c->completion_delay) complete_one(L, i);
 }
 
 static inline int peer_reachable(const orc_cluster_t *c, const replica_t *L, int i)
@@ -527,6 +545,7 @@ static void log_adjustment(orc_cluster_t *c, replica_t *L)
         }
         L->send_flag[i] = 0;
         L->pending[i] = PEND_ADJ;
+        posted(c, L, i);
     }
 }
 
@@ -564,6 +583,7 @@ static void update_remote_logs(orc_cluster_t *c, replica_t *L)
             continue;
         }
         L->send_flag[i] = 0;
+        posted(c, L, i);
     }
 
     /* commit scan over the ACK bytes, :1725-1758 (the offset-median code above
@@ -631,12 +651,16 @@ static void commit_new_entries(orc_cluster_t *c, replica_t *L)
     }
 }
 
+static int  log_pruning(orc_cluster_t *c, replica_t *L);
+static void force_log_pruning(orc_cluster_t *c, replica_t *L);
+
 /* leader polling() pass after the tailq was drained, dare_server.c:1095-1124 */
 static void leader_poll(orc_cluster_t *c, replica_t *L)
 {
     persist_new_entries(c, L);
     commit_new_entries(c, L);
     apply_committed_entries(c, L);
+    force_log_pruning(c, L);                 /* :1121-1124 */
 }
 
 static void note_round(orc_cluster_t *c, replica_t *L)
@@ -695,17 +719,11 @@ int orc_quiesce(orc_cluster_t *c)
 }
 
 /* --- log_pruning, dare_server.c:1996-2067 + rc_get_remote_apply_offsets,
- *     dare_ibv_rc.c:1970-2034 ------------------------------------------- */
-int orc_tick_prune(orc_cluster_t *c)
+ *     dare_ibv_rc.c:1970-2034.  Returns 1 when a <HEAD> entry was appended, -2 when the log is full */
+static int log_pruning(orc_cluster_t *c, replica_t *L)
 {
-    if (c->leader < 0) return -1;
-    replica_t *L = &c->r[c->leader];
     orc_log_t *log = L->log;
     int size = L->cid.size[0];
-    /* Trace semantics: the prune timer fires between polling() passes once every
-     * follower has caught up (ms-scale timer vs us-scale rounds), so the apply
-     * offsets sampled by R8 below do not depend on the lazy commit lag. */
-    orc_quiesce(c);
     uint64_t min_offset = log->apply;
     for (int i = 0; i < size; i++) {
         if (!cid_on(&L->cid, i)) L->apply_offsets[i] = log->apply;
@@ -727,6 +745,42 @@ int orc_tick_prune(orc_cluster_t *c)
         if (L->vote_ack[i] == log->len) continue;
         L->apply_offsets[i] = c->r[i].log->apply;
     }
+    return appended;
+}
+
+/* --- force_log_pruning, dare_server.c:2069-2122: closes every leader pass.  At 75 % fill the
+ * server whose sampled apply offset holds the head back is REMOVED from the configuration
+ * (CONFIG entry), then the log is pruned.  Pinned on the reference, incl. its slip at :2113
+ * (`apply_offsets[i]` with i == size after the loop, not `target`). */
+static void force_log_pruning(orc_cluster_t *c, replica_t *L)
+{
+    orc_log_t *log = L->log;
+    uint64_t log_size = orc_log_end_distance(log, log->head);
+    if ((double)log_size < 0.75 * (double)log->len) return;
+    c->force_prunes++;
+    int size = L->cid.size[0], target = L->idx, i;
+    uint64_t min_offset = log->apply;
+    for (i = 0; i < size; i++)
+        if (orc_log_is_larger(log, min_offset, L->apply_offsets[i])) { min_offset = L->apply_offsets[i]; target = i; }
+    if (target != L->idx) {
+        if (!cid_on(&L->cid, target)) { log_pruning(c, L); return; }
+        L->cid.bitmask &= ~(1u << target);                  /* CID_SERVER_RM + dare_ib_disconnect_server */
+        orc_log_append(log, SID_TERM(L->sid), 0, 0, ORC_CONFIG, &L->cid, 0);
+        if (i < ORC_MAX_SERVERS) L->apply_offsets[i] = log->apply;      /* :2113, i == size */
+    }
+    log_pruning(c, L);
+}
+
+int orc_tick_prune(orc_cluster_t *c)
+{
+    if (c->leader < 0) return -1;
+    replica_t *L = &c->r[c->leader];
+    /* Trace semantics: the prune timer fires between polling() passes once every
+     * follower has caught up (ms-scale timer vs us-scale rounds), so the apply
+     * offsets sampled by R8 do not depend on the lazy commit lag. */
+    orc_quiesce(c);
+    int appended = log_pruning(c, L);
+    if (appended < 0) return appended;
     if (appended) { leader_poll(c, L); note_round(c, L); }
     return appended;
 }
@@ -856,10 +910,12 @@ int orc_elect(orc_cluster_t *c, int winner)
         }
         p->sid = w->sid;
     }
-    leader_poll(c, w);
-    note_round(c, w);
-    /* check_failure_count (dare_server.c:1189-1230), first pass of the new leader: servers
-     * that are ON in the configuration but do not answer are removed with a CONFIG entry */
+    /* check_failure_count (dare_server.c:1189-1230) opens the new leader's first pass: a server
+     * that is ON in the configuration but dead has already failed two CTRL writes (the vote
+     * requests of the two start_election calls above, dare_ibv_rc.c:2747), i.e. it is at
+     * PERMANENT_FAILURE, and is removed with a CONFIG entry BEFORE persist/commit run -- so
+     * the blank entry and the removal commit in one pass (pinned on the reference itself,
+     * tests/test_oracle_vs_refloops.py). */
     {
         uint32_t dead = 0;
         for (int i = 0; i < c->n; i++)
@@ -867,10 +923,10 @@ int orc_elect(orc_cluster_t *c, int winner)
         if (dead) {
             w->cid.bitmask &= ~dead;
             if (orc_log_append(w->log, SID_TERM(w->sid), 0, 0, ORC_CONFIG, &w->cid, 0) == 0) return -2;
-            leader_poll(c, w);
-            note_round(c, w);
         }
     }
+    leader_poll(c, w);
+    note_round(c, w);
     return 0;
 }
 

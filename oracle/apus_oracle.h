@@ -106,6 +106,10 @@ void           orc_cluster_free(orc_cluster_t *c);
 void           orc_cluster_record_apply(orc_cluster_t *c, int on);
 /* by default orc_round fails (-3) when an append lands exactly on len (Q13) */
 void           orc_cluster_allow_exact_fit(orc_cluster_t *c, int on);
+/* 0 (default): a posted WR's completion is seen by the poll behind the post; 1: by the next loop pass */
+void           orc_cluster_completion_delay(orc_cluster_t *c, int on);
+/* how often force_log_pruning (dare_server.c:2069) found the log >= 75 % full and acted */
+uint64_t       orc_force_prune_count(const orc_cluster_t *c);
 
 /* ELECT(winner): start_election -> votes -> poll_vote_count -> blank CONFIG.
  * returns 0, or -1 if the winner cannot collect a majority. */

@@ -69,6 +69,8 @@ def lib() -> C.CDLL:
             "orc_cluster_free": (None, [vp]),
             "orc_cluster_record_apply": (None, [vp, C.c_int]),
             "orc_cluster_allow_exact_fit": (None, [vp, C.c_int]),
+            "orc_cluster_completion_delay": (None, [vp, C.c_int]),
+            "orc_force_prune_count": (u64, [vp]),
             "orc_elect": (C.c_int, [vp, C.c_int]),
             "orc_round": (C.c_int, [vp, vp, C.c_int, vp]),
             "orc_tick_prune": (C.c_int, [vp]),
@@ -285,7 +287,7 @@ class Cluster:
     """N in-process replicas driven by trace events."""
 
     def __init__(self, group_size: int, log_len: int = DEFAULT_LOG, record_apply: bool = True,
-                 allow_exact_fit: bool = True):
+                 allow_exact_fit: bool = True, completion_delay: bool = False):
         self.L = lib()
         self.h = self.L.orc_cluster_new(group_size, log_len)
         if not self.h:
@@ -294,6 +296,7 @@ class Cluster:
         self.log_len = log_len
         self.L.orc_cluster_record_apply(self.h, int(record_apply))
         self.L.orc_cluster_allow_exact_fit(self.h, int(allow_exact_fit))
+        self.L.orc_cluster_completion_delay(self.h, int(completion_delay))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -322,6 +325,9 @@ class Cluster:
         round_n = np.ascontiguousarray(round_n, dtype=np.uint32)
         return self._chk(self.L.orc_run_rounds(self.h, reqs.ctypes.data, round_n.ctypes.data,
                                                len(round_n), arena.ctypes.data, prune_bytes), "run_rounds")
+
+    @property
+    def force_prunes(self): return int(self.L.orc_force_prune_count(self.h))
 
     @property
     def leader(self): return int(self.L.orc_leader(self.h))

@@ -15,8 +15,10 @@
  *       Errors always produce a completion; successes only when signaled.
  *   UD  SEND to (dlid, qpn) or to the multicast group (qpn 0xFFFFFF): copied behind a
  *       40-byte GRH into the next posted receive of every destination QP.
- *   A port can be HELD: operations that target it are parked (payload snapshotted at
- *   post time) and executed in order at release -- a slow link, never a lost message.
+ *   A port can be HELD (link down for a while, the server itself keeps running): RC
+ *   operations to or from it fail like those to a dead port.  That is what the reference's QP
+ *   settings give on a real fabric: timeout = 1 (~8 us), retry_cnt = 0
+ *   (dare_ibv_rc.c:2400-2402), so an unreachable peer means IBV_WC_RETRY_EXC_ERR at once.
  * The trace driver gets a callback after every remote write (fab_set_write_hook).
  */
 #define _GNU_SOURCE
@@ -33,21 +35,13 @@
 typedef struct fcq {
     struct ibv_cq pub;
     struct ibv_wc *ring;
+    uint64_t *visible_at;
     int cap, head, count;
     int port;
     uint64_t empty_polls;
 } fcq_t;
 
 typedef struct frecv { uint64_t wr_id, addr; uint32_t length; } frecv_t;
-
-typedef struct parked {
-    struct parked *next;
-    struct fqp *src;
-    uint64_t wr_id, local_addr, remote_addr;
-    uint32_t len, rkey;
-    int opcode, signaled;
-    uint8_t *snap;               /* payload snapshot for a parked WRITE */
-} parked_t;
 
 typedef struct fqp {
     struct ibv_qp pub;
@@ -63,8 +57,13 @@ typedef struct fmr { struct ibv_mr pub; int port, access, live; } fmr_t;
 
 typedef struct fport {
     int used, alive, held;
+    /* Completion timing.  A real HCA needs microseconds to complete a WRITE, so the poll that
+     * the reference issues right behind every post (post_send -> empty_completion_queue,
+     * dare_ibv_rc.c:2590) finds nothing and the completion is seen by the NEXT poll pass
+     * (the one at the top of rc_write_remote_logs' loop, :1890).  Modelled as: a send
+     * completion becomes visible when its port polls a CQ without having posted in between. */
+    uint64_t epoch; int last_was_post;
     struct ibv_device dev;
-    parked_t *park_head, *park_tail;
 } fport_t;
 
 static fport_t ports[MAX_PORTS];
@@ -75,14 +74,12 @@ static int current_port = -1;
 static fab_write_hook_t write_hook;
 static void *write_hook_arg;
 static struct fab_stats stats;
+static int delay_completions;   /* 0: a completion is visible to the very next poll (default) */
+void fab_set_completion_delay(int on) { delay_completions = on; }
 
 /* ---- driver-facing control ---------------------------------------------------------- */
 void fab_reset(void)
 {
-    for (int i = 0; i < MAX_PORTS; i++) {
-        parked_t *p = ports[i].park_head;
-        while (p) { parked_t *n = p->next; free(p->snap); free(p); p = n; }
-    }
     memset(ports, 0, sizeof ports);
     /* QPs and MRs of a previous cluster: its instances are gone, nobody refers to them */
     for (int i = 0; i < MAX_QPS; i++) if (qps[i]) { free(qps[i]->rq); free(qps[i]); }
@@ -102,15 +99,17 @@ void fab_hold_port(int port) { if (port >= 0 && port < MAX_PORTS) ports[port].he
 int  fab_port_held(int port) { return port >= 0 && port < MAX_PORTS && ports[port].held; }
 const struct fab_stats *fab_get_stats(void) { return &stats; }
 
-static void cq_push(fcq_t *cq, const struct ibv_wc *wc)
+static void cq_push(fcq_t *cq, const struct ibv_wc *wc, int delayed)
 {
     if (cq->count == cq->cap) {            /* CQ overrun: grow (a real HCA would raise a fatal event) */
         int ncap = cq->cap * 2;
         struct ibv_wc *nr = malloc(sizeof(*nr) * ncap);
-        for (int i = 0; i < cq->count; i++) nr[i] = cq->ring[(cq->head + i) % cq->cap];
-        free(cq->ring); cq->ring = nr; cq->cap = ncap; cq->head = 0;
+        uint64_t *nv = malloc(sizeof(*nv) * ncap);
+        for (int i = 0; i < cq->count; i++) { nr[i] = cq->ring[(cq->head + i) % cq->cap]; nv[i] = cq->visible_at[(cq->head + i) % cq->cap]; }
+        free(cq->ring); free(cq->visible_at); cq->ring = nr; cq->visible_at = nv; cq->cap = ncap; cq->head = 0;
     }
     cq->ring[(cq->head + cq->count) % cq->cap] = *wc;
+    cq->visible_at[(cq->head + cq->count) % cq->cap] = ports[cq->port].epoch + (delayed ? 1 : 0);
     cq->count++;
     cq->empty_polls = 0;
 }
@@ -120,7 +119,7 @@ static void complete(fqp_t *qp, uint64_t wr_id, enum ibv_wc_status st, int opcod
     struct ibv_wc wc; memset(&wc, 0, sizeof wc);
     wc.wr_id = wr_id; wc.status = st; wc.qp_num = qp->pub.qp_num;
     wc.opcode = opcode == IBV_WR_RDMA_READ ? IBV_WC_RDMA_READ : opcode == IBV_WR_SEND ? IBV_WC_SEND : IBV_WC_RDMA_WRITE;
-    cq_push(qp->scq, &wc);
+    cq_push(qp->scq, &wc, 1);
 }
 
 static fqp_t *find_qp(uint32_t qpn) { return qpn < MAX_QPS ? qps[qpn] : NULL; }
@@ -135,12 +134,13 @@ static fmr_t *find_mr(int port, uint32_t rkey, uint64_t addr, uint32_t len)
 }
 
 /* execute one RC operation against the responder; returns the completion status */
-static enum ibv_wc_status rc_execute(fqp_t *src, int opcode, uint64_t local, const uint8_t *snap,
+static enum ibv_wc_status rc_execute(fqp_t *src, int opcode, uint64_t local,
                                      uint64_t raddr, uint32_t rkey, uint32_t len, int *tport_out)
 {
     int tport = (int)src->attr.ah_attr.dlid - 1;
     *tport_out = tport;
     if (tport < 0 || tport >= MAX_PORTS || !ports[tport].used || !ports[tport].alive) return IBV_WC_RETRY_EXC_ERR;
+    if (ports[tport].held || ports[src->port].held) return IBV_WC_RETRY_EXC_ERR;
     fqp_t *dst = find_qp(src->attr.dest_qp_num);
     if (!dst || !dst->live || dst->port != tport || dst->pub.qp_type != IBV_QPT_RC) return IBV_WC_RETRY_EXC_ERR;
     if (dst->pub.state != IBV_QPS_RTR && dst->pub.state != IBV_QPS_RTS) return IBV_WC_RETRY_EXC_ERR;
@@ -152,7 +152,7 @@ static enum ibv_wc_status rc_execute(fqp_t *src, int opcode, uint64_t local, con
     if (!m) return IBV_WC_REM_ACCESS_ERR;
     if (opcode == IBV_WR_RDMA_WRITE) {
         if (!(m->access & IBV_ACCESS_REMOTE_WRITE)) return IBV_WC_REM_ACCESS_ERR;
-        memcpy((void *)(uintptr_t)raddr, snap ? (const void *)snap : (const void *)(uintptr_t)local, len);
+        memcpy((void *)(uintptr_t)raddr, (const void *)(uintptr_t)local, len);
         stats.rc_writes++; stats.rc_write_bytes += len;
     } else {
         if (!(m->access & IBV_ACCESS_REMOTE_READ)) return IBV_WC_REM_ACCESS_ERR;
@@ -175,26 +175,7 @@ static void rc_finish(fqp_t *src, uint64_t wr_id, int opcode, int signaled, enum
     if (opcode == IBV_WR_RDMA_WRITE && write_hook) write_hook(write_hook_arg, src->port, tport, raddr, len);
 }
 
-void fab_release_port(int port)
-{
-    if (port < 0 || port >= MAX_PORTS) return;
-    ports[port].held = 0;
-    parked_t *p = ports[port].park_head;
-    ports[port].park_head = ports[port].park_tail = NULL;
-    while (p) {
-        parked_t *n = p->next;
-        fqp_t *src = p->src;
-        if (src->live && src->pub.state == IBV_QPS_RTS) {
-            int tport;
-            enum ibv_wc_status st = rc_execute(src, p->opcode, p->local_addr, p->snap, p->remote_addr, p->rkey, p->len, &tport);
-            rc_finish(src, p->wr_id, p->opcode, p->signaled, st, tport, p->remote_addr, p->len);
-        } else if (src->live) {
-            complete(src, p->wr_id, IBV_WC_WR_FLUSH_ERR, p->opcode);
-        }
-        free(p->snap); free(p);
-        p = n;
-    }
-}
+void fab_release_port(int port) { if (port >= 0 && port < MAX_PORTS) ports[port].held = 0; }
 
 /* ---- device ---------------------------------------------------------------------------- */
 struct ibv_device **ibv_get_device_list(int *num)
@@ -280,16 +261,20 @@ struct ibv_cq *ibv_create_cq(struct ibv_context *c, int cqe, void *ctx, struct i
     q->pub.context = c; q->pub.cq_context = ctx; q->pub.cqe = cqe; q->pub.fab = q;
     q->cap = cqe < 64 ? 64 : (cqe > 4096 ? 4096 : cqe);
     q->ring = malloc(sizeof(struct ibv_wc) * q->cap);
+    q->visible_at = malloc(sizeof(uint64_t) * q->cap);
     q->port = c->fab_port;
     return &q->pub;
 }
-int ibv_destroy_cq(struct ibv_cq *cq) { fcq_t *q = (fcq_t *)cq; free(q->ring); free(q); return 0; }
+int ibv_destroy_cq(struct ibv_cq *cq) { fcq_t *q = (fcq_t *)cq; free(q->ring); free(q->visible_at); free(q); return 0; }
 
 int ibv_poll_cq(struct ibv_cq *cq, int n, struct ibv_wc *wc)
 {
     fcq_t *q = (fcq_t *)cq;
+    fport_t *P = &ports[q->port];
+    if (!P->last_was_post || !delay_completions) P->epoch++;
+    P->last_was_post = 0;
     int k = 0;
-    while (k < n && q->count) {
+    while (k < n && q->count && q->visible_at[q->head] <= P->epoch) {
         wc[k++] = q->ring[q->head];
         q->head = (q->head + 1) % q->cap;
         q->count--;
@@ -320,15 +305,6 @@ struct ibv_qp *ibv_create_qp(struct ibv_pd *pd, struct ibv_qp_init_attr *ia)
 int ibv_destroy_qp(struct ibv_qp *qp)
 {
     fqp_t *q = (fqp_t *)qp;
-    /* parked operations of this QP can no longer complete */
-    for (int i = 0; i < MAX_PORTS; i++) {
-        parked_t **pp = &ports[i].park_head, *last = NULL;
-        while (*pp) {
-            if ((*pp)->src == q) { parked_t *d = *pp; *pp = d->next; free(d->snap); free(d); }
-            else { last = *pp; pp = &(*pp)->next; }
-        }
-        ports[i].park_tail = last;
-    }
     if (q->pub.qp_num < MAX_QPS && qps[q->pub.qp_num] == q) qps[q->pub.qp_num] = NULL;
     q->live = 0; free(q->rq); free(q);
     return 0;
@@ -339,17 +315,9 @@ int ibv_modify_qp(struct ibv_qp *qp, struct ibv_qp_attr *a, int mask)
     fqp_t *q = (fqp_t *)qp;
     if (mask & IBV_QP_STATE) {
         if (a->qp_state == IBV_QPS_RESET) {
-            /* RESET clears every attribute and drops queued work and completions of this QP */
+            /* RESET clears every attribute and drops queued receives */
             memset(&q->attr, 0, sizeof q->attr);
             q->rq_head = q->rq_count = 0;
-            for (int i = 0; i < MAX_PORTS; i++) {
-                parked_t **pp = &ports[i].park_head, *last = NULL;
-                while (*pp) {
-                    if ((*pp)->src == q) { parked_t *d = *pp; *pp = d->next; free(d->snap); free(d); }
-                    else { last = *pp; pp = &(*pp)->next; }
-                }
-                ports[i].park_tail = last;
-            }
         }
         q->pub.state = a->qp_state;
         q->attr.qp_state = a->qp_state;
@@ -383,7 +351,7 @@ int ibv_query_qp(struct ibv_qp *qp, struct ibv_qp_attr *a, int mask, struct ibv_
 /* ---- UD ---------------------------------------------------------------------------------- */
 static void ud_deliver(fqp_t *dst, fqp_t *src, const void *buf, uint32_t len)
 {
-    if (!dst->live || !ports[dst->port].alive) return;
+    if (!dst->live || !ports[dst->port].alive || ports[dst->port].held || ports[src->port].held) return;
     if (dst->pub.state != IBV_QPS_RTR && dst->pub.state != IBV_QPS_RTS) return;
     if (!dst->rq_count) { stats.ud_dropped++; return; }       /* no receive posted: UD drops */
     frecv_t r = dst->rq[dst->rq_head];
@@ -395,7 +363,7 @@ static void ud_deliver(fqp_t *dst, fqp_t *src, const void *buf, uint32_t len)
     wc.wr_id = r.wr_id; wc.status = IBV_WC_SUCCESS; wc.opcode = IBV_WC_RECV; wc.byte_len = len + 40;
     wc.qp_num = dst->pub.qp_num; wc.src_qp = src->pub.qp_num; wc.slid = (uint16_t)(src->port + 1);
     wc.wc_flags = 1;                                           /* IBV_WC_GRH */
-    cq_push(dst->rcq, &wc);
+    cq_push(dst->rcq, &wc, 0);
     stats.ud_msgs++;
 }
 
@@ -434,20 +402,8 @@ static int post_send_rc(fqp_t *q, struct ibv_send_wr *wr)
     uint64_t local = wr->sg_list[0].addr;
     uint32_t len = wr->sg_list[0].length;
     int signaled = (wr->send_flags & IBV_SEND_SIGNALED) != 0;
-    int tport = (int)q->attr.ah_attr.dlid - 1;
-    if (tport >= 0 && tport < MAX_PORTS && ports[tport].used && ports[tport].alive &&
-        (ports[tport].held || ports[q->port].held)) {
-        int hp = ports[tport].held ? tport : q->port;
-        parked_t *p = calloc(1, sizeof *p);
-        p->src = q; p->wr_id = wr->wr_id; p->local_addr = local; p->remote_addr = wr->wr.rdma.remote_addr;
-        p->len = len; p->rkey = wr->wr.rdma.rkey; p->opcode = wr->opcode; p->signaled = signaled;
-        if (wr->opcode == IBV_WR_RDMA_WRITE) { p->snap = malloc(len ? len : 1); memcpy(p->snap, (void *)(uintptr_t)local, len); }
-        if (ports[hp].park_tail) ports[hp].park_tail->next = p; else ports[hp].park_head = p;
-        ports[hp].park_tail = p;
-        stats.rc_parked++;
-        return 0;
-    }
-    enum ibv_wc_status st = rc_execute(q, wr->opcode, local, NULL, wr->wr.rdma.remote_addr, wr->wr.rdma.rkey, len, &tport);
+    int tport;
+    enum ibv_wc_status st = rc_execute(q, wr->opcode, local, wr->wr.rdma.remote_addr, wr->wr.rdma.rkey, len, &tport);
     rc_finish(q, wr->wr_id, wr->opcode, signaled, st, tport, wr->wr.rdma.remote_addr, len);
     return 0;
 }
@@ -455,6 +411,7 @@ static int post_send_rc(fqp_t *q, struct ibv_send_wr *wr)
 int ibv_post_send(struct ibv_qp *qp, struct ibv_send_wr *wr, struct ibv_send_wr **bad)
 {
     fqp_t *q = (fqp_t *)qp;
+    ports[q->port].last_was_post = 1;
     for (; wr; wr = wr->next) {
         int rc = q->pub.qp_type == IBV_QPT_UD ? post_send_ud(q, wr) : post_send_rc(q, wr);
         if (rc) { if (bad) *bad = wr; return rc; }

@@ -11,13 +11,15 @@ extern "C" {
 #endif
 
 struct fab_stats {
-    uint64_t rc_writes, rc_write_bytes, rc_reads, rc_failures, rc_parked, ud_msgs, ud_dropped;
+    uint64_t rc_writes, rc_write_bytes, rc_reads, rc_failures, ud_msgs, ud_dropped;
 };
 
 /* called after every successful RDMA WRITE (from_port -> to_port, raw responder address) */
 typedef void (*fab_write_hook_t)(void *arg, int from_port, int to_port, uint64_t raddr, uint32_t len);
 
 void fab_reset(void);
+/* 1: a send completion is not seen by the poll that directly follows its post (see fabric.c) */
+void fab_set_completion_delay(int on);
 int  fab_enter(int port);          /* the instance that runs until fab_leave(); returns the previous one */
 void fab_leave(int prev);
 int  fab_current(void);

@@ -240,13 +240,15 @@ int refc_elect(refc_t *c, int w)
     call_poll(c, w);
     if (!c->in[w].is_leader()) { snprintf(c->err, sizeof c->err, "server %d did not win", w); return -1; }
     c->leader = w;
-    call_fire(c, w, T_HB);                                   /* hb_send_cb :927: first heartbeat */
-    for (int i = 0; i < c->n; i++) if (i != w) call_poll(c, i);          /* adopt the leader's SID (:1546) */
-    for (int i = 0; i < c->n; i++) if (i != w && c->in[i].alive && !fab_port_held(i)) call_fire(c, i, T_HB);   /* hb_receive_cb */
+    /* the new leader's next pass commits the blank CONFIG entry (:1419) ... */
     call_poll(c, w);
     note_round(c);
-    /* second heartbeat: a dead peer reaches PERMANENT_FAILURE and is removed */
+    /* ... then its heartbeat timer fires (hb_send_cb :927).  For a peer that died this is the
+     * second failed CTRL write after the vote request: PERMANENT_FAILURE, check_failure_count
+     * removes it with a CONFIG entry in the following pass (:1189-1227). */
     call_fire(c, w, T_HB);
+    for (int i = 0; i < c->n; i++) if (i != w) call_poll(c, i);          /* adopt the leader's SID (:1546) */
+    for (int i = 0; i < c->n; i++) if (i != w && c->in[i].alive && !fab_port_held(i)) call_fire(c, i, T_HB);   /* hb_receive_cb */
     uint64_t end0 = offs(&c->in[w])[3];
     call_poll(c, w);
     if (offs(&c->in[w])[3] != end0) note_round(c);

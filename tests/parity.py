@@ -125,4 +125,6 @@ def lockstep(trace, eng, check_at=("PRUNE", "QUIESCE"), coalesce=True, allow_exa
         i += 1
     batch_close()
     eng.check_status()
+    assert cl.force_prunes == 0, ("the trace fills the log to 75 %: the reference's force_log_pruning "
+                                  "(dare_server.c:2069, follower eviction) is modelled by the oracle only")
     return cl

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from apus_amd import trace as T
+from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 
@@ -186,7 +187,7 @@ def test_hold_and_release_catch_up(eng_factory, mode):
 def test_no_quorum_no_commit(eng_factory, mode):
     """With a majority unreachable nothing commits; it all commits on release."""
     from tests.parity import lockstep
-    n, L = 3, 1 << 16
+    n, L = 3, 1 << 17     # stays below 75 % fill: force_log_pruning (eviction, SURVEY 8f-2) is not in the engine
     base = T.steady_trace(n, 400, 64, 4, 16, log_len=L)
     ev = []
     k = 0
@@ -240,6 +241,52 @@ def test_exact_fit_wrap_restarts_index(eng_factory, mode):
     cl = lockstep(tr, eng, **mode)
     # the index restarted at least once: last idx is far smaller than the entry count
     assert eng.counters(0)["last_idx"] < 1024
+
+
+def test_known_deviation_uncommitted_apply_at_wrap(eng_factory):
+    """The one place where the engine does NOT follow the reference, shown with its bound.
+
+    tests/traces.py:park_commit_at_wrap (pinned on the reference itself, tests/golden/cluster_ref.json):
+    the commit pointer is parked on a case-1 wrap position and there is no quorum.  The reference
+    leader "commits" offset 0 and then APPLIES the first entry of the new lap although nobody
+    else has it (dare_ibv_rc.c:1744-1758 + dare_log.h:327-330): the blocked client is released by
+    an uncommitted entry.  The engine reproduces the commit record of that pass but never
+    applies beyond its commit point.  Bound: exactly one entry, only on the leader, only while
+    the quorum is missing; every server is bit-identical again at the next quiescent point with
+    a quorum."""
+    from tests import traces
+    from tests.parity import compare_all
+    tr = traces.park_commit_at_wrap()
+    eng = eng_factory(tr.group_size, tr.log_len)
+    snaps = []
+
+    def snap(i, ev, cl):
+        if ev[0] == "QUIESCE":
+            snaps.append((i, cl.log(0).offsets(), cl.highest_rec(0)))
+    cl = orc.run_trace(tr, on_event=snap)
+    q = [i for i, ev in enumerate(tr.events) if ev[0] == "QUIESCE"]
+    assert len(q) == 4
+    # engine up to the no-quorum quiescent point (2nd QUIESCE)
+    eng.reset(); eng.stage_trace(tr)
+    for ev in tr.events[:q[1] + 1]:
+        op = ev[0]
+        if op == "ROUND": eng.run_rounds(eng.round_of_g0[ev[1]], 1)
+        elif op == "ELECT": eng.elect(ev[1])
+        elif op == "PRUNE": eng.tick_prune()
+        elif op == "QUIESCE": eng.quiesce()
+        elif op == "HOLD": eng.hold(ev[1])
+        elif op == "RELEASE": eng.release(ev[1])
+    eng.check_status()
+    go = eng.offsets(0)
+    _, oo, orec = snaps[1]
+    assert (oo["apply"], oo["commit"], oo["end"]) == (164, 0, 884) and orec == 197     # the reference's state
+    assert go["end"] == oo["end"] and go["commit"] == 16356                           # engine: commit stays parked
+    assert go["apply"] == go["commit"], "the engine never applies an uncommitted entry"
+    assert eng.counters(0)["highest_rec"] == orec - 1, "bound: exactly one upcall behind the reference"
+    # ... and after the release everything is bit-identical again
+    eng.reset()
+    eng.run_trace(tr)
+    compare_all(eng, cl, tag="after release")
 
 
 def test_full_size_c2_against_oracle(eng_factory):

@@ -1,0 +1,120 @@
+"""CPU-only: the restated oracle (oracle/apus_oracle.c) against THE REFERENCE ITSELF.
+
+oracle/_ref/libapus_ref_loops.so = /root/reference/src/dare/{dare_server,dare_ibv,dare_ibv_rc,
+dare_ibv_ud,dare_ep_db,dare_kvs_sm}.c + config-dare.c + rbtree.c compiled UNMODIFIED (recipe:
+oracle/Makefile `loops`) behind the in-process verbs / libev / libconfig stand-ins of
+oracle/refshim/; one private copy per server, driven one polling() pass at a time by the trace.
+Both sides replay the same events in lock step and are compared at every quiescent event:
+all 8 log offsets of every server, every defined ring byte (incl. sender and reply[]), SID,
+upcall counters and the upcall stream, prev_log_entry_head, and the leader's end/commit after
+every pass.  This is the pin for the loop rows of SURVEY.md section 8 (a4, a6-a11, a14).
+
+Skipped where neither the built library nor /root/reference exists; the same records are
+committed as tests/golden/cluster_ref.json (tests/test_trace_oracle.py checks them everywhere)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from oracle import refloops
+from tests import traces
+from tests.refparity import assert_same_state
+
+pytestmark = pytest.mark.skipif(not refloops.available(), reason="oracle/_ref/libapus_ref_loops.so not available")
+
+
+def lockstep(tr, check_at=("QUIESCE", "PRUNE")):
+    oc = orc.Cluster(tr.group_size, tr.log_len)
+    rc = refloops.RefCluster(tr.group_size, tr.log_len)
+    reqs = np.ascontiguousarray(tr.reqs, dtype=orc.REQ_DTYPE)
+    try:
+        for i, ev in enumerate(tr.events):
+            op = ev[0]
+            for c in (oc, rc):
+                if op == "ROUND":
+                    c.round(reqs[ev[1]:ev[1] + ev[2]], tr.arena)
+                elif op == "ELECT":
+                    c.elect(ev[1])
+                elif op == "PRUNE":
+                    c.tick_prune()
+                elif op == "QUIESCE":
+                    c.quiesce()
+                elif op == "KILL":
+                    c.kill(ev[1])
+                elif op == "HOLD":
+                    c.hold(ev[1])
+                elif op == "RELEASE":
+                    c.release(ev[1])
+                else:
+                    raise ValueError(ev)
+            if op in check_at:
+                assert_same_state(oc, rc, tr.group_size, tag=f"{tr.name} event {i} {ev}")
+        assert_same_state(oc, rc, tr.group_size, tag=f"{tr.name} end")
+        return oc, rc
+    except BaseException:
+        rc.close()
+        raise
+
+
+@pytest.mark.parametrize("name", sorted(traces.CATALOGUE))
+def test_oracle_equals_reference(name):
+    oc, rc = lockstep(traces.CATALOGUE[name]())
+    rc.close()
+
+
+def test_reference_boots_and_elects():
+    """start-up as the reference does it: RC_SYN/SYNACK/ACK over UD multicast, every server a
+    candidate of term 1, the winner's timeout fires first (term 2), blank CONFIG committed"""
+    rc = refloops.RefCluster(5, 1 << 16)
+    try:
+        assert [rc.sid(i) for i in range(5)] == [(1 << 9) | i for i in range(5)]
+        rc.elect(3)
+        assert rc.leader == 3 and all(rc.sid(i) == (2 << 9) | (1 << 8) | 3 for i in range(5))
+        for i in range(5):
+            o = rc.log(i).offsets()
+            assert (o["commit"], o["end"], o["apply"]) == (64, 64, 64)
+        assert rc.cid(3)["bitmask"] == 0b11111
+    finally:
+        rc.close()
+
+
+def test_fence_deposed_leader_cannot_write():
+    """rc_revoke_log_access (dare_ibv_rc.c:2156): a server that voted in a new term keeps its
+    LOG QP towards everybody but the new leader in RESET, so the deposed leader's log WRITEs to
+    it are rejected and none of its entries land there."""
+    tr = traces.steady3()
+    rc = refloops.RefCluster(3, tr.log_len)
+    reqs = np.ascontiguousarray(tr.reqs, dtype=orc.REQ_DTYPE)
+    try:
+        rc.elect(0)
+        rc.round(reqs[0:8], tr.arena)
+        rc.quiesce()
+        # servers 1 and 2 stop hearing the leader and elect 1 while 0 keeps running
+        rc.hold(0)
+        for i in (1, 2):
+            while (rc.sid(i) & 0xFF) != i or (rc.sid(i) >> 8) & 1:
+                rc.fire(i, 2)
+        rc.fire(1, 2)
+        rc.poll(2); rc.poll(1)
+        assert (rc.sid(1) >> 8) & 1 and (rc.sid(1) & 0xFF) == 1          # 1 leads a higher term
+        assert rc.sid(0) >> 9 < rc.sid(1) >> 9 and rc.leader == 0        # 0 has not noticed
+        rc.hold(1)                                                        # only the path 0 -> 2 is open
+        rc.release(0)
+        before = rc.log(2).offsets()
+        ring_before = rc.log(2).ring().copy()
+        rc.round(reqs[8:16], tr.arena)          # the deposed leader appends and tries to replicate
+        assert rc.log(0).offsets()["end"] == before["end"] + 8 * 128      # they are in ITS log ...
+        assert rc.log(2).offsets() == before                              # ... and nowhere else
+        assert np.array_equal(rc.log(2).ring(), ring_before)
+        assert not rc.peer(2, 0)["log_access"] and rc.peer(2, 1)["log_access"]
+    finally:
+        rc.close()
+
+
+def test_full_size_c2():
+    """BASELINE configs[1] at full size: 2^20 x 64-byte entries through the 64 MiB ring (wraps,
+    16 prune ticks), 3 servers"""
+    from apus_amd import trace as T
+    tr = T.config_c2()
+    oc, rc = lockstep(tr, check_at=("QUIESCE",))
+    assert oc.highest_rec(0) == (1 << 20) + 16
+    rc.close()

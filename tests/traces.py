@@ -1,0 +1,97 @@
+"""Named event traces shared by the parity tests: the same catalogue is replayed on
+(a) the reference itself (oracle/_ref/libapus_ref_loops.so, tests/test_oracle_vs_refloops.py
+and tests/golden/make_cluster_golden.py), (b) the restated oracle (tests/test_trace_oracle.py
+against the committed golden records) and (c) the GPU engine (tests/test_gpu_parity.py)."""
+from __future__ import annotations
+
+from apus_amd import trace as T
+
+
+def _with_events(base, inserts, drop_prune=False):
+    """inserts: {k: [events]} placed behind the k-th ROUND event (1-based)."""
+    ev, k = [], 0
+    for e in base.events:
+        if drop_prune and e[0] == "PRUNE":
+            continue
+        ev.append(e)
+        if e[0] == "ROUND":
+            k += 1
+            ev += inserts.get(k, [])
+    base.events = ev
+    return base
+
+
+def steady3():
+    return T.steady_trace(3, 2000, 64, 8, 64, log_len=1 << 16, name="steady3")
+
+
+def steady5_unaligned():
+    return T.steady_trace(5, 3000, 100, 8, 32, log_len=1 << 16, name="steady5_unaligned")
+
+
+def steady7_mixed():
+    return T.steady_trace(7, 3000, (64, 128, 256, 512, 1024), 16, (1, 64), log_len=1 << 18, name="steady7_mixed")
+
+
+def c2_small():
+    return T.config_c2(n_send=1 << 14, log_len=1 << 20)
+
+
+def c3_small():
+    return T.config_c3(n_send=1 << 12, log_len=1 << 21)
+
+
+def c4_small():
+    return T.config_c4(n_send=1 << 12, log_len=1 << 21)
+
+
+def c5_failover():
+    return T.config_c5(per_phase=600, log_len=1 << 18, batch=16)
+
+
+def hold_one_of_three():
+    tr = T.steady_trace(3, 200, 64, 4, 10, log_len=1 << 16, name="hold_one_of_three")
+    return _with_events(tr, {2: [("HOLD", 2)]}, drop_prune=True)
+
+
+def hold_release():
+    tr = T.steady_trace(5, 2000, 64, 8, 32, log_len=1 << 19, name="hold_release")
+    return _with_events(tr, {10: [("HOLD", 2)], 20: [("RELEASE", 2), ("QUIESCE",)],
+                             30: [("HOLD", 4), ("HOLD", 1)],
+                             36: [("RELEASE", 4), ("RELEASE", 1), ("QUIESCE",)]}, drop_prune=True)
+
+
+def no_quorum():
+    tr = T.steady_trace(3, 400, 64, 4, 16, log_len=1 << 16, name="no_quorum")
+    return _with_events(tr, {5: [("HOLD", 1), ("HOLD", 2)], 12: [("RELEASE", 1), ("QUIESCE",)]}, drop_prune=True)
+
+
+def no_quorum_prune():
+    tr = T.steady_trace(3, 1200, 64, 4, 16, log_len=1 << 18, prune_bytes=8 << 10, name="no_quorum_prune")
+    return _with_events(tr, {6: [("HOLD", 1), ("HOLD", 2)], 40: [("RELEASE", 1), ("RELEASE", 2), ("QUIESCE",)]})
+
+
+def exact_fit():
+    return T.steady_trace(3, 1024, 64, 1, 8, log_len=1 << 14, prune_bytes=(1 << 14) // 4, name="exact_fit")
+
+
+def kill_follower():
+    tr = T.steady_trace(5, 400, 64, 4, 10, log_len=1 << 16, name="kill_follower")
+    return _with_events(tr, {9: [("KILL", 3)]})
+
+
+def park_commit_at_wrap():
+    """Case-1 wrap (the header does not fit: 28 bytes left) with the commit pointer parked on it
+    and NO quorum: update_remote_logs "commits" offset 0 (dare_ibv_rc.c:1725-1758) and
+    apply_committed_entries then applies the first entry of the new lap although it is not
+    committed (log_get_entry redirects log->apply in place, dare_log.h:327-330) -- the client is
+    released by an entry only the leader has.  Pinned on the reference itself."""
+    tr = T.steady_trace(3, 300, 100, 4, 1, log_len=1 << 14, prune_bytes=2 << 10, name="park_commit_at_wrap")
+    k = 196          # after this round end = 16356 = len - 28
+    return _with_events(tr, {k: [("QUIESCE",), ("HOLD", 1), ("HOLD", 2)],
+                             k + 5: [("QUIESCE",), ("RELEASE", 1), ("RELEASE", 2), ("QUIESCE",)]})
+
+
+CATALOGUE = {f.__name__: f for f in (steady3, steady5_unaligned, steady7_mixed, c2_small, c3_small, c4_small,
+                                     c5_failover, hold_one_of_three, hold_release, no_quorum, no_quorum_prune,
+                                     exact_fit, kill_follower, park_commit_at_wrap)}
