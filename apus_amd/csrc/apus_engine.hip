@@ -48,6 +48,8 @@ struct apus_engine {
     std::vector<uint64_t> h_round_prefix;      /* byte prefix of the staged rounds */
     bool batching;                             /* apus_gpu_batch_begin .. _end */
     uint64_t sp_units;                         /* APUS_SP_UNITS (default 768), see call_args */
+    uint32_t gp_rounds;                        /* APUS_GP_ROUNDS (default 4; 1 = one workgroup per round), see call_args */
+    uint64_t gp_max_units;                     /* APUS_GP_MAX_UNITS: largest mean round (16-byte units) that is grouped */
     struct BatchSeg { CallArgs a; uint32_t blocks; uint64_t bytes; };
     std::vector<BatchSeg> batch;               /* recorded calls: arguments, blocks, bytes they append */
     /* graphs */
@@ -129,6 +131,12 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     {   /* tuning knob, read once: 16-byte units of a round one append workgroup takes */
         const char *sp_env = getenv("APUS_SP_UNITS");
         e->sp_units = (sp_env && atoi(sp_env) > 0) ? (uint64_t)atoi(sp_env) : 768;
+        /* grouped append (one wavefront per round): on unless APUS_GP_ROUNDS=1; for rounds of up to
+         * APUS_GP_MAX_UNITS 16-byte units on average (default 1024 = 16 KiB) */
+        const char *gp_env = getenv("APUS_GP_ROUNDS");
+        e->gp_rounds = (gp_env && atoi(gp_env) > 0) ? (uint32_t)atoi(gp_env) : APUS_GP;
+        const char *gu_env = getenv("APUS_GP_MAX_UNITS");
+        e->gp_max_units = (gu_env && atoi(gu_env) > 0) ? (uint64_t)atoi(gu_env) : 1024;
     }
     e->n_reqs = 0; e->n_rounds_staged = 0;
     e->d_req = e->d_req_len = e->d_arena = e->d_round_first = e->d_round_prefix = nullptr;
@@ -396,7 +404,11 @@ static CallArgs call_args(apus_engine *e, uint64_t c0, uint32_t R, uint32_t tick
     const uint64_t units = (e->h_round_prefix[c0 + R] - e->h_round_prefix[c0]) / 16;
     const uint64_t sp_units = e->sp_units;
     a.SP = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (units / R + sp_units * 2 / 3) / sp_units));
-    *blocks = 1 + R * a.SP + a.nR + 1 + a.nS + a.nA * popc(rm);
+    /* small rounds: one wavefront per round, APUS_GP rounds per workgroup (append_group) -- the
+     * block's load / sequencing chain is paid once for four rounds.  Large rounds stay one
+     * workgroup (or SP) per round: a wavefront per round would leave too few workgroups. */
+    a.GP = (e->gp_rounds > 1 && a.SP == 1 && R >= 4 * APUS_GP && units / R <= e->gp_max_units) ? APUS_GP : 1;
+    *blocks = 1 + call_append_blocks(a) + a.nR + 1 + a.nS + a.nA * popc(rm);
     return a;
 }
 
@@ -593,6 +605,7 @@ static int flush_live(apus_engine *e)
     e->tick_pending = false;
     a.nS = cap_grid(e->live_n, 256, 32); a.nA = cap_grid(e->live_n, 1024, 16); a.nR = cap_grid(R, 256, 8);
     a.SP = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (e->live_bytes / 16 / R + e->sp_units * 2 / 3) / e->sp_units));
+    a.GP = 1;                                      /* (no staged byte prefix on the live path) */
     hipLaunchKernelGGL(k_call, dim3(1 + R * a.SP + a.nR + 1 + a.nS + a.nA * popc(rm)), dim3(256), 0, e->stream, view, a, fm, rm);
     e->live_R = 0;
     HIPCHK(hipGetLastError());

@@ -924,6 +924,227 @@ __device__ static inline void append_round(const EngDev &E, const CallEnv &X, ui
     if (r == 0) STAMP(1, 2);
 }
 
+/* ------------------------------------------------------------------------- */
+/* Grouped append (k_call / k_step, small rounds): ONE WAVEFRONT PER ROUND, APUS_GP rounds per
+ * workgroup.  A 64-entry round of 128-byte entries is only 8 KiB: as one workgroup per round
+ * (append_round) every block spends most of its ~11 us life on two dependent load round trips
+ * and the single-lane sequencing before its 512 stores, and occupancy x latency -- not HBM --
+ * bounds the launch.  Here the block pays that chain once for four rounds:
+ *   round trip 1   every wave: its round's descriptors (lane = entry) and byte prefix;
+ *                  wave 0 also the call's control words (seq_w0_stage)
+ *   on chip        one lane works the call's SeqOut out (seq_w0_decide) while every wave lays
+ *                  its own round out with wave scans -- no block barrier inside a round
+ *   round trip 2   the first payload units (already in flight while the SeqOut is computed)
+ *   stores         lane l writes units l, l+64, ... of its wave's round to the leader ring and
+ *                  every pushed follower ring (consecutive lanes = consecutive 16-byte units)
+ * Semantics are append_round<true>'s, line for line (positions, stale header, fused reply
+ * bytes, directory, in-step apply records and the per-round hash words). */
+#define APUS_GP 4
+#ifndef APUS_GP_PF
+#define APUS_GP_PF 4          /* payload units per lane fetched before the SeqOut is known */
+#endif
+struct GroupLds {
+    uint64_t pos[APUS_GP][WAVE];
+    uint64_t src[APUS_GP][WAVE];
+    uint64_t idx[APUS_GP][WAVE];
+    uint64_t req[APUS_GP][WAVE];
+    uint32_t tail[APUS_GP][WAVE];         /* clt_id | type << 16 | sender << 24 */
+    uint32_t T[APUS_GP][WAVE];
+    uint32_t ubase[APUS_GP][WAVE + 1];
+};
+
+__device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X, uint64_t r0, uint32_t R, uint32_t push_mask,
+                                               uint32_t grp, GroupLds &gl, SeqLds *sq, uint32_t tick,
+                                               const uint64_t *snap, bool post_read)
+{
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const RepDev &Ld = E.rep[E.leader];
+    const uint32_t *rf = E.round_first + r0;
+    const uint32_t r = grp * APUS_GP + wv;
+    const bool has = r < R;
+    const uint32_t g0 = rf[0];
+    const uint32_t first = has ? rf[r] - g0 : 0, nr = has ? rf[r + 1] - rf[r] : 0;
+    const uint64_t pfx_r = has ? E.round_prefix[r0 + r] : 0;
+
+    /* ---- round trip 1 ---- */
+    const bool active = lane < nr;
+    ReqDev d; d.req_id = 0; d.pay16_type = 0; d.len = 0; d.clt_id = 0;
+    if (active) d = E.req[g0 + first + lane];
+    if (wv == 0) {
+        seq_w0_stage(E, r0, R, push_mask, grp * APUS_GP, *sq, snap);
+        if (tid == 0 && post_read) __hip_atomic_fetch_add(X.lines + (grp & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (grp == 0) STAMP(8, 0);
+    __syncthreads();
+    if (grp == 0) STAMP(8, 1);
+    /* one lane of wave 1 works the call's SeqOut out while the waves lay their rounds out */
+    if (tid == WAVE) seq_w0_decide<false, true>(E, push_mask, tick, *sq);
+    if (grp == 0) STAMPW(8, 7, WAVE);
+
+    /* ---- layout of this wave's round (registers + wave scans) ---- */
+    const uint32_t T = active ? APUS_HDR + d.len : 0;
+    const uint64_t incl = wave_incl_scan((uint64_t)T);
+    const uint32_t nu = active ? (T + 15) / 16 : 0;
+    const uint32_t uincl = wave_incl_scan(nu);
+    const uint32_t T0 = __shfl(T, 0, WAVE);
+    const bool uni = __all(!active || T == T0);
+    const uint32_t uall = __shfl(uincl, WAVE - 1, WAVE);
+    const uint32_t unu = uni ? (T0 + 15) / 16 : 0;
+    gl.src[wv][lane] = (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
+    gl.T[wv][lane] = T;
+    gl.ubase[wv][lane] = uincl - nu;
+    if (lane == WAVE - 1) gl.ubase[wv][WAVE] = uincl;
+    __builtin_amdgcn_wave_barrier();          /* LDS is in order within a wave; keep the compiler from reordering */
+
+    /* which entry of the round owns 16-byte unit u, at which byte offset of the entry */
+    auto unit_of = [&](uint32_t u, uint32_t &e, uint32_t &so, uint32_t &Te) {
+        uint32_t j;
+        if (unu) { e = u / unu; j = u - e * unu; }
+        else {
+            uint32_t lo = 0, hi = nr - 1;               /* largest e with ubase[e] <= u */
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (gl.ubase[wv][mid] <= u) lo = mid; else hi = mid - 1;
+            }
+            e = lo; j = u - gl.ubase[wv][e];
+        }
+        Te = gl.T[wv][e];
+        so = min(16u * j, Te - 16u);
+    };
+
+    /* ---- round trip 2: the first payload units into registers ---- */
+    constexpr int PF = APUS_GP_PF;
+    uint4 pv[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        pv[k] = make_uint4(0, 0, 0, 0);
+        const uint32_t u = lane + (uint32_t)k * WAVE;
+        if (u < uall) {
+            uint32_t e, so, Te;
+            unit_of(u, e, so, Te);
+            if (so >= 48) pv[k] = payload_unit(E.arena + gl.src[wv][e], so, Te - APUS_HDR, Te - APUS_HDR);
+        }
+    }
+    if (grp == 0) STAMP(8, 2);
+    __syncthreads();                          /* the SeqOut is in sq->out (or sq->ok == 0) */
+    if (grp == 0) STAMP(8, 3);
+    if (!sq->ok) {                            /* the batch could reach len: the block-wide scan, on the inputs staged above */
+        const uint32_t *rb = E.round_bytes + r0;
+        for (uint32_t i = tid; i < R && i < 1024; i += blockDim.x) sq->bytes0[i] = rb[i];
+        __syncthreads();
+        seq_body<false>(E, r0, R, push_mask, tick, push_mask, *sq, grp * APUS_GP);
+        __syncthreads();
+    }
+
+    /* ---- where the entries go (lane = entry) ---- */
+    const uint64_t e0 = sq->out.e0, n_end0 = sq->out.n_end0, term = sq->out.term;
+    const uint32_t fuse = sq->out.fuse_mask, fast = sq->out.fast;
+    {
+        const SeqOut &s = sq->out;
+        const uint64_t virt_r = sq->ok ? pfx_r - sq->pfx[0] : (has ? sq->virt[r] : 0);
+        const uint64_t a = e0 + virt_r + incl - T;
+        const int64_t gk = (int64_t)first + lane;
+        const uint64_t pos = apus_place(s, gk, a);
+        const uint64_t idx = apus_entry_idx(s, gk);
+        const uint64_t slot = n_end0 + (uint64_t)gk;
+        const uint32_t type = d.pay16_type >> 28;
+        const uint32_t tail = (uint32_t)d.clt_id | (type << 16) | ((uint32_t)E.leader << 24);
+        gl.pos[wv][lane] = pos; gl.idx[wv][lane] = idx; gl.req[wv][lane] = d.req_id; gl.tail[wv][lane] = tail;
+        if (active) {
+            const uint32_t di = (uint32_t)slot & E.dir_mask;
+            const uint32_t dl = T | ((uint32_t)E.leader << 24);     /* derived: total bytes | sender << 24 */
+            Ld.dir_off[di] = pos; Ld.dir_len[di] = dl; Ld.ack[di] = fuse;             /* ACK bits of the fused followers */
+            for (uint32_t m = push_mask; m; m &= m - 1) {
+                const RepDev &Fd = E.rep[__builtin_ctz(m)];
+                Fd.dir_off[di] = pos; Fd.dir_len[di] = dl;
+            }
+            if (s.stale && gk == s.kstar) {
+                /* the header log_append_entry wrote before it found out that the payload does
+                 * not fit (dare_log.h:497-504, 521-523) */
+                const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)term, (uint32_t)(term >> 32));
+                const uint4 h1 = make_uint4((uint32_t)d.req_id, (uint32_t)(d.req_id >> 32), tail, 0);
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                const uint4 lw = make_uint4((uint32_t)d.len, 0, 0, 0);
+                for (uint32_t m = push_mask | (1u << E.leader); m; m &= m - 1) {
+                    uint8_t *rg = E.rep[__builtin_ctz(m)].ring;
+                    st16u(rg + a, h0); st16u(rg + a + 16, h1);
+                    st16u(rg + a + 32, z); st16u(rg + a + 48, lw);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (grp == 0) STAMP(8, 4);
+
+        /* ---- the round's bytes: lane l stores units l, l + 64, ... ---- */
+        const ReplyWords rwl = apus_reply_words(fuse);
+        auto store_unit = [&](uint32_t e, uint32_t so, uint4 v) {
+            const uint64_t p = gl.pos[wv][e] + so;
+            if (fuse && so - 16u <= 16u) {                 /* the two units that hold reply[0..12] */
+                const bool second = so == 16;
+                st16u(Ld.ring + p, second ? make_uint4(v.x, v.y, v.z, rwl.w28) : make_uint4(rwl.x32, rwl.y36, rwl.z40, 0));
+                for (uint32_t m = push_mask; m; m &= m - 1) {
+                    const int f = __builtin_ctz(m);
+                    const ReplyWords rwf = apus_reply_words(fuse & (1u << f));
+                    st16u(E.rep[f].ring + p, second ? make_uint4(v.x, v.y, v.z, rwf.w28) : make_uint4(rwf.x32, rwf.y36, rwf.z40, 0));
+                }
+            } else {
+                st16u(Ld.ring + p, v);
+                for (uint32_t m = push_mask; m; m &= m - 1) st16u(E.rep[__builtin_ctz(m)].ring + p, v);
+            }
+        };
+        auto header_or = [&](uint32_t e, uint32_t so, uint4 pay) -> uint4 {
+            if (so == 0) { const uint64_t ix = gl.idx[wv][e]; return make_uint4((uint32_t)ix, (uint32_t)(ix >> 32), (uint32_t)term, (uint32_t)(term >> 32)); }
+            if (so == 16) { const uint64_t rq = gl.req[wv][e]; return make_uint4((uint32_t)rq, (uint32_t)(rq >> 32), gl.tail[wv][e], 0); }
+            if (so == 32) return make_uint4(0, 0, 0, 0);
+            return pay;
+        };
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const uint32_t u = lane + (uint32_t)k * WAVE;
+            if (u < uall) {
+                uint32_t e, so, Te;
+                unit_of(u, e, so, Te);
+                store_unit(e, so, header_or(e, so, pv[k]));
+            }
+        }
+        for (uint32_t u = lane + PF * WAVE; u < uall; u += WAVE) {
+            uint32_t e, so, Te;
+            unit_of(u, e, so, Te);
+            uint4 pay = make_uint4(0, 0, 0, 0);
+            if (so >= 48) pay = payload_unit(E.arena + gl.src[wv][e], so, Te - APUS_HDR, Te - APUS_HDR);
+            store_unit(e, so, header_or(e, so, pay));
+        }
+
+        if (grp == 0) STAMP(8, 5);
+        /* ---- in step: apply_committed_entries for the round, from the registers that built it
+         * (leader kind 1: proxy_update_state, fused followers kind 2: proxy_do_action) ---- */
+        if (fast) {
+            uint64_t mix1 = 0, mix2 = 0;
+            if (active) {
+                const uint32_t len = T - APUS_HDR;
+                const uint32_t t24 = tail & 0x00FFFFFFu;                      /* clt_id | type << 16 */
+                const uint32_t di = (uint32_t)slot & E.dir_mask;
+                const uint4 r0v = make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32));
+                uint4 *rp = (uint4 *)&Ld.apply[di];
+                rp[0] = r0v; rp[1] = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), len, t24 | (1u << 24));
+                for (uint32_t m = fuse; m; m &= m - 1) {
+                    uint4 *fp = (uint4 *)&E.rep[__builtin_ctz(m)].apply[di];
+                    fp[0] = r0v; fp[1] = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), len, t24 | (2u << 24));
+                }
+                mix1 = apus_apply_mix(slot, pos, idx, len, (uint16_t)t24, (uint8_t)(t24 >> 16), 1);
+                mix2 = apus_apply_mix(slot, pos, idx, len, (uint16_t)t24, (uint8_t)(t24 >> 16), 2);
+            }
+            const uint64_t sum1 = wave_sum(mix1), sum2 = wave_sum(mix2);
+            if (has && lane == 0) {     /* write-through: a record block of the same launch reads them */
+                __hip_atomic_store(&X.hash[2 * r], sum1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&X.hash[2 * r + 1], sum2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (grp == 0) STAMP(8, 6);
+    }
+    return fast;
+}
+
 __global__ __launch_bounds__(256) void k_append_push(const EngDev E, uint64_t r0, uint32_t R, uint32_t push_mask)
 {
     __shared__ AppendLds lds;
@@ -1599,15 +1820,31 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
  * append blocks post before they wait for anything); workgroups are dispatched in index order per
  * XCD, so what a waiting block needs is already running or done: no co-residency assumption. */
 /* one call's parameters (k_call's arguments; one entry per segment in k_step's table) */
+/* k_call / k_step: -DAPUS_LB_W=k asks the register allocator for k workgroups per CU */
+#ifdef APUS_LB_W
+#define APUS_CALL_BOUNDS __launch_bounds__(256, APUS_LB_W)
+#else
+#define APUS_CALL_BOUNDS __launch_bounds__(256)
+#endif
 struct CallArgs {
     uint64_t r0;
     uint32_t R, tick, SP, nR, nS, nA;
+    uint32_t GP;           /* > 1: grouped append, GP (= APUS_GP) small rounds per workgroup (then SP == 1) */
 };
+/* number of append blocks of a call */
+__host__ __device__ static inline uint32_t call_append_blocks(const CallArgs &A)
+{
+    return A.GP > 1 ? (A.R + A.GP - 1) / A.GP : A.R * A.SP;
+}
 union CallLds {
     AppendLds app;
+    GroupLds grp;
     struct { ApplyCtx c; unsigned long long acc[2]; uint64_t np[APUS_DEV_MAX_SERVERS]; uint64_t sc[4]; uint32_t flag; } t;
 };
 
+#ifndef APUS_POLL_SLEEP
+#define APUS_POLL_SLEEP 8       /* x 64 clocks between two polls of a chain count */
+#endif
 /* multi-segment launches: segment k waits until epoch >= k (the bookkeeper of segment k-1 has
  * written snapshot k) / until the sequencer of segment k-1 is done; 32 replicas, one per cache line */
 __device__ static inline void wait_count(const EngDev &E, const uint32_t *lines32, uint32_t b, uint32_t want)
@@ -1615,7 +1852,7 @@ __device__ static inline void wait_count(const EngDev &E, const uint32_t *lines3
     if (threadIdx.x == 0) {
         unsigned long long spins = 0;
         while (__hip_atomic_load(lines32 + (b & 31u) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(APUS_POLL_SLEEP);
             if (++spins > (1ull << 22)) { set_status(E, 1u << 4); break; }     /* bounded */
         }
     }
@@ -1629,13 +1866,21 @@ __device__ static inline void bump_count(uint32_t *lines32, uint32_t value)
     if (threadIdx.x < 32) __hip_atomic_store(lines32 + threadIdx.x * 32, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#define APUS_STEP_SEGS 32
+struct StepTable {
+    CallArgs seg[APUS_STEP_SEGS];
+    uint32_t blk0[APUS_STEP_SEGS + 1];        /* first block of every segment; blk0[S] = grid size */
+    uint32_t S;
+};
+
 /* The body of a call for block b of its grid.  STEP = false: k_call (one call per launch, inputs =
  * the live control blocks).  STEP = true: segment seg of S in a k_step launch: inputs = snapshot
  * seg (seg > 0), the bookkeeper writes snapshot seg + 1 and raises the epoch, the sequencers'
  * effects are chained by their own count. */
 template <bool STEP>
 __device__ static inline void call_block(const EngDev &E, const CallEnv &X, const CallArgs &A, uint32_t push_mask, uint32_t rmask,
-                                         uint32_t b_grid, SeqLds &sq, CallLds &l, uint32_t seg, uint32_t S)
+                                         uint32_t b_grid, SeqLds &sq, CallLds &l, uint32_t seg, uint32_t S,
+                                         const StepTable *TT = nullptr)
 {
     const uint64_t r0 = A.r0;
     const uint32_t R = A.R, tick = A.tick, SP = A.SP, nR = A.nR, nS = A.nS, nA = A.nA;
@@ -1646,7 +1891,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
      * rest of the function was written in: sequencer 0, append 1 .. nAB, records, bookkeeper, ...) */
     uint32_t b;
     {
-        const uint32_t nAB_ = R * SP;
+        const uint32_t nAB_ = call_append_blocks(A);
         if (b_grid == 0) b = 1 + nAB_ + nR;                    /* the bookkeeper */
         else if (b_grid == 1) b = 0;                           /* the sequencer */
         else if (b_grid < 2 + nAB_ + nR) b = b_grid - 1;       /* append and record blocks */
@@ -1656,7 +1901,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
     const uint32_t ny = (uint32_t)__popc(rmask);
     const uint32_t fmask = push_mask;
     ApplyCtx &c = l.t.c;
-    const uint32_t nAB = R * SP;                               /* append blocks: SP per round */
+    const uint32_t nAB = call_append_blocks(A);                /* append blocks: SP per round, or one per GP rounds */
     /* blocks that fetch the control words themselves: append + nR record + 1 bookkeeper */
     const uint32_t n_readers = nAB + nR + 1;
     /* blocks that sign off with T_PASS: everybody but the append blocks and the janitor */
@@ -1668,12 +1913,19 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
     uint64_t *snap_next = STEP ? E.step_snap + (size_t)(seg + 1) * SNAP_STRIDE : nullptr;
 
     if (b >= 1 && b <= nAB) {                                  /* ---- append + push ---- */
-        const uint32_t ab = b - 1, r = ab / SP, slice = ab - r * SP;
+        const uint32_t ab = b - 1;
         if (!live) wait_count(E, E.step_epoch, b, seg);
         if (b == nAB) STAMP(6, 0);
-        append_round<true>(E, X, r0, R, push_mask, r, l.app, &sq, tick, slice, SP, snap, live);
+        uint32_t fast;
+        if (A.GP > 1) {
+            fast = append_group(E, X, r0, R, push_mask, ab, l.grp, &sq, tick, snap, live);
+        } else {
+            const uint32_t r = ab / SP, slice = ab - r * SP;
+            append_round<true>(E, X, r0, R, push_mask, r, l.app, &sq, tick, slice, SP, snap, live);
+            fast = l.app.fast;
+        }
         if (b == nAB) STAMP(6, 1);
-        post_append(E, X, ab, l.app.fast == 0);
+        post_append(E, X, ab, fast == 0);
         if (b == nAB) STAMP(6, 2);
         return;
     }
@@ -1757,47 +2009,102 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
     }
     q -= nR;
     if (q == 0) {                                              /* ---- the bookkeeper ---- */
+        /* In a multi-segment launch ONE block -- segment 0's bookkeeper -- keeps the books of every
+         * segment, one after the other: in step the state after a call follows from the state before
+         * it and the staged sizes, so segment k+1's bookkeeping starts from the LDS copy segment k's
+         * left behind (c.lh, c.fw, c.rec_base) -- no poll of the epoch, no snapshot read-back, and
+         * the epochs run ahead of the stores.  (One bookkeeper block per segment chained through
+         * memory cost ~9 us per segment: measured 10.4 / 13.5 / 15.2 / 21.3 us per call of 1 / 2 / 4 /
+         * 8 MiB, tools/seg_probe.py.)  The other segments' bookkeeper blocks just leave. */
+        if (STEP && seg > 0) return;
         STAMP(3, 0);
-        if (!live) wait_count(E, E.step_epoch, b, seg);
-        /* followers' control words: nobody else writes them while the replicas are in step */
-        if (tid >= 128 && tid < 128 + 8 * APUS_DEV_MAX_SERVERS) {
-            const uint32_t f = (tid - 128) >> 3, j = (tid - 128) & 7;
-            c.fw[f][j] = ((fmask >> f) & 1u) ? stage_follower_word(E, snap, f, j) : 0;     /* FW_* order */
-        }
-        seq_local(E, X, r0, R, push_mask, tick, 0, nAB + nR, sq, snap, true, live);
-        STAMP(3, 1);
-        if (sq.out.fast) {
-            /* in step: everything the bookkeeping needs follows from the sequencing it just worked
-             * out; nothing it writes is read by another block of the launch: publish right away */
-            if (tid < 64) c.lh[tid] = sq.lh[tid];
-            else if (tid < 64 + sizeof(SeqOut) / 8) ((uint64_t *)&c.seq)[tid - 64] = ((const uint64_t *)&sq.out)[tid - 64];
-            __syncthreads();
-            const uint64_t vis = sq.out.vis, cs = vis;
-            if (tid == 0) {
-                c.rec_base = sq.out.rec_base;
-                c.off_cs = sq.end_new; c.off_vis = sq.end_new;       /* vis == n_end: the batch is fully visible */
+        const uint32_t S_ = STEP ? S : 1u;
+        for (uint32_t k = 0; k < S_; k++) {
+            const CallArgs &Ak = (STEP && TT) ? TT->seg[k] : A;
+            const CallEnv Xk = (STEP && TT) ? CallEnv{E.step_lines + (size_t)k * 1024, E.step_tickets + (size_t)k * 32,
+                                                      E.step_hash + (size_t)k * 2 * 1024} : X;
+            const uint64_t r0k = Ak.r0;
+            const uint32_t Rk = Ak.R, tickk = Ak.tick;
+            const uint32_t nABk = call_append_blocks(Ak), nRk = Ak.nR, nSk = Ak.nS, nAk = Ak.nA;
+            const uint32_t n_readers_k = nABk + nRk + 1;
+            const bool live_k = !STEP || k == 0;
+            const uint64_t *snap_k = live_k ? nullptr : E.step_snap + (size_t)k * SNAP_STRIDE;
+            uint64_t *snap_next_k = STEP ? E.step_snap + (size_t)(k + 1) * SNAP_STRIDE : nullptr;
+            if (k < 16) STAMP(7, 4 * k);
+            if (k == 0) {
+                /* followers' control words: nobody else writes them while the replicas are in step */
+                if (tid >= 128 && tid < 128 + 8 * APUS_DEV_MAX_SERVERS) {
+                    const uint32_t f = (tid - 128) >> 3, j = (tid - 128) & 7;
+                    c.fw[f][j] = ((fmask >> f) & 1u) ? stage_follower_word(E, snap_k, f, j) : 0;     /* FW_* order */
+                }
+                seq_local(E, Xk, r0k, Rk, push_mask, tickk, 0, nABk + nRk, sq, snap_k, true, live_k);
+            } else {
+                /* the inputs: the state the previous segment's bookkeeping left in LDS + this
+                 * segment's staged sizes (what seq_w0_stage fetches) */
+                __syncthreads();
+                if (tid < 64) sq.lh[tid] = c.lh[tid];
+                else if (tid < 64 + 5 * APUS_DEV_MAX_SERVERS) {
+                    const uint32_t w = tid - 64, f = w / 5, j = w - f * 5;
+                    (&sq.fw[0][0])[w] = ((push_mask >> f) & 1u) ? c.fw[f][j] : (j == FW_N_PERSIST ? ~0ull : 0ull);
+                } else if (tid == 192) { sq.misc[0] = c.rec_base; sq.rstar = 0xFFFFFFFFu; sq.head_round = 0; }
+                else if (tid == 193) sq.pfx[0] = E.round_prefix[r0k];
+                else if (tid == 194) sq.pfx[1] = E.round_prefix[r0k];
+                else if (tid == 195) sq.pfx[2] = E.round_prefix[r0k + Rk];
+                else if (tid == 196) sq.rfx[0] = E.round_first[r0k];
+                else if (tid == 197) sq.rfx[1] = E.round_first[r0k + Rk];
+                else if (tid == 198) {
+                    const uint32_t a = E.round_first[r0k], bb = E.round_first[r0k + Rk];
+                    sq.misc[1] = (bb > a) ? E.req_len[bb - 1] : 0;
+                }
+                __syncthreads();
+                if (k < 16) STAMP(7, 4 * k + 1);
+                if (tid == 0) seq_w0_decide<false>(E, push_mask, tickk, sq);
+                __syncthreads();
+                if (k < 16) STAMP(7, 4 * k + 2);
+                if (!sq.ok) {
+                    const uint32_t *rb = E.round_bytes + r0k;
+                    for (uint32_t i = tid; i < Rk && i < 1024; i += blockDim.x) sq.bytes0[i] = rb[i];
+                    __syncthreads();
+                    seq_body<false>(E, r0k, Rk, push_mask, tickk, push_mask, sq, 0);
+                }
             }
-            __syncthreads();
-            if (live) wait_readers(E, X, n_readers);           /* it changes words the other blocks sequence from */
-            STAMP(3, 2);
-            keeper_publish(E, c, R, 0, fmask, vis, cs, true, sq.out.head_round ? sq.out.n_end0 : 0, sq.lh[H_HEAD], snap_next);
-            STAMP(3, 3);
-        } else {
-            wait_sequenced(E, X, b, &l.t.flag);                /* the sequencer's results, released */
-            stage_apply_ctx(E, c, -1, true, fmask);
-            wait_ticket(E, X, T_DONE, nA * ny + nR);
-            if (tid == 0)
-                c.seq.first_fail = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const uint64_t vis = c.seq.vis, cs = ctx_commit_slot(c);
-            const uint64_t end_l = c.lh[H_END], n_end_l = c.lh[H_N_END];
-            if (tid == 0) c.off_cs = (cs == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)cs & E.dir_mask];
-            if (tid == 1) c.off_vis = (vis == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)vis & E.dir_mask];
-            __syncthreads();
-            keeper_publish(E, c, R, 0, fmask, vis, cs, false, 0, 0, snap_next);
+            STAMP(3, 1);
+            if (sq.out.fast) {
+                /* in step: everything the bookkeeping needs follows from the sequencing it just worked
+                 * out; nothing it writes is read by another block of the launch: publish right away */
+                __syncthreads();
+                if (tid < 64) c.lh[tid] = sq.lh[tid];
+                else if (tid < 64 + sizeof(SeqOut) / 8) ((uint64_t *)&c.seq)[tid - 64] = ((const uint64_t *)&sq.out)[tid - 64];
+                __syncthreads();
+                const uint64_t vis = sq.out.vis, cs = vis;
+                if (tid == 0) {
+                    c.rec_base = sq.out.rec_base;
+                    c.off_cs = sq.end_new; c.off_vis = sq.end_new;       /* vis == n_end: the batch is fully visible */
+                }
+                __syncthreads();
+                if (live_k) wait_readers(E, Xk, n_readers_k);          /* it changes words the other blocks sequence from */
+                STAMP(3, 2);
+                keeper_publish(E, c, Rk, 0, fmask, vis, cs, true, sq.out.head_round ? sq.out.n_end0 : 0, sq.lh[H_HEAD], snap_next_k);
+                STAMP(3, 3);
+            } else {
+                wait_sequenced(E, Xk, b, &l.t.flag);               /* the sequencer's results, released */
+                stage_apply_ctx(E, c, -1, true, fmask);
+                wait_ticket(E, Xk, T_DONE, nAk * ny + nRk);
+                if (tid == 0)
+                    c.seq.first_fail = __hip_atomic_load((unsigned long long *)&E.seq->first_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                const uint64_t vis = c.seq.vis, cs = ctx_commit_slot(c);
+                const uint64_t end_l = c.lh[H_END], n_end_l = c.lh[H_N_END];
+                if (tid == 0) c.off_cs = (cs == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)cs & E.dir_mask];
+                if (tid == 1) c.off_vis = (vis == n_end_l) ? end_l : E.rep[E.leader].dir_off[(uint32_t)vis & E.dir_mask];
+                __syncthreads();
+                keeper_publish(E, c, Rk, 0, fmask, vis, cs, false, 0, 0, snap_next_k);
+            }
+            if (STEP) bump_count(E.step_epoch, k + 1);             /* snapshot k + 1 is complete */
+            if (k < 16) STAMP(7, 4 * k + 3);
+            post_ticket(E, Xk, T_PASS, false);
+            (void)nSk;
         }
-        if (STEP) bump_count(E.step_epoch, seg + 1);           /* snapshot seg + 1 is complete */
-        post_ticket(E, X, T_PASS, false);
         return;
     }
     q -= 1;
@@ -1829,8 +2136,11 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
     post_ticket(E, X, T_PASS, false);
 }
 
-__global__ __launch_bounds__(256) void k_call(const EngDev E, const CallArgs A, uint32_t push_mask, uint32_t rmask)
+__global__ APUS_CALL_BOUNDS void k_call(const EngDev E_arg, const CallArgs A, uint32_t push_mask, uint32_t rmask)
 {
+    /* E is used where it lies in the kernarg segment (see k_step) */
+    const EngDev &E = *(const EngDev *)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)E_arg;
     __shared__ SeqLds sq;
     __shared__ CallLds l;
     const CallEnv X = APUS_ENV_OF(E);
@@ -1845,13 +2155,7 @@ __global__ __launch_bounds__(256) void k_call(const EngDev E, const CallArgs A, 
  * bookkeeper is done (which in step is early: it needs nothing but its own copy of the
  * sequencing), while segment k-1's stores are still draining.  No end-of-kernel write-back, no
  * dispatch ramp, no graph gap between segments. */
-#define APUS_STEP_SEGS 32
-struct StepTable {
-    CallArgs seg[APUS_STEP_SEGS];
-    uint32_t blk0[APUS_STEP_SEGS + 1];        /* first block of every segment; blk0[S] = grid size */
-    uint32_t S;
-};
-__global__ __launch_bounds__(256) void k_step(const EngDev E_arg, const StepTable T, uint32_t push_mask, uint32_t rmask)
+__global__ APUS_CALL_BOUNDS void k_step(const EngDev E_arg, const StepTable T, uint32_t push_mask, uint32_t rmask)
 {
     /* E is used where it lies in the kernarg segment (first argument): with this much code behind
      * it the compiler otherwise copies the 950-byte struct into scratch for per-lane indexing */
@@ -1862,7 +2166,7 @@ __global__ __launch_bounds__(256) void k_step(const EngDev E_arg, const StepTabl
     uint32_t seg = 0;
     for (uint32_t k = 1; k < T.S; k++) if (blockIdx.x >= T.blk0[k]) seg = k;
     const CallEnv X{E.step_lines + (size_t)seg * 1024, E.step_tickets + (size_t)seg * 32, E.step_hash + (size_t)seg * 2 * 1024};
-    call_block<true>(E, X, T.seg[seg], push_mask, rmask, blockIdx.x - T.blk0[seg], sq, l, seg, T.S);
+    call_block<true>(E, X, T.seg[seg], push_mask, rmask, blockIdx.x - T.blk0[seg], sq, l, seg, T.S, &T);
 }
 
 /* READ the apply offset of peer i for the next prune tick (rc_get_remote_apply_offsets,

@@ -88,7 +88,17 @@ def issue(eng, calls):
         eng.batch_end()
 
 
-def cpu_baseline(args, seconds=15.0):
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline_port(args, seconds=15.0):
     """The CPU oracle (a single-threaded port of the reference's loops, -O2) on a
     bounded sample of the same workload, timed on this box's host cores."""
     from apus_amd import trace as T
@@ -112,7 +122,63 @@ def cpu_baseline(args, seconds=15.0):
     assert o["commit"] == o["end"]
     return {"value": done / el, "unit": "committed entries/s", "cores": 1, "kind": "port",
             "sample": f"{passes} x {len(tr.reqs)} entries of the same 3-replica stream "
-                      f"({el:.1f} s, oracle/liboracle.so -O2, nproc={os.cpu_count()})"}
+                      f"({el:.1f} s, oracle/liboracle.so -O2, {_cpu_model()}, nproc={os.cpu_count()})"}
+
+
+def cpu_baseline_reference(args, seconds=12.0):
+    """THE REFERENCE ITSELF: /root/reference/src/dare/*.c compiled unmodified with its own -O0
+    (oracle/_ref/libapus_ref_loops.so; the prebuilt library travels to the GPU box), 3 server
+    instances on ONE host thread, RDMA = memcpy through the in-process verbs stand-in
+    (oracle/refshim/), no BerkeleyDB, no sockets.  Same stream, same rounds, same prune ticks."""
+    from apus_amd import trace as T
+    from oracle import oracle as orc
+    from oracle import refloops
+    if not refloops.available():
+        return None
+    sample = min(args.entries, 1 << 17)
+    tr = T.steady_trace(3, sample, args.payload, 16, args.batch, log_len=T.DEFAULT_LOG)
+    reqs = np.ascontiguousarray(tr.reqs, dtype=orc.REQ_DTYPE)
+    rounds = [(ev[1], ev[2]) for ev in tr.events if ev[0] == "ROUND"]
+    rc = refloops.RefCluster(3, tr.log_len, record_apply=False)
+    try:
+        rc.elect(0)
+        done, passes, since, t0 = 0, 0, 0, time.perf_counter()
+        while True:
+            for g0, n in rounds:
+                rc.round(reqs[g0:g0 + n], tr.arena)
+                since += int(reqs["len"][g0:g0 + n].sum()) + 64 * n
+                if since >= (8 << 20):
+                    rc.tick_prune()
+                    since = 0
+            done += len(reqs)
+            passes += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or passes >= 4096:
+                break
+        rc.quiesce()
+        o = rc.log(0).offsets()
+        assert o["commit"] == o["end"] and rc.highest_rec(0) == done
+    finally:
+        rc.close()
+    return {"value": done / el, "unit": "committed entries/s", "cores": 1, "kind": "reference",
+            "sample": f"{passes} x {len(reqs)} entries of the same 3-replica stream ({el:.1f} s; the reference's own "
+                      f"dare_server.c / dare_ibv_rc.c loops, unmodified, -O0 as the reference builds them, 3 servers on "
+                      f"one thread, in-process verbs stand-in; {_cpu_model()}, nproc={os.cpu_count()})"}
+
+
+def cpu_baseline(args, seconds=12.0):
+    """`cpu_baseline` = the reference itself when its library is there (kind "reference"),
+    else the restated oracle (kind "port"); the other one rides along as `also`."""
+    port = cpu_baseline_port(args, max(3.0, seconds / 2))
+    try:
+        ref = cpu_baseline_reference(args, seconds)
+    except Exception as exc:
+        print(f"[bench] reference-as-is baseline failed: {exc!r}", file=sys.stderr)
+        ref = None
+    if ref is None:
+        return port
+    ref["also"] = port
+    return ref
 
 
 def bench_single(args):
@@ -296,6 +362,18 @@ def main():
     if args.gpus <= 1:
         out = bench_single(args)
         print(json.dumps(out))
+    elif "RANK" not in os.environ:
+        # started bare (python bench.py --gpus N): become the launcher of N ranks, one per GPU
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
     else:
         out = bench_multi(args)
         if out is not None:
