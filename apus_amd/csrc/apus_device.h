@@ -139,6 +139,7 @@ struct EngDev {
     uint32_t *step_tickets;               /* [segs][32] */
     uint64_t *step_hash;                  /* [segs][2 x 1024] */
     uint64_t *step_snap;                  /* [segs + 1][SNAP_STRIDE] */
+    uint64_t *step_rec;                   /* [segs][REC_WORDS] the segments' sequencing records (uncached, self-tagged granules) */
     uint32_t *step_epoch, *step_seq_done; /* [32 x 32] each: bookkeeper / sequencer of segment k done */
     uint64_t *trace;                      /* -DAPUS_TRACE builds: [kernel][64] wall-clock stamps; else nullptr */
 };
@@ -187,9 +188,24 @@ __host__ __device__ static inline uint64_t apus_apply_mix(uint64_t slot, uint64_
 #ifdef __HIPCC__
 /* unaligned 16-byte global access: gfx950 runs in unaligned access mode, hipcc
  * lowers these to one global_load/store_dwordx4 at any byte address */
-__device__ static inline uint4 ld16u(const uint8_t *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
-__device__ static inline void  st16u(uint8_t *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
-__device__ static inline uint64_t ld8u(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+/* The pointers of the engine descriptor reach the kernels through memory (kernarg segment, LDS
+ * copy), so the compiler sees GENERIC pointers and would emit FLAT loads / stores (aperture check,
+ * both wait counters).  Everything they point at is device memory: the helpers below say so
+ * (address space 1 = global), which gives global_load / global_store. */
+#define APUS_GLOBAL __attribute__((address_space(1)))
+typedef uint32_t apus_v4 __attribute__((ext_vector_type(4)));
+typedef apus_v4 __attribute__((aligned(1))) apus_v4_u;
+typedef uint64_t __attribute__((aligned(1))) apus_u64_u;
+__device__ static inline uint4 ld16u(const uint8_t *p)
+{
+    const apus_v4 v = *(const APUS_GLOBAL apus_v4_u *)(uintptr_t)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ static inline void st16u(uint8_t *p, uint4 v) { *(APUS_GLOBAL apus_v4_u *)(uintptr_t)p = apus_v4{v.x, v.y, v.z, v.w}; }
+__device__ static inline uint64_t ld8u(const uint8_t *p) { return *(const APUS_GLOBAL apus_u64_u *)(uintptr_t)p; }
+/* naturally aligned words / records in device memory */
+template <typename T> __device__ static inline void gst(T *p, T v) { *(APUS_GLOBAL T *)(uintptr_t)p = v; }
+template <typename T> __device__ static inline T gld(const T *p) { return *(const APUS_GLOBAL T *)(uintptr_t)p; }
 
 /* physical placement of batch entry gk whose virtual start is a = e0 + virt */
 __device__ static inline uint64_t apus_place(const SeqOut &s, int64_t gk, uint64_t a)

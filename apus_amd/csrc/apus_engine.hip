@@ -183,6 +183,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     if (!rc) rc = dev_alloc(e, &e->d.step_tickets, sizeof(uint32_t) * APUS_STEP_SEGS * 32);
     if (!rc) rc = dev_alloc(e, &e->d.step_hash, sizeof(uint64_t) * APUS_STEP_SEGS * 2 * 1024);
     if (!rc) rc = dev_alloc(e, &e->d.step_snap, sizeof(uint64_t) * (APUS_STEP_SEGS + 1) * SNAP_STRIDE, true, hipDeviceMallocUncached);
+    if (!rc) rc = dev_alloc(e, &e->d.step_rec, sizeof(uint64_t) * APUS_STEP_SEGS * REC_WORDS, true, hipDeviceMallocUncached);
     if (!rc) rc = dev_alloc(e, &e->d.step_epoch, sizeof(uint32_t) * 32 * 32);
     if (!rc) rc = dev_alloc(e, &e->d.step_seq_done, sizeof(uint32_t) * 32 * 32);
 #ifdef APUS_TRACE

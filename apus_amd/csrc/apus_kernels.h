@@ -46,16 +46,19 @@
 #ifdef APUS_TRACE
 #define STAMP(K, k) do { if (threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); E.trace[(K) * 64 + (k)] = wall_clock64(); } } while (0)
 #define STAMPW(K, k, T) do { if (threadIdx.x == (T)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); E.trace[(K) * 64 + (k)] = wall_clock64(); } } while (0)
+/* STAMPN: no drain -- the time the code got here, not the time its memory operations finished */
+#define STAMPN(K, k) do { if (threadIdx.x == 0) E.trace[(K) * 64 + (k)] = wall_clock64(); } while (0)
 #else
 #define STAMP(K, k) do { } while (0)
 #define STAMPW(K, k, T) do { } while (0)
+#define STAMPN(K, k) do { } while (0)
 #endif
 
 /* a control word (uncached device memory) read past L1 / L2: blocks of one launch may read words
  * an earlier part of the same launch wrote */
 __device__ static inline uint64_t ldw(const uint64_t *p)
 {
-    return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load((const APUS_GLOBAL unsigned long long *)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 /* where a call's blocks meet: arrival counters and the per-round hash scratch.  One set per
@@ -263,6 +266,7 @@ struct SeqLds {
     uint64_t pfx[3];                      /* wave-0 variant: staged byte prefix at round 0, my_r, R of the call */
     uint32_t rfx[2];                      /* wave-0 variant: first request of round 0 and of round R */
     uint32_t ok;                          /* wave-0 variant: 1 = SeqOut worked out, 0 = take the block-wide path */
+    uint32_t chain_did;                   /* rec_wait: the chain block does this segment's sequencer effects itself */
     uint64_t end_new;                     /* the leader's end offset after the batch */
     SeqOut   out;                         /* FX = false: the call's SeqOut */
 };
@@ -648,6 +652,167 @@ __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask,
     q.ok = 1;
 }
 
+/* The chain block's sequencing of a segment that is IN STEP and clear of the end of the ring,
+ * by one wavefront instead of one lane: lane i holds server i's words, the leader's words are
+ * fetched from LDS in one batch, the per-server loops of seq_in_step / control_append (mode 1:
+ * log_pruning, dare_server.c:1996-2067) / sample_into_copy become wave operations.  Produces
+ * exactly what seq_w0_decide<false> leaves in q for such a segment (q.lh = the leader's control
+ * block after the call, q.out, q.end_new, q.ok = 1) and returns 1; returns 0 with q untouched when
+ * any precondition fails -- then the general single-lane path decides.  The single-lane path costs
+ * ~2.6 us of dependent LDS round trips per segment on the launch's critical chain. */
+__device__ static inline uint64_t wave_max_u64(uint64_t v)
+{
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) { const uint64_t o = __shfl_xor(v, d, WAVE); v = o > v ? o : v; }
+    return v;
+}
+__device__ static inline int chain_decide_fast(const EngDev &E, uint32_t push_mask, uint32_t tick, SeqLds &q, uint64_t r0, uint32_t R)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t L = E.log_len;
+    const uint32_t size = E.group_size, leader = E.leader;
+    const bool srv = lane < APUS_DEV_MAX_SERVERS;
+    /* one batch of LDS reads */
+    const uint64_t end = q.lh[H_END], n_end = q.lh[H_N_END], last_idx = q.lh[H_LAST_IDX], sid = q.lh[H_SID];
+    const uint64_t commit = q.lh[H_COMMIT], n_commit = q.lh[H_N_COMMIT], n_apply = q.lh[H_N_APPLY], apply = q.lh[H_APPLY];
+    const uint64_t head = q.lh[H_HEAD], tail = q.lh[H_TAIL], prev_head = q.lh[H_PREV_HEAD], store_count = q.lh[H_STORE_COUNT];
+    const uint32_t bitmask = (uint32_t)q.lh[H_CID_BITMASK];
+    const uint64_t apoff = srv ? q.lh[H_APPLY_OFFSETS + lane] : 0;
+    const uint64_t f_apply = srv ? q.fw[lane][2] : 0, f_np = srv ? q.fw[lane][3] : 0, f_na = srv ? q.fw[lane][4] : 0;
+    const uint64_t vtot = q.pfx[2] - q.pfx[0];
+    const uint32_t n = q.rfx[1] - q.rfx[0];
+    const uint64_t rec_base = q.misc[0], len_last = q.misc[1];
+
+    /* in step (seq_in_step), a fused majority (seq_flags), clear of len, not full */
+    const bool pushed = srv && ((push_mask >> lane) & 1u);
+    const uint32_t size_mask = (1u << size) - 1;
+    const bool quorum = (uint32_t)__popc((push_mask | (1u << leader)) & size_mask) >= size / 2 + 1;
+    /* (a batch that may reach the end of the ring is placed below; one that is longer than the
+     * ring, or an empty log, goes the general way) */
+    const bool pre = end != L && L - end >= APUS_HDR && vtot + APUS_HDR < L && n > 0 && R <= 1024 && quorum &&
+                     n_commit == n_end && n_apply == n_end && end != head;
+    if (!pre || !__all(!pushed || (f_np == n_end && f_na == n_end))) return 0;
+
+    uint64_t e = end, ne = n_end, li = last_idx, hd = head, tl = tail, sc = store_count;
+    uint32_t head_round = 0;
+    uint64_t my_apoff = apoff;
+    if (tick) {
+        /* log_pruning: the offset that lags most (largest distance to end); a server that is OFF counts as apply */
+        const bool in_grp = lane < size;
+        const bool on = in_grp && ((bitmask >> lane) & 1u);
+        if (in_grp && !on) my_apoff = apply;
+        const uint64_t dist = in_grp ? apus_end_distance(e, L, my_apoff) : 0;
+        uint64_t D = wave_max_u64(dist);
+        const uint64_t d_apply = apus_end_distance(e, L, apply);
+        if (d_apply > D) D = d_apply;
+        uint64_t min_off = (D <= e) ? e - D : e + L - D;
+        if (D == 0) min_off = tl;                                        /* leave one entry, :2038-2041 */
+        if (apus_is_larger(e, L, min_off, hd) && !prev_head) {
+            hd = min_off;                                                /* <HEAD, head>: 64 bytes at end (no wrap: pre) */
+            tl = e; e += APUS_HDR; ne += 1; li += 1; sc += 1; head_round = 1;
+        }
+        /* rc_get_remote_apply_offsets for the next tick (sample_into_copy) */
+        if (in_grp) { if (lane == leader || !on) my_apoff = apply; else if (pushed) my_apoff = f_apply; }
+    }
+    if (e == L) return 0;            /* the <HEAD> entry ended exactly on len: the log reads as empty, general path */
+    const uint64_t e0 = e, idx0 = li + 1, n_end0 = ne;
+    /* where the batch wraps, if it does (log_append_entry's two wrap rules, dare_log.h:502-538; what
+     * seq_body's block-wide scan finds): the round whose bytes cross len, by a 64-ary search of the
+     * staged byte prefix, then the entry inside it */
+    int64_t kstar = -1, estar = -1;
+    uint64_t w = 0;
+    uint32_t stale = 0;
+    if (e0 + vtot > L || (e0 + vtot == L)) {
+        if (e0 + vtot == L) return 0;                                    /* ends exactly on len: hidden round, general path */
+        const uint64_t *pf = E.round_prefix + r0;
+        const uint64_t p0 = q.pfx[0];
+        const uint32_t step = (R + WAVE - 1) / WAVE;                     /* <= 16 */
+        const uint32_t ra = min(R, lane * step);
+        const uint64_t va = gld(&pf[ra]) - p0;
+        const uint32_t blk = (uint32_t)__popcll(__ballot(ra < R && e0 + va <= L)) - 1u;   /* monotone: a prefix of lanes */
+        const uint32_t rb = blk * step + lane;
+        const bool inb = lane <= step && rb <= R;
+        const uint64_t vb = inb ? gld(&pf[rb]) - p0 : ~0ull;
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(inb && rb < R && e0 + vb <= L));
+        const uint32_t rstar = blk * step + cnt - 1u;                    /* last round that starts at or before len */
+        const uint64_t vstar = __shfl(vb, (int)(cnt - 1u), WAVE);
+        const uint32_t g_lo = gld(&E.round_first[r0 + rstar]), g_hi = gld(&E.round_first[r0 + rstar + 1]);
+        const uint32_t g0 = q.rfx[0];
+        const bool act = lane < g_hi - g_lo;
+        const uint64_t Te = act ? APUS_HDR + (uint64_t)gld(&E.req_len[g_lo + lane]) : 0;
+        const uint64_t a = e0 + vstar + wave_incl_scan(Te) - Te;
+        const unsigned long long hit = __ballot(act && a + Te > L);
+        if (!hit) return 0;                                              /* (cannot happen: the totals say it wraps) */
+        const int hl = __builtin_ctzll(hit);
+        const uint64_t aw = __shfl(a, hl, WAVE);
+        kstar = (int64_t)(g_lo - g0) + hl; w = aw;
+        if (aw == L) estar = kstar;                                      /* empty encoding: idx restarts, dare_log.h:486-488 */
+        else if (L - aw >= APUS_HDR) stale = 1;                          /* header fitted, payload did not, :521-537 */
+        if (e0 + vtot - w >= L) return 0;                                /* a second wrap, or the batch ends on len: general path */
+    }
+    const uint64_t end_new = (kstar < 0) ? e0 + vtot : e0 + vtot - w;
+    if (lane == 0) {
+        q.lh[H_END] = end_new; q.lh[H_TAIL] = end_new - (APUS_HDR + len_last); q.lh[H_N_END] = n_end0 + n;
+        q.lh[H_LAST_IDX] = (estar < 0) ? idx0 + n - 1 : 1 + (uint64_t)(n - 1 - estar); q.lh[H_PREV_HEAD] = 0; q.lh[H_OLD_END] = end_new;
+        q.lh[H_N_PERSIST] = n_end0 + n; q.lh[H_STORE_COUNT] = sc + n; q.lh[H_HEAD] = hd;
+        SeqOut &s = q.out;
+        s.e0 = e0; s.idx0 = idx0; s.w = w; s.n_end0 = n_end0; s.term = sid >> 9; s.kstar = kstar; s.estar = estar; s.stale = stale;
+        s.n = n; s.head_round = head_round; s.pad0 = 0; s.first_fail = ~0ull; s.commit_before = commit; s.n_commit_before = n_commit;
+        s.vis = n_end0 + n; s.scan_lo = n_commit; s.fuse_mask = push_mask; s.tail_needed = 0; s.fast = 1; s.pad1 = 0; s.rec_base = rec_base;
+        q.end_new = end_new; q.my_virt = q.pfx[1] - q.pfx[0]; q.ok = 1;
+    }
+    if (srv) { q.out.np[lane] = ~0ull; if (tick && lane < size) q.lh[H_APPLY_OFFSETS + lane] = my_apoff; }
+    return 1;
+}
+
+/* The effects of a segment that chain_decide_fast sequenced -- what the sequencer block does
+ * with FX = true (seq_w0_decide<true>: the leader's live control words, the sampled apply
+ * offsets, a due prune tick's <HEAD> entry pushed to every replica, SeqOut) -- by the chain
+ * block's first wavefront, from the post-call state in q: the sequencers of in-step segments
+ * have nothing left to do (they used to form a second serial chain through memory, ~12 us per
+ * segment, that the launch could not end before). */
+__device__ static inline void chain_effects_fast(const EngDev &E, uint32_t push_mask, uint32_t tick, const SeqLds &q)
+{
+    const uint32_t lane = lane_id();
+    const RepDev &Ld = E.rep[E.leader];
+    uint64_t *hdr = Ld.hdr;
+    const uint64_t L = E.log_len;
+    const SeqOut &s = q.out;
+    if (lane == 0) {
+        gst(&hdr[H_END], (uint64_t)(q.lh[H_END])); gst(&hdr[H_TAIL], (uint64_t)(q.lh[H_TAIL])); gst(&hdr[H_N_END], (uint64_t)(q.lh[H_N_END])); gst(&hdr[H_LAST_IDX], (uint64_t)(q.lh[H_LAST_IDX]));
+        gst(&hdr[H_PREV_HEAD], (uint64_t)(0)); gst(&hdr[H_OLD_END], (uint64_t)(q.lh[H_OLD_END])); gst(&hdr[H_N_PERSIST], (uint64_t)(q.lh[H_N_PERSIST]));
+        gst(&hdr[H_STORE_COUNT], (uint64_t)(q.lh[H_STORE_COUNT]));
+        /* free space: the reference only notices end == head exactly (dare_log.h:168) */
+        const uint64_t head = q.lh[H_HEAD], e0 = s.e0;
+        const uint64_t used = e0 >= head ? e0 - head : L - (head - e0);
+        const uint64_t vt = (s.kstar >= 0) ? q.end_new + s.w - e0 : q.end_new - e0, waste = (s.kstar >= 0) ? L - s.w : 0;
+        if (s.n && vt + waste >= L - used) set_status(E, 1u << 1);
+    }
+    if (tick && lane < E.group_size) gst(&hdr[H_APPLY_OFFSETS + lane], (uint64_t)(q.lh[H_APPLY_OFFSETS + lane]));
+    if (s.head_round) {
+        /* <HEAD, head> right in front of the batch (log_append_entry of a 64-byte entry; everybody is in
+         * step: pushed with its reply bytes, committed and applied as it lands) */
+        const uint64_t pos = s.e0 - APUS_HDR, idx = s.idx0 - 1, slot = s.n_end0 - 1, hv = q.lh[H_HEAD], term = s.term;
+        const uint32_t di = (uint32_t)slot & E.dir_mask, fuse = s.fuse_mask;
+        if (lane == 0) { gst(&hdr[H_HEAD], (uint64_t)(hv)); if (s.rec_base < E.rec_cap) gst(&E.rec_end[s.rec_base], (uint64_t)s.e0); }
+        if (lane < APUS_DEV_MAX_SERVERS && (((push_mask | (1u << E.leader)) >> lane) & 1u)) {
+            const RepDev &Rd = E.rep[lane];
+            const ReplyWords rw = apus_reply_words(lane == E.leader ? fuse : (fuse & (1u << lane)));
+            uint8_t *rg = Rd.ring;
+            st16u(rg + pos, make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)term, (uint32_t)(term >> 32)));
+            st16u(rg + pos + 16, make_uint4(0, 0, (3u << 16) | ((uint32_t)E.leader << 24), rw.w28));
+            st16u(rg + pos + 32, make_uint4(rw.x32, rw.y36, rw.z40, 0));
+            st16u(rg + pos + 48, make_uint4((uint32_t)hv, (uint32_t)(hv >> 32), 0, 0));
+            gst(&Rd.dir_off[di], pos); gst(&Rd.dir_len[di], (uint32_t)(APUS_HDR | ((uint32_t)E.leader << 24)));
+            uint8_t *rp = (uint8_t *)&Rd.apply[di];
+            st16u(rp, make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32)));
+            st16u(rp + 16, make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), 0, 3u << 16));
+            if (lane == E.leader) __hip_atomic_store(&Ld.ack[di], fuse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (lane < sizeof(SeqOut) / 8) gst(&((uint64_t *)E.seq)[lane], ((const uint64_t *)&q.out)[lane]);
+}
+
 /* a block of k_call works the call's SeqOut out for itself: wave 0's variant, or the block-wide
  * scan when the batch could reach len; posts its "inputs fetched" ticket on tick line read_line */
 __device__ static inline void seq_local(const EngDev &E, const CallEnv &X, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t tick,
@@ -668,6 +833,83 @@ __device__ static inline void seq_local(const EngDev &E, const CallEnv &X, uint6
         for (uint32_t i = tid; i < R && i < 1024; i += blockDim.x) q.bytes0[i] = rb[i];
         __syncthreads();
         seq_body<false>(E, r0, R, push_mask, tick, push_mask, q, my_r);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Multi-segment launches: the sequencing RECORD of a segment.  The chain block (segment 0's
+ * bookkeeper, which keeps every segment's books) works the call's SeqOut out once and publishes
+ * what an append block needs of it as ten self-tagged 8-byte granules {data, tag} in uncached
+ * memory -- no flag, no fence, no drain on the writer's side (MI355X_MICROARCH.md, hand-off by
+ * data-tagged granules); the append blocks poll the granules instead of staging 100+ control
+ * words and repeating the single-lane sequencing themselves.  ok = 0 (the batch could reach the
+ * end of the ring): the block falls back to the block-wide scan on snapshot `seg`.
+ * The records are cleared by the launch's last janitor, so a stale record never matches. */
+__device__ static inline void wait_count(const EngDev &E, const uint32_t *lines32, uint32_t b, uint32_t want);
+#define REC_WORDS   16
+#ifndef APUS_REC_SLEEP
+#define APUS_REC_SLEEP 2        /* x 64 clocks between two polls of a segment's record */
+#endif
+#define REC_GRAN    14
+#define REC_TAG(seg) (0x5E000000u | ((seg) + 1u))
+enum { RECF_FAST = 1u << 13, RECF_OK = 1u << 14, RECF_HEAD = 1u << 15, RECF_CHAIN = 1u << 16, RECF_STALE = 1u << 17, RECF_ESTAR = 1u << 18 };   /* CHAIN: the chain block does the sequencer's effects */
+
+__device__ static inline void rec_store(uint64_t *rec, uint32_t g, uint32_t data, uint32_t tag)
+{
+    __hip_atomic_store((APUS_GLOBAL unsigned long long *)(uintptr_t)&rec[g], ((unsigned long long)tag << 32) | data, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+/* lanes 0 .. REC_GRAN-1 of the calling wave publish segment seg's record from q.out / q.ok */
+__device__ static inline void rec_publish(const EngDev &E, uint32_t seg, const SeqLds &q, bool chain_did)
+{
+    const uint32_t lane = lane_id();
+    if (lane >= REC_GRAN) return;
+    const SeqOut &s = q.out;
+    const uint32_t ok = q.ok ? 1u : 0u;
+    uint64_t v = 0;
+    switch (lane >> 1) {
+    case 0: v = s.e0; break;
+    case 1: v = s.idx0; break;
+    case 2: v = s.n_end0; break;
+    case 3: v = s.term; break;
+    case 4: v = (uint64_t)((ok ? (s.fuse_mask & 0x1FFFu) | (s.fast ? RECF_FAST : 0u) | (s.head_round ? RECF_HEAD : 0u) | RECF_OK |
+                                 (s.stale ? RECF_STALE : 0u) | (s.estar >= 0 ? RECF_ESTAR : 0u) : 0u) | (chain_did ? RECF_CHAIN : 0u))
+               | ((uint64_t)(ok ? s.n : 0u) << 32);
+            break;
+    case 5: v = (uint64_t)s.kstar; break;          /* -1: the batch does not wrap */
+    default: v = s.w; break;
+    }
+    rec_store(E.step_rec + (size_t)seg * REC_WORDS, lane, (uint32_t)(lane & 1 ? v >> 32 : v), REC_TAG(seg));
+}
+/* wave-wide: poll segment seg's record, fill the SeqOut fields an append block uses (q.out, q.ok);
+ * bounded like every spin of the engine */
+__device__ static inline void rec_wait(const EngDev &E, uint32_t seg, SeqLds &q)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t *rec = E.step_rec + (size_t)seg * REC_WORDS;
+    const uint32_t tag = REC_TAG(seg);
+    uint64_t v = 0;
+    unsigned long long spins = 0;
+    for (;;) {
+        if (lane < REC_GRAN) v = ldw(&rec[lane]);
+        if (__all(lane >= REC_GRAN || (uint32_t)(v >> 32) == tag)) break;
+        __builtin_amdgcn_s_sleep(APUS_REC_SLEEP);
+        if (++spins > (1ull << 22)) { if (lane == 0) set_status(E, 1u << 4); break; }      /* bounded */
+    }
+    const uint32_t d = (uint32_t)v;
+    const uint64_t e0 = (uint64_t)__shfl(d, 0, WAVE) | ((uint64_t)__shfl(d, 1, WAVE) << 32);
+    const uint64_t idx0 = (uint64_t)__shfl(d, 2, WAVE) | ((uint64_t)__shfl(d, 3, WAVE) << 32);
+    const uint64_t n_end0 = (uint64_t)__shfl(d, 4, WAVE) | ((uint64_t)__shfl(d, 5, WAVE) << 32);
+    const uint64_t term = (uint64_t)__shfl(d, 6, WAVE) | ((uint64_t)__shfl(d, 7, WAVE) << 32);
+    const uint32_t flags = __shfl(d, 8, WAVE), n = __shfl(d, 9, WAVE);
+    const uint64_t kst = (uint64_t)__shfl(d, 10, WAVE) | ((uint64_t)__shfl(d, 11, WAVE) << 32);
+    const uint64_t wv_ = (uint64_t)__shfl(d, 12, WAVE) | ((uint64_t)__shfl(d, 13, WAVE) << 32);
+    if (lane == 0) {
+        SeqOut &s = q.out;
+        s.e0 = e0; s.idx0 = idx0; s.w = wv_; s.n_end0 = n_end0; s.term = term; s.kstar = (int64_t)kst;
+        s.estar = (flags & RECF_ESTAR) ? (int64_t)kst : -1; s.stale = (flags & RECF_STALE) ? 1u : 0u;
+        s.n = n; s.head_round = (flags & RECF_HEAD) ? 1u : 0u; s.fuse_mask = flags & 0x1FFFu; s.fast = (flags & RECF_FAST) ? 1u : 0u;
+        q.ok = (flags & RECF_OK) ? 1u : 0u;
+        q.chain_did = (flags & RECF_CHAIN) ? 1u : 0u;
     }
 }
 
@@ -723,7 +965,7 @@ __device__ static inline uint32_t wait_sequenced(const EngDev &E, const CallEnv 
 template <bool IN_LAUNCH>
 __device__ static inline void append_round(const EngDev &E, const CallEnv &X, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t r,
                                            AppendLds &lds, SeqLds *sq, uint32_t tick, uint32_t slice = 0, uint32_t n_slices = 1,
-                                           const uint64_t *snap = nullptr, bool post_read = true)
+                                           const uint64_t *snap = nullptr, bool post_read = true, int rec_seg = -1)
 {
     const uint32_t tid = threadIdx.x, lane = lane_id();
     const RepDev &Ld = E.rep[E.leader];
@@ -738,7 +980,9 @@ __device__ static inline void append_round(const EngDev &E, const CallEnv &X, ui
     uint32_t T = 0;
     uint64_t incl = 0;
     if (tid < WAVE && active) d = E.req[g0 + first + lane];
-    if (IN_LAUNCH) {
+    uint64_t pfx_r = 0, pfx_0 = 0;
+    if (IN_LAUNCH && rec_seg >= 0 && tid < WAVE) { pfx_r = E.round_prefix[r0 + r]; pfx_0 = E.round_prefix[r0]; }
+    if (IN_LAUNCH && rec_seg < 0) {
         if (tid < WAVE) {
             /* the sequencer's inputs, in the same round trip as the descriptors; once they are in LDS
              * the sequencer block may start changing the control words (it waits for these tickets) */
@@ -790,6 +1034,21 @@ __device__ static inline void append_round(const EngDev &E, const CallEnv &X, ui
      * block's, while the payload loads are in flight -- nobody waits for the sequencer */
     if (r == 0) STAMP(1, 4);
     if (IN_LAUNCH) {
+        if (rec_seg >= 0) {            /* a segment of a multi-segment launch: the SeqOut comes from its record */
+            if (tid < WAVE) {
+                rec_wait(E, (uint32_t)rec_seg, *sq);
+                if (tid == 0) { sq->pfx[0] = pfx_0; sq->my_virt = pfx_r - pfx_0; }
+            }
+            __syncthreads();
+            if (!sq->ok) {             /* the block-wide path, on snapshot rec_seg */
+                if (rec_seg > 0) wait_count(E, E.step_epoch, r, (uint32_t)rec_seg);
+                __syncthreads();
+                if (tid < WAVE) seq_w0_stage(E, r0, R, push_mask, r, *sq, E.step_snap + (size_t)rec_seg * SNAP_STRIDE);
+                __syncthreads();
+                if (tid == 0) seq_w0_decide<false, true>(E, push_mask, tick, *sq);
+                __syncthreads();
+            }
+        }
         if (!sq->ok) {                 /* the batch could reach len: the block-wide scan, on the inputs staged above */
             const uint32_t *rb = E.round_bytes + r0;
             for (uint32_t i = tid; i < R && i < 1024; i += blockDim.x) sq->bytes0[i] = rb[i];
@@ -951,35 +1210,48 @@ struct GroupLds {
     uint32_t tail[APUS_GP][WAVE];         /* clt_id | type << 16 | sender << 24 */
     uint32_t T[APUS_GP][WAVE];
     uint32_t ubase[APUS_GP][WAVE + 1];
+    /* the replicas a unit is stored to (leader first), with the reply words their copy carries */
+    uint8_t *tgt_ring[APUS_GP][APUS_DEV_MAX_SERVERS];
+    uint4    tgt_rw[APUS_GP][APUS_DEV_MAX_SERVERS];        /* {w28, x32, y36, z40} */
 };
 
+/* rec_seg >= 0: a segment of a multi-segment launch -- the SeqOut comes from the segment's record
+ * (rec_wait); rec_seg < 0: k_call -- the block stages the control words and sequences for itself */
 __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X, uint64_t r0, uint32_t R, uint32_t push_mask,
                                                uint32_t grp, GroupLds &gl, SeqLds *sq, uint32_t tick,
-                                               const uint64_t *snap, bool post_read)
+                                               const uint64_t *snap, bool post_read, int rec_seg)
 {
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const RepDev &Ld = E.rep[E.leader];
     const uint32_t *rf = E.round_first + r0;
     const uint32_t r = grp * APUS_GP + wv;
     const bool has = r < R;
-    const uint32_t g0 = rf[0];
-    const uint32_t first = has ? rf[r] - g0 : 0, nr = has ? rf[r + 1] - rf[r] : 0;
-    const uint64_t pfx_r = has ? E.round_prefix[r0 + r] : 0;
+    const uint32_t g0 = gld(&rf[0]);
+    const uint32_t first = has ? gld(&rf[r]) - g0 : 0, nr = has ? gld(&rf[r + 1]) - gld(&rf[r]) : 0;
+    const uint64_t pfx_r = has ? gld(&E.round_prefix[r0 + r]) : 0;
+    const uint64_t pfx_0 = gld(&E.round_prefix[r0]);
+    const uint32_t n_grp = (R + APUS_GP - 1) / APUS_GP;
+    if (rec_seg >= 0 && rec_seg < 64) { if (grp == 0) STAMPN(10, rec_seg); if (grp + 1 == n_grp) STAMPN(14, rec_seg); }
 
     /* ---- round trip 1 ---- */
     const bool active = lane < nr;
     ReqDev d; d.req_id = 0; d.pay16_type = 0; d.len = 0; d.clt_id = 0;
-    if (active) d = E.req[g0 + first + lane];
-    if (wv == 0) {
-        seq_w0_stage(E, r0, R, push_mask, grp * APUS_GP, *sq, snap);
-        if (tid == 0 && post_read) __hip_atomic_fetch_add(X.lines + (grp & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (active) {
+        const uint4 dv = ld16u((const uint8_t *)&E.req[g0 + first + lane]);
+        d.req_id = (uint64_t)dv.x | ((uint64_t)dv.y << 32); d.pay16_type = dv.z; d.len = (uint16_t)dv.w; d.clt_id = (uint16_t)(dv.w >> 16);
     }
-    if (grp == 0) STAMP(8, 0);
-    __syncthreads();
-    if (grp == 0) STAMP(8, 1);
-    /* one lane of wave 1 works the call's SeqOut out while the waves lay their rounds out */
-    if (tid == WAVE) seq_w0_decide<false, true>(E, push_mask, tick, *sq);
-    if (grp == 0) STAMPW(8, 7, WAVE);
+    if (rec_seg < 0) {
+        if (wv == 0) {
+            seq_w0_stage(E, r0, R, push_mask, grp * APUS_GP, *sq, snap);
+            if (tid == 0 && post_read) __hip_atomic_fetch_add(X.lines + (grp & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (grp == 0) STAMP(8, 0);
+        __syncthreads();
+        if (grp == 0) STAMP(8, 1);
+        /* one lane of wave 1 works the call's SeqOut out while the waves lay their rounds out */
+        if (tid == WAVE) seq_w0_decide<false, true>(E, push_mask, tick, *sq);
+        if (grp == 0) STAMPW(8, 7, WAVE);
+    } else if (grp == 0) STAMP(8, 0);
 
     /* ---- layout of this wave's round (registers + wave scans) ---- */
     const uint32_t T = active ? APUS_HDR + d.len : 0;
@@ -997,9 +1269,10 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
     __builtin_amdgcn_wave_barrier();          /* LDS is in order within a wave; keep the compiler from reordering */
 
     /* which entry of the round owns 16-byte unit u, at which byte offset of the entry */
+    const uint32_t unu_magic = unu > 1 ? (uint32_t)((1ull << 32) / unu + 1) : 0;   /* u / unu = mulhi(u, magic) for u < 64 * 261 */
     auto unit_of = [&](uint32_t u, uint32_t &e, uint32_t &so, uint32_t &Te) {
         uint32_t j;
-        if (unu) { e = u / unu; j = u - e * unu; }
+        if (unu) { e = unu > 1 ? __umulhi(u, unu_magic) : u; j = u - e * unu; }
         else {
             uint32_t lo = 0, hi = nr - 1;               /* largest e with ubase[e] <= u */
             while (lo < hi) {
@@ -1026,14 +1299,31 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
         }
     }
     if (grp == 0) STAMP(8, 2);
+    if (rec_seg >= 0 && wv == 0) {            /* the segment's record: normally there by now */
+        rec_wait(E, (uint32_t)rec_seg, *sq);
+        if (lane == 0) sq->pfx[0] = pfx_0;
+    }
     __syncthreads();                          /* the SeqOut is in sq->out (or sq->ok == 0) */
     if (grp == 0) STAMP(8, 3);
-    if (!sq->ok) {                            /* the batch could reach len: the block-wide scan, on the inputs staged above */
-        const uint32_t *rb = E.round_bytes + r0;
-        for (uint32_t i = tid; i < R && i < 1024; i += blockDim.x) sq->bytes0[i] = rb[i];
-        __syncthreads();
-        seq_body<false>(E, r0, R, push_mask, tick, push_mask, *sq, grp * APUS_GP);
-        __syncthreads();
+    if (rec_seg >= 0 && rec_seg < 64 && grp == 0) STAMPN(11, rec_seg);
+    if (!sq->ok) {                            /* the batch could reach len: the block-wide scan */
+        if (rec_seg >= 0) {
+            /* on snapshot rec_seg (the state before this segment): complete once the epoch says so
+             * (segment 0's was written before its record) */
+            if (rec_seg > 0) wait_count(E, E.step_epoch, grp, (uint32_t)rec_seg);
+            __syncthreads();
+            if (tid < WAVE) seq_w0_stage(E, r0, R, push_mask, grp * APUS_GP, *sq, E.step_snap + (size_t)rec_seg * SNAP_STRIDE);
+            __syncthreads();
+            if (tid == 0) seq_w0_decide<false, true>(E, push_mask, tick, *sq);
+            __syncthreads();
+        }
+        if (!sq->ok) {
+            const uint32_t *rb = E.round_bytes + r0;
+            for (uint32_t i = tid; i < R && i < 1024; i += blockDim.x) sq->bytes0[i] = rb[i];
+            __syncthreads();
+            seq_body<false>(E, r0, R, push_mask, tick, push_mask, *sq, grp * APUS_GP);
+            __syncthreads();
+        }
     }
 
     /* ---- where the entries go (lane = entry) ---- */
@@ -1053,10 +1343,10 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
         if (active) {
             const uint32_t di = (uint32_t)slot & E.dir_mask;
             const uint32_t dl = T | ((uint32_t)E.leader << 24);     /* derived: total bytes | sender << 24 */
-            Ld.dir_off[di] = pos; Ld.dir_len[di] = dl; Ld.ack[di] = fuse;             /* ACK bits of the fused followers */
+            gst(&Ld.dir_off[di], pos); gst(&Ld.dir_len[di], dl); gst(&Ld.ack[di], fuse);     /* ACK bits of the fused followers */
             for (uint32_t m = push_mask; m; m &= m - 1) {
                 const RepDev &Fd = E.rep[__builtin_ctz(m)];
-                Fd.dir_off[di] = pos; Fd.dir_len[di] = dl;
+                gst(&Fd.dir_off[di], pos); gst(&Fd.dir_len[di], dl);
             }
             if (s.stale && gk == s.kstar) {
                 /* the header log_append_entry wrote before it found out that the payload does
@@ -1072,10 +1362,76 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
                 }
             }
         }
+        /* the wave's target table: lane t < 13 = replica t, the leader first */
+        if (lane < APUS_DEV_MAX_SERVERS && (((push_mask | (1u << E.leader)) >> lane) & 1u)) {
+            const uint32_t at = lane == E.leader ? 0u : 1u + (uint32_t)__popc(push_mask & ~(1u << E.leader) & ((1u << lane) - 1u));
+            const ReplyWords rw = apus_reply_words(lane == E.leader ? fuse : (fuse & (1u << lane)));
+            gl.tgt_ring[wv][at] = E.rep[lane].ring;
+            gl.tgt_rw[wv][at] = make_uint4(rw.w28, rw.x32, rw.y36, rw.z40);
+        }
         __builtin_amdgcn_wave_barrier();
         if (grp == 0) STAMP(8, 4);
 
         /* ---- the round's bytes: lane l stores units l, l + 64, ... ---- */
+        if (unu && sq->ok && sq->out.kstar < 0) {
+            /* Entries of one size, no wrap inside the batch: everything about unit u follows from
+             * arithmetic -- entry e = u / unu (multiply-high), its position a_r + e * T, its index
+             * idx_r + e -- and ONE straight-line store sequence per target replica: the value is
+             * selected, not branched on (header words, the reply words of this replica's copy, or
+             * payload).  The general path below runs every divergent case of the wave one after the
+             * other, ~500 VALU instructions per unit; with 12 wavefronts per CU the append blocks were
+             * bound by instruction issue (~10 us per block), not by HBM (tools/timeline_probe.py). */
+            const uint32_t magic = unu_magic;
+            const uint32_t Tu = T0;
+            const uint64_t a_r = __shfl(a, 0, WAVE);                     /* where the round's first entry goes */
+            const uint64_t idx_r = __shfl(idx, 0, WAVE);
+            const uint32_t n_tgt = 1u + (uint32_t)__popc(push_mask & ~(1u << E.leader));
+            auto fast_unit = [&](uint32_t u, uint4 pay) {
+                const uint32_t e = unu > 1 ? __umulhi(u, magic) : u;
+                const uint32_t j = u - e * unu;
+                const uint32_t so = min(16u * j, Tu - 16u);
+                const uint64_t p = a_r + (uint64_t)e * Tu + so;
+                const uint64_t ix = idx_r + e, rq = gl.req[wv][e];
+                const uint32_t tl = gl.tail[wv][e];
+                uint4 v = pay;
+                if (so == 0) v = make_uint4((uint32_t)ix, (uint32_t)(ix >> 32), (uint32_t)term, (uint32_t)(term >> 32));
+                if (so == 16) v = make_uint4((uint32_t)rq, (uint32_t)(rq >> 32), tl, 0);
+                if (so == 32) v = make_uint4(0, 0, 0, 0);
+                const bool r16 = fuse && so == 16, r32 = fuse && so == 32;
+                for (uint32_t t = 0; t < n_tgt; t++) {
+                    const uint4 rw = gl.tgt_rw[wv][t];
+                    uint4 vt = v;
+                    if (r16) vt.w = rw.x;
+                    if (r32) vt = make_uint4(rw.y, rw.z, rw.w, 0);
+                    st16u(gl.tgt_ring[wv][t] + p, vt);
+                }
+            };
+            auto fast_pay = [&](uint32_t u) -> uint4 {
+                const uint32_t e = unu > 1 ? __umulhi(u, magic) : u;
+                const uint32_t j = u - e * unu;
+                const uint32_t so = min(16u * j, Tu - 16u);
+                uint4 pay = make_uint4(0, 0, 0, 0);
+                if (so >= 48) pay = payload_unit(E.arena + gl.src[wv][e], so, Tu - APUS_HDR, Tu - APUS_HDR);
+                return pay;
+            };
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const uint32_t u = lane + (uint32_t)k * WAVE;
+                if (u < uall) fast_unit(u, pv[k]);
+            }
+            for (uint32_t ub = PF * WAVE; ub < uall; ub += PF * WAVE) {
+#pragma unroll
+                for (int k = 0; k < PF; k++) {
+                    const uint32_t u = ub + lane + (uint32_t)k * WAVE;
+                    pv[k] = (u < uall) ? fast_pay(u) : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < PF; k++) {
+                    const uint32_t u = ub + lane + (uint32_t)k * WAVE;
+                    if (u < uall) fast_unit(u, pv[k]);
+                }
+            }
+        } else {
         const ReplyWords rwl = apus_reply_words(fuse);
         auto store_unit = [&](uint32_t e, uint32_t so, uint4 v) {
             const uint64_t p = gl.pos[wv][e] + so;
@@ -1107,14 +1463,30 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
                 store_unit(e, so, header_or(e, so, pv[k]));
             }
         }
-        for (uint32_t u = lane + PF * WAVE; u < uall; u += WAVE) {
-            uint32_t e, so, Te;
-            unit_of(u, e, so, Te);
-            uint4 pay = make_uint4(0, 0, 0, 0);
-            if (so >= 48) pay = payload_unit(E.arena + gl.src[wv][e], so, Te - APUS_HDR, Te - APUS_HDR);
-            store_unit(e, so, header_or(e, so, pay));
+        /* the rest of the round in batches of PF units per lane: all loads of a batch are issued
+         * before its first store (one load latency per batch, not per unit) */
+        for (uint32_t ub = PF * WAVE; ub < uall; ub += PF * WAVE) {
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                pv[k] = make_uint4(0, 0, 0, 0);
+                const uint32_t u = ub + lane + (uint32_t)k * WAVE;
+                if (u < uall) {
+                    uint32_t e, so, Te;
+                    unit_of(u, e, so, Te);
+                    if (so >= 48) pv[k] = payload_unit(E.arena + gl.src[wv][e], so, Te - APUS_HDR, Te - APUS_HDR);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const uint32_t u = ub + lane + (uint32_t)k * WAVE;
+                if (u < uall) {
+                    uint32_t e, so, Te;
+                    unit_of(u, e, so, Te);
+                    store_unit(e, so, header_or(e, so, pv[k]));
+                }
+            }
         }
-
+        }
         if (grp == 0) STAMP(8, 5);
         /* ---- in step: apply_committed_entries for the round, from the registers that built it
          * (leader kind 1: proxy_update_state, fused followers kind 2: proxy_do_action) ---- */
@@ -1125,11 +1497,11 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
                 const uint32_t t24 = tail & 0x00FFFFFFu;                      /* clt_id | type << 16 */
                 const uint32_t di = (uint32_t)slot & E.dir_mask;
                 const uint4 r0v = make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32));
-                uint4 *rp = (uint4 *)&Ld.apply[di];
-                rp[0] = r0v; rp[1] = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), len, t24 | (1u << 24));
+                uint8_t *rp = (uint8_t *)&Ld.apply[di];
+                st16u(rp, r0v); st16u(rp + 16, make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), len, t24 | (1u << 24)));
                 for (uint32_t m = fuse; m; m &= m - 1) {
-                    uint4 *fp = (uint4 *)&E.rep[__builtin_ctz(m)].apply[di];
-                    fp[0] = r0v; fp[1] = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), len, t24 | (2u << 24));
+                    uint8_t *fp = (uint8_t *)&E.rep[__builtin_ctz(m)].apply[di];
+                    st16u(fp, r0v); st16u(fp + 16, make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), len, t24 | (2u << 24)));
                 }
                 mix1 = apus_apply_mix(slot, pos, idx, len, (uint16_t)t24, (uint8_t)(t24 >> 16), 1);
                 mix2 = apus_apply_mix(slot, pos, idx, len, (uint16_t)t24, (uint8_t)(t24 >> 16), 2);
@@ -1141,6 +1513,7 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
             }
         }
         if (grp == 0) STAMP(8, 6);
+        if (rec_seg >= 0 && rec_seg < 64 && grp + 1 == n_grp) { STAMPN(12, rec_seg); STAMP(13, rec_seg); }
     }
     return fast;
 }
@@ -1609,15 +1982,15 @@ __device__ static inline void keeper_publish(const EngDev &E, ApplyCtx &c, uint3
     if (tid == 0) {
         if (mode == 0) {
             c.rec_base = c.rec_base + R + s.head_round;
-            *E.rec_count = c.rec_base;
+            gst(E.rec_count, (uint64_t)c.rec_base);
         } else if (mode == 1 && s.n) {
             if (c.rec_base < E.rec_cap) E.rec_commit[c.rec_base] = (end_l == L) ? s.commit_before : commit_off;
             c.rec_base = c.rec_base + 1;
-            *E.rec_count = c.rec_base;
+            gst(E.rec_count, (uint64_t)c.rec_base);
         }
-        lh[H_N_VISIBLE] = vis; c.lh[H_N_VISIBLE] = vis;
-        if (cs > s.n_commit_before) { lh[H_COMMIT] = commit_off; lh[H_N_COMMIT] = cs; c.lh[H_COMMIT] = commit_off; c.lh[H_N_COMMIT] = cs; }
-        if (cs > c.lh[H_N_APPLY]) { lh[H_APPLY] = c.off_cs; lh[H_N_APPLY] = cs; c.lh[H_APPLY] = c.off_cs; c.lh[H_N_APPLY] = cs; }
+        gst(&lh[H_N_VISIBLE], (uint64_t)(vis)); c.lh[H_N_VISIBLE] = vis;
+        if (cs > s.n_commit_before) { gst(&lh[H_COMMIT], (uint64_t)(commit_off)); gst(&lh[H_N_COMMIT], (uint64_t)(cs)); c.lh[H_COMMIT] = commit_off; c.lh[H_N_COMMIT] = cs; }
+        if (cs > c.lh[H_N_APPLY]) { gst(&lh[H_APPLY], (uint64_t)(c.off_cs)); gst(&lh[H_N_APPLY], (uint64_t)(cs)); c.lh[H_APPLY] = c.off_cs; c.lh[H_N_APPLY] = cs; }
         if (mode == 0 && s.fast) {
             /* the append blocks applied the batch (every entry a client entry): one upcall each */
             atomicAdd((unsigned long long *)&lh[H_APPLY_COUNT], (unsigned long long)s.n);
@@ -1638,31 +2011,31 @@ __device__ static inline void keeper_publish(const EngDev &E, ApplyCtx &c, uint3
                               : __hip_atomic_load((unsigned long long *)&fh[H_HEAD_SLOT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint64_t end_now = f_end;
             if (vis > f_np) {
-                fh[H_STORE_COUNT] = f_sc + (vis - f_np);
-                fh[H_END] = c.off_vis; fh[H_OLD_END] = c.off_vis;
-                fh[H_N_END] = vis; fh[H_N_PERSIST] = vis;
+                gst(&fh[H_STORE_COUNT], (uint64_t)(f_sc + (vis - f_np)));
+                gst(&fh[H_END], (uint64_t)(c.off_vis)); gst(&fh[H_OLD_END], (uint64_t)(c.off_vis));
+                gst(&fh[H_N_END], (uint64_t)(vis)); gst(&fh[H_N_PERSIST], (uint64_t)(vis));
                 w[FW_STORE_COUNT] = f_sc + (vis - f_np); w[FW_END] = c.off_vis; w[FW_N_END] = vis; w[FW_N_PERSIST] = vis;
                 end_now = c.off_vis;
             }
-            if (cs > f_nc) { fh[H_COMMIT] = c.off_cs; fh[H_N_COMMIT] = cs; w[FW_N_COMMIT] = cs; }
-            if (cs > f_na) { fh[H_APPLY] = c.off_cs; fh[H_N_APPLY] = cs; w[FW_APPLY] = c.off_cs; w[FW_N_APPLY] = cs; }
+            if (cs > f_nc) { gst(&fh[H_COMMIT], (uint64_t)(c.off_cs)); gst(&fh[H_N_COMMIT], (uint64_t)(cs)); w[FW_N_COMMIT] = cs; }
+            if (cs > f_na) { gst(&fh[H_APPLY], (uint64_t)(c.off_cs)); gst(&fh[H_N_APPLY], (uint64_t)(cs)); w[FW_APPLY] = c.off_cs; w[FW_N_APPLY] = cs; }
             if (hs) {
                 uint64_t hv = head_value;
                 if (!pure_head) {
                     const uint64_t hoff = E.rep[f].dir_off[(uint32_t)(hs - 1) & E.dir_mask];
                     hv = ld8u(E.rep[f].ring + hoff + 48);
                 }
-                if (apus_is_larger(end_now, L, hv, f_head)) { fh[H_HEAD] = hv; w[FW_HEAD] = hv; }
-                if (!pure_head) fh[H_HEAD_SLOT] = 0;
+                if (apus_is_larger(end_now, L, hv, f_head)) { gst(&fh[H_HEAD], (uint64_t)(hv)); w[FW_HEAD] = hv; }
+                if (!pure_head) gst(&fh[H_HEAD_SLOT], (uint64_t)(0));
             }
         }
     }
     if (snap_next) {
         /* the state after this call, for the next segment of the launch (write-once, uncached) */
         __syncthreads();
-        if (tid < 64) snap_next[tid] = c.lh[tid];
-        else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) snap_next[SNAP_FW + (tid - 64)] = (&c.fw[0][0])[tid - 64];
-        else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) snap_next[SNAP_REC] = c.rec_base;
+        if (tid < 64) gst(&snap_next[tid], c.lh[tid]);
+        else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) gst(&snap_next[SNAP_FW + (tid - 64)], (&c.fw[0][0])[tid - 64]);
+        else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) gst(&snap_next[SNAP_REC], (uint64_t)c.rec_base);
     }
 }
 
@@ -1902,8 +2275,10 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
     const uint32_t fmask = push_mask;
     ApplyCtx &c = l.t.c;
     const uint32_t nAB = call_append_blocks(A);                /* append blocks: SP per round, or one per GP rounds */
-    /* blocks that fetch the control words themselves: append + nR record + 1 bookkeeper */
-    const uint32_t n_readers = nAB + nR + 1;
+    /* blocks that fetch the live control words themselves: append + nR record + 1 bookkeeper; in a
+     * multi-segment launch the append blocks work from the segments' records instead */
+    const uint32_t n_readers = STEP ? nR + 1 : nAB + nR + 1;
+    const uint32_t rl_base = STEP ? 0u : nAB;             /* tick line index of the first non-append reader */
     /* blocks that sign off with T_PASS: everybody but the append blocks and the janitor */
     const uint32_t n_pass = 1 + (nR - 1) + 1 + nS + nA * ny;
     /* inputs: the live control blocks, or (later segments of a launch) the previous bookkeeper's
@@ -1914,14 +2289,16 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
 
     if (b >= 1 && b <= nAB) {                                  /* ---- append + push ---- */
         const uint32_t ab = b - 1;
-        if (!live) wait_count(E, E.step_epoch, b, seg);
+        /* (a segment of a multi-segment launch: no wait for the epoch -- the block polls the
+         * segment's sequencing record when it needs it, append_group / append_round) */
         if (b == nAB) STAMP(6, 0);
+        const int rec_seg = STEP ? (int)seg : -1;
         uint32_t fast;
         if (A.GP > 1) {
-            fast = append_group(E, X, r0, R, push_mask, ab, l.grp, &sq, tick, snap, live);
+            fast = append_group(E, X, r0, R, push_mask, ab, l.grp, &sq, tick, snap, live && !STEP, rec_seg);
         } else {
             const uint32_t r = ab / SP, slice = ab - r * SP;
-            append_round<true>(E, X, r0, R, push_mask, r, l.app, &sq, tick, slice, SP, snap, live);
+            append_round<true>(E, X, r0, R, push_mask, r, l.app, &sq, tick, slice, SP, snap, live && !STEP, rec_seg);
             fast = l.app.fast;
         }
         if (b == nAB) STAMP(6, 1);
@@ -1930,10 +2307,19 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
         return;
     }
     if (b == 0) {                                              /* ---- the sequencer ---- */
+        if (STEP) {
+            /* a segment that is in step is sequenced AND carried out by the chain block; in a
+             * multi-segment launch this block only works for the segments the chain block hands over
+             * (not in step, or the batch may wrap) -- and the chain block waits for it then, so the
+             * sequencers need no chain of their own */
+            if (tid < WAVE) rec_wait(E, seg, sq);
+            __syncthreads();
+            if (sq.chain_did) { post_ticket(E, X, T_PASS, false); return; }
+            __syncthreads();
+        }
         if (!live) wait_count(E, E.step_epoch, b, seg);
-        seq_stage(E, r0, R, push_mask, push_mask, sq, true, snap);
-        if (live) wait_readers(E, X, n_readers);               /* every reader has its copy of the inputs */
-        if (STEP && seg) wait_count(E, E.step_seq_done, b, seg);   /* the previous segment's sequencer is done */
+        seq_stage(E, r0, R, push_mask, push_mask, sq, true, STEP ? E.step_snap + (size_t)seg * SNAP_STRIDE : snap);
+        if (live) wait_readers(E, X, n_readers);               /* every reader of the live words has its copy */
         /* the common case needs no block-wide scan: one lane decides and does the effects */
         if (tid == 0) seq_w0_decide<true>(E, push_mask, tick, sq);
         __syncthreads();
@@ -1947,7 +2333,6 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
         if (!fast && tid == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   /* SeqOut, control words, <HEAD> entry */
         __syncthreads();
         if (tid < 32) __hip_atomic_store(X.lines + tid * 32 + 1, fast ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (STEP) bump_count(E.step_seq_done, seg + 1);
         post_ticket(E, X, T_PASS, false);
         return;
     }
@@ -1956,7 +2341,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
         if (q == 0) STAMP(5, 0);
         if (!live) wait_count(E, E.step_epoch, b, seg);
         /* the sequencing, worked out locally (SeqOut in sq.out) */
-        seq_local(E, X, r0, R, push_mask, tick, 0, nAB + q, sq, snap, false, live);
+        seq_local(E, X, r0, R, push_mask, tick, 0, rl_base + q, sq, snap, false, live);
         if (q == 0) STAMP(5, 1);
         /* the rounds' byte prefix: the host-staged one, or the block's own scan */
         const uint64_t *virt = sq.ok ? E.round_prefix + r0 : sq.virt;
@@ -1999,6 +2384,9 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
             if (STEP && seg + 1 == S) {
                 __hip_atomic_store(E.step_epoch + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(E.step_seq_done + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                /* and the segments' sequencing records (read first thing by every block that uses them) */
+                for (uint32_t i = tid; i < S * REC_WORDS; i += 32)
+                    __hip_atomic_store((unsigned long long *)&E.step_rec[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else if (tid == 32) {
             __hip_atomic_store(X.ticket + T_PASS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2009,35 +2397,69 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
     }
     q -= nR;
     if (q == 0) {                                              /* ---- the bookkeeper ---- */
-        /* In a multi-segment launch ONE block -- segment 0's bookkeeper -- keeps the books of every
-         * segment, one after the other: in step the state after a call follows from the state before
-         * it and the staged sizes, so segment k+1's bookkeeping starts from the LDS copy segment k's
-         * left behind (c.lh, c.fw, c.rec_base) -- no poll of the epoch, no snapshot read-back, and
-         * the epochs run ahead of the stores.  (One bookkeeper block per segment chained through
-         * memory cost ~9 us per segment: measured 10.4 / 13.5 / 15.2 / 21.3 us per call of 1 / 2 / 4 /
-         * 8 MiB, tools/seg_probe.py.)  The other segments' bookkeeper blocks just leave. */
+        /* In a multi-segment launch ONE block -- segment 0's bookkeeper, the CHAIN BLOCK -- keeps the
+         * books of every segment, one after the other.  In step the state after a call follows from
+         * the state before it and the staged sizes, so segment k+1 starts from the LDS copy segment k
+         * left behind (c.lh, c.fw, c.rec_base): no poll, no snapshot read-back.  Per segment it
+         *   1. works the call's SeqOut out (one lane) and publishes the segment's RECORD (rec_publish:
+         *      ten self-tagged granules, no drain) -- that is all the append blocks wait for;
+         *   2. does the bookkeeping (keeper_publish: live control words + snapshot k+1, issued, not
+         *      waited for);
+         * and only when it has to wait for other blocks itself (a segment that is not in step or may
+         * wrap) or at the very end does it drain its stores and raise the epoch, which the
+         * sequencers, record blocks and fallback paths of later segments wait for.  (Chained through
+         * memory the bookkeeping cost ~9 us per segment, tools/seg_probe.py / chain_probe.py.)
+         * The other segments' bookkeeper blocks just leave. */
         if (STEP && seg > 0) return;
-        STAMP(3, 0);
         const uint32_t S_ = STEP ? S : 1u;
+        __shared__ uint32_t chain_fast;                        /* this segment was sequenced by chain_decide_fast */
+        uint32_t epoch_done = 0;                               /* epochs raised so far (snapshots <= this are complete) */
+        /* every segment's staged sizes, in one round trip: bytes, first / last request, length of the last request */
+        __shared__ uint64_t pre_pfx[APUS_STEP_SEGS][2];
+        __shared__ uint32_t pre_rf[APUS_STEP_SEGS][2];
+        __shared__ uint64_t pre_last[APUS_STEP_SEGS];
+        if (STEP && TT && tid < S_) {
+            const CallArgs &Ap = TT->seg[tid];
+            const uint32_t a = E.round_first[Ap.r0], bb = E.round_first[Ap.r0 + Ap.R];
+            pre_pfx[tid][0] = E.round_prefix[Ap.r0]; pre_pfx[tid][1] = E.round_prefix[Ap.r0 + Ap.R];
+            pre_rf[tid][0] = a; pre_rf[tid][1] = bb;
+            pre_last[tid] = (bb > a) ? E.req_len[bb - 1] : 0;
+        }
         for (uint32_t k = 0; k < S_; k++) {
             const CallArgs &Ak = (STEP && TT) ? TT->seg[k] : A;
             const CallEnv Xk = (STEP && TT) ? CallEnv{E.step_lines + (size_t)k * 1024, E.step_tickets + (size_t)k * 32,
                                                       E.step_hash + (size_t)k * 2 * 1024} : X;
             const uint64_t r0k = Ak.r0;
             const uint32_t Rk = Ak.R, tickk = Ak.tick;
-            const uint32_t nABk = call_append_blocks(Ak), nRk = Ak.nR, nSk = Ak.nS, nAk = Ak.nA;
-            const uint32_t n_readers_k = nABk + nRk + 1;
+            const uint32_t nABk = call_append_blocks(Ak), nRk = Ak.nR, nAk = Ak.nA;
+            const uint32_t n_readers_k = STEP ? nRk + 1 : nABk + nRk + 1;
             const bool live_k = !STEP || k == 0;
-            const uint64_t *snap_k = live_k ? nullptr : E.step_snap + (size_t)k * SNAP_STRIDE;
             uint64_t *snap_next_k = STEP ? E.step_snap + (size_t)(k + 1) * SNAP_STRIDE : nullptr;
-            if (k < 16) STAMP(7, 4 * k);
             if (k == 0) {
                 /* followers' control words: nobody else writes them while the replicas are in step */
                 if (tid >= 128 && tid < 128 + 8 * APUS_DEV_MAX_SERVERS) {
                     const uint32_t f = (tid - 128) >> 3, j = (tid - 128) & 7;
-                    c.fw[f][j] = ((fmask >> f) & 1u) ? stage_follower_word(E, snap_k, f, j) : 0;     /* FW_* order */
+                    c.fw[f][j] = ((fmask >> f) & 1u) ? stage_follower_word(E, nullptr, f, j) : 0;     /* FW_* order */
                 }
-                seq_local(E, Xk, r0k, Rk, push_mask, tickk, 0, nABk + nRk, sq, snap_k, true, live_k);
+                if (tid < WAVE) {
+                    seq_w0_stage(E, r0k, Rk, push_mask, 0, sq, nullptr, true);
+                    if (tid == 0) __hip_atomic_fetch_add(Xk.lines + ((STEP ? nRk : nABk + nRk) & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                if (STEP) {
+                    /* snapshot 0 = the state before the launch: what a fallback path of segment 0
+                     * sequences from (the live words may change as soon as the readers are through) */
+                    uint64_t *s0 = E.step_snap;
+                    if (tid < 64) s0[tid] = sq.lh[tid];
+                    else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) s0[SNAP_FW + (tid - 64)] = (&c.fw[0][0])[tid - 64];
+                    else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) s0[SNAP_REC] = sq.misc[0];
+                }
+                if (tid < WAVE) {
+                    const int cf = STEP ? chain_decide_fast(E, push_mask, tickk, sq, r0k, Rk) : 0;
+                    if (!cf && tid == 0) seq_w0_decide<false>(E, push_mask, tickk, sq);
+                    if (tid == 0) chain_fast = (uint32_t)cf;
+                }
+                __syncthreads();
             } else {
                 /* the inputs: the state the previous segment's bookkeeping left in LDS + this
                  * segment's staged sizes (what seq_w0_stage fetches) */
@@ -2047,28 +2469,35 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                     const uint32_t w = tid - 64, f = w / 5, j = w - f * 5;
                     (&sq.fw[0][0])[w] = ((push_mask >> f) & 1u) ? c.fw[f][j] : (j == FW_N_PERSIST ? ~0ull : 0ull);
                 } else if (tid == 192) { sq.misc[0] = c.rec_base; sq.rstar = 0xFFFFFFFFu; sq.head_round = 0; }
-                else if (tid == 193) sq.pfx[0] = E.round_prefix[r0k];
-                else if (tid == 194) sq.pfx[1] = E.round_prefix[r0k];
-                else if (tid == 195) sq.pfx[2] = E.round_prefix[r0k + Rk];
-                else if (tid == 196) sq.rfx[0] = E.round_first[r0k];
-                else if (tid == 197) sq.rfx[1] = E.round_first[r0k + Rk];
-                else if (tid == 198) {
-                    const uint32_t a = E.round_first[r0k], bb = E.round_first[r0k + Rk];
-                    sq.misc[1] = (bb > a) ? E.req_len[bb - 1] : 0;
+                else if (tid == 193) { sq.pfx[0] = pre_pfx[k][0]; sq.pfx[1] = pre_pfx[k][0]; sq.pfx[2] = pre_pfx[k][1]; }
+                else if (tid == 194) { sq.rfx[0] = pre_rf[k][0]; sq.rfx[1] = pre_rf[k][1]; sq.misc[1] = pre_last[k]; }
+                __syncthreads();
+                if (tid < WAVE) {
+                    const int cf = chain_decide_fast(E, push_mask, tickk, sq, r0k, Rk);
+                    if (!cf && tid == 0) seq_w0_decide<false>(E, push_mask, tickk, sq);
+                    if (tid == 0) chain_fast = (uint32_t)cf;
                 }
                 __syncthreads();
-                if (k < 16) STAMP(7, 4 * k + 1);
-                if (tid == 0) seq_w0_decide<false>(E, push_mask, tickk, sq);
-                __syncthreads();
-                if (k < 16) STAMP(7, 4 * k + 2);
-                if (!sq.ok) {
-                    const uint32_t *rb = E.round_bytes + r0k;
-                    for (uint32_t i = tid; i < Rk && i < 1024; i += blockDim.x) sq.bytes0[i] = rb[i];
-                    __syncthreads();
-                    seq_body<false>(E, r0k, Rk, push_mask, tickk, push_mask, sq, 0);
-                }
             }
-            STAMP(3, 1);
+            if (k < 8) STAMPN(15, 8 * k + 0);              /* decided */
+            /* this segment's other blocks (its sequencer first) have work the books depend on, unless the
+             * chain block sequenced it itself (chain_fast: in step, then it also does the effects) */
+            const bool wait_needed = !chain_fast;
+            if (STEP) {
+                if (wait_needed) {
+                    /* they sequence from snapshot k: complete it (drain) before the record tells them to */
+                    if (k == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+                    else if (epoch_done < k) { bump_count(E.step_epoch, k); epoch_done = k; }
+                }
+                if (tid < WAVE) rec_publish(E, k, sq, chain_fast != 0);
+                if (k < 64) STAMPN(9, k);
+            }
+            if (!sq.ok) {
+                const uint32_t *rb = E.round_bytes + r0k;
+                for (uint32_t i = tid; i < Rk && i < 1024; i += blockDim.x) sq.bytes0[i] = rb[i];
+                __syncthreads();
+                seq_body<false>(E, r0k, Rk, push_mask, tickk, push_mask, sq, 0);
+            }
             if (sq.out.fast) {
                 /* in step: everything the bookkeeping needs follows from the sequencing it just worked
                  * out; nothing it writes is read by another block of the launch: publish right away */
@@ -2083,9 +2512,13 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                 }
                 __syncthreads();
                 if (live_k) wait_readers(E, Xk, n_readers_k);          /* it changes words the other blocks sequence from */
-                STAMP(3, 2);
+                if (k < 8) STAMPN(15, 8 * k + 1);          /* copies + wait_readers done */
+                if (STEP && chain_fast && tid < WAVE) chain_effects_fast(E, push_mask, tickk, sq);
+                if (k < 8) STAMPN(15, 8 * k + 2);          /* effects issued */
+                /* in step, but sequenced by the general path: this segment's sequencer block carries it
+                 * out -- it has to be through before the next segment's effects touch the same words */
+                if (STEP && !chain_fast) wait_sequenced(E, Xk, b, &l.t.flag);
                 keeper_publish(E, c, Rk, 0, fmask, vis, cs, true, sq.out.head_round ? sq.out.n_end0 : 0, sq.lh[H_HEAD], snap_next_k);
-                STAMP(3, 3);
             } else {
                 wait_sequenced(E, Xk, b, &l.t.flag);               /* the sequencer's results, released */
                 stage_apply_ctx(E, c, -1, true, fmask);
@@ -2100,16 +2533,26 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                 __syncthreads();
                 keeper_publish(E, c, Rk, 0, fmask, vis, cs, false, 0, 0, snap_next_k);
             }
-            if (STEP) bump_count(E.step_epoch, k + 1);             /* snapshot k + 1 is complete */
-            if (k < 16) STAMP(7, 4 * k + 3);
+            if (k < 8) STAMPN(15, 8 * k + 3);              /* keeper_publish + snapshot issued */
+            /* the books of the launch are closed: every snapshot is complete -- raised BEFORE this
+             * segment's sign-off (its janitor clears the chain counts once everybody has signed off) */
+            if (STEP && k + 1 == S_) bump_count(E.step_epoch, S_);
             post_ticket(E, Xk, T_PASS, false);
-            (void)nSk;
+            if (k < 8) STAMPN(15, 8 * k + 4);              /* signed off */
         }
         return;
     }
     q -= 1;
     /* ---- the roles that only work when the replicas are not in step ---- */
-    const uint32_t flag = wait_sequenced(E, X, b, &l.t.flag);
+    uint32_t flag = 0;
+    if (STEP) {
+        /* a segment's record says whether it is in step: then these blocks leave at once instead
+         * of sitting on a CU until the segment's sequencer has run */
+        if (tid < WAVE) rec_wait(E, seg, sq);
+        __syncthreads();
+        if (sq.ok && sq.out.fast) flag = 1;
+    }
+    if (!flag) flag = wait_sequenced(E, X, b, &l.t.flag);
     if (flag == 2) {
         if (q < nS) {                                          /* persist + ACK + quorum scan */
             if (tid == 0) l.t.sc[3] = E.seq->tail_needed;
@@ -2136,11 +2579,26 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
     post_ticket(E, X, T_PASS, false);
 }
 
+/* Every block works from a copy of the engine descriptor (pointers, sizes) in LDS.  Read from
+ * the kernarg segment through a generic pointer each E.rep[f].ring / E.dir_mask / ... is a memory load
+ * that the compiler must repeat after every 16-byte store (the stores are char-typed: they may
+ * alias anything in memory) -- a dependent round trip per store, ~10 us per append block under
+ * load (tools/timeline_probe.py).  LDS cannot alias the rings, so the loads are hoisted, and what is
+ * left costs an LDS access. */
+__device__ static inline void stage_engine(EngDev &dst)
+{
+    const uint64_t *src = (const uint64_t *)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
+    static_assert(sizeof(EngDev) % 8 == 0, "EngDev is copied as u64 words");
+    for (uint32_t i = threadIdx.x; i < sizeof(EngDev) / 8; i += blockDim.x) ((uint64_t *)&dst)[i] = src[i];
+    __syncthreads();
+}
+
 __global__ APUS_CALL_BOUNDS void k_call(const EngDev E_arg, const CallArgs A, uint32_t push_mask, uint32_t rmask)
 {
-    /* E is used where it lies in the kernarg segment (see k_step) */
-    const EngDev &E = *(const EngDev *)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
     (void)E_arg;
+    __shared__ EngDev E_s;
+    stage_engine(E_s);
+    const EngDev &E = E_s;
     __shared__ SeqLds sq;
     __shared__ CallLds l;
     const CallEnv X = APUS_ENV_OF(E);
@@ -2157,10 +2615,10 @@ __global__ APUS_CALL_BOUNDS void k_call(const EngDev E_arg, const CallArgs A, ui
  * dispatch ramp, no graph gap between segments. */
 __global__ APUS_CALL_BOUNDS void k_step(const EngDev E_arg, const StepTable T, uint32_t push_mask, uint32_t rmask)
 {
-    /* E is used where it lies in the kernarg segment (first argument): with this much code behind
-     * it the compiler otherwise copies the 950-byte struct into scratch for per-lane indexing */
-    const EngDev &E = *(const EngDev *)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
     (void)E_arg;
+    __shared__ EngDev E_s;                 /* see stage_engine */
+    stage_engine(E_s);
+    const EngDev &E = E_s;
     __shared__ SeqLds sq;
     __shared__ CallLds l;
     uint32_t seg = 0;
@@ -2408,6 +2866,7 @@ __global__ void k_reset(const EngDev E)
         for (int i = 0; i < 8; i++) E.ticket[i] = 0;
         for (int i = 0; i < 32; i++) { E.tick_lines[i * 32] = 0; E.tick_lines[i * 32 + 1] = 0; E.tick_lines[i * 32 + 2] = 0; }
         for (int i = 0; i < 32; i++) { E.step_epoch[i * 32] = 0; E.step_seq_done[i * 32] = 0; }
+        for (int i = 0; i < APUS_STEP_SEGS * REC_WORDS; i++) E.step_rec[i] = 0;
         for (int i = 0; i < APUS_STEP_SEGS * 1024; i++) E.step_lines[i] = 0;
         for (int i = 0; i < APUS_STEP_SEGS * 32; i++) E.step_tickets[i] = 0;
     }

@@ -12,6 +12,8 @@
 struct Bufs { uint4 *ring[3]; uint64_t *doff[3]; uint32_t *dlen[3]; uint32_t *ack; uint4 *apply[3]; const uint4 *arena; };
 __global__ __launch_bounds__(256) void rounds(Bufs B, size_t units_per_ring, size_t slots, int shift, int dir, int apply, int rd, int nbuf)
 {
+    extern __shared__ uint32_t occupancy_limiter[];           // dynamic LDS only limits the workgroups per CU
+    if (slots == 1) occupancy_limiter[threadIdx.x] = 0;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t r = (size_t)blockIdx.x * 4 + wv;            // round
     const size_t base = (r * 512 + (shift ? 4 : 0)) % units_per_ring;
@@ -51,12 +53,16 @@ int main()
     struct Cfg { const char *name; int shift, dir, apply, rd; } cfgs[] = {
         {"rings only", 0, 0, 0, 0}, {"+shift", 1, 0, 0, 0}, {"+dir", 0, 1, 0, 0}, {"+apply", 0, 0, 1, 0}, {"+read", 0, 0, 0, 1},
         {"+dir+apply", 0, 1, 1, 0}, {"all", 1, 1, 1, 1}, {"all but shift", 0, 1, 1, 1}};
-    for (int rounds_per_launch : {5464, 1024}) for (auto &c : cfgs) {
+    hipFuncSetAttribute((const void *)rounds, hipFuncAttributeMaxDynamicSharedMemorySize, 80 << 10);
+    for (int per_cu : {8, 5, 3, 2, 1}) for (int rounds_per_launch : {5464, 1024}) for (auto &c : cfgs) {
+        if (per_cu != 8 && (c.shift + c.dir + c.apply + c.rd) != 4 && (c.shift + c.dir + c.apply + c.rd) != 0) continue;
         const int blocks = rounds_per_launch / 4;
-        for (int w = 0; w < 3; w++) hipLaunchKernelGGL(rounds, blocks, 256, 0, st, B, U, SLOTS, c.shift, c.dir, c.apply, c.rd, 3);
+        const size_t lds = per_cu >= 8 ? 0 : (size_t)(160 << 10) / per_cu - 1024;     // workgroups per CU by LDS
+        if (c.shift + c.dir + c.apply + c.rd == 0 || per_cu == 8) printf("-- %d workgroup(s) per CU\n", per_cu);
+        for (int w = 0; w < 3; w++) hipLaunchKernelGGL(rounds, blocks, 256, lds, st, B, U, SLOTS, c.shift, c.dir, c.apply, c.rd, 3);
         hipEventRecord(e0, st);
         const int reps = 20;
-        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(rounds, blocks, 256, 0, st, B, U, SLOTS, c.shift, c.dir, c.apply, c.rd, 3);
+        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(rounds, blocks, 256, lds, st, B, U, SLOTS, c.shift, c.dir, c.apply, c.rd, 3);
         hipEventRecord(e1, st); hipStreamSynchronize(st);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double us = ms * 1000 / reps;
