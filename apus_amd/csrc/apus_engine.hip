@@ -900,17 +900,18 @@ extern "C" uint32_t apus_gpu_status(apus_engine_t *e)
 {
     if (!e) return 0xFFFFFFFFu;
     flush_tick(e);
-    uint32_t s = 0;
+    uint32_t s[2] = {0, 0};
     hipStreamSynchronize(e->stream);
-    hipMemcpy(&s, e->d.status, sizeof s, hipMemcpyDeviceToHost);
-    return s;
+    hipMemcpy(s, e->d.status, sizeof s, hipMemcpyDeviceToHost);
+    if ((s[0] & (1u << 4)) && getenv("APUS_DEBUG")) fprintf(stderr, "[apus] spin timeout first hit at apus_kernels.h:%u\n", s[1]);
+    return s[0];
 }
 
 extern "C" void apus_gpu_clear_status(apus_engine_t *e)
 {
     if (!e) return;
     hipStreamSynchronize(e->stream);
-    hipMemset(e->d.status, 0, sizeof(uint32_t));
+    hipMemset(e->d.status, 0, 2 * sizeof(uint32_t));
 }
 
 extern "C" void *apus_gpu_device_ptr(apus_engine_t *e, uint32_t replica, int which, uint64_t *bytes)

@@ -97,6 +97,8 @@ __device__ static inline T wave_sum(T v)
 }
 
 __device__ static inline void set_status(const EngDev &E, uint32_t bit) { atomicOr(E.status, bit); }
+/* a bounded spin ran out: status bit 4; the first site to do so leaves its source line in status word 1 */
+__device__ static inline void spin_timeout(const EngDev &E, uint32_t site) { atomicOr(E.status, 1u << 4); atomicCAS(E.status + 1, 0u, site); }
 
 /* bytes [b0, b1) of a little-endian u64 set to 0xFF (0 <= b0, b1 <= 8) */
 __device__ static inline uint64_t byte_mask64(int b0, int b1)
@@ -893,7 +895,7 @@ __device__ static inline void rec_wait(const EngDev &E, uint32_t seg, SeqLds &q)
         if (lane < REC_GRAN) v = ldw(&rec[lane]);
         if (__all(lane >= REC_GRAN || (uint32_t)(v >> 32) == tag)) break;
         __builtin_amdgcn_s_sleep(APUS_REC_SLEEP);
-        if (++spins > (1ull << 22)) { if (lane == 0) set_status(E, 1u << 4); break; }      /* bounded */
+        if (++spins > (1ull << 22)) { if (lane == 0) spin_timeout(E, 896); break; }      /* bounded */
     }
     const uint32_t d = (uint32_t)v;
     const uint64_t e0 = (uint64_t)__shfl(d, 0, WAVE) | ((uint64_t)__shfl(d, 1, WAVE) << 32);
@@ -948,7 +950,7 @@ __device__ static inline uint32_t wait_sequenced(const EngDev &E, const CallEnv 
         uint32_t f;
         while ((f = __hip_atomic_load(X.lines + (b & 31u) * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
             __builtin_amdgcn_s_sleep(32);
-            if (++spins > (1ull << 22)) { set_status(E, 1u << 4); f = 1; break; }     /* bounded */
+            if (++spins > (1ull << 22)) { spin_timeout(E, 951); f = 1; break; }     /* bounded */
         }
         *s_flag = f;
     }
@@ -1969,7 +1971,7 @@ __device__ static inline void recorder_body(const EngDev &E, uint64_t r0, uint32
  * sequencer pushed it; slot + 1 and value are derived (head_slot1, head_value) instead of read */
 __device__ static inline void keeper_publish(const EngDev &E, ApplyCtx &c, uint32_t R, int mode, uint32_t fmask,
                                              uint64_t vis, uint64_t cs, bool pure_head = false, uint64_t head_slot1 = 0,
-                                             uint64_t head_value = 0, uint64_t *snap_next = nullptr)
+                                             uint64_t head_value = 0, uint64_t *snap_next = nullptr, bool dry = false)
 {
     const uint32_t tid = threadIdx.x;
     uint64_t *lh = E.rep[E.leader].hdr;
@@ -1982,21 +1984,21 @@ __device__ static inline void keeper_publish(const EngDev &E, ApplyCtx &c, uint3
     if (tid == 0) {
         if (mode == 0) {
             c.rec_base = c.rec_base + R + s.head_round;
-            gst(E.rec_count, (uint64_t)c.rec_base);
+            if (!dry) gst(E.rec_count, (uint64_t)c.rec_base);
         } else if (mode == 1 && s.n) {
-            if (c.rec_base < E.rec_cap) E.rec_commit[c.rec_base] = (end_l == L) ? s.commit_before : commit_off;
+            if (!dry && c.rec_base < E.rec_cap) E.rec_commit[c.rec_base] = (end_l == L) ? s.commit_before : commit_off;
             c.rec_base = c.rec_base + 1;
-            gst(E.rec_count, (uint64_t)c.rec_base);
+            if (!dry) gst(E.rec_count, (uint64_t)c.rec_base);
         }
-        gst(&lh[H_N_VISIBLE], (uint64_t)(vis)); c.lh[H_N_VISIBLE] = vis;
-        if (cs > s.n_commit_before) { gst(&lh[H_COMMIT], (uint64_t)(commit_off)); gst(&lh[H_N_COMMIT], (uint64_t)(cs)); c.lh[H_COMMIT] = commit_off; c.lh[H_N_COMMIT] = cs; }
-        if (cs > c.lh[H_N_APPLY]) { gst(&lh[H_APPLY], (uint64_t)(c.off_cs)); gst(&lh[H_N_APPLY], (uint64_t)(cs)); c.lh[H_APPLY] = c.off_cs; c.lh[H_N_APPLY] = cs; }
+        if (!dry) gst(&lh[H_N_VISIBLE], (uint64_t)(vis)); c.lh[H_N_VISIBLE] = vis;
+        if (cs > s.n_commit_before) { if (!dry) gst(&lh[H_COMMIT], (uint64_t)(commit_off)); if (!dry) gst(&lh[H_N_COMMIT], (uint64_t)(cs)); c.lh[H_COMMIT] = commit_off; c.lh[H_N_COMMIT] = cs; }
+        if (cs > c.lh[H_N_APPLY]) { if (!dry) gst(&lh[H_APPLY], (uint64_t)(c.off_cs)); if (!dry) gst(&lh[H_N_APPLY], (uint64_t)(cs)); c.lh[H_APPLY] = c.off_cs; c.lh[H_N_APPLY] = cs; }
         if (mode == 0 && s.fast) {
             /* the append blocks applied the batch (every entry a client entry): one upcall each */
-            atomicAdd((unsigned long long *)&lh[H_APPLY_COUNT], (unsigned long long)s.n);
-            atomicAdd((unsigned long long *)&lh[H_HIGHEST_REC], (unsigned long long)s.n);
+            if (!dry) atomicAdd((unsigned long long *)&lh[H_APPLY_COUNT], (unsigned long long)s.n);
+            if (!dry) atomicAdd((unsigned long long *)&lh[H_HIGHEST_REC], (unsigned long long)s.n);
             for (uint32_t m = s.fuse_mask; m; m &= m - 1)
-                atomicAdd((unsigned long long *)&E.rep[__builtin_ctz(m)].hdr[H_APPLY_COUNT], (unsigned long long)s.n);
+                if (!dry) atomicAdd((unsigned long long *)&E.rep[__builtin_ctz(m)].hdr[H_APPLY_COUNT], (unsigned long long)s.n);
         }
     }
     if (tid >= 1 && tid <= APUS_DEV_MAX_SERVERS) {
@@ -2011,31 +2013,33 @@ __device__ static inline void keeper_publish(const EngDev &E, ApplyCtx &c, uint3
                               : __hip_atomic_load((unsigned long long *)&fh[H_HEAD_SLOT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint64_t end_now = f_end;
             if (vis > f_np) {
-                gst(&fh[H_STORE_COUNT], (uint64_t)(f_sc + (vis - f_np)));
-                gst(&fh[H_END], (uint64_t)(c.off_vis)); gst(&fh[H_OLD_END], (uint64_t)(c.off_vis));
-                gst(&fh[H_N_END], (uint64_t)(vis)); gst(&fh[H_N_PERSIST], (uint64_t)(vis));
+                if (!dry) gst(&fh[H_STORE_COUNT], (uint64_t)(f_sc + (vis - f_np)));
+                if (!dry) gst(&fh[H_END], (uint64_t)(c.off_vis)); if (!dry) gst(&fh[H_OLD_END], (uint64_t)(c.off_vis));
+                if (!dry) gst(&fh[H_N_END], (uint64_t)(vis)); if (!dry) gst(&fh[H_N_PERSIST], (uint64_t)(vis));
                 w[FW_STORE_COUNT] = f_sc + (vis - f_np); w[FW_END] = c.off_vis; w[FW_N_END] = vis; w[FW_N_PERSIST] = vis;
                 end_now = c.off_vis;
             }
-            if (cs > f_nc) { gst(&fh[H_COMMIT], (uint64_t)(c.off_cs)); gst(&fh[H_N_COMMIT], (uint64_t)(cs)); w[FW_N_COMMIT] = cs; }
-            if (cs > f_na) { gst(&fh[H_APPLY], (uint64_t)(c.off_cs)); gst(&fh[H_N_APPLY], (uint64_t)(cs)); w[FW_APPLY] = c.off_cs; w[FW_N_APPLY] = cs; }
+            if (cs > f_nc) { if (!dry) gst(&fh[H_COMMIT], (uint64_t)(c.off_cs)); if (!dry) gst(&fh[H_N_COMMIT], (uint64_t)(cs)); w[FW_N_COMMIT] = cs; }
+            if (cs > f_na) { if (!dry) gst(&fh[H_APPLY], (uint64_t)(c.off_cs)); if (!dry) gst(&fh[H_N_APPLY], (uint64_t)(cs)); w[FW_APPLY] = c.off_cs; w[FW_N_APPLY] = cs; }
             if (hs) {
                 uint64_t hv = head_value;
                 if (!pure_head) {
                     const uint64_t hoff = E.rep[f].dir_off[(uint32_t)(hs - 1) & E.dir_mask];
                     hv = ld8u(E.rep[f].ring + hoff + 48);
                 }
-                if (apus_is_larger(end_now, L, hv, f_head)) { gst(&fh[H_HEAD], (uint64_t)(hv)); w[FW_HEAD] = hv; }
-                if (!pure_head) gst(&fh[H_HEAD_SLOT], (uint64_t)(0));
+                if (apus_is_larger(end_now, L, hv, f_head)) { if (!dry) gst(&fh[H_HEAD], (uint64_t)(hv)); w[FW_HEAD] = hv; }
+                if (!pure_head) if (!dry) gst(&fh[H_HEAD_SLOT], (uint64_t)(0));
             }
         }
     }
     if (snap_next) {
         /* the state after this call, for the next segment of the launch (write-once, uncached) */
         __syncthreads();
-        if (tid < 64) gst(&snap_next[tid], c.lh[tid]);
-        else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) gst(&snap_next[SNAP_FW + (tid - 64)], (&c.fw[0][0])[tid - 64]);
-        else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) gst(&snap_next[SNAP_REC], (uint64_t)c.rec_base);
+        if (!dry) {
+            if (tid < 64) gst(&snap_next[tid], c.lh[tid]);
+            else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) gst(&snap_next[SNAP_FW + (tid - 64)], (&c.fw[0][0])[tid - 64]);
+            else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) gst(&snap_next[SNAP_REC], (uint64_t)c.rec_base);
+        }
     }
 }
 
@@ -2047,7 +2051,7 @@ __device__ static inline void wait_ticket(const EngDev &E, const CallEnv &X, int
         unsigned long long spins = 0;
         while (__hip_atomic_load(X.ticket + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1ull << 22)) { set_status(E, 1u << 4); break; }     /* bounded */
+            if (++spins > (1ull << 22)) { spin_timeout(E, 2050); break; }     /* bounded */
         }
     }
     __syncthreads();
@@ -2062,7 +2066,7 @@ __device__ static inline void wait_append(const EngDev &E, const CallEnv &X, uin
         unsigned long long spins = 0;
         while (__hip_atomic_load(X.lines + threadIdx.x * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < quota) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1ull << 22)) { set_status(E, 1u << 4); break; }     /* bounded */
+            if (++spins > (1ull << 22)) { spin_timeout(E, 2065); break; }     /* bounded */
         }
     }
     __syncthreads();
@@ -2085,7 +2089,7 @@ __device__ static inline void wait_readers(const EngDev &E, const CallEnv &X, ui
         unsigned long long spins = 0;
         while (__hip_atomic_load(X.lines + threadIdx.x * 32 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < quota) {
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1ull << 22)) { set_status(E, 1u << 4); break; }     /* bounded */
+            if (++spins > (1ull << 22)) { spin_timeout(E, 2088); break; }     /* bounded */
         }
     }
     __syncthreads();
@@ -2161,7 +2165,7 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
         unsigned long long spins = 0;
         while (__hip_atomic_load(E.ticket + T_APPLY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1ull << 24)) { set_status(E, 1u << 4); break; }     /* bounded */
+            if (++spins > (1ull << 24)) { spin_timeout(E, 2164); break; }     /* bounded */
         }
         __hip_atomic_store(E.ticket + T_APPLY, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -2226,7 +2230,7 @@ __device__ static inline void wait_count(const EngDev &E, const uint32_t *lines3
         unsigned long long spins = 0;
         while (__hip_atomic_load(lines32 + (b & 31u) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             __builtin_amdgcn_s_sleep(APUS_POLL_SLEEP);
-            if (++spins > (1ull << 22)) { set_status(E, 1u << 4); break; }     /* bounded */
+            if (++spins > (1ull << 22)) { spin_timeout(E, 2229); break; }     /* bounded */
         }
     }
     __syncthreads();
@@ -2294,9 +2298,12 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
         if (b == nAB) STAMP(6, 0);
         const int rec_seg = STEP ? (int)seg : -1;
         uint32_t fast;
+#ifndef APUS_NO_GP
         if (A.GP > 1) {
             fast = append_group(E, X, r0, R, push_mask, ab, l.grp, &sq, tick, snap, live && !STEP, rec_seg);
-        } else {
+        } else
+#endif
+        {
             const uint32_t r = ab / SP, slice = ab - r * SP;
             append_round<true>(E, X, r0, R, push_mask, r, l.app, &sq, tick, slice, SP, snap, live && !STEP, rec_seg);
             fast = l.app.fast;
@@ -2418,12 +2425,58 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
         __shared__ uint64_t pre_pfx[APUS_STEP_SEGS][2];
         __shared__ uint32_t pre_rf[APUS_STEP_SEGS][2];
         __shared__ uint64_t pre_last[APUS_STEP_SEGS];
+        /* the state before the launch, kept for the second pass (see below) */
+        __shared__ uint64_t init_lh[64], init_fw[APUS_DEV_MAX_SERVERS][8], init_rec;
         if (STEP && TT && tid < S_) {
             const CallArgs &Ap = TT->seg[tid];
             const uint32_t a = E.round_first[Ap.r0], bb = E.round_first[Ap.r0 + Ap.R];
             pre_pfx[tid][0] = E.round_prefix[Ap.r0]; pre_pfx[tid][1] = E.round_prefix[Ap.r0 + Ap.R];
             pre_rf[tid][0] = a; pre_rf[tid][1] = bb;
             pre_last[tid] = (bb > a) ? E.req_len[bb - 1] : 0;
+        }
+        {   /* ---- the inputs of segment 0: the live control words, one round trip ---- */
+            const CallArgs &A0 = (STEP && TT) ? TT->seg[0] : A;
+            const uint32_t nAB0 = call_append_blocks(A0);
+            /* followers' control words: nobody else writes them while the replicas are in step */
+            if (tid >= 128 && tid < 128 + 8 * APUS_DEV_MAX_SERVERS) {
+                const uint32_t f = (tid - 128) >> 3, j2 = (tid - 128) & 7;
+                c.fw[f][j2] = ((fmask >> f) & 1u) ? stage_follower_word(E, nullptr, f, j2) : 0;     /* FW_* order */
+            }
+            if (tid < WAVE) {
+                seq_w0_stage(E, A0.r0, A0.R, push_mask, 0, sq, nullptr, true);
+                if (tid == 0) __hip_atomic_fetch_add(X.lines + ((STEP ? A0.nR : nAB0 + A0.nR) & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (STEP) {
+                /* snapshot 0 = the state before the launch: what a fallback path of segment 0
+                 * sequences from (the live words may change as soon as the readers are through) */
+                uint64_t *s0 = E.step_snap;
+                if (tid < 64) { gst(&s0[tid], sq.lh[tid]); init_lh[tid] = sq.lh[tid]; c.lh[tid] = sq.lh[tid]; }
+                else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) { gst(&s0[SNAP_FW + (tid - 64)], (&c.fw[0][0])[tid - 64]); (&init_fw[0][0])[tid - 64] = (&c.fw[0][0])[tid - 64]; }
+                else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) { gst(&s0[SNAP_REC], sq.misc[0]); init_rec = sq.misc[0]; c.rec_base = sq.misc[0]; }
+                __syncthreads();
+            }
+        }
+        /* Two passes over the segments in a multi-segment launch.  The DRY pass only sequences
+         * (chain_decide_fast), publishes each segment's record and advances the LDS copy of the state --
+         * no effect on memory besides the records: ~1.5 us per segment, so the append blocks of every
+         * segment have their record a few microseconds into the launch.  It stops at the first
+         * segment the chain block cannot sequence on its own.  The REAL pass starts over from the
+         * saved state and does what the first could not: the live control words, the <HEAD> entries,
+         * the snapshots, the tickets, and the general path for the segments that need it. */
+        uint32_t n_dry = 0;
+#ifdef APUS_NO_DRY
+        for (int pass = 1; pass < 2; pass++) {
+#else
+        for (int pass = STEP ? 0 : 1; pass < 2; pass++) {
+#endif
+        const bool dry = pass == 0;
+        if (STEP && pass == 1) {
+            __syncthreads();
+            if (tid < 64) c.lh[tid] = init_lh[tid];
+            else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) (&c.fw[0][0])[tid - 64] = (&init_fw[0][0])[tid - 64];
+            else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) c.rec_base = init_rec;
+            __syncthreads();
         }
         for (uint32_t k = 0; k < S_; k++) {
             const CallArgs &Ak = (STEP && TT) ? TT->seg[k] : A;
@@ -2435,49 +2488,38 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
             const uint32_t n_readers_k = STEP ? nRk + 1 : nABk + nRk + 1;
             const bool live_k = !STEP || k == 0;
             uint64_t *snap_next_k = STEP ? E.step_snap + (size_t)(k + 1) * SNAP_STRIDE : nullptr;
-            if (k == 0) {
-                /* followers' control words: nobody else writes them while the replicas are in step */
-                if (tid >= 128 && tid < 128 + 8 * APUS_DEV_MAX_SERVERS) {
-                    const uint32_t f = (tid - 128) >> 3, j = (tid - 128) & 7;
-                    c.fw[f][j] = ((fmask >> f) & 1u) ? stage_follower_word(E, nullptr, f, j) : 0;     /* FW_* order */
-                }
-                if (tid < WAVE) {
-                    seq_w0_stage(E, r0k, Rk, push_mask, 0, sq, nullptr, true);
-                    if (tid == 0) __hip_atomic_fetch_add(Xk.lines + ((STEP ? nRk : nABk + nRk) & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __syncthreads();
-                if (STEP) {
-                    /* snapshot 0 = the state before the launch: what a fallback path of segment 0
-                     * sequences from (the live words may change as soon as the readers are through) */
-                    uint64_t *s0 = E.step_snap;
-                    if (tid < 64) s0[tid] = sq.lh[tid];
-                    else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) s0[SNAP_FW + (tid - 64)] = (&c.fw[0][0])[tid - 64];
-                    else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) s0[SNAP_REC] = sq.misc[0];
-                }
-                if (tid < WAVE) {
-                    const int cf = STEP ? chain_decide_fast(E, push_mask, tickk, sq, r0k, Rk) : 0;
-                    if (!cf && tid == 0) seq_w0_decide<false>(E, push_mask, tickk, sq);
-                    if (tid == 0) chain_fast = (uint32_t)cf;
-                }
-                __syncthreads();
-            } else {
-                /* the inputs: the state the previous segment's bookkeeping left in LDS + this
-                 * segment's staged sizes (what seq_w0_stage fetches) */
+            if (STEP) {
+                /* the inputs: the state the previous segment's bookkeeping left in LDS (segment 0: the
+                 * staged live words) + this segment's staged sizes (what seq_w0_stage fetches) */
                 __syncthreads();
                 if (tid < 64) sq.lh[tid] = c.lh[tid];
                 else if (tid < 64 + 5 * APUS_DEV_MAX_SERVERS) {
-                    const uint32_t w = tid - 64, f = w / 5, j = w - f * 5;
-                    (&sq.fw[0][0])[w] = ((push_mask >> f) & 1u) ? c.fw[f][j] : (j == FW_N_PERSIST ? ~0ull : 0ull);
+                    const uint32_t w = tid - 64, f = w / 5, j2 = w - f * 5;
+                    (&sq.fw[0][0])[w] = ((push_mask >> f) & 1u) ? c.fw[f][j2] : (j2 == FW_N_PERSIST ? ~0ull : 0ull);
                 } else if (tid == 192) { sq.misc[0] = c.rec_base; sq.rstar = 0xFFFFFFFFu; sq.head_round = 0; }
                 else if (tid == 193) { sq.pfx[0] = pre_pfx[k][0]; sq.pfx[1] = pre_pfx[k][0]; sq.pfx[2] = pre_pfx[k][1]; }
                 else if (tid == 194) { sq.rfx[0] = pre_rf[k][0]; sq.rfx[1] = pre_rf[k][1]; sq.misc[1] = pre_last[k]; }
                 __syncthreads();
-                if (tid < WAVE) {
-                    const int cf = chain_decide_fast(E, push_mask, tickk, sq, r0k, Rk);
-                    if (!cf && tid == 0) seq_w0_decide<false>(E, push_mask, tickk, sq);
-                    if (tid == 0) chain_fast = (uint32_t)cf;
-                }
+            }
+            if (tid < WAVE) {
+                const int cf = STEP ? chain_decide_fast(E, push_mask, tickk, sq, r0k, Rk) : 0;
+                if (!cf && !dry && tid == 0) seq_w0_decide<false>(E, push_mask, tickk, sq);
+                if (tid == 0) chain_fast = (uint32_t)cf;
+            }
+            __syncthreads();
+            if (dry) {
+                if (!chain_fast) break;                        /* the real pass takes it from here */
+                if (tid < WAVE) rec_publish(E, k, sq, true);
+                if (k < 64) STAMPN(9, k);
+                n_dry = k + 1;
+                /* the books, in LDS only */
+                if (tid < 64) c.lh[tid] = sq.lh[tid];
+                else if (tid < 64 + sizeof(SeqOut) / 8) ((uint64_t *)&c.seq)[tid - 64] = ((const uint64_t *)&sq.out)[tid - 64];
                 __syncthreads();
+                if (tid == 0) { c.rec_base = sq.out.rec_base; c.off_cs = sq.end_new; c.off_vis = sq.end_new; }
+                __syncthreads();
+                keeper_publish(E, c, Rk, 0, fmask, sq.out.vis, sq.out.vis, true, sq.out.head_round ? sq.out.n_end0 : 0, sq.lh[H_HEAD], nullptr, true);
+                continue;
             }
             if (k < 8) STAMPN(15, 8 * k + 0);              /* decided */
             /* this segment's other blocks (its sequencer first) have work the books depend on, unless the
@@ -2489,12 +2531,14 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                     if (k == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
                     else if (epoch_done < k) { bump_count(E.step_epoch, k); epoch_done = k; }
                 }
-                if (tid < WAVE) rec_publish(E, k, sq, chain_fast != 0);
-                if (k < 64) STAMPN(9, k);
+                if (k >= n_dry) {
+                    if (tid < WAVE) rec_publish(E, k, sq, chain_fast != 0);
+                    if (k < 64) STAMPN(9, k);
+                }
             }
             if (!sq.ok) {
                 const uint32_t *rb = E.round_bytes + r0k;
-                for (uint32_t i = tid; i < Rk && i < 1024; i += blockDim.x) sq.bytes0[i] = rb[i];
+                for (uint32_t i2 = tid; i2 < Rk && i2 < 1024; i2 += blockDim.x) sq.bytes0[i2] = rb[i2];
                 __syncthreads();
                 seq_body<false>(E, r0k, Rk, push_mask, tickk, push_mask, sq, 0);
             }
@@ -2539,6 +2583,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
             if (STEP && k + 1 == S_) bump_count(E.step_epoch, S_);
             post_ticket(E, Xk, T_PASS, false);
             if (k < 8) STAMPN(15, 8 * k + 4);              /* signed off */
+        }
         }
         return;
     }
