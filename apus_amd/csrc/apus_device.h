@@ -114,6 +114,8 @@ struct EngDev {
     uint32_t leader;                      /* group index, 0xFFFFFFFF = none */
     uint32_t reachable;                   /* bitmask of peers the leader can post to */
     uint32_t dir_mask;                    /* dir_cap - 1 */
+    uint32_t flags;                       /* apus_cfg_t.flags (APUS_F_*) */
+    uint32_t pad_flags;
     uint64_t log_len;
     uint32_t *status;
     uint32_t *ticket;                     /* [8] arrival counters (k_apply: [1]; k_call: pass [2], scan [3], done [4]) */

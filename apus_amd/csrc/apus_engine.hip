@@ -154,6 +154,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->d.leader = 0xFFFFFFFFu;
     e->dir_cap = pow2_at_least(L / APUS_ENTRY_HDR < 4096 ? 4096 : L / APUS_ENTRY_HDR);
     e->d.dir_mask = e->dir_cap - 1;
+    e->d.flags = cfg->flags;
     e->local_mask = 0;
     e->reachable = (1u << cfg->group_size) - 1;
     e->d.reachable = e->reachable;

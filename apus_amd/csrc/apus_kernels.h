@@ -281,6 +281,7 @@ __device__ static inline void seq_in_step(const EngDev &E, const uint64_t *lh, c
     const uint64_t L = E.log_len;
     const uint64_t e_pre = lh[H_END], n_pre = lh[H_N_END];
     fuse_mask = 0;
+    if (!(E.flags & 1u))            /* APUS_F_NO_FUSED_ACKS: every ACK goes through the reply byte, the ACK word and the scan */
     for (uint32_t m = push_mask; m; m &= m - 1)
         if (fw[__builtin_ctz(m)][3] == n_pre && e_pre != L) fuse_mask |= 1u << __builtin_ctz(m);
     const uint32_t size = E.group_size, size_mask = (1u << size) - 1;
@@ -691,7 +692,7 @@ __device__ static inline int chain_decide_fast(const EngDev &E, uint32_t push_ma
     const bool quorum = (uint32_t)__popc((push_mask | (1u << leader)) & size_mask) >= size / 2 + 1;
     /* (a batch that may reach the end of the ring is placed below; one that is longer than the
      * ring, or an empty log, goes the general way) */
-    const bool pre = end != L && L - end >= APUS_HDR && vtot + APUS_HDR < L && n > 0 && R <= 1024 && quorum &&
+    const bool pre = !(E.flags & 1u) && end != L && L - end >= APUS_HDR && vtot + APUS_HDR < L && n > 0 && R <= 1024 && quorum &&
                      n_commit == n_end && n_apply == n_end && end != head;
     if (!pre || !__all(!pushed || (f_np == n_end && f_na == n_end))) return 0;
 

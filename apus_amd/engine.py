@@ -32,7 +32,7 @@ class Engine:
     of a group that spans several processes)."""
 
     def __init__(self, group_size: int, log_len: int = DEFAULT_LOG, local_ids=None,
-                 device: int = 0, stream: int | None = None):
+                 device: int = 0, stream: int | None = None, flags: int = 0):
         self.L = _lib.load()
         self.group_size = group_size
         self.log_len = log_len
@@ -44,7 +44,7 @@ class Engine:
             cfg.local_ids[k] = i
         cfg.log_len = log_len
         cfg.device = device
-        cfg.flags = 0
+        cfg.flags = flags          # include/apus_gpu.h APUS_F_*: 1 = no fused ACKs (per-entry ACK words + quorum scan)
         cfg.stream = stream
         h = C.c_void_p()
         rc = self.L.apus_gpu_create(C.byref(cfg), C.byref(h))

@@ -181,6 +181,47 @@ def cpu_baseline(args, seconds=12.0):
     return ref
 
 
+def measure_ack_path(args, tr, n_rep):
+    """The same step with APUS_F_NO_FUSED_ACKS: per-entry ACK words written by the followers'
+    persist pass, commit decided by the popcount / ballot scan (the path a group that spans GPUs
+    must take).  Same verification as the main measurement."""
+    import torch
+    from apus_amd.engine import Engine
+    eng = Engine(n_rep, tr.log_len, device=0, flags=1)
+    try:
+        eng.stage_trace(tr)
+        eng.elect(0)
+        calls = step_calls(tr, eng)
+        issue(eng, calls)
+        eng.sync(); eng.check_status()
+        eng.capture_begin(); issue(eng, calls); gid = eng.capture_end()
+        for _ in range(args.warmup):
+            eng.graph_launch(gid)
+        eng.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.graph_launch(gid)
+        eng.sync(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        eng.check_status()
+        total = (1 + args.warmup + args.steps) * len(tr.reqs)
+        for r in range(n_rep):
+            o = eng.offsets(r)
+            assert o["commit"] == o["end"] == o["apply"], f"ack path: replica {r} not caught up: {o}"
+        assert eng.counters(0)["highest_rec"] == total
+        eng.set_timing(True)
+        for _ in range(args.steps):
+            issue(eng, calls)
+        eng.sync()
+        k_ms, k_launches = eng.kernel_time(0)
+        eng.set_timing(False)
+        return {"value": len(tr.reqs) * args.steps / dt, "unit": "entries/s", "ms_per_step": dt / args.steps * 1e3,
+                "kernel": "k_step" if BATCH else "k_call", "avg_launch_us": k_ms * 1e3 / max(k_launches, 1), "launches": k_launches,
+                "note": "APUS_F_NO_FUSED_ACKS: follower persist + reply byte + ACK word per entry, quorum by popcount/ballot scan"}
+    finally:
+        eng.close()
+
+
 def bench_single(args):
     import torch
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
@@ -325,9 +366,14 @@ def bench_single(args):
         "whole_path": {"bytes_per_entry": path_bytes, "achieved": path_bytes * value / 1e9,
                        "unit": "GB/s", "frac": path_bytes * value / 1e9 / HBM_PEAK_GBS},
     }
+    eng.close()
+    if not args.no_ack_path:
+        try:
+            out["ack_aggregation_path"] = measure_ack_path(args, tr, n_rep)
+        except Exception as exc:
+            print(f"[bench] ACK-aggregation path measurement failed: {exc!r}", file=sys.stderr)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-    eng.close()
     return out
 
 
@@ -350,6 +396,7 @@ def main():
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-ack-path", action="store_true", help="skip the second measurement without fused ACKs")
     ap.add_argument("--no-batch", action="store_true", help="one launch per run_rounds call (k_call) instead of batches (k_step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()

@@ -97,9 +97,17 @@ typedef struct {
     uint8_t  pad[3];
     uint64_t log_len;                    /* ring bytes; 0 = APUS_LOG_SIZE                         */
     int32_t  device;                     /* HIP device ordinal                                    */
-    uint32_t flags;                      /* reserved, 0                                           */
+    uint32_t flags;                      /* APUS_F_* bits, 0 by default                           */
     void    *stream;                     /* hipStream_t to launch on; NULL = engine-owned stream  */
 } apus_cfg_t;
+
+/* apus_cfg_t.flags */
+/* Followers never persist + ACK as part of the leader's push: every entry goes the way it has to
+ * go between GPUs -- follower persist_new_entries + rc_send_entries_reply write the reply byte and
+ * the per-entry ACK word, the leader's scan decides the commit with popcount / wave ballot
+ * (update_remote_logs, src/dare/dare_ibv_rc.c:1725-1758).  Results are identical; only the
+ * schedule inside a call differs (bench.py reports this path as `ack_aggregation_path`). */
+#define APUS_F_NO_FUSED_ACKS 1u
 
 typedef struct apus_engine apus_engine_t;
 

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 run() {
   local label=$1; shift
   local out
-  out=$(env "$@" timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu --no-latency 2>&1 | tail -1)
+  out=$(env "$@" timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu --no-latency --no-ack-path 2>&1 | tail -1)
   echo "$label $(echo "$out" | python -c "
 import sys, json
 try:

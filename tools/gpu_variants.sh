@@ -10,7 +10,7 @@ tail -15 gpurun_out/pytest_gpu.log
 run() {  # label, env...
   local label=$1; shift
   local out
-  out=$(env "$@" timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu --no-latency 2>&1 | tail -1)
+  out=$(env "$@" timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu --no-latency --no-ack-path 2>&1 | tail -1)
   echo "$label $(echo "$out" | python -c "
 import sys, json
 try:
