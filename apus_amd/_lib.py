@@ -10,6 +10,12 @@ u64, u32, u16, u8 = C.c_uint64, C.c_uint32, C.c_uint16, C.c_uint8
 vp = C.c_void_p
 
 
+class IpcReplica(C.Structure):
+    """apus_ipc_replica_t (include/apus_gpu.h)"""
+    _fields_ = [("handle", (u8 * 64) * 6), ("log_len", u64), ("dir_cap", u32), ("replica", u32),
+                ("device", C.c_int32), ("pad", u32)]
+
+
 class Cfg(C.Structure):
     _fields_ = [("group_size", u32), ("n_local", u32), ("local_ids", u8 * 13), ("pad", u8 * 3),
                 ("log_len", u64), ("device", C.c_int32), ("flags", u32), ("stream", vp)]
@@ -68,6 +74,8 @@ SIGNATURES = {
     "apus_gpu_submit": (C.c_int, [vp, vp, u32, vp, u64]),
     "apus_gpu_append_live": (C.c_int, [vp, vp, u32, vp, u64]),
     "apus_gpu_commit_live": (C.c_int, [vp, C.c_int]),
+    "apus_gpu_export_replica": (C.c_int, [vp, u32, C.POINTER(IpcReplica)]),
+    "apus_gpu_import_replica": (C.c_int, [vp, C.POINTER(IpcReplica)]),
     "apus_gpu_batch_begin": (C.c_int, [vp]),
     "apus_gpu_batch_end": (C.c_int, [vp]),
 }

@@ -36,7 +36,9 @@ struct apus_engine {
     hipStream_t stream;
     bool own_stream;
     uint32_t dir_cap;
-    uint32_t local_mask;            /* replicas hosted here */
+    uint32_t local_mask;            /* replicas hosted here, or peer-mapped (imported) */
+    uint32_t imported_mask;         /* the peer-mapped ones: memory owned by another process */
+    std::vector<void *> ipc_ptrs;    /* hipIpcOpenMemHandle results, closed at destroy */
     uint32_t reachable;             /* peers the leader can post to (trace KILL/HOLD/RELEASE) */
     bool lag_possible;              /* a follower may be far behind: run the wide catch-up first */
     bool tick_pending;              /* a prune tick waits to be fused into the next batch's sequencer */
@@ -155,7 +157,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->dir_cap = pow2_at_least(L / APUS_ENTRY_HDR < 4096 ? 4096 : L / APUS_ENTRY_HDR);
     e->d.dir_mask = e->dir_cap - 1;
     e->d.flags = cfg->flags;
-    e->local_mask = 0;
+    e->local_mask = 0; e->imported_mask = 0;
     e->reachable = (1u << cfg->group_size) - 1;
     e->d.reachable = e->reachable;
     int rc = 0;
@@ -210,6 +212,7 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
     hipStreamSynchronize(e->stream);
     for (auto g : e->graphs) hipGraphExecDestroy(g);
     for (auto &t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    for (void *p : e->ipc_ptrs) hipIpcCloseMemHandle(p);
     for (void *p : e->allocs) hipFree(p);
     if (e->d_req) hipFree(e->d_req);
     if (e->d_req_len) hipFree(e->d_req_len);
@@ -242,7 +245,7 @@ extern "C" int apus_gpu_reset(apus_engine_t *e)
 {
     if (!e) return APUS_E_ARG;
     for (uint32_t i = 0; i < e->d.group_size; i++)
-        if (e->d.rep[i].ring) {
+        if (e->d.rep[i].ring && !((e->imported_mask >> i) & 1u)) {
             /* log_new() zeroes the whole log (dare_log.h:128) */
             HIPCHK(hipMemsetAsync(e->d.rep[i].ring, 0, e->d.log_len + 4096, e->stream));
             HIPCHK(hipMemsetAsync(e->d.rep[i].ack, 0, sizeof(uint32_t) * e->dir_cap, e->stream));
@@ -251,8 +254,57 @@ extern "C" int apus_gpu_reset(apus_engine_t *e)
     e->tick_pending = false;
     e->reachable = (1u << e->d.group_size) - 1;
     e->d.reachable = e->reachable;
-    hipLaunchKernelGGL(k_reset, dim3(e->d.group_size), dim3(64), 0, e->stream, e->d);
+    {
+        /* a peer's replica is reset by the process that hosts it */
+        EngDev own = e->d;
+        for (uint32_t i = 0; i < e->d.group_size; i++) if ((e->imported_mask >> i) & 1u) own.rep[i].ring = nullptr;
+        hipLaunchKernelGGL(k_reset, dim3(e->d.group_size), dim3(64), 0, e->stream, own);
+    }
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+/* ---- peer-mapped replicas (one replica per GPU / process) ------------------------------- */
+extern "C" int apus_gpu_export_replica(apus_engine_t *e, uint32_t replica, apus_ipc_replica_t *out)
+{
+    if (!e || !out || replica >= e->d.group_size) return APUS_E_ARG;
+    if (!((e->local_mask >> replica) & 1u) || ((e->imported_mask >> replica) & 1u)) return APUS_E_STATE;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const RepDev &r = e->d.rep[replica];
+    void *bufs[APUS_IPC_BUFFERS] = { r.ring, r.hdr, r.dir_off, r.dir_len, r.ack, r.apply };
+    static_assert(sizeof(hipIpcMemHandle_t) <= 64, "apus_ipc_replica_t carries 64 bytes per handle");
+    memset(out, 0, sizeof *out);
+    for (uint32_t k = 0; k < APUS_IPC_BUFFERS; k++) {
+        hipIpcMemHandle_t h;
+        HIPCHK(hipIpcGetMemHandle(&h, bufs[k]));
+        memcpy(out->handle[k], &h, sizeof h);
+    }
+    out->log_len = e->d.log_len; out->dir_cap = e->dir_cap; out->replica = replica; out->device = e->cfg.device;
+    return 0;
+}
+
+extern "C" int apus_gpu_import_replica(apus_engine_t *e, const apus_ipc_replica_t *in)
+{
+    if (!e || !in || in->replica >= e->d.group_size) return APUS_E_ARG;
+    if (in->log_len != e->d.log_len || in->dir_cap != e->dir_cap) return APUS_E_ARG;
+    if ((e->local_mask >> in->replica) & 1u) return APUS_E_STATE;          /* hosted here, or imported already */
+    HIPCHK(hipSetDevice(e->cfg.device));
+    void *p[APUS_IPC_BUFFERS];
+    for (uint32_t k = 0; k < APUS_IPC_BUFFERS; k++) {
+        hipIpcMemHandle_t h;
+        memcpy(&h, in->handle[k], sizeof h);
+        if (hipIpcOpenMemHandle(&p[k], h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            fprintf(stderr, "[apus_gpu] hipIpcOpenMemHandle failed for replica %u buffer %u: %s\n", in->replica, k, hipGetErrorString(hipGetLastError()));
+            for (uint32_t j = 0; j < k; j++) hipIpcCloseMemHandle(p[j]);
+            return APUS_E_HIP;
+        }
+    }
+    for (uint32_t k = 0; k < APUS_IPC_BUFFERS; k++) e->ipc_ptrs.push_back(p[k]);
+    RepDev &r = e->d.rep[in->replica];
+    r.ring = (uint8_t *)p[0]; r.hdr = (uint64_t *)p[1]; r.dir_off = (uint64_t *)p[2]; r.dir_len = (uint32_t *)p[3];
+    r.ack = (uint32_t *)p[4]; r.apply = (apus_apply_rec *)p[5]; r.idx = in->replica;
+    e->local_mask |= 1u << in->replica;
+    e->imported_mask |= 1u << in->replica;
     return 0;
 }
 

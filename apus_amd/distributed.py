@@ -324,23 +324,14 @@ def run_trace_group(member: GroupMember, trace):
     member.leader_stop()
 
 
-def bench_group(args):
-    """bench.py --gpus N (N >= 2): N replicas, one per GPU, over RCCL p2p."""
+def bench_group(args, initialised=None):
+    """bench.py --gpus N with APUS_GROUP_TRANSPORT=p2p (or where the devices cannot map each
+    other's memory): N replicas, one per GPU, ranges shipped over RCCL point-to-point."""
     from . import trace as T
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
-    local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29511")
-    # test hooks for a one-GPU box: every rank on device 0, exchange staged through gloo
-    backend = os.environ.get("APUS_DIST_BACKEND", "nccl")
-    if os.environ.get("APUS_DIST_ONE_DEVICE"):
-        local = 0
-    torch.cuda.set_device(local)
-    if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+    if initialised is None:
+        from .peers import init_process_group_from_env
+        initialised = init_process_group_from_env(args.gpus)
+    rank, world, local, backend = initialised
     n = world
     tr = T.steady_trace(n, args.entries, args.payload, 16, args.batch, log_len=T.DEFAULT_LOG, name="C2")
     m = GroupMember(n, rank, 0, local, backend, tr.log_len)

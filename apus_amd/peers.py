@@ -1,0 +1,219 @@
+"""One replica per GPU / process with peer-mapped logs: the data plane of `bench.py --gpus N`.
+
+The reference's followers are passive while the leader replicates: its NIC writes their log,
+`end` and `commit` words in place (src/dare/dare_ibv_rc.c:1465-1643, 1761-1819) once the
+RC_SYN / RC_SYNACK handshake has exchanged MR addresses and rkeys (dare_ibv_ud.c:1098-1380).
+Here rank r hosts replica r in its own GPU's HBM, exports its six buffers as HIP IPC handles
+(apus_gpu_export_replica) and maps everybody else's (apus_gpu_import_replica) -- that exchange,
+once at start-up, is the only thing torch.distributed carries.  From then on the engine of
+whichever rank leads runs the SAME fused kernels as for logical replicas on one device; their
+stores to the followers' rings, directories, control blocks and apply streams are peer stores
+(xGMI between GPUs).  No message, host read-back or host round trip per batch: the followers'
+processes read their own HBM when they want to look (tests: at every quiescent event), and any
+rank can take over as leader from what is in the control blocks (k_set_roles).
+
+Ranks walk one trace together (SPMD).  Only control-plane events synchronise them: ELECT and
+KILL(leader) (a barrier, the election's message exchange in the reference) and the test's check
+points.  ROUND / PRUNE / QUIESCE are carried out by the leader alone."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .engine import Engine, EngineError
+from .trace import DEFAULT_LOG
+
+
+def _gather_bytes(blob: bytes, device) -> list[bytes]:
+    """all_gather of equal-sized byte strings (device tensors on RCCL, host tensors on gloo)."""
+    world = dist.get_world_size()
+    on_dev = dist.get_backend() == "nccl"
+    t = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+    if on_dev:
+        t = t.to(device)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return [bytes(o.cpu().numpy().tobytes()) for o in outs]
+
+
+class PeerMappingUnavailable(EngineError):
+    """some rank could not map a peer's buffers (no IPC / peer access between the devices)"""
+
+
+class PeerMember:
+    """The replica this rank hosts + the mapped replicas of every peer."""
+
+    def __init__(self, group_size: int, rank: int, device_index: int, log_len: int = DEFAULT_LOG, flags: int = 0,
+                 engine_factory=Engine):
+        if dist.get_world_size() != group_size:
+            raise EngineError("one process per replica: world size must equal the group size")
+        self.n, self.rank = group_size, rank
+        self.device = torch.device("cuda", device_index)
+        self.eng = engine_factory(group_size, log_len, local_ids=[rank], device=device_index, flags=flags)
+        self.log_len = log_len
+        L = self.eng.L
+        mine = _lib.IpcReplica()
+        rc_exp = L.apus_gpu_export_replica(self.eng.h, rank, C.byref(mine))
+        blobs = _gather_bytes(bytes(mine), self.device)
+        failed = f"export_replica rc={rc_exp}" if rc_exp else None
+        for r, b in enumerate(blobs):
+            if r == rank or failed:
+                continue
+            h = _lib.IpcReplica.from_buffer_copy(b)
+            rc = L.apus_gpu_import_replica(self.eng.h, C.byref(h)) if h.replica == r else -1
+            if rc:
+                failed = f"import_replica({r}) rc={rc}"
+        # collective verdict (also: every mapping exists before anybody leads)
+        ok = torch.tensor([0 if failed else 1], dtype=torch.int32, device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            self.eng.close()
+            raise PeerMappingUnavailable(failed or "a peer could not map this group's buffers")
+        self.eng.local_ids = list(range(group_size))
+        self.leader = -1
+        self.led = []                       # (first pass, passes) of the round record for every term this rank led
+
+    @property
+    def is_leader(self) -> bool:
+        return self.leader == self.rank
+
+    # ---- control plane: every rank keeps the same view (term, configuration, who answers) ----------
+    def elect(self, winner: int):
+        """ELECT(winner).  The barrier stands for the vote exchange; the previous leader's stream
+        has drained before it (kill / the end of its last call), so the control blocks the winner
+        starts from (k_set_roles) are final."""
+        e = self.eng
+        if self.is_leader:
+            e.sync()
+        dist.barrier()
+        if self.rank == winner:
+            first = len(e.round_record()[0])
+            e.elect(winner)                 # term += 2, blank CONFIG (+ removal of the dead) on the device
+            self.led.append(first)
+        else:
+            if not (e.reachable >> winner) & 1:
+                raise EngineError("the winner of an election must be alive")
+            e.term += 2
+            e.leader = winner
+            e.bitmask &= ~(e.bitmask & ~e.reachable & ~(1 << winner))
+        self.leader = winner
+
+    def kill(self, r: int):
+        e = self.eng
+        if self.is_leader and r != self.rank:
+            e.kill(r)                       # CONFIG entry that removes it
+            return
+        if r == self.leader:
+            if self.is_leader:
+                e.sync()                    # what it had posted is on the wire; nothing more comes
+            self.leader = -1
+            e.leader = -1
+        elif (e.bitmask >> r) & 1 and self.leader >= 0:
+            e.bitmask &= ~(1 << r)
+        e.set_reachable(e.reachable & ~(1 << r))
+
+    def hold(self, r: int): self.eng.hold(r)
+    def release(self, r: int): self.eng.release(r)
+
+    # ---- data plane: the leader only ------------------------------------------------------------
+    def rounds(self, r0: int, n: int):
+        if self.is_leader:
+            self.eng.run_rounds(r0, n)
+
+    def tick_prune(self):
+        if self.is_leader:
+            self.eng.tick_prune()
+
+    def quiesce(self):
+        if self.is_leader:
+            self.eng.quiesce()
+
+    def settle(self):
+        """Check point: the leader's stream has drained, everybody may look at its own replica."""
+        if self.is_leader:
+            self.eng.sync()
+        dist.barrier()
+
+    def close(self):
+        try:
+            self.eng.sync()
+        except EngineError:
+            pass
+        dist.barrier()                      # nobody unmaps / frees while a peer may still write
+        self.eng.close()
+
+
+def walk_trace(m: PeerMember, trace, on_check=None, check_at=("QUIESCE",), max_batch_rounds: int = 4096, batch: bool = False):
+    """Every rank walks the trace; on_check(i, event, member) runs on every rank after settle().
+    batch=True: stretches of ROUND / PRUNE events become one multi-segment launch (apus_gpu_batch_*)."""
+    m.eng.stage_trace(trace)            # any rank may have to lead
+    ev, i = trace.events, 0
+    opened = False
+
+    def b_open():
+        nonlocal opened
+        if batch and m.is_leader and not opened:
+            m.eng.batch_begin(); opened = True
+
+    def b_close():
+        nonlocal opened
+        if opened:
+            m.eng.batch_end(); opened = False
+
+    while i < len(ev):
+        op = ev[i][0]
+        if op == "ROUND":
+            j = i
+            while j < len(ev) and ev[j][0] == "ROUND" and j - i < max_batch_rounds:
+                j += 1
+            b_open()
+            m.rounds(m.eng.round_of_g0[ev[i][1]], j - i)
+            i = j
+            continue
+        if op == "PRUNE" and op not in check_at:
+            b_open()
+        else:
+            b_close()
+        if op == "ELECT":
+            m.elect(ev[i][1])
+        elif op == "PRUNE":
+            m.tick_prune()
+        elif op == "QUIESCE":
+            m.quiesce()
+        elif op == "HOLD":
+            m.hold(ev[i][1])
+        elif op == "RELEASE":
+            m.release(ev[i][1])
+        elif op == "KILL":
+            m.kill(ev[i][1])
+        else:
+            raise EngineError(f"trace event {ev[i]} is not supported")
+        if op in check_at and on_check is not None:
+            m.settle()
+            on_check(i, ev[i], m)
+        i += 1
+    b_close()
+    m.settle()
+
+
+def init_process_group_from_env(gpus: int):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(gpus)))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    # test hooks for a one-GPU box: every rank on device 0, handles exchanged over gloo
+    backend = os.environ.get("APUS_DIST_BACKEND", "nccl")
+    if os.environ.get("APUS_DIST_ONE_DEVICE"):
+        local = 0
+    torch.cuda.set_device(local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local, backend

@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+XGMI_LINK_GBS = 153.0        # one xGMI link (7 per GPU, point to point)
 
 
 def build_trace(args, group_size):
@@ -125,7 +126,7 @@ def cpu_baseline_port(args, seconds=15.0):
                       f"({el:.1f} s, oracle/liboracle.so -O2, {_cpu_model()}, nproc={os.cpu_count()})"}
 
 
-def cpu_baseline_reference(args, seconds=12.0):
+def cpu_baseline_reference(args, seconds=12.0, group_size=3):
     """THE REFERENCE ITSELF: /root/reference/src/dare/*.c compiled unmodified with its own -O0
     (oracle/_ref/libapus_ref_loops.so; the prebuilt library travels to the GPU box), 3 server
     instances on ONE host thread, RDMA = memcpy through the in-process verbs stand-in
@@ -136,10 +137,10 @@ def cpu_baseline_reference(args, seconds=12.0):
     if not refloops.available():
         return None
     sample = min(args.entries, 1 << 17)
-    tr = T.steady_trace(3, sample, args.payload, 16, args.batch, log_len=T.DEFAULT_LOG)
+    tr = T.steady_trace(group_size, sample, args.payload, 16, args.batch, log_len=T.DEFAULT_LOG)
     reqs = np.ascontiguousarray(tr.reqs, dtype=orc.REQ_DTYPE)
     rounds = [(ev[1], ev[2]) for ev in tr.events if ev[0] == "ROUND"]
-    rc = refloops.RefCluster(3, tr.log_len, record_apply=False)
+    rc = refloops.RefCluster(group_size, tr.log_len, record_apply=False)
     try:
         rc.elect(0)
         done, passes, since, t0 = 0, 0, 0, time.perf_counter()
@@ -161,8 +162,8 @@ def cpu_baseline_reference(args, seconds=12.0):
     finally:
         rc.close()
     return {"value": done / el, "unit": "committed entries/s", "cores": 1, "kind": "reference",
-            "sample": f"{passes} x {len(reqs)} entries of the same 3-replica stream ({el:.1f} s; the reference's own "
-                      f"dare_server.c / dare_ibv_rc.c loops, unmodified, -O0 as the reference builds them, 3 servers on "
+            "sample": f"{passes} x {len(reqs)} entries of the same {group_size}-replica stream ({el:.1f} s; the reference's own "
+                      f"dare_server.c / dare_ibv_rc.c loops, unmodified, -O0 as the reference builds them, {group_size} servers on "
                       f"one thread, in-process verbs stand-in; {_cpu_model()}, nproc={os.cpu_count()})"}
 
 
@@ -378,8 +379,116 @@ def bench_single(args):
 
 
 def bench_multi(args):
-    from apus_amd.distributed import bench_group
-    return bench_group(args)
+    """--gpus N (N >= 2): N replicas, one per GPU and process, logs peer-mapped over HIP IPC
+    (apus_amd/peers.py).  The leader (rank 0) runs the same batched step as at N=1; its kernels'
+    stores to the followers' HBM cross xGMI.  The followers are passive (as under one-sided RDMA):
+    they take part in the two timing barriers and afterwards check, from their own memory, that
+    every entry of every step was committed and applied.  APUS_GROUP_TRANSPORT=p2p (or a node
+    whose devices cannot map each other) selects the message-passing transport of
+    apus_amd/distributed.py instead and says so in `config.mode`."""
+    import torch
+    import torch.distributed as dist
+    from apus_amd import peers
+    if os.environ.get("APUS_GROUP_TRANSPORT") == "p2p":
+        from apus_amd.distributed import bench_group
+        return bench_group(args)
+    rank, world, local, backend = peers.init_process_group_from_env(args.gpus)
+    n = world
+    tr = build_trace(args, n)
+    try:
+        m = peers.PeerMember(n, rank, local, tr.log_len)
+    except peers.PeerMappingUnavailable as exc:
+        print(f"[bench] rank {rank}: peer mapping unavailable ({exc}); falling back to the p2p transport", file=sys.stderr)
+        from apus_amd.distributed import bench_group
+        return bench_group(args, initialised=(rank, world, local, backend))
+    eng = m.eng
+    n_entries = len(tr.reqs)
+    red_dev = m.device if backend == "nccl" else torch.device("cpu")
+    calls, gid = None, None
+    m.elect(0)
+    if m.is_leader:
+        eng.stage_trace(tr)
+        calls = step_calls(tr, eng)
+        issue(eng, calls)                        # one eager step: pages in, validates
+        eng.sync(); eng.check_status()
+        if not args.eager:
+            eng.capture_begin(); issue(eng, calls); gid = eng.capture_end()
+
+    def run_step():
+        if gid is not None:
+            eng.graph_launch(gid)
+        else:
+            issue(eng, calls)
+
+    def mark():
+        if m.is_leader:
+            eng.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        return time.perf_counter()
+
+    if m.is_leader:
+        for _ in range(args.warmup):
+            run_step()
+    t0 = mark()
+    if m.is_leader:
+        for _ in range(args.steps):
+            run_step()
+    t1 = mark()
+    t = torch.tensor([t1 - t0], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    # verification, every rank from its own HBM
+    total = (1 + args.warmup + args.steps) * n_entries
+    o = eng.offsets(rank)
+    applied = eng.counters(rank)["highest_rec"] if m.is_leader else int(eng.hdr_words(rank)[16])
+    good = (o["commit"] == o["end"] == o["apply"]) and applied == total and (not m.is_leader or eng.status() == 0)
+    if not good:
+        print(f"[bench] rank {rank}: verification failed: offsets={o} applied={applied} expected={total}", file=sys.stderr)
+    ok = torch.tensor([1.0 if good else 0.0], device=red_dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    out = None
+    if m.is_leader:
+        eng.set_timing(True)
+        for _ in range(args.steps):
+            issue(eng, calls)
+        eng.sync()
+        k_ms, k_launches = eng.kernel_time(0)
+        eng.set_timing(False)
+    m.settle()
+    if rank == 0:
+        E = 64 + args.payload
+        value = n_entries * args.steps / dt
+        k_avg_s = (k_ms / 1e3) / max(k_launches, 1)
+        per_launch = n_entries * args.steps / max(k_launches, 1)
+        link = E * per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+        one_dev = bool(os.environ.get("APUS_DIST_ONE_DEVICE"))
+        out = {
+            "metric": "committed entries/sec", "value": value, "unit": "entries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{n} replicas, one per GPU and process, {n_entries} entries/step of {args.payload} B, "
+                                   f"rounds of {args.batch}, prune tick every 8 MiB, 64 MiB rings",
+                       "mode": ("peer-mapped logs (HIP IPC): the leader's kernels store into the followers' HBM"
+                                + (" -- TEST MODE, every rank on device 0" if one_dev else " over xGMI")
+                                + ("; hipGraph replay of one step" if gid is not None else "; eager launches")),
+                       "replicas": n, "entry_bytes": E, "launches_per_step": len(calls)},
+            "verified": bool(ok.item() == 1),
+            "roofline": {"bound": "xgmi", "achieved": link, "peak": XGMI_LINK_GBS, "unit": "GB/s",
+                         "frac": link / XGMI_LINK_GBS, "traffic": None, "kernel": "k_step" if BATCH else "k_call",
+                         "avg_launch_us": k_avg_s * 1e6, "launches": k_launches, "entries_per_launch": per_launch,
+                         "note": "per leader->follower link: E bytes per entry (log bytes; the 12-B directory slot and 32-B "
+                                 "apply record per entry ride along) over the dominant kernel's launch time, against ONE xGMI link"},
+        }
+        if not args.no_cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline_reference(args, min(args.cpu_seconds, 8.0), group_size=n) or cpu_baseline_port(args, 4.0)
+            except Exception as exc:
+                print(f"[bench] cpu baseline failed: {exc!r}", file=sys.stderr)
+    m.close()
+    dist.destroy_process_group()
+    return out
 
 
 def main():

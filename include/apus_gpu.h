@@ -125,6 +125,31 @@ int  apus_gpu_stage(apus_engine_t *e, const apus_req_t *reqs, uint64_t n,
                     const uint8_t *arena, uint64_t arena_bytes,
                     const uint32_t *round_n, uint64_t n_rounds);
 
+/* ---- one replica per GPU / process: peer-mapped logs ------------------------ */
+/* The reference's followers are passive during replication: the leader's NIC writes their log,
+ * `end` and `commit` in place (one-sided RDMA, src/dare/dare_ibv_rc.c:1465-1643) after the
+ * RC_SYN / RC_SYNACK handshake has told it their MR address and rkey (dare_ibv_ud.c:1098-1380).
+ * Here a process exports the HBM buffers of the replica it hosts as HIP IPC handles and imports
+ * its peers': the leader's kernels then store into the peers' rings, directories, control
+ * blocks and apply streams directly -- over xGMI when the peers sit on other GPUs -- with the
+ * same fused push / ACK / commit path that serves logical replicas on one device, and a follower
+ * process only reads its own memory.  Handles travel between processes by any means (the tests
+ * and bench.py use torch.distributed all_gather). */
+#define APUS_IPC_BUFFERS 6u              /* ring, control block, directory offsets / lengths, ACK words, apply stream */
+typedef struct {
+    uint8_t  handle[APUS_IPC_BUFFERS][64];   /* hipIpcMemHandle_t each */
+    uint64_t log_len;
+    uint32_t dir_cap;
+    uint32_t replica;                         /* group index of the replica */
+    int32_t  device;                          /* HIP device ordinal in the exporting process */
+    uint32_t pad;
+} apus_ipc_replica_t;
+/* replica must be hosted (allocated) by this engine */
+int  apus_gpu_export_replica(apus_engine_t *e, uint32_t replica, apus_ipc_replica_t *out);
+/* maps a peer process's replica; from then on this engine can lead a group that contains it.
+ * The memory stays owned by the exporter (never reset or freed here). */
+int  apus_gpu_import_replica(apus_engine_t *e, const apus_ipc_replica_t *in);
+
 /* ---- control plane (host-driven, ms-scale in the reference) ---------------- */
 /* Role/term change: the caller (host election logic) decided that `leader` won
  * term `term`; appends the blank CONFIG entry a new leader always writes

@@ -376,6 +376,7 @@ int orc_leader(const orc_cluster_t *c) { return c->leader; }
 int orc_group_size(const orc_cluster_t *c) { return c->n; }
 orc_log_t *orc_replica_log(orc_cluster_t *c, int r) { return c->r[r].log; }
 uint64_t orc_replica_sid(const orc_cluster_t *c, int r) { return c->r[r].sid; }
+uint32_t orc_replica_cid_bitmask(const orc_cluster_t *c, int r) { return c->r[r].cid.bitmask; }
 uint64_t orc_replica_highest_rec(const orc_cluster_t *c, int r) { return c->r[r].highest_rec; }
 uint64_t orc_replica_apply_count(const orc_cluster_t *c, int r) { return c->r[r].apply_count; }
 uint64_t orc_replica_apply_hash(const orc_cluster_t *c, int r) { return c->r[r].apply_hash; }

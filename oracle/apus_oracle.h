@@ -126,6 +126,7 @@ int        orc_leader(const orc_cluster_t *c);
 int        orc_group_size(const orc_cluster_t *c);
 orc_log_t *orc_replica_log(orc_cluster_t *c, int r);
 uint64_t   orc_replica_sid(const orc_cluster_t *c, int r);
+uint32_t   orc_replica_cid_bitmask(const orc_cluster_t *c, int r);   /* SID.cid.bitmask: the configured servers */
 uint64_t   orc_replica_highest_rec(const orc_cluster_t *c, int r);
 uint64_t   orc_replica_apply_count(const orc_cluster_t *c, int r);
 uint64_t   orc_replica_apply_hash(const orc_cluster_t *c, int r);

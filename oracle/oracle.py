@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
             "orc_group_size": (C.c_int, [vp]),
             "orc_replica_log": (vp, [vp, C.c_int]),
             "orc_replica_sid": (u64, [vp, C.c_int]),
+            "orc_replica_cid_bitmask": (C.c_uint32, [vp, C.c_int]),
             "orc_replica_highest_rec": (u64, [vp, C.c_int]),
             "orc_replica_apply_count": (u64, [vp, C.c_int]),
             "orc_replica_apply_hash": (u64, [vp, C.c_int]),
@@ -338,6 +339,7 @@ class Cluster:
         return lg
 
     def sid(self, r): return int(self.L.orc_replica_sid(self.h, r))
+    def cid_bitmask(self, r): return int(self.L.orc_replica_cid_bitmask(self.h, r))
     def term(self, r): return self.sid(r) >> 9
     def highest_rec(self, r): return int(self.L.orc_replica_highest_rec(self.h, r))
     def apply_count(self, r): return int(self.L.orc_replica_apply_count(self.h, r))

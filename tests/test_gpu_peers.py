@@ -1,0 +1,66 @@
+"""One process per replica with peer-mapped logs (apus_amd/peers.py, the `bench.py --gpus N`
+data plane) against the oracle: steady state, hold / release, no quorum, fail-over of the leader
+PROCESS (BASELINE config 5: another rank takes over from what is in the control blocks), exact
+fit.  Worker: tests/_peer_worker.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_group(world, name, mode="per-call", flags=0, timeout=420):
+    out = os.path.join(tempfile.mkdtemp(), "res")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "_peer_worker.py"), out, name, mode, str(flags)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", APUS_DIST_BACKEND="gloo", APUS_DIST_ONE_DEVICE="1")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    res = [json.load(open(f"{out}.{r}")) for r in range(world) if os.path.exists(f"{out}.{r}")]
+    for r in res:
+        assert r["ok"], f"rank {r['rank']}: {r.get('error')}"
+    assert len(res) == world, f"{world - len(res)} ranks produced no result\n{p.stdout[-2000:]}\n{p.stderr[-3000:]}"
+    assert len({r["end"] for r in res if "end" in r}) >= 1
+    return res
+
+
+@pytest.mark.parametrize("name,world", [("steady3", 3), ("steady5_unaligned", 5), ("exact_fit", 3)])
+def test_peer_mapped_group_matches_oracle(name, world):
+    res = run_group(world, name)
+    assert all(r["checks"] > 2 for r in res)
+    assert [r["led"] for r in res] == [1] + [0] * (world - 1)
+
+
+def test_peer_mapped_group_batched_launches():
+    run_group(7, "steady7_mixed", mode="batched")
+
+
+@pytest.mark.parametrize("name,world", [("hold_release", 5), ("no_quorum_wide", 3), ("kill_follower", 5)])
+def test_peer_mapped_group_failures(name, world):
+    run_group(world, name)
+
+
+def test_peer_mapped_leader_process_fails_over():
+    """config 5: the leader rank stops, rank 1 is elected and leads from its own process; later a
+    follower is removed (benchmarks/reconf_bench.sh:249-343)"""
+    res = run_group(5, "c5_failover")
+    assert [r["led"] for r in res] == [1, 1, 0, 0, 0]
+
+
+def test_peer_mapped_ack_aggregation_path():
+    """per-entry ACK words + quorum scan (APUS_F_NO_FUSED_ACKS) across processes"""
+    run_group(3, "steady3", flags=1)

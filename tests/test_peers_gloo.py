@@ -1,0 +1,172 @@
+"""CPU, gloo, world size 2 and 5: the host side of the peer-mapped group (apus_amd/peers.py)
+with a stand-in for the device engine.  Checked: the handle exchange (every rank imports exactly
+the blob every other rank exported), that only the current leader issues data-plane calls, and
+that every rank's view of the control plane (term, configuration bitmask, who answers, leader)
+follows the oracle's through elections, a leader fail-over and a follower removal (BASELINE
+config 5).  The device side of the same walk is tests/test_gpu_peers.py."""
+import ctypes as C
+import os
+import socket
+
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakeLib:
+    def __init__(self, eng):
+        self.eng = eng
+
+    def apus_gpu_export_replica(self, h, replica, out):
+        o = out._obj
+        o.replica, o.log_len, o.dir_cap, o.device = replica, self.eng.log_len, 4096, 0
+        for k in range(6):
+            for b in range(64):
+                o.handle[k][b] = (replica * 37 + k * 7 + b) & 0xFF
+        return 0
+
+    def apus_gpu_import_replica(self, h, inp):
+        o = inp._obj
+        self.eng.imported[o.replica] = bytes(o)
+        return 0
+
+
+class _FakeEngine:
+    """records what the host asks of the device; control-plane bookkeeping as in apus_amd/engine.py"""
+
+    def __init__(self, group_size, log_len, local_ids=None, device=0, flags=0):
+        from apus_amd.engine import Engine
+        self.group_size, self.log_len, self.local_ids = group_size, log_len, list(local_ids)
+        self.h = None
+        self.L = _FakeLib(self)
+        self.imported = {}
+        self.calls = []
+        self.leader, self.term = -1, 0
+        self.bitmask = self.reachable = (1 << group_size) - 1
+        self.round_of_g0 = {}
+        self._elect, self._kill = Engine.elect, Engine.kill
+        self.n_passes = 0
+
+    def _chk(self, rc, what):
+        assert rc == 0, what
+
+    def stage_trace(self, tr):
+        rounds = [(ev[1], ev[2]) for ev in tr.events if ev[0] == "ROUND"]
+        self.round_of_g0 = {g0: i for i, (g0, _) in enumerate(rounds)}
+
+    def elect(self, w): self._elect(self, w)
+    def kill(self, r): self._kill(self, r)
+    def set_reachable(self, mask): self.reachable = mask
+    def hold(self, r): self.set_reachable(self.reachable & ~(1 << r))
+    def release(self, r): self.set_reachable(self.reachable | (1 << r))
+    def append_control(self, t, data=None): self.calls.append(("control", t))
+    def _cid_bytes(self): return b"\0" * 16
+    def run_rounds(self, r0, n): self.calls.append(("rounds", r0, n)); self.n_passes += n
+    def tick_prune(self): self.calls.append(("prune",))
+    def quiesce(self): self.calls.append(("quiesce",))
+    def sync(self): self.calls.append(("sync",))
+    def round_record(self): return [0] * self.n_passes, [0] * self.n_passes
+    def close(self): pass
+
+    # Engine.elect calls the C ABI through these two
+    class _L:
+        pass
+
+
+def _worker(rank, world, port, name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from apus_amd import _lib, peers
+        from oracle import oracle as orc
+        from tests import traces
+
+        tr = traces.CATALOGUE[name]()
+        assert tr.group_size == world
+
+        def factory(n, log_len, local_ids=None, device=0, flags=0):
+            e = _FakeEngine(n, log_len, local_ids, device, flags)
+            e.L.apus_gpu_become_leader_ex = lambda h, w, term, bm, dead: (e.calls.append(("lead", w, term, bm, dead)), 0)[1]
+            e.L.apus_gpu_set_reachable = lambda h, m: 0
+            return e
+
+        m = peers.PeerMember(world, rank, 0, tr.log_len, engine_factory=factory)
+        # the exchange: everybody else's blob, byte for byte
+        for r in range(world):
+            if r == rank:
+                assert r not in m.eng.imported
+                continue
+            want = _lib.IpcReplica()
+            m.eng.L.apus_gpu_export_replica(None, r, C.byref(want))
+            assert m.eng.imported[r] == bytes(want), f"rank {rank}: blob of replica {r} arrived damaged"
+
+        cl = orc.Cluster(world, tr.log_len)
+        reqs = np.ascontiguousarray(tr.reqs, dtype=orc.REQ_DTYPE)
+        pos = 0
+        led_calls = {}
+
+        def check(i, ev, mm):
+            nonlocal pos
+            while pos <= i and pos < len(tr.events):
+                e = tr.events[pos]
+                if e[0] == "ROUND":
+                    cl.round(reqs[e[1]:e[1] + e[2]], tr.arena)
+                else:
+                    getattr(cl, {"ELECT": "elect", "KILL": "kill", "PRUNE": "tick_prune", "QUIESCE": "quiesce",
+                                 "HOLD": "hold", "RELEASE": "release"}[e[0]])(*e[1:])
+                pos += 1
+            assert mm.leader == cl.leader, f"rank {rank} event {i}: leader {mm.leader} vs {cl.leader}"
+            if cl.leader >= 0:
+                sid = cl.sid(cl.leader)
+                assert mm.eng.term == sid >> 9, f"rank {rank} event {i}: term {mm.eng.term} vs {sid >> 9}"
+                assert mm.eng.bitmask == cl.cid_bitmask(cl.leader), f"rank {rank} event {i}: configuration"
+            data = [c for c in mm.eng.calls if c[0] in ("rounds", "prune", "quiesce", "control", "lead")]
+            led_calls[i] = (mm.is_leader, len(data))
+
+        peers.walk_trace(m, tr, on_check=check, check_at=("QUIESCE", "PRUNE", "ELECT", "KILL"))
+        data = [c for c in m.eng.calls if c[0] in ("rounds", "prune", "quiesce", "control")]
+        if not m.led:
+            assert not data, f"rank {rank} never led but issued {data[:3]}"
+        else:
+            assert any(c[0] == "rounds" for c in data)
+        q.put((rank, True, len(m.led), sum(c[2] for c in data if c[0] == "rounds")))
+        m.close()
+    except BaseException as exc:      # noqa: BLE001
+        import traceback
+        q.put((rank, False, repr(exc) + traceback.format_exc()[-1200:], 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("steady3", 3), ("c5_failover", 5), ("hold_release", 5)])
+def test_peer_group_host_logic(name, world):
+    from oracle import oracle as orc
+    if not hasattr(orc.Cluster, "cid_bitmask"):
+        pytest.skip("oracle without cid accessor")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    for r in sorted(res):
+        assert r[1], f"rank {r[0]}: {r[2]}"
+    from tests import traces
+    tr = traces.CATALOGUE[name]()
+    n_rounds = sum(1 for e in tr.events if e[0] == "ROUND")
+    assert sum(r[3] for r in res) == n_rounds            # every round was run by exactly one rank
+    if name == "c5_failover":
+        assert [r[2] for r in sorted(res)] == [1, 1, 0, 0, 0]

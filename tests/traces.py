@@ -95,3 +95,15 @@ def park_commit_at_wrap():
 CATALOGUE = {f.__name__: f for f in (steady3, steady5_unaligned, steady7_mixed, c2_small, c3_small, c4_small,
                                      c5_failover, hold_one_of_three, hold_release, no_quorum, no_quorum_prune,
                                      exact_fit, kill_follower, park_commit_at_wrap)}
+
+
+def no_quorum_wide():
+    """no_quorum in a ring twice as big: stays below the 75 % fill at which the reference's
+    force_log_pruning (dare_server.c:2069) evicts the slow followers -- the engine has no
+    eviction, so its tests keep clear of it"""
+    tr = T.steady_trace(3, 400, 64, 4, 16, log_len=1 << 17, name="no_quorum_wide")
+    return _with_events(tr, {5: [("HOLD", 1), ("HOLD", 2)], 12: [("RELEASE", 1), ("QUIESCE",)]}, drop_prune=True)
+
+
+# traces for the GPU tests only (not part of the golden records written from the reference)
+EXTRA = {f.__name__: f for f in (no_quorum_wide,)}
