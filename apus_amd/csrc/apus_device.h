@@ -203,7 +203,17 @@ __device__ static inline uint4 ld16u(const uint8_t *p)
     const apus_v4 v = *(const APUS_GLOBAL apus_v4_u *)(uintptr_t)p;
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+/* Log bytes, directory slots and apply records are written once and not read back by the launch
+ * that writes them: streaming (non-temporal) stores.  Written back at the end of the kernel instead,
+ * the dirty lines of a 200 MB launch cost ~7 us of every k_step launch (profiles/README.md).
+ * -DAPUS_NO_NT_STORES: plain stores, for comparison. */
+#ifndef APUS_NO_NT_STORES
+__device__ static inline void st16u(uint8_t *p, uint4 v) { __builtin_nontemporal_store(apus_v4{v.x, v.y, v.z, v.w}, (APUS_GLOBAL apus_v4_u *)(uintptr_t)p); }
+template <typename T> __device__ static inline void gst_nt(T *p, T v) { __builtin_nontemporal_store(v, (APUS_GLOBAL T *)(uintptr_t)p); }
+#else
 __device__ static inline void st16u(uint8_t *p, uint4 v) { *(APUS_GLOBAL apus_v4_u *)(uintptr_t)p = apus_v4{v.x, v.y, v.z, v.w}; }
+template <typename T> __device__ static inline void gst_nt(T *p, T v) { *(APUS_GLOBAL T *)(uintptr_t)p = v; }
+#endif
 __device__ static inline uint64_t ld8u(const uint8_t *p) { return *(const APUS_GLOBAL apus_u64_u *)(uintptr_t)p; }
 /* naturally aligned words / records in device memory */
 template <typename T> __device__ static inline void gst(T *p, T v) { *(APUS_GLOBAL T *)(uintptr_t)p = v; }

@@ -52,6 +52,7 @@ struct apus_engine {
     uint64_t sp_units;                         /* APUS_SP_UNITS (default 768), see call_args */
     uint32_t gp_rounds;                        /* APUS_GP_ROUNDS (default 4; 1 = one workgroup per round), see call_args */
     uint64_t gp_max_units;                     /* APUS_GP_MAX_UNITS: largest mean round (16-byte units) that is grouped */
+    uint32_t step_slots;                       /* workgroups of k_step the device holds at once (occupancy x CUs) */
     struct BatchSeg { CallArgs a; uint32_t blocks; uint64_t bytes; };
     std::vector<BatchSeg> batch;               /* recorded calls: arguments, blocks, bytes they append */
     /* graphs */
@@ -139,6 +140,17 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
         e->gp_rounds = (gp_env && atoi(gp_env) > 0) ? (uint32_t)atoi(gp_env) : APUS_GP;
         const char *gu_env = getenv("APUS_GP_MAX_UNITS");
         e->gp_max_units = (gu_env && atoi(gu_env) > 0) ? (uint64_t)atoi(gu_env) : 1024;
+    }
+    {
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        e->step_slots = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_step, 256, 0) == hipSuccess &&
+            hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && per_cu > 0)
+            e->step_slots = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+        if (getenv("APUS_DEBUG")) fprintf(stderr, "[apus_gpu] k_step: %d workgroups per CU, %u slots\n", per_cu, e->step_slots);
+        const char *so_env = getenv("APUS_STEP_ORDER");          /* 0: always segment by segment */
+        if (so_env && atoi(so_env) == 0) e->step_slots = 0;
     }
     e->n_reqs = 0; e->n_rounds_staged = 0;
     e->d_req = e->d_req_len = e->d_arena = e->d_round_first = e->d_round_prefix = nullptr;
@@ -485,17 +497,54 @@ static int flush_batch(apus_engine *e)
         uint32_t blk = 0;
         uint64_t bytes = 0;
         uint32_t k = 0;
+        /* A launch whose append workgroups are all resident at once issues every load before anybody
+         * stores and then runs at the HBM roofline (append_group); one that is bigger than the device
+         * does not.  So: as many segments as fit with APUS_GD rounds per wavefront, then as few rounds
+         * per wavefront as still fit (more wavefronts in flight for a small launch). */
+        auto grouped_blocks = [](const CallArgs &a, uint32_t gd) { return a.GP > 1 ? (a.R + APUS_GP * gd - 1) / (APUS_GP * gd) : a.R * a.SP; };
+        auto svc_of = [](const apus_engine::BatchSeg &g) { return g.blocks - 2 - call_append_blocks(g.a); };
+        const bool fit_ok = !e->p_running && e->step_slots > 0;
+        uint32_t fit_app = 0, fit_svc = 0;
         while (i + k < e->batch.size() && k < APUS_STEP_SEGS) {
             const apus_engine::BatchSeg &g = e->batch[i + k];
             if (k && bytes + g.bytes + APUS_HDR > lap) break;
+            const uint32_t nab = grouped_blocks(g.a, APUS_GD), ms = std::max(fit_svc, svc_of(g));
+            if (k && fit_ok && 2 * (k + 1) + fit_app + nab + ms > e->step_slots && 2 * k + fit_app + fit_svc <= e->step_slots) break;
+            fit_app += nab; fit_svc = ms;
             T.seg[k] = g.a;
-            T.blk0[k] = blk;
-            blk += g.blocks;
             bytes += g.bytes + APUS_HDR;
             k++;
         }
         T.S = k;
+        uint32_t gd = 1;
+        for (; gd < APUS_GD; gd++) {
+            uint32_t n_app = 0;
+            for (uint32_t j = 0; j < k; j++) n_app += grouped_blocks(T.seg[j], gd);
+            if (fit_ok && 2 * k + n_app + fit_svc <= e->step_slots) break;
+        }
+        if (!fit_ok) gd = 1;
+        uint32_t n_app = 0;
+        for (uint32_t j = 0; j < k; j++) {
+            if (T.seg[j].GP > 1) T.seg[j].GP = APUS_GP * gd;
+            const uint32_t nab = call_append_blocks(T.seg[j]);
+            T.blk0[j] = blk;
+            blk += 2 + nab + svc_of(e->batch[i + j]);
+            n_app += nab;
+        }
         T.blk0[k] = blk;
+        {
+            /* append blocks first, if all of them + the single blocks + any one segment's other blocks
+             * fit on the device at once (and nothing else of this engine occupies it) */
+            T.order = (k > 1 && fit_ok && 2 * k + n_app + fit_svc <= e->step_slots) ? 1u : 0u;
+            if (getenv("APUS_DEBUG")) fprintf(stderr, "[apus_gpu] k_step launch: %u segments, %u append blocks (%u rounds per wavefront), %u blocks, order %u\n", k, n_app, gd, blk, T.order);
+            uint32_t ab = 2 * k, sv = 2 * k + n_app;
+            for (uint32_t j = 0; j < k; j++) {
+                const uint32_t nab = call_append_blocks(T.seg[j]);
+                T.ab0[j] = ab; T.sv0[j] = sv;
+                ab += nab; sv += (T.blk0[j + 1] - T.blk0[j]) - 2 - nab;
+            }
+            T.ab0[k] = ab; T.sv0[k] = sv;
+        }
         TimedLaunch *tl = nullptr;
         if (e->timing && !e->capturing) {
             if (e->timed_used == e->timed.size()) {

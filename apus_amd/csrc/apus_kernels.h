@@ -71,7 +71,7 @@ struct CallEnv {
 #define APUS_ENV_OF(E) CallEnv{(E).tick_lines, (E).ticket, (E).round_hash}
 
 /* E.ticket words */
-enum { T_APPLY = 1, T_PASS = 2, T_SCAN = 3, T_DONE = 4 };
+enum { T_APPLY = 1, T_PASS = 2, T_SCAN = 3, T_DONE = 4, T_JANITORS = 8 /* segment 0's block only: janitors of a launch that are through */ };
 
 __device__ static inline uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
 
@@ -663,28 +663,35 @@ __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask,
  * block after the call, q.out, q.end_new, q.ok = 1) and returns 1; returns 0 with q untouched when
  * any precondition fails -- then the general single-lane path decides.  The single-lane path costs
  * ~2.6 us of dependent LDS round trips per segment on the launch's critical chain. */
-__device__ static inline uint64_t wave_max_u64(uint64_t v)
+/* The same sequencing on REGISTERS: the chain block's first wavefront runs it for every segment of
+ * a launch before anything else (the record pass), so it must not queue behind the append blocks
+ * that share its CU -- no LDS, no memory access except the staged byte prefix of a batch that wraps.
+ * Scalars are wave-uniform; apoff / f_* are per lane (lane = server). */
+struct ChainRegs {
+    uint64_t end, n_end, last_idx, sid, commit, n_commit, n_apply, apply, head, tail, prev_head, store_count, rec_base;
+    uint32_t bitmask;
+    uint64_t apoff, f_apply, f_np, f_na;         /* per lane */
+};
+struct ChainSeg { uint64_t r0, pfx0, pfx2, len_last; uint32_t rf0, rf1, R, tick; };
+struct ChainOut {
+    uint64_t e0, idx0, n_end0, w, end_new, hd, sc, my_apoff /* per lane */;
+    int64_t kstar, estar;
+    uint32_t stale, head_round, n;
+};
+__device__ static inline uint64_t rl64(uint64_t v, uint32_t l)
 {
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) { const uint64_t o = __shfl_xor(v, d, WAVE); v = o > v ? o : v; }
-    return v;
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l) << 32);
 }
-__device__ static inline int chain_decide_fast(const EngDev &E, uint32_t push_mask, uint32_t tick, SeqLds &q, uint64_t r0, uint32_t R)
+__device__ static inline int chain_core(const EngDev &E, uint32_t push_mask, const ChainRegs &c, const ChainSeg &g, ChainOut &o)
 {
     const uint32_t lane = lane_id();
     const uint64_t L = E.log_len;
     const uint32_t size = E.group_size, leader = E.leader;
     const bool srv = lane < APUS_DEV_MAX_SERVERS;
-    /* one batch of LDS reads */
-    const uint64_t end = q.lh[H_END], n_end = q.lh[H_N_END], last_idx = q.lh[H_LAST_IDX], sid = q.lh[H_SID];
-    const uint64_t commit = q.lh[H_COMMIT], n_commit = q.lh[H_N_COMMIT], n_apply = q.lh[H_N_APPLY], apply = q.lh[H_APPLY];
-    const uint64_t head = q.lh[H_HEAD], tail = q.lh[H_TAIL], prev_head = q.lh[H_PREV_HEAD], store_count = q.lh[H_STORE_COUNT];
-    const uint32_t bitmask = (uint32_t)q.lh[H_CID_BITMASK];
-    const uint64_t apoff = srv ? q.lh[H_APPLY_OFFSETS + lane] : 0;
-    const uint64_t f_apply = srv ? q.fw[lane][2] : 0, f_np = srv ? q.fw[lane][3] : 0, f_na = srv ? q.fw[lane][4] : 0;
-    const uint64_t vtot = q.pfx[2] - q.pfx[0];
-    const uint32_t n = q.rfx[1] - q.rfx[0];
-    const uint64_t rec_base = q.misc[0], len_last = q.misc[1];
+    const uint64_t end = c.end, n_end = c.n_end;
+    const uint64_t vtot = g.pfx2 - g.pfx0;
+    const uint32_t n = g.rf1 - g.rf0, R = g.R;
 
     /* in step (seq_in_step), a fused majority (seq_flags), clear of len, not full */
     const bool pushed = srv && ((push_mask >> lane) & 1u);
@@ -693,29 +700,28 @@ __device__ static inline int chain_decide_fast(const EngDev &E, uint32_t push_ma
     /* (a batch that may reach the end of the ring is placed below; one that is longer than the
      * ring, or an empty log, goes the general way) */
     const bool pre = !(E.flags & 1u) && end != L && L - end >= APUS_HDR && vtot + APUS_HDR < L && n > 0 && R <= 1024 && quorum &&
-                     n_commit == n_end && n_apply == n_end && end != head;
-    if (!pre || !__all(!pushed || (f_np == n_end && f_na == n_end))) return 0;
+                     c.n_commit == n_end && c.n_apply == n_end && end != c.head;
+    if (!pre || !__all(!pushed || (c.f_np == n_end && c.f_na == n_end))) return 0;
 
-    uint64_t e = end, ne = n_end, li = last_idx, hd = head, tl = tail, sc = store_count;
+    uint64_t e = end, ne = n_end, li = c.last_idx, hd = c.head, tl = c.tail, sc = c.store_count;
     uint32_t head_round = 0;
-    uint64_t my_apoff = apoff;
-    if (tick) {
+    uint64_t my_apoff = c.apoff;
+    if (g.tick) {
         /* log_pruning: the offset that lags most (largest distance to end); a server that is OFF counts as apply */
         const bool in_grp = lane < size;
-        const bool on = in_grp && ((bitmask >> lane) & 1u);
-        if (in_grp && !on) my_apoff = apply;
+        const bool on = in_grp && ((c.bitmask >> lane) & 1u);
+        if (in_grp && !on) my_apoff = c.apply;
         const uint64_t dist = in_grp ? apus_end_distance(e, L, my_apoff) : 0;
-        uint64_t D = wave_max_u64(dist);
-        const uint64_t d_apply = apus_end_distance(e, L, apply);
-        if (d_apply > D) D = d_apply;
+        uint64_t D = apus_end_distance(e, L, c.apply);
+        for (uint32_t i = 0; i < size; i++) { const uint64_t di = rl64(dist, i); if (di > D) D = di; }
         uint64_t min_off = (D <= e) ? e - D : e + L - D;
         if (D == 0) min_off = tl;                                        /* leave one entry, :2038-2041 */
-        if (apus_is_larger(e, L, min_off, hd) && !prev_head) {
+        if (apus_is_larger(e, L, min_off, hd) && !c.prev_head) {
             hd = min_off;                                                /* <HEAD, head>: 64 bytes at end (no wrap: pre) */
             tl = e; e += APUS_HDR; ne += 1; li += 1; sc += 1; head_round = 1;
         }
         /* rc_get_remote_apply_offsets for the next tick (sample_into_copy) */
-        if (in_grp) { if (lane == leader || !on) my_apoff = apply; else if (pushed) my_apoff = f_apply; }
+        if (in_grp) { if (lane == leader || !on) my_apoff = c.apply; else if (pushed) my_apoff = c.f_apply; }
     }
     if (e == L) return 0;            /* the <HEAD> entry ended exactly on len: the log reads as empty, general path */
     const uint64_t e0 = e, idx0 = li + 1, n_end0 = ne;
@@ -725,10 +731,10 @@ __device__ static inline int chain_decide_fast(const EngDev &E, uint32_t push_ma
     int64_t kstar = -1, estar = -1;
     uint64_t w = 0;
     uint32_t stale = 0;
-    if (e0 + vtot > L || (e0 + vtot == L)) {
+    if (e0 + vtot >= L) {
         if (e0 + vtot == L) return 0;                                    /* ends exactly on len: hidden round, general path */
-        const uint64_t *pf = E.round_prefix + r0;
-        const uint64_t p0 = q.pfx[0];
+        const uint64_t *pf = E.round_prefix + g.r0;
+        const uint64_t p0 = g.pfx0;
         const uint32_t step = (R + WAVE - 1) / WAVE;                     /* <= 16 */
         const uint32_t ra = min(R, lane * step);
         const uint64_t va = gld(&pf[ra]) - p0;
@@ -738,33 +744,70 @@ __device__ static inline int chain_decide_fast(const EngDev &E, uint32_t push_ma
         const uint64_t vb = inb ? gld(&pf[rb]) - p0 : ~0ull;
         const uint32_t cnt = (uint32_t)__popcll(__ballot(inb && rb < R && e0 + vb <= L));
         const uint32_t rstar = blk * step + cnt - 1u;                    /* last round that starts at or before len */
-        const uint64_t vstar = __shfl(vb, (int)(cnt - 1u), WAVE);
-        const uint32_t g_lo = gld(&E.round_first[r0 + rstar]), g_hi = gld(&E.round_first[r0 + rstar + 1]);
-        const uint32_t g0 = q.rfx[0];
+        const uint64_t vstar = rl64(vb, cnt - 1u);
+        const uint32_t g_lo = gld(&E.round_first[g.r0 + rstar]), g_hi = gld(&E.round_first[g.r0 + rstar + 1]);
+        const uint32_t g0 = g.rf0;
         const bool act = lane < g_hi - g_lo;
         const uint64_t Te = act ? APUS_HDR + (uint64_t)gld(&E.req_len[g_lo + lane]) : 0;
         const uint64_t a = e0 + vstar + wave_incl_scan(Te) - Te;
         const unsigned long long hit = __ballot(act && a + Te > L);
         if (!hit) return 0;                                              /* (cannot happen: the totals say it wraps) */
         const int hl = __builtin_ctzll(hit);
-        const uint64_t aw = __shfl(a, hl, WAVE);
+        const uint64_t aw = rl64(a, (uint32_t)hl);
         kstar = (int64_t)(g_lo - g0) + hl; w = aw;
         if (aw == L) estar = kstar;                                      /* empty encoding: idx restarts, dare_log.h:486-488 */
         else if (L - aw >= APUS_HDR) stale = 1;                          /* header fitted, payload did not, :521-537 */
         if (e0 + vtot - w >= L) return 0;                                /* a second wrap, or the batch ends on len: general path */
     }
-    const uint64_t end_new = (kstar < 0) ? e0 + vtot : e0 + vtot - w;
+    o.e0 = e0; o.idx0 = idx0; o.n_end0 = n_end0; o.w = w; o.kstar = kstar; o.estar = estar; o.stale = stale;
+    o.end_new = (kstar < 0) ? e0 + vtot : e0 + vtot - w;
+    o.hd = hd; o.sc = sc; o.my_apoff = my_apoff; o.head_round = head_round; o.n = n;
+    return 1;
+}
+/* the state after a segment that chain_core sequenced: the control words as the sequencer leaves
+ * them, then what keeper_publish does to them in step (everything visible is committed and applied
+ * on every pushed replica) */
+__device__ static inline void chain_advance(const EngDev &E, uint32_t push_mask, ChainRegs &c, const ChainSeg &g, const ChainOut &o)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t vis = o.n_end0 + o.n;
+    c.end = o.end_new; c.tail = o.end_new - (APUS_HDR + g.len_last); c.n_end = vis;
+    c.last_idx = (o.estar < 0) ? o.idx0 + o.n - 1 : 1 + (uint64_t)(o.n - 1 - o.estar);
+    c.prev_head = 0; c.store_count = o.sc + o.n; c.head = o.hd;
+    if (g.tick && lane < E.group_size) c.apoff = o.my_apoff;
+    c.commit = o.end_new; c.n_commit = vis; c.apply = o.end_new; c.n_apply = vis;
+    if (lane < APUS_DEV_MAX_SERVERS && ((push_mask >> lane) & 1u)) { c.f_np = vis; c.f_na = vis; c.f_apply = o.end_new; }
+    c.rec_base += g.R + o.head_round;
+}
+/* LDS form (the chain block's second pass, and the single source of the logic above) */
+__device__ static inline int chain_decide_fast(const EngDev &E, uint32_t push_mask, uint32_t tick, SeqLds &q, uint64_t r0, uint32_t R)
+{
+    const uint32_t lane = lane_id();
+    const bool srv = lane < APUS_DEV_MAX_SERVERS;
+    ChainRegs c;
+    /* one batch of LDS reads */
+    c.end = q.lh[H_END]; c.n_end = q.lh[H_N_END]; c.last_idx = q.lh[H_LAST_IDX]; c.sid = q.lh[H_SID];
+    c.commit = q.lh[H_COMMIT]; c.n_commit = q.lh[H_N_COMMIT]; c.n_apply = q.lh[H_N_APPLY]; c.apply = q.lh[H_APPLY];
+    c.head = q.lh[H_HEAD]; c.tail = q.lh[H_TAIL]; c.prev_head = q.lh[H_PREV_HEAD]; c.store_count = q.lh[H_STORE_COUNT];
+    c.bitmask = (uint32_t)q.lh[H_CID_BITMASK];
+    c.apoff = srv ? q.lh[H_APPLY_OFFSETS + lane] : 0;
+    c.f_apply = srv ? q.fw[lane][2] : 0; c.f_np = srv ? q.fw[lane][3] : 0; c.f_na = srv ? q.fw[lane][4] : 0;
+    c.rec_base = q.misc[0];
+    ChainSeg g;
+    g.r0 = r0; g.pfx0 = q.pfx[0]; g.pfx2 = q.pfx[2]; g.len_last = q.misc[1]; g.rf0 = q.rfx[0]; g.rf1 = q.rfx[1]; g.R = R; g.tick = tick;
+    ChainOut o;
+    if (!chain_core(E, push_mask, c, g, o)) return 0;
     if (lane == 0) {
-        q.lh[H_END] = end_new; q.lh[H_TAIL] = end_new - (APUS_HDR + len_last); q.lh[H_N_END] = n_end0 + n;
-        q.lh[H_LAST_IDX] = (estar < 0) ? idx0 + n - 1 : 1 + (uint64_t)(n - 1 - estar); q.lh[H_PREV_HEAD] = 0; q.lh[H_OLD_END] = end_new;
-        q.lh[H_N_PERSIST] = n_end0 + n; q.lh[H_STORE_COUNT] = sc + n; q.lh[H_HEAD] = hd;
+        q.lh[H_END] = o.end_new; q.lh[H_TAIL] = o.end_new - (APUS_HDR + g.len_last); q.lh[H_N_END] = o.n_end0 + o.n;
+        q.lh[H_LAST_IDX] = (o.estar < 0) ? o.idx0 + o.n - 1 : 1 + (uint64_t)(o.n - 1 - o.estar); q.lh[H_PREV_HEAD] = 0; q.lh[H_OLD_END] = o.end_new;
+        q.lh[H_N_PERSIST] = o.n_end0 + o.n; q.lh[H_STORE_COUNT] = o.sc + o.n; q.lh[H_HEAD] = o.hd;
         SeqOut &s = q.out;
-        s.e0 = e0; s.idx0 = idx0; s.w = w; s.n_end0 = n_end0; s.term = sid >> 9; s.kstar = kstar; s.estar = estar; s.stale = stale;
-        s.n = n; s.head_round = head_round; s.pad0 = 0; s.first_fail = ~0ull; s.commit_before = commit; s.n_commit_before = n_commit;
-        s.vis = n_end0 + n; s.scan_lo = n_commit; s.fuse_mask = push_mask; s.tail_needed = 0; s.fast = 1; s.pad1 = 0; s.rec_base = rec_base;
-        q.end_new = end_new; q.my_virt = q.pfx[1] - q.pfx[0]; q.ok = 1;
+        s.e0 = o.e0; s.idx0 = o.idx0; s.w = o.w; s.n_end0 = o.n_end0; s.term = c.sid >> 9; s.kstar = o.kstar; s.estar = o.estar; s.stale = o.stale;
+        s.n = o.n; s.head_round = o.head_round; s.pad0 = 0; s.first_fail = ~0ull; s.commit_before = c.commit; s.n_commit_before = c.n_commit;
+        s.vis = o.n_end0 + o.n; s.scan_lo = c.n_commit; s.fuse_mask = push_mask; s.tail_needed = 0; s.fast = 1; s.pad1 = 0; s.rec_base = c.rec_base;
+        q.end_new = o.end_new; q.my_virt = q.pfx[1] - q.pfx[0]; q.ok = 1;
     }
-    if (srv) { q.out.np[lane] = ~0ull; if (tick && lane < size) q.lh[H_APPLY_OFFSETS + lane] = my_apoff; }
+    if (srv) { q.out.np[lane] = ~0ull; if (tick && lane < E.group_size) q.lh[H_APPLY_OFFSETS + lane] = o.my_apoff; }
     return 1;
 }
 
@@ -816,6 +859,109 @@ __device__ static inline void chain_effects_fast(const EngDev &E, uint32_t push_
     if (lane < sizeof(SeqOut) / 8) gst(&((uint64_t *)E.seq)[lane], ((const uint64_t *)&q.out)[lane]);
 }
 
+/* The books of a launch whose segments were ALL sequenced by the record pass (in step, chain_core):
+ * one wavefront walks the segments once more on registers and does, per segment, only what is not
+ * overwritten by the next one -- a due prune tick's <HEAD> entry on every replica (chain_effects_fast),
+ * its per-round record, the log-full check, the segment's sign-off -- and then stores the control
+ * words of the leader and of every pushed follower ONCE, as the last segment leaves them
+ * (chain_effects_fast + keeper_publish of every segment in turn write the same words; nobody can
+ * observe the intermediate values: no block of the launch reads them, the host sees the launch's
+ * end).  Per-segment stores from this block queue behind the append blocks that share its CU
+ * (~5.5 us per segment, the launch could not end before 7 x that; profiles/README.md).
+ * cr = the state before the launch; fw_sc / fw_head / fw_nc: the followers' store count, head and
+ * commit slot (lane = server). */
+template <typename SEG>      /* CallArgs (defined below) */
+__device__ static inline void chain_books_fast(const EngDev &E, uint32_t push_mask, ChainRegs cr, uint64_t fw_sc, uint64_t fw_head,
+                                               uint32_t S, const uint64_t (*pre_pfx)[2], const uint32_t (*pre_rf)[2], const uint64_t *pre_last,
+                                               const SEG *segs, SeqOut &last_out)
+{
+    const uint32_t lane = lane_id();
+    const RepDev &Ld = E.rep[E.leader];
+    uint64_t *hdr = Ld.hdr;
+    const uint64_t L = E.log_len;
+    const bool srv = lane < APUS_DEV_MAX_SERVERS;
+    const bool pushed = srv && ((push_mask >> lane) & 1u);
+    const bool target = srv && (((push_mask | (1u << E.leader)) >> lane) & 1u);
+    const uint64_t n_end_before = cr.n_end;
+    uint64_t my_pfx0 = 0, my_pfx2 = 0, my_last = 0, my_r0 = 0;
+    uint32_t my_rf0 = 0, my_rf1 = 0, my_R = 0, my_tick = 0;
+    if (lane < S) {
+        my_pfx0 = pre_pfx[lane][0]; my_pfx2 = pre_pfx[lane][1]; my_last = pre_last[lane];
+        my_rf0 = pre_rf[lane][0]; my_rf1 = pre_rf[lane][1];
+        my_r0 = segs[lane].r0; my_R = segs[lane].R; my_tick = segs[lane].tick;
+    }
+    uint64_t n_total = 0;
+    for (uint32_t k = 0; k < S; k++) {
+        ChainSeg g;
+        g.r0 = rl64(my_r0, k); g.pfx0 = rl64(my_pfx0, k); g.pfx2 = rl64(my_pfx2, k); g.len_last = rl64(my_last, k);
+        g.rf0 = (uint32_t)__builtin_amdgcn_readlane((int)my_rf0, (int)k); g.rf1 = (uint32_t)__builtin_amdgcn_readlane((int)my_rf1, (int)k);
+        g.R = (uint32_t)__builtin_amdgcn_readlane((int)my_R, (int)k); g.tick = (uint32_t)__builtin_amdgcn_readlane((int)my_tick, (int)k);
+        ChainOut o;
+        if (!chain_core(E, push_mask, cr, g, o)) { if (lane == 0) set_status(E, 1u << 4); break; }      /* (the record pass took it: cannot happen) */
+        const uint64_t term = cr.sid >> 9;
+        if (lane == 0) {
+            /* free space: the reference only notices end == head exactly (dare_log.h:168) */
+            const uint64_t used = o.e0 >= o.hd ? o.e0 - o.hd : L - (o.hd - o.e0);
+            const uint64_t vt = (o.kstar >= 0) ? o.end_new + o.w - o.e0 : o.end_new - o.e0, waste = (o.kstar >= 0) ? L - o.w : 0;
+            if (o.n && vt + waste >= L - used) set_status(E, 1u << 1);
+        }
+        if (o.head_round) {
+            /* <HEAD, head> right in front of the batch, pushed with its reply bytes, committed and applied as it lands */
+            const uint64_t pos = o.e0 - APUS_HDR, idx = o.idx0 - 1, slot = o.n_end0 - 1, hv = o.hd;
+            const uint32_t di = (uint32_t)slot & E.dir_mask, fuse = push_mask;
+            if (lane == 0 && cr.rec_base < E.rec_cap) gst(&E.rec_end[cr.rec_base], (uint64_t)o.e0);
+            if (target) {
+                const RepDev &Rd = E.rep[lane];
+                const ReplyWords rw = apus_reply_words(lane == E.leader ? fuse : (fuse & (1u << lane)));
+                uint8_t *rg = Rd.ring;
+                st16u(rg + pos, make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)term, (uint32_t)(term >> 32)));
+                st16u(rg + pos + 16, make_uint4(0, 0, (3u << 16) | ((uint32_t)E.leader << 24), rw.w28));
+                st16u(rg + pos + 32, make_uint4(rw.x32, rw.y36, rw.z40, 0));
+                st16u(rg + pos + 48, make_uint4((uint32_t)hv, (uint32_t)(hv >> 32), 0, 0));
+                gst(&Rd.dir_off[di], pos); gst(&Rd.dir_len[di], (uint32_t)(APUS_HDR | ((uint32_t)E.leader << 24)));
+                uint8_t *rp = (uint8_t *)&Rd.apply[di];
+                st16u(rp, make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32)));
+                st16u(rp + 16, make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), 0, 3u << 16));
+                if (lane == E.leader) __hip_atomic_store(&Ld.ack[di], fuse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            /* a follower adopts a committed <HEAD> (keeper_publish, pure_head) */
+            if (pushed && apus_is_larger(o.end_new, L, hv, fw_head)) fw_head = hv;
+        }
+        if (k + 1 == S && lane == 0) {
+            SeqOut &s = last_out;
+            s.e0 = o.e0; s.idx0 = o.idx0; s.w = o.w; s.n_end0 = o.n_end0; s.term = term; s.kstar = o.kstar; s.estar = o.estar; s.stale = o.stale;
+            s.n = o.n; s.head_round = o.head_round; s.pad0 = 0; s.first_fail = ~0ull; s.commit_before = cr.commit; s.n_commit_before = cr.n_commit;
+            s.vis = o.n_end0 + o.n; s.scan_lo = cr.n_commit; s.fuse_mask = push_mask; s.tail_needed = 0; s.fast = 1; s.pad1 = 0; s.rec_base = cr.rec_base;
+        }
+        if (k + 1 == S && srv) last_out.np[lane] = ~0ull;
+        n_total += o.n;
+        chain_advance(E, push_mask, cr, g, o);
+        /* the segment's sign-off (its janitor waits for it) */
+        if (lane == 0) __hip_atomic_fetch_add(E.step_tickets + (size_t)k * 32 + T_PASS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    /* ---- the control words, once ---- */
+    const uint64_t vis = cr.n_end;
+    if (lane == 0) {
+        gst(&hdr[H_END], cr.end); gst(&hdr[H_TAIL], cr.tail); gst(&hdr[H_N_END], cr.n_end); gst(&hdr[H_LAST_IDX], cr.last_idx);
+        gst(&hdr[H_PREV_HEAD], (uint64_t)0); gst(&hdr[H_OLD_END], cr.end); gst(&hdr[H_N_PERSIST], cr.n_end); gst(&hdr[H_STORE_COUNT], cr.store_count);
+        gst(&hdr[H_HEAD], cr.head);
+        gst(&hdr[H_N_VISIBLE], vis); gst(&hdr[H_COMMIT], cr.commit); gst(&hdr[H_N_COMMIT], cr.n_commit);
+        gst(&hdr[H_APPLY], cr.apply); gst(&hdr[H_N_APPLY], cr.n_apply);
+        gst(E.rec_count, (uint64_t)cr.rec_base);
+        atomicAdd((unsigned long long *)&hdr[H_APPLY_COUNT], (unsigned long long)n_total);
+        atomicAdd((unsigned long long *)&hdr[H_HIGHEST_REC], (unsigned long long)n_total);
+    }
+    if (lane < E.group_size) gst(&hdr[H_APPLY_OFFSETS + lane], cr.apoff);
+    if (pushed) {
+        uint64_t *fh = E.rep[lane].hdr;
+        gst(&fh[H_STORE_COUNT], fw_sc + (vis - n_end_before));
+        gst(&fh[H_END], cr.end); gst(&fh[H_OLD_END], cr.end); gst(&fh[H_N_END], vis); gst(&fh[H_N_PERSIST], vis);
+        gst(&fh[H_COMMIT], cr.end); gst(&fh[H_N_COMMIT], vis); gst(&fh[H_APPLY], cr.end); gst(&fh[H_N_APPLY], vis);
+        gst(&fh[H_HEAD], fw_head);
+        atomicAdd((unsigned long long *)&fh[H_APPLY_COUNT], (unsigned long long)n_total);
+    }
+}
+
 /* a block of k_call works the call's SeqOut out for itself: wave 0's variant, or the block-wide
  * scan when the batch could reach len; posts its "inputs fetched" ticket on tick line read_line */
 __device__ static inline void seq_local(const EngDev &E, const CallEnv &X, uint64_t r0, uint32_t R, uint32_t push_mask, uint32_t tick,
@@ -849,11 +995,11 @@ __device__ static inline void seq_local(const EngDev &E, const CallEnv &X, uint6
  * end of the ring): the block falls back to the block-wide scan on snapshot `seg`.
  * The records are cleared by the launch's last janitor, so a stale record never matches. */
 __device__ static inline void wait_count(const EngDev &E, const uint32_t *lines32, uint32_t b, uint32_t want);
-#define REC_WORDS   16
+#define REC_WORDS   32
 #ifndef APUS_REC_SLEEP
 #define APUS_REC_SLEEP 2        /* x 64 clocks between two polls of a segment's record */
 #endif
-#define REC_GRAN    14
+#define REC_GRAN    20
 #define REC_TAG(seg) (0x5E000000u | ((seg) + 1u))
 enum { RECF_FAST = 1u << 13, RECF_OK = 1u << 14, RECF_HEAD = 1u << 15, RECF_CHAIN = 1u << 16, RECF_STALE = 1u << 17, RECF_ESTAR = 1u << 18 };   /* CHAIN: the chain block does the sequencer's effects */
 
@@ -861,27 +1007,43 @@ __device__ static inline void rec_store(uint64_t *rec, uint32_t g, uint32_t data
 {
     __hip_atomic_store((APUS_GLOBAL unsigned long long *)(uintptr_t)&rec[g], ((unsigned long long)tag << 32) | data, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-/* lanes 0 .. REC_GRAN-1 of the calling wave publish segment seg's record from q.out / q.ok */
-__device__ static inline void rec_publish(const EngDev &E, uint32_t seg, const SeqLds &q, bool chain_did)
+/* the fields of a record, 8 bytes each = two granules: e0, idx0, n_end0, term, flags | n << 32, kstar, w,
+ * rec_base, commit_before, n_commit_before */
+struct RecFields { uint64_t e0, idx0, n_end0, term, flags_n, kstar, w, rec_base, commit_before, n_commit_before; };
+__device__ static inline uint32_t rec_flags(uint32_t ok, uint32_t fuse_mask, uint32_t fast, uint32_t head_round, uint32_t stale, bool estar, bool chain_did)
+{
+    return (ok ? (fuse_mask & 0x1FFFu) | (fast ? RECF_FAST : 0u) | (head_round ? RECF_HEAD : 0u) | RECF_OK |
+                 (stale ? RECF_STALE : 0u) | (estar ? RECF_ESTAR : 0u) : 0u) | (chain_did ? RECF_CHAIN : 0u);
+}
+__device__ static inline void rec_publish_fields(const EngDev &E, uint32_t seg, const RecFields &f)
 {
     const uint32_t lane = lane_id();
     if (lane >= REC_GRAN) return;
-    const SeqOut &s = q.out;
-    const uint32_t ok = q.ok ? 1u : 0u;
     uint64_t v = 0;
     switch (lane >> 1) {
-    case 0: v = s.e0; break;
-    case 1: v = s.idx0; break;
-    case 2: v = s.n_end0; break;
-    case 3: v = s.term; break;
-    case 4: v = (uint64_t)((ok ? (s.fuse_mask & 0x1FFFu) | (s.fast ? RECF_FAST : 0u) | (s.head_round ? RECF_HEAD : 0u) | RECF_OK |
-                                 (s.stale ? RECF_STALE : 0u) | (s.estar >= 0 ? RECF_ESTAR : 0u) : 0u) | (chain_did ? RECF_CHAIN : 0u))
-               | ((uint64_t)(ok ? s.n : 0u) << 32);
-            break;
-    case 5: v = (uint64_t)s.kstar; break;          /* -1: the batch does not wrap */
-    default: v = s.w; break;
+    case 0: v = f.e0; break;
+    case 1: v = f.idx0; break;
+    case 2: v = f.n_end0; break;
+    case 3: v = f.term; break;
+    case 4: v = f.flags_n; break;
+    case 5: v = f.kstar; break;                    /* -1: the batch does not wrap */
+    case 6: v = f.w; break;
+    case 7: v = f.rec_base; break;
+    case 8: v = f.commit_before; break;
+    default: v = f.n_commit_before; break;
     }
     rec_store(E.step_rec + (size_t)seg * REC_WORDS, lane, (uint32_t)(lane & 1 ? v >> 32 : v), REC_TAG(seg));
+}
+/* lanes 0 .. REC_GRAN-1 of the calling wave publish segment seg's record from q.out / q.ok */
+__device__ static inline void rec_publish(const EngDev &E, uint32_t seg, const SeqLds &q, bool chain_did)
+{
+    const SeqOut &s = q.out;
+    const uint32_t ok = q.ok ? 1u : 0u;
+    RecFields f;
+    f.e0 = s.e0; f.idx0 = s.idx0; f.n_end0 = s.n_end0; f.term = s.term;
+    f.flags_n = (uint64_t)rec_flags(ok, s.fuse_mask, s.fast, s.head_round, s.stale, s.estar >= 0, chain_did) | ((uint64_t)(ok ? s.n : 0u) << 32);
+    f.kstar = (uint64_t)s.kstar; f.w = s.w; f.rec_base = s.rec_base; f.commit_before = s.commit_before; f.n_commit_before = s.n_commit_before;
+    rec_publish_fields(E, seg, f);
 }
 /* wave-wide: poll segment seg's record, fill the SeqOut fields an append block uses (q.out, q.ok);
  * bounded like every spin of the engine */
@@ -906,8 +1068,12 @@ __device__ static inline void rec_wait(const EngDev &E, uint32_t seg, SeqLds &q)
     const uint32_t flags = __shfl(d, 8, WAVE), n = __shfl(d, 9, WAVE);
     const uint64_t kst = (uint64_t)__shfl(d, 10, WAVE) | ((uint64_t)__shfl(d, 11, WAVE) << 32);
     const uint64_t wv_ = (uint64_t)__shfl(d, 12, WAVE) | ((uint64_t)__shfl(d, 13, WAVE) << 32);
+    const uint64_t rb_ = (uint64_t)__shfl(d, 14, WAVE) | ((uint64_t)__shfl(d, 15, WAVE) << 32);
+    const uint64_t cb_ = (uint64_t)__shfl(d, 16, WAVE) | ((uint64_t)__shfl(d, 17, WAVE) << 32);
+    const uint64_t ncb_ = (uint64_t)__shfl(d, 18, WAVE) | ((uint64_t)__shfl(d, 19, WAVE) << 32);
     if (lane == 0) {
         SeqOut &s = q.out;
+        s.rec_base = rb_; s.commit_before = cb_; s.n_commit_before = ncb_; s.vis = n_end0 + n;
         s.e0 = e0; s.idx0 = idx0; s.w = wv_; s.n_end0 = n_end0; s.term = term; s.kstar = (int64_t)kst;
         s.estar = (flags & RECF_ESTAR) ? (int64_t)kst : -1; s.stale = (flags & RECF_STALE) ? 1u : 0u;
         s.n = n; s.head_round = (flags & RECF_HEAD) ? 1u : 0u; s.fuse_mask = flags & 0x1FFFu; s.fast = (flags & RECF_FAST) ? 1u : 0u;
@@ -1187,65 +1353,83 @@ __device__ static inline void append_round(const EngDev &E, const CallEnv &X, ui
 }
 
 /* ------------------------------------------------------------------------- */
-/* Grouped append (k_call / k_step, small rounds): ONE WAVEFRONT PER ROUND, APUS_GP rounds per
- * workgroup.  A 64-entry round of 128-byte entries is only 8 KiB: as one workgroup per round
- * (append_round) every block spends most of its ~11 us life on two dependent load round trips
- * and the single-lane sequencing before its 512 stores, and occupancy x latency -- not HBM --
- * bounds the launch.  Here the block pays that chain once for four rounds:
- *   round trip 1   every wave: its round's descriptors (lane = entry) and byte prefix;
- *                  wave 0 also the call's control words (seq_w0_stage)
- *   on chip        one lane works the call's SeqOut out (seq_w0_decide) while every wave lays
- *                  its own round out with wave scans -- no block barrier inside a round
- *   round trip 2   the first payload units (already in flight while the SeqOut is computed)
- *   stores         lane l writes units l, l+64, ... of its wave's round to the leader ring and
- *                  every pushed follower ring (consecutive lanes = consecutive 16-byte units)
- * Semantics are append_round<true>'s, line for line (positions, stale header, fused reply
- * bytes, directory, in-step apply records and the per-round hash words). */
-#define APUS_GP 4
+#define APUS_GP 4            /* wavefronts of an append workgroup */
+#ifndef APUS_GD
+#define APUS_GD 2            /* rounds per wavefront, one after the other; the second one's loads are issued with the first one's */
+#endif
+#define APUS_GR (APUS_GP * APUS_GD)      /* rounds per workgroup */
 #ifndef APUS_GP_PF
 #define APUS_GP_PF 4          /* payload units per lane fetched before the SeqOut is known */
 #endif
 struct GroupLds {
+    /* per wave, reused from one round to the next */
     uint64_t pos[APUS_GP][WAVE];
-    uint64_t src[APUS_GP][WAVE];
     uint64_t idx[APUS_GP][WAVE];
     uint64_t req[APUS_GP][WAVE];
     uint32_t tail[APUS_GP][WAVE];         /* clt_id | type << 16 | sender << 24 */
-    uint32_t T[APUS_GP][WAVE];
-    uint32_t ubase[APUS_GP][WAVE + 1];
     /* the replicas a unit is stored to (leader first), with the reply words their copy carries */
     uint8_t *tgt_ring[APUS_GP][APUS_DEV_MAX_SERVERS];
     uint4    tgt_rw[APUS_GP][APUS_DEV_MAX_SERVERS];        /* {w28, x32, y36, z40} */
+    /* per round of the wave: its layout ... */
+    uint32_t src16[APUS_GD][APUS_GP][WAVE];                /* payload offset in the arena / 16 */
+    uint32_t T[APUS_GD][APUS_GP][WAVE];
+    uint32_t ubase[APUS_GD][APUS_GP][WAVE + 1];
+    /* ... and, for the rounds after the first, what was fetched ahead: descriptors and payload units */
+    uint4    dsc[APUS_GD - 1][APUS_GP][WAVE];
+    uint4    pay[APUS_GD - 1][APUS_GP][APUS_GP_PF][WAVE];
 };
 
-/* rec_seg >= 0: a segment of a multi-segment launch -- the SeqOut comes from the segment's record
+/* Grouped append (k_call / k_step, small rounds): ONE WAVEFRONT PER ROUND at a time, APUS_GD rounds
+ * per wavefront, APUS_GP wavefronts per workgroup.
+ *   round trip 1   the descriptors (lane = entry) and byte prefix of ALL the wave's rounds;
+ *                  k_call: wave 0 also the call's control words (seq_w0_stage)
+ *   on chip        the layout of every round (wave scans, no block barrier inside a round)
+ *   round trip 2   the first APUS_GP_PF payload units per lane of every round: the first round's
+ *                  stay in registers, the later rounds' are parked in LDS
+ *   the segment's sequencing record (k_step) / the call's SeqOut (k_call)
+ *   stores         round after round: lane l writes units l, l+64, ... to the leader ring and every
+ *                  pushed follower ring (consecutive lanes = consecutive 16-byte units)
+ * Everything a wave loads before its first store is in flight while it waits for the record, and a
+ * launch's append workgroups are ALL resident from the start (5462 rounds of configs[1] = 683
+ * workgroups on 768 slots): when they trickled in behind each other, every newcomer's two dependent
+ * round trips queued behind the residents' store traffic and the launch ran at ~3 TB/s instead of
+ * the ~7 TB/s the first, pre-loaded wave of workgroups reached (profiles/README.md, timeline).
+ * Semantics are append_round<true>'s, line for line (positions, stale header, fused reply
+ * bytes, directory, in-step apply records and the per-round hash words).
+ * rec_seg >= 0: a segment of a multi-segment launch -- the SeqOut comes from the segment's record
  * (rec_wait); rec_seg < 0: k_call -- the block stages the control words and sequences for itself */
 __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X, uint64_t r0, uint32_t R, uint32_t push_mask,
                                                uint32_t grp, GroupLds &gl, SeqLds *sq, uint32_t tick,
-                                               const uint64_t *snap, bool post_read, int rec_seg)
+                                               const uint64_t *snap, bool post_read, int rec_seg, uint32_t gd)
 {
+    /* gd <= APUS_GD rounds per wave (the host's choice: as few as keep all append workgroups of the launch resident) */
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const RepDev &Ld = E.rep[E.leader];
     const uint32_t *rf = E.round_first + r0;
-    const uint32_t r = grp * APUS_GP + wv;
-    const bool has = r < R;
-    const uint32_t g0 = gld(&rf[0]);
-    const uint32_t first = has ? gld(&rf[r]) - g0 : 0, nr = has ? gld(&rf[r + 1]) - gld(&rf[r]) : 0;
-    const uint64_t pfx_r = has ? gld(&E.round_prefix[r0 + r]) : 0;
-    const uint64_t pfx_0 = gld(&E.round_prefix[r0]);
-    const uint32_t n_grp = (R + APUS_GP - 1) / APUS_GP;
+    const uint32_t rbase = (grp * APUS_GP + wv) * gd;          /* the wave's first round */
+    const uint32_t GRr = APUS_GP * gd;                         /* rounds per workgroup */
+    const uint32_t n_grp = (R + GRr - 1) / GRr;
+    constexpr int PF = APUS_GP_PF;
     if (rec_seg >= 0 && rec_seg < 64) { if (grp == 0) STAMPN(10, rec_seg); if (grp + 1 == n_grp) STAMPN(14, rec_seg); }
 
-    /* ---- round trip 1 ---- */
-    const bool active = lane < nr;
-    ReqDev d; d.req_id = 0; d.pay16_type = 0; d.len = 0; d.clt_id = 0;
-    if (active) {
-        const uint4 dv = ld16u((const uint8_t *)&E.req[g0 + first + lane]);
-        d.req_id = (uint64_t)dv.x | ((uint64_t)dv.y << 32); d.pay16_type = dv.z; d.len = (uint16_t)dv.w; d.clt_id = (uint16_t)(dv.w >> 16);
+    /* ---- round trip 0 / 1: round bounds, then descriptors, of every round of the wave ---- */
+    const uint32_t g0 = gld(&rf[0]);
+    const uint64_t pfx_0 = gld(&E.round_prefix[r0]);
+    uint32_t rfv[APUS_GD + 1];
+    uint64_t pfx_r[APUS_GD];
+#pragma unroll
+    for (int it = 0; it <= APUS_GD; it++) rfv[it] = gld(&rf[min(rbase + (uint32_t)it, R)]);
+#pragma unroll
+    for (int it = 0; it < APUS_GD; it++) pfx_r[it] = gld(&E.round_prefix[r0 + min(rbase + (uint32_t)it, R)]);
+    uint4 dv[APUS_GD];
+#pragma unroll
+    for (int it = 0; it < APUS_GD; it++) {
+        dv[it] = make_uint4(0, 0, 0, 0);
+        if ((uint32_t)it < gd && rbase + it < R && lane < rfv[it + 1] - rfv[it]) dv[it] = ld16u((const uint8_t *)&E.req[rfv[it] + lane]);
     }
     if (rec_seg < 0) {
         if (wv == 0) {
-            seq_w0_stage(E, r0, R, push_mask, grp * APUS_GP, *sq, snap);
+            seq_w0_stage(E, r0, R, push_mask, grp * GRr, *sq, snap);
             if (tid == 0 && post_read) __hip_atomic_fetch_add(X.lines + (grp & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (grp == 0) STAMP(8, 0);
@@ -1256,49 +1440,85 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
         if (grp == 0) STAMPW(8, 7, WAVE);
     } else if (grp == 0) STAMP(8, 0);
 
-    /* ---- layout of this wave's round (registers + wave scans) ---- */
-    const uint32_t T = active ? APUS_HDR + d.len : 0;
-    const uint64_t incl = wave_incl_scan((uint64_t)T);
-    const uint32_t nu = active ? (T + 15) / 16 : 0;
-    const uint32_t uincl = wave_incl_scan(nu);
-    const uint32_t T0 = __shfl(T, 0, WAVE);
-    const bool uni = __all(!active || T == T0);
-    const uint32_t uall = __shfl(uincl, WAVE - 1, WAVE);
-    const uint32_t unu = uni ? (T0 + 15) / 16 : 0;
-    gl.src[wv][lane] = (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
-    gl.T[wv][lane] = T;
-    gl.ubase[wv][lane] = uincl - nu;
-    if (lane == WAVE - 1) gl.ubase[wv][WAVE] = uincl;
-    __builtin_amdgcn_wave_barrier();          /* LDS is in order within a wave; keep the compiler from reordering */
-
+    /* ---- the layout of a round (registers + wave scans) ---- */
+    struct Lay { bool active; uint32_t T, uall, unu, T0, magic, nr; uint64_t incl; };
+    auto lay_of = [&](const uint4 &d, uint32_t nr) -> Lay {
+        Lay y;
+        y.nr = nr;
+        y.active = lane < nr;
+        y.T = y.active ? APUS_HDR + (d.w & 0xFFFFu) : 0;
+        y.incl = wave_incl_scan((uint64_t)y.T);
+        y.T0 = __shfl(y.T, 0, WAVE);
+        const bool uni = __all(!y.active || y.T == y.T0);
+        y.unu = uni ? (y.T0 + 15) / 16 : 0;
+        y.magic = y.unu > 1 ? (uint32_t)((1ull << 32) / y.unu + 1) : 0;   /* u / unu = mulhi(u, magic) for u < 64 * 261 */
+        y.uall = 0;
+        return y;
+    };
     /* which entry of the round owns 16-byte unit u, at which byte offset of the entry */
-    const uint32_t unu_magic = unu > 1 ? (uint32_t)((1ull << 32) / unu + 1) : 0;   /* u / unu = mulhi(u, magic) for u < 64 * 261 */
-    auto unit_of = [&](uint32_t u, uint32_t &e, uint32_t &so, uint32_t &Te) {
+    auto unit_of = [&](int it, const Lay &y, uint32_t u, uint32_t &e, uint32_t &so, uint32_t &Te) {
         uint32_t j;
-        if (unu) { e = unu > 1 ? __umulhi(u, unu_magic) : u; j = u - e * unu; }
+        if (y.unu) { e = y.unu > 1 ? __umulhi(u, y.magic) : u; j = u - e * y.unu; }
         else {
-            uint32_t lo = 0, hi = nr - 1;               /* largest e with ubase[e] <= u */
+            uint32_t lo = 0, hi = y.nr - 1;             /* largest e with ubase[e] <= u */
             while (lo < hi) {
                 const uint32_t mid = (lo + hi + 1) >> 1;
-                if (gl.ubase[wv][mid] <= u) lo = mid; else hi = mid - 1;
+                if (gl.ubase[it][wv][mid] <= u) lo = mid; else hi = mid - 1;
             }
-            e = lo; j = u - gl.ubase[wv][e];
+            e = lo; j = u - gl.ubase[it][wv][e];
         }
-        Te = gl.T[wv][e];
+        Te = gl.T[it][wv][e];
         so = min(16u * j, Te - 16u);
     };
-
-    /* ---- round trip 2: the first payload units into registers ---- */
-    constexpr int PF = APUS_GP_PF;
+    auto src_of = [&](int it, uint32_t e) -> const uint8_t * { return E.arena + (uint64_t)gl.src16[it][wv][e] * 16; };
+    /* tables of round `it` + the number of units; returns the layout */
+    auto lay_out = [&](int it, const uint4 &d, uint32_t nr) -> Lay {
+        Lay y = lay_of(d, nr);
+        const uint32_t nu = y.active ? (y.T + 15) / 16 : 0;
+        const uint32_t uincl = wave_incl_scan(nu);
+        y.uall = __shfl(uincl, WAVE - 1, WAVE);
+        gl.src16[it][wv][lane] = d.z & 0x0FFFFFFFu;
+        gl.T[it][wv][lane] = y.T;
+        gl.ubase[it][wv][lane] = uincl - nu;
+        if (lane == WAVE - 1) gl.ubase[it][wv][WAVE] = uincl;
+        return y;
+    };
+    Lay L0;
+    {
+        Lay ly[APUS_GD];
+#pragma unroll
+        for (int it = 0; it < APUS_GD; it++) ly[it] = lay_out(it, dv[it], ((uint32_t)it < gd && rbase + it < R) ? rfv[it + 1] - rfv[it] : 0u);
+        __builtin_amdgcn_wave_barrier();          /* LDS is in order within a wave; keep the compiler from reordering */
+        L0 = ly[0];
+        /* ---- round trip 2: the first payload units of every round; the later rounds' go to LDS ---- */
+#pragma unroll
+        for (int it = APUS_GD - 1; it >= 1; it--) {
+            if ((uint32_t)it >= gd) continue;
+            uint4 t[PF];
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                t[k] = make_uint4(0, 0, 0, 0);
+                const uint32_t u = lane + (uint32_t)k * WAVE;
+                if (u < ly[it].uall) {
+                    uint32_t e, so, Te;
+                    unit_of(it, ly[it], u, e, so, Te);
+                    if (so >= 48) t[k] = payload_unit(src_of(it, e), so, Te - APUS_HDR, Te - APUS_HDR);
+                }
+            }
+            gl.dsc[it - 1][wv][lane] = dv[it];
+#pragma unroll
+            for (int k = 0; k < PF; k++) gl.pay[it - 1][wv][k][lane] = t[k];
+        }
+    }
     uint4 pv[PF];
 #pragma unroll
     for (int k = 0; k < PF; k++) {
         pv[k] = make_uint4(0, 0, 0, 0);
         const uint32_t u = lane + (uint32_t)k * WAVE;
-        if (u < uall) {
+        if (u < L0.uall) {
             uint32_t e, so, Te;
-            unit_of(u, e, so, Te);
-            if (so >= 48) pv[k] = payload_unit(E.arena + gl.src[wv][e], so, Te - APUS_HDR, Te - APUS_HDR);
+            unit_of(0, L0, u, e, so, Te);
+            if (so >= 48) pv[k] = payload_unit(src_of(0, e), so, Te - APUS_HDR, Te - APUS_HDR);
         }
     }
     if (grp == 0) STAMP(8, 2);
@@ -1315,7 +1535,7 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
              * (segment 0's was written before its record) */
             if (rec_seg > 0) wait_count(E, E.step_epoch, grp, (uint32_t)rec_seg);
             __syncthreads();
-            if (tid < WAVE) seq_w0_stage(E, r0, R, push_mask, grp * APUS_GP, *sq, E.step_snap + (size_t)rec_seg * SNAP_STRIDE);
+            if (tid < WAVE) seq_w0_stage(E, r0, R, push_mask, grp * GRr, *sq, E.step_snap + (size_t)rec_seg * SNAP_STRIDE);
             __syncthreads();
             if (tid == 0) seq_w0_decide<false, true>(E, push_mask, tick, *sq);
             __syncthreads();
@@ -1324,17 +1544,33 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
             const uint32_t *rb = E.round_bytes + r0;
             for (uint32_t i = tid; i < R && i < 1024; i += blockDim.x) sq->bytes0[i] = rb[i];
             __syncthreads();
-            seq_body<false>(E, r0, R, push_mask, tick, push_mask, *sq, grp * APUS_GP);
+            seq_body<false>(E, r0, R, push_mask, tick, push_mask, *sq, grp * GRr);
             __syncthreads();
         }
     }
 
-    /* ---- where the entries go (lane = entry) ---- */
     const uint64_t e0 = sq->out.e0, n_end0 = sq->out.n_end0, term = sq->out.term;
     const uint32_t fuse = sq->out.fuse_mask, fast = sq->out.fast;
-    {
+    /* the wave's target table: lane t < 13 = replica t, the leader first */
+    if (lane < APUS_DEV_MAX_SERVERS && (((push_mask | (1u << E.leader)) >> lane) & 1u)) {
+        const uint32_t at = lane == E.leader ? 0u : 1u + (uint32_t)__popc(push_mask & ~(1u << E.leader) & ((1u << lane) - 1u));
+        const ReplyWords rw = apus_reply_words(lane == E.leader ? fuse : (fuse & (1u << lane)));
+        gl.tgt_ring[wv][at] = E.rep[lane].ring;
+        gl.tgt_rw[wv][at] = make_uint4(rw.w28, rw.x32, rw.y36, rw.z40);
+    }
+
+    /* ---- one round: where its entries go (lane = entry), its bytes, its apply records ---- */
+    auto emit = [&](int it, const uint4 &dvv, const Lay &y) {
+        const uint32_t r = rbase + (uint32_t)it;
+        const bool has = r < R;          /* (it < gd: the caller's loop) */
+        const uint32_t first = rfv[it] - g0;
+        const bool active = y.active;
+        const uint32_t T = y.T, uall = y.uall, unu = y.unu, nr = y.nr;
+        const uint64_t incl = y.incl;
+        ReqDev d;
+        d.req_id = (uint64_t)dvv.x | ((uint64_t)dvv.y << 32); d.pay16_type = dvv.z; d.len = (uint16_t)dvv.w; d.clt_id = (uint16_t)(dvv.w >> 16);
         const SeqOut &s = sq->out;
-        const uint64_t virt_r = sq->ok ? pfx_r - sq->pfx[0] : (has ? sq->virt[r] : 0);
+        const uint64_t virt_r = sq->ok ? pfx_r[it] - sq->pfx[0] : (has ? sq->virt[r] : 0);
         const uint64_t a = e0 + virt_r + incl - T;
         const int64_t gk = (int64_t)first + lane;
         const uint64_t pos = apus_place(s, gk, a);
@@ -1346,10 +1582,10 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
         if (active) {
             const uint32_t di = (uint32_t)slot & E.dir_mask;
             const uint32_t dl = T | ((uint32_t)E.leader << 24);     /* derived: total bytes | sender << 24 */
-            gst(&Ld.dir_off[di], pos); gst(&Ld.dir_len[di], dl); gst(&Ld.ack[di], fuse);     /* ACK bits of the fused followers */
+            gst_nt(&Ld.dir_off[di], pos); gst_nt(&Ld.dir_len[di], dl); gst_nt(&Ld.ack[di], fuse);     /* ACK bits of the fused followers */
             for (uint32_t m = push_mask; m; m &= m - 1) {
                 const RepDev &Fd = E.rep[__builtin_ctz(m)];
-                gst(&Fd.dir_off[di], pos); gst(&Fd.dir_len[di], dl);
+                gst_nt(&Fd.dir_off[di], pos); gst_nt(&Fd.dir_len[di], dl);
             }
             if (s.stale && gk == s.kstar) {
                 /* the header log_append_entry wrote before it found out that the payload does
@@ -1365,15 +1601,8 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
                 }
             }
         }
-        /* the wave's target table: lane t < 13 = replica t, the leader first */
-        if (lane < APUS_DEV_MAX_SERVERS && (((push_mask | (1u << E.leader)) >> lane) & 1u)) {
-            const uint32_t at = lane == E.leader ? 0u : 1u + (uint32_t)__popc(push_mask & ~(1u << E.leader) & ((1u << lane) - 1u));
-            const ReplyWords rw = apus_reply_words(lane == E.leader ? fuse : (fuse & (1u << lane)));
-            gl.tgt_ring[wv][at] = E.rep[lane].ring;
-            gl.tgt_rw[wv][at] = make_uint4(rw.w28, rw.x32, rw.y36, rw.z40);
-        }
         __builtin_amdgcn_wave_barrier();
-        if (grp == 0) STAMP(8, 4);
+        if (grp == 0 && it == 0) STAMP(8, 4);
 
         /* ---- the round's bytes: lane l stores units l, l + 64, ... ---- */
         if (unu && sq->ok && sq->out.kstar < 0) {
@@ -1384,8 +1613,8 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
              * payload).  The general path below runs every divergent case of the wave one after the
              * other, ~500 VALU instructions per unit; with 12 wavefronts per CU the append blocks were
              * bound by instruction issue (~10 us per block), not by HBM (tools/timeline_probe.py). */
-            const uint32_t magic = unu_magic;
-            const uint32_t Tu = T0;
+            const uint32_t magic = y.magic;
+            const uint32_t Tu = y.T0;
             const uint64_t a_r = __shfl(a, 0, WAVE);                     /* where the round's first entry goes */
             const uint64_t idx_r = __shfl(idx, 0, WAVE);
             const uint32_t n_tgt = 1u + (uint32_t)__popc(push_mask & ~(1u << E.leader));
@@ -1414,7 +1643,7 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
                 const uint32_t j = u - e * unu;
                 const uint32_t so = min(16u * j, Tu - 16u);
                 uint4 pay = make_uint4(0, 0, 0, 0);
-                if (so >= 48) pay = payload_unit(E.arena + gl.src[wv][e], so, Tu - APUS_HDR, Tu - APUS_HDR);
+                if (so >= 48) pay = payload_unit(src_of(it, e), so, Tu - APUS_HDR, Tu - APUS_HDR);
                 return pay;
             };
 #pragma unroll
@@ -1435,62 +1664,62 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
                 }
             }
         } else {
-        const ReplyWords rwl = apus_reply_words(fuse);
-        auto store_unit = [&](uint32_t e, uint32_t so, uint4 v) {
-            const uint64_t p = gl.pos[wv][e] + so;
-            if (fuse && so - 16u <= 16u) {                 /* the two units that hold reply[0..12] */
-                const bool second = so == 16;
-                st16u(Ld.ring + p, second ? make_uint4(v.x, v.y, v.z, rwl.w28) : make_uint4(rwl.x32, rwl.y36, rwl.z40, 0));
-                for (uint32_t m = push_mask; m; m &= m - 1) {
-                    const int f = __builtin_ctz(m);
-                    const ReplyWords rwf = apus_reply_words(fuse & (1u << f));
-                    st16u(E.rep[f].ring + p, second ? make_uint4(v.x, v.y, v.z, rwf.w28) : make_uint4(rwf.x32, rwf.y36, rwf.z40, 0));
+            const ReplyWords rwl = apus_reply_words(fuse);
+            auto store_unit = [&](uint32_t e, uint32_t so, uint4 v) {
+                const uint64_t p = gl.pos[wv][e] + so;
+                if (fuse && so - 16u <= 16u) {                 /* the two units that hold reply[0..12] */
+                    const bool second = so == 16;
+                    st16u(Ld.ring + p, second ? make_uint4(v.x, v.y, v.z, rwl.w28) : make_uint4(rwl.x32, rwl.y36, rwl.z40, 0));
+                    for (uint32_t m = push_mask; m; m &= m - 1) {
+                        const int f = __builtin_ctz(m);
+                        const ReplyWords rwf = apus_reply_words(fuse & (1u << f));
+                        st16u(E.rep[f].ring + p, second ? make_uint4(v.x, v.y, v.z, rwf.w28) : make_uint4(rwf.x32, rwf.y36, rwf.z40, 0));
+                    }
+                } else {
+                    st16u(Ld.ring + p, v);
+                    for (uint32_t m = push_mask; m; m &= m - 1) st16u(E.rep[__builtin_ctz(m)].ring + p, v);
                 }
-            } else {
-                st16u(Ld.ring + p, v);
-                for (uint32_t m = push_mask; m; m &= m - 1) st16u(E.rep[__builtin_ctz(m)].ring + p, v);
-            }
-        };
-        auto header_or = [&](uint32_t e, uint32_t so, uint4 pay) -> uint4 {
-            if (so == 0) { const uint64_t ix = gl.idx[wv][e]; return make_uint4((uint32_t)ix, (uint32_t)(ix >> 32), (uint32_t)term, (uint32_t)(term >> 32)); }
-            if (so == 16) { const uint64_t rq = gl.req[wv][e]; return make_uint4((uint32_t)rq, (uint32_t)(rq >> 32), gl.tail[wv][e], 0); }
-            if (so == 32) return make_uint4(0, 0, 0, 0);
-            return pay;
-        };
-#pragma unroll
-        for (int k = 0; k < PF; k++) {
-            const uint32_t u = lane + (uint32_t)k * WAVE;
-            if (u < uall) {
-                uint32_t e, so, Te;
-                unit_of(u, e, so, Te);
-                store_unit(e, so, header_or(e, so, pv[k]));
-            }
-        }
-        /* the rest of the round in batches of PF units per lane: all loads of a batch are issued
-         * before its first store (one load latency per batch, not per unit) */
-        for (uint32_t ub = PF * WAVE; ub < uall; ub += PF * WAVE) {
+            };
+            auto header_or = [&](uint32_t e, uint32_t so, uint4 pay) -> uint4 {
+                if (so == 0) { const uint64_t ix = gl.idx[wv][e]; return make_uint4((uint32_t)ix, (uint32_t)(ix >> 32), (uint32_t)term, (uint32_t)(term >> 32)); }
+                if (so == 16) { const uint64_t rq = gl.req[wv][e]; return make_uint4((uint32_t)rq, (uint32_t)(rq >> 32), gl.tail[wv][e], 0); }
+                if (so == 32) return make_uint4(0, 0, 0, 0);
+                return pay;
+            };
 #pragma unroll
             for (int k = 0; k < PF; k++) {
-                pv[k] = make_uint4(0, 0, 0, 0);
-                const uint32_t u = ub + lane + (uint32_t)k * WAVE;
+                const uint32_t u = lane + (uint32_t)k * WAVE;
                 if (u < uall) {
                     uint32_t e, so, Te;
-                    unit_of(u, e, so, Te);
-                    if (so >= 48) pv[k] = payload_unit(E.arena + gl.src[wv][e], so, Te - APUS_HDR, Te - APUS_HDR);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const uint32_t u = ub + lane + (uint32_t)k * WAVE;
-                if (u < uall) {
-                    uint32_t e, so, Te;
-                    unit_of(u, e, so, Te);
+                    unit_of(it, y, u, e, so, Te);
                     store_unit(e, so, header_or(e, so, pv[k]));
                 }
             }
+            /* the rest of the round in batches of PF units per lane: all loads of a batch are issued
+             * before its first store (one load latency per batch, not per unit) */
+            for (uint32_t ub = PF * WAVE; ub < uall; ub += PF * WAVE) {
+#pragma unroll
+                for (int k = 0; k < PF; k++) {
+                    pv[k] = make_uint4(0, 0, 0, 0);
+                    const uint32_t u = ub + lane + (uint32_t)k * WAVE;
+                    if (u < uall) {
+                        uint32_t e, so, Te;
+                        unit_of(it, y, u, e, so, Te);
+                        if (so >= 48) pv[k] = payload_unit(src_of(it, e), so, Te - APUS_HDR, Te - APUS_HDR);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < PF; k++) {
+                    const uint32_t u = ub + lane + (uint32_t)k * WAVE;
+                    if (u < uall) {
+                        uint32_t e, so, Te;
+                        unit_of(it, y, u, e, so, Te);
+                        store_unit(e, so, header_or(e, so, pv[k]));
+                    }
+                }
+            }
         }
-        }
-        if (grp == 0) STAMP(8, 5);
+        if (grp == 0 && it == 0) STAMP(8, 5);
         /* ---- in step: apply_committed_entries for the round, from the registers that built it
          * (leader kind 1: proxy_update_state, fused followers kind 2: proxy_do_action) ---- */
         if (fast) {
@@ -1515,9 +1744,22 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
                 __hip_atomic_store(&X.hash[2 * r + 1], sum2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (grp == 0) STAMP(8, 6);
-        if (rec_seg >= 0 && rec_seg < 64 && grp + 1 == n_grp) { STAMPN(12, rec_seg); STAMP(13, rec_seg); }
+        __builtin_amdgcn_wave_barrier();          /* the next round reuses pos / idx / req / tail */
+    };
+    emit(0, dv[0], L0);
+#pragma unroll
+    for (int it = 1; it < APUS_GD; it++) {
+        if ((uint32_t)it >= gd) break;
+        /* what was fetched ahead for this round: its descriptors, its first payload units */
+        const uint4 dn = gl.dsc[it - 1][wv][lane];
+#pragma unroll
+        for (int k = 0; k < PF; k++) pv[k] = gl.pay[it - 1][wv][k][lane];
+        Lay y = lay_of(dn, (rbase + it < R) ? rfv[it + 1] - rfv[it] : 0u);
+        y.uall = gl.ubase[it][wv][WAVE];
+        emit(it, dn, y);
     }
+    if (grp == 0) STAMP(8, 6);
+    if (rec_seg >= 0 && rec_seg < 64 && grp + 1 == n_grp) { STAMPN(12, rec_seg); STAMP(13, rec_seg); }
     return fast;
 }
 
@@ -2207,7 +2449,7 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
 struct CallArgs {
     uint64_t r0;
     uint32_t R, tick, SP, nR, nS, nA;
-    uint32_t GP;           /* > 1: grouped append, GP (= APUS_GP) small rounds per workgroup (then SP == 1) */
+    uint32_t GP;           /* > 1: grouped append, GP = APUS_GP x (1 .. APUS_GD) small rounds per workgroup (then SP == 1) */
 };
 /* number of append blocks of a call */
 __host__ __device__ static inline uint32_t call_append_blocks(const CallArgs &A)
@@ -2247,8 +2489,17 @@ __device__ static inline void bump_count(uint32_t *lines32, uint32_t value)
 #define APUS_STEP_SEGS 32
 struct StepTable {
     CallArgs seg[APUS_STEP_SEGS];
-    uint32_t blk0[APUS_STEP_SEGS + 1];        /* first block of every segment; blk0[S] = grid size */
+    uint32_t blk0[APUS_STEP_SEGS + 1];        /* order 0: first block of every segment; blk0[S] = grid size */
     uint32_t S;
+    /* order 1 (append blocks first): blocks [0, S) the segments' bookkeepers, [S, 2S) their sequencers,
+     * then every segment's append blocks (ab0[k] = first of segment k), then every segment's record /
+     * scan / apply blocks (sv0[k]).  All append blocks of the launch are then resident from the
+     * start and issue their loads before anybody stores (see append_group); the host only picks it
+     * when they -- and one segment's other blocks -- fit on the device together (flush_batch), which
+     * keeps "a block only waits for blocks that are running or done" true in this order as well. */
+    uint32_t order;
+    uint32_t ab0[APUS_STEP_SEGS + 1];
+    uint32_t sv0[APUS_STEP_SEGS + 1];
 };
 
 /* The body of a call for block b of its grid.  STEP = false: k_call (one call per launch, inputs =
@@ -2301,7 +2552,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
         uint32_t fast;
 #ifndef APUS_NO_GP
         if (A.GP > 1) {
-            fast = append_group(E, X, r0, R, push_mask, ab, l.grp, &sq, tick, snap, live && !STEP, rec_seg);
+            fast = append_group(E, X, r0, R, push_mask, ab, l.grp, &sq, tick, snap, live && !STEP, rec_seg, A.GP / APUS_GP);
         } else
 #endif
         {
@@ -2347,9 +2598,26 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
     uint32_t q = b - 1 - nAB;
     if (q < nR) {                                              /* ---- per-round records ---- */
         if (q == 0) STAMP(5, 0);
-        if (!live) wait_count(E, E.step_epoch, b, seg);
-        /* the sequencing, worked out locally (SeqOut in sq.out) */
-        seq_local(E, X, r0, R, push_mask, tick, 0, rl_base + q, sq, snap, false, live);
+        if (STEP && q == 0 && seg < 8) STAMPN(15, 8 * seg + 0);      /* janitor block: started */
+        bool from_rec = false;
+        if (STEP) {
+            /* a segment the chain block sequenced: everything finish_records needs is in its record */
+            if (tid < WAVE) {
+                rec_wait(E, seg, sq);
+                if (tid == 0) sq.pfx[0] = gld(&E.round_prefix[r0]);
+            }
+            __syncthreads();
+            from_rec = sq.ok && sq.out.fast && sq.chain_did;
+            /* (segment 0: the chain block counts this block among the readers of the live words) */
+            if (from_rec && live && tid == 0)
+                __hip_atomic_fetch_add(X.lines + ((rl_base + q) & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!from_rec) {
+            if (STEP) __syncthreads();
+            if (!live) wait_count(E, E.step_epoch, b, seg);
+            /* the sequencing, worked out locally (SeqOut in sq.out) */
+            seq_local(E, X, r0, R, push_mask, tick, 0, rl_base + q, sq, snap, false, live);
+        }
         if (q == 0) STAMP(5, 1);
         /* the rounds' byte prefix: the host-staged one, or the block's own scan */
         const uint64_t *virt = sq.ok ? E.round_prefix + r0 : sq.virt;
@@ -2360,10 +2628,13 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
             finish_records(E, r0, R, sq.out.vis, (uint64_t)q * blockDim.x + tid, (uint64_t)nR * blockDim.x, sq.out,
                            sq.out.rec_base, virt, vbase);
             if (q == 0) STAMP(5, 2);
+            if (STEP && q == 0 && seg < 8) STAMPN(15, 8 * seg + 1);  /* records written */
             wait_append(E, X, nAB);
             if (q == 0) STAMP(5, 3);
+            if (STEP && q == 0 && seg < 8) STAMPN(15, 8 * seg + 2);  /* the segment's append blocks are done */
             fold_round_hashes(E, X, R, q, nR, sq.out.fuse_mask);
             if (q == 0) STAMP(5, 4);
+            if (STEP && q == 0 && seg < 8) STAMPN(15, 8 * seg + 3);  /* hashes folded */
         } else {
             wait_append(E, X, nAB);
             wait_ticket(E, X, T_SCAN, nS);
@@ -2379,6 +2650,25 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
         /* the janitor: every append block is done (wait_append above), everybody else -- the
          * sequencer with its <HEAD> entry too -- signs off with T_PASS */
         wait_ticket(E, X, T_PASS, n_pass);
+        if (STEP && seg < 8) STAMPN(15, 8 * seg + 4);                    /* everybody has signed off */
+        /* a multi-segment launch: the last segment's janitor clears what the whole launch shares, so it
+         * goes last of all janitors (every other block of a segment has signed off with its janitor) */
+        if (STEP && S > 1) {
+            uint32_t *jan = E.step_tickets + T_JANITORS;
+            if (seg + 1 != S) {
+                if (tid == 0) __hip_atomic_fetch_add(jan, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (tid == 0) {
+                    unsigned long long spins = 0;
+                    while (__hip_atomic_load(jan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S - 1) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > (1ull << 22)) { spin_timeout(E, 2470); break; }     /* bounded */
+                    }
+                    __hip_atomic_store(jan, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+            }
+        }
         /* then the call's counters and the flag are cleared for the next call */
         if (tid < 32) {
             __hip_atomic_store(X.lines + tid * 32 + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2426,8 +2716,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
         __shared__ uint64_t pre_pfx[APUS_STEP_SEGS][2];
         __shared__ uint32_t pre_rf[APUS_STEP_SEGS][2];
         __shared__ uint64_t pre_last[APUS_STEP_SEGS];
-        /* the state before the launch, kept for the second pass (see below) */
-        __shared__ uint64_t init_lh[64], init_fw[APUS_DEV_MAX_SERVERS][8], init_rec;
+        __shared__ uint32_t n_dry_s;
         if (STEP && TT && tid < S_) {
             const CallArgs &Ap = TT->seg[tid];
             const uint32_t a = E.round_first[Ap.r0], bb = E.round_first[Ap.r0 + Ap.R];
@@ -2447,38 +2736,98 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                 seq_w0_stage(E, A0.r0, A0.R, push_mask, 0, sq, nullptr, true);
                 if (tid == 0) __hip_atomic_fetch_add(X.lines + ((STEP ? A0.nR : nAB0 + A0.nR) & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (tid == 0) n_dry_s = 0;
             __syncthreads();
+#ifndef APUS_NO_DRY
+            if (STEP && TT) {
+                /* ---- the RECORD PASS: wave 0 sequences every segment it can on registers (chain_core)
+                 * and publishes the records, before the block does anything else -- no LDS, no barrier, no
+                 * store other than the records (on a CU it shares with two append blocks every LDS or
+                 * memory round trip queues behind theirs: ~3.5 us per segment when this pass worked on
+                 * the LDS copies, profiles/README.md).  It stops at the first segment that is not in
+                 * step or needs the general path; the second pass publishes the records from there on. */
+                if (tid < WAVE) {
+                    const uint32_t lane = tid;
+                    const bool srv = lane < APUS_DEV_MAX_SERVERS;
+                    ChainRegs cr;
+                    cr.end = sq.lh[H_END]; cr.n_end = sq.lh[H_N_END]; cr.last_idx = sq.lh[H_LAST_IDX]; cr.sid = sq.lh[H_SID];
+                    cr.commit = sq.lh[H_COMMIT]; cr.n_commit = sq.lh[H_N_COMMIT]; cr.n_apply = sq.lh[H_N_APPLY]; cr.apply = sq.lh[H_APPLY];
+                    cr.head = sq.lh[H_HEAD]; cr.tail = sq.lh[H_TAIL]; cr.prev_head = sq.lh[H_PREV_HEAD]; cr.store_count = sq.lh[H_STORE_COUNT];
+                    cr.bitmask = (uint32_t)sq.lh[H_CID_BITMASK];
+                    cr.apoff = srv ? sq.lh[H_APPLY_OFFSETS + lane] : 0;
+                    cr.f_apply = srv ? c.fw[lane][FW_APPLY] : 0; cr.f_np = srv ? c.fw[lane][FW_N_PERSIST] : 0; cr.f_na = srv ? c.fw[lane][FW_N_APPLY] : 0;
+                    cr.rec_base = sq.misc[0];
+                    /* lane k holds segment k's staged sizes */
+                    uint64_t my_pfx0 = 0, my_pfx2 = 0, my_last = 0, my_r0 = 0;
+                    uint32_t my_rf0 = 0, my_rf1 = 0, my_R = 0, my_tick = 0;
+                    if (lane < S_) {
+                        my_pfx0 = pre_pfx[lane][0]; my_pfx2 = pre_pfx[lane][1]; my_last = pre_last[lane];
+                        my_rf0 = pre_rf[lane][0]; my_rf1 = pre_rf[lane][1];
+                        my_r0 = TT->seg[lane].r0; my_R = TT->seg[lane].R; my_tick = TT->seg[lane].tick;
+                    }
+                    uint32_t nd = 0;
+                    for (uint32_t k = 0; k < S_; k++) {
+                        ChainSeg g;
+                        g.r0 = rl64(my_r0, k); g.pfx0 = rl64(my_pfx0, k); g.pfx2 = rl64(my_pfx2, k); g.len_last = rl64(my_last, k);
+                        g.rf0 = (uint32_t)__builtin_amdgcn_readlane((int)my_rf0, (int)k); g.rf1 = (uint32_t)__builtin_amdgcn_readlane((int)my_rf1, (int)k);
+                        g.R = (uint32_t)__builtin_amdgcn_readlane((int)my_R, (int)k); g.tick = (uint32_t)__builtin_amdgcn_readlane((int)my_tick, (int)k);
+                        ChainOut o;
+                        if (!chain_core(E, push_mask, cr, g, o)) break;
+                        RecFields f;
+                        f.e0 = o.e0; f.idx0 = o.idx0; f.n_end0 = o.n_end0; f.term = cr.sid >> 9;
+                        f.flags_n = (uint64_t)rec_flags(1u, push_mask, 1u, o.head_round, o.stale, o.estar >= 0, true) | ((uint64_t)o.n << 32);
+                        f.kstar = (uint64_t)o.kstar; f.w = o.w; f.rec_base = cr.rec_base; f.commit_before = cr.commit; f.n_commit_before = cr.n_commit;
+                        rec_publish_fields(E, k, f);
+                        if (k < 64) STAMPN(9, k);
+                        chain_advance(E, push_mask, cr, g, o);
+                        nd = k + 1;
+                    }
+                    if (lane == 0) n_dry_s = nd;
+                }
+                __syncthreads();
+            }
+#endif
             if (STEP) {
                 /* snapshot 0 = the state before the launch: what a fallback path of segment 0
                  * sequences from (the live words may change as soon as the readers are through) */
                 uint64_t *s0 = E.step_snap;
-                if (tid < 64) { gst(&s0[tid], sq.lh[tid]); init_lh[tid] = sq.lh[tid]; c.lh[tid] = sq.lh[tid]; }
-                else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) { gst(&s0[SNAP_FW + (tid - 64)], (&c.fw[0][0])[tid - 64]); (&init_fw[0][0])[tid - 64] = (&c.fw[0][0])[tid - 64]; }
-                else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) { gst(&s0[SNAP_REC], sq.misc[0]); init_rec = sq.misc[0]; c.rec_base = sq.misc[0]; }
+                const bool snap0 = !TT || n_dry_s < S_;
+                if (tid < 64) { if (snap0) gst(&s0[tid], sq.lh[tid]); c.lh[tid] = sq.lh[tid]; }
+                else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) { if (snap0) gst(&s0[SNAP_FW + (tid - 64)], (&c.fw[0][0])[tid - 64]); }
+                else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) { if (snap0) gst(&s0[SNAP_REC], sq.misc[0]); c.rec_base = sq.misc[0]; }
                 __syncthreads();
             }
         }
-        /* Two passes over the segments in a multi-segment launch.  The DRY pass only sequences
-         * (chain_decide_fast), publishes each segment's record and advances the LDS copy of the state --
-         * no effect on memory besides the records: ~1.5 us per segment, so the append blocks of every
-         * segment have their record a few microseconds into the launch.  It stops at the first
-         * segment the chain block cannot sequence on its own.  The REAL pass starts over from the
-         * saved state and does what the first could not: the live control words, the <HEAD> entries,
-         * the snapshots, the tickets, and the general path for the segments that need it. */
-        uint32_t n_dry = 0;
-#ifdef APUS_NO_DRY
-        for (int pass = 1; pass < 2; pass++) {
-#else
-        for (int pass = STEP ? 0 : 1; pass < 2; pass++) {
-#endif
-        const bool dry = pass == 0;
-        if (STEP && pass == 1) {
-            __syncthreads();
-            if (tid < 64) c.lh[tid] = init_lh[tid];
-            else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) (&c.fw[0][0])[tid - 64] = (&init_fw[0][0])[tid - 64];
-            else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) c.rec_base = init_rec;
-            __syncthreads();
+        /* The second pass: everything but the records of the segments the record pass sequenced -- the
+         * live control words, the <HEAD> entries, the snapshots, the tickets, and the general path for
+         * the segments that need it.  It starts over from the state before the launch (c.lh / c.fw). */
+        const uint32_t n_dry = (STEP && TT) ? n_dry_s : 0u;
+#ifndef APUS_NO_FAST_BOOKS
+        if (STEP && TT && S_ > 0 && n_dry == S_) {
+            /* every segment is in step and was sequenced on registers: so are the books (chain_books_fast) */
+            if (tid < WAVE) {
+                const uint32_t lane = tid;
+                const bool srv = lane < APUS_DEV_MAX_SERVERS;
+                ChainRegs cr;
+                cr.end = sq.lh[H_END]; cr.n_end = sq.lh[H_N_END]; cr.last_idx = sq.lh[H_LAST_IDX]; cr.sid = sq.lh[H_SID];
+                cr.commit = sq.lh[H_COMMIT]; cr.n_commit = sq.lh[H_N_COMMIT]; cr.n_apply = sq.lh[H_N_APPLY]; cr.apply = sq.lh[H_APPLY];
+                cr.head = sq.lh[H_HEAD]; cr.tail = sq.lh[H_TAIL]; cr.prev_head = sq.lh[H_PREV_HEAD]; cr.store_count = sq.lh[H_STORE_COUNT];
+                cr.bitmask = (uint32_t)sq.lh[H_CID_BITMASK];
+                cr.apoff = srv ? sq.lh[H_APPLY_OFFSETS + lane] : 0;
+                cr.f_apply = srv ? c.fw[lane][FW_APPLY] : 0; cr.f_np = srv ? c.fw[lane][FW_N_PERSIST] : 0; cr.f_na = srv ? c.fw[lane][FW_N_APPLY] : 0;
+                cr.rec_base = sq.misc[0];
+                chain_books_fast(E, push_mask, cr, srv ? c.fw[lane][FW_STORE_COUNT] : 0, srv ? c.fw[lane][FW_HEAD] : 0,
+                                 S_, pre_pfx, pre_rf, pre_last, TT->seg, sq.out);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < sizeof(SeqOut) / 8) gst(&((uint64_t *)E.seq)[lane], ((const uint64_t *)&sq.out)[lane]);
+            }
+            bump_count(E.step_epoch, S_);          /* (nobody waits for it in such a launch; the janitor clears it) */
+            return;
         }
+#endif
+        /* snapshots are what the fallback paths of a segment sequence from: none of them runs when the
+         * record pass got through the whole launch */
+        const bool snaps = STEP && n_dry < S_;
         for (uint32_t k = 0; k < S_; k++) {
             const CallArgs &Ak = (STEP && TT) ? TT->seg[k] : A;
             const CallEnv Xk = (STEP && TT) ? CallEnv{E.step_lines + (size_t)k * 1024, E.step_tickets + (size_t)k * 32,
@@ -2488,7 +2837,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
             const uint32_t nABk = call_append_blocks(Ak), nRk = Ak.nR, nAk = Ak.nA;
             const uint32_t n_readers_k = STEP ? nRk + 1 : nABk + nRk + 1;
             const bool live_k = !STEP || k == 0;
-            uint64_t *snap_next_k = STEP ? E.step_snap + (size_t)(k + 1) * SNAP_STRIDE : nullptr;
+            uint64_t *snap_next_k = snaps ? E.step_snap + (size_t)(k + 1) * SNAP_STRIDE : nullptr;
             if (STEP) {
                 /* the inputs: the state the previous segment's bookkeeping left in LDS (segment 0: the
                  * staged live words) + this segment's staged sizes (what seq_w0_stage fetches) */
@@ -2504,25 +2853,10 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
             }
             if (tid < WAVE) {
                 const int cf = STEP ? chain_decide_fast(E, push_mask, tickk, sq, r0k, Rk) : 0;
-                if (!cf && !dry && tid == 0) seq_w0_decide<false>(E, push_mask, tickk, sq);
+                if (!cf && tid == 0) seq_w0_decide<false>(E, push_mask, tickk, sq);
                 if (tid == 0) chain_fast = (uint32_t)cf;
             }
             __syncthreads();
-            if (dry) {
-                if (!chain_fast) break;                        /* the real pass takes it from here */
-                if (tid < WAVE) rec_publish(E, k, sq, true);
-                if (k < 64) STAMPN(9, k);
-                n_dry = k + 1;
-                /* the books, in LDS only */
-                if (tid < 64) c.lh[tid] = sq.lh[tid];
-                else if (tid < 64 + sizeof(SeqOut) / 8) ((uint64_t *)&c.seq)[tid - 64] = ((const uint64_t *)&sq.out)[tid - 64];
-                __syncthreads();
-                if (tid == 0) { c.rec_base = sq.out.rec_base; c.off_cs = sq.end_new; c.off_vis = sq.end_new; }
-                __syncthreads();
-                keeper_publish(E, c, Rk, 0, fmask, sq.out.vis, sq.out.vis, true, sq.out.head_round ? sq.out.n_end0 : 0, sq.lh[H_HEAD], nullptr, true);
-                continue;
-            }
-            if (k < 8) STAMPN(15, 8 * k + 0);              /* decided */
             /* this segment's other blocks (its sequencer first) have work the books depend on, unless the
              * chain block sequenced it itself (chain_fast: in step, then it also does the effects) */
             const bool wait_needed = !chain_fast;
@@ -2557,9 +2891,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                 }
                 __syncthreads();
                 if (live_k) wait_readers(E, Xk, n_readers_k);          /* it changes words the other blocks sequence from */
-                if (k < 8) STAMPN(15, 8 * k + 1);          /* copies + wait_readers done */
                 if (STEP && chain_fast && tid < WAVE) chain_effects_fast(E, push_mask, tickk, sq);
-                if (k < 8) STAMPN(15, 8 * k + 2);          /* effects issued */
                 /* in step, but sequenced by the general path: this segment's sequencer block carries it
                  * out -- it has to be through before the next segment's effects touch the same words */
                 if (STEP && !chain_fast) wait_sequenced(E, Xk, b, &l.t.flag);
@@ -2578,13 +2910,10 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                 __syncthreads();
                 keeper_publish(E, c, Rk, 0, fmask, vis, cs, false, 0, 0, snap_next_k);
             }
-            if (k < 8) STAMPN(15, 8 * k + 3);              /* keeper_publish + snapshot issued */
             /* the books of the launch are closed: every snapshot is complete -- raised BEFORE this
              * segment's sign-off (its janitor clears the chain counts once everybody has signed off) */
             if (STEP && k + 1 == S_) bump_count(E.step_epoch, S_);
             post_ticket(E, Xk, T_PASS, false);
-            if (k < 8) STAMPN(15, 8 * k + 4);              /* signed off */
-        }
         }
         return;
     }
@@ -2667,10 +2996,24 @@ __global__ APUS_CALL_BOUNDS void k_step(const EngDev E_arg, const StepTable T, u
     const EngDev &E = E_s;
     __shared__ SeqLds sq;
     __shared__ CallLds l;
-    uint32_t seg = 0;
-    for (uint32_t k = 1; k < T.S; k++) if (blockIdx.x >= T.blk0[k]) seg = k;
+    uint32_t seg = 0, b_grid;
+    if (T.order == 0) {
+        for (uint32_t k = 1; k < T.S; k++) if (blockIdx.x >= T.blk0[k]) seg = k;
+        b_grid = blockIdx.x - T.blk0[seg];
+    } else {
+        const uint32_t b = blockIdx.x;
+        if (b < T.S) { seg = b; b_grid = 0; }
+        else if (b < 2 * T.S) { seg = b - T.S; b_grid = 1; }
+        else if (b < T.sv0[0]) {
+            for (uint32_t k = 1; k < T.S; k++) if (b >= T.ab0[k]) seg = k;
+            b_grid = 2 + (b - T.ab0[seg]);
+        } else {
+            for (uint32_t k = 1; k < T.S; k++) if (b >= T.sv0[k]) seg = k;
+            b_grid = 2 + call_append_blocks(T.seg[seg]) + (b - T.sv0[seg]);
+        }
+    }
     const CallEnv X{E.step_lines + (size_t)seg * 1024, E.step_tickets + (size_t)seg * 32, E.step_hash + (size_t)seg * 2 * 1024};
-    call_block<true>(E, X, T.seg[seg], push_mask, rmask, blockIdx.x - T.blk0[seg], sq, l, seg, T.S, &T);
+    call_block<true>(E, X, T.seg[seg], push_mask, rmask, b_grid, sq, l, seg, T.S, &T);
 }
 
 /* READ the apply offset of peer i for the next prune tick (rc_get_remote_apply_offsets,

@@ -17,7 +17,8 @@ for c in calls:
     first.append(c)
     if c[0] == "rounds":
         n += 1
-        if n == 6: break
+        if n == 5: break
+eng.set_timing(True)
 for rep in range(3):
     eng.batch_begin()
     for c in first:
@@ -25,6 +26,7 @@ for rep in range(3):
         elif c[0] == "prune": eng.tick_prune()
     eng.batch_end()
     eng.sync()
+print('launch (HIP events): total ms, launches =', eng.kernel_time(0))
 L = eng.L
 L.apus_gpu_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 buf = np.zeros(64 * 16, dtype=np.uint64)
@@ -38,7 +40,7 @@ for k in range(8):
     print(" %2d | %7s | %7s %7s | %7s %7s %7s" % (k, us(row(9)[k]), us(row(10)[k]), us(row(11)[k]), us(row(14)[k]), us(row(12)[k]), us(row(13)[k])))
 
 c = row(15)
-print("chain block per segment (us): decided, copies+readers, effects issued, books issued, signed off")
+print("janitor (record block 0) per segment (us): started, records written, append blocks done, hashes folded, all signed off")
 for k in range(8):
     v = c[8 * k:8 * k + 5]
     if not v[0]: break
