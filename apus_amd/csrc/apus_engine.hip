@@ -53,6 +53,11 @@ struct apus_engine {
     uint32_t gp_rounds;                        /* APUS_GP_ROUNDS (default 4; 1 = one workgroup per round), see call_args */
     uint64_t gp_max_units;                     /* APUS_GP_MAX_UNITS: largest mean round (16-byte units) that is grouped */
     uint32_t step_slots;                       /* workgroups of k_step the device holds at once (occupancy x CUs) */
+    /* admission (log_append_entry refuses a full log, dare_log.h:168,492-495): a lower bound of the free
+     * bytes of the leader's ring, refreshed from the control block only when it does not cover a batch */
+    uint64_t free_lb;
+    uint64_t stage_max_T;                      /* largest entry (header + payload) of the staged requests */
+    uint32_t host_status;                      /* status bits raised on the host side (APUS_ST_LOG_FULL) */
     struct BatchSeg { CallArgs a; uint32_t blocks; uint64_t bytes; };
     std::vector<BatchSeg> batch;               /* recorded calls: arguments, blocks, bytes they append */
     /* graphs */
@@ -152,6 +157,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
         const char *so_env = getenv("APUS_STEP_ORDER");          /* 0: always segment by segment */
         if (so_env && atoi(so_env) == 0) e->step_slots = 0;
     }
+    e->free_lb = 0; e->stage_max_T = APUS_HDR; e->host_status = 0;
     e->n_reqs = 0; e->n_rounds_staged = 0;
     e->d_req = e->d_req_len = e->d_arena = e->d_round_first = e->d_round_prefix = nullptr;
     e->h_live = nullptr; e->d_live = nullptr; e->live_pending = false; e->live_copied = nullptr;
@@ -224,6 +230,7 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
     hipStreamSynchronize(e->stream);
     for (auto g : e->graphs) hipGraphExecDestroy(g);
     for (auto &t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    if (e->p_running) apus_gpu_persist_stop(e);       /* before anything it reads is freed */
     for (void *p : e->ipc_ptrs) hipIpcCloseMemHandle(p);
     for (void *p : e->allocs) hipFree(p);
     if (e->d_req) hipFree(e->d_req);
@@ -231,7 +238,6 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
     if (e->d_arena) hipFree(e->d_arena);
     if (e->d_round_first) hipFree(e->d_round_first);
     if (e->d_round_prefix) hipFree(e->d_round_prefix);
-    if (e->p_running) apus_gpu_persist_stop(e);
     if (e->ph) hipHostFree(e->ph);
     if (e->pd) hipFree(e->pd);
     if (e->pstream) hipStreamDestroy(e->pstream);
@@ -264,6 +270,7 @@ extern "C" int apus_gpu_reset(apus_engine_t *e)
         }
     e->d.leader = 0xFFFFFFFFu;
     e->tick_pending = false;
+    e->free_lb = 0; e->host_status = 0;
     e->reachable = (1u << e->d.group_size) - 1;
     e->d.reachable = e->reachable;
     {
@@ -329,6 +336,8 @@ extern "C" int apus_gpu_stage(apus_engine_t *e, const apus_req_t *reqs, uint64_t
     HIPCHK(hipStreamSynchronize(e->stream));
     std::vector<ReqDev> hd(n);
     std::vector<uint16_t> hl(n);
+    e->stage_max_T = APUS_HDR;
+    for (uint64_t i = 0; i < n; i++) e->stage_max_T = std::max<uint64_t>(e->stage_max_T, APUS_HDR + (uint64_t)reqs[i].len);
     for (uint64_t g = 0; g < n; g++) {
         const apus_req_t &q = reqs[g];
         if (q.payload_off % 16 || q.payload_off + q.len > arena_bytes) return APUS_E_ARG;
@@ -452,6 +461,33 @@ static int launch_append(apus_engine *e, const EngDev &view, uint64_t r0, uint32
     return 0;
 }
 
+/* Admission of `bytes` of new entries (+ `slack`: <HEAD> entries of due prune ticks, the bytes a wrap
+ * skips) BEFORE anything is launched.  The reference's leader refuses a request when the log is full
+ * (log_add_new_entry returns NULL at end == head, dare_log.h:168,213-221, 492-495) -- and runs over
+ * un-pruned entries when a request merely crosses head; here a batch that does not fit into the free
+ * part of the ring is refused as a whole and nothing of it is stored.  The bound is conservative
+ * (head only moves forward); the control block is read back only when the bound does not cover the
+ * batch, i.e. about once per lap of the ring.  A captured graph cannot consult the host: its
+ * launches rely on the device-side flag alone (apus_gpu_status, APUS_ST_LOG_FULL). */
+static int admit_bytes(apus_engine *e, uint64_t bytes, uint64_t slack)
+{
+    if (e->capturing) return 0;
+    const uint64_t need = bytes + slack;
+    if (e->free_lb >= need) { e->free_lb -= need; return 0; }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    uint64_t h[64];
+    HIPCHK(hipMemcpy(h, e->d.rep[e->d.leader].hdr, sizeof h, hipMemcpyDeviceToHost));
+    const uint64_t L = e->d.log_len, end = h[H_END], head = h[H_HEAD];
+    uint64_t fr;
+    if (end == L) fr = L;                                   /* reads as empty */
+    else if (end == head) fr = 0;                           /* log_is_full */
+    else fr = L - (end > head ? end - head : L - (head - end));
+    e->free_lb = fr;
+    if (need > fr) { e->host_status |= APUS_ST_LOG_FULL; return APUS_E_FULL; }
+    e->free_lb -= need;
+    return 0;
+}
+
 /* k_call sequences up to this many rounds per launch (their prefix stays in LDS) */
 #define APUS_CALL_ROUNDS 1024u
 
@@ -490,6 +526,8 @@ static int flush_batch(apus_engine *e)
      * segments while they append less than one ring (minus slack for <HEAD> entries and the bytes
      * skipped at a wrap). */
     const uint64_t lap = e->d.log_len - e->d.log_len / 8;
+    /* (admission of a batch is the device's: prune ticks inside it move head -- segment_refused) */
+    e->free_lb = 0;
     size_t i = 0;
     while (i < e->batch.size()) {
         StepTable T;
@@ -516,6 +554,7 @@ static int flush_batch(apus_engine *e)
             k++;
         }
         T.S = k;
+        T.max_T = (uint32_t)e->stage_max_T;
         uint32_t gd = 1;
         for (; gd < APUS_GD; gd++) {
             uint32_t n_app = 0;
@@ -573,6 +612,11 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
     if (n_rounds == 0) return 0;
     const uint32_t fm = sync_mask(e);
     const uint32_t rm = fm | ((e->local_mask >> e->d.leader) & 1u ? (1u << e->d.leader) : 0);
+    if (!e->batching) {
+        const uint64_t chunks = (n_rounds + APUS_CALL_ROUNDS - 1) / APUS_CALL_ROUNDS;
+        if ((rc = admit_bytes(e, e->h_round_prefix[r0 + n_rounds] - e->h_round_prefix[r0],
+                              chunks * e->stage_max_T + (e->tick_pending ? APUS_HDR : 0) + APUS_HDR))) return rc;
+    }
     if (!e->batching || e->batch.empty()) { if ((rc = launch_catchup(e))) return rc; }
     for (uint64_t done = 0; done < n_rounds; done += APUS_CALL_ROUNDS) {
         const uint64_t c0 = r0 + done;
@@ -681,6 +725,12 @@ extern "C" int apus_gpu_append_live(apus_engine_t *e, const apus_req_t *reqs, ui
         rf[R++] = g;
     }
     rf[R] = n;
+    {
+        /* get_tailq_message refuses what the log cannot take (dare_ibv_ud.c:780-790 -> log_append_entry) */
+        uint64_t max_T = APUS_HDR;
+        for (uint32_t g = 0; g < n; g++) max_T = std::max<uint64_t>(max_T, APUS_HDR + (uint64_t)hl[g]);
+        if ((rc = admit_bytes(e, pf[R], max_T + (e->tick_pending ? APUS_HDR : 0) + APUS_HDR))) return rc;
+    }
     if (arena_bytes) memcpy(ha + 16, arena, arena_bytes);
     HIPCHK(hipMemcpyAsync(e->d_live, e->h_live, LIVE_OFF_ARENA + 16 + arena_bytes, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipEventRecord(e->live_copied, e->stream));
@@ -750,6 +800,7 @@ static int launch_control_round(apus_engine *e, int mode, uint32_t type, uint64_
     int rc = launch_catchup(e);
     if (rc) return rc;
     const uint32_t fm = sync_mask(e);
+    if (mode != 2) e->free_lb = e->free_lb > 2 * APUS_HDR ? e->free_lb - 2 * APUS_HDR : 0;     /* at most one 64-byte entry (+ a skipped tail) */
     hipLaunchKernelGGL(k_control_round, dim3(1), dim3(256), 0, e->stream, e->d, mode, type, d0, d1, fm, fm);
     HIPCHK(hipGetLastError());
     return 0;
@@ -841,6 +892,7 @@ extern "C" int apus_gpu_become_leader_ex(apus_engine_t *e, uint32_t leader, uint
     if (!((e->local_mask >> leader) & 1u)) return APUS_E_STATE;
     if (e->d.leader < e->d.group_size) { int frc = flush_tick(e); if (frc) return frc; }
     e->tick_pending = false;
+    e->free_lb = 0;                                  /* another server's ring from now on */
     e->d.leader = leader;
     const uint64_t sid = (term << 9) | (1ull << 8) | leader;
     hipLaunchKernelGGL(k_set_roles, dim3(1), dim3(64), 0, e->stream, e->d, sid, bitmask, e->reachable);
@@ -868,6 +920,7 @@ extern "C" int apus_gpu_become_leader(apus_engine_t *e, uint32_t leader, uint64_
 extern "C" int apus_gpu_set_reachable(apus_engine_t *e, uint32_t mask)
 {
     if (!e) return APUS_E_ARG;
+    if (e->batching) return APUS_E_STATE;           /* close the batch first (apus_gpu_batch_end) */
     { int frc = flush_tick(e); if (frc) return frc; }
     if (mask & ~e->reachable) e->lag_possible = true;     /* somebody was released */
     e->reachable = mask;
@@ -906,6 +959,7 @@ extern "C" int apus_gpu_graph_launch(apus_engine_t *e, int graph_id)
     if (e && e->batching) return APUS_E_STATE;      /* close the batch first (apus_gpu_batch_end) */
     if (!e || graph_id < 0 || graph_id >= (int)e->graphs.size()) return APUS_E_ARG;
     HIPCHK(hipGraphLaunch(e->graphs[graph_id], e->stream));
+    e->free_lb = 0;                                  /* (what the replay appends is not accounted: read back next time) */
     return 0;
 }
 
@@ -1006,7 +1060,7 @@ extern "C" uint32_t apus_gpu_status(apus_engine_t *e)
     hipStreamSynchronize(e->stream);
     hipMemcpy(s, e->d.status, sizeof s, hipMemcpyDeviceToHost);
     if ((s[0] & (1u << 4)) && getenv("APUS_DEBUG")) fprintf(stderr, "[apus] spin timeout first hit at apus_kernels.h:%u\n", s[1]);
-    return s[0];
+    return s[0] | e->host_status;
 }
 
 extern "C" void apus_gpu_clear_status(apus_engine_t *e)
@@ -1014,6 +1068,7 @@ extern "C" void apus_gpu_clear_status(apus_engine_t *e)
     if (!e) return;
     hipStreamSynchronize(e->stream);
     hipMemset(e->d.status, 0, 2 * sizeof(uint32_t));
+    e->host_status = 0;
 }
 
 extern "C" void *apus_gpu_device_ptr(apus_engine_t *e, uint32_t replica, int which, uint64_t *bytes)
@@ -1201,6 +1256,9 @@ extern "C" int apus_gpu_persist_drain(apus_engine_t *e, uint32_t timeout_ms)
     return 0;
 }
 
+/* 1 once the persistent kernel refused a round because the log is full (the requests of that round
+ * are dropped: their submitters are never released by highest_rec) */
+extern "C" int apus_gpu_persist_full(apus_engine_t *e) { return (e && e->ph) ? (int)e->ph->full : 0; }
 extern "C" uint64_t apus_gpu_persist_highest_rec(apus_engine_t *e) { return (e && e->ph) ? e->ph->highest_rec : 0; }
 extern "C" const volatile uint64_t *apus_gpu_persist_highest_rec_ptr(apus_engine_t *e) { return (e && e->ph) ? &e->ph->highest_rec : nullptr; }
 

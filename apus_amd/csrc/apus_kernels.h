@@ -269,6 +269,7 @@ struct SeqLds {
     uint32_t rfx[2];                      /* wave-0 variant: first request of round 0 and of round R */
     uint32_t ok;                          /* wave-0 variant: 1 = SeqOut worked out, 0 = take the block-wide path */
     uint32_t chain_did;                   /* rec_wait: the chain block does this segment's sequencer effects itself */
+    uint32_t refused;                     /* rec_wait: the segment was refused (segment_refused): nothing is stored */
     uint64_t end_new;                     /* the leader's end offset after the batch */
     SeqOut   out;                         /* FX = false: the call's SeqOut */
 };
@@ -667,6 +668,22 @@ __device__ static inline void seq_w0_decide(const EngDev &E, uint32_t push_mask,
  * a launch before anything else (the record pass), so it must not queue behind the append blocks
  * that share its CU -- no LDS, no memory access except the staged byte prefix of a batch that wraps.
  * Scalars are wave-uniform; apoff / f_* are per lane (lane = server). */
+/* Admission of a segment of a multi-segment launch, on the device (between two prune ticks of one
+ * launch the host cannot know where head is).  log_append_entry refuses a request when the log is
+ * full (end == head, dare_log.h:168,492-495) and the reference runs over un-pruned entries when a
+ * request merely crosses head; here a segment whose bytes (+ a due tick's <HEAD> entry + the bytes
+ * a wrap may skip, at most one entry: max_T) do not fit into the free part of the ring is refused
+ * AS A WHOLE: its record says so, nobody stores anything, the state stays as it is, status bit
+ * LOG_FULL tells the host.  (Calls outside a batch and the live path are admitted on the host,
+ * apus_engine.hip:admit_bytes.) */
+__device__ static inline bool segment_refused(uint64_t L, uint64_t end, uint64_t head, uint64_t vtot, uint32_t tick, uint32_t max_T)
+{
+    if (end == L) return vtot + (tick ? APUS_HDR : 0) > L;             /* reads as empty */
+    if (end == head) return true;                                      /* log_is_full */
+    const uint64_t used = end > head ? end - head : L - (head - end);
+    return vtot + (tick ? APUS_HDR : 0) + max_T > L - used;
+}
+
 struct ChainRegs {
     uint64_t end, n_end, last_idx, sid, commit, n_commit, n_apply, apply, head, tail, prev_head, store_count, rec_base;
     uint32_t bitmask;
@@ -873,7 +890,7 @@ __device__ static inline void chain_effects_fast(const EngDev &E, uint32_t push_
 template <typename SEG>      /* CallArgs (defined below) */
 __device__ static inline void chain_books_fast(const EngDev &E, uint32_t push_mask, ChainRegs cr, uint64_t fw_sc, uint64_t fw_head,
                                                uint32_t S, const uint64_t (*pre_pfx)[2], const uint32_t (*pre_rf)[2], const uint64_t *pre_last,
-                                               const SEG *segs, SeqOut &last_out)
+                                               const SEG *segs, SeqOut &last_out, uint32_t max_T)
 {
     const uint32_t lane = lane_id();
     const RepDev &Ld = E.rep[E.leader];
@@ -897,6 +914,21 @@ __device__ static inline void chain_books_fast(const EngDev &E, uint32_t push_ma
         g.rf0 = (uint32_t)__builtin_amdgcn_readlane((int)my_rf0, (int)k); g.rf1 = (uint32_t)__builtin_amdgcn_readlane((int)my_rf1, (int)k);
         g.R = (uint32_t)__builtin_amdgcn_readlane((int)my_R, (int)k); g.tick = (uint32_t)__builtin_amdgcn_readlane((int)my_tick, (int)k);
         ChainOut o;
+        if (segment_refused(L, cr.end, cr.head, g.pfx2 - g.pfx0, g.tick, max_T)) {
+            /* refused by the record pass: nothing was stored, nothing changes; its blocks sign off on their own */
+            if (lane == 0) {
+                set_status(E, 1u << 1);
+                __hip_atomic_fetch_add(E.step_tickets + (size_t)k * 32 + T_PASS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (k + 1 == S && lane == 0) {
+                SeqOut &s = last_out;
+                s.e0 = cr.end; s.idx0 = cr.last_idx + 1; s.w = 0; s.n_end0 = cr.n_end; s.term = cr.sid >> 9; s.kstar = -1; s.estar = -1; s.stale = 0;
+                s.n = 0; s.head_round = 0; s.pad0 = 0; s.first_fail = ~0ull; s.commit_before = cr.commit; s.n_commit_before = cr.n_commit;
+                s.vis = cr.n_end; s.scan_lo = cr.n_commit; s.fuse_mask = push_mask; s.tail_needed = 0; s.fast = 1; s.pad1 = 0; s.rec_base = cr.rec_base;
+            }
+            if (k + 1 == S && srv) last_out.np[lane] = ~0ull;
+            continue;
+        }
         if (!chain_core(E, push_mask, cr, g, o)) { if (lane == 0) set_status(E, 1u << 4); break; }      /* (the record pass took it: cannot happen) */
         const uint64_t term = cr.sid >> 9;
         if (lane == 0) {
@@ -1001,7 +1033,8 @@ __device__ static inline void wait_count(const EngDev &E, const uint32_t *lines3
 #endif
 #define REC_GRAN    20
 #define REC_TAG(seg) (0x5E000000u | ((seg) + 1u))
-enum { RECF_FAST = 1u << 13, RECF_OK = 1u << 14, RECF_HEAD = 1u << 15, RECF_CHAIN = 1u << 16, RECF_STALE = 1u << 17, RECF_ESTAR = 1u << 18 };   /* CHAIN: the chain block does the sequencer's effects */
+enum { RECF_REFUSED = 1u << 19,      /* the segment does not fit into the free part of the ring: nobody stores anything */
+       RECF_FAST = 1u << 13, RECF_OK = 1u << 14, RECF_HEAD = 1u << 15, RECF_CHAIN = 1u << 16, RECF_STALE = 1u << 17, RECF_ESTAR = 1u << 18 };   /* CHAIN: the chain block does the sequencer's effects */
 
 __device__ static inline void rec_store(uint64_t *rec, uint32_t g, uint32_t data, uint32_t tag)
 {
@@ -1079,6 +1112,7 @@ __device__ static inline void rec_wait(const EngDev &E, uint32_t seg, SeqLds &q)
         s.n = n; s.head_round = (flags & RECF_HEAD) ? 1u : 0u; s.fuse_mask = flags & 0x1FFFu; s.fast = (flags & RECF_FAST) ? 1u : 0u;
         q.ok = (flags & RECF_OK) ? 1u : 0u;
         q.chain_did = (flags & RECF_CHAIN) ? 1u : 0u;
+        q.refused = (flags & RECF_REFUSED) ? 1u : 0u;
     }
 }
 
@@ -1209,6 +1243,7 @@ __device__ static inline void append_round(const EngDev &E, const CallEnv &X, ui
                 if (tid == 0) { sq->pfx[0] = pfx_0; sq->my_virt = pfx_r - pfx_0; }
             }
             __syncthreads();
+            if (sq->refused) { if (tid == 0) lds.fast = 1; __syncthreads(); return; }     /* segment_refused: nothing is stored */
             if (!sq->ok) {             /* the block-wide path, on snapshot rec_seg */
                 if (rec_seg > 0) wait_count(E, E.step_epoch, r, (uint32_t)rec_seg);
                 __syncthreads();
@@ -1529,6 +1564,7 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
     __syncthreads();                          /* the SeqOut is in sq->out (or sq->ok == 0) */
     if (grp == 0) STAMP(8, 3);
     if (rec_seg >= 0 && rec_seg < 64 && grp == 0) STAMPN(11, rec_seg);
+    if (rec_seg >= 0 && sq->refused) return 1;     /* the segment does not fit into the log (segment_refused): nothing is stored */
     if (!sq->ok) {                            /* the batch could reach len: the block-wide scan */
         if (rec_seg >= 0) {
             /* on snapshot rec_seg (the state before this segment): complete once the epoch says so
@@ -2498,6 +2534,7 @@ struct StepTable {
      * when they -- and one segment's other blocks -- fit on the device together (flush_batch), which
      * keeps "a block only waits for blocks that are running or done" true in this order as well. */
     uint32_t order;
+    uint32_t max_T;                           /* largest entry of the staged requests (segment_refused) */
     uint32_t ab0[APUS_STEP_SEGS + 1];
     uint32_t sv0[APUS_STEP_SEGS + 1];
 };
@@ -2622,9 +2659,11 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
         /* the rounds' byte prefix: the host-staged one, or the block's own scan */
         const uint64_t *virt = sq.ok ? E.round_prefix + r0 : sq.virt;
         const uint64_t vbase = sq.ok ? sq.pfx[0] : 0;
+        const bool refused = STEP && from_rec && sq.refused;     /* segment_refused: no rounds, no records */
         if (sq.out.fast) {
             /* in step: the commit slot is known (everything visible commits); only the rounds'
              * hash words have to be waited for */
+            if (!refused)
             finish_records(E, r0, R, sq.out.vis, (uint64_t)q * blockDim.x + tid, (uint64_t)nR * blockDim.x, sq.out,
                            sq.out.rec_base, virt, vbase);
             if (q == 0) STAMP(5, 2);
@@ -2632,7 +2671,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
             wait_append(E, X, nAB);
             if (q == 0) STAMP(5, 3);
             if (STEP && q == 0 && seg < 8) STAMPN(15, 8 * seg + 2);  /* the segment's append blocks are done */
-            fold_round_hashes(E, X, R, q, nR, sq.out.fuse_mask);
+            if (!refused) fold_round_hashes(E, X, R, q, nR, sq.out.fuse_mask);
             if (q == 0) STAMP(5, 4);
             if (STEP && q == 0 && seg < 8) STAMPN(15, 8 * seg + 3);  /* hashes folded */
         } else {
@@ -2772,6 +2811,15 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                         g.rf0 = (uint32_t)__builtin_amdgcn_readlane((int)my_rf0, (int)k); g.rf1 = (uint32_t)__builtin_amdgcn_readlane((int)my_rf1, (int)k);
                         g.R = (uint32_t)__builtin_amdgcn_readlane((int)my_R, (int)k); g.tick = (uint32_t)__builtin_amdgcn_readlane((int)my_tick, (int)k);
                         ChainOut o;
+                        if (segment_refused(E.log_len, cr.end, cr.head, g.pfx2 - g.pfx0, g.tick, TT->max_T)) {
+                            RecFields f;
+                            f.e0 = cr.end; f.idx0 = cr.last_idx + 1; f.n_end0 = cr.n_end; f.term = cr.sid >> 9;
+                            f.flags_n = (uint64_t)(rec_flags(1u, push_mask, 1u, 0u, 0u, false, true) | RECF_REFUSED);
+                            f.kstar = ~0ull; f.w = 0; f.rec_base = cr.rec_base; f.commit_before = cr.commit; f.n_commit_before = cr.n_commit;
+                            rec_publish_fields(E, k, f);
+                            nd = k + 1;
+                            continue;
+                        }
                         if (!chain_core(E, push_mask, cr, g, o)) break;
                         RecFields f;
                         f.e0 = o.e0; f.idx0 = o.idx0; f.n_end0 = o.n_end0; f.term = cr.sid >> 9;
@@ -2817,7 +2865,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                 cr.f_apply = srv ? c.fw[lane][FW_APPLY] : 0; cr.f_np = srv ? c.fw[lane][FW_N_PERSIST] : 0; cr.f_na = srv ? c.fw[lane][FW_N_APPLY] : 0;
                 cr.rec_base = sq.misc[0];
                 chain_books_fast(E, push_mask, cr, srv ? c.fw[lane][FW_STORE_COUNT] : 0, srv ? c.fw[lane][FW_HEAD] : 0,
-                                 S_, pre_pfx, pre_rf, pre_last, TT->seg, sq.out);
+                                 S_, pre_pfx, pre_rf, pre_last, TT->seg, sq.out, TT->max_T);
                 __builtin_amdgcn_wave_barrier();
                 if (lane < sizeof(SeqOut) / 8) gst(&((uint64_t *)E.seq)[lane], ((const uint64_t *)&sq.out)[lane]);
             }
@@ -2850,6 +2898,25 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                 else if (tid == 193) { sq.pfx[0] = pre_pfx[k][0]; sq.pfx[1] = pre_pfx[k][0]; sq.pfx[2] = pre_pfx[k][1]; }
                 else if (tid == 194) { sq.rfx[0] = pre_rf[k][0]; sq.rfx[1] = pre_rf[k][1]; sq.misc[1] = pre_last[k]; }
                 __syncthreads();
+            }
+            if (STEP && TT && segment_refused(E.log_len, sq.lh[H_END], sq.lh[H_HEAD], pre_pfx[k][1] - pre_pfx[k][0], tickk, TT->max_T)) {
+                /* does not fit into the log: refused as a whole (the record pass said the same for k < n_dry) */
+                if (tid == 0) { set_status(E, 1u << 1); sq.ok = 1; }
+                if (k >= n_dry && tid < WAVE) {
+                    RecFields f;
+                    f.e0 = sq.lh[H_END]; f.idx0 = sq.lh[H_LAST_IDX] + 1; f.n_end0 = sq.lh[H_N_END]; f.term = sq.lh[H_SID] >> 9;
+                    f.flags_n = (uint64_t)(rec_flags(1u, push_mask, 1u, 0u, 0u, false, true) | RECF_REFUSED);
+                    f.kstar = ~0ull; f.w = 0; f.rec_base = c.rec_base; f.commit_before = sq.lh[H_COMMIT]; f.n_commit_before = sq.lh[H_N_COMMIT];
+                    rec_publish_fields(E, k, f);
+                }
+                if (snap_next_k) {       /* the state after this segment = the state before it */
+                    if (tid < 64) gst(&snap_next_k[tid], c.lh[tid]);
+                    else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) gst(&snap_next_k[SNAP_FW + (tid - 64)], (&c.fw[0][0])[tid - 64]);
+                    else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) gst(&snap_next_k[SNAP_REC], (uint64_t)c.rec_base);
+                }
+                if (STEP && k + 1 == S_) bump_count(E.step_epoch, S_);
+                post_ticket(E, Xk, T_PASS, false);
+                continue;
             }
             if (tid < WAVE) {
                 const int cf = STEP ? chain_decide_fast(E, push_mask, tickk, sq, r0k, Rk) : 0;
@@ -3244,14 +3311,11 @@ __global__ void k_mp_apply_fin(const EngDev E, uint32_t f, uint64_t cs)
 __global__ void k_reset(const EngDev E)
 {
     const int p = blockIdx.x;
-    if (threadIdx.x != 0 || !E.rep[p].ring) return;
-    uint64_t *h = E.rep[p].hdr;
-    for (int i = 0; i < H_WORDS; i++) h[i] = 0;
-    h[H_LEN] = E.log_len; h[H_END] = E.log_len; h[H_TAIL] = E.log_len; h[H_OLD_END] = E.log_len;
-    h[H_SID] = (uint64_t)p;
-    h[H_CID_BITMASK] = (1u << E.group_size) - 1;
+    if (threadIdx.x != 0) return;
     if (p == 0) {
-        *E.rec_count = 0; *E.status = 0;
+        /* the engine's own scratch (not gated on hosting replica 0: a process of a multi-process
+         * group hosts only its own replica) */
+        *E.rec_count = 0; *E.status = 0; E.status[1] = 0;
         for (int i = 0; i < 8; i++) E.ticket[i] = 0;
         for (int i = 0; i < 32; i++) { E.tick_lines[i * 32] = 0; E.tick_lines[i * 32 + 1] = 0; E.tick_lines[i * 32 + 2] = 0; }
         for (int i = 0; i < 32; i++) { E.step_epoch[i * 32] = 0; E.step_seq_done[i * 32] = 0; }
@@ -3259,4 +3323,10 @@ __global__ void k_reset(const EngDev E)
         for (int i = 0; i < APUS_STEP_SEGS * 1024; i++) E.step_lines[i] = 0;
         for (int i = 0; i < APUS_STEP_SEGS * 32; i++) E.step_tickets[i] = 0;
     }
+    if (!E.rep[p].ring) return;
+    uint64_t *h = E.rep[p].hdr;
+    for (int i = 0; i < H_WORDS; i++) h[i] = 0;
+    h[H_LEN] = E.log_len; h[H_END] = E.log_len; h[H_TAIL] = E.log_len; h[H_OLD_END] = E.log_len;
+    h[H_SID] = (uint64_t)p;
+    h[H_CID_BITMASK] = (1u << E.group_size) - 1;
 }

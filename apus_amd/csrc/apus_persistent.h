@@ -50,6 +50,7 @@ struct PersistHost {
     volatile uint64_t alive;         /* kernel -> host: 1 running, 2 exited           */
     volatile uint64_t exit_code;     /* 0 stop, 1 idle limit, 2 spin timeout          */
     volatile uint64_t rounds_done;
+    volatile uint64_t full;          /* kernel -> host: a round was refused, the log is full (dare_log.h:168,492-495) */
     PEvent   ev[P_EV_CAP];
     ReqDev   req[P_REQ_CAP];
     uint16_t req_len[P_REQ_CAP];
@@ -304,6 +305,19 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
                     s.w = __shfl(a, ks, WAVE);
                     if (s.w == L) s.estar = ks; else if (L - s.w >= APUS_HDR) s.stale = 1;
                 }
+                /* log_append_entry refuses a full log (end == head, dare_log.h:168,492-495); the engine refuses
+                 * the whole round when it does not fit into the free part of the ring (the reference would
+                 * run over un-pruned entries): nothing is stored, the host is told (H->full) */
+                bool refuse = false;
+                if (e0 != L) {
+                    const uint64_t head = mh[H_HEAD];
+                    const uint64_t total = __shfl(incl, (int)nr - 1, WAVE), waste = over ? L - s.w : 0;
+                    const uint64_t used = e0 >= head ? e0 - head : L - (head - e0);
+                    refuse = e0 == head || total + waste > L - used;
+                }
+                if (refuse) {
+                    if (lane == 0) { set_status(E, 1u << 1); st_sys(&H->full, 1); s_word[0] = 8; }
+                } else {
                 const int64_t gk = lane;
                 const uint64_t pos = apus_place(s, gk, a);
                 const uint64_t idx = apus_entry_idx(s, gk);
@@ -346,6 +360,7 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
                     s_word[4] = end_new;
                 }
                 if (lane == 0) s_seq = s;
+                }
             }
             if (pre) {
 #pragma unroll
@@ -355,9 +370,10 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
                 }
             }
             __syncthreads();
+            const bool refused = s_word[0] == 8;
             if (tid == 0) s_word[7] = wall_clock64();
             /* ---- the round's bytes: own ring + R1 to every in-sync follower ---- */
-            const uint32_t utotal = lds.ubase[WAVE];
+            const uint32_t utotal = refused ? 0u : lds.ubase[WAVE];
             constexpr int PUSH_ILP = 4;           /* units per thread and pass: the PCIe payload reads overlap */
             for (uint32_t u0 = tid; u0 < utotal; u0 += blockDim.x * PUSH_ILP) {
                 uint4 v[PUSH_ILP];
@@ -390,7 +406,8 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          /* every storing wave drains */
             __syncthreads();
-            appended = true;
+            appended = !refused;
+            if (tid == 0) s_word[0] = 0;
         } else if (op == P_OP_PRUNE) {
             /* log_pruning: wait until the reachable followers applied what is committed
              * (the timer fires between polling() passes), then decide */

@@ -96,6 +96,9 @@ typedef struct {
     uint32_t group_size, idx, leader;
     uint64_t term;
     volatile int running, terminate, ready;
+    volatile int failed;                       /* the log is full: admission is closed (fail-stop) */
+    int live_persist;                          /* 1: the persistent consensus kernel is the live loop (default) */
+    const volatile uint64_t *dev_hr;           /* proxy->highest_rec as the persistent kernel publishes it (pinned host memory) */
     pthread_t thread;
     uint64_t applied_slot[APUS_MAX_SERVERS];   /* next apply-stream slot to hand to the upcalls */
     double prune_period_s;
@@ -133,9 +136,22 @@ void dare_ib_poll_tailq(void)
         g_q.arena_used = 0;
     }
     pthread_spin_unlock(&g_q.lock);
+    if (s->batch_n && s->live_persist) {
+        /* straight into the pinned command ring of the persistent kernel: it appends, replicates,
+         * aggregates the ACKs, commits, applies and bumps highest_rec -- no launch, no read-back */
+        int rc = apus_gpu_persist_submit(s->eng, s->batch, s->batch_n, s->batch_arena, s->batch_bytes);
+        if (rc) { fprintf(stderr, "[apus] persist_submit failed rc=%d: admission closed\n", rc); s->failed = 1; }
+        s->batch_n = 0;
+        return;
+    }
     if (s->batch_n) {
         int rc = apus_gpu_append_live(s->eng, s->batch, s->batch_n, s->batch_arena, s->batch_bytes);
-        if (rc) fprintf(stderr, "[apus] append_live failed rc=%d\n", rc);
+        if (rc == APUS_E_FULL) {
+            /* log_append_entry refused the requests (dare_log.h:492-495): they are dropped; nobody
+             * waiting for them can be released any more */
+            fprintf(stderr, "[apus] the log is full: requests dropped, admission closed\n");
+            s->failed = 1; s->batch_n = 0;
+        } else if (rc) fprintf(stderr, "[apus] append_live failed rc=%d\n", rc);
     }
 }
 
@@ -200,6 +216,8 @@ void dare_server_shutdown(void)
     g_smr.terminate = 1;
 }
 
+static void proxy_mirror_highest_rec(uint64_t v);   /* proxy->highest_rec follows the device's word */
+
 void *dare_server_init(void *arg)
 {
     smr_t *s = &g_smr;
@@ -215,6 +233,17 @@ void *dare_server_init(void *arg)
     const char *pp = getenv("APUS_PRUNE_PERIOD_MS");
     s->prune_period_s = pp ? atof(pp) * 1e-3 : 0.05;   /* log_pruning_period, nodes.local.cfg:35 */
 
+    /* This host layer runs ONE process: the group's replicas are logical replicas on this process's
+     * GPU and this server leads them.  A process per server -- what
+     * benchmarks/run.sh starts on three nodes -- is the peer-mapped group of apus_amd/peers.py, which
+     * this C layer does not drive yet: refuse instead of starting a second, independent leader. */
+    if (s->in.srv_type == SRV_TYPE_JOIN || (s->idx != 0 && !getenv("APUS_ALLOW_ANY_SERVER_IDX"))) {
+        fprintf(stderr, "[apus] server_idx=%u server_type=%s: this build replicates inside ONE process (logical replicas on one GPU, "
+                        "server_idx 0 leads); a process per server needs the peer-mapped group (apus_amd/peers.py, INTEGRATION.md section 6)\n",
+                s->idx, s->in.srv_type == SRV_TYPE_JOIN ? "join" : "start");
+        s->ready = -1;
+        return NULL;
+    }
     apus_cfg_t cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.group_size = s->group_size;
@@ -240,6 +269,16 @@ void *dare_server_init(void *arg)
         s->ready = -1;
         return NULL;
     }
+    const char *lm = getenv("APUS_LIVE_MODE");     /* "calls": one launch per drained batch instead of the persistent kernel */
+    s->live_persist = !(lm && !strcmp(lm, "calls"));
+    if (s->live_persist) {
+        if (apus_gpu_persist_start(s->eng, 24u * 3600u * 1000u, 200)) {
+            fprintf(stderr, "[apus] cannot start the persistent consensus kernel\n");
+            s->ready = -1;
+            return NULL;
+        }
+        s->dev_hr = apus_gpu_persist_highest_rec_ptr(s->eng);
+    }
     fprintf(s->log, "[T%lu] LEADER\n", (unsigned long)s->term);     /* dare_server.c:1396, grepped by run.sh */
     fflush(s->log);
     signal(SIGINT, on_sigint);
@@ -249,6 +288,26 @@ void *dare_server_init(void *arg)
 
     double last_prune = now_s();
     while (!s->terminate) {                        /* polling(), dare_server.c:1012-1125 */
+        if (s->live_persist) {
+            /* the consensus loop itself runs on the device; this thread only moves what the
+             * application threads queued into the command ring and keeps the prune timer */
+            pthread_spin_lock(&g_q.lock);
+            const uint32_t queued = g_q.n;
+            pthread_spin_unlock(&g_q.lock);
+            if (queued && !s->failed) dare_ib_poll_tailq();
+            else { struct timespec ts = {0, 2000}; nanosleep(&ts, NULL); }
+            proxy_mirror_highest_rec(*s->dev_hr);
+            if (!s->failed && apus_gpu_persist_full(s->eng)) {
+                fprintf(stderr, "[apus] the log is full: requests dropped, admission closed\n");
+                s->failed = 1;
+            }
+            const double t = now_s();
+            if (t - last_prune >= s->prune_period_s) {  /* prune_log_cb, dare_server.c:1977 */
+                apus_gpu_persist_prune(s->eng);
+                last_prune = t;
+            }
+            continue;
+        }
         dare_ib_poll_tailq();
         if (s->batch_n) {
             dare_ib_write_remote_logs(1);
@@ -265,9 +324,19 @@ void *dare_server_init(void *arg)
             last_prune = t;
         }
     }
+    if (s->live_persist) {
+        apus_gpu_persist_drain(s->eng, 5000);
+        proxy_mirror_highest_rec(*s->dev_hr);
+        s->dev_hr = NULL;
+        apus_gpu_persist_stop(s->eng);
+    }
     apus_gpu_sync(s->eng);
     const uint32_t st = apus_gpu_status(s->eng);
     if (st) fprintf(stderr, "[apus] device status %#x at shutdown\n", st);
+    if (getenv("APUS_PROXY_KEEP_ENGINE")) {          /* tests: the caller inspects the engine (apus_gpu_global) and destroys it */
+        s->running = 0;
+        return NULL;
+    }
     apus_gpu_destroy(s->eng);
     s->eng = NULL;
     s->running = 0;
@@ -295,6 +364,8 @@ struct proxy_node_t {
 };
 
 static struct proxy_node_t *g_proxy;
+
+static void proxy_mirror_highest_rec(uint64_t v) { if (g_proxy) g_proxy->highest_rec = v; }
 
 static void update_highest_rec(void *arg)                        /* proxy.c:263-267 */
 {
@@ -375,8 +446,12 @@ static void leader_handle_submit_req(uint8_t type, ssize_t data_size, void *buf,
     }
     q_push_locked(type, connection_id, req_id, buf, (uint16_t)data_size);
     pthread_spin_unlock(&g_q.lock);
-    while (cur_rec > p->highest_rec) {               /* proxy.c:160 */
-        if (g_smr.terminate || g_smr.ready < 0) break;
+    /* proxy.c:160: the caller returns once its entry is applied.  With the persistent kernel the word
+     * it spins on is the one the DEVICE bumps (pinned host memory): no host thread in between */
+    for (;;) {
+        const volatile uint64_t *hr = g_smr.dev_hr;
+        if (cur_rec <= (hr ? *hr : p->highest_rec)) break;
+        if (g_smr.terminate || g_smr.failed || g_smr.ready < 0) break;
         __builtin_ia32_pause();
     }
 }
@@ -493,4 +568,11 @@ void apus_proxy_shutdown(struct proxy_node_t *p)
     pthread_join(p->dare_thread, NULL);
 }
 
-uint64_t apus_proxy_highest_rec(struct proxy_node_t *p) { return p ? p->highest_rec : 0; }
+uint64_t apus_proxy_highest_rec(struct proxy_node_t *p)
+{
+    const volatile uint64_t *hr = g_smr.dev_hr;
+    return hr ? *hr : (p ? p->highest_rec : 0);
+}
+
+/* 1 once requests were dropped because the log is full (admission is closed from then on) */
+int apus_proxy_failed(void) { return g_smr.failed; }

@@ -329,17 +329,22 @@ def bench_single(args):
     k_avg_s = (k_ms / 1e3) / max(k_launches, 1)
     achieved = kern_bytes * entries_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
     value = n_entries * args.steps / dt
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    # HBM bytes that really move, per launch: from the PMC passes of THIS configuration and kernel
+    # (profiles/r02_pmc_traffic.json, written by tools/gpu_profile.sh + tools/mk_traffic.py from
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); null if there is none
+    traffic, moved_per_entry, traffic_src = None, None, None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    kern_name = "k_step" if BATCH else "k_call"
     if os.path.exists(pmc):
         try:
-            pj = json.load(open(pmc))
-            if BATCH and pj.get("k_step_bytes_per_entry"):
-                traffic = int(pj["k_step_bytes_per_entry"] * entries_per_launch)
-            else:
-                traffic = pj.get("k_call_bytes_per_launch")
+            pj = json.load(open(pmc))["configs"].get(args.config)
+            if pj and pj.get("kernel") == kern_name and args.replicas == pj.get("replicas", args.replicas):
+                moved_per_entry = float(pj["bytes_per_entry"])
+                traffic = int(moved_per_entry * entries_per_launch)
+                traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, this config and kernel)"
         except Exception:
             traffic = None
+    moved = traffic / k_avg_s / 1e9 if (traffic and k_avg_s > 0) else None
     out = {
         "metric": "committed entries/sec", "value": value, "unit": "entries/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -361,9 +366,12 @@ def bench_single(args):
                             "device latency from wall_clock64 inside the persistent kernel"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_step" if BATCH else "k_call", "bytes_per_entry": kern_bytes,
+                     "moved": moved, "frac_moved": (moved / HBM_PEAK_GBS) if moved else None,
+                     "moved_bytes_per_entry": moved_per_entry, "traffic_source": traffic_src,
+                     "kernel": kern_name, "bytes_per_entry": kern_bytes,
                      "avg_launch_us": k_avg_s * 1e6, "launches": k_launches,
                      "entries_per_launch": entries_per_launch},
+        "entries_per_step": n_entries, "steps_executed": total_steps + args.steps,
         "whole_path": {"bytes_per_entry": path_bytes, "achieved": path_bytes * value / 1e9,
                        "unit": "GB/s", "frac": path_bytes * value / 1e9 / HBM_PEAK_GBS},
     }

@@ -57,6 +57,7 @@ extern "C" {
 #define APUS_E_HIP      (-3)
 #define APUS_E_NOMEM    (-4)
 #define APUS_E_STATE    (-5)   /* no leader / not staged / bad replica */
+#define APUS_E_FULL     (-6)   /* the batch does not fit into the free part of the log: nothing was appended (status bit APUS_ST_LOG_FULL) */
 #define APUS_E_DEVICE   (-6)   /* a device-side status bit is set: see apus_gpu_status */
 
 /* device status bits (sticky until apus_gpu_clear_status) */
@@ -212,6 +213,7 @@ int  apus_gpu_persist_submit(apus_engine_t *e, const apus_req_t *reqs, uint32_t 
                              const uint8_t *arena, uint64_t arena_bytes);   /* rounds of <= 64 */
 int  apus_gpu_persist_prune(apus_engine_t *e);                              /* log_pruning tick */
 int  apus_gpu_persist_drain(apus_engine_t *e, uint32_t timeout_ms);         /* all events consumed */
+int  apus_gpu_persist_full(apus_engine_t *e);     /* 1 once a round was refused: the log is full (the round's requests are dropped) */
 uint64_t apus_gpu_persist_highest_rec(apus_engine_t *e);
 const volatile uint64_t *apus_gpu_persist_highest_rec_ptr(apus_engine_t *e);
 int  apus_gpu_persist_stop(apus_engine_t *e);            /* returns the kernel's exit code: 0 stop, 1 idle, 2 timeout */

@@ -74,6 +74,11 @@ uint8_t get_node_id(void);
  * Thread-safe; copies `len` bytes.  Returns 0, or -1 when the queue is full. */
 int apus_tailq_push(uint8_t type, uint16_t connection_id, uint64_t req_id, const void *buf, uint16_t len);
 
+/* ---- additions of this build (tests, shutdown) ----------------------------------- */
+void     apus_proxy_shutdown(struct proxy_node_t *p);       /* stop the DARE thread and wait for it */
+uint64_t apus_proxy_highest_rec(struct proxy_node_t *p);    /* proxy->highest_rec (proxy.h:47) as the device publishes it */
+int      apus_proxy_failed(void);                           /* 1 once requests were dropped because the log is full */
+
 /* action codes carried in entry->type, proxy.h:10-12 */
 #define PROXY_CONNECT 4
 #define PROXY_SEND    5

@@ -20,7 +20,8 @@ def test_proxy_api_single_app_thread_matches_oracle():
     from tests.parity import compare_replica
     L = _lib.load(build_if_missing=False)
     LOG = 1 << 20
-    os.environ.update(server_idx="0", group_size="3", APUS_GPU_LOG_LEN=str(LOG), APUS_PRUNE_PERIOD_MS="100000000")
+    os.environ.update(server_idx="0", group_size="3", APUS_GPU_LOG_LEN=str(LOG), APUS_PRUNE_PERIOD_MS="100000000",
+                      APUS_PROXY_KEEP_ENGINE="1")
     L.proxy_init.restype = C.c_void_p
     L.proxy_init.argtypes = [C.c_char_p, C.c_char_p]
     for f in ("proxy_on_accept", "proxy_on_close"):
@@ -74,22 +75,32 @@ def test_proxy_api_single_app_thread_matches_oracle():
         cl.round(reqs[g:g + 1], arena)
     cl.quiesce()
 
+    # the DARE thread stops the persistent kernel and leaves the engine to us (APUS_PROXY_KEEP_ENGINE)
+    L.apus_proxy_shutdown(p)
+    L.apus_gpu_global.restype = C.c_void_p
+    L.apus_gpu_destroy.argtypes = [C.c_void_p]
     eng = Engine.from_handle(L.apus_gpu_global(), 3, LOG)
+    eng.leader, eng.term = 0, 2
     eng.quiesce()
     assert eng.status() == 0
     for r in range(3):
         compare_replica(eng, cl, r, tag="proxy path")
-    L.apus_proxy_shutdown(p)
+    L.apus_gpu_destroy(L.apus_gpu_global())
 
 
 def test_concurrent_submitters_all_commit():
-    """memcached-style: several application threads block in proxy_on_read at once."""
-    from apus_amd import _lib
-    L = _lib.load(build_if_missing=False)
-    if not L.apus_gpu_global():
-        os.environ.update(server_idx="0", group_size="3", APUS_GPU_LOG_LEN=str(1 << 17), APUS_PRUNE_PERIOD_MS="20")
-        L.proxy_init.restype = C.c_void_p
-        L.proxy_init.argtypes = [C.c_char_p, C.c_char_p]
-        p = L.proxy_init(b"", None)
-    else:
-        pytest.skip("one SMR instance per process (global singleton, like the reference)")
+    """memcached-style: 8 application threads x 2000 proxy_on_read block at once; the leader's log is
+    read back, replayed through the oracle in that order and every replica compared bit for bit
+    (tests/_proxy_mt_worker.py; a process of its own: one SMR instance per process)."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(tempfile.mkdtemp(), "mt.json")
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "_proxy_mt_worker.py"), out, "8", "2000"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert os.path.exists(out), f"worker died\n{p.stdout[-1500:]}\n{p.stderr[-3000:]}"
+    res = json.load(open(out))
+    assert res["ok"], f"{res.get('error')}\n{p.stderr[-1500:]}"
+    assert res["total"] == 8 * 2001 and res["connections"] == 8

@@ -404,3 +404,69 @@ def test_single_replica_group(eng_factory):
     lockstep(tr, eng)
     gc, ge = eng.round_record()
     assert ((gc == ge) | (gc == 0)).all()      # 0 = the wrap-position pass
+
+
+def _snapshot(eng, n):
+    eng.sync()
+    return [(eng.offsets(r), eng.ring(r).copy(), eng.counters(r)) for r in range(n)]
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_log_full_batch_is_refused_before_any_store(eng_factory, batched):
+    """log_append_entry refuses a request when the log is full (dare_log.h:168, 492-495: end == head)
+    -- and the reference runs over un-pruned entries when a request merely crosses head.  The engine
+    refuses a batch that does not fit into the free part of the ring AS A WHOLE, before anything is
+    stored (APUS_E_FULL, status LOG_FULL): nothing of it is in any log, the state is the oracle's
+    state after the last accepted round.  No prune tick in the trace: head never moves, the ring
+    fills.  (The oracle itself is only compared below 75 % fill: from there the reference's
+    force_log_pruning, dare_server.c:2069, prunes on its own -- SURVEY.md section 8 f2.)"""
+    from apus_amd import _lib
+    from oracle import oracle as orc
+    from tests.parity import compare_replica
+    n, L = 3, 1 << 14
+    tr = T.steady_trace(n, 400, 64, 4, 8, log_len=L)
+    tr.events = [e for e in tr.events if e[0] != "PRUNE"]
+    eng = eng_factory(n, L)
+    eng.reset()
+    eng.stage_trace(tr)
+    cl = orc.Cluster(n, L)
+    reqs = np.ascontiguousarray(tr.reqs, dtype=orc.REQ_DTYPE)
+    rounds = [e for e in tr.events if e[0] == "ROUND"]
+    eng.elect(0); cl.elect(0)
+    lib = eng.L
+    accepted, rc = 0, 0
+    before = _snapshot(eng, n)
+    for k, ev in enumerate(rounds):
+        if batched:
+            # a batch is admitted on the DEVICE, segment by segment (prune ticks inside a batch move head):
+            # a refused segment stores nothing and raises LOG_FULL
+            eng.batch_begin()
+            assert lib.apus_gpu_run_rounds(eng.h, k, 1) == 0
+            assert lib.apus_gpu_batch_end(eng.h) == 0
+            eng.sync()
+            rc = -6 if (eng.status() & 2) else 0
+        else:
+            rc = lib.apus_gpu_run_rounds(eng.h, k, 1)      # admitted on the host, before anything is launched
+        if rc != 0:
+            break
+        accepted += 1
+        if cl.force_prunes == 0:
+            cl.round(reqs[ev[1]:ev[1] + ev[2]], tr.arena)
+            if cl.force_prunes == 0:
+                eng.quiesce(); cl.quiesce()
+                for r in range(n):
+                    compare_replica(eng, cl, r, tag=f"round {k}")
+        before = _snapshot(eng, n)
+    assert rc == -6, f"the ring of {L} bytes took {accepted} rounds of {8 * 128} bytes and never refused (rc={rc})"
+    assert eng.status() & 2                       # APUS_ST_LOG_FULL
+    after = _snapshot(eng, n)
+    for r in range(n):
+        assert after[r][0] == before[r][0], f"replica {r}: offsets moved by a refused batch"
+        assert np.array_equal(after[r][1], before[r][1]), f"replica {r}: a refused batch left bytes in the ring"
+        assert after[r][2] == before[r][2]
+    # not refused early: what is free would not have taken the round plus the slack admission keeps
+    o = after[0][0]
+    used = o["end"] - o["head"] if o["end"] >= o["head"] else L - (o["head"] - o["end"])
+    assert L - used < 8 * 128 + 128 + 3 * 64
+    assert accepted >= 12
+    lib.apus_gpu_clear_status(eng.h)
