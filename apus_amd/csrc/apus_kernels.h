@@ -2476,12 +2476,14 @@ __global__ __launch_bounds__(256) void k_apply(const EngDev E, uint64_t r0, uint
  * append blocks post before they wait for anything); workgroups are dispatched in index order per
  * XCD, so what a waiting block needs is already running or done: no co-residency assumption. */
 /* one call's parameters (k_call's arguments; one entry per segment in k_step's table) */
-/* k_call / k_step: -DAPUS_LB_W=k asks the register allocator for k workgroups per CU */
-#ifdef APUS_LB_W
-#define APUS_CALL_BOUNDS __launch_bounds__(256, APUS_LB_W)
-#else
-#define APUS_CALL_BOUNDS __launch_bounds__(256)
+/* k_call / k_step: three workgroups per CU (12 wavefronts) is what the launch geometry counts on
+ * (flush_batch: all append workgroups of a launch resident at once); the register allocator is told
+ * so -- left alone it drifts a few registers over the 168 that allows (a handful of spills in cold
+ * paths instead).  -DAPUS_LB_W=k: another target. */
+#ifndef APUS_LB_W
+#define APUS_LB_W 3
 #endif
+#define APUS_CALL_BOUNDS __launch_bounds__(256, APUS_LB_W)
 struct CallArgs {
     uint64_t r0;
     uint32_t R, tick, SP, nR, nS, nA;

@@ -218,6 +218,37 @@ void dare_server_shutdown(void)
 
 static void proxy_mirror_highest_rec(uint64_t v);   /* proxy->highest_rec follows the device's word */
 
+/* APUS_PROXY_DUMP=<file>: what every replica holds when the server stops, for the end-to-end test of
+ * an application under LD_PRELOAD (the process is the application's, nobody can ask it afterwards):
+ * one text line per replica "replica i head apply commit end tail len highest_rec status", then the
+ * ring bytes [0, len) of each, raw. */
+static void dump_replicas(smr_t *s, const char *path)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return;
+    apus_gpu_quiesce(s->eng);                      /* followers learn the newest commit (the lazy R4) */
+    apus_gpu_sync(s->eng);
+    const uint32_t st = apus_gpu_status(s->eng);
+    uint64_t len = 0;
+    for (uint32_t i = 0; i < s->group_size; i++) {
+        uint64_t o[8] = {0}, c[8] = {0};
+        apus_gpu_offsets(s->eng, i, o);
+        apus_gpu_counters(s->eng, i, c);
+        len = o[7];
+        fprintf(f, "replica %u head %llu apply %llu commit %llu end %llu tail %llu len %llu highest_rec %llu status %u\n", i,
+                (unsigned long long)o[0], (unsigned long long)o[1], (unsigned long long)o[2], (unsigned long long)o[3],
+                (unsigned long long)o[4], (unsigned long long)o[7], (unsigned long long)c[6], st);
+    }
+    fprintf(f, "rings\n");
+    uint8_t *buf = malloc(len ? len : 1);
+    for (uint32_t i = 0; buf && i < s->group_size; i++) {
+        if (apus_gpu_read_ring(s->eng, i, 0, len, buf)) memset(buf, 0xEE, len);
+        fwrite(buf, 1, len, f);
+    }
+    free(buf);
+    fclose(f);
+}
+
 void *dare_server_init(void *arg)
 {
     smr_t *s = &g_smr;
@@ -333,6 +364,8 @@ void *dare_server_init(void *arg)
     apus_gpu_sync(s->eng);
     const uint32_t st = apus_gpu_status(s->eng);
     if (st) fprintf(stderr, "[apus] device status %#x at shutdown\n", st);
+    const char *dump = getenv("APUS_PROXY_DUMP");
+    if (dump && *dump) dump_replicas(s, dump);
     if (getenv("APUS_PROXY_KEEP_ENGINE")) {          /* tests: the caller inspects the engine (apus_gpu_global) and destroys it */
         s->running = 0;
         return NULL;

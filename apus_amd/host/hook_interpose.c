@@ -19,6 +19,8 @@
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <sys/socket.h>
@@ -32,16 +34,49 @@ static struct proxy_node_t *proxy;
 static __thread int guard;
 static int initialising;
 
+/* APUS_DEBUG: a backtrace on SIGSEGV (the application may install its own handler later) */
+static void on_segv(int sig)
+{
+    void *bt[64];
+    int n = backtrace(bt, 64);
+    backtrace_symbols_fd(bt, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 __attribute__((constructor)) static void apus_hook_init(void)
 {
+    if (getenv("APUS_DEBUG")) signal(SIGSEGV, on_segv);
     const char *cfg = getenv("config_path");
     if (!getenv("server_idx")) return;              /* not an APUS-managed process */
     initialising = 1;
     guard = 1;
     proxy = proxy_init(cfg ? cfg : "", NULL);       /* tern_init_func, spec_hooks.cpp:22-45 */
+    {
+        /* The ROCm libraries this one pulls in setenv() a few variables (GLOG_*) in their own
+         * constructors, so `environ` is a glibc-owned heap array by the time main() runs.  redis 2.8.17's
+         * setproctitle (spt_copyenv) then clearenv()s -- which frees that array -- and goes on reading
+         * it.  Hand main() an array glibc does not own, as if nobody had touched the environment. */
+        extern char **environ;
+        int n = 0;
+        while (environ && environ[n]) n++;
+        char **copy = malloc(((size_t)n + 1) * sizeof *copy);
+        if (copy) { for (int i = 0; i <= n; i++) copy[i] = environ[i]; environ = copy; }
+    }
     guard = 0;
     initialising = 0;
     if (!proxy) fprintf(stderr, "[apus] proxy_init failed: hooks are inert\n");
+}
+
+/* the application exits (redis: exit() after SHUTDOWN): stop the DARE thread, which drains the
+ * persistent kernel and, if asked to (APUS_PROXY_DUMP), leaves the replicas' state behind */
+__attribute__((destructor)) static void apus_hook_fini(void)
+{
+    if (!proxy) return;
+    guard = 1;
+    struct proxy_node_t *p = proxy;
+    proxy = NULL;
+    apus_proxy_shutdown(p);
 }
 
 static int is_sock(int fd)
