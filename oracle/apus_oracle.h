@@ -6,15 +6,23 @@
  * load it, and only as the checker / the reported CPU baseline.
  *
  * Parity pin: the reference has no tests, golden vectors or KATs for this
- * path.  The restatement is therefore pinned against
- * the reference's own header, src/include/dare/dare_log.h, compiled
- * unchanged into oracle/_ref/libapus_ref.so (see ref_harness.c), by
- * tests/test_oracle_vs_ref.py, and against the fixtures in tests/golden/
- * that were generated from that library (tests/golden/make_golden.py).
- * The consensus loops that live in libibverbs-tainted reference files cannot
- * be compiled here; they are restated from the cited lines and are pinned
- * only through the log header they drive ("loops: parity pinned by
- * construction + header KATs").
+ * path, so the oracle is pinned on the reference ITSELF,
+ * run here:
+ *  - the log layer against the reference's own header, src/include/dare/dare_log.h,
+ *    compiled unchanged into oracle/_ref/libapus_ref.so (ref_harness.c;
+ *    tests/test_oracle_vs_ref.py, fixtures tests/golden/digests.json);
+ *  - the consensus loops against the reference's own dare_server.c, dare_ibv.c,
+ *    dare_ibv_rc.c, dare_ibv_ud.c, dare_ep_db.c, dare_kvs_sm.c, config-dare.c and
+ *    rbtree.c, compiled UNMODIFIED into oracle/_ref/libapus_ref_loops.so behind
+ *    in-process stand-ins for <infiniband/verbs.h>, <ev.h> and <libconfig.h>
+ *    (oracle/refshim/, recipe oracle/Makefile `loops`): one private copy per
+ *    server, a shared in-process fabric, driven one polling() pass at a time.
+ *    tests/test_oracle_vs_refloops.py replays 14 named traces + BASELINE configs[1]
+ *    at full size on both in lock step (all offsets, every defined ring byte, SID,
+ *    counters, apply upcalls, the leader's end/commit after every pass); the same
+ *    records are committed as tests/golden/cluster_ref.json (written from the
+ *    reference's outputs by tests/golden/make_cluster_golden.py) and travel to
+ *    the GPU box.
  *
  * All citations are relative to /root/reference/.
  */
