@@ -131,6 +131,7 @@ class Engine:
         # servers that did not answer the two vote requests are removed with a second CONFIG entry
         # that commits in the same pass as the blank one
         dead = self.bitmask & ~self.reachable & ~(1 << winner)
+        self._chk(self.L.apus_gpu_set_reachable(self.h, self.reachable & self.bitmask), "set_reachable")
         self._chk(self.L.apus_gpu_become_leader_ex(self.h, winner, self.term, self.bitmask, dead), "become_leader")
         self.bitmask &= ~dead
 
@@ -148,8 +149,11 @@ class Engine:
             self.append_control(2, self._cid_bytes())
 
     def set_reachable(self, mask: int):
+        """Who answers.  The leader only posts to servers that are also ON in its configuration
+        (CID_IS_SERVER_ON, dare_ibv_rc.c:1480): one that was removed while it was cut off stays out
+        when it comes back."""
         self.reachable = mask
-        self._chk(self.L.apus_gpu_set_reachable(self.h, mask), "set_reachable")
+        self._chk(self.L.apus_gpu_set_reachable(self.h, mask & self.bitmask), "set_reachable")
 
     def hold(self, r: int): self.set_reachable(self.reachable & ~(1 << r))
     def release(self, r: int): self.set_reachable(self.reachable | (1 << r))

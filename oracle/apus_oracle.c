@@ -870,7 +870,9 @@ int orc_elect(orc_cluster_t *c, int winner)
     /* Step 1: every live server misses the leader's heartbeat (or, at start-up,
      * reaches RC_ESTABLISHED, dare_server.c:1169) and becomes a candidate of
      * term t+1; same-term requests are mutually dropped (:1568). */
-    for (int i = 0; i < c->n; i++) if (c->r[i].alive) start_election(c, &c->r[i]);
+    /* (a held server is cut off and, in this schedule, does not time out on its own: it keeps its old
+     * SID until it hears from the new leader -- the schedule tests/test_oracle_vs_refloops.py pins) */
+    for (int i = 0; i < c->n; i++) if (c->r[i].alive && (!c->r[i].held || i == winner)) start_election(c, &c->r[i]);
     /* Step 2: the winner's election timeout fires first: term t+2 */
     start_election(c, w);
     uint64_t req_idx, req_term;
@@ -920,7 +922,7 @@ int orc_elect(orc_cluster_t *c, int winner)
     {
         uint32_t dead = 0;
         for (int i = 0; i < c->n; i++)
-            if (i != winner && cid_on(&w->cid, i) && !c->r[i].alive) dead |= 1u << i;
+            if (i != winner && cid_on(&w->cid, i) && (!c->r[i].alive || c->r[i].held)) dead |= 1u << i;   /* dead, or cut off: both vote requests failed */
         if (dead) {
             w->cid.bitmask &= ~dead;
             if (orc_log_append(w->log, SID_TERM(w->sid), 0, 0, ORC_CONFIG, &w->cid, 0) == 0) return -2;

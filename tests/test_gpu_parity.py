@@ -470,3 +470,22 @@ def test_log_full_batch_is_refused_before_any_store(eng_factory, batched):
     assert L - used < 8 * 128 + 128 + 3 * 64
     assert accepted >= 12
     lib.apus_gpu_clear_status(eng.h)
+
+
+@pytest.mark.parametrize("mode", BATCH_MODES)
+def test_failover_with_divergence_at_the_crash(eng_factory, mode):
+    """BASELINE config 5 with the logs diverging at the crash (tests/traces.py:diverge_failover, pinned
+    on the reference itself): the old leader and one follower hold entries nobody else has; the new
+    leader removes both from the configuration in its first pass (the follower was cut off during
+    the election: two failed vote requests) and never posts to the follower again, which keeps its
+    divergent log when it comes back."""
+    from tests import traces
+    from tests.parity import lockstep, compare_replica
+    tr = traces.diverge_failover()
+    eng = eng_factory(5, tr.log_len)
+    cl = lockstep(tr, eng, **mode)
+    assert cl.leader == 2 and cl.cid_bitmask(2) == 0b11100
+    for r in range(5):
+        compare_replica(eng, cl, r, tag="after the divergent fail-over")
+    assert eng.offsets(1)["end"] > eng.offsets(1)["commit"]          # the stale server still has what never committed
+    assert eng.offsets(2)["end"] == eng.offsets(2)["commit"]

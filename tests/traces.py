@@ -92,7 +92,38 @@ def park_commit_at_wrap():
                              k + 5: [("QUIESCE",), ("RELEASE", 1), ("RELEASE", 2), ("QUIESCE",)]})
 
 
-CATALOGUE = {f.__name__: f for f in (steady3, steady5_unaligned, steady7_mixed, c2_small, c3_small, c4_small,
+def diverge_failover():
+    """BASELINE config 5 with REAL divergence at the crash: the leader loses its majority (2, 3, 4
+    held), keeps appending and pushing to the one follower it still reaches -- entries that cannot
+    commit -- and dies while that follower (1) is cut off as well.  2 wins the next term with the
+    votes of 3 and 4.  What the reference does with 1 (pinned, tests/test_oracle_vs_refloops.py):
+    both vote requests to it failed, so check_failure_count (dare_server.c:1189-1230) removes it from
+    the configuration together with the dead leader, in the new leader's first pass; when 1 comes
+    back nobody replicates to it any more -- it keeps its divergent log until it re-joins.  (Had 1
+    been reachable it would have refused its vote -- its log is longer, poll_vote_requests
+    :1661-1673 -- raised its term to the candidate's and then never followed the new leader:
+    hb_receive_cb :903-910 only calls server_to_follower for a NEW term.  log_adjustment's truncation,
+    dare_ibv_rc.c:1292-1451, needs a voter whose extra entries are of an OLDER term than the
+    candidate's last entry, i.e. two fail-overs in a row.)"""
+    tr = T.steady_trace(5, 900, (64, 107), 8, 16, log_len=1 << 18, name="diverge_failover")
+    ev, k = [], 0
+    for e in tr.events:
+        if e[0] == "PRUNE":
+            continue
+        ev.append(e)
+        if e[0] == "ROUND":
+            k += 1
+            if k == 20:
+                ev += [("QUIESCE",), ("HOLD", 2), ("HOLD", 3), ("HOLD", 4)]
+            if k == 26:
+                ev += [("HOLD", 1), ("KILL", 0), ("RELEASE", 2), ("RELEASE", 3), ("RELEASE", 4), ("ELECT", 2), ("QUIESCE",)]
+            if k == 30:
+                ev += [("RELEASE", 1), ("QUIESCE",)]
+    tr.events = ev
+    return tr
+
+
+CATALOGUE = {f.__name__: f for f in (diverge_failover, steady3, steady5_unaligned, steady7_mixed, c2_small, c3_small, c4_small,
                                      c5_failover, hold_one_of_three, hold_release, no_quorum, no_quorum_prune,
                                      exact_fit, kill_follower, park_commit_at_wrap)}
 
