@@ -317,6 +317,35 @@ def bench_single(args):
     except Exception as exc:          # the throughput line must survive a latency-probe failure
         print(f"[bench] persistent latency probe failed: {exc!r}", file=sys.stderr)
 
+    # the same latency probe for groups of 5 and 7 logical replicas (north_star: consensus-round latency
+    # at 3 / 5 / 7 replicas): device append -> commit and host submit -> highest_rec, 64-entry rounds
+    lat_by_group = {}
+    if not args.no_latency:
+        if plat_dev is not None:
+            lat_by_group[str(n_rep)] = {"append_to_commit_us_p50": plat_dev, "host_submit_to_highest_rec_us_p50": plat_host}
+        for g in (5, 7):
+            if g == n_rep:
+                continue
+            try:
+                from apus_amd import trace as T2
+                trg = T2.steady_trace(g, 64 * 64, args.payload, 16, 64, log_len=T2.DEFAULT_LOG)
+                eg = Engine(g, trg.log_len, device=0)
+                try:
+                    eg.elect(0)
+                    eg.sync()
+                    eg.persist_start(idle_ms=2000, peer_ms=200)
+                    hl = eg.persist_roundtrip_ns(np.ascontiguousarray(trg.reqs[16:16 + 64]), trg.arena, 300) / 1e3
+                    eg.persist_drain()
+                    eg.persist_stop()
+                    dl = eg.persist_latency_ns()
+                    eg.quiesce(); eg.check_status()
+                    lat_by_group[str(g)] = {"append_to_commit_us_p50": float(np.percentile(dl[20:], 50)) / 1e3 if len(dl) > 20 else None,
+                                            "host_submit_to_highest_rec_us_p50": float(np.percentile(hl[40:], 50))}
+                finally:
+                    eg.close()
+            except Exception as exc:
+                print(f"[bench] latency probe for {g} replicas failed: {exc!r}", file=sys.stderr)
+
     E = 64 + args.payload
     N = n_rep
     entries_per_launch = n_entries * args.steps / max(k_launches, 1)
@@ -362,6 +391,7 @@ def bench_single(args):
                     "persistent_kernel_host_submit_to_highest_rec_us_p50": plat_host,
                     "persistent_kernel_phase_breakdown": plat_phases,
                     "phased_kernels_host_round_trip_us_p50": p50,
+                    "by_group_size": lat_by_group,
                     "note": "one 64-entry round per measurement, 3 logical replicas on one MI355X; "
                             "device latency from wall_clock64 inside the persistent kernel"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
