@@ -74,6 +74,7 @@ SIGNATURES = {
     "apus_gpu_submit": (C.c_int, [vp, vp, u32, vp, u64]),
     "apus_gpu_append_live": (C.c_int, [vp, vp, u32, vp, u64]),
     "apus_gpu_commit_live": (C.c_int, [vp, C.c_int]),
+    "apus_gpu_elect": (C.c_int, [vp, u32, u32, u32, C.POINTER(u64)]),
     "apus_gpu_export_replica": (C.c_int, [vp, u32, C.POINTER(IpcReplica)]),
     "apus_gpu_import_replica": (C.c_int, [vp, C.POINTER(IpcReplica)]),
     "apus_gpu_batch_begin": (C.c_int, [vp]),

@@ -58,6 +58,11 @@ struct apus_engine {
     uint64_t free_lb;
     uint64_t stage_max_T;                      /* largest entry (header + payload) of the staged requests */
     uint32_t host_status;                      /* status bits raised on the host side (APUS_ST_LOG_FULL) */
+    /* election (apus_gpu_elect): servers that refused their vote keep their log closed to the winner
+     * (no vote ACK, hb_receive_cb dare_server.c:903-910) until the next election; those that granted it
+     * get their logs adjusted by the new leader's first pass (log_adjustment, dare_ibv_rc.c:1292-1451) */
+    uint32_t no_access, adjust_mask;
+    uint64_t *d_elect;                         /* k_elect's verdict */
     struct BatchSeg { CallArgs a; uint32_t blocks; uint64_t bytes; };
     std::vector<BatchSeg> batch;               /* recorded calls: arguments, blocks, bytes they append */
     /* graphs */
@@ -117,7 +122,7 @@ static inline uint32_t sync_mask(const apus_engine *e)
 {
     /* local followers the leader can currently post to */
     if (e->d.leader >= APUS_MAX_SERVERS) return 0;
-    return e->local_mask & e->reachable & ~(1u << e->d.leader);
+    return e->local_mask & e->reachable & ~e->no_access & ~(1u << e->d.leader);
 }
 static inline int popc(uint32_t v) { return __builtin_popcount(v); }
 
@@ -158,6 +163,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
         if (so_env && atoi(so_env) == 0) e->step_slots = 0;
     }
     e->free_lb = 0; e->stage_max_T = APUS_HDR; e->host_status = 0;
+    e->no_access = 0; e->adjust_mask = 0; e->d_elect = nullptr;
     e->n_reqs = 0; e->n_rounds_staged = 0;
     e->d_req = e->d_req_len = e->d_arena = e->d_round_first = e->d_round_prefix = nullptr;
     e->h_live = nullptr; e->d_live = nullptr; e->live_pending = false; e->live_copied = nullptr;
@@ -217,6 +223,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     if (!rc) rc = dev_alloc(e, &e->d.rec_end, sizeof(uint64_t) * e->d.rec_cap);
     if (!rc) rc = dev_alloc(e, &e->d.rec_commit, sizeof(uint64_t) * e->d.rec_cap);
     if (!rc) rc = dev_alloc(e, &e->d.rec_count, 64, true, hipDeviceMallocUncached);
+    if (!rc) rc = dev_alloc(e, &e->d_elect, 64);
     if (rc) { apus_gpu_destroy(e); return rc; }
     *out = e;
     rc = apus_gpu_reset(e);
@@ -270,7 +277,7 @@ extern "C" int apus_gpu_reset(apus_engine_t *e)
         }
     e->d.leader = 0xFFFFFFFFu;
     e->tick_pending = false;
-    e->free_lb = 0; e->host_status = 0;
+    e->free_lb = 0; e->host_status = 0; e->no_access = 0; e->adjust_mask = 0;
     e->reachable = (1u << e->d.group_size) - 1;
     e->d.reachable = e->reachable;
     {
@@ -879,6 +886,120 @@ __global__ void k_set_roles(const EngDev E, uint64_t sid, uint32_t bitmask, uint
     }
 }
 
+
+/* ---- election on the device ------------------------------------------------------------------ */
+/* ELECT(winner) of the trace, in the schedule the oracle is pinned on (oracle/apus_oracle.c:orc_elect):
+ * every live server that is not cut off becomes a candidate of term t+1 (start_election,
+ * dare_server.c:1264-1322), the winner's timeout fires first (t+2) and its vote request reaches
+ * every live configured server.  One lane per server decides as poll_vote_requests does
+ * (:1526-1743): no vote from a leader or for a SID that is not newer; the candidate's last entry
+ * (term, idx) must be at least as good as the voter's own, else the voter raises its term to the
+ * candidate's and refuses (:1661-1673); otherwise it adopts the SID and grants.  poll_vote_count
+ * (:1327-1518): the winner needs size/2+1 votes, its own included.
+ * out: [0] elected, [1] grant mask, [2] refuse mask, [3] the winner's SID as a candidate, [4] votes */
+__global__ void k_elect(const EngDev E, uint32_t winner, uint32_t live_mask, uint32_t bitmask, uint64_t *out)
+{
+    const uint32_t i = threadIdx.x;
+    const uint64_t L = E.log_len;
+    const bool mine = i < E.group_size && E.rep[i].ring && ((live_mask >> i) & 1u);
+    uint64_t sid = 0, last_idx = 0, last_term = 0;
+    if (mine) {
+        const RepDev &R = E.rep[i];
+        sid = R.hdr[H_SID];
+        sid = (((sid >> 9) + 1) << 9) | i;                                   /* candidate of term t+1 */
+        if (i == winner) sid = (((sid >> 9) + 1) << 9) | i;                  /* its timeout fires first: t+2 */
+        const uint64_t n_end = R.hdr[H_N_END], end = R.hdr[H_END];
+        if (end != L && n_end > 0) {                                         /* last_entry_of: log_get_tail + the entry there */
+            const uint64_t off = R.dir_off[(uint32_t)(n_end - 1) & E.dir_mask];
+            last_idx = ld8u(R.ring + off); last_term = ld8u(R.ring + off + 8);
+        }
+    }
+    const uint64_t req_sid = rl64(sid, winner), req_idx = rl64(last_idx, winner), req_term = rl64(last_term, winner);
+    bool grant = false, refuse = false;
+    if (mine && i != winner && ((bitmask >> i) & 1u)) {
+        const uint64_t old = sid | (1ull << 8);
+        if (!((sid >> 8) & 1u) && old < req_sid) {
+            if (last_term > req_term || (last_term == req_term && last_idx > req_idx)) {
+                sid = ((req_sid >> 9) << 9) | i;                             /* raise own term, no vote */
+                refuse = true;
+            } else { sid = req_sid; grant = true; }
+        }
+    }
+    if (mine) E.rep[i].hdr[H_SID] = sid;
+    const unsigned long long gm = __ballot(grant), rm = __ballot(refuse);
+    if (i == 0) {
+        const uint32_t votes = 1u + (uint32_t)__popcll(gm);
+        out[0] = (((live_mask >> winner) & 1u) && votes >= E.group_size / 2 + 1) ? 1 : 0;
+        out[1] = gm; out[2] = rm; out[3] = req_sid; out[4] = votes;
+    }
+}
+
+/* log_adjustment for the followers that granted their vote (dare_ibv_rc.c:1292-1451), one workgroup
+ * (one lane) per follower: walk its not-committed entries (log_entries_to_nc_buf, dare_log.h:339:
+ * from its commit to its end), compare (idx, term) with what the new leader's log holds at the same
+ * offset (log_find_remote_end_offset, :367) and set the follower's end to the first offset that
+ * differs.  Then the follower's own next polling() pass: its end now lies BEHIND its old_end, so
+ * persist_new_entries (dare_server.c:1793-1810) walks from old_end forward -- over the rest of its
+ * old entries, the untouched ring behind them, around through 0 -- "storing" and ACKing every entry
+ * shape it meets until it arrives at the new end (reproduced: it moves old_end and counts as store
+ * upcalls; pinned on the reference, tests/traces.py:double_failover_truncate). */
+__global__ void k_adjust(const EngDev E, uint32_t mask, uint32_t alive_mask)
+{
+    if (threadIdx.x != 0) return;
+    int f = -1;
+    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
+        if (mask & (1u << i)) { if (k == (int)blockIdx.x) { f = i; break; } k++; }
+    if (f < 0 || !E.rep[f].ring) return;
+    const RepDev &F = E.rep[f], &Ld = E.rep[E.leader];
+    uint64_t *fh = F.hdr;
+    const uint64_t L = E.log_len;
+    const uint64_t f_end = fh[H_END], l_end = Ld.hdr[H_END];
+    const uint64_t n_commit = fh[H_N_COMMIT], n_end = fh[H_N_END];
+    if (f_end == L || n_end <= n_commit) return;                 /* empty not-committed buffer: nothing to adjust */
+    uint64_t off = 0, s = n_commit;
+    for (; s < n_end; s++) {
+        off = F.dir_off[(uint32_t)s & E.dir_mask];
+        if (l_end == L || off == l_end) break;                   /* log_get_entry: nothing there in the leader's log */
+        if (ld8u(Ld.ring + off) != ld8u(F.ring + off) || ld8u(Ld.ring + off + 8) != ld8u(F.ring + off + 8)) break;
+        const uint32_t type = Ld.ring[off + 26];
+        const uint64_t elen = APUS_HDR + ((type == APUS_NOOP || type == APUS_CONFIG || type == APUS_HEAD) ? 0u : (uint32_t)(Ld.ring[off + 48] | (Ld.ring[off + 49] << 8)));
+        if (L - off < elen) off = 0;
+        off += elen;
+    }
+    const uint64_t rem_end = off;
+    if (rem_end == f_end) return;                                /* every entry it has is the leader's too */
+    fh[H_END] = rem_end; fh[H_N_END] = s; fh[H_N_PERSIST] = s; fh[H_TAIL] = L;
+    /* the follower's pass */
+    uint64_t old_end = fh[H_OLD_END], count = 0;
+    for (uint64_t guard = 0; guard < 2 * (L / APUS_HDR) + 16 && apus_is_larger(rem_end, L, rem_end, old_end); guard++) {
+        if (L - old_end < APUS_HDR) old_end = 0;                 /* log_get_entry */
+        const uint32_t type = F.ring[old_end + 26];
+        const uint64_t elen = APUS_HDR + ((type == APUS_NOOP || type == APUS_CONFIG || type == APUS_HEAD) ? 0u : (uint32_t)(F.ring[old_end + 48] | (F.ring[old_end + 49] << 8)));
+        if (L - old_end < elen) { old_end = 0; continue; }
+        count++;
+        F.ring[old_end + 28 + f] = 1;                            /* rc_send_entries_reply: own copy ... */
+        const uint32_t sender = F.ring[old_end + 27];
+        if (sender < E.group_size && ((alive_mask >> sender) & 1u) && E.rep[sender].ring)
+            E.rep[sender].ring[old_end + 28 + f] = 1;            /* ... and the sender's */
+        old_end += elen;
+    }
+    fh[H_OLD_END] = old_end;
+    fh[H_STORE_COUNT] += count;
+}
+
+extern "C" int apus_gpu_elect(apus_engine_t *e, uint32_t winner, uint32_t live_mask, uint32_t bitmask, uint64_t out[8])
+{
+    if (!e || !out || winner >= e->d.group_size) return APUS_E_ARG;
+    if (e->batching) return APUS_E_STATE;
+    if (e->d.leader < e->d.group_size) { int frc = flush_tick(e); if (frc) return frc; }
+    hipLaunchKernelGGL(k_elect, dim3(1), dim3(64), 0, e->stream, e->d, winner, live_mask & e->local_mask, bitmask, e->d_elect);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, e->d_elect, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (out[0]) { e->no_access = (uint32_t)out[2]; e->adjust_mask = (uint32_t)out[1]; }
+    return 0;
+}
+
 /* The election itself (who wins which term) is the trace's ELECT event; this is what the winner
  * does in poll_vote_count (dare_server.c:1389-1421) and in the pass that follows.  `removed` =
  * servers that are ON in `bitmask` but have reached PERMANENT_FAILURE during the election (both
@@ -899,6 +1020,16 @@ extern "C" int apus_gpu_become_leader_ex(apus_engine_t *e, uint32_t leader, uint
     const uint64_t sid = (term << 9) | (1ull << 8) | leader;
     hipLaunchKernelGGL(k_set_roles, dim3(1), dim3(64), 0, e->stream, e->d, sid, bitmask, e->reachable);
     HIPCHK(hipGetLastError());
+    {
+        /* the followers that voted: their logs are adjusted before anything is replicated to them */
+        const uint32_t am = e->adjust_mask & e->local_mask & e->reachable & ~(1u << leader);
+        e->adjust_mask = 0;
+        if (am) {
+            hipLaunchKernelGGL(k_adjust, dim3(popc(am)), dim3(64), 0, e->stream, e->d, am, e->reachable);
+            HIPCHK(hipGetLastError());
+            e->lag_possible = true;
+        }
+    }
     /* blank CONFIG entry: dare_cid_t {epoch, size[2], state, pad, bitmask} */
     uint8_t cid[16] = {0};
     cid[8] = (uint8_t)e->d.group_size;

@@ -125,8 +125,18 @@ class Engine:
         oracle/apus_oracle.c:orc_elect, from dare_server.c:1264-1518)."""
         if not (self.reachable >> winner) & 1:
             raise EngineError("the winner of an election must be alive")
+        # the votes are cast on the device (k_elect): who grants, who refuses (a longer log), majority or not
+        out = (C.c_uint64 * 8)()
+        if len(self.local_ids) == self.group_size:
+            self._chk(self.L.apus_gpu_elect(self.h, winner, self.reachable, self.bitmask, out), "elect")
+        else:
+            # (the message-passing transport: this process sees one replica only; the trace's word is taken)
+            out[0], out[1] = 1, self.reachable & self.bitmask & ~(1 << winner)
         self.term += 2
+        if not out[0]:
+            raise EngineError(f"server {winner} did not get a majority ({int(out[4])} votes)")
         self.leader = winner
+        self.granted, self.refused = int(out[1]), int(out[2])
         # check_failure_count (dare_server.c:1189-1230) opens the new leader's first pass: configured
         # servers that did not answer the two vote requests are removed with a second CONFIG entry
         # that commits in the same pass as the blank one

@@ -158,6 +158,14 @@ int  apus_gpu_import_replica(apus_engine_t *e, const apus_ipc_replica_t *in);
 int  apus_gpu_become_leader(apus_engine_t *e, uint32_t leader, uint64_t term, uint32_t bitmask);
 /* same, with the servers check_failure_count (dare_server.c:1189-1227) removes in the new
  * leader's first pass: blank CONFIG <bitmask> + CONFIG <bitmask & ~removed> commit in one pass */
+/* ELECT(winner) decided on the device (start_election / poll_vote_requests / poll_vote_count,
+ * src/dare/dare_server.c:1264-1743): live_mask = the servers that are up and not cut off (the winner
+ * among them), bitmask = the configuration.  out[0] = 1 when the winner has size/2+1 votes, out[1] =
+ * the servers that granted theirs (their logs are adjusted by apus_gpu_become_leader_ex: log_adjustment,
+ * dare_ibv_rc.c:1292-1451, incl. the truncation of entries the winner does not have), out[2] = the
+ * servers that refused (log longer than the winner's: they keep their log closed to it until the
+ * next election), out[3] = the winner's SID as a candidate, out[4] = votes.  Synchronises. */
+int  apus_gpu_elect(apus_engine_t *e, uint32_t winner, uint32_t live_mask, uint32_t bitmask, uint64_t out[8]);
 int  apus_gpu_become_leader_ex(apus_engine_t *e, uint32_t leader, uint64_t term, uint32_t bitmask,
                                uint32_t removed);
 /* reachability of peers from the leader (KILL / HOLD / RELEASE of the trace;

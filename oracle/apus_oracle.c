@@ -511,6 +511,7 @@ static inline int peer_reachable(const orc_cluster_t *c, const replica_t *L, int
 }
 
 /* --- log_adjustment, dare_ibv_rc.c:1292-1451 ------------------------ */
+static void follower_poll(orc_cluster_t *c, replica_t *p);
 static void log_adjustment(orc_cluster_t *c, replica_t *L)
 {
     orc_log_t *log = L->log;
@@ -540,6 +541,13 @@ static void log_adjustment(orc_cluster_t *c, replica_t *L)
         case LR_SET_END:
             L->rem_end[i] = orc_log_find_remote_end(log, &log->nc_buf[i]);
             F->log->end = L->rem_end[i];                      /* WRITE 8 bytes */
+            /* the follower's next polling() pass sees an end that lies BEHIND its old_end:
+             * persist_new_entries (dare_server.c:1793-1810) then walks from old_end forward -- over what
+             * is left of its old entries, the untouched rest of the ring, and around through 0 -- until it
+             * arrives at the new end, "storing" and ACKing everything on the way.  Harmless garbage in
+             * the reference (the bytes are overwritten or lie outside the log), but it moves old_end to
+             * the right place and counts as store upcalls: reproduced (pinned on the reference). */
+            follower_poll(c, F);
             break;
         default:
             continue;
@@ -907,7 +915,12 @@ int orc_elect(orc_cluster_t *c, int winner)
         replica_t *p = &c->r[i];
         if (i == winner || !p->alive || p->held) continue;
         p->log->tail = p->log->len;
-        if (SID_TERM(p->sid) != SID_TERM(w->sid) || w->vote_ack[i] == w->log->len) {
+        /* hb_receive_cb :903-910: server_to_follower (restore the log access for the new leader,
+         * send the vote ACK with the not-committed buffer) only when the HB carries a NEW term.  A
+         * server that refused its vote raised its term to the candidate's (:1661-1673): same term,
+         * so it adopts the SID and nothing else -- the leader never gets a vote ACK from it and
+         * leaves its log alone until the next election (pinned on the reference). */
+        if (SID_TERM(p->sid) != SID_TERM(w->sid)) {
             orc_log_to_ncbuf(p->log, &p->log->nc_buf[p->idx]);
             w->vote_ack[i] = p->log->commit;
         }

@@ -489,3 +489,41 @@ def test_failover_with_divergence_at_the_crash(eng_factory, mode):
         compare_replica(eng, cl, r, tag="after the divergent fail-over")
     assert eng.offsets(1)["end"] > eng.offsets(1)["commit"]          # the stale server still has what never committed
     assert eng.offsets(2)["end"] == eng.offsets(2)["commit"]
+
+
+@pytest.mark.parametrize("mode", BATCH_MODES)
+def test_two_failovers_truncate_a_divergent_log(eng_factory, mode):
+    """log_adjustment with a real truncation (tests/traces.py:double_failover_truncate, pinned on the
+    reference itself): votes cast on the device (k_elect: server 1 refuses the first candidate -- its log
+    is longer -- and is left alone by that leader; it votes for the second one), the second leader's
+    first pass compares 1's not-committed entries with its own log, cuts 1's log at the first offset
+    that differs (k_adjust: log_entries_to_nc_buf + log_find_remote_end_offset + SET_END, and the
+    follower's own persist walk over what lies behind its old end) and replicates from there."""
+    from tests import traces
+    from tests.parity import lockstep, compare_replica
+    tr = traces.double_failover_truncate()
+    eng = eng_factory(5, tr.log_len)
+    cl = lockstep(tr, eng, **mode)
+    assert cl.leader == 3 and cl.term(3) == 6
+    assert eng.granted & 0b10 and not eng.refused          # server 1 voted in the second election
+    for r in (1, 3, 4):
+        compare_replica(eng, cl, r, tag="after two fail-overs")
+    assert eng.offsets(1) == eng.offsets(3) or eng.offsets(1)["end"] == eng.offsets(3)["end"]
+
+
+def test_election_needs_a_majority_of_votes(eng_factory):
+    """poll_vote_count (dare_server.c:1327-1518): a candidate whose log is shorter than a majority's does
+    not win -- the oracle refuses ELECT(w) for it, so does the device"""
+    from tests.parity import lockstep
+    n, L = 5, 1 << 18
+    tr = T.steady_trace(n, 600, 64, 8, 16, log_len=L)
+    rounds = [e for e in tr.events if e[0] == "ROUND"]
+    tr.events = [("ELECT", 0)] + rounds[:10] + [("QUIESCE",), ("HOLD", 4)] + rounds[10:20] + [("QUIESCE",), ("KILL", 0), ("RELEASE", 4)]
+    tr.reqs = tr.reqs[:rounds[19][1] + rounds[19][2]]
+    eng = eng_factory(n, L)
+    cl = lockstep(tr, eng)
+    # 4 missed ten rounds: 1, 2, 3 have longer logs and refuse
+    with pytest.raises(Exception):
+        cl.elect(4)
+    with pytest.raises(Exception, match="majority"):
+        eng.elect(4)

@@ -98,6 +98,11 @@ def _worker(rank, world, port, name, q):
             e = _FakeEngine(n, log_len, local_ids, device, flags)
             e.L.apus_gpu_become_leader_ex = lambda h, w, term, bm, dead: (e.calls.append(("lead", w, term, bm, dead)), 0)[1]
             e.L.apus_gpu_set_reachable = lambda h, m: 0
+
+            def fake_elect(h, w, live, bm, out):
+                out[0], out[1], out[2], out[4] = 1, live & bm & ~(1 << w), 0, bin(live & bm).count('1')
+                return 0
+            e.L.apus_gpu_elect = fake_elect
             return e
 
         m = peers.PeerMember(world, rank, 0, tr.log_len, engine_factory=factory)

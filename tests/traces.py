@@ -123,7 +123,35 @@ def diverge_failover():
     return tr
 
 
-CATALOGUE = {f.__name__: f for f in (diverge_failover, steady3, steady5_unaligned, steady7_mixed, c2_small, c3_small, c4_small,
+def double_failover_truncate():
+    """log_adjustment's truncation (dare_ibv_rc.c:1292-1451: not-committed buffer, dare_log.h:339;
+    log_find_remote_end_offset, :367), reached the only way the reference reaches it: two fail-overs.
+    Term 2: the leader loses its majority and pushes entries X to server 1 only; it dies.  Server 2
+    wins term 4 with the votes of 3 and 4; server 1 -- reachable, but its log is longer -- refuses,
+    raises its term to the candidate's and is left alone by the new leader (no vote ACK, hb_receive_cb
+    :903-910), which commits entries Y with 3 and 4.  Then 2 dies: server 3 wins term 6, and this time
+    1 votes (its last entry is of term 2, the candidate's of term 4): the new leader compares 1's
+    not-committed entries with its own log, sets 1's end to the first offset that differs and
+    replicates from there -- X is gone, 1 is a follower like the others."""
+    tr = T.steady_trace(5, 1200, (64, 107), 8, 16, log_len=1 << 18, name="double_failover_truncate")
+    ev, k = [], 0
+    for e in tr.events:
+        if e[0] == "PRUNE":
+            continue
+        ev.append(e)
+        if e[0] == "ROUND":
+            k += 1
+            if k == 20:
+                ev += [("QUIESCE",), ("HOLD", 2), ("HOLD", 3), ("HOLD", 4)]
+            if k == 26:
+                ev += [("KILL", 0), ("RELEASE", 2), ("RELEASE", 3), ("RELEASE", 4), ("ELECT", 2), ("QUIESCE",)]
+            if k == 38:
+                ev += [("QUIESCE",), ("KILL", 2), ("ELECT", 3), ("QUIESCE",)]
+    tr.events = ev
+    return tr
+
+
+CATALOGUE = {f.__name__: f for f in (diverge_failover, double_failover_truncate, steady3, steady5_unaligned, steady7_mixed, c2_small, c3_small, c4_small,
                                      c5_failover, hold_one_of_three, hold_release, no_quorum, no_quorum_prune,
                                      exact_fit, kill_follower, park_commit_at_wrap)}
 
