@@ -17,7 +17,7 @@
  *    in-process stand-ins for <infiniband/verbs.h>, <ev.h> and <libconfig.h>
  *    (oracle/refshim/, recipe oracle/Makefile `loops`): one private copy per
  *    server, a shared in-process fabric, driven one polling() pass at a time.
- *    tests/test_oracle_vs_refloops.py replays 14 named traces + BASELINE configs[1]
+ *    tests/test_oracle_vs_refloops.py replays 16 named traces + BASELINE configs[1]
  *    at full size on both in lock step (all offsets, every defined ring byte, SID,
  *    counters, apply upcalls, the leader's end/commit after every pass); the same
  *    records are committed as tests/golden/cluster_ref.json (written from the

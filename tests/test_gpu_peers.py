@@ -64,3 +64,11 @@ def test_peer_mapped_leader_process_fails_over():
 def test_peer_mapped_ack_aggregation_path():
     """per-entry ACK words + quorum scan (APUS_F_NO_FUSED_ACKS) across processes"""
     run_group(3, "steady3", flags=1)
+
+
+def test_peer_mapped_two_failovers_truncate_a_divergent_log():
+    """two leader PROCESSES die one after the other; the third leader's process casts the votes on its
+    device, truncates server 1's divergent log through the mapping and replicates from there
+    (tests/traces.py:double_failover_truncate, pinned on the reference)"""
+    res = run_group(5, "double_failover_truncate")
+    assert [r["led"] for r in res] == [1, 0, 1, 1, 0]
