@@ -247,11 +247,14 @@ class GroupMember:
     def leader_prune(self):
         replies = self.leader_quiesce()
         self.eng.tick_prune()                                  # decision + maybe a HEAD entry
-        # R8: the apply offsets just read become the input of the next tick
+        # R8: the apply offsets just read become the input of the next tick.  The tick runs on the
+        # engine's own stream, the stores below on torch's: drain the first before, the second after
+        self.eng.sync()
         hdr_ptr, _ = self.eng.device_ptr(self.rank, 1)
         hdr = torch.as_tensor(_DevMem(hdr_ptr, 64 * 8), device=self.device).view(torch.int64)
         for f, r in replies.items():
             hdr[H_APPLY_OFFSETS + f] = r[2]
+        torch.cuda.synchronize(self.device)
         self.sync_followers()                                  # ship the HEAD entry, if any
         self.eng.quiesce()
 
