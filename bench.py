@@ -296,7 +296,7 @@ def bench_single(args):
 
     # the persistent consensus kernel (live path): one 64-entry round at a time through the
     # pinned command ring; host-observed submit -> highest_rec, and device append -> commit
-    plat_host, plat_dev, plat_phases = None, None, None
+    plat_host, plat_dev, plat_phases, host_fed = None, None, None, None
     try:
         if args.no_latency:
             raise RuntimeError('skipped (--no-latency)')
@@ -306,6 +306,25 @@ def bench_single(args):
         blk = reqs64[:64]
         hl = eng.persist_roundtrip_ns(blk, tr.arena, 400) / 1e3       # C loop: submit -> highest_rec
         eng.persist_drain()
+        # host-fed throughput of the live loop: requests and payload cross PCIe through the pinned command
+        # ring (what the proxy's DARE thread does with a drained batch), the kernel runs them as rounds of 64
+        hr0 = eng.persist_highest_rec()
+        blk4k = np.ascontiguousarray(tr.reqs[16:16 + 4096])
+        n_fed, t_f0 = 0, time.perf_counter()
+        n_sub = 0
+        while time.perf_counter() - t_f0 < 0.5:
+            eng.persist_submit(blk4k, tr.arena)
+            n_fed += len(blk4k)
+            n_sub += 1
+            if n_sub % 16 == 0:
+                eng.persist_prune()              # the prune timer: every 8 MiB of log, as in the staged workload
+        eng.persist_drain(timeout_ms=20000)
+        t_fed = time.perf_counter() - t_f0
+        host_fed = {"value": n_fed / t_fed, "unit": "entries/s", "entries": n_fed,
+                    "note": "host-fed: apus_gpu_persist_submit of 4096-request batches (64-B payload) from host memory through the "
+                            "pinned command ring into the persistent consensus kernel, 3 logical replicas; submit of the first "
+                            "batch -> highest_rec covers the last.  Never the headline (inputs are not resident in HBM)"} \
+            if eng.persist_highest_rec() == hr0 + n_fed else None
         code = eng.persist_stop()
         dl = eng.persist_latency_ns()
         ph1, ph2 = eng.persist_latency_phase_ns(1), eng.persist_latency_phase_ns(2)
@@ -392,6 +411,7 @@ def bench_single(args):
                     "persistent_kernel_phase_breakdown": plat_phases,
                     "phased_kernels_host_round_trip_us_p50": p50,
                     "by_group_size": lat_by_group,
+                    "host_fed_live_loop": host_fed,
                     "note": "one 64-entry round per measurement, 3 logical replicas on one MI355X; "
                             "device latency from wall_clock64 inside the persistent kernel"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
