@@ -325,8 +325,13 @@ void *dare_server_init(void *arg)
             pthread_spin_lock(&g_q.lock);
             const uint32_t queued = g_q.n;
             pthread_spin_unlock(&g_q.lock);
-            if (queued && !s->failed) dare_ib_poll_tailq();
-            else { struct timespec ts = {0, 2000}; nanosleep(&ts, NULL); }
+            /* the reference's DARE thread busy-polls (polling() is libev's idle callback); so does this
+             * one while requests keep coming -- nanosleep() costs 50+ us of timer slack per request
+             * otherwise -- and backs off only after a millisecond of silence */
+            static unsigned idle_spins;
+            if (queued && !s->failed) { dare_ib_poll_tailq(); idle_spins = 0; }
+            else if (++idle_spins < 20000) __builtin_ia32_pause();
+            else { struct timespec ts = {0, 20000}; nanosleep(&ts, NULL); }
             proxy_mirror_highest_rec(*s->dev_hr);
             if (!s->failed && apus_gpu_persist_full(s->eng)) {
                 fprintf(stderr, "[apus] the log is full: requests dropped, admission closed\n");

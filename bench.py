@@ -412,8 +412,9 @@ def bench_single(args):
                     "phased_kernels_host_round_trip_us_p50": p50,
                     "by_group_size": lat_by_group,
                     "host_fed_live_loop": host_fed,
-                    "note": "one 64-entry round per measurement, 3 logical replicas on one MI355X; "
-                            "device latency from wall_clock64 inside the persistent kernel"},
+                    "note": "one 64-entry round per measurement, logical replicas on ONE MI355X: append -> commit between workgroups "
+                            "of one device (no xGMI hop is in it; a group that spans GPUs adds one peer-store and one doorbell hop "
+                            "per follower); device latency from wall_clock64 inside the persistent kernel"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "moved": moved, "frac_moved": (moved / HBM_PEAK_GBS) if moved else None,
@@ -552,8 +553,8 @@ def bench_multi(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--entries", type=int, default=1 << 20)
     ap.add_argument("--payload", type=int, default=64)
     ap.add_argument("--batch", type=int, default=64)

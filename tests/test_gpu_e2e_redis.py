@@ -59,9 +59,11 @@ def parse_dump(path, n):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "redis-server")), reason="oracle/_ref/redis-server not built (make -C oracle redis)")
-def test_redis_under_ld_preload_replicates_every_request():
+@pytest.mark.parametrize("n_req,n_conn,dsize", [(20000, 1, 3), (100000, 50, 64)])
+def test_redis_under_ld_preload_replicates_every_request(n_req, n_conn, dsize):
+    """redis-benchmark -t set -d <dsize> -n <n_req> -c <n_conn> (benchmarks/run.sh:71-88,127: one client, and fifty)"""
     from oracle import oracle as orc
-    n, LOG, n_req, n_conn = 3, 1 << 24, 20000, 4
+    n, LOG = 3, 1 << 26
     port = _free_port()
     tmp = tempfile.mkdtemp()
     dump = os.path.join(tmp, "replicas.bin")
@@ -75,7 +77,7 @@ def test_redis_under_ld_preload_replicates_every_request():
         assert _wait_port(port, srv), f"redis-server did not come up\n{srv.stdout.read()[-3000:] if srv.poll() is not None else ''}"
         clean = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
         t0 = time.time()
-        b = subprocess.run([os.path.join(REF, "redis-benchmark"), "-p", str(port), "-t", "set", "-n", str(n_req), "-c", str(n_conn), "-q"],
+        b = subprocess.run([os.path.join(REF, "redis-benchmark"), "-p", str(port), "-t", "set", "-d", str(dsize), "-n", str(n_req), "-c", str(n_conn), "-q"],
                            env=clean, capture_output=True, text=True, timeout=300)
         dt = time.time() - t0
         assert b.returncode == 0 and "requests per second" in b.stdout, b.stdout + b.stderr

@@ -527,3 +527,13 @@ def test_election_needs_a_majority_of_votes(eng_factory):
         cl.elect(4)
     with pytest.raises(Exception, match="majority"):
         eng.elect(4)
+
+
+def test_failover_reconf_bench_full_size(eng_factory):
+    """BASELINE config 5 at the reference's size: 20 000 requests per phase (benchmarks/reconf_bench.sh),
+    kill the leader, elect (votes on the device), kill a follower, 5 replicas"""
+    from tests.parity import lockstep
+    tr = T.config_c5()
+    eng = eng_factory(5, tr.log_len)
+    cl = lockstep(tr, eng, batch=True, check_at=("QUIESCE",))
+    assert cl.leader == 1 and eng.counters(1)["sid"] == cl.sid(1)
