@@ -2250,7 +2250,7 @@ __device__ static inline void recorder_body(const EngDev &E, uint64_t r0, uint32
  * sequencer pushed it; slot + 1 and value are derived (head_slot1, head_value) instead of read */
 __device__ static inline void keeper_publish(const EngDev &E, ApplyCtx &c, uint32_t R, int mode, uint32_t fmask,
                                              uint64_t vis, uint64_t cs, bool pure_head = false, uint64_t head_slot1 = 0,
-                                             uint64_t head_value = 0, uint64_t *snap_next = nullptr, bool dry = false)
+                                             uint64_t head_value = 0, uint64_t *snap_next = nullptr)
 {
     const uint32_t tid = threadIdx.x;
     uint64_t *lh = E.rep[E.leader].hdr;
@@ -2263,21 +2263,21 @@ __device__ static inline void keeper_publish(const EngDev &E, ApplyCtx &c, uint3
     if (tid == 0) {
         if (mode == 0) {
             c.rec_base = c.rec_base + R + s.head_round;
-            if (!dry) gst(E.rec_count, (uint64_t)c.rec_base);
+            gst(E.rec_count, (uint64_t)c.rec_base);
         } else if (mode == 1 && s.n) {
-            if (!dry && c.rec_base < E.rec_cap) E.rec_commit[c.rec_base] = (end_l == L) ? s.commit_before : commit_off;
+            if (c.rec_base < E.rec_cap) E.rec_commit[c.rec_base] = (end_l == L) ? s.commit_before : commit_off;
             c.rec_base = c.rec_base + 1;
-            if (!dry) gst(E.rec_count, (uint64_t)c.rec_base);
+            gst(E.rec_count, (uint64_t)c.rec_base);
         }
-        if (!dry) gst(&lh[H_N_VISIBLE], (uint64_t)(vis)); c.lh[H_N_VISIBLE] = vis;
-        if (cs > s.n_commit_before) { if (!dry) gst(&lh[H_COMMIT], (uint64_t)(commit_off)); if (!dry) gst(&lh[H_N_COMMIT], (uint64_t)(cs)); c.lh[H_COMMIT] = commit_off; c.lh[H_N_COMMIT] = cs; }
-        if (cs > c.lh[H_N_APPLY]) { if (!dry) gst(&lh[H_APPLY], (uint64_t)(c.off_cs)); if (!dry) gst(&lh[H_N_APPLY], (uint64_t)(cs)); c.lh[H_APPLY] = c.off_cs; c.lh[H_N_APPLY] = cs; }
+        gst(&lh[H_N_VISIBLE], (uint64_t)(vis)); c.lh[H_N_VISIBLE] = vis;
+        if (cs > s.n_commit_before) { gst(&lh[H_COMMIT], (uint64_t)(commit_off)); gst(&lh[H_N_COMMIT], (uint64_t)(cs)); c.lh[H_COMMIT] = commit_off; c.lh[H_N_COMMIT] = cs; }
+        if (cs > c.lh[H_N_APPLY]) { gst(&lh[H_APPLY], (uint64_t)(c.off_cs)); gst(&lh[H_N_APPLY], (uint64_t)(cs)); c.lh[H_APPLY] = c.off_cs; c.lh[H_N_APPLY] = cs; }
         if (mode == 0 && s.fast) {
             /* the append blocks applied the batch (every entry a client entry): one upcall each */
-            if (!dry) atomicAdd((unsigned long long *)&lh[H_APPLY_COUNT], (unsigned long long)s.n);
-            if (!dry) atomicAdd((unsigned long long *)&lh[H_HIGHEST_REC], (unsigned long long)s.n);
+            atomicAdd((unsigned long long *)&lh[H_APPLY_COUNT], (unsigned long long)s.n);
+            atomicAdd((unsigned long long *)&lh[H_HIGHEST_REC], (unsigned long long)s.n);
             for (uint32_t m = s.fuse_mask; m; m &= m - 1)
-                if (!dry) atomicAdd((unsigned long long *)&E.rep[__builtin_ctz(m)].hdr[H_APPLY_COUNT], (unsigned long long)s.n);
+                atomicAdd((unsigned long long *)&E.rep[__builtin_ctz(m)].hdr[H_APPLY_COUNT], (unsigned long long)s.n);
         }
     }
     if (tid >= 1 && tid <= APUS_DEV_MAX_SERVERS) {
@@ -2292,29 +2292,29 @@ __device__ static inline void keeper_publish(const EngDev &E, ApplyCtx &c, uint3
                               : __hip_atomic_load((unsigned long long *)&fh[H_HEAD_SLOT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint64_t end_now = f_end;
             if (vis > f_np) {
-                if (!dry) gst(&fh[H_STORE_COUNT], (uint64_t)(f_sc + (vis - f_np)));
-                if (!dry) gst(&fh[H_END], (uint64_t)(c.off_vis)); if (!dry) gst(&fh[H_OLD_END], (uint64_t)(c.off_vis));
-                if (!dry) gst(&fh[H_N_END], (uint64_t)(vis)); if (!dry) gst(&fh[H_N_PERSIST], (uint64_t)(vis));
+                gst(&fh[H_STORE_COUNT], (uint64_t)(f_sc + (vis - f_np)));
+                gst(&fh[H_END], (uint64_t)(c.off_vis)); gst(&fh[H_OLD_END], (uint64_t)(c.off_vis));
+                gst(&fh[H_N_END], (uint64_t)(vis)); gst(&fh[H_N_PERSIST], (uint64_t)(vis));
                 w[FW_STORE_COUNT] = f_sc + (vis - f_np); w[FW_END] = c.off_vis; w[FW_N_END] = vis; w[FW_N_PERSIST] = vis;
                 end_now = c.off_vis;
             }
-            if (cs > f_nc) { if (!dry) gst(&fh[H_COMMIT], (uint64_t)(c.off_cs)); if (!dry) gst(&fh[H_N_COMMIT], (uint64_t)(cs)); w[FW_N_COMMIT] = cs; }
-            if (cs > f_na) { if (!dry) gst(&fh[H_APPLY], (uint64_t)(c.off_cs)); if (!dry) gst(&fh[H_N_APPLY], (uint64_t)(cs)); w[FW_APPLY] = c.off_cs; w[FW_N_APPLY] = cs; }
+            if (cs > f_nc) { gst(&fh[H_COMMIT], (uint64_t)(c.off_cs)); gst(&fh[H_N_COMMIT], (uint64_t)(cs)); w[FW_N_COMMIT] = cs; }
+            if (cs > f_na) { gst(&fh[H_APPLY], (uint64_t)(c.off_cs)); gst(&fh[H_N_APPLY], (uint64_t)(cs)); w[FW_APPLY] = c.off_cs; w[FW_N_APPLY] = cs; }
             if (hs) {
                 uint64_t hv = head_value;
                 if (!pure_head) {
                     const uint64_t hoff = E.rep[f].dir_off[(uint32_t)(hs - 1) & E.dir_mask];
                     hv = ld8u(E.rep[f].ring + hoff + 48);
                 }
-                if (apus_is_larger(end_now, L, hv, f_head)) { if (!dry) gst(&fh[H_HEAD], (uint64_t)(hv)); w[FW_HEAD] = hv; }
-                if (!pure_head) if (!dry) gst(&fh[H_HEAD_SLOT], (uint64_t)(0));
+                if (apus_is_larger(end_now, L, hv, f_head)) { gst(&fh[H_HEAD], (uint64_t)(hv)); w[FW_HEAD] = hv; }
+                if (!pure_head) gst(&fh[H_HEAD_SLOT], (uint64_t)(0));
             }
         }
     }
     if (snap_next) {
         /* the state after this call, for the next segment of the launch (write-once, uncached) */
         __syncthreads();
-        if (!dry) {
+        {
             if (tid < 64) gst(&snap_next[tid], c.lh[tid]);
             else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) gst(&snap_next[SNAP_FW + (tid - 64)], (&c.fw[0][0])[tid - 64]);
             else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) gst(&snap_next[SNAP_REC], (uint64_t)c.rec_base);
@@ -2542,9 +2542,9 @@ struct StepTable {
 };
 
 /* The body of a call for block b of its grid.  STEP = false: k_call (one call per launch, inputs =
- * the live control blocks).  STEP = true: segment seg of S in a k_step launch: inputs = snapshot
- * seg (seg > 0), the bookkeeper writes snapshot seg + 1 and raises the epoch, the sequencers'
- * effects are chained by their own count. */
+ * the live control blocks).  STEP = true: segment seg of S in a k_step launch: the blocks work from
+ * the segment's sequencing record (rec_wait); where the record says "not in step" they fall back to
+ * snapshot seg, which the chain block completes (epoch >= seg) before it publishes that record. */
 template <bool STEP>
 __device__ static inline void call_block(const EngDev &E, const CallEnv &X, const CallArgs &A, uint32_t push_mask, uint32_t rmask,
                                          uint32_t b_grid, SeqLds &sq, CallLds &l, uint32_t seg, uint32_t S,
@@ -2737,18 +2737,19 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
     q -= nR;
     if (q == 0) {                                              /* ---- the bookkeeper ---- */
         /* In a multi-segment launch ONE block -- segment 0's bookkeeper, the CHAIN BLOCK -- keeps the
-         * books of every segment, one after the other.  In step the state after a call follows from
-         * the state before it and the staged sizes, so segment k+1 starts from the LDS copy segment k
-         * left behind (c.lh, c.fw, c.rec_base): no poll, no snapshot read-back.  Per segment it
-         *   1. works the call's SeqOut out (one lane) and publishes the segment's RECORD (rec_publish:
-         *      ten self-tagged granules, no drain) -- that is all the append blocks wait for;
-         *   2. does the bookkeeping (keeper_publish: live control words + snapshot k+1, issued, not
-         *      waited for);
-         * and only when it has to wait for other blocks itself (a segment that is not in step or may
-         * wrap) or at the very end does it drain its stores and raise the epoch, which the
-         * sequencers, record blocks and fallback paths of later segments wait for.  (Chained through
-         * memory the bookkeeping cost ~9 us per segment, tools/seg_probe.py / chain_probe.py.)
-         * The other segments' bookkeeper blocks just leave. */
+         * books of every segment; the other segments' bookkeeper blocks just leave.
+         *   1. RECORD PASS (wave 0, registers only, chain_core): every segment that is in step is
+         *      sequenced from the state the previous one leaves and its record published -- that is
+         *      all the append / record blocks wait for.  It stops at the first segment it cannot take.
+         *   2a. every segment was taken: chain_books_fast -- per segment only what the next one does
+         *      not overwrite (a due tick's <HEAD> entry, the log-full check, the sign-off), then the
+         *      control words once, as the last segment leaves them.
+         *   2b. otherwise the SECOND PASS below walks the segments on the LDS copies (c.lh, c.fw,
+         *      c.rec_base): records for the segments the first pass did not reach, the sequencer's
+         *      effects, keeper_publish with the snapshot the fallback roles of the next segment
+         *      sequence from, the waits for a segment's own blocks where it is not in step, the epoch.
+         * (Chained through memory the bookkeeping cost ~9 us per segment, through LDS and block barriers
+         * ~3.5-5.5 us: tools/timeline_probe.py.) */
         if (STEP && seg > 0) return;
         const uint32_t S_ = STEP ? S : 1u;
         __shared__ uint32_t chain_fast;                        /* this segment was sequenced by chain_decide_fast */
@@ -2757,7 +2758,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
         __shared__ uint64_t pre_pfx[APUS_STEP_SEGS][2];
         __shared__ uint32_t pre_rf[APUS_STEP_SEGS][2];
         __shared__ uint64_t pre_last[APUS_STEP_SEGS];
-        __shared__ uint32_t n_dry_s;
+        __shared__ uint32_t n_rec_s;
         if (STEP && TT && tid < S_) {
             const CallArgs &Ap = TT->seg[tid];
             const uint32_t a = E.round_first[Ap.r0], bb = E.round_first[Ap.r0 + Ap.R];
@@ -2777,9 +2778,9 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                 seq_w0_stage(E, A0.r0, A0.R, push_mask, 0, sq, nullptr, true);
                 if (tid == 0) __hip_atomic_fetch_add(X.lines + ((STEP ? A0.nR : nAB0 + A0.nR) & 31u) * 32 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (tid == 0) n_dry_s = 0;
+            if (tid == 0) n_rec_s = 0;
             __syncthreads();
-#ifndef APUS_NO_DRY
+#ifndef APUS_NO_RECORD_PASS      /* diagnostics: every segment through the second pass */
             if (STEP && TT) {
                 /* ---- the RECORD PASS: wave 0 sequences every segment it can on registers (chain_core)
                  * and publishes the records, before the block does anything else -- no LDS, no barrier, no
@@ -2832,7 +2833,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                         chain_advance(E, push_mask, cr, g, o);
                         nd = k + 1;
                     }
-                    if (lane == 0) n_dry_s = nd;
+                    if (lane == 0) n_rec_s = nd;
                 }
                 __syncthreads();
             }
@@ -2841,7 +2842,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                 /* snapshot 0 = the state before the launch: what a fallback path of segment 0
                  * sequences from (the live words may change as soon as the readers are through) */
                 uint64_t *s0 = E.step_snap;
-                const bool snap0 = !TT || n_dry_s < S_;
+                const bool snap0 = !TT || n_rec_s < S_;
                 if (tid < 64) { if (snap0) gst(&s0[tid], sq.lh[tid]); c.lh[tid] = sq.lh[tid]; }
                 else if (tid < 64 + 8 * APUS_DEV_MAX_SERVERS) { if (snap0) gst(&s0[SNAP_FW + (tid - 64)], (&c.fw[0][0])[tid - 64]); }
                 else if (tid == 64 + 8 * APUS_DEV_MAX_SERVERS) { if (snap0) gst(&s0[SNAP_REC], sq.misc[0]); c.rec_base = sq.misc[0]; }
@@ -2851,9 +2852,9 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
         /* The second pass: everything but the records of the segments the record pass sequenced -- the
          * live control words, the <HEAD> entries, the snapshots, the tickets, and the general path for
          * the segments that need it.  It starts over from the state before the launch (c.lh / c.fw). */
-        const uint32_t n_dry = (STEP && TT) ? n_dry_s : 0u;
+        const uint32_t n_rec = (STEP && TT) ? n_rec_s : 0u;
 #ifndef APUS_NO_FAST_BOOKS
-        if (STEP && TT && S_ > 0 && n_dry == S_) {
+        if (STEP && TT && S_ > 0 && n_rec == S_) {
             /* every segment is in step and was sequenced on registers: so are the books (chain_books_fast) */
             if (tid < WAVE) {
                 const uint32_t lane = tid;
@@ -2877,7 +2878,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
 #endif
         /* snapshots are what the fallback paths of a segment sequence from: none of them runs when the
          * record pass got through the whole launch */
-        const bool snaps = STEP && n_dry < S_;
+        const bool snaps = STEP && n_rec < S_;
         for (uint32_t k = 0; k < S_; k++) {
             const CallArgs &Ak = (STEP && TT) ? TT->seg[k] : A;
             const CallEnv Xk = (STEP && TT) ? CallEnv{E.step_lines + (size_t)k * 1024, E.step_tickets + (size_t)k * 32,
@@ -2902,9 +2903,9 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                 __syncthreads();
             }
             if (STEP && TT && segment_refused(E.log_len, sq.lh[H_END], sq.lh[H_HEAD], pre_pfx[k][1] - pre_pfx[k][0], tickk, TT->max_T)) {
-                /* does not fit into the log: refused as a whole (the record pass said the same for k < n_dry) */
+                /* does not fit into the log: refused as a whole (the record pass said the same for k < n_rec) */
                 if (tid == 0) { set_status(E, 1u << 1); sq.ok = 1; }
-                if (k >= n_dry && tid < WAVE) {
+                if (k >= n_rec && tid < WAVE) {
                     RecFields f;
                     f.e0 = sq.lh[H_END]; f.idx0 = sq.lh[H_LAST_IDX] + 1; f.n_end0 = sq.lh[H_N_END]; f.term = sq.lh[H_SID] >> 9;
                     f.flags_n = (uint64_t)(rec_flags(1u, push_mask, 1u, 0u, 0u, false, true) | RECF_REFUSED);
@@ -2935,7 +2936,7 @@ __device__ static inline void call_block(const EngDev &E, const CallEnv &X, cons
                     if (k == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
                     else if (epoch_done < k) { bump_count(E.step_epoch, k); epoch_done = k; }
                 }
-                if (k >= n_dry) {
+                if (k >= n_rec) {
                     if (tid < WAVE) rec_publish(E, k, sq, chain_fast != 0);
                     if (k < 64) STAMPN(9, k);
                 }
@@ -3049,14 +3050,16 @@ __global__ APUS_CALL_BOUNDS void k_call(const EngDev E_arg, const CallArgs A, ui
     call_block<false>(E, X, A, push_mask, rmask, blockIdx.x, sq, l, 0, 1);
 }
 
-/* k_step: several consecutive calls (segments) in ONE launch.  The blocks of segment k sit behind
- * those of segment k-1 in the grid and run k_call's roles on segment-private counters; what
- * replaces the kernel boundary between two calls is a state snapshot: the bookkeeper of segment
- * k-1 writes the control state after its call (write-once, uncached memory) and raises the epoch,
- * and segment k sequences from that snapshot -- its append blocks start as soon as that
- * bookkeeper is done (which in step is early: it needs nothing but its own copy of the
- * sequencing), while segment k-1's stores are still draining.  No end-of-kernel write-back, no
- * dispatch ramp, no graph gap between segments. */
+/* k_step: several consecutive calls (segments) in ONE launch -- k_call's roles per segment on
+ * segment-private counters.  What replaces the kernel boundary between two calls: the chain block
+ * (segment 0's bookkeeper) sequences every in-step segment ahead on registers and publishes a
+ * sequencing RECORD per segment (rec_publish_fields / rec_wait) that the segment's append, record and
+ * idle blocks work from; segments that are not in step fall back to snapshots of the control state
+ * (write-once, uncached memory) chained by an epoch count.  Grid order 0: segment by segment; order 1
+ * (StepTable::order, chosen by flush_batch when everything fits on the device at once): the single
+ * blocks, then every segment's append blocks, then the rest -- all loads of the launch are issued
+ * before anybody stores.  No end-of-kernel write-back, no dispatch ramp, no graph gap between
+ * segments. */
 __global__ APUS_CALL_BOUNDS void k_step(const EngDev E_arg, const StepTable T, uint32_t push_mask, uint32_t rmask)
 {
     (void)E_arg;
