@@ -34,6 +34,7 @@
 #define P_LAT_CAP    (1u << 16)
 
 enum { P_OP_ROUND = 1, P_OP_PRUNE = 2, P_OP_STOP = 3 };
+#define P_BURST      16u            /* rounds whose commit pass may be shared when the host keeps the ring filled */
 
 struct PEvent { uint32_t op; uint32_t n; uint64_t req_first;
                 uint32_t arena_off;      /* the round's payloads are contiguous in the pinned arena: [off, off+bytes) */
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
     /* ================================ leader ================================ */
     uint64_t ev_head = 0;
     uint64_t exit_code = 0;
+    uint32_t burst = 0;                               /* rounds appended since the last commit pass */
     if (tid < APUS_DEV_MAX_SERVERS) s_sid[tid] = (tid < E.group_size && E.rep[tid].ring) ? E.rep[tid].hdr[H_SID] : 0;
     if (tid == 0) st_sys(&H->alive, 1);
     __syncthreads();
@@ -465,7 +467,25 @@ __global__ __launch_bounds__(256) void k_consensus_persistent(const EngDev E, Pe
         /* the log reads as empty when end sits on len: nothing of this round is visible yet */
         const uint64_t vis = (end_off == L) ? n_end0 : n_end;
 
-        if (vis > mh[H_N_COMMIT]) {
+        /* A burst: when the host has already queued the next ROUND, this round's doorbell / ACK
+         * aggregation / commit / apply ride with the next one's (up to P_BURST rounds): the followers
+         * then persist and ACK the burst in one go and the ballot loop below commits it in windows of
+         * 64.  Polling() does the same when requests queue up (one pass takes the whole tailq); batch
+         * boundaries never change the logs.  A lone round is never held back. */
+        if (tid == 0) {
+            uint32_t defer = 0;
+            if (op == P_OP_ROUND && appended && burst < P_BURST && ld_sys(&H->ev_tail) > ev_head + 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                if (H->ev[(ev_head + 1) % P_EV_CAP].op == P_OP_ROUND) defer = 1;
+            }
+            s_word[2] = defer;
+        }
+        __syncthreads();
+        const bool defer = s_word[2] != 0;
+        burst = defer ? burst + 1 : 0;
+        __syncthreads();
+
+        if (!defer && vis > mh[H_N_COMMIT]) {
             /* ---- R2: end doorbell to every in-sync follower ---- */
             uint64_t t_bell = 0;
             if (tid == 0) {

@@ -306,6 +306,8 @@ def bench_single(args):
         blk = reqs64[:64]
         hl = eng.persist_roundtrip_ns(blk, tr.arena, 400) / 1e3       # C loop: submit -> highest_rec
         eng.persist_drain()
+        dl = eng.persist_latency_ns()                 # (the lone rounds of the probe only: read before the bulk run below)
+        ph1, ph2 = eng.persist_latency_phase_ns(1), eng.persist_latency_phase_ns(2)
         # host-fed throughput of the live loop: requests and payload cross PCIe through the pinned command
         # ring (what the proxy's DARE thread does with a drained batch), the kernel runs them as rounds of 64
         hr0 = eng.persist_highest_rec()
@@ -326,8 +328,6 @@ def bench_single(args):
                             "batch -> highest_rec covers the last.  Never the headline (inputs are not resident in HBM)"} \
             if eng.persist_highest_rec() == hr0 + n_fed else None
         code = eng.persist_stop()
-        dl = eng.persist_latency_ns()
-        ph1, ph2 = eng.persist_latency_phase_ns(1), eng.persist_latency_phase_ns(2)
         plat_phases = {"sequenced_us_p50": float(np.percentile(ph1[20:], 50)) / 1e3, "pushed_and_doorbell_us_p50": float(np.percentile(ph2[20:], 50)) / 1e3} if len(ph1) > 20 else None
         plat_host = float(np.percentile(hl[40:], 50))
         plat_dev = float(np.percentile(dl[20:], 50)) / 1e3 if len(dl) > 20 else None
