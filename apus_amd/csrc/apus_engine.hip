@@ -63,7 +63,7 @@ struct apus_engine {
      * get their logs adjusted by the new leader's first pass (log_adjustment, dare_ibv_rc.c:1292-1451) */
     uint32_t no_access, adjust_mask;
     uint64_t *d_elect;                         /* k_elect's verdict */
-    struct BatchSeg { CallArgs a; uint32_t blocks; uint64_t bytes; };
+    struct BatchSeg { CallArgs a; uint32_t blocks; uint64_t bytes; bool lean; };
     std::vector<BatchSeg> batch;               /* recorded calls: arguments, blocks, bytes they append */
     /* graphs */
     std::vector<hipGraphExec_t> graphs;
@@ -499,7 +499,7 @@ static int admit_bytes(apus_engine *e, uint64_t bytes, uint64_t slack)
 #define APUS_CALL_ROUNDS 1024u
 
 /* one call's launch parameters */
-static CallArgs call_args(apus_engine *e, uint64_t c0, uint32_t R, uint32_t tick, uint32_t *blocks)
+static CallArgs call_args(apus_engine *e, uint64_t c0, uint32_t R, uint32_t tick, uint32_t *blocks, bool lean = false)
 {
     const uint32_t fm = sync_mask(e);
     const uint32_t rm = fm | ((e->local_mask >> e->d.leader) & 1u ? (1u << e->d.leader) : 0);
@@ -508,6 +508,10 @@ static CallArgs call_args(apus_engine *e, uint64_t c0, uint32_t R, uint32_t tick
     a.r0 = c0; a.R = R; a.tick = tick;
     /* the scan / apply blocks only work when the replicas are not in step: a modest number, grid-stride */
     a.nS = cap_grid(n, 256, 32); a.nA = cap_grid(n, 1024, 16); a.nR = cap_grid(R, 256, 8);
+    /* lean: every configured follower is reachable and nobody lags -- the call is expected to be in step,
+     * where these blocks only look at the segment's record and leave; a few of them keep the not-in-step
+     * path correct (grid-stride) and leave the device to the append workgroups (flush_batch) */
+    if (lean) { a.nS = std::min(a.nS, 8u); a.nA = std::min(a.nA, 4u); a.nR = std::min(a.nR, 4u); }
     /* rounds with many 16-byte units are shared by SP workgroups each (a launch of a few hundred
      * large rounds would leave most of the 256 CUs idle) */
     const uint64_t units = (e->h_round_prefix[c0 + R] - e->h_round_prefix[c0]) / 16;
@@ -551,16 +555,40 @@ static int flush_batch(apus_engine *e)
         /* (with APUS_F_NO_FUSED_ACKS no segment is sequenced ahead: every one waits for its ACK scan, the
          * segments run one after the other and the order of the grid follows them) */
         const bool fit_ok = !e->p_running && e->step_slots > 0 && !(e->d.flags & 1u);
-        uint32_t fit_app = 0, fit_svc = 0;
+        uint32_t fit_app = 0, fit_svc = 0, consumed = 0, seg_svc[APUS_STEP_SEGS];
+        apus_engine::BatchSeg split_rest;
+        bool have_rest = false;
         while (i + k < e->batch.size() && k < APUS_STEP_SEGS) {
             const apus_engine::BatchSeg &g = e->batch[i + k];
             if (k && bytes + g.bytes + APUS_HDR > lap) break;
             const uint32_t nab = grouped_blocks(g.a, APUS_GD), ms = std::max(fit_svc, svc_of(g));
-            if (k && fit_ok && 2 * (k + 1) + fit_app + nab + ms > e->step_slots && 2 * k + fit_app + fit_svc <= e->step_slots) break;
+            if (k && fit_ok && 2 * (k + 1) + fit_app + nab + ms > e->step_slots && 2 * k + fit_app + fit_svc <= e->step_slots) {
+                /* the segment does not fit as a whole: its first rounds fill the launch (a call is a run of
+                 * rounds; where it is cut never changes the logs), the rest opens the next one */
+                const uint32_t used = 2 * (k + 1) + fit_app + ms;
+                const uint32_t room = e->step_slots > used ? e->step_slots - used : 0;
+                const uint32_t R1 = room * APUS_GR;
+                if (g.a.GP > 1 && R1 >= 64 && g.a.R >= R1 + 4 * APUS_GP) {
+                    uint32_t b1 = 0, b2 = 0;
+                    apus_engine::BatchSeg first = g, rest = g;
+                    first.a = call_args(e, g.a.r0, R1, g.a.tick, &b1, g.lean);
+                    first.blocks = b1; first.bytes = e->h_round_prefix[g.a.r0 + R1] - e->h_round_prefix[g.a.r0];
+                    rest.a = call_args(e, g.a.r0 + R1, g.a.R - R1, 0, &b2, g.lean);
+                    rest.blocks = b2; rest.bytes = g.bytes - first.bytes;
+                    split_rest = rest; have_rest = true;
+                    fit_app += grouped_blocks(first.a, APUS_GD); fit_svc = std::max(fit_svc, first.blocks - 2 - call_append_blocks(first.a));
+                    T.seg[k] = first.a;
+                    seg_svc[k] = first.blocks - 2 - call_append_blocks(first.a);
+                    bytes += first.bytes + APUS_HDR;
+                    k++;
+                }
+                break;
+            }
             fit_app += nab; fit_svc = ms;
             T.seg[k] = g.a;
+            seg_svc[k] = svc_of(g);
             bytes += g.bytes + APUS_HDR;
-            k++;
+            k++; consumed++;
         }
         T.S = k;
         T.max_T = (uint32_t)e->stage_max_T;
@@ -576,7 +604,7 @@ static int flush_batch(apus_engine *e)
             if (T.seg[j].GP > 1) T.seg[j].GP = APUS_GP * gd;
             const uint32_t nab = call_append_blocks(T.seg[j]);
             T.blk0[j] = blk;
-            blk += 2 + nab + svc_of(e->batch[i + j]);
+            blk += 2 + nab + seg_svc[j];
             n_app += nab;
         }
         T.blk0[k] = blk;
@@ -605,7 +633,8 @@ static int flush_batch(apus_engine *e)
         }
         hipLaunchKernelGGL(k_step, dim3(blk), dim3(256), 0, e->stream, e->d, T, fm, rm);
         if (tl) HIPCHK(hipEventRecord(tl->b, e->stream));
-        i += k;
+        i += consumed;
+        if (have_rest) e->batch[i] = split_rest;       /* the rest of the segment that was cut opens the next launch */
     }
     e->batch.clear();
     HIPCHK(hipGetLastError());
@@ -633,9 +662,11 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
         const uint32_t tick = e->tick_pending ? 1u : 0u;
         e->tick_pending = false;
         uint32_t blocks = 0;
-        const CallArgs a = call_args(e, c0, R, tick, &blocks);
+        const bool lean = e->batching && !(e->d.flags & 1u) && !e->lag_possible &&
+                          popc(fm) + 1 == (int)e->d.group_size;
+        const CallArgs a = call_args(e, c0, R, tick, &blocks, lean);
         if (e->batching) {                    /* recorded; apus_gpu_batch_end launches the lot as k_step */
-            e->batch.push_back(apus_engine::BatchSeg{a, blocks, e->h_round_prefix[c0 + R] - e->h_round_prefix[c0]});
+            e->batch.push_back(apus_engine::BatchSeg{a, blocks, e->h_round_prefix[c0 + R] - e->h_round_prefix[c0], lean});
             continue;
         }
         TimedLaunch *tl = nullptr;
