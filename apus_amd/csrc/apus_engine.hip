@@ -562,7 +562,9 @@ static int flush_batch(apus_engine *e)
             const apus_engine::BatchSeg &g = e->batch[i + k];
             if (k && bytes + g.bytes + APUS_HDR > lap) break;
             const uint32_t nab = grouped_blocks(g.a, APUS_GD), ms = std::max(fit_svc, svc_of(g));
-            if (k && fit_ok && 2 * (k + 1) + fit_app + nab + ms > e->step_slots && 2 * k + fit_app + fit_svc <= e->step_slots) {
+            /* (only launches of grouped segments are cut to the device: with a workgroup or more per round
+             * the append blocks of even one segment exceed it, residency is not to be had) */
+            if (k && fit_ok && g.a.GP > 1 && 2 * (k + 1) + fit_app + nab + ms > e->step_slots && 2 * k + fit_app + fit_svc <= e->step_slots) {
                 /* the segment does not fit as a whole: its first rounds fill the launch (a call is a run of
                  * rounds; where it is cut never changes the logs), the rest opens the next one */
                 const uint32_t used = 2 * (k + 1) + fit_app + ms;

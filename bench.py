@@ -306,8 +306,10 @@ def bench_single(args):
         blk = reqs64[:64]
         hl = eng.persist_roundtrip_ns(blk, tr.arena, 400) / 1e3       # C loop: submit -> highest_rec
         eng.persist_drain()
+        eng.persist_stop()
         dl = eng.persist_latency_ns()                 # (the lone rounds of the probe only: read before the bulk run below)
         ph1, ph2 = eng.persist_latency_phase_ns(1), eng.persist_latency_phase_ns(2)
+        eng.persist_start(idle_ms=2000, peer_ms=200)
         # host-fed throughput of the live loop: requests and payload cross PCIe through the pinned command
         # ring (what the proxy's DARE thread does with a drained batch), the kernel runs them as rounds of 64
         hr0 = eng.persist_highest_rec()
