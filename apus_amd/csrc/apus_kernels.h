@@ -1641,7 +1641,9 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
         if (grp == 0 && it == 0) STAMP(8, 4);
 
         /* ---- the round's bytes: lane l stores units l, l + 64, ... ---- */
-        if (unu && sq->ok && sq->out.kstar < 0) {
+        /* (a batch that wraps: every round but the one the wrapping entry sits INSIDE is still laid out
+         * in one piece -- before the wrap as sequenced, from the wrapping entry on shifted to offset 0) */
+        if (unu && sq->ok && (sq->out.kstar < 0 || sq->out.kstar <= (int64_t)first || sq->out.kstar >= (int64_t)(first + nr))) {
             /* Entries of one size, no wrap inside the batch: everything about unit u follows from
              * arithmetic -- entry e = u / unu (multiply-high), its position a_r + e * T, its index
              * idx_r + e -- and ONE straight-line store sequence per target replica: the value is
@@ -1651,7 +1653,7 @@ __device__ static inline uint32_t append_group(const EngDev &E, const CallEnv &X
              * bound by instruction issue (~10 us per block), not by HBM (tools/timeline_probe.py). */
             const uint32_t magic = y.magic;
             const uint32_t Tu = y.T0;
-            const uint64_t a_r = __shfl(a, 0, WAVE);                     /* where the round's first entry goes */
+            const uint64_t a_r = __shfl(pos, 0, WAVE);                   /* where the round's first entry goes */
             const uint64_t idx_r = __shfl(idx, 0, WAVE);
             const uint32_t n_tgt = 1u + (uint32_t)__popc(push_mask & ~(1u << E.leader));
             auto fast_unit = [&](uint32_t u, uint4 pay) {

@@ -17,7 +17,7 @@ for c in calls:
     first.append(c)
     if c[0] == "rounds":
         n += 1
-        if n == 5: break
+        if n == 6: break
 eng.set_timing(True)
 for rep in range(3):
     eng.batch_begin()
