@@ -230,10 +230,14 @@ def config_c4(n_send: int = 1 << 18, group_size: int = 7, log_len: int = DEFAULT
 
 
 def config_c5(per_phase: int = 20000, group_size: int = 5, log_len: int = DEFAULT_LOG,
-              conns: int = 16, batch: int = 16) -> Trace:
+              conns: int = 16, batch: int = 16, rejoin: bool = False, prune_bytes: int | None = None) -> Trace:
     """reconf_bench.sh shape (benchmarks/reconf_bench.sh:249-343): bench, kill the
-    leader, bench, kill one follower, bench.  SET/GET-sized 107/40-byte requests."""
-    phases = 3
+    leader, bench, kill one follower, bench.  SET/GET-sized 107/40-byte requests.
+    rejoin: the optional tail -- a new server joins into the lowest empty slot (the dead leader's), recovers
+    the log from the group and a fourth phase runs on four servers again."""
+    phases = 4 if rejoin else 3
+    if prune_bytes is None:
+        prune_bytes = max(log_len // 8, 1024)
     n_send = per_phase * phases
     lens_send = np.where(np.arange(n_send) % 2 == 0, 107, 40).astype(np.int64)
     # connections are re-established against the new leader after the fail-over
@@ -251,10 +255,12 @@ def config_c5(per_phase: int = 20000, group_size: int = 5, log_len: int = DEFAUL
             alive.remove(leader)
             leader = alive[0]
             events.append(("ELECT", leader))
-        else:
+        elif ph == 2:
             victim = alive[-1]
             events.append(("KILL", victim))
             alive.remove(victim)
+        else:
+            events += [("JOIN", 0), ("QUIESCE",)]
         lens_p = lens_send[ph * per_phase:(ph + 1) * per_phase]
         if ph < 2:
             types = np.concatenate([np.full(conns, CONNECT), np.full(per_phase, SEND)]).astype(np.uint8)
@@ -278,7 +284,7 @@ def config_c5(per_phase: int = 20000, group_size: int = 5, log_len: int = DEFAUL
             events.append(("ROUND", g + k, b))
             since += int((lens[k:k + b] + HDR).sum())
             k += b
-            if since >= max(log_len // 8, 1024):
+            if since >= prune_bytes:
                 events.append(("PRUNE",))
                 since = 0
         g += n

@@ -287,6 +287,10 @@ typedef struct {
     uint64_t apply_slot;                        /* entries walked by apply_committed_entries */
     orc_apply_t *apply_log; uint64_t apply_cap;
     orc_det_t last_applied;                     /* dare_server.c:73 */
+    /* joining */
+    uint16_t lid;                               /* the machine's LID: clt_id of the CONFIG entry that admits it */
+    int      snapshot_on;                       /* dare_state & SNAPSHOT, dare_server.c:641 */
+    uint64_t snapshot_last;                     /* snapshot->last_entry.offset, :637 */
 } replica_t;
 
 struct orc_cluster {
@@ -298,6 +302,11 @@ struct orc_cluster {
     int committed_flag;                          /* `committed`, dare_ibv_rc.c:1461 */
     int completion_delay;                        /* see posted() */
     uint64_t force_prunes;                       /* times force_log_pruning found the log >= 75 % full */
+    /* a JOIN in progress: what the leader's reply carries (reconf_rep_t, dare_ibv_ud.c:1451-1490) */
+    int next_lid, join_slot, join_replied;
+    int hung;                                    /* a persist walk that does not terminate (orc_join, -8) */
+    uint64_t join_head, join_cid_idx;
+    orc_cid_t join_cid;
     replica_t r[ORC_MAX_SERVERS];
     uint64_t *round_commit, *round_end; uint64_t n_rounds, rounds_cap;
 };
@@ -306,6 +315,25 @@ static inline int is_leader_r(const replica_t *p)                /* IS_LEADER, d
 { return SID_L(p->sid) && SID_IDX(p->sid) == p->idx; }
 
 static inline int cid_on(const orc_cid_t *cid, int i) { return (cid->bitmask >> i) & 1; }
+
+/* configuration states, src/include/dare/dare_config.h:18-24 */
+enum { CID_STABLE = 0, CID_TRANSIT = 1, CID_EXTENDED = 2 };
+static inline int ext_group_size(const orc_cid_t *cid)          /* get_extended_group_size, dare_config.h:78-86 */
+{
+    if (cid->state == CID_STABLE) return cid->size[0];
+    return cid->size[0] < cid->size[1] ? cid->size[1] : cid->size[0];
+}
+static inline int group_size(const orc_cid_t *cid)              /* get_group_size, dare_config.h:89-97 */
+{
+    if (cid->state != CID_TRANSIT) return cid->size[0];
+    return cid->size[0] < cid->size[1] ? cid->size[1] : cid->size[0];
+}
+/* the `size` the commit scan and the lazy commit loop of update_remote_logs run with: what the (dead)
+ * offset-median loop above them leaves behind, dare_ibv_rc.c:1650-1723 -- cid.size[0] in a STABLE or
+ * EXTENDED configuration ("only the old majority"), cid.size[1] in a TRANSIT one (the loop always
+ * ends with j == 1 there), i.e. the NEW group's majority alone, not both */
+static inline int scan_size(const orc_cid_t *cid)
+{ return cid->state == CID_TRANSIT ? cid->size[1] : cid->size[0]; }
 
 uint64_t orc_apply_mix(uint64_t slot, uint64_t off, uint64_t idx, uint32_t len,
                        uint16_t clt_id, uint8_t type, uint8_t kind)
@@ -351,19 +379,22 @@ orc_cluster_t *orc_cluster_new(int group_size, uint64_t log_len)
         p->cid.epoch = 0; p->cid.size[0] = (uint8_t)group_size; p->cid.size[1] = 0;
         p->cid.state = 0; p->cid.bitmask = (1u << group_size) - 1;
         p->sid = SID_MAKE(0, 0, i);
+        p->lid = (uint16_t)(i + 1);
         for (int j = 0; j < ORC_MAX_SERVERS; j++) {
             p->vote_ack[j] = log_len;
             p->lr_step[j] = LR_GET_WRITE;
             p->send_flag[j] = 1;
         }
     }
+    c->next_lid = group_size;
+    c->join_slot = -1;
     return c;
 }
 
 void orc_cluster_free(orc_cluster_t *c)
 {
     if (!c) return;
-    for (int i = 0; i < c->n; i++) { orc_log_free(c->r[i].log); free(c->r[i].apply_log); }
+    for (int i = 0; i < ORC_MAX_SERVERS; i++) { orc_log_free(c->r[i].log); free(c->r[i].apply_log); }
     free(c->round_commit); free(c->round_end);
     free(c);
 }
@@ -377,6 +408,8 @@ int orc_group_size(const orc_cluster_t *c) { return c->n; }
 orc_log_t *orc_replica_log(orc_cluster_t *c, int r) { return c->r[r].log; }
 uint64_t orc_replica_sid(const orc_cluster_t *c, int r) { return c->r[r].sid; }
 uint32_t orc_replica_cid_bitmask(const orc_cluster_t *c, int r) { return c->r[r].cid.bitmask; }
+void orc_replica_cid(const orc_cluster_t *c, int r, orc_cid_t *out) { *out = c->r[r].cid; }
+int orc_replica_alive(const orc_cluster_t *c, int r) { return c->r[r].alive; }
 uint64_t orc_replica_highest_rec(const orc_cluster_t *c, int r) { return c->r[r].highest_rec; }
 uint64_t orc_replica_apply_count(const orc_cluster_t *c, int r) { return c->r[r].apply_count; }
 uint64_t orc_replica_apply_hash(const orc_cluster_t *c, int r) { return c->r[r].apply_hash; }
@@ -394,7 +427,11 @@ const uint64_t *orc_round_end(const orc_cluster_t *c) { return c->round_end; }
 static void persist_new_entries(orc_cluster_t *c, replica_t *p)
 {
     orc_log_t *log = p->log;
+    uint64_t guard = 0;
     while (orc_log_is_larger(log, log->end, log->old_end)) {
+        /* four laps of the smallest entries and still not at `end`: the walk of a joiner that never gets
+         * there (see orc_join, -8) -- the reference spins forever at this point */
+        if (++guard > log->len / 16 + 1024) { c->hung = 1; return; }
         orc_entry_t *e = get_entry(log, &log->old_end);
         if (!fits_entry(log, log->old_end, e)) { log->old_end = 0; continue; }
         p->store_count++;                                   /* proxy_store_cmd(&entry->clt_id) */
@@ -434,8 +471,10 @@ static void poll_config_entries(replica_t *p)
         if (e->type == ORC_CONFIG) {
             if (e->idx > p->cid_idx) update_cid(p, &e->data.cid);
         } else if (e->type == ORC_HEAD) {
-            if (!orc_log_is_larger(log, off, commit))       /* committed HEAD entries only */
+            if (!orc_log_is_larger(log, off, commit)) {     /* committed HEAD entries only */
                 head_offset = e->data.head;
+                p->snapshot_on = 0;                         /* dare_state &= ~SNAPSHOT, :2171 */
+            }
         }
         off += entry_len(e);
     }
@@ -443,9 +482,20 @@ static void poll_config_entries(replica_t *p)
     if (orc_log_is_larger(log, head_offset, log->head)) log->head = head_offset;
 }
 
+/* ud_send_clt_reply(lid, req_id, CONFIG), dare_ibv_ud.c:1451-1490: the answer to a JOIN request carries
+ * the configuration as it is NOW, the index of the CONFIG entry that admitted the server and the
+ * leader's head offset */
+static void join_reply(orc_cluster_t *c, replica_t *L)
+{
+    if (c->join_slot < 0) return;               /* nobody is waiting (a new leader re-applying the entry) */
+    c->join_head = L->log->head;
+    c->join_cid = L->cid;
+    c->join_replied = 1;
+}
+
 /* --- apply_committed_entries, dare_server.c:1815-1974 --------------- */
-/* stable configurations only: the 3-phase resize branches (:1883-1937) are
- * outside the hot-path scope */
+/* incl. the leader's CONFIG branches (:1858-1937): reply to the joiner, the 3-phase resize
+ * EXTENDED -> TRANSIT -> STABLE, each phase a new CONFIG entry appended while the previous one is applied */
 static void apply_committed_entries(orc_cluster_t *c, replica_t *p)
 {
     orc_log_t *log = p->log;
@@ -453,6 +503,30 @@ static void apply_committed_entries(orc_cluster_t *c, replica_t *p)
     while (orc_log_is_larger(log, log->commit, log->apply)) {
         orc_entry_t *e = get_entry(log, &log->apply);
         if (!fits_entry(log, log->apply, e)) { log->apply = 0; continue; }
+        if (leader && e->type == ORC_CONFIG) {
+            uint64_t req_id = e->req_id;
+            uint16_t clt_id = e->clt_id;
+            if (e->data.cid.state == CID_STABLE) {                        /* :1859-1874 */
+                if (req_id != 0) join_reply(c, p);
+            } else if (p->cid.epoch > e->data.cid.epoch) {                 /* :1875-1879 */
+                /* from a previous configuration: ignored */
+            } else {
+                if (e->data.cid.state == CID_EXTENDED) {                   /* :1886-1900 */
+                    p->cid.state = CID_TRANSIT;
+                    if (req_id != 0) { join_reply(c, p); req_id = 0; clt_id = 0; }
+                } else if (e->data.cid.state == CID_TRANSIT) {             /* :1901-1927 */
+                    p->cid.state = CID_STABLE;
+                    for (int i = p->cid.size[1]; i < p->cid.size[0]; i++)  /* servers a down-size removes */
+                        p->cid.bitmask &= ~(1u << i);
+                    p->cid.size[0] = p->cid.size[1];
+                    p->cid.size[1] = 0;
+                }
+                orc_log_append(log, SID_TERM(p->sid), req_id, clt_id, ORC_CONFIG, &p->cid, 0);   /* :1932 */
+            }
+            log->apply += entry_len(e);
+            p->apply_slot++;
+            continue;
+        }
         int client = (e->type != ORC_CONFIG && e->type != ORC_NOOP && e->type != ORC_HEAD);
         if (client) {
             if (leader) { p->highest_rec++; record_apply(c, p, log->apply, e, 1); }
@@ -567,7 +641,7 @@ static void ring_write(orc_log_t *dst, const orc_log_t *src, uint64_t from, uint
 static void update_remote_logs(orc_cluster_t *c, replica_t *L)
 {
     orc_log_t *log = L->log;
-    int size = L->cid.size[0];      /* stable cid: get_extended_group_size == size[0] */
+    int size = ext_group_size(&L->cid);                        /* :1489 */
 
     for (int i = 0; i < size; i++) {
         if (!peer_reachable(c, L, i) || !L->send_flag[i]) continue;
@@ -596,7 +670,8 @@ static void update_remote_logs(orc_cluster_t *c, replica_t *L)
     }
 
     /* commit scan over the ACK bytes, :1725-1758 (the offset-median code above
-     * it is dead: its result is overwritten at :1725) */
+     * it is dead: its result is overwritten at :1725 -- but it leaves `size` behind) */
+    size = scan_size(&L->cid);
     uint64_t min_offset = log->commit;
     while (orc_log_end_distance(log, min_offset)) {
         orc_entry_t *e = get_entry(log, &min_offset);
@@ -649,7 +724,7 @@ static void commit_new_entries(orc_cluster_t *c, replica_t *L)
     if (orc_log_end_distance(log, log->commit)) {
         write_remote_logs(c, L, 1);
     } else if (!log_empty(log)) {
-        for (int i = 0; i < L->cid.size[0]; i++) {
+        for (int i = 0; i < group_size(&L->cid); i++) {          /* :1766 */
             if (!peer_reachable(c, L, i)) continue;
             if (L->vote_ack[i] == log->len) continue;
             if (L->lr_step[i] != LR_UPDATE_LOG || L->rem_end[i] != log->end) {
@@ -732,7 +807,7 @@ int orc_quiesce(orc_cluster_t *c)
 static int log_pruning(orc_cluster_t *c, replica_t *L)
 {
     orc_log_t *log = L->log;
-    int size = L->cid.size[0];
+    int size = ext_group_size(&L->cid);                        /* :2026 */
     uint64_t min_offset = log->apply;
     for (int i = 0; i < size; i++) {
         if (!cid_on(&L->cid, i)) L->apply_offsets[i] = log->apply;
@@ -767,7 +842,7 @@ static void force_log_pruning(orc_cluster_t *c, replica_t *L)
     uint64_t log_size = orc_log_end_distance(log, log->head);
     if ((double)log_size < 0.75 * (double)log->len) return;
     c->force_prunes++;
-    int size = L->cid.size[0], target = L->idx, i;
+    int size = ext_group_size(&L->cid), target = L->idx, i;    /* :2082 */
     uint64_t min_offset = log->apply;
     for (i = 0; i < size; i++)
         if (orc_log_is_larger(log, min_offset, L->apply_offsets[i])) { min_offset = L->apply_offsets[i]; target = i; }
@@ -816,6 +891,144 @@ int orc_kill(orc_cluster_t *c, int r)
 
 int orc_hold(orc_cluster_t *c, int r)    { if (r < 0 || r >= c->n) return -1; c->r[r].held = 1; return 0; }
 int orc_release(orc_cluster_t *c, int r) { if (r < 0 || r >= c->n) return -1; c->r[r].held = 0; return 0; }
+
+/* --- JOIN(r): a new server joins -----------------------------------------------
+ * Leader: handle_server_join_request dare_ibv_ud.c:973-1068; joiner: handle_server_join_reply :1071-1088,
+ * get_replicated_vote_cb dare_server.c:524, poll_sm_requests :599 (on the followers) / poll_sm_reply :658 /
+ * rc_recover_sm dare_ibv_rc.c:597, rc_recover_log :726-866, recover_log_cb dare_server.c:710 ->
+ * server_to_follower :2238 (vote ACK), then the leader's log_adjustment.  Schedule = the one
+ * oracle/refshim/refcluster.c:refc_join drives the reference through: the joiner's timer fires once per
+ * sweep, every sweep is four polling passes of everybody (leader, the others, the joiner).
+ * The joiner is a NEW machine: a fresh log, fresh upcall counters, LID = number of machines so far.
+ * Returns 0; -1 no leader / resize in progress (Case 1: the request is ignored, the joiner retries);
+ * -4 the leader would hand out another slot than r; -5 a follower is asked for its state machine a second
+ * time before a <HEAD> entry was committed (the reference answers from an uninitialised pointer there,
+ * dare_server.c:604-651: `snapshot` is only set when SNAPSHOT is clear); -6 no follower to recover from;
+ * -7 the CONFIG entry does not commit (no quorum); -8 the joiner's first persist_new_entries pass never
+ * ends: old_end starts at len (log_new, dare_log.h:134; nothing in the recovery path sets it), so the
+ * pass walks from offset 0 through the zeroed part of the joiner's ring in 64-byte "NOOP" steps and on
+ * through the recovered entries, and only stops when it lands EXACTLY on `end` -- it does when head == 0
+ * or when head and every entry length are multiples of 64, otherwise it runs into the entries
+ * misaligned and cycles (found by running the reference; the joiner hangs in polling()).  Every entry
+ * the pass meets is "stored" and ACKed into the log of the server its `sender` byte names. */
+static void replica_fresh(orc_cluster_t *c, int r, uint16_t lid)
+{
+    replica_t *p = &c->r[r];
+    orc_log_free(p->log); free(p->apply_log);
+    memset(p, 0, sizeof *p);
+    p->log = orc_log_new(c->log_len);
+    p->idx = (uint8_t)r;
+    p->lid = lid;
+    for (int j = 0; j < ORC_MAX_SERVERS; j++) {
+        p->vote_ack[j] = c->log_len;
+        p->lr_step[j] = LR_GET_WRITE;
+        p->send_flag[j] = 1;
+    }
+}
+
+static void join_pass(orc_cluster_t *c, replica_t *L, int times)
+{
+    for (int t = 0; t < times; t++) {
+        leader_poll(c, L);
+        for (int i = 0; i < c->n; i++)
+            if (i != c->leader && c->r[i].log && !c->r[i].held) follower_poll(c, &c->r[i]);
+    }
+}
+
+int orc_join(orc_cluster_t *c, int r)
+{
+    if (c->leader < 0) return -1;
+    replica_t *L = &c->r[c->leader];
+    orc_log_t *log = L->log;
+    if (L->cid.state != CID_STABLE) return -1;                  /* Case 1, :978-982 */
+    int size = L->cid.size[0], empty = size;
+    for (int i = size - 1; i >= 0; i--) if (!cid_on(&L->cid, i)) empty = i;     /* :995-1021 */
+    if (empty != r || r >= ORC_MAX_SERVERS) return -4;
+    int donors = 0;
+    for (int i = 0; i < size; i++) {
+        if (i == c->leader || i == r || !cid_on(&L->cid, i)) continue;
+        /* a configured server that cannot be reached: the joiner needs RC connections to and the
+         * replicated vote from a majority (rc_get_replicated_vote dare_ibv_rc.c:874) and retries until it has
+         * them -- this oracle's JOIN is one event, so it covers joins into a fully reachable group */
+        if (!c->r[i].alive || c->r[i].held) return -6;
+        if (c->r[i].snapshot_on) return -5;
+        donors++;
+    }
+    if (!donors) return -6;
+
+    /* Case 3 (an empty place) or Case 4 (the group is full: extend it), :1022-1041 */
+    uint16_t lid = (uint16_t)++c->next_lid;
+    uint64_t end0 = log->end;
+    L->cid.bitmask |= 1u << empty;
+    if (empty == size) {
+        L->cid.state = CID_EXTENDED;
+        L->cid.size[1] = (uint8_t)(size + 1);
+        L->cid.epoch++;
+    }
+    L->lr_step[empty] = LR_GET_WRITE; L->send_flag[empty] = 1; L->pending[empty] = PEND_NONE;   /* :1043-1051 */
+    L->vote_ack[empty] = log->len;
+    L->apply_offsets[empty] = log->head;
+    replica_fresh(c, r, lid);                                   /* not connected yet: alive == 0 */
+    if (r >= c->n) c->n = r + 1;
+    c->join_slot = r; c->join_replied = 0;
+    /* the request id of a machine's first request is 1 (IBDEV->request_id, dare_ibv.c:130) */
+    c->join_cid_idx = orc_log_append(log, SID_TERM(L->sid), 1, lid, ORC_CONFIG, &L->cid, 0);   /* :1057-1060 */
+    if (c->join_cid_idx == 0) { c->join_slot = -1; return -2; }
+    join_pass(c, L, 4);                                         /* sweep 0: commit, apply, reply, resize phases */
+    if (!c->join_replied) { c->join_slot = -1; return -7; }
+
+    replica_t *J = &c->r[r];
+    J->cid = c->join_cid;                                       /* handle_server_join_reply */
+    J->log->head = c->join_head;
+    J->cid_idx = c->join_cid_idx;
+    J->cid_offset = J->log->head;
+    join_pass(c, L, 4);                                         /* sweep 1: RC_SYN / SYNACK */
+    J->sid = SID_MAKE(0, 1, r);                                 /* sweep 2: get_replicated_vote_cb :529-531 */
+    join_pass(c, L, 4);
+    /* sweep 3: the SM request reaches every connected server; the followers (the leader does not poll for
+     * it, dare_server.c:1089-1091) dump their state machine and answer; the joiner takes the first answer
+     * in index order */
+    leader_poll(c, L);
+    int target = -1;
+    for (int i = 0; i < group_size(&J->cid); i++) {
+        replica_t *F = &c->r[i];
+        if (i == r || i == c->leader || !cid_on(&J->cid, i) || !F->alive || F->held) continue;
+        follower_poll(c, F);
+        F->snapshot_last = F->last_applied.offset;              /* :637 */
+        F->snapshot_on = 1;
+        if (target < 0) target = i;
+    }
+    if (target < 0) { c->join_slot = -1; return -6; }
+    J->sid = c->r[target].sid;                                  /* poll_sm_reply :671 */
+    J->log->apply = c->r[target].snapshot_last;                 /* rc_recover_sm dare_ibv_rc.c:691 */
+    join_pass(c, L, 3);
+    /* sweep 4: rc_recover_log -- commit and end of the first connected server in index order, then the
+     * bytes between the head the leader named and that end (up to the ring's end if they wrap) */
+    {
+        int t = -1;
+        for (int i = 0; i < group_size(&J->cid) && t < 0; i++)
+            if (i != r && cid_on(&J->cid, i) && c->r[i].alive && !c->r[i].held) t = i;
+        orc_log_t *T = c->r[t].log, *jl = J->log;
+        uint64_t rend = T->end, rcommit = T->commit;
+        if (rend != T->len) {
+            jl->end = rend;
+            if (rend > 0 && rend < jl->head) rend = 0;
+            if (orc_log_is_larger(jl, rcommit, rend)) rcommit = rend;
+            jl->end = rend;
+            jl->commit = rcommit;
+            uint64_t n = orc_log_end_distance(jl, jl->head);
+            memcpy(jl->entries + jl->head, T->entries + jl->head, n);
+        }
+    }
+    J->alive = 1;                                               /* LOG_RECOVERED, RC connected */
+    orc_log_to_ncbuf(J->log, &J->log->nc_buf[J->idx]);          /* server_to_follower :2260-2262 */
+    L->vote_ack[r] = J->log->commit;                            /* rc_send_vote_ack */
+    join_pass(c, L, 4);
+    c->join_slot = -1;
+    if (c->hung) return -8;
+    if (log->end != end0) note_round(c, L);
+    return 0;
+}
 
 /* --- election: start_election dare_server.c:1264-1322, poll_vote_requests
  *     :1526-1743, poll_vote_count :1327-1518, vote request / ack

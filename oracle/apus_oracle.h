@@ -129,12 +129,17 @@ int      orc_kill(orc_cluster_t *c, int r);
 int      orc_hold(orc_cluster_t *c, int r);
 int      orc_release(orc_cluster_t *c, int r);
 int      orc_quiesce(orc_cluster_t *c);                       /* poll until fixpoint */
+/* JOIN(r): a new server joins and must be given slot r -- an empty one, or group_size (the group is
+ * extended: EXTENDED -> TRANSIT -> STABLE).  Return codes: see apus_oracle.c */
+int      orc_join(orc_cluster_t *c, int r);
 
 int        orc_leader(const orc_cluster_t *c);
 int        orc_group_size(const orc_cluster_t *c);
 orc_log_t *orc_replica_log(orc_cluster_t *c, int r);
 uint64_t   orc_replica_sid(const orc_cluster_t *c, int r);
 uint32_t   orc_replica_cid_bitmask(const orc_cluster_t *c, int r);   /* SID.cid.bitmask: the configured servers */
+void       orc_replica_cid(const orc_cluster_t *c, int r, orc_cid_t *out);
+int        orc_replica_alive(const orc_cluster_t *c, int r);
 uint64_t   orc_replica_highest_rec(const orc_cluster_t *c, int r);
 uint64_t   orc_replica_apply_count(const orc_cluster_t *c, int r);
 uint64_t   orc_replica_apply_hash(const orc_cluster_t *c, int r);

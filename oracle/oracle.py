@@ -78,6 +78,9 @@ def lib() -> C.CDLL:
             "orc_hold": (C.c_int, [vp, C.c_int]),
             "orc_release": (C.c_int, [vp, C.c_int]),
             "orc_quiesce": (C.c_int, [vp]),
+            "orc_join": (C.c_int, [vp, C.c_int]),
+            "orc_replica_cid": (None, [vp, C.c_int, vp]),
+            "orc_replica_alive": (C.c_int, [vp, C.c_int]),
             "orc_leader": (C.c_int, [vp]),
             "orc_group_size": (C.c_int, [vp]),
             "orc_replica_log": (vp, [vp, C.c_int]),
@@ -316,6 +319,20 @@ class Cluster:
     def release(self, r): return self._chk(self.L.orc_release(self.h, r), "release")
     def quiesce(self): return self._chk(self.L.orc_quiesce(self.h), "quiesce")
 
+    def join(self, r):
+        rc = self._chk(self.L.orc_join(self.h, r), "join")
+        self.n = int(self.L.orc_group_size(self.h))
+        return rc
+
+    def alive(self, r): return bool(self.L.orc_replica_alive(self.h, r))
+
+    def cid(self, r) -> dict:
+        buf = (C.c_uint8 * 16)()
+        self.L.orc_replica_cid(self.h, r, buf)
+        b = bytes(buf)
+        return {"epoch": int.from_bytes(b[0:8], "little"), "size0": b[8], "size1": b[9], "state": b[10],
+                "bitmask": int.from_bytes(b[12:16], "little")}
+
     def round(self, reqs: np.ndarray, arena: np.ndarray):
         reqs = np.ascontiguousarray(reqs, dtype=REQ_DTYPE)
         return self._chk(self.L.orc_round(self.h, reqs.ctypes.data, len(reqs),
@@ -411,6 +428,8 @@ def run_trace(trace, record_apply: bool = True, allow_exact_fit: bool = True,
             c.hold(ev[1])
         elif op == "RELEASE":
             c.release(ev[1])
+        elif op == "JOIN":
+            c.join(ev[1])
         else:
             raise ValueError(f"unknown trace event {ev}")
         if on_event is not None:

@@ -82,6 +82,8 @@ def lib() -> C.CDLL:
             "refc_hold": (C.c_int, [vp, C.c_int]),
             "refc_release": (C.c_int, [vp, C.c_int]),
             "refc_quiesce": (C.c_int, [vp]),
+            "refc_join": (C.c_int, [vp, C.c_int]),
+            "refc_state": (u64, [vp, C.c_int]),
             "refc_poll": (C.c_int, [vp, C.c_int]),
             "refc_fire": (C.c_int, [vp, C.c_int, C.c_int]),
             "refc_leader": (C.c_int, [vp]),
@@ -177,6 +179,11 @@ class RefCluster:
     def hold(self, r): return self._chk(self.L.refc_hold(self.h, r), "hold")
     def release(self, r): return self._chk(self.L.refc_release(self.h, r), "release")
     def quiesce(self): return self._chk(self.L.refc_quiesce(self.h), "quiesce")
+
+    def join(self, r):
+        rc = self._chk(self.L.refc_join(self.h, r), "join")
+        self.n = int(self.L.refc_group_size(self.h))
+        return rc
     def poll(self, r): return self.L.refc_poll(self.h, r)
     def fire(self, r, which): return self.L.refc_fire(self.h, r, which)
 
@@ -248,6 +255,8 @@ def run_trace(trace, record_apply: bool = True, on_event=None) -> RefCluster:
                 c.hold(ev[1])
             elif op == "RELEASE":
                 c.release(ev[1])
+            elif op == "JOIN":
+                c.join(ev[1])
             else:
                 raise ValueError(f"unknown trace event {ev}")
             if on_event is not None:

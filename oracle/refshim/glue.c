@@ -251,6 +251,7 @@ void glue_submit(uint8_t type, uint16_t conn, uint64_t req_id, const void *buf, 
 void    *glue_log(void) { return data.log; }
 uint8_t *glue_entries(void) { return data.log->entries; }
 void    *glue_ctrl(void) { return data.ctrl_data; }
+int      glue_idx(void) { return data.config.idx; }
 uint64_t glue_sid(void) { return data.ctrl_data ? data.ctrl_data->sid : 0; }
 uint64_t glue_state(void) { return dare_state; }
 int      glue_exited(void) { return exited; }

@@ -30,16 +30,31 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <signal.h>
+#include <execinfo.h>
 #include "fabric.h"
 #include "refcluster.h"
 
+/* APUS_REF_DEBUG=1: print a backtrace when the reference crashes (it has undefined behaviour of its
+ * own on some schedules, e.g. poll_sm_requests dare_server.c:599-655 with SNAPSHOT already set) */
+static void crash_bt(int sig)
+{
+    void *bt[48]; int n = backtrace(bt, 48);
+    static const char msg[] = "refcluster: the reference crashed; backtrace:\n";
+    if (write(2, msg, sizeof msg - 1) < 0) {}
+    backtrace_symbols_fd(bt, n, 2);
+    signal(sig, SIG_DFL); raise(sig);
+}
+
 #define MAXN 13
+#define MAXI 16                    /* fabric ports: every server that ever ran, joiners included */
 enum { T_INIT = 0, T_PRUNE = 1, T_HB = 2, T_ADJ = 3 };
 #define ST_LOG_RECOVERED 0x20
 
 typedef struct {
     void *dl; int fd;
     int alive, busy;
+    int slot;                      /* index in the configuration (data.config.idx); -1: a joiner that has no answer yet */
     int      (*start)(int, int, int, const char *, const char *, uint64_t);
     int      (*fire)(int);
     int      (*timer_armed)(int);
@@ -60,12 +75,20 @@ typedef struct {
     void     (*cid)(uint64_t *);
     void     (*peer)(int, uint64_t *);
     int      (*all_connected)(void);
+    int      (*idx)(void);
 } inst_t;
 
+/* A server instance owns fabric port k (LID k+1) for its whole life; the trace names servers by their
+ * SLOT in the configuration.  At start-up slot == instance; a joiner is a new instance (a new machine)
+ * that takes over an empty slot or the one the group is extended by. */
 struct refc {
-    int n;
+    int n;                         /* slots in use (the extended group size) */
+    int n_inst;
     uint64_t log_len;
-    inst_t in[MAXN];
+    inst_t in[MAXI];
+    int slot_inst[MAXN];           /* slot -> instance that holds it now (-1: nobody ever did) */
+    void *img; size_t img_len;     /* the library image joiners are loaded from */
+    char cfg_path[256], log_dir[256];
     int leader;
     uint64_t n_rounds, rounds_cap, *round_commit, *round_end;
     char err[256];
@@ -73,34 +96,45 @@ struct refc {
 
 static uint64_t *offs(inst_t *t) { return (uint64_t *)t->log(); }   /* head apply commit end tail old_end old_commit len */
 
-static int call_poll(refc_t *c, int i)
+/* the instance that holds slot r (NULL: none) */
+static inst_t *S(refc_t *c, int r)
 {
-    inst_t *t = &c->in[i];
+    if (r < 0 || r >= c->n || c->slot_inst[r] < 0) return NULL;
+    return &c->in[c->slot_inst[r]];
+}
+static int port_of(refc_t *c, int r) { return (r < 0 || r >= c->n) ? -1 : c->slot_inst[r]; }
+
+static int call_poll(refc_t *c, int k)
+{
+    inst_t *t = &c->in[k];
     if (!t->alive || t->busy || t->exited()) return 0;
     t->busy = 1;
-    int prev = fab_enter(i);
+    int prev = fab_enter(k);
     int r = t->poll();
     fab_leave(prev);
     t->busy = 0;
     return r;
 }
-static int call_fire(refc_t *c, int i, int which)
+static int call_fire(refc_t *c, int k, int which)
 {
-    inst_t *t = &c->in[i];
+    inst_t *t = &c->in[k];
     if (!t->alive || t->busy || t->exited()) return 0;
     t->busy = 1;
-    int prev = fab_enter(i);
+    int prev = fab_enter(k);
     int r = t->fire(which);
     fab_leave(prev);
     t->busy = 0;
     return r;
 }
+static int poll_slot(refc_t *c, int r) { int k = port_of(c, r); return k < 0 ? 0 : call_poll(c, k); }
+static int fire_slot(refc_t *c, int r, int which) { int k = port_of(c, r); return k < 0 ? 0 : call_fire(c, k, which); }
+static int slot_up(refc_t *c, int r) { inst_t *t = S(c, r); return t && t->alive && !fab_port_held(port_of(c, r)); }
 
 static void on_write(void *arg, int from, int to, uint64_t raddr, uint32_t len)
 {
     (void)from;
     refc_t *c = arg;
-    if (to < 0 || to >= c->n || len != 8) return;
+    if (to < 0 || to >= c->n_inst || len != 8) return;
     inst_t *t = &c->in[to];
     if (!t->alive || t->busy) return;
     uint64_t base = (uint64_t)(uintptr_t)t->log();
@@ -121,37 +155,48 @@ static int load_instance(refc_t *c, int i, const void *img, size_t img_len)
 #define SYM(f) do { *(void **)&t->f = dlsym(t->dl, "glue_" #f); if (!t->f) { snprintf(c->err, sizeof c->err, "missing glue_%s", #f); return -1; } } while (0)
     SYM(start); SYM(fire); SYM(timer_armed); SYM(poll); SYM(submit); SYM(log); SYM(entries); SYM(sid); SYM(state);
     SYM(exited); SYM(is_leader); SYM(prev_head); SYM(highest_rec); SYM(store_count); SYM(apply_count);
-    SYM(record_apply); SYM(apply_log); SYM(cid); SYM(peer); SYM(all_connected);
+    SYM(record_apply); SYM(apply_log); SYM(cid); SYM(peer); SYM(all_connected); SYM(idx);
 #undef SYM
     return 0;
 }
 
 const char *refc_error(const refc_t *c) { return c->err; }
 
+static int start_instance(refc_t *c, int k, int group_size, int join)
+{
+    char lp[300] = "";
+    if (c->log_dir[0]) snprintf(lp, sizeof lp, "%s/ref_srv%d.log", c->log_dir, k);
+    int prev = fab_enter(k);
+    int rc = c->in[k].start(k, group_size, join, c->cfg_path, lp, c->log_len);
+    fab_leave(prev);
+    if (rc) return rc;
+    c->in[k].alive = 1;
+    return 0;
+}
+
 refc_t *refc_new(int n, uint64_t log_len, const char *lib_path, const char *cfg_path, const char *log_dir)
 {
     if (n < 1 || n > MAXN) return NULL;
     refc_t *c = calloc(1, sizeof *c);
-    c->n = n; c->log_len = log_len; c->leader = -1;
+    c->n = n; c->n_inst = n; c->log_len = log_len; c->leader = -1;
+    for (int i = 0; i < MAXN; i++) c->slot_inst[i] = -1;
+    snprintf(c->cfg_path, sizeof c->cfg_path, "%s", cfg_path ? cfg_path : "");
+    snprintf(c->log_dir, sizeof c->log_dir, "%s", log_dir ? log_dir : "");
     FILE *f = fopen(lib_path, "rb");
     if (!f) { free(c); return NULL; }
     fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
     void *img = malloc((size_t)sz);
     if (fread(img, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(img); free(c); return NULL; }
     fclose(f);
+    c->img = img; c->img_len = (size_t)sz;
     fab_reset();
     fab_set_write_hook(on_write, c);
+    if (getenv("APUS_REF_DEBUG")) signal(SIGSEGV, crash_bt);
     for (int i = 0; i < n; i++) {
-        if (load_instance(c, i, img, (size_t)sz)) { fprintf(stderr, "refc_new: %s\n", c->err); free(img); return NULL; }
-        char lp[256] = "";
-        if (log_dir && log_dir[0]) snprintf(lp, sizeof lp, "%s/ref_srv%d.log", log_dir, i);
-        int prev = fab_enter(i);
-        int rc = c->in[i].start(i, n, 0, cfg_path, lp, log_len);
-        fab_leave(prev);
-        if (rc) { fprintf(stderr, "refc_new: dare_server_init failed on %d\n", i); free(img); return NULL; }
-        c->in[i].alive = 1;
+        if (load_instance(c, i, img, (size_t)sz)) { fprintf(stderr, "refc_new: %s\n", c->err); return NULL; }
+        if (start_instance(c, i, n, 0)) { fprintf(stderr, "refc_new: dare_server_init failed on %d\n", i); return NULL; }
+        c->in[i].slot = i; c->slot_inst[i] = i;
     }
-    free(img);
     for (int i = 0; i < n; i++) call_fire(c, i, T_INIT);            /* init_network_cb :372 */
     if (n == 1) {
         /* "I'm the only one; I am the leader" (:416-424); LOG_RECOVERED is never set on this
@@ -180,7 +225,7 @@ void refc_free(refc_t *c)
 {
     if (!c) return;
     fab_set_write_hook(NULL, NULL);
-    for (int i = 0; i < c->n; i++) {
+    for (int i = 0; i < c->n_inst; i++) {
         /* the instances are dropped without dare_server_shutdown (it would pthread_exit);
          * their 64 MiB logs are released here */
         if (c->in[i].dl) {
@@ -191,6 +236,7 @@ void refc_free(refc_t *c)
         if (c->in[i].fd > 0) close(c->in[i].fd);
     }
     fab_reset();
+    free(c->img);
     free(c->round_commit); free(c->round_end); free(c);
 }
 
@@ -202,7 +248,7 @@ static void note_round(refc_t *c)
         c->round_commit = realloc(c->round_commit, c->rounds_cap * sizeof(uint64_t));
         c->round_end = realloc(c->round_end, c->rounds_cap * sizeof(uint64_t));
     }
-    uint64_t *o = offs(&c->in[c->leader]);
+    uint64_t *o = offs(S(c, c->leader));
     c->round_commit[c->n_rounds] = o[2];
     c->round_end[c->n_rounds] = o[3];
     c->n_rounds++;
@@ -211,10 +257,10 @@ static void note_round(refc_t *c)
 #define SID_TERM(s) ((s) >> 9)
 #define SID_L(s)    (((s) >> 8) & 1)
 #define SID_IDX(s)  ((int)((s) & 0xFF))
-static int is_candidate(refc_t *c, int i)
+static int is_candidate(refc_t *c, int r)
 {
-    uint64_t s = c->in[i].sid();
-    return SID_IDX(s) == i && !SID_L(s) && SID_TERM(s) > 0;
+    uint64_t s = S(c, r)->sid();
+    return SID_IDX(s) == r && !SID_L(s) && SID_TERM(s) > 0;
 }
 
 int refc_leader(const refc_t *c) { return c->leader; }
@@ -222,46 +268,46 @@ int refc_group_size(const refc_t *c) { return c->n; }
 
 int refc_elect(refc_t *c, int w)
 {
-    if (w < 0 || w >= c->n || !c->in[w].alive) return -1;
+    if (w < 0 || w >= c->n || !S(c, w) || !S(c, w)->alive) return -1;
     if (c->leader >= 0 && c->leader != w) return -1;
     if (c->n == 1) return 0;
     /* step 1: every live server that still follows somebody misses the heartbeat */
     for (int i = 0; i < c->n; i++) {
-        if (!c->in[i].alive || fab_port_held(i)) continue;
-        for (int k = 0; k < 4 && !is_candidate(c, i); k++) call_fire(c, i, T_HB);
+        if (!slot_up(c, i)) continue;
+        for (int k = 0; k < 4 && !is_candidate(c, i); k++) fire_slot(c, i, T_HB);
         if (!is_candidate(c, i)) { snprintf(c->err, sizeof c->err, "server %d did not become a candidate", i); return -1; }
     }
     /* step 2: w's election timeout fires first */
-    uint64_t t0 = SID_TERM(c->in[w].sid());
-    for (int k = 0; k < 4 && SID_TERM(c->in[w].sid()) == t0; k++) call_fire(c, w, T_HB);
-    if (SID_TERM(c->in[w].sid()) != t0 + 1) { snprintf(c->err, sizeof c->err, "winner did not start an election"); return -1; }
+    uint64_t t0 = SID_TERM(S(c, w)->sid());
+    for (int k = 0; k < 4 && SID_TERM(S(c, w)->sid()) == t0; k++) fire_slot(c, w, T_HB);
+    if (SID_TERM(S(c, w)->sid()) != t0 + 1) { snprintf(c->err, sizeof c->err, "winner did not start an election"); return -1; }
     /* votes (poll_vote_requests :1526), then the count (poll_vote_count :1327) */
-    for (int i = 0; i < c->n; i++) if (i != w) call_poll(c, i);
-    call_poll(c, w);
-    if (!c->in[w].is_leader()) { snprintf(c->err, sizeof c->err, "server %d did not win", w); return -1; }
+    for (int i = 0; i < c->n; i++) if (i != w) poll_slot(c, i);
+    poll_slot(c, w);
+    if (!S(c, w)->is_leader()) { snprintf(c->err, sizeof c->err, "server %d did not win", w); return -1; }
     c->leader = w;
     /* the new leader's next pass commits the blank CONFIG entry (:1419) ... */
-    call_poll(c, w);
+    poll_slot(c, w);
     note_round(c);
     /* ... then its heartbeat timer fires (hb_send_cb :927).  For a peer that died this is the
      * second failed CTRL write after the vote request: PERMANENT_FAILURE, check_failure_count
      * removes it with a CONFIG entry in the following pass (:1189-1227). */
-    call_fire(c, w, T_HB);
-    for (int i = 0; i < c->n; i++) if (i != w) call_poll(c, i);          /* adopt the leader's SID (:1546) */
-    for (int i = 0; i < c->n; i++) if (i != w && c->in[i].alive && !fab_port_held(i)) call_fire(c, i, T_HB);   /* hb_receive_cb */
-    uint64_t end0 = offs(&c->in[w])[3];
-    call_poll(c, w);
-    if (offs(&c->in[w])[3] != end0) note_round(c);
+    fire_slot(c, w, T_HB);
+    for (int i = 0; i < c->n; i++) if (i != w) poll_slot(c, i);          /* adopt the leader's SID (:1546) */
+    for (int i = 0; i < c->n; i++) if (i != w && slot_up(c, i)) fire_slot(c, i, T_HB);   /* hb_receive_cb */
+    uint64_t end0 = offs(S(c, w))[3];
+    poll_slot(c, w);
+    if (offs(S(c, w))[3] != end0) note_round(c);
     return 0;
 }
 
 int refc_round(refc_t *c, const refc_req_t *reqs, int n, const uint8_t *arena)
 {
     if (c->leader < 0) return -1;
-    inst_t *L = &c->in[c->leader];
+    inst_t *L = S(c, c->leader);
     for (int k = 0; k < n; k++)
         L->submit(reqs[k].type, reqs[k].clt_id, reqs[k].req_id, arena ? arena + reqs[k].payload_off : NULL, reqs[k].len);
-    call_poll(c, c->leader);
+    poll_slot(c, c->leader);
     note_round(c);
     return 0;
 }
@@ -272,17 +318,19 @@ int refc_quiesce(refc_t *c)
     for (int it = 0; it < 64; it++) {
         uint64_t before[MAXN][4], pb[MAXN][2];
         for (int i = 0; i < c->n; i++) {
-            uint64_t *o = offs(&c->in[i]);
+            if (!S(c, i)) continue;
+            uint64_t *o = offs(S(c, i));
             before[i][0] = o[3]; before[i][1] = o[2]; before[i][2] = o[1]; before[i][3] = o[5];
-            uint64_t p[6]; c->in[c->leader].peer(i, p); pb[i][0] = p[0]; pb[i][1] = p[1];
+            uint64_t p[6]; S(c, c->leader)->peer(i, p); pb[i][0] = p[0]; pb[i][1] = p[1];
         }
-        call_poll(c, c->leader);
-        for (int i = 0; i < c->n; i++) if (i != c->leader && !fab_port_held(i)) call_poll(c, i);
+        poll_slot(c, c->leader);
+        for (int i = 0; i < c->n; i++) if (i != c->leader && S(c, i) && !fab_port_held(port_of(c, i))) poll_slot(c, i);
         int moved = 0;
         for (int i = 0; i < c->n; i++) {
-            uint64_t *o = offs(&c->in[i]);
+            if (!S(c, i)) continue;
+            uint64_t *o = offs(S(c, i));
             moved |= before[i][0] != o[3] || before[i][1] != o[2] || before[i][2] != o[1] || before[i][3] != o[5];
-            uint64_t p[6]; c->in[c->leader].peer(i, p);
+            uint64_t p[6]; S(c, c->leader)->peer(i, p);
             moved |= pb[i][0] != p[0] || pb[i][1] != p[1];
         }
         if (!moved) return 0;
@@ -294,48 +342,92 @@ int refc_tick_prune(refc_t *c)
 {
     if (c->leader < 0) return -1;
     refc_quiesce(c);                                 /* trace semantics: see orc_tick_prune */
-    uint64_t end0 = offs(&c->in[c->leader])[3];
-    if (!call_fire(c, c->leader, T_PRUNE)) return -1;       /* prune_log_cb :1977 */
-    int appended = offs(&c->in[c->leader])[3] != end0;
-    if (appended) { call_poll(c, c->leader); note_round(c); }
+    uint64_t end0 = offs(S(c, c->leader))[3];
+    if (!fire_slot(c, c->leader, T_PRUNE)) return -1;       /* prune_log_cb :1977 */
+    int appended = offs(S(c, c->leader))[3] != end0;
+    if (appended) { poll_slot(c, c->leader); note_round(c); }
     return appended;
 }
 
 int refc_kill(refc_t *c, int r)
 {
-    if (r < 0 || r >= c->n) return -1;
-    c->in[r].alive = 0;
-    fab_kill_port(r);
+    if (!S(c, r)) return -1;
+    S(c, r)->alive = 0;
+    fab_kill_port(port_of(c, r));
     if (c->leader == r) { c->leader = -1; return 0; }
     if (c->leader >= 0) {
-        uint64_t end0 = offs(&c->in[c->leader])[3];
-        call_fire(c, c->leader, T_HB);
-        call_fire(c, c->leader, T_HB);
-        call_poll(c, c->leader);
-        if (offs(&c->in[c->leader])[3] != end0) note_round(c);
+        uint64_t end0 = offs(S(c, c->leader))[3];
+        fire_slot(c, c->leader, T_HB);
+        fire_slot(c, c->leader, T_HB);
+        poll_slot(c, c->leader);
+        if (offs(S(c, c->leader))[3] != end0) note_round(c);
     }
     return 0;
 }
 
-int refc_hold(refc_t *c, int r) { if (r < 0 || r >= c->n) return -1; fab_hold_port(r); return 0; }
-int refc_release(refc_t *c, int r) { if (r < 0 || r >= c->n) return -1; fab_release_port(r); return 0; }
+int refc_hold(refc_t *c, int r) { if (!S(c, r)) return -1; fab_hold_port(port_of(c, r)); return 0; }
+int refc_release(refc_t *c, int r) { if (!S(c, r)) return -1; fab_release_port(port_of(c, r)); return 0; }
+
+/* JOIN(r): a new server (a new machine: its own port and LID) starts with SRV_TYPE_JOIN and walks
+ * through the reference's own recovery: JOIN request over UD multicast (join_cluster_cb
+ * dare_server.c:445 -> handle_server_join_request dare_ibv_ud.c:973: the leader turns the server's
+ * bit on -- or extends the group when no slot is empty -- and logs a CONFIG entry), the reply once
+ * that entry is applied (:1863 / :1895), RC_SYN / SYNACK, the replicated vote, the snapshot of a
+ * follower (poll_sm_requests :599, rc_recover_sm dare_ibv_rc.c:597), the log between the leader's
+ * head and a server's end (rc_recover_log :726), then server_to_follower + vote ACK and the leader's
+ * log adjustment.  The joiner's timer is fired whenever a sweep over all servers left it armed and
+ * moved nothing else -- i.e. every period is long against a polling pass.  `r` is the slot the trace
+ * expects the leader to hand out; -1 on a mismatch. */
+int refc_join(refc_t *c, int r)
+{
+    if (c->leader < 0 || c->n_inst >= MAXI || r < 0 || r >= MAXN) return -1;
+    int k = c->n_inst;
+    if (load_instance(c, k, c->img, c->img_len)) return -1;
+    c->n_inst++;
+    c->in[k].slot = -1;
+    uint64_t cid[4]; S(c, c->leader)->cid(cid);
+    int size0 = (int)(cid[1] & 0xFF);
+    if (start_instance(c, k, size0, 1)) { snprintf(c->err, sizeof c->err, "joiner: dare_server_init failed"); return -1; }
+    c->in[k].record_apply(1);
+    call_fire(c, k, T_INIT);                                       /* init_network_cb -> join_cluster_cb armed */
+    uint64_t end0 = offs(S(c, c->leader))[3];
+    for (int sweep = 0; sweep < 400; sweep++) {
+        if (c->in[k].state() & ST_LOG_RECOVERED) break;
+        call_fire(c, k, T_INIT);
+        for (int pass = 0; pass < 4; pass++) {
+            poll_slot(c, c->leader);
+            for (int i = 0; i < c->n_inst; i++) if (i != k && i != port_of(c, c->leader) && !fab_port_held(i)) call_poll(c, i);
+            call_poll(c, k);
+        }
+        if (c->in[k].exited()) { snprintf(c->err, sizeof c->err, "joiner shut down"); return -1; }
+    }
+    if (!(c->in[k].state() & ST_LOG_RECOVERED)) { snprintf(c->err, sizeof c->err, "joiner did not recover its log (state %llx)", (unsigned long long)c->in[k].state()); return -1; }
+    int slot = c->in[k].idx();
+    if (slot != r) { snprintf(c->err, sizeof c->err, "leader handed out slot %d, trace expected %d", slot, r); return -1; }
+    if (slot >= c->n) c->n = slot + 1;
+    c->in[k].slot = slot;
+    c->slot_inst[slot] = k;
+    if (offs(S(c, c->leader))[3] != end0) note_round(c);
+    return 0;
+}
 
 /* raw access for tests that want a schedule of their own */
-int refc_poll(refc_t *c, int r) { return (r < 0 || r >= c->n) ? -1 : call_poll(c, r); }
-int refc_fire(refc_t *c, int r, int which) { return (r < 0 || r >= c->n) ? -1 : call_fire(c, r, which); }
+int refc_poll(refc_t *c, int r) { return S(c, r) ? poll_slot(c, r) : -1; }
+int refc_fire(refc_t *c, int r, int which) { return S(c, r) ? fire_slot(c, r, which) : -1; }
 
-void refc_offsets(refc_t *c, int r, uint64_t out[8]) { memcpy(out, offs(&c->in[r]), 64); }
-uint8_t *refc_entries(refc_t *c, int r) { return c->in[r].entries(); }
-uint64_t refc_sid(refc_t *c, int r) { return c->in[r].sid(); }
-int      refc_prev_head(refc_t *c, int r) { return c->in[r].prev_head(); }
-uint64_t refc_highest_rec(refc_t *c, int r) { return c->in[r].highest_rec(); }
-uint64_t refc_store_count(refc_t *c, int r) { return c->in[r].store_count(); }
-uint64_t refc_apply_count(refc_t *c, int r) { return c->in[r].apply_count(); }
-void     refc_record_apply(refc_t *c, int on) { for (int i = 0; i < c->n; i++) c->in[i].record_apply(on); }
-const void *refc_apply_log(refc_t *c, int r, uint64_t *n) { return c->in[r].apply_log(n); }
-void     refc_cid(refc_t *c, int r, uint64_t out[4]) { c->in[r].cid(out); }
-void     refc_peer(refc_t *c, int r, int i, uint64_t out[6]) { c->in[r].peer(i, out); }
-int      refc_alive(refc_t *c, int r) { return c->in[r].alive && !c->in[r].exited(); }
+void refc_offsets(refc_t *c, int r, uint64_t out[8]) { memcpy(out, offs(S(c, r)), 64); }
+uint8_t *refc_entries(refc_t *c, int r) { return S(c, r)->entries(); }
+uint64_t refc_sid(refc_t *c, int r) { return S(c, r)->sid(); }
+int      refc_prev_head(refc_t *c, int r) { return S(c, r)->prev_head(); }
+uint64_t refc_highest_rec(refc_t *c, int r) { return S(c, r)->highest_rec(); }
+uint64_t refc_store_count(refc_t *c, int r) { return S(c, r)->store_count(); }
+uint64_t refc_apply_count(refc_t *c, int r) { return S(c, r)->apply_count(); }
+void     refc_record_apply(refc_t *c, int on) { for (int i = 0; i < c->n_inst; i++) c->in[i].record_apply(on); }
+const void *refc_apply_log(refc_t *c, int r, uint64_t *n) { return S(c, r)->apply_log(n); }
+void     refc_cid(refc_t *c, int r, uint64_t out[4]) { S(c, r)->cid(out); }
+void     refc_peer(refc_t *c, int r, int i, uint64_t out[6]) { S(c, r)->peer(i, out); }
+int      refc_alive(refc_t *c, int r) { return S(c, r) && S(c, r)->alive && !S(c, r)->exited(); }
+uint64_t refc_state(refc_t *c, int r) { return S(c, r) ? S(c, r)->state() : 0; }
 uint64_t refc_round_count(const refc_t *c) { return c->n_rounds; }
 const uint64_t *refc_round_commit(const refc_t *c) { return c->round_commit; }
 const uint64_t *refc_round_end(const refc_t *c) { return c->round_end; }

@@ -33,6 +33,8 @@ int refc_kill(refc_t *c, int r);
 int refc_hold(refc_t *c, int r);
 int refc_release(refc_t *c, int r);
 int refc_quiesce(refc_t *c);
+int refc_join(refc_t *c, int r);                 /* a new server joins; the leader must hand out slot r */
+uint64_t refc_state(refc_t *c, int r);
 int refc_poll(refc_t *c, int r);
 int refc_fire(refc_t *c, int r, int which);     /* 0 init/rc-info, 1 prune, 2 heartbeat, 3 timeout adjust */
 

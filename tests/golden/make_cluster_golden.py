@@ -33,11 +33,12 @@ def main():
            "cases": {}}
     cases = dict(traces.CATALOGUE)
     cases["c2_full"] = T.config_c2
+    cases["c5_rejoin_full"] = lambda: T.config_c5(rejoin=True)      # BASELINE configs[4] at full size incl. the JOIN tail
     for name in sorted(cases):
         tr = cases[name]()
         rc = refloops.run_trace(tr)
         out["cases"][name] = {"group_size": tr.group_size, "log_len": tr.log_len, "n_reqs": int(tr.n_reqs),
-                              "n_events": len(tr.events), "record": cluster_record(rc, tr.group_size)}
+                              "n_events": len(tr.events), "record": cluster_record(rc, rc.n)}
         rc.close()
         print(name, "leader", out["cases"][name]["record"]["leader"], "passes", out["cases"][name]["record"]["rounds"])
     with open(os.path.join(HERE, "cluster_ref.json"), "w") as f:

@@ -44,11 +44,18 @@ def lockstep(tr, check_at=("QUIESCE", "PRUNE")):
                     c.hold(ev[1])
                 elif op == "RELEASE":
                     c.release(ev[1])
+                elif op == "JOIN":
+                    c.join(ev[1])
                 else:
                     raise ValueError(ev)
+            assert oc.n == rc.n
             if op in check_at:
-                assert_same_state(oc, rc, tr.group_size, tag=f"{tr.name} event {i} {ev}")
-        assert_same_state(oc, rc, tr.group_size, tag=f"{tr.name} end")
+                assert_same_state(oc, rc, oc.n, tag=f"{tr.name} event {i} {ev}")
+                for r in range(oc.n):
+                    if oc.alive(r):
+                        cr = rc.cid(r); cr.pop("cid_offset")
+                        assert oc.cid(r) == cr, f"{tr.name} event {i} {ev}: configuration of server {r}"
+        assert_same_state(oc, rc, oc.n, tag=f"{tr.name} end")
         return oc, rc
     except BaseException:
         rc.close()

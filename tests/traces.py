@@ -151,7 +151,42 @@ def double_failover_truncate():
     return tr
 
 
-CATALOGUE = {f.__name__: f for f in (diverge_failover, double_failover_truncate, steady3, steady5_unaligned, steady7_mixed, c2_small, c3_small, c4_small,
+def c5_rejoin():
+    """BASELINE config 5 with its optional tail: after the two kills a new server joins into the lowest
+    empty slot (the dead leader's, slot 0), recovers snapshot offset and log from the group
+    (rc_recover_sm / rc_recover_log, dare_ibv_rc.c:597-866), is adjusted by the leader and takes part in a
+    fourth phase.  No prune tick before the join: the reference's joiner only survives its first persist
+    pass when head is 0 or everything is 64-byte aligned (oracle/apus_oracle.c, orc_join -8)."""
+    return T.config_c5(per_phase=600, log_len=1 << 19, batch=16, rejoin=True, prune_bytes=1 << 30)
+
+
+def join_empty_slot():
+    """a follower dies and is removed; later a new machine joins into its slot (Case 3 of
+    handle_server_join_request, dare_ibv_ud.c:1022-1041: the bit is turned on again, STABLE stays) while
+    the ring has been pruned (head > 0, 128-byte entries keep the joiner's persist walk aligned)"""
+    tr = T.steady_trace(3, 900, 64, 4, 10, log_len=1 << 16, name="join_empty_slot")
+    return _with_events(tr, {9: [("QUIESCE",), ("KILL", 2), ("QUIESCE",)], 40: [("QUIESCE",), ("JOIN", 2), ("QUIESCE",)]})
+
+
+def join_upsize_3_to_5():
+    """the group is full: two joins extend it 3 -> 4 -> 5, each through the three CONFIG entries
+    EXTENDED -> TRANSIT -> STABLE (Case 4, dare_ibv_ud.c:1026-1041; apply_committed_entries
+    dare_server.c:1883-1937; TRANSIT commits with the NEW group's majority, dare_ibv_rc.c:1650-1758).  Prune
+    ticks between the joins commit a <HEAD> entry, which is what lets a follower dump its state machine a
+    second time (dare_server.c:611, :2171)."""
+    tr = T.steady_trace(3, 1500, 64, 4, 10, log_len=1 << 16, name="join_upsize_3_to_5")
+    return _with_events(tr, {20: [("QUIESCE",), ("JOIN", 3), ("QUIESCE",)], 80: [("QUIESCE",), ("JOIN", 4), ("QUIESCE",)]})
+
+
+def join_then_failover():
+    """a joined server is a full member: after 3 -> 4 the leader dies, the JOINED server wins the next term
+    (votes, log adjustment and the blank CONFIG entry with the group of four) and leads"""
+    tr = T.steady_trace(3, 900, 64, 4, 10, log_len=1 << 16, name="join_then_failover")
+    return _with_events(tr, {20: [("QUIESCE",), ("JOIN", 3), ("QUIESCE",)],
+                             50: [("QUIESCE",), ("KILL", 0), ("ELECT", 3), ("QUIESCE",)]})
+
+
+CATALOGUE = {f.__name__: f for f in (c5_rejoin, join_empty_slot, join_upsize_3_to_5, join_then_failover, diverge_failover, double_failover_truncate, steady3, steady5_unaligned, steady7_mixed, c2_small, c3_small, c4_small,
                                      c5_failover, hold_one_of_three, hold_release, no_quorum, no_quorum_prune,
                                      exact_fit, kill_follower, park_commit_at_wrap)}
 
