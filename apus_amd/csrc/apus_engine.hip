@@ -63,6 +63,7 @@ struct apus_engine {
      * get their logs adjusted by the new leader's first pass (log_adjustment, dare_ibv_rc.c:1292-1451) */
     uint32_t no_access, adjust_mask;
     uint64_t *d_elect;                         /* k_elect's verdict */
+    uint64_t cid_epoch;                        /* config.cid.epoch: one more with every group extension (apus_gpu_join) */
     struct BatchSeg { CallArgs a; uint32_t blocks; uint64_t bytes; bool lean; };
     std::vector<BatchSeg> batch;               /* recorded calls: arguments, blocks, bytes they append */
     /* graphs */
@@ -163,7 +164,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
         if (so_env && atoi(so_env) == 0) e->step_slots = 0;
     }
     e->free_lb = 0; e->stage_max_T = APUS_HDR; e->host_status = 0;
-    e->no_access = 0; e->adjust_mask = 0; e->d_elect = nullptr;
+    e->no_access = 0; e->adjust_mask = 0; e->d_elect = nullptr; e->cid_epoch = 0;
     e->n_reqs = 0; e->n_rounds_staged = 0;
     e->d_req = e->d_req_len = e->d_arena = e->d_round_first = e->d_round_prefix = nullptr;
     e->h_live = nullptr; e->d_live = nullptr; e->live_pending = false; e->live_copied = nullptr;
@@ -223,7 +224,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     if (!rc) rc = dev_alloc(e, &e->d.rec_end, sizeof(uint64_t) * e->d.rec_cap);
     if (!rc) rc = dev_alloc(e, &e->d.rec_commit, sizeof(uint64_t) * e->d.rec_cap);
     if (!rc) rc = dev_alloc(e, &e->d.rec_count, 64, true, hipDeviceMallocUncached);
-    if (!rc) rc = dev_alloc(e, &e->d_elect, 64);
+    if (!rc) rc = dev_alloc(e, &e->d_elect, 256);
     if (rc) { apus_gpu_destroy(e); return rc; }
     *out = e;
     rc = apus_gpu_reset(e);
@@ -266,10 +267,22 @@ extern "C" int apus_gpu_sync(apus_engine_t *e)
     return 0;
 }
 
+/* cfg.group_size is the CAPACITY (replicas that exist); d.group_size the size of the configuration the
+ * leader decides with -- cid.size[0], or cid.size[1] while a resize is in its TRANSIT phase (the `size`
+ * of the commit scan, dare_ibv_rc.c:1650-1758).  They differ only when a group is meant to grow. */
+extern "C" int apus_gpu_set_group_size(apus_engine_t *e, uint32_t n)
+{
+    if (!e || n < 1 || n > e->cfg.group_size) return APUS_E_ARG;
+    if (e->batching) return APUS_E_STATE;
+    if (e->d.leader < e->cfg.group_size) { int frc = flush_tick(e); if (frc) return frc; }
+    e->d.group_size = n;
+    return 0;
+}
+
 extern "C" int apus_gpu_reset(apus_engine_t *e)
 {
     if (!e) return APUS_E_ARG;
-    for (uint32_t i = 0; i < e->d.group_size; i++)
+    for (uint32_t i = 0; i < e->cfg.group_size; i++)
         if (e->d.rep[i].ring && !((e->imported_mask >> i) & 1u)) {
             /* log_new() zeroes the whole log (dare_log.h:128) */
             HIPCHK(hipMemsetAsync(e->d.rep[i].ring, 0, e->d.log_len + 4096, e->stream));
@@ -277,14 +290,14 @@ extern "C" int apus_gpu_reset(apus_engine_t *e)
         }
     e->d.leader = 0xFFFFFFFFu;
     e->tick_pending = false;
-    e->free_lb = 0; e->host_status = 0; e->no_access = 0; e->adjust_mask = 0;
+    e->free_lb = 0; e->host_status = 0; e->no_access = 0; e->adjust_mask = 0; e->cid_epoch = 0;
     e->reachable = (1u << e->d.group_size) - 1;
     e->d.reachable = e->reachable;
     {
         /* a peer's replica is reset by the process that hosts it */
         EngDev own = e->d;
-        for (uint32_t i = 0; i < e->d.group_size; i++) if ((e->imported_mask >> i) & 1u) own.rep[i].ring = nullptr;
-        hipLaunchKernelGGL(k_reset, dim3(e->d.group_size), dim3(64), 0, e->stream, own);
+        for (uint32_t i = 0; i < e->cfg.group_size; i++) if ((e->imported_mask >> i) & 1u) own.rep[i].ring = nullptr;
+        hipLaunchKernelGGL(k_reset, dim3(e->cfg.group_size), dim3(64), 0, e->stream, own);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -293,7 +306,7 @@ extern "C" int apus_gpu_reset(apus_engine_t *e)
 /* ---- peer-mapped replicas (one replica per GPU / process) ------------------------------- */
 extern "C" int apus_gpu_export_replica(apus_engine_t *e, uint32_t replica, apus_ipc_replica_t *out)
 {
-    if (!e || !out || replica >= e->d.group_size) return APUS_E_ARG;
+    if (!e || !out || replica >= e->cfg.group_size) return APUS_E_ARG;
     if (!((e->local_mask >> replica) & 1u) || ((e->imported_mask >> replica) & 1u)) return APUS_E_STATE;
     HIPCHK(hipStreamSynchronize(e->stream));
     const RepDev &r = e->d.rep[replica];
@@ -311,7 +324,7 @@ extern "C" int apus_gpu_export_replica(apus_engine_t *e, uint32_t replica, apus_
 
 extern "C" int apus_gpu_import_replica(apus_engine_t *e, const apus_ipc_replica_t *in)
 {
-    if (!e || !in || in->replica >= e->d.group_size) return APUS_E_ARG;
+    if (!e || !in || in->replica >= e->cfg.group_size) return APUS_E_ARG;
     if (in->log_len != e->d.log_len || in->dir_cap != e->dir_cap) return APUS_E_ARG;
     if ((e->local_mask >> in->replica) & 1u) return APUS_E_STATE;          /* hosted here, or imported already */
     HIPCHK(hipSetDevice(e->cfg.device));
@@ -829,7 +842,8 @@ extern "C" int apus_gpu_submit(apus_engine_t *e, const apus_req_t *reqs, uint32_
     return apus_gpu_commit_live(e, 0);
 }
 
-static int launch_control_round(apus_engine *e, int mode, uint32_t type, uint64_t d0, uint64_t d1);
+static int launch_control_round(apus_engine *e, int mode, uint32_t type, uint64_t d0, uint64_t d1,
+                                uint64_t req_id = 0, uint32_t clt_id = 0);
 static int flush_tick(apus_engine *e)
 {
     if (!e->tick_pending) return 0;
@@ -837,13 +851,14 @@ static int flush_tick(apus_engine *e)
     return launch_control_round(e, 1, APUS_HEAD, 0, 0);
 }
 
-static int launch_control_round(apus_engine *e, int mode, uint32_t type, uint64_t d0, uint64_t d1)
+static int launch_control_round(apus_engine *e, int mode, uint32_t type, uint64_t d0, uint64_t d1,
+                                uint64_t req_id, uint32_t clt_id)
 {
     int rc = launch_catchup(e);
     if (rc) return rc;
     const uint32_t fm = sync_mask(e);
-    if (mode != 2) e->free_lb = e->free_lb > 2 * APUS_HDR ? e->free_lb - 2 * APUS_HDR : 0;     /* at most one 64-byte entry (+ a skipped tail) */
-    hipLaunchKernelGGL(k_control_round, dim3(1), dim3(256), 0, e->stream, e->d, mode, type, d0, d1, fm, fm);
+    if ((mode & 7) != 2) e->free_lb = e->free_lb > 2 * APUS_HDR ? e->free_lb - 2 * APUS_HDR : 0;     /* at most one 64-byte entry (+ a skipped tail) */
+    hipLaunchKernelGGL(k_control_round, dim3(1), dim3(256), 0, e->stream, e->d, mode, type, d0, d1, fm, fm, req_id, clt_id);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -881,12 +896,13 @@ extern "C" int apus_gpu_tick_prune(apus_engine_t *e)
     int rc = need_leader(e);
     if (rc) return rc;
     /* an open batch: anything that has to run now goes behind what was recorded so far */
-    if (e->batching && (e->tick_pending || e->local_mask != (1u << e->d.group_size) - 1) && (rc = flush_batch(e))) return rc;
+    const uint32_t all_here = (1u << e->d.group_size) - 1;
+    if (e->batching && (e->tick_pending || (e->local_mask & all_here) != all_here) && (rc = flush_batch(e))) return rc;
     if ((rc = flush_tick(e))) return rc;            /* two ticks in a row: the first one runs now */
     /* When every replica lives on this device the tick is deferred and fused into the
      * sequencer of the next batch (same position in the order of events, one launch less);
      * any other call flushes it first. */
-    if (e->local_mask == (1u << e->d.group_size) - 1) { e->tick_pending = true; return 0; }
+    if ((e->local_mask & all_here) == all_here) { e->tick_pending = true; return 0; }
     return launch_control_round(e, 1, APUS_HEAD, 0, 0);
 }
 
@@ -1065,6 +1081,7 @@ extern "C" int apus_gpu_become_leader_ex(apus_engine_t *e, uint32_t leader, uint
     }
     /* blank CONFIG entry: dare_cid_t {epoch, size[2], state, pad, bitmask} */
     uint8_t cid[16] = {0};
+    memcpy(cid, &e->cid_epoch, 8);
     cid[8] = (uint8_t)e->d.group_size;
     memcpy(cid + 12, &bitmask, 4);
     removed &= bitmask & ~(1u << leader);
@@ -1091,6 +1108,232 @@ extern "C" int apus_gpu_set_reachable(apus_engine_t *e, uint32_t mask)
     if (mask & ~e->reachable) e->lag_possible = true;     /* somebody was released */
     e->reachable = mask;
     e->d.reachable = mask;
+    return 0;
+}
+
+
+/* ---- a server joins ------------------------------------------------------------ */
+/* The reference: handle_server_join_request (dare_ibv_ud.c:973-1068) on the leader, the CONFIG
+ * branches of apply_committed_entries (dare_server.c:1858-1937: reply to the joiner; the 3-phase resize
+ * EXTENDED -> TRANSIT -> STABLE when the group is full), and on the joiner handle_server_join_reply
+ * (:1071-1088), rc_recover_sm (dare_ibv_rc.c:597-705: apply = the donor's last applied entry),
+ * rc_recover_log (:726-866: the bytes between the leader's head and a server's end, read in ONE
+ * transfer), server_to_follower + vote ACK.  Here the joiner's replica is a slot of this engine (local
+ * HBM, or a peer's mapped over xGMI -- the kernels do not care): k_join_prepare works out what the
+ * joiner will hold, k_join_copy is the bulk transfer (ring range + directory, every CU), k_join_finish
+ * is the joiner's first polling() pass: persist_new_entries with old_end still at len (log_new,
+ * dare_log.h:134) -- a walk from offset 0 through the zeroed part of its ring in 64-byte steps and on
+ * through the recovered entries, ACKing whatever it meets -- then apply_committed_entries from the
+ * snapshot's offset.  Pinned on the reference: oracle/apus_oracle.c:orc_join, tests/traces.py join_*. */
+enum { J_HEAD = 0, J_COPY_FROM, J_COPY_BYTES, J_S_FIRST, J_HEAD_SLOT, J_N_END, J_EMPTY, J_WRAP, J_WORDS = 8 };
+
+__global__ __launch_bounds__(256) void k_join_prepare(const EngDev E, uint32_t r, uint32_t src, uint32_t donor,
+                                                      uint32_t bitmask, uint64_t epoch, uint64_t *jw)
+{
+    __shared__ unsigned long long s_max[3];
+    const uint32_t tid = threadIdx.x;
+    const RepDev &Ld = E.rep[E.leader], &Td = E.rep[src], &Dd = E.rep[donor], &Jd = E.rep[r];
+    const uint64_t L = E.log_len;
+    const uint64_t head = Ld.hdr[H_HEAD];
+    uint64_t rend = Td.hdr[H_END], rcommit = Td.hdr[H_COMMIT];
+    const uint64_t tn_end = Td.hdr[H_N_END], tn_commit = Td.hdr[H_N_COMMIT], t_last = Td.hdr[H_LAST_IDX];
+    const uint64_t dn_apply = Dd.hdr[H_N_APPLY], d_sid = Dd.hdr[H_SID], d_end = Dd.hdr[H_END], dn_end = Dd.hdr[H_N_END];
+    if (tid < 3) s_max[tid] = 0;
+    __syncthreads();
+    const bool empty = rend == L;
+    const bool wrap = !empty && rend > 0 && rend < head;
+    /* slots: the newest one that starts at `head` (+1), the newest one that still lies in the old lap
+     * (offset >= head) when the log wraps (+1), the donor's newest applied client entry (+1) */
+    const uint64_t span = tn_end < E.dir_mask + 1ull ? tn_end : E.dir_mask + 1ull;
+    for (uint64_t k = tid; k < span && !empty; k += blockDim.x) {
+        const uint64_t sl = tn_end - 1 - k;
+        const uint64_t off = Td.dir_off[(uint32_t)sl & E.dir_mask];
+        if (off == head) atomicMax(&s_max[0], (unsigned long long)(sl + 1));
+        if (wrap && off >= head) atomicMax(&s_max[1], (unsigned long long)(sl + 1));
+    }
+    __syncthreads();
+    const uint64_t head_slot = s_max[0] ? s_max[0] - 1 : (tn_end > span ? tn_end - span : 0);
+    for (uint64_t sl = head_slot + tid; sl < dn_apply && !empty; sl += blockDim.x) {
+        const uint32_t type = Dd.ring[Dd.dir_off[(uint32_t)sl & E.dir_mask] + 26];
+        if (type != APUS_NOOP && type != APUS_CONFIG && type != APUS_HEAD) atomicMax(&s_max[2], (unsigned long long)(sl + 1));
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    uint64_t *jh = Jd.hdr;
+    for (int i = 0; i < 64; i++) jh[i] = 0;
+    jh[H_LEN] = L; jh[H_END] = L; jh[H_TAIL] = L; jh[H_OLD_END] = L;
+    jh[H_HEAD] = head;                                                   /* handle_server_join_reply :1084 */
+    jh[H_SID] = d_sid;                                                   /* poll_sm_reply, dare_server.c:671 */
+    jh[H_CID_BITMASK] = bitmask; jh[H_CID_EPOCH] = epoch;
+    Ld.hdr[H_APPLY_OFFSETS + r] = head;                                  /* handle_server_join_request :1051 */
+    jw[J_HEAD] = head; jw[J_EMPTY] = empty; jw[J_WRAP] = wrap; jw[J_HEAD_SLOT] = head_slot;
+    jw[J_COPY_FROM] = head; jw[J_COPY_BYTES] = 0; jw[J_S_FIRST] = 0; jw[J_N_END] = 0;
+    if (empty) return;
+    /* rc_recover_sm: apply = offset behind the donor's last applied client entry */
+    uint64_t s_first = s_max[2] ? s_max[2] : head_slot;
+    uint64_t apply_off;
+    if (s_max[2]) {
+        const uint32_t di = (uint32_t)(s_first - 1) & E.dir_mask;
+        apply_off = Dd.dir_off[di] + (Dd.dir_len[di] & 0xFFFFFFu);
+    } else apply_off = (s_first == dn_end) ? d_end : Dd.dir_off[(uint32_t)s_first & E.dir_mask];
+    /* rc_recover_log :806-818 */
+    uint64_t n_end = tn_end, n_commit = tn_commit;
+    if (wrap) { rend = 0; n_end = s_max[1]; }
+    if (apus_is_larger(Td.hdr[H_END], L, rcommit, rend)) { rcommit = rend; n_commit = n_end; }
+    if (n_commit > n_end) n_commit = n_end;
+    jh[H_END] = rend; jh[H_COMMIT] = rcommit; jh[H_APPLY] = apply_off;
+    jh[H_N_END] = n_end; jh[H_N_COMMIT] = n_commit; jh[H_N_APPLY] = s_first;
+    if (wrap && apply_off != 0 && apply_off < head) {
+        /* The snapshot ends in the new lap, but the joiner's end = commit = 0: commit is "larger" than apply
+         * (log_is_offset_larger, dare_log.h:269), so apply_committed_entries runs from there through the
+         * zeroed ring (64-byte "NOOP" steps, no upcall) up to head and RE-APPLIES [head, len) on top of the
+         * snapshot, and [0, apply) too once the new lap has arrived -- what the reference does (pinned,
+         * tests/traces.py:join_wrapped); here: the joiner's apply position goes back to the head slot. */
+        jh[H_N_APPLY] = head_slot;
+        if ((head - apply_off) & 63) set_status(E, 1u << 5);            /* the steps do not land on head: see k_join_finish */
+    }
+    jh[H_LAST_IDX] = t_last;
+    jh[H_N_PERSIST] = head_slot;                                         /* nothing persisted yet; k_join_finish walks */
+    jw[J_COPY_BYTES] = wrap ? L - head : rend - head;                    /* log_offset_end_distance(head) */
+    jw[J_S_FIRST] = s_first; jw[J_N_END] = n_end;
+}
+
+/* rc_recover_log's READ (:826-855) and the directory that goes with the bytes; any grid */
+__global__ __launch_bounds__(256) void k_join_copy(const EngDev E, uint32_t r, uint32_t src, const uint64_t *jw)
+{
+    if (jw[J_EMPTY]) return;
+    const RepDev &Td = E.rep[src], &Jd = E.rep[r];
+    const uint64_t from = jw[J_COPY_FROM], bytes = jw[J_COPY_BYTES];
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t a = (from + 15) & ~15ull, b = (from + bytes) & ~15ull;
+    if (b > a) for (uint64_t u = tid; u < (b - a) / 16; u += nth) st16u(Jd.ring + a + 16 * u, ld16u(Td.ring + a + 16 * u));
+    for (uint64_t x = from + tid; x < from + bytes && x < a; x += nth) Jd.ring[x] = Td.ring[x];
+    for (uint64_t x = (b > a ? b : a) + tid; x < from + bytes; x += nth) Jd.ring[x] = Td.ring[x];
+    for (uint64_t i = tid; i <= E.dir_mask; i += nth) { Jd.dir_off[i] = Td.dir_off[i]; Jd.dir_len[i] = Td.dir_len[i]; }
+}
+
+/* the joiner's first pass: persist_new_entries from old_end = len (dare_server.c:1793-1810) */
+__global__ __launch_bounds__(256) void k_join_finish(const EngDev E, uint32_t r, uint32_t alive_mask, const uint64_t *jw)
+{
+    if (jw[J_EMPTY]) return;
+    const RepDev &Jd = E.rep[r];
+    uint64_t *jh = Jd.hdr;
+    const uint64_t L = E.log_len;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t head = jw[J_HEAD], head_slot = jw[J_HEAD_SLOT], n_end = jw[J_N_END];
+    const uint64_t end = jh[H_END];
+    const bool zero_alive = E.rep[0].ring && ((alive_mask >> 0) & 1u) && E.group_size > 0;
+    if (jw[J_WRAP] || end == 0) {
+        /* end = 0 and old_end = len are the same place (log_is_offset_larger, dare_log.h:269): the pass has
+         * nothing to do; the new lap arrives with the leader's log update and is persisted like any other */
+        if (tid == 0) jh[H_N_PERSIST] = n_end;
+        return;
+    }
+    if ((head & 63) == 0) {
+        /* the 64-byte steps through the zeroed part [0, head) land exactly on head, from there the walk
+         * follows the entries: head / 64 "NOOP entries" of sender 0, then slots [head_slot, n_end) */
+        for (uint64_t k = tid; k < head / 64; k += blockDim.x) {
+            Jd.ring[k * 64 + 28 + r] = 1;
+            if (zero_alive && r != 0) E.rep[0].ring[k * 64 + 28 + r] = 1;
+        }
+        for (uint64_t sl = head_slot + tid; sl < n_end; sl += blockDim.x) {
+            const uint64_t off = Jd.dir_off[(uint32_t)sl & E.dir_mask];
+            Jd.ring[off + 28 + r] = 1;                                   /* rc_send_entries_reply: own copy ... */
+            const uint32_t sender = Jd.ring[off + 27];
+            if (sender != r && sender < E.group_size && ((alive_mask >> sender) & 1u) && E.rep[sender].ring)
+                E.rep[sender].ring[off + 28 + r] = 1;                    /* ... and the sender's */
+        }
+        if (tid == 0) {
+            jh[H_STORE_COUNT] = head / 64 + (n_end - head_slot);
+            jh[H_OLD_END] = end; jh[H_N_PERSIST] = n_end;
+        }
+        return;
+    }
+    if (tid != 0) return;
+    /* head is not a multiple of 64: the walk runs into the recovered entries misaligned and reads entry
+     * shapes out of payload bytes.  The reference's joiner only leaves this loop if the walk happens to
+     * land exactly on `end` (otherwise it spins in polling() forever, oracle/apus_oracle.c:orc_join -8);
+     * followed step by step, bounded to four laps -- then the pass is taken as done (status bit) */
+    uint64_t old_end = L, count = 0, guard = 0;
+    const uint64_t limit = L / 16 + 1024;
+    while (apus_is_larger(end, L, end, old_end) && ++guard <= limit) {
+        if (L - old_end < APUS_HDR) old_end = 0;                         /* log_get_entry */
+        const uint32_t type = Jd.ring[old_end + 26];
+        const uint64_t elen = APUS_HDR + ((type == APUS_NOOP || type == APUS_CONFIG || type == APUS_HEAD) ? 0u : (uint32_t)(Jd.ring[old_end + 48] | (Jd.ring[old_end + 49] << 8)));
+        if (L - old_end < elen) { old_end = 0; continue; }
+        count++;
+        Jd.ring[old_end + 28 + r] = 1;
+        const uint32_t sender = Jd.ring[old_end + 27];
+        if (sender != r && sender < E.group_size && ((alive_mask >> sender) & 1u) && E.rep[sender].ring)
+            E.rep[sender].ring[old_end + 28 + r] = 1;
+        old_end += elen;
+    }
+    if (guard > limit) { set_status(E, 1u << 5); old_end = end; count = n_end - head_slot; }
+    jh[H_STORE_COUNT] = count; jh[H_OLD_END] = old_end; jh[H_N_PERSIST] = n_end;
+}
+
+/* JOIN(r): a new machine with LID `lid` joins the group this engine leads and gets slot r -- the lowest
+ * slot that is OFF in `bitmask`, or the current group size when every slot is taken (the group is
+ * extended; r must be below the capacity the engine was created with).  `reachable` = who answers (the
+ * donor of the snapshot is the first follower in index order, the source of the log the first server).
+ * out[0] = the new bitmask, out[1] = the new group size, out[2] = the new epoch.  One per-round record
+ * for the whole join.  APUS_E_STATE: no leader, a batch is open, r is not the slot the leader would hand
+ * out, or no follower to recover from. */
+extern "C" int apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_t bitmask, uint32_t reachable, uint64_t out[4])
+{
+    if (!e || !out || r >= e->cfg.group_size) return APUS_E_ARG;
+    if (e->live_R) { int rc_ = flush_live(e); if (rc_) return rc_; }
+    if (e->batching) return APUS_E_STATE;
+    int rc = need_leader(e);
+    if (rc) return rc;
+    if ((rc = flush_tick(e))) return rc;
+    const uint32_t size = e->d.group_size, leader = e->d.leader;
+    uint32_t empty = size;
+    for (int i = (int)size - 1; i >= 0; i--) if (!((bitmask >> i) & 1u)) empty = (uint32_t)i;   /* dare_ibv_ud.c:995-1021 */
+    if (empty != r || !e->d.rep[r].ring || ((e->imported_mask >> r) & 1u)) return APUS_E_STATE;
+    int donor = -1, src = -1;
+    for (uint32_t i = 0; i < size; i++) {
+        if (i == r || !((bitmask >> i) & 1u) || !((reachable >> i) & 1u) || !e->d.rep[i].ring) continue;
+        if (src < 0) src = (int)i;
+        if (donor < 0 && i != leader) donor = (int)i;
+    }
+    if (donor < 0 || src < 0) return APUS_E_STATE;
+
+    /* leader side: the CONFIG entries, each committed by the pass that follows it */
+    uint8_t cid[16] = {0};
+    uint64_t d0, d1;
+    uint32_t nb = bitmask | (1u << r);
+    auto put = [&](uint64_t epoch, uint32_t s0, uint32_t s1, uint32_t state) {
+        memset(cid, 0, 16); memcpy(cid, &epoch, 8); cid[8] = (uint8_t)s0; cid[9] = (uint8_t)s1; cid[10] = (uint8_t)state;
+        memcpy(cid + 12, &nb, 4); memcpy(&d0, cid, 8); memcpy(&d1, cid + 8, 8);
+    };
+    if (r < size) {                                           /* Case 3: an empty place */
+        put(e->cid_epoch, size, 0, 0);
+        if ((rc = launch_control_round(e, 0 | 16, APUS_CONFIG, d0, d1, 1, lid))) return rc;
+    } else {                                                  /* Case 4: [N,0,STABLE] -> [N,N+1,EXTENDED] -> [N,N+1,TRANSIT] -> [N+1,0,STABLE] */
+        e->cid_epoch++;
+        put(e->cid_epoch, size, size + 1, 2);
+        if ((rc = launch_control_round(e, 0 | 16, APUS_CONFIG, d0, d1, 1, lid))) return rc;    /* old majority (EXTENDED) */
+        e->d.group_size = size + 1;                           /* TRANSIT: the scan runs with cid.size[1] */
+        put(e->cid_epoch, size, size + 1, 1);
+        if ((rc = launch_control_round(e, 0 | 16, APUS_CONFIG, d0, d1, 0, 0))) return rc;
+        put(e->cid_epoch, size + 1, 0, 0);
+        if ((rc = launch_control_round(e, 0 | 16, APUS_CONFIG, d0, d1, 0, 0))) return rc;
+    }
+    /* joiner side */
+    uint64_t *jw = e->d_elect + 8;                            /* scratch words behind k_elect's verdict */
+    HIPCHK(hipMemsetAsync(e->d.rep[r].ring, 0, e->d.log_len + 4096, e->stream));       /* log_new() */
+    HIPCHK(hipMemsetAsync(e->d.rep[r].ack, 0, sizeof(uint32_t) * e->dir_cap, e->stream));
+    hipLaunchKernelGGL(k_join_prepare, dim3(1), dim3(256), 0, e->stream, e->d, r, (uint32_t)src, (uint32_t)donor, nb, e->cid_epoch, jw);
+    hipLaunchKernelGGL(k_join_copy, dim3(512), dim3(256), 0, e->stream, e->d, r, (uint32_t)src, jw);
+    hipLaunchKernelGGL(k_join_finish, dim3(1), dim3(256), 0, e->stream, e->d, r, reachable | (1u << r), jw);
+    HIPCHK(hipGetLastError());
+    /* connected: vote ACK, log adjustment (nothing to cut: the joiner's log is a prefix of the leader's),
+     * log update + lazy commit + the joiner's apply in the pass that closes the join */
+    e->reachable |= 1u << r; e->d.reachable = e->reachable;
+    e->lag_possible = true;
+    if ((rc = launch_control_round(e, 2 | 32, 0, 0, 0))) return rc;
+    out[0] = nb; out[1] = e->d.group_size; out[2] = e->cid_epoch; out[3] = 0;
     return 0;
 }
 
@@ -1132,7 +1375,7 @@ extern "C" int apus_gpu_graph_launch(apus_engine_t *e, int graph_id)
 /* ---- observation ------------------------------------------------------------ */
 static int local_rep(apus_engine *e, uint32_t r)
 {
-    if (!e || r >= e->d.group_size || !e->d.rep[r].ring) return APUS_E_STATE;
+    if (!e || r >= e->cfg.group_size || !e->d.rep[r].ring) return APUS_E_STATE;
     return 0;
 }
 

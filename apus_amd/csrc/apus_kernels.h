@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_catchup(const EngDev E, uint32_t fmask)
 template <bool FX>
 __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32_t type, uint64_t d0, uint64_t d1,
                                                uint32_t push_mask, uint64_t *s_lh, uint64_t rec_base, uint32_t ack_mask,
-                                               bool apply_now, bool note_head_slot = true);
+                                               bool apply_now, bool note_head_slot = true, uint64_t req_id = 0, uint32_t clt_id = 0);
 __device__ static inline void sample_apply_offsets(const EngDev &E, const uint64_t *s_lh, uint32_t sample_mask, uint32_t i,
                                                    const uint64_t *staged_apply);
 
@@ -3114,7 +3114,7 @@ __device__ static inline void sample_apply_offsets(const EngDev &E, const uint64
 template <bool FX>
 __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32_t type, uint64_t d0, uint64_t d1,
                                                uint32_t push_mask, uint64_t *s_lh, uint64_t rec_base, uint32_t ack_mask,
-                                               bool apply_now, bool note_head_slot)
+                                               bool apply_now, bool note_head_slot, uint64_t req_id, uint32_t clt_id)
 {
     const RepDev &Ld = E.rep[E.leader];
     uint64_t *hdr = Ld.hdr;
@@ -3150,7 +3150,9 @@ __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32
         const uint64_t slot = s.n_end0;
         const uint32_t di = (uint32_t)slot & E.dir_mask;
         const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)term, (uint32_t)(term >> 32));
-        const uint4 h1 = make_uint4(0, 0, (type << 16) | ((uint32_t)E.leader << 24), 0);  /* req_id = clt_id = 0 */
+        /* req_id and clt_id are 0 but for the CONFIG entry that admits a joining server (its request id and LID,
+         * handle_server_join_request dare_ibv_ud.c:1057-1060) */
+        const uint4 h1 = make_uint4((uint32_t)req_id, (uint32_t)(req_id >> 32), (clt_id & 0xFFFFu) | (type << 16) | ((uint32_t)E.leader << 24), 0);
         const uint4 h3 = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
         for (uint32_t m = FX ? (push_mask | (1u << E.leader)) : 0u; m; m &= m - 1) {
             const int t = __builtin_ctz(m);
@@ -3200,13 +3202,18 @@ __device__ static inline SeqOut control_append(const EngDev &E, int mode, uint32
  *   mode 3: append <type, d0, d1> and stop: the entry joins the next pass (the new leader's
  *           blank CONFIG when check_failure_count appends a removal behind it)
  * then followers persist + ACK, the ACK scan, apply and the bookkeeping.          */
-__global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode, uint32_t type,
+__global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode_flags, uint32_t type,
                                                        uint64_t d0, uint64_t d1, uint32_t push_mask,
-                                                       uint32_t sample_mask)
+                                                       uint32_t sample_mask, uint64_t req_id, uint32_t clt_id)
 {
     __shared__ uint32_t s_ack[256];
     __shared__ unsigned long long s_acc[2];
     const uint32_t tid = threadIdx.x;
+    /* flags above the mode: 16 = the pass leaves no per-round record (the CONFIG entries of a JOIN: the
+     * whole join is one record, as in the schedule the oracle is pinned on), 32 = record end / commit as
+     * they are after this pass even though it appended nothing (the pass that closes a JOIN) */
+    const int mode = mode_flags & 7;
+    const uint64_t rec0 = *E.rec_count;
     const RepDev &Ld = E.rep[E.leader];
     uint64_t *hdr = Ld.hdr;
     const uint64_t L = E.log_len;
@@ -3227,7 +3234,7 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode,
     __shared__ uint64_t s_lh[64];
     if (tid < 64) s_lh[tid] = hdr[tid];
     __syncthreads();
-    if (tid == 0) *E.seq = control_append<true>(E, mode, type, d0, d1, push_mask, s_lh, *E.rec_count, 0, false);
+    if (tid == 0) *E.seq = control_append<true>(E, mode, type, d0, d1, push_mask, s_lh, *E.rec_count, 0, false, true, req_id, clt_id);
     if (mode == 1 && tid >= 64 && tid < 64 + APUS_DEV_MAX_SERVERS) sample_apply_offsets(E, s_lh, sample_mask, tid - 64, nullptr);
     __syncthreads();
     if (mode == 3) return;     /* the followers' end words follow in the next pass's catch-up prelude */
@@ -3243,6 +3250,13 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode,
         apply_range(E, __builtin_ctz(m), E.rep[__builtin_ctz(m)].hdr[H_N_APPLY], cs, 0, blockDim.x, s_acc);
     __syncthreads();
     finish_call(E, 0, 0, mode == 2 ? 2 : 1, push_mask);
+    if (tid == 0) {                                   /* (finish_call's leader words are thread 0's stores too) */
+        if (mode_flags & 16) *E.rec_count = rec0;
+        if (mode_flags & 32) {
+            if (rec0 < E.rec_cap) { E.rec_end[rec0] = hdr[H_END]; E.rec_commit[rec0] = hdr[H_COMMIT]; }
+            *E.rec_count = rec0 + 1;
+        }
+    }
 }
 
 /* ------------------------------------------------------------------------- */

@@ -20,7 +20,7 @@ COUNTER_NAMES = ("n_end", "n_persist", "n_commit", "n_apply", "last_idx", "sid",
 # hdr word indices (apus_device.h)
 H_APPLY_COUNT, H_PREV_HEAD, H_CID_BITMASK, H_STORE_COUNT = 16, 17, 18, 21
 
-ST_NAMES = {1: "SECOND_WRAP", 2: "LOG_FULL", 4: "TERM_FENCE", 8: "DIR_OVERRUN", 16: "SPIN_TIMEOUT"}
+ST_NAMES = {1: "SECOND_WRAP", 2: "LOG_FULL", 4: "TERM_FENCE", 8: "DIR_OVERRUN", 16: "SPIN_TIMEOUT", 32: "JOIN_WALK"}
 
 
 class EngineError(RuntimeError):
@@ -32,13 +32,16 @@ class Engine:
     of a group that spans several processes)."""
 
     def __init__(self, group_size: int, log_len: int = DEFAULT_LOG, local_ids=None,
-                 device: int = 0, stream: int | None = None, flags: int = 0):
+                 device: int = 0, stream: int | None = None, flags: int = 0, capacity: int | None = None):
+        """capacity: replicas that exist (>= group_size); a group that is meant to grow by JOINs starts
+        with fewer configured servers than replicas."""
         self.L = _lib.load()
         self.group_size = group_size
+        self.capacity = capacity = max(group_size, capacity or group_size)
         self.log_len = log_len
-        self.local_ids = list(range(group_size)) if local_ids is None else list(local_ids)
+        self.local_ids = list(range(capacity)) if local_ids is None else list(local_ids)
         cfg = _lib.Cfg()
-        cfg.group_size = group_size
+        cfg.group_size = capacity
         cfg.n_local = len(self.local_ids)
         for k, i in enumerate(self.local_ids):
             cfg.local_ids[k] = i
@@ -51,10 +54,16 @@ class Engine:
         if rc != 0:
             raise EngineError(f"apus_gpu_create failed rc={rc} (a gfx950 device is required)")
         self.h = h
+        self.initial_size = group_size
+        if capacity != group_size:
+            self._chk(self.L.apus_gpu_set_group_size(self.h, group_size), "set_group_size")
         self.leader = -1
         self.term = 0
+        self.epoch = 0
+        self.machines = group_size          # LIDs handed out so far (a joiner is a new machine)
         self.bitmask = (1 << group_size) - 1
         self.reachable = (1 << group_size) - 1
+        self.snap_head = {}                 # follower -> its head when it last dumped its state machine
         self.round_of_g0 = {}
         self._keep = []
 
@@ -93,8 +102,14 @@ class Engine:
         self._chk(self.L.apus_gpu_sync(self.h), "sync")
 
     def reset(self):
+        if getattr(self, "initial_size", self.group_size) != self.group_size:
+            self.group_size = self.initial_size
+        if getattr(self, "capacity", self.group_size) != self.group_size:
+            self._chk(self.L.apus_gpu_set_group_size(self.h, self.group_size), "set_group_size")
         self._chk(self.L.apus_gpu_reset(self.h), "reset")
-        self.leader, self.term = -1, 0
+        self.leader, self.term, self.epoch = -1, 0, 0
+        self.machines = self.group_size
+        self.snap_head = {}
         self.bitmask = self.reachable = (1 << self.group_size) - 1
 
     # -- admission --------------------------------------------------------------
@@ -127,7 +142,7 @@ class Engine:
             raise EngineError("the winner of an election must be alive")
         # the votes are cast on the device (k_elect): who grants, who refuses (a longer log), majority or not
         out = (C.c_uint64 * 8)()
-        if len(self.local_ids) == self.group_size:
+        if set(range(self.group_size)) <= set(self.local_ids):
             self._chk(self.L.apus_gpu_elect(self.h, winner, self.reachable, self.bitmask, out), "elect")
         else:
             # (the message-passing transport: this process sees one replica only; the trace's word is taken)
@@ -147,7 +162,30 @@ class Engine:
 
     def _cid_bytes(self) -> bytes:
         import struct
-        return struct.pack("<QBBBBI", 0, self.group_size, 0, 0, 0, self.bitmask)
+        return struct.pack("<QBBBBI", getattr(self, "epoch", 0), self.group_size, 0, 0, 0, self.bitmask)
+
+    def join(self, r: int):
+        """JOIN(r) of the trace: a new machine joins and must be given slot r (an empty one, or the group
+        size: the group is extended).  Mirrors oracle/apus_oracle.c:orc_join, incl. what it refuses."""
+        if self.leader < 0:
+            raise EngineError("JOIN without a leader")
+        size = self.group_size
+        for i in range(size):
+            if i != r and (self.bitmask >> i) & 1 and not (self.reachable >> i) & 1:
+                raise EngineError("JOIN into a group with an unreachable configured server is not covered")
+        donors = [i for i in range(size) if i not in (r, self.leader) and (self.bitmask >> i) & 1]
+        for f in donors:
+            # a follower answers a second state-machine request before the next committed <HEAD> entry from
+            # an uninitialised pointer in the reference (dare_server.c:604-651); <HEAD> committed == head moved
+            if f in self.snap_head and self.snap_head[f] == self.offsets(f)["head"]:
+                raise EngineError(f"follower {f} was asked for its state machine already and no <HEAD> entry was committed since")
+        out = (C.c_uint64 * 4)()
+        self._chk(self.L.apus_gpu_join(self.h, r, self.machines + 1, self.bitmask, self.reachable, out), "join")
+        self.machines += 1
+        for f in donors:
+            self.snap_head[f] = self.offsets(f)["head"]
+        self.bitmask, self.group_size, self.epoch = int(out[0]), int(out[1]), int(out[2])
+        self.reachable |= 1 << r
 
     def kill(self, r: int):
         """KILL(r) of the trace: the server stops answering."""
@@ -209,6 +247,8 @@ class Engine:
                     self.release(ev[i][1])
                 elif op == "KILL":
                     self.kill(ev[i][1])
+                elif op == "JOIN":
+                    self.join(ev[i][1])
                 else:
                     raise EngineError(f"trace event {ev[i]} is not supported by the engine yet")
                 last = i

@@ -66,6 +66,7 @@ extern "C" {
 #define APUS_ST_TERM_FENCE   (1u << 2)  /* a follower saw an entry batch from a stale term            */
 #define APUS_ST_DIR_OVERRUN  (1u << 3)  /* more live entries than directory slots                     */
 #define APUS_ST_SPIN_TIMEOUT (1u << 4)  /* persistent kernel gave up waiting (bounded spin)           */
+#define APUS_ST_JOIN_WALK    (1u << 5)  /* a joiner's first persist pass did not end (the reference spins there forever): taken as done */
 
 /* one admitted client request = what a tailq_entry_t carries
  * (src/include/dare/message.h:11-18), produced by leader_handle_submit_req
@@ -168,6 +169,20 @@ int  apus_gpu_become_leader(apus_engine_t *e, uint32_t leader, uint64_t term, ui
 int  apus_gpu_elect(apus_engine_t *e, uint32_t winner, uint32_t live_mask, uint32_t bitmask, uint64_t out[8]);
 int  apus_gpu_become_leader_ex(apus_engine_t *e, uint32_t leader, uint64_t term, uint32_t bitmask,
                                uint32_t removed);
+/* cfg.group_size is the number of replicas that EXIST (the capacity); this sets the size of the
+ * configuration the leader decides with (cid.size[0]: quorum = n/2+1, the servers a prune tick looks
+ * at).  Default = the capacity; a group that is meant to grow starts smaller (apus_gpu_join extends it). */
+int  apus_gpu_set_group_size(apus_engine_t *e, uint32_t n);
+/* JOIN: a new machine (LID `lid`) joins and is given slot r -- the lowest slot that is OFF in `bitmask`,
+ * or the group size when all are taken: the group is then extended through the three CONFIG entries
+ * EXTENDED -> TRANSIT -> STABLE (handle_server_join_request src/dare/dare_ibv_ud.c:973-1068,
+ * apply_committed_entries src/dare/dare_server.c:1858-1937; TRANSIT commits with the new group's
+ * majority, src/dare/dare_ibv_rc.c:1650-1758).  The joiner's replica is recovered on the device:
+ * snapshot offset of the first follower (rc_recover_sm :597-705), the log between the leader's head and
+ * the first server's end in one bulk transfer (rc_recover_log :726-866), its first persist and apply
+ * passes, then it is a follower like the others.  reachable = who answers.  out[0] = new bitmask,
+ * out[1] = new group size, out[2] = new epoch.  One per-round record for the whole join. */
+int  apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_t bitmask, uint32_t reachable, uint64_t out[4]);
 /* reachability of peers from the leader (KILL / HOLD / RELEASE of the trace;
  * fail_count >= PERMANENT_FAILURE or rc_connected == 0 in the reference) */
 int  apus_gpu_set_reachable(apus_engine_t *e, uint32_t mask);

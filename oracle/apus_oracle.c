@@ -289,6 +289,8 @@ typedef struct {
     orc_det_t last_applied;                     /* dare_server.c:73 */
     /* joining */
     uint16_t lid;                               /* the machine's LID: clt_id of the CONFIG entry that admits it */
+    int      resync_armed;                      /* checker's numbering only: see orc_join */
+    uint64_t resync_off, resync_slot;
     int      snapshot_on;                       /* dare_state & SNAPSHOT, dare_server.c:641 */
     uint64_t snapshot_last;                     /* snapshot->last_entry.offset, :637 */
 } replica_t;
@@ -503,6 +505,7 @@ static void apply_committed_entries(orc_cluster_t *c, replica_t *p)
     while (orc_log_is_larger(log, log->commit, log->apply)) {
         orc_entry_t *e = get_entry(log, &log->apply);
         if (!fits_entry(log, log->apply, e)) { log->apply = 0; continue; }
+        if (p->resync_armed && log->apply == p->resync_off) { p->apply_slot = p->resync_slot; p->resync_armed = 0; }
         if (leader && e->type == ORC_CONFIG) {
             uint64_t req_id = e->req_id;
             uint16_t clt_id = e->clt_id;
@@ -1001,6 +1004,34 @@ int orc_join(orc_cluster_t *c, int r)
     if (target < 0) { c->join_slot = -1; return -6; }
     J->sid = c->r[target].sid;                                  /* poll_sm_reply :671 */
     J->log->apply = c->r[target].snapshot_last;                 /* rc_recover_sm dare_ibv_rc.c:691 */
+    {
+        /* `slot` of the apply stream = position of the entry in the total order of the log (not a field of
+         * the reference: the checker's own numbering, orc_apply_t): the joiner continues the donor's count
+         * from the entry its snapshot ends with */
+        orc_log_t *dl = c->r[target].log;
+        uint64_t k = 0, off = c->r[target].snapshot_last;
+        while (off != dl->apply && k < (1ull << 32)) {
+            orc_entry_t *e = get_entry(dl, &off);
+            if (!e) break;
+            if (!fits_entry(dl, off, e)) { off = 0; continue; }
+            off += entry_len(e); k++;
+        }
+        J->apply_slot = c->r[target].apply_slot - k;
+        /* A joiner that arrives while the log wraps gets apply = an offset of the NEW lap but end = commit = 0
+         * (rc_recover_log fetches [head, len) only), so its apply loop (commit "larger" than apply) runs from
+         * there through the zeroed ring up to head and RE-APPLIES [head, len) on top of the snapshot, later
+         * [0, apply) as well (found by running the reference; pinned, tests/traces.py:join_wrapped).  The walk
+         * through zeroes makes no upcalls; the numbering is put right where it reaches real entries again. */
+        uint64_t kh = 0;
+        off = J->log->head;
+        while (off != dl->apply && kh < (1ull << 32)) {
+            orc_entry_t *e = get_entry(dl, &off);
+            if (!e) break;
+            if (!fits_entry(dl, off, e)) { off = 0; continue; }
+            off += entry_len(e); kh++;
+        }
+        J->resync_off = J->log->head; J->resync_slot = c->r[target].apply_slot - kh; J->resync_armed = 1;
+    }
     join_pass(c, L, 3);
     /* sweep 4: rc_recover_log -- commit and end of the first connected server in index order, then the
      * bytes between the head the leader named and that end (up to the ring's end if they wrap) */
@@ -1025,6 +1056,7 @@ int orc_join(orc_cluster_t *c, int r)
     L->vote_ack[r] = J->log->commit;                            /* rc_send_vote_ack */
     join_pass(c, L, 4);
     c->join_slot = -1;
+    J->resync_armed = 0;                                        /* (the offset comes round again a lap later) */
     if (c->hung) return -8;
     if (log->end != end0) note_round(c, L);
     return 0;

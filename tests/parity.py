@@ -111,6 +111,9 @@ def lockstep(trace, eng, check_at=("PRUNE", "QUIESCE"), coalesce=True, allow_exa
             cl.release(ev[i][1]); eng.release(ev[i][1])
         elif op == "KILL":
             cl.kill(ev[i][1]); eng.kill(ev[i][1])
+        elif op == "JOIN":
+            cl.join(ev[i][1]); eng.join(ev[i][1])
+            assert cl.n == eng.group_size
         else:
             raise ValueError(ev[i])
         if op in check_at:
@@ -119,9 +122,9 @@ def lockstep(trace, eng, check_at=("PRUNE", "QUIESCE"), coalesce=True, allow_exa
                 # later, dare_ibv_rc.c:1761-1819); settle both sides before comparing
                 cl.quiesce(); eng.quiesce()
             eng.check_status()
-            held = [r for r in range(trace.group_size) if not (eng.reachable >> r) & 1]
+            held = [r for r in range(eng.group_size) if not (eng.reachable >> r) & 1]
             compare_all(eng, cl, tag=f"event {i} {ev[i]}",
-                        replicas=[r for r in range(trace.group_size) if r not in held])
+                        replicas=[r for r in range(eng.group_size) if r not in held])
         i += 1
     batch_close()
     eng.check_status()

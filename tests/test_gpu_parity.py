@@ -15,8 +15,8 @@ def eng_factory():
     from apus_amd.engine import Engine
     made = []
 
-    def make(group_size, log_len):
-        e = Engine(group_size, log_len)
+    def make(group_size, log_len, **kw):
+        e = Engine(group_size, log_len, **kw)
         made.append(e)
         return e
     yield make
@@ -586,3 +586,55 @@ def _random_trace(n, n_send, sizes, batch, L, seed, picks, who):
     ev.append(("QUIESCE",))
     base.events = ev
     return base
+
+
+JOIN_TRACES = ["join_empty_slot", "join_upsize_3_to_5", "join_wrapped", "join_then_failover", "c5_rejoin"]
+
+
+@pytest.mark.parametrize("batch", [False, True])
+@pytest.mark.parametrize("name", JOIN_TRACES)
+def test_join_traces(eng_factory, name, batch):
+    """SURVEY.md 8 f2 on the device: a new machine joins -- into the slot of a removed server, or the group
+    is extended through EXTENDED -> TRANSIT -> STABLE (TRANSIT commits with the new group's majority) --,
+    recovers snapshot offset and log from the group in one bulk transfer, makes the reference's first
+    persist / apply passes and is a follower (and, in join_then_failover, the next leader) like the
+    others.  Every trace is pinned on the reference itself (tests/golden/cluster_ref.json)."""
+    from tests import traces
+    from tests.parity import lockstep, compare_apply_tail
+    tr = traces.CATALOGUE[name]()
+    eng = eng_factory(tr.group_size, tr.log_len, capacity=5)
+    cl = lockstep(tr, eng, batch=batch, check_at=("QUIESCE",))
+    assert eng.group_size == cl.n
+    for r in range(cl.n):
+        if (eng.reachable >> r) & 1:
+            compare_apply_tail(eng, cl, r)
+
+
+def test_config5_with_join_tail_full_size(eng_factory):
+    """BASELINE configs[4] complete: 20 000 requests per phase, leader killed, follower killed, a new
+    server joins into slot 0 and catches up (60 000 entries in one transfer), fourth phase on four servers"""
+    from tests.parity import lockstep, compare_apply_tail
+    tr = T.config_c5(rejoin=True)
+    eng = eng_factory(5, tr.log_len)
+    cl = lockstep(tr, eng, batch=True, check_at=("QUIESCE",))
+    assert cl.leader == 1 and eng.counters(0)["sid"] == cl.sid(0)
+    assert eng.counters(0)["n_apply"] == eng.counters(1)["n_apply"]
+    compare_apply_tail(eng, cl, 0)
+
+
+def test_join_is_refused_where_the_reference_cannot_do_it(eng_factory):
+    """the leader hands out the LOWEST empty slot; a second state-machine request before a <HEAD> entry was
+    committed is undefined behaviour in the reference (dare_server.c:604-651) and refused here"""
+    from apus_amd.engine import EngineError
+    tr = T.steady_trace(3, 200, 64, 4, 10, log_len=1 << 20, name="j", prune_bytes=1 << 30)
+    eng = eng_factory(3, tr.log_len, capacity=5)
+    eng.reset(); eng.stage_trace(tr)
+    eng.elect(0)
+    eng.run_rounds(0, 5); eng.quiesce()
+    with pytest.raises(EngineError):
+        eng.join(4)                       # slot 3 comes first
+    eng.join(3); eng.quiesce()
+    assert eng.group_size == 4 and eng.bitmask == 0b1111
+    with pytest.raises(EngineError):
+        eng.join(4)                       # no <HEAD> entry since the followers dumped their state machines
+    eng.check_status()

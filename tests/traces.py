@@ -178,6 +178,13 @@ def join_upsize_3_to_5():
     return _with_events(tr, {20: [("QUIESCE",), ("JOIN", 3), ("QUIESCE",)], 80: [("QUIESCE",), ("JOIN", 4), ("QUIESCE",)]})
 
 
+def join_wrapped():
+    """the joiner arrives while the log wraps (end < head): rc_recover_log fetches [head, len) only and leaves
+    end = commit = 0 (dare_ibv_rc.c:806-818), the leader's log update brings the new lap"""
+    tr = T.steady_trace(3, 1500, 64, 4, 10, log_len=1 << 16, name="join_wrapped")
+    return _with_events(tr, {9: [("QUIESCE",), ("KILL", 1), ("QUIESCE",)], 52: [("QUIESCE",), ("JOIN", 1), ("QUIESCE",)]})
+
+
 def join_then_failover():
     """a joined server is a full member: after 3 -> 4 the leader dies, the JOINED server wins the next term
     (votes, log adjustment and the blank CONFIG entry with the group of four) and leads"""
@@ -186,7 +193,7 @@ def join_then_failover():
                              50: [("QUIESCE",), ("KILL", 0), ("ELECT", 3), ("QUIESCE",)]})
 
 
-CATALOGUE = {f.__name__: f for f in (c5_rejoin, join_empty_slot, join_upsize_3_to_5, join_then_failover, diverge_failover, double_failover_truncate, steady3, steady5_unaligned, steady7_mixed, c2_small, c3_small, c4_small,
+CATALOGUE = {f.__name__: f for f in (c5_rejoin, join_empty_slot, join_wrapped, join_upsize_3_to_5, join_then_failover, diverge_failover, double_failover_truncate, steady3, steady5_unaligned, steady7_mixed, c2_small, c3_small, c4_small,
                                      c5_failover, hold_one_of_three, hold_release, no_quorum, no_quorum_prune,
                                      exact_fit, kill_follower, park_commit_at_wrap)}
 
