@@ -23,7 +23,26 @@ def _free_port():
     return p
 
 
-def run_group(world, name, mode="per-call", flags=0, timeout=420):
+def run_group(world, name, mode="per-call", flags=0, timeout=420, attempts=2):
+    """One retry when a rank vanished without a result (seen once in ~5 runs of 5 processes on a fresh box:
+    a peer's gloo connection closes during start-up); what the lost rank wrote to stderr is kept under
+    gpurun_out/ for the post-mortem.  A rank that REPORTS a mismatch fails the test at once."""
+    for attempt in range(attempts):
+        try:
+            return _run_group(world, name, mode, flags, timeout)
+        except _RankLost as e:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", f"peers_lost_{name}_{attempt}.err"), "w") as f:
+                f.write(str(e))
+            if attempt == attempts - 1:
+                raise AssertionError(str(e))
+
+
+class _RankLost(Exception):
+    pass
+
+
+def _run_group(world, name, mode, flags, timeout):
     out = os.path.join(tempfile.mkdtemp(), "res")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
@@ -31,9 +50,13 @@ def run_group(world, name, mode="per-call", flags=0, timeout=420):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", APUS_DIST_BACKEND="gloo", APUS_DIST_ONE_DEVICE="1")
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     res = [json.load(open(f"{out}.{r}")) for r in range(world) if os.path.exists(f"{out}.{r}")]
+    if len(res) != world:
+        raise _RankLost(f"{world - len(res)} ranks produced no result\n{p.stdout[-2000:]}\n{p.stderr[-6000:]}")
     for r in res:
+        if not r["ok"] and "Connection closed by peer" in str(r.get("error")) and all(
+                q["ok"] or "Connection closed by peer" in str(q.get("error")) for q in res):
+            raise _RankLost(f"rank {r['rank']}: {r.get('error')}\n{p.stderr[-6000:]}")
         assert r["ok"], f"rank {r['rank']}: {r.get('error')}"
-    assert len(res) == world, f"{world - len(res)} ranks produced no result\n{p.stdout[-2000:]}\n{p.stderr[-3000:]}"
     assert len({r["end"] for r in res if "end" in r}) >= 1
     return res
 
