@@ -56,7 +56,7 @@ orc_log_t *orc_log_new(uint64_t len)           /* log_new, dare_log.h:120-136 */
 {
     orc_log_t *log = calloc(1, sizeof *log);
     if (!log) return NULL;
-    log->entries = calloc(1, len + ORC_HDR_BYTES);
+    log->entries = calloc(1, len + 1024);       /* slack: a store record may read a little past the last entry */
     if (!log->entries) { free(log); return NULL; }
     log->len = len;
     log->end = len;
@@ -293,6 +293,9 @@ typedef struct {
     uint64_t resync_off, resync_slot;
     int      snapshot_on;                       /* dare_state & SNAPSHOT, dare_server.c:641 */
     uint64_t snapshot_last;                     /* snapshot->last_entry.offset, :637 */
+    /* durability side channel: what proxy_store_cmd hands to BerkeleyDB */
+    uint8_t *store_buf; uint64_t store_len, store_cap;
+    uint32_t records_len;                       /* db-interface.c:17,81 */
 } replica_t;
 
 struct orc_cluster {
@@ -307,6 +310,7 @@ struct orc_cluster {
     /* a JOIN in progress: what the leader's reply carries (reconf_rep_t, dare_ibv_ud.c:1451-1490) */
     int next_lid, join_slot, join_replied;
     int hung;                                    /* a persist walk that does not terminate (orc_join, -8) */
+    int record_store;
     uint64_t join_head, join_cid_idx;
     orc_cid_t join_cid;
     replica_t r[ORC_MAX_SERVERS];
@@ -396,12 +400,15 @@ orc_cluster_t *orc_cluster_new(int group_size, uint64_t log_len)
 void orc_cluster_free(orc_cluster_t *c)
 {
     if (!c) return;
-    for (int i = 0; i < ORC_MAX_SERVERS; i++) { orc_log_free(c->r[i].log); free(c->r[i].apply_log); }
+    for (int i = 0; i < ORC_MAX_SERVERS; i++) { orc_log_free(c->r[i].log); free(c->r[i].apply_log); free(c->r[i].store_buf); }
     free(c->round_commit); free(c->round_end);
     free(c);
 }
 
 void orc_cluster_record_apply(orc_cluster_t *c, int on) { c->record_apply = on; }
+void orc_cluster_record_store(orc_cluster_t *c, int on) { c->record_store = on; }
+const uint8_t *orc_replica_store_stream(const orc_cluster_t *c, int r, uint64_t *n) { *n = c->r[r].store_len; return c->r[r].store_buf; }
+uint32_t orc_replica_records_len(const orc_cluster_t *c, int r) { return c->r[r].records_len; }
 void orc_cluster_allow_exact_fit(orc_cluster_t *c, int on) { c->allow_exact_fit = on; }
 void orc_cluster_completion_delay(orc_cluster_t *c, int on) { c->completion_delay = on; }
 uint64_t orc_force_prune_count(const orc_cluster_t *c) { return c->force_prunes; }
@@ -422,6 +429,35 @@ uint64_t orc_round_count(const orc_cluster_t *c) { return c->n_rounds; }
 const uint64_t *orc_round_commit(const orc_cluster_t *c) { return c->round_commit; }
 const uint64_t *orc_round_end(const orc_cluster_t *c) { return c->round_end; }
 
+/* --- proxy_store_cmd = stablestorage_save_request, src/proxy/proxy.c:268-291 + store_record,
+ *     src/db/db-interface.c:65-96.  `data` = &entry->clt_id (dare_server.c:1802) is read as a
+ *     proxy_msg_header {u16 connection_id; u8 action} (proxy.h:57-60); a SEND record is
+ *     PROXY_SEND_MSG_SIZE = sizeof(proxy_send_msg) + data.cmd.len long (proxy.h:83-91), where
+ *     sizeof(proxy_send_msg) = 24 and the overlay puts data.cmd.len at +8 of the record = entry bytes
+ *     32..33 = reply[4], reply[5] -- NOT the entry's cmd.len at 48: the record carries
+ *     clt_id, type, sender, reply[] and the struct padding, no command byte, and grows by 1 / 256 / 257 bytes
+ *     when server 4 / 5 had already acknowledged.  CONNECT / CLOSE records: 4 bytes.  Other types: nothing. */
+#define STORE_CONNECT_BYTES 4u      /* sizeof(proxy_connect_msg), proxy.h:63-66 */
+#define STORE_SEND_BYTES    24u     /* sizeof(proxy_send_msg), proxy.h:83-90 (SURVEY.md 9-Q1 [probed]) */
+static void store_cmd(orc_cluster_t *c, replica_t *p, const orc_entry_t *e)
+{
+    const uint8_t *d = (const uint8_t *)&e->clt_id;
+    uint32_t n = 0;
+    switch (e->type) {
+    case ORC_CONNECT: case ORC_CLOSE: n = STORE_CONNECT_BYTES; break;
+    case ORC_SEND: n = STORE_SEND_BYTES + (uint32_t)(d[8] | (d[9] << 8)); break;
+    default: return;
+    }
+    p->records_len += n;
+    if (!c->record_store) return;
+    if (p->store_len + n > p->store_cap) {
+        p->store_cap = (p->store_len + n) * 2 + 4096;
+        p->store_buf = realloc(p->store_buf, p->store_cap);
+    }
+    memcpy(p->store_buf + p->store_len, d, n);
+    p->store_len += n;
+}
+
 /* --- persist_new_entries, dare_server.c:1792-1810 ------------------- */
 /* the follower ACK inside it is rc_send_entries_reply, dare_ibv_rc.c:1828-1863:
  * reply[my_idx]=1 locally and, by a 1-byte WRITE, at the same offset of the
@@ -437,6 +473,7 @@ static void persist_new_entries(orc_cluster_t *c, replica_t *p)
         orc_entry_t *e = get_entry(log, &log->old_end);
         if (!fits_entry(log, log->old_end, e)) { log->old_end = 0; continue; }
         p->store_count++;                                   /* proxy_store_cmd(&entry->clt_id) */
+        store_cmd(c, p, e);
         if (is_leader_r(p)) {
             e->sender = p->idx;
         } else {
@@ -917,7 +954,7 @@ int orc_release(orc_cluster_t *c, int r) { if (r < 0 || r >= c->n) return -1; c-
 static void replica_fresh(orc_cluster_t *c, int r, uint16_t lid)
 {
     replica_t *p = &c->r[r];
-    orc_log_free(p->log); free(p->apply_log);
+    orc_log_free(p->log); free(p->apply_log); free(p->store_buf);
     memset(p, 0, sizeof *p);
     p->log = orc_log_new(c->log_len);
     p->idx = (uint8_t)r;

@@ -112,6 +112,11 @@ typedef struct {
 orc_cluster_t *orc_cluster_new(int group_size, uint64_t log_len);
 void           orc_cluster_free(orc_cluster_t *c);
 void           orc_cluster_record_apply(orc_cluster_t *c, int on);
+/* the durability side channel: the records proxy_store_cmd hands to BerkeleyDB, back to back (= what
+ * dump_records / the snapshot of a joiner's donor holds), and db-interface.c's records_len */
+void           orc_cluster_record_store(orc_cluster_t *c, int on);
+const uint8_t *orc_replica_store_stream(const orc_cluster_t *c, int r, uint64_t *n);
+uint32_t       orc_replica_records_len(const orc_cluster_t *c, int r);
 /* by default orc_round fails (-3) when an append lands exactly on len (Q13) */
 void           orc_cluster_allow_exact_fit(orc_cluster_t *c, int on);
 /* 0 (default): a posted WR's completion is seen by the poll behind the post; 1: by the next loop pass */

@@ -79,6 +79,9 @@ def lib() -> C.CDLL:
             "orc_release": (C.c_int, [vp, C.c_int]),
             "orc_quiesce": (C.c_int, [vp]),
             "orc_join": (C.c_int, [vp, C.c_int]),
+            "orc_cluster_record_store": (None, [vp, C.c_int]),
+            "orc_replica_store_stream": (vp, [vp, C.c_int, C.POINTER(u64)]),
+            "orc_replica_records_len": (u32, [vp, C.c_int]),
             "orc_replica_cid": (None, [vp, C.c_int, vp]),
             "orc_replica_alive": (C.c_int, [vp, C.c_int]),
             "orc_leader": (C.c_int, [vp]),
@@ -301,6 +304,7 @@ class Cluster:
         self.L.orc_cluster_record_apply(self.h, int(record_apply))
         self.L.orc_cluster_allow_exact_fit(self.h, int(allow_exact_fit))
         self.L.orc_cluster_completion_delay(self.h, int(completion_delay))
+        self.L.orc_cluster_record_store(self.h, int(record_apply))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -325,6 +329,15 @@ class Cluster:
         return rc
 
     def alive(self, r): return bool(self.L.orc_replica_alive(self.h, r))
+
+    def record_store(self, on=True): self.L.orc_cluster_record_store(self.h, int(on))
+
+    def store_stream(self, r) -> bytes:
+        n = u64(0)
+        ptr = self.L.orc_replica_store_stream(self.h, r, C.byref(n))
+        return C.string_at(ptr, n.value) if n.value else b""
+
+    def records_len(self, r): return int(self.L.orc_replica_records_len(self.h, r))
 
     def cid(self, r) -> dict:
         buf = (C.c_uint8 * 16)()

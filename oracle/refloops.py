@@ -48,7 +48,7 @@ _lib = None
 def build(force: bool = False) -> None:
     if not os.path.exists(REF_SRC):
         return
-    srcs = [os.path.join(HERE, "refshim", f) for f in ("fabric.c", "refcluster.c", "glue.c", "fabric.h",
+    srcs = [os.path.join(HERE, "refshim", f) for f in ("fabric.c", "refcluster.c", "glue.c", "glue_store.c", "fabric.h",
                                                           "refcluster.h", "ev.h", "libconfig.h",
                                                           os.path.join("infiniband", "verbs.h"))]
     stale = force or not (os.path.exists(FABRIC_SO) and os.path.exists(LOOPS_SO))
@@ -99,6 +99,9 @@ def lib() -> C.CDLL:
             "refc_record_apply": (None, [vp, C.c_int]),
             "refc_apply_log": (vp, [vp, C.c_int, pu64]),
             "refc_cid": (None, [vp, C.c_int, pu64]),
+            "refc_record_store": (None, [vp, C.c_int]),
+            "refc_store_stream": (vp, [vp, C.c_int, pu64]),
+            "refc_records_len": (u32, [vp, C.c_int]),
             "refc_peer": (None, [vp, C.c_int, C.c_int, pu64]),
             "refc_round_count": (u64, [vp]),
             "refc_round_commit": (pu64, [vp]),
@@ -157,6 +160,7 @@ class RefCluster:
         self.n = group_size
         self.log_len = log_len
         self.L.refc_record_apply(self.h, int(record_apply))
+        self.L.refc_record_store(self.h, int(record_apply))
 
     def close(self):
         if getattr(self, "h", None):
@@ -222,6 +226,15 @@ class RefCluster:
             return np.zeros(0, dtype=REF_APPLY_DTYPE)
         buf = (C.c_char * (n.value * REF_APPLY_DTYPE.itemsize)).from_address(ptr)
         return np.frombuffer(buf, dtype=REF_APPLY_DTYPE).copy()
+
+    def record_store(self, on=True): self.L.refc_record_store(self.h, int(on))
+
+    def store_stream(self, r) -> bytes:
+        n = u64(0)
+        ptr = self.L.refc_store_stream(self.h, r, C.byref(n))
+        return C.string_at(ptr, n.value) if n.value else b""
+
+    def records_len(self, r): return int(self.L.refc_records_len(self.h, r))
 
     def round_record(self):
         n = int(self.L.refc_round_count(self.h))

@@ -176,7 +176,24 @@ static void rec(uint8_t kind)
     glue_apply_t *r = &apply_log[apply_n++];
     r->off = off; r->idx = e->idx; r->len = e->data.cmd.len; r->clt_id = e->clt_id; r->type = e->type; r->kind = kind;
 }
-static void cb_store_cmd(void *d, void *arg) { (void)d; (void)arg; store_count++; }
+/* what BerkeleyDB is handed: stablestorage_save_request (src/proxy/proxy.c:268-291) with the reference's own
+ * structs -- the record starts at &entry->clt_id and its length comes out of the proxy_send_msg overlay
+ * (SURVEY.md 9-Q1); store_record (src/db/db-interface.c:65-96) appends it and adds its size to records_len */
+static uint8_t *store_buf; static uint64_t store_len, store_cap; static uint32_t records_len_; static int record_store;
+static void store_record_(size_t n, const void *d)
+{
+    records_len_ += (uint32_t)n;
+    if (!record_store) return;
+    if (store_len + n > store_cap) { store_cap = (store_len + n) * 2 + 4096; store_buf = realloc(store_buf, store_cap); }
+    memcpy(store_buf + store_len, d, n); store_len += n;
+}
+size_t glue_store_record_size(const void *d);      /* glue_store.c: the reference's own structs say how long */
+static void cb_store_cmd(void *d, void *arg)
+{
+    (void)arg; store_count++;
+    size_t n = glue_store_record_size(d);
+    if (n) store_record_(n, d);
+}
 static void cb_do_action(uint16_t clt_id, uint8_t type, size_t n, void *d, void *arg)
 { (void)clt_id; (void)type; (void)n; (void)d; (void)arg; follower_applied++; rec(2); }
 static void cb_update_state(void *arg) { (void)arg; highest_rec++; rec(1); }
@@ -261,6 +278,9 @@ uint64_t glue_highest_rec(void) { return highest_rec; }
 uint64_t glue_store_count(void) { return store_count; }
 uint64_t glue_apply_count(void) { return highest_rec + follower_applied; }
 void     glue_record_apply(int on) { record_apply = on; }
+void     glue_record_store(int on) { record_store = on; }
+const void *glue_store_stream(uint64_t *n) { *n = store_len; return store_buf; }
+uint32_t glue_records_len(void) { return records_len_; }
 const void *glue_apply_log(uint64_t *n) { *n = apply_n; return apply_log; }
 void glue_cid(uint64_t out[4])
 {

@@ -76,6 +76,9 @@ typedef struct {
     void     (*peer)(int, uint64_t *);
     int      (*all_connected)(void);
     int      (*idx)(void);
+    void     (*record_store)(int);
+    const void *(*store_stream)(uint64_t *);
+    uint32_t (*records_len)(void);
 } inst_t;
 
 /* A server instance owns fabric port k (LID k+1) for its whole life; the trace names servers by their
@@ -90,6 +93,7 @@ struct refc {
     void *img; size_t img_len;     /* the library image joiners are loaded from */
     char cfg_path[256], log_dir[256];
     int leader;
+    int record_store_on;
     uint64_t n_rounds, rounds_cap, *round_commit, *round_end;
     char err[256];
 };
@@ -156,6 +160,7 @@ static int load_instance(refc_t *c, int i, const void *img, size_t img_len)
     SYM(start); SYM(fire); SYM(timer_armed); SYM(poll); SYM(submit); SYM(log); SYM(entries); SYM(sid); SYM(state);
     SYM(exited); SYM(is_leader); SYM(prev_head); SYM(highest_rec); SYM(store_count); SYM(apply_count);
     SYM(record_apply); SYM(apply_log); SYM(cid); SYM(peer); SYM(all_connected); SYM(idx);
+    SYM(record_store); SYM(store_stream); SYM(records_len);
 #undef SYM
     return 0;
 }
@@ -389,6 +394,7 @@ int refc_join(refc_t *c, int r)
     int size0 = (int)(cid[1] & 0xFF);
     if (start_instance(c, k, size0, 1)) { snprintf(c->err, sizeof c->err, "joiner: dare_server_init failed"); return -1; }
     c->in[k].record_apply(1);
+    c->in[k].record_store(c->record_store_on);
     call_fire(c, k, T_INIT);                                       /* init_network_cb -> join_cluster_cb armed */
     uint64_t end0 = offs(S(c, c->leader))[3];
     for (int sweep = 0; sweep < 400; sweep++) {
@@ -423,6 +429,9 @@ uint64_t refc_highest_rec(refc_t *c, int r) { return S(c, r)->highest_rec(); }
 uint64_t refc_store_count(refc_t *c, int r) { return S(c, r)->store_count(); }
 uint64_t refc_apply_count(refc_t *c, int r) { return S(c, r)->apply_count(); }
 void     refc_record_apply(refc_t *c, int on) { for (int i = 0; i < c->n_inst; i++) c->in[i].record_apply(on); }
+void     refc_record_store(refc_t *c, int on) { c->record_store_on = on; for (int i = 0; i < c->n_inst; i++) c->in[i].record_store(on); }
+const void *refc_store_stream(refc_t *c, int r, uint64_t *n) { return S(c, r)->store_stream(n); }
+uint32_t refc_records_len(refc_t *c, int r) { return S(c, r)->records_len(); }
 const void *refc_apply_log(refc_t *c, int r, uint64_t *n) { return S(c, r)->apply_log(n); }
 void     refc_cid(refc_t *c, int r, uint64_t out[4]) { S(c, r)->cid(out); }
 void     refc_peer(refc_t *c, int r, int i, uint64_t out[6]) { S(c, r)->peer(i, out); }

@@ -50,6 +50,10 @@ uint64_t refc_store_count(refc_t *c, int r);
 uint64_t refc_apply_count(refc_t *c, int r);
 void     refc_record_apply(refc_t *c, int on);
 const void *refc_apply_log(refc_t *c, int r, uint64_t *n);
+/* the bytes handed to BerkeleyDB by persist_new_entries -> proxy_store_cmd, record after record (glue.c) */
+void     refc_record_store(refc_t *c, int on);
+const void *refc_store_stream(refc_t *c, int r, uint64_t *n);
+uint32_t refc_records_len(refc_t *c, int r);
 void     refc_cid(refc_t *c, int r, uint64_t out[4]);       /* epoch, size0|size1<<8|state<<16, bitmask, cid_offset */
 void     refc_peer(refc_t *c, int r, int i, uint64_t out[6]);
 uint64_t refc_round_count(const refc_t *c);

@@ -32,6 +32,11 @@ def replica_record(cl, r) -> dict:
         h.update(np.ascontiguousarray(al[f]).astype("<u8").tobytes())
     rec["apply_records"] = len(al)
     rec["apply_sha256"] = h.hexdigest()
+    # the durability side channel: what proxy_store_cmd handed to BerkeleyDB (proxy.c:268-291), back to back
+    st = cl.store_stream(r)
+    rec["store_bytes"] = len(st)
+    rec["records_len"] = cl.records_len(r)
+    rec["store_sha256"] = hashlib.sha256(st).hexdigest()
     return rec
 
 
@@ -61,6 +66,9 @@ def assert_same_state(a, b, n, tag="", names=("oracle", "reference")):
             va, vb = getattr(a, f)(r), getattr(b, f)(r)
             assert va == vb, f"{tag} server {r}: {f} {va} vs {vb}"
         assert int(a.log(r).prev_head) == int(b.log(r).prev_head), f"{tag} server {r}: prev_log_entry_head"
+        sa, sb = a.store_stream(r), b.store_stream(r)
+        assert a.records_len(r) == b.records_len(r), f"{tag} server {r}: records_len {a.records_len(r)} vs {b.records_len(r)}"
+        assert sa == sb, f"{tag} server {r}: the bytes handed to the storage callback differ ({len(sa)} vs {len(sb)} bytes)"
         aa, ab = a.apply_log(r), b.apply_log(r)
         assert len(aa) == len(ab), f"{tag} server {r}: {len(aa)} vs {len(ab)} apply upcalls"
         for f in APPLY_FIELDS:
