@@ -42,6 +42,7 @@ enum {
     H_STORE_COUNT,    /* proxy_store_cmd upcalls (persist_new_entries)  */
     H_N_VISIBLE,      /* leader: entries visible to followers / the ACK scan */
     H_APPLY_OFFSETS,  /* 13 words: ctrl_data->apply_offsets[], dare_server.h:137 */
+    H_JOINED_AT = H_APPLY_OFFSETS + APUS_DEV_MAX_SERVERS,   /* a joined server: the entries below this slot were appended by other machines (a former holder of its slot included) */
     H_WORDS = H_APPLY_OFFSETS + APUS_DEV_MAX_SERVERS + 3   /* 38 -> padded */
 };
 

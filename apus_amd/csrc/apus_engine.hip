@@ -1193,6 +1193,7 @@ __global__ __launch_bounds__(256) void k_join_prepare(const EngDev E, uint32_t r
         if ((head - apply_off) & 63) set_status(E, 1u << 5);            /* the steps do not land on head: see k_join_finish */
     }
     jh[H_LAST_IDX] = t_last;
+    jh[H_JOINED_AT] = tn_end;
     jh[H_N_PERSIST] = head_slot;                                         /* nothing persisted yet; k_join_finish walks */
     jw[J_COPY_BYTES] = wrap ? L - head : rend - head;                    /* log_offset_end_distance(head) */
     jw[J_S_FIRST] = s_first; jw[J_N_END] = n_end;
@@ -1458,6 +1459,91 @@ extern "C" int apus_gpu_apply_records(apus_engine_t *e, uint32_t replica, uint64
         HIPCHK(hipMemcpy(out + done, base + i, chunk * sizeof(apus_apply_rec), hipMemcpyDeviceToHost));
         done += chunk;
     }
+    return 0;
+}
+
+
+/* ---- durability side channel --------------------------------------------------- */
+/* What persist_new_entries hands to proxy_store_cmd for every entry (dare_server.c:1802: &entry->clt_id)
+ * and stablestorage_save_request (src/proxy/proxy.c:268-291) appends to BerkeleyDB: a CONNECT / CLOSE
+ * record is the 4 bytes clt_id, type, sender; a SEND record is sizeof(proxy_send_msg) = 24 bytes from
+ * clt_id on (sender, reply[13], the struct padding) plus "data.cmd.len" more -- which the overlay reads
+ * at +8 of the record = reply[4] | reply[5] << 8, not the entry's cmd.len: no command
+ * byte is stored unless servers 4 / 5 had acknowledged.  Back to back these records are dump_records'
+ * output, i.e. the snapshot a joiner's donor ships (stablestorage_dump_records, proxy.c:300-304).
+ * The callback sees the entry AS IT IS WHEN THIS SERVER PERSISTS IT: the leader right behind the append
+ * (reply[] zero, `sender` not stamped yet); a follower after the bytes landed (the sender's stamp, the
+ * replies the leader had collected when it sent them -- none in step, others' after a catch-up -- and
+ * its own reply byte still zero).  A follower's ring keeps exactly those bytes (ACKs go to its own byte and
+ * to the sender's copy), so the records are regenerated from the ring: own reply byte cleared; all
+ * replies cleared where this server appended the entry itself.  One workgroup: block scan of the record
+ * lengths, then each thread copies its record. */
+__global__ __launch_bounds__(1024) void k_store_stream(const EngDev E, uint32_t r, uint64_t first, uint64_t n,
+                                                       uint8_t *out, uint64_t cap, uint64_t *res)
+{
+    __shared__ uint64_t s_tot[16];
+    __shared__ uint64_t s_base, s_recs;
+    const RepDev &Rd = E.rep[r];
+    const uint64_t joined_at = Rd.hdr[H_JOINED_AT];
+    if (threadIdx.x == 0) { s_base = 0; s_recs = 0; }
+    __syncthreads();
+    for (uint64_t c0 = 0; c0 < n; c0 += blockDim.x) {
+        const uint64_t k = c0 + threadIdx.x;
+        uint64_t off = 0; uint32_t len = 0, type = 0, sender = 0;
+        uint8_t rep[13];
+        for (int i = 0; i < 13; i++) rep[i] = 0;
+        if (k < n) {
+            off = Rd.dir_off[(uint32_t)(first + k) & E.dir_mask];
+            type = Rd.ring[off + 26]; sender = Rd.ring[off + 27];
+            if (type == APUS_CONNECT || type == APUS_CLOSE) len = 4;
+            else if (type == APUS_SEND) {
+                const bool own = sender == r && first + k >= joined_at;      /* appended by this very machine */
+                if (!own) { for (int i = 0; i < 13; i++) rep[i] = Rd.ring[off + 28 + i]; if (r < 13) rep[r] = 0; }
+                len = 24u + (uint32_t)(rep[4] | (rep[5] << 8));
+            }
+        }
+        uint64_t tot;
+        const uint64_t incl = block_incl_scan(len, s_tot, &tot);
+        const uint64_t at = s_base + incl - len;
+        if (len && at + len <= cap) {
+            uint8_t *o = out + at;
+            o[0] = Rd.ring[off + 24]; o[1] = Rd.ring[off + 25]; o[2] = (uint8_t)type; o[3] = (uint8_t)sender;
+            if (len > 4) {
+                for (int i = 0; i < 13; i++) o[4 + i] = rep[i];
+                for (uint32_t i = 17; i < len; i++) o[i] = Rd.ring[off + 24 + i];      /* padding 41..47, then what follows */
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { s_base += tot; }
+        if (len) atomicAdd((unsigned long long *)&s_recs, 1ull);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { res[0] = s_base; res[1] = s_recs; }
+}
+
+/* records of entry slots [first, first + n) of `replica`, back to back, into dst (host memory, cap bytes);
+ * *bytes = what they take (even when > cap: nothing beyond cap is written), *records = how many */
+extern "C" int apus_gpu_store_stream(apus_engine_t *e, uint32_t replica, uint64_t first, uint64_t n,
+                                     void *dst, uint64_t cap, uint64_t *bytes, uint64_t *records)
+{
+    int rc = local_rep(e, replica);
+    if (rc) return rc;
+    if (!bytes || n > e->dir_cap || (cap && !dst)) return APUS_E_ARG;
+    if (e->batching) return APUS_E_STATE;
+    if ((rc = flush_tick(e))) return rc;
+    uint8_t *d_out = nullptr; uint64_t *d_res = nullptr;
+    if (hipMalloc(&d_out, cap + 16) != hipSuccess) return APUS_E_NOMEM;
+    if (hipMalloc(&d_res, 16) != hipSuccess) { hipFree(d_out); return APUS_E_NOMEM; }
+    hipLaunchKernelGGL(k_store_stream, dim3(1), dim3(1024), 0, e->stream, e->d, replica, first, n, d_out, cap, d_res);
+    uint64_t res[2] = {0, 0};
+    hipError_t he = hipGetLastError();
+    if (he == hipSuccess) he = hipMemcpyAsync(res, d_res, 16, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess && cap) he = hipMemcpy(dst, d_out, res[0] < cap ? res[0] : cap, hipMemcpyDeviceToHost);
+    hipFree(d_out); hipFree(d_res);
+    if (he != hipSuccess) return APUS_E_HIP;
+    *bytes = res[0];
+    if (records) *records = res[1];
     return 0;
 }
 

@@ -211,6 +211,18 @@ class Engine:
         self._chk(self.L.apus_gpu_append_control(self.h, type_, C.cast(buf, C.c_void_p) if buf else None),
                   "append_control")
 
+    def store_stream(self, r: int, first: int, n: int) -> tuple:
+        """(bytes, records): what proxy_store_cmd hands to BerkeleyDB for entry slots [first, first + n)"""
+        total, recs = C.c_uint64(0), C.c_uint64(0)
+        cap = 32 * n + 4096
+        while True:
+            buf = C.create_string_buffer(cap)
+            self._chk(self.L.apus_gpu_store_stream(self.h, r, first, n, buf, cap, C.byref(total), C.byref(recs)),
+                      "store_stream")
+            if total.value <= cap:
+                return buf.raw[:total.value], int(recs.value)
+            cap = total.value
+
     def run_rounds(self, r0: int, n: int):
         self._chk(self.L.apus_gpu_run_rounds(self.h, r0, n), "run_rounds")
 

@@ -614,3 +614,38 @@ uint64_t apus_proxy_highest_rec(struct proxy_node_t *p)
 
 /* 1 once requests were dropped because the log is full (admission is closed from then on) */
 int apus_proxy_failed(void) { return g_smr.failed; }
+
+/* stablestorage_load_records, src/proxy/proxy.c:306-339: a snapshot is the stored records back to back;
+ * every record goes back into the store and is replayed into the application.  Record layout =
+ * proxy_msg_header {u16 connection_id; u8 action; pad} (proxy.h:57-60); a SEND record is
+ * sizeof(proxy_send_msg) = 24 bytes + data.cmd.len, data at +8 of the record (proxy.h:83-91). */
+int apus_snapshot_replay(const void *buf, uint32_t size,
+                         void (*store)(const void *rec, uint32_t n, void *arg),
+                         proxy_do_action_cb_t do_action, void *arg)
+{
+    const uint8_t *b = (const uint8_t *)buf;
+    uint32_t len = 0;
+    int records = 0;
+    while (len < size) {
+        if (size - len < 4) return -1;
+        const uint8_t *rec = b + len;
+        uint16_t conn; memcpy(&conn, rec, 2);
+        const uint8_t action = rec[2];
+        uint32_t n;
+        if (action == PROXY_SEND) {
+            if (size - len < 24) return -1;
+            uint16_t cmd_len; memcpy(&cmd_len, rec + 8, 2);
+            n = 24u + cmd_len;
+            if (size - len < n) return -1;
+            if (store) store(rec, n, arg);
+            if (do_action) do_action(conn, PROXY_SEND, cmd_len, (void *)(rec + 10), arg);
+        } else if (action == PROXY_CONNECT || action == PROXY_CLOSE) {
+            n = 4;
+            if (store) store(rec, n, arg);
+            if (do_action) do_action(conn, action, 0, NULL, arg);
+        } else return -1;
+        len += n;
+        records++;
+    }
+    return records;
+}

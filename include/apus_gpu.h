@@ -276,6 +276,14 @@ int  apus_gpu_round_record(apus_engine_t *e, uint64_t first, uint64_t n, uint64_
 uint64_t apus_gpu_round_count(apus_engine_t *e);
 /* apply stream records of slots [first, first+n) of one replica */
 int  apus_gpu_apply_records(apus_engine_t *e, uint32_t replica, uint64_t first, uint64_t n, apus_apply_t *out);
+/* Durability side channel: the records persist_new_entries -> proxy_store_cmd -> stablestorage_save_request
+ * (src/dare/dare_server.c:1802, src/proxy/proxy.c:268-291) appends to BerkeleyDB for entry slots
+ * [first, first + n) of `replica`, back to back = the bytes of dump_records / a joiner's snapshot
+ * (proxy.c:300-304).  The reference's layout incl. its overlay: CONNECT / CLOSE 4 bytes,
+ * SEND 24 + (reply[4] | reply[5] << 8) bytes from clt_id on.  *bytes = total size (nothing beyond cap is
+ * written), *records = number of records.  Synchronises. */
+int  apus_gpu_store_stream(apus_engine_t *e, uint32_t replica, uint64_t first, uint64_t n,
+                           void *dst, uint64_t cap, uint64_t *bytes, uint64_t *records);
 uint32_t apus_gpu_status(apus_engine_t *e);
 void apus_gpu_clear_status(apus_engine_t *e);
 /* raw device pointers for zero-copy wrapping by the host transport (RCCL p2p):

@@ -79,6 +79,20 @@ void     apus_proxy_shutdown(struct proxy_node_t *p);       /* stop the DARE thr
 uint64_t apus_proxy_highest_rec(struct proxy_node_t *p);    /* proxy->highest_rec (proxy.h:47) as the device publishes it */
 int      apus_proxy_failed(void);                           /* 1 once requests were dropped because the log is full */
 
+/* ---- durability side channel (snapshot of a joiner's donor) ------------------------------- */
+/* The snapshot the reference ships to a joining server is the BerkeleyDB records back to back
+ * (stablestorage_dump_records, src/proxy/proxy.c:300-304) = the stream apus_gpu_store_stream
+ * (apus_gpu.h) regenerates from a replica's HBM.  This is the other end: stablestorage_load_records
+ * (proxy.c:306-339) -- walk the records (CONNECT / CLOSE 4 bytes; SEND sizeof(proxy_send_msg) = 24 +
+ * the u16 at +8, the reference's overlay), hand each to `store` (what store_record
+ * gets: pointer + size; may be NULL) and replay it through `do_action` (connection id, action,
+ * data.cmd.len, data.cmd.cmd -- both read at the overlay's place, as the reference does).
+ * Returns the number of records, -1 on a malformed stream (an action that is none of the three, or a
+ * record that runs past `size`; the reference would run off the buffer there). */
+int apus_snapshot_replay(const void *buf, uint32_t size,
+                         void (*store)(const void *rec, uint32_t n, void *arg),
+                         proxy_do_action_cb_t do_action, void *arg);
+
 /* action codes carried in entry->type, proxy.h:10-12 */
 #define PROXY_CONNECT 4
 #define PROXY_SEND    5

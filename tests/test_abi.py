@@ -13,7 +13,7 @@ def declared_symbols():
         txt = open(os.path.join(ROOT, "include", hdr)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         txt = re.sub(r"typedef[^;]*;", "", txt)
-        names += re.findall(r"\b((?:apus_gpu_|apus_tailq_|dare_ib_|dare_server_|proxy_(?:init|on_)|is_leader|get_node_id)\w*)\s*\(", txt)
+        names += re.findall(r"\b((?:apus_gpu_|apus_tailq_|apus_snapshot_|apus_proxy_|dare_ib_|dare_server_|proxy_(?:init|on_)|is_leader|get_node_id)\w*)\s*\(", txt)
     return sorted(set(names))
 
 

@@ -638,3 +638,60 @@ def test_join_is_refused_where_the_reference_cannot_do_it(eng_factory):
     with pytest.raises(EngineError):
         eng.join(4)                       # no <HEAD> entry since the followers dumped their state machines
     eng.check_status()
+
+
+def _split_records(stream: bytes):
+    """cut a store stream into its records (apus_snapshot_replay's walk)"""
+    recs, i = [], 0
+    while i < len(stream):
+        typ = stream[i + 2]
+        n = 4 if typ in (4, 6) else 24 + (stream[i + 8] | stream[i + 9] << 8)
+        recs.append(stream[i:i + n]); i += n
+    assert i == len(stream)
+    return recs
+
+
+@pytest.mark.parametrize("name", ["steady3", "steady5_unaligned", "hold_release", "c5_rejoin"])
+def test_store_stream_matches_the_reference_records(eng_factory, name):
+    """the records proxy_store_cmd hands to BerkeleyDB (= the snapshot a joiner's donor
+    ships), regenerated from a replica's HBM (apus_gpu_store_stream), against the oracle's stream (pinned
+    byte for byte on the reference, tests/golden/cluster_ref.json).  Compared: record boundaries and
+    sizes (incl. the overlay that takes a SEND record's length from reply[4..5] -- hold_release: server 2
+    persists bytes that carry server 4's ACK), clt_id, type, reply[] and what follows; `sender` where the
+    server did not append the entry itself (the leader's callback runs before the stamp: the byte of the
+    lap before) and not the struct padding 41..47 (never written by log_append_entry)."""
+    from tests import traces
+    from tests.parity import lockstep
+    tr = traces.CATALOGUE[name]()
+    eng = eng_factory(tr.group_size, tr.log_len)
+    cl = lockstep(tr, eng, check_at=("QUIESCE",))
+    for r in range(cl.n):
+        if not (eng.reachable >> r) & 1:
+            continue
+        c = eng.counters(r)
+        o = cl.log(r).offsets()
+        # the entries this replica still holds: slots [head_slot, n_end)
+        ring = cl.log(r).ring()
+        n_live, off = 0, o["head"]
+        while off != o["end"]:
+            if o["len"] - off < 64:
+                off = 0
+                continue
+            typ = int(ring[off + 26])
+            ln = 64 if typ in (0, 2, 3) else 64 + int(ring[off + 48]) + (int(ring[off + 49]) << 8)
+            if o["len"] - off < ln:
+                off = 0
+                continue
+            off += ln; n_live += 1
+        got, n_rec = eng.store_stream(r, c["n_end"] - n_live, n_live)
+        want_all = _split_records(cl.store_stream(r))
+        g = _split_records(got)
+        assert len(g) == n_rec and n_rec > 0
+        w = want_all[-len(g):]
+        assert [len(x) for x in g] == [len(x) for x in w], f"replica {r}: record sizes differ"
+        for a, b in zip(g, w):
+            assert a[:3] == b[:3], f"replica {r}: clt_id / type differ"
+            if len(a) > 4:
+                assert a[4:17] == b[4:17] and a[24:] == b[24:], f"replica {r}: reply[] / overlay tail differ"
+            if b[3] != r and a[3] != r:
+                assert a[3] == b[3], f"replica {r}: sender differs"
