@@ -1338,6 +1338,82 @@ extern "C" int apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_
     return 0;
 }
 
+/* ---- force_log_pruning (dare_server.c:2069-2122) ------------------------------------------------ */
+/* Closes every leader pass in the reference: once the log is 75 % full the server whose sampled apply
+ * offset holds the head back is REMOVED from the configuration (a CONFIG entry; the slip at :2113 --
+ * apply_offsets[size] instead of [target] -- included), then log_pruning runs (head, <HEAD> entry, the
+ * apply offsets are read again).  What it appends is committed by the NEXT pass.  One workgroup; the
+ * decision on the device, from the leader's control block.  out: [0] 1 when the log was 75 % full,
+ * [1] the server removed (0xFF none), [2] entries appended, [3] the bitmask afterwards. */
+__global__ __launch_bounds__(128) void k_force_prune(const EngDev E, uint64_t epoch, uint32_t sample_mask, uint64_t *out)
+{
+    __shared__ uint64_t s_lh[64];
+    __shared__ uint32_t s_go;
+    const uint32_t tid = threadIdx.x;
+    const RepDev &Ld = E.rep[E.leader];
+    uint64_t *hdr = Ld.hdr;
+    const uint64_t L = E.log_len;
+    if (tid < 64) s_lh[tid] = hdr[tid];
+    if (tid == 0) s_go = 0;
+    __syncthreads();
+    if (tid == 0) {
+        out[0] = 0; out[1] = 0xFF; out[2] = 0; out[3] = s_lh[H_CID_BITMASK];
+        const uint64_t end = s_lh[H_END];
+        const uint64_t log_size = apus_end_distance(end, L, s_lh[H_HEAD]);
+        if (!((double)log_size < 0.75 * (double)L)) {                           /* :2075 */
+            out[0] = 1; s_go = 1;
+            const uint32_t size = E.group_size;
+            uint32_t target = E.leader, bitmask = (uint32_t)s_lh[H_CID_BITMASK];
+            uint64_t min_off = s_lh[H_APPLY];
+            for (uint32_t i = 0; i < size; i++)
+                if (apus_is_larger(end, L, min_off, s_lh[H_APPLY_OFFSETS + i])) { min_off = s_lh[H_APPLY_OFFSETS + i]; target = i; }
+            uint32_t appended = 0;
+            if (target != E.leader && ((bitmask >> target) & 1u)) {
+                bitmask &= ~(1u << target);                                     /* CID_SERVER_RM + dare_ib_disconnect_server */
+                const uint64_t d1 = (uint64_t)size | ((uint64_t)bitmask << 32); /* size[0], size[1] = 0, state STABLE, pad, bitmask */
+                appended += control_append<true>(E, 0, APUS_CONFIG, epoch, d1, 0, s_lh, *E.rec_count, 0, false).n;
+                s_lh[H_CID_BITMASK] = bitmask;
+                if (size < APUS_DEV_MAX_SERVERS) { s_lh[H_APPLY_OFFSETS + size] = s_lh[H_APPLY]; hdr[H_APPLY_OFFSETS + size] = s_lh[H_APPLY]; }
+                out[1] = target;
+            }
+            appended += control_append<true>(E, 1, APUS_HEAD, 0, 0, 0, s_lh, *E.rec_count, 0, false).n;   /* log_pruning :1996-2067 */
+            out[2] = appended; out[3] = bitmask;
+            /* the reference takes this pass's end / commit record behind force_log_pruning */
+            const uint64_t rc = *E.rec_count;
+            if (appended && rc > 0 && rc - 1 < E.rec_cap) E.rec_end[rc - 1] = s_lh[H_END];
+        }
+    }
+}
+
+/* rc_get_remote_apply_offsets (dare_ibv_rc.c:1970-2034) behind it, with the configuration as it is now: a
+ * launch of its own -- one lane per server, the leader's control block read afresh */
+__global__ __launch_bounds__(64) void k_force_sample(const EngDev E, uint32_t sample_mask, const uint64_t *out)
+{
+    __shared__ uint64_t s_lh[64];
+    if (!out[0]) return;
+    s_lh[threadIdx.x] = E.rep[E.leader].hdr[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < APUS_DEV_MAX_SERVERS) sample_apply_offsets(E, s_lh, sample_mask, threadIdx.x, nullptr);
+}
+
+extern "C" int apus_gpu_force_prune(apus_engine_t *e, uint64_t out[4])
+{
+    if (!e || !out) return APUS_E_ARG;
+    if (e->live_R) { int rc_ = flush_live(e); if (rc_) return rc_; }
+    if (e->batching) return APUS_E_STATE;
+    int rc = need_leader(e);
+    if (rc) return rc;
+    if ((rc = flush_tick(e))) return rc;
+    hipLaunchKernelGGL(k_force_prune, dim3(1), dim3(128), 0, e->stream, e->d, e->cid_epoch, sync_mask(e), e->d_elect + 16);
+    hipLaunchKernelGGL(k_force_sample, dim3(1), dim3(64), 0, e->stream, e->d, sync_mask(e), e->d_elect + 16);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, e->d_elect + 16, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (out[2]) { e->free_lb = 0; e->lag_possible = true; }
+    if (out[1] != 0xFF) { e->reachable &= ~(1u << out[1]); e->d.reachable = e->reachable; }
+    return 0;
+}
+
 /* ---- graphs ----------------------------------------------------------------- */
 extern "C" int apus_gpu_capture_begin(apus_engine_t *e)
 {

@@ -228,6 +228,14 @@ class Engine:
 
     def tick_prune(self): self._chk(self.L.apus_gpu_tick_prune(self.h), "tick_prune")
 
+    def force_prune(self) -> dict:
+        """force_log_pruning (dare_server.c:2069-2122) behind a leader pass: returns what it did"""
+        out = (C.c_uint64 * 4)()
+        self._chk(self.L.apus_gpu_force_prune(self.h, out), "force_prune")
+        if out[1] != 0xFF:
+            self.bitmask = int(out[3])
+        return {"full": bool(out[0]), "removed": None if out[1] == 0xFF else int(out[1]), "appended": int(out[2])}
+
     def batch_begin(self): self._chk(self.L.apus_gpu_batch_begin(self.h), "batch_begin")
     def batch_end(self): self._chk(self.L.apus_gpu_batch_end(self.h), "batch_end")
     def quiesce(self): self._chk(self.L.apus_gpu_quiesce(self.h), "quiesce")

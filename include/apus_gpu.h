@@ -199,6 +199,13 @@ int  apus_gpu_append_control(apus_engine_t *e, uint8_t type, const void *data);
 int  apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rounds);
 /* log_pruning() timer tick (dare_server.c:1996-2067) incl. the R8 apply-offset gather */
 int  apus_gpu_tick_prune(apus_engine_t *e);
+/* force_log_pruning() (dare_server.c:2069-2122), the check that closes every leader pass of the
+ * reference: at 75 % fill the server whose sampled apply offset holds the head back is removed from the
+ * configuration (CONFIG entry), then the log is pruned.  Decided on the device.  out[0] = 1 when the log
+ * was that full, out[1] = the server removed (0xFF: none), out[2] = entries appended (they commit with the
+ * next pass), out[3] = the bitmask afterwards.  Synchronises; for per-pass operation (inside a batch the
+ * engine refuses what does not fit instead). */
+int  apus_gpu_force_prune(apus_engine_t *e, uint64_t out[4]);
 /* Batching: between _begin and _end, apus_gpu_run_rounds calls (and the prune ticks that
  * fall between them, which the engine defers into the next call's sequencer) are recorded and
  * then issued as multi-segment launches -- the same polling() passes in the same order, without a

@@ -695,3 +695,65 @@ def test_store_stream_matches_the_reference_records(eng_factory, name):
                 assert a[4:17] == b[4:17] and a[24:] == b[24:], f"replica {r}: reply[] / overlay tail differ"
             if b[3] != r and a[3] != r:
                 assert a[3] == b[3], f"replica {r}: sender differs"
+
+
+def _force_lockstep(tr, eng):
+    """one ABI call per leader pass, force_log_pruning behind every pass (the reference's polling() order,
+    dare_server.c:1095-1124), compared with the oracle at every quiescent event"""
+    from tests.parity import compare_all
+    cl = orc.Cluster(tr.group_size, tr.log_len, record_apply=True)
+    eng.reset(); eng.stage_trace(tr)
+    reqs = np.ascontiguousarray(tr.reqs, dtype=orc.REQ_DTYPE)
+
+    def settle():
+        for _ in range(64):
+            before = [eng.offsets(r) for r in range(tr.group_size)]
+            eng.quiesce(); eng.force_prune()
+            if before == [eng.offsets(r) for r in range(tr.group_size)]:
+                break
+
+    evicted = []
+    for i, ev in enumerate(tr.events):
+        op = ev[0]
+        if op == "ROUND":
+            cl.round(reqs[ev[1]:ev[1] + ev[2]], tr.arena)
+            eng.run_rounds(eng.round_of_g0[ev[1]], 1)
+            fp = eng.force_prune()
+            if fp["removed"] is not None:
+                evicted.append(fp["removed"])
+        elif op == "ELECT":
+            cl.elect(ev[1]); eng.elect(ev[1]); eng.force_prune()
+        elif op == "HOLD":
+            cl.hold(ev[1]); eng.hold(ev[1])
+        elif op == "RELEASE":
+            cl.release(ev[1]); eng.release(ev[1])
+        elif op == "PRUNE":
+            # orc_tick_prune: settle, the timer's log_pruning, and -- only when it appended a <HEAD> entry --
+            # the pass that commits it (with force_log_pruning behind it like behind every pass)
+            cl.tick_prune(); settle()
+            end0 = eng.offsets(eng.leader)["end"]
+            eng.tick_prune(); eng.sync()
+            if eng.offsets(eng.leader)["end"] != end0:
+                eng.force_prune()
+        elif op == "QUIESCE":
+            cl.quiesce(); settle()
+            eng.check_status()
+            live = [r for r in range(tr.group_size) if (eng.reachable >> r) & 1 and (eng.bitmask >> r) & 1]
+            compare_all(eng, cl, tag=f"event {i} {ev}", replicas=live)
+            assert eng.bitmask == cl.cid_bitmask(cl.leader)
+        else:
+            raise ValueError(ev)
+    return cl, evicted
+
+
+@pytest.mark.parametrize("name", ["no_quorum", "evict_slow_follower"])
+def test_force_log_pruning_evicts_the_slow_follower(eng_factory, name):
+    """SURVEY.md 8 f2, force_log_pruning (dare_server.c:2069-2122): followers that are cut off hold the head
+    back, the log fills to 75 %, the leader removes the server with the oldest sampled apply offset from
+    the configuration and prunes -- decided on the device (k_force_prune) behind every pass, pinned on the
+    reference (both traces are in tests/golden/cluster_ref.json with their evictions)."""
+    from tests import traces
+    tr = traces.CATALOGUE[name]()
+    eng = eng_factory(tr.group_size, tr.log_len)
+    cl, evicted = _force_lockstep(tr, eng)
+    assert cl.force_prunes > 0 and evicted, "the trace was meant to fill the log"

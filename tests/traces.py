@@ -80,6 +80,14 @@ def kill_follower():
     return _with_events(tr, {9: [("KILL", 3)]})
 
 
+def evict_slow_follower():
+    """one of three followers is cut off and stays so: the prune ticks cannot move the head past its apply
+    offset, the log fills to 75 % and force_log_pruning (dare_server.c:2069-2122) removes it from the
+    configuration; the other two go on and the ring wraps over where it was stuck"""
+    tr = T.steady_trace(3, 1200, 64, 4, 10, log_len=1 << 16, name="evict_slow_follower")
+    return _with_events(tr, {6: [("QUIESCE",), ("HOLD", 2)], 60: [("QUIESCE",)]})
+
+
 def park_commit_at_wrap():
     """Case-1 wrap (the header does not fit: 28 bytes left) with the commit pointer parked on it
     and NO quorum: update_remote_logs "commits" offset 0 (dare_ibv_rc.c:1725-1758) and
@@ -193,7 +201,7 @@ def join_then_failover():
                              50: [("QUIESCE",), ("KILL", 0), ("ELECT", 3), ("QUIESCE",)]})
 
 
-CATALOGUE = {f.__name__: f for f in (c5_rejoin, join_empty_slot, join_wrapped, join_upsize_3_to_5, join_then_failover, diverge_failover, double_failover_truncate, steady3, steady5_unaligned, steady7_mixed, c2_small, c3_small, c4_small,
+CATALOGUE = {f.__name__: f for f in (evict_slow_follower, c5_rejoin, join_empty_slot, join_wrapped, join_upsize_3_to_5, join_then_failover, diverge_failover, double_failover_truncate, steady3, steady5_unaligned, steady7_mixed, c2_small, c3_small, c4_small,
                                      c5_failover, hold_one_of_three, hold_release, no_quorum, no_quorum_prune,
                                      exact_fit, kill_follower, park_commit_at_wrap)}
 
