@@ -127,6 +127,11 @@ static inline uint32_t sync_mask(const apus_engine *e)
 }
 static inline int popc(uint32_t v) { return __builtin_popcount(v); }
 
+/* the term fence (k_fence_check): in front of every launch that stores into followers, where another
+ * process can move a follower to a newer term behind this leader's back */
+static inline bool fence_on(const apus_engine *e) { return e->imported_mask != 0 || (e->cfg.flags & 2u); }
+#define FENCE_CHECK(e, fm) do { if (fence_on(e) && (fm)) hipLaunchKernelGGL(k_fence_check, dim3(1), dim3(64), 0, (e)->stream, (e)->d, (fm)); } while (0)
+
 extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
 {
     if (!cfg || !out || cfg->group_size < 1 || cfg->group_size > APUS_MAX_SERVERS ||
@@ -453,6 +458,7 @@ static int launch_tail(apus_engine *e, uint64_t r0, uint32_t R, int mode, uint64
 static int launch_catchup(apus_engine *e)
 {
     const uint32_t fm = sync_mask(e);
+    FENCE_CHECK(e, fm);                         /* every launch path comes through here first */
     if (!fm || !e->lag_possible) return 0;      /* small lags are handled inside k_sequence / k_control_round */
     hipLaunchKernelGGL(k_catchup, dim3(128, popc(fm)), dim3(256), 0, e->stream, e->d, fm);
     HIPCHK(hipGetLastError());
@@ -646,7 +652,9 @@ static int flush_batch(apus_engine *e)
             tl = &e->timed[e->timed_used++];
             HIPCHK(hipEventRecord(tl->a, e->stream));
         }
-        hipLaunchKernelGGL(k_step, dim3(blk), dim3(256), 0, e->stream, e->d, T, fm, rm);
+        FENCE_CHECK(e, fm);
+        if (fence_on(e)) hipLaunchKernelGGL(k_step_fenced, dim3(blk), dim3(256), 0, e->stream, e->d, T, fm, rm);
+        else hipLaunchKernelGGL(k_step, dim3(blk), dim3(256), 0, e->stream, e->d, T, fm, rm);
         if (tl) HIPCHK(hipEventRecord(tl->b, e->stream));
         i += consumed;
         if (have_rest) e->batch[i] = split_rest;       /* the rest of the segment that was cut opens the next launch */
@@ -696,7 +704,8 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
         }
         /* the whole call in one launch: sequencer, append + push, per-round records, bookkeeper,
          * persist + ACK scan, apply (k_call's block roles) */
-        hipLaunchKernelGGL(k_call, dim3(blocks), dim3(256), 0, e->stream, e->d, a, fm, rm);
+        if (fence_on(e)) hipLaunchKernelGGL(k_call_fenced, dim3(blocks), dim3(256), 0, e->stream, e->d, a, fm, rm);
+        else hipLaunchKernelGGL(k_call, dim3(blocks), dim3(256), 0, e->stream, e->d, a, fm, rm);
         if (tl) HIPCHK(hipEventRecord(tl->b, e->stream));
     }
     HIPCHK(hipGetLastError());
@@ -814,7 +823,8 @@ static int flush_live(apus_engine *e)
     a.nS = cap_grid(e->live_n, 256, 32); a.nA = cap_grid(e->live_n, 1024, 16); a.nR = cap_grid(R, 256, 8);
     a.SP = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (e->live_bytes / 16 / R + e->sp_units * 2 / 3) / e->sp_units));
     a.GP = 1;                                      /* (no staged byte prefix on the live path) */
-    hipLaunchKernelGGL(k_call, dim3(1 + R * a.SP + a.nR + 1 + a.nS + a.nA * popc(rm)), dim3(256), 0, e->stream, view, a, fm, rm);
+    if (fence_on(e)) hipLaunchKernelGGL(k_call_fenced, dim3(1 + R * a.SP + a.nR + 1 + a.nS + a.nA * popc(rm)), dim3(256), 0, e->stream, view, a, fm, rm);
+    else hipLaunchKernelGGL(k_call, dim3(1 + R * a.SP + a.nR + 1 + a.nS + a.nA * popc(rm)), dim3(256), 0, e->stream, view, a, fm, rm);
     e->live_R = 0;
     HIPCHK(hipGetLastError());
     return 0;
@@ -1638,7 +1648,7 @@ extern "C" void apus_gpu_clear_status(apus_engine_t *e)
 {
     if (!e) return;
     hipStreamSynchronize(e->stream);
-    hipMemset(e->d.status, 0, 2 * sizeof(uint32_t));
+    hipMemset(e->d.status, 0, 3 * sizeof(uint32_t));      /* bits, spin site, fence word */
     e->host_status = 0;
 }
 
@@ -1913,6 +1923,25 @@ __global__ void k_follow(const EngDev E, uint32_t f, uint64_t sid, uint32_t bitm
     if (threadIdx.x || blockIdx.x) return;
     uint64_t *fh = E.rep[f].hdr;
     fh[H_SID] = sid; fh[H_TAIL] = E.log_len; fh[H_CID_BITMASK] = bitmask;
+}
+
+/* a server adopts a SID it heard of: its vote for a candidate (poll_vote_requests, dare_server.c:1690) or
+ * the heartbeat of a leader of a newer term (hb_receive_cb :903-910), when that candidate / leader is
+ * driven by ANOTHER engine; from then on launches of a leader of an older term are fenced off */
+__global__ void k_adopt_sid(const EngDev E, uint32_t f, uint64_t sid)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    if (E.rep[f].hdr[H_SID] < sid) E.rep[f].hdr[H_SID] = sid;
+}
+
+extern "C" int apus_gpu_adopt_sid(apus_engine_t *e, uint32_t replica, uint64_t sid)
+{
+    int rc = local_rep(e, replica);
+    if (rc) return rc;
+    if (e->batching) return APUS_E_STATE;
+    hipLaunchKernelGGL(k_adopt_sid, dim3(1), dim3(64), 0, e->stream, e->d, replica, sid);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 extern "C" int apus_gpu_follow(apus_engine_t *e, uint32_t replica, uint32_t leader, uint64_t term, uint32_t bitmask)

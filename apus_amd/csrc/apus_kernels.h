@@ -169,6 +169,7 @@ __device__ static inline void catchup_range(const EngDev &E, int f, uint64_t end
  * by a lot (RELEASE after a HOLD).  grid.y = follower ordinal in fmask.        */
 __global__ __launch_bounds__(256) void k_catchup(const EngDev E, uint32_t fmask)
 {
+    if (E.status[2]) return;                          /* the term fence (k_fence_check) */
     int f = -1;
     for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
         if (fmask & (1u << i)) { if (k == (int)blockIdx.y) { f = i; break; } k++; }
@@ -3090,6 +3091,69 @@ __global__ APUS_CALL_BOUNDS void k_step(const EngDev E_arg, const StepTable T, u
     call_block<true>(E, X, T.seg[seg], push_mask, rmask, b_grid, sq, l, seg, T.S, &T);
 }
 
+/* ---- the term fence ---------------------------------------------------------------------------- */
+/* The reference fences a deposed leader in the RECEIVER's NIC: a server that votes for, or hears from, a
+ * leader of a newer term resets its LOG QPs towards everybody else (rc_revoke_log_access,
+ * dare_ibv_rc.c:2156-2243), the old leader's WRITEs bounce (IBV_WC_RETRY_EXC_ERR).  Peer-mapped HBM has
+ * no receiver that could refuse a store, so the check sits in front of the writer's launch, on the
+ * device: k_fence_check compares the SID in every pushed follower's control block (written by its own
+ * process, or by the winner of an election through the mapping: k_elect / k_set_roles) with the
+ * leader's; a follower that has moved on to a newer term raises APUS_ST_TERM_FENCE and the fence word
+ * (status[2]), and every workgroup of the launches behind it leaves before its first store -- the
+ * deposed leader's batch lands nowhere, its own log included (the reference would still append
+ * locally; those entries could never commit and are cut by the next leader's log adjustment).
+ * Launched only where another process can change a follower's term (peer-mapped groups,
+ * APUS_F_TERM_FENCE); the unfenced kernels are the same code without the load. */
+#define FENCE_WORD 2
+__global__ __launch_bounds__(64) void k_fence_check(const EngDev E, uint32_t push_mask)
+{
+    const uint32_t i = threadIdx.x;
+    bool newer = false;
+    if (i < APUS_DEV_MAX_SERVERS && ((push_mask >> i) & 1u) && E.rep[i].ring && E.leader < APUS_DEV_MAX_SERVERS)
+        newer = (E.rep[i].hdr[H_SID] >> 9) > (E.rep[E.leader].hdr[H_SID] >> 9);
+    if (__ballot(newer) && i == 0) { atomicOr(E.status, 1u << 2); E.status[FENCE_WORD] = 1; }
+}
+
+__global__ APUS_CALL_BOUNDS void k_call_fenced(const EngDev E_arg, const CallArgs A, uint32_t push_mask, uint32_t rmask)
+{
+    if (E_arg.status[FENCE_WORD]) return;
+    __shared__ EngDev E_s;
+    stage_engine(E_s);
+    const EngDev &E = E_s;
+    __shared__ SeqLds sq;
+    __shared__ CallLds l;
+    const CallEnv X = APUS_ENV_OF(E);
+    call_block<false>(E, X, A, push_mask, rmask, blockIdx.x, sq, l, 0, 1);
+}
+
+__global__ APUS_CALL_BOUNDS void k_step_fenced(const EngDev E_arg, const StepTable T, uint32_t push_mask, uint32_t rmask)
+{
+    if (E_arg.status[FENCE_WORD]) return;
+    __shared__ EngDev E_s;
+    stage_engine(E_s);
+    const EngDev &E = E_s;
+    __shared__ SeqLds sq;
+    __shared__ CallLds l;
+    uint32_t seg = 0, b_grid;
+    if (T.order == 0) {
+        for (uint32_t k = 1; k < T.S; k++) if (blockIdx.x >= T.blk0[k]) seg = k;
+        b_grid = blockIdx.x - T.blk0[seg];
+    } else {
+        const uint32_t b = blockIdx.x;
+        if (b < T.S) { seg = b; b_grid = 0; }
+        else if (b < 2 * T.S) { seg = b - T.S; b_grid = 1; }
+        else if (b < T.sv0[0]) {
+            for (uint32_t k = 1; k < T.S; k++) if (b >= T.ab0[k]) seg = k;
+            b_grid = 2 + (b - T.ab0[seg]);
+        } else {
+            for (uint32_t k = 1; k < T.S; k++) if (b >= T.sv0[k]) seg = k;
+            b_grid = 2 + call_append_blocks(T.seg[seg]) + (b - T.sv0[seg]);
+        }
+    }
+    const CallEnv X{E.step_lines + (size_t)seg * 1024, E.step_tickets + (size_t)seg * 32, E.step_hash + (size_t)seg * 2 * 1024};
+    call_block<true>(E, X, T.seg[seg], push_mask, rmask, b_grid, sq, l, seg, T.S, &T);
+}
+
 /* READ the apply offset of peer i for the next prune tick (rc_get_remote_apply_offsets,
  * dare_ibv_rc.c:1970-2034); one lane per peer, s_lh = the leader's control block
  * as it was before the tick */
@@ -3213,6 +3277,7 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode_
      * whole join is one record, as in the schedule the oracle is pinned on), 32 = record end / commit as
      * they are after this pass even though it appended nothing (the pass that closes a JOIN) */
     const int mode = mode_flags & 7;
+    if (E.status[2]) return;                          /* the term fence (k_fence_check) */
     const uint64_t rec0 = *E.rec_count;
     const RepDev &Ld = E.rep[E.leader];
     uint64_t *hdr = Ld.hdr;
@@ -3336,7 +3401,7 @@ __global__ void k_reset(const EngDev E)
     if (p == 0) {
         /* the engine's own scratch (not gated on hosting replica 0: a process of a multi-process
          * group hosts only its own replica) */
-        *E.rec_count = 0; *E.status = 0; E.status[1] = 0;
+        *E.rec_count = 0; *E.status = 0; E.status[1] = 0; E.status[2] = 0;
         for (int i = 0; i < 8; i++) E.ticket[i] = 0;
         for (int i = 0; i < 32; i++) { E.tick_lines[i * 32] = 0; E.tick_lines[i * 32 + 1] = 0; E.tick_lines[i * 32 + 2] = 0; }
         for (int i = 0; i < 32; i++) { E.step_epoch[i * 32] = 0; E.step_seq_done[i * 32] = 0; }

@@ -110,6 +110,13 @@ typedef struct {
  * (update_remote_logs, src/dare/dare_ibv_rc.c:1725-1758).  Results are identical; only the
  * schedule inside a call differs (bench.py reports this path as `ack_aggregation_path`). */
 #define APUS_F_NO_FUSED_ACKS 1u
+/* The term fence in front of every launch that stores into followers (k_fence_check): a follower whose
+ * control block shows a SID of a NEWER term than the leader's -- it voted for, or heard from, a leader
+ * driven by another engine -- fences this leader off: APUS_ST_TERM_FENCE is raised and the launches behind
+ * the check store nothing anywhere (the receiver-side QP reset of the reference, rc_revoke_log_access
+ * src/dare/dare_ibv_rc.c:2156-2243, moved in front of the writer).  Always on in peer-mapped groups
+ * (replicas imported with apus_gpu_import_replica); this flag turns it on for a single process. */
+#define APUS_F_TERM_FENCE 2u
 
 typedef struct apus_engine apus_engine_t;
 
@@ -183,6 +190,10 @@ int  apus_gpu_set_group_size(apus_engine_t *e, uint32_t n);
  * passes, then it is a follower like the others.  reachable = who answers.  out[0] = new bitmask,
  * out[1] = new group size, out[2] = new epoch.  One per-round record for the whole join. */
 int  apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_t bitmask, uint32_t reachable, uint64_t out[4]);
+/* replica adopts a SID it heard of from a candidate / leader that ANOTHER engine drives (its vote,
+ * poll_vote_requests src/dare/dare_server.c:1690; a heartbeat of a newer term, hb_receive_cb :903-910);
+ * never lowers the SID.  A leader of an older term is fenced off from then on (APUS_F_TERM_FENCE). */
+int  apus_gpu_adopt_sid(apus_engine_t *e, uint32_t replica, uint64_t sid);
 /* reachability of peers from the leader (KILL / HOLD / RELEASE of the trace;
  * fail_count >= PERMANENT_FAILURE or rc_connected == 0 in the reference) */
 int  apus_gpu_set_reachable(apus_engine_t *e, uint32_t mask);

@@ -757,3 +757,40 @@ def test_force_log_pruning_evicts_the_slow_follower(eng_factory, name):
     eng = eng_factory(tr.group_size, tr.log_len)
     cl, evicted = _force_lockstep(tr, eng)
     assert cl.force_prunes > 0 and evicted, "the trace was meant to fill the log"
+
+
+@pytest.mark.parametrize("batch", [False, True])
+def test_term_fence_a_deposed_leader_stores_nothing(eng_factory, batch):
+    """rc_revoke_log_access (dare_ibv_rc.c:2156-2243) as a check on the device in front of the writer: a
+    follower adopts the SID of a newer term behind the leader's back (its vote for a candidate that another
+    engine drives); the old leader's next launches raise APUS_ST_TERM_FENCE and store nothing -- not into the
+    followers' logs, not into its own; what was committed before stays bit-identical to the oracle's."""
+    from apus_amd.engine import EngineError
+    from tests.parity import compare_all
+    tr = T.steady_trace(3, 600, 64, 4, 10, log_len=1 << 18, name="fence", prune_bytes=1 << 30)
+    eng = eng_factory(3, tr.log_len, flags=2)                    # APUS_F_TERM_FENCE
+    cl = orc.Cluster(3, tr.log_len)
+    eng.reset(); eng.stage_trace(tr)
+    reqs = np.ascontiguousarray(tr.reqs, dtype=orc.REQ_DTYPE)
+    rounds = [e for e in tr.events if e[0] == "ROUND"]
+    cl.elect(0); eng.elect(0)
+    for e in rounds[:20]:
+        cl.round(reqs[e[1]:e[1] + e[2]], tr.arena)
+    eng.run_rounds(0, 20); eng.quiesce(); cl.quiesce()
+    compare_all(eng, cl, tag="before the fence")
+    before = [eng.offsets(r) for r in range(3)]
+    ring0 = eng.ring(0).copy()
+    # server 2 votes for a candidate of term 4 that some other engine drives
+    assert eng.L.apus_gpu_adopt_sid(eng.h, 2, (4 << 9) | 1) == 0
+    if batch:
+        eng.batch_begin()
+    eng.run_rounds(20, 10)
+    if batch:
+        eng.batch_end()
+    eng.quiesce()
+    assert eng.status() & 4, "APUS_ST_TERM_FENCE was not raised"
+    with pytest.raises(EngineError):
+        eng.check_status()
+    assert [eng.offsets(r) for r in range(3)] == before, "a fenced launch moved an offset"
+    assert np.array_equal(eng.ring(0), ring0), "a fenced launch stored into the deposed leader's own log"
+    assert eng.counters(2)["sid"] == (4 << 9) | 1
