@@ -17,9 +17,12 @@
  *    in-process stand-ins for <infiniband/verbs.h>, <ev.h> and <libconfig.h>
  *    (oracle/refshim/, recipe oracle/Makefile `loops`): one private copy per
  *    server, a shared in-process fabric, driven one polling() pass at a time.
- *    tests/test_oracle_vs_refloops.py replays 16 named traces + BASELINE configs[1]
- *    at full size on both in lock step (all offsets, every defined ring byte, SID,
- *    counters, apply upcalls, the leader's end/commit after every pass); the same
+ *    tests/test_oracle_vs_refloops.py replays 22 named traces (steady state, hold /
+ *    release, no quorum, fail-overs with divergence and truncation, JOIN into an empty
+ *    slot / extending the group / while the log wraps, force_log_pruning evictions)
+ *    + BASELINE configs[1] at full size on both in lock step (all offsets, every
+ *    defined ring byte, SID, configuration, counters, apply upcalls, the bytes handed
+ *    to the storage callback, the leader's end/commit after every pass); the same
  *    records are committed as tests/golden/cluster_ref.json (written from the
  *    reference's outputs by tests/golden/make_cluster_golden.py) and travel to
  *    the GPU box.
