@@ -80,6 +80,8 @@ SIGNATURES = {
     "apus_gpu_store_stream": (C.c_int, [vp, u32, u64, u64, vp, u64, C.POINTER(u64), C.POINTER(u64)]),
     "apus_gpu_force_prune": (C.c_int, [vp, C.POINTER(u64)]),
     "apus_gpu_adopt_sid": (C.c_int, [vp, u32, u64]),
+    "apus_gpu_clear_replica": (C.c_int, [vp, u32]),
+    "apus_gpu_set_config": (C.c_int, [vp, u32, u64]),
     "apus_gpu_set_group_size": (C.c_int, [vp, u32]),
     "apus_gpu_join": (C.c_int, [vp, u32, u16, u32, u32, C.POINTER(u64)]),
     "apus_gpu_batch_begin": (C.c_int, [vp]),

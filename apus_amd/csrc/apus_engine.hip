@@ -284,6 +284,27 @@ extern "C" int apus_gpu_set_group_size(apus_engine_t *e, uint32_t n)
     return 0;
 }
 
+/* a machine that (re)joins starts from log_new() (dare_log.h:120-136): its own process zeroes the replica
+ * it hosts before the leader's apus_gpu_join recovers it (a peer's memory is never cleared from here) */
+extern "C" int apus_gpu_clear_replica(apus_engine_t *e, uint32_t r)
+{
+    if (!e || r >= e->cfg.group_size || !e->d.rep[r].ring || ((e->imported_mask >> r) & 1u)) return APUS_E_STATE;
+    if (e->batching) return APUS_E_STATE;
+    HIPCHK(hipMemsetAsync(e->d.rep[r].ring, 0, e->d.log_len + 4096, e->stream));
+    HIPCHK(hipMemsetAsync(e->d.rep[r].ack, 0, sizeof(uint32_t) * e->dir_cap, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+/* the configuration as another rank's leader changed it (a JOIN it carried out): size and epoch */
+extern "C" int apus_gpu_set_config(apus_engine_t *e, uint32_t group_size, uint64_t epoch)
+{
+    int rc = apus_gpu_set_group_size(e, group_size);
+    if (rc) return rc;
+    e->cid_epoch = epoch;
+    return 0;
+}
+
 extern "C" int apus_gpu_reset(apus_engine_t *e)
 {
     if (!e) return APUS_E_ARG;
@@ -1301,7 +1322,8 @@ extern "C" int apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_
     const uint32_t size = e->d.group_size, leader = e->d.leader;
     uint32_t empty = size;
     for (int i = (int)size - 1; i >= 0; i--) if (!((bitmask >> i) & 1u)) empty = (uint32_t)i;   /* dare_ibv_ud.c:995-1021 */
-    if (empty != r || !e->d.rep[r].ring || ((e->imported_mask >> r) & 1u)) return APUS_E_STATE;
+    if (empty != r || !e->d.rep[r].ring) return APUS_E_STATE;
+    const bool peer_owned = (e->imported_mask >> r) & 1u;      /* its process cleared it (apus_gpu_clear_replica) */
     int donor = -1, src = -1;
     for (uint32_t i = 0; i < size; i++) {
         if (i == r || !((bitmask >> i) & 1u) || !((reachable >> i) & 1u) || !e->d.rep[i].ring) continue;
@@ -1333,8 +1355,10 @@ extern "C" int apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_
     }
     /* joiner side */
     uint64_t *jw = e->d_elect + 8;                            /* scratch words behind k_elect's verdict */
-    HIPCHK(hipMemsetAsync(e->d.rep[r].ring, 0, e->d.log_len + 4096, e->stream));       /* log_new() */
-    HIPCHK(hipMemsetAsync(e->d.rep[r].ack, 0, sizeof(uint32_t) * e->dir_cap, e->stream));
+    if (!peer_owned) {
+        HIPCHK(hipMemsetAsync(e->d.rep[r].ring, 0, e->d.log_len + 4096, e->stream));   /* log_new() */
+        HIPCHK(hipMemsetAsync(e->d.rep[r].ack, 0, sizeof(uint32_t) * e->dir_cap, e->stream));
+    }
     hipLaunchKernelGGL(k_join_prepare, dim3(1), dim3(256), 0, e->stream, e->d, r, (uint32_t)src, (uint32_t)donor, nb, e->cid_epoch, jw);
     hipLaunchKernelGGL(k_join_copy, dim3(512), dim3(256), 0, e->stream, e->d, r, (uint32_t)src, jw);
     hipLaunchKernelGGL(k_join_finish, dim3(1), dim3(256), 0, e->stream, e->d, r, reachable | (1u << r), jw);

@@ -49,12 +49,18 @@ class PeerMember:
     """The replica this rank hosts + the mapped replicas of every peer."""
 
     def __init__(self, group_size: int, rank: int, device_index: int, log_len: int = DEFAULT_LOG, flags: int = 0,
-                 engine_factory=Engine):
+                 engine_factory=Engine, configured: int | None = None):
+        """group_size = processes = replicas that exist; configured (<= group_size) = servers of the initial
+        configuration -- the other ranks are machines that JOIN later (apus_gpu_join extends the group)."""
         if dist.get_world_size() != group_size:
-            raise EngineError("one process per replica: world size must equal the group size")
+            raise EngineError("one process per replica: world size must equal the number of replicas")
         self.n, self.rank = group_size, rank
         self.device = torch.device("cuda", device_index)
-        self.eng = engine_factory(group_size, log_len, local_ids=[rank], device=device_index, flags=flags)
+        if configured is None or configured == group_size:
+            self.eng = engine_factory(group_size, log_len, local_ids=[rank], device=device_index, flags=flags)
+        else:
+            self.eng = engine_factory(configured, log_len, local_ids=[rank], device=device_index, flags=flags,
+                                      capacity=group_size)
         self.log_len = log_len
         L = self.eng.L
         mine = _lib.IpcReplica()
@@ -119,6 +125,32 @@ class PeerMember:
 
     def hold(self, r: int): self.eng.hold(r)
     def release(self, r: int): self.eng.release(r)
+
+    def join(self, r: int):
+        """JOIN(r): the process of slot r is a NEW machine -- it zeroes the replica it hosts (log_new); the
+        leader's engine does the rest on the device through the mappings (apus_gpu_join: CONFIG entries,
+        the joiner's recovery as a bulk transfer into ITS HBM, first persist / apply passes); every other
+        rank takes over the configuration the leader made.  Barriers = the JOIN request / reply exchange."""
+        e = self.eng
+        if self.is_leader:
+            e.sync()
+        if self.rank == r:
+            e._chk(e.L.apus_gpu_clear_replica(e.h, r), "clear_replica")
+        dist.barrier()
+        if self.is_leader:
+            e.join(r)
+            e.sync()
+            cfg = torch.tensor([e.bitmask, e.group_size, e.epoch, e.machines], dtype=torch.int64)
+        else:
+            cfg = torch.zeros(4, dtype=torch.int64)
+        if dist.get_backend() == "nccl":
+            cfg = cfg.to(self.device)
+        dist.broadcast(cfg, src=self.leader)
+        if not self.is_leader:
+            bitmask, size, epoch, machines = (int(v) for v in cfg.cpu().tolist())
+            e._chk(e.L.apus_gpu_set_config(e.h, size, epoch), "set_config")
+            e.bitmask, e.group_size, e.epoch, e.machines = bitmask, size, epoch, machines
+            e.set_reachable(e.reachable | (1 << r))
 
     # ---- data plane: the leader only ------------------------------------------------------------
     def rounds(self, r0: int, n: int):
@@ -191,6 +223,8 @@ def walk_trace(m: PeerMember, trace, on_check=None, check_at=("QUIESCE",), max_b
             m.release(ev[i][1])
         elif op == "KILL":
             m.kill(ev[i][1])
+        elif op == "JOIN":
+            m.join(ev[i][1])
         else:
             raise EngineError(f"trace event {ev[i]} is not supported")
         if op in check_at and on_check is not None:

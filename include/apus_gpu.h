@@ -180,6 +180,10 @@ int  apus_gpu_become_leader_ex(apus_engine_t *e, uint32_t leader, uint64_t term,
  * configuration the leader decides with (cid.size[0]: quorum = n/2+1, the servers a prune tick looks
  * at).  Default = the capacity; a group that is meant to grow starts smaller (apus_gpu_join extends it). */
 int  apus_gpu_set_group_size(apus_engine_t *e, uint32_t n);
+/* peer-mapped groups: the joiner's process zeroes the replica it hosts (log_new) before the leader's
+ * apus_gpu_join; the other ranks take over size and epoch of the configuration the leader made */
+int  apus_gpu_clear_replica(apus_engine_t *e, uint32_t replica);
+int  apus_gpu_set_config(apus_engine_t *e, uint32_t group_size, uint64_t epoch);
 /* JOIN: a new machine (LID `lid`) joins and is given slot r -- the lowest slot that is OFF in `bitmask`,
  * or the group size when all are taken: the group is then extended through the three CONFIG entries
  * EXTENDED -> TRANSIT -> STABLE (handle_server_join_request src/dare/dare_ibv_ud.c:973-1068,

@@ -33,8 +33,8 @@ def main():
     try:
         rank, world, local, backend = peers.init_process_group_from_env(0)
         tr = {**traces.CATALOGUE, **traces.EXTRA}[name]()
-        assert tr.group_size == world
-        m = peers.PeerMember(world, rank, local, tr.log_len, flags=flags)
+        assert tr.group_size <= world       # the other ranks are machines that JOIN later
+        m = peers.PeerMember(world, rank, local, tr.log_len, flags=flags, configured=tr.group_size)
         cl = orc.Cluster(tr.group_size, tr.log_len, record_apply=True)
         reqs = np.ascontiguousarray(tr.reqs, dtype=orc.REQ_DTYPE)
         pos = 0
@@ -59,7 +59,8 @@ def main():
                         led[-1][1] = len(cl.round_record()[0])
                     cl.kill(ev[1])
                 else:
-                    getattr(cl, {"PRUNE": "tick_prune", "QUIESCE": "quiesce", "HOLD": "hold", "RELEASE": "release"}[op])(*ev[1:])
+                    getattr(cl, {"PRUNE": "tick_prune", "QUIESCE": "quiesce", "HOLD": "hold", "RELEASE": "release",
+                                 "JOIN": "join"}[op])(*ev[1:])
                 pos += 1
 
         def record_expected():
@@ -73,7 +74,7 @@ def main():
             oracle_to(i)
             e = mm.eng
             tag = f"{name} rank {rank} event {i} {ev}"
-            alive = [r for r in range(world) if (e.reachable >> r) & 1]
+            alive = [r for r in range(cl.n) if (e.reachable >> r) & 1 and (e.bitmask >> r) & 1]
             if rank in alive:
                 compare_replica(e, cl, rank, tag=tag)
             if mm.is_leader:

@@ -95,3 +95,15 @@ def test_peer_mapped_two_failovers_truncate_a_divergent_log():
     (tests/traces.py:double_failover_truncate, pinned on the reference)"""
     res = run_group(5, "double_failover_truncate")
     assert [r["led"] for r in res] == [1, 0, 1, 1, 0]
+
+
+@pytest.mark.parametrize("name,world", [("join_upsize_3_to_5", 5), ("c5_rejoin", 5), ("join_then_failover", 4)])
+def test_peer_mapped_group_join(name, world):
+    """JOIN across processes (SURVEY.md 8 f2 + e): the joiner is a PROCESS of its own -- a spare rank, or the
+    rank of a server that was killed and comes back as a new machine -- that zeroes the replica it hosts;
+    the leader's engine recovers it on the device through the HIP IPC mappings (bulk transfer of log range +
+    directory into the joiner's HBM: xGMI between GPUs), the group is extended 3 -> 4 -> 5 across processes,
+    and in join_then_failover the joined process wins the next term and leads from its own engine.  Every
+    rank checks its own replica from its own memory against the oracle."""
+    res = run_group(world, name)
+    assert all(r["checks"] >= 2 for r in res)
