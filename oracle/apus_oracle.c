@@ -996,6 +996,10 @@ int orc_join(orc_cluster_t *c, int r)
     }
     if (!donors) return -6;
 
+    /* a member whose configuration still shows the slot's FORMER holder (it never took in the removal, see
+     * below) keeps that server's RC endpoint as connected and does not set up a new one for the joiner */
+    uint32_t stale = 0;
+    for (int i = 0; i < size; i++) if (i != r && c->r[i].log && cid_on(&c->r[i].cid, r)) stale |= 1u << i;
     /* Case 3 (an empty place) or Case 4 (the group is full: extend it), :1022-1041 */
     uint16_t lid = (uint16_t)++c->next_lid;
     uint64_t end0 = log->end;
@@ -1022,7 +1026,22 @@ int orc_join(orc_cluster_t *c, int r)
     J->log->head = c->join_head;
     J->cid_idx = c->join_cid_idx;
     J->cid_offset = J->log->head;
-    join_pass(c, L, 4);                                         /* sweep 1: RC_SYN / SYNACK */
+    {
+        /* sweep 1: RC_SYN / SYNACK.  A member answers the joiner's RC_SYN only if ITS OWN configuration has
+         * the joiner's bit ON (handle_rc_syn, dare_ibv_ud.c: "Configuration inconsistency; it will be solved
+         * later") -- and a server that itself joined ignores every CONFIG entry whose idx is not above the
+         * idx of the entry that admitted it (poll_config_entries dare_server.c:2152, cid_idx from the join
+         * reply), i.e. ALL of them once the index sequence has restarted at an exact-fit wrap.
+         * The joiner then needs the replicated vote from more than half of the group it joins (the new size
+         * while the configuration is not STABLE: wait_for_majority, dare_ibv_rc.c) and retries for ever if the
+         * members that answer are too few (found by running the reference).  -6: not a schedule of this oracle. */
+        int jsize = J->cid.state == CID_STABLE ? J->cid.size[0] : J->cid.size[1], conn = 0;
+        for (int i = 0; i < jsize; i++)
+            if (i != r && cid_on(&J->cid, i) && c->r[i].alive && !c->r[i].held && cid_on(&c->r[i].cid, r) &&
+                !((stale >> i) & 1u) && i < ext_group_size(&J->cid)) conn++;
+        if (conn <= jsize / 2) { c->join_slot = -1; return -6; }
+    }
+    join_pass(c, L, 4);
     J->sid = SID_MAKE(0, 1, r);                                 /* sweep 2: get_replicated_vote_cb :529-531 */
     join_pass(c, L, 4);
     /* sweep 3: the SM request reaches every connected server; the followers (the leader does not poll for

@@ -399,6 +399,12 @@ int refc_join(refc_t *c, int r)
     uint64_t end0 = offs(S(c, c->leader))[3];
     for (int sweep = 0; sweep < 400; sweep++) {
         if (c->in[k].state() & ST_LOG_RECOVERED) break;
+        /* a server whose configuration was one pass behind when the joiner's RC_SYN came drops it
+         * ("Configuration inconsistency; it will be solved later", dare_ibv_ud.c handle_rc_syn): solved by
+         * the members' periodic RC-info timer (update_rc_info_cb, dare_server.c:501) -- fired here once the
+         * joiner has been waiting for a while */
+        if (sweep >= 8 && (sweep & 3) == 0)
+            for (int i = 0; i < c->n_inst; i++) if (i != k && c->in[i].alive && !fab_port_held(i)) call_fire(c, i, T_INIT);
         call_fire(c, k, T_INIT);
         for (int pass = 0; pass < 4; pass++) {
             poll_slot(c, c->leader);

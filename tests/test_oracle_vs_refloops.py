@@ -125,3 +125,51 @@ def test_full_size_c2():
     oc, rc = lockstep(tr, check_at=("QUIESCE",))
     assert oc.highest_rec(0) == (1 << 20) + 16
     rc.close()
+
+
+def _random_join_trace(seed):
+    """kills, joins into the freed slots and group extensions at random places of a stream of 128-byte
+    entries (64-aligned: the reference's joiner survives its first persist pass, oracle/apus_oracle.c
+    orc_join -8), prune ticks in between so that followers can dump their state machine again (-5)"""
+    from apus_amd import trace as T
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([3, 4, 5]))
+    tr = T.steady_trace(n, 2400, 64, 4, 10, log_len=1 << 16, name=f"random_join_{seed}")
+    ev, k, size, alive, dead = [], 0, n, set(range(n)), []
+    next_evt = int(rng.integers(8, 30))
+    for e in tr.events:
+        ev.append(e)
+        if e[0] != "ROUND":
+            continue
+        k += 1
+        if k < next_evt:
+            continue
+        next_evt = k + int(rng.integers(25, 60))
+        p = rng.random()
+        if dead and p < 0.6:
+            r = min(dead)                                  # the leader hands out the lowest empty slot
+            ev += [("QUIESCE",), ("JOIN", r), ("QUIESCE",)]
+            dead.remove(r); alive.add(r)
+        elif p < 0.8 and size < 7 and not dead:
+            ev += [("QUIESCE",), ("JOIN", size), ("QUIESCE",)]
+            alive.add(size); size += 1
+        elif len(alive) - 1 > size // 2 and len(alive) > 2:
+            r = int(rng.choice(sorted(alive - {0})))
+            ev += [("QUIESCE",), ("KILL", r), ("QUIESCE",)]
+            alive.remove(r); dead.append(r)
+    ev.append(("QUIESCE",))
+    tr.events = ev
+    return tr
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_joins_equal_reference(seed):
+    tr = _random_join_trace(seed)
+    try:
+        orc.run_trace(tr)              # a dry run: a JOIN the reference cannot survive (-5 crash, -8 hang) is skipped
+    except RuntimeError as e:
+        pytest.skip(f"the oracle refuses this schedule ({e}): the reference itself crashes, hangs or leaves the "
+                    "joiner retrying for ever there (orc_join's return codes)")
+    oc, rc = lockstep(tr, check_at=("QUIESCE",))
+    assert sum(1 for e in tr.events if e[0] == "JOIN") >= 1
+    rc.close()
