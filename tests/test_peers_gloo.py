@@ -1,9 +1,12 @@
-"""CPU, gloo, world size 2 and 5: the host side of the peer-mapped group (apus_amd/peers.py)
+"""CPU, gloo, world size 3 and 5: the host side of the peer-mapped group (apus_amd/peers.py)
 with a stand-in for the device engine.  Checked: the handle exchange (every rank imports exactly
 the blob every other rank exported), that only the current leader issues data-plane calls, and
 that every rank's view of the control plane (term, configuration bitmask, who answers, leader)
 follows the oracle's through elections, a leader fail-over and a follower removal (BASELINE
-config 5).  The device side of the same walk is tests/test_gpu_peers.py."""
+config 5) and through JOINs -- spare ranks that join later and extend the group 3 -> 4 -> 5, the rank of a
+killed server that comes back as a new machine: only the leader asks the device to carry the join out,
+only the joiner clears its own replica, every rank ends up with the leader's bitmask, size and epoch.
+The device side of the same walk is tests/test_gpu_peers.py."""
 import ctypes as C
 import os
 import socket
@@ -42,9 +45,12 @@ class _FakeLib:
 class _FakeEngine:
     """records what the host asks of the device; control-plane bookkeeping as in apus_amd/engine.py"""
 
-    def __init__(self, group_size, log_len, local_ids=None, device=0, flags=0):
+    def __init__(self, group_size, log_len, local_ids=None, device=0, flags=0, capacity=None):
         from apus_amd.engine import Engine
         self.group_size, self.log_len, self.local_ids = group_size, log_len, list(local_ids)
+        self.capacity = capacity or group_size
+        self.epoch, self.machines, self.snap_head, self.joined_at = 0, group_size, {}, 0
+        self._join = Engine.join
         self.h = None
         self.L = _FakeLib(self)
         self.imported = {}
@@ -63,6 +69,8 @@ class _FakeEngine:
         self.round_of_g0 = {g0: i for i, (g0, _) in enumerate(rounds)}
 
     def elect(self, w): self._elect(self, w)
+    def join(self, r): self._join(self, r)
+    def offsets(self, r): return {"head": self.n_passes}          # (moves with every pass: a <HEAD> entry was committed)
     def kill(self, r): self._kill(self, r)
     def set_reachable(self, mask): self.reachable = mask
     def hold(self, r): self.set_reachable(self.reachable & ~(1 << r))
@@ -92,10 +100,20 @@ def _worker(rank, world, port, name, q):
         from tests import traces
 
         tr = traces.CATALOGUE[name]()
-        assert tr.group_size == world
+        assert tr.group_size <= world          # the other ranks are machines that JOIN later
 
-        def factory(n, log_len, local_ids=None, device=0, flags=0):
-            e = _FakeEngine(n, log_len, local_ids, device, flags)
+        def factory(n, log_len, local_ids=None, device=0, flags=0, capacity=None):
+            e = _FakeEngine(n, log_len, local_ids, device, flags, capacity)
+
+            def fake_join(h, r, lid, bitmask, reachable, out):
+                # what apus_gpu_join reports back: the new bitmask, group size and epoch
+                up = r == e.group_size
+                out[0], out[1], out[2] = bitmask | (1 << r), e.group_size + (1 if up else 0), e.epoch + (1 if up else 0)
+                e.calls.append(("join", r, lid))
+                return 0
+            e.L.apus_gpu_join = fake_join
+            e.L.apus_gpu_clear_replica = lambda h, r: (e.calls.append(("clear", r)), 0)[1]
+            e.L.apus_gpu_set_config = lambda h, n_, ep: (e.calls.append(("config", n_, ep)), 0)[1]
             e.L.apus_gpu_become_leader_ex = lambda h, w, term, bm, dead: (e.calls.append(("lead", w, term, bm, dead)), 0)[1]
             e.L.apus_gpu_set_reachable = lambda h, m: 0
 
@@ -105,7 +123,7 @@ def _worker(rank, world, port, name, q):
             e.L.apus_gpu_elect = fake_elect
             return e
 
-        m = peers.PeerMember(world, rank, 0, tr.log_len, engine_factory=factory)
+        m = peers.PeerMember(world, rank, 0, tr.log_len, engine_factory=factory, configured=tr.group_size)
         # the exchange: everybody else's blob, byte for byte
         for r in range(world):
             if r == rank:
@@ -115,7 +133,7 @@ def _worker(rank, world, port, name, q):
             m.eng.L.apus_gpu_export_replica(None, r, C.byref(want))
             assert m.eng.imported[r] == bytes(want), f"rank {rank}: blob of replica {r} arrived damaged"
 
-        cl = orc.Cluster(world, tr.log_len)
+        cl = orc.Cluster(tr.group_size, tr.log_len)
         reqs = np.ascontiguousarray(tr.reqs, dtype=orc.REQ_DTYPE)
         pos = 0
         led_calls = {}
@@ -128,18 +146,23 @@ def _worker(rank, world, port, name, q):
                     cl.round(reqs[e[1]:e[1] + e[2]], tr.arena)
                 else:
                     getattr(cl, {"ELECT": "elect", "KILL": "kill", "PRUNE": "tick_prune", "QUIESCE": "quiesce",
-                                 "HOLD": "hold", "RELEASE": "release"}[e[0]])(*e[1:])
+                                 "HOLD": "hold", "RELEASE": "release", "JOIN": "join"}[e[0]])(*e[1:])
                 pos += 1
             assert mm.leader == cl.leader, f"rank {rank} event {i}: leader {mm.leader} vs {cl.leader}"
             if cl.leader >= 0:
                 sid = cl.sid(cl.leader)
                 assert mm.eng.term == sid >> 9, f"rank {rank} event {i}: term {mm.eng.term} vs {sid >> 9}"
                 assert mm.eng.bitmask == cl.cid_bitmask(cl.leader), f"rank {rank} event {i}: configuration"
+                cid = cl.cid(cl.leader)
+                assert (mm.eng.group_size, mm.eng.epoch) == (cid["size0"], cid["epoch"]), f"rank {rank} event {i}: size / epoch"
             data = [c for c in mm.eng.calls if c[0] in ("rounds", "prune", "quiesce", "control", "lead")]
             led_calls[i] = (mm.is_leader, len(data))
 
-        peers.walk_trace(m, tr, on_check=check, check_at=("QUIESCE", "PRUNE", "ELECT", "KILL"))
-        data = [c for c in m.eng.calls if c[0] in ("rounds", "prune", "quiesce", "control")]
+        peers.walk_trace(m, tr, on_check=check, check_at=("QUIESCE", "PRUNE", "ELECT", "KILL", "JOIN"))
+        data = [c for c in m.eng.calls if c[0] in ("rounds", "prune", "quiesce", "control", "join")]
+        joins = [e[1] for e in tr.events if e[0] == "JOIN"]
+        # a machine that joins clears the replica it hosts; nobody else's is cleared from here
+        assert [c[1] for c in m.eng.calls if c[0] == "clear"] == [r for r in joins if r == rank]
         if not m.led:
             assert not data, f"rank {rank} never led but issued {data[:3]}"
         else:
@@ -153,7 +176,8 @@ def _worker(rank, world, port, name, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("steady3", 3), ("c5_failover", 5), ("hold_release", 5)])
+@pytest.mark.parametrize("name,world", [("steady3", 3), ("c5_failover", 5), ("hold_release", 5),
+                                        ("join_upsize_3_to_5", 5), ("c5_rejoin", 5)])
 def test_peer_group_host_logic(name, world):
     from oracle import oracle as orc
     if not hasattr(orc.Cluster, "cid_bitmask"):
