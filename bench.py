@@ -223,6 +223,42 @@ def measure_ack_path(args, tr, n_rep):
         eng.close()
 
 
+def measure_join(args):
+    """BASELINE configs[4]'s tail as an extra figure: a server joins a 5-server group whose ring holds
+    ~32 MiB of 1 KiB entries -- apus_gpu_join end to end (CONFIG entry + pass, the joiner's recovery: bulk
+    transfer of the log range and directory, its first persist / apply passes, the closing pass), timed on
+    the host around the synchronous call.  One device here: the transfer is an HBM copy; between GPUs it is
+    the same kernel reading through the peer mapping (xGMI)."""
+    from apus_amd import trace as T
+    from apus_amd.engine import Engine
+    tr = T.steady_trace(5, 1 << 15, 1024 - 64, 16, 32, log_len=T.DEFAULT_LOG, name="join", prune_bytes=1 << 40)
+    eng = Engine(5, tr.log_len, device=0)
+    try:
+        eng.stage_trace(tr)
+        eng.elect(0)
+        n_rounds = sum(1 for e in tr.events if e[0] == "ROUND")
+        eng.batch_begin()
+        for r0 in range(0, n_rounds, 512):
+            eng.run_rounds(r0, min(512, n_rounds - r0))
+        eng.batch_end(); eng.quiesce(); eng.sync()
+        eng.kill(4); eng.quiesce(); eng.sync(); eng.check_status()
+        o = eng.offsets(0)
+        log_bytes = o["end"] - o["head"]
+        t0 = time.perf_counter()
+        eng.join(4)
+        eng.sync()
+        dt = time.perf_counter() - t0
+        eng.check_status()
+        oj = eng.offsets(4)
+        assert (oj["end"], oj["commit"], oj["apply"]) == (eng.offsets(0)["end"],) * 3, f"joiner not caught up: {oj}"
+        return {"value": dt * 1e3, "unit": "ms", "log_bytes": int(log_bytes), "entries": int(eng.counters(0)["n_end"]),
+                "catch_up_GBps": log_bytes / dt / 1e9,
+                "note": "apus_gpu_join end to end on one MI355X (host clock around the synchronous call: CONFIG entry + pass, "
+                        "64 MiB ring cleared, log range + directory copied, the joiner's first persist / apply passes, closing pass)"}
+    finally:
+        eng.close()
+
+
 def bench_single(args):
     import torch
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
@@ -434,6 +470,11 @@ def bench_single(args):
             out["ack_aggregation_path"] = measure_ack_path(args, tr, n_rep)
         except Exception as exc:
             print(f"[bench] ACK-aggregation path measurement failed: {exc!r}", file=sys.stderr)
+    if not args.no_ack_path:
+        try:
+            out["join_catch_up"] = measure_join(args)
+        except Exception as exc:
+            print(f"[bench] join measurement failed: {exc!r}", file=sys.stderr)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
     return out
