@@ -182,6 +182,7 @@ class Engine:
         out = (C.c_uint64 * 4)()
         self._chk(self.L.apus_gpu_join(self.h, r, self.machines + 1, self.bitmask, self.reachable, out), "join")
         self.machines += 1
+        self.snap_head.pop(r, None)             # a new machine: it has not dumped anything yet
         for f in donors:
             self.snap_head[f] = self.offsets(f)["head"]
         self.bitmask, self.group_size, self.epoch = int(out[0]), int(out[1]), int(out[2])

@@ -794,3 +794,23 @@ def test_term_fence_a_deposed_leader_stores_nothing(eng_factory, batch):
     assert [eng.offsets(r) for r in range(3)] == before, "a fenced launch moved an offset"
     assert np.array_equal(eng.ring(0), ring0), "a fenced launch stored into the deposed leader's own log"
     assert eng.counters(2)["sid"] == (4 << 9) | 1
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 15])
+def test_random_join_traces(eng_factory, seed):
+    """kills, re-joins into freed slots and group extensions at random places (the schedules
+    tests/test_oracle_vs_refloops.py::test_random_joins_equal_reference runs in lock step with the reference),
+    through batched launches, against the oracle"""
+    from tests.parity import lockstep, compare_apply_tail
+    from tests.test_oracle_vs_refloops import _random_join_trace
+    tr = _random_join_trace(seed)
+    try:
+        orc.run_trace(tr)
+    except RuntimeError as e:
+        pytest.skip(f"the oracle refuses this schedule ({e})")
+    eng = eng_factory(tr.group_size, tr.log_len, capacity=7)
+    cl = lockstep(tr, eng, batch=True, check_at=("QUIESCE",))
+    assert eng.group_size == cl.n and eng.bitmask == cl.cid_bitmask(cl.leader)
+    for r in range(cl.n):
+        if (eng.reachable >> r) & 1 and (eng.bitmask >> r) & 1:
+            compare_apply_tail(eng, cl, r)
