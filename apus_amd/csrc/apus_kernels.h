@@ -2095,6 +2095,14 @@ __device__ static inline void finish_records(const EngDev &E, uint64_t r0, uint3
         if (s.kstar >= 0 && (int64_t)(rf[r] - rf[0]) == s.kstar && s.w < L && cs >= slot_start_r &&
             (r ? true : base_commit == s.e0))
             cr = 0;
+        /* ... and the pass behind it starts with the followers one step back (the end doorbell of the
+         * wrapped round is still to be sent): its first scan finds the wrapped round acknowledged, commits
+         * it, `committed` is set and the pass returns before its own entries went out -- it ends with
+         * commit == the END OF THE ROUND BEFORE (pinned on the reference, tests/traces.py:
+         * wrap_quirk_second_round); the pass after that one catches up. */
+        if (r >= 1 && s.kstar >= 0 && (int64_t)(rf[r - 1] - rf[0]) == s.kstar && s.w < L && c > slot_start_r &&
+            (r - 1 ? true : base_commit == s.e0))
+            cr = virt ? end_prev : E.rec_end[rec_base + r - 1];
         /* a round that ended exactly on len could not commit: the log read as empty
          * (dare_log.h:158), the leader's scan saw distance 0 (dare_ibv_rc.c:1726) */
         if (end_r == L) {

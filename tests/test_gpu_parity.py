@@ -814,3 +814,17 @@ def test_random_join_traces(eng_factory, seed):
     for r in range(cl.n):
         if (eng.reachable >> r) & 1 and (eng.bitmask >> r) & 1:
             compare_apply_tail(eng, cl, r)
+
+
+@pytest.mark.parametrize("batch", [False, True])
+def test_wrap_quirk_second_round(eng_factory, batch):
+    """the per-pass commit record around a case-2 wrap that falls on a round boundary: (1280, 0), then the
+    pass behind it one round back, (2560, 1280), then caught up -- pinned on the reference
+    (tests/traces.py:wrap_quirk_second_round), found by the random join traces"""
+    from tests import traces
+    from tests.parity import lockstep
+    tr = traces.wrap_quirk_second_round()
+    cl = lockstep(tr, eng_factory(3, tr.log_len), batch=batch, check_at=("QUIESCE",))
+    rc, re = cl.round_record()
+    k = int(np.nonzero(rc == 0)[0][-1])
+    assert [(int(re[i]), int(rc[i])) for i in (k, k + 1, k + 2)] == [(1280, 0), (2560, 1280), (3840, 3840)]

@@ -88,6 +88,15 @@ def evict_slow_follower():
     return _with_events(tr, {6: [("QUIESCE",), ("HOLD", 2)], 60: [("QUIESCE",)]})
 
 
+def wrap_quirk_second_round():
+    """a round boundary lands on len - 64: the next round's first entry leaves a stale header there and goes
+    to offset 0 (case-2 wrap) while the commit pointer is parked on that position -- the pass "commits"
+    offset 0 (dare_ibv_rc.c:1725-1758) and, because it returned before the end doorbell went out, the pass
+    BEHIND it commits only the wrapped round and returns again: end / commit after the three passes are
+    (1280, 0), (2560, 1280), (3840, 3840)"""
+    return T.steady_trace(3, 1200, 64, 16, 10, log_len=1 << 16, name="wrap_quirk_second_round")
+
+
 def park_commit_at_wrap():
     """Case-1 wrap (the header does not fit: 28 bytes left) with the commit pointer parked on it
     and NO quorum: update_remote_logs "commits" offset 0 (dare_ibv_rc.c:1725-1758) and
@@ -201,7 +210,7 @@ def join_then_failover():
                              50: [("QUIESCE",), ("KILL", 0), ("ELECT", 3), ("QUIESCE",)]})
 
 
-CATALOGUE = {f.__name__: f for f in (evict_slow_follower, c5_rejoin, join_empty_slot, join_wrapped, join_upsize_3_to_5, join_then_failover, diverge_failover, double_failover_truncate, steady3, steady5_unaligned, steady7_mixed, c2_small, c3_small, c4_small,
+CATALOGUE = {f.__name__: f for f in (wrap_quirk_second_round, evict_slow_follower, c5_rejoin, join_empty_slot, join_wrapped, join_upsize_3_to_5, join_then_failover, diverge_failover, double_failover_truncate, steady3, steady5_unaligned, steady7_mixed, c2_small, c3_small, c4_small,
                                      c5_failover, hold_one_of_three, hold_release, no_quorum, no_quorum_prune,
                                      exact_fit, kill_follower, park_commit_at_wrap)}
 
