@@ -51,7 +51,8 @@ def _run_group(world, name, mode, flags, timeout):
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     res = [json.load(open(f"{out}.{r}")) for r in range(world) if os.path.exists(f"{out}.{r}")]
     if len(res) != world:
-        raise _RankLost(f"{world - len(res)} ranks produced no result\n{p.stdout[-2000:]}\n{p.stderr[-6000:]}")
+        said = "\n".join(f"rank {r['rank']}: {r.get('error')}" for r in res if not r["ok"])
+        raise _RankLost(f"{world - len(res)} ranks produced no result; the others said:\n{said}\n{p.stdout[-2000:]}\n{p.stderr[-6000:]}")
     for r in res:
         if not r["ok"] and "Connection closed by peer" in str(r.get("error")) and all(
                 q["ok"] or "Connection closed by peer" in str(q.get("error")) for q in res):
