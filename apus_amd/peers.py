@@ -56,11 +56,19 @@ class PeerMember:
             raise EngineError("one process per replica: world size must equal the number of replicas")
         self.n, self.rank = group_size, rank
         self.device = torch.device("cuda", device_index)
-        if configured is None or configured == group_size:
-            self.eng = engine_factory(group_size, log_len, local_ids=[rank], device=device_index, flags=flags)
-        else:
-            self.eng = engine_factory(configured, log_len, local_ids=[rank], device=device_index, flags=flags,
-                                      capacity=group_size)
+        kw = {} if configured is None or configured == group_size else {"capacity": group_size}
+        n0 = group_size if not kw else configured
+        for attempt in range(4):
+            # several processes opening the same device at the same moment: engine creation has been seen to
+            # fail once in a while on a fresh box (one rank of five); it is retried before the group gives up
+            try:
+                self.eng = engine_factory(n0, log_len, local_ids=[rank], device=device_index, flags=flags, **kw)
+                break
+            except EngineError:
+                if attempt == 3:
+                    raise
+                import time
+                time.sleep(0.25 * (attempt + 1))
         self.log_len = log_len
         L = self.eng.L
         mine = _lib.IpcReplica()
