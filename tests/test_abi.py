@@ -50,3 +50,14 @@ def test_struct_sizes_match_header():
     from apus_amd.engine import APPLY_DTYPE
     assert T.REQ_DTYPE.itemsize == 24        # apus_req_t
     assert APPLY_DTYPE.itemsize == 32        # apus_apply_t
+
+
+def test_headers_are_plain_c_and_cxx(tmp_path):
+    """the boundary is a C ABI: both headers compile on their own as C99 and as C++17, warnings as errors"""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "apus_gpu.h"\n#include "apus_smr.h"\n'
+                   'int main(void) { apus_cfg_t c; apus_req_t r; apus_apply_t a; (void)c; (void)r; (void)a; return 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", str(src)])
