@@ -1340,18 +1340,20 @@ extern "C" int apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_
         memset(cid, 0, 16); memcpy(cid, &epoch, 8); cid[8] = (uint8_t)s0; cid[9] = (uint8_t)s1; cid[10] = (uint8_t)state;
         memcpy(cid + 12, &nb, 4); memcpy(&d0, cid, 8); memcpy(&d1, cid + 8, 8);
     };
+    const uint64_t epoch0 = e->cid_epoch;
     if (r < size) {                                           /* Case 3: an empty place */
         put(e->cid_epoch, size, 0, 0);
         if ((rc = launch_control_round(e, 0 | 16, APUS_CONFIG, d0, d1, 1, lid))) return rc;
     } else {                                                  /* Case 4: [N,0,STABLE] -> [N,N+1,EXTENDED] -> [N,N+1,TRANSIT] -> [N+1,0,STABLE] */
-        e->cid_epoch++;
-        put(e->cid_epoch, size, size + 1, 2);
+        put(epoch0 + 1, size, size + 1, 2);
         if ((rc = launch_control_round(e, 0 | 16, APUS_CONFIG, d0, d1, 1, lid))) return rc;    /* old majority (EXTENDED) */
+        e->cid_epoch = epoch0 + 1;
         e->d.group_size = size + 1;                           /* TRANSIT: the scan runs with cid.size[1] */
         put(e->cid_epoch, size, size + 1, 1);
-        if ((rc = launch_control_round(e, 0 | 16, APUS_CONFIG, d0, d1, 0, 0))) return rc;
+        rc = launch_control_round(e, 0 | 16, APUS_CONFIG, d0, d1, 0, 0);
         put(e->cid_epoch, size + 1, 0, 0);
-        if ((rc = launch_control_round(e, 0 | 16, APUS_CONFIG, d0, d1, 0, 0))) return rc;
+        if (!rc) rc = launch_control_round(e, 0 | 16, APUS_CONFIG, d0, d1, 0, 0);
+        if (rc) return rc;                                    /* (a launch that cannot be issued: the stream is broken anyway) */
     }
     /* joiner side */
     uint64_t *jw = e->d_elect + 8;                            /* scratch words behind k_elect's verdict */

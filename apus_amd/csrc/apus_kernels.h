@@ -96,6 +96,7 @@ __device__ static inline T wave_sum(T v)
     return v;
 }
 
+#define FENCE_WORD 2      /* status[2]: raised by k_fence_check, every fenced launch leaves when it is set */
 __device__ static inline void set_status(const EngDev &E, uint32_t bit) { atomicOr(E.status, bit); }
 /* a bounded spin ran out: status bit 4; the first site to do so leaves its source line in status word 1 */
 __device__ static inline void spin_timeout(const EngDev &E, uint32_t site) { atomicOr(E.status, 1u << 4); atomicCAS(E.status + 1, 0u, site); }
@@ -169,7 +170,7 @@ __device__ static inline void catchup_range(const EngDev &E, int f, uint64_t end
  * by a lot (RELEASE after a HOLD).  grid.y = follower ordinal in fmask.        */
 __global__ __launch_bounds__(256) void k_catchup(const EngDev E, uint32_t fmask)
 {
-    if (E.status[2]) return;                          /* the term fence (k_fence_check) */
+    if (E.status[FENCE_WORD]) return;                 /* the term fence (k_fence_check) */
     int f = -1;
     for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
         if (fmask & (1u << i)) { if (k == (int)blockIdx.y) { f = i; break; } k++; }
@@ -3112,7 +3113,6 @@ __global__ APUS_CALL_BOUNDS void k_step(const EngDev E_arg, const StepTable T, u
  * locally; those entries could never commit and are cut by the next leader's log adjustment).
  * Launched only where another process can change a follower's term (peer-mapped groups,
  * APUS_F_TERM_FENCE); the unfenced kernels are the same code without the load. */
-#define FENCE_WORD 2
 __global__ __launch_bounds__(64) void k_fence_check(const EngDev E, uint32_t push_mask)
 {
     const uint32_t i = threadIdx.x;
@@ -3285,7 +3285,7 @@ __global__ __launch_bounds__(256) void k_control_round(const EngDev E, int mode_
      * whole join is one record, as in the schedule the oracle is pinned on), 32 = record end / commit as
      * they are after this pass even though it appended nothing (the pass that closes a JOIN) */
     const int mode = mode_flags & 7;
-    if (E.status[2]) return;                          /* the term fence (k_fence_check) */
+    if (E.status[FENCE_WORD]) return;                 /* the term fence (k_fence_check) */
     const uint64_t rec0 = *E.rec_count;
     const RepDev &Ld = E.rep[E.leader];
     uint64_t *hdr = Ld.hdr;

@@ -192,7 +192,10 @@ int  apus_gpu_set_config(apus_engine_t *e, uint32_t group_size, uint64_t epoch);
  * snapshot offset of the first follower (rc_recover_sm :597-705), the log between the leader's head and
  * the first server's end in one bulk transfer (rc_recover_log :726-866), its first persist and apply
  * passes, then it is a follower like the others.  reachable = who answers.  out[0] = new bitmask,
- * out[1] = new group size, out[2] = new epoch.  One per-round record for the whole join. */
+ * out[1] = new group size, out[2] = new epoch.  One per-round record for the whole join.
+ * The caller decides WHETHER a join may happen now (apus_amd/engine.py:Engine.join mirrors what the
+ * reference can do: every configured server reachable, no follower asked for its state machine twice
+ * without a committed <HEAD> entry in between); this call carries it out. */
 int  apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_t bitmask, uint32_t reachable, uint64_t out[4]);
 /* replica adopts a SID it heard of from a candidate / leader that ANOTHER engine drives (its vote,
  * poll_vote_requests src/dare/dare_server.c:1690; a heartbeat of a newer term, hb_receive_cb :903-910);
