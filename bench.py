@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_CEILING_GBS = 6290.0   # the measured-copy ceiling SURVEY.md 8(d) asks to report against as well
 XGMI_LINK_GBS = 153.0        # one xGMI link (7 per GPU, point to point)
 
 
@@ -456,6 +457,8 @@ def bench_single(args):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "moved": moved, "frac_moved": (moved / HBM_PEAK_GBS) if moved else None,
+                     "copy_ceiling": HBM_COPY_CEILING_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
+                     "frac_moved_of_copy_ceiling": (moved / HBM_COPY_CEILING_GBS) if moved else None,
                      "moved_bytes_per_entry": moved_per_entry, "traffic_source": traffic_src,
                      "kernel": kern_name, "bytes_per_entry": kern_bytes,
                      "avg_launch_us": k_avg_s * 1e6, "launches": k_launches,
