@@ -310,6 +310,7 @@ struct orc_cluster {
     /* a JOIN in progress: what the leader's reply carries (reconf_rep_t, dare_ibv_ud.c:1451-1490) */
     int next_lid, join_slot, join_replied;
     int hung;                                    /* a persist walk that does not terminate (orc_join, -8) */
+    int leader_quit;                             /* the leader shut itself down (check_failure_count, -9) */
     int record_store;
     uint64_t join_head, join_cid_idx;
     orc_cid_t join_cid;
@@ -781,6 +782,15 @@ static void force_log_pruning(orc_cluster_t *c, replica_t *L);
 /* leader polling() pass after the tailq was drained, dare_server.c:1095-1124 */
 static void leader_poll(orc_cluster_t *c, replica_t *L)
 {
+    /* check_failure_count opens the pass (dare_server.c:1189-1230): a server that counts no more than half of
+     * the group as connected -- ON in its configuration and not at PERMANENT_FAILURE -- shuts itself down
+     * ("Not enough connections... bye bye", :1212-1216).  Removals shrink the bitmask, never cid.size[0]: a
+     * leader that has removed (or evicted, force_log_pruning) half of its group leaves; the group is gone. */
+    {
+        int size = group_size(&L->cid), on = 0;
+        for (int i = 0; i < size; i++) on += cid_on(&L->cid, i);
+        if (on <= size / 2) { c->leader_quit = 1; return; }
+    }
     persist_new_entries(c, L);
     commit_new_entries(c, L);
     apply_committed_entries(c, L);
@@ -812,6 +822,7 @@ int orc_round(orc_cluster_t *c, const orc_req_t *reqs, int n, const uint8_t *are
         if (L->log->end == L->log->len && !c->allow_exact_fit) return -3;   /* exact-fit wrap, SURVEY.md Q13 */
     }
     leader_poll(c, L);
+    if (c->leader_quit) { L->alive = 0; c->leader = -1; return -9; }
     note_round(c, L);
     return 0;
 }
@@ -837,6 +848,7 @@ int orc_quiesce(orc_cluster_t *c)
                      before[i][2] != c->r[i].log->apply || before[i][3] != c->r[i].log->old_end;
         }
         for (int i = 0; i < c->n; i++) moved |= L->pending[i] != PEND_NONE;
+        if (c->leader_quit) { L->alive = 0; c->leader = -1; return -9; }
         if (!moved) return 0;
     }
     return 1;
@@ -902,10 +914,14 @@ int orc_tick_prune(orc_cluster_t *c)
     /* Trace semantics: the prune timer fires between polling() passes once every
      * follower has caught up (ms-scale timer vs us-scale rounds), so the apply
      * offsets sampled by R8 do not depend on the lazy commit lag. */
-    orc_quiesce(c);
+    if (orc_quiesce(c) == -9) return -9;
     int appended = log_pruning(c, L);
     if (appended < 0) return appended;
-    if (appended) { leader_poll(c, L); note_round(c, L); }
+    if (appended) {
+        leader_poll(c, L);
+        if (c->leader_quit) { L->alive = 0; c->leader = -1; return -9; }
+        note_round(c, L);
+    }
     return appended;
 }
 
@@ -923,6 +939,7 @@ int orc_kill(orc_cluster_t *c, int r)
             uint64_t idx = orc_log_append(L->log, SID_TERM(L->sid), 0, 0, ORC_CONFIG, &L->cid, 0);
             if (idx == 0) return -2;
             leader_poll(c, L);
+            if (c->leader_quit) { L->alive = 0; c->leader = -1; return -9; }
             note_round(c, L);
         }
     }

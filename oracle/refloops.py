@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
             "refc_leader": (C.c_int, [vp]),
             "refc_group_size": (C.c_int, [vp]),
             "refc_alive": (C.c_int, [vp, C.c_int]),
+            "refc_gone": (C.c_int, [vp, C.c_int]),
             "refc_offsets": (None, [vp, C.c_int, pu64]),
             "refc_entries": (vp, [vp, C.c_int]),
             "refc_sid": (u64, [vp, C.c_int]),
@@ -199,6 +200,7 @@ class RefCluster:
     @property
     def leader(self): return int(self.L.refc_leader(self.h))
     def alive(self, r): return bool(self.L.refc_alive(self.h, r))
+    def gone(self, r): return bool(self.L.refc_gone(self.h, r))
     def log(self, r) -> _RefLogView: return _RefLogView(self, r)
     def sid(self, r): return int(self.L.refc_sid(self.h, r))
     def term(self, r): return self.sid(r) >> 9

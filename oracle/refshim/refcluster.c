@@ -104,7 +104,11 @@ static uint64_t *offs(inst_t *t) { return (uint64_t *)t->log(); }   /* head appl
 static inst_t *S(refc_t *c, int r)
 {
     if (r < 0 || r >= c->n || c->slot_inst[r] < 0) return NULL;
-    return &c->in[c->slot_inst[r]];
+    inst_t *t = &c->in[c->slot_inst[r]];
+    /* a server that shut itself down ("Somebody removed me... bye bye", update_cid dare_server.c:2216) has
+     * freed its log and control data (free_server_data :333): nothing of it can be looked at any more */
+    if (t->exited && t->exited()) return NULL;
+    return t;
 }
 static int port_of(refc_t *c, int r) { return (r < 0 || r >= c->n) ? -1 : c->slot_inst[r]; }
 
@@ -129,6 +133,12 @@ static int call_fire(refc_t *c, int k, int which)
     fab_leave(prev);
     t->busy = 0;
     return r;
+}
+/* the leader may shut itself down in any pass ("Not enough connections... bye bye", dare_server.c:1212) */
+static int leader_gone(refc_t *c)
+{
+    if (c->leader >= 0 && !S(c, c->leader)) { snprintf(c->err, sizeof c->err, "the leader (server %d) shut itself down", c->leader); c->leader = -1; }
+    return c->leader < 0;
 }
 static int poll_slot(refc_t *c, int r) { int k = port_of(c, r); return k < 0 ? 0 : call_poll(c, k); }
 static int fire_slot(refc_t *c, int r, int which) { int k = port_of(c, r); return k < 0 ? 0 : call_fire(c, k, which); }
@@ -234,7 +244,8 @@ void refc_free(refc_t *c)
         /* the instances are dropped without dare_server_shutdown (it would pthread_exit);
          * their 64 MiB logs are released here */
         if (c->in[i].dl) {
-            void *lg = c->in[i].log ? c->in[i].log() : NULL;
+            /* (a server that shut itself down has freed its own, free_server_data dare_server.c:333) */
+            void *lg = (c->in[i].log && !(c->in[i].exited && c->in[i].exited())) ? c->in[i].log() : NULL;
             free(lg);
             dlclose(c->in[i].dl);
         }
@@ -313,13 +324,14 @@ int refc_round(refc_t *c, const refc_req_t *reqs, int n, const uint8_t *arena)
     for (int k = 0; k < n; k++)
         L->submit(reqs[k].type, reqs[k].clt_id, reqs[k].req_id, arena ? arena + reqs[k].payload_off : NULL, reqs[k].len);
     poll_slot(c, c->leader);
+    if (leader_gone(c)) return -9;
     note_round(c);
     return 0;
 }
 
 int refc_quiesce(refc_t *c)
 {
-    if (c->leader < 0) return -1;
+    if (leader_gone(c)) return -1;
     for (int it = 0; it < 64; it++) {
         uint64_t before[MAXN][4], pb[MAXN][2];
         for (int i = 0; i < c->n; i++) {
@@ -329,6 +341,7 @@ int refc_quiesce(refc_t *c)
             uint64_t p[6]; S(c, c->leader)->peer(i, p); pb[i][0] = p[0]; pb[i][1] = p[1];
         }
         poll_slot(c, c->leader);
+        if (leader_gone(c)) return -9;
         for (int i = 0; i < c->n; i++) if (i != c->leader && S(c, i) && !fab_port_held(port_of(c, i))) poll_slot(c, i);
         int moved = 0;
         for (int i = 0; i < c->n; i++) {
@@ -345,12 +358,12 @@ int refc_quiesce(refc_t *c)
 
 int refc_tick_prune(refc_t *c)
 {
-    if (c->leader < 0) return -1;
-    refc_quiesce(c);                                 /* trace semantics: see orc_tick_prune */
+    if (leader_gone(c)) return -1;
+    if (refc_quiesce(c) < 0) return -9;              /* trace semantics: see orc_tick_prune */
     uint64_t end0 = offs(S(c, c->leader))[3];
     if (!fire_slot(c, c->leader, T_PRUNE)) return -1;       /* prune_log_cb :1977 */
     int appended = offs(S(c, c->leader))[3] != end0;
-    if (appended) { poll_slot(c, c->leader); note_round(c); }
+    if (appended) { poll_slot(c, c->leader); if (leader_gone(c)) return -9; note_round(c); }
     return appended;
 }
 
@@ -441,7 +454,8 @@ uint32_t refc_records_len(refc_t *c, int r) { return S(c, r)->records_len(); }
 const void *refc_apply_log(refc_t *c, int r, uint64_t *n) { return S(c, r)->apply_log(n); }
 void     refc_cid(refc_t *c, int r, uint64_t out[4]) { S(c, r)->cid(out); }
 void     refc_peer(refc_t *c, int r, int i, uint64_t out[6]) { S(c, r)->peer(i, out); }
-int      refc_alive(refc_t *c, int r) { return S(c, r) && S(c, r)->alive && !S(c, r)->exited(); }
+int      refc_alive(refc_t *c, int r) { return S(c, r) && S(c, r)->alive; }
+int      refc_gone(refc_t *c, int r) { return r >= 0 && r < c->n && c->slot_inst[r] >= 0 && !S(c, r); }
 uint64_t refc_state(refc_t *c, int r) { return S(c, r) ? S(c, r)->state() : 0; }
 uint64_t refc_round_count(const refc_t *c) { return c->n_rounds; }
 const uint64_t *refc_round_commit(const refc_t *c) { return c->round_commit; }

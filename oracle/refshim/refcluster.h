@@ -41,6 +41,7 @@ int refc_fire(refc_t *c, int r, int which);     /* 0 init/rc-info, 1 prune, 2 he
 int      refc_leader(const refc_t *c);
 int      refc_group_size(const refc_t *c);
 int      refc_alive(refc_t *c, int r);
+int      refc_gone(refc_t *c, int r);            /* the server shut itself down and freed its state */
 void     refc_offsets(refc_t *c, int r, uint64_t out[8]);   /* head apply commit end tail old_end old_commit len */
 uint8_t *refc_entries(refc_t *c, int r);
 uint64_t refc_sid(refc_t *c, int r);
