@@ -127,6 +127,32 @@ def cpu_baseline_port(args, seconds=15.0):
                       f"({el:.1f} s, oracle/liboracle.so -O2, {_cpu_model()}, nproc={os.cpu_count()})"}
 
 
+def cpu_baseline_port_mt(args, seconds=4.0):
+    """the port on one pinned THREAD per server (the leader thread also does its NIC's
+    work), memcpy "RDMA"; the leader waits for the ACK majority of every round like the reference's
+    rc_write_remote_logs(wait_for_commit)."""
+    from apus_amd import trace as T
+    from oracle import oracle as orc
+    sample = min(args.entries, 1 << 18)
+    tr = T.steady_trace(3, sample, args.payload, 16, args.batch, log_len=T.DEFAULT_LOG)
+    cl = orc.Cluster(3, tr.log_len, record_apply=False)
+    cl.elect(0)
+    round_n = np.array([ev[2] for ev in tr.events if ev[0] == "ROUND"], dtype=np.uint32)
+    done, passes, t0 = 0, 0, time.perf_counter()
+    while True:
+        cl.run_rounds_mt(tr.reqs, round_n, tr.arena, prune_bytes=8 << 20, max_seconds=30.0)
+        done += len(tr.reqs)
+        passes += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or passes >= 4096:
+            break
+    o = cl.log(0).offsets()
+    assert o["commit"] == o["end"]
+    return {"value": done / el, "unit": "committed entries/s", "cores": 3, "kind": "port",
+            "sample": f"{passes} x {len(tr.reqs)} entries of the same 3-replica stream on 3 pinned threads "
+                      f"({el:.1f} s, oracle/liboracle.so -O2 orc_run_rounds_mt, {_cpu_model()}, nproc={os.cpu_count()})"}
+
+
 def cpu_baseline_reference(args, seconds=12.0, group_size=3):
     """THE REFERENCE ITSELF: /root/reference/src/dare/*.c compiled unmodified with its own -O0
     (oracle/_ref/libapus_ref_loops.so; the prebuilt library travels to the GPU box), 3 server
@@ -177,6 +203,10 @@ def cpu_baseline(args, seconds=12.0):
     except Exception as exc:
         print(f"[bench] reference-as-is baseline failed: {exc!r}", file=sys.stderr)
         ref = None
+    try:
+        port["threads_3"] = cpu_baseline_port_mt(args, max(2.0, seconds / 4))
+    except Exception as exc:
+        print(f"[bench] threaded port baseline failed: {exc!r}", file=sys.stderr)
     if ref is None:
         return port
     ref["also"] = port

@@ -13,6 +13,9 @@
  * lands in its memory.  Log bytes, offsets and the order of apply callbacks
  * at every quiescent point do not depend on that choice.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE            /* CPU_SET, pthread_setaffinity_np (Part 3) */
+#endif
 #include "apus_oracle.h"
 
 #include <stdlib.h>
@@ -1284,6 +1287,198 @@ int orc_run_rounds(orc_cluster_t *c, const orc_req_t *reqs, const uint32_t *roun
         }
     }
     return 0;
+}
+
+
+/* ================================================================== */
+/* Part 3: the same steady-state loops on N threads (CPU baseline only)  */
+/*
+ * "the CPU oracle compiled -O2, N replica threads pinned 1/core, memcpy RDMA".
+ * One thread per server.  The leader thread does what its NIC would do as well (the log WRITE into every
+ * follower's ring, the end and commit doorbells); a follower thread polls its own end / commit words,
+ * persists + ACKs (the reply byte in its own ring and in the leader's), applies.  The leader waits for the
+ * ACK majority of a round before it takes the next one (rc_write_remote_logs with wait_for_commit).
+ * Steady state only -- no failures, the prune tick quiesces like orc_tick_prune.  At the end every ring,
+ * offset and upcall count equals the single-threaded run's (tests/test_trace_oracle.py); the per-pass
+ * record is not kept (passes are not a notion here).  Every spin checks a deadline: the function returns
+ * -10 instead of hanging.
+ */
+#define _MT_RELAX() __asm__ __volatile__("pause" ::: "memory")
+#include <pthread.h>
+#include <sched.h>
+#include <time.h>
+
+typedef struct { orc_cluster_t *c; int idx; int stop; int failed; uint64_t deadline_ns; } mt_ctx_t;
+
+static uint64_t mt_now(void)
+{
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+/* the entry that starts at *off in a log whose bytes up to `lim` are valid (reader rule of log_get_entry /
+ * log_fit_entry, dare_log.h:316-331,241); returns NULL at lim */
+static orc_entry_t *mt_next(orc_log_t *log, uint64_t *off, uint64_t lim)
+{
+    for (;;) {
+        if (*off == lim) return NULL;
+        if (log->len - *off < ORC_HDR_BYTES) { *off = 0; continue; }
+        orc_entry_t *e = entry_at(log, *off);
+        if (log->len - *off < entry_len(e)) { *off = 0; continue; }
+        return e;
+    }
+}
+
+static void *mt_follower(void *arg)
+{
+    mt_ctx_t *x = arg;
+    orc_cluster_t *c = x->c;
+    replica_t *p = &c->r[x->idx];
+    orc_log_t *log = p->log;
+    cpu_set_t set; CPU_ZERO(&set); CPU_SET(x->idx, &set);
+    pthread_setaffinity_np(pthread_self(), sizeof set, &set);          /* best effort */
+    uint64_t old_end = log->old_end, apply = log->apply;
+    for (;;) {
+        const uint64_t end = __atomic_load_n(&log->end, __ATOMIC_ACQUIRE);
+        const uint64_t commit = __atomic_load_n(&log->commit, __ATOMIC_ACQUIRE);
+        int did = 0;
+        if (end != log->len && old_end != end) {                       /* persist_new_entries + rc_send_entries_reply */
+            if (old_end == log->len) old_end = 0;
+            orc_entry_t *e;
+            while ((e = mt_next(log, &old_end, end))) {
+                p->store_count++;
+                store_cmd(c, p, e);
+                e->reply[p->idx] = 1;
+                replica_t *dst = &c->r[e->sender];
+                if (e->sender < c->n && dst->alive)
+                    __atomic_store_n(&entry_at(dst->log, old_end)->reply[p->idx], 1, __ATOMIC_RELEASE);
+                old_end += entry_len(e);
+            }
+            __atomic_store_n(&log->old_end, old_end, __ATOMIC_RELEASE);
+            did = 1;
+        }
+        if (end != log->len && apply != commit) {                      /* poll_config_entries (HEAD) + apply_committed_entries */
+            orc_entry_t *e;
+            while ((e = mt_next(log, &apply, commit))) {
+                if (e->type == ORC_HEAD) { if (orc_log_is_larger(log, e->data.head, log->head)) log->head = e->data.head; }
+                else if (e->type != ORC_CONFIG && e->type != ORC_NOOP) {
+                    log->apply = apply;
+                    record_apply(c, p, apply, e, 2);
+                    p->last_applied.idx = e->idx; p->last_applied.term = e->term; p->last_applied.offset = apply + entry_len(e);
+                }
+                apply += entry_len(e);
+                p->apply_slot++;
+            }
+            __atomic_store_n(&log->apply, apply, __ATOMIC_RELEASE);
+            p->cid_offset = commit;
+            did = 1;
+        }
+        if (!did) {
+            if (__atomic_load_n(&x->stop, __ATOMIC_ACQUIRE)) break;
+            if (mt_now() > x->deadline_ns) { x->failed = 1; break; }
+            _MT_RELAX();
+        }
+    }
+    return NULL;
+}
+
+/* leader: replicate [from, log->end) of its ring into follower f (two pieces on a wrap), then the end doorbell */
+static void mt_push(replica_t *L, replica_t *F, uint64_t from)
+{
+    orc_log_t *log = L->log;
+    if (from == log->len) from = 0;
+    if (log->end >= from) memcpy(F->log->entries + from, log->entries + from, log->end - from);
+    else { memcpy(F->log->entries + from, log->entries + from, log->len - from); memcpy(F->log->entries, log->entries, log->end); }
+    __atomic_store_n(&F->log->end, log->end, __ATOMIC_RELEASE);
+}
+
+/* leader: persist its own new entries, push, wait for the ACK majority up to its end, commit, doorbells, apply */
+static int mt_leader_pass(orc_cluster_t *c, replica_t *L, uint64_t from, uint64_t deadline_ns)
+{
+    orc_log_t *log = L->log;
+    persist_new_entries(c, L);
+    for (int i = 0; i < c->n; i++) if (i != L->idx) mt_push(L, &c->r[i], from);
+    /* a round that ends exactly on len: the log reads as empty (dare_log.h:158), nothing is committable
+     * until the next append -- nobody persists or acknowledges it before then */
+    if (log->end == log->len) return 0;
+    const int size = L->cid.size[0];
+    uint64_t off = log->commit;
+    if (off == log->len) off = 0;
+    orc_entry_t *e;
+    while ((e = mt_next(log, &off, log->end))) {
+        for (;;) {
+            int replies = 0;
+            for (int i = 0; i < size; i++)
+                if (i == L->idx || __atomic_load_n(&e->reply[i], __ATOMIC_ACQUIRE) == 1) replies++;
+            if (replies >= size / 2 + 1) break;
+            if (mt_now() > deadline_ns) return -10;
+            _MT_RELAX();
+        }
+        off += entry_len(e);
+    }
+    log->commit = off; L->cid_offset = off;
+    for (int i = 0; i < c->n; i++) if (i != L->idx) __atomic_store_n(&c->r[i].log->commit, off, __ATOMIC_RELEASE);
+    apply_committed_entries(c, L);
+    return 0;
+}
+
+int orc_run_rounds_mt(orc_cluster_t *c, const orc_req_t *reqs, const uint32_t *round_n, uint64_t n_rounds,
+                      const uint8_t *arena, uint64_t prune_bytes, double max_seconds)
+{
+    if (c->leader < 0 || c->n < 2) return -1;
+    replica_t *L = &c->r[c->leader];
+    for (int i = 0; i < c->n; i++) if (!c->r[i].alive || c->r[i].held || !cid_on(&L->cid, i)) return -1;
+    if (orc_quiesce(c)) return -1;                                  /* every follower in step before the threads start */
+    const uint64_t deadline = mt_now() + (uint64_t)(max_seconds * 1e9);
+    mt_ctx_t ctx[ORC_MAX_SERVERS];
+    pthread_t th[ORC_MAX_SERVERS];
+    for (int i = 0; i < c->n; i++) {
+        ctx[i] = (mt_ctx_t){ c, i, 0, 0, deadline };
+        if (i != c->leader && pthread_create(&th[i], NULL, mt_follower, &ctx[i])) return -1;
+    }
+    { cpu_set_t set; CPU_ZERO(&set); CPU_SET(c->leader, &set); pthread_setaffinity_np(pthread_self(), sizeof set, &set); }
+    int rc = 0;
+    uint64_t since = 0, g = 0;
+    for (uint64_t r = 0; r < n_rounds && !rc; r++) {
+        const uint64_t from = L->log->end;
+        for (uint32_t k = 0; k < round_n[r] && !rc; k++, g++) {
+            if (!orc_log_append(L->log, SID_TERM(L->sid), reqs[g].req_id, reqs[g].clt_id, reqs[g].type,
+                                arena ? arena + reqs[g].payload_off : NULL, reqs[g].len)) rc = -2;
+            since += ORC_HDR_BYTES + reqs[g].len;
+        }
+        if (!rc) rc = mt_leader_pass(c, L, from, deadline);
+        if (!rc && prune_bytes && since >= prune_bytes) {
+            /* the prune tick: everybody caught up (trace semantics of orc_tick_prune), then log_pruning */
+            since = 0;
+            for (int i = 0; i < c->n && !rc; i++)
+                while (i != c->leader && __atomic_load_n(&c->r[i].log->apply, __ATOMIC_ACQUIRE) != L->log->commit) {
+                    if (mt_now() > deadline) { rc = -10; break; }
+                    _MT_RELAX();
+                }
+            if (!rc) {
+                const uint64_t f2 = L->log->end;
+                const int appended = log_pruning(c, L);
+                if (appended < 0) rc = appended;
+                else if (appended) rc = mt_leader_pass(c, L, f2, deadline);
+            }
+        }
+    }
+    /* drain: every follower persisted and applied everything, then the threads leave */
+    for (int i = 0; i < c->n && !rc; i++)
+        while (i != c->leader && (__atomic_load_n(&c->r[i].log->apply, __ATOMIC_ACQUIRE) != L->log->commit ||
+                                  __atomic_load_n(&c->r[i].log->old_end, __ATOMIC_ACQUIRE) != L->log->end)) {
+            if (mt_now() > deadline) { rc = -10; break; }
+            _MT_RELAX();
+        }
+    for (int i = 0; i < c->n; i++) if (i != c->leader) __atomic_store_n(&ctx[i].stop, 1, __ATOMIC_RELEASE);
+    for (int i = 0; i < c->n; i++) if (i != c->leader) { pthread_join(th[i], NULL); if (ctx[i].failed && !rc) rc = -10; }
+    { cpu_set_t set; CPU_ZERO(&set); for (int k = 0; k < CPU_SETSIZE; k++) CPU_SET(k, &set); pthread_setaffinity_np(pthread_self(), sizeof set, &set); }
+    /* the leader-side step machine of the single-threaded loops, as it stands when everybody is in step */
+    for (int i = 0; i < c->n; i++) if (i != c->leader) {
+        L->rem_end[i] = L->log->end; L->rem_commit[i] = L->log->commit; L->cached_end[i] = L->log->end;
+        L->lr_step[i] = LR_UPDATE_LOG; L->send_flag[i] = 1; L->pending[i] = PEND_NONE;
+    }
+    return rc;
 }
 
 /* ================================================================== */

@@ -163,6 +163,13 @@ const uint64_t *orc_round_end(const orc_cluster_t *c);
 int      orc_run_rounds(orc_cluster_t *c, const orc_req_t *reqs, const uint32_t *round_n,
                         uint64_t n_rounds, const uint8_t *arena, uint64_t prune_bytes);
 
+/* the same steady-state stream on one THREAD per server (pinned; the leader thread also does its NIC's
+ * work: log WRITEs and doorbells), for bench.py's CPU baseline only.  No failures; ends
+ * with every server in step, rings / offsets / upcall counts equal to orc_run_rounds'.  -10: a spin ran
+ * past max_seconds. */
+int      orc_run_rounds_mt(orc_cluster_t *c, const orc_req_t *reqs, const uint32_t *round_n,
+                           uint64_t n_rounds, const uint8_t *arena, uint64_t prune_bytes, double max_seconds);
+
 /* ------------------------------------------------------------------ */
 /* helpers shared by tests: payload stream and canonical digest walk   */
 uint64_t orc_splitmix64(uint64_t *state);

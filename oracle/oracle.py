@@ -98,6 +98,7 @@ def lib() -> C.CDLL:
             "orc_round_commit": (C.POINTER(u64), [vp]),
             "orc_round_end": (C.POINTER(u64), [vp]),
             "orc_run_rounds": (C.c_int, [vp, vp, vp, u64, vp, u64]),
+            "orc_run_rounds_mt": (C.c_int, [vp, vp, vp, u64, vp, u64, C.c_double]),
             "orc_fill_payload": (None, [u64, vp, u32]),
             "orc_apply_mix": (u64, [u64, u64, u64, u32, u16, u8, u8]),
             "orc_canon": (u64, [vp, u64, u64, u64, u64, vp, u64, C.POINTER(u64)]),
@@ -356,6 +357,14 @@ class Cluster:
         round_n = np.ascontiguousarray(round_n, dtype=np.uint32)
         return self._chk(self.L.orc_run_rounds(self.h, reqs.ctypes.data, round_n.ctypes.data,
                                                len(round_n), arena.ctypes.data, prune_bytes), "run_rounds")
+
+    def run_rounds_mt(self, reqs: np.ndarray, round_n: np.ndarray, arena: np.ndarray, prune_bytes: int = 0,
+                      max_seconds: float = 60.0):
+        """the same stream on one pinned thread per server (CPU baseline only)"""
+        reqs = np.ascontiguousarray(reqs, dtype=REQ_DTYPE)
+        round_n = np.ascontiguousarray(round_n, dtype=np.uint32)
+        return self._chk(self.L.orc_run_rounds_mt(self.h, reqs.ctypes.data, round_n.ctypes.data, len(round_n),
+                                                  arena.ctypes.data, prune_bytes, max_seconds), "run_rounds_mt")
 
     @property
     def force_prunes(self): return int(self.L.orc_force_prune_count(self.h))
