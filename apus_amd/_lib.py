@@ -12,7 +12,7 @@ vp = C.c_void_p
 
 class IpcReplica(C.Structure):
     """apus_ipc_replica_t (include/apus_gpu.h)"""
-    _fields_ = [("handle", (u8 * 64) * 6), ("log_len", u64), ("dir_cap", u32), ("replica", u32),
+    _fields_ = [("handle", (u8 * 64) * 8), ("log_len", u64), ("dir_cap", u32), ("replica", u32),
                 ("device", C.c_int32), ("pad", u32)]
 
 
@@ -48,6 +48,7 @@ SIGNATURES = {
     "apus_gpu_apply_records": (C.c_int, [vp, u32, u64, u64, vp]),
     "apus_gpu_status": (u32, [vp]),
     "apus_gpu_clear_status": (None, [vp]),
+    "apus_gpu_status_words": (C.c_int, [vp, C.POINTER(u32)]),
     "apus_gpu_device_ptr": (vp, [vp, u32, C.c_int, C.POINTER(u64)]),
     "apus_gpu_set_timing": (C.c_int, [vp, C.c_int]),
     "apus_gpu_kernel_time": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(u64)]),
@@ -86,6 +87,19 @@ SIGNATURES = {
     "apus_gpu_join": (C.c_int, [vp, u32, u16, u32, u32, C.POINTER(u64)]),
     "apus_gpu_batch_begin": (C.c_int, [vp]),
     "apus_gpu_batch_end": (C.c_int, [vp]),
+    "apus_gpu_rep_start": (C.c_int, [vp, u32, u32, u32, u32]),
+    "apus_gpu_rep_park": (C.c_int, [vp]),
+    "apus_gpu_rep_reserve": (C.c_int, [vp, u32, C.POINTER(u64), C.POINTER(vp)]),
+    "apus_gpu_rep_publish": (C.c_int, [vp, u64, vp, u64, u16, u8, u16]),
+    "apus_gpu_rep_submit": (C.c_int, [vp, vp, u32, vp, u64]),
+    "apus_gpu_rep_run": (C.c_int, [vp, u64, u64]),
+    "apus_gpu_rep_prune": (C.c_int, [vp]),
+    "apus_gpu_rep_drain": (C.c_int, [vp, u32]),
+    "apus_gpu_rep_full": (C.c_int, [vp]),
+    "apus_gpu_rep_highest_rec": (u64, [vp]),
+    "apus_gpu_rep_stats": (C.c_int, [vp, C.POINTER(u64)]),
+    "apus_gpu_rep_latency": (C.c_int, [vp, vp, u32, C.POINTER(u32)]),
+    "apus_gpu_rep_roundtrip": (C.c_int, [vp, vp, u32, vp, u64, u32, vp]),
 }
 
 

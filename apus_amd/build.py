@@ -15,7 +15,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = [os.path.join(CSRC, "apus_engine.hip")]
 DEPS = [os.path.join(CSRC, "apus_kernels.h"), os.path.join(CSRC, "apus_device.h"),
-        os.path.join(CSRC, "apus_persistent.h"), os.path.join(ROOT, "include", "apus_gpu.h")]
+        os.path.join(CSRC, "apus_persistent.h"), os.path.join(CSRC, "apus_replica.h"), os.path.join(ROOT, "include", "apus_gpu.h")]
 
 
 def _host_c_sources():

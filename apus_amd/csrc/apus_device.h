@@ -108,9 +108,13 @@ struct SeqOut {
     uint64_t rec_base;     /* *rec_count when the call started (index of its first per-round record) */
 };
 
+struct RepBox;                            /* apus_replica.h: a replica's mailbox (uncached, mapped by its peers) */
+
 /* engine-wide device state */
 struct EngDev {
     RepDev   rep[APUS_DEV_MAX_SERVERS];   /* indexed by group index; ring == nullptr when not local */
+    RepBox  *box[APUS_DEV_MAX_SERVERS];   /* replica kernels: mailbox of replica i (doorbells in, progress of its followers in) */
+    uint8_t *ackb[APUS_DEV_MAX_SERVERS];  /* replica kernels: [follower][dir_cap] ACK byte maps of replica i when it leads (uncached) */
     uint32_t group_size;
     uint32_t leader;                      /* group index, 0xFFFFFFFF = none */
     uint32_t reachable;                   /* bitmask of peers the leader can post to */

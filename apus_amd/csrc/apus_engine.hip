@@ -17,6 +17,8 @@
 #include "../../include/apus_gpu.h"
 #include "apus_kernels.h"
 #include "apus_persistent.h"
+#include "apus_replica.h"
+#include <pthread.h>
 #include <time.h>
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { \
@@ -88,6 +90,18 @@ struct apus_engine {
     bool p_running;
     uint64_t p_ev_tail, p_req_tail, p_arena_pos;
     uint64_t p_req_end[P_EV_CAP];   /* cumulative request count after each published event */
+    /* replica kernels (apus_gpu_rep_*): every hosted replica runs its own workgroups */
+    RepHost *rh, *rh_dev;           /* pinned, coherent: the leader's request ring, command ring, progress words */
+    RepLead *rl;                    /* leader-local hand-off state */
+    RepFollow *rfs[APUS_MAX_SERVERS];
+    hipStream_t rstream;
+    bool r_running, r_lead;         /* a launch is resident; it carries the leader's workgroups */
+    uint32_t r_follow_mask;
+    uint32_t r_test_skip;           /* tests: followers whose workgroups are NOT launched although they are pushed to (a dead process) */
+    uint64_t r_slot_tail, r_arena_tail, r_cmd_tail;   /* producer side of the pinned rings (under r_lock) */
+    uint64_t *r_slot_aend;          /* [RQ_CAP] logical arena position behind every slot's payload */
+    pthread_spinlock_t r_lock;
+    bool r_lock_init;
 };
 
 #define LIVE_REQS   4096u
@@ -102,6 +116,7 @@ struct apus_engine {
 static apus_engine *g_engine = nullptr;
 static int flush_tick(apus_engine *e);
 extern "C" int apus_gpu_persist_stop(apus_engine_t *e);
+extern "C" int apus_gpu_rep_park(apus_engine_t *e);
 
 static int flush_live(apus_engine *e);        /* a staged live batch runs before anything else touches the engine */
 
@@ -111,7 +126,9 @@ static int dev_alloc(apus_engine *e, T **out, size_t bytes, bool zero = true, un
     void *p = nullptr;
     if (ext_flags) { if (hipExtMallocWithFlags(&p, bytes, ext_flags) != hipSuccess) return APUS_E_NOMEM; }
     else if (hipMalloc(&p, bytes) != hipSuccess) return APUS_E_NOMEM;
-    if (zero && hipMemset(p, 0, bytes) != hipSuccess) return APUS_E_HIP;
+    /* (on the engine's stream: a hipMemset on the null stream may still be in flight when the first kernel of the
+     * non-blocking engine stream runs -- k_reset's words were seen zeroed again by a late memset) */
+    if (zero && hipMemsetAsync(p, 0, bytes, e->stream) != hipSuccess) return APUS_E_HIP;
     e->allocs.push_back(p);
     *out = (T *)p;
     return 0;
@@ -176,6 +193,10 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->live_r0 = e->live_R = e->live_n = 0;
     e->ph = e->ph_dev = nullptr; e->pd = nullptr; e->pstream = nullptr; e->p_running = false;
     e->p_ev_tail = e->p_req_tail = e->p_arena_pos = 0;
+    e->rh = e->rh_dev = nullptr; e->rl = nullptr; e->rstream = nullptr; e->r_running = e->r_lead = false; e->r_follow_mask = 0; e->r_test_skip = 0;
+    for (auto &f : e->rfs) f = nullptr;
+    e->r_slot_tail = e->r_arena_tail = e->r_cmd_tail = 0; e->r_slot_aend = nullptr;
+    pthread_spin_init(&e->r_lock, PTHREAD_PROCESS_PRIVATE); e->r_lock_init = true;
     if (cfg->stream) { e->stream = (hipStream_t)cfg->stream; e->own_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
 
@@ -205,6 +226,10 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
         if ((rc = dev_alloc(e, &r.dir_len, sizeof(uint32_t) * e->dir_cap))) break;
         if ((rc = dev_alloc(e, &r.ack, sizeof(uint32_t) * e->dir_cap))) break;
         if ((rc = dev_alloc(e, &r.apply, sizeof(apus_apply_rec) * (size_t)e->dir_cap))) break;
+        /* the replica kernels' mailbox and ACK byte maps: uncached, so that a peer's system-scope stores are
+         * what the owner's polls read (and the other way round) */
+        if ((rc = dev_alloc(e, &e->d.box[i], sizeof(RepBox), true, hipDeviceMallocUncached))) break;
+        if ((rc = dev_alloc(e, &e->d.ackb[i], (size_t)cfg->group_size * e->dir_cap, true, hipDeviceMallocUncached))) break;
     }
     e->max_rounds = 1u << 16;
     e->d.rec_cap = 1ull << 22;
@@ -244,6 +269,7 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
     for (auto g : e->graphs) hipGraphExecDestroy(g);
     for (auto &t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (e->p_running) apus_gpu_persist_stop(e);       /* before anything it reads is freed */
+    if (e->r_running) apus_gpu_rep_park(e);
     for (void *p : e->ipc_ptrs) hipIpcCloseMemHandle(p);
     for (void *p : e->allocs) hipFree(p);
     if (e->d_req) hipFree(e->d_req);
@@ -251,6 +277,12 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
     if (e->d_arena) hipFree(e->d_arena);
     if (e->d_round_first) hipFree(e->d_round_first);
     if (e->d_round_prefix) hipFree(e->d_round_prefix);
+    if (e->rh) hipHostFree(e->rh);
+    if (e->rl) hipFree(e->rl);
+    for (auto f : e->rfs) if (f) hipFree(f);
+    if (e->rstream) hipStreamDestroy(e->rstream);
+    free(e->r_slot_aend);
+    if (e->r_lock_init) pthread_spin_destroy(&e->r_lock);
     if (e->ph) hipHostFree(e->ph);
     if (e->pd) hipFree(e->pd);
     if (e->pstream) hipStreamDestroy(e->pstream);
@@ -292,6 +324,8 @@ extern "C" int apus_gpu_clear_replica(apus_engine_t *e, uint32_t r)
     if (e->batching) return APUS_E_STATE;
     HIPCHK(hipMemsetAsync(e->d.rep[r].ring, 0, e->d.log_len + 4096, e->stream));
     HIPCHK(hipMemsetAsync(e->d.rep[r].ack, 0, sizeof(uint32_t) * e->dir_cap, e->stream));
+    HIPCHK(hipMemsetAsync(e->d.box[r], 0, sizeof(RepBox), e->stream));       /* a new machine: its doorbell sequence restarts */
+    HIPCHK(hipMemsetAsync(e->d.ackb[r], 0, (size_t)e->cfg.group_size * e->dir_cap, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
@@ -313,6 +347,8 @@ extern "C" int apus_gpu_reset(apus_engine_t *e)
             /* log_new() zeroes the whole log (dare_log.h:128) */
             HIPCHK(hipMemsetAsync(e->d.rep[i].ring, 0, e->d.log_len + 4096, e->stream));
             HIPCHK(hipMemsetAsync(e->d.rep[i].ack, 0, sizeof(uint32_t) * e->dir_cap, e->stream));
+            HIPCHK(hipMemsetAsync(e->d.box[i], 0, sizeof(RepBox), e->stream));
+            HIPCHK(hipMemsetAsync(e->d.ackb[i], 0, (size_t)e->cfg.group_size * e->dir_cap, e->stream));
         }
     e->d.leader = 0xFFFFFFFFu;
     e->tick_pending = false;
@@ -336,7 +372,7 @@ extern "C" int apus_gpu_export_replica(apus_engine_t *e, uint32_t replica, apus_
     if (!((e->local_mask >> replica) & 1u) || ((e->imported_mask >> replica) & 1u)) return APUS_E_STATE;
     HIPCHK(hipStreamSynchronize(e->stream));
     const RepDev &r = e->d.rep[replica];
-    void *bufs[APUS_IPC_BUFFERS] = { r.ring, r.hdr, r.dir_off, r.dir_len, r.ack, r.apply };
+    void *bufs[APUS_IPC_BUFFERS] = { r.ring, r.hdr, r.dir_off, r.dir_len, r.ack, r.apply, e->d.box[replica], e->d.ackb[replica] };
     static_assert(sizeof(hipIpcMemHandle_t) <= 64, "apus_ipc_replica_t carries 64 bytes per handle");
     memset(out, 0, sizeof *out);
     for (uint32_t k = 0; k < APUS_IPC_BUFFERS; k++) {
@@ -368,6 +404,7 @@ extern "C" int apus_gpu_import_replica(apus_engine_t *e, const apus_ipc_replica_
     RepDev &r = e->d.rep[in->replica];
     r.ring = (uint8_t *)p[0]; r.hdr = (uint64_t *)p[1]; r.dir_off = (uint64_t *)p[2]; r.dir_len = (uint32_t *)p[3];
     r.ack = (uint32_t *)p[4]; r.apply = (apus_apply_rec *)p[5]; r.idx = in->replica;
+    e->d.box[in->replica] = (RepBox *)p[6]; e->d.ackb[in->replica] = (uint8_t *)p[7];
     e->local_mask |= 1u << in->replica;
     e->imported_mask |= 1u << in->replica;
     return 0;
@@ -1100,6 +1137,9 @@ extern "C" int apus_gpu_become_leader_ex(apus_engine_t *e, uint32_t leader, uint
     const uint64_t sid = (term << 9) | (1ull << 8) | leader;
     hipLaunchKernelGGL(k_set_roles, dim3(1), dim3(64), 0, e->stream, e->d, sid, bitmask, e->reachable);
     HIPCHK(hipGetLastError());
+    /* the ACK byte maps of a new leader start empty (entries of these slots may have been acknowledged to it in an earlier term) */
+    if (!((e->imported_mask >> leader) & 1u))
+        HIPCHK(hipMemsetAsync(e->d.ackb[leader], 0, (size_t)e->cfg.group_size * e->dir_cap, e->stream));
     {
         /* the followers that voted: their logs are adjusted before anything is replicated to them */
         const uint32_t am = e->adjust_mask & e->local_mask & e->reachable & ~(1u << leader);
@@ -1369,6 +1409,11 @@ extern "C" int apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_
      * log update + lazy commit + the joiner's apply in the pass that closes the join */
     e->reachable |= 1u << r; e->d.reachable = e->reachable;
     e->lag_possible = true;
+    {   /* the slot's former holder told this leader how far IT had got: a new machine starts over */
+        RepBox *lb = e->d.box[leader];
+        uint64_t *words[5] = { &lb->seqdone_by[r], &lb->persisted_by[r], &lb->applied_by[r], &lb->apply_off_by[r], &lb->sid_by[r] };
+        for (auto w : words) HIPCHK(hipMemsetAsync(w, 0, sizeof(uint64_t), e->stream));
+    }
     if ((rc = launch_control_round(e, 2 | 32, 0, 0, 0))) return rc;
     out[0] = nb; out[1] = e->d.group_size; out[2] = e->cid_epoch; out[3] = 0;
     return 0;
@@ -1670,11 +1715,20 @@ extern "C" uint32_t apus_gpu_status(apus_engine_t *e)
     return s[0] | e->host_status;
 }
 
+/* diagnostics: the eight status words (bits, first spin-timeout site, fence word, five words a kernel left behind) */
+extern "C" int apus_gpu_status_words(apus_engine_t *e, uint32_t out[8])
+{
+    if (!e || !out) return APUS_E_ARG;
+    hipStreamSynchronize(e->stream);
+    HIPCHK(hipMemcpy(out, e->d.status, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" void apus_gpu_clear_status(apus_engine_t *e)
 {
     if (!e) return;
     hipStreamSynchronize(e->stream);
-    hipMemset(e->d.status, 0, 3 * sizeof(uint32_t));      /* bits, spin site, fence word */
+    hipMemset(e->d.status, 0, 8 * sizeof(uint32_t));      /* bits, spin site, fence word, diagnostics */
     e->host_status = 0;
 }
 
@@ -2048,6 +2102,268 @@ extern "C" int apus_gpu_follower_commit(apus_engine_t *e, uint32_t replica, uint
     hipLaunchKernelGGL(k_mp_apply, dim3(cap_grid(n_hint ? n_hint : 1, 256, 1024)), dim3(256), 0, e->stream, e->d, replica, commit_slot);
     hipLaunchKernelGGL(k_mp_apply_fin, dim3(1), dim3(64), 0, e->stream, e->d, replica, commit_slot);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+
+/* ---- replica kernels: every replica runs its own resident workgroups (apus_replica.h) -------------- */
+/* Which followers are "in step" with the leader -- hold everything it has appended, an exact-fit round
+ * they hold back included -- and can take the rounds of a run: the others need the leader's catch-up
+ * (update_remote_logs step I, the control-plane pass) first. */
+static int rep_in_step(apus_engine *e, uint32_t cand, uint32_t *out_mask, uint64_t qbase[APUS_MAX_SERVERS], uint64_t fruns[APUS_MAX_SERVERS])
+{
+    uint64_t lh[64];
+    HIPCHK(hipMemcpy(lh, e->d.rep[e->d.leader].hdr, sizeof lh, hipMemcpyDeviceToHost));
+    uint32_t in = 0;
+    for (uint32_t m = cand; m; m &= m - 1) {
+        const uint32_t f = (uint32_t)__builtin_ctz(m);
+        uint64_t fh[64], notes[8];
+        HIPCHK(hipMemcpy(fh, e->d.rep[f].hdr, sizeof fh, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(notes, &e->d.box[f]->f_seq_next, sizeof notes, hipMemcpyDeviceToHost));   /* f_seq_next, pend x 3, f_exit, f_runs */
+        qbase[f] = notes[0]; fruns[f] = notes[5];
+        uint64_t n_end = fh[H_N_END];
+        if (notes[2] > notes[1] && notes[3] == fh[H_SID] && notes[1] == fh[H_N_END]) n_end = notes[2];
+        if (n_end == lh[H_N_END] && (fh[H_SID] >> 9) == (lh[H_SID] >> 9)) in |= 1u << f;
+    }
+    *out_mask = in;
+    return 0;
+}
+
+extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t peer_ms, uint32_t n_append, uint32_t n_fwork)
+{
+    if (!e || e->d.leader >= e->d.group_size) return APUS_E_STATE;
+    if (e->r_running || e->p_running || e->batching) return APUS_E_STATE;
+    if (e->live_R) { int rc_ = flush_live(e); if (rc_) return rc_; }
+    const uint32_t leader = e->d.leader;
+    const uint32_t hosted = e->local_mask & ~e->imported_mask;
+    const bool lead_here = (hosted >> leader) & 1u;
+    if (lead_here) { int frc = flush_tick(e); if (frc) return frc; }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (!n_append) n_append = 32;
+    if (!n_fwork) n_fwork = 8;
+    if (!e->rstream) HIPCHK(hipStreamCreateWithFlags(&e->rstream, hipStreamNonBlocking));
+    RepArgs A;
+    memset(&A, 0, sizeof A);
+    const uint32_t members = ((1u << e->d.group_size) - 1) & ~(1u << leader);
+    A.follow_mask = hosted & members & e->reachable & ~e->r_test_skip;
+    A.n_append = n_append; A.n_fwork = n_fwork;
+    A.idle_polls = (uint64_t)idle_ms * 1000ull;
+    A.peer_polls = (uint64_t)peer_ms * 1000ull;
+    A.lead_here = lead_here ? 1u : 0u;
+    if (lead_here) {
+        if (!e->rh) {
+            HIPCHK(hipHostMalloc((void **)&e->rh, sizeof(RepHost), hipHostMallocMapped | hipHostMallocCoherent));
+            HIPCHK(hipHostGetDevicePointer((void **)&e->rh_dev, e->rh, 0));
+            memset((void *)e->rh, 0, offsetof(RepHost, desc));
+            HIPCHK(hipMalloc((void **)&e->rl, sizeof(RepLead)));
+            e->r_slot_aend = (uint64_t *)calloc(RQ_CAP, sizeof(uint64_t));
+            if (!e->r_slot_aend) return APUS_E_NOMEM;
+        }
+        const uint32_t cand = sync_mask(e);
+        uint32_t push = 0;
+        int rc = rep_in_step(e, cand, &push, A.qbase, A.fruns);
+        if (rc) return rc;
+        A.push_mask = push; A.park_mask = cand;
+        if (push != cand) e->lag_possible = true;
+        HIPCHK(hipMemsetAsync(e->rl, 0, sizeof(RepLead), e->rstream));
+        HIPCHK(hipMemsetAsync(&e->rl->seq_final, 0xFF, sizeof(uint64_t), e->rstream));
+        HIPCHK(hipMemsetAsync(e->rl->t_drop, 0xFF, sizeof e->rl->t_drop, e->rstream));
+        uint64_t h[64];
+        HIPCHK(hipMemcpy(h, e->d.rep[leader].hdr, sizeof h, hipMemcpyDeviceToHost));
+        /* (a run that ended abnormally may have left commands or slots behind: they are dropped) */
+        e->rh->cmd_tail = e->r_cmd_tail; e->rh->cmd_head = e->r_cmd_tail; e->rh->slots_done = e->r_slot_tail;
+        e->rh->settled = e->r_cmd_tail + e->r_slot_tail;
+        e->rh->stop = 0; e->rh->alive = 0; e->rh->exit_code = 0; e->rh->full = 0; e->rh->rounds = 0;
+        e->rh->highest_rec = h[H_HIGHEST_REC];
+        e->rh->commit_slot = h[H_N_COMMIT];
+        A.H = e->rh_dev; A.LS = e->rl;
+    }
+    for (uint32_t m = A.follow_mask; m; m &= m - 1) {
+        const uint32_t f = (uint32_t)__builtin_ctz(m);
+        if (!e->rfs[f]) HIPCHK(hipMalloc((void **)&e->rfs[f], sizeof(RepFollow)));
+        HIPCHK(hipMemsetAsync(e->rfs[f], 0, sizeof(RepFollow), e->rstream));
+        A.FS[f] = e->rfs[f];
+    }
+    const uint32_t grid = (lead_here ? 1 + n_append : 0) + popc(A.follow_mask) * n_fwork;
+    if (!grid) return 0;                               /* nothing of this group runs here */
+    hipLaunchKernelGGL(k_replica, dim3(grid), dim3(256), 0, e->rstream, e->d, A);
+    HIPCHK(hipGetLastError());
+    if (lead_here) {
+        const double t0 = mono_s();
+        while (e->rh->alive == 0)
+            if (mono_s() - t0 > 10.0) { fprintf(stderr, "[apus_gpu] the leader's workgroups did not start\n"); return APUS_E_HIP; }
+    }
+    e->r_running = true; e->r_lead = lead_here; e->r_follow_mask = A.follow_mask;
+    return 0;
+}
+
+static int rep_push_cmd(apus_engine *e, uint32_t op, uint64_t a, uint64_t b)
+{
+    if (!e || !e->r_running || !e->r_lead) return APUS_E_STATE;
+    const double t0 = mono_s();
+    pthread_spin_lock(&e->r_lock);
+    while (e->r_cmd_tail - e->rh->cmd_head >= RC_CAP - 1)
+        if (e->rh->alive == 2 || mono_s() - t0 > 5.0) { pthread_spin_unlock(&e->r_lock); return APUS_E_STATE; }
+    RepCmd &c = e->rh->cmd[e->r_cmd_tail % RC_CAP];
+    c.op = op; c.pad = 0; c.after_slot = e->r_slot_tail; c.a = a; c.b = b;
+    e->r_cmd_tail++;
+    __atomic_store_n((uint64_t *)&e->rh->cmd_tail, e->r_cmd_tail, __ATOMIC_RELEASE);
+    pthread_spin_unlock(&e->r_lock);
+    return 0;
+}
+
+/* Admission, multi-producer (replaces the malloc'd TAILQ + tailq_lock of leader_handle_submit_req,
+ * src/proxy/proxy.c:108-161): a producer RESERVES the next request slot and a range of the pinned payload
+ * arena (short critical section: two counters), copies its payload there itself, then PUBLISHES the slot.
+ * The leader's sequencer takes published slots in slot order, up to 64 per round.  *dst = where the len
+ * payload bytes go. */
+extern "C" int apus_gpu_rep_reserve(apus_engine_t *e, uint32_t len, uint64_t *slot, void **dst)
+{
+    if (!e || !e->r_running || !e->r_lead || !slot || !dst || len > 65535) return APUS_E_STATE;
+    const uint64_t need = ((uint64_t)len + 15) & ~15ull;
+    const double t0 = mono_s();
+    pthread_spin_lock(&e->r_lock);
+    for (;;) {
+        uint64_t pos = e->r_arena_tail;
+        uint64_t phys = pos % RA_CAP;
+        if (phys + need + 16 > RA_CAP) { pos += RA_CAP - phys; phys = 0; }      /* the payload does not straddle the end */
+        if (phys == 0) { pos += 16; phys = 16; }                                 /* bytes -2, -1 of a payload must exist */
+        const uint64_t done = e->rh->slots_done;
+        const uint64_t freed = done ? e->r_slot_aend[(done - 1) % RQ_CAP] : 0;
+        if (e->r_slot_tail - done < RQ_CAP && pos + need - freed <= RA_CAP) {
+            *slot = e->r_slot_tail++;
+            e->r_arena_tail = pos + need;
+            e->r_slot_aend[*slot % RQ_CAP] = pos + need;
+            *dst = (void *)(e->rh->arena + phys);
+            pthread_spin_unlock(&e->r_lock);
+            return 0;
+        }
+        if (e->rh->alive == 2 || mono_s() - t0 > 5.0) { pthread_spin_unlock(&e->r_lock); return e->rh->alive == 2 ? APUS_E_STATE : -1; }
+    }
+}
+
+extern "C" int apus_gpu_rep_publish(apus_engine_t *e, uint64_t slot, const void *dst, uint64_t req_id, uint16_t clt_id, uint8_t type, uint16_t len)
+{
+    if (!e || !e->rh) return APUS_E_STATE;
+    if (type == APUS_NOOP || type == APUS_CONFIG || type == APUS_HEAD || type > 15) return APUS_E_ARG;
+    const uint64_t phys = (uint64_t)((const uint8_t *)dst - e->rh->arena);
+    ReqDev d;
+    d.req_id = req_id; d.pay16_type = (uint32_t)(phys / 16) | ((uint32_t)type << 28); d.len = len; d.clt_id = clt_id;
+    e->rh->desc[slot % RQ_CAP] = d;
+    __atomic_store_n((uint32_t *)&e->rh->ready_len[slot % RQ_CAP], (rep_slot_tag(slot) << 16) | len, __ATOMIC_RELEASE);
+    return 0;
+}
+
+extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uint32_t n, const uint8_t *arena, uint64_t arena_bytes)
+{
+    if (!e || !reqs) return APUS_E_ARG;
+    for (uint32_t g = 0; g < n; g++) {
+        const apus_req_t &q = reqs[g];
+        if (q.payload_off + q.len > arena_bytes) return APUS_E_ARG;
+        uint64_t slot; void *dst;
+        int rc = apus_gpu_rep_reserve(e, q.len, &slot, &dst);
+        if (rc) return rc;
+        if (q.len) memcpy(dst, arena + q.payload_off, q.len);
+        if ((rc = apus_gpu_rep_publish(e, slot, dst, q.req_id, q.clt_id, q.type, q.len))) return rc;
+    }
+    return 0;
+}
+
+/* device-resident input: rounds [r0, r0 + n) of the staged requests (apus_gpu_stage) go through the leader's
+ * workgroups -- the "single persistent kernel per replica" throughput path */
+extern "C" int apus_gpu_rep_run(apus_engine_t *e, uint64_t r0, uint64_t n_rounds)
+{
+    if (!e || r0 + n_rounds > e->n_rounds_staged) return APUS_E_ARG;
+    return rep_push_cmd(e, R_OP_RUN, r0, n_rounds);
+}
+extern "C" int apus_gpu_rep_prune(apus_engine_t *e) { return rep_push_cmd(e, R_OP_PRUNE, 0, 0); }
+
+/* everything submitted so far is appended everywhere, and committed + applied as far as a majority allows */
+extern "C" int apus_gpu_rep_drain(apus_engine_t *e, uint32_t timeout_ms)
+{
+    if (!e || !e->r_running || !e->r_lead) return APUS_E_STATE;
+    const double t0 = mono_s();
+    for (;;) {
+        if (e->rh->settled >= e->r_cmd_tail + e->r_slot_tail) return 0;
+        if (e->rh->alive == 2) return APUS_E_STATE;
+        if ((mono_s() - t0) * 1e3 > timeout_ms) return -1;
+    }
+}
+
+/* Stop the run: the leader's workgroups finish what they were given, wait (bounded) for the ACKs that can
+ * still come, write the control words back and tell every follower to park; follower workgroups hosted here
+ * leave once they have consumed their doorbells.  Returns the leader's exit code (0 stop, 1 idle, 2 timeout),
+ * a follower-only process the worst exit code of its followers.  Afterwards the phased / control-plane
+ * calls may be used again. */
+extern "C" int apus_gpu_rep_park(apus_engine_t *e)
+{
+    if (!e || !e->r_running) return APUS_E_STATE;
+    int code = 0;
+    if (e->r_lead) {
+        int rc = rep_push_cmd(e, R_OP_STOP, 0, 0);
+        if (rc) __atomic_store_n((uint64_t *)&e->rh->stop, 1ull, __ATOMIC_RELEASE);
+    }
+    HIPCHK(hipStreamSynchronize(e->rstream));
+    if (e->r_lead) code = (int)e->rh->exit_code;
+    for (uint32_t m = e->r_follow_mask; m; m &= m - 1) {
+        uint64_t x = 0;
+        HIPCHK(hipMemcpy(&x, &e->d.box[__builtin_ctz(m)]->f_exit, sizeof x, hipMemcpyDeviceToHost));
+        if (x > 1 && (int)(x - 1) > code) code = (int)(x - 1);
+    }
+    e->r_running = false;
+    e->free_lb = 0;
+    e->lag_possible = true;
+    return code;
+}
+
+/* tests only: a hosted follower whose workgroups are not launched -- a dead follower process that the leader still pushes to */
+extern "C" int apus_gpu_rep_test_skip_follower(apus_engine_t *e, uint32_t mask) { if (!e) return APUS_E_ARG; e->r_test_skip = mask; return 0; }
+
+extern "C" uint64_t apus_gpu_rep_highest_rec(apus_engine_t *e) { return (e && e->rh) ? e->rh->highest_rec : 0; }
+extern "C" const volatile uint64_t *apus_gpu_rep_highest_rec_ptr(apus_engine_t *e) { return (e && e->rh) ? &e->rh->highest_rec : nullptr; }
+extern "C" int apus_gpu_rep_full(apus_engine_t *e) { return (e && e->rh) ? (int)e->rh->full : 0; }
+/* out[8] = rounds issued, request slots taken, commands carried out, committed slots, highest_rec, rounds refused,
+ *          followers dropped from the push set (mask), alive */
+extern "C" int apus_gpu_rep_stats(apus_engine_t *e, uint64_t out[8])
+{
+    if (!e || !e->rh || !out) return APUS_E_STATE;
+    out[0] = e->rh->rounds; out[1] = e->rh->slots_done; out[2] = e->rh->cmd_head; out[3] = e->rh->commit_slot;
+    out[4] = e->rh->highest_rec; out[5] = e->rh->full; out[6] = 0; out[7] = e->rh->alive;
+    if (!e->r_running && e->rl) HIPCHK(hipMemcpy(&out[6], &e->rl->drop_mask, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+/* round latency samples of the last run, in nanoseconds: sequenced (the round's requests were seen by the
+ * leader) -> committed by a majority and applied by the leader */
+extern "C" int apus_gpu_rep_latency(apus_engine_t *e, uint32_t *out_ns, uint32_t cap, uint32_t *n_out)
+{
+    if (!e || !e->rl || e->r_running) return APUS_E_STATE;
+    uint32_t n = 0;
+    HIPCHK(hipMemcpy(&n, &e->rl->lat_n, sizeof n, hipMemcpyDeviceToHost));
+    if (n > cap) n = cap;
+    if (n) HIPCHK(hipMemcpy(out_ns, e->rl->lat_ticks, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    int khz = 100000;
+    hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device);
+    if (khz <= 0) khz = 100000;
+    for (uint32_t i = 0; i < n; i++) out_ns[i] = (uint32_t)((uint64_t)out_ns[i] * 1000000ull / (uint64_t)khz);
+    if (n_out) *n_out = n;
+    return 0;
+}
+
+/* submit one round of n <= 64 requests and spin on highest_rec, `iters` times (what proxy.c:160 does) */
+extern "C" int apus_gpu_rep_roundtrip(apus_engine_t *e, const apus_req_t *reqs, uint32_t n, const uint8_t *arena, uint64_t arena_bytes,
+                                      uint32_t iters, uint32_t *out_ns)
+{
+    if (!e || !e->r_running || !e->r_lead || n == 0 || n > APUS_MAX_ROUND) return APUS_E_STATE;
+    for (uint32_t i = 0; i < iters; i++) {
+        const uint64_t target = e->rh->highest_rec + n;
+        const double t0 = mono_s();
+        int rc = apus_gpu_rep_submit(e, reqs, n, arena, arena_bytes);
+        if (rc) return rc;
+        while (e->rh->highest_rec < target)
+            if (e->rh->alive == 2 || mono_s() - t0 > 2.0) return -1;
+        out_ns[i] = (uint32_t)((mono_s() - t0) * 1e9);
+    }
     return 0;
 }
 

@@ -3419,8 +3419,13 @@ __global__ void k_reset(const EngDev E)
     }
     if (!E.rep[p].ring) return;
     uint64_t *h = E.rep[p].hdr;
-    for (int i = 0; i < H_WORDS; i++) h[i] = 0;
-    h[H_LEN] = E.log_len; h[H_END] = E.log_len; h[H_TAIL] = E.log_len; h[H_OLD_END] = E.log_len;
-    h[H_SID] = (uint64_t)p;
-    h[H_CID_BITMASK] = (1u << E.group_size) - 1;
+    /* every word is stored exactly once: the control block is uncached memory, and two stores of one thread to
+     * one word are not something to lean on there */
+    for (int i = 0; i < H_WORDS; i++) {
+        uint64_t v = 0;
+        if (i == H_LEN || i == H_END || i == H_TAIL || i == H_OLD_END) v = E.log_len;
+        else if (i == H_SID) v = (uint64_t)p;
+        else if (i == H_CID_BITMASK) v = (1u << E.group_size) - 1;
+        h[i] = v;
+    }
 }

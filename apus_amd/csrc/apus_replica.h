@@ -1,0 +1,1084 @@
+/*
+ * apus_replica.h -- every replica runs its OWN resident kernel: the reference's one-server-per-machine
+ * structure on GPUs (one replica per GPU / process; or several on one device, each with its workgroups).
+ *
+ *   leader workgroups: the dare_server polling() loop of the LEADER
+ *   (/root/reference/src/dare/dare_server.c:1012-1125), pipelined --
+ *     sequencer (one wavefront)   get_tailq_message + the placement half of log_append_entry
+ *                                 (dare_ibv_ud.c:780-790, dare_log.h:466-558): drains the pinned
+ *                                 multi-producer request ring (or staged, device-resident rounds),
+ *                                 decides where every round goes (both wrap rules, exact fit, the
+ *                                 log-full rule), log_pruning ticks (dare_server.c:1996-2067); one
+ *                                 ticket per round, MANY rounds in flight
+ *     append wavefronts           the byte half of log_append_entry + R1/R2 of update_remote_logs
+ *                                 (dare_ibv_rc.c:1465-1643): the round's bytes into the own ring and,
+ *                                 write-through, into every pushed follower's ring -- ONLY the E log
+ *                                 bytes -- then one 32-byte round doorbell per follower
+ *     committer (one wavefront)   the ACK scan of update_remote_logs (dare_ibv_rc.c:1725-1758): the
+ *                                 followers' per-replica ACK maps of a 64-entry window, one lane per
+ *                                 entry, popcount(acks | self) >= size/2+1, __ballot,
+ *                                 count-trailing-ones = commit prefix; R4 commit doorbell; the
+ *                                 leader's apply (dare_server.c:1815-1974) round by round;
+ *                                 highest_rec to the host
+ *   follower workgroups: the follower's polling() pass on ITS device --
+ *     work wavefronts             poll the round doorbell, read the landed entry headers from the own
+ *                                 ring, build directory + apply records LOCALLY, persist_new_entries
+ *                                 (dare_server.c:1792-1810), rc_send_entries_reply
+ *                                 (dare_ibv_rc.c:1828-1863): reply byte in the own log, R3 = the same
+ *                                 byte in the sender's log + its ACK byte in the sender's map
+ *     control wavefront           retires rounds in order (end, old_end, store count), applies on the
+ *                                 commit doorbell, tells the leader how far it persisted / applied
+ *
+ * A dead or slow follower costs its ACK, nothing else: the commit is decided by majority, every wait
+ * is bounded, a follower that stops consuming its doorbells is dropped from the push set.
+ *
+ * Hand-offs between replicas cross processes and (on a multi-GPU node) xGMI: every shared word lives
+ * in uncached device memory of the replica that READS it (RepBox, ACK maps), is written with
+ * system-scope stores through the HIP-IPC mapping and polled locally; ring bytes are written with
+ * system-scope write-through 16-byte stores, drained (s_waitcnt vmcnt(0)) before the doorbell, and read
+ * with system-scope loads (tools/micro/xproc.hip: 0.64 us one way for a doorbell between two processes'
+ * kernels on one MI355X, 1.25 us with a drained payload in front).  Inside the leader the sequencer ->
+ * append -> committer hand-offs are agent scope (cdna_hip_programming.md Guideline 16).
+ */
+#pragma once
+#include "apus_persistent.h"
+
+#define RB_CAP    2048u          /* round doorbells in flight per follower                    */
+#define RS_CAP    4096u          /* leader: tickets in flight                                 */
+#define RQ_CAP    (1u << 16)     /* pinned request slots                                      */
+#define RA_CAP    (64u << 20)    /* pinned payload arena (bytes)                              */
+#define RC_CAP    256u           /* host command ring                                         */
+#define R_WIN     4              /* 64-slot windows the sequencer reads per PCIe round trip   */
+#define R_LAT_CAP (1u << 16)
+#define R_SLACK   (3u * WAVE)    /* head room kept in the ticket / doorbell rings             */
+
+enum { R_OP_PRUNE = 1, R_OP_RUN = 2, R_OP_STOP = 3 };
+enum { R_SRC_PINNED = 0, R_SRC_STAGED = 1, R_SRC_CONTROL = 2 };
+/* exit codes */
+enum { R_EXIT_STOP = 0, R_EXIT_IDLE = 1, R_EXIT_TIMEOUT = 2, R_EXIT_GAP = 3 };
+
+struct RepCmd { uint32_t op, pad; uint64_t after_slot, a, b; };
+
+/* host <-> leader: pinned, coherent (hipHostMalloc mapped) */
+struct RepHost {
+    /* host -> kernel */
+    volatile uint64_t cmd_tail;
+    volatile uint64_t stop;
+    uint64_t pad0[6];
+    /* kernel -> host */
+    volatile uint64_t cmd_head;          /* commands carried out                               */
+    volatile uint64_t slots_done;        /* request slots whose bytes were read (ring reuse)   */
+    volatile uint64_t highest_rec;       /* proxy->highest_rec (src/proxy/proxy.c:263)         */
+    volatile uint64_t commit_slot;
+    volatile uint64_t alive;             /* 1 running, 2 exited                                */
+    volatile uint64_t exit_code;
+    volatile uint64_t full;              /* rounds refused: the log was full                   */
+    volatile uint64_t rounds;            /* tickets issued                                     */
+    volatile uint64_t settled;           /* commands carried out + request slots taken whose rounds are all in every ring, committed and applied as far as a majority allows */
+    uint64_t pad1[7];
+    RepCmd   cmd[RC_CAP];
+    /* multi-producer request ring: a producer reserves slot + arena range, copies the payload, fills
+     * desc[slot], then publishes ready_len[slot] = tag << 16 | len (release) */
+    volatile uint32_t ready_len[RQ_CAP];
+    ReqDev   desc[RQ_CAP];
+    uint8_t  arena[RA_CAP + 64];
+};
+__host__ __device__ static inline uint32_t rep_slot_tag(uint64_t slot) { return (uint32_t)((slot / RQ_CAP) % 65535u) + 1u; }
+
+/* one replica's mailbox: uncached device memory of the replica, mapped by its peers */
+struct RepBox {
+    /* the leader -> this replica.  One round = four self-tagged granules {seq + 1, value}:
+     *   [0] end offset after the round   [1] low 32 bits of the slot count after the round
+     *   [2] end offset before the round (len: the log read as empty)
+     *   [3] n << 17 | T when all n entries are T bytes long, n << 17 when the sizes differ (lens[]) */
+    uint64_t rnd[RB_CAP][4];
+    uint16_t lens[RB_CAP][WAVE];         /* cmd.len of every entry of a round of mixed sizes (2 B per entry) */
+    uint64_t commit_bell;                /* R4: committed slots                                 */
+    uint64_t ctrl;                       /* (f_runs + 1) << 40 | rounds of this run to consume + 1: park */
+    uint64_t pad0[6];
+    /* followers -> this replica while it leads (index = follower) */
+    uint64_t seqdone_by[16];             /* rounds applied (their doorbell slots are free)      */
+    uint64_t persisted_by[16];           /* entry slots persisted, in order                     */
+    uint64_t applied_by[16];             /* entry slots applied                                 */
+    uint64_t apply_off_by[16];           /* ... and the apply offset that goes with it          */
+    uint64_t sid_by[16];                 /* a follower that moved on to a newer SID says so here: the term fence */
+    /* this replica's own notes, kept across runs of its follower workgroups */
+    uint64_t f_seq_next;                 /* next round it expects                               */
+    uint64_t f_pend_slot0, f_pend_slot_end, f_pend_sid;   /* an exact-fit round it holds back (its end == len) */
+    uint64_t f_exit;                     /* exit code + 1 of the last run                       */
+    uint64_t f_runs;                     /* runs of its follower workgroups that have ended     */
+    uint64_t pad1[2];
+};
+
+struct RepTicket { uint64_t w[8]; };     /* one round, sequencer -> append wavefront / committer */
+enum { TK_E0 = 0, TK_IDX0, TK_SLOT0, TK_SRC, TK_END, TK_D0, TK_D1, TK_META };
+/* TK_D1: control entry data word 1, else the sequencer's wall clock (latency samples)
+ * TK_META: [7:0] n  [11:8] source kind  [12] hidden (the round ends exactly on len)  [23:16] control entry type
+ *          [47:32] push mask */
+struct RepDone { uint64_t tag, hash, nclient, pad; };
+
+/* leader-local state shared by its workgroups (device memory, agent scope) */
+struct RepLead {
+    uint64_t seq_tail;  uint64_t pad0[7];
+    uint64_t seq_final; uint64_t pad1[7];       /* ~0 while running, then the number of tickets */
+    uint64_t t_retired, n_apply, commit_slot, commit_off, apply_off, drop_mask, slots_dropped;
+    uint64_t progress;                          /* commands carried out + request slots taken (written AFTER the tickets they made) */
+    uint64_t t_drop[16];                        /* tickets issued when follower f left the push set (~0: still in) */
+    uint32_t lat_n, pad3;
+    uint32_t lat_ticks[R_LAT_CAP];
+    RepTicket tk[RS_CAP];
+    RepDone   dn[RS_CAP];
+};
+
+/* one round as a follower's work wavefront leaves it for its control wavefront */
+struct RepFRound { uint64_t tag, end_after, slot_end, hash, nclient, head_val, e0, n; };
+struct RepFollow {                       /* follower-local (device memory, agent scope) */
+    uint64_t quit; uint64_t pad[7];
+    RepFRound fr[RB_CAP];
+};
+
+struct RepArgs {
+    RepHost *H;                          /* leader here: its pinned block                         */
+    RepLead *LS;
+    RepFollow *FS[APUS_DEV_MAX_SERVERS]; /* followers hosted here                                 */
+    uint32_t lead_here;                  /* 1: the first 1 + n_append workgroups are the leader's */
+    uint32_t push_mask;                  /* followers in step that get every round of this run    */
+    uint32_t park_mask;                  /* followers the leader tells to park at the end         */
+    uint32_t follow_mask;                /* followers whose workgroups this launch carries         */
+    uint32_t n_append, n_fwork;          /* append workgroups; workgroups per follower             */
+    uint64_t fruns[APUS_DEV_MAX_SERVERS];/* leader: every follower's f_runs when this run began       */
+    uint64_t idle_polls, peer_polls;
+    uint64_t qbase[APUS_DEV_MAX_SERVERS];
+};
+
+/* a short nap between two polls while work is expected, a longer one once the poller has been idle */
+__device__ static inline void rep_nap(bool eager) { if (eager) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(12); }
+__device__ static inline uint32_t ld_sys32(const volatile uint32_t *p) { return __hip_atomic_load((const uint32_t *)p, RLX_SYSTEM); }
+__device__ static inline void st_sys8(uint8_t *p, uint8_t v) { __hip_atomic_store(p, v, RLX_SYSTEM); }
+__device__ static inline uint8_t ld_sys8(const uint8_t *p) { return __hip_atomic_load(p, RLX_SYSTEM); }
+__device__ static inline uint8_t rep_ack_tag(uint64_t slot, uint32_t dir_mask)
+{
+    return (uint8_t)(((slot / ((uint64_t)dir_mask + 1)) & 0x7F) + 1);
+}
+/* 32 bytes of a ring that a peer's kernel wrote (system-scope loads: never an L1 copy of an older lap) */
+__device__ static inline void ld32_sys(const uint8_t *p, uint4 &a, uint4 &b)
+{
+    v4u_t d0, d1;
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(d0), "=&v"(d1) : "v"(p) : "memory");
+    a = make_uint4(d0.x, d0.y, d0.z, d0.w); b = make_uint4(d1.x, d1.y, d1.z, d1.w);
+}
+__device__ static inline uint64_t rl64u(uint64_t v, int l)
+{
+    return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), l, WAVE) << 32) | (uint32_t)__shfl((int)(uint32_t)v, l, WAVE);
+}
+
+/* where the n entries of one round go (log_append_entry, dare_log.h:466-558): lane j holds the size T of
+ * entry j (0 beyond n), e0 = the log's end before the round (len: it reads as empty).  The entry that does
+ * not fit before len wraps to offset 0 -- leaving a stale header behind when only its payload did not fit
+ * (dare_log.h:502-538); an entry that starts exactly on len finds the log "empty" and restarts idx at 1
+ * (dare_log.h:158-162, 486-488: SURVEY Q13). */
+struct RepPlace { int kstar, estar; uint32_t stale; uint64_t w, a, total; };
+__device__ static inline RepPlace rep_place(uint64_t e0, uint64_t L, uint32_t T, uint32_t n)
+{
+    const bool active = lane_id() < n;
+    const uint64_t incl = wave_incl_scan((uint64_t)T);
+    RepPlace s;
+    s.a = e0 + incl - T;
+    const unsigned long long over = __ballot(active && s.a + T > L);
+    s.kstar = -1; s.estar = -1; s.stale = 0; s.w = 0;
+    if (over) {
+        const int ks = __builtin_ctzll(over);
+        s.kstar = ks;
+        s.w = rl64u(s.a, ks);
+        if (s.w == L) s.estar = ks; else if (L - s.w >= APUS_HDR) s.stale = 1;
+    }
+    s.total = rl64u(incl, (int)n - 1);
+    return s;
+}
+__device__ static inline uint64_t rep_pos(const RepPlace &s, int j) { return (s.kstar < 0 || j < s.kstar) ? s.a : (j == s.kstar ? 0 : s.a - s.w); }
+__device__ static inline uint64_t rep_idx(const RepPlace &s, int j, uint64_t idx0) { return (s.estar < 0 || j < s.estar) ? idx0 + (uint64_t)j : 1 + (uint64_t)(j - s.estar); }
+/* the engine's log-full rule (deviation 2): a round that does not fit into the free
+ * part of the ring is refused as a whole, before any store */
+__device__ static inline bool rep_refuse(uint64_t e0, uint64_t L, uint64_t head, const RepPlace &s)
+{
+    if (e0 == L) return false;
+    const uint64_t waste = s.kstar >= 0 ? L - s.w : 0;
+    const uint64_t used = e0 >= head ? e0 - head : L - (head - e0);
+    return e0 == head || s.total + waste > L - used;
+}
+
+/* ===================================================================================== leader */
+struct RepSeqState {                    /* the sequencer's registers: the leader's append-side words */
+    uint64_t end, tail, last_idx, n_end, head, prev_head, store_count;
+    uint64_t c_off, c_slot;             /* the commit as it stands once everything issued has its majority */
+    uint64_t sample_slot;               /* slots the servers sampled by the last tick are taken to have applied */
+    uint64_t t;                         /* tickets issued                                      */
+    uint32_t push_mask;
+    bool     can_commit;
+};
+
+__device__ static inline bool rep_quorum(const EngDev &E, uint32_t push_mask)
+{
+    const uint32_t size = E.group_size, size_mask = (1u << size) - 1;
+    return (uint32_t)__popc((push_mask | (1u << E.leader)) & size_mask) >= size / 2 + 1;
+}
+
+/* one round through the general placement code: lane j holds its entry's size.  False: refused (log full). */
+__device__ static inline bool rep_seq_round(const EngDev &E, RepSeqState &S, RepLead *LS, uint32_t T, uint32_t n, uint32_t kind,
+                                            uint64_t first, uint32_t ctype, uint64_t d0, uint64_t d1)
+{
+    const uint64_t L = E.log_len;
+    const uint32_t lane = lane_id();
+    const RepPlace p = rep_place(S.end, L, T, n);
+    if (rep_refuse(S.end, L, S.head, p)) return false;
+    const int last = (int)n - 1;
+    const uint64_t pos_l = rl64u(rep_pos(p, (int)lane), last);
+    const uint32_t T_l = (uint32_t)__shfl((int)T, last, WAVE);
+    const uint64_t idx_l = rep_idx(p, last, S.last_idx + 1);
+    const uint64_t end_new = pos_l + T_l;
+    const uint32_t hidden = end_new == L;
+    uint64_t v = 0;
+    switch (lane) {
+    case TK_E0: v = S.end; break;
+    case TK_IDX0: v = S.last_idx + 1; break;
+    case TK_SLOT0: v = S.n_end; break;
+    case TK_SRC: v = first; break;
+    case TK_END: v = end_new; break;
+    case TK_D0: v = d0; break;
+    case TK_D1: v = (kind == R_SRC_CONTROL) ? d1 : wall_clock64(); break;
+    case TK_META: v = (uint64_t)n | ((uint64_t)kind << 8) | ((uint64_t)hidden << 12) | ((uint64_t)ctype << 16) | ((uint64_t)S.push_mask << 32); break;
+    default: break;
+    }
+    if (lane < 8) st_agent(&LS->tk[S.t % RS_CAP].w[lane], v);
+    S.t++;
+    S.end = end_new; S.tail = pos_l; S.last_idx = idx_l; S.n_end += n; S.store_count += n;
+    if (!(kind == R_SRC_CONTROL && ctype == 3)) S.prev_head = 0;
+    if (S.can_commit && !hidden) { S.c_off = end_new; S.c_slot = S.n_end; }
+    return true;
+}
+
+__device__ static inline void rep_seq_publish(RepLead *LS, RepHost *H, const RepSeqState &S, uint64_t progress)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane_id() == 0) {
+        st_agent(&LS->seq_tail, S.t); st_sys(&H->rounds, S.t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_agent(&LS->progress, progress);            /* whoever reads this first and seq_tail second sees every ticket behind it */
+    }
+}
+
+/* a follower leaves the push set (it did not consume its doorbells / did not apply in time) */
+__device__ static inline void rep_seq_drop(const EngDev &E, RepSeqState &S, RepLead *LS, uint32_t drop, uint32_t site)
+{
+    drop &= S.push_mask;
+    if (!drop) return;
+    S.push_mask &= ~drop;
+    if (lane_id() == 0) {
+        atomicOr((unsigned long long *)&LS->drop_mask, (unsigned long long)drop);
+        for (uint32_t m = drop; m; m &= m - 1) st_agent(&LS->t_drop[__builtin_ctz(m)], S.t);
+        spin_timeout(E, site);
+    }
+    S.can_commit = rep_quorum(E, S.push_mask);
+}
+
+/* log_pruning (dare_server.c:1996-2067) as the leader's timer tick.  The reference's timer fires between
+ * polling() passes: every reachable server has applied what is committed, and the tick (a) moves the head
+ * to the smallest apply offset SAMPLED BY THE PREVIOUS TICK, (b) appends <HEAD, head>, (c) samples the apply
+ * offsets for the next one (rc_get_remote_apply_offsets, dare_ibv_rc.c:1970-2034).  With many rounds in
+ * flight the pipeline is not drained for that: the offsets sampled are the ones the pinned schedule gives
+ * (everything issued before the tick has its majority and is applied: S.c_off) and the NEXT tick first
+ * verifies that every sampled server really got there (applied_by[] in the leader's mailbox, the leader's
+ * own n_apply) before the head may move -- a server that did not is waited for (bounded), then it leaves
+ * the push set and the head stays.  Without a majority nothing commits: S.c_off stands still, the sample
+ * is the real state. */
+__device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, RepSeqState &S, volatile uint64_t *s_ao /*[16] LDS*/,
+                                            uint32_t bitmask, RepBox *mybox, uint64_t progress)
+{
+    RepLead *LS = A.LS;
+    const uint64_t L = E.log_len;
+    const uint32_t lane = lane_id();
+    /* (0) the last tick's samples must have become true */
+    bool ok = true;
+    if (lane == 0) {
+        for (uint64_t i = 0; ld_agent(&LS->n_apply) < S.sample_slot; i++) {
+            if (i > A.peer_polls) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    } else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) {
+        for (uint64_t i = 0; ld_sys(&mybox->applied_by[lane - 1]) < S.sample_slot; i++) {
+            if (i > A.peer_polls) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    const unsigned long long late = __ballot(!ok);
+    if (late >> 1) rep_seq_drop(E, S, LS, (uint32_t)(late >> 1), 7101);
+    const uint32_t size = E.group_size;
+    const uint64_t c_before = S.c_off, cs_before = S.c_slot;
+    if (!late) {
+        /* (a) + (b) */
+        uint64_t min_off = S.c_off;                                    /* the leader's own apply offset */
+        for (uint32_t i = 0; i < size; i++) {
+            if (!((bitmask >> i) & 1u)) s_ao[i] = S.c_off;
+            if (apus_is_larger(S.end, L, min_off, s_ao[i])) min_off = s_ao[i];
+        }
+        if (apus_end_distance(S.end, L, min_off) == 0) min_off = S.tail;      /* leave one entry, :2038-2041 */
+        if (apus_is_larger(S.end, L, min_off, S.head) && !S.prev_head) {
+            const uint64_t head_before = S.head;
+            S.head = min_off;
+            if (rep_seq_round(E, S, LS, lane == 0 ? APUS_HDR : 0u, 1, R_SRC_CONTROL, 0, 3, min_off, 0)) S.prev_head = 1;
+            else { S.head = head_before; if (lane == 0) { set_status(E, 1u << 1); st_sys(&A.H->full, ld_sys(&A.H->full) + 1); } }
+        }
+    }
+    /* (c): what the servers will have applied when the timer's pass is over = the commit before <HEAD> */
+    for (uint32_t i = 0; i < size; i++) {
+        if (i == E.leader || !((bitmask >> i) & 1u)) s_ao[i] = c_before;
+        else if ((S.push_mask >> i) & 1u) s_ao[i] = c_before;
+    }
+    S.sample_slot = cs_before;
+    rep_seq_publish(LS, A.H, S, progress);
+}
+
+/* the leader's first workgroup: wavefront 0 sequences, wavefront 1 commits */
+__device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, volatile uint64_t *s_h, volatile uint64_t *s_ao, volatile uint64_t *s_x)
+{
+    RepHost *H = A.H;
+    RepLead *LS = A.LS;
+    RepBox *mybox = E.box[E.leader];
+    const uint64_t L = E.log_len;
+    const uint32_t lane = lane_id();
+    RepSeqState S;
+    S.end = s_h[H_END]; S.tail = s_h[H_TAIL]; S.last_idx = s_h[H_LAST_IDX]; S.n_end = s_h[H_N_END]; S.head = s_h[H_HEAD];
+    S.prev_head = s_h[H_PREV_HEAD]; S.store_count = s_h[H_STORE_COUNT];
+    S.c_off = s_h[H_COMMIT]; S.c_slot = s_h[H_N_COMMIT]; S.sample_slot = 0; S.t = 0;
+    S.push_mask = A.push_mask; S.can_commit = rep_quorum(E, S.push_mask);
+    const uint32_t bitmask = (uint32_t)s_h[H_CID_BITMASK];
+    if (lane < 16) s_ao[lane] = (lane < APUS_DEV_MAX_SERVERS) ? s_h[H_APPLY_OFFSETS + lane] : 0;
+    uint64_t req_head = ld_sys(&H->slots_done), cmd_head = ld_sys(&H->cmd_head);
+    bool have_cmd = false;
+    RepCmd cmd; cmd.op = 0; cmd.after_slot = 0; cmd.a = cmd.b = 0;
+    uint64_t run_next = 0, run_end = 0;
+    uint64_t idle = 0, budget = 0;
+    uint32_t exit_code = R_EXIT_STOP;
+    if (lane == 0) st_sys(&H->alive, 1);
+
+    for (;;) {
+        /* ---- flow control: room in the ticket ring and in every pushed follower's doorbell ring ---- */
+        if (budget < WAVE) {
+            uint64_t spins = 0;
+            for (;;) {
+                uint64_t room = ~0ull;
+                if (lane == 0) {
+                    const uint64_t inflight = S.t - ld_agent(&LS->t_retired);
+                    room = inflight + R_SLACK >= RS_CAP ? 0 : RS_CAP - R_SLACK - inflight;
+                } else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) {
+                    const uint64_t inflight = A.qbase[lane - 1] + S.t - ld_sys(&mybox->seqdone_by[lane - 1]);
+                    room = inflight + R_SLACK >= RB_CAP ? 0 : RB_CAP - R_SLACK - inflight;
+                }
+                const unsigned long long tight = __ballot(room < WAVE);
+                if (!tight) {
+                    for (int d = WAVE / 2; d > 0; d >>= 1) { const uint64_t o = rl64u(room, (int)(lane ^ (uint32_t)d)); room = o < room ? o : room; }
+                    budget = room;
+                    break;
+                }
+                if (++spins > A.peer_polls) {
+                    if (tight >> 1) { rep_seq_drop(E, S, LS, (uint32_t)(tight >> 1), 7102); spins = 0; continue; }
+                    exit_code = R_EXIT_TIMEOUT;                     /* the leader's own commit does not move: no majority */
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (exit_code == R_EXIT_TIMEOUT) { if (lane == 0) spin_timeout(E, 7103); break; }
+        }
+        /* ---- the next host command, once every request queued before it was taken ---- */
+        if (!have_cmd && run_next == run_end) {
+            if (ld_sys(&H->cmd_tail) > cmd_head) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                const RepCmd *c = &H->cmd[cmd_head % RC_CAP];
+                cmd.op = c->op; cmd.after_slot = c->after_slot; cmd.a = c->a; cmd.b = c->b;
+                have_cmd = true;
+            }
+        }
+        if (run_next < run_end) {
+            /* ---- staged (device-resident) rounds: one lane per round ---- */
+            const uint64_t rc = run_next;
+            const uint32_t nch = (uint32_t)min((uint64_t)WAVE, min(run_end - rc, budget));
+            const bool on = lane < nch;
+            const uint64_t r = rc + (on ? lane : 0);
+            const uint64_t pf0 = E.round_prefix[r], pf1 = E.round_prefix[r + 1];
+            const uint32_t rf0 = E.round_first[r], rf1 = E.round_first[r + 1];
+            const uint32_t len_l = E.req_len[rf1 - 1];
+            const uint64_t bpf = rl64u(pf0, 0);
+            const uint32_t brf = (uint32_t)__shfl((int)rf0, 0, WAVE);
+            const uint64_t used = S.end >= S.head ? S.end - S.head : L - (S.head - S.end);
+            /* lanes that can go without the general code: the log does not read as empty, no entry of rounds
+             * 0..j crosses or touches len, everything fits into the free part of the ring */
+            const bool plain = on && S.end != L && S.end + (pf1 - bpf) < L && S.end != S.head && (pf1 - bpf) + APUS_HDR <= L - used;
+            const unsigned long long pm = __ballot(plain);
+            const uint32_t np = (~pm) ? (uint32_t)__builtin_ctzll(~pm) : WAVE;      /* prefix of plain rounds */
+            if (np) {
+                const uint64_t stamp = wall_clock64();
+                if (lane < np) {
+                    uint64_t *w = LS->tk[(S.t + lane) % RS_CAP].w;
+                    st_agent(&w[TK_E0], S.end + (pf0 - bpf));
+                    st_agent(&w[TK_IDX0], S.last_idx + 1 + (rf0 - brf));
+                    st_agent(&w[TK_SLOT0], S.n_end + (rf0 - brf));
+                    st_agent(&w[TK_SRC], (uint64_t)rf0);
+                    st_agent(&w[TK_END], S.end + (pf1 - bpf));
+                    st_agent(&w[TK_D0], 0ull);
+                    st_agent(&w[TK_D1], stamp);
+                    st_agent(&w[TK_META], (uint64_t)(rf1 - rf0) | ((uint64_t)R_SRC_STAGED << 8) | ((uint64_t)S.push_mask << 32));
+                }
+                const uint64_t tot = rl64u(pf1, (int)np - 1) - bpf;
+                const uint32_t ntot = (uint32_t)__shfl((int)rf1, (int)np - 1, WAVE) - brf;
+                const uint32_t Tl = APUS_HDR + (uint32_t)__shfl((int)len_l, (int)np - 1, WAVE);
+                S.end += tot; S.tail = S.end - Tl; S.last_idx += ntot; S.n_end += ntot; S.store_count += ntot; S.prev_head = 0;
+                if (S.can_commit) { S.c_off = S.end; S.c_slot = S.n_end; }
+                S.t += np; budget -= np; run_next += np;
+            } else {
+                /* the round at the head of the chunk needs the general code (wrap, exact fit, nearly full) */
+                const uint32_t n = (uint32_t)__shfl((int)(rf1 - rf0), 0, WAVE);
+                const uint32_t T = lane < n ? APUS_HDR + (uint32_t)E.req_len[brf + lane] : 0u;
+                if (!rep_seq_round(E, S, LS, T, n, R_SRC_STAGED, brf, 0, 0, 0)) {
+                    if (lane == 0) { set_status(E, 1u << 1); st_sys(&H->full, ld_sys(&H->full) + 1); }
+                } else budget--;
+                run_next++;
+            }
+            if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); }
+            rep_seq_publish(LS, H, S, cmd_head + req_head);
+            idle = 0;
+            continue;
+        }
+        if (have_cmd && cmd.after_slot <= req_head) {
+            have_cmd = false;
+            if (cmd.op == R_OP_STOP) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); exit_code = R_EXIT_STOP; break; }
+            if (cmd.op == R_OP_RUN) {
+                run_next = cmd.a; run_end = cmd.a + cmd.b;
+                if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); rep_seq_publish(LS, H, S, cmd_head + req_head); }
+                idle = 0;
+                continue;
+            }
+            cmd_head++;
+            if (lane == 0) st_sys(&H->cmd_head, cmd_head);
+            if (cmd.op == R_OP_PRUNE) { rep_seq_prune(E, A, S, s_ao, bitmask, mybox, cmd_head + req_head); if (budget) budget--; }
+            else rep_seq_publish(LS, H, S, cmd_head + req_head);
+            idle = 0;
+            continue;
+        }
+        /* ---- the pinned request ring: whatever is published, in rounds of <= 64 (one polling() pass takes
+         *      the whole tailq, dare_ibv_ud.c:780-790) ---- */
+        const uint64_t limit = have_cmd ? cmd.after_slot : ~0ull;
+        uint32_t v[R_WIN];
+#pragma unroll
+        for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = ld_sys32(&H->ready_len[(req_head + (uint64_t)wdw * WAVE + lane) % RQ_CAP]);
+        bool any = false;
+#pragma unroll
+        for (int wdw = 0; wdw < R_WIN; wdw++) {
+            if (budget == 0) break;
+            const uint64_t slot = req_head + lane;
+            const bool ok = slot < limit && (v[wdw] >> 16) == rep_slot_tag(slot);
+            const unsigned long long bal = __ballot(ok);
+            const uint32_t n = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
+            if (n == 0) break;
+            if (!any) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                 /* descriptors + payload behind the tags */
+            any = true;
+            const uint32_t T = lane < n ? APUS_HDR + (v[wdw] & 0xFFFFu) : 0u;
+            if (!rep_seq_round(E, S, LS, T, n, R_SRC_PINNED, req_head, 0, 0, 0)) {
+                /* refused: the requests are dropped (get_tailq_message frees the node anyway), the host is told */
+                if (lane == 0) { set_status(E, 1u << 1); st_sys(&H->full, ld_sys(&H->full) + 1); }
+                s_x[8] += n;                                                         /* slots consumed without a ticket */
+            } else budget--;
+            req_head += n;
+            if (n < WAVE) break;
+        }
+        if (any) { if (lane == 0) st_agent(&LS->slots_dropped, (uint64_t)s_x[8]); rep_seq_publish(LS, H, S, cmd_head + req_head); idle = 0; continue; }
+        /* ---- nothing to do ---- */
+        if (ld_sys(&H->stop)) { exit_code = R_EXIT_STOP; break; }
+        if (++idle > A.idle_polls) { exit_code = R_EXIT_IDLE; break; }
+        rep_nap(idle < 64);
+    }
+    rep_seq_publish(LS, H, S, cmd_head + req_head);
+    if (lane == 0) {
+        st_agent(&LS->seq_final, S.t);
+        /* the leader's append-side words (log_append_entry's bookkeeping, persist_new_entries' own part) */
+        uint64_t *mh = E.rep[E.leader].hdr;
+        mh[H_END] = S.end; mh[H_TAIL] = S.tail; mh[H_LAST_IDX] = S.last_idx; mh[H_N_END] = S.n_end; mh[H_HEAD] = S.head;
+        mh[H_PREV_HEAD] = S.prev_head; mh[H_STORE_COUNT] = S.store_count; mh[H_OLD_END] = S.end; mh[H_N_PERSIST] = S.n_end;
+        for (uint32_t i = 0; i < APUS_DEV_MAX_SERVERS; i++) mh[H_APPLY_OFFSETS + i] = s_ao[i];
+        s_x[0] = exit_code; s_x[1] = S.t; s_x[2] = S.push_mask; s_x[3] = S.end; s_x[4] = S.n_end;
+    }
+}
+
+__device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, volatile uint64_t *s_h, volatile uint64_t *s_x)
+{
+    RepHost *H = A.H;
+    RepLead *LS = A.LS;
+    const RepDev &Md = E.rep[E.leader];
+    const uint32_t lane = lane_id(), me = E.leader;
+    const uint32_t size = E.group_size, size_mask = (1u << size) - 1, quorum = size / 2 + 1;
+    const uint32_t members = size_mask & ~(1u << me);
+    const uint8_t *ackb = E.ackb[me];
+    const uint64_t cap = (uint64_t)E.dir_mask + 1;
+    uint64_t t_done = 0, t_app = 0;                      /* tickets whose bytes are everywhere / applied */
+    uint64_t vis = s_h[H_N_VISIBLE], vis_off = s_h[H_END];
+    uint64_t n_end_seen = s_h[H_N_END];
+    uint64_t cs = s_h[H_N_COMMIT], c_off = s_h[H_COMMIT];
+    uint64_t n_apply = s_h[H_N_APPLY], a_off = s_h[H_APPLY];
+    uint64_t hash = 0, ncl = 0, slots_done = ld_sys(&H->slots_done), settled = ~0ull;
+    uint32_t lat_n = 0;
+    if (s_h[H_END] != E.log_len) vis = n_end_seen;       /* (an exact-fit round left hidden stays so until the next round is in) */
+    else if (vis < n_end_seen) vis_off = Md.dir_off[(uint32_t)vis & E.dir_mask];
+    if (lane == 0) { st_agent(&LS->n_apply, n_apply); st_agent(&LS->commit_slot, cs); st_agent(&LS->commit_off, c_off); }
+    uint64_t patience = 0;
+    uint32_t push_live = A.push_mask;
+    for (;;) {
+        bool progress = false;
+        const uint64_t prog = ld_agent(&LS->progress);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t tail = ld_agent(&LS->seq_tail), fin = ld_agent(&LS->seq_final);
+        /* ---- rounds whose bytes are in every pushed ring, in order ---- */
+        if (t_done < tail) {
+            const uint64_t k = t_done + lane;
+            const bool in = k < tail;
+            const uint64_t tag = in ? ld_agent(&LS->dn[k % RS_CAP].tag) : 0;
+            const unsigned long long bal = __ballot(in && tag == k + 1);
+            const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
+            if (p) {
+                const bool mine = lane < p;
+                const uint64_t meta = mine ? ld_agent(&LS->tk[k % RS_CAP].w[TK_META]) : 0;
+                const uint64_t slot0 = mine ? ld_agent(&LS->tk[k % RS_CAP].w[TK_SLOT0]) : 0;
+                const uint64_t endk = mine ? ld_agent(&LS->tk[k % RS_CAP].w[TK_END]) : 0;
+                const uint32_t n = (uint32_t)(meta & 0xFF);
+                const uint32_t pinned = mine && ((meta >> 8) & 0xF) == R_SRC_PINNED ? n : 0;
+                slots_done += wave_sum(pinned);
+                const uint64_t e0k = mine ? ld_agent(&LS->tk[k % RS_CAP].w[TK_E0]) : 0;
+                const uint64_t se_l = rl64u(slot0 + n, (int)p - 1), s0_l = rl64u(slot0, (int)p - 1), end_l = rl64u(endk, (int)p - 1), e0_l = rl64u(e0k, (int)p - 1);
+                const uint32_t pm_l = (uint32_t)(rl64u(meta, (int)p - 1) >> 32) & 0xFFFF;
+                n_end_seen = se_l;
+                if (end_l == E.log_len) { vis = s0_l; vis_off = e0_l; }   /* the round sits exactly on len: the log reads as empty, nothing of it is visible yet */
+                else { vis = se_l; vis_off = end_l; }
+                push_live = pm_l;
+                t_done += p;
+                progress = true;
+                if (lane == 0) st_sys(&H->slots_done, slots_done + ld_agent(&LS->slots_dropped));
+            }
+        }
+        /* ---- the ACK scan: one lane per entry of the window ---- */
+        while (cs < vis) {
+            const uint64_t s = cs + lane;
+            const bool in = s < vis;
+            uint32_t bits = 0;
+            if (in) {
+                const uint32_t di = (uint32_t)s & E.dir_mask;
+                const uint8_t want = rep_ack_tag(s, E.dir_mask);
+                for (uint32_t m = members; m; m &= m - 1) {
+                    const uint32_t f = (uint32_t)__builtin_ctz(m);
+                    if (ld_sys8(ackb + (uint64_t)f * cap + di) == want) bits |= 1u << f;
+                }
+            }
+            const bool okc = !in || (uint32_t)__popc((bits | (1u << me)) & size_mask) >= quorum;   /* replies >= size/2+1, :1738 */
+            const unsigned long long bal = __ballot(okc);
+            const uint32_t prefix = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;               /* trailing ones */
+            const uint64_t adv = min((uint64_t)prefix, vis - cs);
+            if (adv) { cs += adv; progress = true; }
+            if (prefix < WAVE) break;
+        }
+        if (progress && cs > ld_agent(&LS->commit_slot)) {
+            c_off = (cs == vis) ? vis_off : ld_agent(&Md.dir_off[(uint32_t)cs & E.dir_mask]);
+            if (lane == 0) { st_agent(&LS->commit_off, c_off); st_agent(&LS->commit_slot, cs); st_sys(&H->commit_slot, cs); }
+            else if (lane <= APUS_DEV_MAX_SERVERS && ((push_live >> (lane - 1)) & 1u)) st_sys(&E.box[lane - 1]->commit_bell, cs);   /* R4 */
+        }
+        /* ---- the leader applies round by round (it never runs do_action: highest_rec) ---- */
+        if (t_app < t_done) {
+            const uint64_t k = t_app + lane;
+            const bool in = k < t_done;
+            uint64_t slot_end = ~0ull, endk = 0, hk = 0, nk = 0, stamp = 0;
+            if (in) {
+                const RepTicket &tkt = LS->tk[k % RS_CAP];
+                const uint64_t meta = ld_agent(&tkt.w[TK_META]);
+                slot_end = ld_agent(&tkt.w[TK_SLOT0]) + (meta & 0xFF);
+                endk = ld_agent(&tkt.w[TK_END]);
+                stamp = ((meta >> 8) & 0xF) == R_SRC_CONTROL ? 0 : ld_agent(&tkt.w[TK_D1]);
+                hk = ld_agent(&LS->dn[k % RS_CAP].hash); nk = ld_agent(&LS->dn[k % RS_CAP].nclient);
+            }
+            const unsigned long long bal = __ballot(in && slot_end <= cs);
+            const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
+            if (p) {
+                const bool mine = lane < p;
+                hash += wave_sum(mine ? hk : 0ull);
+                const uint64_t nc = wave_sum(mine ? nk : 0ull);
+                ncl += nc;
+                n_apply = rl64u(slot_end, (int)p - 1);
+                a_off = (n_apply == vis) ? vis_off : ld_agent(&Md.dir_off[(uint32_t)n_apply & E.dir_mask]);
+                const uint64_t now = wall_clock64();
+                const uint32_t ln = lat_n;
+                if (mine && stamp && ln + lane < R_LAT_CAP) LS->lat_ticks[ln + lane] = (uint32_t)(now - stamp);
+                lat_n = min(ln + p, R_LAT_CAP);
+                t_app += p;
+                progress = true;
+                if (lane == 0) {
+                    st_agent(&LS->apply_off, a_off); st_agent(&LS->n_apply, n_apply); st_agent(&LS->t_retired, t_app);
+                    if (nc) st_sys(&H->highest_rec, s_h[H_HIGHEST_REC] + ncl);
+                }
+            }
+        }
+        /* ---- done? ---- */
+        {
+            const bool can = (uint32_t)__popc((push_live | (1u << me)) & size_mask) >= quorum;
+            if (t_done == tail && ((cs == vis && n_apply == cs) || !can) && settled != prog) { settled = prog; if (lane == 0) st_sys(&H->settled, prog); }
+        }
+        if (fin != ~0ull && t_done >= fin && cs == vis && n_apply == cs) break;
+        if (fin != ~0ull && t_done >= fin) {
+            /* nothing more will be appended; ACKs may still be on their way -- unless no majority can answer */
+            const bool can = (uint32_t)__popc((push_live | (1u << me)) & size_mask) >= quorum;
+            if (!can || ++patience > A.peer_polls) { if (can && lane == 0) spin_timeout(E, 7201); break; }
+        } else if (fin != ~0ull && ++patience > 64 * A.peer_polls) { if (lane == 0) spin_timeout(E, 7202); break; }
+        if (!progress) __builtin_amdgcn_s_sleep(2);
+    }
+    if (lane == 0) {
+        uint64_t *mh = Md.hdr;
+        mh[H_N_VISIBLE] = vis;
+        LS->lat_n = lat_n;
+        mh[H_COMMIT] = c_off; mh[H_N_COMMIT] = cs;
+        mh[H_APPLY] = a_off; mh[H_N_APPLY] = n_apply;
+        mh[H_APPLY_HASH] = s_h[H_APPLY_HASH] + hash; mh[H_APPLY_COUNT] = s_h[H_APPLY_COUNT] + ncl;
+        mh[H_HIGHEST_REC] = s_h[H_HIGHEST_REC] + ncl;
+        st_sys(&H->highest_rec, s_h[H_HIGHEST_REC] + ncl);
+        s_x[5] = cs;
+    }
+    /* what the followers acknowledged of the entries that did not commit (no majority): into the slot words
+     * the control-plane kernels scan (k_control_round's commit_scan) */
+    for (uint64_t s = cs + lane; s < n_end_seen; s += WAVE) {
+        const uint32_t di = (uint32_t)s & E.dir_mask;
+        const uint8_t want = rep_ack_tag(s, E.dir_mask);
+        uint32_t bits = 0;
+        for (uint32_t m = members; m; m &= m - 1) {
+            const uint32_t f = (uint32_t)__builtin_ctz(m);
+            if (ld_sys8(ackb + (uint64_t)f * cap + di) == want) bits |= 1u << f;
+        }
+        __hip_atomic_store(&Md.ack[di], bits, RLX_AGENT);
+    }
+    /* the last word on the commit, then the followers may park */
+    if (lane >= 1 && lane <= APUS_DEV_MAX_SERVERS && ((push_live >> (lane - 1)) & 1u)) st_sys(&E.box[lane - 1]->commit_bell, cs);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+struct RepAppLds {
+    uint64_t pos[WAVE];
+    uint64_t src[WAVE];
+    uint32_t T[WAVE];
+    uint32_t ubase[WAVE + 1];
+    uint4    h0[WAVE];
+    uint4    h1[WAVE];
+};
+
+/* one append wavefront: ticket k, k + G, ... */
+__device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A, RepAppLds &lds, uint32_t g, uint32_t G)
+{
+    RepHost *H = A.H;
+    RepLead *LS = A.LS;
+    const uint32_t lane = lane_id(), me = E.leader;
+    const RepDev &Md = E.rep[me];
+    const uint64_t L = E.log_len;
+    const uint64_t term = Md.hdr[H_SID] >> 9;
+    for (uint64_t k = g;; k += G) {
+        /* ---- wait for ticket k ---- */
+        uint32_t go = 0;
+        if (lane == 0) {
+            for (uint64_t i = 0;; i++) {
+                if (ld_agent(&LS->seq_tail) > k) { go = 1; break; }
+                if (ld_agent(&LS->seq_final) <= k) break;
+                rep_nap(i < 256);
+            }
+        }
+        go = (uint32_t)__shfl((int)go, 0, WAVE);
+        if (!go) return;
+        const RepTicket &tkt = LS->tk[k % RS_CAP];
+        const uint64_t wv = lane < 8 ? ld_agent(&tkt.w[lane]) : 0;
+        const uint64_t e0 = rl64u(wv, TK_E0), idx0 = rl64u(wv, TK_IDX0), slot0 = rl64u(wv, TK_SLOT0), first = rl64u(wv, TK_SRC);
+        const uint64_t end_after = rl64u(wv, TK_END), d0 = rl64u(wv, TK_D0), d1 = rl64u(wv, TK_D1), meta = rl64u(wv, TK_META);
+        const uint32_t n = (uint32_t)(meta & 0xFF), kind = (uint32_t)(meta >> 8) & 0xF, ctype = (uint32_t)(meta >> 16) & 0xFF;
+        const uint32_t push = (uint32_t)(meta >> 32) & 0xFFFF;
+        const uint32_t rings = push | (1u << me);
+        const bool active = lane < n;
+        /* ---- get_tailq_message: the requests of the round ---- */
+        ReqDev d; d.req_id = 0; d.pay16_type = 0; d.len = 0; d.clt_id = 0;
+        const uint8_t *arena = nullptr;
+        if (kind == R_SRC_PINNED) {
+            /* descriptors and payload sit in host memory whose lines this CU may hold from an earlier, partly
+             * filled state (a vector L1 is never refreshed by anybody's stores): drop them */
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            if (active) { const uint4 q = *(const uint4 *)&H->desc[(first + lane) % RQ_CAP]; d.req_id = (uint64_t)q.x | ((uint64_t)q.y << 32); d.pay16_type = q.z; d.len = (uint16_t)(q.w & 0xFFFF); d.clt_id = (uint16_t)(q.w >> 16); }
+            arena = H->arena;
+        } else if (kind == R_SRC_STAGED) {
+            if (active) d = E.req[first + lane];
+            arena = E.arena;
+        } else {
+            d.pay16_type = ctype << 28;
+        }
+        const uint32_t T = active ? APUS_HDR + d.len : 0;
+        const RepPlace pl = rep_place(e0, L, T, n);
+        const uint64_t pos = rep_pos(pl, (int)lane);
+        const uint64_t idx = rep_idx(pl, (int)lane, idx0);
+        const uint32_t type = d.pay16_type >> 28;
+        const uint32_t nu = active ? (T + 15) / 16 : 0;
+        const uint32_t uincl = wave_incl_scan(nu);
+        const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)term, (uint32_t)(term >> 32));
+        const uint4 h1 = make_uint4((uint32_t)d.req_id, (uint32_t)(d.req_id >> 32), (uint32_t)d.clt_id | (type << 16) | (me << 24), 0);
+        lds.pos[lane] = pos;
+        lds.src[lane] = (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
+        lds.T[lane] = T;
+        lds.ubase[lane] = uincl - nu;
+        lds.h0[lane] = h0; lds.h1[lane] = h1;
+        if (lane == WAVE - 1) lds.ubase[WAVE] = uincl;
+        /* every entry of the same size?  (the followers then place the round from one number) */
+        const uint32_t T0 = (uint32_t)__shfl((int)T, 0, WAVE);
+        const bool uniform = !__ballot(active && T != T0);
+        uint64_t mix = 0;
+        uint32_t client = 0;
+        if (active) {
+            const uint64_t slot = slot0 + lane;
+            const uint32_t di = (uint32_t)slot & E.dir_mask;
+            st_agent(&Md.dir_off[di], pos);
+            __hip_atomic_store(&Md.dir_len[di], T | (me << 24), RLX_AGENT);
+            /* the leader's apply record (apply_committed_entries, dare_server.c:1941-1955): written with the
+             * entry, counted by the committer once the entry's round is committed */
+            client = (type != APUS_NOOP && type != APUS_CONFIG && type != APUS_HEAD);
+            uint4 *rp = (uint4 *)&Md.apply[di];
+            /* (write-through like everything a run stores: one run laps the apply ring, and two XCDs' dirty copies of
+             * one line could be written back in either order) */
+            st16_agent((uint8_t *)rp, make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32)));
+            st16_agent((uint8_t *)(rp + 1), make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), T - APUS_HDR, (uint32_t)d.clt_id | (type << 16) | (client << 24)));
+            if (client) mix = apus_apply_mix(slot, pos, idx, T - APUS_HDR, d.clt_id, (uint8_t)type, 1);
+            if (pl.stale && (int)lane == pl.kstar) {
+                /* case 2 of the wrap: the header stays where it did fit (dare_log.h:521-538) */
+                const uint4 z = make_uint4(0, 0, 0, 0), l4 = make_uint4((uint32_t)d.len, 0, 0, 0);
+                for (uint32_t m = rings; m; m &= m - 1) {
+                    uint8_t *rg = E.rep[__builtin_ctz(m)].ring;
+                    st16_agent(rg + pl.a, h0); st16_agent(rg + pl.a + 16, h1); st16_agent(rg + pl.a + 32, z); st16_agent(rg + pl.a + 48, l4);
+                }
+            }
+            if (!uniform) for (uint32_t m = push; m; m &= m - 1) {
+                const uint32_t f = (uint32_t)__builtin_ctz(m);
+                __hip_atomic_store(&E.box[f]->lens[(A.qbase[f] + k) % RB_CAP][lane], (uint16_t)d.len, RLX_SYSTEM);
+            }
+        }
+        const uint64_t hsum = wave_sum(mix);
+        const uint32_t nclient = wave_sum(client);
+        {
+            const uint64_t end_chk = rl64u(pos + T, (int)n - 1);        /* the sequencer and this wavefront must agree */
+            const uint32_t T0x = (uint32_t)__shfl((int)T, 0, WAVE);
+            if (lane == 0 && end_chk != end_after && !(atomicOr(E.status, 1u << 3) & (1u << 3))) {
+                E.status[3] = (uint32_t)k; E.status[4] = (uint32_t)end_chk; E.status[5] = (uint32_t)end_after;
+                E.status[6] = n | (kind << 8) | (T0x << 16); E.status[7] = (uint32_t)e0;
+            }
+        }
+        /* ---- the round's bytes: own ring + R1 to every pushed follower ---- */
+        const uint32_t utotal = lds.ubase[WAVE];
+        constexpr int ILP = 4;
+        for (uint32_t u0 = lane; u0 < utotal; u0 += WAVE * ILP) {
+            uint4 v[ILP];
+            uint64_t p[ILP];
+            bool on[ILP];
+#pragma unroll
+            for (int q = 0; q < ILP; q++) {
+                const uint32_t u = u0 + q * WAVE;
+                on[q] = u < utotal;
+                v[q] = make_uint4(0, 0, 0, 0); p[q] = 0;
+                if (!on[q]) continue;
+                uint32_t lo = 0, hi = n - 1;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1) >> 1;
+                    if (lds.ubase[mid] <= u) lo = mid; else hi = mid - 1;
+                }
+                const uint32_t e = lo, Te = lds.T[e], j = u - lds.ubase[e];
+                const uint32_t so = min(16u * j, Te - 16u);
+                if (so == 0) v[q] = lds.h0[e];
+                else if (so == 16) v[q] = lds.h1[e];
+                else if (so == 32) v[q] = make_uint4(0, 0, 0, 0);
+                else if (kind == R_SRC_CONTROL) v[q] = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
+                else v[q] = payload_unit(arena + lds.src[e], so, Te - APUS_HDR, Te - APUS_HDR);
+                p[q] = lds.pos[e] + so;
+            }
+#pragma unroll
+            for (int q = 0; q < ILP; q++)
+                if (on[q])
+                    for (uint32_t m = rings; m; m &= m - 1) st16_agent(E.rep[__builtin_ctz(m)].ring + p[q], v[q]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        /* ---- R2: the round's doorbell in every pushed follower's mailbox ---- */
+        if (lane < 4) {
+            const uint32_t val = lane == 0 ? (uint32_t)end_after : lane == 1 ? (uint32_t)(slot0 + n) : lane == 2 ? (uint32_t)e0
+                                                                                             : ((n << 17) | (uniform ? T0 : 0u));
+            for (uint32_t m = push; m; m &= m - 1) {
+                const uint32_t f = (uint32_t)__builtin_ctz(m);
+                const uint64_t q = A.qbase[f] + k;
+                st_sys(&E.box[f]->rnd[q % RB_CAP][lane], ((q + 1) << 32) | val);
+            }
+        }
+        if (lane == 0) { st_agent(&LS->dn[k % RS_CAP].hash, hsum); st_agent(&LS->dn[k % RS_CAP].nclient, (uint64_t)nclient); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) st_agent(&LS->dn[k % RS_CAP].tag, k + 1);
+    }
+}
+
+/* ===================================================================================== follower */
+/* one work wavefront of follower `me`: rounds q0 + g, q0 + g + G, ... */
+__device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A, uint32_t me, uint32_t g, uint32_t G)
+{
+    RepBox *box = E.box[me];
+    RepFollow *FS = A.FS[me];
+    const RepDev &Md = E.rep[me];
+    const uint32_t lane = lane_id();
+    const uint64_t L = E.log_len;
+    const uint64_t q0 = ld_sys(&box->f_seq_next), my_run = ld_sys(&box->f_runs);
+    const uint64_t n_end0 = Md.hdr[H_N_END], my_sid = Md.hdr[H_SID];
+    const uint32_t leader = E.leader;
+    const uint64_t cap = (uint64_t)E.dir_mask + 1;
+    for (uint64_t q = q0 + g;; q += G) {
+        const uint32_t r = (uint32_t)(q % RB_CAP);
+        /* ---- wait for the doorbell of round q ---- */
+        uint64_t wv = 0;
+        uint32_t go = 0;
+        for (uint64_t i = 0;; i++) {
+            if (lane < 4) wv = ld_sys(&box->rnd[r][lane]);
+            if (__ballot(lane < 4 && (wv >> 32) == ((q + 1) & 0xFFFFFFFFull)) == 0xFull) { go = 1; break; }
+            if ((i & 15) == 15) {
+                const uint64_t ctrl = ld_sys(&box->ctrl);
+                if ((ctrl >> 40) == my_run + 1 && q0 + (ctrl & 0xFFFFFFFFFFull) - 1 <= q) break;   /* parked: round q never comes */
+                if (ld_agent(&FS->quit)) break;
+            }
+            rep_nap(i < 512);
+        }
+        if (!go) return;
+        const uint32_t end_after = (uint32_t)rl64u(wv, 0), slot_lo = (uint32_t)rl64u(wv, 1), e0 = (uint32_t)rl64u(wv, 2), w3 = (uint32_t)rl64u(wv, 3);
+        const uint32_t n = w3 >> 17, Tu = w3 & 0x1FFFF;
+        /* the slot count's high half: this run stays within 2^31 slots of where it began */
+        uint64_t slot_end = (n_end0 & ~0xFFFFFFFFull) | slot_lo;
+        if (slot_end + (1ull << 31) < n_end0) slot_end += 1ull << 32;
+        const uint64_t slot0 = slot_end - n;
+        const bool active = lane < n;
+        const uint32_t T = !active ? 0u : (Tu ? Tu : APUS_HDR + (uint32_t)__hip_atomic_load(&box->lens[r][lane], RLX_SYSTEM));
+        const RepPlace pl = rep_place(e0, L, T, n);
+        const uint64_t pos = rep_pos(pl, (int)lane);
+        /* ---- persist_new_entries: the entries as they landed in the own log ---- */
+        uint4 u0 = make_uint4(0, 0, 0, 0), u1 = u0;
+        uint64_t mix = 0, head_val = ~0ull;
+        uint32_t client = 0;
+        if (active) {
+            ld32_sys(Md.ring + pos, u0, u1);
+            const uint64_t idx = (uint64_t)u0.x | ((uint64_t)u0.y << 32);
+            const uint32_t type = (u1.z >> 16) & 0xFF, sender = u1.z >> 24;
+            const uint16_t clt = (uint16_t)(u1.z & 0xFFFF);
+            const uint64_t slot = slot0 + lane;
+            const uint32_t di = (uint32_t)slot & E.dir_mask;
+            st_agent(&Md.dir_off[di], pos);
+            __hip_atomic_store(&Md.dir_len[di], T | (sender << 24), RLX_AGENT);
+            client = (type != APUS_NOOP && type != APUS_CONFIG && type != APUS_HEAD);
+            uint4 *rp = (uint4 *)&Md.apply[di];
+            st16_agent((uint8_t *)rp, make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32)));
+            st16_agent((uint8_t *)(rp + 1), make_uint4(u0.x, u0.y, T - APUS_HDR, (uint32_t)clt | (type << 16) | ((client ? 2u : 0u) << 24)));
+            if (client) mix = apus_apply_mix(slot, pos, idx, T - APUS_HDR, clt, (uint8_t)type, 2);
+            if (type == APUS_HEAD) { uint4 x0, x1; ld32_sys(Md.ring + pos + 32, x0, x1); head_val = (uint64_t)x1.x | ((uint64_t)x1.y << 32); }
+            /* rc_send_entries_reply (dare_ibv_rc.c:1828-1863): the own reply byte, R3 = the same byte in the
+             * sender's log at the same offset, and the ACK byte in the sender's map -- unless this server has
+             * moved on to a newer term than the one the round comes from (the term fence, receiver side) */
+            st_sys8(Md.ring + pos + 28 + me, 1);
+            if (sender == leader && sender < APUS_DEV_MAX_SERVERS && E.rep[sender].ring && (my_sid >> 9) <= (uint64_t)u0.z + ((uint64_t)u0.w << 32)) {
+                st_sys8(E.rep[sender].ring + pos + 28 + me, 1);
+                st_sys8(E.ackb[sender] + (uint64_t)me * cap + di, rep_ack_tag(slot, E.dir_mask));
+            }
+        }
+        const uint64_t hsum = wave_sum(mix);
+        const uint32_t nclient = wave_sum(client);
+        head_val = rl64u(head_val, 0);                       /* (a <HEAD> entry is a round of its own) */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            RepFRound &fr = FS->fr[r];
+            st_agent(&fr.end_after, (uint64_t)end_after); st_agent(&fr.slot_end, slot_end); st_agent(&fr.hash, hsum);
+            st_agent(&fr.nclient, (uint64_t)nclient); st_agent(&fr.head_val, head_val); st_agent(&fr.e0, (uint64_t)e0); st_agent(&fr.n, (uint64_t)n);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) st_agent(&FS->fr[r].tag, q + 1);
+    }
+}
+
+/* the follower's control wavefront */
+__device__ static inline void rep_follow_control(const EngDev &E, const RepArgs &A, uint32_t me)
+{
+    RepBox *box = E.box[me];
+    RepBox *lbox = E.box[E.leader];
+    RepFollow *FS = A.FS[me];
+    const RepDev &Md = E.rep[me];
+    uint64_t *mh = Md.hdr;
+    const uint32_t lane = lane_id();
+    const uint64_t L = E.log_len;
+    const uint64_t q0 = ld_sys(&box->f_seq_next), my_run = ld_sys(&box->f_runs);
+    uint64_t end = mh[H_END], n_end = mh[H_N_END], store_count = mh[H_STORE_COUNT], head = mh[H_HEAD];
+    uint64_t n_commit = mh[H_N_COMMIT], c_off = mh[H_COMMIT], n_apply = mh[H_N_APPLY], a_off = mh[H_APPLY];
+    const uint64_t hash0 = mh[H_APPLY_HASH], cnt0 = mh[H_APPLY_COUNT], my_sid = mh[H_SID];
+    uint64_t hash = 0, ncl = 0;
+    uint64_t q_ret = q0, q_app = q0;
+    /* an exact-fit round held back by the last run (its end is len: the log would read as empty) */
+    uint64_t pend_n = 0, pend_slot_end = 0;
+    {
+        const uint64_t ps0 = ld_sys(&box->f_pend_slot0), pse = ld_sys(&box->f_pend_slot_end), psid = ld_sys(&box->f_pend_sid);
+        if (pse > ps0 && psid == my_sid && ps0 == n_end) { pend_n = pse - ps0; pend_slot_end = pse; }
+    }
+    uint64_t real_n_end = n_end + pend_n;                /* slots consumed, the held-back round included */
+    uint64_t real_end = pend_n ? L : end;
+    if (lane == 0) { st_sys(&lbox->seqdone_by[me], q_app); st_sys(&lbox->persisted_by[me], n_end); st_sys(&lbox->applied_by[me], n_apply); st_sys(&lbox->apply_off_by[me], a_off); }
+    uint64_t idle = 0;
+    uint32_t exit_code = R_EXIT_STOP;
+    uint64_t final_q = ~0ull;
+    for (;;) {
+        bool progress = false;
+        /* ---- retire rounds in order: persist_new_entries' bookkeeping ---- */
+        {
+            const uint64_t q = q_ret + lane;
+            const RepFRound &fr = FS->fr[q % RB_CAP];
+            const uint64_t tag = ld_agent(&fr.tag);
+            const unsigned long long bal = __ballot(tag == q + 1 && q < final_q);
+            const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
+            if (p) {
+                const bool mine = lane < p;
+                const uint64_t ea = mine ? ld_agent(&fr.end_after) : 0, se = mine ? ld_agent(&fr.slot_end) : 0;
+                const uint64_t e0 = mine ? ld_agent(&fr.e0) : 0, nn = mine ? ld_agent(&fr.n) : 0;
+                /* the first round must continue where this log stands (a follower that missed rounds needs
+                 * the leader's catch-up first) */
+                const uint64_t e0_0 = rl64u(e0, 0), s0_0 = rl64u(se - nn, 0);
+                if (e0_0 != real_end || s0_0 != real_n_end) { exit_code = R_EXIT_GAP; if (lane == 0) spin_timeout(E, 7301); break; }
+                /* rounds up to the last one that does not end on len become visible */
+                const unsigned long long vis_b = __ballot(mine && ea != L);
+                const uint64_t se_l = rl64u(se, (int)p - 1), ea_l = rl64u(ea, (int)p - 1);
+                real_n_end = se_l; real_end = ea_l;
+                if (vis_b) {
+                    const int jj = 63 - __builtin_clzll(vis_b);
+                    const uint64_t se_v = rl64u(se, jj), ea_v = rl64u(ea, jj);
+                    store_count += se_v - n_end;
+                    n_end = se_v; end = ea_v;
+                    pend_n = se_l - se_v; pend_slot_end = se_l;
+                    if (lane == 0) {
+                        mh[H_END] = end; mh[H_OLD_END] = end; mh[H_N_END] = n_end; mh[H_N_PERSIST] = n_end; mh[H_STORE_COUNT] = store_count;
+                        st_sys(&lbox->persisted_by[me], n_end);
+                    }
+                } else { pend_n = se_l - n_end; pend_slot_end = se_l; }
+                q_ret += p;
+                progress = true;
+            }
+        }
+        /* ---- the commit doorbell (R4), apply_committed_entries round by round ---- */
+        {
+            uint64_t cs = ld_sys(&box->commit_bell);
+            if (cs > n_end) cs = n_end;
+            if (cs > n_commit) {
+                n_commit = cs;
+                c_off = (cs == n_end) ? end : ld_agent(&Md.dir_off[(uint32_t)cs & E.dir_mask]);
+                if (lane == 0) { mh[H_COMMIT] = c_off; mh[H_N_COMMIT] = cs; }
+                progress = true;
+            }
+            if (q_app < q_ret) {
+                const uint64_t q = q_app + lane;
+                const bool in = q < q_ret;
+                const RepFRound &fr = FS->fr[q % RB_CAP];
+                const uint64_t se = in ? ld_agent(&fr.slot_end) : ~0ull;
+                const unsigned long long bal = __ballot(in && se <= n_commit && se <= n_end);
+                const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
+                if (p) {
+                    const bool mine = lane < p;
+                    hash += wave_sum(mine ? ld_agent(&fr.hash) : 0ull);
+                    ncl += wave_sum(mine ? ld_agent(&fr.nclient) : 0ull);
+                    const uint64_t hv = mine ? ld_agent(&fr.head_val) : ~0ull;
+                    /* poll_config_entries: a committed <HEAD> entry moves the head (dare_server.c:2164) */
+                    const unsigned long long hb = __ballot(hv != ~0ull);
+                    if (hb) { const uint64_t h = rl64u(hv, 63 - __builtin_clzll(hb)); if (apus_is_larger(end, L, h, head)) head = h; }
+                    n_apply = rl64u(se, (int)p - 1);
+                    a_off = (n_apply == n_end) ? end : ld_agent(&Md.dir_off[(uint32_t)n_apply & E.dir_mask]);
+                    q_app += p;
+                    progress = true;
+                    if (lane == 0) {
+                        mh[H_APPLY] = a_off; mh[H_N_APPLY] = n_apply; mh[H_HEAD] = head;
+                        mh[H_APPLY_HASH] = hash0 + hash; mh[H_APPLY_COUNT] = cnt0 + ncl;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        st_sys(&lbox->apply_off_by[me], a_off); st_sys(&lbox->applied_by[me], n_apply); st_sys(&lbox->seqdone_by[me], q_app);
+                    }
+                }
+            }
+        }
+        /* ---- park? ---- */
+        if (final_q == ~0ull) {
+            const uint64_t ctrl = ld_sys(&box->ctrl);
+            if ((ctrl >> 40) == my_run + 1) final_q = q0 + (ctrl & 0xFFFFFFFFFFull) - 1;
+        }
+        if (final_q != ~0ull && q_ret >= final_q) {
+            /* everything that was sent is persisted; the leader's last commit doorbell was rung before the
+             * park word: one more look at it, then leave */
+            if (!progress && (q_app == q_ret || ld_sys(&box->commit_bell) <= n_apply || idle > 4)) break;
+        }
+        if (progress) idle = 0;
+        else {
+            if (++idle > A.idle_polls) { exit_code = R_EXIT_IDLE; break; }
+            rep_nap(idle < 64);
+        }
+    }
+    if (lane == 0) {
+        st_agent(&FS->quit, 1ull);
+        st_sys(&box->f_seq_next, q_ret);
+        st_sys(&box->f_pend_slot0, n_end); st_sys(&box->f_pend_slot_end, pend_n ? pend_slot_end : 0ull); st_sys(&box->f_pend_sid, my_sid);
+        st_sys(&box->f_exit, (uint64_t)exit_code + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_sys(&box->f_runs, my_run + 1);
+        if (exit_code) atomicOr(E.status, 1u << 4);
+    }
+}
+
+/* ===================================================================================== the launch */
+/* One launch carries every role this process hosts: [leader control, n_append append workgroups,] then
+ * n_fwork workgroups per hosted follower (the first wavefront of a follower's first workgroup is its
+ * control wavefront).  All workgroups must be resident together: the host sizes the grid for that. */
+__global__ __launch_bounds__(256) void k_replica(const EngDev E, const RepArgs A)
+{
+    __shared__ RepAppLds s_lds[4];
+    __shared__ uint64_t s_h[64];
+    __shared__ uint64_t s_ao[16];
+    __shared__ uint64_t s_x[16];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    uint32_t b = blockIdx.x;
+    if (A.lead_here) {
+        if (b == 0) {
+            RepHost *H = A.H;
+            if (tid < 64) s_h[tid] = E.rep[E.leader].hdr[tid];
+            if (tid < 16) s_x[tid] = 0;
+            __syncthreads();
+            if (wave == 0) rep_sequencer(E, A, s_h, s_ao, s_x);
+            else if (wave == 1) rep_committer(E, A, s_h, s_x);
+            __syncthreads();
+            if (tid == 0) {
+                /* park the followers: every round they were sent is in their doorbell ring */
+                const uint64_t t_fin = s_x[1];
+                for (uint32_t m = A.park_mask; m; m &= m - 1) {
+                    const uint32_t f = (uint32_t)__builtin_ctz(m);
+                    uint64_t sent = 0;
+                    if ((A.push_mask >> f) & 1u) { const uint64_t td = ld_agent(&A.LS->t_drop[f]); sent = td == ~0ull ? t_fin : td; }
+                    st_sys(&E.box[f]->ctrl, ((A.fruns[f] + 1) << 40) | (sent + 1));
+                }
+                st_sys(&H->exit_code, s_x[0]);
+                st_sys(&H->rounds, t_fin);
+                if (s_x[0] == R_EXIT_TIMEOUT) atomicOr(E.status, 1u << 4);
+                __threadfence_system();
+                st_sys(&H->alive, 2);
+            }
+            return;
+        }
+        if (b <= A.n_append) { rep_append_wave(E, A, s_lds[wave], (b - 1) * 4 + wave, A.n_append * 4); return; }
+        b -= 1 + A.n_append;
+    }
+    const uint32_t ord = b / A.n_fwork, fb = b % A.n_fwork;
+    int me = -1;
+    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
+        if (A.follow_mask & (1u << i)) { if (k == (int)ord) { me = i; break; } k++; }
+    if (me < 0) return;
+    const uint32_t G = A.n_fwork * 4 - 1;
+    if (fb == 0 && wave == 0) { rep_follow_control(E, A, (uint32_t)me); return; }
+    rep_follow_wave(E, A, (uint32_t)me, fb * 4 + wave - 1, G);
+}

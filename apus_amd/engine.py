@@ -365,6 +365,114 @@ class Engine:
                     pass
         self.check_status()
 
+    # -- replica kernels: every replica runs its own resident workgroups (apus_replica.h) ----------
+    def rep_start(self, idle_ms: int = 3000, peer_ms: int = 500, n_append: int = 0, n_fwork: int = 0):
+        self._chk(self.L.apus_gpu_rep_start(self.h, idle_ms, peer_ms, n_append, n_fwork), "rep_start")
+
+    def rep_park(self) -> int: return int(self.L.apus_gpu_rep_park(self.h))
+
+    def rep_submit(self, reqs: np.ndarray, arena: np.ndarray):
+        reqs = np.ascontiguousarray(reqs, dtype=REQ_DTYPE)
+        self._chk(self.L.apus_gpu_rep_submit(self.h, reqs.ctypes.data, len(reqs), arena.ctypes.data, len(arena)), "rep_submit")
+
+    def rep_run(self, r0: int, n: int): self._chk(self.L.apus_gpu_rep_run(self.h, r0, n), "rep_run")
+
+    def rep_prune(self): self._chk(self.L.apus_gpu_rep_prune(self.h), "rep_prune")
+
+    def rep_drain(self, timeout_ms: int = 10000):
+        rc = self.L.apus_gpu_rep_drain(self.h, timeout_ms)
+        if rc != 0:
+            raise EngineError(f"replica kernels did not drain rc={rc} stats={self.rep_stats()} status={self.status_names()}")
+
+    def rep_highest_rec(self) -> int: return int(self.L.apus_gpu_rep_highest_rec(self.h))
+
+    def rep_stats(self) -> dict:
+        out = (C.c_uint64 * 8)()
+        self.L.apus_gpu_rep_stats(self.h, out)
+        return dict(zip(("rounds", "slots_done", "cmd_head", "commit_slot", "highest_rec", "refused", "dropped", "alive"), [int(v) for v in out]))
+
+    def rep_latency_ns(self) -> np.ndarray:
+        out = np.zeros(1 << 16, dtype=np.uint32)
+        n = C.c_uint32(0)
+        self._chk(self.L.apus_gpu_rep_latency(self.h, out.ctypes.data, len(out), C.byref(n)), "rep_latency")
+        return out[:n.value].copy()
+
+    def rep_roundtrip_ns(self, reqs: np.ndarray, arena: np.ndarray, iters: int) -> np.ndarray:
+        reqs = np.ascontiguousarray(reqs, dtype=REQ_DTYPE)
+        out = np.zeros(iters, dtype=np.uint32)
+        self._chk(self.L.apus_gpu_rep_roundtrip(self.h, reqs.ctypes.data, len(reqs), arena.ctypes.data, len(arena), iters, out.ctypes.data),
+                  "rep_roundtrip")
+        return out
+
+    def run_trace_rep(self, trace: Trace, source: str = "pinned", idle_ms: int = 3000, peer_ms: int = 500,
+                      n_append: int = 0, n_fwork: int = 0, drain_each: bool = False):
+        """The trace with its ROUND / PRUNE events going through the replica kernels: the leader's and every
+        follower's own workgroups.  source = "pinned": the requests cross the pinned multi-producer ring one
+        ROUND event at a time (drained per event when drain_each, so that round boundaries are the trace's);
+        "staged": stretches of ROUND events run from the staged, device-resident input.  Control-plane events
+        (ELECT, HOLD, RELEASE, KILL, JOIN, QUIESCE) park the run and use the control-plane kernels."""
+        reqs = np.ascontiguousarray(trace.reqs, dtype=REQ_DTYPE)
+        arena = np.ascontiguousarray(trace.arena, dtype=np.uint8)
+        if source == "staged":
+            self.stage_trace(trace)
+        running = False
+
+        def park():
+            nonlocal running
+            if running:
+                self.rep_drain()
+                code = self.rep_park()
+                running = False
+                if code != 0:
+                    raise EngineError(f"replica kernels exited with code {code}, status {self.status_names()}")
+        ev, i = trace.events, 0
+        try:
+            while i < len(ev):
+                op = ev[i][0]
+                if op in ("ROUND", "PRUNE"):
+                    if not running:
+                        self.rep_start(idle_ms, peer_ms, n_append, n_fwork)
+                        running = True
+                    if op == "PRUNE":
+                        self.rep_prune()
+                    elif source == "staged":
+                        j = i
+                        while j < len(ev) and ev[j][0] == "ROUND":
+                            j += 1
+                        self.rep_run(self.round_of_g0[ev[i][1]], j - i)
+                        i = j
+                        continue
+                    else:
+                        self.rep_submit(reqs[ev[i][1]:ev[i][1] + ev[i][2]], arena)
+                        if drain_each:
+                            self.rep_drain()
+                    i += 1
+                    continue
+                park()
+                if op == "ELECT":
+                    self.elect(ev[i][1])
+                elif op == "QUIESCE":
+                    self.quiesce()
+                elif op == "HOLD":
+                    self.hold(ev[i][1])
+                elif op == "RELEASE":
+                    self.release(ev[i][1])
+                elif op == "KILL":
+                    self.kill(ev[i][1])
+                elif op == "JOIN":
+                    self.join(ev[i][1])
+                else:
+                    raise EngineError(f"trace event {ev[i]} is not supported")
+                i += 1
+            park()
+        finally:
+            if running:
+                try:
+                    self.rep_park()
+                except Exception:
+                    pass
+        self.check_status()
+
     # -- graphs -------------------------------------------------------------------
     def capture_begin(self): self._chk(self.L.apus_gpu_capture_begin(self.h), "capture_begin")
 
@@ -413,6 +521,12 @@ class Engine:
 
     def status(self) -> int: return int(self.L.apus_gpu_status(self.h))
 
+    def status_words(self):
+        out = (C.c_uint32 * 8)()
+        self.L.apus_gpu_status_words.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        self.L.apus_gpu_status_words(self.h, out)
+        return [int(v) for v in out]
+
     def status_names(self):
         try:
             s = self.status()
@@ -423,7 +537,7 @@ class Engine:
     def check_status(self):
         s = self.status()
         if s:
-            raise EngineError(f"device status {self.status_names()}")
+            raise EngineError(f"device status {self.status_names()} words={self.status_words()}")
 
     def set_timing(self, on: bool): self._chk(self.L.apus_gpu_set_timing(self.h, int(on)), "set_timing")
 

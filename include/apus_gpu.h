@@ -144,7 +144,8 @@ int  apus_gpu_stage(apus_engine_t *e, const apus_req_t *reqs, uint64_t n,
  * same fused push / ACK / commit path that serves logical replicas on one device, and a follower
  * process only reads its own memory.  Handles travel between processes by any means (the tests
  * and bench.py use torch.distributed all_gather). */
-#define APUS_IPC_BUFFERS 6u              /* ring, control block, directory offsets / lengths, ACK words, apply stream */
+#define APUS_IPC_BUFFERS 8u              /* ring, control block, directory offsets / lengths, ACK words, apply stream,
+                                          * mailbox + ACK byte maps of the replica kernels (apus_gpu_rep_*) */
 typedef struct {
     uint8_t  handle[APUS_IPC_BUFFERS][64];   /* hipIpcMemHandle_t each */
     uint64_t log_len;
@@ -272,6 +273,41 @@ int  apus_gpu_persist_roundtrip(apus_engine_t *e, const apus_req_t *reqs, uint32
                                 const uint8_t *arena, uint64_t arena_bytes, uint32_t iters, uint32_t *out_ns);
 int  apus_gpu_device_arch(int device, char *out, int cap);
 
+/* ---- replica kernels: every replica runs its OWN resident workgroups ---------------------
+ * The one-server-per-machine structure of the reference on GPUs (apus_amd/csrc/apus_replica.h).  The
+ * leader's workgroups run the leader's polling() loop pipelined (sequencer -> append wavefronts -> committer:
+ * many rounds in flight) and push ONLY the log bytes + one 32-byte doorbell per round to every follower;
+ * each follower's workgroups -- on the follower's own device, in its own process when the replica is
+ * peer-mapped -- poll their doorbells, build directory and apply records locally from the landed bytes,
+ * persist, write the reply byte into the sender's log (R3) and their ACK byte into the sender's map, and
+ * apply on the commit doorbell; the leader commits by majority over the per-replica ACK maps (popcount +
+ * wave ballot), so a dead follower costs its ACK, not the round.
+ *
+ * apus_gpu_rep_start launches the workgroups of every replica HOSTED by this engine (the leader's when it
+ * is hosted here, and those of every hosted follower); in a peer-mapped group every process calls it.  While
+ * a run is resident the phased calls must not be used; apus_gpu_rep_park ends the run (the leader's side
+ * parks the followers through their mailboxes) and hands the replicas back to the control-plane calls
+ * (election, JOIN, catch-up of a released follower run between runs).
+ *   idle_ms : the leader's workgroups leave by themselves after this long without input
+ *   peer_ms : bound of every device-side wait for a peer
+ *   n_append, n_fwork : append workgroups of the leader / workgroups per follower (0 = defaults)   */
+int  apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t peer_ms, uint32_t n_append, uint32_t n_fwork);
+int  apus_gpu_rep_park(apus_engine_t *e);     /* exit code of the run: 0 stop, 1 idle, 2 a wait timed out, 3 a follower had a gap */
+/* admission (leader side; replaces the TAILQ + tailq_lock, src/include/dare/message.h:20-22): thread safe */
+int  apus_gpu_rep_reserve(apus_engine_t *e, uint32_t len, uint64_t *slot, void **payload_dst);
+int  apus_gpu_rep_publish(apus_engine_t *e, uint64_t slot, const void *payload_dst, uint64_t req_id, uint16_t clt_id, uint8_t type, uint16_t len);
+int  apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uint32_t n, const uint8_t *arena, uint64_t arena_bytes);
+int  apus_gpu_rep_run(apus_engine_t *e, uint64_t r0, uint64_t n_rounds);     /* staged (device-resident) rounds */
+int  apus_gpu_rep_prune(apus_engine_t *e);                                   /* log_pruning tick */
+int  apus_gpu_rep_drain(apus_engine_t *e, uint32_t timeout_ms);
+int  apus_gpu_rep_full(apus_engine_t *e);                                    /* rounds refused because the log was full */
+uint64_t apus_gpu_rep_highest_rec(apus_engine_t *e);
+const volatile uint64_t *apus_gpu_rep_highest_rec_ptr(apus_engine_t *e);
+int  apus_gpu_rep_stats(apus_engine_t *e, uint64_t out[8]);
+int  apus_gpu_rep_latency(apus_engine_t *e, uint32_t *out_ns, uint32_t cap, uint32_t *n_out);
+int  apus_gpu_rep_roundtrip(apus_engine_t *e, const apus_req_t *reqs, uint32_t n, const uint8_t *arena, uint64_t arena_bytes,
+                            uint32_t iters, uint32_t *out_ns);
+
 /* ---- multi-process groups: one replica per GPU / process --------------------------
  * The leader's new log range [end before, end after) and the matching directory
  * slots travel between processes by RCCL point-to-point (apus_amd/distributed.py);
@@ -311,6 +347,7 @@ int  apus_gpu_store_stream(apus_engine_t *e, uint32_t replica, uint64_t first, u
                            void *dst, uint64_t cap, uint64_t *bytes, uint64_t *records);
 uint32_t apus_gpu_status(apus_engine_t *e);
 void apus_gpu_clear_status(apus_engine_t *e);
+int  apus_gpu_status_words(apus_engine_t *e, uint32_t out[8]);   /* diagnostics: status bits, first spin-timeout site, fence word, five words the flagging kernel left */
 /* raw device pointers for zero-copy wrapping by the host transport (RCCL p2p):
  * which: 0 ring, 1 hdr, 2 dir_off, 3 dir_len, 4 ack, 5 apply ring */
 void *apus_gpu_device_ptr(apus_engine_t *e, uint32_t replica, int which, uint64_t *bytes);
