@@ -1,0 +1,135 @@
+"""Throughput / latency of the replica kernels (apus_replica.h) on BASELINE configs[1]'s stream:
+device-resident rounds (apus_gpu_rep_run) and host-fed requests (the pinned multi-producer ring).
+  python tools/rep_bench.py [--sweep] [--entries N] [--steps K]
+Prints one JSON line per measurement."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from apus_amd import trace as T  # noqa: E402
+from apus_amd.engine import Engine  # noqa: E402
+
+
+def step_cmds(tr, eng):
+    out, ev, i = [], tr.events, 0
+    while i < len(ev):
+        if ev[i][0] == "ROUND":
+            j = i
+            while j < len(ev) and ev[j][0] == "ROUND":
+                j += 1
+            out.append(("run", eng.round_of_g0[ev[i][1]], j - i))
+            i = j
+            continue
+        if ev[i][0] == "PRUNE":
+            out.append(("prune",))
+        i += 1
+    return out
+
+
+def staged(n_rep, entries, payload, batch, steps, n_append, n_fwork, warmup=1):
+    tr = T.steady_trace(n_rep, entries, payload, 16, batch, log_len=T.DEFAULT_LOG)
+    eng = Engine(n_rep, tr.log_len)
+    try:
+        eng.stage_trace(tr)
+        eng.elect(0)
+        eng.sync()
+        cmds = step_cmds(tr, eng)
+        eng.rep_start(idle_ms=5000, peer_ms=1000, n_append=n_append, n_fwork=n_fwork)
+
+        def step():
+            for c in cmds:
+                if c[0] == "run":
+                    eng.rep_run(c[1], c[2])
+                else:
+                    eng.rep_prune()
+        for _ in range(warmup):
+            step()
+        eng.rep_drain(timeout_ms=60000)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        eng.rep_drain(timeout_ms=120000)
+        dt = time.perf_counter() - t0
+        st = eng.rep_stats()
+        code = eng.rep_park()
+        lat = eng.rep_latency_ns()
+        eng.quiesce()
+        total = (warmup + steps) * len(tr.reqs)
+        ok = eng.status() == 0 and code == 0
+        for r in range(n_rep):
+            o = eng.offsets(r)
+            ok = ok and (o["commit"] == o["end"] == o["apply"])
+        ok = ok and eng.counters(0)["highest_rec"] == total
+        return {"mode": "staged", "replicas": n_rep, "payload": payload, "n_append": n_append, "n_fwork": n_fwork,
+                "entries_per_s": len(tr.reqs) * steps / dt, "ms_per_step": dt / steps * 1e3, "verified": bool(ok),
+                "exit": code, "status": eng.status_names(), "stats": st,
+                "lat_us_p50": float(np.percentile(lat, 50)) / 1e3 if len(lat) else None}
+    finally:
+        eng.close()
+
+
+def hostfed(n_rep, payload, seconds, n_append, n_fwork, blk=4096):
+    tr = T.steady_trace(n_rep, 1 << 16, payload, 16, 64, log_len=T.DEFAULT_LOG)
+    eng = Engine(n_rep, tr.log_len)
+    try:
+        eng.elect(0)
+        eng.sync()
+        eng.rep_start(idle_ms=5000, peer_ms=1000, n_append=n_append, n_fwork=n_fwork)
+        reqs = np.ascontiguousarray(tr.reqs[16:16 + blk])
+        # latency first: one 64-entry round at a time, host submit -> highest_rec
+        hl = eng.rep_roundtrip_ns(reqs[:64], tr.arena, 300) / 1e3
+        hl1 = eng.rep_roundtrip_ns(reqs[:1], tr.arena, 300) / 1e3
+        eng.rep_drain()
+        hr0 = eng.rep_highest_rec()
+        n, nsub, t0 = 0, 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            eng.rep_submit(reqs, tr.arena)
+            n += len(reqs)
+            nsub += 1
+            if nsub % (max(1, (8 << 20) // ((64 + payload) * blk))) == 0:
+                eng.rep_prune()
+        eng.rep_drain(timeout_ms=60000)
+        dt = time.perf_counter() - t0
+        ok = eng.rep_highest_rec() == hr0 + n
+        code = eng.rep_park()
+        lat = eng.rep_latency_ns()
+        eng.quiesce()
+        return {"mode": "host-fed (one submitting thread)", "replicas": n_rep, "payload": payload, "entries_per_s": n / dt, "verified": bool(ok and code == 0),
+                "host_rt64_us_p50": float(np.percentile(hl[20:], 50)), "host_rt1_us_p50": float(np.percentile(hl1[20:], 50)),
+                "dev_lat_us_p50": float(np.percentile(lat[:600], 50)) / 1e3 if len(lat) else None, "status": eng.status_names()}
+    finally:
+        eng.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--entries", type=int, default=1 << 20)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--n-append", type=int, default=32)
+    ap.add_argument("--n-fwork", type=int, default=8)
+    ap.add_argument("--replicas", type=int, default=3)
+    ap.add_argument("--no-hostfed", action="store_true")
+    a = ap.parse_args()
+    combos = [(a.replicas, a.n_append, a.n_fwork)]
+    if a.sweep:
+        combos = [(3, 32, 8), (3, 64, 16), (3, 96, 24), (1, 64, 1), (5, 64, 12)]
+    for n_rep, na, nf in combos:
+        try:
+            print(json.dumps(staged(n_rep, a.entries, 64, 64, a.steps, na, nf)), flush=True)
+        except Exception as exc:
+            print(json.dumps({"mode": "staged", "replicas": n_rep, "n_append": na, "n_fwork": nf, "error": repr(exc)[:600]}), flush=True)
+    if not a.no_hostfed:
+        try:
+            print(json.dumps(hostfed(a.replicas, 64, 1.0, a.n_append, a.n_fwork)), flush=True)
+        except Exception as exc:
+            print(json.dumps({"mode": "host-fed", "error": repr(exc)[:600]}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
