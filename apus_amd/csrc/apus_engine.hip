@@ -2139,13 +2139,26 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
     const bool lead_here = (hosted >> leader) & 1u;
     if (lead_here) { int frc = flush_tick(e); if (frc) return frc; }
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (!n_append) n_append = 32;
-    if (!n_fwork) n_fwork = 8;
     if (!e->rstream) HIPCHK(hipStreamCreateWithFlags(&e->rstream, hipStreamNonBlocking));
     RepArgs A;
     memset(&A, 0, sizeof A);
     const uint32_t members = ((1u << e->d.group_size) - 1) & ~(1u << leader);
     A.follow_mask = hosted & members & e->reachable & ~e->r_test_skip;
+    {
+        /* every workgroup of the launch must be resident at once: the grid is cut to what the device holds */
+        int occ = 0, cus = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_replica, 256, 0));
+        HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device));
+        const uint32_t room = (uint32_t)std::max(8, occ * cus - 8);
+        const uint32_t nfh = (uint32_t)popc(A.follow_mask);
+        if (!n_append) n_append = lead_here ? 96 : 0;
+        if (!n_fwork) n_fwork = nfh ? std::min(96u, std::max(8u, 192u / nfh)) : 1;
+        while ((lead_here ? 1 + n_append : 0) + nfh * n_fwork > room && (n_append > 8 || n_fwork > 2)) {
+            if (n_append > 8) n_append -= n_append / 4;
+            if (n_fwork > 2) n_fwork -= (n_fwork + 3) / 4;
+        }
+        if (!n_fwork) n_fwork = 1;
+    }
     A.n_append = n_append; A.n_fwork = n_fwork;
     A.idle_polls = (uint64_t)idle_ms * 1000ull;
     A.peer_polls = (uint64_t)peer_ms * 1000ull;
@@ -2154,7 +2167,7 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
         if (!e->rh) {
             HIPCHK(hipHostMalloc((void **)&e->rh, sizeof(RepHost), hipHostMallocMapped | hipHostMallocCoherent));
             HIPCHK(hipHostGetDevicePointer((void **)&e->rh_dev, e->rh, 0));
-            memset((void *)e->rh, 0, offsetof(RepHost, desc));
+            memset((void *)e->rh, 0, offsetof(RepHost, slot));
             HIPCHK(hipMalloc((void **)&e->rl, sizeof(RepLead)));
             e->r_slot_aend = (uint64_t *)calloc(RQ_CAP, sizeof(uint64_t));
             if (!e->r_slot_aend) return APUS_E_NOMEM;
@@ -2171,7 +2184,7 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
         uint64_t h[64];
         HIPCHK(hipMemcpy(h, e->d.rep[leader].hdr, sizeof h, hipMemcpyDeviceToHost));
         /* (a run that ended abnormally may have left commands or slots behind: they are dropped) */
-        e->rh->cmd_tail = e->r_cmd_tail; e->rh->cmd_head = e->r_cmd_tail; e->rh->slots_done = e->r_slot_tail;
+        e->rh->cmd_head = e->r_cmd_tail; e->rh->slots_done = e->r_slot_tail;
         e->rh->settled = e->r_cmd_tail + e->r_slot_tail;
         e->rh->stop = 0; e->rh->alive = 0; e->rh->exit_code = 0; e->rh->full = 0; e->rh->rounds = 0;
         e->rh->highest_rec = h[H_HIGHEST_REC];
@@ -2204,41 +2217,56 @@ static int rep_push_cmd(apus_engine *e, uint32_t op, uint64_t a, uint64_t b)
     pthread_spin_lock(&e->r_lock);
     while (e->r_cmd_tail - e->rh->cmd_head >= RC_CAP - 1)
         if (e->rh->alive == 2 || mono_s() - t0 > 5.0) { pthread_spin_unlock(&e->r_lock); return APUS_E_STATE; }
+    /* four self-tagged granules {command number + 1 : value}: the command is there once all four are */
     RepCmd &c = e->rh->cmd[e->r_cmd_tail % RC_CAP];
-    c.op = op; c.pad = 0; c.after_slot = e->r_slot_tail; c.a = a; c.b = b;
+    const uint64_t tag = ((e->r_cmd_tail + 1) & 0xFFFFFFFFull) << 32;
+    const uint64_t vals[4] = { op, e->r_slot_tail & 0xFFFFFFFFull, a & 0xFFFFFFFFull, b & 0xFFFFFFFFull };
+    for (int i = 3; i >= 0; i--) __atomic_store_n((uint64_t *)&c.g[i], tag | vals[i], __ATOMIC_RELEASE);
     e->r_cmd_tail++;
-    __atomic_store_n((uint64_t *)&e->rh->cmd_tail, e->r_cmd_tail, __ATOMIC_RELEASE);
     pthread_spin_unlock(&e->r_lock);
     return 0;
 }
 
 /* Admission, multi-producer (replaces the malloc'd TAILQ + tailq_lock of leader_handle_submit_req,
- * src/proxy/proxy.c:108-161): a producer RESERVES the next request slot and a range of the pinned payload
- * arena (short critical section: two counters), copies its payload there itself, then PUBLISHES the slot.
- * The leader's sequencer takes published slots in slot order, up to 64 per round.  *dst = where the len
- * payload bytes go. */
+ * src/proxy/proxy.c:108-161): a producer RESERVES the next request slot -- and, for a payload that does not fit
+ * into the slot itself, a range of the pinned payload arena -- in a short critical section (two counters),
+ * copies its payload there itself, then PUBLISHES the slot.  The leader's sequencer takes published slots in
+ * slot order, up to 64 per round.  *dst = where the len payload bytes go. */
+static inline bool rep_reserve_locked(apus_engine *e, uint32_t len, uint64_t *slot, void **dst)
+{
+    const uint64_t done = e->rh->slots_done;
+    if (e->r_slot_tail - done >= RQ_CAP) return false;
+    if (len <= R_INLINE) {
+        *slot = e->r_slot_tail++;
+        e->r_slot_aend[*slot % RQ_CAP] = e->r_arena_tail;
+        *dst = (void *)e->rh->slot[*slot % RQ_CAP].pay;
+        return true;
+    }
+    const uint64_t need = ((uint64_t)len + 15) & ~15ull;
+    uint64_t pos = e->r_arena_tail;
+    uint64_t phys = pos % RA_CAP;
+    if (phys + need + 16 > RA_CAP) { pos += RA_CAP - phys; phys = 0; }      /* the payload does not straddle the end */
+    if (phys == 0) { pos += 16; phys = 16; }                                 /* bytes -2, -1 of a payload must exist */
+    const uint64_t freed = done ? e->r_slot_aend[(done - 1) % RQ_CAP] : 0;
+    if (pos + need - freed > RA_CAP) return false;
+    *slot = e->r_slot_tail++;
+    e->r_arena_tail = pos + need;
+    e->r_slot_aend[*slot % RQ_CAP] = pos + need;
+    *dst = (void *)(e->rh->arena + phys);
+    return true;
+}
+
 extern "C" int apus_gpu_rep_reserve(apus_engine_t *e, uint32_t len, uint64_t *slot, void **dst)
 {
     if (!e || !e->r_running || !e->r_lead || !slot || !dst || len > 65535) return APUS_E_STATE;
-    const uint64_t need = ((uint64_t)len + 15) & ~15ull;
     const double t0 = mono_s();
-    pthread_spin_lock(&e->r_lock);
     for (;;) {
-        uint64_t pos = e->r_arena_tail;
-        uint64_t phys = pos % RA_CAP;
-        if (phys + need + 16 > RA_CAP) { pos += RA_CAP - phys; phys = 0; }      /* the payload does not straddle the end */
-        if (phys == 0) { pos += 16; phys = 16; }                                 /* bytes -2, -1 of a payload must exist */
-        const uint64_t done = e->rh->slots_done;
-        const uint64_t freed = done ? e->r_slot_aend[(done - 1) % RQ_CAP] : 0;
-        if (e->r_slot_tail - done < RQ_CAP && pos + need - freed <= RA_CAP) {
-            *slot = e->r_slot_tail++;
-            e->r_arena_tail = pos + need;
-            e->r_slot_aend[*slot % RQ_CAP] = pos + need;
-            *dst = (void *)(e->rh->arena + phys);
-            pthread_spin_unlock(&e->r_lock);
-            return 0;
-        }
-        if (e->rh->alive == 2 || mono_s() - t0 > 5.0) { pthread_spin_unlock(&e->r_lock); return e->rh->alive == 2 ? APUS_E_STATE : -1; }
+        pthread_spin_lock(&e->r_lock);
+        const bool ok = rep_reserve_locked(e, len, slot, dst);
+        pthread_spin_unlock(&e->r_lock);
+        if (ok) return 0;
+        if (e->rh->alive == 2) return APUS_E_STATE;
+        if (mono_s() - t0 > 5.0) return -1;
     }
 }
 
@@ -2246,25 +2274,46 @@ extern "C" int apus_gpu_rep_publish(apus_engine_t *e, uint64_t slot, const void 
 {
     if (!e || !e->rh) return APUS_E_STATE;
     if (type == APUS_NOOP || type == APUS_CONFIG || type == APUS_HEAD || type > 15) return APUS_E_ARG;
-    const uint64_t phys = (uint64_t)((const uint8_t *)dst - e->rh->arena);
+    RepSlot &sl = e->rh->slot[slot % RQ_CAP];
+    const bool inl = (const uint8_t *)dst == sl.pay;
+    const uint64_t phys = inl ? 0 : (uint64_t)((const uint8_t *)dst - e->rh->arena);
     ReqDev d;
-    d.req_id = req_id; d.pay16_type = (uint32_t)(phys / 16) | ((uint32_t)type << 28); d.len = len; d.clt_id = clt_id;
-    e->rh->desc[slot % RQ_CAP] = d;
+    d.req_id = req_id; d.pay16_type = (inl ? R_PAY_INLINE : (uint32_t)(phys / 16)) | ((uint32_t)type << 28); d.len = len; d.clt_id = clt_id;
+    sl.d = d;
     __atomic_store_n((uint32_t *)&e->rh->ready_len[slot % RQ_CAP], (rep_slot_tag(slot) << 16) | len, __ATOMIC_RELEASE);
     return 0;
 }
 
+/* n requests: slots are reserved in blocks (one critical section per block), payloads copied and slots
+ * published outside it */
 extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uint32_t n, const uint8_t *arena, uint64_t arena_bytes)
 {
     if (!e || !reqs) return APUS_E_ARG;
-    for (uint32_t g = 0; g < n; g++) {
-        const apus_req_t &q = reqs[g];
-        if (q.payload_off + q.len > arena_bytes) return APUS_E_ARG;
-        uint64_t slot; void *dst;
-        int rc = apus_gpu_rep_reserve(e, q.len, &slot, &dst);
-        if (rc) return rc;
-        if (q.len) memcpy(dst, arena + q.payload_off, q.len);
-        if ((rc = apus_gpu_rep_publish(e, slot, dst, q.req_id, q.clt_id, q.type, q.len))) return rc;
+    if (!e->r_running || !e->r_lead) return APUS_E_STATE;
+    for (uint32_t g = 0; g < n; g++)
+        if (reqs[g].payload_off + reqs[g].len > arena_bytes) return APUS_E_ARG;
+    constexpr uint32_t BLK = 64;
+    uint64_t slot[BLK]; void *dst[BLK];
+    uint32_t g = 0;
+    const double t0 = mono_s();
+    while (g < n) {
+        const uint32_t want = std::min(BLK, n - g);
+        uint32_t got = 0;
+        pthread_spin_lock(&e->r_lock);
+        while (got < want && rep_reserve_locked(e, reqs[g + got].len, &slot[got], &dst[got])) got++;
+        pthread_spin_unlock(&e->r_lock);
+        if (!got) {
+            if (e->rh->alive == 2) return APUS_E_STATE;
+            if (mono_s() - t0 > 5.0) return -1;
+            continue;
+        }
+        for (uint32_t i = 0; i < got; i++) {
+            const apus_req_t &q = reqs[g + i];
+            if (q.len) memcpy(dst[i], arena + q.payload_off, q.len);
+            int rc = apus_gpu_rep_publish(e, slot[i], dst[i], q.req_id, q.clt_id, q.type, q.len);
+            if (rc) return rc;
+        }
+        g += got;
     }
     return 0;
 }
@@ -2350,6 +2399,23 @@ extern "C" int apus_gpu_rep_latency(apus_engine_t *e, uint32_t *out_ns, uint32_t
     return 0;
 }
 
+/* ... and from "the round's bytes are in every pushed ring" (the end of the leader's append, SURVEY 8d's
+ * definition of the consensus-round latency) to committed and applied */
+extern "C" int apus_gpu_rep_latency_appended(apus_engine_t *e, uint32_t *out_ns, uint32_t cap, uint32_t *n_out)
+{
+    if (!e || !e->rl || e->r_running) return APUS_E_STATE;
+    uint32_t n = 0;
+    HIPCHK(hipMemcpy(&n, &e->rl->lat_n, sizeof n, hipMemcpyDeviceToHost));
+    if (n > cap) n = cap;
+    if (n) HIPCHK(hipMemcpy(out_ns, e->rl->lat_app, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    int khz = 100000;
+    hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device);
+    if (khz <= 0) khz = 100000;
+    for (uint32_t i = 0; i < n; i++) out_ns[i] = (uint32_t)((uint64_t)out_ns[i] * 1000000ull / (uint64_t)khz);
+    if (n_out) *n_out = n;
+    return 0;
+}
+
 /* submit one round of n <= 64 requests and spin on highest_rec, `iters` times (what proxy.c:160 does) */
 extern "C" int apus_gpu_rep_roundtrip(apus_engine_t *e, const apus_req_t *reqs, uint32_t n, const uint8_t *arena, uint64_t arena_bytes,
                                       uint32_t iters, uint32_t *out_ns)
@@ -2365,6 +2431,44 @@ extern "C" int apus_gpu_rep_roundtrip(apus_engine_t *e, const apus_req_t *reqs, 
         out_ns[i] = (uint32_t)((mono_s() - t0) * 1e9);
     }
     return 0;
+}
+
+/* Host-fed throughput of the multi-producer ring: n_threads application threads (what memcached's worker
+ * threads are to leader_handle_submit_req, src/proxy/proxy.c:108-161) each submit the same block of requests
+ * over and over for `seconds`; thread 0 also plays the prune timer (one tick per prune_bytes of log).  Then
+ * everything is drained.  out[0] = requests submitted, out[1] = nanoseconds from the first submit to the
+ * drain's end. */
+struct RepFeedArg { apus_engine *e; const apus_req_t *reqs; uint32_t n; const uint8_t *arena; uint64_t arena_bytes;
+                    double t_end; uint64_t prune_every; int tid; uint64_t done; int rc; };
+static void *rep_feed_thread(void *p)
+{
+    RepFeedArg *a = (RepFeedArg *)p;
+    uint64_t since = 0;
+    while (mono_s() < a->t_end) {
+        int rc = apus_gpu_rep_submit(a->e, a->reqs, a->n, a->arena, a->arena_bytes);
+        if (rc) { a->rc = rc; break; }
+        a->done += a->n;
+        since += a->n;
+        if (a->tid == 0 && a->prune_every && since >= a->prune_every) { apus_gpu_rep_prune(a->e); since = 0; }
+    }
+    return nullptr;
+}
+extern "C" int apus_gpu_rep_feed(apus_engine_t *e, const apus_req_t *reqs, uint32_t n, const uint8_t *arena, uint64_t arena_bytes,
+                                 uint32_t n_threads, double seconds, uint64_t prune_every_reqs, uint64_t out[2])
+{
+    if (!e || !e->r_running || !e->r_lead || !reqs || !n || n_threads == 0 || n_threads > 64 || !out) return APUS_E_ARG;
+    RepFeedArg args[64];
+    pthread_t th[64];
+    const double t0 = mono_s();
+    for (uint32_t i = 0; i < n_threads; i++) {
+        args[i] = RepFeedArg{ e, reqs, n, arena, arena_bytes, t0 + seconds, prune_every_reqs / n_threads, (int)i, 0, 0 };
+        if (pthread_create(&th[i], nullptr, rep_feed_thread, &args[i])) return APUS_E_STATE;
+    }
+    uint64_t total = 0; int rc = 0;
+    for (uint32_t i = 0; i < n_threads; i++) { pthread_join(th[i], nullptr); total += args[i].done; if (args[i].rc) rc = args[i].rc; }
+    if (!rc) rc = apus_gpu_rep_drain(e, 60000);
+    out[0] = total; out[1] = (uint64_t)((mono_s() - t0) * 1e9);
+    return rc;
 }
 
 #ifdef APUS_TRACE

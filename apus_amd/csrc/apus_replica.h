@@ -6,19 +6,21 @@
  *   (/root/reference/src/dare/dare_server.c:1012-1125), pipelined --
  *     sequencer (one wavefront)   get_tailq_message + the placement half of log_append_entry
  *                                 (dare_ibv_ud.c:780-790, dare_log.h:466-558): drains the pinned
- *                                 multi-producer request ring (or staged, device-resident rounds),
- *                                 decides where every round goes (both wrap rules, exact fit, the
- *                                 log-full rule), log_pruning ticks (dare_server.c:1996-2067); one
+ *                                 multi-producer request ring (or staged, device-resident rounds, 256
+ *                                 per pass), decides where every round goes (both wrap rules, exact fit,
+ *                                 the log-full rule), log_pruning ticks (dare_server.c:1996-2067); one
  *                                 ticket per round, MANY rounds in flight
  *     append wavefronts           the byte half of log_append_entry + R1/R2 of update_remote_logs
  *                                 (dare_ibv_rc.c:1465-1643): the round's bytes into the own ring and,
  *                                 write-through, into every pushed follower's ring -- ONLY the E log
  *                                 bytes -- then one 32-byte round doorbell per follower
  *     committer (one wavefront)   the ACK scan of update_remote_logs (dare_ibv_rc.c:1725-1758): the
- *                                 followers' per-replica ACK maps of a 64-entry window, one lane per
- *                                 entry, popcount(acks | self) >= size/2+1, __ballot,
- *                                 count-trailing-ones = commit prefix; R4 commit doorbell; the
- *                                 leader's apply (dare_server.c:1815-1974) round by round;
+ *                                 followers' per-replica ACK byte maps of a window of up to 4096
+ *                                 entries, eight entries per lane and load; per entry
+ *                                 popcount(acks | self) >= size/2+1 (byte-parallel), per lane the
+ *                                 count of trailing ones, __ballot over the lanes that are all ones,
+ *                                 count-trailing-ones again = commit prefix; R4 commit doorbell
+ *     applier (one wavefront)     the leader's apply (dare_server.c:1815-1974) round by round;
  *                                 highest_rec to the host
  *   follower workgroups: the follower's polling() pass on ITS device --
  *     work wavefronts             poll the round doorbell, read the landed entry headers from the own
@@ -26,19 +28,23 @@
  *                                 (dare_server.c:1792-1810), rc_send_entries_reply
  *                                 (dare_ibv_rc.c:1828-1863): reply byte in the own log, R3 = the same
  *                                 byte in the sender's log + its ACK byte in the sender's map
- *     control wavefront           retires rounds in order (end, old_end, store count), applies on the
- *                                 commit doorbell, tells the leader how far it persisted / applied
+ *     retire wavefront            retires rounds in order (end, old_end, store count), tells the leader
+ *                                 how far it persisted
+ *     apply wavefront             applies on the commit doorbell, tells the leader how far it applied
  *
  * A dead or slow follower costs its ACK, nothing else: the commit is decided by majority, every wait
  * is bounded, a follower that stops consuming its doorbells is dropped from the push set.
  *
- * Hand-offs between replicas cross processes and (on a multi-GPU node) xGMI: every shared word lives
- * in uncached device memory of the replica that READS it (RepBox, ACK maps), is written with
- * system-scope stores through the HIP-IPC mapping and polled locally; ring bytes are written with
- * system-scope write-through 16-byte stores, drained (s_waitcnt vmcnt(0)) before the doorbell, and read
- * with system-scope loads (tools/micro/xproc.hip: 0.64 us one way for a doorbell between two processes'
- * kernels on one MI355X, 1.25 us with a drained payload in front).  Inside the leader the sequencer ->
- * append -> committer hand-offs are agent scope (cdna_hip_programming.md Guideline 16).
+ * Hand-offs.  A dependent memory round trip costs 0.5-3 us on this device, so every serial role does ONE
+ * per pass and as much work per pass as the rings allow: whatever one role leaves for another in memory is
+ * made of self-tagged 8-byte granules {sequence number + 1 : value} that are valid the moment they are
+ * seen (no flag, no second drain on the writer's side, no acquire + second load on the reader's);
+ * wavefronts of one workgroup talk through LDS.  Between replicas the words cross processes and (on a
+ * multi-GPU node) xGMI: every shared word lives in uncached device memory of the replica that READS it
+ * (RepBox, ACK maps), is written with system-scope stores through the HIP-IPC mapping and polled locally;
+ * ring bytes are written with write-through 16-byte stores, drained (s_waitcnt vmcnt(0)) before the
+ * doorbell, and read with system-scope loads (tools/micro/xproc.hip: 0.64 us one way for a doorbell
+ * between two processes' kernels on one MI355X, 1.25 us with a drained payload in front).
  */
 #pragma once
 #include "apus_persistent.h"
@@ -48,23 +54,29 @@
 #define RQ_CAP    (1u << 16)     /* pinned request slots                                      */
 #define RA_CAP    (64u << 20)    /* pinned payload arena (bytes)                              */
 #define RC_CAP    256u           /* host command ring                                         */
-#define R_WIN     4              /* 64-slot windows the sequencer reads per PCIe round trip   */
+#define R_WIN     8              /* 64-slot windows of the request ring read per PCIe round trip */
+#define R_SUB     4              /* 64-round chunks a serial role handles per memory round trip  */
 #define R_LAT_CAP (1u << 16)
 #define R_SLACK   (3u * WAVE)    /* head room kept in the ticket / doorbell rings             */
+#define R_INLINE  96u            /* payload bytes that fit into the request slot itself       */
+#define R_PAY_INLINE 0x0FFFFFFFu /* ReqDev.pay16_type: the payload sits in the slot           */
 
 enum { R_OP_PRUNE = 1, R_OP_RUN = 2, R_OP_STOP = 3 };
 enum { R_SRC_PINNED = 0, R_SRC_STAGED = 1, R_SRC_CONTROL = 2 };
 /* exit codes */
 enum { R_EXIT_STOP = 0, R_EXIT_IDLE = 1, R_EXIT_TIMEOUT = 2, R_EXIT_GAP = 3 };
 
-struct RepCmd { uint32_t op, pad; uint64_t after_slot, a, b; };
+/* one host command = four self-tagged granules {command number + 1 : value}: op, low half of the request
+ * slot count it waits for, a, b */
+struct RepCmd { volatile uint64_t g[4]; };
+/* one request slot: descriptor + the payload itself when it is short */
+struct RepSlot { ReqDev d; uint8_t pay[112]; };
 
 /* host <-> leader: pinned, coherent (hipHostMalloc mapped) */
 struct RepHost {
     /* host -> kernel */
-    volatile uint64_t cmd_tail;
     volatile uint64_t stop;
-    uint64_t pad0[6];
+    uint64_t pad0[7];
     /* kernel -> host */
     volatile uint64_t cmd_head;          /* commands carried out                               */
     volatile uint64_t slots_done;        /* request slots whose bytes were read (ring reuse)   */
@@ -73,14 +85,14 @@ struct RepHost {
     volatile uint64_t alive;             /* 1 running, 2 exited                                */
     volatile uint64_t exit_code;
     volatile uint64_t full;              /* rounds refused: the log was full                   */
-    volatile uint64_t rounds;            /* tickets issued                                     */
+    volatile uint64_t rounds;            /* tickets issued (written when the run ends)         */
     volatile uint64_t settled;           /* commands carried out + request slots taken whose rounds are all in every ring, committed and applied as far as a majority allows */
     uint64_t pad1[7];
     RepCmd   cmd[RC_CAP];
-    /* multi-producer request ring: a producer reserves slot + arena range, copies the payload, fills
-     * desc[slot], then publishes ready_len[slot] = tag << 16 | len (release) */
+    /* multi-producer request ring: a producer reserves slot (+ arena range for a long payload), copies
+     * the payload, fills slot[].d, then publishes ready_len[slot] = tag << 16 | len (release) */
     volatile uint32_t ready_len[RQ_CAP];
-    ReqDev   desc[RQ_CAP];
+    RepSlot  slot[RQ_CAP];
     uint8_t  arena[RA_CAP + 64];
 };
 __host__ __device__ static inline uint32_t rep_slot_tag(uint64_t slot) { return (uint32_t)((slot / RQ_CAP) % 65535u) + 1u; }
@@ -100,7 +112,7 @@ struct RepBox {
     uint64_t seqdone_by[16];             /* rounds applied (their doorbell slots are free)      */
     uint64_t persisted_by[16];           /* entry slots persisted, in order                     */
     uint64_t applied_by[16];             /* entry slots applied                                 */
-    uint64_t apply_off_by[16];           /* ... and the apply offset that goes with it          */
+    uint64_t apply_off_by[16];           /* ... and the apply offset that goes with it (when the run ends) */
     uint64_t sid_by[16];                 /* a follower that moved on to a newer SID says so here: the term fence */
     /* this replica's own notes, kept across runs of its follower workgroups */
     uint64_t f_seq_next;                 /* next round it expects                               */
@@ -110,32 +122,39 @@ struct RepBox {
     uint64_t pad1[2];
 };
 
-struct RepTicket { uint64_t w[8]; };     /* one round, sequencer -> append wavefront / committer */
+struct RepTicket { uint64_t w[8]; };     /* one round, sequencer -> append wavefront */
 enum { TK_E0 = 0, TK_IDX0, TK_SLOT0, TK_SRC, TK_END, TK_D0, TK_D1, TK_META };
 /* TK_D1: control entry data word 1, else the sequencer's wall clock (latency samples)
  * TK_META: [7:0] n  [11:8] source kind  [12] hidden (the round ends exactly on len)  [23:16] control entry type
  *          [47:32] push mask */
-struct RepDone { uint64_t tag, hash, nclient, pad; };
+/* one round as its append wavefront leaves it for the committer / the applier: granules {ticket + 1 : value} */
+enum { DN_META = 0, DN_SLOT_END, DN_END, DN_HASH_LO, DN_HASH_HI, DN_NCLIENT, DN_T_APPENDED, DN_T_SEQUENCED };
+/* DN_META: [7:0] n  [11:8] source kind  [12] hidden  [31:16] push mask */
 
 /* leader-local state shared by its workgroups (device memory, agent scope) */
 struct RepLead {
-    uint64_t seq_tail;  uint64_t pad0[7];
+    uint64_t pub;       uint64_t pad0[7];       /* low half of (commands carried out + request slots taken) << 32 | low half of the tickets issued; the progress is written with the tickets it made */
     uint64_t seq_final; uint64_t pad1[7];       /* ~0 while running, then the number of tickets */
-    uint64_t t_retired, n_apply, commit_slot, commit_off, apply_off, drop_mask, slots_dropped;
-    uint64_t progress;                          /* commands carried out + request slots taken (written AFTER the tickets they made) */
+    uint64_t drop_mask, slots_dropped, pad2[6];
     uint64_t t_drop[16];                        /* tickets issued when follower f left the push set (~0: still in) */
     uint32_t lat_n, pad3;
-    uint32_t lat_ticks[R_LAT_CAP];
+    uint32_t lat_ticks[R_LAT_CAP];              /* sequenced -> committed and applied by the leader      */
+    uint32_t lat_app[R_LAT_CAP];                /* bytes in every pushed ring -> committed and applied   */
     RepTicket tk[RS_CAP];
-    RepDone   dn[RS_CAP];
+    uint64_t  dn[RS_CAP][8];
 };
+/* the leader's first workgroup: its wavefronts' words in LDS */
+enum { M_TAIL = 0, M_PROG, M_FINAL, M_T_DONE, M_CS, M_C_FINAL, M_T_RETIRED, M_N_APPLY, M_A_FINAL, M_A_HASH, M_A_NCL, M_DROPPED, M_WORDS = 16 };
 
-/* one round as a follower's work wavefront leaves it for its control wavefront */
-struct RepFRound { uint64_t tag, end_after, slot_end, hash, nclient, head_val, e0, n; };
+/* one round as a follower's work wavefront leaves it for its retire / apply wavefronts: granules {round + 1 : value} */
+enum { FR_END = 0, FR_E0, FR_SLOT_END, FR_N, FR_HASH_LO, FR_HASH_HI, FR_HEAD, FR_WORDS = 8 };
+/* FR_N: [7:0] n  [15:8] client entries   FR_HEAD: the head a <HEAD> entry carries, 0xFFFFFFFF none */
 struct RepFollow {                       /* follower-local (device memory, agent scope) */
     uint64_t quit; uint64_t pad[7];
-    RepFRound fr[RB_CAP];
+    uint64_t fr[RB_CAP][FR_WORDS];
 };
+/* a follower's first workgroup: its retire / apply wavefronts' words in LDS */
+enum { F_END = 0, F_N_END, F_Q_RET, F_R_FINAL, F_STORE_COUNT, F_PEND_N, F_PEND_SLOT_END, F_EXIT, F_WORDS = 8 };
 
 struct RepArgs {
     RepHost *H;                          /* leader here: its pinned block                         */
@@ -160,6 +179,11 @@ __device__ static inline uint8_t rep_ack_tag(uint64_t slot, uint32_t dir_mask)
 {
     return (uint8_t)(((slot / ((uint64_t)dir_mask + 1)) & 0x7F) + 1);
 }
+/* a granule: {sequence number + 1 : 32-bit value} */
+__device__ static inline uint64_t rep_gran(uint64_t seq, uint32_t v) { return ((seq + 1) << 32) | v; }
+__device__ static inline bool rep_gran_ok(uint64_t g, uint64_t seq) { return (uint32_t)(g >> 32) == (uint32_t)(seq + 1); }
+/* a 64-bit counter from its low half and a nearby (not larger by 2^31) value of the same counter */
+__device__ static inline uint64_t rep_extend(uint64_t near, uint32_t lo) { return near + (uint64_t)(int64_t)(int32_t)(lo - (uint32_t)near); }
 /* 32 bytes of a ring that a peer's kernel wrote (system-scope loads: never an L1 copy of an older lap) */
 __device__ static inline void ld32_sys(const uint8_t *p, uint4 &a, uint4 &b)
 {
@@ -172,7 +196,6 @@ __device__ static inline uint64_t rl64u(uint64_t v, int l)
 {
     return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), l, WAVE) << 32) | (uint32_t)__shfl((int)(uint32_t)v, l, WAVE);
 }
-
 /* where the n entries of one round go (log_append_entry, dare_log.h:466-558): lane j holds the size T of
  * entry j (0 beyond n), e0 = the log's end before the round (len: it reads as empty).  The entry that does
  * not fit before len wraps to offset 0 -- leaving a stale header behind when only its payload did not fit
@@ -258,13 +281,14 @@ __device__ static inline bool rep_seq_round(const EngDev &E, RepSeqState &S, Rep
     return true;
 }
 
-__device__ static inline void rep_seq_publish(RepLead *LS, RepHost *H, const RepSeqState &S, uint64_t progress)
+/* the tickets issued so far are in memory: tell the append wavefronts (device memory) and the committer (LDS) */
+__device__ static inline void rep_seq_publish(RepLead *LS, volatile uint64_t *s_m, const RepSeqState &S, uint64_t progress)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane_id() == 0) {
-        st_agent(&LS->seq_tail, S.t); st_sys(&H->rounds, S.t);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st_agent(&LS->progress, progress);            /* whoever reads this first and seq_tail second sees every ticket behind it */
+        st_agent(&LS->pub, (progress << 32) | (S.t & 0xFFFFFFFFull));
+        s_m[M_TAIL] = S.t;                             /* (whoever reads M_PROG first and M_TAIL second sees every ticket behind the progress) */
+        s_m[M_PROG] = progress;
     }
 }
 
@@ -289,11 +313,11 @@ __device__ static inline void rep_seq_drop(const EngDev &E, RepSeqState &S, RepL
  * flight the pipeline is not drained for that: the offsets sampled are the ones the pinned schedule gives
  * (everything issued before the tick has its majority and is applied: S.c_off) and the NEXT tick first
  * verifies that every sampled server really got there (applied_by[] in the leader's mailbox, the leader's
- * own n_apply) before the head may move -- a server that did not is waited for (bounded), then it leaves
+ * own applier) before the head may move -- a server that did not is waited for (bounded), then it leaves
  * the push set and the head stays.  Without a majority nothing commits: S.c_off stands still, the sample
  * is the real state. */
 __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, RepSeqState &S, volatile uint64_t *s_ao /*[16] LDS*/,
-                                            uint32_t bitmask, RepBox *mybox, uint64_t progress)
+                                            volatile uint64_t *s_m, uint32_t bitmask, RepBox *mybox, uint64_t progress)
 {
     RepLead *LS = A.LS;
     const uint64_t L = E.log_len;
@@ -301,7 +325,7 @@ __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, R
     /* (0) the last tick's samples must have become true */
     bool ok = true;
     if (lane == 0) {
-        for (uint64_t i = 0; ld_agent(&LS->n_apply) < S.sample_slot; i++) {
+        for (uint64_t i = 0; s_m[M_N_APPLY] < S.sample_slot; i++) {
             if (i > A.peer_polls) { ok = false; break; }
             __builtin_amdgcn_s_sleep(4);
         }
@@ -336,11 +360,12 @@ __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, R
         else if ((S.push_mask >> i) & 1u) s_ao[i] = c_before;
     }
     S.sample_slot = cs_before;
-    rep_seq_publish(LS, A.H, S, progress);
+    rep_seq_publish(LS, s_m, S, progress);
 }
 
-/* the leader's first workgroup: wavefront 0 sequences, wavefront 1 commits */
-__device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, volatile uint64_t *s_h, volatile uint64_t *s_ao, volatile uint64_t *s_x)
+/* the leader's first workgroup: wavefront 0 sequences, wavefront 1 commits, wavefront 2 applies */
+__device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, volatile uint64_t *s_h, volatile uint64_t *s_ao,
+                                            volatile uint64_t *s_m, volatile uint64_t *s_x)
 {
     RepHost *H = A.H;
     RepLead *LS = A.LS;
@@ -356,20 +381,20 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
     if (lane < 16) s_ao[lane] = (lane < APUS_DEV_MAX_SERVERS) ? s_h[H_APPLY_OFFSETS + lane] : 0;
     uint64_t req_head = ld_sys(&H->slots_done), cmd_head = ld_sys(&H->cmd_head);
     bool have_cmd = false;
-    RepCmd cmd; cmd.op = 0; cmd.after_slot = 0; cmd.a = cmd.b = 0;
+    uint32_t cmd_op = 0; uint64_t cmd_after = 0, cmd_a = 0, cmd_b = 0;
     uint64_t run_next = 0, run_end = 0;
-    uint64_t idle = 0, budget = 0;
+    uint64_t idle = 0, budget = 0, dropped = 0;
     uint32_t exit_code = R_EXIT_STOP;
     if (lane == 0) st_sys(&H->alive, 1);
 
     for (;;) {
         /* ---- flow control: room in the ticket ring and in every pushed follower's doorbell ring ---- */
-        if (budget < WAVE) {
+        if (budget < WAVE * R_SUB) {
             uint64_t spins = 0;
             for (;;) {
                 uint64_t room = ~0ull;
                 if (lane == 0) {
-                    const uint64_t inflight = S.t - ld_agent(&LS->t_retired);
+                    const uint64_t inflight = S.t - s_m[M_T_RETIRED];
                     room = inflight + R_SLACK >= RS_CAP ? 0 : RS_CAP - R_SLACK - inflight;
                 } else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) {
                     const uint64_t inflight = A.qbase[lane - 1] + S.t - ld_sys(&mybox->seqdone_by[lane - 1]);
@@ -390,87 +415,114 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
             }
             if (exit_code == R_EXIT_TIMEOUT) { if (lane == 0) spin_timeout(E, 7103); break; }
         }
-        /* ---- the next host command, once every request queued before it was taken ---- */
-        if (!have_cmd && run_next == run_end) {
-            if (ld_sys(&H->cmd_tail) > cmd_head) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-                const RepCmd *c = &H->cmd[cmd_head % RC_CAP];
-                cmd.op = c->op; cmd.after_slot = c->after_slot; cmd.a = c->a; cmd.b = c->b;
-                have_cmd = true;
-            }
-        }
         if (run_next < run_end) {
-            /* ---- staged (device-resident) rounds: one lane per round ---- */
+            /* ---- staged (device-resident) rounds: one lane per round, R_SUB x 64 rounds per pass ---- */
             const uint64_t rc = run_next;
-            const uint32_t nch = (uint32_t)min((uint64_t)WAVE, min(run_end - rc, budget));
-            const bool on = lane < nch;
-            const uint64_t r = rc + (on ? lane : 0);
-            const uint64_t pf0 = E.round_prefix[r], pf1 = E.round_prefix[r + 1];
-            const uint32_t rf0 = E.round_first[r], rf1 = E.round_first[r + 1];
-            const uint32_t len_l = E.req_len[rf1 - 1];
-            const uint64_t bpf = rl64u(pf0, 0);
-            const uint32_t brf = (uint32_t)__shfl((int)rf0, 0, WAVE);
-            const uint64_t used = S.end >= S.head ? S.end - S.head : L - (S.head - S.end);
-            /* lanes that can go without the general code: the log does not read as empty, no entry of rounds
-             * 0..j crosses or touches len, everything fits into the free part of the ring */
-            const bool plain = on && S.end != L && S.end + (pf1 - bpf) < L && S.end != S.head && (pf1 - bpf) + APUS_HDR <= L - used;
-            const unsigned long long pm = __ballot(plain);
-            const uint32_t np = (~pm) ? (uint32_t)__builtin_ctzll(~pm) : WAVE;      /* prefix of plain rounds */
-            if (np) {
-                const uint64_t stamp = wall_clock64();
-                if (lane < np) {
-                    uint64_t *w = LS->tk[(S.t + lane) % RS_CAP].w;
-                    st_agent(&w[TK_E0], S.end + (pf0 - bpf));
-                    st_agent(&w[TK_IDX0], S.last_idx + 1 + (rf0 - brf));
-                    st_agent(&w[TK_SLOT0], S.n_end + (rf0 - brf));
-                    st_agent(&w[TK_SRC], (uint64_t)rf0);
-                    st_agent(&w[TK_END], S.end + (pf1 - bpf));
-                    st_agent(&w[TK_D0], 0ull);
-                    st_agent(&w[TK_D1], stamp);
-                    st_agent(&w[TK_META], (uint64_t)(rf1 - rf0) | ((uint64_t)R_SRC_STAGED << 8) | ((uint64_t)S.push_mask << 32));
-                }
-                const uint64_t tot = rl64u(pf1, (int)np - 1) - bpf;
-                const uint32_t ntot = (uint32_t)__shfl((int)rf1, (int)np - 1, WAVE) - brf;
-                const uint32_t Tl = APUS_HDR + (uint32_t)__shfl((int)len_l, (int)np - 1, WAVE);
-                S.end += tot; S.tail = S.end - Tl; S.last_idx += ntot; S.n_end += ntot; S.store_count += ntot; S.prev_head = 0;
-                if (S.can_commit) { S.c_off = S.end; S.c_slot = S.n_end; }
-                S.t += np; budget -= np; run_next += np;
-            } else {
-                /* the round at the head of the chunk needs the general code (wrap, exact fit, nearly full) */
-                const uint32_t n = (uint32_t)__shfl((int)(rf1 - rf0), 0, WAVE);
-                const uint32_t T = lane < n ? APUS_HDR + (uint32_t)E.req_len[brf + lane] : 0u;
-                if (!rep_seq_round(E, S, LS, T, n, R_SRC_STAGED, brf, 0, 0, 0)) {
-                    if (lane == 0) { set_status(E, 1u << 1); st_sys(&H->full, ld_sys(&H->full) + 1); }
-                } else budget--;
-                run_next++;
+            const uint32_t avail = (uint32_t)min((uint64_t)(WAVE * R_SUB), min(run_end - rc, budget));
+            uint64_t pf0[R_SUB], pf1[R_SUB];
+            uint32_t rf0[R_SUB], rf1[R_SUB], lenl[R_SUB];
+#pragma unroll
+            for (int s = 0; s < R_SUB; s++) {
+                const uint32_t j = (uint32_t)s * WAVE + lane;
+                const uint64_t r = rc + (j < avail ? j : 0);
+                pf0[s] = E.round_prefix[r]; pf1[s] = E.round_prefix[r + 1];
+                rf0[s] = E.round_first[r];  rf1[s] = E.round_first[r + 1];
             }
+#pragma unroll
+            for (int s = 0; s < R_SUB; s++) lenl[s] = E.req_len[rf1[s] - 1];
+            /* (the next host command, if it is there: its PCIe round trip runs under this pass) */
+            const uint64_t next_cmd = cmd_head + 1;               /* (cmd_head is the RUN in progress) */
+            uint64_t cg = 0;
+            if (!have_cmd && lane < 4) cg = ld_sys(&H->cmd[next_cmd % RC_CAP].g[lane]);
+            uint32_t taken = 0;
+#pragma unroll
+            for (int s = 0; s < R_SUB; s++) {
+                if ((uint32_t)s * WAVE >= avail || taken != (uint32_t)s * WAVE) break;
+                const uint32_t nch = min((uint32_t)WAVE, avail - (uint32_t)s * WAVE);
+                const bool on = lane < nch;
+                const uint64_t bpf = rl64u(pf0[s], 0);
+                const uint32_t brf = (uint32_t)__shfl((int)rf0[s], 0, WAVE);
+                const uint64_t used = S.end >= S.head ? S.end - S.head : L - (S.head - S.end);
+                /* lanes that can go without the general code: the log does not read as empty, no entry of rounds
+                 * 0..j crosses or touches len, everything fits into the free part of the ring */
+                const bool plain = on && S.end != L && S.end + (pf1[s] - bpf) < L && S.end != S.head && (pf1[s] - bpf) + APUS_HDR <= L - used;
+                const unsigned long long pm = __ballot(plain);
+                const uint32_t np = (~pm) ? (uint32_t)__builtin_ctzll(~pm) : WAVE;      /* prefix of plain rounds */
+                if (np) {
+                    const uint64_t stamp = wall_clock64();
+                    if (lane < np) {
+                        uint64_t *w = LS->tk[(S.t + lane) % RS_CAP].w;
+                        st_agent(&w[TK_E0], S.end + (pf0[s] - bpf));
+                        st_agent(&w[TK_IDX0], S.last_idx + 1 + (rf0[s] - brf));
+                        st_agent(&w[TK_SLOT0], S.n_end + (rf0[s] - brf));
+                        st_agent(&w[TK_SRC], (uint64_t)rf0[s]);
+                        st_agent(&w[TK_END], S.end + (pf1[s] - bpf));
+                        st_agent(&w[TK_D0], 0ull);
+                        st_agent(&w[TK_D1], stamp);
+                        st_agent(&w[TK_META], (uint64_t)(rf1[s] - rf0[s]) | ((uint64_t)R_SRC_STAGED << 8) | ((uint64_t)S.push_mask << 32));
+                    }
+                    const uint64_t tot = rl64u(pf1[s], (int)np - 1) - bpf;
+                    const uint32_t ntot = (uint32_t)__shfl((int)rf1[s], (int)np - 1, WAVE) - brf;
+                    const uint32_t Tl = APUS_HDR + (uint32_t)__shfl((int)lenl[s], (int)np - 1, WAVE);
+                    S.end += tot; S.tail = S.end - Tl; S.last_idx += ntot; S.n_end += ntot; S.store_count += ntot; S.prev_head = 0;
+                    if (S.can_commit) { S.c_off = S.end; S.c_slot = S.n_end; }
+                    S.t += np; taken += np;
+                } else if (s == 0) {
+                    /* the round at the head of the pass needs the general code (wrap, exact fit, nearly full) */
+                    const uint32_t n = (uint32_t)__shfl((int)(rf1[0] - rf0[0]), 0, WAVE);
+                    const uint32_t T = lane < n ? APUS_HDR + (uint32_t)E.req_len[brf + lane] : 0u;
+                    if (!rep_seq_round(E, S, LS, T, n, R_SRC_STAGED, brf, 0, 0, 0)) {
+                        if (lane == 0) { set_status(E, 1u << 1); st_sys(&H->full, ld_sys(&H->full) + 1); }
+                        budget++;                                                   /* (no ticket was used) */
+                    }
+                    taken = 1;
+                    break;
+                }
+            }
+            run_next += taken; budget -= min((uint64_t)taken, budget);
             if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); }
-            rep_seq_publish(LS, H, S, cmd_head + req_head);
+            rep_seq_publish(LS, s_m, S, cmd_head + req_head);
+            if (!have_cmd && __ballot(lane < 4 && rep_gran_ok(cg, next_cmd)) == 0xFull) {
+                have_cmd = true;
+                cmd_op = (uint32_t)rl64u(cg, 0); cmd_after = rep_extend(req_head, (uint32_t)rl64u(cg, 1));
+                cmd_a = (uint32_t)rl64u(cg, 2); cmd_b = (uint32_t)rl64u(cg, 3);
+            }
             idle = 0;
             continue;
         }
-        if (have_cmd && cmd.after_slot <= req_head) {
+        /* ---- one PCIe round trip: the next host command and R_WIN windows of the request ring ---- */
+        uint32_t v[R_WIN];
+#pragma unroll
+        for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = ld_sys32(&H->ready_len[(req_head + (uint64_t)wdw * WAVE + lane) % RQ_CAP]);
+        if (!have_cmd) {
+            uint64_t cg = 0;
+            if (lane < 4) cg = ld_sys(&H->cmd[cmd_head % RC_CAP].g[lane]);
+            if (__ballot(lane < 4 && rep_gran_ok(cg, cmd_head)) == 0xFull) {
+                have_cmd = true;
+                cmd_op = (uint32_t)rl64u(cg, 0); cmd_after = rep_extend(req_head, (uint32_t)rl64u(cg, 1));
+                cmd_a = (uint32_t)rl64u(cg, 2); cmd_b = (uint32_t)rl64u(cg, 3);
+            }
+        }
+        const uint64_t stopw = ld_sys(&H->stop);
+        if (have_cmd && cmd_after <= req_head) {
             have_cmd = false;
-            if (cmd.op == R_OP_STOP) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); exit_code = R_EXIT_STOP; break; }
-            if (cmd.op == R_OP_RUN) {
-                run_next = cmd.a; run_end = cmd.a + cmd.b;
-                if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); rep_seq_publish(LS, H, S, cmd_head + req_head); }
+            if (cmd_op == R_OP_STOP) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); exit_code = R_EXIT_STOP; break; }
+            if (cmd_op == R_OP_RUN) {
+                run_next = cmd_a; run_end = cmd_a + cmd_b;
+                if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); rep_seq_publish(LS, s_m, S, cmd_head + req_head); }
                 idle = 0;
                 continue;
             }
             cmd_head++;
             if (lane == 0) st_sys(&H->cmd_head, cmd_head);
-            if (cmd.op == R_OP_PRUNE) { rep_seq_prune(E, A, S, s_ao, bitmask, mybox, cmd_head + req_head); if (budget) budget--; }
-            else rep_seq_publish(LS, H, S, cmd_head + req_head);
+            if (cmd_op == R_OP_PRUNE) { rep_seq_prune(E, A, S, s_ao, s_m, bitmask, mybox, cmd_head + req_head); if (budget) budget--; }
+            else rep_seq_publish(LS, s_m, S, cmd_head + req_head);
             idle = 0;
             continue;
         }
         /* ---- the pinned request ring: whatever is published, in rounds of <= 64 (one polling() pass takes
          *      the whole tailq, dare_ibv_ud.c:780-790) ---- */
-        const uint64_t limit = have_cmd ? cmd.after_slot : ~0ull;
-        uint32_t v[R_WIN];
-#pragma unroll
-        for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = ld_sys32(&H->ready_len[(req_head + (uint64_t)wdw * WAVE + lane) % RQ_CAP]);
+        const uint64_t limit = have_cmd ? cmd_after : ~0ull;
         bool any = false;
 #pragma unroll
         for (int wdw = 0; wdw < R_WIN; wdw++) {
@@ -480,26 +532,26 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
             const unsigned long long bal = __ballot(ok);
             const uint32_t n = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
             if (n == 0) break;
-            if (!any) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                 /* descriptors + payload behind the tags */
             any = true;
             const uint32_t T = lane < n ? APUS_HDR + (v[wdw] & 0xFFFFu) : 0u;
             if (!rep_seq_round(E, S, LS, T, n, R_SRC_PINNED, req_head, 0, 0, 0)) {
                 /* refused: the requests are dropped (get_tailq_message frees the node anyway), the host is told */
                 if (lane == 0) { set_status(E, 1u << 1); st_sys(&H->full, ld_sys(&H->full) + 1); }
-                s_x[8] += n;                                                         /* slots consumed without a ticket */
+                dropped += n;                                                        /* slots consumed without a ticket */
             } else budget--;
             req_head += n;
             if (n < WAVE) break;
         }
-        if (any) { if (lane == 0) st_agent(&LS->slots_dropped, (uint64_t)s_x[8]); rep_seq_publish(LS, H, S, cmd_head + req_head); idle = 0; continue; }
+        if (any) { if (lane == 0) s_m[M_DROPPED] = dropped; rep_seq_publish(LS, s_m, S, cmd_head + req_head); idle = 0; continue; }
         /* ---- nothing to do ---- */
-        if (ld_sys(&H->stop)) { exit_code = R_EXIT_STOP; break; }
+        if (stopw) { exit_code = R_EXIT_STOP; break; }
         if (++idle > A.idle_polls) { exit_code = R_EXIT_IDLE; break; }
         rep_nap(idle < 64);
     }
-    rep_seq_publish(LS, H, S, cmd_head + req_head);
+    rep_seq_publish(LS, s_m, S, cmd_head + req_head);
     if (lane == 0) {
         st_agent(&LS->seq_final, S.t);
+        s_m[M_FINAL] = S.t;
         /* the leader's append-side words (log_append_entry's bookkeeping, persist_new_entries' own part) */
         uint64_t *mh = E.rep[E.leader].hdr;
         mh[H_END] = S.end; mh[H_TAIL] = S.tail; mh[H_LAST_IDX] = S.last_idx; mh[H_N_END] = S.n_end; mh[H_HEAD] = S.head;
@@ -509,7 +561,135 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
     }
 }
 
-__device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, volatile uint64_t *s_h, volatile uint64_t *s_x)
+/* ---- the ACK scan (update_remote_logs, dare_ibv_rc.c:1725-1758) over a window of 64 x W x 8 entries -------
+ * Lane l, word q looks at the eight consecutive entry slots base + (q * 64 + l) * 8 ...: one 8-byte load per
+ * follower from its ACK byte map in the leader's memory.  Per entry: replies = #{followers whose byte carries
+ * this lap's tag} + 1 (the leader itself), committed iff replies >= size / 2 + 1 (:1738) -- counted for all
+ * eight entries at once in the bytes of a 64-bit word; per lane the count of trailing ones; the lanes whose
+ * eight entries are all there by __ballot, count-trailing-ones again: the scan stops at the first entry that
+ * lacks its majority, exactly like the reference's loop. */
+template <int F, int W> struct RepAckWin { uint64_t a[F][W]; uint64_t base; };
+
+template <int F, int W>
+__device__ static inline void rep_ack_load(RepAckWin<F, W> &win, const uint8_t *ackb, uint64_t cap, uint32_t dir_mask, uint32_t members, uint64_t cs)
+{
+    const uint32_t lane = lane_id();
+    win.base = cs & ~7ull;
+    uint32_t m = members;
+#pragma unroll
+    for (int j = 0; j < F; j++) {
+        const bool has = m != 0;
+        const uint32_t f = has ? (uint32_t)__builtin_ctz(m) : 0;
+        m &= m - 1;
+#pragma unroll
+        for (int q = 0; q < W; q++) {
+            const uint32_t di = (uint32_t)(win.base + (uint64_t)(q * WAVE + lane) * 8) & dir_mask;
+            win.a[j][q] = has ? ld_sys((const uint64_t *)(ackb + (uint64_t)f * cap + di)) : 0ull;
+        }
+    }
+}
+
+/* -> the slot up to which every entry from cs on has its majority (<= vis) */
+template <int F, int W>
+__device__ static inline uint64_t rep_ack_eval(const RepAckWin<F, W> &win, uint32_t dir_mask, uint32_t members, uint32_t quorum, uint64_t cs, uint64_t vis)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t ONES = 0x0101010101010101ull, HI = 0x8080808080808080ull, LO7 = 0x7F7F7F7F7F7F7F7Full;
+    const uint64_t K = (uint64_t)(0x80u - min(quorum - 1, 0x80u)) * ONES;     /* byte + K reaches bit 7 iff byte >= quorum - 1 */
+    uint64_t total = 0;
+    bool stop = false;
+#pragma unroll
+    for (int q = 0; q < W; q++) {
+        const uint64_t g0 = win.base + (uint64_t)(q * WAVE + lane) * 8;
+        const uint64_t want = (uint64_t)rep_ack_tag(g0, dir_mask) * ONES;
+        uint64_t cnt = 0;
+        uint32_t m = members;
+#pragma unroll
+        for (int j = 0; j < F; j++) {
+            if (m) {
+                const uint64_t t = win.a[j][q] ^ want;                        /* a zero byte = this lap's tag = ACK */
+                const uint64_t nz = (((t & LO7) + LO7) | t) & HI;
+                cnt += ((~nz) & HI) >> 7;
+            }
+            m &= m - 1;
+        }
+        uint64_t okb = (cnt + K) & HI;                                        /* popcount(acks | self) >= size/2 + 1, per byte */
+        const int nb = cs > g0 ? (int)min(cs - g0, (uint64_t)8) : 0;          /* entries below cs are committed already */
+        const int nv = vis > g0 ? (int)min(vis - g0, (uint64_t)8) : 0;        /* entries from vis on do not exist yet     */
+        okb |= byte_mask64(0, nb) & HI;
+        okb &= byte_mask64(0, nv);
+        const uint64_t bad = ~okb & HI;
+        const uint32_t pre = bad ? (uint32_t)__builtin_ctzll(bad) >> 3 : 8u;  /* trailing ones of this lane's eight */
+        const unsigned long long bal = __ballot(pre == 8);
+        const uint32_t nfull = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
+        if (!stop) {
+            total += (uint64_t)nfull * 8;
+            if (nfull < WAVE) { total += (uint32_t)__shfl((int)pre, (int)nfull, WAVE); stop = true; }
+        }
+    }
+    const uint64_t upto = win.base + total;
+    return upto <= cs ? cs : (upto < vis ? upto : vis);
+}
+
+struct RepCommitState {
+    uint64_t t_done, vis, vis_off, n_end_seen, cs, slots_done;
+    uint32_t push_live;
+    bool progress;
+};
+
+template <int F, int W>
+__device__ static inline void rep_commit_pass(const EngDev &E, RepLead *LS, RepCommitState &C, uint64_t tail, const uint8_t *ackb,
+                                              uint64_t cap, uint32_t members, uint32_t quorum)
+{
+    /* everything this pass looks at, in ONE memory round trip: the done granules of the next tickets and the
+     * ACK bytes of the window behind the commit (both may be looked at before they are there: a granule or an
+     * ACK byte that is not this lap's does not count) */
+    const uint32_t lane = lane_id();
+    uint64_t g0[R_SUB], g1[R_SUB], g2[R_SUB];
+#pragma unroll
+    for (int s = 0; s < R_SUB; s++) {
+        const uint64_t *d = LS->dn[(C.t_done + (uint64_t)s * WAVE + lane) % RS_CAP];
+        g0[s] = ld_agent(&d[DN_META]); g1[s] = ld_agent(&d[DN_SLOT_END]); g2[s] = ld_agent(&d[DN_END]);
+    }
+    RepAckWin<F, W> win;
+    rep_ack_load<F, W>(win, ackb, cap, E.dir_mask, members, C.cs);
+    /* (the granules of chunk s are those of tickets t_done + s * 64 + lane only while every chunk before it retires whole) */
+    {
+        const uint64_t t0 = C.t_done;
+#pragma unroll
+        for (int s = 0; s < R_SUB; s++) {
+            if (C.t_done != t0 + (uint64_t)s * WAVE) break;
+            const uint64_t k = C.t_done + lane;
+            const bool okk = k < tail && rep_gran_ok(g0[s], k) && rep_gran_ok(g1[s], k) && rep_gran_ok(g2[s], k);
+            const unsigned long long bal = __ballot(okk);
+            const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
+            if (!p) break;
+            const uint32_t meta = (uint32_t)g0[s];
+            const uint32_t n = meta & 0xFF;
+            const uint32_t pinned = (lane < p && ((meta >> 8) & 0xF) == R_SRC_PINNED) ? n : 0;
+            C.slots_done += wave_sum(pinned);
+            const uint32_t meta_l = (uint32_t)__shfl((int)meta, (int)p - 1, WAVE);
+            const uint32_t se_l = (uint32_t)__shfl((int)(uint32_t)g1[s], (int)p - 1, WAVE);
+            const uint32_t end_l = (uint32_t)__shfl((int)(uint32_t)g2[s], (int)p - 1, WAVE);
+            const uint64_t slot_end = rep_extend(C.n_end_seen, se_l);
+            C.n_end_seen = slot_end;
+            if ((uint64_t)end_l == E.log_len) {
+                /* the round sits exactly on len: the log reads as empty, nothing of it is visible yet */
+                C.vis = slot_end - (meta_l & 0xFF);
+                C.vis_off = ld_agent(&LS->tk[(C.t_done + p - 1) % RS_CAP].w[TK_E0]);
+            } else { C.vis = slot_end; C.vis_off = end_l; }
+            C.push_live = meta_l >> 16;
+            C.t_done += p;
+            C.progress = true;
+        }
+    }
+    if (C.cs < C.vis) {
+        const uint64_t upto = rep_ack_eval<F, W>(win, E.dir_mask, members, quorum, C.cs, C.vis);
+        if (upto > C.cs) { C.cs = upto; C.progress = true; }
+    }
+}
+
+__device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, volatile uint64_t *s_h, volatile uint64_t *s_m, volatile uint64_t *s_x)
 {
     RepHost *H = A.H;
     RepLead *LS = A.LS;
@@ -517,138 +697,69 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
     const uint32_t lane = lane_id(), me = E.leader;
     const uint32_t size = E.group_size, size_mask = (1u << size) - 1, quorum = size / 2 + 1;
     const uint32_t members = size_mask & ~(1u << me);
+    const uint32_t nf = (uint32_t)__popc(members);
     const uint8_t *ackb = E.ackb[me];
     const uint64_t cap = (uint64_t)E.dir_mask + 1;
-    uint64_t t_done = 0, t_app = 0;                      /* tickets whose bytes are everywhere / applied */
-    uint64_t vis = s_h[H_N_VISIBLE], vis_off = s_h[H_END];
-    uint64_t n_end_seen = s_h[H_N_END];
-    uint64_t cs = s_h[H_N_COMMIT], c_off = s_h[H_COMMIT];
-    uint64_t n_apply = s_h[H_N_APPLY], a_off = s_h[H_APPLY];
-    uint64_t hash = 0, ncl = 0, slots_done = ld_sys(&H->slots_done), settled = ~0ull;
-    uint32_t lat_n = 0;
-    if (s_h[H_END] != E.log_len) vis = n_end_seen;       /* (an exact-fit round left hidden stays so until the next round is in) */
-    else if (vis < n_end_seen) vis_off = Md.dir_off[(uint32_t)vis & E.dir_mask];
-    if (lane == 0) { st_agent(&LS->n_apply, n_apply); st_agent(&LS->commit_slot, cs); st_agent(&LS->commit_off, c_off); }
+    RepCommitState C;
+    C.t_done = 0;                                        /* tickets whose bytes are everywhere */
+    C.vis = s_h[H_N_VISIBLE]; C.vis_off = s_h[H_END];
+    C.n_end_seen = s_h[H_N_END];
+    C.cs = s_h[H_N_COMMIT];
+    C.slots_done = ld_sys(&H->slots_done);
+    C.push_live = A.push_mask;
+    if (s_h[H_END] != E.log_len) C.vis = C.n_end_seen;   /* (an exact-fit round left hidden stays so until the next round is in) */
+    else if (C.vis < C.n_end_seen) C.vis_off = Md.dir_off[(uint32_t)C.vis & E.dir_mask];
+    uint64_t settled = ~0ull, cs_pub = C.cs, sd_pub = C.slots_done;
     uint64_t patience = 0;
-    uint32_t push_live = A.push_mask;
     for (;;) {
-        bool progress = false;
-        const uint64_t prog = ld_agent(&LS->progress);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint64_t tail = ld_agent(&LS->seq_tail), fin = ld_agent(&LS->seq_final);
-        /* ---- rounds whose bytes are in every pushed ring, in order ---- */
-        if (t_done < tail) {
-            const uint64_t k = t_done + lane;
-            const bool in = k < tail;
-            const uint64_t tag = in ? ld_agent(&LS->dn[k % RS_CAP].tag) : 0;
-            const unsigned long long bal = __ballot(in && tag == k + 1);
-            const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
-            if (p) {
-                const bool mine = lane < p;
-                const uint64_t meta = mine ? ld_agent(&LS->tk[k % RS_CAP].w[TK_META]) : 0;
-                const uint64_t slot0 = mine ? ld_agent(&LS->tk[k % RS_CAP].w[TK_SLOT0]) : 0;
-                const uint64_t endk = mine ? ld_agent(&LS->tk[k % RS_CAP].w[TK_END]) : 0;
-                const uint32_t n = (uint32_t)(meta & 0xFF);
-                const uint32_t pinned = mine && ((meta >> 8) & 0xF) == R_SRC_PINNED ? n : 0;
-                slots_done += wave_sum(pinned);
-                const uint64_t e0k = mine ? ld_agent(&LS->tk[k % RS_CAP].w[TK_E0]) : 0;
-                const uint64_t se_l = rl64u(slot0 + n, (int)p - 1), s0_l = rl64u(slot0, (int)p - 1), end_l = rl64u(endk, (int)p - 1), e0_l = rl64u(e0k, (int)p - 1);
-                const uint32_t pm_l = (uint32_t)(rl64u(meta, (int)p - 1) >> 32) & 0xFFFF;
-                n_end_seen = se_l;
-                if (end_l == E.log_len) { vis = s0_l; vis_off = e0_l; }   /* the round sits exactly on len: the log reads as empty, nothing of it is visible yet */
-                else { vis = se_l; vis_off = end_l; }
-                push_live = pm_l;
-                t_done += p;
-                progress = true;
-                if (lane == 0) st_sys(&H->slots_done, slots_done + ld_agent(&LS->slots_dropped));
-            }
-        }
-        /* ---- the ACK scan: one lane per entry of the window ---- */
-        while (cs < vis) {
-            const uint64_t s = cs + lane;
-            const bool in = s < vis;
-            uint32_t bits = 0;
-            if (in) {
-                const uint32_t di = (uint32_t)s & E.dir_mask;
-                const uint8_t want = rep_ack_tag(s, E.dir_mask);
-                for (uint32_t m = members; m; m &= m - 1) {
-                    const uint32_t f = (uint32_t)__builtin_ctz(m);
-                    if (ld_sys8(ackb + (uint64_t)f * cap + di) == want) bits |= 1u << f;
-                }
-            }
-            const bool okc = !in || (uint32_t)__popc((bits | (1u << me)) & size_mask) >= quorum;   /* replies >= size/2+1, :1738 */
-            const unsigned long long bal = __ballot(okc);
-            const uint32_t prefix = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;               /* trailing ones */
-            const uint64_t adv = min((uint64_t)prefix, vis - cs);
-            if (adv) { cs += adv; progress = true; }
-            if (prefix < WAVE) break;
-        }
-        if (progress && cs > ld_agent(&LS->commit_slot)) {
-            c_off = (cs == vis) ? vis_off : ld_agent(&Md.dir_off[(uint32_t)cs & E.dir_mask]);
-            if (lane == 0) { st_agent(&LS->commit_off, c_off); st_agent(&LS->commit_slot, cs); st_sys(&H->commit_slot, cs); }
-            else if (lane <= APUS_DEV_MAX_SERVERS && ((push_live >> (lane - 1)) & 1u)) st_sys(&E.box[lane - 1]->commit_bell, cs);   /* R4 */
-        }
-        /* ---- the leader applies round by round (it never runs do_action: highest_rec) ---- */
-        if (t_app < t_done) {
-            const uint64_t k = t_app + lane;
-            const bool in = k < t_done;
-            uint64_t slot_end = ~0ull, endk = 0, hk = 0, nk = 0, stamp = 0;
-            if (in) {
-                const RepTicket &tkt = LS->tk[k % RS_CAP];
-                const uint64_t meta = ld_agent(&tkt.w[TK_META]);
-                slot_end = ld_agent(&tkt.w[TK_SLOT0]) + (meta & 0xFF);
-                endk = ld_agent(&tkt.w[TK_END]);
-                stamp = ((meta >> 8) & 0xF) == R_SRC_CONTROL ? 0 : ld_agent(&tkt.w[TK_D1]);
-                hk = ld_agent(&LS->dn[k % RS_CAP].hash); nk = ld_agent(&LS->dn[k % RS_CAP].nclient);
-            }
-            const unsigned long long bal = __ballot(in && slot_end <= cs);
-            const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
-            if (p) {
-                const bool mine = lane < p;
-                hash += wave_sum(mine ? hk : 0ull);
-                const uint64_t nc = wave_sum(mine ? nk : 0ull);
-                ncl += nc;
-                n_apply = rl64u(slot_end, (int)p - 1);
-                a_off = (n_apply == vis) ? vis_off : ld_agent(&Md.dir_off[(uint32_t)n_apply & E.dir_mask]);
-                const uint64_t now = wall_clock64();
-                const uint32_t ln = lat_n;
-                if (mine && stamp && ln + lane < R_LAT_CAP) LS->lat_ticks[ln + lane] = (uint32_t)(now - stamp);
-                lat_n = min(ln + p, R_LAT_CAP);
-                t_app += p;
-                progress = true;
-                if (lane == 0) {
-                    st_agent(&LS->apply_off, a_off); st_agent(&LS->n_apply, n_apply); st_agent(&LS->t_retired, t_app);
-                    if (nc) st_sys(&H->highest_rec, s_h[H_HIGHEST_REC] + ncl);
-                }
-            }
+        C.progress = false;
+        const uint64_t prog = s_m[M_PROG];
+        const uint64_t tail = s_m[M_TAIL], fin = s_m[M_FINAL];
+        if (nf <= 2) rep_commit_pass<2, 8>(E, LS, C, tail, ackb, cap, members, quorum);
+        else if (nf <= 4) rep_commit_pass<4, 4>(E, LS, C, tail, ackb, cap, members, quorum);
+        else if (nf <= 6) rep_commit_pass<6, 2>(E, LS, C, tail, ackb, cap, members, quorum);
+        else rep_commit_pass<12, 1>(E, LS, C, tail, ackb, cap, members, quorum);
+        if (lane == 0) { s_m[M_T_DONE] = C.t_done; s_m[M_CS] = C.cs; }      /* (the applier reads M_CS first) */
+        if (C.slots_done != sd_pub) { sd_pub = C.slots_done; if (lane == 0) st_sys(&H->slots_done, C.slots_done + s_m[M_DROPPED]); }
+        if (C.cs > cs_pub) {
+            cs_pub = C.cs;
+            if (lane == 0) st_sys(&H->commit_slot, C.cs);
+            else if (lane <= APUS_DEV_MAX_SERVERS && ((C.push_live >> (lane - 1)) & 1u)) st_sys(&E.box[lane - 1]->commit_bell, C.cs);   /* R4 */
         }
         /* ---- done? ---- */
-        {
-            const bool can = (uint32_t)__popc((push_live | (1u << me)) & size_mask) >= quorum;
-            if (t_done == tail && ((cs == vis && n_apply == cs) || !can) && settled != prog) { settled = prog; if (lane == 0) st_sys(&H->settled, prog); }
-        }
-        if (fin != ~0ull && t_done >= fin && cs == vis && n_apply == cs) break;
-        if (fin != ~0ull && t_done >= fin) {
+        const uint64_t n_apply = s_m[M_N_APPLY];
+        const bool can = (uint32_t)__popc((C.push_live | (1u << me)) & size_mask) >= quorum;
+        if (C.t_done == tail && ((C.cs == C.vis && n_apply == C.cs) || !can) && settled != prog) { settled = prog; if (lane == 0) st_sys(&H->settled, prog); }
+        if (fin != ~0ull && C.t_done >= fin && C.cs == C.vis && n_apply == C.cs) break;
+        if (fin != ~0ull && C.t_done >= fin) {
             /* nothing more will be appended; ACKs may still be on their way -- unless no majority can answer */
-            const bool can = (uint32_t)__popc((push_live | (1u << me)) & size_mask) >= quorum;
             if (!can || ++patience > A.peer_polls) { if (can && lane == 0) spin_timeout(E, 7201); break; }
         } else if (fin != ~0ull && ++patience > 64 * A.peer_polls) { if (lane == 0) spin_timeout(E, 7202); break; }
-        if (!progress) __builtin_amdgcn_s_sleep(2);
+        if (!C.progress) __builtin_amdgcn_s_sleep(1);
     }
+    /* the applier takes what is committed, then the control words go back */
+    if (lane == 0) s_m[M_C_FINAL] = 1;
+    for (uint64_t i = 0; !s_m[M_A_FINAL]; i++) {
+        if (i > 64 * A.peer_polls) { if (lane == 0) spin_timeout(E, 7203); break; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    const uint64_t n_apply = s_m[M_N_APPLY], ncl = s_m[M_A_NCL];
+    const uint64_t c_off = (C.cs == C.vis) ? C.vis_off : ld_agent(&Md.dir_off[(uint32_t)C.cs & E.dir_mask]);
+    const uint64_t a_off = (n_apply == C.vis) ? C.vis_off : ld_agent(&Md.dir_off[(uint32_t)n_apply & E.dir_mask]);
     if (lane == 0) {
         uint64_t *mh = Md.hdr;
-        mh[H_N_VISIBLE] = vis;
-        LS->lat_n = lat_n;
-        mh[H_COMMIT] = c_off; mh[H_N_COMMIT] = cs;
+        mh[H_N_VISIBLE] = C.vis;
+        mh[H_COMMIT] = c_off; mh[H_N_COMMIT] = C.cs;
         mh[H_APPLY] = a_off; mh[H_N_APPLY] = n_apply;
-        mh[H_APPLY_HASH] = s_h[H_APPLY_HASH] + hash; mh[H_APPLY_COUNT] = s_h[H_APPLY_COUNT] + ncl;
+        mh[H_APPLY_HASH] = s_h[H_APPLY_HASH] + s_m[M_A_HASH]; mh[H_APPLY_COUNT] = s_h[H_APPLY_COUNT] + ncl;
         mh[H_HIGHEST_REC] = s_h[H_HIGHEST_REC] + ncl;
         st_sys(&H->highest_rec, s_h[H_HIGHEST_REC] + ncl);
-        s_x[5] = cs;
+        st_sys(&H->commit_slot, C.cs);
+        s_x[5] = C.cs;
     }
     /* what the followers acknowledged of the entries that did not commit (no majority): into the slot words
      * the control-plane kernels scan (k_control_round's commit_scan) */
-    for (uint64_t s = cs + lane; s < n_end_seen; s += WAVE) {
+    for (uint64_t s = C.cs + lane; s < C.n_end_seen; s += WAVE) {
         const uint32_t di = (uint32_t)s & E.dir_mask;
         const uint8_t want = rep_ack_tag(s, E.dir_mask);
         uint32_t bits = 0;
@@ -659,8 +770,72 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
         __hip_atomic_store(&Md.ack[di], bits, RLX_AGENT);
     }
     /* the last word on the commit, then the followers may park */
-    if (lane >= 1 && lane <= APUS_DEV_MAX_SERVERS && ((push_live >> (lane - 1)) & 1u)) st_sys(&E.box[lane - 1]->commit_bell, cs);
+    if (lane >= 1 && lane <= APUS_DEV_MAX_SERVERS && ((C.push_live >> (lane - 1)) & 1u)) st_sys(&E.box[lane - 1]->commit_bell, C.cs);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+/* the leader applies round by round (it never runs do_action: highest_rec; apply_committed_entries,
+ * dare_server.c:1815-1974): the apply records were written with the entries, here they are counted once their
+ * round is committed */
+__device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, volatile uint64_t *s_h, volatile uint64_t *s_m)
+{
+    RepHost *H = A.H;
+    RepLead *LS = A.LS;
+    const uint32_t lane = lane_id();
+    uint64_t t_app = 0, n_apply = s_h[H_N_APPLY], hash = 0, ncl = 0;
+    const uint64_t hr0 = s_h[H_HIGHEST_REC];
+    uint32_t lat_n = 0;
+    for (;;) {
+        const uint64_t cfin = s_m[M_C_FINAL];
+        const uint64_t cs = s_m[M_CS], t_done = s_m[M_T_DONE];
+        bool progress = false;
+        if (t_app < t_done) {
+            uint64_t g1[R_SUB], g3[R_SUB], g4[R_SUB], g5[R_SUB], g6[R_SUB], g7[R_SUB];
+#pragma unroll
+            for (int s = 0; s < R_SUB; s++) {
+                const uint64_t *d = LS->dn[(t_app + (uint64_t)s * WAVE + lane) % RS_CAP];
+                g1[s] = ld_agent(&d[DN_SLOT_END]); g3[s] = ld_agent(&d[DN_HASH_LO]); g4[s] = ld_agent(&d[DN_HASH_HI]);
+                g5[s] = ld_agent(&d[DN_NCLIENT]); g6[s] = ld_agent(&d[DN_T_APPENDED]); g7[s] = ld_agent(&d[DN_T_SEQUENCED]);
+            }
+            const uint64_t t0 = t_app;
+            uint64_t nc_pass = 0;
+#pragma unroll
+            for (int s = 0; s < R_SUB; s++) {
+                if (t_app != t0 + (uint64_t)s * WAVE) break;
+                const uint64_t k = t_app + lane;
+                const uint64_t slot_end = rep_extend(n_apply, (uint32_t)g1[s]);
+                const bool okk = k < t_done && rep_gran_ok(g1[s], k) && rep_gran_ok(g3[s], k) && rep_gran_ok(g4[s], k) && rep_gran_ok(g5[s], k)
+                                 && rep_gran_ok(g6[s], k) && rep_gran_ok(g7[s], k) && slot_end <= cs;
+                const unsigned long long bal = __ballot(okk);
+                const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
+                if (!p) break;
+                const bool mine = lane < p;
+                hash += wave_sum(mine ? ((uint64_t)(uint32_t)g3[s] | (g4[s] << 32)) : 0ull);
+                nc_pass += wave_sum(mine ? (uint64_t)(uint32_t)g5[s] : 0ull);
+                n_apply = rl64u(slot_end, (int)p - 1);
+                const uint32_t now = (uint32_t)wall_clock64();
+                const uint32_t t_seq = (uint32_t)g7[s], t_apd = (uint32_t)g6[s];
+                if (mine && t_seq && lat_n + lane < R_LAT_CAP) { LS->lat_ticks[lat_n + lane] = now - t_seq; LS->lat_app[lat_n + lane] = now - t_apd; }
+                lat_n = min(lat_n + p, R_LAT_CAP);
+                t_app += p;
+                progress = true;
+            }
+            if (progress) {
+                ncl += nc_pass;
+                if (lane == 0) {
+                    s_m[M_N_APPLY] = n_apply; s_m[M_T_RETIRED] = t_app;
+                    if (nc_pass) st_sys(&H->highest_rec, hr0 + ncl);
+                }
+            }
+        }
+        if (cfin && !progress) break;                    /* (M_C_FINAL was read before M_CS / M_T_DONE: they were final) */
+        if (!progress) __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane == 0) {
+        LS->lat_n = lat_n;
+        s_m[M_A_HASH] = hash; s_m[M_A_NCL] = ncl;
+        s_m[M_A_FINAL] = 1;
+    }
 }
 
 struct RepAppLds {
@@ -686,8 +861,9 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         uint32_t go = 0;
         if (lane == 0) {
             for (uint64_t i = 0;; i++) {
-                if (ld_agent(&LS->seq_tail) > k) { go = 1; break; }
-                if (ld_agent(&LS->seq_final) <= k) break;
+                const uint64_t pub = ld_agent(&LS->pub), fin = ld_agent(&LS->seq_final);
+                if ((int32_t)((uint32_t)pub - (uint32_t)k) > 0) { go = 1; break; }
+                if (fin <= k) break;
                 rep_nap(i < 256);
             }
         }
@@ -698,21 +874,25 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         const uint64_t e0 = rl64u(wv, TK_E0), idx0 = rl64u(wv, TK_IDX0), slot0 = rl64u(wv, TK_SLOT0), first = rl64u(wv, TK_SRC);
         const uint64_t end_after = rl64u(wv, TK_END), d0 = rl64u(wv, TK_D0), d1 = rl64u(wv, TK_D1), meta = rl64u(wv, TK_META);
         const uint32_t n = (uint32_t)(meta & 0xFF), kind = (uint32_t)(meta >> 8) & 0xF, ctype = (uint32_t)(meta >> 16) & 0xFF;
+        const uint32_t hidden = (uint32_t)(meta >> 12) & 1u;
         const uint32_t push = (uint32_t)(meta >> 32) & 0xFFFF;
         const uint32_t rings = push | (1u << me);
         const bool active = lane < n;
         /* ---- get_tailq_message: the requests of the round ---- */
         ReqDev d; d.req_id = 0; d.pay16_type = 0; d.len = 0; d.clt_id = 0;
-        const uint8_t *arena = nullptr;
+        const uint8_t *src = nullptr;
         if (kind == R_SRC_PINNED) {
             /* descriptors and payload sit in host memory whose lines this CU may hold from an earlier, partly
              * filled state (a vector L1 is never refreshed by anybody's stores): drop them */
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-            if (active) { const uint4 q = *(const uint4 *)&H->desc[(first + lane) % RQ_CAP]; d.req_id = (uint64_t)q.x | ((uint64_t)q.y << 32); d.pay16_type = q.z; d.len = (uint16_t)(q.w & 0xFFFF); d.clt_id = (uint16_t)(q.w >> 16); }
-            arena = H->arena;
+            if (active) {
+                const RepSlot *sl = &H->slot[(first + lane) % RQ_CAP];
+                const uint4 q = *(const uint4 *)&sl->d;
+                d.req_id = (uint64_t)q.x | ((uint64_t)q.y << 32); d.pay16_type = q.z; d.len = (uint16_t)(q.w & 0xFFFF); d.clt_id = (uint16_t)(q.w >> 16);
+                src = (d.pay16_type & 0x0FFFFFFFu) == R_PAY_INLINE ? sl->pay : H->arena + (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
+            }
         } else if (kind == R_SRC_STAGED) {
-            if (active) d = E.req[first + lane];
-            arena = E.arena;
+            if (active) { d = E.req[first + lane]; src = E.arena + (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16; }
         } else {
             d.pay16_type = ctype << 28;
         }
@@ -726,7 +906,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)term, (uint32_t)(term >> 32));
         const uint4 h1 = make_uint4((uint32_t)d.req_id, (uint32_t)(d.req_id >> 32), (uint32_t)d.clt_id | (type << 16) | (me << 24), 0);
         lds.pos[lane] = pos;
-        lds.src[lane] = (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
+        lds.src[lane] = (uint64_t)(uintptr_t)src;
         lds.T[lane] = T;
         lds.ubase[lane] = uincl - nu;
         lds.h0[lane] = h0; lds.h1[lane] = h1;
@@ -742,7 +922,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             st_agent(&Md.dir_off[di], pos);
             __hip_atomic_store(&Md.dir_len[di], T | (me << 24), RLX_AGENT);
             /* the leader's apply record (apply_committed_entries, dare_server.c:1941-1955): written with the
-             * entry, counted by the committer once the entry's round is committed */
+             * entry, counted by the applier once the entry's round is committed */
             client = (type != APUS_NOOP && type != APUS_CONFIG && type != APUS_HEAD);
             uint4 *rp = (uint4 *)&Md.apply[di];
             /* (write-through like everything a run stores: one run laps the apply ring, and two XCDs' dirty copies of
@@ -797,7 +977,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                 else if (so == 16) v[q] = lds.h1[e];
                 else if (so == 32) v[q] = make_uint4(0, 0, 0, 0);
                 else if (kind == R_SRC_CONTROL) v[q] = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
-                else v[q] = payload_unit(arena + lds.src[e], so, Te - APUS_HDR, Te - APUS_HDR);
+                else v[q] = payload_unit((const uint8_t *)(uintptr_t)lds.src[e], so, Te - APUS_HDR, Te - APUS_HDR);
                 p[q] = lds.pos[e] + so;
             }
 #pragma unroll
@@ -806,7 +986,9 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                     for (uint32_t m = rings; m; m &= m - 1) st16_agent(E.rep[__builtin_ctz(m)].ring + p[q], v[q]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        /* ---- R2: the round's doorbell in every pushed follower's mailbox ---- */
+        /* ---- the bytes are in every pushed ring.  R2: the round's doorbell in every pushed follower's mailbox;
+         *      the round's done granules for the committer and the applier -- one batch of stores, no second drain ---- */
+        const uint32_t t_now = (uint32_t)wall_clock64();
         if (lane < 4) {
             const uint32_t val = lane == 0 ? (uint32_t)end_after : lane == 1 ? (uint32_t)(slot0 + n) : lane == 2 ? (uint32_t)e0
                                                                                              : ((n << 17) | (uniform ? T0 : 0u));
@@ -816,9 +998,20 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                 st_sys(&E.box[f]->rnd[q % RB_CAP][lane], ((q + 1) << 32) | val);
             }
         }
-        if (lane == 0) { st_agent(&LS->dn[k % RS_CAP].hash, hsum); st_agent(&LS->dn[k % RS_CAP].nclient, (uint64_t)nclient); }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) st_agent(&LS->dn[k % RS_CAP].tag, k + 1);
+        if (lane < 8) {
+            uint32_t val = 0;
+            switch (lane) {
+            case DN_META: val = n | (kind << 8) | (hidden << 12) | (push << 16); break;
+            case DN_SLOT_END: val = (uint32_t)(slot0 + n); break;
+            case DN_END: val = (uint32_t)end_after; break;
+            case DN_HASH_LO: val = (uint32_t)hsum; break;
+            case DN_HASH_HI: val = (uint32_t)(hsum >> 32); break;
+            case DN_NCLIENT: val = nclient; break;
+            case DN_T_APPENDED: val = kind == R_SRC_CONTROL ? 0u : t_now; break;
+            default: val = kind == R_SRC_CONTROL ? 0u : ((uint32_t)d1 ? (uint32_t)d1 : 1u); break;
+            }
+            st_agent(&LS->dn[k % RS_CAP][lane], rep_gran(k, val));
+        }
     }
 }
 
@@ -863,7 +1056,8 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
         const uint64_t pos = rep_pos(pl, (int)lane);
         /* ---- persist_new_entries: the entries as they landed in the own log ---- */
         uint4 u0 = make_uint4(0, 0, 0, 0), u1 = u0;
-        uint64_t mix = 0, head_val = ~0ull;
+        uint64_t mix = 0;
+        uint32_t head_val = 0xFFFFFFFFu;
         uint32_t client = 0;
         if (active) {
             ld32_sys(Md.ring + pos, u0, u1);
@@ -872,6 +1066,15 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
             const uint16_t clt = (uint16_t)(u1.z & 0xFFFF);
             const uint64_t slot = slot0 + lane;
             const uint32_t di = (uint32_t)slot & E.dir_mask;
+            /* rc_send_entries_reply (dare_ibv_rc.c:1828-1863): the own reply byte, R3 = the same byte in the
+             * sender's log at the same offset, and the ACK byte in the sender's map -- unless this server has
+             * moved on to a newer term than the one the round comes from (the term fence, receiver side).
+             * (The ACK goes first: the entry IS in this log; what follows is this server's own bookkeeping.) */
+            if (sender == leader && sender < APUS_DEV_MAX_SERVERS && E.rep[sender].ring && (my_sid >> 9) <= (uint64_t)u0.z + ((uint64_t)u0.w << 32)) {
+                st_sys8(E.ackb[sender] + (uint64_t)me * cap + di, rep_ack_tag(slot, E.dir_mask));
+                st_sys8(E.rep[sender].ring + pos + 28 + me, 1);
+            }
+            st_sys8(Md.ring + pos + 28 + me, 1);
             st_agent(&Md.dir_off[di], pos);
             __hip_atomic_store(&Md.dir_len[di], T | (sender << 24), RLX_AGENT);
             client = (type != APUS_NOOP && type != APUS_CONFIG && type != APUS_HEAD);
@@ -879,32 +1082,32 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
             st16_agent((uint8_t *)rp, make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32)));
             st16_agent((uint8_t *)(rp + 1), make_uint4(u0.x, u0.y, T - APUS_HDR, (uint32_t)clt | (type << 16) | ((client ? 2u : 0u) << 24)));
             if (client) mix = apus_apply_mix(slot, pos, idx, T - APUS_HDR, clt, (uint8_t)type, 2);
-            if (type == APUS_HEAD) { uint4 x0, x1; ld32_sys(Md.ring + pos + 32, x0, x1); head_val = (uint64_t)x1.x | ((uint64_t)x1.y << 32); }
-            /* rc_send_entries_reply (dare_ibv_rc.c:1828-1863): the own reply byte, R3 = the same byte in the
-             * sender's log at the same offset, and the ACK byte in the sender's map -- unless this server has
-             * moved on to a newer term than the one the round comes from (the term fence, receiver side) */
-            st_sys8(Md.ring + pos + 28 + me, 1);
-            if (sender == leader && sender < APUS_DEV_MAX_SERVERS && E.rep[sender].ring && (my_sid >> 9) <= (uint64_t)u0.z + ((uint64_t)u0.w << 32)) {
-                st_sys8(E.rep[sender].ring + pos + 28 + me, 1);
-                st_sys8(E.ackb[sender] + (uint64_t)me * cap + di, rep_ack_tag(slot, E.dir_mask));
-            }
+            if (type == APUS_HEAD) { uint4 x0, x1; ld32_sys(Md.ring + pos + 32, x0, x1); head_val = x1.x; }
         }
         const uint64_t hsum = wave_sum(mix);
         const uint32_t nclient = wave_sum(client);
-        head_val = rl64u(head_val, 0);                       /* (a <HEAD> entry is a round of its own) */
+        head_val = (uint32_t)__shfl((int)head_val, 0, WAVE);    /* (a <HEAD> entry is a round of its own) */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
-            RepFRound &fr = FS->fr[r];
-            st_agent(&fr.end_after, (uint64_t)end_after); st_agent(&fr.slot_end, slot_end); st_agent(&fr.hash, hsum);
-            st_agent(&fr.nclient, (uint64_t)nclient); st_agent(&fr.head_val, head_val); st_agent(&fr.e0, (uint64_t)e0); st_agent(&fr.n, (uint64_t)n);
+        /* ---- persisted: the round's granules for the retire / apply wavefronts ---- */
+        if (lane < FR_WORDS) {
+            uint32_t val = 0;
+            switch (lane) {
+            case FR_END: val = end_after; break;
+            case FR_E0: val = e0; break;
+            case FR_SLOT_END: val = (uint32_t)slot_end; break;
+            case FR_N: val = n | (nclient << 8); break;
+            case FR_HASH_LO: val = (uint32_t)hsum; break;
+            case FR_HASH_HI: val = (uint32_t)(hsum >> 32); break;
+            case FR_HEAD: val = head_val; break;
+            default: break;
+            }
+            st_agent(&FS->fr[r][lane], rep_gran(q, val));
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) st_agent(&FS->fr[r].tag, q + 1);
     }
 }
 
-/* the follower's control wavefront */
-__device__ static inline void rep_follow_control(const EngDev &E, const RepArgs &A, uint32_t me)
+/* the follower's retire wavefront: rounds in order -- persist_new_entries' bookkeeping */
+__device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &A, uint32_t me, volatile uint64_t *s_f)
 {
     RepBox *box = E.box[me];
     RepBox *lbox = E.box[E.leader];
@@ -914,11 +1117,9 @@ __device__ static inline void rep_follow_control(const EngDev &E, const RepArgs 
     const uint32_t lane = lane_id();
     const uint64_t L = E.log_len;
     const uint64_t q0 = ld_sys(&box->f_seq_next), my_run = ld_sys(&box->f_runs);
-    uint64_t end = mh[H_END], n_end = mh[H_N_END], store_count = mh[H_STORE_COUNT], head = mh[H_HEAD];
-    uint64_t n_commit = mh[H_N_COMMIT], c_off = mh[H_COMMIT], n_apply = mh[H_N_APPLY], a_off = mh[H_APPLY];
-    const uint64_t hash0 = mh[H_APPLY_HASH], cnt0 = mh[H_APPLY_COUNT], my_sid = mh[H_SID];
-    uint64_t hash = 0, ncl = 0;
-    uint64_t q_ret = q0, q_app = q0;
+    uint64_t end = mh[H_END], n_end = mh[H_N_END], store_count = mh[H_STORE_COUNT];
+    const uint64_t my_sid = mh[H_SID];
+    uint64_t q_ret = q0;
     /* an exact-fit round held back by the last run (its end is len: the log would read as empty) */
     uint64_t pend_n = 0, pend_slot_end = 0;
     {
@@ -927,94 +1128,59 @@ __device__ static inline void rep_follow_control(const EngDev &E, const RepArgs 
     }
     uint64_t real_n_end = n_end + pend_n;                /* slots consumed, the held-back round included */
     uint64_t real_end = pend_n ? L : end;
-    if (lane == 0) { st_sys(&lbox->seqdone_by[me], q_app); st_sys(&lbox->persisted_by[me], n_end); st_sys(&lbox->applied_by[me], n_apply); st_sys(&lbox->apply_off_by[me], a_off); }
+    if (lane == 0) st_sys(&lbox->persisted_by[me], n_end);
     uint64_t idle = 0;
     uint32_t exit_code = R_EXIT_STOP;
     uint64_t final_q = ~0ull;
     for (;;) {
         bool progress = false;
-        /* ---- retire rounds in order: persist_new_entries' bookkeeping ---- */
-        {
-            const uint64_t q = q_ret + lane;
-            const RepFRound &fr = FS->fr[q % RB_CAP];
-            const uint64_t tag = ld_agent(&fr.tag);
-            const unsigned long long bal = __ballot(tag == q + 1 && q < final_q);
-            const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
-            if (p) {
-                const bool mine = lane < p;
-                const uint64_t ea = mine ? ld_agent(&fr.end_after) : 0, se = mine ? ld_agent(&fr.slot_end) : 0;
-                const uint64_t e0 = mine ? ld_agent(&fr.e0) : 0, nn = mine ? ld_agent(&fr.n) : 0;
-                /* the first round must continue where this log stands (a follower that missed rounds needs
-                 * the leader's catch-up first) */
-                const uint64_t e0_0 = rl64u(e0, 0), s0_0 = rl64u(se - nn, 0);
-                if (e0_0 != real_end || s0_0 != real_n_end) { exit_code = R_EXIT_GAP; if (lane == 0) spin_timeout(E, 7301); break; }
-                /* rounds up to the last one that does not end on len become visible */
-                const unsigned long long vis_b = __ballot(mine && ea != L);
-                const uint64_t se_l = rl64u(se, (int)p - 1), ea_l = rl64u(ea, (int)p - 1);
-                real_n_end = se_l; real_end = ea_l;
-                if (vis_b) {
-                    const int jj = 63 - __builtin_clzll(vis_b);
-                    const uint64_t se_v = rl64u(se, jj), ea_v = rl64u(ea, jj);
-                    store_count += se_v - n_end;
-                    n_end = se_v; end = ea_v;
-                    pend_n = se_l - se_v; pend_slot_end = se_l;
-                    if (lane == 0) {
-                        mh[H_END] = end; mh[H_OLD_END] = end; mh[H_N_END] = n_end; mh[H_N_PERSIST] = n_end; mh[H_STORE_COUNT] = store_count;
-                        st_sys(&lbox->persisted_by[me], n_end);
-                    }
-                } else { pend_n = se_l - n_end; pend_slot_end = se_l; }
-                q_ret += p;
-                progress = true;
-            }
+        const uint64_t ctrl = ld_sys(&box->ctrl);
+        uint64_t f0[R_SUB], f1[R_SUB], f2[R_SUB], f3[R_SUB];
+#pragma unroll
+        for (int s = 0; s < R_SUB; s++) {
+            const uint64_t *fr = FS->fr[(q_ret + (uint64_t)s * WAVE + lane) % RB_CAP];
+            f0[s] = ld_agent(&fr[FR_END]); f1[s] = ld_agent(&fr[FR_E0]); f2[s] = ld_agent(&fr[FR_SLOT_END]); f3[s] = ld_agent(&fr[FR_N]);
         }
-        /* ---- the commit doorbell (R4), apply_committed_entries round by round ---- */
-        {
-            uint64_t cs = ld_sys(&box->commit_bell);
-            if (cs > n_end) cs = n_end;
-            if (cs > n_commit) {
-                n_commit = cs;
-                c_off = (cs == n_end) ? end : ld_agent(&Md.dir_off[(uint32_t)cs & E.dir_mask]);
-                if (lane == 0) { mh[H_COMMIT] = c_off; mh[H_N_COMMIT] = cs; }
-                progress = true;
-            }
-            if (q_app < q_ret) {
-                const uint64_t q = q_app + lane;
-                const bool in = q < q_ret;
-                const RepFRound &fr = FS->fr[q % RB_CAP];
-                const uint64_t se = in ? ld_agent(&fr.slot_end) : ~0ull;
-                const unsigned long long bal = __ballot(in && se <= n_commit && se <= n_end);
-                const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
-                if (p) {
-                    const bool mine = lane < p;
-                    hash += wave_sum(mine ? ld_agent(&fr.hash) : 0ull);
-                    ncl += wave_sum(mine ? ld_agent(&fr.nclient) : 0ull);
-                    const uint64_t hv = mine ? ld_agent(&fr.head_val) : ~0ull;
-                    /* poll_config_entries: a committed <HEAD> entry moves the head (dare_server.c:2164) */
-                    const unsigned long long hb = __ballot(hv != ~0ull);
-                    if (hb) { const uint64_t h = rl64u(hv, 63 - __builtin_clzll(hb)); if (apus_is_larger(end, L, h, head)) head = h; }
-                    n_apply = rl64u(se, (int)p - 1);
-                    a_off = (n_apply == n_end) ? end : ld_agent(&Md.dir_off[(uint32_t)n_apply & E.dir_mask]);
-                    q_app += p;
-                    progress = true;
-                    if (lane == 0) {
-                        mh[H_APPLY] = a_off; mh[H_N_APPLY] = n_apply; mh[H_HEAD] = head;
-                        mh[H_APPLY_HASH] = hash0 + hash; mh[H_APPLY_COUNT] = cnt0 + ncl;
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        st_sys(&lbox->apply_off_by[me], a_off); st_sys(&lbox->applied_by[me], n_apply); st_sys(&lbox->seqdone_by[me], q_app);
-                    }
-                }
-            }
+        if (final_q == ~0ull && (ctrl >> 40) == my_run + 1) final_q = q0 + (ctrl & 0xFFFFFFFFFFull) - 1;
+        const uint64_t t0 = q_ret;
+        bool gap = false;
+#pragma unroll
+        for (int s = 0; s < R_SUB; s++) {
+            if (q_ret != t0 + (uint64_t)s * WAVE) break;
+            const uint64_t q = q_ret + lane;
+            const bool okq = q < final_q && rep_gran_ok(f0[s], q) && rep_gran_ok(f1[s], q) && rep_gran_ok(f2[s], q) && rep_gran_ok(f3[s], q);
+            const unsigned long long bal = __ballot(okq);
+            const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
+            if (!p) break;
+            const bool mine = lane < p;
+            const uint64_t ea = (uint32_t)f0[s], e0 = (uint32_t)f1[s], nn = (uint32_t)f3[s] & 0xFF;
+            const uint64_t se = rep_extend(real_n_end, (uint32_t)f2[s]);
+            /* the first round must continue where this log stands (a follower that missed rounds needs
+             * the leader's catch-up first) */
+            const uint64_t e0_0 = rl64u(e0, 0), s0_0 = rl64u(se - nn, 0);
+            if (e0_0 != real_end || s0_0 != real_n_end) { gap = true; break; }
+            /* rounds up to the last one that does not end on len become visible */
+            const unsigned long long vis_b = __ballot(mine && ea != L);
+            const uint64_t se_l = rl64u(se, (int)p - 1), ea_l = rl64u(ea, (int)p - 1);
+            real_n_end = se_l; real_end = ea_l;
+            if (vis_b) {
+                const int jj = 63 - __builtin_clzll(vis_b);
+                const uint64_t se_v = rl64u(se, jj), ea_v = rl64u(ea, jj);
+                store_count += se_v - n_end;
+                n_end = se_v; end = ea_v;
+                pend_n = se_l - se_v; pend_slot_end = se_l;
+            } else { pend_n = se_l - n_end; pend_slot_end = se_l; }
+            q_ret += p;
+            progress = true;
+        }
+        if (gap) { exit_code = R_EXIT_GAP; if (lane == 0) spin_timeout(E, 7301); break; }
+        if (progress && lane == 0) {
+            s_f[F_END] = end; s_f[F_N_END] = n_end;
+            s_f[F_Q_RET] = q_ret;                       /* (the apply wavefront reads F_Q_RET first) */
+            st_sys(&lbox->persisted_by[me], n_end);
         }
         /* ---- park? ---- */
-        if (final_q == ~0ull) {
-            const uint64_t ctrl = ld_sys(&box->ctrl);
-            if ((ctrl >> 40) == my_run + 1) final_q = q0 + (ctrl & 0xFFFFFFFFFFull) - 1;
-        }
-        if (final_q != ~0ull && q_ret >= final_q) {
-            /* everything that was sent is persisted; the leader's last commit doorbell was rung before the
-             * park word: one more look at it, then leave */
-            if (!progress && (q_app == q_ret || ld_sys(&box->commit_bell) <= n_apply || idle > 4)) break;
-        }
+        if (final_q != ~0ull && q_ret >= final_q) break;      /* everything that was sent is persisted */
         if (progress) idle = 0;
         else {
             if (++idle > A.idle_polls) { exit_code = R_EXIT_IDLE; break; }
@@ -1022,9 +1188,96 @@ __device__ static inline void rep_follow_control(const EngDev &E, const RepArgs 
         }
     }
     if (lane == 0) {
+        s_f[F_END] = end; s_f[F_N_END] = n_end; s_f[F_Q_RET] = q_ret;
+        s_f[F_STORE_COUNT] = store_count; s_f[F_PEND_N] = pend_n; s_f[F_PEND_SLOT_END] = pend_slot_end; s_f[F_EXIT] = exit_code;
+        s_f[F_R_FINAL] = 1;
+    }
+}
+
+/* the follower's apply wavefront: the commit doorbell (R4), apply_committed_entries round by round */
+__device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A, uint32_t me, volatile uint64_t *s_f)
+{
+    RepBox *box = E.box[me];
+    RepBox *lbox = E.box[E.leader];
+    RepFollow *FS = A.FS[me];
+    const RepDev &Md = E.rep[me];
+    uint64_t *mh = Md.hdr;
+    const uint32_t lane = lane_id();
+    const uint64_t L = E.log_len;
+    const uint64_t q0 = ld_sys(&box->f_seq_next), my_run = ld_sys(&box->f_runs);
+    uint64_t head = mh[H_HEAD];
+    uint64_t n_commit = mh[H_N_COMMIT], n_apply = mh[H_N_APPLY];
+    const uint64_t c_off0 = mh[H_COMMIT], a_off0 = mh[H_APPLY];
+    const uint64_t n_commit0 = n_commit, n_apply0 = n_apply;
+    const uint64_t hash0 = mh[H_APPLY_HASH], cnt0 = mh[H_APPLY_COUNT], my_sid = mh[H_SID];
+    uint64_t hash = 0, ncl = 0;
+    uint64_t q_app = q0;
+    if (lane == 0) { st_sys(&lbox->seqdone_by[me], q_app); st_sys(&lbox->applied_by[me], n_apply); st_sys(&lbox->apply_off_by[me], a_off0); }
+    uint64_t idle_fin = 0;
+    uint64_t end = 0, n_end = 0, q_ret = q0;
+    for (;;) {
+        bool progress = false;
+        const uint64_t rfin = s_f[F_R_FINAL];
+        q_ret = s_f[F_Q_RET]; n_end = s_f[F_N_END]; end = s_f[F_END];
+        uint64_t cs = ld_sys(&box->commit_bell);
+        uint64_t f2[R_SUB], f3[R_SUB], f4[R_SUB], f5[R_SUB], f6[R_SUB];
+        if (q_app < q_ret) {
+#pragma unroll
+            for (int s = 0; s < R_SUB; s++) {
+                const uint64_t *fr = FS->fr[(q_app + (uint64_t)s * WAVE + lane) % RB_CAP];
+                f2[s] = ld_agent(&fr[FR_SLOT_END]); f3[s] = ld_agent(&fr[FR_N]); f4[s] = ld_agent(&fr[FR_HASH_LO]);
+                f5[s] = ld_agent(&fr[FR_HASH_HI]); f6[s] = ld_agent(&fr[FR_HEAD]);
+            }
+        }
+        if (cs > n_end) cs = n_end;
+        if (cs > n_commit) { n_commit = cs; progress = true; }
+        if (q_app < q_ret) {
+            const uint64_t t0 = q_app;
+#pragma unroll
+            for (int s = 0; s < R_SUB; s++) {
+                if (q_app != t0 + (uint64_t)s * WAVE) break;
+                const uint64_t q = q_app + lane;
+                const uint64_t se = rep_extend(n_apply, (uint32_t)f2[s]);
+                const bool okq = q < q_ret && rep_gran_ok(f2[s], q) && rep_gran_ok(f3[s], q) && rep_gran_ok(f4[s], q) && rep_gran_ok(f5[s], q)
+                                 && rep_gran_ok(f6[s], q) && se <= n_commit && se <= n_end;
+                const unsigned long long bal = __ballot(okq);
+                const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
+                if (!p) break;
+                const bool mine = lane < p;
+                hash += wave_sum(mine ? ((uint64_t)(uint32_t)f4[s] | (f5[s] << 32)) : 0ull);
+                ncl += wave_sum(mine ? (uint64_t)(((uint32_t)f3[s] >> 8) & 0xFF) : 0ull);
+                /* poll_config_entries: a committed <HEAD> entry moves the head (dare_server.c:2164) */
+                const uint32_t hv = mine ? (uint32_t)f6[s] : 0xFFFFFFFFu;
+                const unsigned long long hb = __ballot(hv != 0xFFFFFFFFu);
+                if (hb) { const uint64_t h = (uint32_t)__shfl((int)hv, 63 - __builtin_clzll(hb), WAVE); if (apus_is_larger(end, L, h, head)) head = h; }
+                n_apply = rl64u(se, (int)p - 1);
+                q_app += p;
+                progress = true;
+            }
+            if (q_app != t0 && lane == 0) { st_sys(&lbox->applied_by[me], n_apply); st_sys(&lbox->seqdone_by[me], q_app); }
+        }
+        /* ---- park?  everything that was sent is persisted; the leader's last commit doorbell was rung before the
+         *      park word: one more look at it, then leave ---- */
+        if (rfin) {
+            if (!progress && (q_app == q_ret || ld_sys(&box->commit_bell) <= n_apply || idle_fin > 4)) break;
+            if (!progress) idle_fin++;
+        }
+        if (!progress) rep_nap(true);
+    }
+    /* (F_R_FINAL was read before F_Q_RET / F_N_END / F_END in the last pass: they were final) */
+    const uint32_t exit_code = (uint32_t)s_f[F_EXIT];
+    const uint64_t c_off = n_commit == n_commit0 ? c_off0 : (n_commit == n_end ? end : ld_agent(&Md.dir_off[(uint32_t)n_commit & E.dir_mask]));
+    const uint64_t a_off = n_apply == n_apply0 ? a_off0 : (n_apply == n_end ? end : ld_agent(&Md.dir_off[(uint32_t)n_apply & E.dir_mask]));
+    if (lane == 0) {
+        const uint64_t pend_n = s_f[F_PEND_N];
+        mh[H_END] = end; mh[H_OLD_END] = end; mh[H_N_END] = n_end; mh[H_N_PERSIST] = n_end; mh[H_STORE_COUNT] = s_f[F_STORE_COUNT];
+        mh[H_COMMIT] = c_off; mh[H_N_COMMIT] = n_commit;
+        mh[H_APPLY] = a_off; mh[H_N_APPLY] = n_apply; mh[H_HEAD] = head;
+        mh[H_APPLY_HASH] = hash0 + hash; mh[H_APPLY_COUNT] = cnt0 + ncl;
         st_agent(&FS->quit, 1ull);
+        st_sys(&lbox->apply_off_by[me], a_off);
         st_sys(&box->f_seq_next, q_ret);
-        st_sys(&box->f_pend_slot0, n_end); st_sys(&box->f_pend_slot_end, pend_n ? pend_slot_end : 0ull); st_sys(&box->f_pend_sid, my_sid);
+        st_sys(&box->f_pend_slot0, n_end); st_sys(&box->f_pend_slot_end, pend_n ? s_f[F_PEND_SLOT_END] : 0ull); st_sys(&box->f_pend_sid, my_sid);
         st_sys(&box->f_exit, (uint64_t)exit_code + 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         st_sys(&box->f_runs, my_run + 1);
@@ -1034,14 +1287,15 @@ __device__ static inline void rep_follow_control(const EngDev &E, const RepArgs 
 
 /* ===================================================================================== the launch */
 /* One launch carries every role this process hosts: [leader control, n_append append workgroups,] then
- * n_fwork workgroups per hosted follower (the first wavefront of a follower's first workgroup is its
- * control wavefront).  All workgroups must be resident together: the host sizes the grid for that. */
+ * n_fwork workgroups per hosted follower (the first two wavefronts of a follower's first workgroup are its
+ * retire and apply wavefronts).  All workgroups must be resident together: the host sizes the grid for that. */
 __global__ __launch_bounds__(256) void k_replica(const EngDev E, const RepArgs A)
 {
     __shared__ RepAppLds s_lds[4];
     __shared__ uint64_t s_h[64];
     __shared__ uint64_t s_ao[16];
     __shared__ uint64_t s_x[16];
+    __shared__ uint64_t s_m[M_WORDS];
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     uint32_t b = blockIdx.x;
     if (A.lead_here) {
@@ -1049,9 +1303,11 @@ __global__ __launch_bounds__(256) void k_replica(const EngDev E, const RepArgs A
             RepHost *H = A.H;
             if (tid < 64) s_h[tid] = E.rep[E.leader].hdr[tid];
             if (tid < 16) s_x[tid] = 0;
+            if (tid < M_WORDS) s_m[tid] = tid == M_FINAL ? ~0ull : (tid == M_N_APPLY ? E.rep[E.leader].hdr[H_N_APPLY] : 0ull);
             __syncthreads();
-            if (wave == 0) rep_sequencer(E, A, s_h, s_ao, s_x);
-            else if (wave == 1) rep_committer(E, A, s_h, s_x);
+            if (wave == 0) rep_sequencer(E, A, s_h, s_ao, s_m, s_x);
+            else if (wave == 1) rep_committer(E, A, s_h, s_m, s_x);
+            else if (wave == 2) rep_applier(E, A, s_h, s_m);
             __syncthreads();
             if (tid == 0) {
                 /* park the followers: every round they were sent is in their doorbell ring */
@@ -1078,7 +1334,17 @@ __global__ __launch_bounds__(256) void k_replica(const EngDev E, const RepArgs A
     for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
         if (A.follow_mask & (1u << i)) { if (k == (int)ord) { me = i; break; } k++; }
     if (me < 0) return;
-    const uint32_t G = A.n_fwork * 4 - 1;
-    if (fb == 0 && wave == 0) { rep_follow_control(E, A, (uint32_t)me); return; }
-    rep_follow_wave(E, A, (uint32_t)me, fb * 4 + wave - 1, G);
+    const uint32_t G = A.n_fwork * 4 - 2;
+    if (fb == 0) {
+        if (tid < F_WORDS) {
+            const uint64_t *mh = E.rep[me].hdr;
+            s_m[tid] = tid == F_END ? mh[H_END] : tid == F_N_END ? mh[H_N_END] : tid == F_Q_RET ? ld_sys(&E.box[me]->f_seq_next) : 0ull;
+        }
+        __syncthreads();
+        if (wave == 0) { rep_follow_retire(E, A, (uint32_t)me, s_m); return; }
+        if (wave == 1) { rep_follow_apply(E, A, (uint32_t)me, s_m); return; }
+        rep_follow_wave(E, A, (uint32_t)me, wave - 2, G);
+        return;
+    }
+    rep_follow_wave(E, A, (uint32_t)me, fb * 4 + wave - 2, G);
 }

@@ -397,6 +397,21 @@ class Engine:
         self._chk(self.L.apus_gpu_rep_latency(self.h, out.ctypes.data, len(out), C.byref(n)), "rep_latency")
         return out[:n.value].copy()
 
+    def rep_latency_appended_ns(self) -> np.ndarray:
+        """the round's bytes in every pushed ring -> committed and applied by the leader (SURVEY 8d's round latency)"""
+        out = np.zeros(1 << 16, dtype=np.uint32)
+        n = C.c_uint32(0)
+        self._chk(self.L.apus_gpu_rep_latency_appended(self.h, out.ctypes.data, len(out), C.byref(n)), "rep_latency_appended")
+        return out[:n.value].copy()
+
+    def rep_feed(self, reqs: np.ndarray, arena: np.ndarray, n_threads: int, seconds: float, prune_every_reqs: int = 0):
+        """n_threads producers on the pinned multi-producer ring for `seconds`, then drained -> (requests, seconds)"""
+        reqs = np.ascontiguousarray(reqs, dtype=REQ_DTYPE)
+        out = (C.c_uint64 * 2)()
+        self._chk(self.L.apus_gpu_rep_feed(self.h, reqs.ctypes.data, len(reqs), arena.ctypes.data, len(arena), n_threads, seconds,
+                                           prune_every_reqs, out), "rep_feed")
+        return int(out[0]), out[1] / 1e9
+
     def rep_roundtrip_ns(self, reqs: np.ndarray, arena: np.ndarray, iters: int) -> np.ndarray:
         reqs = np.ascontiguousarray(reqs, dtype=REQ_DTYPE)
         out = np.zeros(iters, dtype=np.uint32)

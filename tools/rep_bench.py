@@ -58,6 +58,7 @@ def staged(n_rep, entries, payload, batch, steps, n_append, n_fwork, warmup=1):
         st = eng.rep_stats()
         code = eng.rep_park()
         lat = eng.rep_latency_ns()
+        lat_a = eng.rep_latency_appended_ns()
         eng.quiesce()
         total = (warmup + steps) * len(tr.reqs)
         ok = eng.status() == 0 and code == 0
@@ -68,12 +69,13 @@ def staged(n_rep, entries, payload, batch, steps, n_append, n_fwork, warmup=1):
         return {"mode": "staged", "replicas": n_rep, "payload": payload, "n_append": n_append, "n_fwork": n_fwork,
                 "entries_per_s": len(tr.reqs) * steps / dt, "ms_per_step": dt / steps * 1e3, "verified": bool(ok),
                 "exit": code, "status": eng.status_names(), "stats": st,
-                "lat_us_p50": float(np.percentile(lat, 50)) / 1e3 if len(lat) else None}
+                "lat_us_p50": float(np.percentile(lat, 50)) / 1e3 if len(lat) else None,
+                "lat_appended_us_p50": float(np.percentile(lat_a, 50)) / 1e3 if len(lat_a) else None}
     finally:
         eng.close()
 
 
-def hostfed(n_rep, payload, seconds, n_append, n_fwork, blk=4096):
+def hostfed(n_rep, payload, seconds, n_append, n_fwork, blk=4096, threads=(1, 4, 8)):
     tr = T.steady_trace(n_rep, 1 << 16, payload, 16, 64, log_len=T.DEFAULT_LOG)
     eng = Engine(n_rep, tr.log_len)
     try:
@@ -85,23 +87,28 @@ def hostfed(n_rep, payload, seconds, n_append, n_fwork, blk=4096):
         hl = eng.rep_roundtrip_ns(reqs[:64], tr.arena, 300) / 1e3
         hl1 = eng.rep_roundtrip_ns(reqs[:1], tr.arena, 300) / 1e3
         eng.rep_drain()
-        hr0 = eng.rep_highest_rec()
-        n, nsub, t0 = 0, 0, time.perf_counter()
-        while time.perf_counter() - t0 < seconds:
-            eng.rep_submit(reqs, tr.arena)
-            n += len(reqs)
-            nsub += 1
-            if nsub % (max(1, (8 << 20) // ((64 + payload) * blk))) == 0:
-                eng.rep_prune()
-        eng.rep_drain(timeout_ms=60000)
-        dt = time.perf_counter() - t0
-        ok = eng.rep_highest_rec() == hr0 + n
-        code = eng.rep_park()
+        code0 = eng.rep_park()                   # (the latency samples of the lone rounds: read before the bulk runs)
         lat = eng.rep_latency_ns()
+        lat_a = eng.rep_latency_appended_ns()
+        out = {"mode": "host-fed", "replicas": n_rep, "payload": payload,
+               "host_rt64_us_p50": float(np.percentile(hl[20:], 50)), "host_rt1_us_p50": float(np.percentile(hl1[20:], 50)),
+               "dev_seq_to_applied_us_p50": float(np.percentile(lat, 50)) / 1e3 if len(lat) else None,
+               "dev_appended_to_applied_us_p50": float(np.percentile(lat_a, 50)) / 1e3 if len(lat_a) else None, "by_threads": {}}
+        ok = code0 == 0
+        for nt in threads:
+            eng.rep_start(idle_ms=5000, peer_ms=1000, n_append=n_append, n_fwork=n_fwork)
+            hr0 = eng.rep_highest_rec()
+            n, dt = eng.rep_feed(reqs, tr.arena, nt, seconds, prune_every_reqs=(8 << 20) // (64 + payload))
+            good = eng.rep_highest_rec() == hr0 + n
+            code = eng.rep_park()
+            out["by_threads"][str(nt)] = {"entries_per_s": n / dt, "verified": bool(good and code == 0)}
+            ok = ok and good and code == 0
         eng.quiesce()
-        return {"mode": "host-fed (one submitting thread)", "replicas": n_rep, "payload": payload, "entries_per_s": n / dt, "verified": bool(ok and code == 0),
-                "host_rt64_us_p50": float(np.percentile(hl[20:], 50)), "host_rt1_us_p50": float(np.percentile(hl1[20:], 50)),
-                "dev_lat_us_p50": float(np.percentile(lat[:600], 50)) / 1e3 if len(lat) else None, "status": eng.status_names()}
+        for r in range(n_rep):
+            o = eng.offsets(r)
+            ok = ok and (o["commit"] == o["end"] == o["apply"])
+        out["verified"] = bool(ok); out["status"] = eng.status_names()
+        return out
     finally:
         eng.close()
 
@@ -111,14 +118,14 @@ def main():
     ap.add_argument("--entries", type=int, default=1 << 20)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--sweep", action="store_true")
-    ap.add_argument("--n-append", type=int, default=32)
-    ap.add_argument("--n-fwork", type=int, default=8)
+    ap.add_argument("--n-append", type=int, default=0)
+    ap.add_argument("--n-fwork", type=int, default=0)
     ap.add_argument("--replicas", type=int, default=3)
     ap.add_argument("--no-hostfed", action="store_true")
     a = ap.parse_args()
     combos = [(a.replicas, a.n_append, a.n_fwork)]
     if a.sweep:
-        combos = [(3, 32, 8), (3, 64, 16), (3, 96, 24), (1, 64, 1), (5, 64, 12)]
+        combos = [(3, 0, 0), (3, 48, 48), (1, 0, 0), (5, 0, 0), (7, 0, 0)]
     for n_rep, na, nf in combos:
         try:
             print(json.dumps(staged(n_rep, a.entries, 64, 64, a.steps, na, nf)), flush=True)
