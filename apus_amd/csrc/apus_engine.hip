@@ -1413,6 +1413,7 @@ extern "C" int apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_
         RepBox *lb = e->d.box[leader];
         uint64_t *words[5] = { &lb->seqdone_by[r], &lb->persisted_by[r], &lb->applied_by[r], &lb->apply_off_by[r], &lb->sid_by[r] };
         for (auto w : words) HIPCHK(hipMemsetAsync(w, 0, sizeof(uint64_t), e->stream));
+        HIPCHK(hipMemsetAsync(lb->rack[r], 0, sizeof lb->rack[r], e->stream));       /* ... and its round counter restarts */
     }
     if ((rc = launch_control_round(e, 2 | 32, 0, 0, 0))) return rc;
     out[0] = nb; out[1] = e->d.group_size; out[2] = e->cid_epoch; out[3] = 0;
@@ -2379,6 +2380,22 @@ extern "C" int apus_gpu_rep_stats(apus_engine_t *e, uint64_t out[8])
     out[0] = e->rh->rounds; out[1] = e->rh->slots_done; out[2] = e->rh->cmd_head; out[3] = e->rh->commit_slot;
     out[4] = e->rh->highest_rec; out[5] = e->rh->full; out[6] = 0; out[7] = e->rh->alive;
     if (!e->r_running && e->rl) HIPCHK(hipMemcpy(&out[6], &e->rl->drop_mask, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+/* diagnostics: how the serial roles of the last run spent their passes.  out[role][8]: roles 0..2 = the leader's
+ * sequencer, committer, applier; 3 + 2 i, 4 + 2 i = retire / apply wavefront of the i-th hosted follower (i < 6):
+ * [0] passes [1] passes that moved something [2] rounds [3] wall-clock ticks (100 MHz) */
+extern "C" int apus_gpu_rep_role_stats(apus_engine_t *e, uint64_t out[16][8])
+{
+    if (!e || e->r_running || !out) return APUS_E_STATE;
+    memset(out, 0, sizeof(uint64_t) * 16 * 8);
+    if (e->rl) HIPCHK(hipMemcpy(out, e->rl->stat, sizeof(uint64_t) * 3 * 8, hipMemcpyDeviceToHost));
+    int k = 0;
+    for (uint32_t m = e->r_follow_mask; m && k < 6; m &= m - 1, k++) {
+        RepFollow *fs = e->rfs[__builtin_ctz(m)];
+        if (fs) HIPCHK(hipMemcpy(out[3 + 2 * k], fs->stat, sizeof(uint64_t) * 2 * 8, hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 

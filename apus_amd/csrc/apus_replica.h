@@ -102,8 +102,9 @@ struct RepBox {
     /* the leader -> this replica.  One round = four self-tagged granules {seq + 1, value}:
      *   [0] end offset after the round   [1] low 32 bits of the slot count after the round
      *   [2] end offset before the round (len: the log read as empty)
-     *   [3] n << 17 | T when all n entries are T bytes long, n << 17 when the sizes differ (lens[]) */
-    uint64_t rnd[RB_CAP][4];
+     *   [3] n << 17 | T when all n entries are T bytes long, n << 17 when the sizes differ (lens[])
+     * (written as a whole 64-byte line: a partial line is a read-modify-write in the memory that receives it) */
+    uint64_t rnd[RB_CAP][8];
     uint16_t lens[RB_CAP][WAVE];         /* cmd.len of every entry of a round of mixed sizes (2 B per entry) */
     uint64_t commit_bell;                /* R4: committed slots                                 */
     uint64_t ctrl;                       /* (f_runs + 1) << 40 | rounds of this run to consume + 1: park */
@@ -114,6 +115,9 @@ struct RepBox {
     uint64_t applied_by[16];             /* entry slots applied                                 */
     uint64_t apply_off_by[16];           /* ... and the apply offset that goes with it (when the run ends) */
     uint64_t sid_by[16];                 /* a follower that moved on to a newer SID says so here: the term fence */
+    /* R3, round by round: follower f has persisted round q and written the reply byte of every one of its entries
+     * into this replica's log -- granule {q + 1 : entries}.  What the committer's window is made of. */
+    uint64_t rack[APUS_DEV_MAX_SERVERS][RB_CAP];
     /* this replica's own notes, kept across runs of its follower workgroups */
     uint64_t f_seq_next;                 /* next round it expects                               */
     uint64_t f_pend_slot0, f_pend_slot_end, f_pend_sid;   /* an exact-fit round it holds back (its end == len) */
@@ -122,11 +126,16 @@ struct RepBox {
     uint64_t pad1[2];
 };
 
-struct RepTicket { uint64_t w[8]; };     /* one round, sequencer -> append wavefront */
+/* one round, sequencer -> append wavefront: eight words {low 16 bits of ticket + 1 : 48-bit value}, valid the
+ * moment all eight carry the ticket's tag -- the sequencer never waits for its stores */
+struct RepTicket { uint64_t w[8]; };
 enum { TK_E0 = 0, TK_IDX0, TK_SLOT0, TK_SRC, TK_END, TK_D0, TK_D1, TK_META };
-/* TK_D1: control entry data word 1, else the sequencer's wall clock (latency samples)
+/* TK_D1: control entry data word 1, else the low half of the sequencer's wall clock (latency samples)
  * TK_META: [7:0] n  [11:8] source kind  [12] hidden (the round ends exactly on len)  [23:16] control entry type
  *          [47:32] push mask */
+#define TK_VAL 0x0000FFFFFFFFFFFFull
+__device__ static inline uint64_t rep_tk(uint64_t t, uint64_t v) { return (((t + 1) & 0xFFFFull) << 48) | (v & TK_VAL); }
+__device__ static inline bool rep_tk_ok(uint64_t w, uint64_t t) { return (w >> 48) == ((t + 1) & 0xFFFFull); }
 /* one round as its append wavefront leaves it for the committer / the applier: granules {ticket + 1 : value} */
 enum { DN_META = 0, DN_SLOT_END, DN_END, DN_HASH_LO, DN_HASH_HI, DN_NCLIENT, DN_T_APPENDED, DN_T_SEQUENCED };
 /* DN_META: [7:0] n  [11:8] source kind  [12] hidden  [31:16] push mask */
@@ -138,6 +147,7 @@ struct RepLead {
     uint64_t drop_mask, slots_dropped, pad2[6];
     uint64_t t_drop[16];                        /* tickets issued when follower f left the push set (~0: still in) */
     uint32_t lat_n, pad3;
+    uint64_t stat[4][8];                        /* per serial role (sequencer, committer, applier): passes, passes that moved something, items, wall-clock ticks */
     uint32_t lat_ticks[R_LAT_CAP];              /* sequenced -> committed and applied by the leader      */
     uint32_t lat_app[R_LAT_CAP];                /* bytes in every pushed ring -> committed and applied   */
     RepTicket tk[RS_CAP];
@@ -151,6 +161,7 @@ enum { FR_END = 0, FR_E0, FR_SLOT_END, FR_N, FR_HASH_LO, FR_HASH_HI, FR_HEAD, FR
 /* FR_N: [7:0] n  [15:8] client entries   FR_HEAD: the head a <HEAD> entry carries, 0xFFFFFFFF none */
 struct RepFollow {                       /* follower-local (device memory, agent scope) */
     uint64_t quit; uint64_t pad[7];
+    uint64_t stat[2][8];                 /* retire / apply wavefront: passes, passes that moved something, rounds, wall-clock ticks */
     uint64_t fr[RB_CAP][FR_WORDS];
 };
 /* a follower's first workgroup: its retire / apply wavefronts' words in LDS */
@@ -196,6 +207,43 @@ __device__ static inline uint64_t rl64u(uint64_t v, int l)
 {
     return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), l, WAVE) << 32) | (uint32_t)__shfl((int)(uint32_t)v, l, WAVE);
 }
+/* Rows that the lanes of a wavefront hold (row r in lane r) go to memory as WHOLE LINES: instruction j writes
+ * 1 KiB contiguous, lane l the 16 bytes [l * 16, l * 16 + 16) of it -- a write-through store that covers part of
+ * a line is a read-modify-write in HBM, eight 8-byte stores to one line are eight of them in a row. */
+__device__ static inline uint4 rl128(uint4 v, int l)
+{
+    return make_uint4((uint32_t)__shfl((int)v.x, l, WAVE), (uint32_t)__shfl((int)v.y, l, WAVE), (uint32_t)__shfl((int)v.z, l, WAVE), (uint32_t)__shfl((int)v.w, l, WAVE));
+}
+/* 64-byte rows: w[0..7] of row r in lane r; row r goes to row_base(r) */
+template <typename AddrOf>
+__device__ static inline void rep_store_rows64(const uint64_t (&w)[8], uint32_t nrows, AddrOf row_addr)
+{
+    const uint32_t lane = lane_id(), q = lane & 3;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int src = j * 16 + (int)(lane >> 2);
+        uint64_t lo = 0, hi = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint64_t a = rl64u(w[2 * c], src), b = rl64u(w[2 * c + 1], src);
+            if ((uint32_t)c == q) { lo = a; hi = b; }
+        }
+        if ((uint32_t)src < nrows) st16_agent(row_addr((uint32_t)src) + q * 16, make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)));
+    }
+}
+/* 32-byte rows: (a, b) of row r in lane r */
+template <typename AddrOf>
+__device__ static inline void rep_store_rows32(uint4 a, uint4 b, uint32_t nrows, AddrOf row_addr)
+{
+    const uint32_t lane = lane_id(), h = lane & 1;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int src = j * 32 + (int)(lane >> 1);
+        const uint4 va = rl128(a, src), vb = rl128(b, src);
+        if ((uint32_t)src < nrows) st16_agent(row_addr((uint32_t)src) + h * 16, h ? vb : va);
+    }
+}
+
 /* where the n entries of one round go (log_append_entry, dare_log.h:466-558): lane j holds the size T of
  * entry j (0 beyond n), e0 = the log's end before the round (len: it reads as empty).  The entry that does
  * not fit before len wraps to offset 0 -- leaving a stale header behind when only its payload did not fit
@@ -237,9 +285,18 @@ struct RepSeqState {                    /* the sequencer's registers: the leader
     uint64_t c_off, c_slot;             /* the commit as it stands once everything issued has its majority */
     uint64_t sample_slot;               /* slots the servers sampled by the last tick are taken to have applied */
     uint64_t t;                         /* tickets issued                                      */
+    uint64_t tail_round;                /* staged round whose last entry is the tail (tail worked out when somebody asks) */
     uint32_t push_mask;
-    bool     can_commit;
+    bool     can_commit, tail_known;
 };
+/* the offset of the last entry (log->tail): only a prune tick and the end of the run want it */
+__device__ static inline void rep_seq_fix_tail(const EngDev &E, RepSeqState &S)
+{
+    if (S.tail_known) return;
+    const uint32_t last = E.round_first[S.tail_round + 1] - 1;
+    S.tail = S.end - (APUS_HDR + (uint64_t)E.req_len[last]);
+    S.tail_known = true;
+}
 
 __device__ static inline bool rep_quorum(const EngDev &E, uint32_t push_mask)
 {
@@ -269,24 +326,22 @@ __device__ static inline bool rep_seq_round(const EngDev &E, RepSeqState &S, Rep
     case TK_SRC: v = first; break;
     case TK_END: v = end_new; break;
     case TK_D0: v = d0; break;
-    case TK_D1: v = (kind == R_SRC_CONTROL) ? d1 : wall_clock64(); break;
+    case TK_D1: v = (kind == R_SRC_CONTROL) ? d1 : (wall_clock64() & 0xFFFFFFFFull); break;
     case TK_META: v = (uint64_t)n | ((uint64_t)kind << 8) | ((uint64_t)hidden << 12) | ((uint64_t)ctype << 16) | ((uint64_t)S.push_mask << 32); break;
     default: break;
     }
-    if (lane < 8) st_agent(&LS->tk[S.t % RS_CAP].w[lane], v);
+    if (lane < 8) st_agent(&LS->tk[S.t % RS_CAP].w[lane], rep_tk(S.t, v));
     S.t++;
-    S.end = end_new; S.tail = pos_l; S.last_idx = idx_l; S.n_end += n; S.store_count += n;
+    S.end = end_new; S.tail = pos_l; S.tail_known = true; S.last_idx = idx_l; S.n_end += n; S.store_count += n;
     if (!(kind == R_SRC_CONTROL && ctype == 3)) S.prev_head = 0;
     if (S.can_commit && !hidden) { S.c_off = end_new; S.c_slot = S.n_end; }
     return true;
 }
 
-/* the tickets issued so far are in memory: tell the append wavefronts (device memory) and the committer (LDS) */
+/* the tickets issued so far: for the committer (LDS).  The append wavefronts poll their tickets themselves. */
 __device__ static inline void rep_seq_publish(RepLead *LS, volatile uint64_t *s_m, const RepSeqState &S, uint64_t progress)
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane_id() == 0) {
-        st_agent(&LS->pub, (progress << 32) | (S.t & 0xFFFFFFFFull));
         s_m[M_TAIL] = S.t;                             /* (whoever reads M_PROG first and M_TAIL second sees every ticket behind the progress) */
         s_m[M_PROG] = progress;
     }
@@ -346,7 +401,7 @@ __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, R
             if (!((bitmask >> i) & 1u)) s_ao[i] = S.c_off;
             if (apus_is_larger(S.end, L, min_off, s_ao[i])) min_off = s_ao[i];
         }
-        if (apus_end_distance(S.end, L, min_off) == 0) min_off = S.tail;      /* leave one entry, :2038-2041 */
+        if (apus_end_distance(S.end, L, min_off) == 0) { rep_seq_fix_tail(E, S); min_off = S.tail; }      /* leave one entry, :2038-2041 */
         if (apus_is_larger(S.end, L, min_off, S.head) && !S.prev_head) {
             const uint64_t head_before = S.head;
             S.head = min_off;
@@ -375,7 +430,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
     RepSeqState S;
     S.end = s_h[H_END]; S.tail = s_h[H_TAIL]; S.last_idx = s_h[H_LAST_IDX]; S.n_end = s_h[H_N_END]; S.head = s_h[H_HEAD];
     S.prev_head = s_h[H_PREV_HEAD]; S.store_count = s_h[H_STORE_COUNT];
-    S.c_off = s_h[H_COMMIT]; S.c_slot = s_h[H_N_COMMIT]; S.sample_slot = 0; S.t = 0;
+    S.c_off = s_h[H_COMMIT]; S.c_slot = s_h[H_N_COMMIT]; S.sample_slot = 0; S.t = 0; S.tail_known = true; S.tail_round = 0;
     S.push_mask = A.push_mask; S.can_commit = rep_quorum(E, S.push_mask);
     const uint32_t bitmask = (uint32_t)s_h[H_CID_BITMASK];
     if (lane < 16) s_ao[lane] = (lane < APUS_DEV_MAX_SERVERS) ? s_h[H_APPLY_OFFSETS + lane] : 0;
@@ -386,11 +441,15 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
     uint64_t idle = 0, budget = 0, dropped = 0;
     uint32_t exit_code = R_EXIT_STOP;
     if (lane == 0) st_sys(&H->alive, 1);
+    uint64_t st_pass = 0, st_staged = 0, st_flow = 0;
+    const uint64_t st_t0 = wall_clock64();
 
     for (;;) {
+        st_pass++;
         /* ---- flow control: room in the ticket ring and in every pushed follower's doorbell ring ---- */
-        if (budget < WAVE * R_SUB) {
+        if (budget < WAVE * R_SUB && run_next == run_end) {
             uint64_t spins = 0;
+            st_flow++;
             for (;;) {
                 uint64_t room = ~0ull;
                 if (lane == 0) {
@@ -416,77 +475,108 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
             if (exit_code == R_EXIT_TIMEOUT) { if (lane == 0) spin_timeout(E, 7103); break; }
         }
         if (run_next < run_end) {
-            /* ---- staged (device-resident) rounds: one lane per round, R_SUB x 64 rounds per pass ---- */
-            const uint64_t rc = run_next;
-            const uint32_t avail = (uint32_t)min((uint64_t)(WAVE * R_SUB), min(run_end - rc, budget));
-            uint64_t pf0[R_SUB], pf1[R_SUB];
-            uint32_t rf0[R_SUB], rf1[R_SUB], lenl[R_SUB];
+            /* ---- staged (device-resident) rounds: one lane per round, R_SUB x 64 rounds per pass, ONE memory
+             *      round trip per pass (the loads of the pass; the ticket stores are never waited for) ---- */
+            uint64_t spins = 0;
+            bool out = false;
+            while (run_next < run_end) {
+                const uint64_t rc = run_next;
+                st_staged++;
+                const uint32_t want = (uint32_t)min((uint64_t)(WAVE * R_SUB), run_end - rc);
+                uint64_t pf0[R_SUB], pf1[R_SUB];
+                uint32_t rf0[R_SUB], rf1[R_SUB];
 #pragma unroll
-            for (int s = 0; s < R_SUB; s++) {
-                const uint32_t j = (uint32_t)s * WAVE + lane;
-                const uint64_t r = rc + (j < avail ? j : 0);
-                pf0[s] = E.round_prefix[r]; pf1[s] = E.round_prefix[r + 1];
-                rf0[s] = E.round_first[r];  rf1[s] = E.round_first[r + 1];
-            }
-#pragma unroll
-            for (int s = 0; s < R_SUB; s++) lenl[s] = E.req_len[rf1[s] - 1];
-            /* (the next host command, if it is there: its PCIe round trip runs under this pass) */
-            const uint64_t next_cmd = cmd_head + 1;               /* (cmd_head is the RUN in progress) */
-            uint64_t cg = 0;
-            if (!have_cmd && lane < 4) cg = ld_sys(&H->cmd[next_cmd % RC_CAP].g[lane]);
-            uint32_t taken = 0;
-#pragma unroll
-            for (int s = 0; s < R_SUB; s++) {
-                if ((uint32_t)s * WAVE >= avail || taken != (uint32_t)s * WAVE) break;
-                const uint32_t nch = min((uint32_t)WAVE, avail - (uint32_t)s * WAVE);
-                const bool on = lane < nch;
-                const uint64_t bpf = rl64u(pf0[s], 0);
-                const uint32_t brf = (uint32_t)__shfl((int)rf0[s], 0, WAVE);
-                const uint64_t used = S.end >= S.head ? S.end - S.head : L - (S.head - S.end);
-                /* lanes that can go without the general code: the log does not read as empty, no entry of rounds
-                 * 0..j crosses or touches len, everything fits into the free part of the ring */
-                const bool plain = on && S.end != L && S.end + (pf1[s] - bpf) < L && S.end != S.head && (pf1[s] - bpf) + APUS_HDR <= L - used;
-                const unsigned long long pm = __ballot(plain);
-                const uint32_t np = (~pm) ? (uint32_t)__builtin_ctzll(~pm) : WAVE;      /* prefix of plain rounds */
-                if (np) {
-                    const uint64_t stamp = wall_clock64();
-                    if (lane < np) {
-                        uint64_t *w = LS->tk[(S.t + lane) % RS_CAP].w;
-                        st_agent(&w[TK_E0], S.end + (pf0[s] - bpf));
-                        st_agent(&w[TK_IDX0], S.last_idx + 1 + (rf0[s] - brf));
-                        st_agent(&w[TK_SLOT0], S.n_end + (rf0[s] - brf));
-                        st_agent(&w[TK_SRC], (uint64_t)rf0[s]);
-                        st_agent(&w[TK_END], S.end + (pf1[s] - bpf));
-                        st_agent(&w[TK_D0], 0ull);
-                        st_agent(&w[TK_D1], stamp);
-                        st_agent(&w[TK_META], (uint64_t)(rf1[s] - rf0[s]) | ((uint64_t)R_SRC_STAGED << 8) | ((uint64_t)S.push_mask << 32));
+                for (int s = 0; s < R_SUB; s++) {
+                    const uint32_t j = (uint32_t)s * WAVE + lane;
+                    const uint64_t r = rc + (j < want ? j : 0);
+                    pf0[s] = E.round_prefix[r]; pf1[s] = E.round_prefix[r + 1];
+                    rf0[s] = E.round_first[r];  rf1[s] = E.round_first[r + 1];
+                }
+                /* flow control rides along: room in the ticket ring and in every pushed follower's doorbell ring */
+                uint64_t room = ~0ull;
+                if (lane == 0) {
+                    const uint64_t inflight = S.t - s_m[M_T_RETIRED];
+                    room = inflight + R_SLACK >= RS_CAP ? 0 : RS_CAP - R_SLACK - inflight;
+                } else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) {
+                    const uint64_t inflight = A.qbase[lane - 1] + S.t - ld_sys(&mybox->seqdone_by[lane - 1]);
+                    room = inflight + R_SLACK >= RB_CAP ? 0 : RB_CAP - R_SLACK - inflight;
+                }
+                /* (and the next host command, if it is there: its PCIe round trip runs under this pass) */
+                const uint64_t next_cmd = cmd_head + 1;               /* (cmd_head is the RUN in progress) */
+                uint64_t cg = 0;
+                if (!have_cmd && lane < 4) cg = ld_sys(&H->cmd[next_cmd % RC_CAP].g[lane]);
+                const unsigned long long tight = __ballot(room < WAVE);
+                if (tight) {
+                    if (++spins > A.peer_polls) {
+                        if (tight >> 1) { rep_seq_drop(E, S, LS, (uint32_t)(tight >> 1), 7102); spins = 0; continue; }
+                        exit_code = R_EXIT_TIMEOUT; out = true;     /* the leader's own commit does not move: no majority */
+                        if (lane == 0) spin_timeout(E, 7103);
+                        break;
                     }
-                    const uint64_t tot = rl64u(pf1[s], (int)np - 1) - bpf;
-                    const uint32_t ntot = (uint32_t)__shfl((int)rf1[s], (int)np - 1, WAVE) - brf;
-                    const uint32_t Tl = APUS_HDR + (uint32_t)__shfl((int)lenl[s], (int)np - 1, WAVE);
-                    S.end += tot; S.tail = S.end - Tl; S.last_idx += ntot; S.n_end += ntot; S.store_count += ntot; S.prev_head = 0;
-                    if (S.can_commit) { S.c_off = S.end; S.c_slot = S.n_end; }
-                    S.t += np; taken += np;
-                } else if (s == 0) {
-                    /* the round at the head of the pass needs the general code (wrap, exact fit, nearly full) */
-                    const uint32_t n = (uint32_t)__shfl((int)(rf1[0] - rf0[0]), 0, WAVE);
-                    const uint32_t T = lane < n ? APUS_HDR + (uint32_t)E.req_len[brf + lane] : 0u;
-                    if (!rep_seq_round(E, S, LS, T, n, R_SRC_STAGED, brf, 0, 0, 0)) {
-                        if (lane == 0) { set_status(E, 1u << 1); st_sys(&H->full, ld_sys(&H->full) + 1); }
-                        budget++;                                                   /* (no ticket was used) */
+                    st_flow++;
+                    __builtin_amdgcn_s_sleep(8);
+                    continue;
+                }
+                spins = 0;
+                for (int d = WAVE / 2; d > 0; d >>= 1) { const uint64_t o = rl64u(room, (int)(lane ^ (uint32_t)d)); room = o < room ? o : room; }
+                const uint32_t avail = (uint32_t)min((uint64_t)want, room);
+                uint32_t taken = 0;
+#pragma unroll
+                for (int s = 0; s < R_SUB; s++) {
+                    if ((uint32_t)s * WAVE >= avail || taken != (uint32_t)s * WAVE) break;
+                    const uint32_t nch = min((uint32_t)WAVE, avail - (uint32_t)s * WAVE);
+                    const bool on = lane < nch;
+                    const uint64_t bpf = rl64u(pf0[s], 0);
+                    const uint32_t brf = (uint32_t)__shfl((int)rf0[s], 0, WAVE);
+                    const uint64_t used = S.end >= S.head ? S.end - S.head : L - (S.head - S.end);
+                    /* lanes that can go without the general code: the log does not read as empty, no entry of rounds
+                     * 0..j crosses or touches len, everything fits into the free part of the ring */
+                    const bool plain = on && S.end != L && S.end + (pf1[s] - bpf) < L && S.end != S.head && (pf1[s] - bpf) + APUS_HDR <= L - used;
+                    const unsigned long long pm = __ballot(plain);
+                    const uint32_t np = (~pm) ? (uint32_t)__builtin_ctzll(~pm) : WAVE;      /* prefix of plain rounds */
+                    if (np) {
+                        const uint64_t stamp = wall_clock64() & 0xFFFFFFFFull;
+                        {
+                            const uint64_t t0 = S.t, tk = t0 + lane;
+                            uint64_t w[8];
+                            w[TK_E0] = rep_tk(tk, S.end + (pf0[s] - bpf));
+                            w[TK_IDX0] = rep_tk(tk, S.last_idx + 1 + (rf0[s] - brf));
+                            w[TK_SLOT0] = rep_tk(tk, S.n_end + (rf0[s] - brf));
+                            w[TK_SRC] = rep_tk(tk, (uint64_t)rf0[s]);
+                            w[TK_END] = rep_tk(tk, S.end + (pf1[s] - bpf));
+                            w[TK_D0] = rep_tk(tk, 0ull);
+                            w[TK_D1] = rep_tk(tk, stamp);
+                            w[TK_META] = rep_tk(tk, (uint64_t)(rf1[s] - rf0[s]) | ((uint64_t)R_SRC_STAGED << 8) | ((uint64_t)S.push_mask << 32));
+                            rep_store_rows64(w, np, [&](uint32_t r) { return (uint8_t *)LS->tk[(t0 + r) % RS_CAP].w; });
+                        }
+                        const uint64_t tot = rl64u(pf1[s], (int)np - 1) - bpf;
+                        const uint32_t ntot = (uint32_t)__shfl((int)rf1[s], (int)np - 1, WAVE) - brf;
+                        S.end += tot; S.last_idx += ntot; S.n_end += ntot; S.store_count += ntot; S.prev_head = 0;
+                        S.tail_known = false; S.tail_round = rc + taken + np - 1;
+                        if (S.can_commit) { S.c_off = S.end; S.c_slot = S.n_end; }
+                        S.t += np; taken += np;
+                    } else if (s == 0) {
+                        /* the round at the head of the pass needs the general code (wrap, exact fit, nearly full) */
+                        const uint32_t n = (uint32_t)__shfl((int)(rf1[0] - rf0[0]), 0, WAVE);
+                        const uint32_t T = lane < n ? APUS_HDR + (uint32_t)E.req_len[brf + lane] : 0u;
+                        if (!rep_seq_round(E, S, LS, T, n, R_SRC_STAGED, brf, 0, 0, 0)) {
+                            if (lane == 0) { set_status(E, 1u << 1); st_sys(&H->full, ld_sys(&H->full) + 1); }
+                        }
+                        taken = 1;
+                        break;
                     }
-                    taken = 1;
-                    break;
+                }
+                run_next += taken;
+                if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); }
+                rep_seq_publish(LS, s_m, S, cmd_head + req_head);
+                if (!have_cmd && __ballot(lane < 4 && rep_gran_ok(cg, next_cmd)) == 0xFull) {
+                    have_cmd = true;
+                    cmd_op = (uint32_t)rl64u(cg, 0); cmd_after = rep_extend(req_head, (uint32_t)rl64u(cg, 1));
+                    cmd_a = (uint32_t)rl64u(cg, 2); cmd_b = (uint32_t)rl64u(cg, 3);
                 }
             }
-            run_next += taken; budget -= min((uint64_t)taken, budget);
-            if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); }
-            rep_seq_publish(LS, s_m, S, cmd_head + req_head);
-            if (!have_cmd && __ballot(lane < 4 && rep_gran_ok(cg, next_cmd)) == 0xFull) {
-                have_cmd = true;
-                cmd_op = (uint32_t)rl64u(cg, 0); cmd_after = rep_extend(req_head, (uint32_t)rl64u(cg, 1));
-                cmd_a = (uint32_t)rl64u(cg, 2); cmd_b = (uint32_t)rl64u(cg, 3);
-            }
+            if (out) break;
+            budget = 0;                                   /* (the other sources work their room out again) */
             idle = 0;
             continue;
         }
@@ -549,9 +639,11 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
         rep_nap(idle < 64);
     }
     rep_seq_publish(LS, s_m, S, cmd_head + req_head);
+    rep_seq_fix_tail(E, S);
     if (lane == 0) {
         st_agent(&LS->seq_final, S.t);
         s_m[M_FINAL] = S.t;
+        LS->stat[0][0] = st_pass; LS->stat[0][1] = st_staged; LS->stat[0][2] = S.t; LS->stat[0][3] = wall_clock64() - st_t0; LS->stat[0][4] = st_flow;
         /* the leader's append-side words (log_append_entry's bookkeeping, persist_new_entries' own part) */
         uint64_t *mh = E.rep[E.leader].hdr;
         mh[H_END] = S.end; mh[H_TAIL] = S.tail; mh[H_LAST_IDX] = S.last_idx; mh[H_N_END] = S.n_end; mh[H_HEAD] = S.head;
@@ -632,61 +724,108 @@ __device__ static inline uint64_t rep_ack_eval(const RepAckWin<F, W> &win, uint3
 }
 
 struct RepCommitState {
-    uint64_t t_done, vis, vis_off, n_end_seen, cs, slots_done;
+    uint64_t t_done, t_com;             /* tickets whose bytes are in every pushed ring / committed */
+    uint64_t vis, vis_off, n_end_seen, cs, slots_done;
+    uint64_t pre_end;                   /* entries below this slot were appended before this run: no ticket stands for them */
     uint32_t push_live;
     bool progress;
 };
 
-template <int F, int W>
-__device__ static inline void rep_commit_pass(const EngDev &E, RepLead *LS, RepCommitState &C, uint64_t tail, const uint8_t *ackb,
-                                              uint64_t cap, uint32_t members, uint32_t quorum)
+/* One pass of the committer = ONE memory round trip: the done granules of the next R_SUB x 64 tickets and, for each of
+ * them, every follower's round ACK granule (R3: "I have persisted this round and written the reply byte of each of its
+ * entries into your log").  One lane per round: replies = popcount(ACKs) + 1 (the leader itself), committed iff the
+ * round's bytes are everywhere and replies >= size / 2 + 1 (dare_ibv_rc.c:1738); __ballot over the lanes,
+ * count-trailing-ones = the prefix of rounds that commit -- the scan stops at the first round that lacks its majority
+ * (:1741).  Granules may be looked at before they are there: one that is not this round's does not count. */
+template <int F>
+__device__ static inline void rep_commit_pass(const EngDev &E, const RepArgs &A, RepLead *LS, RepCommitState &C, uint64_t tail,
+                                              const RepBox *mybox, uint32_t members, uint32_t quorum)
 {
-    /* everything this pass looks at, in ONE memory round trip: the done granules of the next tickets and the
-     * ACK bytes of the window behind the commit (both may be looked at before they are there: a granule or an
-     * ACK byte that is not this lap's does not count) */
     const uint32_t lane = lane_id();
-    uint64_t g0[R_SUB], g1[R_SUB], g2[R_SUB];
+    const uint64_t base = C.t_com;
+    uint64_t g0[R_SUB], g1[R_SUB], g2[R_SUB], ra[F][R_SUB];
 #pragma unroll
     for (int s = 0; s < R_SUB; s++) {
-        const uint64_t *d = LS->dn[(C.t_done + (uint64_t)s * WAVE + lane) % RS_CAP];
+        const uint64_t *d = LS->dn[(base + (uint64_t)s * WAVE + lane) % RS_CAP];
         g0[s] = ld_agent(&d[DN_META]); g1[s] = ld_agent(&d[DN_SLOT_END]); g2[s] = ld_agent(&d[DN_END]);
     }
-    RepAckWin<F, W> win;
-    rep_ack_load<F, W>(win, ackb, cap, E.dir_mask, members, C.cs);
-    /* (the granules of chunk s are those of tickets t_done + s * 64 + lane only while every chunk before it retires whole) */
     {
-        const uint64_t t0 = C.t_done;
+        uint32_t m = members;
 #pragma unroll
-        for (int s = 0; s < R_SUB; s++) {
-            if (C.t_done != t0 + (uint64_t)s * WAVE) break;
-            const uint64_t k = C.t_done + lane;
-            const bool okk = k < tail && rep_gran_ok(g0[s], k) && rep_gran_ok(g1[s], k) && rep_gran_ok(g2[s], k);
-            const unsigned long long bal = __ballot(okk);
-            const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
-            if (!p) break;
-            const uint32_t meta = (uint32_t)g0[s];
+        for (int j = 0; j < F; j++) {
+            const bool has = m != 0;
+            const uint32_t f = has ? (uint32_t)__builtin_ctz(m) : 0;
+            m &= m - 1;
+#pragma unroll
+            for (int s = 0; s < R_SUB; s++)
+                ra[j][s] = has ? ld_sys(&mybox->rack[f][(A.qbase[f] + base + (uint64_t)s * WAVE + lane) % RB_CAP]) : 0ull;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < R_SUB; s++) {
+        if (C.t_com != base + (uint64_t)s * WAVE) break;            /* (chunk s is looked at only when every chunk before it committed whole) */
+        const uint64_t k = base + (uint64_t)s * WAVE + lane;
+        const bool ret = k < tail && rep_gran_ok(g0[s], k) && rep_gran_ok(g1[s], k) && rep_gran_ok(g2[s], k);
+        const unsigned long long balr = __ballot(ret);
+        const uint32_t pr = (~balr) ? (uint32_t)__builtin_ctzll(~balr) : WAVE;
+        if (!pr) break;
+        const uint32_t meta = (uint32_t)g0[s];
+        /* ---- rounds whose bytes are in every pushed ring, in order ---- */
+        if (k - lane + pr > C.t_done) {
             const uint32_t n = meta & 0xFF;
-            const uint32_t pinned = (lane < p && ((meta >> 8) & 0xF) == R_SRC_PINNED) ? n : 0;
+            const uint32_t pinned = (lane < pr && k >= C.t_done && ((meta >> 8) & 0xF) == R_SRC_PINNED) ? n : 0;
             C.slots_done += wave_sum(pinned);
-            const uint32_t meta_l = (uint32_t)__shfl((int)meta, (int)p - 1, WAVE);
-            const uint32_t se_l = (uint32_t)__shfl((int)(uint32_t)g1[s], (int)p - 1, WAVE);
-            const uint32_t end_l = (uint32_t)__shfl((int)(uint32_t)g2[s], (int)p - 1, WAVE);
+            const uint32_t meta_l = (uint32_t)__shfl((int)meta, (int)pr - 1, WAVE);
+            const uint32_t se_l = (uint32_t)__shfl((int)(uint32_t)g1[s], (int)pr - 1, WAVE);
+            const uint32_t end_l = (uint32_t)__shfl((int)(uint32_t)g2[s], (int)pr - 1, WAVE);
             const uint64_t slot_end = rep_extend(C.n_end_seen, se_l);
             C.n_end_seen = slot_end;
+            C.t_done = k - lane + pr;
             if ((uint64_t)end_l == E.log_len) {
                 /* the round sits exactly on len: the log reads as empty, nothing of it is visible yet */
                 C.vis = slot_end - (meta_l & 0xFF);
-                C.vis_off = ld_agent(&LS->tk[(C.t_done + p - 1) % RS_CAP].w[TK_E0]);
+                C.vis_off = ld_agent(&LS->tk[(C.t_done - 1) % RS_CAP].w[TK_E0]) & TK_VAL;
             } else { C.vis = slot_end; C.vis_off = end_l; }
             C.push_live = meta_l >> 16;
-            C.t_done += p;
             C.progress = true;
         }
+        if (C.cs < C.pre_end) break;                                 /* (what was appended before this run commits first) */
+        /* ---- the ACK scan, one lane per round ---- */
+        uint32_t replies = 1;                                        /* the leader itself */
+        {
+            uint32_t m = members;
+#pragma unroll
+            for (int j = 0; j < F; j++) {
+                if (m) { const uint32_t f = (uint32_t)__builtin_ctz(m); replies += rep_gran_ok(ra[j][s], A.qbase[f] + k) ? 1u : 0u; }
+                m &= m - 1;
+            }
+        }
+        /* a round that ends exactly on len is visible once the next one is in */
+        const bool hidden = (meta >> 12) & 1u;
+        const bool next_in = (__shfl_down((int)ret, 1, WAVE) != 0) && lane < WAVE - 1;
+        const bool okc = ret && replies >= quorum && (!hidden || next_in);
+        const unsigned long long balc = __ballot(okc);
+        const uint32_t pc = (~balc) ? (uint32_t)__builtin_ctzll(~balc) : WAVE;    /* trailing ones */
+        if (pc) {
+            const uint32_t se_c = (uint32_t)__shfl((int)(uint32_t)g1[s], (int)pc - 1, WAVE);
+            C.cs = rep_extend(C.cs, se_c);
+            C.t_com += pc;
+            C.progress = true;
+        }
+        if (pc < WAVE) break;
     }
-    if (C.cs < C.vis) {
-        const uint64_t upto = rep_ack_eval<F, W>(win, E.dir_mask, members, quorum, C.cs, C.vis);
-        if (upto > C.cs) { C.cs = upto; C.progress = true; }
-    }
+}
+
+/* what was appended before this run and is not committed yet (an exact-fit round left hidden, entries that had no
+ * majority): the scan over the followers' per-entry ACK bytes */
+__device__ static inline void rep_commit_pre(const EngDev &E, RepCommitState &C, const uint8_t *ackb, uint64_t cap, uint32_t members, uint32_t quorum)
+{
+    const uint64_t lim = C.vis < C.pre_end ? C.vis : C.pre_end;
+    if (C.cs >= lim) return;
+    RepAckWin<12, 1> win;
+    rep_ack_load<12, 1>(win, ackb, cap, E.dir_mask, members, C.cs);
+    const uint64_t upto = rep_ack_eval<12, 1>(win, E.dir_mask, members, quorum, C.cs, lim);
+    if (upto > C.cs) { C.cs = upto; C.progress = true; }
 }
 
 __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, volatile uint64_t *s_h, volatile uint64_t *s_m, volatile uint64_t *s_x)
@@ -700,8 +839,10 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
     const uint32_t nf = (uint32_t)__popc(members);
     const uint8_t *ackb = E.ackb[me];
     const uint64_t cap = (uint64_t)E.dir_mask + 1;
+    const RepBox *mybox = E.box[me];
     RepCommitState C;
-    C.t_done = 0;                                        /* tickets whose bytes are everywhere */
+    C.t_done = 0; C.t_com = 0;
+    C.pre_end = s_h[H_N_END];
     C.vis = s_h[H_N_VISIBLE]; C.vis_off = s_h[H_END];
     C.n_end_seen = s_h[H_N_END];
     C.cs = s_h[H_N_COMMIT];
@@ -711,14 +852,18 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
     else if (C.vis < C.n_end_seen) C.vis_off = Md.dir_off[(uint32_t)C.vis & E.dir_mask];
     uint64_t settled = ~0ull, cs_pub = C.cs, sd_pub = C.slots_done;
     uint64_t patience = 0;
+    uint64_t st_pass = 0, st_prog = 0;
+    const uint64_t st_t0 = wall_clock64();
     for (;;) {
         C.progress = false;
+        st_pass++;
         const uint64_t prog = s_m[M_PROG];
         const uint64_t tail = s_m[M_TAIL], fin = s_m[M_FINAL];
-        if (nf <= 2) rep_commit_pass<2, 8>(E, LS, C, tail, ackb, cap, members, quorum);
-        else if (nf <= 4) rep_commit_pass<4, 4>(E, LS, C, tail, ackb, cap, members, quorum);
-        else if (nf <= 6) rep_commit_pass<6, 2>(E, LS, C, tail, ackb, cap, members, quorum);
-        else rep_commit_pass<12, 1>(E, LS, C, tail, ackb, cap, members, quorum);
+        if (C.cs < C.pre_end) rep_commit_pre(E, C, ackb, cap, members, quorum);
+        if (nf <= 2) rep_commit_pass<2>(E, A, LS, C, tail, mybox, members, quorum);
+        else if (nf <= 4) rep_commit_pass<4>(E, A, LS, C, tail, mybox, members, quorum);
+        else if (nf <= 6) rep_commit_pass<6>(E, A, LS, C, tail, mybox, members, quorum);
+        else rep_commit_pass<12>(E, A, LS, C, tail, mybox, members, quorum);
         if (lane == 0) { s_m[M_T_DONE] = C.t_done; s_m[M_CS] = C.cs; }      /* (the applier reads M_CS first) */
         if (C.slots_done != sd_pub) { sd_pub = C.slots_done; if (lane == 0) st_sys(&H->slots_done, C.slots_done + s_m[M_DROPPED]); }
         if (C.cs > cs_pub) {
@@ -735,10 +880,10 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
             /* nothing more will be appended; ACKs may still be on their way -- unless no majority can answer */
             if (!can || ++patience > A.peer_polls) { if (can && lane == 0) spin_timeout(E, 7201); break; }
         } else if (fin != ~0ull && ++patience > 64 * A.peer_polls) { if (lane == 0) spin_timeout(E, 7202); break; }
-        if (!C.progress) __builtin_amdgcn_s_sleep(1);
+        if (!C.progress) __builtin_amdgcn_s_sleep(1); else st_prog++;
     }
     /* the applier takes what is committed, then the control words go back */
-    if (lane == 0) s_m[M_C_FINAL] = 1;
+    if (lane == 0) { s_m[M_C_FINAL] = 1; LS->stat[1][0] = st_pass; LS->stat[1][1] = st_prog; LS->stat[1][2] = C.t_done; LS->stat[1][3] = wall_clock64() - st_t0; }
     for (uint64_t i = 0; !s_m[M_A_FINAL]; i++) {
         if (i > 64 * A.peer_polls) { if (lane == 0) spin_timeout(E, 7203); break; }
         __builtin_amdgcn_s_sleep(2);
@@ -785,7 +930,10 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, vol
     uint64_t t_app = 0, n_apply = s_h[H_N_APPLY], hash = 0, ncl = 0;
     const uint64_t hr0 = s_h[H_HIGHEST_REC];
     uint32_t lat_n = 0;
+    uint64_t st_pass = 0, st_prog = 0;
+    const uint64_t st_t0 = wall_clock64();
     for (;;) {
+        st_pass++;
         const uint64_t cfin = s_m[M_C_FINAL];
         const uint64_t cs = s_m[M_CS], t_done = s_m[M_T_DONE];
         bool progress = false;
@@ -829,10 +977,11 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, vol
             }
         }
         if (cfin && !progress) break;                    /* (M_C_FINAL was read before M_CS / M_T_DONE: they were final) */
-        if (!progress) __builtin_amdgcn_s_sleep(1);
+        if (!progress) __builtin_amdgcn_s_sleep(1); else st_prog++;
     }
     if (lane == 0) {
         LS->lat_n = lat_n;
+        LS->stat[2][0] = st_pass; LS->stat[2][1] = st_prog; LS->stat[2][2] = t_app; LS->stat[2][3] = wall_clock64() - st_t0;
         s_m[M_A_HASH] = hash; s_m[M_A_NCL] = ncl;
         s_m[M_A_FINAL] = 1;
     }
@@ -857,20 +1006,19 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
     const uint64_t L = E.log_len;
     const uint64_t term = Md.hdr[H_SID] >> 9;
     for (uint64_t k = g;; k += G) {
-        /* ---- wait for ticket k ---- */
-        uint32_t go = 0;
-        if (lane == 0) {
-            for (uint64_t i = 0;; i++) {
-                const uint64_t pub = ld_agent(&LS->pub), fin = ld_agent(&LS->seq_final);
-                if ((int32_t)((uint32_t)pub - (uint32_t)k) > 0) { go = 1; break; }
-                if (fin <= k) break;
-                rep_nap(i < 256);
-            }
-        }
-        go = (uint32_t)__shfl((int)go, 0, WAVE);
-        if (!go) return;
+        /* ---- wait for ticket k: its eight words carry its tag ---- */
         const RepTicket &tkt = LS->tk[k % RS_CAP];
-        const uint64_t wv = lane < 8 ? ld_agent(&tkt.w[lane]) : 0;
+        uint64_t wv = 0;
+        bool go = false;
+        for (uint64_t i = 0;; i++) {
+            if (lane < 8) wv = ld_agent(&tkt.w[lane]);
+            const uint64_t fin = ld_agent(&LS->seq_final);
+            if (__ballot(lane < 8 && rep_tk_ok(wv, k)) == 0xFFull) { go = true; break; }
+            if (fin <= k) break;
+            rep_nap(i < 256);
+        }
+        if (!go) return;
+        wv &= TK_VAL;
         const uint64_t e0 = rl64u(wv, TK_E0), idx0 = rl64u(wv, TK_IDX0), slot0 = rl64u(wv, TK_SLOT0), first = rl64u(wv, TK_SRC);
         const uint64_t end_after = rl64u(wv, TK_END), d0 = rl64u(wv, TK_D0), d1 = rl64u(wv, TK_D1), meta = rl64u(wv, TK_META);
         const uint32_t n = (uint32_t)(meta & 0xFF), kind = (uint32_t)(meta >> 8) & 0xF, ctype = (uint32_t)(meta >> 16) & 0xFF;
@@ -916,6 +1064,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         const bool uniform = !__ballot(active && T != T0);
         uint64_t mix = 0;
         uint32_t client = 0;
+        uint4 ar0 = make_uint4(0, 0, 0, 0), ar1 = ar0;
         if (active) {
             const uint64_t slot = slot0 + lane;
             const uint32_t di = (uint32_t)slot & E.dir_mask;
@@ -924,11 +1073,10 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             /* the leader's apply record (apply_committed_entries, dare_server.c:1941-1955): written with the
              * entry, counted by the applier once the entry's round is committed */
             client = (type != APUS_NOOP && type != APUS_CONFIG && type != APUS_HEAD);
-            uint4 *rp = (uint4 *)&Md.apply[di];
             /* (write-through like everything a run stores: one run laps the apply ring, and two XCDs' dirty copies of
              * one line could be written back in either order) */
-            st16_agent((uint8_t *)rp, make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32)));
-            st16_agent((uint8_t *)(rp + 1), make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), T - APUS_HDR, (uint32_t)d.clt_id | (type << 16) | (client << 24)));
+            ar0 = make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32));
+            ar1 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), T - APUS_HDR, (uint32_t)d.clt_id | (type << 16) | (client << 24));
             if (client) mix = apus_apply_mix(slot, pos, idx, T - APUS_HDR, d.clt_id, (uint8_t)type, 1);
             if (pl.stale && (int)lane == pl.kstar) {
                 /* case 2 of the wrap: the header stays where it did fit (dare_log.h:521-538) */
@@ -943,6 +1091,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                 __hip_atomic_store(&E.box[f]->lens[(A.qbase[f] + k) % RB_CAP][lane], (uint16_t)d.len, RLX_SYSTEM);
             }
         }
+        rep_store_rows32(ar0, ar1, n, [&](uint32_t r) { return (uint8_t *)&Md.apply[(uint32_t)(slot0 + r) & E.dir_mask]; });
         const uint64_t hsum = wave_sum(mix);
         const uint32_t nclient = wave_sum(client);
         {
@@ -989,9 +1138,9 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         /* ---- the bytes are in every pushed ring.  R2: the round's doorbell in every pushed follower's mailbox;
          *      the round's done granules for the committer and the applier -- one batch of stores, no second drain ---- */
         const uint32_t t_now = (uint32_t)wall_clock64();
-        if (lane < 4) {
+        if (lane < 8) {
             const uint32_t val = lane == 0 ? (uint32_t)end_after : lane == 1 ? (uint32_t)(slot0 + n) : lane == 2 ? (uint32_t)e0
-                                                                                             : ((n << 17) | (uniform ? T0 : 0u));
+                                                                             : lane == 3 ? ((n << 17) | (uniform ? T0 : 0u)) : 0u;
             for (uint32_t m = push; m; m &= m - 1) {
                 const uint32_t f = (uint32_t)__builtin_ctz(m);
                 const uint64_t q = A.qbase[f] + k;
@@ -1059,6 +1208,8 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
         uint64_t mix = 0;
         uint32_t head_val = 0xFFFFFFFFu;
         uint32_t client = 0;
+        uint4 ar0 = make_uint4(0, 0, 0, 0), ar1 = ar0;
+        bool acked = false;
         if (active) {
             ld32_sys(Md.ring + pos, u0, u1);
             const uint64_t idx = (uint64_t)u0.x | ((uint64_t)u0.y << 32);
@@ -1073,17 +1224,20 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
             if (sender == leader && sender < APUS_DEV_MAX_SERVERS && E.rep[sender].ring && (my_sid >> 9) <= (uint64_t)u0.z + ((uint64_t)u0.w << 32)) {
                 st_sys8(E.ackb[sender] + (uint64_t)me * cap + di, rep_ack_tag(slot, E.dir_mask));
                 st_sys8(E.rep[sender].ring + pos + 28 + me, 1);
+                acked = true;
             }
             st_sys8(Md.ring + pos + 28 + me, 1);
             st_agent(&Md.dir_off[di], pos);
             __hip_atomic_store(&Md.dir_len[di], T | (sender << 24), RLX_AGENT);
             client = (type != APUS_NOOP && type != APUS_CONFIG && type != APUS_HEAD);
-            uint4 *rp = (uint4 *)&Md.apply[di];
-            st16_agent((uint8_t *)rp, make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32)));
-            st16_agent((uint8_t *)(rp + 1), make_uint4(u0.x, u0.y, T - APUS_HDR, (uint32_t)clt | (type << 16) | ((client ? 2u : 0u) << 24)));
+            ar0 = make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32));
+            ar1 = make_uint4(u0.x, u0.y, T - APUS_HDR, (uint32_t)clt | (type << 16) | ((client ? 2u : 0u) << 24));
             if (client) mix = apus_apply_mix(slot, pos, idx, T - APUS_HDR, clt, (uint8_t)type, 2);
             if (type == APUS_HEAD) { uint4 x0, x1; ld32_sys(Md.ring + pos + 32, x0, x1); head_val = x1.x; }
         }
+        /* ... and the round's ACK granule in the sender's mailbox once every entry of the round is acknowledged */
+        if (!__ballot(active && !acked) && lane == 0) st_sys(&E.box[leader]->rack[me][q % RB_CAP], rep_gran(q, n));
+        rep_store_rows32(ar0, ar1, n, [&](uint32_t r) { return (uint8_t *)&Md.apply[(uint32_t)(slot0 + r) & E.dir_mask]; });
         const uint64_t hsum = wave_sum(mix);
         const uint32_t nclient = wave_sum(client);
         head_val = (uint32_t)__shfl((int)head_val, 0, WAVE);    /* (a <HEAD> entry is a round of its own) */
@@ -1132,8 +1286,11 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
     uint64_t idle = 0;
     uint32_t exit_code = R_EXIT_STOP;
     uint64_t final_q = ~0ull;
+    uint64_t st_pass = 0, st_prog = 0;
+    const uint64_t st_t0 = wall_clock64();
     for (;;) {
         bool progress = false;
+        st_pass++;
         const uint64_t ctrl = ld_sys(&box->ctrl);
         uint64_t f0[R_SUB], f1[R_SUB], f2[R_SUB], f3[R_SUB];
 #pragma unroll
@@ -1181,7 +1338,7 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
         }
         /* ---- park? ---- */
         if (final_q != ~0ull && q_ret >= final_q) break;      /* everything that was sent is persisted */
-        if (progress) idle = 0;
+        if (progress) { idle = 0; st_prog++; }
         else {
             if (++idle > A.idle_polls) { exit_code = R_EXIT_IDLE; break; }
             rep_nap(idle < 64);
@@ -1189,6 +1346,7 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
     }
     if (lane == 0) {
         s_f[F_END] = end; s_f[F_N_END] = n_end; s_f[F_Q_RET] = q_ret;
+        FS->stat[0][0] = st_pass; FS->stat[0][1] = st_prog; FS->stat[0][2] = q_ret - q0; FS->stat[0][3] = wall_clock64() - st_t0;
         s_f[F_STORE_COUNT] = store_count; s_f[F_PEND_N] = pend_n; s_f[F_PEND_SLOT_END] = pend_slot_end; s_f[F_EXIT] = exit_code;
         s_f[F_R_FINAL] = 1;
     }
@@ -1215,8 +1373,11 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
     if (lane == 0) { st_sys(&lbox->seqdone_by[me], q_app); st_sys(&lbox->applied_by[me], n_apply); st_sys(&lbox->apply_off_by[me], a_off0); }
     uint64_t idle_fin = 0;
     uint64_t end = 0, n_end = 0, q_ret = q0;
+    uint64_t st_pass = 0, st_prog = 0;
+    const uint64_t st_t0 = wall_clock64();
     for (;;) {
         bool progress = false;
+        st_pass++;
         const uint64_t rfin = s_f[F_R_FINAL];
         q_ret = s_f[F_Q_RET]; n_end = s_f[F_N_END]; end = s_f[F_END];
         uint64_t cs = ld_sys(&box->commit_bell);
@@ -1262,8 +1423,9 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
             if (!progress && (q_app == q_ret || ld_sys(&box->commit_bell) <= n_apply || idle_fin > 4)) break;
             if (!progress) idle_fin++;
         }
-        if (!progress) rep_nap(true);
+        if (!progress) rep_nap(true); else st_prog++;
     }
+    if (lane == 0) { FS->stat[1][0] = st_pass; FS->stat[1][1] = st_prog; FS->stat[1][2] = q_app - q0; FS->stat[1][3] = wall_clock64() - st_t0; }
     /* (F_R_FINAL was read before F_Q_RET / F_N_END / F_END in the last pass: they were final) */
     const uint32_t exit_code = (uint32_t)s_f[F_EXIT];
     const uint64_t c_off = n_commit == n_commit0 ? c_off0 : (n_commit == n_end ? end : ld_agent(&Md.dir_off[(uint32_t)n_commit & E.dir_mask]));

@@ -412,6 +412,14 @@ class Engine:
                                            prune_every_reqs, out), "rep_feed")
         return int(out[0]), out[1] / 1e9
 
+    def rep_role_stats(self) -> dict:
+        """diagnostics of the last run: per serial role passes, passes that moved something, rounds, microseconds"""
+        out = np.zeros((16, 8), dtype=np.uint64)
+        self._chk(self.L.apus_gpu_rep_role_stats(self.h, out.ctypes.data), "rep_role_stats")
+        names = ["sequencer", "committer", "applier"] + [f"f{i}_{w}" for i in range(6) for w in ("retire", "apply")]
+        return {nm: {"passes": int(r[0]), "moved": int(r[1]), "rounds": int(r[2]), "us": int(r[3]) / 100.0, "x": int(r[4])}
+                for nm, r in zip(names, out) if r[0]}
+
     def rep_roundtrip_ns(self, reqs: np.ndarray, arena: np.ndarray, iters: int) -> np.ndarray:
         reqs = np.ascontiguousarray(reqs, dtype=REQ_DTYPE)
         out = np.zeros(iters, dtype=np.uint32)

@@ -59,6 +59,7 @@ def staged(n_rep, entries, payload, batch, steps, n_append, n_fwork, warmup=1):
         code = eng.rep_park()
         lat = eng.rep_latency_ns()
         lat_a = eng.rep_latency_appended_ns()
+        roles = eng.rep_role_stats()
         eng.quiesce()
         total = (warmup + steps) * len(tr.reqs)
         ok = eng.status() == 0 and code == 0
@@ -70,7 +71,7 @@ def staged(n_rep, entries, payload, batch, steps, n_append, n_fwork, warmup=1):
                 "entries_per_s": len(tr.reqs) * steps / dt, "ms_per_step": dt / steps * 1e3, "verified": bool(ok),
                 "exit": code, "status": eng.status_names(), "stats": st,
                 "lat_us_p50": float(np.percentile(lat, 50)) / 1e3 if len(lat) else None,
-                "lat_appended_us_p50": float(np.percentile(lat_a, 50)) / 1e3 if len(lat_a) else None}
+                "lat_appended_us_p50": float(np.percentile(lat_a, 50)) / 1e3 if len(lat_a) else None, "roles": roles}
     finally:
         eng.close()
 
