@@ -2164,6 +2164,7 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
     A.idle_polls = (uint64_t)idle_ms * 1000ull;
     A.peer_polls = (uint64_t)peer_ms * 1000ull;
     A.lead_here = lead_here ? 1u : 0u;
+    { const char *dbg = getenv("APUS_REP_DBG"); A.dbg = dbg ? (uint32_t)atoi(dbg) : 0u; }
     if (lead_here) {
         if (!e->rh) {
             HIPCHK(hipHostMalloc((void **)&e->rh, sizeof(RepHost), hipHostMallocMapped | hipHostMallocCoherent));
@@ -2391,6 +2392,7 @@ extern "C" int apus_gpu_rep_role_stats(apus_engine_t *e, uint64_t out[16][8])
     if (!e || e->r_running || !out) return APUS_E_STATE;
     memset(out, 0, sizeof(uint64_t) * 16 * 8);
     if (e->rl) HIPCHK(hipMemcpy(out, e->rl->stat, sizeof(uint64_t) * 3 * 8, hipMemcpyDeviceToHost));
+    if (e->rl) HIPCHK(hipMemcpy(out[15], e->rl->stat[3], sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
     int k = 0;
     for (uint32_t m = e->r_follow_mask; m && k < 6; m &= m - 1, k++) {
         RepFollow *fs = e->rfs[__builtin_ctz(m)];

@@ -49,8 +49,8 @@
 #pragma once
 #include "apus_persistent.h"
 
-#define RB_CAP    2048u          /* round doorbells in flight per follower                    */
-#define RS_CAP    4096u          /* leader: tickets in flight                                 */
+#define RB_CAP    8192u          /* round doorbells in flight per follower                    */
+#define RS_CAP    16384u         /* leader: tickets in flight                                 */
 #define RQ_CAP    (1u << 16)     /* pinned request slots                                      */
 #define RA_CAP    (64u << 20)    /* pinned payload arena (bytes)                              */
 #define RC_CAP    256u           /* host command ring                                         */
@@ -179,6 +179,7 @@ struct RepArgs {
     uint64_t fruns[APUS_DEV_MAX_SERVERS];/* leader: every follower's f_runs when this run began       */
     uint64_t idle_polls, peer_polls;
     uint64_t qbase[APUS_DEV_MAX_SERVERS];
+    uint32_t dbg, pad_dbg;               /* measurements only (APUS_REP_DBG): 1 no reply bytes, 2 no follower directory / apply records, 4 no push */
 };
 
 /* a short nap between two polls while work is expected, a longer one once the poller has been idle */
@@ -202,6 +203,48 @@ __device__ static inline void ld32_sys(const uint8_t *p, uint4 &a, uint4 &b)
     asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(d0), "=&v"(d1) : "v"(p) : "memory");
     a = make_uint4(d0.x, d0.y, d0.z, d0.w); b = make_uint4(d1.x, d1.y, d1.z, d1.w);
+}
+/* payload_unit() in two halves: the load (issued for every lane, never inside a divergent branch -- a load in a
+ * branch is waited for where the branch ends, one memory round trip per unit) and the masking of what came back.
+ * 16 bytes [so, so+16) of the byte stream of a client entry, so >= 48: [48,50) cmd.len, [50,50+P) payload, rest 0. */
+__device__ static inline uint4 payload_mask(uint4 v, uint32_t so, uint32_t P, uint32_t len16)
+{
+    uint64_t lo = 0, hi = 0;
+    if (P != 0) {
+        lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        const int vb = so < 50 ? (int)(50 - so) : 0;
+        const int ve = (int)min(16u, 50u + P - so);
+        lo &= byte_mask64(vb, ve);
+        hi &= byte_mask64(vb - 8, ve - 8);
+    }
+    if (so == 48)      lo |= (uint64_t)(len16 & 0xFFFFu);
+    else if (so == 49) lo |= (uint64_t)((len16 >> 8) & 0xFFu);
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+/* 16 bytes, dword aligned, written through (system scope): st16_agent without its byte-wise path for unaligned addresses */
+__device__ static inline void st16_wt(uint8_t *p, uint4 v)
+{
+    v4u_t d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(d) : "memory");
+}
+/* 16 bytes written through to the device's memory (agent scope: sc1) */
+__device__ static inline void st16_dev(uint8_t *p, uint4 v)
+{
+    v4u_t d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(d) : "memory");
+}
+__device__ static inline void ld32_dev(const uint8_t *p, uint4 &a, uint4 &b)
+{
+    v4u_t d0, d1;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(d0), "=&v"(d1) : "v"(p) : "memory");
+    a = make_uint4(d0.x, d0.y, d0.z, d0.w); b = make_uint4(d1.x, d1.y, d1.z, d1.w);
+}
+/* lane l's 64-bit value as a scalar (l wave-uniform): v_readlane, no trip through the LDS crossbar */
+__device__ static inline uint64_t rdl64(uint64_t v, int l)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
 }
 __device__ static inline uint64_t rl64u(uint64_t v, int l)
 {
@@ -228,7 +271,7 @@ __device__ static inline void rep_store_rows64(const uint64_t (&w)[8], uint32_t 
             const uint64_t a = rl64u(w[2 * c], src), b = rl64u(w[2 * c + 1], src);
             if ((uint32_t)c == q) { lo = a; hi = b; }
         }
-        if ((uint32_t)src < nrows) st16_agent(row_addr((uint32_t)src) + q * 16, make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)));
+        if ((uint32_t)src < nrows) st16_wt(row_addr((uint32_t)src) + q * 16, make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)));
     }
 }
 /* 32-byte rows: (a, b) of row r in lane r */
@@ -240,7 +283,7 @@ __device__ static inline void rep_store_rows32(uint4 a, uint4 b, uint32_t nrows,
     for (int j = 0; j < 2; j++) {
         const int src = j * 32 + (int)(lane >> 1);
         const uint4 va = rl128(a, src), vb = rl128(b, src);
-        if ((uint32_t)src < nrows) st16_agent(row_addr((uint32_t)src) + h * 16, h ? vb : va);
+        if ((uint32_t)src < nrows) st16_wt(row_addr((uint32_t)src) + h * 16, h ? vb : va);
     }
 }
 
@@ -441,7 +484,8 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
     uint64_t idle = 0, budget = 0, dropped = 0;
     uint32_t exit_code = R_EXIT_STOP;
     if (lane == 0) st_sys(&H->alive, 1);
-    uint64_t st_pass = 0, st_staged = 0, st_flow = 0;
+    const uint64_t my_qbase = (lane >= 1 && lane <= APUS_DEV_MAX_SERVERS) ? A.qbase[lane - 1] : 0;    /* (lane f + 1 looks after follower f) */
+    uint64_t st_pass = 0, st_staged = 0, st_flow = 0, st_busy = 0;
     const uint64_t st_t0 = wall_clock64();
 
     for (;;) {
@@ -456,7 +500,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                     const uint64_t inflight = S.t - s_m[M_T_RETIRED];
                     room = inflight + R_SLACK >= RS_CAP ? 0 : RS_CAP - R_SLACK - inflight;
                 } else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) {
-                    const uint64_t inflight = A.qbase[lane - 1] + S.t - ld_sys(&mybox->seqdone_by[lane - 1]);
+                    const uint64_t inflight = my_qbase + S.t - ld_sys(&mybox->seqdone_by[lane - 1]);
                     room = inflight + R_SLACK >= RB_CAP ? 0 : RB_CAP - R_SLACK - inflight;
                 }
                 const unsigned long long tight = __ballot(room < WAVE);
@@ -481,6 +525,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
             bool out = false;
             while (run_next < run_end) {
                 const uint64_t rc = run_next;
+                const uint64_t st_p0 = wall_clock64();
                 st_staged++;
                 const uint32_t want = (uint32_t)min((uint64_t)(WAVE * R_SUB), run_end - rc);
                 uint64_t pf0[R_SUB], pf1[R_SUB];
@@ -498,13 +543,14 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                     const uint64_t inflight = S.t - s_m[M_T_RETIRED];
                     room = inflight + R_SLACK >= RS_CAP ? 0 : RS_CAP - R_SLACK - inflight;
                 } else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) {
-                    const uint64_t inflight = A.qbase[lane - 1] + S.t - ld_sys(&mybox->seqdone_by[lane - 1]);
+                    const uint64_t inflight = my_qbase + S.t - ld_sys(&mybox->seqdone_by[lane - 1]);
                     room = inflight + R_SLACK >= RB_CAP ? 0 : RB_CAP - R_SLACK - inflight;
                 }
                 /* (and the next host command, if it is there: its PCIe round trip runs under this pass) */
                 const uint64_t next_cmd = cmd_head + 1;               /* (cmd_head is the RUN in progress) */
                 uint64_t cg = 0;
-                if (!have_cmd && lane < 4) cg = ld_sys(&H->cmd[next_cmd % RC_CAP].g[lane]);
+                const bool peek = !have_cmd && run_end - rc <= 2 * WAVE * R_SUB;      /* (only near the end of the run) */
+                if (peek && lane < 4) cg = ld_sys(&H->cmd[next_cmd % RC_CAP].g[lane]);
                 const unsigned long long tight = __ballot(room < WAVE);
                 if (tight) {
                     if (++spins > A.peer_polls) {
@@ -569,7 +615,8 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                 run_next += taken;
                 if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); }
                 rep_seq_publish(LS, s_m, S, cmd_head + req_head);
-                if (!have_cmd && __ballot(lane < 4 && rep_gran_ok(cg, next_cmd)) == 0xFull) {
+                st_busy += wall_clock64() - st_p0;
+                if (peek && __ballot(lane < 4 && rep_gran_ok(cg, next_cmd)) == 0xFull) {
                     have_cmd = true;
                     cmd_op = (uint32_t)rl64u(cg, 0); cmd_after = rep_extend(req_head, (uint32_t)rl64u(cg, 1));
                     cmd_a = (uint32_t)rl64u(cg, 2); cmd_b = (uint32_t)rl64u(cg, 3);
@@ -643,7 +690,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
     if (lane == 0) {
         st_agent(&LS->seq_final, S.t);
         s_m[M_FINAL] = S.t;
-        LS->stat[0][0] = st_pass; LS->stat[0][1] = st_staged; LS->stat[0][2] = S.t; LS->stat[0][3] = wall_clock64() - st_t0; LS->stat[0][4] = st_flow;
+        LS->stat[0][0] = st_pass; LS->stat[0][1] = st_staged; LS->stat[0][2] = S.t; LS->stat[0][3] = wall_clock64() - st_t0; LS->stat[0][4] = st_flow; LS->stat[0][5] = st_busy;
         /* the leader's append-side words (log_append_entry's bookkeeping, persist_new_entries' own part) */
         uint64_t *mh = E.rep[E.leader].hdr;
         mh[H_END] = S.end; mh[H_TAIL] = S.tail; mh[H_LAST_IDX] = S.last_idx; mh[H_N_END] = S.n_end; mh[H_HEAD] = S.head;
@@ -852,11 +899,12 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
     else if (C.vis < C.n_end_seen) C.vis_off = Md.dir_off[(uint32_t)C.vis & E.dir_mask];
     uint64_t settled = ~0ull, cs_pub = C.cs, sd_pub = C.slots_done;
     uint64_t patience = 0;
-    uint64_t st_pass = 0, st_prog = 0;
+    uint64_t st_pass = 0, st_prog = 0, st_busy = 0;
     const uint64_t st_t0 = wall_clock64();
     for (;;) {
         C.progress = false;
         st_pass++;
+        const uint64_t st_p0 = wall_clock64();
         const uint64_t prog = s_m[M_PROG];
         const uint64_t tail = s_m[M_TAIL], fin = s_m[M_FINAL];
         if (C.cs < C.pre_end) rep_commit_pre(E, C, ackb, cap, members, quorum);
@@ -880,10 +928,10 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
             /* nothing more will be appended; ACKs may still be on their way -- unless no majority can answer */
             if (!can || ++patience > A.peer_polls) { if (can && lane == 0) spin_timeout(E, 7201); break; }
         } else if (fin != ~0ull && ++patience > 64 * A.peer_polls) { if (lane == 0) spin_timeout(E, 7202); break; }
-        if (!C.progress) __builtin_amdgcn_s_sleep(1); else st_prog++;
+        if (!C.progress) __builtin_amdgcn_s_sleep(1); else { st_prog++; st_busy += wall_clock64() - st_p0; }
     }
     /* the applier takes what is committed, then the control words go back */
-    if (lane == 0) { s_m[M_C_FINAL] = 1; LS->stat[1][0] = st_pass; LS->stat[1][1] = st_prog; LS->stat[1][2] = C.t_done; LS->stat[1][3] = wall_clock64() - st_t0; }
+    if (lane == 0) { s_m[M_C_FINAL] = 1; LS->stat[1][0] = st_pass; LS->stat[1][1] = st_prog; LS->stat[1][2] = C.t_done; LS->stat[1][3] = wall_clock64() - st_t0; LS->stat[1][5] = st_busy; }
     for (uint64_t i = 0; !s_m[M_A_FINAL]; i++) {
         if (i > 64 * A.peer_polls) { if (lane == 0) spin_timeout(E, 7203); break; }
         __builtin_amdgcn_s_sleep(2);
@@ -930,10 +978,11 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, vol
     uint64_t t_app = 0, n_apply = s_h[H_N_APPLY], hash = 0, ncl = 0;
     const uint64_t hr0 = s_h[H_HIGHEST_REC];
     uint32_t lat_n = 0;
-    uint64_t st_pass = 0, st_prog = 0;
+    uint64_t st_pass = 0, st_prog = 0, st_busy = 0;
     const uint64_t st_t0 = wall_clock64();
     for (;;) {
         st_pass++;
+        const uint64_t st_p0 = wall_clock64();
         const uint64_t cfin = s_m[M_C_FINAL];
         const uint64_t cs = s_m[M_CS], t_done = s_m[M_T_DONE];
         bool progress = false;
@@ -977,16 +1026,24 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, vol
             }
         }
         if (cfin && !progress) break;                    /* (M_C_FINAL was read before M_CS / M_T_DONE: they were final) */
-        if (!progress) __builtin_amdgcn_s_sleep(1); else st_prog++;
+        if (!progress) __builtin_amdgcn_s_sleep(1); else { st_prog++; st_busy += wall_clock64() - st_p0; }
     }
     if (lane == 0) {
         LS->lat_n = lat_n;
+        LS->stat[2][5] = st_busy;
         LS->stat[2][0] = st_pass; LS->stat[2][1] = st_prog; LS->stat[2][2] = t_app; LS->stat[2][3] = wall_clock64() - st_t0;
         s_m[M_A_HASH] = hash; s_m[M_A_NCL] = ncl;
         s_m[M_A_FINAL] = 1;
     }
 }
 
+/* what the append wavefronts need of the engine descriptor, by group index, in LDS: an index that is not a
+ * compile-time constant into the kernel's argument block is a global load (and a wait for every store in front of it) */
+struct RepPtrLds {
+    uint8_t *ring[APUS_DEV_MAX_SERVERS];
+    RepBox  *box[APUS_DEV_MAX_SERVERS];
+    uint64_t qbase[APUS_DEV_MAX_SERVERS];
+};
 struct RepAppLds {
     uint64_t pos[WAVE];
     uint64_t src[WAVE];
@@ -997,7 +1054,7 @@ struct RepAppLds {
 };
 
 /* one append wavefront: ticket k, k + G, ... */
-__device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A, RepAppLds &lds, uint32_t g, uint32_t G)
+__device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A, RepAppLds &lds, const RepPtrLds &PT, uint32_t g, uint32_t G)
 {
     RepHost *H = A.H;
     RepLead *LS = A.LS;
@@ -1005,6 +1062,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
     const RepDev &Md = E.rep[me];
     const uint64_t L = E.log_len;
     const uint64_t term = Md.hdr[H_SID] >> 9;
+    uint64_t a_rounds = 0, a_total = 0, a_drain = 0, a_desc = 0, a_pay = 0, a_pre = 0, a_it1 = 0;
     for (uint64_t k = g;; k += G) {
         /* ---- wait for ticket k: its eight words carry its tag ---- */
         const RepTicket &tkt = LS->tk[k % RS_CAP];
@@ -1012,19 +1070,31 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         bool go = false;
         for (uint64_t i = 0;; i++) {
             if (lane < 8) wv = ld_agent(&tkt.w[lane]);
-            const uint64_t fin = ld_agent(&LS->seq_final);
             if (__ballot(lane < 8 && rep_tk_ok(wv, k)) == 0xFFull) { go = true; break; }
-            if (fin <= k) break;
+            if ((i & 7) == 7 && ld_agent(&LS->seq_final) <= k) break;      /* (one word for everybody: looked at now and then) */
             rep_nap(i < 256);
         }
-        if (!go) return;
+        if (!go) {
+            if (lane == 0 && a_rounds) {
+                atomicAdd((unsigned long long *)&LS->stat[3][0], (unsigned long long)a_rounds);
+                atomicAdd((unsigned long long *)&LS->stat[3][1], (unsigned long long)a_total);
+                atomicAdd((unsigned long long *)&LS->stat[3][2], (unsigned long long)a_drain);
+                atomicAdd((unsigned long long *)&LS->stat[3][3], (unsigned long long)a_desc);
+                atomicAdd((unsigned long long *)&LS->stat[3][4], (unsigned long long)a_pay);
+                atomicAdd((unsigned long long *)&LS->stat[3][5], (unsigned long long)a_pre);
+                atomicAdd((unsigned long long *)&LS->stat[3][6], (unsigned long long)a_it1);
+            }
+            return;
+        }
+        const bool timed = A.dbg & 256;
+        const uint64_t t_seen = timed ? wall_clock64() : 0;
         wv &= TK_VAL;
-        const uint64_t e0 = rl64u(wv, TK_E0), idx0 = rl64u(wv, TK_IDX0), slot0 = rl64u(wv, TK_SLOT0), first = rl64u(wv, TK_SRC);
-        const uint64_t end_after = rl64u(wv, TK_END), d0 = rl64u(wv, TK_D0), d1 = rl64u(wv, TK_D1), meta = rl64u(wv, TK_META);
+        const uint64_t e0 = rdl64(wv, TK_E0), idx0 = rdl64(wv, TK_IDX0), slot0 = rdl64(wv, TK_SLOT0), first = rdl64(wv, TK_SRC);
+        const uint64_t end_after = rdl64(wv, TK_END), d0 = rdl64(wv, TK_D0), d1 = rdl64(wv, TK_D1), meta = rdl64(wv, TK_META);
         const uint32_t n = (uint32_t)(meta & 0xFF), kind = (uint32_t)(meta >> 8) & 0xF, ctype = (uint32_t)(meta >> 16) & 0xFF;
         const uint32_t hidden = (uint32_t)(meta >> 12) & 1u;
         const uint32_t push = (uint32_t)(meta >> 32) & 0xFFFF;
-        const uint32_t rings = push | (1u << me);
+        const uint32_t rings = ((A.dbg & 4) ? 0u : push) | (1u << me);
         const bool active = lane < n;
         /* ---- get_tailq_message: the requests of the round ---- */
         ReqDev d; d.req_id = 0; d.pay16_type = 0; d.len = 0; d.clt_id = 0;
@@ -1046,6 +1116,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         }
         const uint32_t T = active ? APUS_HDR + d.len : 0;
         const RepPlace pl = rep_place(e0, L, T, n);
+        const uint64_t t_desc = timed ? wall_clock64() : 0;
         const uint64_t pos = rep_pos(pl, (int)lane);
         const uint64_t idx = rep_idx(pl, (int)lane, idx0);
         const uint32_t type = d.pay16_type >> 28;
@@ -1082,13 +1153,13 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                 /* case 2 of the wrap: the header stays where it did fit (dare_log.h:521-538) */
                 const uint4 z = make_uint4(0, 0, 0, 0), l4 = make_uint4((uint32_t)d.len, 0, 0, 0);
                 for (uint32_t m = rings; m; m &= m - 1) {
-                    uint8_t *rg = E.rep[__builtin_ctz(m)].ring;
+                    uint8_t *rg = PT.ring[__builtin_ctz(m)];
                     st16_agent(rg + pl.a, h0); st16_agent(rg + pl.a + 16, h1); st16_agent(rg + pl.a + 32, z); st16_agent(rg + pl.a + 48, l4);
                 }
             }
             if (!uniform) for (uint32_t m = push; m; m &= m - 1) {
                 const uint32_t f = (uint32_t)__builtin_ctz(m);
-                __hip_atomic_store(&E.box[f]->lens[(A.qbase[f] + k) % RB_CAP][lane], (uint16_t)d.len, RLX_SYSTEM);
+                __hip_atomic_store(&PT.box[f]->lens[(PT.qbase[f] + k) % RB_CAP][lane], (uint16_t)d.len, RLX_SYSTEM);
             }
         }
         rep_store_rows32(ar0, ar1, n, [&](uint32_t r) { return (uint8_t *)&Md.apply[(uint32_t)(slot0 + r) & E.dir_mask]; });
@@ -1104,37 +1175,91 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         }
         /* ---- the round's bytes: own ring + R1 to every pushed follower ---- */
         const uint32_t utotal = lds.ubase[WAVE];
-        constexpr int ILP = 4;
-        for (uint32_t u0 = lane; u0 < utotal; u0 += WAVE * ILP) {
-            uint4 v[ILP];
-            uint64_t p[ILP];
-            bool on[ILP];
+        const uint32_t upe = (T0 + 15) / 16;                       /* 16-byte units per entry when all are the same size */
+        const uint64_t t_loop = timed ? wall_clock64() : 0;
+        uint64_t t_it1 = 0;
+        /* the common shape -- every entry the same multiple of 16 bytes, no wrap inside the round, 16-byte aligned --
+         * is ONE contiguous range of bytes in every ring: unit u goes to e0 + 16 u */
+        const bool straight = uniform && (T0 & 15u) == 0 && pl.kstar < 0 && (e0 & 15ull) == 0;
+        const uint8_t *safe = (const uint8_t *)Md.dir_off;          /* where a lane that needs no payload bytes loads from */
+        if (straight) {
+            constexpr int ILP = 8;
+            const uint32_t P = T0 - APUS_HDR;
+            for (uint32_t u0 = lane; u0 < utotal; u0 += WAVE * ILP) {
+                if (timed && u0 >= WAVE * ILP && !t_it1) t_it1 = wall_clock64();
+                uint4 v[ILP];
+                uint32_t so_[ILP], e_[ILP];
+                /* the payload loads of ALL units of the pass go out together, for every lane, nothing but address arithmetic
+                 * between them: ONE memory round trip per pass */
 #pragma unroll
-            for (int q = 0; q < ILP; q++) {
-                const uint32_t u = u0 + q * WAVE;
-                on[q] = u < utotal;
-                v[q] = make_uint4(0, 0, 0, 0); p[q] = 0;
-                if (!on[q]) continue;
-                uint32_t lo = 0, hi = n - 1;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi + 1) >> 1;
-                    if (lds.ubase[mid] <= u) lo = mid; else hi = mid - 1;
+                for (int q = 0; q < ILP; q++) {
+                    const uint32_t u = u0 + q * WAVE;
+                    const uint32_t e = min(u / upe, n - 1);
+                    e_[q] = e; so_[q] = 16u * (u - e * upe);
+                    const bool need = u < utotal && so_[q] >= 48 && kind != R_SRC_CONTROL && P != 0;
+                    v[q] = ld16u(need ? (const uint8_t *)(uintptr_t)lds.src[e] + so_[q] - 50 : safe);
                 }
-                const uint32_t e = lo, Te = lds.T[e], j = u - lds.ubase[e];
-                const uint32_t so = min(16u * j, Te - 16u);
-                if (so == 0) v[q] = lds.h0[e];
-                else if (so == 16) v[q] = lds.h1[e];
-                else if (so == 32) v[q] = make_uint4(0, 0, 0, 0);
-                else if (kind == R_SRC_CONTROL) v[q] = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
-                else v[q] = payload_unit((const uint8_t *)(uintptr_t)lds.src[e], so, Te - APUS_HDR, Te - APUS_HDR);
-                p[q] = lds.pos[e] + so;
-            }
 #pragma unroll
-            for (int q = 0; q < ILP; q++)
-                if (on[q])
-                    for (uint32_t m = rings; m; m &= m - 1) st16_agent(E.rep[__builtin_ctz(m)].ring + p[q], v[q]);
+                for (int q = 0; q < ILP; q++) {
+                    if (so_[q] == 0) v[q] = lds.h0[e_[q]];
+                    else if (so_[q] == 16) v[q] = lds.h1[e_[q]];
+                    else if (so_[q] == 32) v[q] = make_uint4(0, 0, 0, 0);
+                    else if (kind == R_SRC_CONTROL) v[q] = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
+                    else v[q] = payload_mask(v[q], so_[q], P, P);
+                }
+                for (uint32_t m = rings; m; m &= m - 1) {
+                    uint8_t *rg = PT.ring[__builtin_ctz(m)] + e0;
+#pragma unroll
+                    for (int q = 0; q < ILP; q++) {
+                        const uint32_t u = u0 + q * WAVE;
+                        if (u < utotal) st16_wt(rg + 16ull * u, v[q]);
+                    }
+                }
+            }
+        } else {
+            constexpr int ILP = 4;
+            for (uint32_t u0 = lane; u0 < utotal; u0 += WAVE * ILP) {
+                uint4 v[ILP];
+                uint64_t p[ILP];
+                uint32_t so_[ILP], e_[ILP];
+                bool on[ILP];
+#pragma unroll
+                for (int q = 0; q < ILP; q++) {
+                    const uint32_t u = u0 + q * WAVE;
+                    on[q] = u < utotal;
+                    uint32_t lo = 0, hi = n - 1;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi + 1) >> 1;
+                        if (lds.ubase[mid] <= u) lo = mid; else hi = mid - 1;
+                    }
+                    const uint32_t e = lo, Te = lds.T[e], j = on[q] ? u - lds.ubase[e] : 0;
+                    e_[q] = e;
+                    so_[q] = min(16u * j, Te - 16u);
+                    p[q] = lds.pos[e] + so_[q];
+                    const bool need = on[q] && so_[q] >= 48 && kind != R_SRC_CONTROL && Te != APUS_HDR;
+                    v[q] = ld16u(need ? (const uint8_t *)(uintptr_t)lds.src[e] + so_[q] - 50 : safe);
+                }
+#pragma unroll
+                for (int q = 0; q < ILP; q++) {
+                    if (!on[q]) continue;
+                    const uint32_t Pq = lds.T[e_[q]] - APUS_HDR;
+                    if (so_[q] == 0) v[q] = lds.h0[e_[q]];
+                    else if (so_[q] == 16) v[q] = lds.h1[e_[q]];
+                    else if (so_[q] == 32) v[q] = make_uint4(0, 0, 0, 0);
+                    else if (kind == R_SRC_CONTROL) v[q] = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
+                    else v[q] = payload_mask(v[q], so_[q], Pq, Pq);
+                }
+                for (uint32_t m = rings; m; m &= m - 1) {
+                    uint8_t *rg = PT.ring[__builtin_ctz(m)];
+#pragma unroll
+                    for (int q = 0; q < ILP; q++)
+                        if (on[q]) st16_agent(rg + p[q], v[q]);
+                }
+            }
         }
+        const uint64_t t_stores = timed ? wall_clock64() : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t t_drained = timed ? wall_clock64() : 0;
         /* ---- the bytes are in every pushed ring.  R2: the round's doorbell in every pushed follower's mailbox;
          *      the round's done granules for the committer and the applier -- one batch of stores, no second drain ---- */
         const uint32_t t_now = (uint32_t)wall_clock64();
@@ -1143,8 +1268,8 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                                                                              : lane == 3 ? ((n << 17) | (uniform ? T0 : 0u)) : 0u;
             for (uint32_t m = push; m; m &= m - 1) {
                 const uint32_t f = (uint32_t)__builtin_ctz(m);
-                const uint64_t q = A.qbase[f] + k;
-                st_sys(&E.box[f]->rnd[q % RB_CAP][lane], ((q + 1) << 32) | val);
+                const uint64_t q = PT.qbase[f] + k;
+                st_sys(&PT.box[f]->rnd[q % RB_CAP][lane], ((q + 1) << 32) | val);
             }
         }
         if (lane < 8) {
@@ -1161,6 +1286,9 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             }
             st_agent(&LS->dn[k % RS_CAP][lane], rep_gran(k, val));
         }
+        /* diagnostics: rounds and ticks from "ticket seen" to "done granules issued" */
+        if (timed) { a_rounds++; a_total += wall_clock64() - t_seen; a_drain += t_drained - t_stores; a_desc += t_desc - t_seen; a_pay += t_stores - t_desc;
+        a_pre += t_loop - t_desc; a_it1 += (t_it1 ? t_it1 : t_stores) - t_loop; }
     }
 }
 
@@ -1177,6 +1305,9 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
     const uint64_t n_end0 = Md.hdr[H_N_END], my_sid = Md.hdr[H_SID];
     const uint32_t leader = E.leader;
     const uint64_t cap = (uint64_t)E.dir_mask + 1;
+    uint8_t *const lring = leader < APUS_DEV_MAX_SERVERS ? E.rep[leader].ring : nullptr;     /* (once: the sender's log, ACK map and mailbox) */
+    uint8_t *const lack = leader < APUS_DEV_MAX_SERVERS ? E.ackb[leader] : nullptr;
+    RepBox *const lbox = leader < APUS_DEV_MAX_SERVERS ? E.box[leader] : nullptr;
     for (uint64_t q = q0 + g;; q += G) {
         const uint32_t r = (uint32_t)(q % RB_CAP);
         /* ---- wait for the doorbell of round q ---- */
@@ -1193,7 +1324,7 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
             rep_nap(i < 512);
         }
         if (!go) return;
-        const uint32_t end_after = (uint32_t)rl64u(wv, 0), slot_lo = (uint32_t)rl64u(wv, 1), e0 = (uint32_t)rl64u(wv, 2), w3 = (uint32_t)rl64u(wv, 3);
+        const uint32_t end_after = (uint32_t)rdl64(wv, 0), slot_lo = (uint32_t)rdl64(wv, 1), e0 = (uint32_t)rdl64(wv, 2), w3 = (uint32_t)rdl64(wv, 3);
         const uint32_t n = w3 >> 17, Tu = w3 & 0x1FFFF;
         /* the slot count's high half: this run stays within 2^31 slots of where it began */
         uint64_t slot_end = (n_end0 & ~0xFFFFFFFFull) | slot_lo;
@@ -1211,7 +1342,7 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
         uint4 ar0 = make_uint4(0, 0, 0, 0), ar1 = ar0;
         bool acked = false;
         if (active) {
-            ld32_sys(Md.ring + pos, u0, u1);
+            if (A.dbg & 16) ld32_dev(Md.ring + pos, u0, u1); else ld32_sys(Md.ring + pos, u0, u1);
             const uint64_t idx = (uint64_t)u0.x | ((uint64_t)u0.y << 32);
             const uint32_t type = (u1.z >> 16) & 0xFF, sender = u1.z >> 24;
             const uint16_t clt = (uint16_t)(u1.z & 0xFFFF);
@@ -1221,14 +1352,16 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
              * sender's log at the same offset, and the ACK byte in the sender's map -- unless this server has
              * moved on to a newer term than the one the round comes from (the term fence, receiver side).
              * (The ACK goes first: the entry IS in this log; what follows is this server's own bookkeeping.) */
-            if (sender == leader && sender < APUS_DEV_MAX_SERVERS && E.rep[sender].ring && (my_sid >> 9) <= (uint64_t)u0.z + ((uint64_t)u0.w << 32)) {
-                st_sys8(E.ackb[sender] + (uint64_t)me * cap + di, rep_ack_tag(slot, E.dir_mask));
-                st_sys8(E.rep[sender].ring + pos + 28 + me, 1);
+            if (sender == leader && lring && (my_sid >> 9) <= (uint64_t)u0.z + ((uint64_t)u0.w << 32)) {
+                st_sys8(lack + (uint64_t)me * cap + di, rep_ack_tag(slot, E.dir_mask));
+                if (!(A.dbg & 1)) st_sys8(lring + pos + 28 + me, 1);
                 acked = true;
             }
-            st_sys8(Md.ring + pos + 28 + me, 1);
+            if (!(A.dbg & 1)) st_sys8(Md.ring + pos + 28 + me, 1);
+            if (!(A.dbg & 2)) {
             st_agent(&Md.dir_off[di], pos);
             __hip_atomic_store(&Md.dir_len[di], T | (sender << 24), RLX_AGENT);
+            }
             client = (type != APUS_NOOP && type != APUS_CONFIG && type != APUS_HEAD);
             ar0 = make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32));
             ar1 = make_uint4(u0.x, u0.y, T - APUS_HDR, (uint32_t)clt | (type << 16) | ((client ? 2u : 0u) << 24));
@@ -1236,8 +1369,8 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
             if (type == APUS_HEAD) { uint4 x0, x1; ld32_sys(Md.ring + pos + 32, x0, x1); head_val = x1.x; }
         }
         /* ... and the round's ACK granule in the sender's mailbox once every entry of the round is acknowledged */
-        if (!__ballot(active && !acked) && lane == 0) st_sys(&E.box[leader]->rack[me][q % RB_CAP], rep_gran(q, n));
-        rep_store_rows32(ar0, ar1, n, [&](uint32_t r) { return (uint8_t *)&Md.apply[(uint32_t)(slot0 + r) & E.dir_mask]; });
+        if (!__ballot(active && !acked) && lane == 0) st_sys(&lbox->rack[me][q % RB_CAP], rep_gran(q, n));
+        if (!(A.dbg & 2)) rep_store_rows32(ar0, ar1, n, [&](uint32_t r) { return (uint8_t *)&Md.apply[(uint32_t)(slot0 + r) & E.dir_mask]; });
         const uint64_t hsum = wave_sum(mix);
         const uint32_t nclient = wave_sum(client);
         head_val = (uint32_t)__shfl((int)head_val, 0, WAVE);    /* (a <HEAD> entry is a round of its own) */
@@ -1286,11 +1419,12 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
     uint64_t idle = 0;
     uint32_t exit_code = R_EXIT_STOP;
     uint64_t final_q = ~0ull;
-    uint64_t st_pass = 0, st_prog = 0;
+    uint64_t st_pass = 0, st_prog = 0, st_busy = 0;
     const uint64_t st_t0 = wall_clock64();
     for (;;) {
         bool progress = false;
         st_pass++;
+        const uint64_t st_p0 = wall_clock64();
         const uint64_t ctrl = ld_sys(&box->ctrl);
         uint64_t f0[R_SUB], f1[R_SUB], f2[R_SUB], f3[R_SUB];
 #pragma unroll
@@ -1338,7 +1472,7 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
         }
         /* ---- park? ---- */
         if (final_q != ~0ull && q_ret >= final_q) break;      /* everything that was sent is persisted */
-        if (progress) { idle = 0; st_prog++; }
+        if (progress) { idle = 0; st_prog++; st_busy += wall_clock64() - st_p0; }
         else {
             if (++idle > A.idle_polls) { exit_code = R_EXIT_IDLE; break; }
             rep_nap(idle < 64);
@@ -1346,7 +1480,7 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
     }
     if (lane == 0) {
         s_f[F_END] = end; s_f[F_N_END] = n_end; s_f[F_Q_RET] = q_ret;
-        FS->stat[0][0] = st_pass; FS->stat[0][1] = st_prog; FS->stat[0][2] = q_ret - q0; FS->stat[0][3] = wall_clock64() - st_t0;
+        FS->stat[0][0] = st_pass; FS->stat[0][1] = st_prog; FS->stat[0][2] = q_ret - q0; FS->stat[0][3] = wall_clock64() - st_t0; FS->stat[0][5] = st_busy;
         s_f[F_STORE_COUNT] = store_count; s_f[F_PEND_N] = pend_n; s_f[F_PEND_SLOT_END] = pend_slot_end; s_f[F_EXIT] = exit_code;
         s_f[F_R_FINAL] = 1;
     }
@@ -1373,11 +1507,12 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
     if (lane == 0) { st_sys(&lbox->seqdone_by[me], q_app); st_sys(&lbox->applied_by[me], n_apply); st_sys(&lbox->apply_off_by[me], a_off0); }
     uint64_t idle_fin = 0;
     uint64_t end = 0, n_end = 0, q_ret = q0;
-    uint64_t st_pass = 0, st_prog = 0;
+    uint64_t st_pass = 0, st_prog = 0, st_busy = 0;
     const uint64_t st_t0 = wall_clock64();
     for (;;) {
         bool progress = false;
         st_pass++;
+        const uint64_t st_p0 = wall_clock64();
         const uint64_t rfin = s_f[F_R_FINAL];
         q_ret = s_f[F_Q_RET]; n_end = s_f[F_N_END]; end = s_f[F_END];
         uint64_t cs = ld_sys(&box->commit_bell);
@@ -1423,9 +1558,9 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
             if (!progress && (q_app == q_ret || ld_sys(&box->commit_bell) <= n_apply || idle_fin > 4)) break;
             if (!progress) idle_fin++;
         }
-        if (!progress) rep_nap(true); else st_prog++;
+        if (!progress) rep_nap(true); else { st_prog++; st_busy += wall_clock64() - st_p0; }
     }
-    if (lane == 0) { FS->stat[1][0] = st_pass; FS->stat[1][1] = st_prog; FS->stat[1][2] = q_app - q0; FS->stat[1][3] = wall_clock64() - st_t0; }
+    if (lane == 0) { FS->stat[1][0] = st_pass; FS->stat[1][1] = st_prog; FS->stat[1][2] = q_app - q0; FS->stat[1][3] = wall_clock64() - st_t0; FS->stat[1][5] = st_busy; }
     /* (F_R_FINAL was read before F_Q_RET / F_N_END / F_END in the last pass: they were final) */
     const uint32_t exit_code = (uint32_t)s_f[F_EXIT];
     const uint64_t c_off = n_commit == n_commit0 ? c_off0 : (n_commit == n_end ? end : ld_agent(&Md.dir_off[(uint32_t)n_commit & E.dir_mask]));
@@ -1458,6 +1593,7 @@ __global__ __launch_bounds__(256) void k_replica(const EngDev E, const RepArgs A
     __shared__ uint64_t s_ao[16];
     __shared__ uint64_t s_x[16];
     __shared__ uint64_t s_m[M_WORDS];
+    __shared__ RepPtrLds s_pt;
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     uint32_t b = blockIdx.x;
     if (A.lead_here) {
@@ -1488,7 +1624,12 @@ __global__ __launch_bounds__(256) void k_replica(const EngDev E, const RepArgs A
             }
             return;
         }
-        if (b <= A.n_append) { rep_append_wave(E, A, s_lds[wave], (b - 1) * 4 + wave, A.n_append * 4); return; }
+        if (b <= A.n_append) {
+            if (tid < APUS_DEV_MAX_SERVERS) { s_pt.ring[tid] = E.rep[tid].ring; s_pt.box[tid] = E.box[tid]; s_pt.qbase[tid] = A.qbase[tid]; }
+            __syncthreads();
+            rep_append_wave(E, A, s_lds[wave], s_pt, (b - 1) * 4 + wave, A.n_append * 4);
+            return;
+        }
         b -= 1 + A.n_append;
     }
     const uint32_t ord = b / A.n_fwork, fb = b % A.n_fwork;

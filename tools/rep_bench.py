@@ -123,13 +123,20 @@ def main():
     ap.add_argument("--n-fwork", type=int, default=0)
     ap.add_argument("--replicas", type=int, default=3)
     ap.add_argument("--no-hostfed", action="store_true")
+    ap.add_argument("--grid", default="", help="n_append:n_fwork,... for --replicas")
+    ap.add_argument("--brief", action="store_true")
     a = ap.parse_args()
     combos = [(a.replicas, a.n_append, a.n_fwork)]
-    if a.sweep:
+    if a.grid:
+        combos = [(a.replicas, int(x.split(":")[0]), int(x.split(":")[1])) for x in a.grid.split(",")]
+    elif a.sweep:
         combos = [(3, 0, 0), (3, 48, 48), (1, 0, 0), (5, 0, 0), (7, 0, 0)]
     for n_rep, na, nf in combos:
         try:
-            print(json.dumps(staged(n_rep, a.entries, 64, 64, a.steps, na, nf)), flush=True)
+            res = staged(n_rep, a.entries, 64, 64, a.steps, na, nf)
+            if a.brief:
+                res = {k: res[k] for k in ("replicas", "n_append", "n_fwork", "entries_per_s", "verified", "lat_us_p50", "lat_appended_us_p50", "roles")}
+            print(json.dumps(res), flush=True)
         except Exception as exc:
             print(json.dumps({"mode": "staged", "replicas": n_rep, "n_append": na, "n_fwork": nf, "error": repr(exc)[:600]}), flush=True)
     if not a.no_hostfed:
