@@ -97,8 +97,11 @@ typedef struct {
     uint64_t term;
     volatile int running, terminate, ready;
     volatile int failed;                       /* the log is full: admission is closed (fail-stop) */
-    int live_persist;                          /* 1: the persistent consensus kernel is the live loop (default) */
-    const volatile uint64_t *dev_hr;           /* proxy->highest_rec as the persistent kernel publishes it (pinned host memory) */
+    int live_persist;                          /* 1: the single-workgroup persistent consensus kernel is the live loop (APUS_LIVE_MODE=persist) */
+    int live_replica;                          /* 1: the replica kernels are the live loop (default): application threads reserve and publish
+                                                * their requests in the pinned multi-producer ring themselves, every replica runs its own workgroups */
+    const volatile uint64_t *dev_hr;           /* proxy->highest_rec as the resident kernel publishes it (pinned host memory) */
+    uint64_t upcalled;                         /* update_state upcalls delivered to a caller's own callback */
     pthread_t thread;
     uint64_t applied_slot[APUS_MAX_SERVERS];   /* next apply-stream slot to hand to the upcalls */
     double prune_period_s;
@@ -139,8 +142,10 @@ void dare_ib_poll_tailq(void)
     if (s->batch_n && s->live_persist) {
         /* straight into the pinned command ring of the persistent kernel: it appends, replicates,
          * aggregates the ACKs, commits, applies and bumps highest_rec -- no launch, no read-back */
-        int rc = apus_gpu_persist_submit(s->eng, s->batch, s->batch_n, s->batch_arena, s->batch_bytes);
-        if (rc) { fprintf(stderr, "[apus] persist_submit failed rc=%d: admission closed\n", rc); s->failed = 1; }
+        int rc = -1;
+        for (int attempt = 0; attempt < 4 && rc == -1 && !s->terminate; attempt++)     /* (-1: the ring stayed full for seconds -- try again before giving up) */
+            rc = apus_gpu_persist_submit(s->eng, s->batch, s->batch_n, s->batch_arena, s->batch_bytes);
+        if (rc) { fprintf(stderr, "[apus] persist_submit failed rc=%d: admission closed, the hooks are inert from here on\n", rc); s->failed = 1; }
         s->batch_n = 0;
         return;
     }
@@ -217,6 +222,18 @@ void dare_server_shutdown(void)
 }
 
 static void proxy_mirror_highest_rec(uint64_t v);   /* proxy->highest_rec follows the device's word */
+static void update_highest_rec(void *arg);
+
+/* apply_committed_entries on the leader = one update_state upcall per applied client entry (dare_server.c:1952-1955).
+ * The proxy's own callback only counts (proxy.c:263-267): the word the device publishes is mirrored instead.  A
+ * caller's own callback (INTEGRATION.md option B) is called once per applied entry, in order, on this thread. */
+static void leader_upcalls(uint64_t hr)
+{
+    smr_t *s = &g_smr;
+    proxy_mirror_highest_rec(hr);
+    if (s->in.update_state && s->in.update_state != update_highest_rec)
+        while (s->upcalled < hr) { s->in.update_state(s->in.up_para); s->upcalled++; }
+}
 
 /* APUS_PROXY_DUMP=<file>: what every replica holds when the server stops, for the end-to-end test of
  * an application under LD_PRELOAD (the process is the application's, nobody can ask it afterwards):
@@ -300,8 +317,21 @@ void *dare_server_init(void *arg)
         s->ready = -1;
         return NULL;
     }
-    const char *lm = getenv("APUS_LIVE_MODE");     /* "calls": one launch per drained batch instead of the persistent kernel */
-    s->live_persist = !(lm && !strcmp(lm, "calls"));
+    /* APUS_LIVE_MODE: "replica" (default) the replica kernels, "persist" the single-workgroup persistent kernel,
+     * "calls" one launch per drained batch */
+    const char *lm = getenv("APUS_LIVE_MODE");
+    s->live_persist = lm && !strcmp(lm, "persist");
+    s->live_replica = !lm || !*lm || !strcmp(lm, "replica");
+    if (s->live_replica) {
+        const char *na = getenv("APUS_REP_APPEND"), *nf = getenv("APUS_REP_FWORK");
+        if (apus_gpu_rep_start(s->eng, 24u * 3600u * 1000u, 500, na ? (uint32_t)atoi(na) : 16, nf ? (uint32_t)atoi(nf) : 8)) {
+            fprintf(stderr, "[apus] cannot start the replica kernels\n");
+            s->ready = -1;
+            return NULL;
+        }
+        s->dev_hr = apus_gpu_rep_highest_rec_ptr(s->eng);
+        s->upcalled = *s->dev_hr;
+    }
     if (s->live_persist) {
         if (apus_gpu_persist_start(s->eng, 24u * 3600u * 1000u, 200)) {
             fprintf(stderr, "[apus] cannot start the persistent consensus kernel\n");
@@ -309,6 +339,7 @@ void *dare_server_init(void *arg)
             return NULL;
         }
         s->dev_hr = apus_gpu_persist_highest_rec_ptr(s->eng);
+        s->upcalled = *s->dev_hr;
     }
     fprintf(s->log, "[T%lu] LEADER\n", (unsigned long)s->term);     /* dare_server.c:1396, grepped by run.sh */
     fflush(s->log);
@@ -319,6 +350,35 @@ void *dare_server_init(void *arg)
 
     double last_prune = now_s();
     while (!s->terminate) {                        /* polling(), dare_server.c:1012-1125 */
+        if (s->live_replica) {
+            /* the consensus loop runs on the device and the application threads feed it themselves: this thread
+             * keeps the prune timer, hands out the upcalls and watches the resident kernel */
+            leader_upcalls(*s->dev_hr);
+            if (!s->failed && apus_gpu_rep_full(s->eng)) {
+                fprintf(stderr, "[apus] the log is full: requests were dropped, admission is closed, the hooks are inert from here on\n");
+                s->failed = 1;
+            }
+            uint64_t st[8];
+            if (!s->failed && !apus_gpu_rep_stats(s->eng, st) && st[7] == 2) {
+                /* the resident kernel left (idle limit, a bounded wait ran out): start it again */
+                const int code = apus_gpu_rep_park(s->eng);
+                fprintf(stderr, "[apus] the replica kernels left with code %d: starting them again\n", code);
+                const char *na = getenv("APUS_REP_APPEND"), *nf = getenv("APUS_REP_FWORK");
+                if (apus_gpu_quiesce(s->eng) || apus_gpu_sync(s->eng) ||
+                    apus_gpu_rep_start(s->eng, 24u * 3600u * 1000u, 500, na ? (uint32_t)atoi(na) : 16, nf ? (uint32_t)atoi(nf) : 8)) {
+                    fprintf(stderr, "[apus] restart failed: admission is closed, the hooks are inert from here on\n");
+                    s->failed = 1;
+                }
+            }
+            const double t = now_s();
+            if (!s->failed && t - last_prune >= s->prune_period_s) {  /* prune_log_cb, dare_server.c:1977 */
+                apus_gpu_rep_prune(s->eng);
+                last_prune = t;
+            }
+            struct timespec ts = {0, 100000};
+            nanosleep(&ts, NULL);
+            continue;
+        }
         if (s->live_persist) {
             /* the consensus loop itself runs on the device; this thread only moves what the
              * application threads queued into the command ring and keeps the prune timer */
@@ -332,9 +392,9 @@ void *dare_server_init(void *arg)
             if (queued && !s->failed) { dare_ib_poll_tailq(); idle_spins = 0; }
             else if (++idle_spins < 20000) __builtin_ia32_pause();
             else { struct timespec ts = {0, 20000}; nanosleep(&ts, NULL); }
-            proxy_mirror_highest_rec(*s->dev_hr);
+            leader_upcalls(*s->dev_hr);
             if (!s->failed && apus_gpu_persist_full(s->eng)) {
-                fprintf(stderr, "[apus] the log is full: requests dropped, admission closed\n");
+                fprintf(stderr, "[apus] the log is full: requests dropped, admission closed, the hooks are inert from here on\n");
                 s->failed = 1;
             }
             const double t = now_s();
@@ -360,9 +420,15 @@ void *dare_server_init(void *arg)
             last_prune = t;
         }
     }
+    if (s->live_replica) {
+        apus_gpu_rep_drain(s->eng, 5000);
+        leader_upcalls(*s->dev_hr);
+        s->dev_hr = NULL;
+        apus_gpu_rep_park(s->eng);
+    }
     if (s->live_persist) {
         apus_gpu_persist_drain(s->eng, 5000);
-        proxy_mirror_highest_rec(*s->dev_hr);
+        leader_upcalls(*s->dev_hr);
         s->dev_hr = NULL;
         apus_gpu_persist_stop(s->eng);
     }
@@ -449,14 +515,20 @@ static int is_inner(pthread_t tid)                               /* proxy.c:91-9
 static void leader_handle_submit_req(uint8_t type, ssize_t data_size, void *buf, int fd, struct proxy_node_t *p)
 {
     if (fd < 0 || fd >= MAX_FDS || data_size < 0 || data_size > 65535) return;
+    /* once admission is closed (log full, the engine is gone) the hooks are inert: the application goes on
+     * unreplicated, loudly (the message is printed where `failed` is set) -- like the reference after a failed
+     * proxy_init (proxy.c:502-506, the `proxy != NULL` guards of spec_hooks.cpp) */
+    if (g_smr.failed || g_smr.terminate || g_smr.ready < 0) return;
     pthread_once(&g_q_once, q_init);
     lead_pair_t *pair = &p->leader_map[fd];
     uint64_t req_id = 0;
     uint16_t connection_id = 0;
+    const int replica = g_smr.live_replica;
     for (;;) {
         pthread_spin_lock(&g_q.lock);
-        if (g_q.n < Q_CAP && g_q.arena_used + (uint64_t)data_size + 16 <= Q_ARENA) break;
+        if (replica || (g_q.n < Q_CAP && g_q.arena_used + (uint64_t)data_size + 16 <= Q_ARENA)) break;
         pthread_spin_unlock(&g_q.lock);              /* queue full: wait for the DARE thread to drain */
+        if (g_smr.failed || g_smr.terminate || g_smr.ready < 0) return;
         sched_yield();
     }
     const uint64_t cur_rec = ++p->cur_rec;
@@ -482,8 +554,23 @@ static void leader_handle_submit_req(uint8_t type, ssize_t data_size, void *buf,
     default:
         p->cur_rec--; pthread_spin_unlock(&g_q.lock); return;
     }
-    q_push_locked(type, connection_id, req_id, buf, (uint16_t)data_size);
-    pthread_spin_unlock(&g_q.lock);
+    if (replica) {
+        /* the multi-producer ring: the slot (= the place in the log order) is reserved together with the ids, the
+         * payload is copied and the slot published outside the lock, by this thread -- no queue, no second copy */
+        uint64_t slot = 0; void *dst = NULL;
+        const int rc = apus_gpu_rep_reserve(g_smr.eng, (uint32_t)data_size, &slot, &dst);
+        pthread_spin_unlock(&g_q.lock);
+        if (rc) {
+            fprintf(stderr, "[apus] no request slot (rc=%d): admission is closed, the hooks are inert from here on\n", rc);
+            g_smr.failed = 1;
+            return;
+        }
+        if (data_size) memcpy(dst, buf, (size_t)data_size);
+        apus_gpu_rep_publish(g_smr.eng, slot, dst, req_id, connection_id, type, (uint16_t)data_size);
+    } else {
+        q_push_locked(type, connection_id, req_id, buf, (uint16_t)data_size);
+        pthread_spin_unlock(&g_q.lock);
+    }
     /* proxy.c:160: the caller returns once its entry is applied.  With the persistent kernel the word
      * it spins on is the one the DEVICE bumps (pinned host memory): no host thread in between */
     for (;;) {
