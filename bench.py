@@ -37,6 +37,21 @@ HBM_COPY_CEILING_GBS = 6290.0   # the measured-copy ceiling SURVEY.md 8(d) asks 
 XGMI_LINK_GBS = 153.0        # one xGMI link (7 per GPU, point to point)
 
 
+PMC_FILE = "r03_pmc_traffic.json"
+
+
+def kernel_source_hash():
+    """sha256 over the device sources the engine is built from (apus_amd/csrc/*): ties a PMC traffic figure to a build"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "apus_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 def build_trace(args, group_size):
     from apus_amd import trace as T
     if args.config == "c3":      # BASELINE configs[2]: 1 KiB entries, batch 32
@@ -69,6 +84,7 @@ def step_calls(tr, eng):
     return calls
 
 
+REPS = 5          # repetitions of the timed region (median reported, min / max beside it)
 BATCH = True      # submit a step's calls as batches (multi-segment launches, k_step); --no-batch: one launch per call
 
 
@@ -254,6 +270,109 @@ def measure_ack_path(args, tr, n_rep):
         eng.close()
 
 
+def _rep_step_cmds(tr, eng):
+    out, ev, i = [], tr.events, 0
+    while i < len(ev):
+        if ev[i][0] == "ROUND":
+            j = i
+            while j < len(ev) and ev[j][0] == "ROUND":
+                j += 1
+            out.append(("run", eng.round_of_g0[ev[i][1]], j - i))
+            i = j
+            continue
+        if ev[i][0] == "PRUNE":
+            out.append(("prune",))
+        i += 1
+    return out
+
+
+def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True):
+    """BASELINE configs[1] read literally -- "single persistent kernel per replica": every replica runs its OWN
+    resident workgroups (apus_amd/csrc/apus_replica.h).  The leader's pipelined workgroups push only log bytes and
+    a doorbell per round; each follower's workgroups build directory / apply records from the landed bytes, persist,
+    write the reply bytes into the sender's log and the round's ACK granule into its mailbox, apply on the commit
+    doorbell; the leader commits by majority (popcount over the followers' ACKs per round, ballot, count-trailing-
+    ones).  Three figures: (a) device-resident input -- the same staged stream as the headline, one host command
+    per stretch of rounds / prune tick, wall clock from the first command to "everything committed and applied";
+    (b) host-fed -- producer threads on the pinned multi-producer ring (what proxy_on_read does); (c) latency of a
+    lone 64-entry round: device clock from "the round's bytes are in every pushed ring" (the end of the leader's
+    append, SURVEY 8d's definition) and from "sequenced" to "committed and applied", host clock submit ->
+    highest_rec."""
+    from apus_amd.engine import Engine
+    steps = steps or max(3, min(args.steps, 10))
+    out = {}
+    eng = Engine(n_rep, tr.log_len, device=0)
+    try:
+        eng.stage_trace(tr)
+        eng.elect(0)
+        eng.sync()
+        cmds = _rep_step_cmds(tr, eng)
+
+        def step():
+            for c in cmds:
+                if c[0] == "run":
+                    eng.rep_run(c[1], c[2])
+                else:
+                    eng.rep_prune()
+        # (c) first, on an otherwise idle device
+        reqs64 = np.ascontiguousarray(tr.reqs[16:16 + 64])
+        eng.rep_start(idle_ms=5000, peer_ms=1000)
+        hl64 = eng.rep_roundtrip_ns(reqs64, tr.arena, 300) / 1e3
+        hl1 = eng.rep_roundtrip_ns(reqs64[:1], tr.arena, 300) / 1e3
+        eng.rep_drain()
+        code = eng.rep_park()
+        lat_seq, lat_app = eng.rep_latency_ns(), eng.rep_latency_appended_ns()
+        out["latency"] = {"appended_to_committed_and_applied_us_p50": float(np.percentile(lat_app[20:], 50)) / 1e3 if len(lat_app) > 20 else None,
+                          "sequenced_to_committed_and_applied_us_p50": float(np.percentile(lat_seq[20:], 50)) / 1e3 if len(lat_seq) > 20 else None,
+                          "host_submit_to_highest_rec_us_p50_64_entries": float(np.percentile(hl64[40:], 50)),
+                          "host_submit_to_highest_rec_us_p50_1_entry": float(np.percentile(hl1[40:], 50)), "exit": code}
+        hr_base = eng.counters(0)["highest_rec"]
+        # (a) device-resident input
+        eng.rep_start(idle_ms=5000, peer_ms=1000)
+        step()
+        eng.rep_drain(timeout_ms=60000)
+        regions = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            eng.rep_drain(timeout_ms=120000)
+            regions.append(time.perf_counter() - t0)
+        code = eng.rep_park()
+        roles = eng.rep_role_stats()
+        eng.quiesce()
+        total = hr_base + (1 + 3 * steps) * len(tr.reqs)
+        ok = eng.status() == 0 and code == 0 and eng.counters(0)["highest_rec"] == total
+        for r in range(n_rep):
+            o = eng.offsets(r)
+            ok = ok and (o["commit"] == o["end"] == o["apply"])
+        dt = float(np.median(regions))
+        out["device_resident"] = {"value": len(tr.reqs) * steps / dt, "unit": "entries/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                                  "regions_entries_per_s": [len(tr.reqs) * steps / x for x in regions], "verified": bool(ok),
+                                  "roles": {k: {kk: v[kk] for kk in ("moved", "rounds", "busy_us", "us") if kk in v} for k, v in roles.items()
+                                            if k in ("sequencer", "committer", "applier", "f0_retire", "f0_apply")}}
+        # (b) host-fed
+        if hostfed:
+            blk = np.ascontiguousarray(tr.reqs[16:16 + 4096])
+            hf = {}
+            for nt in (1, 2, 4):
+                eng.rep_start(idle_ms=5000, peer_ms=1000)
+                hr0 = eng.rep_highest_rec()
+                n, sec = eng.rep_feed(blk, tr.arena, nt, 0.4, prune_every_reqs=(8 << 20) // (64 + args.payload))
+                good = eng.rep_highest_rec() == hr0 + n
+                code = eng.rep_park()
+                hf[str(nt)] = {"entries_per_s": n / sec, "verified": bool(good and code == 0)}
+            eng.quiesce()
+            best = max((v["entries_per_s"] for v in hf.values() if v["verified"]), default=None)
+            out["host_fed"] = {"value": best, "unit": "entries/s", "by_producer_threads": hf,
+                               "note": "producer threads reserve slots in the pinned multi-producer ring, copy their 64-B payloads there "
+                                       "themselves and publish (apus_gpu_rep_submit); requests and payloads cross PCIe.  Never the headline"}
+        eng.check_status()
+    finally:
+        eng.close()
+    return out
+
+
 def measure_join(args):
     """BASELINE configs[4]'s tail as an extra figure: a server joins a 5-server group whose ring holds
     ~32 MiB of 1 KiB entries -- apus_gpu_join end to end (CONFIG entry + pass, the joiner's recovery: bulk
@@ -321,18 +440,22 @@ def bench_single(args):
 
     for _ in range(args.warmup):
         run_step()
-    eng.sync()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
-    eng.sync()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # the timed region (exactly K steps between two syncs), REPS times: the line reports the median region
+    regions = []
+    for _ in range(REPS):
+        eng.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run_step()
+        eng.sync()
+        torch.cuda.synchronize()
+        regions.append(time.perf_counter() - t0)
+    dt = float(np.median(regions))
     eng.check_status()
 
     # the work really happened: every entry of every step is committed and applied everywhere
-    total_steps = 1 + args.warmup + args.steps
+    total_steps = 1 + args.warmup + REPS * args.steps
     for r in range(n_rep):
         o = eng.offsets(r)
         assert o["commit"] == o["end"] == o["apply"], f"replica {r} not caught up: {o}"
@@ -450,15 +573,19 @@ def bench_single(args):
     # (profiles/r02_pmc_traffic.json, written by tools/gpu_profile.sh + tools/mk_traffic.py from
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); null if there is none
     traffic, moved_per_entry, traffic_src = None, None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", PMC_FILE)
     kern_name = "k_step" if BATCH else "k_call"
     if os.path.exists(pmc):
         try:
-            pj = json.load(open(pmc))["configs"].get(args.config)
-            if pj and pj.get("kernel") == kern_name and args.replicas == pj.get("replicas", args.replicas):
+            pall = json.load(open(pmc))
+            pj = pall["configs"].get(args.config)
+            # the counters are only quoted for the kernels they were taken on: the file carries the hash of the device
+            # sources (apus_amd/csrc) of the build that was profiled; another build -> traffic stays null
+            if (pj and pj.get("kernel") == kern_name and args.replicas == pj.get("replicas", args.replicas)
+                    and pall.get("kernel_source_sha256") == kernel_source_hash()):
                 moved_per_entry = float(pj["bytes_per_entry"])
                 traffic = int(moved_per_entry * entries_per_launch)
-                traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, this config and kernel)"
+                traffic_src = f"profiles/{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, this config, kernel and build)"
         except Exception:
             traffic = None
     moved = traffic / k_avg_s / 1e9 if (traffic and k_avg_s > 0) else None
@@ -493,11 +620,23 @@ def bench_single(args):
                      "kernel": kern_name, "bytes_per_entry": kern_bytes,
                      "avg_launch_us": k_avg_s * 1e6, "launches": k_launches,
                      "entries_per_launch": entries_per_launch},
+        "repetitions": {"n": REPS, "entries_per_s": [n_entries * args.steps / x for x in regions],
+                        "min": n_entries * args.steps / max(regions), "median": value, "max": n_entries * args.steps / min(regions)},
         "entries_per_step": n_entries, "steps_executed": total_steps + args.steps,
         "whole_path": {"bytes_per_entry": path_bytes, "achieved": path_bytes * value / 1e9,
                        "unit": "GB/s", "frac": path_bytes * value / 1e9 / HBM_PEAK_GBS},
     }
     eng.close()
+    if not args.no_replica and args.config == "c2":
+        try:
+            rk = measure_replica_kernels(args, tr, n_rep)
+            out["replica_kernels"] = rk
+            la = rk.get("latency", {}).get("appended_to_committed_and_applied_us_p50")
+            if la is not None:
+                out["latency"]["replica_kernels"] = rk["latency"]
+                out["p50_round_latency_us"] = la
+        except Exception as exc:
+            print(f"[bench] replica kernel measurement failed: {exc!r}", file=sys.stderr)
     if not args.no_ack_path:
         try:
             out["ack_aggregation_path"] = measure_ack_path(args, tr, n_rep)
@@ -641,6 +780,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-ack-path", action="store_true", help="skip the second measurement without fused ACKs")
+    ap.add_argument("--no-replica", action="store_true", help="skip the replica-kernel measurements")
     ap.add_argument("--no-batch", action="store_true", help="one launch per run_rounds call (k_call) instead of batches (k_step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()

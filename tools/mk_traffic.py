@@ -7,8 +7,11 @@ bytes per entry = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over every launch 
 divided by the entries those launches appended (gfx950: FETCH_SIZE counts half of a wide coalesced
 read, WRITE_SIZE is exact -- the guide's HBM section)."""
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def kernel_sum(path, counter, like):
@@ -45,6 +48,8 @@ def main():
                            "FETCH_SIZE_KB_total": fetch_kb, "WRITE_SIZE_KB_total": write_kb,
                            "entries": entries, "bytes_total": total, "bytes_per_entry": total / entries,
                            "workload": line["config"]["workload"]}
+    from bench import kernel_source_hash
+    doc["kernel_source_sha256"] = kernel_source_hash()       # bench.py quotes these counters only for the build they were taken on
     json.dump(doc, open(out, "w"), indent=1)
     print(cfg, doc["configs"][cfg])
 
