@@ -87,6 +87,7 @@ SIGNATURES = {
     "apus_gpu_join": (C.c_int, [vp, u32, u16, u32, u32, C.POINTER(u64)]),
     "apus_gpu_batch_begin": (C.c_int, [vp]),
     "apus_gpu_batch_end": (C.c_int, [vp]),
+    "apus_gpu_set_leader": (C.c_int, [vp, u32]),
     "apus_gpu_rep_start": (C.c_int, [vp, u32, u32, u32, u32]),
     "apus_gpu_rep_park": (C.c_int, [vp]),
     "apus_gpu_rep_reserve": (C.c_int, [vp, u32, C.POINTER(u64), C.POINTER(vp)]),

@@ -2025,6 +2025,16 @@ extern "C" int apus_gpu_adopt_sid(apus_engine_t *e, uint32_t replica, uint64_t s
     return 0;
 }
 
+/* a process that hosts followers only learns who leads from its control plane (the election's messages in the
+ * reference): nothing is launched, the replica kernels it starts afterwards look the leader's mailbox / log up by it */
+extern "C" int apus_gpu_set_leader(apus_engine_t *e, uint32_t leader)
+{
+    if (!e || leader >= e->d.group_size) return APUS_E_ARG;
+    if (e->r_running || e->p_running || e->batching) return APUS_E_STATE;
+    e->d.leader = leader;
+    return 0;
+}
+
 extern "C" int apus_gpu_follow(apus_engine_t *e, uint32_t replica, uint32_t leader, uint64_t term, uint32_t bitmask)
 {
     int rc = local_rep(e, replica);

@@ -91,6 +91,8 @@ class PeerMember:
         self.eng.local_ids = list(range(group_size))
         self.leader = -1
         self.led = []                       # (first pass, passes) of the round record for every term this rank led
+        self.rep_running = False            # a run of the replica kernels is resident (rep_begin .. rep_end)
+        self.rep_here = False               # ... and this process carries workgroups of it
 
     @property
     def is_leader(self) -> bool:
@@ -160,6 +162,55 @@ class PeerMember:
             e.bitmask, e.group_size, e.epoch, e.machines = bitmask, size, epoch, machines
             e.set_reachable(e.reachable | (1 << r))
 
+    # ---- data plane, replica kernels: EVERY process runs the workgroups of the replica it hosts --------
+    def rep_begin(self, n_append: int = 0, n_fwork: int = 0, idle_ms: int = 20000, peer_ms: int = 2000):
+        """Start a run of the replica kernels (apus_amd/csrc/apus_replica.h) across the group: every process that
+        hosts a live follower launches that follower's workgroups on ITS device (they poll their mailbox), then
+        the leader's process launches the leader's.  The leader pushes log bytes + one doorbell per round through
+        the mappings; each follower persists, writes its reply bytes into the leader's log and its round ACK into
+        the leader's mailbox (R3) from its own kernel; the leader commits by majority.  Collective."""
+        e = self.eng
+        if self.rep_running:
+            return
+        if self.is_leader:
+            e.sync()
+        dist.barrier()                      # the control plane's last words are in everybody's control blocks
+        alive = self.leader >= 0 and (e.reachable >> self.rank) & 1 and (e.bitmask >> self.rank) & 1
+        self.rep_here = False
+        if alive and not self.is_leader:
+            e._chk(e.L.apus_gpu_set_leader(e.h, self.leader), "set_leader")
+            e.rep_start(idle_ms, peer_ms, n_append, n_fwork)
+            self.rep_here = True
+        dist.barrier()                      # every follower's workgroups are resident
+        if self.is_leader:
+            e.rep_start(idle_ms, peer_ms, n_append, n_fwork)
+            self.rep_here = True
+        self.rep_running = True
+
+    def rep_end(self):
+        """Park the run: the leader drains and parks (its last act tells every follower to park through its mailbox),
+        the follower processes wait for their workgroups to leave.  Collective."""
+        if not self.rep_running:
+            return
+        e = self.eng
+        code = 0
+        if self.rep_here:
+            if self.is_leader:
+                e.rep_drain(timeout_ms=60000)
+            code = e.rep_park()
+        self.rep_running = self.rep_here = False
+        dist.barrier()
+        if code != 0:
+            raise EngineError(f"rank {self.rank}: the replica kernels left with code {code}, status {e.status_names()}")
+
+    def rep_rounds(self, r0: int, n: int):
+        if self.is_leader:
+            self.eng.rep_run(r0, n)
+
+    def rep_prune(self):
+        if self.is_leader:
+            self.eng.rep_prune()
+
     # ---- data plane: the leader only ------------------------------------------------------------
     def rounds(self, r0: int, n: int):
         if self.is_leader:
@@ -188,12 +239,54 @@ class PeerMember:
         self.eng.close()
 
 
-def walk_trace(m: PeerMember, trace, on_check=None, check_at=("QUIESCE",), max_batch_rounds: int = 4096, batch: bool = False):
+def walk_trace(m: PeerMember, trace, on_check=None, check_at=("QUIESCE",), max_batch_rounds: int = 4096, batch: bool = False,
+               replica: bool = False, rep_grid=(0, 0)):
     """Every rank walks the trace; on_check(i, event, member) runs on every rank after settle().
-    batch=True: stretches of ROUND / PRUNE events become one multi-segment launch (apus_gpu_batch_*)."""
+    batch=True: stretches of ROUND / PRUNE events become one multi-segment launch (apus_gpu_batch_*).
+    replica=True: stretches of ROUND / PRUNE events run through the replica kernels -- every process runs the
+    workgroups of its own replica; the control-plane events park the run."""
     m.eng.stage_trace(trace)            # any rank may have to lead
     ev, i = trace.events, 0
     opened = False
+    if replica:
+        while i < len(ev):
+            op = ev[i][0]
+            if op in ("ROUND", "PRUNE") and op not in check_at:
+                m.rep_begin(*rep_grid)
+                if op == "PRUNE":
+                    m.rep_prune()
+                    i += 1
+                    continue
+                j = i
+                while j < len(ev) and ev[j][0] == "ROUND":
+                    j += 1
+                m.rep_rounds(m.eng.round_of_g0[ev[i][1]], j - i)
+                i = j
+                continue
+            m.rep_end()
+            if op == "ELECT":
+                m.elect(ev[i][1])
+            elif op == "PRUNE":
+                m.tick_prune()
+            elif op == "QUIESCE":
+                m.quiesce()
+            elif op == "HOLD":
+                m.hold(ev[i][1])
+            elif op == "RELEASE":
+                m.release(ev[i][1])
+            elif op == "KILL":
+                m.kill(ev[i][1])
+            elif op == "JOIN":
+                m.join(ev[i][1])
+            else:
+                raise EngineError(f"trace event {ev[i]} is not supported")
+            if op in check_at and on_check is not None:
+                m.settle()
+                on_check(i, ev[i], m)
+            i += 1
+        m.rep_end()
+        m.settle()
+        return
 
     def b_open():
         nonlocal opened

@@ -291,6 +291,7 @@ int  apus_gpu_device_arch(int device, char *out, int cap);
  *   idle_ms : the leader's workgroups leave by themselves after this long without input
  *   peer_ms : bound of every device-side wait for a peer
  *   n_append, n_fwork : append workgroups of the leader / workgroups per follower (0 = defaults)   */
+int  apus_gpu_set_leader(apus_engine_t *e, uint32_t leader);    /* a follower-only process: who leads (host mirror only, nothing is launched) */
 int  apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t peer_ms, uint32_t n_append, uint32_t n_fwork);
 int  apus_gpu_rep_park(apus_engine_t *e);     /* exit code of the run: 0 stop, 1 idle, 2 a wait timed out, 3 a follower had a gap */
 /* admission (leader side; replaces the TAILQ + tailq_lock, src/include/dare/message.h:20-22): thread safe */

@@ -81,7 +81,7 @@ def main():
                 e.check_status()
                 for r in alive:
                     compare_replica(e, cl, r, tag=tag + " (leader's view)")
-            if mm.led:
+            if mm.led and mode != "replica":          # (the replica kernels keep no per-pass record)
                 gc, ge = e.round_record()
                 oc, oe = record_expected()
                 assert len(gc) == len(oc), f"{tag}: {len(gc)} passes recorded, oracle {len(oc)}"
@@ -90,7 +90,7 @@ def main():
             res["checks"] += 1
 
         peers.walk_trace(m, tr, on_check=check, check_at=("QUIESCE", "PRUNE") if mode == "per-call" else ("QUIESCE",),
-                         batch=(mode == "batched"))
+                         batch=(mode == "batched"), replica=(mode == "replica"), rep_grid=(24, 12))
         # settle both sides like tests/parity.py does at the end, then the final comparison
         oracle_to(len(tr.events) - 1)
         cl.quiesce(); m.quiesce(); m.settle()

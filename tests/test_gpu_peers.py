@@ -108,3 +108,18 @@ def test_peer_mapped_group_join(name, world):
     rank checks its own replica from its own memory against the oracle."""
     res = run_group(world, name)
     assert all(r["checks"] >= 2 for r in res)
+
+
+@pytest.mark.parametrize("name,world", [("steady3", 3), ("steady5_unaligned", 5), ("hold_release", 5), ("no_quorum_wide", 3),
+                                        ("c5_failover", 5), ("join_then_failover", 4), ("steady7_mixed", 7)])
+def test_peer_mapped_group_replica_kernels(name, world):
+    """Every PROCESS runs the workgroups of the replica it hosts (apus_amd/csrc/apus_replica.h): the follower
+    processes launch their follower kernels on their device, the leader's process its pipelined leader kernel; the
+    leader pushes only log bytes + one doorbell per round through the HIP IPC mappings, every follower persists,
+    writes its reply bytes into the leader's log and its round ACK into the leader's mailbox from ITS OWN kernel
+    (R3), the leader commits by majority (popcount + ballot + count-trailing-ones over the round ACKs) and rings
+    the commit doorbells (R4), every follower applies on its own.  Steady state, hold / release, no quorum, the
+    fail-over of the leader process, JOIN and the election of the joined process: every rank checks its own
+    replica from its own memory against the oracle at every quiescent event."""
+    res = run_group(world, name, mode="replica")
+    assert all(r["checks"] >= 2 for r in res)
