@@ -84,12 +84,21 @@ class _FakeEngine:
     def round_record(self): return [0] * self.n_passes, [0] * self.n_passes
     def close(self): pass
 
+    # the replica kernels (PeerMember.rep_begin / rep_end)
+    def rep_start(self, idle_ms=0, peer_ms=0, n_append=0, n_fwork=0): self.calls.append(("rep_start", self.c_leader))
+    def rep_park(self): self.calls.append(("rep_park",)); return 0
+    def rep_drain(self, timeout_ms=0): self.calls.append(("rep_drain",))
+    def rep_run(self, r0, n): self.calls.append(("rep_run", r0, n)); self.n_passes += n
+    def rep_prune(self): self.calls.append(("rep_prune",))
+    def status_names(self): return "OK"
+    c_leader = -1                       # what the C engine was told (apus_gpu_set_leader / an election it ran itself)
+
     # Engine.elect calls the C ABI through these two
     class _L:
         pass
 
 
-def _worker(rank, world, port, name, q):
+def _worker(rank, world, port, name, q, replica=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -116,6 +125,12 @@ def _worker(rank, world, port, name, q):
             e.L.apus_gpu_set_config = lambda h, n_, ep: (e.calls.append(("config", n_, ep)), 0)[1]
             e.L.apus_gpu_become_leader_ex = lambda h, w, term, bm, dead: (e.calls.append(("lead", w, term, bm, dead)), 0)[1]
             e.L.apus_gpu_set_reachable = lambda h, m: 0
+
+            def fake_set_leader(h, l):
+                e.c_leader = l
+                e.calls.append(("set_leader", l))
+                return 0
+            e.L.apus_gpu_set_leader = fake_set_leader
 
             def fake_elect(h, w, live, bm, out):
                 out[0], out[1], out[2], out[4] = 1, live & bm & ~(1 << w), 0, bin(live & bm).count('1')
@@ -158,6 +173,27 @@ def _worker(rank, world, port, name, q):
             data = [c for c in mm.eng.calls if c[0] in ("rounds", "prune", "quiesce", "control", "lead")]
             led_calls[i] = (mm.is_leader, len(data))
 
+        if replica:
+            peers.walk_trace(m, tr, on_check=check, check_at=("QUIESCE", "ELECT", "KILL", "JOIN"), replica=True)
+            calls = m.eng.calls
+            starts = [k for k, c in enumerate(calls) if c[0] == "rep_start"]
+            parks = [k for k, c in enumerate(calls) if c[0] == "rep_park"]
+            # every run this process took part in was parked again, in order
+            assert len(starts) == len(parks) and all(a < b for a, b in zip(starts, parks)), f"rank {rank}: {calls}"
+            assert all(b < a2 for b, a2 in zip(parks, starts[1:]))
+            led_terms = 0
+            for a, b in zip(starts, parks):
+                inside = [c[0] for c in calls[a + 1:b]]
+                if any(c in ("rep_run", "rep_prune", "rep_drain") for c in inside):
+                    led_terms += 1              # only a process that leads feeds the run and drains it
+                else:
+                    # a follower's process: told who leads right before it launched its own replica's workgroups
+                    assert calls[a - 1][0] == "set_leader" and calls[a - 1][1] == calls[a][1] != rank, f"rank {rank}: {calls[a - 2:a + 1]}"
+            if not m.led:
+                assert led_terms == 0 and not any(c[0] in ("rep_run", "rep_prune") for c in calls)
+            q.put((rank, True, len(m.led), sum(c[2] for c in calls if c[0] == "rep_run"), len(starts)))
+            m.close()
+            return
         peers.walk_trace(m, tr, on_check=check, check_at=("QUIESCE", "PRUNE", "ELECT", "KILL", "JOIN"))
         data = [c for c in m.eng.calls if c[0] in ("rounds", "prune", "quiesce", "control", "join")]
         joins = [e[1] for e in tr.events if e[0] == "JOIN"]
@@ -199,3 +235,32 @@ def test_peer_group_host_logic(name, world):
     assert sum(r[3] for r in res) == n_rounds            # every round was run by exactly one rank
     if name == "c5_failover":
         assert [r[2] for r in sorted(res)] == [1, 1, 0, 0, 0]
+
+
+@pytest.mark.parametrize("name,world", [("steady3", 3), ("c5_failover", 5), ("hold_release", 5), ("c5_rejoin", 5)])
+def test_peer_group_replica_kernels_host_logic(name, world):
+    """The replica-kernel walk (every process runs the workgroups of the replica it hosts): who starts a run,
+    who is told the leader first, who feeds and drains it, that every run is parked before a control-plane
+    event, that a killed / held server's process stays out and a joined one comes in."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, name, q, True)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    for r in sorted(res):
+        assert r[1], f"rank {r[0]}: {r[2]}"
+    from tests import traces
+    tr = traces.CATALOGUE[name]()
+    n_rounds = sum(1 for e in tr.events if e[0] == "ROUND")
+    assert sum(r[3] for r in res) == n_rounds            # every round went through exactly one leader's run
+    runs = {r[0]: r[4] for r in res}
+    if name == "c5_failover":
+        # rank 0 led and was killed: it takes part in fewer runs than the servers that stay
+        assert runs[0] < runs[1] and [r[2] for r in sorted(res)] == [1, 1, 0, 0, 0]
+    if name == "hold_release":
+        held = [e[1] for e in tr.events if e[0] == "HOLD"]
+        assert all(runs[h] < max(runs.values()) for h in held)      # a held server's process sits runs out
