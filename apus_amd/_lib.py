@@ -87,6 +87,8 @@ SIGNATURES = {
     "apus_gpu_join": (C.c_int, [vp, u32, u16, u32, u32, C.POINTER(u64)]),
     "apus_gpu_batch_begin": (C.c_int, [vp]),
     "apus_gpu_batch_end": (C.c_int, [vp]),
+    "apus_gpu_calib_pingpong": (C.c_int, [vp, u32, u32, u32, u32, u64, vp, u32]),
+    "apus_gpu_calib_store_bw": (C.c_int, [vp, u32, u64, u32, vp]),
     "apus_gpu_set_leader": (C.c_int, [vp, u32]),
     "apus_gpu_rep_start": (C.c_int, [vp, u32, u32, u32, u32]),
     "apus_gpu_rep_park": (C.c_int, [vp]),

@@ -2389,7 +2389,7 @@ extern "C" int apus_gpu_rep_stats(apus_engine_t *e, uint64_t out[8])
 {
     if (!e || !e->rh || !out) return APUS_E_STATE;
     out[0] = e->rh->rounds; out[1] = e->rh->slots_done; out[2] = e->rh->cmd_head; out[3] = e->rh->commit_slot;
-    out[4] = e->rh->highest_rec; out[5] = e->rh->full; out[6] = 0; out[7] = e->rh->alive;
+    out[4] = e->rh->highest_rec; out[5] = e->rh->full | (e->rh->exit_code << 32); out[6] = 0; out[7] = e->rh->alive;
     if (!e->r_running && e->rl) HIPCHK(hipMemcpy(&out[6], &e->rl->drop_mask, sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
 }
@@ -2460,6 +2460,59 @@ extern "C" int apus_gpu_rep_roundtrip(apus_engine_t *e, const apus_req_t *reqs, 
         out_ns[i] = (uint32_t)((mono_s() - t0) * 1e9);
     }
     return 0;
+}
+
+/* ---- link calibration (the reference's rc_get_loggp_params, dare_ibv_rc.c:3323-3739, for peer stores) ---- */
+/* role 0: starts `iters` 8-byte round trips with `peer` and returns the samples (ns); role 1: answers them.  Both
+ * processes call at about the same time (the control plane pairs them); `base` makes the words of this exchange
+ * distinct from an earlier one's.  The replicas must be idle (no run resident). */
+extern "C" int apus_gpu_calib_pingpong(apus_engine_t *e, uint32_t me, uint32_t peer, uint32_t role, uint32_t iters, uint64_t base,
+                                       uint32_t *out_ns, uint32_t timeout_ms)
+{
+    if (!e || me >= e->cfg.group_size || peer >= e->cfg.group_size || me == peer || !e->d.box[me] || !e->d.box[peer] || iters == 0 || iters > 65535)
+        return APUS_E_ARG;
+    if (e->r_running || e->p_running || e->batching) return APUS_E_STATE;
+    uint32_t *d_t = nullptr;
+    HIPCHK(hipMalloc((void **)&d_t, sizeof(uint32_t) * (iters + 1)));
+    HIPCHK(hipMemsetAsync(d_t, 0, sizeof(uint32_t) * (iters + 1), e->stream));
+    hipLaunchKernelGGL(k_calib_pingpong, dim3(1), dim3(64), 0, e->stream, e->d, me, peer, role, iters, base, d_t,
+                       (uint64_t)timeout_ms * 2000ull);
+    hipError_t er = hipStreamSynchronize(e->stream);
+    std::vector<uint32_t> h(iters + 1);
+    if (er == hipSuccess) er = hipMemcpy(h.data(), d_t, sizeof(uint32_t) * (iters + 1), hipMemcpyDeviceToHost);
+    hipFree(d_t);
+    if (er != hipSuccess) return APUS_E_HIP;
+    if (h[0] != iters) return -1;                         /* the peer did not answer in time */
+    if (role == 0 && out_ns) {
+        int khz = 100000;
+        hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->cfg.device);
+        if (khz <= 0) khz = 100000;
+        for (uint32_t i = 0; i < iters; i++) out_ns[i] = (uint32_t)((uint64_t)h[i + 1] * 1000000ull / (uint64_t)khz);
+    }
+    return 0;
+}
+
+/* write-through 16-byte stores of `bytes` into replica `peer`'s ring, `iters` times, HIP events around each pass:
+ * out_gbps[i] = GB/s of pass i.  The ring's contents are destroyed: calibrate before the group starts (or reset). */
+extern "C" int apus_gpu_calib_store_bw(apus_engine_t *e, uint32_t peer, uint64_t bytes, uint32_t iters, float *out_gbps)
+{
+    if (!e || peer >= e->cfg.group_size || !e->d.rep[peer].ring || bytes < 16 || bytes > e->d.log_len || !out_gbps || iters == 0) return APUS_E_ARG;
+    if (e->r_running || e->p_running || e->batching) return APUS_E_STATE;
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(2048, std::max<uint64_t>(1, bytes / 16 / 256));
+    int rc = 0;
+    for (uint32_t i = 0; i < iters && !rc; i++) {
+        hipEventRecord(a, e->stream);
+        hipLaunchKernelGGL(k_calib_store, dim3(grid), dim3(256), 0, e->stream, e->d.rep[peer].ring, bytes, i + 1);
+        hipEventRecord(b, e->stream);
+        if (hipEventSynchronize(b) != hipSuccess) { rc = APUS_E_HIP; break; }
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, a, b);
+        out_gbps[i] = ms > 0.f ? (float)((double)bytes / (ms * 1e-3) / 1e9) : 0.f;
+    }
+    hipEventDestroy(a); hipEventDestroy(b);
+    return rc;
 }
 
 /* Host-fed throughput of the multi-producer ring: n_threads application threads (what memcached's worker

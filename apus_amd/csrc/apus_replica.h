@@ -108,7 +108,8 @@ struct RepBox {
     uint16_t lens[RB_CAP][WAVE];         /* cmd.len of every entry of a round of mixed sizes (2 B per entry) */
     uint64_t commit_bell;                /* R4: committed slots                                 */
     uint64_t ctrl;                       /* (f_runs + 1) << 40 | rounds of this run to consume + 1: park */
-    uint64_t pad0[6];
+    uint64_t ping, pong;                 /* link calibration (k_calib_pingpong): the word the peer writes, the word it answers in */
+    uint64_t pad0[4];
     /* followers -> this replica while it leads (index = follower) */
     uint64_t seqdone_by[16];             /* rounds applied (their doorbell slots are free)      */
     uint64_t persisted_by[16];           /* entry slots persisted, in order                     */
@@ -1650,4 +1651,42 @@ __global__ __launch_bounds__(256) void k_replica(const EngDev E, const RepArgs A
         return;
     }
     rep_follow_wave(E, A, (uint32_t)me, fb * 4 + wave - 2, G);
+}
+
+
+/* ===================================================================================== link calibration */
+/* The reference measures its fabric before it runs (rc_get_loggp_params, dare_ibv_rc.c:3323-3739: overhead, latency
+ * and gap per byte of RDMA WRITE / READ); these two kernels do the same for the path the replica kernels use --
+ * system-scope stores into a peer's HBM (xGMI between two GPUs, the device's own fabric between two processes on one):
+ *   k_calib_pingpong   one 8-byte store to the peer's mailbox, the peer's kernel answers with one: the round trip of a
+ *                      doorbell, `iters` times, every sample kept.  role 0 starts, role 1 answers.
+ *   k_calib_store      every workgroup streams write-through 16-byte stores into the peer's ring (the R1 push). */
+__global__ __launch_bounds__(64) void k_calib_pingpong(const EngDev E, uint32_t me, uint32_t peer, uint32_t role, uint32_t iters,
+                                                     uint64_t base, uint32_t *ticks, uint64_t max_polls)
+{
+    RepBox *mine = E.box[me], *theirs = E.box[peer];
+    if (threadIdx.x != 0) return;
+    for (uint32_t i = 1; i <= iters; i++) {
+        const uint64_t want = base + i;
+        if (role == 0) {
+            const uint64_t t0 = wall_clock64();
+            st_sys(&theirs->ping, want);
+            uint64_t polls = 0;
+            while (ld_sys(&mine->pong) != want) if (++polls > max_polls) { ticks[0] = 0xFFFFFFFFu; return; }
+            ticks[i] = (uint32_t)(wall_clock64() - t0);
+        } else {
+            uint64_t polls = 0;
+            while (ld_sys(&mine->ping) != want) if (++polls > max_polls) { ticks[0] = 0xFFFFFFFFu; return; }
+            st_sys(&theirs->pong, want);
+        }
+    }
+    ticks[0] = iters;
+}
+
+__global__ __launch_bounds__(256) void k_calib_store(uint8_t *dst, uint64_t bytes, uint32_t seed)
+{
+    const uint64_t units = bytes / 16;
+    const uint4 v = make_uint4(seed, blockIdx.x, threadIdx.x, 0x9E3779B9u);
+    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (uint64_t)gridDim.x * blockDim.x)
+        st16_wt(dst + 16 * u, v);
 }

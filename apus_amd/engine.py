@@ -389,7 +389,9 @@ class Engine:
     def rep_stats(self) -> dict:
         out = (C.c_uint64 * 8)()
         self.L.apus_gpu_rep_stats(self.h, out)
-        return dict(zip(("rounds", "slots_done", "cmd_head", "commit_slot", "highest_rec", "refused", "dropped", "alive"), [int(v) for v in out]))
+        d = dict(zip(("rounds", "slots_done", "cmd_head", "commit_slot", "highest_rec", "refused", "dropped", "alive"), [int(v) for v in out]))
+        d["exit_code"], d["refused"] = d["refused"] >> 32, d["refused"] & 0xFFFFFFFF      # (exit code of a run that has left: 0 stop, 1 idle, 2 timeout)
+        return d
 
     def rep_latency_ns(self) -> np.ndarray:
         out = np.zeros(1 << 16, dtype=np.uint32)

@@ -147,17 +147,24 @@ class PeerMember:
         if self.rank == r:
             e._chk(e.L.apus_gpu_clear_replica(e.h, r), "clear_replica")
         dist.barrier()
+        err = None
         if self.is_leader:
-            e.join(r)
-            e.sync()
-            cfg = torch.tensor([e.bitmask, e.group_size, e.epoch, e.machines], dtype=torch.int64)
+            try:
+                e.join(r)
+                e.sync()
+                cfg = torch.tensor([e.bitmask, e.group_size, e.epoch, e.machines, 1], dtype=torch.int64)
+            except EngineError as exc:      # (the other ranks wait in the broadcast: they must hear about it)
+                err = exc
+                cfg = torch.zeros(5, dtype=torch.int64)
         else:
-            cfg = torch.zeros(4, dtype=torch.int64)
+            cfg = torch.zeros(5, dtype=torch.int64)
         if dist.get_backend() == "nccl":
             cfg = cfg.to(self.device)
         dist.broadcast(cfg, src=self.leader)
+        if int(cfg.cpu()[4]) != 1:
+            raise err if err is not None else EngineError(f"rank {self.rank}: the leader could not carry out JOIN({r})")
         if not self.is_leader:
-            bitmask, size, epoch, machines = (int(v) for v in cfg.cpu().tolist())
+            bitmask, size, epoch, machines = (int(v) for v in cfg.cpu().tolist()[:4])
             e._chk(e.L.apus_gpu_set_config(e.h, size, epoch), "set_config")
             e.bitmask, e.group_size, e.epoch, e.machines = bitmask, size, epoch, machines
             e.set_reachable(e.reachable | (1 << r))
@@ -336,7 +343,7 @@ def walk_trace(m: PeerMember, trace, on_check=None, check_at=("QUIESCE",), max_b
     m.settle()
 
 
-def init_process_group_from_env(gpus: int):
+def init_process_group_from_env(gpus: int, timeout=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", str(gpus)))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -347,8 +354,9 @@ def init_process_group_from_env(gpus: int):
     if os.environ.get("APUS_DIST_ONE_DEVICE"):
         local = 0
     torch.cuda.set_device(local)
+    kw = {} if timeout is None else {"timeout": timeout}         # collectives end with an error instead of waiting for ever
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), **kw)
     else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local, backend

@@ -652,116 +652,273 @@ def bench_single(args):
     return out
 
 
+def _calibrate_links(m, world, rank, backend, one_dev):
+    """What the reference measures before it runs (rc_get_loggp_params, dare_ibv_rc.c:3323-3739) for the path the
+    replica kernels use: (a) the round trip of an 8-byte doorbell between the leader's kernel and every other rank's
+    kernel (system-scope stores into the peer's HBM: xGMI between GPUs); (b) the bandwidth of write-through 16-byte
+    peer stores into rank 1's ring for 64 B ... 32 MiB (the R1 push), next to the same stores into the own ring;
+    (c) with RCCL: send / recv between rank 0 and rank 1 for the same sizes.  Collective; destroys ring contents."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    L, h = m.eng.L, m.eng.h
+    out = {"doorbell_round_trip_us_p50": {}, "peer_store_GBps": {}, "own_store_GBps": {}, "rccl_send_recv_GBps": {}}
+    for r in range(1, world):
+        dist.barrier()
+        if rank == 0:
+            ns = np.zeros(300, dtype=np.uint32)
+            rc = L.apus_gpu_calib_pingpong(h, 0, r, 0, 300, r << 20, ns.ctypes.data, 8000)
+            out["doorbell_round_trip_us_p50"][str(r)] = float(np.percentile(ns[50:], 50)) / 1e3 if rc == 0 else None
+        elif rank == r:
+            L.apus_gpu_calib_pingpong(h, r, 0, 1, 300, r << 20, None, 8000)
+    dist.barrier()
+    sizes = [64, 4096, 65536, 1 << 20, 4 << 20, 32 << 20]
+    if rank == 0:
+        g = (C.c_float * 5)()
+        for sz in sizes:
+            if L.apus_gpu_calib_store_bw(h, 1, sz, 5, g) == 0:
+                out["peer_store_GBps"][str(sz)] = float(max(g))
+            if L.apus_gpu_calib_store_bw(h, 0, sz, 5, g) == 0:
+                out["own_store_GBps"][str(sz)] = float(max(g))
+    dist.barrier()
+    if backend == "nccl" and rank in (0, 1):
+        for sz in sizes[1:]:
+            t = torch.empty(sz, dtype=torch.uint8, device=m.device)
+            for it in range(4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if rank == 0:
+                    dist.send(t, dst=1)
+                else:
+                    dist.recv(t, src=0)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            if rank == 0:
+                out["rccl_send_recv_GBps"][str(sz)] = sz / dt / 1e9
+    dist.barrier()
+    vals = [v for v in out["doorbell_round_trip_us_p50"].values() if v]
+    out["doorbell_one_way_us"] = min(vals) / 2 if vals else None
+    pk = [v for v in out["peer_store_GBps"].values() if v]
+    out["peer_store_peak_GBps"] = max(pk) if pk else None
+    out["note"] = ("TEST MODE: every rank on ONE device -- the hops stay inside the device, no xGMI link is in these numbers" if one_dev else
+                   "rank 0's GPU <-> the other ranks' GPUs over xGMI")
+    return out
+
+
 def bench_multi(args):
-    """--gpus N (N >= 2): N replicas, one per GPU and process, logs peer-mapped over HIP IPC
-    (apus_amd/peers.py).  The leader (rank 0) runs the same batched step as at N=1; its kernels'
-    stores to the followers' HBM cross xGMI.  The followers are passive (as under one-sided RDMA):
-    they take part in the two timing barriers and afterwards check, from their own memory, that
-    every entry of every step was committed and applied.  APUS_GROUP_TRANSPORT=p2p (or a node
-    whose devices cannot map each other) selects the message-passing transport of
+    """--gpus N (N >= 2): one replica per GPU and process, logs peer-mapped over HIP IPC (apus_amd/peers.py), the
+    consensus round carried by the replica kernels (apus_amd/csrc/apus_replica.h): EVERY process runs the workgroups
+    of the replica it hosts -- the leader pushes only log bytes + one doorbell per round over its links, every follower
+    persists, writes its reply bytes and its round ACK back (R3) from its own kernel, the leader commits by majority
+    and rings the commit doorbells (R4), every follower applies on its own GPU.
+    N -> replicas: BASELINE asks for 1 / 3 / 5 / 7 replica GPUs; an even N runs N - 1 replicas and keeps the last
+    rank as a spare MACHINE that JOINs after the timed region (catch-up over xGMI, BASELINE configs[4]'s tail).
+    The line carries the placement (devices, peer-access matrix), the link calibration, the xGMI roofline with the
+    bytes actually shipped per link and entry, the lone-round latency, and the CPU baseline.  Every wait is bounded:
+    the process group's collectives time out, and a watchdog ends a rank that sits anywhere for too long.
+    APUS_GROUP_TRANSPORT=p2p (or devices that cannot map each other) selects the message-passing transport of
     apus_amd/distributed.py instead and says so in `config.mode`."""
+    import datetime
+    import faulthandler
     import torch
     import torch.distributed as dist
     from apus_amd import peers
+    faulthandler.dump_traceback_later(args.watchdog, exit=True)          # nothing here may hang the driver
     if os.environ.get("APUS_GROUP_TRANSPORT") == "p2p":
         from apus_amd.distributed import bench_group
         return bench_group(args)
-    rank, world, local, backend = peers.init_process_group_from_env(args.gpus)
-    n = world
-    tr = build_trace(args, n)
+    rank, world, local, backend = peers.init_process_group_from_env(args.gpus, timeout=datetime.timedelta(seconds=min(args.watchdog, 300)))
+    one_dev = bool(os.environ.get("APUS_DIST_ONE_DEVICE"))
+    n_rep = world if world % 2 == 1 else world - 1
+    spare = world - n_rep
+    red_dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
+    # ---- placement: one GPU per rank, who can reach whom
+    prop = torch.cuda.get_device_properties(local)
+    me = {"rank": rank, "device": local, "name": prop.name, "uuid": str(getattr(prop, "uuid", "")), "pci_bus_id": getattr(prop, "pci_bus_id", None)}
+    place = [None] * world
+    dist.all_gather_object(place, me)
+    distinct = len({(p_["device"], p_["uuid"]) for p_ in place}) == world
+    if not distinct and not one_dev:
+        raise RuntimeError(f"--gpus {world}: the ranks do not sit on {world} distinct devices: {place} (APUS_DIST_ONE_DEVICE=1 is the one-device test mode)")
+    nvis = torch.cuda.device_count()
+    peer_matrix = [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(nvis)] for i in range(nvis)] if rank == 0 else None
+    tr = build_trace(args, n_rep)
     try:
-        m = peers.PeerMember(n, rank, local, tr.log_len)
+        m = peers.PeerMember(world, rank, local, tr.log_len, configured=n_rep)
     except peers.PeerMappingUnavailable as exc:
         print(f"[bench] rank {rank}: peer mapping unavailable ({exc}); falling back to the p2p transport", file=sys.stderr)
         from apus_amd.distributed import bench_group
         return bench_group(args, initialised=(rank, world, local, backend))
     eng = m.eng
     n_entries = len(tr.reqs)
-    red_dev = m.device if backend == "nccl" else torch.device("cpu")
-    calls, gid = None, None
+    # ---- calibrate the links first (the reference's LogGP probes), then start from a clean slate
+    calib = None
+    if not args.no_calibration:
+        try:
+            calib = _calibrate_links(m, world, rank, backend, one_dev)
+        except Exception as exc:
+            print(f"[bench] rank {rank}: link calibration failed: {exc!r}", file=sys.stderr)
+        eng.reset()
+        eng.sync()
+        dist.barrier()
     m.elect(0)
-    if m.is_leader:
-        eng.stage_trace(tr)
-        calls = step_calls(tr, eng)
-        issue(eng, calls)                        # one eager step: pages in, validates
-        eng.sync(); eng.check_status()
-        if not args.eager:
-            eng.capture_begin(); issue(eng, calls); gid = eng.capture_end()
+    eng.stage_trace(tr)
+    cmds = _rep_step_cmds(tr, eng)
+    grid = (args.rep_append, args.rep_fwork)
+    if one_dev and grid == (0, 0):
+        grid = (max(8, 96 // world), max(4, 96 // world))          # (all ranks share the one device's workgroup slots)
 
-    def run_step():
-        if gid is not None:
-            eng.graph_launch(gid)
-        else:
-            issue(eng, calls)
+    def step():
+        for c in cmds:
+            if c[0] == "run":
+                eng.rep_run(c[1], c[2])
+            else:
+                eng.rep_prune()
 
     def mark():
+        # every rank's kernels are RESIDENT here (they are the replicas): a device-wide synchronize would wait for them to
+        # leave.  The drain is the synchronisation point -- it returns once everything issued is in every ring, committed
+        # and applied by the leader (the followers' applied counts are checked from their own HBM afterwards)
         if m.is_leader:
-            eng.sync()
-        torch.cuda.synchronize()
+            eng.rep_drain(timeout_ms=120000)
         dist.barrier()
         return time.perf_counter()
 
+    # ---- lone rounds first: the consensus-round latency with every follower on its own GPU
+    lat = None
+    m.rep_begin(*grid)
+    if m.is_leader and not args.no_latency:
+        reqs64 = np.ascontiguousarray(tr.reqs[16:16 + 64])
+        hl = eng.rep_roundtrip_ns(reqs64, tr.arena, 300) / 1e3
+        eng.rep_drain()
+    m.rep_end()
+    if m.is_leader and not args.no_latency:
+        la, ls = eng.rep_latency_appended_ns(), eng.rep_latency_ns()
+        lat = {"appended_to_committed_and_applied_us_p50": float(np.percentile(la[20:], 50)) / 1e3 if len(la) > 20 else None,
+               "sequenced_to_committed_and_applied_us_p50": float(np.percentile(ls[20:], 50)) / 1e3 if len(ls) > 20 else None,
+               "host_submit_to_highest_rec_us_p50_64_entries": float(np.percentile(hl[40:], 50))}
+    lone = 300 * 64 if (m.is_leader and not args.no_latency) else 0
+    lone_t = torch.tensor([float(lone)], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(lone_t, op=dist.ReduceOp.MAX)
+    lone = int(lone_t.item())
+    # ---- the timed region: K steps between two barriers, every rank's kernels resident
+    m.rep_begin(*grid)
     if m.is_leader:
+        step()                                  # one untimed step: pages in, validates
         for _ in range(args.warmup):
-            run_step()
+            step()
     t0 = mark()
     if m.is_leader:
         for _ in range(args.steps):
-            run_step()
+            step()
     t1 = mark()
+    m.rep_end()
     t = torch.tensor([t1 - t0], dtype=torch.float64, device=red_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    # verification, every rank from its own HBM
-    total = (1 + args.warmup + args.steps) * n_entries
-    o = eng.offsets(rank)
-    applied = eng.counters(rank)["highest_rec"] if m.is_leader else int(eng.hdr_words(rank)[16])
-    good = (o["commit"] == o["end"] == o["apply"]) and applied == total and (not m.is_leader or eng.status() == 0)
-    if not good:
-        print(f"[bench] rank {rank}: verification failed: offsets={o} applied={applied} expected={total}", file=sys.stderr)
+    if m.is_leader:
+        eng.quiesce()
+    m.settle()
+    # ---- verification, every rank from its own HBM
+    total = lone + (1 + args.warmup + args.steps) * n_entries
+    good = True
+    if rank < n_rep:
+        o = eng.offsets(rank)
+        applied = eng.counters(rank)["highest_rec"] if m.is_leader else int(eng.hdr_words(rank)[16])
+        good = (o["commit"] == o["end"] == o["apply"]) and applied == total and (not m.is_leader or eng.status() == 0)
+        if not good:
+            print(f"[bench] rank {rank}: verification failed: offsets={o} applied={applied} expected={total} status={eng.status_names()}", file=sys.stderr)
     ok = torch.tensor([1.0 if good else 0.0], device=red_dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    # ---- the spare machine joins: catch-up of the whole log range over the link
+    join = None
+    if spare and n_rep < 2:
+        join = {"skipped": "a group of one server has no follower to take the state-machine snapshot from (dare_server.c:604-651): the spare machine stays out"}
+    elif spare and not args.no_join:
+        try:
+            log_bytes = 0
+            if m.is_leader:
+                o = eng.offsets(0)
+                log_bytes = (o["end"] - o["head"]) % tr.log_len or tr.log_len
+            tj0 = time.perf_counter()
+            m.join(n_rep)
+            if m.is_leader:
+                eng.sync()
+            dist.barrier()
+            tj = time.perf_counter() - tj0
+            if m.is_leader:
+                join = {"ms": tj * 1e3, "log_bytes": int(log_bytes), "catch_up_GBps": log_bytes / tj / 1e9,
+                        "note": "apus_gpu_join end to end across processes: CONFIG entries + passes, the joiner's ring cleared, log range + "
+                                "directory copied into the joiner's HBM by k_join_copy through the mapping, its first persist / apply passes"}
+            if backend == "nccl":
+                # the same bytes as ONE RCCL send / recv on a side stream, for comparison
+                nb = torch.tensor([float(log_bytes)], dtype=torch.float64, device=red_dev)
+                dist.broadcast(nb, src=0)
+                if rank in (0, n_rep):
+                    buf = torch.empty(int(nb.item()), dtype=torch.uint8, device=m.device)
+                    side = torch.cuda.Stream()
+                    with torch.cuda.stream(side):
+                        torch.cuda.synchronize()
+                        ts = time.perf_counter()
+                        if rank == 0:
+                            dist.send(buf, dst=n_rep)
+                        else:
+                            dist.recv(buf, src=0)
+                        side.synchronize()
+                        tr_ = time.perf_counter() - ts
+                    if rank == 0 and join is not None:
+                        join["rccl_send_recv_same_bytes_ms"] = tr_ * 1e3
+        except Exception as exc:
+            print(f"[bench] rank {rank}: join measurement failed: {exc!r}", file=sys.stderr)
     out = None
-    if m.is_leader:
-        eng.set_timing(True)
-        for _ in range(args.steps):
-            issue(eng, calls)
-        eng.sync()
-        k_ms, k_launches = eng.kernel_time(0)
-        eng.set_timing(False)
-    m.settle()
     if rank == 0:
         E = 64 + args.payload
         value = n_entries * args.steps / dt
-        k_avg_s = (k_ms / 1e3) / max(k_launches, 1)
-        per_launch = n_entries * args.steps / max(k_launches, 1)
-        link = E * per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
-        one_dev = bool(os.environ.get("APUS_DIST_ONE_DEVICE"))
+        rounds_per_step = sum(c[2] for c in cmds if c[0] == "run")
+        link_bytes_per_entry = E + 64.0 * rounds_per_step / n_entries           # log bytes + one 64-byte doorbell per round
+        link = value * link_bytes_per_entry / 1e9
         out = {
             "metric": "committed entries/sec", "value": value, "unit": "entries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{n} replicas, one per GPU and process, {n_entries} entries/step of {args.payload} B, "
-                                   f"rounds of {args.batch}, prune tick every 8 MiB, 64 MiB rings",
-                       "mode": ("peer-mapped logs (HIP IPC): the leader's kernels store into the followers' HBM"
-                                + (" -- TEST MODE, every rank on device 0" if one_dev else " over xGMI")
-                                + ("; hipGraph replay of one step" if gid is not None else "; eager launches")),
-                       "replicas": n, "entry_bytes": E, "launches_per_step": len(calls)},
+            "config": {"workload": f"{n_rep} replicas, one per GPU and process" + (f" (+ {spare} spare machine that JOINs after the timed region)" if spare else "")
+                                   + f", {n_entries} entries/step of {args.payload} B, rounds of {args.batch}, prune tick every 8 MiB, 64 MiB rings",
+                       "mode": ("replica kernels: every process runs its replica's own workgroups; log bytes + one doorbell per round pushed through "
+                                "HIP-IPC mappings, reply bytes and round ACKs written back by the followers' kernels, commit by majority"
+                                + (" -- TEST MODE, every rank on device 0 (no xGMI hop)" if one_dev else " over xGMI")),
+                       "replicas": n_rep, "spare_machines": spare, "entry_bytes": E, "workgroups": {"leader_append": grid[0], "per_follower": grid[1]}},
             "verified": bool(ok.item() == 1),
-            "roofline": {"bound": "xgmi", "achieved": link, "peak": XGMI_LINK_GBS, "unit": "GB/s",
-                         "frac": link / XGMI_LINK_GBS, "traffic": None, "kernel": "k_step" if BATCH else "k_call",
-                         "avg_launch_us": k_avg_s * 1e6, "launches": k_launches, "entries_per_launch": per_launch,
-                         "note": "per leader->follower link: E bytes per entry (log bytes; the 12-B directory slot and 32-B "
-                                 "apply record per entry ride along) over the dominant kernel's launch time, against ONE xGMI link"},
+            "placement": {"ranks": place, "distinct_devices": distinct, "visible_devices": nvis, "peer_access_matrix": peer_matrix,
+                          "collective_backend": backend, "ranks_in_group": world},
+            "link_calibration": calib,
+            "roofline": {"bound": "xgmi", "achieved": link, "peak": XGMI_LINK_GBS, "unit": "GB/s", "frac": link / XGMI_LINK_GBS,
+                         "traffic": None, "kernel": "k_replica", "bytes_per_entry": link_bytes_per_entry,
+                         "bytes_per_link_per_step": link_bytes_per_entry * n_entries,
+                         "note": "per leader->follower link: E log bytes per entry + one 64-byte doorbell per round (nothing derived crosses: directory, "
+                                 "apply records and ACK bookkeeping are built by the follower's own kernel); against ONE xGMI link (153 GB/s), "
+                                 "each follower sits on its own link; back: 1 reply byte per entry + 1 round ACK granule and the commit doorbell"
+                                 + ("; TEST MODE: nothing crossed a link" if one_dev else ""),
+                         "measured_peer_store_peak": calib.get("peer_store_peak_GBps") if calib else None},
+            "p50_round_latency_us": lat["appended_to_committed_and_applied_us_p50"] if lat else None,
+            "latency": lat,
+            "join_catch_up": join,
         }
+        if lat and calib and calib.get("doorbell_one_way_us"):
+            out["latency"]["floor_two_doorbell_hops_us"] = 2 * calib["doorbell_one_way_us"]
         if not args.no_cpu:
             try:
-                out["cpu_baseline"] = cpu_baseline_reference(args, min(args.cpu_seconds, 8.0), group_size=n) or cpu_baseline_port(args, 4.0)
+                ref = None
+                try:
+                    ref = cpu_baseline_reference(args, min(args.cpu_seconds, 8.0), group_size=n_rep) if n_rep >= 3 else None
+                except Exception as exc:
+                    print(f"[bench] reference-as-is baseline failed: {exc!r}", file=sys.stderr)
+                out["cpu_baseline"] = ref or cpu_baseline_port(args, min(args.cpu_seconds, 4.0))
             except Exception as exc:
                 print(f"[bench] cpu baseline failed: {exc!r}", file=sys.stderr)
     m.close()
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
     return out
 
 
@@ -781,6 +938,11 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-ack-path", action="store_true", help="skip the second measurement without fused ACKs")
     ap.add_argument("--no-replica", action="store_true", help="skip the replica-kernel measurements")
+    ap.add_argument("--no-calibration", action="store_true", help="--gpus N: skip the link calibration")
+    ap.add_argument("--no-join", action="store_true", help="--gpus N (even): do not let the spare machine join")
+    ap.add_argument("--rep-append", type=int, default=0, help="--gpus N: append workgroups of the leader (0 = default)")
+    ap.add_argument("--rep-fwork", type=int, default=0, help="--gpus N: workgroups per follower (0 = default)")
+    ap.add_argument("--watchdog", type=int, default=420, help="--gpus N: seconds after which a rank that is still running ends itself")
     ap.add_argument("--no-batch", action="store_true", help="one launch per run_rounds call (k_call) instead of batches (k_step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()

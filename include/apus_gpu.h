@@ -291,6 +291,14 @@ int  apus_gpu_device_arch(int device, char *out, int cap);
  *   idle_ms : the leader's workgroups leave by themselves after this long without input
  *   peer_ms : bound of every device-side wait for a peer
  *   n_append, n_fwork : append workgroups of the leader / workgroups per follower (0 = defaults)   */
+/* Link calibration -- what the reference's rc_get_loggp_params (src/dare/dare_ibv_rc.c:3323-3739) measures for RDMA, for
+ * the path the replica kernels use: system-scope stores into a peer's HBM (xGMI between GPUs).  pingpong: `iters` 8-byte
+ * doorbell round trips between this process's replica `me` and the mapped replica `peer` (role 0 starts and gets the
+ * samples in ns, role 1 answers; both call at about the same time); store_bw: write-through 16-byte stores of `bytes`
+ * into `peer`'s ring, GB/s per pass (destroys the ring's contents: before the group starts, or reset afterwards). */
+int  apus_gpu_calib_pingpong(apus_engine_t *e, uint32_t me, uint32_t peer, uint32_t role, uint32_t iters, uint64_t base,
+                             uint32_t *out_ns, uint32_t timeout_ms);
+int  apus_gpu_calib_store_bw(apus_engine_t *e, uint32_t peer, uint64_t bytes, uint32_t iters, float *out_gbps);
 int  apus_gpu_set_leader(apus_engine_t *e, uint32_t leader);    /* a follower-only process: who leads (host mirror only, nothing is launched) */
 int  apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t peer_ms, uint32_t n_append, uint32_t n_fwork);
 int  apus_gpu_rep_park(apus_engine_t *e);     /* exit code of the run: 0 stop, 1 idle, 2 a wait timed out, 3 a follower had a gap */

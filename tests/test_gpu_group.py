@@ -39,3 +39,35 @@ def test_group_of_processes_matches_oracle(world, n_send, log_len):
     for r in res:
         assert r["ok"], f"rank {r['rank']}: {r.get('error')}\n{p.stderr[-2000:]}"
     assert len({r["end"] for r in res}) == 1
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 7, 8])
+def test_bench_gpus_n_dry_run_full_schema(n):
+    """`python bench.py --gpus N` as the driver starts it on an 8-GPU node, here in the one-device test mode (every
+    rank on GPU 0, handles over gloo): N -> 1 / 3 / 5 / 7 replicas (an even N keeps a spare machine that JOINs), every
+    process runs its replica's own kernels, and rank 0's line carries the whole schema -- placement, link calibration,
+    the xGMI roofline with the bytes shipped per link, the lone-round latency, the join, the CPU baseline -- verified."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--entries", "131072", "--cpu-seconds", "1",
+           "--watchdog", "240"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", APUS_DIST_BACKEND="gloo", APUS_DIST_ONE_DEVICE="1")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, f"rc={p.returncode}\n{p.stdout[-1500:]}\n{p.stderr[-4000:]}"
+    d = json.loads(lines[0])
+    replicas = n if n % 2 else n - 1
+    assert d["n_gpus"] == n and d["config"]["replicas"] == replicas and d["config"]["spare_machines"] == n - replicas
+    assert d["verified"] is True and d["value"] > 0 and d["metric"] == "committed entries/sec" and d["scaling"] == "weak"
+    assert d["roofline"]["bound"] == "xgmi" and d["roofline"]["kernel"] == "k_replica" and 0 < d["roofline"]["bytes_per_entry"] < 64 + 64 + 2
+    assert d["placement"]["ranks_in_group"] == n and len(d["placement"]["ranks"]) == n and d["placement"]["peer_access_matrix"]
+    cal = d["link_calibration"]
+    assert cal and all(v and v > 0 for v in cal["doorbell_round_trip_us_p50"].values()) and len(cal["doorbell_round_trip_us_p50"]) == n - 1
+    assert cal["peer_store_peak_GBps"] and cal["peer_store_peak_GBps"] > 1
+    if replicas > 1:
+        assert d["latency"]["appended_to_committed_and_applied_us_p50"] and d["p50_round_latency_us"] > 0
+    if n % 2 == 0 and replicas >= 3:
+        assert d["join_catch_up"] and d["join_catch_up"]["log_bytes"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    print(f"--gpus {n}: {d['value'] / 1e6:.0f} M entries/s, p50 {d['p50_round_latency_us']} us, doorbell rt {cal['doorbell_round_trip_us_p50']}, "
+          f"peer store peak {cal['peer_store_peak_GBps']:.0f} GB/s, join {d['join_catch_up']}")
