@@ -1001,6 +1001,14 @@ __global__ void k_set_roles(const EngDev E, uint64_t sid, uint32_t bitmask, uint
         fh[H_TAIL] = E.log_len;
         fh[H_CID_BITMASK] = bitmask;
     }
+    /* A term fence raised against this engine while it led an OLDER term (k_fence_check) ends here: it has won a
+     * term that no follower it pushes to is ahead of -- the reference's voters restore the log access of the server
+     * they vote for (rc_restore_log_access, dare_ibv_rc.c:2245-2290).  A follower that is still ahead (not reachable,
+     * so not given the new SID above) keeps the fence up. */
+    bool ahead = false;
+    for (uint32_t i = 0; i < E.group_size; i++)
+        if (i != E.leader && ((follow_mask >> i) & 1u) && E.rep[i].ring && (E.rep[i].hdr[H_SID] >> 9) > (sid >> 9)) ahead = true;
+    if (!ahead) { E.status[FENCE_WORD] = 0; atomicAnd(E.status, ~(1u << 2)); }
 }
 
 

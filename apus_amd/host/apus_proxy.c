@@ -32,6 +32,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/queue.h>
 #include <sys/socket.h>
 #include <time.h>
 #include <unistd.h>
@@ -55,12 +56,16 @@ typedef struct {
 static subq_t g_q;
 static pthread_once_t g_q_once = PTHREAD_ONCE_INIT;
 
+extern pthread_spinlock_t tailq_lock;          /* message.h:22 -- defined below, with the reference's queue */
 static void q_init(void)
 {
     memset(&g_q, 0, sizeof g_q);
     g_q.arena = malloc(Q_ARENA);
     pthread_spin_init(&g_q.lock, PTHREAD_PROCESS_PRIVATE);
 }
+/* `tailq_lock` is usable from the moment the library is loaded (the reference's proxy_init initialises it again,
+ * proxy.c:494, before any thread can hold it; it is never re-initialised later) */
+__attribute__((constructor)) static void tailq_lock_init(void) { pthread_spin_init(&tailq_lock, PTHREAD_PROCESS_PRIVATE); }
 
 /* caller holds the lock */
 static int q_push_locked(uint8_t type, uint16_t connection_id, uint64_t req_id, const void *buf, uint16_t len)
@@ -89,6 +94,44 @@ int apus_tailq_push(uint8_t type, uint16_t connection_id, uint64_t req_id, const
 }
 
 /* ------------------------------------------------------------------------- */
+/* The reference's submission queue under its own names (src/include/dare/message.h:5-22): `tailhead` and
+ * `tailq_lock` are the two globals its proxy.c fills (proxy.c:114-158) and its DARE thread drains
+ * (get_tailq_message, dare_ibv_ud.c:780-790).  They are defined and exported here with the reference's layout, so
+ * the reference's OWN proxy.c links against this library without a source change (INTEGRATION.md option B): whatever
+ * it queues is taken over by this library's DARE thread (apus_tailq_drain) and freed like the reference frees it. */
+struct tailq_cmd_t { uint16_t len; uint8_t cmd[87380]; };
+typedef struct tailq_cmd_t tailq_cmd_t;
+struct tailq_entry_t {
+    uint8_t type;
+    uint16_t connection_id;
+    uint64_t req_id;
+    tailq_cmd_t cmd;
+    TAILQ_ENTRY(tailq_entry_t) entries;
+};
+typedef struct tailq_entry_t tailq_entry_t;
+TAILQ_HEAD(apus_tailq_head_t, tailq_entry_t) tailhead = TAILQ_HEAD_INITIALIZER(tailhead);
+pthread_spinlock_t tailq_lock;
+_Static_assert(sizeof(tailq_entry_t) == 87416, "tailq_entry_t must keep the reference's layout (SURVEY.md section 10)");
+static int submit_one(uint8_t type, uint16_t connection_id, uint64_t req_id, const void *buf, uint16_t len);
+
+/* get_tailq_message (dare_ibv_ud.c:780-790): everything the reference's proxy queued, in order -> number taken */
+int apus_tailq_drain(void)
+{
+    if (TAILQ_EMPTY(&tailhead)) return 0;
+    int n = 0;
+    pthread_spin_lock(&tailq_lock);
+    while (!TAILQ_EMPTY(&tailhead)) {
+        tailq_entry_t *n3 = TAILQ_FIRST(&tailhead);
+        submit_one(n3->type, n3->connection_id, n3->req_id, n3->cmd.cmd, n3->cmd.len);
+        TAILQ_REMOVE(&tailhead, n3, entries);
+        free(n3);
+        n++;
+    }
+    pthread_spin_unlock(&tailq_lock);
+    return n;
+}
+
+/* ------------------------------------------------------------------------- */
 /* SMR core state (the reference keeps it in the global `data`, dare_server.c:69) */
 typedef struct {
     apus_engine_t *eng;
@@ -112,6 +155,19 @@ typedef struct {
 
 static smr_t g_smr;
 
+/* one request of the reference's queue into this library's admission path */
+static int submit_one(uint8_t type, uint16_t connection_id, uint64_t req_id, const void *buf, uint16_t len)
+{
+    smr_t *s = &g_smr;
+    if (s->live_replica && s->eng && s->ready > 0) {
+        uint64_t slot = 0; void *dst = NULL;
+        if (apus_gpu_rep_reserve(s->eng, len, &slot, &dst)) { s->failed = 1; return -1; }
+        if (len) memcpy(dst, buf, len);
+        return apus_gpu_rep_publish(s->eng, slot, dst, req_id, connection_id, type, len);
+    }
+    return apus_tailq_push(type, connection_id, req_id, buf, len);
+}
+
 int is_leader(void) { return g_smr.ready && g_smr.leader == g_smr.idx; }        /* dare_server.c:2299 */
 uint8_t get_node_id(void) { return (uint8_t)g_smr.idx; }                         /* dare_server.c:2304 */
 
@@ -129,6 +185,7 @@ void dare_ib_poll_tailq(void)
     smr_t *s = &g_smr;
     if (!s->eng || s->batch_n) return;
     pthread_once(&g_q_once, q_init);
+    apus_tailq_drain();                            /* what the reference's own proxy.c queued (message.h:20-22) */
     pthread_spin_lock(&g_q.lock);
     if (g_q.n) {
         memcpy(s->batch, g_q.reqs, sizeof(apus_req_t) * g_q.n);
@@ -354,6 +411,8 @@ void *dare_server_init(void *arg)
             /* the consensus loop runs on the device and the application threads feed it themselves: this thread
              * keeps the prune timer, hands out the upcalls and watches the resident kernel */
             leader_upcalls(*s->dev_hr);
+            static unsigned ref_queue_used;              /* the reference's own proxy.c feeds `tailhead`: busy-poll it like its DARE thread does */
+            if (apus_tailq_drain() > 0) ref_queue_used = 20000;
             if (!s->failed && apus_gpu_rep_full(s->eng)) {
                 fprintf(stderr, "[apus] the log is full: requests were dropped, admission is closed, the hooks are inert from here on\n");
                 s->failed = 1;
@@ -375,8 +434,8 @@ void *dare_server_init(void *arg)
                 apus_gpu_rep_prune(s->eng);
                 last_prune = t;
             }
-            struct timespec ts = {0, 100000};
-            nanosleep(&ts, NULL);
+            if (ref_queue_used) { ref_queue_used--; __builtin_ia32_pause(); }
+            else { struct timespec ts = {0, 100000}; nanosleep(&ts, NULL); }
             continue;
         }
         if (s->live_persist) {

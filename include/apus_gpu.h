@@ -115,7 +115,16 @@ typedef struct {
  * driven by another engine -- fences this leader off: APUS_ST_TERM_FENCE is raised and the launches behind
  * the check store nothing anywhere (the receiver-side QP reset of the reference, rc_revoke_log_access
  * src/dare/dare_ibv_rc.c:2156-2243, moved in front of the writer).  Always on in peer-mapped groups
- * (replicas imported with apus_gpu_import_replica); this flag turns it on for a single process. */
+ * (replicas imported with apus_gpu_import_replica); this flag turns it on for a single process.
+ *  - The fence ends when this engine wins a term again that none of the followers it pushes to is ahead of
+ *    (apus_gpu_elect / apus_gpu_become_leader: rc_restore_log_access, dare_ibv_rc.c:2245-2290).
+ *  - The check runs IN FRONT of a launch, not inside it: a follower that adopts a newer SID after the check (another
+ *    process's k_elect, apus_gpu_adopt_sid) is still written to by the launch behind it, and the kernels of JOIN, log
+ *    adjustment, forced pruning and the persistent kernel carry no check of their own.  The control plane must
+ *    therefore order an election behind the old leader's stream (apus_amd/peers.py: barrier + sync in elect() and
+ *    join()); without that the fence is advisory.  The replica kernels (apus_gpu_rep_*) fence on the RECEIVER's side
+ *    instead, like the reference: a follower's own workgroups do not acknowledge a round of a term older than their
+ *    SID's -- no reply byte, no ACK: nothing of it can commit. */
 #define APUS_F_TERM_FENCE 2u
 
 typedef struct apus_engine apus_engine_t;

@@ -73,6 +73,12 @@ uint8_t get_node_id(void);
  * proxy.c:147-158): one call enqueues an admitted request for the DARE thread.
  * Thread-safe; copies `len` bytes.  Returns 0, or -1 when the queue is full. */
 int apus_tailq_push(uint8_t type, uint16_t connection_id, uint64_t req_id, const void *buf, uint16_t len);
+/* The reference's own submission queue (src/include/dare/message.h:5-22) is exported under its names and with its
+ * layout -- `tailhead` (a TAILQ_HEAD of tailq_entry_t, 87416 bytes each) and `tailq_lock` -- so that the reference's
+ * proxy.c (proxy.c:114-158: malloc, fill, TAILQ_INSERT_TAIL under the spinlock) links against this library
+ * unchanged; this library's DARE thread drains it like get_tailq_message (dare_ibv_ud.c:780-790) and frees the nodes.
+ * Include the reference's message.h for the types; apus_tailq_drain() = one such drain by hand, returns the count. */
+int apus_tailq_drain(void);
 
 /* ---- additions of this build (tests, shutdown) ----------------------------------- */
 void     apus_proxy_shutdown(struct proxy_node_t *p);       /* stop the DARE thread and wait for it */

@@ -61,3 +61,52 @@ def test_headers_are_plain_c_and_cxx(tmp_path):
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", str(src)])
+
+
+def test_reference_submission_queue_symbols(tmp_path):
+    """message.h:20-22: `tailhead` and `tailq_lock` are exported with the reference's layout, so the reference's own
+    proxy.c binds without a source change.  Where the reference tree is present: a C program that includes the
+    reference's message.h (its tentative definitions become references to this library's objects), queues three
+    requests exactly as proxy.c:147-158 does, and lets the library drain them (get_tailq_message)."""
+    import subprocess
+    from apus_amd import build
+    lib = build.build()
+    L = ctypes.CDLL(lib)
+    for sym in ("tailhead", "tailq_lock"):
+        assert ctypes.c_char.in_dll(L, sym) is not None
+    ref = "/root/reference/src/include/dare/message.h"
+    if not os.path.exists(ref):
+        return
+    src = tmp_path / "q.c"
+    src.write_text(r"""
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "message.h"
+int apus_tailq_drain(void);
+int main(void)
+{
+    if (sizeof(tailq_entry_t) != 87416) return 2;
+    TAILQ_INIT(&tailhead);                                                          /* proxy.c:486 */
+    if (pthread_spin_init(&tailq_lock, PTHREAD_PROCESS_PRIVATE)) return 3;          /* proxy.c:494 */
+    for (int i = 0; i < 3; i++) {
+        tailq_entry_t *n2 = (tailq_entry_t *)malloc(sizeof(tailq_entry_t));      /* proxy.c:147-158 */
+        n2->req_id = (uint64_t)i + 1; n2->connection_id = 7; n2->type = 5; n2->cmd.len = 4;
+        memcpy(n2->cmd.cmd, "abcd", 4);
+        pthread_spin_lock(&tailq_lock);
+        TAILQ_INSERT_TAIL(&tailhead, n2, entries);
+        pthread_spin_unlock(&tailq_lock);
+    }
+    const int n = apus_tailq_drain();
+    printf("%d %d\n", n, TAILQ_EMPTY(&tailhead) ? 1 : 0);
+    return (n == 3 && TAILQ_EMPTY(&tailhead)) ? 0 : 1;
+}
+""")
+    exe = tmp_path / "q"
+    pkg = os.path.dirname(lib)
+    subprocess.check_call(["gcc", "-O1", "-fcommon", "-I", os.path.dirname(ref), str(src), "-o", str(exe), "-L", pkg, "-lapus_gpu",
+                           "-lpthread", f"-Wl,-rpath,{pkg}"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.split() == ["3", "1"], (r.returncode, r.stdout, r.stderr)

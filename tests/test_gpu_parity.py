@@ -794,6 +794,24 @@ def test_term_fence_a_deposed_leader_stores_nothing(eng_factory, batch):
     assert [eng.offsets(r) for r in range(3)] == before, "a fenced launch moved an offset"
     assert np.array_equal(eng.ring(0), ring0), "a fenced launch stored into the deposed leader's own log"
     assert eng.counters(2)["sid"] == (4 << 9) | 1
+    # fenced, then follower, then re-elected: the fence ends with the term this engine wins next (the voters restore
+    # the winner's log access, rc_restore_log_access dare_ibv_rc.c:2245-2290) -- it appends its blank CONFIG entry,
+    # replicates and commits again
+    bm = (1 << 3) - 1
+    assert eng.L.apus_gpu_become_leader(eng.h, 0, 6, bm) == 0
+    eng.term, eng.leader = 6, 0
+    eng.L.apus_gpu_clear_status.argtypes = [type(eng.h)]
+    if batch:
+        eng.batch_begin()
+    eng.run_rounds(20, 10)
+    if batch:
+        eng.batch_end()
+    eng.quiesce()
+    assert eng.status() == 0, f"the fence did not end with the new term: {eng.status_names()}"
+    after = [eng.offsets(r) for r in range(3)]
+    assert after[0]["end"] > before[0]["end"] and after[0]["commit"] == after[0]["end"], after[0]
+    assert all(o["end"] == after[0]["end"] and o["commit"] == after[0]["end"] for o in after), after
+    assert all(eng.counters(r)["sid"] >> 9 == 6 for r in range(3))
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 15])
