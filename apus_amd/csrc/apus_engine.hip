@@ -2240,7 +2240,7 @@ static int rep_push_cmd(apus_engine *e, uint32_t op, uint64_t a, uint64_t b)
     /* four self-tagged granules {command number + 1 : value}: the command is there once all four are */
     RepCmd &c = e->rh->cmd[e->r_cmd_tail % RC_CAP];
     const uint64_t tag = ((e->r_cmd_tail + 1) & 0xFFFFFFFFull) << 32;
-    const uint64_t vals[4] = { op, e->r_slot_tail & 0xFFFFFFFFull, a & 0xFFFFFFFFull, b & 0xFFFFFFFFull };
+    const uint64_t vals[4] = { op, __atomic_load_n(&e->r_slot_tail, __ATOMIC_ACQUIRE) & 0xFFFFFFFFull, a & 0xFFFFFFFFull, b & 0xFFFFFFFFull };
     for (int i = 3; i >= 0; i--) __atomic_store_n((uint64_t *)&c.g[i], tag | vals[i], __ATOMIC_RELEASE);
     e->r_cmd_tail++;
     pthread_spin_unlock(&e->r_lock);
@@ -2252,42 +2252,59 @@ static int rep_push_cmd(apus_engine *e, uint32_t op, uint64_t a, uint64_t b)
  * into the slot itself, a range of the pinned payload arena -- in a short critical section (two counters),
  * copies its payload there itself, then PUBLISHES the slot.  The leader's sequencer takes published slots in
  * slot order, up to 64 per round.  *dst = where the len payload bytes go. */
-static inline bool rep_reserve_locked(apus_engine *e, uint32_t len, uint64_t *slot, void **dst)
+/* Short payloads (<= R_INLINE bytes: they live in the slot itself) reserve WITHOUT a lock: one fetch-and-add hands out
+ * `n` consecutive slots -- their place in the log order -- then the caller waits until the ring has room for them (slots
+ * are consumed in order, so a producer only ever waits for producers in front of it).  What the slot remembers of the
+ * payload arena is its tail as read BEFORE the fetch-and-add: an arena allocation takes its slot number first and its
+ * bytes second (below), so no allocation of a LATER slot is included and the arena is never freed too early. */
+static inline int rep_reserve_inline(apus_engine *e, uint32_t n, uint64_t *first)
 {
-    const uint64_t done = e->rh->slots_done;
-    if (e->r_slot_tail - done >= RQ_CAP) return false;
-    if (len <= R_INLINE) {
-        *slot = e->r_slot_tail++;
-        e->r_slot_aend[*slot % RQ_CAP] = e->r_arena_tail;
-        *dst = (void *)e->rh->slot[*slot % RQ_CAP].pay;
-        return true;
+    const uint64_t atail = __atomic_load_n(&e->r_arena_tail, __ATOMIC_ACQUIRE);
+    const uint64_t s0 = __atomic_fetch_add(&e->r_slot_tail, (uint64_t)n, __ATOMIC_ACQ_REL);
+    const double t0 = mono_s();
+    while (s0 + n - e->rh->slots_done > RQ_CAP) {
+        if (e->rh->alive == 2) return APUS_E_STATE;
+        if (mono_s() - t0 > 5.0) return -1;
     }
+    for (uint32_t i = 0; i < n; i++) e->r_slot_aend[(s0 + i) % RQ_CAP] = atail;
+    *first = s0;
+    return 0;
+}
+
+/* a payload that goes into the pinned arena: slot number first, then the bytes (under the lock) */
+static inline int rep_reserve_arena(apus_engine *e, uint32_t len, uint64_t *slot, void **dst)
+{
     const uint64_t need = ((uint64_t)len + 15) & ~15ull;
-    uint64_t pos = e->r_arena_tail;
-    uint64_t phys = pos % RA_CAP;
-    if (phys + need + 16 > RA_CAP) { pos += RA_CAP - phys; phys = 0; }      /* the payload does not straddle the end */
-    if (phys == 0) { pos += 16; phys = 16; }                                 /* bytes -2, -1 of a payload must exist */
-    const uint64_t freed = done ? e->r_slot_aend[(done - 1) % RQ_CAP] : 0;
-    if (pos + need - freed > RA_CAP) return false;
-    *slot = e->r_slot_tail++;
-    e->r_arena_tail = pos + need;
-    e->r_slot_aend[*slot % RQ_CAP] = pos + need;
-    *dst = (void *)(e->rh->arena + phys);
-    return true;
+    const double t0 = mono_s();
+    pthread_spin_lock(&e->r_lock);
+    const uint64_t s0 = __atomic_fetch_add(&e->r_slot_tail, 1ull, __ATOMIC_ACQ_REL);
+    for (;;) {
+        const uint64_t done = e->rh->slots_done;
+        uint64_t pos = e->r_arena_tail;
+        uint64_t phys = pos % RA_CAP;
+        if (phys + need + 16 > RA_CAP) { pos += RA_CAP - phys; phys = 0; }      /* the payload does not straddle the end */
+        if (phys == 0) { pos += 16; phys = 16; }                                 /* bytes -2, -1 of a payload must exist */
+        const uint64_t freed = done ? e->r_slot_aend[(done - 1) % RQ_CAP] : 0;
+        if (s0 + 1 - done <= RQ_CAP && pos + need - freed <= RA_CAP) {
+            __atomic_store_n(&e->r_arena_tail, pos + need, __ATOMIC_RELEASE);
+            e->r_slot_aend[s0 % RQ_CAP] = pos + need;
+            *slot = s0;
+            *dst = (void *)(e->rh->arena + phys);
+            pthread_spin_unlock(&e->r_lock);
+            return 0;
+        }
+        if (e->rh->alive == 2 || mono_s() - t0 > 5.0) { pthread_spin_unlock(&e->r_lock); return e->rh->alive == 2 ? APUS_E_STATE : -1; }
+    }
 }
 
 extern "C" int apus_gpu_rep_reserve(apus_engine_t *e, uint32_t len, uint64_t *slot, void **dst)
 {
     if (!e || !e->r_running || !e->r_lead || !slot || !dst || len > 65535) return APUS_E_STATE;
-    const double t0 = mono_s();
-    for (;;) {
-        pthread_spin_lock(&e->r_lock);
-        const bool ok = rep_reserve_locked(e, len, slot, dst);
-        pthread_spin_unlock(&e->r_lock);
-        if (ok) return 0;
-        if (e->rh->alive == 2) return APUS_E_STATE;
-        if (mono_s() - t0 > 5.0) return -1;
-    }
+    if (len > R_INLINE) return rep_reserve_arena(e, len, slot, dst);
+    int rc = rep_reserve_inline(e, 1, slot);
+    if (rc) return rc;
+    *dst = (void *)e->rh->slot[*slot % RQ_CAP].pay;
+    return 0;
 }
 
 extern "C" int apus_gpu_rep_publish(apus_engine_t *e, uint64_t slot, const void *dst, uint64_t req_id, uint16_t clt_id, uint8_t type, uint16_t len)
@@ -2304,8 +2321,8 @@ extern "C" int apus_gpu_rep_publish(apus_engine_t *e, uint64_t slot, const void 
     return 0;
 }
 
-/* n requests: slots are reserved in blocks (one critical section per block), payloads copied and slots
- * published outside it */
+/* n requests: runs of short payloads take their slots with ONE fetch-and-add per block; payloads are copied and
+ * slots published by the caller's thread */
 extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uint32_t n, const uint8_t *arena, uint64_t arena_bytes)
 {
     if (!e || !reqs) return APUS_E_ARG;
@@ -2313,27 +2330,29 @@ extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uin
     for (uint32_t g = 0; g < n; g++)
         if (reqs[g].payload_off + reqs[g].len > arena_bytes) return APUS_E_ARG;
     constexpr uint32_t BLK = 64;
-    uint64_t slot[BLK]; void *dst[BLK];
     uint32_t g = 0;
-    const double t0 = mono_s();
     while (g < n) {
-        const uint32_t want = std::min(BLK, n - g);
-        uint32_t got = 0;
-        pthread_spin_lock(&e->r_lock);
-        while (got < want && rep_reserve_locked(e, reqs[g + got].len, &slot[got], &dst[got])) got++;
-        pthread_spin_unlock(&e->r_lock);
-        if (!got) {
-            if (e->rh->alive == 2) return APUS_E_STATE;
-            if (mono_s() - t0 > 5.0) return -1;
+        if (reqs[g].len > R_INLINE) {
+            uint64_t slot; void *dst;
+            int rc = rep_reserve_arena(e, reqs[g].len, &slot, &dst);
+            if (rc) return rc;
+            memcpy(dst, arena + reqs[g].payload_off, reqs[g].len);
+            if ((rc = apus_gpu_rep_publish(e, slot, dst, reqs[g].req_id, reqs[g].clt_id, reqs[g].type, reqs[g].len))) return rc;
+            g++;
             continue;
         }
-        for (uint32_t i = 0; i < got; i++) {
+        uint32_t run = 1;
+        while (run < BLK && g + run < n && reqs[g + run].len <= R_INLINE) run++;
+        uint64_t s0;
+        int rc = rep_reserve_inline(e, run, &s0);
+        if (rc) return rc;
+        for (uint32_t i = 0; i < run; i++) {
             const apus_req_t &q = reqs[g + i];
-            if (q.len) memcpy(dst[i], arena + q.payload_off, q.len);
-            int rc = apus_gpu_rep_publish(e, slot[i], dst[i], q.req_id, q.clt_id, q.type, q.len);
-            if (rc) return rc;
+            void *dst = (void *)e->rh->slot[(s0 + i) % RQ_CAP].pay;
+            if (q.len) memcpy(dst, arena + q.payload_off, q.len);
+            if ((rc = apus_gpu_rep_publish(e, s0 + i, dst, q.req_id, q.clt_id, q.type, q.len))) return rc;
         }
-        g += got;
+        g += run;
     }
     return 0;
 }
