@@ -210,6 +210,25 @@ def cpu_baseline_reference(args, seconds=12.0, group_size=3):
                       f"one thread, in-process verbs stand-in; {_cpu_model()}, nproc={os.cpu_count()})"}
 
 
+def cpu_baseline_configs0(seconds=10.0):
+    """BASELINE configs[0] as the reference runs it (benchmarks/run.sh:71-88,127): three
+    redis-server processes on this box's host cores, each under the reference's OWN interposer (spec_hooks.cpp,
+    proxy.c, db-interface.c, libdare: unmodified, -O0 as the reference builds them; oracle/_ref/interpose_ref_O0.so),
+    RDMA = process_vm_writev through the verbs stand-in ("CPU loopback (no RDMA/GPU)"), BerkeleyDB = a flat-file page
+    buffer, redis-benchmark -t set -d 64 at the leader with 1 and 50 clients.  A bounded sample."""
+    from oracle import procref
+    if not procref.available("O0"):
+        return None
+    r = procref.run("O0", 3, 0, (1, 50), 64, timeout=max(30, int(seconds * 6)), n_req_by_conns={1: 20000, 50: 60000})
+    plain = procref.unreplicated(40000, (1, 50), 64, timeout=60)
+    return {"value": (r.get("requests_per_s") or {}).get("50"), "unit": "SET requests/s (redis-benchmark -c 50)", "kind": "reference",
+            "cores": 3, "requests_per_s": r.get("requests_per_s"), "replicated_on_every_server": r.get("replicated"), "ok": r.get("ok"),
+            "error": r.get("error"), "unreplicated_redis_requests_per_s": plain,
+            "sample": f"3 x (redis-server 2.8.17 + the reference's interposer, unmodified, -O0) on {_cpu_model()}, nproc={os.cpu_count()}; "
+                      "20000 SETs with 1 client, 60000 with 50; RDMA = process_vm_writev between the three processes, BerkeleyDB = flat-file "
+                      "page buffer; the -O2 build of the reference does not complete a request (proxy.c:160 spins on a plain word)"}
+
+
 def cpu_baseline(args, seconds=12.0):
     """`cpu_baseline` = the reference itself when its library is there (kind "reference"),
     else the restated oracle (kind "port"); the other one rides along as `also`."""
@@ -223,10 +242,15 @@ def cpu_baseline(args, seconds=12.0):
         port["threads_3"] = cpu_baseline_port_mt(args, max(2.0, seconds / 4))
     except Exception as exc:
         print(f"[bench] threaded port baseline failed: {exc!r}", file=sys.stderr)
-    if ref is None:
-        return port
-    ref["also"] = port
-    return ref
+    out = port if ref is None else ref
+    if ref is not None:
+        ref["also"] = port
+    if not getattr(args, "no_configs0", False):
+        try:
+            out["configs0"] = cpu_baseline_configs0(seconds)
+        except Exception as exc:
+            print(f"[bench] configs[0] reference baseline failed: {exc!r}", file=sys.stderr)
+    return out
 
 
 def measure_ack_path(args, tr, n_rep):
@@ -370,6 +394,54 @@ def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True):
         eng.check_status()
     finally:
         eng.close()
+    return out
+
+
+def measure_configs0_gpu(args):
+    """BASELINE configs[0] on THIS engine: redis-server 2.8.17 (the reference's tarball, unmodified) under
+    LD_PRELOAD=libapus_interpose.so -- every socket read / accept / close goes through proxy_on_* into the replica
+    kernels (3 logical replicas on the one MI355X) and blocks until its entry is committed and applied --
+    redis-benchmark -t set -d 64 with 1 and 50 clients (benchmarks/run.sh:71-88,127).  Host-fed by construction; the
+    reference side of the same thing is cpu_baseline.configs0."""
+    import socket
+    import subprocess
+    import tempfile
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    hook = os.path.join(ROOT, "apus_amd", "libapus_interpose.so")
+    if not (os.path.exists(os.path.join(ref, "redis-server")) and os.path.exists(hook)):
+        return None
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    tmp = tempfile.mkdtemp(prefix="apus_c0_")
+    env = dict(os.environ, server_idx="0", group_size="3", APUS_GPU_LOG_LEN=str(1 << 26), LD_PRELOAD=hook, dare_log_file=os.path.join(tmp, "dare.log"))
+    clean = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    srv = subprocess.Popen([os.path.join(ref, "redis-server"), "--port", str(port), "--save", "", "--appendonly", "no"], cwd=tmp, env=env,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = {"requests_per_s": {}}
+    try:
+        t0 = time.time()
+        up = False
+        while time.time() - t0 < 90 and srv.poll() is None:
+            try:
+                socket.create_connection(("127.0.0.1", port), timeout=0.5).close(); up = True; break
+            except OSError:
+                time.sleep(0.2)
+        if not up:
+            return None
+        import re
+        for c, n in ((1, 20000), (50, 60000)):
+            b = subprocess.run([os.path.join(ref, "redis-benchmark"), "-p", str(port), "-t", "set", "-d", "64", "-n", str(n), "-c", str(c), "-q"],
+                               env=clean, capture_output=True, text=True, timeout=120)
+            m = re.search(r"SET:\s*([0-9.]+) requests per second", b.stdout)
+            out["requests_per_s"][str(c)] = float(m.group(1)) if (b.returncode == 0 and m) else None
+        subprocess.run([os.path.join(ref, "redis-cli"), "-p", str(port), "shutdown", "nosave"], env=clean, capture_output=True, text=True, timeout=60)
+        srv.wait(timeout=60)
+    finally:
+        if srv.poll() is None:
+            srv.kill()
+    out["value"] = out["requests_per_s"].get("50")
+    out["unit"] = "SET requests/s (redis-benchmark -c 50)"
+    out["note"] = ("redis-server under LD_PRELOAD=libapus_interpose.so, 3 logical replicas on one MI355X, every request blocks until committed "
+                   "by majority and applied (replica kernels, APUS_LIVE_MODE=replica); 20000 SETs with 1 client, 60000 with 50")
     return out
 
 
@@ -647,6 +719,11 @@ def bench_single(args):
             out["join_catch_up"] = measure_join(args)
         except Exception as exc:
             print(f"[bench] join measurement failed: {exc!r}", file=sys.stderr)
+    if not args.no_configs0:
+        try:
+            out["configs0_redis"] = measure_configs0_gpu(args)
+        except Exception as exc:
+            print(f"[bench] configs[0] (redis under LD_PRELOAD) failed: {exc!r}", file=sys.stderr)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
     return out
@@ -938,6 +1015,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-ack-path", action="store_true", help="skip the second measurement without fused ACKs")
     ap.add_argument("--no-replica", action="store_true", help="skip the replica-kernel measurements")
+    ap.add_argument("--no-configs0", action="store_true", help="skip the reference-as-is redis baseline (configs[0])")
     ap.add_argument("--no-calibration", action="store_true", help="--gpus N: skip the link calibration")
     ap.add_argument("--no-join", action="store_true", help="--gpus N (even): do not let the spare machine join")
     ap.add_argument("--rep-append", type=int, default=0, help="--gpus N: append workgroups of the leader (0 = default)")

@@ -25,8 +25,25 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <errno.h>
 #include <infiniband/verbs.h>
 #include "fabric.h"
+#ifdef FAB_PROC
+/* -DFAB_PROC: ONE SERVER PER PROCESS (BASELINE configs[0]: three redis-server processes under the reference's own
+ * interposer on one host, "CPU loopback (no RDMA/GPU)").  The same fabric, with its state in a shared-memory arena
+ * that every process maps at the same address (so the pointers in it mean the same everywhere), one process-shared
+ * lock around every verb, and the data movement of RDMA WRITE / READ / UD SEND done with process_vm_writev / readv
+ * against the process that owns the port.  The port of a process comes from the environment
+ * (server_idx, the reference's own variable).  A process that is gone answers like a dead port: RETRY_EXC_ERR. */
+#include <fcntl.h>
+#include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/uio.h>
+#include <unistd.h>
+#define FAB_BASE  ((void *)0x6f0000000000ull)
+#define FAB_BYTES (1ull << 30)
+#endif
 
 #define MAX_PORTS   16
 #define MAX_QPS     4096
@@ -66,18 +83,108 @@ typedef struct fport {
     struct ibv_device dev;
 } fport_t;
 
+#ifndef FAB_PROC
 static fport_t ports[MAX_PORTS];
 static fqp_t *qps[MAX_QPS];
 static fmr_t *mrs[MAX_MRS];
 static uint32_t next_qpn = 16, next_key = 100;
 static int current_port = -1;
+static struct fab_stats stats;
+#define FAB_LOCK()   ((void)0)
+#define FAB_UNLOCK() ((void)0)
+#define fab_malloc malloc
+#define fab_calloc calloc
+#define fab_free   free
+static inline int fab_put(int port, uint64_t raddr, const void *local, uint32_t len) { (void)port; memcpy((void *)(uintptr_t)raddr, local, len); return 0; }
+static inline int fab_get(int port, void *local, uint64_t raddr, uint32_t len) { (void)port; memcpy(local, (const void *)(uintptr_t)raddr, len); return 0; }
+static inline int fab_zero(int port, uint64_t raddr, uint32_t len) { (void)port; memset((void *)(uintptr_t)raddr, 0, len); return 0; }
+#else
+typedef struct fab_shared {
+    pthread_mutex_t mu;
+    volatile int ready;
+    size_t brk;                              /* bump allocator behind this struct */
+    fport_t ports_[MAX_PORTS];
+    int pid_of[MAX_PORTS];
+    fqp_t *qps_[MAX_QPS];
+    fmr_t *mrs_[MAX_MRS];
+    uint32_t next_qpn_, next_key_;
+    struct fab_stats stats_;
+} fab_shared_t;
+static fab_shared_t *G;
+static int current_port = -1;
+#define ports    (G->ports_)
+#define qps      (G->qps_)
+#define mrs      (G->mrs_)
+#define next_qpn (G->next_qpn_)
+#define next_key (G->next_key_)
+#define stats    (G->stats_)
+#define FAB_LOCK()   pthread_mutex_lock(&G->mu)
+#define FAB_UNLOCK() pthread_mutex_unlock(&G->mu)
+static void fab_attach(void)
+{
+    if (G) return;
+    const char *name = getenv("APUS_FAB_SHM");
+    if (!name || !*name) name = "/apus_fab";
+    int creator = 1;
+    int fd = shm_open(name, O_RDWR | O_CREAT | O_EXCL, 0600);
+    if (fd < 0) { creator = 0; fd = shm_open(name, O_RDWR, 0600); }
+    if (fd < 0) { perror("fabric: shm_open"); abort(); }
+    if (creator && ftruncate(fd, (off_t)FAB_BYTES)) { perror("fabric: ftruncate"); abort(); }
+    if (!creator) { struct stat st; for (int i = 0; i < 2000; i++) { if (!fstat(fd, &st) && (unsigned long long)st.st_size >= FAB_BYTES) break; usleep(1000); } }
+    void *m = mmap(FAB_BASE, FAB_BYTES, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED_NOREPLACE, fd, 0);
+    if (m != FAB_BASE) { perror("fabric: mmap at the agreed address"); abort(); }
+    close(fd);
+    G = (fab_shared_t *)m;
+    if (creator) {
+        pthread_mutexattr_t a; pthread_mutexattr_init(&a);
+        pthread_mutexattr_setpshared(&a, PTHREAD_PROCESS_SHARED);
+        pthread_mutexattr_setrobust(&a, PTHREAD_MUTEX_ROBUST);
+        pthread_mutex_init(&G->mu, &a);
+        G->brk = (sizeof(fab_shared_t) + 4095) & ~(size_t)4095;
+        G->next_qpn_ = 16; G->next_key_ = 100;
+        __sync_synchronize();
+        G->ready = 1;
+    } else while (!G->ready) usleep(1000);
+    const char *idx = getenv("server_idx");
+    current_port = idx ? atoi(idx) : 0;
+}
+static void *fab_malloc(size_t n)
+{
+    n = (n + 63) & ~(size_t)63;
+    if (G->brk + n > FAB_BYTES) { fprintf(stderr, "fabric: shared arena exhausted\n"); abort(); }
+    void *p = (char *)G + G->brk; G->brk += n;
+    return p;
+}
+static void *fab_calloc(size_t a, size_t b) { void *p = fab_malloc(a * b); memset(p, 0, a * b); return p; }
+static void fab_free(void *p) { (void)p; }
+/* data movement against the process that owns `port` */
+static int fab_put(int port, uint64_t raddr, const void *local, uint32_t len)
+{
+    if (port == current_port) { memcpy((void *)(uintptr_t)raddr, local, len); return 0; }
+    struct iovec l = { (void *)local, len }, r = { (void *)(uintptr_t)raddr, len };
+    return process_vm_writev(G->pid_of[port], &l, 1, &r, 1, 0) == (ssize_t)len ? 0 : -1;
+}
+static int fab_get(int port, void *local, uint64_t raddr, uint32_t len)
+{
+    if (port == current_port) { memcpy(local, (const void *)(uintptr_t)raddr, len); return 0; }
+    struct iovec l = { local, len }, r = { (void *)(uintptr_t)raddr, len };
+    return process_vm_readv(G->pid_of[port], &l, 1, &r, 1, 0) == (ssize_t)len ? 0 : -1;
+}
+static int fab_zero(int port, uint64_t raddr, uint32_t len)
+{
+    static const char z[64];
+    return fab_put(port, raddr, z, len > 64 ? 64 : len);
+}
+#endif
 static fab_write_hook_t write_hook;
 static void *write_hook_arg;
-static struct fab_stats stats;
 static int delay_completions;   /* 0: a completion is visible to the very next poll (default) */
 void fab_set_completion_delay(int on) { delay_completions = on; }
 
 /* ---- driver-facing control ---------------------------------------------------------- */
+#ifdef FAB_PROC
+void fab_reset(void) { }
+#else
 void fab_reset(void)
 {
     memset(ports, 0, sizeof ports);
@@ -89,24 +196,27 @@ void fab_reset(void)
     next_qpn = 16; next_key = 100; current_port = -1;
     memset(&stats, 0, sizeof stats);
 }
+#endif
 int  fab_enter(int port) { int prev = current_port; current_port = port; return prev; }
 void fab_leave(int prev) { current_port = prev; }
 int  fab_current(void) { return current_port; }
 void fab_set_write_hook(fab_write_hook_t h, void *arg) { write_hook = h; write_hook_arg = arg; }
+#ifndef FAB_PROC
 void fab_kill_port(int port) { if (port >= 0 && port < MAX_PORTS) ports[port].alive = 0; }
 int  fab_port_alive(int port) { return port >= 0 && port < MAX_PORTS && ports[port].alive; }
 void fab_hold_port(int port) { if (port >= 0 && port < MAX_PORTS) ports[port].held = 1; }
 int  fab_port_held(int port) { return port >= 0 && port < MAX_PORTS && ports[port].held; }
 const struct fab_stats *fab_get_stats(void) { return &stats; }
+#endif
 
 static void cq_push(fcq_t *cq, const struct ibv_wc *wc, int delayed)
 {
     if (cq->count == cq->cap) {            /* CQ overrun: grow (a real HCA would raise a fatal event) */
         int ncap = cq->cap * 2;
-        struct ibv_wc *nr = malloc(sizeof(*nr) * ncap);
-        uint64_t *nv = malloc(sizeof(*nv) * ncap);
+        struct ibv_wc *nr = fab_malloc(sizeof(*nr) * ncap);
+        uint64_t *nv = fab_malloc(sizeof(*nv) * ncap);
         for (int i = 0; i < cq->count; i++) { nr[i] = cq->ring[(cq->head + i) % cq->cap]; nv[i] = cq->visible_at[(cq->head + i) % cq->cap]; }
-        free(cq->ring); free(cq->visible_at); cq->ring = nr; cq->visible_at = nv; cq->cap = ncap; cq->head = 0;
+        fab_free(cq->ring); fab_free(cq->visible_at); cq->ring = nr; cq->visible_at = nv; cq->cap = ncap; cq->head = 0;
     }
     cq->ring[(cq->head + cq->count) % cq->cap] = *wc;
     cq->visible_at[(cq->head + cq->count) % cq->cap] = ports[cq->port].epoch + (delayed ? 1 : 0);
@@ -152,11 +262,11 @@ static enum ibv_wc_status rc_execute(fqp_t *src, int opcode, uint64_t local,
     if (!m) return IBV_WC_REM_ACCESS_ERR;
     if (opcode == IBV_WR_RDMA_WRITE) {
         if (!(m->access & IBV_ACCESS_REMOTE_WRITE)) return IBV_WC_REM_ACCESS_ERR;
-        memcpy((void *)(uintptr_t)raddr, (const void *)(uintptr_t)local, len);
+        if (fab_put(tport, raddr, (const void *)(uintptr_t)local, len)) return IBV_WC_RETRY_EXC_ERR;
         stats.rc_writes++; stats.rc_write_bytes += len;
     } else {
         if (!(m->access & IBV_ACCESS_REMOTE_READ)) return IBV_WC_REM_ACCESS_ERR;
-        memcpy((void *)(uintptr_t)local, (const void *)(uintptr_t)raddr, len);
+        if (fab_get(tport, (void *)(uintptr_t)local, raddr, len)) return IBV_WC_RETRY_EXC_ERR;
         stats.rc_reads++;
     }
     return IBV_WC_SUCCESS;
@@ -175,19 +285,29 @@ static void rc_finish(fqp_t *src, uint64_t wr_id, int opcode, int signaled, enum
     if (opcode == IBV_WR_RDMA_WRITE && write_hook) write_hook(write_hook_arg, src->port, tport, raddr, len);
 }
 
+#ifndef FAB_PROC
 void fab_release_port(int port) { if (port >= 0 && port < MAX_PORTS) ports[port].held = 0; }
+#endif
 
 /* ---- device ---------------------------------------------------------------------------- */
 struct ibv_device **ibv_get_device_list(int *num)
 {
+#ifdef FAB_PROC
+    fab_attach();
+    FAB_LOCK();
+#endif
     int port = current_port;
-    if (port < 0 || port >= MAX_PORTS) { if (num) *num = 0; return NULL; }
+    if (port < 0 || port >= MAX_PORTS) { if (num) *num = 0; FAB_UNLOCK(); return NULL; }
     fport_t *p = &ports[port];
     if (!p->used) {
         p->used = 1; p->alive = 1; p->held = 0;
         snprintf(p->dev.name, sizeof p->dev.name, "fab%d", port);
         p->dev.fab_port = port;
     }
+#ifdef FAB_PROC
+    G->pid_of[port] = (int)getpid();
+#endif
+    FAB_UNLOCK();
     struct ibv_device **l = calloc(2, sizeof *l);
     l[0] = &p->dev;
     if (num) *num = 1;
@@ -238,38 +358,48 @@ int ibv_dealloc_pd(struct ibv_pd *p) { free(p); return 0; }
 
 struct ibv_mr *ibv_reg_mr(struct ibv_pd *pd, void *addr, size_t length, int access)
 {
-    if (next_key >= MAX_MRS) { errno = ENOMEM; return NULL; }
-    fmr_t *m = calloc(1, sizeof *m);
+    FAB_LOCK();
+    if (next_key >= MAX_MRS) { FAB_UNLOCK(); errno = ENOMEM; return NULL; }
+    fmr_t *m = fab_calloc(1, sizeof *m);
     m->pub.context = pd->context; m->pub.pd = pd; m->pub.addr = addr; m->pub.length = length;
     m->pub.lkey = m->pub.rkey = m->pub.handle = next_key;
     m->port = pd->context->fab_port; m->access = access; m->live = 1;
     mrs[next_key++] = m;
+    FAB_UNLOCK();
     return &m->pub;
 }
 int ibv_dereg_mr(struct ibv_mr *mr)
 {
     fmr_t *m = (fmr_t *)mr;
+    FAB_LOCK();
     if (m->pub.rkey < MAX_MRS && mrs[m->pub.rkey] == m) mrs[m->pub.rkey] = NULL;
-    m->live = 0; free(m);
+    m->live = 0; fab_free(m);
+    FAB_UNLOCK();
     return 0;
 }
 
 struct ibv_cq *ibv_create_cq(struct ibv_context *c, int cqe, void *ctx, struct ibv_comp_channel *ch, int vec)
 {
     (void)ch; (void)vec;
-    fcq_t *q = calloc(1, sizeof *q);
+    FAB_LOCK();
+    fcq_t *q = fab_calloc(1, sizeof *q);
     q->pub.context = c; q->pub.cq_context = ctx; q->pub.cqe = cqe; q->pub.fab = q;
     q->cap = cqe < 64 ? 64 : (cqe > 4096 ? 4096 : cqe);
-    q->ring = malloc(sizeof(struct ibv_wc) * q->cap);
-    q->visible_at = malloc(sizeof(uint64_t) * q->cap);
+    q->ring = fab_malloc(sizeof(struct ibv_wc) * q->cap);
+    q->visible_at = fab_malloc(sizeof(uint64_t) * q->cap);
     q->port = c->fab_port;
+    FAB_UNLOCK();
     return &q->pub;
 }
-int ibv_destroy_cq(struct ibv_cq *cq) { fcq_t *q = (fcq_t *)cq; free(q->ring); free(q->visible_at); free(q); return 0; }
+int ibv_destroy_cq(struct ibv_cq *cq) { fcq_t *q = (fcq_t *)cq; FAB_LOCK(); fab_free(q->ring); fab_free(q->visible_at); fab_free(q); FAB_UNLOCK(); return 0; }
 
 int ibv_poll_cq(struct ibv_cq *cq, int n, struct ibv_wc *wc)
 {
     fcq_t *q = (fcq_t *)cq;
+#ifdef FAB_PROC
+    if (!q->count) return 0;                          /* (the common case of a polling loop: no lock) */
+#endif
+    FAB_LOCK();
     fport_t *P = &ports[q->port];
     if (!P->last_was_post || !delay_completions) P->epoch++;
     P->last_was_post = 0;
@@ -279,10 +409,13 @@ int ibv_poll_cq(struct ibv_cq *cq, int n, struct ibv_wc *wc)
         q->head = (q->head + 1) % q->cap;
         q->count--;
     }
+    FAB_UNLOCK();
+#ifndef FAB_PROC
     if (!k && ++q->empty_polls > 200000000ull) {
         fprintf(stderr, "fabric: port %d spins on an empty CQ (a completion that a held/dead peer will never produce)\n", q->port);
         abort();
     }
+#endif
     return k;
 }
 
@@ -290,29 +423,34 @@ struct ibv_qp *ibv_create_qp(struct ibv_pd *pd, struct ibv_qp_init_attr *ia)
 {
     /* find_max_inline (dare_ibv.c:672) probes downward from 1 MiB: accept <= 256 B like a ConnectX */
     if (ia->cap.max_inline_data > 256) { errno = EINVAL; return NULL; }
-    if (next_qpn >= MAX_QPS) { errno = ENOMEM; return NULL; }
-    fqp_t *q = calloc(1, sizeof *q);
+    FAB_LOCK();
+    if (next_qpn >= MAX_QPS) { FAB_UNLOCK(); errno = ENOMEM; return NULL; }
+    fqp_t *q = fab_calloc(1, sizeof *q);
     q->pub.context = pd->context; q->pub.pd = pd; q->pub.qp_context = ia->qp_context;
     q->pub.send_cq = ia->send_cq; q->pub.recv_cq = ia->recv_cq; q->pub.qp_type = ia->qp_type;
     q->pub.state = IBV_QPS_RESET; q->pub.qp_num = q->pub.handle = next_qpn; q->pub.fab = q;
     q->port = pd->context->fab_port; q->live = 1; q->cap = ia->cap;
     q->scq = (fcq_t *)ia->send_cq; q->rcq = (fcq_t *)ia->recv_cq;
     q->rq_cap = ia->cap.max_recv_wr ? (int)ia->cap.max_recv_wr : 1;
-    q->rq = calloc(q->rq_cap, sizeof *q->rq);
+    q->rq = fab_calloc(q->rq_cap, sizeof *q->rq);
     qps[next_qpn++] = q;
+    FAB_UNLOCK();
     return &q->pub;
 }
 int ibv_destroy_qp(struct ibv_qp *qp)
 {
     fqp_t *q = (fqp_t *)qp;
+    FAB_LOCK();
     if (q->pub.qp_num < MAX_QPS && qps[q->pub.qp_num] == q) qps[q->pub.qp_num] = NULL;
-    q->live = 0; free(q->rq); free(q);
+    q->live = 0; fab_free(q->rq); fab_free(q);
+    FAB_UNLOCK();
     return 0;
 }
 
 int ibv_modify_qp(struct ibv_qp *qp, struct ibv_qp_attr *a, int mask)
 {
     fqp_t *q = (fqp_t *)qp;
+    FAB_LOCK();
     if (mask & IBV_QP_STATE) {
         if (a->qp_state == IBV_QPS_RESET) {
             /* RESET clears every attribute and drops queued receives */
@@ -337,6 +475,7 @@ int ibv_modify_qp(struct ibv_qp *qp, struct ibv_qp_attr *a, int mask)
     if (mask & IBV_QP_TIMEOUT) q->attr.timeout = a->timeout;
     if (mask & IBV_QP_RETRY_CNT) q->attr.retry_cnt = a->retry_cnt;
     if (mask & IBV_QP_RNR_RETRY) q->attr.rnr_retry = a->rnr_retry;
+    FAB_UNLOCK();
     return 0;
 }
 int ibv_query_qp(struct ibv_qp *qp, struct ibv_qp_attr *a, int mask, struct ibv_qp_init_attr *ia)
@@ -357,8 +496,7 @@ static void ud_deliver(fqp_t *dst, fqp_t *src, const void *buf, uint32_t len)
     frecv_t r = dst->rq[dst->rq_head];
     dst->rq_head = (dst->rq_head + 1) % dst->rq_cap; dst->rq_count--;
     if (r.length < len + 40) { stats.ud_dropped++; return; }
-    memset((void *)(uintptr_t)r.addr, 0, 40);                  /* GRH */
-    memcpy((uint8_t *)(uintptr_t)r.addr + 40, buf, len);
+    if (fab_zero(dst->port, r.addr, 40) || fab_put(dst->port, r.addr + 40, buf, len)) { stats.ud_dropped++; return; }   /* GRH + payload */
     struct ibv_wc wc; memset(&wc, 0, sizeof wc);
     wc.wr_id = r.wr_id; wc.status = IBV_WC_SUCCESS; wc.opcode = IBV_WC_RECV; wc.byte_len = len + 40;
     wc.qp_num = dst->pub.qp_num; wc.src_qp = src->pub.qp_num; wc.slid = (uint16_t)(src->port + 1);
@@ -411,23 +549,27 @@ static int post_send_rc(fqp_t *q, struct ibv_send_wr *wr)
 int ibv_post_send(struct ibv_qp *qp, struct ibv_send_wr *wr, struct ibv_send_wr **bad)
 {
     fqp_t *q = (fqp_t *)qp;
+    FAB_LOCK();
     ports[q->port].last_was_post = 1;
     for (; wr; wr = wr->next) {
         int rc = q->pub.qp_type == IBV_QPT_UD ? post_send_ud(q, wr) : post_send_rc(q, wr);
-        if (rc) { if (bad) *bad = wr; return rc; }
+        if (rc) { if (bad) *bad = wr; FAB_UNLOCK(); return rc; }
     }
+    FAB_UNLOCK();
     return 0;
 }
 
 int ibv_post_recv(struct ibv_qp *qp, struct ibv_recv_wr *wr, struct ibv_recv_wr **bad)
 {
     fqp_t *q = (fqp_t *)qp;
+    FAB_LOCK();
     for (; wr; wr = wr->next) {
-        if (q->rq_count == q->rq_cap) { if (bad) *bad = wr; return ENOMEM; }
+        if (q->rq_count == q->rq_cap) { if (bad) *bad = wr; FAB_UNLOCK(); return ENOMEM; }
         frecv_t *r = &q->rq[(q->rq_head + q->rq_count) % q->rq_cap];
         r->wr_id = wr->wr_id; r->addr = wr->sg_list[0].addr; r->length = wr->sg_list[0].length;
         q->rq_count++;
     }
+    FAB_UNLOCK();
     return 0;
 }
 
@@ -458,6 +600,7 @@ const char *ibv_wc_status_str(enum ibv_wc_status s)
     }
 }
 
+#ifndef FAB_PROC
 int fab_pending_ud(int port)
 {
     int n = 0;
@@ -467,3 +610,4 @@ int fab_pending_ud(int port)
     }
     return n;
 }
+#endif

@@ -41,6 +41,7 @@ extern dare_log_entry_det_t last_applied_entry;
 extern ev_idle poll_event;
 extern ev_timer timer_event, hb_event, to_adjust_event, prune_event;
 
+#ifndef GLUE_PROC          /* (one server per process, oracle/Makefile `procref`: the real libev, no harness) */
 /* ------------------------------------------------------------------ 1. libev */
 static struct ev_loop the_loop;
 struct ev_loop *apus_ev_default_loop(void) { return &the_loop; }
@@ -55,6 +56,7 @@ ev_tstamp ev_now(struct ev_loop *loop) { return loop->now; }
 int  ev_run(struct ev_loop *loop, int flags) { (void)loop; (void)flags; return 0; }
 void ev_break(struct ev_loop *loop, int how) { (void)how; loop->broken = 1; }
 
+#endif
 /* ------------------------------------------------------------------ 2. libconfig */
 void config_init(config_t *c) { memset(c, 0, sizeof *c); }
 void config_destroy(config_t *c) { free(c->root.children); c->root.children = NULL; }
@@ -137,6 +139,44 @@ int config_setting_lookup_int64(const config_setting_t *g, const char *name, lon
     *v = strtoll(s, NULL, 0); return CONFIG_TRUE;
 }
 
+#ifdef GLUE_PROC
+/* the two top-level lookups src/config-comp/config-proxy.c makes (db_name, ip_address: strings; req_log, port: ints) */
+static const char *top_value(const config_t *c, const char *name)
+{
+    for (int i = 0; i < c->root.n_children; i++)
+        if (!c->root.children[i].is_group && !strcmp(c->root.children[i].name, name)) return c->root.children[i].value;
+    return NULL;
+}
+int config_lookup_int(const config_t *c, const char *path, int *v)
+{
+    const char *s = top_value(c, path);
+    if (!s || *s == '"' || strpbrk(s, ".eE")) return CONFIG_FALSE;
+    *v = (int)strtol(s, NULL, 0); return CONFIG_TRUE;
+}
+int config_lookup_string(const config_t *c, const char *path, const char **v)
+{
+    config_t *cc = (config_t *)c;
+    for (int i = 0; i < cc->root.n_children; i++) {
+        config_setting_t *st = &cc->root.children[i];
+        if (st->is_group || strcmp(st->name, path)) continue;
+        char *s = st->value;
+        if (*s != '"') return CONFIG_FALSE;
+        size_t n = strlen(s);
+        if (n >= 2 && s[n - 1] == '"') s[n - 1] = 0;           /* (in place: the quotes go) */
+        *v = s + 1; return CONFIG_TRUE;
+    }
+    return CONFIG_FALSE;
+}
+/* get_unique_slid() = hostname[21] - '0' (dare_ibv_ud.c:1523-1530) must be this server's LID = server_idx + 1:
+ * the reference assumes one server per host; here three share one */
+int gethostname(char *name, size_t len)
+{
+    const char *idx = getenv("server_idx");
+    if (len < 23) return -1;
+    memset(name, 'a', 21); name[21] = (char)('0' + (idx ? atoi(idx) : 0) + 1); name[22] = 0;
+    return 0;
+}
+#else
 /* ------------------------------------------------------------------ 4. libc names */
 static int my_index = -1;
 static void *kept_input;
@@ -307,3 +347,4 @@ int glue_all_connected(void)
     }
     return 1;
 }
+#endif

@@ -34,6 +34,8 @@ int  config_read_file(config_t *config, const char *filename);
 config_setting_t *config_lookup(const config_t *config, const char *path);
 int  config_setting_lookup_float(const config_setting_t *setting, const char *name, double *value);
 int  config_setting_lookup_int64(const config_setting_t *setting, const char *name, long long *value);
+int  config_lookup_int(const config_t *config, const char *path, int *value);                 /* config-proxy.c */
+int  config_lookup_string(const config_t *config, const char *path, const char **value);
 
 #define config_error_text(c) ((c)->error_text ? (c)->error_text : "")
 #define config_error_file(c) ((c)->error_file ? (c)->error_file : "")
