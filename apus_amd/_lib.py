@@ -104,6 +104,8 @@ SIGNATURES = {
     "apus_gpu_rep_latency": (C.c_int, [vp, vp, u32, C.POINTER(u32)]),
     "apus_gpu_rep_latency_appended": (C.c_int, [vp, vp, u32, C.POINTER(u32)]),
     "apus_gpu_rep_feed": (C.c_int, [vp, vp, u32, vp, u64, u32, C.c_double, u64, C.POINTER(u64)]),
+    "apus_gpu_rep_follower_progress": (C.c_int, [vp, u32, C.POINTER(u64)]),
+    "apus_gpu_rep_follower_stop": (C.c_int, [vp, u32]),
     "apus_gpu_rep_role_stats": (C.c_int, [vp, vp]),
     "apus_gpu_rep_roundtrip": (C.c_int, [vp, vp, u32, vp, u64, u32, vp]),
 }

@@ -94,6 +94,7 @@ struct apus_engine {
     RepHost *rh, *rh_dev;           /* pinned, coherent: the leader's request ring, command ring, progress words */
     RepLead *rl;                    /* leader-local hand-off state */
     RepFollow *rfs[APUS_MAX_SERVERS];
+    RepFHost *rfh[APUS_MAX_SERVERS], *rfh_dev[APUS_MAX_SERVERS];   /* pinned: a hosted follower's progress / stop words */
     hipStream_t rstream;
     bool r_running, r_lead;         /* a launch is resident; it carries the leader's workgroups */
     uint32_t r_follow_mask;
@@ -2216,6 +2217,12 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
         if (!e->rfs[f]) HIPCHK(hipMalloc((void **)&e->rfs[f], sizeof(RepFollow)));
         HIPCHK(hipMemsetAsync(e->rfs[f], 0, sizeof(RepFollow), e->rstream));
         A.FS[f] = e->rfs[f];
+        if (!e->rfh[f]) {
+            HIPCHK(hipHostMalloc((void **)&e->rfh[f], sizeof(RepFHost), hipHostMallocMapped | hipHostMallocCoherent));
+            HIPCHK(hipHostGetDevicePointer((void **)&e->rfh_dev[f], e->rfh[f], 0));
+        }
+        memset((void *)e->rfh[f], 0, sizeof(RepFHost));
+        A.FH[f] = e->rfh_dev[f];
     }
     const uint32_t grid = (lead_here ? 1 + n_append : 0) + popc(A.follow_mask) * n_fwork;
     if (!grid) return 0;                               /* nothing of this group runs here */
@@ -2402,6 +2409,24 @@ extern "C" int apus_gpu_rep_park(apus_engine_t *e)
     e->free_lb = 0;
     e->lag_possible = true;
     return code;
+}
+
+/* A follower's process while its run is resident: out[0] = entry slots applied, [1] = persisted, [2] = 1 running /
+ * 2 left / 0 not started, [3] = exit code.  (What its DARE thread replays into its own application.) */
+extern "C" int apus_gpu_rep_follower_progress(apus_engine_t *e, uint32_t replica, uint64_t out[4])
+{
+    if (!e || replica >= APUS_MAX_SERVERS || !out) return APUS_E_ARG;
+    RepFHost *h = e->rfh[replica];
+    if (!h) { out[0] = out[1] = out[2] = out[3] = 0; return 0; }
+    out[0] = h->n_apply; out[1] = h->n_end; out[2] = h->alive; out[3] = h->exit_code;
+    return 0;
+}
+/* ... and when its leader is gone (no park doorbell will come): ask the follower's workgroups to leave; then apus_gpu_rep_park */
+extern "C" int apus_gpu_rep_follower_stop(apus_engine_t *e, uint32_t replica)
+{
+    if (!e || replica >= APUS_MAX_SERVERS || !e->rfh[replica]) return APUS_E_ARG;
+    __atomic_store_n((uint64_t *)&e->rfh[replica]->stop, 1ull, __ATOMIC_RELEASE);
+    return 0;
 }
 
 /* tests only: a hosted follower whose workgroups are not launched -- a dead follower process that the leader still pushes to */

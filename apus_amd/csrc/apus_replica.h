@@ -168,8 +168,22 @@ struct RepFollow {                       /* follower-local (device memory, agent
 /* a follower's first workgroup: its retire / apply wavefronts' words in LDS */
 enum { F_END = 0, F_N_END, F_Q_RET, F_R_FINAL, F_STORE_COUNT, F_PEND_N, F_PEND_SLOT_END, F_EXIT, F_WORDS = 8 };
 
+/* host <-> one hosted follower: pinned, coherent.  A follower's process follows its replica's progress here while
+ * the run is resident (its DARE thread replays what is applied into its own application, proxy.c:341-439) and can
+ * ask its workgroups to leave when the leader is gone (nobody rings the park doorbell then). */
+struct RepFHost {
+    volatile uint64_t stop;              /* host -> kernel: leave at the next look                */
+    uint64_t pad0[7];
+    volatile uint64_t n_apply;           /* kernel -> host: entry slots applied                   */
+    volatile uint64_t n_end;             /*                 entry slots persisted                 */
+    volatile uint64_t alive;             /* 1 running, 2 left                                     */
+    volatile uint64_t exit_code;
+    uint64_t pad1[4];
+};
+
 struct RepArgs {
     RepHost *H;                          /* leader here: its pinned block                         */
+    RepFHost *FH[APUS_DEV_MAX_SERVERS];  /* followers hosted here: their pinned blocks            */
     RepLead *LS;
     RepFollow *FS[APUS_DEV_MAX_SERVERS]; /* followers hosted here                                 */
     uint32_t lead_here;                  /* 1: the first 1 + n_append workgroups are the leader's */
@@ -1422,6 +1436,8 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
     uint64_t final_q = ~0ull;
     uint64_t st_pass = 0, st_prog = 0, st_busy = 0;
     const uint64_t st_t0 = wall_clock64();
+    RepFHost *FHm = A.FH[me];
+    if (lane == 0 && FHm) { st_sys(&FHm->n_end, n_end); st_sys(&FHm->alive, 1); }
     for (;;) {
         bool progress = false;
         st_pass++;
@@ -1470,7 +1486,10 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
             s_f[F_END] = end; s_f[F_N_END] = n_end;
             s_f[F_Q_RET] = q_ret;                       /* (the apply wavefront reads F_Q_RET first) */
             st_sys(&lbox->persisted_by[me], n_end);
+            if (FHm) st_sys(&FHm->n_end, n_end);
         }
+        /* the host asks this follower to leave (its leader is gone: nobody will ring the park doorbell) */
+        if (!progress && FHm && final_q == ~0ull && (idle & 15) == 15 && ld_sys(&FHm->stop)) final_q = q_ret;
         /* ---- park? ---- */
         if (final_q != ~0ull && q_ret >= final_q) break;      /* everything that was sent is persisted */
         if (progress) { idle = 0; st_prog++; st_busy += wall_clock64() - st_p0; }
@@ -1551,7 +1570,10 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
                 q_app += p;
                 progress = true;
             }
-            if (q_app != t0 && lane == 0) { st_sys(&lbox->applied_by[me], n_apply); st_sys(&lbox->seqdone_by[me], q_app); }
+            if (q_app != t0 && lane == 0) {
+                st_sys(&lbox->applied_by[me], n_apply); st_sys(&lbox->seqdone_by[me], q_app);
+                if (A.FH[me]) st_sys(&A.FH[me]->n_apply, n_apply);
+            }
         }
         /* ---- park?  everything that was sent is persisted; the leader's last commit doorbell was rung before the
          *      park word: one more look at it, then leave ---- */
@@ -1577,8 +1599,10 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
         st_sys(&box->f_seq_next, q_ret);
         st_sys(&box->f_pend_slot0, n_end); st_sys(&box->f_pend_slot_end, pend_n ? s_f[F_PEND_SLOT_END] : 0ull); st_sys(&box->f_pend_sid, my_sid);
         st_sys(&box->f_exit, (uint64_t)exit_code + 1);
+        if (A.FH[me]) { st_sys(&A.FH[me]->n_apply, n_apply); st_sys(&A.FH[me]->exit_code, (uint64_t)exit_code); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         st_sys(&box->f_runs, my_run + 1);
+        if (A.FH[me]) st_sys(&A.FH[me]->alive, 2);
         if (exit_code) atomicOr(E.status, 1u << 4);
     }
 }

@@ -326,6 +326,11 @@ int  apus_gpu_rep_latency(apus_engine_t *e, uint32_t *out_ns, uint32_t cap, uint
 int  apus_gpu_rep_latency_appended(apus_engine_t *e, uint32_t *out_ns, uint32_t cap, uint32_t *n_out);   /* the round's bytes in every pushed ring -> committed + applied */
 int  apus_gpu_rep_feed(apus_engine_t *e, const apus_req_t *reqs, uint32_t n, const uint8_t *arena, uint64_t arena_bytes,
                        uint32_t n_threads, double seconds, uint64_t prune_every_reqs, uint64_t out[2]);      /* n_threads producers on the pinned ring */
+/* a process that hosts a follower, while its run is resident: progress of replica `replica` (out[0] entry slots applied,
+ * [1] persisted, [2] 1 running / 2 left / 0 never started, [3] exit code) -- what its DARE thread replays into its own
+ * application (proxy.c:341-439); and, when the leader is gone and nobody will ring the park doorbell: leave */
+int  apus_gpu_rep_follower_progress(apus_engine_t *e, uint32_t replica, uint64_t out[4]);
+int  apus_gpu_rep_follower_stop(apus_engine_t *e, uint32_t replica);
 int  apus_gpu_rep_role_stats(apus_engine_t *e, uint64_t out[16][8]);          /* diagnostics: passes / rounds / time of the serial roles of the last run */
 int  apus_gpu_rep_roundtrip(apus_engine_t *e, const apus_req_t *reqs, uint32_t n, const uint8_t *arena, uint64_t arena_bytes,
                             uint32_t iters, uint32_t *out_ns);
