@@ -29,11 +29,14 @@
 #include <netinet/tcp.h>
 #include <pthread.h>
 #include <signal.h>
+#include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/queue.h>
 #include <sys/socket.h>
+#include <sys/stat.h>
+#include <sys/types.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -145,6 +148,12 @@ typedef struct {
                                                 * their requests in the pinned multi-producer ring themselves, every replica runs its own workgroups */
     const volatile uint64_t *dev_hr;           /* proxy->highest_rec as the resident kernel publishes it (pinned host memory) */
     uint64_t upcalled;                         /* update_state upcalls delivered to a caller's own callback */
+    /* one PROCESS per server (APUS_GROUP_DIR): this process hosts replica `idx` only, the others are peer-mapped */
+    int group;                                 /* 1: group mode */
+    char group_dir[256];
+    pid_t peer_pid[APUS_MAX_SERVERS];
+    uint32_t alive_mask, bitmask;              /* servers whose process answers; cid.bitmask as this process knows it */
+    uint64_t replayed;                         /* follower: apply-stream slots handed to do_action so far */
     pthread_t thread;
     uint64_t applied_slot[APUS_MAX_SERVERS];   /* next apply-stream slot to hand to the upcalls */
     double prune_period_s;
@@ -300,7 +309,8 @@ static void dump_replicas(smr_t *s, const char *path)
 {
     FILE *f = fopen(path, "wb");
     if (!f) return;
-    apus_gpu_quiesce(s->eng);                      /* followers learn the newest commit (the lazy R4) */
+    if (!s->group || s->leader == s->idx)          /* (only the process that leads may drive the group's control blocks) */
+        apus_gpu_quiesce(s->eng);                  /* followers learn the newest commit (the lazy R4) */
     apus_gpu_sync(s->eng);
     const uint32_t st = apus_gpu_status(s->eng);
     uint64_t len = 0;
@@ -323,6 +333,207 @@ static void dump_replicas(smr_t *s, const char *path)
     fclose(f);
 }
 
+/* ------------------------------------------------------------------------- */
+/* One process per server (benchmarks/run.sh starts one redis + interposer per node; here: per GPU).  The control plane
+ * between the processes is a directory (APUS_GROUP_DIR): what the reference exchanges in UD messages -- MR addresses and
+ * rkeys (RC_SYN / SYNACK, dare_ibv_ud.c:1098-1380), "I follow you", "I lead term t" -- are small files written with
+ * rename(); any other transport would do.  The data plane is the replica kernels: every
+ * process runs the workgroups of the replica it hosts.  Election schedule: start-up = server 0 (the start-up ELECT of the
+ * pinned traces); after the leader's PROCESS is gone = the live server with the lowest index (the reference draws random
+ * timeouts, dare_server.c:1237-1250; a trace's ELECT(w) names the winner -- this is one legal schedule). */
+static void g_path(smr_t *s, char *out, size_t cap, const char *fmt, ...)
+{
+    va_list ap;
+    int n = snprintf(out, cap, "%s/", s->group_dir);
+    va_start(ap, fmt);
+    vsnprintf(out + n, cap - (size_t)n, fmt, ap);
+    va_end(ap);
+}
+static int g_write(smr_t *s, const void *buf, size_t len, const char *name)
+{
+    char tmp[480], dst[400];
+    g_path(s, dst, sizeof dst, "%s", name);
+    snprintf(tmp, sizeof tmp, "%s.tmp.%d", dst, (int)getpid());
+    FILE *f = fopen(tmp, "wb");
+    if (!f) return -1;
+    const int ok = fwrite(buf, 1, len, f) == len;
+    fclose(f);
+    if (!ok || rename(tmp, dst)) { unlink(tmp); return -1; }
+    return 0;
+}
+static int g_read(smr_t *s, void *buf, size_t len, const char *name)
+{
+    char src[400];
+    g_path(s, src, sizeof src, "%s", name);
+    FILE *f = fopen(src, "rb");
+    if (!f) return -1;
+    const int ok = fread(buf, 1, len, f) == len;
+    fclose(f);
+    return ok ? 0 : -1;
+}
+static int g_exists(smr_t *s, const char *name) { char pth[400]; struct stat st; g_path(s, pth, sizeof pth, "%s", name); return stat(pth, &st) == 0; }
+static int g_wait(smr_t *s, const char *name, double seconds)
+{
+    const double t0 = now_s();
+    while (!g_exists(s, name)) {
+        if (s->terminate || now_s() - t0 > seconds) return -1;
+        struct timespec ts = {0, 2000000}; nanosleep(&ts, NULL);
+    }
+    return 0;
+}
+static int g_alive(smr_t *s, uint32_t i) { return s->peer_pid[i] > 0 && (kill(s->peer_pid[i], 0) == 0 || errno == EPERM); }
+
+typedef struct { apus_ipc_replica_t ipc; int32_t pid; int32_t pad; } g_hello_t;
+
+/* RC_SYN / SYNACK once: export the replica this process hosts, map everybody else's */
+static int group_connect(smr_t *s)
+{
+    g_hello_t me;
+    memset(&me, 0, sizeof me);
+    if (apus_gpu_export_replica(s->eng, s->idx, &me.ipc)) return -1;
+    me.pid = (int32_t)getpid();
+    char name[64];
+    snprintf(name, sizeof name, "replica_%u.ipc", s->idx);
+    if (g_write(s, &me, sizeof me, name)) return -1;
+    s->peer_pid[s->idx] = getpid();
+    for (uint32_t i = 0; i < s->group_size; i++) {
+        if (i == s->idx) continue;
+        snprintf(name, sizeof name, "replica_%u.ipc", i);
+        if (g_wait(s, name, 120.0)) { fprintf(stderr, "[apus] server %u: server %u never showed up in %s\n", s->idx, i, s->group_dir); return -1; }
+        g_hello_t h;
+        if (g_read(s, &h, sizeof h, name) || h.ipc.replica != i) return -1;
+        if (apus_gpu_import_replica(s->eng, &h.ipc)) { fprintf(stderr, "[apus] server %u: cannot map server %u's replica\n", s->idx, i); return -1; }
+        s->peer_pid[i] = (pid_t)h.pid;
+    }
+    s->alive_mask = s->bitmask = (1u << s->group_size) - 1;
+    return 0;
+}
+
+static uint32_t rep_grid_env(const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t)atoi(v) : dflt; }
+
+/* the replica kernels of a term: followers first (their workgroups poll their mailboxes), then the leader */
+static int group_start_term(smr_t *s)
+{
+    char name[64];
+    const uint32_t na = rep_grid_env("APUS_REP_APPEND", 16), nf = rep_grid_env("APUS_REP_FWORK", 8);
+    if (s->leader != s->idx) {
+        if (apus_gpu_set_leader(s->eng, s->leader) || apus_gpu_rep_start(s->eng, 24u * 3600u * 1000u, 2000, na, nf)) return -1;
+        snprintf(name, sizeof name, "ready_%llu_%u", (unsigned long long)s->term, s->idx);
+        return g_write(s, "1", 1, name);
+    }
+    for (uint32_t i = 0; i < s->group_size; i++) {
+        if (i == s->idx || !((s->alive_mask >> i) & 1u) || !((s->bitmask >> i) & 1u)) continue;
+        snprintf(name, sizeof name, "ready_%llu_%u", (unsigned long long)s->term, i);
+        if (g_wait(s, name, 30.0)) fprintf(stderr, "[apus] leader %u: follower %u did not start its workgroups for term %llu\n", s->idx, i, (unsigned long long)s->term);
+    }
+    if (apus_gpu_rep_start(s->eng, 24u * 3600u * 1000u, 500, na, nf)) return -1;
+    s->dev_hr = apus_gpu_rep_highest_rec_ptr(s->eng);
+    s->upcalled = *s->dev_hr;
+    return 0;
+}
+
+/* a follower's apply_committed_entries upcalls (dare_server.c:1941-1955 -> proxy_do_action, proxy.c:341-439): what its
+ * own kernel has applied since the last look, replayed into the local application in log order */
+static void follower_upcalls(smr_t *s)
+{
+    uint64_t pr[4];
+    if (apus_gpu_rep_follower_progress(s->eng, s->idx, pr)) return;
+    static apus_apply_t recs[512];
+    static uint8_t *bytes;
+    if (!bytes) bytes = malloc(512u * (65536u + 64u) > (64u << 20) ? (64u << 20) : 512u * (65536u + 64u));
+    while (s->replayed < pr[0]) {
+        uint64_t n = pr[0] - s->replayed;
+        if (n > 512) n = 512;
+        if (apus_gpu_apply_records(s->eng, s->idx, s->replayed, n, recs)) return;
+        for (uint64_t i = 0; i < n; i++) {
+            if (recs[i].kind == 2 && s->in.do_action) {
+                if (recs[i].len) apus_gpu_read_ring(s->eng, s->idx, recs[i].off + 50, recs[i].len, bytes);
+                s->in.do_action(recs[i].clt_id, recs[i].type, recs[i].len, bytes, s->in.up_para);
+            }
+        }
+        s->replayed += n;
+    }
+}
+
+/* the leader's process is gone: park, agree on the survivors, the lowest live index wins the next term */
+static int group_failover(smr_t *s)
+{
+    char name[64];
+    const uint32_t old_leader = s->leader;
+    apus_gpu_rep_follower_stop(s->eng, s->idx);
+    apus_gpu_rep_park(s->eng);
+    follower_upcalls(s);
+    s->alive_mask &= ~(1u << old_leader);
+    for (uint32_t i = 0; i < s->group_size; i++) if (i != s->idx && !g_alive(s, i)) s->alive_mask &= ~(1u << i);
+    const uint64_t term = s->term + 2;
+    snprintf(name, sizeof name, "parked_%llu_%u", (unsigned long long)term, s->idx);
+    g_write(s, "1", 1, name);
+    uint32_t winner = s->group_size;
+    for (uint32_t i = 0; i < s->group_size; i++) if ((s->alive_mask >> i) & 1u && (s->bitmask >> i) & 1u) { winner = i; break; }
+    if (winner >= s->group_size) return -1;
+    if (winner == s->idx) {
+        /* nothing of the old term may still be running on a survivor when the votes are cast through the mappings */
+        for (uint32_t i = 0; i < s->group_size; i++) {
+            if (i == s->idx || !((s->alive_mask >> i) & 1u)) continue;
+            snprintf(name, sizeof name, "parked_%llu_%u", (unsigned long long)term, i);
+            if (g_wait(s, name, 20.0)) s->alive_mask &= ~(1u << i);           /* it does not answer: cut off */
+        }
+        uint64_t out[8] = {0};
+        const uint32_t live = s->alive_mask & s->bitmask;
+        if (apus_gpu_set_reachable(s->eng, live) || apus_gpu_elect(s->eng, winner, live, s->bitmask, out) || !out[0]) {
+            fprintf(stderr, "[apus] server %u: no majority for term %llu (%llu votes)\n", s->idx, (unsigned long long)term, (unsigned long long)out[4]);
+            return -1;
+        }
+        const uint32_t dead = s->bitmask & ~live & ~(1u << winner);
+        if (apus_gpu_become_leader_ex(s->eng, winner, term, s->bitmask, dead) || apus_gpu_sync(s->eng)) return -1;
+        s->bitmask &= ~dead;
+        s->term = term; s->leader = winner;
+        uint32_t cfg[2] = { winner, s->bitmask };
+        snprintf(name, sizeof name, "leader_%llu", (unsigned long long)term);
+        g_write(s, cfg, sizeof cfg, name);
+        fprintf(s->log, "[T%lu] LEADER\n", (unsigned long)s->term);
+        fflush(s->log);
+    } else {
+        snprintf(name, sizeof name, "leader_%llu", (unsigned long long)term);
+        if (g_wait(s, name, 60.0)) return -1;
+        uint32_t cfg[2];
+        if (g_read(s, cfg, sizeof cfg, name)) return -1;
+        s->term = term; s->leader = cfg[0]; s->bitmask = cfg[1];
+        apus_gpu_set_reachable(s->eng, s->alive_mask & s->bitmask);
+        if (!((s->bitmask >> s->idx) & 1u)) return -1;                   /* this server was removed */
+    }
+    return group_start_term(s);
+}
+
+static void group_loop(smr_t *s)
+{
+    double last_prune = now_s(), last_look = now_s();
+    while (!s->terminate) {
+        if (s->leader == s->idx) {
+            leader_upcalls(*s->dev_hr);
+            apus_tailq_drain();
+            if (!s->failed && apus_gpu_rep_full(s->eng)) {
+                fprintf(stderr, "[apus] the log is full: requests were dropped, admission is closed, the hooks are inert from here on\n");
+                s->failed = 1;
+            }
+            const double t = now_s();
+            if (!s->failed && t - last_prune >= s->prune_period_s) { apus_gpu_rep_prune(s->eng); last_prune = t; }
+            struct timespec ts = {0, 100000}; nanosleep(&ts, NULL);
+            continue;
+        }
+        follower_upcalls(s);
+        const double t = now_s();
+        if (t - last_look > 0.01) {                       /* the heartbeat timer (hb_period, nodes.local.cfg): is the leader there? */
+            last_look = t;
+            if (!g_alive(s, s->leader)) {
+                fprintf(s->log, "[T%lu] the leader p%u is gone\n", (unsigned long)s->term, s->leader);
+                if (group_failover(s)) { fprintf(stderr, "[apus] server %u: fail-over failed, the hooks are inert from here on\n", s->idx); s->failed = 1; s->leader = s->group_size; break; }
+            }
+        }
+        struct timespec ts = {0, 50000}; nanosleep(&ts, NULL);
+    }
+}
+
 void *dare_server_init(void *arg)
 {
     smr_t *s = &g_smr;
@@ -342,7 +553,10 @@ void *dare_server_init(void *arg)
      * GPU and this server leads them.  A process per server -- what
      * benchmarks/run.sh starts on three nodes -- is the peer-mapped group of apus_amd/peers.py, which
      * this C layer does not drive yet: refuse instead of starting a second, independent leader. */
-    if (s->in.srv_type == SRV_TYPE_JOIN || (s->idx != 0 && !getenv("APUS_ALLOW_ANY_SERVER_IDX"))) {
+    const char *gdir = getenv("APUS_GROUP_DIR");
+    s->group = gdir && *gdir;
+    if (s->group) snprintf(s->group_dir, sizeof s->group_dir, "%s", gdir);
+    if (!s->group && (s->in.srv_type == SRV_TYPE_JOIN || (s->idx != 0 && !getenv("APUS_ALLOW_ANY_SERVER_IDX")))) {
         fprintf(stderr, "[apus] server_idx=%u server_type=%s: this build replicates inside ONE process (logical replicas on one GPU, "
                         "server_idx 0 leads); a process per server needs the peer-mapped group (apus_amd/peers.py, INTEGRATION.md section 6)\n",
                 s->idx, s->in.srv_type == SRV_TYPE_JOIN ? "join" : "start");
@@ -352,8 +566,11 @@ void *dare_server_init(void *arg)
     apus_cfg_t cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.group_size = s->group_size;
-    cfg.n_local = s->group_size;                   /* logical replicas on one device */
-    for (uint32_t i = 0; i < s->group_size; i++) cfg.local_ids[i] = (uint8_t)i;
+    if (s->group) { cfg.n_local = 1; cfg.local_ids[0] = (uint8_t)s->idx; }      /* one process per server: this one hosts replica idx */
+    else {
+        cfg.n_local = s->group_size;               /* logical replicas on one device */
+        for (uint32_t i = 0; i < s->group_size; i++) cfg.local_ids[i] = (uint8_t)i;
+    }
     const char *ll = getenv("APUS_GPU_LOG_LEN");
     cfg.log_len = ll ? strtoull(ll, NULL, 0) : 0;
     const char *dv = getenv("APUS_GPU_DEVICE");
@@ -365,6 +582,41 @@ void *dare_server_init(void *arg)
         return NULL;
     }
     apus_gpu_bind_global(s->eng);
+    if (s->group) {
+        /* ---- one process per server ---- */
+        if (s->in.srv_type == SRV_TYPE_JOIN) {
+            fprintf(stderr, "[apus] server_type=join: a machine that joins a running group is driven through apus_gpu_join by the leader's process "
+                            "(apus_amd/peers.py:PeerMember.join); this host layer starts groups and fails over\n");
+            s->ready = -1;
+            return NULL;
+        }
+        if (group_connect(s)) { s->ready = -1; return NULL; }
+        s->term = 2; s->leader = 0;
+        s->live_replica = 1; s->live_persist = 0;
+        char name[64];
+        if (s->idx == 0) {
+            /* start-up election (dare_server.c:1169, 1264-1518): server 0's timeout fires first */
+            if (apus_gpu_become_leader(s->eng, 0, s->term, s->bitmask) || apus_gpu_sync(s->eng)) { fprintf(stderr, "[apus] election failed\n"); s->ready = -1; return NULL; }
+            uint32_t cfg2[2] = { 0, s->bitmask };
+            g_write(s, cfg2, sizeof cfg2, "leader_2");
+        } else if (g_wait(s, "leader_2", 120.0)) { s->ready = -1; return NULL; }
+        if (group_start_term(s)) { fprintf(stderr, "[apus] server %u: cannot start the replica kernels\n", s->idx); s->ready = -1; return NULL; }
+        if (s->idx == 0) { fprintf(s->log, "[T%lu] LEADER\n", (unsigned long)s->term); fflush(s->log); }
+        (void)name;
+        signal(SIGINT, on_sigint);
+        s->running = 1;
+        __sync_synchronize();
+        s->ready = 1;
+        group_loop(s);
+        /* shutdown: the leader drains and parks everybody; a follower waits for its workgroups (or asks them to leave) */
+        if (s->leader == s->idx) { apus_gpu_rep_drain(s->eng, 5000); leader_upcalls(*s->dev_hr); s->dev_hr = NULL; apus_gpu_rep_park(s->eng); }
+        else if (s->leader < s->group_size) { apus_gpu_rep_follower_stop(s->eng, s->idx); apus_gpu_rep_park(s->eng); follower_upcalls(s); }
+        apus_gpu_sync(s->eng);
+        const char *dump_g = getenv("APUS_PROXY_DUMP");
+        if (dump_g && *dump_g) dump_replicas(s, dump_g);
+        s->running = 0;
+        return NULL;                                   /* (the engine stays: peers may still have this replica mapped) */
+    }
     /* start-up election: every server becomes a candidate of term 1, this server's
      * timeout fires first (dare_server.c:1169, 1264-1518) */
     s->term = 2;
