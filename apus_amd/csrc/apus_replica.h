@@ -152,7 +152,7 @@ struct RepLead {
     uint32_t lat_ticks[R_LAT_CAP];              /* sequenced -> committed and applied by the leader      */
     uint32_t lat_app[R_LAT_CAP];                /* bytes in every pushed ring -> committed and applied   */
     RepTicket tk[RS_CAP];
-    uint64_t  dn[RS_CAP][8];
+    uint64_t  dn[8][RS_CAP];                     /* granule-major: the committer / applier read 64 consecutive tickets' granules in whole lines */
 };
 /* the leader's first workgroup: its wavefronts' words in LDS */
 enum { M_TAIL = 0, M_PROG, M_FINAL, M_T_DONE, M_CS, M_C_FINAL, M_T_RETIRED, M_N_APPLY, M_A_FINAL, M_A_HASH, M_A_NCL, M_DROPPED, M_WORDS = 16 };
@@ -163,7 +163,7 @@ enum { FR_END = 0, FR_E0, FR_SLOT_END, FR_N, FR_HASH_LO, FR_HASH_HI, FR_HEAD, FR
 struct RepFollow {                       /* follower-local (device memory, agent scope) */
     uint64_t quit; uint64_t pad[7];
     uint64_t stat[2][8];                 /* retire / apply wavefront: passes, passes that moved something, rounds, wall-clock ticks */
-    uint64_t fr[RB_CAP][FR_WORDS];
+    uint64_t fr[FR_WORDS][RB_CAP];          /* granule-major, like the leader's done granules */
 };
 /* a follower's first workgroup: its retire / apply wavefronts' words in LDS */
 enum { F_END = 0, F_N_END, F_Q_RET, F_R_FINAL, F_STORE_COUNT, F_PEND_N, F_PEND_SLOT_END, F_EXIT, F_WORDS = 8 };
@@ -552,15 +552,17 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                     pf0[s] = E.round_prefix[r]; pf1[s] = E.round_prefix[r + 1];
                     rf0[s] = E.round_first[r];  rf1[s] = E.round_first[r + 1];
                 }
-                /* flow control rides along: room in the ticket ring and in every pushed follower's doorbell ring */
+                /* flow control rides along when the room last seen runs low: the ticket ring and every pushed follower's doorbell ring */
                 uint64_t room = ~0ull;
-                if (lane == 0) {
-                    const uint64_t inflight = S.t - s_m[M_T_RETIRED];
-                    room = inflight + R_SLACK >= RS_CAP ? 0 : RS_CAP - R_SLACK - inflight;
-                } else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) {
-                    const uint64_t inflight = my_qbase + S.t - ld_sys(&mybox->seqdone_by[lane - 1]);
-                    room = inflight + R_SLACK >= RB_CAP ? 0 : RB_CAP - R_SLACK - inflight;
-                }
+                if (budget < 2 * WAVE * R_SUB) {
+                    if (lane == 0) {
+                        const uint64_t inflight = S.t - s_m[M_T_RETIRED];
+                        room = inflight + R_SLACK >= RS_CAP ? 0 : RS_CAP - R_SLACK - inflight;
+                    } else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) {
+                        const uint64_t inflight = my_qbase + S.t - ld_sys(&mybox->seqdone_by[lane - 1]);
+                        room = inflight + R_SLACK >= RB_CAP ? 0 : RB_CAP - R_SLACK - inflight;
+                    }
+                } else room = budget;
                 /* (and the next host command, if it is there: its PCIe round trip runs under this pass) */
                 const uint64_t next_cmd = cmd_head + 1;               /* (cmd_head is the RUN in progress) */
                 uint64_t cg = 0;
@@ -580,7 +582,9 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                 }
                 spins = 0;
                 for (int d = WAVE / 2; d > 0; d >>= 1) { const uint64_t o = rl64u(room, (int)(lane ^ (uint32_t)d)); room = o < room ? o : room; }
+                budget = room;
                 const uint32_t avail = (uint32_t)min((uint64_t)want, room);
+                const uint64_t stamp = wall_clock64() & 0xFFFFFFFFull;
                 uint32_t taken = 0;
 #pragma unroll
                 for (int s = 0; s < R_SUB; s++) {
@@ -596,7 +600,6 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                     const unsigned long long pm = __ballot(plain);
                     const uint32_t np = (~pm) ? (uint32_t)__builtin_ctzll(~pm) : WAVE;      /* prefix of plain rounds */
                     if (np) {
-                        const uint64_t stamp = wall_clock64() & 0xFFFFFFFFull;
                         {
                             const uint64_t t0 = S.t, tk = t0 + lane;
                             uint64_t w[8];
@@ -608,7 +611,9 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                             w[TK_D0] = rep_tk(tk, 0ull);
                             w[TK_D1] = rep_tk(tk, stamp);
                             w[TK_META] = rep_tk(tk, (uint64_t)(rf1[s] - rf0[s]) | ((uint64_t)R_SRC_STAGED << 8) | ((uint64_t)S.push_mask << 32));
-                            rep_store_rows64(w, np, [&](uint32_t r) { return (uint8_t *)LS->tk[(t0 + r) % RS_CAP].w; });
+                            if (A.dbg & 512) {                       /* measurement: eight strided 8-byte stores instead of the transposition */
+                                if (lane < np) for (int wi = 0; wi < 8; wi++) st_agent(&LS->tk[tk % RS_CAP].w[wi], w[wi]);
+                            } else rep_store_rows64(w, np, [&](uint32_t r) { return (uint8_t *)LS->tk[(t0 + r) % RS_CAP].w; });
                         }
                         const uint64_t tot = rl64u(pf1[s], (int)np - 1) - bpf;
                         const uint32_t ntot = (uint32_t)__shfl((int)rf1[s], (int)np - 1, WAVE) - brf;
@@ -627,7 +632,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                         break;
                     }
                 }
-                run_next += taken;
+                run_next += taken; budget -= min((uint64_t)taken, budget);
                 if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); }
                 rep_seq_publish(LS, s_m, S, cmd_head + req_head);
                 st_busy += wall_clock64() - st_p0;
@@ -808,8 +813,8 @@ __device__ static inline void rep_commit_pass(const EngDev &E, const RepArgs &A,
     uint64_t g0[R_SUB], g1[R_SUB], g2[R_SUB], ra[F][R_SUB];
 #pragma unroll
     for (int s = 0; s < R_SUB; s++) {
-        const uint64_t *d = LS->dn[(base + (uint64_t)s * WAVE + lane) % RS_CAP];
-        g0[s] = ld_agent(&d[DN_META]); g1[s] = ld_agent(&d[DN_SLOT_END]); g2[s] = ld_agent(&d[DN_END]);
+        const uint64_t ix = (base + (uint64_t)s * WAVE + lane) % RS_CAP;
+        g0[s] = ld_agent(&LS->dn[DN_META][ix]); g1[s] = ld_agent(&LS->dn[DN_SLOT_END][ix]); g2[s] = ld_agent(&LS->dn[DN_END][ix]);
     }
     {
         uint32_t m = members;
@@ -1005,9 +1010,9 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, vol
             uint64_t g1[R_SUB], g3[R_SUB], g4[R_SUB], g5[R_SUB], g6[R_SUB], g7[R_SUB];
 #pragma unroll
             for (int s = 0; s < R_SUB; s++) {
-                const uint64_t *d = LS->dn[(t_app + (uint64_t)s * WAVE + lane) % RS_CAP];
-                g1[s] = ld_agent(&d[DN_SLOT_END]); g3[s] = ld_agent(&d[DN_HASH_LO]); g4[s] = ld_agent(&d[DN_HASH_HI]);
-                g5[s] = ld_agent(&d[DN_NCLIENT]); g6[s] = ld_agent(&d[DN_T_APPENDED]); g7[s] = ld_agent(&d[DN_T_SEQUENCED]);
+                const uint64_t ix = (t_app + (uint64_t)s * WAVE + lane) % RS_CAP;
+                g1[s] = ld_agent(&LS->dn[DN_SLOT_END][ix]); g3[s] = ld_agent(&LS->dn[DN_HASH_LO][ix]); g4[s] = ld_agent(&LS->dn[DN_HASH_HI][ix]);
+                g5[s] = ld_agent(&LS->dn[DN_NCLIENT][ix]); g6[s] = ld_agent(&LS->dn[DN_T_APPENDED][ix]); g7[s] = ld_agent(&LS->dn[DN_T_SEQUENCED][ix]);
             }
             const uint64_t t0 = t_app;
             uint64_t nc_pass = 0;
@@ -1299,7 +1304,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             case DN_T_APPENDED: val = kind == R_SRC_CONTROL ? 0u : t_now; break;
             default: val = kind == R_SRC_CONTROL ? 0u : ((uint32_t)d1 ? (uint32_t)d1 : 1u); break;
             }
-            st_agent(&LS->dn[k % RS_CAP][lane], rep_gran(k, val));
+            st_agent(&LS->dn[lane][k % RS_CAP], rep_gran(k, val));
         }
         /* diagnostics: rounds and ticks from "ticket seen" to "done granules issued" */
         if (timed) { a_rounds++; a_total += wall_clock64() - t_seen; a_drain += t_drained - t_stores; a_desc += t_desc - t_seen; a_pay += t_stores - t_desc;
@@ -1403,7 +1408,7 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
             case FR_HEAD: val = head_val; break;
             default: break;
             }
-            st_agent(&FS->fr[r][lane], rep_gran(q, val));
+            st_agent(&FS->fr[lane][r], rep_gran(q, val));
         }
     }
 }
@@ -1446,8 +1451,8 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
         uint64_t f0[R_SUB], f1[R_SUB], f2[R_SUB], f3[R_SUB];
 #pragma unroll
         for (int s = 0; s < R_SUB; s++) {
-            const uint64_t *fr = FS->fr[(q_ret + (uint64_t)s * WAVE + lane) % RB_CAP];
-            f0[s] = ld_agent(&fr[FR_END]); f1[s] = ld_agent(&fr[FR_E0]); f2[s] = ld_agent(&fr[FR_SLOT_END]); f3[s] = ld_agent(&fr[FR_N]);
+            const uint64_t ix = (q_ret + (uint64_t)s * WAVE + lane) % RB_CAP;
+            f0[s] = ld_agent(&FS->fr[FR_END][ix]); f1[s] = ld_agent(&FS->fr[FR_E0][ix]); f2[s] = ld_agent(&FS->fr[FR_SLOT_END][ix]); f3[s] = ld_agent(&FS->fr[FR_N][ix]);
         }
         if (final_q == ~0ull && (ctrl >> 40) == my_run + 1) final_q = q0 + (ctrl & 0xFFFFFFFFFFull) - 1;
         const uint64_t t0 = q_ret;
@@ -1540,9 +1545,9 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
         if (q_app < q_ret) {
 #pragma unroll
             for (int s = 0; s < R_SUB; s++) {
-                const uint64_t *fr = FS->fr[(q_app + (uint64_t)s * WAVE + lane) % RB_CAP];
-                f2[s] = ld_agent(&fr[FR_SLOT_END]); f3[s] = ld_agent(&fr[FR_N]); f4[s] = ld_agent(&fr[FR_HASH_LO]);
-                f5[s] = ld_agent(&fr[FR_HASH_HI]); f6[s] = ld_agent(&fr[FR_HEAD]);
+                const uint64_t ix = (q_app + (uint64_t)s * WAVE + lane) % RB_CAP;
+                f2[s] = ld_agent(&FS->fr[FR_SLOT_END][ix]); f3[s] = ld_agent(&FS->fr[FR_N][ix]); f4[s] = ld_agent(&FS->fr[FR_HASH_LO][ix]);
+                f5[s] = ld_agent(&FS->fr[FR_HASH_HI][ix]); f6[s] = ld_agent(&FS->fr[FR_HEAD][ix]);
             }
         }
         if (cs > n_end) cs = n_end;
