@@ -289,6 +289,24 @@ __device__ static inline void rep_store_rows64(const uint64_t (&w)[8], uint32_t 
         if ((uint32_t)src < nrows) st16_wt(row_addr((uint32_t)src) + q * 16, make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)));
     }
 }
+/* the same through 4 KiB of LDS (8 LDS instructions per lane instead of 64 cross-lane reads): lane r leaves its row at
+ * scratch + 64 r, then reads the 16 bytes it is to store */
+template <typename AddrOf>
+__device__ static inline void rep_store_rows64_lds(uint4 *scratch, const uint64_t (&w)[8], uint32_t nrows, AddrOf row_addr)
+{
+    const uint32_t lane = lane_id(), q = lane & 3;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        scratch[lane * 4 + c] = make_uint4((uint32_t)w[2 * c], (uint32_t)(w[2 * c] >> 32), (uint32_t)w[2 * c + 1], (uint32_t)(w[2 * c + 1] >> 32));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t src = (uint32_t)j * 16 + (lane >> 2);
+        const uint4 v = scratch[j * WAVE + lane];              /* = row src, quarter q */
+        if (src < nrows) st16_wt(row_addr(src) + q * 16, v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       /* (the rows are read before the next chunk overwrites them) */
+}
 /* 32-byte rows: (a, b) of row r in lane r */
 template <typename AddrOf>
 __device__ static inline void rep_store_rows32(uint4 a, uint4 b, uint32_t nrows, AddrOf row_addr)
@@ -478,7 +496,7 @@ __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, R
 
 /* the leader's first workgroup: wavefront 0 sequences, wavefront 1 commits, wavefront 2 applies */
 __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, volatile uint64_t *s_h, volatile uint64_t *s_ao,
-                                            volatile uint64_t *s_m, volatile uint64_t *s_x)
+                                            volatile uint64_t *s_m, volatile uint64_t *s_x, uint4 *s_tr /* 4 KiB of LDS: ticket transposition */)
 {
     RepHost *H = A.H;
     RepLead *LS = A.LS;
@@ -493,8 +511,9 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
     const uint32_t bitmask = (uint32_t)s_h[H_CID_BITMASK];
     if (lane < 16) s_ao[lane] = (lane < APUS_DEV_MAX_SERVERS) ? s_h[H_APPLY_OFFSETS + lane] : 0;
     uint64_t req_head = ld_sys(&H->slots_done), cmd_head = ld_sys(&H->cmd_head);
-    bool have_cmd = false;
+    bool have_cmd = false, have_cmd2 = false;            /* the next host command, and the one behind it (fetched in the same PCIe round trip) */
     uint32_t cmd_op = 0; uint64_t cmd_after = 0, cmd_a = 0, cmd_b = 0;
+    uint32_t cmd2_op = 0; uint64_t cmd2_after = 0, cmd2_a = 0, cmd2_b = 0;
     uint64_t run_next = 0, run_end = 0;
     uint64_t idle = 0, budget = 0, dropped = 0;
     uint32_t exit_code = R_EXIT_STOP;
@@ -567,7 +586,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                 const uint64_t next_cmd = cmd_head + 1;               /* (cmd_head is the RUN in progress) */
                 uint64_t cg = 0;
                 const bool peek = !have_cmd && run_end - rc <= 2 * WAVE * R_SUB;      /* (only near the end of the run) */
-                if (peek && lane < 4) cg = ld_sys(&H->cmd[next_cmd % RC_CAP].g[lane]);
+                if (peek && lane < 8) cg = ld_sys(&H->cmd[(next_cmd + (lane >> 2)) % RC_CAP].g[lane & 3]);
                 const unsigned long long tight = __ballot(room < WAVE);
                 if (tight) {
                     if (++spins > A.peer_polls) {
@@ -613,7 +632,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                             w[TK_META] = rep_tk(tk, (uint64_t)(rf1[s] - rf0[s]) | ((uint64_t)R_SRC_STAGED << 8) | ((uint64_t)S.push_mask << 32));
                             if (A.dbg & 512) {                       /* measurement: eight strided 8-byte stores instead of the transposition */
                                 if (lane < np) for (int wi = 0; wi < 8; wi++) st_agent(&LS->tk[tk % RS_CAP].w[wi], w[wi]);
-                            } else rep_store_rows64(w, np, [&](uint32_t r) { return (uint8_t *)LS->tk[(t0 + r) % RS_CAP].w; });
+                            } else rep_store_rows64_lds(s_tr, w, np, [&](uint32_t r) { return (uint8_t *)LS->tk[(t0 + r) % RS_CAP].w; });
                         }
                         const uint64_t tot = rl64u(pf1[s], (int)np - 1) - bpf;
                         const uint32_t ntot = (uint32_t)__shfl((int)rf1[s], (int)np - 1, WAVE) - brf;
@@ -636,10 +655,18 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                 if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); }
                 rep_seq_publish(LS, s_m, S, cmd_head + req_head);
                 st_busy += wall_clock64() - st_p0;
-                if (peek && __ballot(lane < 4 && rep_gran_ok(cg, next_cmd)) == 0xFull) {
-                    have_cmd = true;
-                    cmd_op = (uint32_t)rl64u(cg, 0); cmd_after = rep_extend(req_head, (uint32_t)rl64u(cg, 1));
-                    cmd_a = (uint32_t)rl64u(cg, 2); cmd_b = (uint32_t)rl64u(cg, 3);
+                if (peek) {
+                    const unsigned long long okb = __ballot(lane < 8 && rep_gran_ok(cg, next_cmd + (lane >> 2)));
+                    if ((okb & 0xFull) == 0xFull) {
+                        have_cmd = true;
+                        cmd_op = (uint32_t)rl64u(cg, 0); cmd_after = rep_extend(req_head, (uint32_t)rl64u(cg, 1));
+                        cmd_a = (uint32_t)rl64u(cg, 2); cmd_b = (uint32_t)rl64u(cg, 3);
+                        if ((okb & 0xF0ull) == 0xF0ull) {
+                            have_cmd2 = true;
+                            cmd2_op = (uint32_t)rl64u(cg, 4); cmd2_after = rep_extend(req_head, (uint32_t)rl64u(cg, 5));
+                            cmd2_a = (uint32_t)rl64u(cg, 6); cmd2_b = (uint32_t)rl64u(cg, 7);
+                        }
+                    }
                 }
             }
             if (out) break;
@@ -651,13 +678,23 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
         uint32_t v[R_WIN];
 #pragma unroll
         for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = ld_sys32(&H->ready_len[(req_head + (uint64_t)wdw * WAVE + lane) % RQ_CAP]);
+        if (!have_cmd && have_cmd2) {                  /* (fetched with the command before it) */
+            have_cmd = true; have_cmd2 = false;
+            cmd_op = cmd2_op; cmd_after = cmd2_after; cmd_a = cmd2_a; cmd_b = cmd2_b;
+        }
         if (!have_cmd) {
             uint64_t cg = 0;
-            if (lane < 4) cg = ld_sys(&H->cmd[cmd_head % RC_CAP].g[lane]);
-            if (__ballot(lane < 4 && rep_gran_ok(cg, cmd_head)) == 0xFull) {
+            if (lane < 8) cg = ld_sys(&H->cmd[(cmd_head + (lane >> 2)) % RC_CAP].g[lane & 3]);
+            const unsigned long long okb = __ballot(lane < 8 && rep_gran_ok(cg, cmd_head + (lane >> 2)));
+            if ((okb & 0xFull) == 0xFull) {
                 have_cmd = true;
                 cmd_op = (uint32_t)rl64u(cg, 0); cmd_after = rep_extend(req_head, (uint32_t)rl64u(cg, 1));
                 cmd_a = (uint32_t)rl64u(cg, 2); cmd_b = (uint32_t)rl64u(cg, 3);
+                if ((okb & 0xF0ull) == 0xF0ull) {
+                    have_cmd2 = true;
+                    cmd2_op = (uint32_t)rl64u(cg, 4); cmd2_after = rep_extend(req_head, (uint32_t)rl64u(cg, 5));
+                    cmd2_a = (uint32_t)rl64u(cg, 6); cmd2_b = (uint32_t)rl64u(cg, 7);
+                }
             }
         }
         const uint64_t stopw = ld_sys(&H->stop);
@@ -1083,13 +1120,15 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
     const uint64_t L = E.log_len;
     const uint64_t term = Md.hdr[H_SID] >> 9;
     uint64_t a_rounds = 0, a_total = 0, a_drain = 0, a_desc = 0, a_pay = 0, a_pre = 0, a_it1 = 0;
+    uint64_t wv_next = 0;
+    bool have_next = false;
     for (uint64_t k = g;; k += G) {
         /* ---- wait for ticket k: its eight words carry its tag ---- */
         const RepTicket &tkt = LS->tk[k % RS_CAP];
-        uint64_t wv = 0;
+        uint64_t wv = wv_next;                       /* (looked at under the previous round's store drain) */
         bool go = false;
         for (uint64_t i = 0;; i++) {
-            if (lane < 8) wv = ld_agent(&tkt.w[lane]);
+            if (i || !have_next) { if (lane < 8) wv = ld_agent(&tkt.w[lane]); }
             if (__ballot(lane < 8 && rep_tk_ok(wv, k)) == 0xFFull) { go = true; break; }
             if ((i & 7) == 7 && ld_agent(&LS->seq_final) <= k) break;      /* (one word for everybody: looked at now and then) */
             rep_nap(i < 256);
@@ -1278,6 +1317,9 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             }
         }
         const uint64_t t_stores = timed ? wall_clock64() : 0;
+        /* the next ticket's words are asked for now: their round trip runs under the drain of this round's stores */
+        if (lane < 8) wv_next = ld_agent(&LS->tk[(k + G) % RS_CAP].w[lane]);
+        have_next = true;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint64_t t_drained = timed ? wall_clock64() : 0;
         /* ---- the bytes are in every pushed ring.  R2: the round's doorbell in every pushed follower's mailbox;
@@ -1328,13 +1370,15 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
     uint8_t *const lring = leader < APUS_DEV_MAX_SERVERS ? E.rep[leader].ring : nullptr;     /* (once: the sender's log, ACK map and mailbox) */
     uint8_t *const lack = leader < APUS_DEV_MAX_SERVERS ? E.ackb[leader] : nullptr;
     RepBox *const lbox = leader < APUS_DEV_MAX_SERVERS ? E.box[leader] : nullptr;
+    uint64_t bell_next = 0;
+    bool have_bell = false;
     for (uint64_t q = q0 + g;; q += G) {
         const uint32_t r = (uint32_t)(q % RB_CAP);
         /* ---- wait for the doorbell of round q ---- */
-        uint64_t wv = 0;
+        uint64_t wv = bell_next;                     /* (looked at under the previous round's store drain) */
         uint32_t go = 0;
         for (uint64_t i = 0;; i++) {
-            if (lane < 4) wv = ld_sys(&box->rnd[r][lane]);
+            if (i || !have_bell) { if (lane < 4) wv = ld_sys(&box->rnd[r][lane]); }
             if (__ballot(lane < 4 && (wv >> 32) == ((q + 1) & 0xFFFFFFFFull)) == 0xFull) { go = 1; break; }
             if ((i & 15) == 15) {
                 const uint64_t ctrl = ld_sys(&box->ctrl);
@@ -1394,6 +1438,8 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
         const uint64_t hsum = wave_sum(mix);
         const uint32_t nclient = wave_sum(client);
         head_val = (uint32_t)__shfl((int)head_val, 0, WAVE);    /* (a <HEAD> entry is a round of its own) */
+        if (lane < 4) bell_next = ld_sys(&box->rnd[(q + G) % RB_CAP][lane]);     /* the next doorbell: its round trip runs under this drain */
+        have_bell = true;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         /* ---- persisted: the round's granules for the retire / apply wavefronts ---- */
         if (lane < FR_WORDS) {
@@ -1633,7 +1679,7 @@ __global__ __launch_bounds__(256) void k_replica(const EngDev E, const RepArgs A
             if (tid < 16) s_x[tid] = 0;
             if (tid < M_WORDS) s_m[tid] = tid == M_FINAL ? ~0ull : (tid == M_N_APPLY ? E.rep[E.leader].hdr[H_N_APPLY] : 0ull);
             __syncthreads();
-            if (wave == 0) rep_sequencer(E, A, s_h, s_ao, s_m, s_x);
+            if (wave == 0) rep_sequencer(E, A, s_h, s_ao, s_m, s_x, (uint4 *)&s_lds[0]);   /* (the append stage's LDS is free in this workgroup) */
             else if (wave == 1) rep_committer(E, A, s_h, s_m, s_x);
             else if (wave == 2) rep_applier(E, A, s_h, s_m);
             __syncthreads();
