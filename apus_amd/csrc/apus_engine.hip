@@ -95,6 +95,7 @@ struct apus_engine {
     RepLead *rl;                    /* leader-local hand-off state */
     RepFollow *rfs[APUS_MAX_SERVERS];
     RepFHost *rfh[APUS_MAX_SERVERS], *rfh_dev[APUS_MAX_SERVERS];   /* pinned: a hosted follower's progress / stop words */
+    uint8_t *ss_buf; uint64_t ss_cap;       /* apus_gpu_store_stream's scratch, kept between calls */
     hipStream_t rstream;
     bool r_running, r_lead;         /* a launch is resident; it carries the leader's workgroups */
     uint32_t r_follow_mask;
@@ -281,6 +282,8 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
     if (e->rh) hipHostFree(e->rh);
     if (e->rl) hipFree(e->rl);
     for (auto f : e->rfs) if (f) hipFree(f);
+    for (auto f : e->rfh) if (f) hipHostFree(f);
+    if (e->ss_buf) hipFree(e->ss_buf);
     if (e->rstream) hipStreamDestroy(e->rstream);
     free(e->r_slot_aend);
     if (e->r_lock_init) pthread_spin_destroy(&e->r_lock);
@@ -1698,16 +1701,23 @@ extern "C" int apus_gpu_store_stream(apus_engine_t *e, uint32_t replica, uint64_
     if (!bytes || n > e->dir_cap || (cap && !dst)) return APUS_E_ARG;
     if (e->batching) return APUS_E_STATE;
     if ((rc = flush_tick(e))) return rc;
-    uint8_t *d_out = nullptr; uint64_t *d_res = nullptr;
-    if (hipMalloc(&d_out, cap + 16) != hipSuccess) return APUS_E_NOMEM;
-    if (hipMalloc(&d_res, 16) != hipSuccess) { hipFree(d_out); return APUS_E_NOMEM; }
-    hipLaunchKernelGGL(k_store_stream, dim3(1), dim3(1024), 0, e->stream, e->d, replica, first, n, d_out, cap, d_res);
+    /* a scratch buffer kept between calls (two hipMalloc / hipFree per call synchronise the device), zeroed on the engine's
+     * stream: a record that straddles `cap` is skipped as a whole by the kernel, the bytes behind the last record written are
+     * zeros, never stale device memory */
+    if (e->ss_cap < cap + 32) {
+        if (e->ss_buf) { hipStreamSynchronize(e->stream); hipFree(e->ss_buf); e->ss_buf = nullptr; e->ss_cap = 0; }
+        const uint64_t want = std::max<uint64_t>(cap + 32, 1u << 20);
+        if (hipMalloc((void **)&e->ss_buf, want) != hipSuccess) return APUS_E_NOMEM;
+        e->ss_cap = want;
+    }
+    uint8_t *d_out = e->ss_buf + 16; uint64_t *d_res = (uint64_t *)e->ss_buf;
+    hipError_t he = hipMemsetAsync(e->ss_buf, 0, cap + 32, e->stream);
+    if (he == hipSuccess) hipLaunchKernelGGL(k_store_stream, dim3(1), dim3(1024), 0, e->stream, e->d, replica, first, n, d_out, cap, d_res);
     uint64_t res[2] = {0, 0};
-    hipError_t he = hipGetLastError();
+    if (he == hipSuccess) he = hipGetLastError();
     if (he == hipSuccess) he = hipMemcpyAsync(res, d_res, 16, hipMemcpyDeviceToHost, e->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
     if (he == hipSuccess && cap) he = hipMemcpy(dst, d_out, res[0] < cap ? res[0] : cap, hipMemcpyDeviceToHost);
-    hipFree(d_out); hipFree(d_res);
     if (he != hipSuccess) return APUS_E_HIP;
     *bytes = res[0];
     if (records) *records = res[1];
