@@ -2182,7 +2182,7 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
         const uint32_t room = (uint32_t)std::max(8, occ * cus - 8);
         const uint32_t nfh = (uint32_t)popc(A.follow_mask);
         if (!n_append) n_append = lead_here ? 96 : 0;
-        if (!n_fwork) n_fwork = nfh ? std::min(96u, std::max(8u, 192u / nfh)) : 1;
+        if (!n_fwork) n_fwork = nfh ? std::min(64u, std::max(24u, 96u / nfh)) : 1;     /* (measured: 96 append + 48 per follower at 3 replicas; more only adds contention) */
         while ((lead_here ? 1 + n_append : 0) + nfh * n_fwork > room && (n_append > 8 || n_fwork > 2)) {
             if (n_append > 8) n_append -= n_append / 4;
             if (n_fwork > 2) n_fwork -= (n_fwork + 3) / 4;

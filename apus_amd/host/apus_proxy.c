@@ -440,7 +440,7 @@ static void follower_upcalls(smr_t *s)
     if (apus_gpu_rep_follower_progress(s->eng, s->idx, pr)) return;
     static apus_apply_t recs[512];
     static uint8_t *bytes;
-    if (!bytes) bytes = malloc(512u * (65536u + 64u) > (64u << 20) ? (64u << 20) : 512u * (65536u + 64u));
+    if (!bytes) bytes = malloc(65536u + 64u);             /* one record's payload at a time */
     while (s->replayed < pr[0]) {
         uint64_t n = pr[0] - s->replayed;
         if (n > 512) n = 512;
