@@ -201,12 +201,32 @@ def cpu_baseline_reference(args, seconds=12.0, group_size=3):
         rc.quiesce()
         o = rc.log(0).offsets()
         assert o["commit"] == o["end"] and rc.highest_rec(0) == done
+        # the same with a storage callback that costs something: every persisted entry's record (what stablestorage_save_request
+        # hands to BerkeleyDB, proxy.c:268-291) appended to a file through a 32 KiB buffer, on every server
+        with_store = None
+        try:
+            rc.record_store(2)
+            d2, t1 = 0, time.perf_counter()
+            while time.perf_counter() - t1 < max(2.0, seconds / 4):
+                for g0, n in rounds:
+                    rc.round(reqs[g0:g0 + n], tr.arena)
+                    since += int(reqs["len"][g0:g0 + n].sum()) + 64 * n
+                    if since >= (8 << 20):
+                        rc.tick_prune()
+                        since = 0
+                d2 += len(reqs)
+            with_store = d2 / (time.perf_counter() - t1)
+            rc.record_store(0)
+        except Exception as exc:
+            print(f"[bench] reference baseline with a file store failed: {exc!r}", file=sys.stderr)
     finally:
         rc.close()
     return {"value": done / el, "unit": "committed entries/s", "cores": 1, "kind": "reference",
+            "with_file_store": with_store,
             "sample": f"{passes} x {len(reqs)} entries of the same {group_size}-replica stream ({el:.1f} s; the reference's own "
                       f"dare_server.c / dare_ibv_rc.c loops, unmodified, -O0 as the reference builds them, {group_size} servers on "
-                      f"one thread, in-process verbs stand-in; {_cpu_model()}, nproc={os.cpu_count()})"}
+                      f"one thread, in-process verbs stand-in; `value`: the storage callback only counts (no BerkeleyDB), `with_file_store`: every record "
+                      f"appended to a file through a 32 KiB buffer; {_cpu_model()}, nproc={os.cpu_count()})"}
 
 
 def cpu_baseline_configs0(seconds=10.0):
@@ -349,6 +369,13 @@ def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True):
                           "sequenced_to_committed_and_applied_us_p50": float(np.percentile(lat_seq[20:], 50)) / 1e3 if len(lat_seq) > 20 else None,
                           "host_submit_to_highest_rec_us_p50_64_entries": float(np.percentile(hl64[40:], 50)),
                           "host_submit_to_highest_rec_us_p50_1_entry": float(np.percentile(hl1[40:], 50)), "exit": code}
+        la_, ls_, lh_ = (out["latency"][k] for k in ("appended_to_committed_and_applied_us_p50", "sequenced_to_committed_and_applied_us_p50",
+                                                     "host_submit_to_highest_rec_us_p50_64_entries"))
+        if la_ is not None and ls_ is not None:
+            out["latency"]["phase_breakdown_us_p50"] = {
+                "host_publish_to_sequenced_plus_highest_rec_back_to_host": lh_ - ls_,     # two PCIe crossings: the sequencer's poll, the applier's store
+                "sequenced_to_bytes_in_every_ring": ls_ - la_,                            # ticket, descriptor + payload over PCIe, stores + drain
+                "bytes_in_every_ring_to_committed_and_applied": la_}                      # doorbell, follower persist + ACK, committer, applier
         hr_base = eng.counters(0)["highest_rec"]
         # (a) device-resident input
         eng.rep_start(idle_ms=5000, peer_ms=1000)

@@ -220,10 +220,16 @@ static void rec(uint8_t kind)
  * structs -- the record starts at &entry->clt_id and its length comes out of the proxy_send_msg overlay
  * (SURVEY.md 9-Q1); store_record (src/db/db-interface.c:65-96) appends it and adds its size to records_len */
 static uint8_t *store_buf; static uint64_t store_len, store_cap; static uint32_t records_len_; static int record_store;
+static FILE *store_file;              /* record_store == 2: the records go to a file (32 KiB buffer = the reference's pagesize), not to memory */
 static void store_record_(size_t n, const void *d)
 {
     records_len_ += (uint32_t)n;
     if (!record_store) return;
+    if (record_store == 2) {
+        if (!store_file) { store_file = tmpfile(); if (store_file) setvbuf(store_file, NULL, _IOFBF, 32 * 1024); }
+        if (store_file) fwrite(d, 1, n, store_file);
+        return;
+    }
     if (store_len + n > store_cap) { store_cap = (store_len + n) * 2 + 4096; store_buf = realloc(store_buf, store_cap); }
     memcpy(store_buf + store_len, d, n); store_len += n;
 }
