@@ -728,6 +728,20 @@ def bench_single(args):
     if not args.no_replica and args.config == "c2":
         try:
             rk = measure_replica_kernels(args, tr, n_rep)
+            # north_star: latency and throughput at 3 / 5 / 7 replicas -- the same measurement, shorter, for the larger groups
+            rk["by_group_size"] = {}
+            from apus_amd import trace as T3
+            for g in (5, 7):
+                if g == n_rep:
+                    continue
+                try:
+                    trg = T3.steady_trace(g, args.entries, args.payload, 16, args.batch, log_len=T3.DEFAULT_LOG, name=f"C2x{g}")
+                    rg = measure_replica_kernels(args, trg, g, steps=2, hostfed=False)
+                    rk["by_group_size"][str(g)] = {"entries_per_s": rg["device_resident"]["value"], "verified": rg["device_resident"]["verified"],
+                                                   "appended_to_committed_and_applied_us_p50": rg["latency"]["appended_to_committed_and_applied_us_p50"],
+                                                   "host_submit_to_highest_rec_us_p50_64_entries": rg["latency"]["host_submit_to_highest_rec_us_p50_64_entries"]}
+                except Exception as exc:
+                    print(f"[bench] replica kernels at {g} replicas failed: {exc!r}", file=sys.stderr)
             out["replica_kernels"] = rk
             la = rk.get("latency", {}).get("appended_to_committed_and_applied_us_p50")
             if la is not None:

@@ -110,3 +110,19 @@ int main(void)
                            "-lpthread", f"-Wl,-rpath,{pkg}"])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and r.stdout.split() == ["3", "1"], (r.returncode, r.stdout, r.stderr)
+
+
+def test_pmc_traffic_file_belongs_to_this_build():
+    """bench.py quotes roofline.traffic only for the build the PMC passes were taken on: the committed
+    profiles/r03_pmc_traffic.json must carry the hash of the kernel sources as they are now (apus_device.h + apus_kernels.h) --
+    a later edit of those files without new PMC passes would silently null the figure in the driver's bench line."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    path = os.path.join(ROOT, "profiles", bench.PMC_FILE)
+    assert os.path.exists(path), f"{path} is missing"
+    doc = json.load(open(path))
+    assert doc.get("kernel_source_sha256") == bench.kernel_source_hash(), \
+        "apus_device.h / apus_kernels.h changed after the PMC passes: re-run tools/gpu_profile.sh and commit profiles/r03_pmc_traffic.json"
+    assert doc["configs"]["c2"]["kernel"] == "k_step" and 400 < doc["configs"]["c2"]["bytes_per_entry"] < 1088
