@@ -18,6 +18,7 @@
 #include "apus_kernels.h"
 #include "apus_persistent.h"
 #include "apus_replica.h"
+#include "apus_quirks.h"
 #include <pthread.h>
 #include <time.h>
 
@@ -51,6 +52,7 @@ struct apus_engine {
     std::vector<uint32_t> h_round_first;
     std::vector<uint64_t> h_round_prefix;      /* byte prefix of the staged rounds */
     bool batching;                             /* apus_gpu_batch_begin .. _end */
+    uint64_t *d_quirk;                         /* APUS_F_REF_QUIRKS: k_ref_quirk_wrap's word between passes */
     uint64_t sp_units;                         /* APUS_SP_UNITS (default 768), see call_args */
     uint32_t gp_rounds;                        /* APUS_GP_ROUNDS (default 4; 1 = one workgroup per round), see call_args */
     uint64_t gp_max_units;                     /* APUS_GP_MAX_UNITS: largest mean round (16-byte units) that is grouped */
@@ -149,6 +151,9 @@ static inline int popc(uint32_t v) { return __builtin_popcount(v); }
 /* the term fence (k_fence_check): in front of every launch that stores into followers, where another
  * process can move a follower to a newer term behind this leader's back */
 static inline bool fence_on(const apus_engine *e) { return e->imported_mask != 0 || (e->cfg.flags & 2u); }
+/* APUS_F_REF_QUIRKS: behind every pass, the reference's state at a commit pointer parked on a wrap position (apus_quirks.h) */
+static inline bool ref_quirks(const apus_engine *e) { return (e->cfg.flags & APUS_F_REF_QUIRKS) != 0; }
+#define QUIRK_PASS(e, kind) do { if (ref_quirks(e)) hipLaunchKernelGGL(k_ref_quirk_wrap, dim3(1), dim3(64), 0, (e)->stream, (e)->d, (e)->d_quirk, (int)(kind)); } while (0)
 #define FENCE_CHECK(e, fm) do { if (fence_on(e) && (fm)) hipLaunchKernelGGL(k_fence_check, dim3(1), dim3(64), 0, (e)->stream, (e)->d, (fm)); } while (0)
 
 extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
@@ -210,6 +215,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->dir_cap = pow2_at_least(L / APUS_ENTRY_HDR < 4096 ? 4096 : L / APUS_ENTRY_HDR);
     e->d.dir_mask = e->dir_cap - 1;
     e->d.flags = cfg->flags;
+    if (cfg->flags & APUS_F_REF_QUIRKS) { if (dev_alloc(e, &e->d_quirk, 16)) { delete e; return APUS_E_NOMEM; } }
     e->local_mask = 0; e->imported_mask = 0;
     e->reachable = (1u << cfg->group_size) - 1;
     e->d.reachable = e->reachable;
@@ -354,6 +360,7 @@ extern "C" int apus_gpu_reset(apus_engine_t *e)
             HIPCHK(hipMemsetAsync(e->d.box[i], 0, sizeof(RepBox), e->stream));
             HIPCHK(hipMemsetAsync(e->d.ackb[i], 0, (size_t)e->cfg.group_size * e->dir_cap, e->stream));
         }
+    if (e->d_quirk) HIPCHK(hipMemsetAsync(e->d_quirk, 0, 16, e->stream));
     e->d.leader = 0xFFFFFFFFu;
     e->tick_pending = false;
     e->free_lb = 0; e->host_status = 0; e->no_access = 0; e->adjust_mask = 0; e->cid_epoch = 0;
@@ -508,6 +515,7 @@ static int launch_tail_view(apus_engine *e, const EngDev &view, uint64_t r0, uin
     const uint32_t nR = (mode == 0 && R) ? cap_grid(R, 256, 8) : 0;
     hipLaunchKernelGGL(k_apply, dim3(cap_grid(n, 1024, 1024) + nR + 1, popc(rm)), dim3(256), 0, e->stream, view, r0, R, rm, mode,
                        fm, nR);
+    QUIRK_PASS(e, 1);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -769,6 +777,7 @@ extern "C" int apus_gpu_run_rounds(apus_engine_t *e, uint64_t r0, uint64_t n_rou
         if (fence_on(e)) hipLaunchKernelGGL(k_call_fenced, dim3(blocks), dim3(256), 0, e->stream, e->d, a, fm, rm);
         else hipLaunchKernelGGL(k_call, dim3(blocks), dim3(256), 0, e->stream, e->d, a, fm, rm);
         if (tl) HIPCHK(hipEventRecord(tl->b, e->stream));
+        QUIRK_PASS(e, tick ? 1 : 0);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -783,7 +792,7 @@ extern "C" int apus_gpu_batch_begin(apus_engine_t *e)
     if (e && e->live_R) { int rc_ = flush_live(e); if (rc_) return rc_; }
     int rc = need_leader(e);
     if (rc) return rc;
-    if (e->batching) return APUS_E_STATE;
+    if (e->batching || ref_quirks(e)) return APUS_E_STATE;      /* (the quirk pass runs behind single calls only) */
     e->batching = true;
     e->batch.clear();
     return 0;
@@ -888,6 +897,7 @@ static int flush_live(apus_engine *e)
     if (fence_on(e)) hipLaunchKernelGGL(k_call_fenced, dim3(1 + R * a.SP + a.nR + 1 + a.nS + a.nA * popc(rm)), dim3(256), 0, e->stream, view, a, fm, rm);
     else hipLaunchKernelGGL(k_call, dim3(1 + R * a.SP + a.nR + 1 + a.nS + a.nA * popc(rm)), dim3(256), 0, e->stream, view, a, fm, rm);
     e->live_R = 0;
+    QUIRK_PASS(e, a.tick ? 1 : 0);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -931,6 +941,7 @@ static int launch_control_round(apus_engine *e, int mode, uint32_t type, uint64_
     const uint32_t fm = sync_mask(e);
     if ((mode & 7) != 2) e->free_lb = e->free_lb > 2 * APUS_HDR ? e->free_lb - 2 * APUS_HDR : 0;     /* at most one 64-byte entry (+ a skipped tail) */
     hipLaunchKernelGGL(k_control_round, dim3(1), dim3(256), 0, e->stream, e->d, mode, type, d0, d1, fm, fm, req_id, clt_id);
+    QUIRK_PASS(e, 1);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1824,6 +1835,7 @@ extern "C" int apus_gpu_persist_start(apus_engine_t *e, uint32_t idle_ms, uint32
 {
     int rc = need_leader(e);
     if (rc) return rc;
+    if (ref_quirks(e)) return APUS_E_STATE;      /* APUS_F_REF_QUIRKS covers the call-per-pass path only */
     { int frc = flush_tick(e); if (frc) return frc; }
     if (e->p_running) return APUS_E_STATE;
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -2162,7 +2174,7 @@ static int rep_in_step(apus_engine *e, uint32_t cand, uint32_t *out_mask, uint64
 extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t peer_ms, uint32_t n_append, uint32_t n_fwork)
 {
     if (!e || e->d.leader >= e->d.group_size) return APUS_E_STATE;
-    if (e->r_running || e->p_running || e->batching) return APUS_E_STATE;
+    if (e->r_running || e->p_running || e->batching || ref_quirks(e)) return APUS_E_STATE;
     if (e->live_R) { int rc_ = flush_live(e); if (rc_) return rc_; }
     const uint32_t leader = e->d.leader;
     const uint32_t hosted = e->local_mask & ~e->imported_mask;

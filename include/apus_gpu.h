@@ -126,6 +126,15 @@ typedef struct {
  *    instead, like the reference: a follower's own workgroups do not acknowledge a round of a term older than their
  *    SID's -- no reply byte, no ACK: nothing of it can commit. */
 #define APUS_F_TERM_FENCE 2u
+/* Strict reference behaviour where the engine is deliberately safer by default: with the commit pointer parked on
+ * a wrap position and no majority for the entry that wrapped to offset 0, the reference's leader sets commit = 0
+ * (src/dare/dare_ibv_rc.c:1725-1758) and, at a case-1 wrap, APPLIES that entry although it is not committed
+ * (log_get_entry redirects log->apply in place, src/include/dare/dare_log.h:327-330) -- one upcall, highest_rec + 1,
+ * apply ahead of commit.  With this flag a one-thread kernel behind every pass (k_ref_quirk_wrap,
+ * apus_amd/csrc/apus_quirks.h) brings the leader's control block, apply stream and counters to exactly that state.
+ * Covers the call-per-pass path (apus_gpu_run_rounds outside a batch, the live calls, control rounds, quiesce);
+ * apus_gpu_batch_begin, apus_gpu_persist_start and apus_gpu_rep_start return APUS_E_STATE under it. */
+#define APUS_F_REF_QUIRKS 4u
 
 typedef struct apus_engine apus_engine_t;
 

@@ -317,6 +317,58 @@ def test_known_deviation_uncommitted_apply_at_wrap(eng_factory):
     assert gc[-1] == oc[-1] and all(gc[b + 1] == oc[b + 1] for b in bad if b + 1 not in bad)
 
 
+@pytest.mark.parametrize("coalesce", [True, False])
+def test_ref_quirks_flag_closes_the_deviation(coalesce):
+    """APUS_F_REF_QUIRKS (include/apus_gpu.h, apus_amd/csrc/apus_quirks.h): the same trace as above, now an EQUALITY
+    test.  With the flag the leader's state at the no-quorum quiescent point is the reference's bit for bit --
+    commit 0, apply 164 (ahead of commit), highest_rec 197, the apply stream hash with the uncommitted entry in it --
+    and so is every per-pass record, whether consecutive rounds go out as one call or one call per round (the record
+    of the pass behind a wrap pass is patched across calls)."""
+    from apus_amd.engine import Engine
+    from tests import traces
+    from tests.parity import lockstep
+    tr = traces.park_commit_at_wrap()
+    eng = Engine(tr.group_size, tr.log_len, flags=4)
+    seen = []
+    try:
+        q = [i for i, ev in enumerate(tr.events) if ev[0] == "QUIESCE"]
+        cl = lockstep(tr, eng, check_at=("QUIESCE",), coalesce=coalesce)          # compares at every QUIESCE, records included
+        # the no-quorum point again, by hand: replay up to the 2nd QUIESCE and look at the leader
+        eng.reset(); eng.stage_trace(tr)
+        for ev in tr.events[:q[1] + 1]:
+            op = ev[0]
+            if op == "ROUND": eng.run_rounds(eng.round_of_g0[ev[1]], 1)
+            elif op == "ELECT": eng.elect(ev[1])
+            elif op == "PRUNE": eng.tick_prune()
+            elif op == "QUIESCE": eng.quiesce()
+            elif op == "HOLD": eng.hold(ev[1])
+        eng.check_status()
+        go = eng.offsets(0)
+        assert (go["apply"], go["commit"], go["end"]) == (164, 0, 884) and eng.counters(0)["highest_rec"] == 197
+        assert cl.log(0).offsets()["commit"] == cl.log(0).offsets()["end"]
+        # what the flag does not cover says so
+        with pytest.raises(Exception):
+            eng.batch_begin()
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("name", ["wrap_quirk_second_round", "exact_fit", "hold_release", "no_quorum_prune", "c5_failover", "steady5_unaligned"])
+def test_ref_quirks_flag_changes_nothing_elsewhere(name):
+    """the strict flag on the pinned traces, one call per round (the hard case for the per-pass record: the record of
+    the pass behind a case-1 wrap depends on the pass before it, here another call) and coalesced"""
+    from apus_amd.engine import Engine
+    from tests import traces
+    from tests.parity import lockstep
+    tr = traces.CATALOGUE[name]()
+    for coalesce in (False, True):
+        eng = Engine(tr.group_size, tr.log_len, flags=4)
+        try:
+            lockstep(tr, eng, check_at=("QUIESCE",), coalesce=coalesce)
+        finally:
+            eng.close()
+
+
 def test_full_size_c2_against_oracle(eng_factory):
     """BASELINE config 2 at full size: 3 replicas, 2^20 SEND entries of 64 B
     (128 MiB through the 64 MiB ring), batch 64, prune tick every 8 MiB."""
