@@ -19,6 +19,7 @@
 #include "apus_persistent.h"
 #include "apus_replica.h"
 #include "apus_quirks.h"
+#include "apus_members.h"
 #include <pthread.h>
 #include <time.h>
 
@@ -53,6 +54,9 @@ struct apus_engine {
     std::vector<uint64_t> h_round_prefix;      /* byte prefix of the staged rounds */
     bool batching;                             /* apus_gpu_batch_begin .. _end */
     uint64_t *d_quirk;                         /* APUS_F_REF_QUIRKS: k_ref_quirk_wrap's word between passes */
+    CfgJournal *d_cfgj;                        /* every CONFIG entry a leader appended, every vote (apus_members.h) */
+    MemberView mv[APUS_MAX_SERVERS];           /* what each server's own configuration is derived from */
+    bool cfg_appended;
     uint64_t sp_units;                         /* APUS_SP_UNITS (default 768), see call_args */
     uint32_t gp_rounds;                        /* APUS_GP_ROUNDS (default 4; 1 = one workgroup per round), see call_args */
     uint64_t gp_max_units;                     /* APUS_GP_MAX_UNITS: largest mean round (16-byte units) that is grouped */
@@ -216,6 +220,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->d.dir_mask = e->dir_cap - 1;
     e->d.flags = cfg->flags;
     if (cfg->flags & APUS_F_REF_QUIRKS) { if (dev_alloc(e, &e->d_quirk, 16)) { delete e; return APUS_E_NOMEM; } }
+    if (dev_alloc(e, &e->d_cfgj, sizeof(CfgJournal))) { delete e; return APUS_E_NOMEM; }
     e->local_mask = 0; e->imported_mask = 0;
     e->reachable = (1u << cfg->group_size) - 1;
     e->d.reachable = e->reachable;
@@ -323,6 +328,8 @@ extern "C" int apus_gpu_set_group_size(apus_engine_t *e, uint32_t n)
     if (e->batching) return APUS_E_STATE;
     if (e->d.leader < e->cfg.group_size) { int frc = flush_tick(e); if (frc) return frc; }
     e->d.group_size = n;
+    if (!e->cfg_appended)           /* the configured size the group starts with: every server holds that configuration */
+        for (uint32_t i = 0; i < APUS_MAX_SERVERS; i++) e->mv[i].base = (1u << n) - 1;
     return 0;
 }
 
@@ -361,6 +368,9 @@ extern "C" int apus_gpu_reset(apus_engine_t *e)
             HIPCHK(hipMemsetAsync(e->d.ackb[i], 0, (size_t)e->cfg.group_size * e->dir_cap, e->stream));
         }
     if (e->d_quirk) HIPCHK(hipMemsetAsync(e->d_quirk, 0, 16, e->stream));
+    HIPCHK(hipMemsetAsync(e->d_cfgj, 0, 16, e->stream));
+    for (uint32_t i = 0; i < APUS_MAX_SERVERS; i++) e->mv[i] = MemberView{(1u << e->d.group_size) - 1, 0, 0, 0};
+    e->cfg_appended = false;
     e->d.leader = 0xFFFFFFFFu;
     e->tick_pending = false;
     e->free_lb = 0; e->host_status = 0; e->no_access = 0; e->adjust_mask = 0; e->cid_epoch = 0;
@@ -942,6 +952,10 @@ static int launch_control_round(apus_engine *e, int mode, uint32_t type, uint64_
     if ((mode & 7) != 2) e->free_lb = e->free_lb > 2 * APUS_HDR ? e->free_lb - 2 * APUS_HDR : 0;     /* at most one 64-byte entry (+ a skipped tail) */
     hipLaunchKernelGGL(k_control_round, dim3(1), dim3(256), 0, e->stream, e->d, mode, type, d0, d1, fm, fm, req_id, clt_id);
     QUIRK_PASS(e, 1);
+    if (type == APUS_CONFIG && (mode & 7) != 2) {
+        hipLaunchKernelGGL(k_cfg_journal, dim3(1), dim3(64), 0, e->stream, e->d, e->d_cfgj);
+        e->cfg_appended = true;
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1166,6 +1180,8 @@ extern "C" int apus_gpu_become_leader_ex(apus_engine_t *e, uint32_t leader, uint
     {
         /* the followers that voted: their logs are adjusted before anything is replicated to them */
         const uint32_t am = e->adjust_mask & e->local_mask & e->reachable & ~(1u << leader);
+        /* ... and they took this candidate's configuration with their vote (dare_server.c:1697) */
+        hipLaunchKernelGGL(k_cfg_note, dim3(1), dim3(64), 0, e->stream, e->d_cfgj, e->adjust_mask & ~(1u << leader), bitmask);
         e->adjust_mask = 0;
         if (am) {
             hipLaunchKernelGGL(k_adjust, dim3(popc(am)), dim3(64), 0, e->stream, e->d, am, e->reachable);
@@ -1386,6 +1402,11 @@ extern "C" int apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_
     uint32_t empty = size;
     for (int i = (int)size - 1; i >= 0; i--) if (!((bitmask >> i) & 1u)) empty = (uint32_t)i;   /* dare_ibv_ud.c:995-1021 */
     if (empty != r || !e->d.rep[r].ring) return APUS_E_STATE;
+    /* a configured server that does not answer: the joiner needs RC connections to, and the replicated vote from, a
+     * majority and retries until it has them (rc_get_replicated_vote dare_ibv_rc.c:874); the oracle's JOIN is one
+     * event and covers joins into a fully reachable group (orc_join, -6): so does this one */
+    for (uint32_t i = 0; i < size; i++)
+        if (i != r && ((bitmask >> i) & 1u) && !((reachable >> i) & 1u)) return APUS_E_NOANSWER;
     const bool peer_owned = (e->imported_mask >> r) & 1u;      /* its process cleared it (apus_gpu_clear_replica) */
     int donor = -1, src = -1;
     for (uint32_t i = 0; i < size; i++) {
@@ -1394,6 +1415,11 @@ extern "C" int apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_
         if (donor < 0 && i != leader) donor = (int)i;
     }
     if (donor < 0 || src < 0) return APUS_E_STATE;
+
+    /* the journal of CONFIG entries so far (apus_members.h): what every member itself holds before this JOIN */
+    uint64_t cfg_n0 = 0;
+    HIPCHK(hipMemcpyAsync(&cfg_n0, &e->d_cfgj->n, sizeof cfg_n0, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
 
     /* leader side: the CONFIG entries, each committed by the pass that follows it */
     uint8_t cid[16] = {0};
@@ -1418,6 +1444,33 @@ extern "C" int apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_
         if (!rc) rc = launch_control_round(e, 0 | 16, APUS_CONFIG, d0, d1, 0, 0);
         if (rc) return rc;                                    /* (a launch that cannot be issued: the stream is broken anyway) */
     }
+    /* Who answers the joiner's RC_SYN (handle_rc_syn, dare_ibv_ud.c): a member whose OWN configuration has the
+     * joiner's bit ON -- it took in one of the entries above: a server that itself joined ignores CONFIG entries whose
+     * idx is not above the idx of the entry that admitted it (poll_config_entries dare_server.c:2152) -- and did not
+     * still show the slot's former holder before.  The joiner needs more than half of the group it joins and retries
+     * for ever otherwise (oracle/apus_oracle.c:orc_join, -6): refused here, with the CONFIG entries in the log as
+     * they are in the reference's. */
+    static_assert(sizeof(CfgJournal) < (1u << 16), "the journal is copied to the host in one piece");
+    CfgJournal *H = (CfgJournal *)malloc(sizeof(CfgJournal));
+    if (!H) return APUS_E_NOMEM;
+    if (hipMemcpyAsync(H, e->d_cfgj, sizeof(CfgJournal), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess) { free(H); return APUS_E_HIP; }
+    const uint64_t cfg_n1 = H->n;
+    {
+        const uint32_t jsize = r < size ? size : size + 1;
+        uint32_t conn = 0;
+        for (uint32_t i = 0; i < jsize; i++) {
+            if (i == r || !((nb >> i) & 1u) || !((reachable >> i) & 1u)) continue;
+            if (i == leader) { conn++; continue; }
+            const bool stale = (member_view(*H, e->mv[i], i, cfg_n0) >> r) & 1u;
+            const bool knows = (member_view(*H, e->mv[i], i, cfg_n1) >> r) & 1u;
+            if (!stale && knows) conn++;
+        }
+        if (cfg_n1 == cfg_n0 || conn <= jsize / 2) { free(H); return cfg_n1 == cfg_n0 ? APUS_E_FULL : APUS_E_NOANSWER; }
+    }
+    const uint64_t join_cid_idx = H->it[cfg_n0 % CFGJ_CAP].idx;
+    free(H);
+
     /* joiner side */
     uint64_t *jw = e->d_elect + 8;                            /* scratch words behind k_elect's verdict */
     if (!peer_owned) {
@@ -1439,7 +1492,14 @@ extern "C" int apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_
         HIPCHK(hipMemsetAsync(lb->rack[r], 0, sizeof lb->rack[r], e->stream));       /* ... and its round counter restarts */
     }
     if ((rc = launch_control_round(e, 2 | 32, 0, 0, 0))) return rc;
-    out[0] = nb; out[1] = e->d.group_size; out[2] = e->cid_epoch; out[3] = 0;
+    {   /* the new member's own configuration from now on: the one of the join reply, then whatever it polls from the
+         * head it was given (apus_members.h) */
+        uint64_t head_slot = 0;
+        HIPCHK(hipMemcpyAsync(&head_slot, &jw[J_HEAD_SLOT], sizeof head_slot, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        e->mv[r] = MemberView{nb, cfg_n1, head_slot, join_cid_idx};
+    }
+    out[0] = nb; out[1] = e->d.group_size; out[2] = e->cid_epoch; out[3] = join_cid_idx;
     return 0;
 }
 
@@ -1510,6 +1570,7 @@ extern "C" int apus_gpu_force_prune(apus_engine_t *e, uint64_t out[4])
     if (rc) return rc;
     if ((rc = flush_tick(e))) return rc;
     hipLaunchKernelGGL(k_force_prune, dim3(1), dim3(128), 0, e->stream, e->d, e->cid_epoch, sync_mask(e), e->d_elect + 16);
+    hipLaunchKernelGGL(k_cfg_journal, dim3(1), dim3(64), 0, e->stream, e->d, e->d_cfgj);       /* (it may have appended a removal) */
     hipLaunchKernelGGL(k_force_sample, dim3(1), dim3(64), 0, e->stream, e->d, sync_mask(e), e->d_elect + 16);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, e->d_elect + 16, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));

@@ -24,7 +24,7 @@ ST_NAMES = {1: "SECOND_WRAP", 2: "LOG_FULL", 4: "TERM_FENCE", 8: "DIR_OVERRUN", 
 
 
 class EngineError(RuntimeError):
-    pass
+    rc = None            # the APUS_E_* code of the C call that failed, when there was one
 
 
 class Engine:
@@ -96,7 +96,9 @@ class Engine:
 
     def _chk(self, rc, what):
         if rc != 0:
-            raise EngineError(f"{what} failed rc={rc} status={self.status_names()}")
+            err = EngineError(f"{what} failed rc={rc} status={self.status_names()}")
+            err.rc = rc
+            raise err
 
     def sync(self):
         self._chk(self.L.apus_gpu_sync(self.h), "sync")
@@ -170,9 +172,8 @@ class Engine:
         if self.leader < 0:
             raise EngineError("JOIN without a leader")
         size = self.group_size
-        for i in range(size):
-            if i != r and (self.bitmask >> i) & 1 and not (self.reachable >> i) & 1:
-                raise EngineError("JOIN into a group with an unreachable configured server is not covered")
+        # (a configured server that does not answer, or too few members whose OWN configuration shows the joiner:
+        #  apus_gpu_join refuses with APUS_E_NOANSWER = -8, where the reference's joiner retries for ever, oracle -6)
         donors = [i for i in range(size) if i not in (r, self.leader) and (self.bitmask >> i) & 1]
         for f in donors:
             # a follower answers a second state-machine request before the next committed <HEAD> entry from

@@ -58,6 +58,7 @@ extern "C" {
 #define APUS_E_NOMEM    (-4)
 #define APUS_E_STATE    (-5)   /* no leader / not staged / bad replica */
 #define APUS_E_FULL     (-6)   /* the batch does not fit into the free part of the log: nothing was appended (status bit APUS_ST_LOG_FULL) */
+#define APUS_E_NOANSWER (-8)   /* apus_gpu_join: too few members would answer the joiner (their OWN configuration does not show it, or still shows the slot's former holder): the reference's joiner retries for ever */
 #define APUS_E_DEVICE   (-6)   /* a device-side status bit is set: see apus_gpu_status */
 
 /* device status bits (sticky until apus_gpu_clear_status) */
@@ -211,10 +212,17 @@ int  apus_gpu_set_config(apus_engine_t *e, uint32_t group_size, uint64_t epoch);
  * snapshot offset of the first follower (rc_recover_sm :597-705), the log between the leader's head and
  * the first server's end in one bulk transfer (rc_recover_log :726-866), its first persist and apply
  * passes, then it is a follower like the others.  reachable = who answers.  out[0] = new bitmask,
- * out[1] = new group size, out[2] = new epoch.  One per-round record for the whole join.
- * The caller decides WHETHER a join may happen now (apus_amd/engine.py:Engine.join mirrors what the
- * reference can do: every configured server reachable, no follower asked for its state machine twice
- * without a committed <HEAD> entry in between); this call carries it out. */
+ * out[1] = new group size, out[2] = new epoch, out[3] = idx of the CONFIG entry that admitted the server (its
+ * cid_idx).  One per-round record for the whole join.  Synchronises.
+ * Refused with APUS_E_NOANSWER where the reference's joiner would retry for ever (oracle/apus_oracle.c:orc_join, -6):
+ * a configured server is not reachable, or too few members would answer its RC_SYN -- a member answers only if its OWN
+ * configuration shows the joiner and did not still show the slot's former holder, and a server that itself joined
+ * ignores every CONFIG entry whose idx is not above the idx of the one that admitted it (all of them once the index
+ * sequence has restarted at an exact-fit wrap); what each member holds is derived from the engine's journal of CONFIG
+ * entries and votes (apus_amd/csrc/apus_members.h).  In the second case the CONFIG entries of the attempt are in the
+ * log, as they are in the reference's.  What the caller still decides (apus_amd/engine.py:Engine.join): no follower
+ * is asked for its state machine twice without a committed <HEAD> entry in between (the reference answers from an
+ * uninitialised pointer there, dare_server.c:604-651). */
 int  apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_t bitmask, uint32_t reachable, uint64_t out[4]);
 /* replica adopts a SID it heard of from a candidate / leader that ANOTHER engine drives (its vote,
  * poll_vote_requests src/dare/dare_server.c:1690; a heartbeat of a newer term, hb_receive_cb :903-910);

@@ -866,7 +866,7 @@ def test_term_fence_a_deposed_leader_stores_nothing(eng_factory, batch):
     assert all(eng.counters(r)["sid"] >> 9 == 6 for r in range(3))
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 15])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 15, 16, 18, 19, 20, 21, 22])
 def test_random_join_traces(eng_factory, seed):
     """kills, re-joins into freed slots and group extensions at random places (the schedules
     tests/test_oracle_vs_refloops.py::test_random_joins_equal_reference runs in lock step with the reference),
@@ -884,6 +884,37 @@ def test_random_join_traces(eng_factory, seed):
     for r in range(cl.n):
         if (eng.reachable >> r) & 1 and (eng.bitmask >> r) & 1:
             compare_apply_tail(eng, cl, r)
+
+
+@pytest.mark.parametrize("seed", [0, 10, 12, 14, 17, 23])
+def test_random_join_traces_the_reference_cannot_finish(eng_factory, seed):
+    """The random join schedules the oracle REFUSES (-6: too few members would answer the joiner's RC_SYN -- a server
+    that itself joined ignores every CONFIG entry once the index sequence has restarted at an exact-fit wrap, keeps a
+    stale configuration and neither sees the removal of a dead server nor the next joiner; the reference's joiner
+    retries for ever, found by running it: tests/test_oracle_vs_refloops.py).  The engine is bit-identical up to that
+    JOIN and refuses the same one: apus_gpu_join derives what every member itself holds from its journal of CONFIG
+    entries (apus_amd/csrc/apus_members.h) and returns APUS_E_NOANSWER."""
+    import copy
+    from apus_amd.engine import EngineError
+    from tests.parity import lockstep
+    from tests.test_oracle_vs_refloops import _random_join_trace
+    tr = _random_join_trace(seed)
+    last = [-1]
+
+    def note(i, ev, cl):
+        last[0] = i
+    with pytest.raises(RuntimeError, match="rc=-6"):
+        orc.run_trace(tr, on_event=note)
+    k = last[0] + 1
+    assert tr.events[k][0] == "JOIN"
+    head = copy.copy(tr)
+    head.events = list(tr.events[:k])
+    head.reqs = tr.reqs[:sum(ev[2] for ev in head.events if ev[0] == "ROUND")]      # (stage_trace wants events and requests to match)
+    eng = eng_factory(tr.group_size, tr.log_len, capacity=7)
+    lockstep(head, eng, batch=True, check_at=("QUIESCE",))            # equal at every quiescent point before it
+    with pytest.raises(EngineError) as ei:
+        eng.join(tr.events[k][1])
+    assert ei.value.rc == -8, ei.value
 
 
 @pytest.mark.parametrize("batch", [False, True])
