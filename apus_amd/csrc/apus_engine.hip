@@ -1458,14 +1458,7 @@ extern "C" int apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_
     const uint64_t cfg_n1 = H->n;
     {
         const uint32_t jsize = r < size ? size : size + 1;
-        uint32_t conn = 0;
-        for (uint32_t i = 0; i < jsize; i++) {
-            if (i == r || !((nb >> i) & 1u) || !((reachable >> i) & 1u)) continue;
-            if (i == leader) { conn++; continue; }
-            const bool stale = (member_view(*H, e->mv[i], i, cfg_n0) >> r) & 1u;
-            const bool knows = (member_view(*H, e->mv[i], i, cfg_n1) >> r) & 1u;
-            if (!stale && knows) conn++;
-        }
+        const uint32_t conn = join_answers(*H, e->mv, r, leader, nb, reachable, jsize, cfg_n0, cfg_n1);
         if (cfg_n1 == cfg_n0 || conn <= jsize / 2) { free(H); return cfg_n1 == cfg_n0 ? APUS_E_FULL : APUS_E_NOANSWER; }
     }
     const uint64_t join_cid_idx = H->it[cfg_n0 % CFGJ_CAP].idx;

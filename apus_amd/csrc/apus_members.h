@@ -19,13 +19,7 @@
 #pragma once
 #include "apus_kernels.h"
 
-#define CFGJ_CAP 1024
-struct CfgItem {
-    uint64_t slot, idx;          /* position in the total order of the log; the entry's idx */
-    uint32_t bitmask, who;       /* who: 0 = a log entry (every member that received it, subject to idx > cid_idx);
-                                    otherwise the mask of voters that took the candidate's configuration with their vote */
-};
-struct CfgJournal { uint64_t n, next_slot; CfgItem it[CFGJ_CAP]; };
+#include "apus_members_host.h"
 
 /* the CONFIG entries among the last (at most 8) entries the leader appended that are not in the journal yet */
 __global__ __launch_bounds__(64) void k_cfg_journal(const EngDev E, CfgJournal *J)
@@ -61,21 +55,4 @@ __global__ __launch_bounds__(64) void k_cfg_note(CfgJournal *J, uint32_t voters,
     CfgItem &it = J->it[J->n % CFGJ_CAP];
     it.slot = ~0ull; it.idx = ~0ull; it.bitmask = bitmask; it.who = voters;
     J->n = J->n + 1;
-}
-
-/* host side: what server i holds after the first `upto` journal items (H = a host copy of the journal).
- * base: the configuration it was given outright (initial group; join reply); since: the first slot of its log (a
- * server that joined polls from the head it was given -- entries OLDER than the one that admitted it included, if
- * they are still in the log); cid_idx as above; votes_from: journal length when it joined (votes of the slot's
- * former holder are not its own). */
-struct MemberView { uint32_t base; uint64_t votes_from, since, cid_idx; };
-static inline uint32_t member_view(const CfgJournal &H, const MemberView &m, uint32_t i, uint64_t upto)
-{
-    uint32_t v = m.base;
-    for (uint64_t k = H.n > CFGJ_CAP ? H.n - CFGJ_CAP : 0; k < upto && k < H.n; k++) {
-        const CfgItem &it = H.it[k % CFGJ_CAP];
-        if (it.who) { if (k >= m.votes_from && ((it.who >> i) & 1u)) v = it.bitmask; }
-        else if (it.idx > m.cid_idx && it.slot >= m.since) v = it.bitmask;
-    }
-    return v;
 }
