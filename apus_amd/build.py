@@ -14,8 +14,13 @@ HOOK_LIB = os.path.join(PKG, "libapus_interpose.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = [os.path.join(CSRC, "apus_engine.hip")]
-DEPS = [os.path.join(CSRC, "apus_kernels.h"), os.path.join(CSRC, "apus_device.h"),
-        os.path.join(CSRC, "apus_persistent.h"), os.path.join(CSRC, "apus_replica.h"), os.path.join(ROOT, "include", "apus_gpu.h")]
+def _headers():
+    """every header the library is made of: csrc/*.h and include/*.h"""
+    inc = os.path.join(ROOT, "include")
+    return sorted(os.path.join(d, f) for d in (CSRC, inc) if os.path.isdir(d) for f in os.listdir(d) if f.endswith(".h"))
+
+
+DEPS = _headers()
 
 
 def _host_c_sources():
