@@ -237,6 +237,16 @@ class PeerMember:
             self.eng.sync()
         dist.barrier()
 
+    def check_done(self):
+        """Closes a check point: nobody moves on before EVERY rank has finished looking at its replica.  (Without it
+        the leader went on with the next rounds while a slower rank was still reading its own memory -- a rank that
+        read its offsets early and its counters late saw the counters of up to one stretch of rounds later:
+        the intermittent `apply_count 50 vs 0` of round 3's join_upsize_3_to_5, rank 4's first and therefore
+        slowest comparison, five rounds of ten entries before the next check point.)"""
+        if os.environ.get("APUS_PEER_NO_CHECK_BARRIER"):        # diagnostic only: reproduces that failure (tests/test_gpu_peers.py)
+            return
+        dist.barrier()
+
     def close(self):
         try:
             self.eng.sync()
@@ -248,7 +258,8 @@ class PeerMember:
 
 def walk_trace(m: PeerMember, trace, on_check=None, check_at=("QUIESCE",), max_batch_rounds: int = 4096, batch: bool = False,
                replica: bool = False, rep_grid=(0, 0)):
-    """Every rank walks the trace; on_check(i, event, member) runs on every rank after settle().
+    """Every rank walks the trace; on_check(i, event, member) runs on every rank between settle() and check_done():
+    the leader's stream has drained and nothing is launched until every rank has looked.
     batch=True: stretches of ROUND / PRUNE events become one multi-segment launch (apus_gpu_batch_*).
     replica=True: stretches of ROUND / PRUNE events run through the replica kernels -- every process runs the
     workgroups of its own replica; the control-plane events park the run."""
@@ -290,6 +301,7 @@ def walk_trace(m: PeerMember, trace, on_check=None, check_at=("QUIESCE",), max_b
             if op in check_at and on_check is not None:
                 m.settle()
                 on_check(i, ev[i], m)
+                m.check_done()
             i += 1
         m.rep_end()
         m.settle()
@@ -338,6 +350,7 @@ def walk_trace(m: PeerMember, trace, on_check=None, check_at=("QUIESCE",), max_b
         if op in check_at and on_check is not None:
             m.settle()
             on_check(i, ev[i], m)
+            m.check_done()
         i += 1
     b_close()
     m.settle()

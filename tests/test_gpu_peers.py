@@ -23,42 +23,58 @@ def _free_port():
     return p
 
 
-def run_group(world, name, mode="per-call", flags=0, timeout=420, attempts=3):
-    """Up to two retries when a rank vanished without a result (seen once in ~5 runs of 5 processes on a fresh box:
-    a peer's gloo connection closes during start-up); what the lost rank wrote to stderr is kept under
-    gpurun_out/ for the post-mortem.  A rank that REPORTS a mismatch fails the test at once."""
+# what a start-up failure of the process group looks like (a peer's gloo connection closes while the ranks
+# rendez-vous: seen once in ~5 runs of 5 processes on a fresh box); nothing else is ever retried
+_STARTUP = ("Connection closed by peer", "Connection reset by peer", "connectFullMesh", "Socket Timeout",
+            "failed to connect", "Gloo connectFullMesh failed")
+
+
+class _StartupFlake(Exception):
+    pass
+
+
+def run_group(world, name, mode="per-call", flags=0, timeout=420, attempts=3, repeat=1, env_extra=None):
+    """One torchrun of tests/_peer_worker.py.  ANY rank that reports a mismatch (or any other error of its own) fails
+    the test at once, whether or not the other ranks lived to write a result -- torchrun SIGTERMs them as soon as one
+    rank exits, so "some ranks produced no result" is the NORMAL shape of a parity failure and is never retried.
+    Retried (up to twice, stderr kept under gpurun_out/): only a run in which no rank reported anything but the gloo
+    start-up signature."""
     for attempt in range(attempts):
         try:
-            return _run_group(world, name, mode, flags, timeout)
-        except _RankLost as e:
+            return _run_group(world, name, mode, flags, timeout, repeat, env_extra)
+        except _StartupFlake as e:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", f"peers_lost_{name}_{attempt}.err"), "w") as f:
+            with open(os.path.join(ROOT, "gpurun_out", f"peers_startup_{name}_{attempt}.err"), "w") as f:
                 f.write(str(e))
             if attempt == attempts - 1:
                 raise AssertionError(str(e))
 
 
-class _RankLost(Exception):
-    pass
+def _classify(world, res, stdout, stderr):
+    """-> None when every rank is fine; raises AssertionError for a failure, _StartupFlake for the one retried case"""
+    errors = [(r["rank"], str(r.get("error"))) for r in res if not r["ok"]]
+    real = [(k, e) for k, e in errors if not any(sig in e for sig in _STARTUP)]
+    if real:
+        said = "\n".join(f"rank {k}: {e}" for k, e in real)
+        raise AssertionError(f"{len(real)} rank(s) reported a failure ({world - len(res)} produced no result):\n{said}\n{stderr[-3000:]}")
+    if errors or len(res) != world:
+        txt = "\n".join(f"rank {k}: {e}" for k, e in errors)
+        if errors or any(sig in stderr for sig in _STARTUP):
+            raise _StartupFlake(f"start-up: {world - len(res)} ranks without a result\n{txt}\n{stdout[-2000:]}\n{stderr[-6000:]}")
+        raise AssertionError(f"{world - len(res)} ranks produced no result and nobody said why:\n{stdout[-2000:]}\n{stderr[-6000:]}")
 
 
-def _run_group(world, name, mode, flags, timeout):
+def _run_group(world, name, mode, flags, timeout, repeat=1, env_extra=None):
     out = os.path.join(tempfile.mkdtemp(), "res")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "_peer_worker.py"), out, name, mode, str(flags)]
+           os.path.join(ROOT, "tests", "_peer_worker.py"), out, name, mode, str(flags), str(repeat)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", APUS_DIST_BACKEND="gloo", APUS_DIST_ONE_DEVICE="1")
+    env.update(env_extra or {})
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     res = [json.load(open(f"{out}.{r}")) for r in range(world) if os.path.exists(f"{out}.{r}")]
-    if len(res) != world:
-        said = "\n".join(f"rank {r['rank']}: {r.get('error')}" for r in res if not r["ok"])
-        raise _RankLost(f"{world - len(res)} ranks produced no result; the others said:\n{said}\n{p.stdout[-2000:]}\n{p.stderr[-6000:]}")
-    for r in res:
-        if not r["ok"] and "Connection closed by peer" in str(r.get("error")) and all(
-                q["ok"] or "Connection closed by peer" in str(q.get("error")) for q in res):
-            raise _RankLost(f"rank {r['rank']}: {r.get('error')}\n{p.stderr[-6000:]}")
-        assert r["ok"], f"rank {r['rank']}: {r.get('error')}"
-    assert len({r["end"] for r in res if "end" in r}) >= 1
+    _classify(world, res, p.stdout, p.stderr)
+    assert all(r["runs"] == repeat for r in res)
     return res
 
 
@@ -123,3 +139,25 @@ def test_peer_mapped_group_replica_kernels(name, world):
     replica from its own memory against the oracle at every quiescent event."""
     res = run_group(world, name, mode="replica")
     assert all(r["checks"] >= 2 for r in res)
+
+
+SOAK = int(os.environ.get("APUS_PEER_SOAK", "3"))
+
+
+@pytest.mark.parametrize("mode", ["per-call", "batched", "replica"])
+@pytest.mark.parametrize("name,world", [("join_upsize_3_to_5", 5), ("c5_rejoin", 5), ("join_then_failover", 4)])
+def test_peer_mapped_group_join_soak(name, world, mode):
+    """The JOIN traces APUS_PEER_SOAK times over in ONE process group (a fresh PeerMember -- engine, HIP-IPC export /
+    import -- per run), no retry of any kind inside: `tools/gpu_soak.sh` sets 50 for the evidence under profiles/."""
+    res = run_group(world, name, mode=mode, repeat=SOAK, timeout=900, attempts=1 if SOAK > 3 else 3)
+    assert all(r["runs"] == SOAK and r["checks"] >= 2 * SOAK for r in res)
+
+
+def test_a_check_point_needs_its_closing_barrier():
+    """Round 3's intermittent `join_upsize_3_to_5 rank 4 ... apply_count 50 vs 0`, reproduced on purpose: without the
+    barrier that closes a check point (PeerMember.check_done) the leader goes on with the next stretch of rounds while
+    a slower rank is still reading its own replica; with it the same slow rank passes."""
+    slow = {"APUS_PEER_SLOW_RANK": "4"}
+    with pytest.raises(AssertionError, match="rank 4"):
+        run_group(5, "join_upsize_3_to_5", env_extra=dict(slow, APUS_PEER_NO_CHECK_BARRIER="1"), attempts=1)
+    run_group(5, "join_upsize_3_to_5", env_extra=slow)
