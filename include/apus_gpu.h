@@ -134,7 +134,13 @@ typedef struct {
  * apply ahead of commit.  With this flag a one-thread kernel behind every pass (k_ref_quirk_wrap,
  * apus_amd/csrc/apus_quirks.h) brings the leader's control block, apply stream and counters to exactly that state.
  * Covers the call-per-pass path (apus_gpu_run_rounds outside a batch, the live calls, control rounds, quiesce);
- * apus_gpu_batch_begin, apus_gpu_persist_start and apus_gpu_rep_start return APUS_E_STATE under it. */
+ * apus_gpu_batch_begin, apus_gpu_persist_start and apus_gpu_rep_start return APUS_E_STATE under it.
+ * STATUS, FINAL: this flag is a DIAGNOSTIC of the call-per-pass path -- it exists so that a test can exhibit the
+ * reference's state bit for bit (tests/test_gpu_parity.py::test_ref_quirks_flag_closes_the_deviation).  It is not
+ * and will not be accepted by the batch, persistent or replica kernels: what it reproduces is a client released by
+ * an entry that only the leader holds, i.e. a safety violation of the reference that no deployment wants, and the
+ * resident kernels (the product's live loop) never apply an uncommitted entry.  Deviation 1 in DESIGN.md section 6
+ * states the bound (apply, one upcall, <= 8 per-pass records, only while the quorum is gone). */
 #define APUS_F_REF_QUIRKS 4u
 
 typedef struct apus_engine apus_engine_t;

@@ -57,6 +57,27 @@ def test_rep_catalogue_staged(name):
     run_and_compare(traces.CATALOGUE[name](), "staged")
 
 
+FULL = {"c2": T.config_c2, "c3": T.config_c3, "c4": T.config_c4, "c5": lambda: T.config_c5(), "c5_join": lambda: T.config_c5(rejoin=True)}
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4", "c5", "c5_join"])
+def test_rep_full_size_staged(cfg):
+    """BASELINE configs[1..4] at FULL size through the replica kernels -- the kernel `north_star` describes, a resident
+    kernel per replica -- bit for bit against the oracle on EVERY replica: all 8 offsets, every defined ring byte,
+    canonical digest, counters, apply-stream hash + the newest 512 apply records (compare_replica + compare_apply_tail:
+    what test_batched_step_at_full_size checks for k_step).  c2: 2^20 x 64 B over two laps of the 64 MiB ring with 16
+    prune ticks, 3 replicas; c3: 2^18 x 1 KiB, 5 replicas, >= 4 laps; c4: 2^18 mixed 64 B .. 4 KiB in rounds of 1 .. 64,
+    7 replicas; c5: 3 x 20 000 requests, the leader and a follower killed (+ the JOIN tail and a fourth phase).
+    Reference loop: dare_server.c:1012-1125 (polling), dare_ibv_rc.c:1725-1758 (commit scan)."""
+    run_and_compare(FULL[cfg](), "staged", idle_ms=20000, peer_ms=5000)
+
+
+def test_rep_full_size_c2_host_fed():
+    """configs[1] at full size with every request crossing the multi-producer request ring (the LD_PRELOAD path's
+    admission), one ROUND event at a time"""
+    run_and_compare(T.config_c2(), "pinned", idle_ms=20000, peer_ms=5000)
+
+
 @pytest.mark.parametrize("name", ["hold_one_of_three", "hold_release", "no_quorum_prune", "kill_follower"])
 def test_rep_failures(name):
     """HOLD / RELEASE / KILL park the run; the control-plane pass brings a released follower up to date; while a
