@@ -2524,17 +2524,19 @@ extern "C" int apus_gpu_rep_stats(apus_engine_t *e, uint64_t out[8])
 
 /* diagnostics: how the serial roles of the last run spent their passes.  out[role][8]: roles 0..2 = the leader's
  * sequencer, committer, applier; 3 + 2 i, 4 + 2 i = retire / apply wavefront of the i-th hosted follower (i < 6):
- * [0] passes [1] passes that moved something [2] rounds [3] wall-clock ticks (100 MHz) */
-extern "C" int apus_gpu_rep_role_stats(apus_engine_t *e, uint64_t out[16][8])
+ * [0] passes [1] passes that moved something [2] rounds [3] wall-clock ticks (100 MHz); 15 = the append wavefronts' and
+ * 16 = the first hosted follower's work wavefronts' phase timers (APUS_REP_DBG & 256) */
+extern "C" int apus_gpu_rep_role_stats(apus_engine_t *e, uint64_t out[20][8])
 {
     if (!e || e->r_running || !out) return APUS_E_STATE;
-    memset(out, 0, sizeof(uint64_t) * 16 * 8);
+    memset(out, 0, sizeof(uint64_t) * 20 * 8);
     if (e->rl) HIPCHK(hipMemcpy(out, e->rl->stat, sizeof(uint64_t) * 3 * 8, hipMemcpyDeviceToHost));
     if (e->rl) HIPCHK(hipMemcpy(out[15], e->rl->stat[3], sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
     int k = 0;
     for (uint32_t m = e->r_follow_mask; m && k < 6; m &= m - 1, k++) {
         RepFollow *fs = e->rfs[__builtin_ctz(m)];
         if (fs) HIPCHK(hipMemcpy(out[3 + 2 * k], fs->stat, sizeof(uint64_t) * 2 * 8, hipMemcpyDeviceToHost));
+        if (fs && k == 0) HIPCHK(hipMemcpy(out[16], fs->stat[2], sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));   /* its work wavefronts' phase timers */
     }
     return 0;
 }

@@ -55,7 +55,9 @@
 #define RA_CAP    (64u << 20)    /* pinned payload arena (bytes)                              */
 #define RC_CAP    256u           /* host command ring                                         */
 #define R_WIN     8              /* 64-slot windows of the request ring read per PCIe round trip */
+#ifndef R_SUB
 #define R_SUB     4              /* 64-round chunks a serial role handles per memory round trip  */
+#endif
 #define R_LAT_CAP (1u << 16)
 #define R_SLACK   (3u * WAVE)    /* head room kept in the ticket / doorbell rings             */
 #define R_INLINE  96u            /* payload bytes that fit into the request slot itself       */
@@ -162,7 +164,8 @@ enum { FR_END = 0, FR_E0, FR_SLOT_END, FR_N, FR_HASH_LO, FR_HASH_HI, FR_HEAD, FR
 /* FR_N: [7:0] n  [15:8] client entries   FR_HEAD: the head a <HEAD> entry carries, 0xFFFFFFFF none */
 struct RepFollow {                       /* follower-local (device memory, agent scope) */
     uint64_t quit; uint64_t pad[7];
-    uint64_t stat[2][8];                 /* retire / apply wavefront: passes, passes that moved something, rounds, wall-clock ticks */
+    uint64_t stat[3][8];                 /* retire / apply wavefront: passes, passes that moved something, rounds, wall-clock ticks; [2]: the work
+                                          * wavefronts' phase timers (APUS_REP_DBG & 256): rounds, total, bell -> headers, headers -> stores issued, drain */
     uint64_t fr[FR_WORDS][RB_CAP];          /* granule-major, like the leader's done granules */
 };
 /* a follower's first workgroup: its retire / apply wavefronts' words in LDS */
@@ -242,6 +245,18 @@ __device__ static inline void st16_wt(uint8_t *p, uint4 v)
 {
     v4u_t d = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(d) : "memory");
+}
+/* 16 bytes as a streaming store: acknowledged by the L2, on its way to memory behind that -- visible to others only
+ * behind rep_release() */
+__device__ static inline void st16_nt(uint8_t *p, uint4 v)
+{
+    v4u_t d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(d) : "memory");
+}
+/* everything this wavefront has stored is in memory (system scope): write-back of the L2's dirty lines + drain */
+__device__ static inline void rep_release()
+{
+    asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_wbl2 sc0 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
 }
 /* 16 bytes written through to the device's memory (agent scope: sc1) */
 __device__ static inline void st16_dev(uint8_t *p, uint4 v)
@@ -973,7 +988,7 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
         if (C.slots_done != sd_pub) { sd_pub = C.slots_done; if (lane == 0) st_sys(&H->slots_done, C.slots_done + s_m[M_DROPPED]); }
         if (C.cs > cs_pub) {
             cs_pub = C.cs;
-            if (lane == 0) st_sys(&H->commit_slot, C.cs);
+            if (lane == 0) { if (!(A.dbg & 2048)) st_sys(&H->commit_slot, C.cs); }
             else if (lane <= APUS_DEV_MAX_SERVERS && ((C.push_live >> (lane - 1)) & 1u)) st_sys(&E.box[lane - 1]->commit_bell, C.cs);   /* R4 */
         }
         /* ---- done? ---- */
@@ -1069,7 +1084,7 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, vol
                 n_apply = rl64u(slot_end, (int)p - 1);
                 const uint32_t now = (uint32_t)wall_clock64();
                 const uint32_t t_seq = (uint32_t)g7[s], t_apd = (uint32_t)g6[s];
-                if (mine && t_seq && lat_n + lane < R_LAT_CAP) { LS->lat_ticks[lat_n + lane] = now - t_seq; LS->lat_app[lat_n + lane] = now - t_apd; }
+                if (mine && t_seq && lat_n + lane < R_LAT_CAP && !(A.dbg & 2048)) { LS->lat_ticks[lat_n + lane] = now - t_seq; LS->lat_app[lat_n + lane] = now - t_apd; }
                 lat_n = min(lat_n + p, R_LAT_CAP);
                 t_app += p;
                 progress = true;
@@ -1078,7 +1093,7 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, vol
                 ncl += nc_pass;
                 if (lane == 0) {
                     s_m[M_N_APPLY] = n_apply; s_m[M_T_RETIRED] = t_app;
-                    if (nc_pass) st_sys(&H->highest_rec, hr0 + ncl);
+                    if (nc_pass && !(A.dbg & 2048)) st_sys(&H->highest_rec, hr0 + ncl);
                 }
             }
         }
@@ -1146,6 +1161,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             return;
         }
         const bool timed = A.dbg & 256;
+        const bool nt_ring = A.dbg & 1024;            /* measurement: streaming ring stores + one release per round */
         const uint64_t t_seen = timed ? wall_clock64() : 0;
         wv &= TK_VAL;
         const uint64_t e0 = rdl64(wv, TK_E0), idx0 = rdl64(wv, TK_IDX0), slot0 = rdl64(wv, TK_SLOT0), first = rdl64(wv, TK_SRC);
@@ -1198,8 +1214,10 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         if (active) {
             const uint64_t slot = slot0 + lane;
             const uint32_t di = (uint32_t)slot & E.dir_mask;
+            if (!(A.dbg & 8192)) {
             st_agent(&Md.dir_off[di], pos);
             __hip_atomic_store(&Md.dir_len[di], T | (me << 24), RLX_AGENT);
+            }
             /* the leader's apply record (apply_committed_entries, dare_server.c:1941-1955): written with the
              * entry, counted by the applier once the entry's round is committed */
             client = (type != APUS_NOOP && type != APUS_CONFIG && type != APUS_HEAD);
@@ -1221,7 +1239,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                 __hip_atomic_store(&PT.box[f]->lens[(PT.qbase[f] + k) % RB_CAP][lane], (uint16_t)d.len, RLX_SYSTEM);
             }
         }
-        rep_store_rows32(ar0, ar1, n, [&](uint32_t r) { return (uint8_t *)&Md.apply[(uint32_t)(slot0 + r) & E.dir_mask]; });
+        if (!(A.dbg & 8192)) rep_store_rows32(ar0, ar1, n, [&](uint32_t r) { return (uint8_t *)&Md.apply[(uint32_t)(slot0 + r) & E.dir_mask]; });
         const uint64_t hsum = wave_sum(mix);
         const uint32_t nclient = wave_sum(client);
         {
@@ -1271,7 +1289,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
 #pragma unroll
                     for (int q = 0; q < ILP; q++) {
                         const uint32_t u = u0 + q * WAVE;
-                        if (u < utotal) st16_wt(rg + 16ull * u, v[q]);
+                        if (u < utotal) { if (nt_ring) st16_nt(rg + 16ull * u, v[q]); else st16_wt(rg + 16ull * u, v[q]); }
                     }
                 }
             }
@@ -1320,7 +1338,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         /* the next ticket's words are asked for now: their round trip runs under the drain of this round's stores */
         if (lane < 8) wv_next = ld_agent(&LS->tk[(k + G) % RS_CAP].w[lane]);
         have_next = true;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nt_ring) rep_release(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint64_t t_drained = timed ? wall_clock64() : 0;
         /* ---- the bytes are in every pushed ring.  R2: the round's doorbell in every pushed follower's mailbox;
          *      the round's done granules for the committer and the applier -- one batch of stores, no second drain ---- */
@@ -1372,6 +1390,8 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
     RepBox *const lbox = leader < APUS_DEV_MAX_SERVERS ? E.box[leader] : nullptr;
     uint64_t bell_next = 0;
     bool have_bell = false;
+    const bool timed = A.dbg & 256;
+    uint64_t w_rounds = 0, w_total = 0, w_hdr = 0, w_st = 0, w_drain = 0;
     for (uint64_t q = q0 + g;; q += G) {
         const uint32_t r = (uint32_t)(q % RB_CAP);
         /* ---- wait for the doorbell of round q ---- */
@@ -1387,7 +1407,17 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
             }
             rep_nap(i < 512);
         }
-        if (!go) return;
+        if (!go) {
+            if (timed && lane == 0 && w_rounds) {
+                atomicAdd((unsigned long long *)&FS->stat[2][0], (unsigned long long)w_rounds);
+                atomicAdd((unsigned long long *)&FS->stat[2][1], (unsigned long long)w_total);
+                atomicAdd((unsigned long long *)&FS->stat[2][2], (unsigned long long)w_hdr);
+                atomicAdd((unsigned long long *)&FS->stat[2][3], (unsigned long long)w_st);
+                atomicAdd((unsigned long long *)&FS->stat[2][4], (unsigned long long)w_drain);
+            }
+            return;
+        }
+        const uint64_t t_bell = timed ? wall_clock64() : 0;
         const uint32_t end_after = (uint32_t)rdl64(wv, 0), slot_lo = (uint32_t)rdl64(wv, 1), e0 = (uint32_t)rdl64(wv, 2), w3 = (uint32_t)rdl64(wv, 3);
         const uint32_t n = w3 >> 17, Tu = w3 & 0x1FFFF;
         /* the slot count's high half: this run stays within 2^31 slots of where it began */
@@ -1405,8 +1435,10 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
         uint32_t client = 0;
         uint4 ar0 = make_uint4(0, 0, 0, 0), ar1 = ar0;
         bool acked = false;
+        uint64_t t_hdr = 0;
         if (active) {
             if (A.dbg & 16) ld32_dev(Md.ring + pos, u0, u1); else ld32_sys(Md.ring + pos, u0, u1);
+            if (timed) t_hdr = wall_clock64();
             const uint64_t idx = (uint64_t)u0.x | ((uint64_t)u0.y << 32);
             const uint32_t type = (u1.z >> 16) & 0xFF, sender = u1.z >> 24;
             const uint16_t clt = (uint16_t)(u1.z & 0xFFFF);
@@ -1438,9 +1470,11 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
         const uint64_t hsum = wave_sum(mix);
         const uint32_t nclient = wave_sum(client);
         head_val = (uint32_t)__shfl((int)head_val, 0, WAVE);    /* (a <HEAD> entry is a round of its own) */
+        const uint64_t t_st = timed ? wall_clock64() : 0;
         if (lane < 4) bell_next = ld_sys(&box->rnd[(q + G) % RB_CAP][lane]);     /* the next doorbell: its round trip runs under this drain */
         have_bell = true;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (timed) { const uint64_t t_dr = wall_clock64(); w_rounds++; w_total += t_dr - t_bell; w_hdr += rdl64(t_hdr, 0) - t_bell; w_st += t_st - rdl64(t_hdr, 0); w_drain += t_dr - t_st; }
         /* ---- persisted: the round's granules for the retire / apply wavefronts ---- */
         if (lane < FR_WORDS) {
             uint32_t val = 0;
@@ -1537,7 +1571,7 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
             s_f[F_END] = end; s_f[F_N_END] = n_end;
             s_f[F_Q_RET] = q_ret;                       /* (the apply wavefront reads F_Q_RET first) */
             st_sys(&lbox->persisted_by[me], n_end);
-            if (FHm) st_sys(&FHm->n_end, n_end);
+            if (FHm && !(A.dbg & 2048)) st_sys(&FHm->n_end, n_end);
         }
         /* the host asks this follower to leave (its leader is gone: nobody will ring the park doorbell) */
         if (!progress && FHm && final_q == ~0ull && (idle & 15) == 15 && ld_sys(&FHm->stop)) final_q = q_ret;
@@ -1623,7 +1657,7 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
             }
             if (q_app != t0 && lane == 0) {
                 st_sys(&lbox->applied_by[me], n_apply); st_sys(&lbox->seqdone_by[me], q_app);
-                if (A.FH[me]) st_sys(&A.FH[me]->n_apply, n_apply);
+                if (A.FH[me] && !(A.dbg & 2048)) st_sys(&A.FH[me]->n_apply, n_apply);
             }
         }
         /* ---- park?  everything that was sent is persisted; the leader's last commit doorbell was rung before the

@@ -417,7 +417,7 @@ class Engine:
 
     def rep_role_stats(self) -> dict:
         """diagnostics of the last run: per serial role passes, passes that moved something, rounds, microseconds"""
-        out = np.zeros((16, 8), dtype=np.uint64)
+        out = np.zeros((20, 8), dtype=np.uint64)
         self._chk(self.L.apus_gpu_rep_role_stats(self.h, out.ctypes.data), "rep_role_stats")
         names = ["sequencer", "committer", "applier"] + [f"f{i}_{w}" for i in range(6) for w in ("retire", "apply")]
         d = {nm: {"passes": int(r[0]), "moved": int(r[1]), "rounds": int(r[2]), "us": int(r[3]) / 100.0, "x": int(r[4]), "busy_us": int(r[5]) / 100.0}
@@ -427,6 +427,10 @@ class Engine:
             d["append"] = {"rounds": int(a[0]), "us_per_round": int(a[1]) / 100.0 / int(a[0]), "drain_us": int(a[2]) / 100.0 / int(a[0]),
                            "desc_us": int(a[3]) / 100.0 / int(a[0]), "payload_stores_us": int(a[4]) / 100.0 / int(a[0]),
                            "pre_loop_us": int(a[5]) / 100.0 / int(a[0]), "first_iter_us": int(a[6]) / 100.0 / int(a[0])}
+        w = out[16]
+        if w[0]:
+            d["f0_work"] = {"rounds": int(w[0]), "us_per_round": int(w[1]) / 100.0 / int(w[0]), "bell_to_headers_us": int(w[2]) / 100.0 / int(w[0]),
+                            "stores_issue_us": int(w[3]) / 100.0 / int(w[0]), "drain_us": int(w[4]) / 100.0 / int(w[0])}
         return d
 
     def rep_roundtrip_ns(self, reqs: np.ndarray, arena: np.ndarray, iters: int) -> np.ndarray:
