@@ -78,6 +78,7 @@ SIGNATURES = {
     "apus_gpu_elect": (C.c_int, [vp, u32, u32, u32, C.POINTER(u64)]),
     "apus_gpu_export_replica": (C.c_int, [vp, u32, C.POINTER(IpcReplica)]),
     "apus_gpu_import_replica": (C.c_int, [vp, C.POINTER(IpcReplica)]),
+    "apus_gpu_unmap_peers": (C.c_int, [vp]),
     "apus_gpu_store_stream": (C.c_int, [vp, u32, u64, u64, vp, u64, C.POINTER(u64), C.POINTER(u64)]),
     "apus_gpu_force_prune": (C.c_int, [vp, C.POINTER(u64)]),
     "apus_gpu_adopt_sid": (C.c_int, [vp, u32, u64]),

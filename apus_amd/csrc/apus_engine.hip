@@ -405,6 +405,26 @@ extern "C" int apus_gpu_export_replica(apus_engine_t *e, uint32_t replica, apus_
     return 0;
 }
 
+/* Drop every peer mapping (hipIpcCloseMemHandle) without freeing anything of this engine's own: the first half of an
+ * orderly shutdown of a peer-mapped group -- every process unmaps, a barrier, then every process frees (apus_gpu_destroy).
+ * An owner that frees a buffer a peer still has open cannot export the memory it gets next (hipIpcGetMemHandle fails). */
+extern "C" int apus_gpu_unmap_peers(apus_engine_t *e)
+{
+    if (!e) return APUS_E_ARG;
+    if (e->r_running || e->p_running || e->batching) return APUS_E_STATE;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (uint32_t r = 0; r < APUS_MAX_SERVERS; r++)
+        if ((e->imported_mask >> r) & 1u) {
+            e->d.rep[r] = RepDev{};
+            e->d.box[r] = nullptr; e->d.ackb[r] = nullptr;
+        }
+    e->local_mask &= ~e->imported_mask;
+    e->imported_mask = 0;
+    for (void *p : e->ipc_ptrs) hipIpcCloseMemHandle(p);
+    e->ipc_ptrs.clear();
+    return 0;
+}
+
 extern "C" int apus_gpu_import_replica(apus_engine_t *e, const apus_ipc_replica_t *in)
 {
     if (!e || !in || in->replica >= e->cfg.group_size) return APUS_E_ARG;
@@ -1482,7 +1502,6 @@ extern "C" int apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_
         RepBox *lb = e->d.box[leader];
         uint64_t *words[5] = { &lb->seqdone_by[r], &lb->persisted_by[r], &lb->applied_by[r], &lb->apply_off_by[r], &lb->sid_by[r] };
         for (auto w : words) HIPCHK(hipMemsetAsync(w, 0, sizeof(uint64_t), e->stream));
-        HIPCHK(hipMemsetAsync(lb->rack[r], 0, sizeof lb->rack[r], e->stream));       /* ... and its round counter restarts */
     }
     if ((rc = launch_control_round(e, 2 | 32, 0, 0, 0))) return rc;
     {   /* the new member's own configuration from now on: the one of the join reply, then whatever it polls from the
@@ -2319,7 +2338,12 @@ static int rep_push_cmd(apus_engine *e, uint32_t op, uint64_t a, uint64_t b)
     const double t0 = mono_s();
     pthread_spin_lock(&e->r_lock);
     while (e->r_cmd_tail - e->rh->cmd_head >= RC_CAP - 1)
-        if (e->rh->alive == 2 || mono_s() - t0 > 5.0) { pthread_spin_unlock(&e->r_lock); return APUS_E_STATE; }
+        if (e->rh->alive == 2 || mono_s() - t0 > 5.0) {
+            fprintf(stderr, "[apus_gpu] command ring: no room for command %llu (op %u) after %.1f s: carried out %llu, alive %llu\n",
+                    (unsigned long long)e->r_cmd_tail, op, mono_s() - t0, (unsigned long long)e->rh->cmd_head, (unsigned long long)e->rh->alive);
+            pthread_spin_unlock(&e->r_lock);
+            return APUS_E_STATE;
+        }
     /* four self-tagged granules {command number + 1 : value}: the command is there once all four are */
     RepCmd &c = e->rh->cmd[e->r_cmd_tail % RC_CAP];
     const uint64_t tag = ((e->r_cmd_tail + 1) & 0xFFFFFFFFull) << 32;

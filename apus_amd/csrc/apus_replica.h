@@ -66,7 +66,7 @@
 enum { R_OP_PRUNE = 1, R_OP_RUN = 2, R_OP_STOP = 3 };
 enum { R_SRC_PINNED = 0, R_SRC_STAGED = 1, R_SRC_CONTROL = 2 };
 /* exit codes */
-enum { R_EXIT_STOP = 0, R_EXIT_IDLE = 1, R_EXIT_TIMEOUT = 2, R_EXIT_GAP = 3 };
+enum { R_EXIT_STOP = 0, R_EXIT_IDLE = 1, R_EXIT_TIMEOUT = 2, R_EXIT_GAP = 3, R_EXIT_FENCED = 4 /* a follower met a round of a term older than its own */ };
 
 /* one host command = four self-tagged granules {command number + 1 : value}: op, low half of the request
  * slot count it waits for, a, b */
@@ -114,13 +114,16 @@ struct RepBox {
     uint64_t pad0[4];
     /* followers -> this replica while it leads (index = follower) */
     uint64_t seqdone_by[16];             /* rounds applied (their doorbell slots are free)      */
-    uint64_t persisted_by[16];           /* entry slots persisted, in order                     */
+    /* R3, cumulative and IN ORDER: (f_runs + 1) << 40 | entry slots follower f holds and has persisted, every one of
+     * them -- written by its retire wavefront, which walks the rounds in order.  What the leader's commit is decided
+     * from: an entry counts as acknowledged by f only when f holds everything in front of it, as with the reference's
+     * in-order RC writes (dare_ibv_rc.c:1828-1863 walks old_end -> end).  Round 3 counted per-round ACK granules sent by
+     * the work wavefronts as the rounds landed, out of order: a leader that died between two rounds' arrivals could
+     * have committed (and told a client about) a round that no survivor held behind a contiguous log. */
+    uint64_t persisted_by[16];
     uint64_t applied_by[16];             /* entry slots applied                                 */
     uint64_t apply_off_by[16];           /* ... and the apply offset that goes with it (when the run ends) */
     uint64_t sid_by[16];                 /* a follower that moved on to a newer SID says so here: the term fence */
-    /* R3, round by round: follower f has persisted round q and written the reply byte of every one of its entries
-     * into this replica's log -- granule {q + 1 : entries}.  What the committer's window is made of. */
-    uint64_t rack[APUS_DEV_MAX_SERVERS][RB_CAP];
     /* this replica's own notes, kept across runs of its follower workgroups */
     uint64_t f_seq_next;                 /* next round it expects                               */
     uint64_t f_pend_slot0, f_pend_slot_end, f_pend_sid;   /* an exact-fit round it holds back (its end == len) */
@@ -130,8 +133,10 @@ struct RepBox {
 };
 
 /* one round, sequencer -> append wavefront: eight words {low 16 bits of ticket + 1 : 48-bit value}, valid the
- * moment all eight carry the ticket's tag -- the sequencer never waits for its stores */
-struct RepTicket { uint64_t w[8]; };
+ * moment all eight carry the ticket's tag -- the sequencer never waits for its stores.  Kept word-major
+ * (RepLead.tkw[word][ticket]): the sequencer holds one ticket per lane, so word w of 64 consecutive tickets is ONE
+ * store instruction over 512 contiguous bytes -- whole lines, no transposition through LDS in the serial role
+ * (round 3 did one: 4 KiB through LDS and back per 64 tickets, two LDS round trips per chunk of a pass). */
 enum { TK_E0 = 0, TK_IDX0, TK_SLOT0, TK_SRC, TK_END, TK_D0, TK_D1, TK_META };
 /* TK_D1: control entry data word 1, else the low half of the sequencer's wall clock (latency samples)
  * TK_META: [7:0] n  [11:8] source kind  [12] hidden (the round ends exactly on len)  [23:16] control entry type
@@ -153,7 +158,7 @@ struct RepLead {
     uint64_t stat[4][8];                        /* per serial role (sequencer, committer, applier): passes, passes that moved something, items, wall-clock ticks */
     uint32_t lat_ticks[R_LAT_CAP];              /* sequenced -> committed and applied by the leader      */
     uint32_t lat_app[R_LAT_CAP];                /* bytes in every pushed ring -> committed and applied   */
-    RepTicket tk[RS_CAP];
+    uint64_t  tkw[8][RS_CAP];
     uint64_t  dn[8][RS_CAP];                     /* granule-major: the committer / applier read 64 consecutive tickets' granules in whole lines */
 };
 /* the leader's first workgroup: its wavefronts' words in LDS */
@@ -161,7 +166,11 @@ enum { M_TAIL = 0, M_PROG, M_FINAL, M_T_DONE, M_CS, M_C_FINAL, M_T_RETIRED, M_N_
 
 /* one round as a follower's work wavefront leaves it for its retire / apply wavefronts: granules {round + 1 : value} */
 enum { FR_END = 0, FR_E0, FR_SLOT_END, FR_N, FR_HASH_LO, FR_HASH_HI, FR_HEAD, FR_WORDS = 8 };
-/* FR_N: [7:0] n  [15:8] client entries   FR_HEAD: the head a <HEAD> entry carries, 0xFFFFFFFF none */
+/* FR_N: [7:0] n  [15:8] client entries  [16] every entry acknowledged (none of a term older than this server's)
+ * FR_HEAD: the head a <HEAD> entry carries, 0xFFFFFFFF none.
+ * FR_END .. FR_N go out as soon as the round's entries are read and its stores are issued (the retire wavefront's
+ * cumulative ACK does not wait for this server's own bookkeeping to drain), FR_HASH_LO .. FR_HEAD behind the drain. */
+#define PB_VAL 0xFFFFFFFFFFull
 struct RepFollow {                       /* follower-local (device memory, agent scope) */
     uint64_t quit; uint64_t pad[7];
     uint64_t stat[3][8];                 /* retire / apply wavefront: passes, passes that moved something, rounds, wall-clock ticks; [2]: the work
@@ -276,10 +285,57 @@ __device__ static inline uint64_t rdl64(uint64_t v, int l)
 {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
 }
-__device__ static inline uint64_t rl64u(uint64_t v, int l)
+/* Crossing lanes.  __shfl / __shfl_xor / __shfl_up compile to ds_bpermute_b32 here: a trip through the LDS crossbar,
+ * ~100+ cycles each and a dependent chain of 12 of them for one 64-bit reduction -- a serial role that reduces, scans
+ * and picks "the value of the last lane that ..." a dozen times per pass spends its pass on that (round 4: the
+ * sequencer's 4.4 us per 256 rounds, the applier's 3 us).  So: a WAVE-UNIFORM lane index reads through v_readlane
+ * (rl64u / rl32u), sums / scans / minima over the wavefront go through DPP row shifts + row broadcasts (wscan32 ...),
+ * and only a genuinely per-lane index pays for the crossbar (rl64v).  The DPP forms need all 64 lanes active. */
+__device__ static inline uint64_t rl64v(uint64_t v, int l)       /* l may differ from lane to lane */
 {
     return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), l, WAVE) << 32) | (uint32_t)__shfl((int)(uint32_t)v, l, WAVE);
 }
+__device__ static inline uint64_t rl64u(uint64_t v, int l)       /* l wave-uniform */
+{
+    l = __builtin_amdgcn_readfirstlane(l) & (WAVE - 1);
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+}
+__device__ static inline uint32_t rl32u(uint32_t v, int l)       /* l wave-uniform */
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(l) & (WAVE - 1));
+}
+#define REP_DPP(old, v, ctrl, rows) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(v), ctrl, rows, 0xf, false))
+/* inclusive scan over the 64 lanes: row_shr 1, 2, 4, 8 (a lane without a source adds 0), then lane 15 of rows 0 / 2 into
+ * rows 1 / 3 (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31) */
+__device__ static inline uint32_t wscan32(uint32_t v)
+{
+    v += REP_DPP(0, v, 0x111, 0xf);
+    v += REP_DPP(0, v, 0x112, 0xf);
+    v += REP_DPP(0, v, 0x114, 0xf);
+    v += REP_DPP(0, v, 0x118, 0xf);
+    v += REP_DPP(0, v, 0x142, 0xa);
+    v += REP_DPP(0, v, 0x143, 0xc);
+    return v;
+}
+__device__ static inline uint32_t wsum32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wscan32(v), WAVE - 1); }
+/* 64-bit sum (mod 2^64) as three sums of 22-bit pieces: each stays below 2^28 */
+__device__ static inline uint64_t wsum64(uint64_t v)
+{
+    const uint32_t a = wsum32((uint32_t)v & 0x3FFFFFu), b = wsum32((uint32_t)(v >> 22) & 0x3FFFFFu), c = wsum32((uint32_t)(v >> 44));
+    return (uint64_t)a + ((uint64_t)b << 22) + ((uint64_t)c << 44);
+}
+__device__ static inline uint32_t wmin32(uint32_t v)
+{
+    v = min(v, REP_DPP(v, v, 0x111, 0xf));
+    v = min(v, REP_DPP(v, v, 0x112, 0xf));
+    v = min(v, REP_DPP(v, v, 0x114, 0xf));
+    v = min(v, REP_DPP(v, v, 0x118, 0xf));
+    v = min(v, REP_DPP(v, v, 0x142, 0xa));
+    v = min(v, REP_DPP(v, v, 0x143, 0xc));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, WAVE - 1);
+}
+/* the value of the lane below (lane 0: its own) */
+__device__ static inline uint32_t wprev32(uint32_t v) { return REP_DPP(v, v, 0x138, 0xf); }      /* wave_shr:1 */
 /* Rows that the lanes of a wavefront hold (row r in lane r) go to memory as WHOLE LINES: instruction j writes
  * 1 KiB contiguous, lane l the 16 bytes [l * 16, l * 16 + 16) of it -- a write-through store that covers part of
  * a line is a read-modify-write in HBM, eight 8-byte stores to one line are eight of them in a row. */
@@ -298,7 +354,7 @@ __device__ static inline void rep_store_rows64(const uint64_t (&w)[8], uint32_t 
         uint64_t lo = 0, hi = 0;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const uint64_t a = rl64u(w[2 * c], src), b = rl64u(w[2 * c + 1], src);
+            const uint64_t a = rl64v(w[2 * c], src), b = rl64v(w[2 * c + 1], src);
             if ((uint32_t)c == q) { lo = a; hi = b; }
         }
         if ((uint32_t)src < nrows) st16_wt(row_addr((uint32_t)src) + q * 16, make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)));
@@ -344,7 +400,7 @@ struct RepPlace { int kstar, estar; uint32_t stale; uint64_t w, a, total; };
 __device__ static inline RepPlace rep_place(uint64_t e0, uint64_t L, uint32_t T, uint32_t n)
 {
     const bool active = lane_id() < n;
-    const uint64_t incl = wave_incl_scan((uint64_t)T);
+    const uint64_t incl = wscan32(T);                  /* (a round is at most 64 x 65 599 bytes) */
     RepPlace s;
     s.a = e0 + incl - T;
     const unsigned long long over = __ballot(active && s.a + T > L);
@@ -405,7 +461,7 @@ __device__ static inline bool rep_seq_round(const EngDev &E, RepSeqState &S, Rep
     if (rep_refuse(S.end, L, S.head, p)) return false;
     const int last = (int)n - 1;
     const uint64_t pos_l = rl64u(rep_pos(p, (int)lane), last);
-    const uint32_t T_l = (uint32_t)__shfl((int)T, last, WAVE);
+    const uint32_t T_l = rl32u(T, last);
     const uint64_t idx_l = rep_idx(p, last, S.last_idx + 1);
     const uint64_t end_new = pos_l + T_l;
     const uint32_t hidden = end_new == L;
@@ -421,7 +477,7 @@ __device__ static inline bool rep_seq_round(const EngDev &E, RepSeqState &S, Rep
     case TK_META: v = (uint64_t)n | ((uint64_t)kind << 8) | ((uint64_t)hidden << 12) | ((uint64_t)ctype << 16) | ((uint64_t)S.push_mask << 32); break;
     default: break;
     }
-    if (lane < 8) st_agent(&LS->tk[S.t % RS_CAP].w[lane], rep_tk(S.t, v));
+    if (lane < 8) st_agent(&LS->tkw[lane][S.t % RS_CAP], rep_tk(S.t, v));
     S.t++;
     S.end = end_new; S.tail = pos_l; S.tail_known = true; S.last_idx = idx_l; S.n_end += n; S.store_count += n;
     if (!(kind == R_SRC_CONTROL && ctype == 3)) S.prev_head = 0;
@@ -537,8 +593,38 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
     uint64_t st_pass = 0, st_staged = 0, st_flow = 0, st_busy = 0;
     const uint64_t st_t0 = wall_clock64();
 
+    /* the host command in the first register, once every request slot in front of it is taken: 0 not yet, 1 carried
+     * out, 2 the run ends (STOP) */
+    auto exec_cmd = [&]() -> int {
+        if (!have_cmd && have_cmd2) {                  /* (fetched with the command before it) */
+            have_cmd = true; have_cmd2 = false;
+            cmd_op = cmd2_op; cmd_after = cmd2_after; cmd_a = cmd2_a; cmd_b = cmd2_b;
+        }
+        if (!have_cmd || cmd_after > req_head) return 0;
+        if (cmd_op == R_OP_PRUNE && budget == 0) return 0;          /* (a tick may append a <HEAD> entry: room first) */
+        have_cmd = false;
+        if (cmd_op == R_OP_STOP) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); exit_code = R_EXIT_STOP; return 2; }
+        if (cmd_op == R_OP_RUN) {
+            run_next = cmd_a; run_end = cmd_a + cmd_b;
+            if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); rep_seq_publish(LS, s_m, S, cmd_head + req_head); }
+            return 1;
+        }
+        cmd_head++;
+        if (lane == 0) st_sys(&H->cmd_head, cmd_head);
+        if (cmd_op == R_OP_PRUNE) { rep_seq_prune(E, A, S, s_ao, s_m, bitmask, mybox, cmd_head + req_head); budget--; }
+        else rep_seq_publish(LS, s_m, S, cmd_head + req_head);
+        return 1;
+    };
+
     for (;;) {
         st_pass++;
+        /* ---- a host command that is already here runs at once: no look at the rings in front of it (round 3 paid a
+         *      flow-control round trip and a PCIe round trip per command: a third of the sequencer's time on configs[1]) ---- */
+        if (run_next == run_end) {
+            const int x = exec_cmd();
+            if (x == 2) break;
+            if (x == 1) { idle = 0; continue; }
+        }
         /* ---- flow control: room in the ticket ring and in every pushed follower's doorbell ring ---- */
         if (budget < WAVE * R_SUB && run_next == run_end) {
             uint64_t spins = 0;
@@ -554,8 +640,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                 }
                 const unsigned long long tight = __ballot(room < WAVE);
                 if (!tight) {
-                    for (int d = WAVE / 2; d > 0; d >>= 1) { const uint64_t o = rl64u(room, (int)(lane ^ (uint32_t)d)); room = o < room ? o : room; }
-                    budget = room;
+                    budget = wmin32((uint32_t)min(room, (uint64_t)0xFFFFFFFFu));
                     break;
                 }
                 if (++spins > A.peer_polls) {
@@ -588,7 +673,8 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                 }
                 /* flow control rides along when the room last seen runs low: the ticket ring and every pushed follower's doorbell ring */
                 uint64_t room = ~0ull;
-                if (budget < 2 * WAVE * R_SUB) {
+                const bool fresh = budget < 2 * WAVE * R_SUB;
+                if (fresh) {
                     if (lane == 0) {
                         const uint64_t inflight = S.t - s_m[M_T_RETIRED];
                         room = inflight + R_SLACK >= RS_CAP ? 0 : RS_CAP - R_SLACK - inflight;
@@ -596,28 +682,34 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                         const uint64_t inflight = my_qbase + S.t - ld_sys(&mybox->seqdone_by[lane - 1]);
                         room = inflight + R_SLACK >= RB_CAP ? 0 : RB_CAP - R_SLACK - inflight;
                     }
-                } else room = budget;
+                }
                 /* (and the next host command, if it is there: its PCIe round trip runs under this pass) */
                 const uint64_t next_cmd = cmd_head + 1;               /* (cmd_head is the RUN in progress) */
                 uint64_t cg = 0;
-                const bool peek = !have_cmd && run_end - rc <= 2 * WAVE * R_SUB;      /* (only near the end of the run) */
+                /* (only near the end of the run -- and only when NEITHER command register holds one: a command fetched together
+                 * with this RUN sits in the second register until the run is over; a peek that found only ONE command used to
+                 * leave that register as it was, and the command in it -- the same prune tick -- was carried out a second time:
+                 * an extra tick, and the host's command count one behind the kernel's for good.  Seen only when the host pushes
+                 * its commands slowly: tests/test_gpu_replica.py::test_rep_full_size_staged) */
+                const bool peek = !have_cmd && !have_cmd2 && run_end - rc <= 2 * WAVE * R_SUB;
                 if (peek && lane < 8) cg = ld_sys(&H->cmd[(next_cmd + (lane >> 2)) % RC_CAP].g[lane & 3]);
-                const unsigned long long tight = __ballot(room < WAVE);
-                if (tight) {
-                    if (++spins > A.peer_polls) {
-                        if (tight >> 1) { rep_seq_drop(E, S, LS, (uint32_t)(tight >> 1), 7102); spins = 0; continue; }
-                        exit_code = R_EXIT_TIMEOUT; out = true;     /* the leader's own commit does not move: no majority */
-                        if (lane == 0) spin_timeout(E, 7103);
-                        break;
+                if (fresh) {
+                    const unsigned long long tight = __ballot(room < WAVE);
+                    if (tight) {
+                        if (++spins > A.peer_polls) {
+                            if (tight >> 1) { rep_seq_drop(E, S, LS, (uint32_t)(tight >> 1), 7102); spins = 0; continue; }
+                            exit_code = R_EXIT_TIMEOUT; out = true;     /* the leader's own commit does not move: no majority */
+                            if (lane == 0) spin_timeout(E, 7103);
+                            break;
+                        }
+                        st_flow++;
+                        __builtin_amdgcn_s_sleep(8);
+                        continue;
                     }
-                    st_flow++;
-                    __builtin_amdgcn_s_sleep(8);
-                    continue;
+                    budget = wmin32((uint32_t)min(room, (uint64_t)0xFFFFFFFFu));
                 }
                 spins = 0;
-                for (int d = WAVE / 2; d > 0; d >>= 1) { const uint64_t o = rl64u(room, (int)(lane ^ (uint32_t)d)); room = o < room ? o : room; }
-                budget = room;
-                const uint32_t avail = (uint32_t)min((uint64_t)want, room);
+                const uint32_t avail = (uint32_t)min((uint64_t)want, budget);
                 const uint64_t stamp = wall_clock64() & 0xFFFFFFFFull;
                 uint32_t taken = 0;
 #pragma unroll
@@ -626,7 +718,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                     const uint32_t nch = min((uint32_t)WAVE, avail - (uint32_t)s * WAVE);
                     const bool on = lane < nch;
                     const uint64_t bpf = rl64u(pf0[s], 0);
-                    const uint32_t brf = (uint32_t)__shfl((int)rf0[s], 0, WAVE);
+                    const uint32_t brf = rl32u(rf0[s], 0);
                     const uint64_t used = S.end >= S.head ? S.end - S.head : L - (S.head - S.end);
                     /* lanes that can go without the general code: the log does not read as empty, no entry of rounds
                      * 0..j crosses or touches len, everything fits into the free part of the ring */
@@ -634,30 +726,26 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                     const unsigned long long pm = __ballot(plain);
                     const uint32_t np = (~pm) ? (uint32_t)__builtin_ctzll(~pm) : WAVE;      /* prefix of plain rounds */
                     if (np) {
-                        {
-                            const uint64_t t0 = S.t, tk = t0 + lane;
-                            uint64_t w[8];
-                            w[TK_E0] = rep_tk(tk, S.end + (pf0[s] - bpf));
-                            w[TK_IDX0] = rep_tk(tk, S.last_idx + 1 + (rf0[s] - brf));
-                            w[TK_SLOT0] = rep_tk(tk, S.n_end + (rf0[s] - brf));
-                            w[TK_SRC] = rep_tk(tk, (uint64_t)rf0[s]);
-                            w[TK_END] = rep_tk(tk, S.end + (pf1[s] - bpf));
-                            w[TK_D0] = rep_tk(tk, 0ull);
-                            w[TK_D1] = rep_tk(tk, stamp);
-                            w[TK_META] = rep_tk(tk, (uint64_t)(rf1[s] - rf0[s]) | ((uint64_t)R_SRC_STAGED << 8) | ((uint64_t)S.push_mask << 32));
-                            if (A.dbg & 512) {                       /* measurement: eight strided 8-byte stores instead of the transposition */
-                                if (lane < np) for (int wi = 0; wi < 8; wi++) st_agent(&LS->tk[tk % RS_CAP].w[wi], w[wi]);
-                            } else rep_store_rows64_lds(s_tr, w, np, [&](uint32_t r) { return (uint8_t *)LS->tk[(t0 + r) % RS_CAP].w; });
+                        if (lane < np) {
+                            const uint64_t tk = S.t + lane, ix = tk % RS_CAP;
+                            st_agent(&LS->tkw[TK_E0][ix], rep_tk(tk, S.end + (pf0[s] - bpf)));
+                            st_agent(&LS->tkw[TK_IDX0][ix], rep_tk(tk, S.last_idx + 1 + (rf0[s] - brf)));
+                            st_agent(&LS->tkw[TK_SLOT0][ix], rep_tk(tk, S.n_end + (rf0[s] - brf)));
+                            st_agent(&LS->tkw[TK_SRC][ix], rep_tk(tk, (uint64_t)rf0[s]));
+                            st_agent(&LS->tkw[TK_END][ix], rep_tk(tk, S.end + (pf1[s] - bpf)));
+                            st_agent(&LS->tkw[TK_D0][ix], rep_tk(tk, 0ull));
+                            st_agent(&LS->tkw[TK_D1][ix], rep_tk(tk, stamp));
+                            st_agent(&LS->tkw[TK_META][ix], rep_tk(tk, (uint64_t)(rf1[s] - rf0[s]) | ((uint64_t)R_SRC_STAGED << 8) | ((uint64_t)S.push_mask << 32)));
                         }
                         const uint64_t tot = rl64u(pf1[s], (int)np - 1) - bpf;
-                        const uint32_t ntot = (uint32_t)__shfl((int)rf1[s], (int)np - 1, WAVE) - brf;
+                        const uint32_t ntot = rl32u(rf1[s], (int)np - 1) - brf;
                         S.end += tot; S.last_idx += ntot; S.n_end += ntot; S.store_count += ntot; S.prev_head = 0;
                         S.tail_known = false; S.tail_round = rc + taken + np - 1;
                         if (S.can_commit) { S.c_off = S.end; S.c_slot = S.n_end; }
                         S.t += np; taken += np;
                     } else if (s == 0) {
                         /* the round at the head of the pass needs the general code (wrap, exact fit, nearly full) */
-                        const uint32_t n = (uint32_t)__shfl((int)(rf1[0] - rf0[0]), 0, WAVE);
+                        const uint32_t n = rl32u(rf1[0] - rf0[0], 0);
                         const uint32_t T = lane < n ? APUS_HDR + (uint32_t)E.req_len[brf + lane] : 0u;
                         if (!rep_seq_round(E, S, LS, T, n, R_SRC_STAGED, brf, 0, 0, 0)) {
                             if (lane == 0) { set_status(E, 1u << 1); st_sys(&H->full, ld_sys(&H->full) + 1); }
@@ -676,8 +764,8 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                         have_cmd = true;
                         cmd_op = (uint32_t)rl64u(cg, 0); cmd_after = rep_extend(req_head, (uint32_t)rl64u(cg, 1));
                         cmd_a = (uint32_t)rl64u(cg, 2); cmd_b = (uint32_t)rl64u(cg, 3);
-                        if ((okb & 0xF0ull) == 0xF0ull) {
-                            have_cmd2 = true;
+                        have_cmd2 = (okb & 0xF0ull) == 0xF0ull;
+                        if (have_cmd2) {
                             cmd2_op = (uint32_t)rl64u(cg, 4); cmd2_after = rep_extend(req_head, (uint32_t)rl64u(cg, 5));
                             cmd2_a = (uint32_t)rl64u(cg, 6); cmd2_b = (uint32_t)rl64u(cg, 7);
                         }
@@ -685,7 +773,6 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                 }
             }
             if (out) break;
-            budget = 0;                                   /* (the other sources work their room out again) */
             idle = 0;
             continue;
         }
@@ -693,10 +780,6 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
         uint32_t v[R_WIN];
 #pragma unroll
         for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = ld_sys32(&H->ready_len[(req_head + (uint64_t)wdw * WAVE + lane) % RQ_CAP]);
-        if (!have_cmd && have_cmd2) {                  /* (fetched with the command before it) */
-            have_cmd = true; have_cmd2 = false;
-            cmd_op = cmd2_op; cmd_after = cmd2_after; cmd_a = cmd2_a; cmd_b = cmd2_b;
-        }
         if (!have_cmd) {
             uint64_t cg = 0;
             if (lane < 8) cg = ld_sys(&H->cmd[(cmd_head + (lane >> 2)) % RC_CAP].g[lane & 3]);
@@ -705,29 +788,18 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                 have_cmd = true;
                 cmd_op = (uint32_t)rl64u(cg, 0); cmd_after = rep_extend(req_head, (uint32_t)rl64u(cg, 1));
                 cmd_a = (uint32_t)rl64u(cg, 2); cmd_b = (uint32_t)rl64u(cg, 3);
-                if ((okb & 0xF0ull) == 0xF0ull) {
-                    have_cmd2 = true;
+                have_cmd2 = (okb & 0xF0ull) == 0xF0ull;
+                if (have_cmd2) {
                     cmd2_op = (uint32_t)rl64u(cg, 4); cmd2_after = rep_extend(req_head, (uint32_t)rl64u(cg, 5));
                     cmd2_a = (uint32_t)rl64u(cg, 6); cmd2_b = (uint32_t)rl64u(cg, 7);
                 }
             }
         }
         const uint64_t stopw = ld_sys(&H->stop);
-        if (have_cmd && cmd_after <= req_head) {
-            have_cmd = false;
-            if (cmd_op == R_OP_STOP) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); exit_code = R_EXIT_STOP; break; }
-            if (cmd_op == R_OP_RUN) {
-                run_next = cmd_a; run_end = cmd_a + cmd_b;
-                if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); rep_seq_publish(LS, s_m, S, cmd_head + req_head); }
-                idle = 0;
-                continue;
-            }
-            cmd_head++;
-            if (lane == 0) st_sys(&H->cmd_head, cmd_head);
-            if (cmd_op == R_OP_PRUNE) { rep_seq_prune(E, A, S, s_ao, s_m, bitmask, mybox, cmd_head + req_head); if (budget) budget--; }
-            else rep_seq_publish(LS, s_m, S, cmd_head + req_head);
-            idle = 0;
-            continue;
+        {
+            const int x = exec_cmd();
+            if (x == 2) break;
+            if (x == 1) { idle = 0; continue; }
         }
         /* ---- the pinned request ring: whatever is published, in rounds of <= 64 (one polling() pass takes
          *      the whole tailq, dare_ibv_ud.c:780-790) ---- */
@@ -835,7 +907,7 @@ __device__ static inline uint64_t rep_ack_eval(const RepAckWin<F, W> &win, uint3
         const uint32_t nfull = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
         if (!stop) {
             total += (uint64_t)nfull * 8;
-            if (nfull < WAVE) { total += (uint32_t)__shfl((int)pre, (int)nfull, WAVE); stop = true; }
+            if (nfull < WAVE) { total += rl32u(pre, (int)nfull); stop = true; }
         }
     }
     const uint64_t upto = win.base + total;
@@ -843,96 +915,76 @@ __device__ static inline uint64_t rep_ack_eval(const RepAckWin<F, W> &win, uint3
 }
 
 struct RepCommitState {
-    uint64_t t_done, t_com;             /* tickets whose bytes are in every pushed ring / committed */
+    uint64_t t_done;                    /* tickets whose bytes are in every pushed ring */
     uint64_t vis, vis_off, n_end_seen, cs, slots_done;
     uint64_t pre_end;                   /* entries below this slot were appended before this run: no ticket stands for them */
     uint32_t push_live;
     bool progress;
 };
 
-/* One pass of the committer = ONE memory round trip: the done granules of the next R_SUB x 64 tickets and, for each of
- * them, every follower's round ACK granule (R3: "I have persisted this round and written the reply byte of each of its
- * entries into your log").  One lane per round: replies = popcount(ACKs) + 1 (the leader itself), committed iff the
- * round's bytes are everywhere and replies >= size / 2 + 1 (dare_ibv_rc.c:1738); __ballot over the lanes,
- * count-trailing-ones = the prefix of rounds that commit -- the scan stops at the first round that lacks its majority
- * (:1741).  Granules may be looked at before they are there: one that is not this round's does not count. */
-template <int F>
-__device__ static inline void rep_commit_pass(const EngDev &E, const RepArgs &A, RepLead *LS, RepCommitState &C, uint64_t tail,
-                                              const RepBox *mybox, uint32_t members, uint32_t quorum)
+/* One pass of the committer = ONE memory round trip: the done granules of the next R_SUB x 64 tickets (which rounds'
+ * bytes are in every pushed ring, in order: what is visible of the log) and the line of the followers' cumulative
+ * ACKs.  replies for an entry = #{followers that hold everything up to it} + 1 (the leader itself); committed iff
+ * replies >= size / 2 + 1 (dare_ibv_rc.c:1738) -- with in-order ACKs that is: everything below the (quorum - 1)-th
+ * largest of the followers' counts; the scan stops at the first entry that lacks its majority (:1741) = at that count.
+ * Granules may be looked at before they are there: one that is not this round's does not count. */
+__device__ static inline void rep_commit_pass(const EngDev &E, RepLead *LS, RepCommitState &C, uint64_t tail,
+                                              const RepBox *mybox, uint32_t members, uint32_t quorum, uint64_t my_tag)
 {
     const uint32_t lane = lane_id();
-    const uint64_t base = C.t_com;
-    uint64_t g0[R_SUB], g1[R_SUB], g2[R_SUB], ra[F][R_SUB];
+    const uint64_t base = C.t_done;
+    uint64_t g0[R_SUB], g1[R_SUB], g2[R_SUB];
 #pragma unroll
     for (int s = 0; s < R_SUB; s++) {
         const uint64_t ix = (base + (uint64_t)s * WAVE + lane) % RS_CAP;
         g0[s] = ld_agent(&LS->dn[DN_META][ix]); g1[s] = ld_agent(&LS->dn[DN_SLOT_END][ix]); g2[s] = ld_agent(&LS->dn[DN_END][ix]);
     }
-    {
-        uint32_t m = members;
-#pragma unroll
-        for (int j = 0; j < F; j++) {
-            const bool has = m != 0;
-            const uint32_t f = has ? (uint32_t)__builtin_ctz(m) : 0;
-            m &= m - 1;
-#pragma unroll
-            for (int s = 0; s < R_SUB; s++)
-                ra[j][s] = has ? ld_sys(&mybox->rack[f][(A.qbase[f] + base + (uint64_t)s * WAVE + lane) % RB_CAP]) : 0ull;
-        }
-    }
+    const uint64_t pbw = lane < 16 ? ld_sys(&mybox->persisted_by[lane]) : 0ull;
 #pragma unroll
     for (int s = 0; s < R_SUB; s++) {
-        if (C.t_com != base + (uint64_t)s * WAVE) break;            /* (chunk s is looked at only when every chunk before it committed whole) */
+        if (C.t_done != base + (uint64_t)s * WAVE) break;           /* (chunk s is looked at only when every chunk before it is in whole) */
         const uint64_t k = base + (uint64_t)s * WAVE + lane;
         const bool ret = k < tail && rep_gran_ok(g0[s], k) && rep_gran_ok(g1[s], k) && rep_gran_ok(g2[s], k);
         const unsigned long long balr = __ballot(ret);
         const uint32_t pr = (~balr) ? (uint32_t)__builtin_ctzll(~balr) : WAVE;
         if (!pr) break;
-        const uint32_t meta = (uint32_t)g0[s];
         /* ---- rounds whose bytes are in every pushed ring, in order ---- */
-        if (k - lane + pr > C.t_done) {
-            const uint32_t n = meta & 0xFF;
-            const uint32_t pinned = (lane < pr && k >= C.t_done && ((meta >> 8) & 0xF) == R_SRC_PINNED) ? n : 0;
-            C.slots_done += wave_sum(pinned);
-            const uint32_t meta_l = (uint32_t)__shfl((int)meta, (int)pr - 1, WAVE);
-            const uint32_t se_l = (uint32_t)__shfl((int)(uint32_t)g1[s], (int)pr - 1, WAVE);
-            const uint32_t end_l = (uint32_t)__shfl((int)(uint32_t)g2[s], (int)pr - 1, WAVE);
-            const uint64_t slot_end = rep_extend(C.n_end_seen, se_l);
-            C.n_end_seen = slot_end;
-            C.t_done = k - lane + pr;
-            if ((uint64_t)end_l == E.log_len) {
-                /* the round sits exactly on len: the log reads as empty, nothing of it is visible yet */
-                C.vis = slot_end - (meta_l & 0xFF);
-                C.vis_off = ld_agent(&LS->tk[(C.t_done - 1) % RS_CAP].w[TK_E0]) & TK_VAL;
-            } else { C.vis = slot_end; C.vis_off = end_l; }
-            C.push_live = meta_l >> 16;
-            C.progress = true;
-        }
-        if (C.cs < C.pre_end) break;                                 /* (what was appended before this run commits first) */
-        /* ---- the ACK scan, one lane per round ---- */
-        uint32_t replies = 1;                                        /* the leader itself */
-        {
-            uint32_t m = members;
-#pragma unroll
-            for (int j = 0; j < F; j++) {
-                if (m) { const uint32_t f = (uint32_t)__builtin_ctz(m); replies += rep_gran_ok(ra[j][s], A.qbase[f] + k) ? 1u : 0u; }
-                m &= m - 1;
-            }
-        }
-        /* a round that ends exactly on len is visible once the next one is in */
-        const bool hidden = (meta >> 12) & 1u;
-        const bool next_in = (__shfl_down((int)ret, 1, WAVE) != 0) && lane < WAVE - 1;
-        const bool okc = ret && replies >= quorum && (!hidden || next_in);
-        const unsigned long long balc = __ballot(okc);
-        const uint32_t pc = (~balc) ? (uint32_t)__builtin_ctzll(~balc) : WAVE;    /* trailing ones */
-        if (pc) {
-            const uint32_t se_c = (uint32_t)__shfl((int)(uint32_t)g1[s], (int)pc - 1, WAVE);
-            C.cs = rep_extend(C.cs, se_c);
-            C.t_com += pc;
-            C.progress = true;
-        }
-        if (pc < WAVE) break;
+        const uint32_t meta = (uint32_t)g0[s];
+        const uint32_t n = meta & 0xFF;
+        const uint32_t pinned = (lane < pr && ((meta >> 8) & 0xF) == R_SRC_PINNED) ? n : 0;
+        if (__ballot(pinned != 0)) C.slots_done += wsum32(pinned);
+        const uint32_t meta_l = rl32u(meta, (int)pr - 1);
+        const uint32_t se_l = rl32u((uint32_t)g1[s], (int)pr - 1);
+        const uint32_t end_l = rl32u((uint32_t)g2[s], (int)pr - 1);
+        const uint64_t slot_end = rep_extend(C.n_end_seen, se_l);
+        C.n_end_seen = slot_end;
+        C.t_done += pr;
+        if ((uint64_t)end_l == E.log_len) {
+            /* the round sits exactly on len: the log reads as empty, nothing of it is visible until the next one is in */
+            C.vis = slot_end - (meta_l & 0xFF);
+            C.vis_off = ld_agent(&LS->tkw[TK_E0][(C.t_done - 1) % RS_CAP]) & TK_VAL;
+        } else { C.vis = slot_end; C.vis_off = end_l; }
+        C.push_live = meta_l >> 16;
+        C.progress = true;
+        if (pr < WAVE) break;
     }
+    if (C.cs < C.pre_end) return;                                    /* (what was appended before this run commits first: rep_commit_pre) */
+    /* ---- the ACKs: the (quorum - 1)-th largest of the followers' in-order counts ---- */
+    uint64_t acked = ~0ull;
+    if (quorum > 1) {
+        const bool mem = lane < 16 && ((members >> lane) & 1u) && (pbw >> 40) == my_tag;
+        const uint64_t val = mem ? (pbw & PB_VAL) : 0ull;
+        uint32_t rank = 0;                                           /* values above this lane's (ties: the lower lane first) */
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint64_t vj = rl64u(val, j);
+            rank += (vj > val || (vj == val && (uint32_t)j < lane)) ? 1u : 0u;
+        }
+        const unsigned long long sel = __ballot(lane < 16 && rank == quorum - 2);
+        acked = sel ? rl64u(val, __builtin_ctzll(sel)) : 0ull;
+    }
+    const uint64_t upto = acked < C.vis ? acked : C.vis;
+    if (upto > C.cs) { C.cs = upto; C.progress = true; }
 }
 
 /* what was appended before this run and is not committed yet (an exact-fit round left hidden, entries that had no
@@ -959,8 +1011,10 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
     const uint8_t *ackb = E.ackb[me];
     const uint64_t cap = (uint64_t)E.dir_mask + 1;
     const RepBox *mybox = E.box[me];
+    /* (lane f: the tag follower f's cumulative ACKs carry in this run -- its run counter as the host read it at the start) */
+    const uint64_t my_tag = lane < APUS_DEV_MAX_SERVERS ? ((A.fruns[lane] + 1) & 0xFFFFFFull) : 0ull;
     RepCommitState C;
-    C.t_done = 0; C.t_com = 0;
+    C.t_done = 0;
     C.pre_end = s_h[H_N_END];
     C.vis = s_h[H_N_VISIBLE]; C.vis_off = s_h[H_END];
     C.n_end_seen = s_h[H_N_END];
@@ -980,10 +1034,7 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
         const uint64_t prog = s_m[M_PROG];
         const uint64_t tail = s_m[M_TAIL], fin = s_m[M_FINAL];
         if (C.cs < C.pre_end) rep_commit_pre(E, C, ackb, cap, members, quorum);
-        if (nf <= 2) rep_commit_pass<2>(E, A, LS, C, tail, mybox, members, quorum);
-        else if (nf <= 4) rep_commit_pass<4>(E, A, LS, C, tail, mybox, members, quorum);
-        else if (nf <= 6) rep_commit_pass<6>(E, A, LS, C, tail, mybox, members, quorum);
-        else rep_commit_pass<12>(E, A, LS, C, tail, mybox, members, quorum);
+        rep_commit_pass(E, LS, C, tail, mybox, members, quorum, my_tag);
         if (lane == 0) { s_m[M_T_DONE] = C.t_done; s_m[M_CS] = C.cs; }      /* (the applier reads M_CS first) */
         if (C.slots_done != sd_pub) { sd_pub = C.slots_done; if (lane == 0) st_sys(&H->slots_done, C.slots_done + s_m[M_DROPPED]); }
         if (C.cs > cs_pub) {
@@ -1024,14 +1075,20 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
     }
     /* what the followers acknowledged of the entries that did not commit (no majority): into the slot words
      * the control-plane kernels scan (k_control_round's commit_scan) */
-    for (uint64_t s = C.cs + lane; s < C.n_end_seen; s += WAVE) {
+    const uint64_t pbw = lane < 16 ? ld_sys(&mybox->persisted_by[lane]) : 0ull;
+    const uint64_t held = (lane < 16 && (pbw >> 40) == my_tag) ? (pbw & PB_VAL) : 0ull;     /* (lane f: what follower f holds in order) */
+    for (uint64_t s0 = C.cs; s0 < C.n_end_seen; s0 += WAVE) {      /* (the whole wavefront makes every pass: rl64u below) */
+        const uint64_t s = s0 + lane;
+        const bool in = s < C.n_end_seen;
         const uint32_t di = (uint32_t)s & E.dir_mask;
         const uint8_t want = rep_ack_tag(s, E.dir_mask);
         uint32_t bits = 0;
         for (uint32_t m = members; m; m &= m - 1) {
             const uint32_t f = (uint32_t)__builtin_ctz(m);
-            if (ld_sys8(ackb + (uint64_t)f * cap + di) == want) bits |= 1u << f;
+            const uint64_t hf = rl64u(held, (int)f);
+            if (in && s < hf && ld_sys8(ackb + (uint64_t)f * cap + di) == want) bits |= 1u << f;
         }
+        if (!in) continue;
         __hip_atomic_store(&Md.ack[di], bits, RLX_AGENT);
     }
     /* the last word on the commit, then the followers may park */
@@ -1079,8 +1136,8 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, vol
                 const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
                 if (!p) break;
                 const bool mine = lane < p;
-                hash += wave_sum(mine ? ((uint64_t)(uint32_t)g3[s] | (g4[s] << 32)) : 0ull);
-                nc_pass += wave_sum(mine ? (uint64_t)(uint32_t)g5[s] : 0ull);
+                hash += wsum64(mine ? ((uint64_t)(uint32_t)g3[s] | (g4[s] << 32)) : 0ull);
+                nc_pass += wsum32(mine ? (uint32_t)g5[s] : 0u);
                 n_apply = rl64u(slot_end, (int)p - 1);
                 const uint32_t now = (uint32_t)wall_clock64();
                 const uint32_t t_seq = (uint32_t)g7[s], t_apd = (uint32_t)g6[s];
@@ -1139,12 +1196,20 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
     bool have_next = false;
     for (uint64_t k = g;; k += G) {
         /* ---- wait for ticket k: its eight words carry its tag ---- */
-        const RepTicket &tkt = LS->tk[k % RS_CAP];
+        const uint64_t kx = k % RS_CAP;
         uint64_t wv = wv_next;                       /* (looked at under the previous round's store drain) */
         bool go = false;
         for (uint64_t i = 0;; i++) {
-            if (i || !have_next) { if (lane < 8) wv = ld_agent(&tkt.w[lane]); }
-            if (__ballot(lane < 8 && rep_tk_ok(wv, k)) == 0xFFull) { go = true; break; }
+            /* the eight words of a ticket sit in eight lines (word-major): after two looks that missed, only the word
+             * that is stored last is polled until it carries the tag */
+            bool look = true;
+            if (i >= 2) {
+                uint64_t m = 0;
+                if (lane == 0) m = ld_agent(&LS->tkw[TK_META][kx]);
+                look = rep_tk_ok(rl64u(m, 0), k);
+            }
+            if (look && (i || !have_next)) { if (lane < 8) wv = ld_agent(&LS->tkw[lane][kx]); }
+            if (look && __ballot(lane < 8 && rep_tk_ok(wv, k)) == 0xFFull) { go = true; break; }
             if ((i & 7) == 7 && ld_agent(&LS->seq_final) <= k) break;      /* (one word for everybody: looked at now and then) */
             rep_nap(i < 256);
         }
@@ -1196,7 +1261,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         const uint64_t idx = rep_idx(pl, (int)lane, idx0);
         const uint32_t type = d.pay16_type >> 28;
         const uint32_t nu = active ? (T + 15) / 16 : 0;
-        const uint32_t uincl = wave_incl_scan(nu);
+        const uint32_t uincl = wscan32(nu);
         const uint4 h0 = make_uint4((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)term, (uint32_t)(term >> 32));
         const uint4 h1 = make_uint4((uint32_t)d.req_id, (uint32_t)(d.req_id >> 32), (uint32_t)d.clt_id | (type << 16) | (me << 24), 0);
         lds.pos[lane] = pos;
@@ -1206,7 +1271,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         lds.h0[lane] = h0; lds.h1[lane] = h1;
         if (lane == WAVE - 1) lds.ubase[WAVE] = uincl;
         /* every entry of the same size?  (the followers then place the round from one number) */
-        const uint32_t T0 = (uint32_t)__shfl((int)T, 0, WAVE);
+        const uint32_t T0 = rl32u(T, 0);
         const bool uniform = !__ballot(active && T != T0);
         uint64_t mix = 0;
         uint32_t client = 0;
@@ -1240,11 +1305,11 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             }
         }
         if (!(A.dbg & 8192)) rep_store_rows32(ar0, ar1, n, [&](uint32_t r) { return (uint8_t *)&Md.apply[(uint32_t)(slot0 + r) & E.dir_mask]; });
-        const uint64_t hsum = wave_sum(mix);
-        const uint32_t nclient = wave_sum(client);
+        const uint64_t hsum = wsum64(mix);
+        const uint32_t nclient = wsum32(client);
         {
             const uint64_t end_chk = rl64u(pos + T, (int)n - 1);        /* the sequencer and this wavefront must agree */
-            const uint32_t T0x = (uint32_t)__shfl((int)T, 0, WAVE);
+            const uint32_t T0x = rl32u(T, 0);
             if (lane == 0 && end_chk != end_after && !(atomicOr(E.status, 1u << 3) & (1u << 3))) {
                 E.status[3] = (uint32_t)k; E.status[4] = (uint32_t)end_chk; E.status[5] = (uint32_t)end_after;
                 E.status[6] = n | (kind << 8) | (T0x << 16); E.status[7] = (uint32_t)e0;
@@ -1336,7 +1401,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         }
         const uint64_t t_stores = timed ? wall_clock64() : 0;
         /* the next ticket's words are asked for now: their round trip runs under the drain of this round's stores */
-        if (lane < 8) wv_next = ld_agent(&LS->tk[(k + G) % RS_CAP].w[lane]);
+        if (lane < 8) wv_next = ld_agent(&LS->tkw[lane][(k + G) % RS_CAP]);
         have_next = true;
         if (nt_ring) rep_release(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint64_t t_drained = timed ? wall_clock64() : 0;
@@ -1464,30 +1529,25 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
             if (client) mix = apus_apply_mix(slot, pos, idx, T - APUS_HDR, clt, (uint8_t)type, 2);
             if (type == APUS_HEAD) { uint4 x0, x1; ld32_sys(Md.ring + pos + 32, x0, x1); head_val = x1.x; }
         }
-        /* ... and the round's ACK granule in the sender's mailbox once every entry of the round is acknowledged */
-        if (!__ballot(active && !acked) && lane == 0) st_sys(&lbox->rack[me][q % RB_CAP], rep_gran(q, n));
+        const uint32_t acked_all = __ballot(active && !acked) ? 0u : 1u;
         if (!(A.dbg & 2)) rep_store_rows32(ar0, ar1, n, [&](uint32_t r) { return (uint8_t *)&Md.apply[(uint32_t)(slot0 + r) & E.dir_mask]; });
-        const uint64_t hsum = wave_sum(mix);
-        const uint32_t nclient = wave_sum(client);
-        head_val = (uint32_t)__shfl((int)head_val, 0, WAVE);    /* (a <HEAD> entry is a round of its own) */
+        const uint64_t hsum = wsum64(mix);
+        const uint32_t nclient = wsum32(client);
+        head_val = rl32u(head_val, 0);    /* (a <HEAD> entry is a round of its own) */
+        /* ---- read, acknowledged entry by entry, the bookkeeping stores issued: the round's geometry for the retire wavefront,
+         *      whose in-order count IS the ACK the leader commits on (R3) -- not held up by this server's own drain ---- */
+        if (lane < 4) {
+            const uint32_t val = lane == FR_END ? end_after : lane == FR_E0 ? e0 : lane == FR_SLOT_END ? (uint32_t)slot_end : (n | (nclient << 8) | (acked_all << 16));
+            st_agent(&FS->fr[lane][r], rep_gran(q, val));
+        }
         const uint64_t t_st = timed ? wall_clock64() : 0;
         if (lane < 4) bell_next = ld_sys(&box->rnd[(q + G) % RB_CAP][lane]);     /* the next doorbell: its round trip runs under this drain */
         have_bell = true;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (timed) { const uint64_t t_dr = wall_clock64(); w_rounds++; w_total += t_dr - t_bell; w_hdr += rdl64(t_hdr, 0) - t_bell; w_st += t_st - rdl64(t_hdr, 0); w_drain += t_dr - t_st; }
-        /* ---- persisted: the round's granules for the retire / apply wavefronts ---- */
-        if (lane < FR_WORDS) {
-            uint32_t val = 0;
-            switch (lane) {
-            case FR_END: val = end_after; break;
-            case FR_E0: val = e0; break;
-            case FR_SLOT_END: val = (uint32_t)slot_end; break;
-            case FR_N: val = n | (nclient << 8); break;
-            case FR_HASH_LO: val = (uint32_t)hsum; break;
-            case FR_HASH_HI: val = (uint32_t)(hsum >> 32); break;
-            case FR_HEAD: val = head_val; break;
-            default: break;
-            }
+        /* ---- everything this round stored is in memory: the granules the apply wavefront waits for ---- */
+        if (lane >= FR_HASH_LO && lane <= FR_HEAD) {
+            const uint32_t val = lane == FR_HASH_LO ? (uint32_t)hsum : lane == FR_HASH_HI ? (uint32_t)(hsum >> 32) : head_val;
             st_agent(&FS->fr[lane][r], rep_gran(q, val));
         }
     }
@@ -1515,7 +1575,8 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
     }
     uint64_t real_n_end = n_end + pend_n;                /* slots consumed, the held-back round included */
     uint64_t real_end = pend_n ? L : end;
-    if (lane == 0) st_sys(&lbox->persisted_by[me], n_end);
+    const uint64_t pb_tag = ((my_run + 1) & 0xFFFFFFull) << 40;
+    if (lane == 0) st_sys(&lbox->persisted_by[me], pb_tag | n_end);
     uint64_t idle = 0;
     uint32_t exit_code = R_EXIT_STOP;
     uint64_t final_q = ~0ull;
@@ -1536,14 +1597,18 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
         }
         if (final_q == ~0ull && (ctrl >> 40) == my_run + 1) final_q = q0 + (ctrl & 0xFFFFFFFFFFull) - 1;
         const uint64_t t0 = q_ret;
-        bool gap = false;
+        bool gap = false, fenced = false;
 #pragma unroll
         for (int s = 0; s < R_SUB; s++) {
-            if (q_ret != t0 + (uint64_t)s * WAVE) break;
+            if (q_ret != t0 + (uint64_t)s * WAVE || fenced) break;
             const uint64_t q = q_ret + lane;
             const bool okq = q < final_q && rep_gran_ok(f0[s], q) && rep_gran_ok(f1[s], q) && rep_gran_ok(f2[s], q) && rep_gran_ok(f3[s], q);
             const unsigned long long bal = __ballot(okq);
-            const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
+            uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
+            /* a round with an entry this server did not acknowledge (a term older than its own: the fence) ends the run
+             * in front of it: the log stops where the deposed leader's rounds begin */
+            const unsigned long long nak = __ballot(lane < p && !(((uint32_t)f3[s] >> 16) & 1u));
+            if (nak) { p = min(p, (uint32_t)__builtin_ctzll(nak)); fenced = true; }
             if (!p) break;
             const bool mine = lane < p;
             const uint64_t ea = (uint32_t)f0[s], e0 = (uint32_t)f1[s], nn = (uint32_t)f3[s] & 0xFF;
@@ -1552,6 +1617,12 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
              * the leader's catch-up first) */
             const uint64_t e0_0 = rl64u(e0, 0), s0_0 = rl64u(se - nn, 0);
             if (e0_0 != real_end || s0_0 != real_n_end) { gap = true; break; }
+            /* ... and EVERY round continues the one before it: a doorbell that is not of this run's sequence (another
+             * leader's, left behind in the ring) would carry this run's tag only by accident, never its geometry */
+            {
+                const uint32_t ea_p = wprev32((uint32_t)ea), se_p = wprev32((uint32_t)se);
+                if (__ballot(mine && lane > 0 && ((uint32_t)e0 != ea_p || (uint32_t)(se - nn) != se_p))) { gap = true; break; }
+            }
             /* rounds up to the last one that does not end on len become visible */
             const unsigned long long vis_b = __ballot(mine && ea != L);
             const uint64_t se_l = rl64u(se, (int)p - 1), ea_l = rl64u(ea, (int)p - 1);
@@ -1570,9 +1641,10 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
         if (progress && lane == 0) {
             s_f[F_END] = end; s_f[F_N_END] = n_end;
             s_f[F_Q_RET] = q_ret;                       /* (the apply wavefront reads F_Q_RET first) */
-            st_sys(&lbox->persisted_by[me], n_end);
+            st_sys(&lbox->persisted_by[me], pb_tag | n_end);
             if (FHm && !(A.dbg & 2048)) st_sys(&FHm->n_end, n_end);
         }
+        if (fenced) { exit_code = R_EXIT_FENCED; break; }
         /* the host asks this follower to leave (its leader is gone: nobody will ring the park doorbell) */
         if (!progress && FHm && final_q == ~0ull && (idle & 15) == 15 && ld_sys(&FHm->stop)) final_q = q_ret;
         /* ---- park? ---- */
@@ -1645,12 +1717,12 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
                 const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
                 if (!p) break;
                 const bool mine = lane < p;
-                hash += wave_sum(mine ? ((uint64_t)(uint32_t)f4[s] | (f5[s] << 32)) : 0ull);
-                ncl += wave_sum(mine ? (uint64_t)(((uint32_t)f3[s] >> 8) & 0xFF) : 0ull);
+                hash += wsum64(mine ? ((uint64_t)(uint32_t)f4[s] | (f5[s] << 32)) : 0ull);
+                ncl += wsum32(mine ? (((uint32_t)f3[s] >> 8) & 0xFF) : 0u);
                 /* poll_config_entries: a committed <HEAD> entry moves the head (dare_server.c:2164) */
                 const uint32_t hv = mine ? (uint32_t)f6[s] : 0xFFFFFFFFu;
                 const unsigned long long hb = __ballot(hv != 0xFFFFFFFFu);
-                if (hb) { const uint64_t h = (uint32_t)__shfl((int)hv, 63 - __builtin_clzll(hb), WAVE); if (apus_is_larger(end, L, h, head)) head = h; }
+                if (hb) { const uint64_t h = rl32u(hv, 63 - __builtin_clzll(hb)); if (apus_is_larger(end, L, h, head)) head = h; }
                 n_apply = rl64u(se, (int)p - 1);
                 q_app += p;
                 progress = true;
@@ -1681,7 +1753,11 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
         mh[H_APPLY_HASH] = hash0 + hash; mh[H_APPLY_COUNT] = cnt0 + ncl;
         st_agent(&FS->quit, 1ull);
         st_sys(&lbox->apply_off_by[me], a_off);
-        st_sys(&box->f_seq_next, q_ret);
+        /* the next run's rounds are numbered from a fresh stretch of the doorbell sequence: whatever a leader that
+         * died (or was deposed) mid-flight left in rnd[] beyond q_ret -- it can have rung doorbells up to
+         * q_app + RB_CAP - R_SLACK, out of order -- carries numbers no later run uses (tags must not be
+         * reusable across runs and terms); the leader's rack[] granules are numbered with the same sequence */
+        st_sys(&box->f_seq_next, q_ret + RB_CAP);
         st_sys(&box->f_pend_slot0, n_end); st_sys(&box->f_pend_slot_end, pend_n ? s_f[F_PEND_SLOT_END] : 0ull); st_sys(&box->f_pend_sid, my_sid);
         st_sys(&box->f_exit, (uint64_t)exit_code + 1);
         if (A.FH[me]) { st_sys(&A.FH[me]->n_apply, n_apply); st_sys(&A.FH[me]->exit_code, (uint64_t)exit_code); }

@@ -253,6 +253,8 @@ class PeerMember:
         except EngineError:
             pass
         dist.barrier()                      # nobody unmaps / frees while a peer may still write
+        self.eng.L.apus_gpu_unmap_peers(self.eng.h)
+        dist.barrier()                      # nobody frees what a peer still has mapped
         self.eng.close()
 
 

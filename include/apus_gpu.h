@@ -184,6 +184,10 @@ int  apus_gpu_export_replica(apus_engine_t *e, uint32_t replica, apus_ipc_replic
 /* maps a peer process's replica; from then on this engine can lead a group that contains it.
  * The memory stays owned by the exporter (never reset or freed here). */
 int  apus_gpu_import_replica(apus_engine_t *e, const apus_ipc_replica_t *in);
+/* Orderly shutdown of a peer-mapped group, first half: close every imported mapping, free nothing.  (Every process
+ * unmaps, a barrier, then every process destroys: an owner that frees a buffer a peer still has open cannot export
+ * the memory it allocates next.)  APUS_E_STATE while a resident kernel or a batch is open. */
+int  apus_gpu_unmap_peers(apus_engine_t *e);
 
 /* ---- control plane (host-driven, ms-scale in the reference) ---------------- */
 /* Role/term change: the caller (host election logic) decided that `leader` won

@@ -41,6 +41,10 @@ class _FakeLib:
         self.eng.imported[o.replica] = bytes(o)
         return 0
 
+    def apus_gpu_unmap_peers(self, h):
+        self.eng.calls.append(("unmap_peers",))
+        return 0
+
 
 class _FakeEngine:
     """records what the host asks of the device; control-plane bookkeeping as in apus_amd/engine.py"""
