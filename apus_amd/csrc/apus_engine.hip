@@ -2556,6 +2556,7 @@ extern "C" int apus_gpu_rep_role_stats(apus_engine_t *e, uint64_t out[20][8])
     memset(out, 0, sizeof(uint64_t) * 20 * 8);
     if (e->rl) HIPCHK(hipMemcpy(out, e->rl->stat, sizeof(uint64_t) * 3 * 8, hipMemcpyDeviceToHost));
     if (e->rl) HIPCHK(hipMemcpy(out[15], e->rl->stat[3], sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
+    if (e->rl) HIPCHK(hipMemcpy(out[17], e->rl->stat[4], sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
     int k = 0;
     for (uint32_t m = e->r_follow_mask; m && k < 6; m &= m - 1, k++) {
         RepFollow *fs = e->rfs[__builtin_ctz(m)];

@@ -74,10 +74,20 @@ struct PersistDev {
 #define RLX_AGENT  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define RLX_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
 
-__device__ static inline uint64_t ld_agent(const uint64_t *p) { return __hip_atomic_load(p, RLX_AGENT); }
-__device__ static inline void st_agent(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, RLX_AGENT); }
-__device__ static inline uint64_t ld_sys(const volatile uint64_t *p) { return __hip_atomic_load((const uint64_t *)p, RLX_SYSTEM); }
-__device__ static inline void st_sys(volatile uint64_t *p, uint64_t v) { __hip_atomic_store((uint64_t *)p, v, RLX_SYSTEM); }
+/* Every word these touch lies in device or pinned host memory: the pointers are cast to the global address space, so
+ * that the compiler emits global_load / global_store.  Through a generic pointer they are FLAT instructions, which count in
+ * vmcnt AND lgkmcnt: every wait for an LDS word then also waits for the write-through stores in flight (2-4 us each). */
+#define APUS_G64(p) ((APUS_GLOBAL uint64_t *)(uintptr_t)(p))
+__device__ static inline uint64_t ld_agent(const uint64_t *p) { return __hip_atomic_load(APUS_G64(p), RLX_AGENT); }
+__device__ static inline void st_agent(uint64_t *p, uint64_t v) { __hip_atomic_store(APUS_G64(p), v, RLX_AGENT); }
+__device__ static inline uint64_t ld_sys(const volatile uint64_t *p) { return __hip_atomic_load(APUS_G64(p), RLX_SYSTEM); }
+__device__ static inline void st_sys(volatile uint64_t *p, uint64_t v) { __hip_atomic_store(APUS_G64(p), v, RLX_SYSTEM); }
+/* words in LDS that wavefronts of one workgroup hand each other: volatile, and typed as LDS -- a volatile access through a
+ * generic pointer is a FLAT instruction followed by s_waitcnt vmcnt(0) (the address space of a volatile access is never
+ * inferred): every look at such a word waited for every store the wavefront had in flight. */
+#define APUS_LDS __attribute__((address_space(3)))
+typedef volatile uint64_t APUS_LDS *lds_u64;
+#define APUS_LDS64(p) ((lds_u64)(p))
 
 /* 16 bytes to another workgroup's view of memory: ONE write-through store
  * (global_store_dwordx4 sc0 sc1 = the R1 store of cdna_hip_programming.md G16); byte-wise
@@ -91,7 +101,7 @@ __device__ static inline void st16_agent(uint8_t *p, uint4 v)
     } else {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         for (int i = 0; i < 16; i++)
-            __hip_atomic_store(p + i, (uint8_t)(w[i >> 2] >> (8 * (i & 3))), RLX_AGENT);
+            __hip_atomic_store((APUS_GLOBAL uint8_t *)(uintptr_t)(p + i), (uint8_t)(w[i >> 2] >> (8 * (i & 3))), RLX_AGENT);
     }
 }
 

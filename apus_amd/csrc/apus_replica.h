@@ -141,6 +141,18 @@ enum { TK_E0 = 0, TK_IDX0, TK_SLOT0, TK_SRC, TK_END, TK_D0, TK_D1, TK_META };
 /* TK_D1: control entry data word 1, else the low half of the sequencer's wall clock (latency samples)
  * TK_META: [7:0] n  [11:8] source kind  [12] hidden (the round ends exactly on len)  [23:16] control entry type
  *          [47:32] push mask */
+/* BULK passes (round 4).  Writing eight words per ticket is what the sequencer's time went into (a wavefront issues one
+ * instruction every four to five cycles: 4 us per pass of 256 tickets, 28 ns per round -- the whole kernel's ceiling).  A
+ * pass of >= 64 PLAIN staged rounds (no wrap, no exact fit, room in the ring: positions are prefix arithmetic) is therefore
+ * ONE pass record {first ticket, first round, end / idx / slot before the pass, the prefix sums of its first round, push
+ * mask, clock} plus TWO words per ticket (TK_META with TK_BULK set: the round's number and the low bits of the pass number; TK_SRC: the
+ * round's first request and their number, so that the descriptors can be asked for together with the record);
+ * the append wavefront works the other seven words out for itself from the record and the staged prefix sums
+ * (E.round_prefix / E.round_first: read-only during a run).  Everything else -- pinned rounds, control entries, the round at
+ * a wrap, short passes -- keeps its eight words. */
+#define TK_BULK   (1ull << 13)          /* TK_META: [11:0] pass number (low bits)  [13] 1  [47:16] staged round; TK_SRC: [31:0] first request  [38:32] n */
+#define PR_CAP    512u                  /* pass records (a bulk pass has >= 64 tickets, RS_CAP tickets are in flight at most) */
+enum { PR_T0 = 0, PR_RC0, PR_END0, PR_IDX0, PR_SLOT0, PR_BPF, PR_BRF_N, PR_PUSH_STAMP };   /* words {low 16 bits of pass + 1 : 48-bit value} */
 #define TK_VAL 0x0000FFFFFFFFFFFFull
 __device__ static inline uint64_t rep_tk(uint64_t t, uint64_t v) { return (((t + 1) & 0xFFFFull) << 48) | (v & TK_VAL); }
 __device__ static inline bool rep_tk_ok(uint64_t w, uint64_t t) { return (w >> 48) == ((t + 1) & 0xFFFFull); }
@@ -155,14 +167,16 @@ struct RepLead {
     uint64_t drop_mask, slots_dropped, pad2[6];
     uint64_t t_drop[16];                        /* tickets issued when follower f left the push set (~0: still in) */
     uint32_t lat_n, pad3;
-    uint64_t stat[4][8];                        /* per serial role (sequencer, committer, applier): passes, passes that moved something, items, wall-clock ticks */
+    uint64_t stat[6][8];                        /* per serial role (sequencer, committer, applier): passes, passes that moved something, items, wall-clock ticks; [3] append phase timers; [4] more of the sequencer's */
     uint32_t lat_ticks[R_LAT_CAP];              /* sequenced -> committed and applied by the leader      */
     uint32_t lat_app[R_LAT_CAP];                /* bytes in every pushed ring -> committed and applied   */
     uint64_t  tkw[8][RS_CAP];
+    uint64_t  prec[PR_CAP][8];
     uint64_t  dn[8][RS_CAP];                     /* granule-major: the committer / applier read 64 consecutive tickets' granules in whole lines */
 };
 /* the leader's first workgroup: its wavefronts' words in LDS */
-enum { M_TAIL = 0, M_PROG, M_FINAL, M_T_DONE, M_CS, M_C_FINAL, M_T_RETIRED, M_N_APPLY, M_A_FINAL, M_A_HASH, M_A_NCL, M_DROPPED, M_WORDS = 16 };
+enum { M_TAIL = 0, M_PROG, M_FINAL, M_T_DONE, M_CS, M_C_FINAL, M_T_RETIRED, M_N_APPLY, M_A_FINAL, M_A_HASH, M_A_NCL, M_DROPPED,
+       M_WORDS = 16 };
 
 /* one round as a follower's work wavefront leaves it for its retire / apply wavefronts: granules {round + 1 : value} */
 enum { FR_END = 0, FR_E0, FR_SLOT_END, FR_N, FR_HASH_LO, FR_HASH_HI, FR_HEAD, FR_WORDS = 8 };
@@ -211,9 +225,9 @@ struct RepArgs {
 
 /* a short nap between two polls while work is expected, a longer one once the poller has been idle */
 __device__ static inline void rep_nap(bool eager) { if (eager) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(12); }
-__device__ static inline uint32_t ld_sys32(const volatile uint32_t *p) { return __hip_atomic_load((const uint32_t *)p, RLX_SYSTEM); }
-__device__ static inline void st_sys8(uint8_t *p, uint8_t v) { __hip_atomic_store(p, v, RLX_SYSTEM); }
-__device__ static inline uint8_t ld_sys8(const uint8_t *p) { return __hip_atomic_load(p, RLX_SYSTEM); }
+__device__ static inline uint32_t ld_sys32(const volatile uint32_t *p) { return __hip_atomic_load((const APUS_GLOBAL uint32_t *)(uintptr_t)p, RLX_SYSTEM); }
+__device__ static inline void st_sys8(uint8_t *p, uint8_t v) { __hip_atomic_store((APUS_GLOBAL uint8_t *)(uintptr_t)p, v, RLX_SYSTEM); }
+__device__ static inline uint8_t ld_sys8(const uint8_t *p) { return __hip_atomic_load((const APUS_GLOBAL uint8_t *)(uintptr_t)p, RLX_SYSTEM); }
 __device__ static inline uint8_t rep_ack_tag(uint64_t slot, uint32_t dir_mask)
 {
     return (uint8_t)(((slot / ((uint64_t)dir_mask + 1)) & 0x7F) + 1);
@@ -432,6 +446,13 @@ struct RepSeqState {                    /* the sequencer's registers: the leader
     uint64_t c_off, c_slot;             /* the commit as it stands once everything issued has its majority */
     uint64_t sample_slot;               /* slots the servers sampled by the last tick are taken to have applied */
     uint64_t t;                         /* tickets issued                                      */
+    uint64_t pass_seq;                  /* bulk passes issued                                  */
+    /* Head moves that are not verified yet (rep_seq_prune): a small queue in LDS of {the slot count every sampled server
+     * must have applied, the head that then holds}, and the head as it stands with the verified moves only -- what
+     * protects the ring (rep_refuse) until the rest is verified. */
+    lds_u64 pv;
+    uint64_t head_safe;
+    uint32_t pv_r, pv_n;
     uint64_t tail_round;                /* staged round whose last entry is the tail (tail worked out when somebody asks) */
     uint32_t push_mask;
     bool     can_commit, tail_known;
@@ -445,6 +466,10 @@ __device__ static inline void rep_seq_fix_tail(const EngDev &E, RepSeqState &S)
     S.tail_known = true;
 }
 
+#define R_PV 8u                         /* head moves that may be unverified at a time */
+struct RepSeqCtx { const RepArgs *A; lds_u64 s_m; RepBox *mybox; };
+__device__ static inline bool rep_seq_wait_verified(const EngDev &E, const RepSeqCtx &X, RepSeqState &S, RepLead *LS, uint32_t keep);
+
 __device__ static inline bool rep_quorum(const EngDev &E, uint32_t push_mask)
 {
     const uint32_t size = E.group_size, size_mask = (1u << size) - 1;
@@ -452,12 +477,16 @@ __device__ static inline bool rep_quorum(const EngDev &E, uint32_t push_mask)
 }
 
 /* one round through the general placement code: lane j holds its entry's size.  False: refused (log full). */
-__device__ static inline bool rep_seq_round(const EngDev &E, RepSeqState &S, RepLead *LS, uint32_t T, uint32_t n, uint32_t kind,
+__device__ static inline bool rep_seq_round(const EngDev &E, const RepSeqCtx &X, RepSeqState &S, RepLead *LS, uint32_t T, uint32_t n, uint32_t kind,
                                             uint64_t first, uint32_t ctype, uint64_t d0, uint64_t d1)
 {
     const uint64_t L = E.log_len;
     const uint32_t lane = lane_id();
     const RepPlace p = rep_place(S.end, L, T, n);
+    /* the round would run into bytes that lie behind the head only by moves nobody has verified yet: verify first */
+    while (S.pv_n && rep_refuse(S.end, L, S.head_safe, p)) {
+        if (!rep_seq_wait_verified(E, X, S, LS, S.pv_n - 1)) return false;
+    }
     if (rep_refuse(S.end, L, S.head, p)) return false;
     const int last = (int)n - 1;
     const uint64_t pos_l = rl64u(rep_pos(p, (int)lane), last);
@@ -486,7 +515,7 @@ __device__ static inline bool rep_seq_round(const EngDev &E, RepSeqState &S, Rep
 }
 
 /* the tickets issued so far: for the committer (LDS).  The append wavefronts poll their tickets themselves. */
-__device__ static inline void rep_seq_publish(RepLead *LS, volatile uint64_t *s_m, const RepSeqState &S, uint64_t progress)
+__device__ static inline void rep_seq_publish(RepLead *LS, lds_u64 s_m, const RepSeqState &S, uint64_t progress)
 {
     if (lane_id() == 0) {
         s_m[M_TAIL] = S.t;                             /* (whoever reads M_PROG first and M_TAIL second sees every ticket behind the progress) */
@@ -518,27 +547,63 @@ __device__ static inline void rep_seq_drop(const EngDev &E, RepSeqState &S, RepL
  * own applier) before the head may move -- a server that did not is waited for (bounded), then it leaves
  * the push set and the head stays.  Without a majority nothing commits: S.c_off stands still, the sample
  * is the real state. */
-__device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, RepSeqState &S, volatile uint64_t *s_ao /*[16] LDS*/,
-                                            volatile uint64_t *s_m, uint32_t bitmask, RepBox *mybox, uint64_t progress)
+/* Round 4: the tick no longer WAITS for the last tick's samples to become true (that wait drained the pipeline to
+ * less than one tick's stretch of rounds seventeen times per pass over configs[1]: the append wavefronts starved, more
+ * workgroups bought nothing).  The head moves at once -- its value is the pinned schedule's, nothing else depends on the
+ * verification -- and the move goes into a queue {slot count the sampled servers must have applied, new head}; the
+ * ring is protected by the VERIFIED head (S.head_safe) until the queue entry is retired: rep_seq_round and the plain
+ * path refuse / wait on S.head_safe, a tick that finds the queue full waits for its oldest entry (bounded; a follower
+ * that does not get there leaves the push set, as before). */
+__device__ static inline uint64_t rep_seq_applied(const RepSeqState &S, lds_u64 s_m, RepBox *mybox)
+{
+    const uint32_t lane = lane_id();
+    if (lane == 0) return s_m[M_N_APPLY];
+    if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) return ld_sys(&mybox->applied_by[lane - 1]);
+    return ~0ull;
+}
+/* retires the head moves that have become true (one look at the applied counts); -> the lanes (0: the leader's own
+ * applier, f + 1: follower f) that are still behind the oldest one left, 0 when nothing is left */
+__device__ static inline unsigned long long rep_seq_verify(RepSeqState &S, lds_u64 s_m, RepBox *mybox)
+{
+    if (!S.pv_n) return 0;
+    const uint64_t v = rep_seq_applied(S, s_m, mybox);
+    for (;;) {
+        if (!S.pv_n) return 0;
+        const uint32_t ix = 2 * (S.pv_r % R_PV);
+        const uint64_t need = S.pv[ix];
+        const unsigned long long late = __ballot(v < need);
+        if (late) return late;
+        S.head_safe = S.pv[ix + 1];
+        S.pv_r++; S.pv_n--;
+    }
+}
+/* waits (bounded) until at most `keep` head moves are unverified.  False: the leader's own applier did not get there. */
+__device__ static inline bool rep_seq_wait_verified(const EngDev &E, const RepSeqCtx &X, RepSeqState &S, RepLead *LS, uint32_t keep)
+{
+    for (uint64_t spins = 0; S.pv_n > keep;) {
+        const uint32_t before = S.pv_n;
+        const unsigned long long late = rep_seq_verify(S, X.s_m, X.mybox);
+        if (S.pv_n <= keep) break;
+        if (S.pv_n != before) { spins = 0; continue; }
+        if (++spins > X.A->peer_polls) {
+            if (late >> 1) { rep_seq_drop(E, S, LS, (uint32_t)(late >> 1), 7101); spins = 0; continue; }
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return true;
+}
+
+__device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, const RepSeqCtx &X, RepSeqState &S, lds_u64 s_ao /*[16] LDS*/,
+                                            lds_u64 s_m, uint32_t bitmask, RepBox *mybox, uint64_t progress)
 {
     RepLead *LS = A.LS;
     const uint64_t L = E.log_len;
     const uint32_t lane = lane_id();
-    /* (0) the last tick's samples must have become true */
-    bool ok = true;
-    if (lane == 0) {
-        for (uint64_t i = 0; s_m[M_N_APPLY] < S.sample_slot; i++) {
-            if (i > A.peer_polls) { ok = false; break; }
-            __builtin_amdgcn_s_sleep(4);
-        }
-    } else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) {
-        for (uint64_t i = 0; ld_sys(&mybox->applied_by[lane - 1]) < S.sample_slot; i++) {
-            if (i > A.peer_polls) { ok = false; break; }
-            __builtin_amdgcn_s_sleep(4);
-        }
-    }
-    const unsigned long long late = __ballot(!ok);
-    if (late >> 1) rep_seq_drop(E, S, LS, (uint32_t)(late >> 1), 7101);
+    /* (0) the earlier ticks' samples: what has become true is retired; with the queue full the oldest is waited for */
+    bool late = false;
+    rep_seq_verify(S, s_m, mybox);
+    if (S.pv_n >= R_PV) late = !rep_seq_wait_verified(E, X, S, LS, R_PV - 1);
     const uint32_t size = E.group_size;
     const uint64_t c_before = S.c_off, cs_before = S.c_slot;
     if (!late) {
@@ -552,8 +617,13 @@ __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, R
         if (apus_is_larger(S.end, L, min_off, S.head) && !S.prev_head) {
             const uint64_t head_before = S.head;
             S.head = min_off;
-            if (rep_seq_round(E, S, LS, lane == 0 ? APUS_HDR : 0u, 1, R_SRC_CONTROL, 0, 3, min_off, 0)) S.prev_head = 1;
-            else { S.head = head_before; if (lane == 0) { set_status(E, 1u << 1); st_sys(&A.H->full, ld_sys(&A.H->full) + 1); } }
+            if (rep_seq_round(E, X, S, LS, lane == 0 ? APUS_HDR : 0u, 1, R_SRC_CONTROL, 0, 3, min_off, 0)) {
+                S.prev_head = 1;
+                /* the move holds once every sampled server has applied what the LAST tick took it to have applied */
+                const uint32_t ix = 2 * ((S.pv_r + S.pv_n) % R_PV);
+                if (lane == 0) { S.pv[ix] = S.sample_slot; S.pv[ix + 1] = S.head; }
+                S.pv_n++;
+            } else { S.head = head_before; if (lane == 0) { set_status(E, 1u << 1); st_sys(&A.H->full, ld_sys(&A.H->full) + 1); } }
         }
     }
     /* (c): what the servers will have applied when the timer's pass is over = the commit before <HEAD> */
@@ -566,8 +636,8 @@ __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, R
 }
 
 /* the leader's first workgroup: wavefront 0 sequences, wavefront 1 commits, wavefront 2 applies */
-__device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, volatile uint64_t *s_h, volatile uint64_t *s_ao,
-                                            volatile uint64_t *s_m, volatile uint64_t *s_x, uint4 *s_tr /* 4 KiB of LDS: ticket transposition */)
+__device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, lds_u64 s_h, lds_u64 s_ao,
+                                            lds_u64 s_m, lds_u64 s_x, uint4 *s_tr /* 4 KiB of LDS: the queue of unverified head moves */)
 {
     RepHost *H = A.H;
     RepLead *LS = A.LS;
@@ -577,8 +647,10 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
     RepSeqState S;
     S.end = s_h[H_END]; S.tail = s_h[H_TAIL]; S.last_idx = s_h[H_LAST_IDX]; S.n_end = s_h[H_N_END]; S.head = s_h[H_HEAD];
     S.prev_head = s_h[H_PREV_HEAD]; S.store_count = s_h[H_STORE_COUNT];
-    S.c_off = s_h[H_COMMIT]; S.c_slot = s_h[H_N_COMMIT]; S.sample_slot = 0; S.t = 0; S.tail_known = true; S.tail_round = 0;
+    S.c_off = s_h[H_COMMIT]; S.c_slot = s_h[H_N_COMMIT]; S.sample_slot = 0; S.t = 0; S.pass_seq = 0; S.tail_known = true; S.tail_round = 0;
     S.push_mask = A.push_mask; S.can_commit = rep_quorum(E, S.push_mask);
+    S.pv = APUS_LDS64(s_tr); S.head_safe = S.head; S.pv_r = 0; S.pv_n = 0;
+    const RepSeqCtx X = {&A, s_m, mybox};
     const uint32_t bitmask = (uint32_t)s_h[H_CID_BITMASK];
     if (lane < 16) s_ao[lane] = (lane < APUS_DEV_MAX_SERVERS) ? s_h[H_APPLY_OFFSETS + lane] : 0;
     uint64_t req_head = ld_sys(&H->slots_done), cmd_head = ld_sys(&H->cmd_head);
@@ -590,8 +662,30 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
     uint32_t exit_code = R_EXIT_STOP;
     if (lane == 0) st_sys(&H->alive, 1);
     const uint64_t my_qbase = (lane >= 1 && lane <= APUS_DEV_MAX_SERVERS) ? A.qbase[lane - 1] : 0;    /* (lane f + 1 looks after follower f) */
-    uint64_t st_pass = 0, st_staged = 0, st_flow = 0, st_busy = 0;
+    uint64_t st_pass = 0, st_staged = 0, st_flow = 0, st_busy = 0, st_prune = 0, st_flowt = 0, st_pcie = 0, st_pcie_n = 0, st_reload = 0;
+    const bool stats = A.dbg & 512;      /* per-pass clocks: every look at the wall clock is a scalar memory round trip */
     const uint64_t st_t0 = wall_clock64();
+
+    /* the staged passes' pipeline registers: the next pass's rounds, the flow-control words and the next host commands
+     * as the last pass asked for them */
+    uint64_t npf0[R_SUB], npf1[R_SUB], pre_rc = ~0ull, pre_end = 0;
+    uint32_t nrf0[R_SUB], nrf1[R_SUB];
+#pragma unroll
+    for (int s = 0; s < R_SUB; s++) { npf0[s] = 0; npf1[s] = 0; nrf0[s] = 0; nrf1[s] = 0; }
+    bool fl_pending = false, pk_pending = false;
+    uint64_t fl_t = 0, fl_v = 0, pk_cg = 0, pk_next = 0;
+    auto take_peek = [&]() {
+        const unsigned long long okb = __ballot(lane < 8 && rep_gran_ok(pk_cg, pk_next + (lane >> 2)));
+        if (have_cmd || have_cmd2 || (okb & 0xFull) != 0xFull) return;
+        have_cmd = true;
+        cmd_op = (uint32_t)rl64u(pk_cg, 0); cmd_after = rep_extend(req_head, (uint32_t)rl64u(pk_cg, 1));
+        cmd_a = (uint32_t)rl64u(pk_cg, 2); cmd_b = (uint32_t)rl64u(pk_cg, 3);
+        have_cmd2 = (okb & 0xF0ull) == 0xF0ull;
+        if (have_cmd2) {
+            cmd2_op = (uint32_t)rl64u(pk_cg, 4); cmd2_after = rep_extend(req_head, (uint32_t)rl64u(pk_cg, 5));
+            cmd2_a = (uint32_t)rl64u(pk_cg, 6); cmd2_b = (uint32_t)rl64u(pk_cg, 7);
+        }
+    };
 
     /* the host command in the first register, once every request slot in front of it is taken: 0 not yet, 1 carried
      * out, 2 the run ends (STOP) */
@@ -611,7 +705,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
         }
         cmd_head++;
         if (lane == 0) st_sys(&H->cmd_head, cmd_head);
-        if (cmd_op == R_OP_PRUNE) { rep_seq_prune(E, A, S, s_ao, s_m, bitmask, mybox, cmd_head + req_head); budget--; }
+        if (cmd_op == R_OP_PRUNE) { const uint64_t tp0 = stats ? wall_clock64() : 0; rep_seq_prune(E, A, X, S, s_ao, s_m, bitmask, mybox, cmd_head + req_head); budget--; if (stats) st_prune += wall_clock64() - tp0; }
         else rep_seq_publish(LS, s_m, S, cmd_head + req_head);
         return 1;
     };
@@ -626,9 +720,11 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
             if (x == 1) { idle = 0; continue; }
         }
         /* ---- flow control: room in the ticket ring and in every pushed follower's doorbell ring ---- */
-        if (budget < WAVE * R_SUB && run_next == run_end) {
+        if ((budget < WAVE * R_SUB && run_next == run_end) || budget < WAVE) {
+            fl_pending = false;
             uint64_t spins = 0;
             st_flow++;
+            const uint64_t tf0 = stats ? wall_clock64() : 0;
             for (;;) {
                 uint64_t room = ~0ull;
                 if (lane == 0) {
@@ -651,78 +747,143 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                 __builtin_amdgcn_s_sleep(8);
             }
             if (exit_code == R_EXIT_TIMEOUT) { if (lane == 0) spin_timeout(E, 7103); break; }
+            if (stats) st_flowt += wall_clock64() - tf0;
         }
         if (run_next < run_end) {
-            /* ---- staged (device-resident) rounds: one lane per round, R_SUB x 64 rounds per pass, ONE memory
-             *      round trip per pass (the loads of the pass; the ticket stores are never waited for) ---- */
-            uint64_t spins = 0;
-            bool out = false;
+            /* ---- staged (device-resident) rounds: one lane per round, R_SUB x 64 rounds per pass.  The pass is software
+             *      pipelined: EVERYTHING a pass needs from memory was asked for by the pass before it -- the rounds'
+             *      prefix sums, the flow-control words when room runs low, the next host commands near the end of the run
+             *      (their PCIe round trip) -- and everything this pass asks for is looked at by the next one: no pass
+             *      waits for a load of its own (round 3 / early round 4: one exposed round trip per pass, 4 us per 256
+             *      rounds, the whole kernel's ceiling at 28 ns per round).  The ticket stores are never waited for. ---- */
             while (run_next < run_end) {
                 const uint64_t rc = run_next;
-                const uint64_t st_p0 = wall_clock64();
+                const uint64_t st_p0 = stats ? wall_clock64() : 0;
                 st_staged++;
                 const uint32_t want = (uint32_t)min((uint64_t)(WAVE * R_SUB), run_end - rc);
+                /* ---- what the last pass asked for ---- */
+                if (!(pre_rc == rc && pre_end == run_end)) {
+                    st_reload++;
+                    /* (the first pass of a run nobody saw coming, a pass behind one that took fewer rounds than it looked at) */
+#pragma unroll
+                    for (int s = 0; s < R_SUB; s++) {
+                        const uint32_t j = (uint32_t)s * WAVE + lane;
+                        const uint64_t r = rc + (j < want ? j : 0);
+                        npf0[s] = E.round_prefix[r]; npf1[s] = E.round_prefix[r + 1];
+                        nrf0[s] = E.round_first[r];  nrf1[s] = E.round_first[r + 1];
+                    }
+                }
                 uint64_t pf0[R_SUB], pf1[R_SUB];
                 uint32_t rf0[R_SUB], rf1[R_SUB];
 #pragma unroll
-                for (int s = 0; s < R_SUB; s++) {
-                    const uint32_t j = (uint32_t)s * WAVE + lane;
-                    const uint64_t r = rc + (j < want ? j : 0);
-                    pf0[s] = E.round_prefix[r]; pf1[s] = E.round_prefix[r + 1];
-                    rf0[s] = E.round_first[r];  rf1[s] = E.round_first[r + 1];
-                }
-                /* flow control rides along when the room last seen runs low: the ticket ring and every pushed follower's doorbell ring */
-                uint64_t room = ~0ull;
-                const bool fresh = budget < 2 * WAVE * R_SUB;
-                if (fresh) {
+                for (int s = 0; s < R_SUB; s++) { pf0[s] = npf0[s]; pf1[s] = npf1[s]; rf0[s] = nrf0[s]; rf1[s] = nrf1[s]; }
+                if (pk_pending) { take_peek(); pk_pending = false; }
+                if (fl_pending) {
+                    fl_pending = false;
+                    uint64_t room = ~0ull;
                     if (lane == 0) {
-                        const uint64_t inflight = S.t - s_m[M_T_RETIRED];
+                        const uint64_t inflight = fl_t - fl_v;
                         room = inflight + R_SLACK >= RS_CAP ? 0 : RS_CAP - R_SLACK - inflight;
                     } else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) {
-                        const uint64_t inflight = my_qbase + S.t - ld_sys(&mybox->seqdone_by[lane - 1]);
+                        const uint64_t inflight = my_qbase + fl_t - fl_v;
                         room = inflight + R_SLACK >= RB_CAP ? 0 : RB_CAP - R_SLACK - inflight;
                     }
+                    const uint64_t since = S.t - fl_t;                /* (tickets issued since the words were asked for) */
+                    const uint64_t r0 = (uint64_t)wmin32((uint32_t)min(room, (uint64_t)0xFFFFFFFFu));
+                    budget = r0 > since ? r0 - since : 0;
                 }
-                /* (and the next host command, if it is there: its PCIe round trip runs under this pass) */
-                const uint64_t next_cmd = cmd_head + 1;               /* (cmd_head is the RUN in progress) */
-                uint64_t cg = 0;
-                /* (only near the end of the run -- and only when NEITHER command register holds one: a command fetched together
-                 * with this RUN sits in the second register until the run is over; a peek that found only ONE command used to
-                 * leave that register as it was, and the command in it -- the same prune tick -- was carried out a second time:
-                 * an extra tick, and the host's command count one behind the kernel's for good.  Seen only when the host pushes
-                 * its commands slowly: tests/test_gpu_replica.py::test_rep_full_size_staged) */
-                const bool peek = !have_cmd && !have_cmd2 && run_end - rc <= 2 * WAVE * R_SUB;
-                if (peek && lane < 8) cg = ld_sys(&H->cmd[(next_cmd + (lane >> 2)) % RC_CAP].g[lane & 3]);
-                if (fresh) {
-                    const unsigned long long tight = __ballot(room < WAVE);
-                    if (tight) {
-                        if (++spins > A.peer_polls) {
-                            if (tight >> 1) { rep_seq_drop(E, S, LS, (uint32_t)(tight >> 1), 7102); spins = 0; continue; }
-                            exit_code = R_EXIT_TIMEOUT; out = true;     /* the leader's own commit does not move: no majority */
-                            if (lane == 0) spin_timeout(E, 7103);
-                            break;
+                /* ---- what the next pass will need ---- */
+                {
+                    uint64_t nrc = ~0ull, nend = 0;
+                    if (rc + WAVE * R_SUB < run_end) { nrc = rc + WAVE * R_SUB; nend = run_end; }
+                    else if (have_cmd && cmd_op == R_OP_RUN && cmd_b) { nrc = cmd_a; nend = cmd_a + cmd_b; }
+                    else if (have_cmd && cmd_op == R_OP_PRUNE && have_cmd2 && cmd2_op == R_OP_RUN && cmd2_b) { nrc = cmd2_a; nend = cmd2_a + cmd2_b; }
+                    pre_rc = nrc; pre_end = nend;
+                    if (nrc != ~0ull) {
+                        const uint32_t nwant = (uint32_t)min((uint64_t)(WAVE * R_SUB), nend - nrc);
+#pragma unroll
+                        for (int s = 0; s < R_SUB; s++) {
+                            const uint32_t j = (uint32_t)s * WAVE + lane;
+                            const uint64_t r = nrc + (j < nwant ? j : 0);
+                            npf0[s] = E.round_prefix[r]; npf1[s] = E.round_prefix[r + 1];
+                            nrf0[s] = E.round_first[r];  nrf1[s] = E.round_first[r + 1];
                         }
-                        st_flow++;
-                        __builtin_amdgcn_s_sleep(8);
-                        continue;
                     }
-                    budget = wmin32((uint32_t)min(room, (uint64_t)0xFFFFFFFFu));
                 }
-                spins = 0;
+                /* flow control: the ticket ring and every pushed follower's doorbell ring, asked for while room for a few passes is left */
+                if (budget < 4 * WAVE * R_SUB) {
+                    fl_pending = true; fl_t = S.t; fl_v = 0;
+                    if (lane == 0) fl_v = s_m[M_T_RETIRED];
+                    else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) fl_v = ld_sys(&mybox->seqdone_by[lane - 1]);
+                }
+                /* the next host commands, near the end of the run -- and only when NEITHER command register holds one: a command
+                 * fetched together with this RUN sits in the second register until the run is over; a peek that found only ONE
+                 * command used to leave that register as it was, and the command in it -- the same prune tick -- was carried out
+                 * a second time (seen only when the host pushes its commands slowly: test_rep_full_size_staged) */
+                if (!have_cmd && !have_cmd2 && run_end - rc <= 3 * WAVE * R_SUB) {
+                    pk_pending = true; pk_next = cmd_head + 1;            /* (cmd_head is the RUN in progress) */
+                    pk_cg = 0;
+                    if (lane < 8) pk_cg = ld_sys(&H->cmd[(pk_next + (lane >> 2)) % RC_CAP].g[lane & 3]);
+                }
+                if (budget < WAVE) break;                             /* (no room: the blocking look at the rings, above) */
                 const uint32_t avail = (uint32_t)min((uint64_t)want, budget);
                 const uint64_t stamp = wall_clock64() & 0xFFFFFFFFull;
                 uint32_t taken = 0;
+                /* ---- a whole pass of plain rounds: one record + one word per ticket (TK_BULK) ---- */
+                if (avail >= WAVE && !(A.dbg & 32)) {
+                    const uint32_t last = avail - 1;
+                    uint64_t pf1_l = 0; uint32_t rf1_l = 0;
+#pragma unroll
+                    for (int s = 0; s < R_SUB; s++)
+                        if ((uint32_t)s == last / WAVE) { pf1_l = rl64u(pf1[s], (int)(last % WAVE)); rf1_l = rl32u(rf1[s], (int)(last % WAVE)); }
+                    const uint64_t bpf = rl64u(pf0[0], 0);
+                    const uint32_t brf = rl32u(rf0[0], 0);
+                    const uint64_t used = S.end >= S.head_safe ? S.end - S.head_safe : L - (S.head_safe - S.end);
+                    const uint64_t tot = pf1_l - bpf;
+                    /* (the conditions of `plain` below grow with the round: they hold for every round of the pass when they hold for its last) */
+                    if (S.end != L && S.end + tot < L && S.end != S.head_safe && tot + APUS_HDR <= L - used && rc + avail < (1ull << 32)) {
+                        const uint64_t pn = S.pass_seq++;
+                        uint64_t v = 0;
+                        switch (lane) {
+                        case PR_T0: v = S.t; break;
+                        case PR_RC0: v = rc; break;
+                        case PR_END0: v = S.end; break;
+                        case PR_IDX0: v = S.last_idx + 1; break;
+                        case PR_SLOT0: v = S.n_end; break;
+                        case PR_BPF: v = bpf; break;
+                        case PR_BRF_N: v = (uint64_t)brf | ((uint64_t)avail << 32); break;
+                        case PR_PUSH_STAMP: v = (uint64_t)(uint32_t)stamp | ((uint64_t)S.push_mask << 32); break;
+                        default: break;
+                        }
+                        if (lane < 8) st_agent(&LS->prec[pn % PR_CAP][lane], rep_tk(pn, v));
+#pragma unroll
+                        for (int s = 0; s < R_SUB; s++) {
+                            const uint32_t j = (uint32_t)s * WAVE + lane;
+                            if (j < avail) {
+                                const uint64_t tk = S.t + j;
+                                st_agent(&LS->tkw[TK_SRC][tk % RS_CAP], rep_tk(tk, (uint64_t)rf0[s] | ((uint64_t)(rf1[s] - rf0[s]) << 32)));
+                                st_agent(&LS->tkw[TK_META][tk % RS_CAP], rep_tk(tk, TK_BULK | (pn & 0xFFFull) | ((rc + j) << 16)));
+                            }
+                        }
+                        const uint32_t ntot = rf1_l - brf;
+                        S.end += tot; S.last_idx += ntot; S.n_end += ntot; S.store_count += ntot; S.prev_head = 0;
+                        S.tail_known = false; S.tail_round = rc + avail - 1;
+                        if (S.can_commit) { S.c_off = S.end; S.c_slot = S.n_end; }
+                        S.t += avail; taken = avail;
+                    }
+                }
 #pragma unroll
                 for (int s = 0; s < R_SUB; s++) {
+                    if (taken >= avail) break;
                     if ((uint32_t)s * WAVE >= avail || taken != (uint32_t)s * WAVE) break;
                     const uint32_t nch = min((uint32_t)WAVE, avail - (uint32_t)s * WAVE);
                     const bool on = lane < nch;
                     const uint64_t bpf = rl64u(pf0[s], 0);
                     const uint32_t brf = rl32u(rf0[s], 0);
-                    const uint64_t used = S.end >= S.head ? S.end - S.head : L - (S.head - S.end);
+                    const uint64_t used = S.end >= S.head_safe ? S.end - S.head_safe : L - (S.head_safe - S.end);      /* (the VERIFIED head: rep_seq_prune) */
                     /* lanes that can go without the general code: the log does not read as empty, no entry of rounds
                      * 0..j crosses or touches len, everything fits into the free part of the ring */
-                    const bool plain = on && S.end != L && S.end + (pf1[s] - bpf) < L && S.end != S.head && (pf1[s] - bpf) + APUS_HDR <= L - used;
+                    const bool plain = on && S.end != L && S.end + (pf1[s] - bpf) < L && S.end != S.head_safe && (pf1[s] - bpf) + APUS_HDR <= L - used;
                     const unsigned long long pm = __ballot(plain);
                     const uint32_t np = (~pm) ? (uint32_t)__builtin_ctzll(~pm) : WAVE;      /* prefix of plain rounds */
                     if (np) {
@@ -747,7 +908,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                         /* the round at the head of the pass needs the general code (wrap, exact fit, nearly full) */
                         const uint32_t n = rl32u(rf1[0] - rf0[0], 0);
                         const uint32_t T = lane < n ? APUS_HDR + (uint32_t)E.req_len[brf + lane] : 0u;
-                        if (!rep_seq_round(E, S, LS, T, n, R_SRC_STAGED, brf, 0, 0, 0)) {
+                        if (!rep_seq_round(E, X, S, LS, T, n, R_SRC_STAGED, brf, 0, 0, 0)) {
                             if (lane == 0) { set_status(E, 1u << 1); st_sys(&H->full, ld_sys(&H->full) + 1); }
                         }
                         taken = 1;
@@ -757,26 +918,15 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
                 run_next += taken; budget -= min((uint64_t)taken, budget);
                 if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); }
                 rep_seq_publish(LS, s_m, S, cmd_head + req_head);
-                st_busy += wall_clock64() - st_p0;
-                if (peek) {
-                    const unsigned long long okb = __ballot(lane < 8 && rep_gran_ok(cg, next_cmd + (lane >> 2)));
-                    if ((okb & 0xFull) == 0xFull) {
-                        have_cmd = true;
-                        cmd_op = (uint32_t)rl64u(cg, 0); cmd_after = rep_extend(req_head, (uint32_t)rl64u(cg, 1));
-                        cmd_a = (uint32_t)rl64u(cg, 2); cmd_b = (uint32_t)rl64u(cg, 3);
-                        have_cmd2 = (okb & 0xF0ull) == 0xF0ull;
-                        if (have_cmd2) {
-                            cmd2_op = (uint32_t)rl64u(cg, 4); cmd2_after = rep_extend(req_head, (uint32_t)rl64u(cg, 5));
-                            cmd2_a = (uint32_t)rl64u(cg, 6); cmd2_b = (uint32_t)rl64u(cg, 7);
-                        }
-                    }
-                }
+                if (stats) st_busy += wall_clock64() - st_p0;
             }
-            if (out) break;
+            if (run_next == run_end && pk_pending) { take_peek(); pk_pending = false; }
             idle = 0;
             continue;
         }
         /* ---- one PCIe round trip: the next host command and R_WIN windows of the request ring ---- */
+        const uint64_t tq0 = stats ? wall_clock64() : 0;
+        st_pcie_n++;
         uint32_t v[R_WIN];
 #pragma unroll
         for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = ld_sys32(&H->ready_len[(req_head + (uint64_t)wdw * WAVE + lane) % RQ_CAP]);
@@ -796,6 +946,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
             }
         }
         const uint64_t stopw = ld_sys(&H->stop);
+        if (stats) st_pcie += wall_clock64() - tq0;
         {
             const int x = exec_cmd();
             if (x == 2) break;
@@ -815,7 +966,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
             if (n == 0) break;
             any = true;
             const uint32_t T = lane < n ? APUS_HDR + (v[wdw] & 0xFFFFu) : 0u;
-            if (!rep_seq_round(E, S, LS, T, n, R_SRC_PINNED, req_head, 0, 0, 0)) {
+            if (!rep_seq_round(E, X, S, LS, T, n, R_SRC_PINNED, req_head, 0, 0, 0)) {
                 /* refused: the requests are dropped (get_tailq_message frees the node anyway), the host is told */
                 if (lane == 0) { set_status(E, 1u << 1); st_sys(&H->full, ld_sys(&H->full) + 1); }
                 dropped += n;                                                        /* slots consumed without a ticket */
@@ -834,7 +985,8 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, v
     if (lane == 0) {
         st_agent(&LS->seq_final, S.t);
         s_m[M_FINAL] = S.t;
-        LS->stat[0][0] = st_pass; LS->stat[0][1] = st_staged; LS->stat[0][2] = S.t; LS->stat[0][3] = wall_clock64() - st_t0; LS->stat[0][4] = st_flow; LS->stat[0][5] = st_busy;
+        LS->stat[0][0] = st_pass; LS->stat[0][1] = st_staged; LS->stat[0][2] = S.t; LS->stat[0][3] = wall_clock64() - st_t0; LS->stat[0][4] = st_flow; LS->stat[0][5] = st_busy; LS->stat[0][6] = st_prune;
+        LS->stat[4][0] = st_flowt; LS->stat[4][1] = st_pcie; LS->stat[4][2] = st_pcie_n; LS->stat[4][3] = st_reload;
         /* the leader's append-side words (log_append_entry's bookkeeping, persist_new_entries' own part) */
         uint64_t *mh = E.rep[E.leader].hdr;
         mh[H_END] = S.end; mh[H_TAIL] = S.tail; mh[H_LAST_IDX] = S.last_idx; mh[H_N_END] = S.n_end; mh[H_HEAD] = S.head;
@@ -999,7 +1151,7 @@ __device__ static inline void rep_commit_pre(const EngDev &E, RepCommitState &C,
     if (upto > C.cs) { C.cs = upto; C.progress = true; }
 }
 
-__device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, volatile uint64_t *s_h, volatile uint64_t *s_m, volatile uint64_t *s_x)
+__device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, lds_u64 s_h, lds_u64 s_m, lds_u64 s_x)
 {
     RepHost *H = A.H;
     RepLead *LS = A.LS;
@@ -1030,7 +1182,7 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
     for (;;) {
         C.progress = false;
         st_pass++;
-        const uint64_t st_p0 = wall_clock64();
+        const uint64_t st_p0 = (A.dbg & 512) ? wall_clock64() : 0;
         const uint64_t prog = s_m[M_PROG];
         const uint64_t tail = s_m[M_TAIL], fin = s_m[M_FINAL];
         if (C.cs < C.pre_end) rep_commit_pre(E, C, ackb, cap, members, quorum);
@@ -1051,7 +1203,7 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
             /* nothing more will be appended; ACKs may still be on their way -- unless no majority can answer */
             if (!can || ++patience > A.peer_polls) { if (can && lane == 0) spin_timeout(E, 7201); break; }
         } else if (fin != ~0ull && ++patience > 64 * A.peer_polls) { if (lane == 0) spin_timeout(E, 7202); break; }
-        if (!C.progress) __builtin_amdgcn_s_sleep(1); else { st_prog++; st_busy += wall_clock64() - st_p0; }
+        if (!C.progress) __builtin_amdgcn_s_sleep(1); else { st_prog++; if (A.dbg & 512) st_busy += wall_clock64() - st_p0; }
     }
     /* the applier takes what is committed, then the control words go back */
     if (lane == 0) { s_m[M_C_FINAL] = 1; LS->stat[1][0] = st_pass; LS->stat[1][1] = st_prog; LS->stat[1][2] = C.t_done; LS->stat[1][3] = wall_clock64() - st_t0; LS->stat[1][5] = st_busy; }
@@ -1075,8 +1227,27 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
     }
     /* what the followers acknowledged of the entries that did not commit (no majority): into the slot words
      * the control-plane kernels scan (k_control_round's commit_scan) */
-    const uint64_t pbw = lane < 16 ? ld_sys(&mybox->persisted_by[lane]) : 0ull;
-    const uint64_t held = (lane < 16 && (pbw >> 40) == my_tag) ? (pbw & PB_VAL) : 0ull;     /* (lane f: what follower f holds in order) */
+    /* (the followers the last rounds were pushed to are given time to acknowledge them: what a follower has not acknowledged
+     * by then it is taken not to hold -- its reply bytes, which rode with the entries (R_BELL_REPLY), are cleared below) */
+    uint64_t pbw = 0, held = 0;
+    for (uint64_t i = 0;; i++) {
+        pbw = lane < 16 ? ld_sys(&mybox->persisted_by[lane]) : 0ull;
+        held = (lane < 16 && (pbw >> 40) == my_tag) ? (pbw & PB_VAL) : 0ull;                /* (lane f: what follower f holds in order) */
+        if (!__ballot(lane < 16 && ((C.push_live & members) >> lane & 1u) && held < C.vis)) break;
+        if (i > A.peer_polls) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    for (uint32_t m = A.push_mask & members; m; m &= m - 1) {
+        const uint32_t f = (uint32_t)__builtin_ctz(m);
+        const uint64_t hf = rl64u(held, (int)f);
+        for (uint64_t s0 = hf > C.pre_end ? hf : C.pre_end; s0 < C.n_end_seen; s0 += WAVE) {
+            const uint64_t s = s0 + lane;
+            if (s < C.n_end_seen) {
+                const uint64_t pos = ld_agent(&Md.dir_off[(uint32_t)s & E.dir_mask]);
+                st_sys8(Md.ring + pos + 28 + f, 0);
+            }
+        }
+    }
     for (uint64_t s0 = C.cs; s0 < C.n_end_seen; s0 += WAVE) {      /* (the whole wavefront makes every pass: rl64u below) */
         const uint64_t s = s0 + lane;
         const bool in = s < C.n_end_seen;
@@ -1089,7 +1260,7 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
             if (in && s < hf && ld_sys8(ackb + (uint64_t)f * cap + di) == want) bits |= 1u << f;
         }
         if (!in) continue;
-        __hip_atomic_store(&Md.ack[di], bits, RLX_AGENT);
+        __hip_atomic_store((APUS_GLOBAL uint32_t *)(uintptr_t)&Md.ack[di], bits, RLX_AGENT);
     }
     /* the last word on the commit, then the followers may park */
     if (lane >= 1 && lane <= APUS_DEV_MAX_SERVERS && ((C.push_live >> (lane - 1)) & 1u)) st_sys(&E.box[lane - 1]->commit_bell, C.cs);
@@ -1099,7 +1270,7 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, v
 /* the leader applies round by round (it never runs do_action: highest_rec; apply_committed_entries,
  * dare_server.c:1815-1974): the apply records were written with the entries, here they are counted once their
  * round is committed */
-__device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, volatile uint64_t *s_h, volatile uint64_t *s_m)
+__device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, lds_u64 s_h, lds_u64 s_m)
 {
     RepHost *H = A.H;
     RepLead *LS = A.LS;
@@ -1111,7 +1282,7 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, vol
     const uint64_t st_t0 = wall_clock64();
     for (;;) {
         st_pass++;
-        const uint64_t st_p0 = wall_clock64();
+        const uint64_t st_p0 = (A.dbg & 512) ? wall_clock64() : 0;
         const uint64_t cfin = s_m[M_C_FINAL];
         const uint64_t cs = s_m[M_CS], t_done = s_m[M_T_DONE];
         bool progress = false;
@@ -1125,6 +1296,7 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, vol
             }
             const uint64_t t0 = t_app;
             uint64_t nc_pass = 0;
+            const uint32_t now = (uint32_t)wall_clock64();             /* (once per pass: the latency samples' end) */
 #pragma unroll
             for (int s = 0; s < R_SUB; s++) {
                 if (t_app != t0 + (uint64_t)s * WAVE) break;
@@ -1139,7 +1311,6 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, vol
                 hash += wsum64(mine ? ((uint64_t)(uint32_t)g3[s] | (g4[s] << 32)) : 0ull);
                 nc_pass += wsum32(mine ? (uint32_t)g5[s] : 0u);
                 n_apply = rl64u(slot_end, (int)p - 1);
-                const uint32_t now = (uint32_t)wall_clock64();
                 const uint32_t t_seq = (uint32_t)g7[s], t_apd = (uint32_t)g6[s];
                 if (mine && t_seq && lat_n + lane < R_LAT_CAP && !(A.dbg & 2048)) { LS->lat_ticks[lat_n + lane] = now - t_seq; LS->lat_app[lat_n + lane] = now - t_apd; }
                 lat_n = min(lat_n + p, R_LAT_CAP);
@@ -1155,7 +1326,7 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, vol
             }
         }
         if (cfin && !progress) break;                    /* (M_C_FINAL was read before M_CS / M_T_DONE: they were final) */
-        if (!progress) __builtin_amdgcn_s_sleep(1); else { st_prog++; st_busy += wall_clock64() - st_p0; }
+        if (!progress) __builtin_amdgcn_s_sleep(1); else { st_prog++; if (A.dbg & 512) st_busy += wall_clock64() - st_p0; }
     }
     if (lane == 0) {
         LS->lat_n = lat_n;
@@ -1182,6 +1353,19 @@ struct RepAppLds {
     uint4    h1[WAVE];
 };
 
+/* reply bytes (dare_log_entry_t.reply[i] at byte 28 + i) of the servers in `mask4` (four of them) as the bytes of one word */
+__device__ static inline uint32_t rep_spread4(uint32_t mask4) { return (mask4 & 1u) | ((mask4 & 2u) << 7) | ((mask4 & 4u) << 14) | ((mask4 & 8u) << 21); }
+/* Reply bytes ride with the entry (round 4).  rc_send_entries_reply (dare_ibv_rc.c:1828-1863) leaves reply[f] = 1 in
+ * follower f's own copy of an entry and in the sender's copy.  As separate one-byte stores from the follower's kernel those
+ * were four read-modify-writes in HBM per entry at 3 replicas (a partial write-through store reads its sector first):
+ * 128 B read + 128 B written of the 1016 B an entry moved.  A round that is one contiguous range of 16-byte units now
+ * carries them in the header words the leader stores anyway: follower f's copy with reply[f], the leader's own with
+ * reply[f] of every follower the round is pushed to -- the state every compared point shows.  What the bytes stand for
+ * is unchanged: the commit is decided by the followers' cumulative in-order ACKs (persisted_by), never by these bytes;
+ * a follower that does NOT acknowledge (dead, dropped, fenced by a newer term) has its byte cleared in the leader's
+ * copy when the run ends (rep_committer), and the doorbell tells the follower that the bytes are there (R_BELL_REPLY). */
+#define R_BELL_REPLY (1u << 31)
+
 /* one append wavefront: ticket k, k + G, ... */
 __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A, RepAppLds &lds, const RepPtrLds &PT, uint32_t g, uint32_t G)
 {
@@ -1191,14 +1375,15 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
     const RepDev &Md = E.rep[me];
     const uint64_t L = E.log_len;
     const uint64_t term = Md.hdr[H_SID] >> 9;
-    uint64_t a_rounds = 0, a_total = 0, a_drain = 0, a_desc = 0, a_pay = 0, a_pre = 0, a_it1 = 0;
+    uint64_t a_rounds = 0, a_total = 0, a_drain = 0, a_desc = 0, a_pay = 0, a_pre = 0, a_it1 = 0, a_wait = 0, a_ldw = 0;
     uint64_t wv_next = 0;
     bool have_next = false;
     for (uint64_t k = g;; k += G) {
         /* ---- wait for ticket k: its eight words carry its tag ---- */
         const uint64_t kx = k % RS_CAP;
         uint64_t wv = wv_next;                       /* (looked at under the previous round's store drain) */
-        bool go = false;
+        bool go = false, bulk = false;
+        const uint64_t t_top = (A.dbg & 256) ? wall_clock64() : 0;
         for (uint64_t i = 0;; i++) {
             /* the eight words of a ticket sit in eight lines (word-major): after two looks that missed, only the word
              * that is stored last is polled until it carries the tag */
@@ -1209,7 +1394,12 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                 look = rep_tk_ok(rl64u(m, 0), k);
             }
             if (look && (i || !have_next)) { if (lane < 8) wv = ld_agent(&LS->tkw[lane][kx]); }
-            if (look && __ballot(lane < 8 && rep_tk_ok(wv, k)) == 0xFFull) { go = true; break; }
+            if (look) {
+                const unsigned long long okb = __ballot(lane < 8 && rep_tk_ok(wv, k));
+                if (okb == 0xFFull) { go = true; break; }
+                /* a ticket of a bulk pass is its TK_META and TK_SRC words alone */
+                if (((okb >> TK_META) & 1ull) && ((okb >> TK_SRC) & 1ull) && (rdl64(wv, TK_META) & TK_BULK)) { go = true; bulk = true; break; }
+            }
             if ((i & 7) == 7 && ld_agent(&LS->seq_final) <= k) break;      /* (one word for everybody: looked at now and then) */
             rep_nap(i < 256);
         }
@@ -1222,15 +1412,50 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                 atomicAdd((unsigned long long *)&LS->stat[3][4], (unsigned long long)a_pay);
                 atomicAdd((unsigned long long *)&LS->stat[3][5], (unsigned long long)a_pre);
                 atomicAdd((unsigned long long *)&LS->stat[3][6], (unsigned long long)a_it1);
+                atomicAdd((unsigned long long *)&LS->stat[3][7], (unsigned long long)a_wait);
+                atomicAdd((unsigned long long *)&LS->stat[0][7], (unsigned long long)a_ldw);        /* (a free word of the sequencer's row) */
             }
             return;
         }
         const bool timed = A.dbg & 256;
         const bool nt_ring = A.dbg & 1024;            /* measurement: streaming ring stores + one release per round */
         const uint64_t t_seen = timed ? wall_clock64() : 0;
+        a_wait += t_seen - t_top;
         wv &= TK_VAL;
-        const uint64_t e0 = rdl64(wv, TK_E0), idx0 = rdl64(wv, TK_IDX0), slot0 = rdl64(wv, TK_SLOT0), first = rdl64(wv, TK_SRC);
-        const uint64_t end_after = rdl64(wv, TK_END), d0 = rdl64(wv, TK_D0), d1 = rdl64(wv, TK_D1), meta = rdl64(wv, TK_META);
+        uint64_t e0, idx0, slot0, first, end_after, d0, d1, meta;
+        ReqDev dbulk; dbulk.req_id = 0; dbulk.pay16_type = 0; dbulk.len = 0; dbulk.clt_id = 0;
+        if (bulk) {
+            /* the other seven words from the pass record and the staged prefix sums: one round trip (the record's words and the
+             * round's four prefix values are asked for together) */
+            const uint64_t mv = rdl64(wv, TK_META);
+            const uint64_t r = mv >> 16, p12 = mv & 0xFFFull;
+            const uint64_t sv = rdl64(wv, TK_SRC);
+            const uint64_t bfirst = sv & 0xFFFFFFFFull;
+            const uint32_t bn = (uint32_t)(sv >> 32) & 0x7F;
+            uint64_t pfv = 0;
+            if (lane == 8) pfv = E.round_prefix[r]; else if (lane == 9) pfv = E.round_prefix[r + 1];
+            if (lane < bn) dbulk = E.req[bfirst + lane];          /* (the round's descriptors: the same round trip) */
+            uint64_t pw = 0;
+            for (uint64_t i = 0;; i++) {
+                if (lane < 8) pw = ld_agent(&LS->prec[p12 % PR_CAP][lane]);
+                /* (the record was stored before the pass's tickets, but nothing orders their arrival) */
+                if (__ballot(lane < 8 && (((pw >> 48) - 1) & 0xFFFull) == p12) == 0xFFull) break;
+                if (i > A.peer_polls) { if (lane == 0) spin_timeout(E, 7401); break; }
+                rep_nap(true);
+            }
+            pw &= TK_VAL;
+            const uint64_t t0 = rdl64(pw, PR_T0), rc0 = rdl64(pw, PR_RC0), end0 = rdl64(pw, PR_END0), pidx0 = rdl64(pw, PR_IDX0), pslot0 = rdl64(pw, PR_SLOT0);
+            const uint64_t bpf = rdl64(pw, PR_BPF), brfn = rdl64(pw, PR_BRF_N), ps = rdl64(pw, PR_PUSH_STAMP);
+            const uint64_t pf0 = rdl64(pfv, 8), pf1 = rdl64(pfv, 9), rf0 = bfirst, rf1 = bfirst + bn;
+            const uint64_t brf = brfn & 0xFFFFFFFFull;
+            e0 = end0 + (pf0 - bpf); idx0 = pidx0 + (rf0 - brf); slot0 = pslot0 + (rf0 - brf); first = rf0;
+            end_after = end0 + (pf1 - bpf); d0 = 0; d1 = ps & 0xFFFFFFFFull;
+            meta = (rf1 - rf0) | ((uint64_t)R_SRC_STAGED << 8) | ((ps >> 32) << 32);
+            if (lane == 0 && rc0 + (k - t0) != r && !(atomicOr(E.status, 1u << 3) & (1u << 3))) { E.status[3] = (uint32_t)k; E.status[4] = (uint32_t)r; E.status[5] = (uint32_t)(rc0 + (k - t0)); E.status[6] = 0xB01Cu; }
+        } else {
+            e0 = rdl64(wv, TK_E0); idx0 = rdl64(wv, TK_IDX0); slot0 = rdl64(wv, TK_SLOT0); first = rdl64(wv, TK_SRC);
+            end_after = rdl64(wv, TK_END); d0 = rdl64(wv, TK_D0); d1 = rdl64(wv, TK_D1); meta = rdl64(wv, TK_META);
+        }
         const uint32_t n = (uint32_t)(meta & 0xFF), kind = (uint32_t)(meta >> 8) & 0xF, ctype = (uint32_t)(meta >> 16) & 0xFF;
         const uint32_t hidden = (uint32_t)(meta >> 12) & 1u;
         const uint32_t push = (uint32_t)(meta >> 32) & 0xFFFF;
@@ -1250,7 +1475,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                 src = (d.pay16_type & 0x0FFFFFFFu) == R_PAY_INLINE ? sl->pay : H->arena + (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
             }
         } else if (kind == R_SRC_STAGED) {
-            if (active) { d = E.req[first + lane]; src = E.arena + (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16; }
+            if (active) { if (bulk) d = dbulk; else d = E.req[first + lane]; src = E.arena + (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16; }
         } else {
             d.pay16_type = ctype << 28;
         }
@@ -1281,7 +1506,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             const uint32_t di = (uint32_t)slot & E.dir_mask;
             if (!(A.dbg & 8192)) {
             st_agent(&Md.dir_off[di], pos);
-            __hip_atomic_store(&Md.dir_len[di], T | (me << 24), RLX_AGENT);
+            __hip_atomic_store((APUS_GLOBAL uint32_t *)(uintptr_t)&Md.dir_len[di], T | (me << 24), RLX_AGENT);
             }
             /* the leader's apply record (apply_committed_entries, dare_server.c:1941-1955): written with the
              * entry, counted by the applier once the entry's round is committed */
@@ -1301,7 +1526,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             }
             if (!uniform) for (uint32_t m = push; m; m &= m - 1) {
                 const uint32_t f = (uint32_t)__builtin_ctz(m);
-                __hip_atomic_store(&PT.box[f]->lens[(PT.qbase[f] + k) % RB_CAP][lane], (uint16_t)d.len, RLX_SYSTEM);
+                __hip_atomic_store((APUS_GLOBAL uint16_t *)(uintptr_t)&PT.box[f]->lens[(PT.qbase[f] + k) % RB_CAP][lane], (uint16_t)d.len, RLX_SYSTEM);
             }
         }
         if (!(A.dbg & 8192)) rep_store_rows32(ar0, ar1, n, [&](uint32_t r) { return (uint8_t *)&Md.apply[(uint32_t)(slot0 + r) & E.dir_mask]; });
@@ -1324,9 +1549,68 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
          * is ONE contiguous range of bytes in every ring: unit u goes to e0 + 16 u */
         const bool straight = uniform && (T0 & 15u) == 0 && pl.kstar < 0 && (e0 & 15ull) == 0;
         const uint8_t *safe = (const uint8_t *)Md.dir_off;          /* where a lane that needs no payload bytes loads from */
-        if (straight) {
+        const bool preset = straight && !(A.dbg & (1 | 64));        /* the reply bytes ride with the entry */
+        if (straight && (upe & (upe - 1)) == 0 && upe <= WAVE) {
+            /* ... and with a power-of-two number of units per entry (64-, 192-, 448-byte payloads ...: configs[1]) a lane
+             * writes the SAME 16 bytes of every entry it touches: which header word or payload bytes, the masks and the
+             * length word are worked out once per round, not once per unit (a wavefront issues one instruction every four to
+             * five cycles: the unit loop's divisions and masks were most of the round's 10 us) */
             constexpr int ILP = 8;
             const uint32_t P = T0 - APUS_HDR;
+            const uint32_t sh = (uint32_t)__builtin_ctz(upe);
+            const uint32_t so = 16u * (lane & (upe - 1));
+            const bool is_ctl = kind == R_SRC_CONTROL;
+            const bool is_pay = so >= 48 && !is_ctl && P != 0;
+            uint64_t mlo = 0, mhi = 0, ins = 0;
+            if (is_pay) {
+                const int vb = so < 50 ? (int)(50 - so) : 0;
+                const int ve = 50u + P > so ? (int)min(16u, 50u + P - so) : 0;
+                mlo = byte_mask64(vb, ve); mhi = byte_mask64(vb - 8, ve - 8);
+            }
+            if (so == 48 && !is_ctl) ins = (uint64_t)(P & 0xFFFFu);
+            const uint4 ctlv = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
+            for (uint32_t u0 = lane; u0 < utotal; u0 += WAVE * ILP) {
+                if (timed && u0 >= WAVE * ILP && !t_it1) t_it1 = wall_clock64();
+                uint4 v[ILP], hv[ILP];
+#pragma unroll
+                for (int q = 0; q < ILP; q++) {
+                    const uint32_t u = u0 + q * WAVE;
+                    const uint32_t e = min(u >> sh, n - 1);
+                    hv[q] = so == 0 ? lds.h0[e] : lds.h1[e];
+                    v[q] = ld16u(is_pay && u < utotal ? (const uint8_t *)(uintptr_t)lds.src[e] + so - 50 : safe);
+                }
+                if (timed) { const uint64_t tl0 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a_ldw += wall_clock64() - tl0; }
+#pragma unroll
+                for (int q = 0; q < ILP; q++) {
+                    if (so < 32) v[q] = hv[q];
+                    else if (so == 32) v[q] = make_uint4(0, 0, 0, 0);
+                    else if (is_ctl) v[q] = ctlv;
+                    else {
+                        const uint64_t lo = (((uint64_t)v[q].x | ((uint64_t)v[q].y << 32)) & mlo) | ins;
+                        const uint64_t hi = ((uint64_t)v[q].z | ((uint64_t)v[q].w << 32)) & mhi;
+                        v[q] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+                    }
+                }
+                for (uint32_t m = rings; m; m &= m - 1) {
+                    const uint32_t ri = (uint32_t)__builtin_ctz(m);
+                    uint8_t *rg = PT.ring[ri] + e0 + 16ull * u0;
+                    const uint32_t rmask = preset ? (ri == me ? push : (1u << ri)) : 0u;
+                    /* (this lane's unit of the entry: bytes 16..31 end with reply[0..3], bytes 32..47 begin with reply[4..12]) */
+                    uint4 rb = make_uint4(0, 0, 0, 0);
+                    if (so == 16) rb.w = rep_spread4(rmask & 0xFu);
+                    else if (so == 32) { rb.x = rep_spread4((rmask >> 4) & 0xFu); rb.y = rep_spread4((rmask >> 8) & 0xFu); rb.z = (rmask >> 12) & 1u; }
+#pragma unroll
+                    for (int q = 0; q < ILP; q++) {
+                        const uint32_t u = u0 + q * WAVE;
+                        const uint4 vv = make_uint4(v[q].x | rb.x, v[q].y | rb.y, v[q].z | rb.z, v[q].w | rb.w);
+                        if (u < utotal) { if (nt_ring) st16_nt(rg + 1024u * q, vv); else st16_wt(rg + 1024u * q, vv); }
+                    }
+                }
+            }
+        } else if (straight) {
+            constexpr int ILP = 8;
+            const uint32_t P = T0 - APUS_HDR;
+            const uint32_t magic = 0xFFFFFFFFu / upe + 1u;           /* u / upe = (u * magic) >> 32 for u * upe < 2^32 */
             for (uint32_t u0 = lane; u0 < utotal; u0 += WAVE * ILP) {
                 if (timed && u0 >= WAVE * ILP && !t_it1) t_it1 = wall_clock64();
                 uint4 v[ILP];
@@ -1336,11 +1620,12 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
 #pragma unroll
                 for (int q = 0; q < ILP; q++) {
                     const uint32_t u = u0 + q * WAVE;
-                    const uint32_t e = min(u / upe, n - 1);
+                    const uint32_t e = min(__umulhi(u, magic), n - 1);
                     e_[q] = e; so_[q] = 16u * (u - e * upe);
                     const bool need = u < utotal && so_[q] >= 48 && kind != R_SRC_CONTROL && P != 0;
                     v[q] = ld16u(need ? (const uint8_t *)(uintptr_t)lds.src[e] + so_[q] - 50 : safe);
                 }
+                if (timed) { const uint64_t tl0 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a_ldw += wall_clock64() - tl0; }
 #pragma unroll
                 for (int q = 0; q < ILP; q++) {
                     if (so_[q] == 0) v[q] = lds.h0[e_[q]];
@@ -1350,11 +1635,16 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                     else v[q] = payload_mask(v[q], so_[q], P, P);
                 }
                 for (uint32_t m = rings; m; m &= m - 1) {
-                    uint8_t *rg = PT.ring[__builtin_ctz(m)] + e0;
+                    const uint32_t ri = (uint32_t)__builtin_ctz(m);
+                    uint8_t *rg = PT.ring[ri] + e0;
+                    const uint32_t rmask = preset ? (ri == me ? push : (1u << ri)) : 0u;
+                    const uint32_t r16 = rep_spread4(rmask & 0xFu), r32x = rep_spread4((rmask >> 4) & 0xFu), r32y = rep_spread4((rmask >> 8) & 0xFu), r32z = (rmask >> 12) & 1u;
 #pragma unroll
                     for (int q = 0; q < ILP; q++) {
                         const uint32_t u = u0 + q * WAVE;
-                        if (u < utotal) { if (nt_ring) st16_nt(rg + 16ull * u, v[q]); else st16_wt(rg + 16ull * u, v[q]); }
+                        uint4 vv = v[q];
+                        if (so_[q] == 16) vv.w |= r16; else if (so_[q] == 32) { vv.x |= r32x; vv.y |= r32y; vv.z |= r32z; }
+                        if (u < utotal) { if (nt_ring) st16_nt(rg + 16ull * u, vv); else st16_wt(rg + 16ull * u, vv); }
                     }
                 }
             }
@@ -1410,7 +1700,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         const uint32_t t_now = (uint32_t)wall_clock64();
         if (lane < 8) {
             const uint32_t val = lane == 0 ? (uint32_t)end_after : lane == 1 ? (uint32_t)(slot0 + n) : lane == 2 ? (uint32_t)e0
-                                                                             : lane == 3 ? ((n << 17) | (uniform ? T0 : 0u)) : 0u;
+                                                                             : lane == 3 ? ((n << 17) | (uniform ? T0 : 0u) | (preset ? R_BELL_REPLY : 0u)) : 0u;
             for (uint32_t m = push; m; m &= m - 1) {
                 const uint32_t f = (uint32_t)__builtin_ctz(m);
                 const uint64_t q = PT.qbase[f] + k;
@@ -1484,13 +1774,14 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
         }
         const uint64_t t_bell = timed ? wall_clock64() : 0;
         const uint32_t end_after = (uint32_t)rdl64(wv, 0), slot_lo = (uint32_t)rdl64(wv, 1), e0 = (uint32_t)rdl64(wv, 2), w3 = (uint32_t)rdl64(wv, 3);
-        const uint32_t n = w3 >> 17, Tu = w3 & 0x1FFFF;
+        const uint32_t n = (w3 >> 17) & 0x7Fu, Tu = w3 & 0x1FFFF;
+        const bool preset = (w3 & R_BELL_REPLY) != 0;              /* the reply bytes came with the entries */
         /* the slot count's high half: this run stays within 2^31 slots of where it began */
         uint64_t slot_end = (n_end0 & ~0xFFFFFFFFull) | slot_lo;
         if (slot_end + (1ull << 31) < n_end0) slot_end += 1ull << 32;
         const uint64_t slot0 = slot_end - n;
         const bool active = lane < n;
-        const uint32_t T = !active ? 0u : (Tu ? Tu : APUS_HDR + (uint32_t)__hip_atomic_load(&box->lens[r][lane], RLX_SYSTEM));
+        const uint32_t T = !active ? 0u : (Tu ? Tu : APUS_HDR + (uint32_t)__hip_atomic_load((const APUS_GLOBAL uint16_t *)(uintptr_t)&box->lens[r][lane], RLX_SYSTEM));
         const RepPlace pl = rep_place(e0, L, T, n);
         const uint64_t pos = rep_pos(pl, (int)lane);
         /* ---- persist_new_entries: the entries as they landed in the own log ---- */
@@ -1515,13 +1806,13 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
              * (The ACK goes first: the entry IS in this log; what follows is this server's own bookkeeping.) */
             if (sender == leader && lring && (my_sid >> 9) <= (uint64_t)u0.z + ((uint64_t)u0.w << 32)) {
                 st_sys8(lack + (uint64_t)me * cap + di, rep_ack_tag(slot, E.dir_mask));
-                if (!(A.dbg & 1)) st_sys8(lring + pos + 28 + me, 1);
+                if (!preset && !(A.dbg & 1)) st_sys8(lring + pos + 28 + me, 1);
                 acked = true;
             }
-            if (!(A.dbg & 1)) st_sys8(Md.ring + pos + 28 + me, 1);
+            if (!preset && !(A.dbg & 1)) st_sys8(Md.ring + pos + 28 + me, 1);
             if (!(A.dbg & 2)) {
             st_agent(&Md.dir_off[di], pos);
-            __hip_atomic_store(&Md.dir_len[di], T | (sender << 24), RLX_AGENT);
+            __hip_atomic_store((APUS_GLOBAL uint32_t *)(uintptr_t)&Md.dir_len[di], T | (sender << 24), RLX_AGENT);
             }
             client = (type != APUS_NOOP && type != APUS_CONFIG && type != APUS_HEAD);
             ar0 = make_uint4((uint32_t)slot, (uint32_t)(slot >> 32), (uint32_t)pos, (uint32_t)(pos >> 32));
@@ -1554,7 +1845,7 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
 }
 
 /* the follower's retire wavefront: rounds in order -- persist_new_entries' bookkeeping */
-__device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &A, uint32_t me, volatile uint64_t *s_f)
+__device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &A, uint32_t me, lds_u64 s_f)
 {
     RepBox *box = E.box[me];
     RepBox *lbox = E.box[E.leader];
@@ -1587,7 +1878,7 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
     for (;;) {
         bool progress = false;
         st_pass++;
-        const uint64_t st_p0 = wall_clock64();
+        const uint64_t st_p0 = (A.dbg & 512) ? wall_clock64() : 0;
         const uint64_t ctrl = ld_sys(&box->ctrl);
         uint64_t f0[R_SUB], f1[R_SUB], f2[R_SUB], f3[R_SUB];
 #pragma unroll
@@ -1649,7 +1940,7 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
         if (!progress && FHm && final_q == ~0ull && (idle & 15) == 15 && ld_sys(&FHm->stop)) final_q = q_ret;
         /* ---- park? ---- */
         if (final_q != ~0ull && q_ret >= final_q) break;      /* everything that was sent is persisted */
-        if (progress) { idle = 0; st_prog++; st_busy += wall_clock64() - st_p0; }
+        if (progress) { idle = 0; st_prog++; if (A.dbg & 512) st_busy += wall_clock64() - st_p0; }
         else {
             if (++idle > A.idle_polls) { exit_code = R_EXIT_IDLE; break; }
             rep_nap(idle < 64);
@@ -1664,7 +1955,7 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
 }
 
 /* the follower's apply wavefront: the commit doorbell (R4), apply_committed_entries round by round */
-__device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A, uint32_t me, volatile uint64_t *s_f)
+__device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A, uint32_t me, lds_u64 s_f)
 {
     RepBox *box = E.box[me];
     RepBox *lbox = E.box[E.leader];
@@ -1689,7 +1980,7 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
     for (;;) {
         bool progress = false;
         st_pass++;
-        const uint64_t st_p0 = wall_clock64();
+        const uint64_t st_p0 = (A.dbg & 512) ? wall_clock64() : 0;
         const uint64_t rfin = s_f[F_R_FINAL];
         q_ret = s_f[F_Q_RET]; n_end = s_f[F_N_END]; end = s_f[F_END];
         uint64_t cs = ld_sys(&box->commit_bell);
@@ -1738,7 +2029,7 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
             if (!progress && (q_app == q_ret || ld_sys(&box->commit_bell) <= n_apply || idle_fin > 4)) break;
             if (!progress) idle_fin++;
         }
-        if (!progress) rep_nap(true); else { st_prog++; st_busy += wall_clock64() - st_p0; }
+        if (!progress) rep_nap(true); else { st_prog++; if (A.dbg & 512) st_busy += wall_clock64() - st_p0; }
     }
     if (lane == 0) { FS->stat[1][0] = st_pass; FS->stat[1][1] = st_prog; FS->stat[1][2] = q_app - q0; FS->stat[1][3] = wall_clock64() - st_t0; FS->stat[1][5] = st_busy; }
     /* (F_R_FINAL was read before F_Q_RET / F_N_END / F_END in the last pass: they were final) */
@@ -1789,9 +2080,9 @@ __global__ __launch_bounds__(256) void k_replica(const EngDev E, const RepArgs A
             if (tid < 16) s_x[tid] = 0;
             if (tid < M_WORDS) s_m[tid] = tid == M_FINAL ? ~0ull : (tid == M_N_APPLY ? E.rep[E.leader].hdr[H_N_APPLY] : 0ull);
             __syncthreads();
-            if (wave == 0) rep_sequencer(E, A, s_h, s_ao, s_m, s_x, (uint4 *)&s_lds[0]);   /* (the append stage's LDS is free in this workgroup) */
-            else if (wave == 1) rep_committer(E, A, s_h, s_m, s_x);
-            else if (wave == 2) rep_applier(E, A, s_h, s_m);
+            if (wave == 0) rep_sequencer(E, A, APUS_LDS64(s_h), APUS_LDS64(s_ao), APUS_LDS64(s_m), APUS_LDS64(s_x), (uint4 *)&s_lds[0]);   /* (the append stage's LDS is free in this workgroup) */
+            else if (wave == 1) rep_committer(E, A, APUS_LDS64(s_h), APUS_LDS64(s_m), APUS_LDS64(s_x));
+            else if (wave == 2) rep_applier(E, A, APUS_LDS64(s_h), APUS_LDS64(s_m));
             __syncthreads();
             if (tid == 0) {
                 /* park the followers: every round they were sent is in their doorbell ring */
@@ -1830,8 +2121,8 @@ __global__ __launch_bounds__(256) void k_replica(const EngDev E, const RepArgs A
             s_m[tid] = tid == F_END ? mh[H_END] : tid == F_N_END ? mh[H_N_END] : tid == F_Q_RET ? ld_sys(&E.box[me]->f_seq_next) : 0ull;
         }
         __syncthreads();
-        if (wave == 0) { rep_follow_retire(E, A, (uint32_t)me, s_m); return; }
-        if (wave == 1) { rep_follow_apply(E, A, (uint32_t)me, s_m); return; }
+        if (wave == 0) { rep_follow_retire(E, A, (uint32_t)me, APUS_LDS64(s_m)); return; }
+        if (wave == 1) { rep_follow_apply(E, A, (uint32_t)me, APUS_LDS64(s_m)); return; }
         rep_follow_wave(E, A, (uint32_t)me, wave - 2, G);
         return;
     }

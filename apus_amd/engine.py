@@ -420,13 +420,17 @@ class Engine:
         out = np.zeros((20, 8), dtype=np.uint64)
         self._chk(self.L.apus_gpu_rep_role_stats(self.h, out.ctypes.data), "rep_role_stats")
         names = ["sequencer", "committer", "applier"] + [f"f{i}_{w}" for i in range(6) for w in ("retire", "apply")]
-        d = {nm: {"passes": int(r[0]), "moved": int(r[1]), "rounds": int(r[2]), "us": int(r[3]) / 100.0, "x": int(r[4]), "busy_us": int(r[5]) / 100.0}
+        d = {nm: {"passes": int(r[0]), "moved": int(r[1]), "rounds": int(r[2]), "us": int(r[3]) / 100.0, "x": int(r[4]), "busy_us": int(r[5]) / 100.0, "y_us": int(r[6]) / 100.0}
              for nm, r in zip(names, out) if r[0]}
+        if "sequencer" in d:
+            d["sequencer"].update({"outer_passes": int(out[0][0]), "flow_us": int(out[17][0]) / 100.0, "pcie_us": int(out[17][1]) / 100.0,
+                                   "pcie_polls": int(out[17][2]), "reloads": int(out[17][3])})
         a = out[15]
         if a[0]:
             d["append"] = {"rounds": int(a[0]), "us_per_round": int(a[1]) / 100.0 / int(a[0]), "drain_us": int(a[2]) / 100.0 / int(a[0]),
                            "desc_us": int(a[3]) / 100.0 / int(a[0]), "payload_stores_us": int(a[4]) / 100.0 / int(a[0]),
-                           "pre_loop_us": int(a[5]) / 100.0 / int(a[0]), "first_iter_us": int(a[6]) / 100.0 / int(a[0])}
+                           "pre_loop_us": int(a[5]) / 100.0 / int(a[0]), "first_iter_us": int(a[6]) / 100.0 / int(a[0]),
+                           "ticket_wait_us": int(a[7]) / 100.0 / int(a[0]), "payload_load_wait_us": int(out[0][7]) / 100.0 / int(a[0])}
         w = out[16]
         if w[0]:
             d["f0_work"] = {"rounds": int(w[0]), "us_per_round": int(w[1]) / 100.0 / int(w[0]), "bell_to_headers_us": int(w[2]) / 100.0 / int(w[0]),

@@ -32,7 +32,8 @@ def step_cmds(tr, eng):
 
 
 def staged(n_rep, entries, payload, batch, steps, n_append, n_fwork, warmup=1):
-    tr = T.steady_trace(n_rep, entries, payload, 16, batch, log_len=T.DEFAULT_LOG)
+    pb = int(os.environ.get("SWEEP_PRUNE_BYTES", "0")) or None
+    tr = T.steady_trace(n_rep, entries, payload, 16, batch, log_len=T.DEFAULT_LOG, prune_bytes=pb)
     eng = Engine(n_rep, tr.log_len)
     try:
         eng.stage_trace(tr)

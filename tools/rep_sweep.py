@@ -19,6 +19,8 @@ def brief(d):
         x = r[k]
         return (x["moved"], round(x["rounds"] / max(1, x["moved"])), round(x["busy_us"] / max(1, x["moved"]), 2), round(x["busy_us"] / max(1e-9, x["us"]), 2))
     out = {"Meps": round(d["entries_per_s"] / 1e6), "ok": d["verified"], "lat": d["lat_us_p50"], "lat_app": d["lat_appended_us_p50"],
+           "seq_prune_us": r.get("sequencer", {}).get("y_us"), "seq_x": r.get("sequencer", {}).get("x"), "seq_us": r.get("sequencer", {}).get("us"),
+           "seq_more": {k: r.get("sequencer", {}).get(k) for k in ("outer_passes", "flow_us", "pcie_us", "pcie_polls", "reloads")},
            "seq": f("sequencer"), "com": f("committer"), "app": f("applier"), "f0r": f("f0_retire"), "f0a": f("f0_apply")}
     for k in ("append", "f0_work"):
         if k in r:
@@ -30,8 +32,9 @@ def main():
     steps = int(os.environ.get("SWEEP_STEPS", "3"))
     entries = int(os.environ.get("SWEEP_ENTRIES", str(1 << 20)))
     for spec in sys.argv[1:]:
-        label, n_rep, na, nf, dbg = spec.split(":")
+        label, n_rep, na, nf, dbg = spec.split(":")[:5]
         os.environ["APUS_REP_DBG"] = dbg
+        os.environ["SWEEP_PRUNE_BYTES"] = (spec.split(":") + ["0"])[5]
         try:
             d = staged(int(n_rep), entries, 64, 64, steps, int(na), int(nf))
             print(label, n_rep, na, nf, "dbg=" + dbg, json.dumps(brief(d)), flush=True)
