@@ -2239,7 +2239,16 @@ static int rep_in_step(apus_engine *e, uint32_t cand, uint32_t *out_mask, uint64
         uint64_t n_end = fh[H_N_END];
         if (notes[2] > notes[1] && notes[3] == fh[H_SID] && notes[1] == fh[H_N_END]) n_end = notes[2];
         if (n_end == lh[H_N_END] && (fh[H_SID] >> 9) == (lh[H_SID] >> 9)) in |= 1u << f;
+        else if (n_end < lh[H_N_END]) {
+            /* behind: whatever reply bytes rode with entries it never acknowledged (R_BELL_REPLY) do not stand */
+            const uint64_t cap = (uint64_t)e->d.dir_mask + 1;
+            const uint64_t s0 = lh[H_N_END] - n_end > cap ? lh[H_N_END] - cap : n_end;
+            hipLaunchKernelGGL(k_rep_clear_reply, dim3((unsigned)std::min<uint64_t>(256, (lh[H_N_END] - s0 + 255) / 256)), dim3(256), 0, e->stream,
+                               e->d, e->d.leader, f, s0, lh[H_N_END]);
+            HIPCHK(hipGetLastError());
+        }
     }
+    HIPCHK(hipStreamSynchronize(e->stream));
     *out_mask = in;
     return 0;
 }
@@ -2266,8 +2275,8 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
         HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device));
         const uint32_t room = (uint32_t)std::max(8, occ * cus - 8);
         const uint32_t nfh = (uint32_t)popc(A.follow_mask);
-        if (!n_append) n_append = lead_here ? 96 : 0;
-        if (!n_fwork) n_fwork = nfh ? std::min(64u, std::max(24u, 96u / nfh)) : 1;     /* (measured: 96 append + 48 per follower at 3 replicas; more only adds contention) */
+        if (!n_append) n_append = lead_here ? 192 : 0;
+        if (!n_fwork) n_fwork = nfh ? std::min(96u, std::max(24u, 288u / nfh)) : 1;    /* (measured, round 4: 192 append + 96 per follower at 3 replicas) */
         while ((lead_here ? 1 + n_append : 0) + nfh * n_fwork > room && (n_append > 8 || n_fwork > 2)) {
             if (n_append > 8) n_append -= n_append / 4;
             if (n_fwork > 2) n_fwork -= (n_fwork + 3) / 4;

@@ -1227,27 +1227,8 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, l
     }
     /* what the followers acknowledged of the entries that did not commit (no majority): into the slot words
      * the control-plane kernels scan (k_control_round's commit_scan) */
-    /* (the followers the last rounds were pushed to are given time to acknowledge them: what a follower has not acknowledged
-     * by then it is taken not to hold -- its reply bytes, which rode with the entries (R_BELL_REPLY), are cleared below) */
-    uint64_t pbw = 0, held = 0;
-    for (uint64_t i = 0;; i++) {
-        pbw = lane < 16 ? ld_sys(&mybox->persisted_by[lane]) : 0ull;
-        held = (lane < 16 && (pbw >> 40) == my_tag) ? (pbw & PB_VAL) : 0ull;                /* (lane f: what follower f holds in order) */
-        if (!__ballot(lane < 16 && ((C.push_live & members) >> lane & 1u) && held < C.vis)) break;
-        if (i > A.peer_polls) break;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    for (uint32_t m = A.push_mask & members; m; m &= m - 1) {
-        const uint32_t f = (uint32_t)__builtin_ctz(m);
-        const uint64_t hf = rl64u(held, (int)f);
-        for (uint64_t s0 = hf > C.pre_end ? hf : C.pre_end; s0 < C.n_end_seen; s0 += WAVE) {
-            const uint64_t s = s0 + lane;
-            if (s < C.n_end_seen) {
-                const uint64_t pos = ld_agent(&Md.dir_off[(uint32_t)s & E.dir_mask]);
-                st_sys8(Md.ring + pos + 28 + f, 0);
-            }
-        }
-    }
+    const uint64_t pbw = lane < 16 ? ld_sys(&mybox->persisted_by[lane]) : 0ull;
+    const uint64_t held = (lane < 16 && (pbw >> 40) == my_tag) ? (pbw & PB_VAL) : 0ull;     /* (lane f: what follower f holds in order) */
     for (uint64_t s0 = C.cs; s0 < C.n_end_seen; s0 += WAVE) {      /* (the whole wavefront makes every pass: rl64u below) */
         const uint64_t s = s0 + lane;
         const bool in = s < C.n_end_seen;
@@ -1361,9 +1342,11 @@ __device__ static inline uint32_t rep_spread4(uint32_t mask4) { return (mask4 & 
  * 128 B read + 128 B written of the 1016 B an entry moved.  A round that is one contiguous range of 16-byte units now
  * carries them in the header words the leader stores anyway: follower f's copy with reply[f], the leader's own with
  * reply[f] of every follower the round is pushed to -- the state every compared point shows.  What the bytes stand for
- * is unchanged: the commit is decided by the followers' cumulative in-order ACKs (persisted_by), never by these bytes;
- * a follower that does NOT acknowledge (dead, dropped, fenced by a newer term) has its byte cleared in the leader's
- * copy when the run ends (rep_committer), and the doorbell tells the follower that the bytes are there (R_BELL_REPLY). */
+ * is unchanged: the commit is decided by the followers' cumulative in-order ACKs (persisted_by), never by these bytes.
+ * The doorbell tells the follower that the bytes are there (R_BELL_REPLY); a follower that DECLINES an entry (a term older
+ * than its own: the fence) clears its byte in both copies; a follower that is found behind the leader when the next run
+ * starts (it died, or was dropped from the push set mid-run) has its byte cleared in the leader's copy of everything it
+ * does not hold (k_rep_clear_reply, from apus_gpu_rep_start) before anything is caught up. */
 #define R_BELL_REPLY (1u << 31)
 
 /* one append wavefront: ticket k, k + G, ... */
@@ -1375,7 +1358,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
     const RepDev &Md = E.rep[me];
     const uint64_t L = E.log_len;
     const uint64_t term = Md.hdr[H_SID] >> 9;
-    uint64_t a_rounds = 0, a_total = 0, a_drain = 0, a_desc = 0, a_pay = 0, a_pre = 0, a_it1 = 0, a_wait = 0, a_ldw = 0;
+    uint64_t a_rounds = 0, a_total = 0, a_drain = 0, a_desc = 0, a_pay = 0, a_pre = 0, a_it1 = 0, a_wait = 0, a_ldw = 0, a_iss = 0, a_sel = 0;
     uint64_t wv_next = 0;
     bool have_next = false;
     for (uint64_t k = g;; k += G) {
@@ -1414,6 +1397,8 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                 atomicAdd((unsigned long long *)&LS->stat[3][6], (unsigned long long)a_it1);
                 atomicAdd((unsigned long long *)&LS->stat[3][7], (unsigned long long)a_wait);
                 atomicAdd((unsigned long long *)&LS->stat[0][7], (unsigned long long)a_ldw);        /* (a free word of the sequencer's row) */
+                atomicAdd((unsigned long long *)&LS->stat[4][4], (unsigned long long)a_iss);
+                atomicAdd((unsigned long long *)&LS->stat[4][5], (unsigned long long)a_sel);
             }
             return;
         }
@@ -1579,7 +1564,8 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                     hv[q] = so == 0 ? lds.h0[e] : lds.h1[e];
                     v[q] = ld16u(is_pay && u < utotal ? (const uint8_t *)(uintptr_t)lds.src[e] + so - 50 : safe);
                 }
-                if (timed) { const uint64_t tl0 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a_ldw += wall_clock64() - tl0; }
+                uint64_t tl1 = 0;
+                if (timed) { const uint64_t tl0 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tl1 = wall_clock64(); a_ldw += tl1 - tl0; a_iss += tl0 - t_loop; }
 #pragma unroll
                 for (int q = 0; q < ILP; q++) {
                     if (so < 32) v[q] = hv[q];
@@ -1591,6 +1577,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                         v[q] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
                     }
                 }
+                if (timed) { asm volatile("" :: "v"(v[0].x), "v"(v[7].w)); a_sel += wall_clock64() - tl1; }
                 for (uint32_t m = rings; m; m &= m - 1) {
                     const uint32_t ri = (uint32_t)__builtin_ctz(m);
                     uint8_t *rg = PT.ring[ri] + e0 + 16ull * u0;
@@ -1810,6 +1797,7 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
                 acked = true;
             }
             if (!preset && !(A.dbg & 1)) st_sys8(Md.ring + pos + 28 + me, 1);
+            if (preset && !acked && sender == leader && lring) st_sys8(lring + pos + 28 + me, 0);      /* declined: the sender's copy says so */
             if (!(A.dbg & 2)) {
             st_agent(&Md.dir_off[di], pos);
             __hip_atomic_store((APUS_GLOBAL uint32_t *)(uintptr_t)&Md.dir_len[di], T | (sender << 24), RLX_AGENT);
@@ -1984,11 +1972,12 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
         const uint64_t rfin = s_f[F_R_FINAL];
         q_ret = s_f[F_Q_RET]; n_end = s_f[F_N_END]; end = s_f[F_END];
         uint64_t cs = ld_sys(&box->commit_bell);
-        uint64_t f2[R_SUB], f3[R_SUB], f4[R_SUB], f5[R_SUB], f6[R_SUB];
+        uint64_t f0[R_SUB], f2[R_SUB], f3[R_SUB], f4[R_SUB], f5[R_SUB], f6[R_SUB];
         if (q_app < q_ret) {
 #pragma unroll
             for (int s = 0; s < R_SUB; s++) {
                 const uint64_t ix = (q_app + (uint64_t)s * WAVE + lane) % RB_CAP;
+                f0[s] = ld_agent(&FS->fr[FR_END][ix]);
                 f2[s] = ld_agent(&FS->fr[FR_SLOT_END][ix]); f3[s] = ld_agent(&FS->fr[FR_N][ix]); f4[s] = ld_agent(&FS->fr[FR_HASH_LO][ix]);
                 f5[s] = ld_agent(&FS->fr[FR_HASH_HI][ix]); f6[s] = ld_agent(&FS->fr[FR_HEAD][ix]);
             }
@@ -2002,7 +1991,7 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
                 if (q_app != t0 + (uint64_t)s * WAVE) break;
                 const uint64_t q = q_app + lane;
                 const uint64_t se = rep_extend(n_apply, (uint32_t)f2[s]);
-                const bool okq = q < q_ret && rep_gran_ok(f2[s], q) && rep_gran_ok(f3[s], q) && rep_gran_ok(f4[s], q) && rep_gran_ok(f5[s], q)
+                const bool okq = q < q_ret && rep_gran_ok(f0[s], q) && rep_gran_ok(f2[s], q) && rep_gran_ok(f3[s], q) && rep_gran_ok(f4[s], q) && rep_gran_ok(f5[s], q)
                                  && rep_gran_ok(f6[s], q) && se <= n_commit && se <= n_end;
                 const unsigned long long bal = __ballot(okq);
                 const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
@@ -2013,7 +2002,16 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
                 /* poll_config_entries: a committed <HEAD> entry moves the head (dare_server.c:2164) */
                 const uint32_t hv = mine ? (uint32_t)f6[s] : 0xFFFFFFFFu;
                 const unsigned long long hb = __ballot(hv != 0xFFFFFFFFu);
-                if (hb) { const uint64_t h = rl32u(hv, 63 - __builtin_clzll(hb)); if (apus_is_larger(end, L, h, head)) head = h; }
+                /* ("larger" is relative to the log's end: the end of the <HEAD> entry's OWN round, as it was when the reference's
+                 * follower looked at the entry -- not this server's persisted end of the moment, which may be most of a lap
+                 * further on when the apply wavefront lags: the new head then reads as the older one and is never adopted) */
+                /* (and EVERY <HEAD> entry of the chunk in its order: with many ticks in flight the heads of one pass can run
+                 * around the ring -- the last one alone may read as older than a head of most of a lap ago) */
+                for (unsigned long long b = hb; b; b &= b - 1) {
+                    const int hl = __builtin_ctzll(b);
+                    const uint64_t h = rl32u(hv, hl), ea_h = rl32u((uint32_t)f0[s], hl);
+                    if (apus_is_larger(ea_h, L, h, head)) head = h;
+                }
                 n_apply = rl64u(se, (int)p - 1);
                 q_app += p;
                 progress = true;
@@ -2056,6 +2054,16 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
         st_sys(&box->f_runs, my_run + 1);
         if (A.FH[me]) st_sys(&A.FH[me]->alive, 2);
         if (exit_code) atomicOr(E.status, 1u << 4);
+    }
+}
+
+/* reply[f] = 0 in replica `lead`'s copy of the entry slots [s0, s1): follower f does not hold them (see R_BELL_REPLY) */
+__global__ __launch_bounds__(256) void k_rep_clear_reply(const EngDev E, uint32_t lead, uint32_t f, uint64_t s0, uint64_t s1)
+{
+    const RepDev &Md = E.rep[lead];
+    for (uint64_t s = s0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < s1; s += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t pos = Md.dir_off[(uint32_t)s & E.dir_mask];
+        st_sys8(Md.ring + pos + 28 + f, 0);
     }
 }
 

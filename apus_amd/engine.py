@@ -430,7 +430,8 @@ class Engine:
             d["append"] = {"rounds": int(a[0]), "us_per_round": int(a[1]) / 100.0 / int(a[0]), "drain_us": int(a[2]) / 100.0 / int(a[0]),
                            "desc_us": int(a[3]) / 100.0 / int(a[0]), "payload_stores_us": int(a[4]) / 100.0 / int(a[0]),
                            "pre_loop_us": int(a[5]) / 100.0 / int(a[0]), "first_iter_us": int(a[6]) / 100.0 / int(a[0]),
-                           "ticket_wait_us": int(a[7]) / 100.0 / int(a[0]), "payload_load_wait_us": int(out[0][7]) / 100.0 / int(a[0])}
+                           "ticket_wait_us": int(a[7]) / 100.0 / int(a[0]), "payload_load_wait_us": int(out[0][7]) / 100.0 / int(a[0]),
+                           "load_issue_us": int(out[17][4]) / 100.0 / int(a[0]), "select_us": int(out[17][5]) / 100.0 / int(a[0])}
         w = out[16]
         if w[0]:
             d["f0_work"] = {"rounds": int(w[0]), "us_per_round": int(w[1]) / 100.0 / int(w[0]), "bell_to_headers_us": int(w[2]) / 100.0 / int(w[0]),
