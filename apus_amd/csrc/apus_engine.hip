@@ -103,6 +103,8 @@ struct apus_engine {
     RepFHost *rfh[APUS_MAX_SERVERS], *rfh_dev[APUS_MAX_SERVERS];   /* pinned: a hosted follower's progress / stop words */
     uint8_t *ss_buf; uint64_t ss_cap;       /* apus_gpu_store_stream's scratch, kept between calls */
     hipStream_t rstream;
+    hipEvent_t rev0, rev1;          /* around the last k_replica launch (apus_gpu_rep_launch_ms) */
+    bool rev_valid;
     bool r_running, r_lead;         /* a launch is resident; it carries the leader's workgroups */
     uint32_t r_follow_mask;
     uint32_t r_test_skip;           /* tests: followers whose workgroups are NOT launched although they are pushed to (a dead process) */
@@ -204,7 +206,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->live_r0 = e->live_R = e->live_n = 0;
     e->ph = e->ph_dev = nullptr; e->pd = nullptr; e->pstream = nullptr; e->p_running = false;
     e->p_ev_tail = e->p_req_tail = e->p_arena_pos = 0;
-    e->rh = e->rh_dev = nullptr; e->rl = nullptr; e->rstream = nullptr; e->r_running = e->r_lead = false; e->r_follow_mask = 0; e->r_test_skip = 0;
+    e->rh = e->rh_dev = nullptr; e->rl = nullptr; e->rstream = nullptr; e->rev0 = e->rev1 = nullptr; e->rev_valid = false; e->r_running = e->r_lead = false; e->r_follow_mask = 0; e->r_test_skip = 0;
     for (auto &f : e->rfs) f = nullptr;
     e->r_slot_tail = e->r_arena_tail = e->r_cmd_tail = 0; e->r_slot_aend = nullptr;
     pthread_spin_init(&e->r_lock, PTHREAD_PROCESS_PRIVATE); e->r_lock_init = true;
@@ -295,6 +297,8 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
     for (auto f : e->rfs) if (f) hipFree(f);
     for (auto f : e->rfh) if (f) hipHostFree(f);
     if (e->ss_buf) hipFree(e->ss_buf);
+    if (e->rev0) hipEventDestroy(e->rev0);
+    if (e->rev1) hipEventDestroy(e->rev1);
     if (e->rstream) hipStreamDestroy(e->rstream);
     free(e->r_slot_aend);
     if (e->r_lock_init) pthread_spin_destroy(&e->r_lock);
@@ -2330,8 +2334,12 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
     }
     const uint32_t grid = (lead_here ? 1 + n_append : 0) + popc(A.follow_mask) * n_fwork;
     if (!grid) return 0;                               /* nothing of this group runs here */
+    if (!e->rev0) { HIPCHK(hipEventCreate(&e->rev0)); HIPCHK(hipEventCreate(&e->rev1)); }
+    HIPCHK(hipEventRecord(e->rev0, e->rstream));
     hipLaunchKernelGGL(k_replica, dim3(grid), dim3(256), 0, e->rstream, e->d, A);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->rev1, e->rstream));
+    e->rev_valid = true;
     if (lead_here) {
         const double t0 = mono_s();
         while (e->rh->alive == 0)
@@ -2552,6 +2560,18 @@ extern "C" int apus_gpu_rep_stats(apus_engine_t *e, uint64_t out[8])
     out[0] = e->rh->rounds; out[1] = e->rh->slots_done; out[2] = e->rh->cmd_head; out[3] = e->rh->commit_slot;
     out[4] = e->rh->highest_rec; out[5] = e->rh->full | (e->rh->exit_code << 32); out[6] = 0; out[7] = e->rh->alive;
     if (!e->r_running && e->rl) HIPCHK(hipMemcpy(&out[6], &e->rl->drop_mask, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+/* duration of the last run's resident launch (k_replica on the engine's replica stream), HIP events around the launch:
+ * what rocprofv3 --kernel-trace reports for the same launch.  Only after the run was parked. */
+extern "C" int apus_gpu_rep_launch_ms(apus_engine_t *e, double *ms)
+{
+    if (!e || !ms || e->r_running || !e->rev_valid) return APUS_E_STATE;
+    float f = 0;
+    HIPCHK(hipEventSynchronize(e->rev1));
+    HIPCHK(hipEventElapsedTime(&f, e->rev0, e->rev1));
+    *ms = (double)f;
     return 0;
 }
 

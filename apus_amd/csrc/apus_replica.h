@@ -154,8 +154,11 @@ enum { TK_E0 = 0, TK_IDX0, TK_SLOT0, TK_SRC, TK_END, TK_D0, TK_D1, TK_META };
 #define PR_CAP    512u                  /* pass records (a bulk pass has >= 64 tickets, RS_CAP tickets are in flight at most) */
 enum { PR_T0 = 0, PR_RC0, PR_END0, PR_IDX0, PR_SLOT0, PR_BPF, PR_BRF_N, PR_PUSH_STAMP };   /* words {low 16 bits of pass + 1 : 48-bit value} */
 #define TK_VAL 0x0000FFFFFFFFFFFFull
-__device__ static inline uint64_t rep_tk(uint64_t t, uint64_t v) { return (((t + 1) & 0xFFFFull) << 48) | (v & TK_VAL); }
-__device__ static inline bool rep_tk_ok(uint64_t w, uint64_t t) { return (w >> 48) == ((t + 1) & 0xFFFFull); }
+/* (the tag is never 0: a word nobody has written yet never reads as valid.  Round 4: the words of a slot that bulk passes
+ * do not rewrite can stay zero for the whole run) */
+__device__ static inline uint64_t rep_tag16(uint64_t t) { return t % 65535ull + 1ull; }
+__device__ static inline uint64_t rep_tk(uint64_t t, uint64_t v) { return (rep_tag16(t) << 48) | (v & TK_VAL); }
+__device__ static inline bool rep_tk_ok(uint64_t w, uint64_t t) { return (w >> 48) == rep_tag16(t); }
 /* one round as its append wavefront leaves it for the committer / the applier: granules {ticket + 1 : value} */
 enum { DN_META = 0, DN_SLOT_END, DN_END, DN_HASH_LO, DN_HASH_HI, DN_NCLIENT, DN_T_APPENDED, DN_T_SEQUENCED };
 /* DN_META: [7:0] n  [11:8] source kind  [12] hidden  [31:16] push mask */
@@ -1379,9 +1382,11 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             if (look && (i || !have_next)) { if (lane < 8) wv = ld_agent(&LS->tkw[lane][kx]); }
             if (look) {
                 const unsigned long long okb = __ballot(lane < 8 && rep_tk_ok(wv, k));
-                if (okb == 0xFFull) { go = true; break; }
-                /* a ticket of a bulk pass is its TK_META and TK_SRC words alone */
-                if (((okb >> TK_META) & 1ull) && ((okb >> TK_SRC) & 1ull) && (rdl64(wv, TK_META) & TK_BULK)) { go = true; bulk = true; break; }
+                /* a ticket of a bulk pass is its TK_META and TK_SRC words alone (looked at FIRST: the slot's other six words
+                 * are whatever the last ticket that had eight left there) */
+                const bool isb = ((okb >> TK_META) & 1ull) && (rdl64(wv, TK_META) & TK_BULK);
+                if (isb && ((okb >> TK_SRC) & 1ull)) { go = true; bulk = true; break; }
+                if (!isb && okb == 0xFFull) { go = true; break; }
             }
             if ((i & 7) == 7 && ld_agent(&LS->seq_final) <= k) break;      /* (one word for everybody: looked at now and then) */
             rep_nap(i < 256);
@@ -1424,7 +1429,11 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             for (uint64_t i = 0;; i++) {
                 if (lane < 8) pw = ld_agent(&LS->prec[p12 % PR_CAP][lane]);
                 /* (the record was stored before the pass's tickets, but nothing orders their arrival) */
-                if (__ballot(lane < 8 && (((pw >> 48) - 1) & 0xFFFull) == p12) == 0xFFull) break;
+                /* (valid: all eight words of ONE pass -- the same non-zero tag -- and that pass holds ticket k) */
+                {
+                    const uint64_t tg = rdl64(pw, 0) >> 48, t0v = rdl64(pw, PR_T0) & TK_VAL, nv = ((rdl64(pw, PR_BRF_N) & TK_VAL) >> 32);
+                    if (tg != 0 && __ballot(lane < 8 && (pw >> 48) == tg) == 0xFFull && k >= t0v && k - t0v < nv) break;
+                }
                 if (i > A.peer_polls) { if (lane == 0) spin_timeout(E, 7401); break; }
                 rep_nap(true);
             }

@@ -415,6 +415,12 @@ class Engine:
                                            prune_every_reqs, out), "rep_feed")
         return int(out[0]), out[1] / 1e9
 
+    def rep_launch_ms(self) -> float:
+        """duration of the last (parked) run's resident k_replica launch, HIP events on its stream"""
+        ms = C.c_double(0)
+        self._chk(self.L.apus_gpu_rep_launch_ms(self.h, C.byref(ms)), "rep_launch_ms")
+        return ms.value
+
     def rep_role_stats(self) -> dict:
         """diagnostics of the last run: per serial role passes, passes that moved something, rounds, microseconds"""
         out = np.zeros((20, 8), dtype=np.uint64)

@@ -37,7 +37,20 @@ HBM_COPY_CEILING_GBS = 6290.0   # the measured-copy ceiling SURVEY.md 8(d) asks 
 XGMI_LINK_GBS = 153.0        # one xGMI link (7 per GPU, point to point)
 
 
-PMC_FILE = "r03_pmc_traffic.json"
+PMC_FILE = "r03_pmc_traffic.json"            # k_step (apus_device.h + apus_kernels.h: unchanged since round 3's passes)
+REP_PMC_FILE = "r04_replica_pmc_traffic.json"  # k_replica (round 4's passes)
+
+
+def replica_source_hash():
+    """sha256 over the device sources of the replica kernels (apus_device.h + apus_persistent.h + apus_replica.h): ties
+    profiles/r04_replica_pmc_traffic.json to a build"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "apus_amd", "csrc")
+    for f in ("apus_device.h", "apus_persistent.h", "apus_replica.h"):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def kernel_source_hash():
@@ -329,7 +342,7 @@ def _rep_step_cmds(tr, eng):
     return out
 
 
-def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True):
+def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True, regions_n=3, latency=True):
     """BASELINE configs[1] read literally -- "single persistent kernel per replica": every replica runs its OWN
     resident workgroups (apus_amd/csrc/apus_replica.h).  The leader's pipelined workgroups push only log bytes and
     a doorbell per round; each follower's workgroups build directory / apply records from the landed bytes, persist,
@@ -342,7 +355,7 @@ def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True):
     append, SURVEY 8d's definition) and from "sequenced" to "committed and applied", host clock submit ->
     highest_rec."""
     from apus_amd.engine import Engine
-    steps = steps or max(3, min(args.steps, 10))
+    steps = steps or args.steps
     out = {}
     eng = Engine(n_rep, tr.log_len, device=0)
     try:
@@ -358,31 +371,33 @@ def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True):
                 else:
                     eng.rep_prune()
         # (c) first, on an otherwise idle device
-        reqs64 = np.ascontiguousarray(tr.reqs[16:16 + 64])
-        eng.rep_start(idle_ms=5000, peer_ms=1000)
-        hl64 = eng.rep_roundtrip_ns(reqs64, tr.arena, 300) / 1e3
-        hl1 = eng.rep_roundtrip_ns(reqs64[:1], tr.arena, 300) / 1e3
-        eng.rep_drain()
-        code = eng.rep_park()
-        lat_seq, lat_app = eng.rep_latency_ns(), eng.rep_latency_appended_ns()
-        out["latency"] = {"appended_to_committed_and_applied_us_p50": float(np.percentile(lat_app[20:], 50)) / 1e3 if len(lat_app) > 20 else None,
-                          "sequenced_to_committed_and_applied_us_p50": float(np.percentile(lat_seq[20:], 50)) / 1e3 if len(lat_seq) > 20 else None,
-                          "host_submit_to_highest_rec_us_p50_64_entries": float(np.percentile(hl64[40:], 50)),
-                          "host_submit_to_highest_rec_us_p50_1_entry": float(np.percentile(hl1[40:], 50)), "exit": code}
-        la_, ls_, lh_ = (out["latency"][k] for k in ("appended_to_committed_and_applied_us_p50", "sequenced_to_committed_and_applied_us_p50",
-                                                     "host_submit_to_highest_rec_us_p50_64_entries"))
-        if la_ is not None and ls_ is not None:
-            out["latency"]["phase_breakdown_us_p50"] = {
-                "host_publish_to_sequenced_plus_highest_rec_back_to_host": lh_ - ls_,     # two PCIe crossings: the sequencer's poll, the applier's store
-                "sequenced_to_bytes_in_every_ring": ls_ - la_,                            # ticket, descriptor + payload over PCIe, stores + drain
-                "bytes_in_every_ring_to_committed_and_applied": la_}                      # doorbell, follower persist + ACK, committer, applier
+        if latency:
+            reqs64 = np.ascontiguousarray(tr.reqs[16:16 + 64])
+            eng.rep_start(idle_ms=5000, peer_ms=1000)
+            hl64 = eng.rep_roundtrip_ns(reqs64, tr.arena, 300) / 1e3
+            hl1 = eng.rep_roundtrip_ns(reqs64[:1], tr.arena, 300) / 1e3
+            eng.rep_drain()
+            code = eng.rep_park()
+            lat_seq, lat_app = eng.rep_latency_ns(), eng.rep_latency_appended_ns()
+            out["latency"] = {"appended_to_committed_and_applied_us_p50": float(np.percentile(lat_app[20:], 50)) / 1e3 if len(lat_app) > 20 else None,
+                              "sequenced_to_committed_and_applied_us_p50": float(np.percentile(lat_seq[20:], 50)) / 1e3 if len(lat_seq) > 20 else None,
+                              "host_submit_to_highest_rec_us_p50_64_entries": float(np.percentile(hl64[40:], 50)),
+                              "host_submit_to_highest_rec_us_p50_1_entry": float(np.percentile(hl1[40:], 50)), "exit": code}
+            la_, ls_, lh_ = (out["latency"][k] for k in ("appended_to_committed_and_applied_us_p50", "sequenced_to_committed_and_applied_us_p50",
+                                                         "host_submit_to_highest_rec_us_p50_64_entries"))
+            if la_ is not None and ls_ is not None:
+                out["latency"]["phase_breakdown_us_p50"] = {
+                    "host_publish_to_sequenced_plus_highest_rec_back_to_host": lh_ - ls_,     # two PCIe crossings: the sequencer's poll, the applier's store
+                    "sequenced_to_bytes_in_every_ring": ls_ - la_,                            # ticket, descriptor + payload over PCIe, stores + drain
+                    "bytes_in_every_ring_to_committed_and_applied": la_}                      # doorbell, follower persist + ACK, committer, applier
         hr_base = eng.counters(0)["highest_rec"]
         # (a) device-resident input
+        print("[bench]   latency done; device-resident run", file=sys.stderr, flush=True)
         eng.rep_start(idle_ms=5000, peer_ms=1000)
         step()
         eng.rep_drain(timeout_ms=60000)
         regions = []
-        for _ in range(3):
+        for _ in range(regions_n):
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
@@ -390,8 +405,9 @@ def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True):
             regions.append(time.perf_counter() - t0)
         code = eng.rep_park()
         roles = eng.rep_role_stats()
+        launch_ms = eng.rep_launch_ms()          # HIP events around the resident launch: 1 + regions_n * steps steps + the host's gaps
         eng.quiesce()
-        total = hr_base + (1 + 3 * steps) * len(tr.reqs)
+        total = hr_base + (1 + regions_n * steps) * len(tr.reqs)
         ok = eng.status() == 0 and code == 0 and eng.counters(0)["highest_rec"] == total
         for r in range(n_rep):
             o = eng.offsets(r)
@@ -399,9 +415,11 @@ def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True):
         dt = float(np.median(regions))
         out["device_resident"] = {"value": len(tr.reqs) * steps / dt, "unit": "entries/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
                                   "regions_entries_per_s": [len(tr.reqs) * steps / x for x in regions], "verified": bool(ok),
+                                  "launch_ms": launch_ms, "entries_in_launch": (1 + regions_n * steps) * len(tr.reqs),
                                   "roles": {k: {kk: v[kk] for kk in ("moved", "rounds", "busy_us", "us") if kk in v} for k, v in roles.items()
                                             if k in ("sequencer", "committer", "applier", "f0_retire", "f0_apply")}}
         # (b) host-fed
+        print("[bench]   device-resident done", file=sys.stderr, flush=True)
         if hostfed:
             blk = np.ascontiguousarray(tr.reqs[16:16 + 4096])
             hf = {}
@@ -505,6 +523,75 @@ def measure_join(args):
                         "64 MiB ring cleared, log range + directory copied, the joiner's first persist / apply passes, closing pass)"}
     finally:
         eng.close()
+
+
+def measure_other_configs(args):
+    """BASELINE configs[2], [3] and [4] (with its JOIN tail) as extra figures, every one through BOTH data planes -- the replica
+    kernels (k_replica) and the fused multi-segment launches (k_step) -- and verified (commit == end == apply on every replica,
+    the apply count = the entries issued).  Short runs: parity at these sizes is the GPU test suite's."""
+    import copy
+    from apus_amd import trace as T
+    from apus_amd.engine import Engine
+    res = {}
+    for name, mk in (("c3", lambda: T.config_c3()), ("c4", lambda: T.config_c4())):
+        tr = mk()
+        n_rep, n = tr.group_size, len(tr.reqs)
+        entry = {"replicas": n_rep, "entries_per_step": n, "mean_entry_bytes": 64 + float(np.mean(tr.reqs["len"]))}
+        a2 = copy.copy(args)
+        a2.payload = int(np.mean(tr.reqs["len"]))
+        try:
+            rk = measure_replica_kernels(a2, tr, n_rep, steps=2, hostfed=False, regions_n=1, latency=False)
+            entry["replica_kernels"] = {"entries_per_s": rk["device_resident"]["value"], "verified": rk["device_resident"]["verified"],
+                                        "GBps_log_bytes": rk["device_resident"]["value"] * entry["mean_entry_bytes"] * n_rep / 1e9}
+        except Exception as exc:
+            entry["replica_kernels"] = {"error": repr(exc)[:300]}
+        try:
+            eng = Engine(n_rep, tr.log_len, device=0)
+            try:
+                eng.stage_trace(tr)
+                eng.elect(0)
+                calls = step_calls(tr, eng)
+                issue(eng, calls)
+                eng.sync()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    issue(eng, calls)
+                eng.sync()
+                dt = time.perf_counter() - t0
+                eng.check_status()
+                ok = all(eng.offsets(r)["commit"] == eng.offsets(r)["end"] == eng.offsets(r)["apply"] for r in range(n_rep)) \
+                    and eng.counters(0)["highest_rec"] == 3 * n
+                entry["fused_step_path"] = {"entries_per_s": 2 * n / dt, "verified": bool(ok)}
+            finally:
+                eng.close()
+        except Exception as exc:
+            entry["fused_step_path"] = {"error": repr(exc)[:300]}
+        res[name] = entry
+    # configs[4]: the fail-over / reconfiguration replay (reconf_bench.sh's shape) with its JOIN tail, start to end
+    tr = T.config_c5(rejoin=True)
+    entry = {"replicas": tr.group_size, "entries": len(tr.reqs), "events": len(tr.events)}
+    for mode in ("replica_kernels", "fused_step_path"):
+        try:
+            eng = Engine(tr.group_size, tr.log_len, device=0, capacity=tr.group_size)
+            try:
+                t0 = time.perf_counter()
+                if mode == "replica_kernels":
+                    eng.run_trace_rep(tr, source="staged", idle_ms=20000, peer_ms=5000)
+                else:
+                    eng.run_trace(tr)
+                eng.quiesce()
+                eng.sync()
+                dt = time.perf_counter() - t0
+                live = [r for r in range(eng.group_size) if (eng.reachable >> r) & 1 and (eng.bitmask >> r) & 1]
+                ok = eng.status() == 0 and all(eng.offsets(r)["commit"] == eng.offsets(r)["end"] for r in live)
+                entry[mode] = {"entries_per_s_whole_replay": len(tr.reqs) / dt, "ms": dt * 1e3, "verified": bool(ok),
+                               "note": "wall clock of the WHOLE replay: three phases of requests, two kills, two elections with log adjustment, a JOIN with catch-up"}
+            finally:
+                eng.close()
+        except Exception as exc:
+            entry[mode] = {"error": repr(exc)[:300]}
+    res["c5_failover_rejoin"] = entry
+    return res
 
 
 def bench_single(args):
@@ -725,17 +812,20 @@ def bench_single(args):
                        "unit": "GB/s", "frac": path_bytes * value / 1e9 / HBM_PEAK_GBS},
     }
     eng.close()
+    print("[bench] fused step path measured; replica kernels next", file=sys.stderr, flush=True)
     if not args.no_replica and args.config == "c2":
         try:
-            rk = measure_replica_kernels(args, tr, n_rep)
+            rk = measure_replica_kernels(args, tr, n_rep, steps=args.steps, regions_n=REPS)
+            print("[bench] replica kernels at the metric's group size measured", file=sys.stderr, flush=True)
             # north_star: latency and throughput at 3 / 5 / 7 replicas -- the same measurement, shorter, for the larger groups
             rk["by_group_size"] = {}
             from apus_amd import trace as T3
-            for g in (5, 7):
+            for g in (1, 5, 7):
                 if g == n_rep:
                     continue
                 try:
                     trg = T3.steady_trace(g, args.entries, args.payload, 16, args.batch, log_len=T3.DEFAULT_LOG, name=f"C2x{g}")
+                    print(f"[bench] replica kernels at {g} replicas", file=sys.stderr, flush=True)
                     rg = measure_replica_kernels(args, trg, g, steps=2, hostfed=False)
                     rk["by_group_size"][str(g)] = {"entries_per_s": rg["device_resident"]["value"], "verified": rg["device_resident"]["verified"],
                                                    "appended_to_committed_and_applied_us_p50": rg["latency"]["appended_to_committed_and_applied_us_p50"],
@@ -747,8 +837,62 @@ def bench_single(args):
             if la is not None:
                 out["latency"]["replica_kernels"] = rk["latency"]
                 out["p50_round_latency_us"] = la
+            # ---- the headline: configs[1] read literally -- every replica its own resident kernel (k_replica), the ACK majority
+            #      decided from the followers' own acknowledgements.  The fused multi-segment launches (k_step: the leader's launch
+            #      writes the followers' bytes itself, the majority is known at sequencing time) stay in the line as `fused_step_path`.
+            dr = rk["device_resident"]
+            if dr["verified"]:
+                fused = {k: out[k] for k in ("value", "ms_per_step", "roofline", "repetitions", "whole_path")}
+                fused["mode"] = out["config"]["mode"]
+                fused["launches_per_step"] = out["config"]["launches_per_step"]
+                fused["note"] = ("k_step: several consecutive run_rounds calls + prune ticks per launch, hipGraph replay; the leader's launch stores "
+                                 "every follower's log bytes, reply bytes and derived records itself and declares the majority at sequencing "
+                                 "time -- bit-identical results, legal for logical replicas on ONE device, but not the shape of a group that "
+                                 "spans GPUs.  Reported beside the headline, never as it")
+                out["fused_step_path"] = fused
+                r_value = dr["value"]
+                launch_s = dr["launch_ms"] / 1e3
+                r_ach = path_bytes * dr["entries_in_launch"] / launch_s / 1e9
+                r_traffic, r_moved_pe, r_src = None, None, None
+                rp = os.path.join(ROOT, "profiles", REP_PMC_FILE)
+                if os.path.exists(rp):
+                    try:
+                        pj = json.load(open(rp))
+                        if pj.get("kernel_source_sha256") == replica_source_hash() and pj.get("replicas") == n_rep:
+                            r_moved_pe = float(pj["bytes_per_entry"])
+                            r_traffic = int(r_moved_pe * dr["entries_in_launch"])
+                            r_src = f"profiles/{REP_PMC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, this kernel and build)"
+                    except Exception:
+                        pass
+                r_moved = r_traffic / launch_s / 1e9 if r_traffic else None
+                out["value"] = r_value
+                out["ms_per_step"] = dr["ms_per_step"]
+                out["repetitions"] = {"n": len(dr["regions_entries_per_s"]), "entries_per_s": dr["regions_entries_per_s"],
+                                      "min": min(dr["regions_entries_per_s"]), "median": r_value, "max": max(dr["regions_entries_per_s"])}
+                out["config"]["mode"] = ("replica kernels (k_replica): ONE resident launch carries the leader's and every follower's own workgroups; "
+                                         "the staged stream is fed as one host command per stretch of rounds / prune tick; the timed region is "
+                                         "exactly K steps between two drains (everything in every ring, committed by majority, applied)")
+                out["config"]["launches_per_step"] = 0
+                out["roofline"] = {"bound": "hbm", "achieved": r_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_ach / HBM_PEAK_GBS,
+                                   "traffic": r_traffic, "moved": r_moved, "frac_moved": (r_moved / HBM_PEAK_GBS) if r_moved else None,
+                                   "copy_ceiling": HBM_COPY_CEILING_GBS, "frac_of_copy_ceiling": r_ach / HBM_COPY_CEILING_GBS,
+                                   "frac_moved_of_copy_ceiling": (r_moved / HBM_COPY_CEILING_GBS) if r_moved else None,
+                                   "moved_bytes_per_entry": r_moved_pe, "traffic_source": r_src,
+                                   "kernel": "k_replica", "bytes_per_entry": path_bytes,
+                                   "avg_launch_us": dr["launch_ms"] * 1e3, "launches": 1, "entries_per_launch": dr["entries_in_launch"],
+                                   "note": "one resident launch per run: its duration by HIP events on the engine's replica stream (start of the "
+                                           "launch to the workgroups' exit after the park command: 1 + REPS x K steps and the host's gaps between "
+                                           "regions), algorithmic bytes = 1088 B x the entries that launch committed"}
+                out["whole_path"] = {"bytes_per_entry": path_bytes, "achieved": path_bytes * r_value / 1e9, "unit": "GB/s",
+                                     "frac": path_bytes * r_value / 1e9 / HBM_PEAK_GBS}
         except Exception as exc:
             print(f"[bench] replica kernel measurement failed: {exc!r}", file=sys.stderr)
+    if not args.no_other and args.config == "c2":
+        print("[bench] other configurations", file=sys.stderr, flush=True)
+        try:
+            out["other_configs"] = measure_other_configs(args)
+        except Exception as exc:
+            print(f"[bench] other configurations failed: {exc!r}", file=sys.stderr)
     if not args.no_ack_path:
         try:
             out["ack_aggregation_path"] = measure_ack_path(args, tr, n_rep)
@@ -1055,6 +1199,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-ack-path", action="store_true", help="skip the second measurement without fused ACKs")
     ap.add_argument("--no-replica", action="store_true", help="skip the replica-kernel measurements")
+    ap.add_argument("--no-other", action="store_true", help="skip configs[2] / [3] / [4] (extra figures)")
     ap.add_argument("--no-configs0", action="store_true", help="skip the reference-as-is redis baseline (configs[0])")
     ap.add_argument("--no-calibration", action="store_true", help="--gpus N: skip the link calibration")
     ap.add_argument("--no-join", action="store_true", help="--gpus N (even): do not let the spare machine join")

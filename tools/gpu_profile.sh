@@ -29,7 +29,7 @@ done
 if [ -n "$REPLICA" ]; then
   d=$PWD/gpurun_out/prof_rep
   rm -rf $d; mkdir -p $d
-  RARGS="--grid ${REP_GRID:-96:48} --steps 3 --no-hostfed --brief"
+  RARGS="--grid ${REP_GRID:-192:96} --steps 3 --no-hostfed --brief"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $d/kt -o kt -- python $OLDPWD/tools/rep_bench.py $RARGS > $d/kt_run.log 2>&1)
   f=$(find $d/kt -name "*.db" | head -1)
   { echo "# rocprofv3 --kernel-trace --stats -- python tools/rep_bench.py $RARGS"; python tools/kstats.py $f; echo; tail -1 $d/kt_run.log | cut -c1-600; } > $d/${R}_replica_kernel_stats.txt
@@ -39,6 +39,7 @@ if [ -n "$REPLICA" ]; then
     python tools/pmcstats.py $(find $d/pmc_$ctr -name "*.db" | head -1) $ctr k_replica >> $d/${R}_replica_pmc.txt 2>&1
     tail -1 $d/pmc_$ctr.log | cut -c1-300 >> $d/${R}_replica_pmc.txt
   done
+  python tools/mk_rep_traffic.py $(find $d/pmc_FETCH_SIZE -name "*.db" | head -1) $(find $d/pmc_WRITE_SIZE -name "*.db" | head -1) $d/pmc_WRITE_SIZE.log gpurun_out/${R}_replica_pmc_traffic.json
   cat $d/${R}_replica_kernel_stats.txt | head -12; cat $d/${R}_replica_pmc.txt
   find $d -name "*.db" -size +20M -delete
 fi

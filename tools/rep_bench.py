@@ -70,6 +70,7 @@ def staged(n_rep, entries, payload, batch, steps, n_append, n_fwork, warmup=1):
         ok = ok and eng.counters(0)["highest_rec"] == total
         return {"mode": "staged", "replicas": n_rep, "payload": payload, "n_append": n_append, "n_fwork": n_fwork,
                 "entries_per_s": len(tr.reqs) * steps / dt, "ms_per_step": dt / steps * 1e3, "verified": bool(ok),
+                "entries_total": total, "launch_ms": eng.rep_launch_ms(),
                 "exit": code, "status": eng.status_names(), "stats": st,
                 "lat_us_p50": float(np.percentile(lat, 50)) / 1e3 if len(lat) else None,
                 "lat_appended_us_p50": float(np.percentile(lat_a, 50)) / 1e3 if len(lat_a) else None, "roles": roles}
@@ -136,7 +137,7 @@ def main():
         try:
             res = staged(n_rep, a.entries, 64, 64, a.steps, na, nf)
             if a.brief:
-                res = {k: res[k] for k in ("replicas", "n_append", "n_fwork", "entries_per_s", "verified", "lat_us_p50", "lat_appended_us_p50", "roles")}
+                res = {k: res[k] for k in ("replicas", "n_append", "n_fwork", "entries_per_s", "verified", "entries_total", "launch_ms", "lat_us_p50", "lat_appended_us_p50", "roles")}
             print(json.dumps(res), flush=True)
         except Exception as exc:
             print(json.dumps({"mode": "staged", "replicas": n_rep, "n_append": na, "n_fwork": nf, "error": repr(exc)[:600]}), flush=True)
