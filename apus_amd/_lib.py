@@ -109,6 +109,7 @@ SIGNATURES = {
     "apus_gpu_rep_follower_stop": (C.c_int, [vp, u32]),
     "apus_gpu_rep_role_stats": (C.c_int, [vp, vp]),
     "apus_gpu_rep_launch_ms": (C.c_int, [vp, C.POINTER(C.c_double)]),
+    "apus_gpu_rep_req_ring_kind": (C.c_int, [vp]),
     "apus_gpu_rep_roundtrip": (C.c_int, [vp, vp, u32, vp, u64, u32, vp]),
 }
 

@@ -97,7 +97,10 @@ struct apus_engine {
     uint64_t p_ev_tail, p_req_tail, p_arena_pos;
     uint64_t p_req_end[P_EV_CAP];   /* cumulative request count after each published event */
     /* replica kernels (apus_gpu_rep_*): every hosted replica runs its own workgroups */
-    RepHost *rh, *rh_dev;           /* pinned, coherent: the leader's request ring, command ring, progress words */
+    RepHost *rh, *rh_dev;           /* pinned, coherent: the leader's progress words */
+    RepReq *rq;                     /* the command + request rings the host fills: device memory behind the BAR, or pinned (rq_bar) */
+    RepReq *rq_dev;
+    bool rq_bar;
     RepLead *rl;                    /* leader-local hand-off state */
     RepFollow *rfs[APUS_MAX_SERVERS];
     RepFHost *rfh[APUS_MAX_SERVERS], *rfh_dev[APUS_MAX_SERVERS];   /* pinned: a hosted follower's progress / stop words */
@@ -206,7 +209,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->live_r0 = e->live_R = e->live_n = 0;
     e->ph = e->ph_dev = nullptr; e->pd = nullptr; e->pstream = nullptr; e->p_running = false;
     e->p_ev_tail = e->p_req_tail = e->p_arena_pos = 0;
-    e->rh = e->rh_dev = nullptr; e->rl = nullptr; e->rstream = nullptr; e->rev0 = e->rev1 = nullptr; e->rev_valid = false; e->r_running = e->r_lead = false; e->r_follow_mask = 0; e->r_test_skip = 0;
+    e->rh = e->rh_dev = nullptr; e->rq = e->rq_dev = nullptr; e->rq_bar = false; e->rl = nullptr; e->rstream = nullptr; e->rev0 = e->rev1 = nullptr; e->rev_valid = false; e->r_running = e->r_lead = false; e->r_follow_mask = 0; e->r_test_skip = 0;
     for (auto &f : e->rfs) f = nullptr;
     e->r_slot_tail = e->r_arena_tail = e->r_cmd_tail = 0; e->r_slot_aend = nullptr;
     pthread_spin_init(&e->r_lock, PTHREAD_PROCESS_PRIVATE); e->r_lock_init = true;
@@ -292,6 +295,7 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
     if (e->d_arena) hipFree(e->d_arena);
     if (e->d_round_first) hipFree(e->d_round_first);
     if (e->d_round_prefix) hipFree(e->d_round_prefix);
+    if (e->rq) { if (e->rq_bar) hipFree(e->rq); else hipHostFree(e->rq); }
     if (e->rh) hipHostFree(e->rh);
     if (e->rl) hipFree(e->rl);
     for (auto f : e->rfs) if (f) hipFree(f);
@@ -2296,7 +2300,23 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
         if (!e->rh) {
             HIPCHK(hipHostMalloc((void **)&e->rh, sizeof(RepHost), hipHostMallocMapped | hipHostMallocCoherent));
             HIPCHK(hipHostGetDevicePointer((void **)&e->rh_dev, e->rh, 0));
-            memset((void *)e->rh, 0, offsetof(RepHost, slot));
+            memset((void *)e->rh, 0, sizeof(RepHost));
+            /* the rings the host fills: in device memory when the host can store into it (large BAR) */
+            int large_bar = 0;
+            const char *rr = getenv("APUS_REQ_RING");
+            if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, e->cfg.device) != hipSuccess) { large_bar = 0; (void)hipGetLastError(); }
+            if (large_bar && !(rr && !strcmp(rr, "host"))) {
+                void *p = nullptr;
+                if (hipExtMallocWithFlags(&p, sizeof(RepReq), hipDeviceMallocUncached) == hipSuccess) {
+                    e->rq = e->rq_dev = (RepReq *)p; e->rq_bar = true;
+                    HIPCHK(hipMemset(p, 0, offsetof(RepReq, slot)));
+                } else (void)hipGetLastError();
+            }
+            if (!e->rq) {
+                HIPCHK(hipHostMalloc((void **)&e->rq, sizeof(RepReq), hipHostMallocMapped | hipHostMallocCoherent));
+                HIPCHK(hipHostGetDevicePointer((void **)&e->rq_dev, e->rq, 0));
+                memset((void *)e->rq, 0, offsetof(RepReq, slot));
+            }
             HIPCHK(hipMalloc((void **)&e->rl, sizeof(RepLead)));
             e->r_slot_aend = (uint64_t *)calloc(RQ_CAP, sizeof(uint64_t));
             if (!e->r_slot_aend) return APUS_E_NOMEM;
@@ -2315,10 +2335,10 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
         /* (a run that ended abnormally may have left commands or slots behind: they are dropped) */
         e->rh->cmd_head = e->r_cmd_tail; e->rh->slots_done = e->r_slot_tail;
         e->rh->settled = e->r_cmd_tail + e->r_slot_tail;
-        e->rh->stop = 0; e->rh->alive = 0; e->rh->exit_code = 0; e->rh->full = 0; e->rh->rounds = 0;
+        e->rq->stop = 0; e->rh->alive = 0; e->rh->exit_code = 0; e->rh->full = 0; e->rh->rounds = 0;
         e->rh->highest_rec = h[H_HIGHEST_REC];
         e->rh->commit_slot = h[H_N_COMMIT];
-        A.H = e->rh_dev; A.LS = e->rl;
+        A.H = e->rh_dev; A.RQ = e->rq_dev; A.LS = e->rl;
     }
     for (uint32_t m = A.follow_mask; m; m &= m - 1) {
         const uint32_t f = (uint32_t)__builtin_ctz(m);
@@ -2362,10 +2382,11 @@ static int rep_push_cmd(apus_engine *e, uint32_t op, uint64_t a, uint64_t b)
             return APUS_E_STATE;
         }
     /* four self-tagged granules {command number + 1 : value}: the command is there once all four are */
-    RepCmd &c = e->rh->cmd[e->r_cmd_tail % RC_CAP];
+    RepCmd &c = e->rq->cmd[e->r_cmd_tail % RC_CAP];
     const uint64_t tag = ((e->r_cmd_tail + 1) & 0xFFFFFFFFull) << 32;
     const uint64_t vals[4] = { op, __atomic_load_n(&e->r_slot_tail, __ATOMIC_ACQUIRE) & 0xFFFFFFFFull, a & 0xFFFFFFFFull, b & 0xFFFFFFFFull };
     for (int i = 3; i >= 0; i--) __atomic_store_n((uint64_t *)&c.g[i], tag | vals[i], __ATOMIC_RELEASE);
+    if (e->rq_bar) __builtin_ia32_sfence();          /* (write-combined stores through the BAR: on their way now) */
     e->r_cmd_tail++;
     pthread_spin_unlock(&e->r_lock);
     return 0;
@@ -2413,7 +2434,7 @@ static inline int rep_reserve_arena(apus_engine *e, uint32_t len, uint64_t *slot
             __atomic_store_n(&e->r_arena_tail, pos + need, __ATOMIC_RELEASE);
             e->r_slot_aend[s0 % RQ_CAP] = pos + need;
             *slot = s0;
-            *dst = (void *)(e->rh->arena + phys);
+            *dst = (void *)(e->rq->arena + phys);
             pthread_spin_unlock(&e->r_lock);
             return 0;
         }
@@ -2427,21 +2448,25 @@ extern "C" int apus_gpu_rep_reserve(apus_engine_t *e, uint32_t len, uint64_t *sl
     if (len > R_INLINE) return rep_reserve_arena(e, len, slot, dst);
     int rc = rep_reserve_inline(e, 1, slot);
     if (rc) return rc;
-    *dst = (void *)e->rh->slot[*slot % RQ_CAP].pay;
+    *dst = (void *)e->rq->slot[*slot % RQ_CAP].pay;
     return 0;
 }
 
 extern "C" int apus_gpu_rep_publish(apus_engine_t *e, uint64_t slot, const void *dst, uint64_t req_id, uint16_t clt_id, uint8_t type, uint16_t len)
 {
-    if (!e || !e->rh) return APUS_E_STATE;
+    if (!e || !e->rh || !e->rq) return APUS_E_STATE;
     if (type == APUS_NOOP || type == APUS_CONFIG || type == APUS_HEAD || type > 15) return APUS_E_ARG;
-    RepSlot &sl = e->rh->slot[slot % RQ_CAP];
+    RepSlot &sl = e->rq->slot[slot % RQ_CAP];
     const bool inl = (const uint8_t *)dst == sl.pay;
-    const uint64_t phys = inl ? 0 : (uint64_t)((const uint8_t *)dst - e->rh->arena);
+    const uint64_t phys = inl ? 0 : (uint64_t)((const uint8_t *)dst - e->rq->arena);
     ReqDev d;
     d.req_id = req_id; d.pay16_type = (inl ? R_PAY_INLINE : (uint32_t)(phys / 16)) | ((uint32_t)type << 28); d.len = len; d.clt_id = clt_id;
     sl.d = d;
-    __atomic_store_n((uint32_t *)&e->rh->ready_len[slot % RQ_CAP], (rep_slot_tag(slot) << 16) | len, __ATOMIC_RELEASE);
+    /* through the BAR the payload and the descriptor are write-combined stores: they leave in front of the publish word,
+     * and the publish word leaves at once */
+    if (e->rq_bar) __builtin_ia32_sfence();
+    __atomic_store_n((uint32_t *)&e->rq->ready_len[slot % RQ_CAP], (rep_slot_tag(slot) << 16) | len, __ATOMIC_RELEASE);
+    if (e->rq_bar) __builtin_ia32_sfence();
     return 0;
 }
 
@@ -2470,12 +2495,21 @@ extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uin
         uint64_t s0;
         int rc = rep_reserve_inline(e, run, &s0);
         if (rc) return rc;
+        /* the whole block's descriptors and payloads, ONE fence, then its publish words: through the BAR every fence waits for
+         * the write-combining buffers to drain (~0.35 us; two per slot made a round of 64 cost 50 us) */
         for (uint32_t i = 0; i < run; i++) {
             const apus_req_t &q = reqs[g + i];
-            void *dst = (void *)e->rh->slot[(s0 + i) % RQ_CAP].pay;
-            if (q.len) memcpy(dst, arena + q.payload_off, q.len);
-            if ((rc = apus_gpu_rep_publish(e, s0 + i, dst, q.req_id, q.clt_id, q.type, q.len))) return rc;
+            if (q.type == APUS_NOOP || q.type == APUS_CONFIG || q.type == APUS_HEAD || q.type > 15) return APUS_E_ARG;
+            RepSlot &sl = e->rq->slot[(s0 + i) % RQ_CAP];
+            if (q.len) memcpy((void *)sl.pay, arena + q.payload_off, q.len);
+            ReqDev d;
+            d.req_id = q.req_id; d.pay16_type = R_PAY_INLINE | ((uint32_t)q.type << 28); d.len = q.len; d.clt_id = q.clt_id;
+            sl.d = d;
         }
+        if (e->rq_bar) __builtin_ia32_sfence();
+        for (uint32_t i = 0; i < run; i++)
+            __atomic_store_n((uint32_t *)&e->rq->ready_len[(s0 + i) % RQ_CAP], (rep_slot_tag(s0 + i) << 16) | reqs[g + i].len, __ATOMIC_RELEASE);
+        if (e->rq_bar) __builtin_ia32_sfence();
         g += run;
     }
     return 0;
@@ -2513,7 +2547,7 @@ extern "C" int apus_gpu_rep_park(apus_engine_t *e)
     int code = 0;
     if (e->r_lead) {
         int rc = rep_push_cmd(e, R_OP_STOP, 0, 0);
-        if (rc) __atomic_store_n((uint64_t *)&e->rh->stop, 1ull, __ATOMIC_RELEASE);
+        if (rc) { __atomic_store_n((uint64_t *)&e->rq->stop, 1ull, __ATOMIC_RELEASE); if (e->rq_bar) __builtin_ia32_sfence(); }
     }
     HIPCHK(hipStreamSynchronize(e->rstream));
     if (e->r_lead) code = (int)e->rh->exit_code;
@@ -2551,6 +2585,8 @@ extern "C" int apus_gpu_rep_test_skip_follower(apus_engine_t *e, uint32_t mask) 
 
 extern "C" uint64_t apus_gpu_rep_highest_rec(apus_engine_t *e) { return (e && e->rh) ? e->rh->highest_rec : 0; }
 extern "C" const volatile uint64_t *apus_gpu_rep_highest_rec_ptr(apus_engine_t *e) { return (e && e->rh) ? &e->rh->highest_rec : nullptr; }
+/* where the command + request rings live: 1 device memory the host stores into through the BAR, 0 pinned host memory, -1 no run yet */
+extern "C" int apus_gpu_rep_req_ring_kind(apus_engine_t *e) { return (e && e->rq) ? (e->rq_bar ? 1 : 0) : -1; }
 extern "C" int apus_gpu_rep_full(apus_engine_t *e) { return (e && e->rh) ? (int)e->rh->full : 0; }
 /* out[8] = rounds issued, request slots taken, commands carried out, committed slots, highest_rec, rounds refused,
  *          followers dropped from the push set (mask), alive */

@@ -90,6 +90,16 @@ struct RepHost {
     volatile uint64_t rounds;            /* tickets issued (written when the run ends)         */
     volatile uint64_t settled;           /* commands carried out + request slots taken whose rounds are all in every ring, committed and applied as far as a majority allows */
     uint64_t pad1[7];
+};
+/* host -> leader: what the HOST writes and the leader's kernel reads -- the command ring and the multi-producer request
+ * ring.  Round 4: in DEVICE memory where the host can store into it (large BAR: hipDeviceAttributeIsLargeBar): a producer's
+ * descriptor, payload and publish word are posted writes across PCIe, the sequencer polls and the append wavefronts read
+ * LOCAL memory (round 3: pinned host memory, every poll and both dependent reads of a lone request a PCIe round trip of
+ * 2.4 us: tools/micro/bar.hip -- host store -> resident kernel -> host 1.7 us through the BAR against 2.4 us).  Pinned host
+ * memory otherwise (APUS_REQ_RING=host forces it).  The host never READS this block. */
+struct RepReq {
+    volatile uint64_t stop;              /* host -> kernel: leave at the next look (apus_gpu_rep_park when the command ring has no room) */
+    uint64_t pad0[7];
     RepCmd   cmd[RC_CAP];
     /* multi-producer request ring: a producer reserves slot (+ arena range for a long payload), copies
      * the payload, fills slot[].d, then publishes ready_len[slot] = tag << 16 | len (release) */
@@ -212,6 +222,7 @@ struct RepFHost {
 
 struct RepArgs {
     RepHost *H;                          /* leader here: its pinned block                         */
+    RepReq  *RQ;                         /* ... and the command + request rings the host fills    */
     RepFHost *FH[APUS_DEV_MAX_SERVERS];  /* followers hosted here: their pinned blocks            */
     RepLead *LS;
     RepFollow *FS[APUS_DEV_MAX_SERVERS]; /* followers hosted here                                 */
@@ -227,7 +238,7 @@ struct RepArgs {
 };
 
 /* a short nap between two polls while work is expected, a longer one once the poller has been idle */
-__device__ static inline void rep_nap(bool eager) { if (eager) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(12); }
+__device__ static inline void rep_nap(bool eager) { if (eager) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(6); }
 __device__ static inline uint32_t ld_sys32(const volatile uint32_t *p) { return __hip_atomic_load((const APUS_GLOBAL uint32_t *)(uintptr_t)p, RLX_SYSTEM); }
 __device__ static inline void st_sys8(uint8_t *p, uint8_t v) { __hip_atomic_store((APUS_GLOBAL uint8_t *)(uintptr_t)p, v, RLX_SYSTEM); }
 __device__ static inline uint8_t ld_sys8(const uint8_t *p) { return __hip_atomic_load((const APUS_GLOBAL uint8_t *)(uintptr_t)p, RLX_SYSTEM); }
@@ -643,6 +654,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                                             lds_u64 s_m, lds_u64 s_x, uint4 *s_tr /* 4 KiB of LDS: the queue of unverified head moves */)
 {
     RepHost *H = A.H;
+    RepReq *RQ = A.RQ;
     RepLead *LS = A.LS;
     RepBox *mybox = E.box[E.leader];
     const uint64_t L = E.log_len;
@@ -826,7 +838,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                 if (!have_cmd && !have_cmd2 && run_end - rc <= 3 * WAVE * R_SUB) {
                     pk_pending = true; pk_next = cmd_head + 1;            /* (cmd_head is the RUN in progress) */
                     pk_cg = 0;
-                    if (lane < 8) pk_cg = ld_sys(&H->cmd[(pk_next + (lane >> 2)) % RC_CAP].g[lane & 3]);
+                    if (lane < 8) pk_cg = ld_sys(&RQ->cmd[(pk_next + (lane >> 2)) % RC_CAP].g[lane & 3]);
                 }
                 if (budget < WAVE) break;                             /* (no room: the blocking look at the rings, above) */
                 const uint32_t avail = (uint32_t)min((uint64_t)want, budget);
@@ -932,10 +944,10 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
         st_pcie_n++;
         uint32_t v[R_WIN];
 #pragma unroll
-        for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = ld_sys32(&H->ready_len[(req_head + (uint64_t)wdw * WAVE + lane) % RQ_CAP]);
+        for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = ld_sys32(&RQ->ready_len[(req_head + (uint64_t)wdw * WAVE + lane) % RQ_CAP]);
         if (!have_cmd) {
             uint64_t cg = 0;
-            if (lane < 8) cg = ld_sys(&H->cmd[(cmd_head + (lane >> 2)) % RC_CAP].g[lane & 3]);
+            if (lane < 8) cg = ld_sys(&RQ->cmd[(cmd_head + (lane >> 2)) % RC_CAP].g[lane & 3]);
             const unsigned long long okb = __ballot(lane < 8 && rep_gran_ok(cg, cmd_head + (lane >> 2)));
             if ((okb & 0xFull) == 0xFull) {
                 have_cmd = true;
@@ -948,7 +960,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                 }
             }
         }
-        const uint64_t stopw = ld_sys(&H->stop);
+        const uint64_t stopw = ld_sys(&RQ->stop);        /* (with the rings: a look at host memory would be the one PCIe round trip of the pass) */
         if (stats) st_pcie += wall_clock64() - tq0;
         {
             const int x = exec_cmd();
@@ -1463,10 +1475,10 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
              * filled state (a vector L1 is never refreshed by anybody's stores): drop them */
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
             if (active) {
-                const RepSlot *sl = &H->slot[(first + lane) % RQ_CAP];
+                const RepSlot *sl = &A.RQ->slot[(first + lane) % RQ_CAP];
                 const uint4 q = *(const uint4 *)&sl->d;
                 d.req_id = (uint64_t)q.x | ((uint64_t)q.y << 32); d.pay16_type = q.z; d.len = (uint16_t)(q.w & 0xFFFF); d.clt_id = (uint16_t)(q.w >> 16);
-                src = (d.pay16_type & 0x0FFFFFFFu) == R_PAY_INLINE ? sl->pay : H->arena + (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
+                src = (d.pay16_type & 0x0FFFFFFFu) == R_PAY_INLINE ? sl->pay : A.RQ->arena + (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
             }
         } else if (kind == R_SRC_STAGED) {
             if (active) { if (bulk) d = dbulk; else d = E.req[first + lane]; src = E.arena + (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16; }

@@ -415,6 +415,10 @@ class Engine:
                                            prune_every_reqs, out), "rep_feed")
         return int(out[0]), out[1] / 1e9
 
+    def rep_req_ring_kind(self) -> str:
+        k = int(self.L.apus_gpu_rep_req_ring_kind(self.h))
+        return {1: "device memory, written by the host through the BAR", 0: "pinned host memory, read by the kernel over PCIe"}.get(k, "none yet")
+
     def rep_launch_ms(self) -> float:
         """duration of the last (parked) run's resident k_replica launch, HIP events on its stream"""
         ms = C.c_double(0)

@@ -382,7 +382,8 @@ def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True, regions_n
             out["latency"] = {"appended_to_committed_and_applied_us_p50": float(np.percentile(lat_app[20:], 50)) / 1e3 if len(lat_app) > 20 else None,
                               "sequenced_to_committed_and_applied_us_p50": float(np.percentile(lat_seq[20:], 50)) / 1e3 if len(lat_seq) > 20 else None,
                               "host_submit_to_highest_rec_us_p50_64_entries": float(np.percentile(hl64[40:], 50)),
-                              "host_submit_to_highest_rec_us_p50_1_entry": float(np.percentile(hl1[40:], 50)), "exit": code}
+                              "host_submit_to_highest_rec_us_p50_1_entry": float(np.percentile(hl1[40:], 50)), "exit": code,
+                              "request_ring": eng.rep_req_ring_kind()}
             la_, ls_, lh_ = (out["latency"][k] for k in ("appended_to_committed_and_applied_us_p50", "sequenced_to_committed_and_applied_us_p50",
                                                          "host_submit_to_highest_rec_us_p50_64_entries"))
             if la_ is not None and ls_ is not None:

@@ -358,6 +358,7 @@ int  apus_gpu_rep_feed(apus_engine_t *e, const apus_req_t *reqs, uint32_t n, con
  * application (proxy.c:341-439); and, when the leader is gone and nobody will ring the park doorbell: leave */
 int  apus_gpu_rep_follower_progress(apus_engine_t *e, uint32_t replica, uint64_t out[4]);
 int  apus_gpu_rep_follower_stop(apus_engine_t *e, uint32_t replica);
+int  apus_gpu_rep_req_ring_kind(apus_engine_t *e);                            /* 1: the request ring is device memory behind the BAR, 0: pinned host memory, -1: no run yet */
 int  apus_gpu_rep_launch_ms(apus_engine_t *e, double *ms);                    /* duration of the last (parked) run's resident launch, HIP events on its stream */
 int  apus_gpu_rep_role_stats(apus_engine_t *e, uint64_t out[20][8]);          /* diagnostics: passes / rounds / time of the serial roles of the last run */
 int  apus_gpu_rep_roundtrip(apus_engine_t *e, const apus_req_t *reqs, uint32_t n, const uint8_t *arena, uint64_t arena_bytes,
