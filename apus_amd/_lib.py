@@ -107,6 +107,7 @@ SIGNATURES = {
     "apus_gpu_rep_feed": (C.c_int, [vp, vp, u32, vp, u64, u32, C.c_double, u64, C.POINTER(u64)]),
     "apus_gpu_rep_follower_progress": (C.c_int, [vp, u32, C.POINTER(u64)]),
     "apus_gpu_rep_follower_stop": (C.c_int, [vp, u32]),
+    "apus_gpu_rep_follower_replayed": (C.c_int, [vp, C.c_uint32, C.c_uint64]),
     "apus_gpu_rep_role_stats": (C.c_int, [vp, vp]),
     "apus_gpu_rep_launch_ms": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "apus_gpu_rep_req_ring_kind": (C.c_int, [vp]),

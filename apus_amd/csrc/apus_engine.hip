@@ -104,6 +104,7 @@ struct apus_engine {
     RepLead *rl;                    /* leader-local hand-off state */
     RepFollow *rfs[APUS_MAX_SERVERS];
     RepFHost *rfh[APUS_MAX_SERVERS], *rfh_dev[APUS_MAX_SERVERS];   /* pinned: a hosted follower's progress / stop words */
+    uint64_t r_consumer[APUS_MAX_SERVERS], r_replayed[APUS_MAX_SERVERS];   /* a host consumer of a hosted follower's apply stream (apus_gpu_rep_follower_replayed) */
     uint8_t *ss_buf; uint64_t ss_cap;       /* apus_gpu_store_stream's scratch, kept between calls */
     hipStream_t rstream;
     hipEvent_t rev0, rev1;          /* around the last k_replica launch (apus_gpu_rep_launch_ms) */
@@ -1051,6 +1052,15 @@ __global__ void k_set_roles(const EngDev E, uint64_t sid, uint32_t bitmask, uint
     /* ACK words of entries this server did not append itself start empty */
     for (uint64_t s2 = lh[H_N_COMMIT]; s2 < n_end; s2++) Ld.ack[(uint32_t)s2 & E.dir_mask] = 0;
     for (uint32_t i = 0; i < E.group_size; i++) lh[H_APPLY_OFFSETS + i] = lh[H_HEAD];  /* dare_server.c:1504-1507 */
+    /* A term fence raised against this engine while it led an OLDER term (k_fence_check) ends here only if no server of the
+     * configuration that this engine can see holds a NEWER term than the one it has just won -- looked at BEFORE the
+     * followers below are given the new SID (round 3 looked afterwards: always false), and over every configured
+     * server that is mapped here, reachable or not: a follower that is ahead and cut off keeps the fence up and the
+     * sticky APUS_ST_TERM_FENCE bit set.  (rc_restore_log_access, dare_ibv_rc.c:2245-2290: the voters restore the log
+     * access of the server they vote for.) */
+    bool ahead = false;
+    for (uint32_t i = 0; i < E.group_size; i++)
+        if (i != E.leader && ((bitmask >> i) & 1u) && E.rep[i].ring && (E.rep[i].hdr[H_SID] >> 9) > (sid >> 9)) ahead = true;
     for (uint32_t i = 0; i < E.group_size; i++) {
         if (i == E.leader || !((follow_mask >> i) & 1u) || !E.rep[i].ring) continue;
         uint64_t *fh = E.rep[i].hdr;
@@ -1058,13 +1068,6 @@ __global__ void k_set_roles(const EngDev E, uint64_t sid, uint32_t bitmask, uint
         fh[H_TAIL] = E.log_len;
         fh[H_CID_BITMASK] = bitmask;
     }
-    /* A term fence raised against this engine while it led an OLDER term (k_fence_check) ends here: it has won a
-     * term that no follower it pushes to is ahead of -- the reference's voters restore the log access of the server
-     * they vote for (rc_restore_log_access, dare_ibv_rc.c:2245-2290).  A follower that is still ahead (not reachable,
-     * so not given the new SID above) keeps the fence up. */
-    bool ahead = false;
-    for (uint32_t i = 0; i < E.group_size; i++)
-        if (i != E.leader && ((follow_mask >> i) & 1u) && E.rep[i].ring && (E.rep[i].hdr[H_SID] >> 9) > (sid >> 9)) ahead = true;
     if (!ahead) { E.status[FENCE_WORD] = 0; atomicAnd(E.status, ~(1u << 2)); }
 }
 
@@ -1487,7 +1490,14 @@ extern "C" int apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_
     {
         const uint32_t jsize = r < size ? size : size + 1;
         const uint32_t conn = join_answers(*H, e->mv, r, leader, nb, reachable, jsize, cfg_n0, cfg_n1);
-        if (cfg_n1 == cfg_n0 || conn <= jsize / 2) { free(H); return cfg_n1 == cfg_n0 ? APUS_E_FULL : APUS_E_NOANSWER; }
+        if (cfg_n1 == cfg_n0 || conn <= jsize / 2) {
+            /* refused AFTER the CONFIG entries went into the log (as in the reference, whose joiner then retries for ever): the
+             * configuration the device now holds goes back to the caller, who must adopt it -- its mirrors (bitmask, size,
+             * epoch) would otherwise disagree with the device on every later call */
+            free(H);
+            if (cfg_n1 != cfg_n0) { out[0] = nb; out[1] = e->d.group_size; out[2] = e->cid_epoch; out[3] = 0; }
+            return cfg_n1 == cfg_n0 ? APUS_E_FULL : APUS_E_NOANSWER;
+        }
     }
     const uint64_t join_cid_idx = H->it[cfg_n0 % CFGJ_CAP].idx;
     free(H);
@@ -2284,7 +2294,7 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
         const uint32_t room = (uint32_t)std::max(8, occ * cus - 8);
         const uint32_t nfh = (uint32_t)popc(A.follow_mask);
         if (!n_append) n_append = lead_here ? 192 : 0;
-        if (!n_fwork) n_fwork = nfh ? std::min(96u, std::max(24u, 288u / nfh)) : 1;    /* (measured, round 4: 192 append + 96 per follower at 3 replicas) */
+        if (!n_fwork) n_fwork = nfh ? std::min(128u, std::max(24u, 288u / nfh)) : 1;   /* (measured, round 4: 192 append + 128 per follower at 3 replicas, 72 at 5, 48 at 7) */
         while ((lead_here ? 1 + n_append : 0) + nfh * n_fwork > room && (n_append > 8 || n_fwork > 2)) {
             if (n_append > 8) n_append -= n_append / 4;
             if (n_fwork > 2) n_fwork -= (n_fwork + 3) / 4;
@@ -2350,6 +2360,7 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
             HIPCHK(hipHostGetDevicePointer((void **)&e->rfh_dev[f], e->rfh[f], 0));
         }
         memset((void *)e->rfh[f], 0, sizeof(RepFHost));
+        e->rfh[f]->consumer = e->r_consumer[f]; e->rfh[f]->replayed = e->r_replayed[f];
         A.FH[f] = e->rfh_dev[f];
     }
     const uint32_t grid = (lead_here ? 1 + n_append : 0) + popc(A.follow_mask) * n_fwork;
@@ -2570,6 +2581,17 @@ extern "C" int apus_gpu_rep_follower_progress(apus_engine_t *e, uint32_t replica
     RepFHost *h = e->rfh[replica];
     if (!h) { out[0] = out[1] = out[2] = out[3] = 0; return 0; }
     out[0] = h->n_apply; out[1] = h->n_end; out[2] = h->alive; out[3] = h->exit_code;
+    return 0;
+}
+/* A host consumer of a hosted follower's apply stream says how far it has replayed (entry slots, the count
+ * apus_gpu_rep_follower_progress reports as out[0]); from the first call on the follower's kernel tells the leader
+ * min(device apply, host replay) as "applied".  Callable before and during a run. */
+extern "C" int apus_gpu_rep_follower_replayed(apus_engine_t *e, uint32_t replica, uint64_t slots)
+{
+    if (!e || replica >= APUS_MAX_SERVERS) return APUS_E_ARG;
+    e->r_consumer[replica] = 1; e->r_replayed[replica] = slots;
+    RepFHost *h = e->rfh[replica];
+    if (h) { __atomic_store_n((uint64_t *)&h->replayed, slots, __ATOMIC_RELEASE); __atomic_store_n((uint64_t *)&h->consumer, 1ull, __ATOMIC_RELEASE); }
     return 0;
 }
 /* ... and when its leader is gone (no park doorbell will come): ask the follower's workgroups to leave; then apus_gpu_rep_park */

@@ -217,7 +217,14 @@ struct RepFHost {
     volatile uint64_t n_end;             /*                 entry slots persisted                 */
     volatile uint64_t alive;             /* 1 running, 2 left                                     */
     volatile uint64_t exit_code;
-    uint64_t pad1[4];
+    /* host -> kernel: a host consumer replays the apply stream into its own application (proxy_do_action, proxy.c:341-439:
+     * in the reference the apply IS that call).  consumer != 0: what this server tells the leader it has applied
+     * (applied_by: the prune samples' verification, and with it how far the head may move) is the SMALLER of the
+     * device's apply count and `replayed`, the entry slots the host has carried out -- the log cannot be pruned and lapped
+     * under a host replay that lags (round 3: the device count alone). */
+    volatile uint64_t consumer;
+    volatile uint64_t replayed;
+    uint64_t pad1[2];
 };
 
 struct RepArgs {
@@ -1981,7 +1988,10 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
     const uint64_t hash0 = mh[H_APPLY_HASH], cnt0 = mh[H_APPLY_COUNT], my_sid = mh[H_SID];
     uint64_t hash = 0, ncl = 0;
     uint64_t q_app = q0;
-    if (lane == 0) { st_sys(&lbox->seqdone_by[me], q_app); st_sys(&lbox->applied_by[me], n_apply); st_sys(&lbox->apply_off_by[me], a_off0); }
+    const bool has_consumer = A.FH[me] && ld_sys(&A.FH[me]->consumer) != 0;
+    uint64_t applied_pub = n_apply;
+    if (has_consumer) { const uint64_t hr = ld_sys(&A.FH[me]->replayed); if (hr < applied_pub) applied_pub = hr; }
+    if (lane == 0) { st_sys(&lbox->seqdone_by[me], q_app); st_sys(&lbox->applied_by[me], applied_pub); st_sys(&lbox->apply_off_by[me], a_off0); }
     uint64_t idle_fin = 0;
     uint64_t end = 0, n_end = 0, q_ret = q0;
     uint64_t st_pass = 0, st_prog = 0, st_busy = 0;
@@ -2038,9 +2048,17 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
                 progress = true;
             }
             if (q_app != t0 && lane == 0) {
-                st_sys(&lbox->applied_by[me], n_apply); st_sys(&lbox->seqdone_by[me], q_app);
+                if (!has_consumer) { st_sys(&lbox->applied_by[me], n_apply); applied_pub = n_apply; }
+                st_sys(&lbox->seqdone_by[me], q_app);
                 if (A.FH[me] && !(A.dbg & 2048)) st_sys(&A.FH[me]->n_apply, n_apply);
             }
+        }
+        /* a host consumer: applied = what the device has applied AND the host has replayed (a look at pinned host memory, only
+         * while the two differ from what the leader was last told) */
+        if (has_consumer && applied_pub < n_apply) {
+            const uint64_t hr = ld_sys(&A.FH[me]->replayed);
+            const uint64_t ap = hr < n_apply ? hr : n_apply;
+            if (ap > applied_pub) { applied_pub = ap; if (lane == 0) st_sys(&lbox->applied_by[me], ap); }
         }
         /* ---- park?  everything that was sent is persisted; the leader's last commit doorbell was rung before the
          *      park word: one more look at it, then leave ---- */
@@ -2092,7 +2110,10 @@ __global__ __launch_bounds__(256) void k_rep_clear_reply(const EngDev E, uint32_
 /* One launch carries every role this process hosts: [leader control, n_append append workgroups,] then
  * n_fwork workgroups per hosted follower (the first two wavefronts of a follower's first workgroup are its
  * retire and apply wavefronts).  All workgroups must be resident together: the host sizes the grid for that. */
-__global__ __launch_bounds__(256) void k_replica(const EngDev E, const RepArgs A)
+#ifndef R_MIN_WG_PER_CU
+#define R_MIN_WG_PER_CU 2
+#endif
+__global__ __launch_bounds__(256, R_MIN_WG_PER_CU) void k_replica(const EngDev E, const RepArgs A)
 {
     __shared__ RepAppLds s_lds[4];
     __shared__ uint64_t s_h[64];

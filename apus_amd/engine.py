@@ -181,7 +181,14 @@ class Engine:
             if f in self.snap_head and self.snap_head[f] == self.offsets(f)["head"]:
                 raise EngineError(f"follower {f} was asked for its state machine already and no <HEAD> entry was committed since")
         out = (C.c_uint64 * 4)()
-        self._chk(self.L.apus_gpu_join(self.h, r, self.machines + 1, self.bitmask, self.reachable, out), "join")
+        out[1] = 0
+        rc = self.L.apus_gpu_join(self.h, r, self.machines + 1, self.bitmask, self.reachable, out)
+        if rc == -8 and int(out[1]):
+            # APUS_E_NOANSWER behind the CONFIG entries: the log holds them (the reference's joiner would retry for ever), the
+            # configuration on the device has moved on -- this object's mirrors follow it before the refusal is raised
+            self.bitmask, self.group_size, self.epoch = int(out[0]), int(out[1]), int(out[2])
+            self.join_refused_with_config = True
+        self._chk(rc, "join")
         self.machines += 1
         self.snap_head.pop(r, None)             # a new machine: it has not dumped anything yet
         for f in donors:

@@ -136,6 +136,7 @@ int apus_tailq_drain(void)
 
 /* ------------------------------------------------------------------------- */
 /* SMR core state (the reference keeps it in the global `data`, dare_server.c:69) */
+typedef struct { int64_t pid; uint64_t start; } g_stamp_t;      /* a process: pid + its start time (field 22 of /proc/<pid>/stat) */
 typedef struct {
     apus_engine_t *eng;
     dare_server_input_t in;
@@ -151,7 +152,7 @@ typedef struct {
     /* one PROCESS per server (APUS_GROUP_DIR): this process hosts replica `idx` only, the others are peer-mapped */
     int group;                                 /* 1: group mode */
     char group_dir[256];
-    pid_t peer_pid[APUS_MAX_SERVERS];
+    g_stamp_t peer_stamp[APUS_MAX_SERVERS];    /* every server's process of THIS run */
     uint32_t alive_mask, bitmask;              /* servers whose process answers; cid.bitmask as this process knows it */
     uint64_t replayed;                         /* follower: apply-stream slots handed to do_action so far */
     pthread_t thread;
@@ -349,6 +350,44 @@ static void g_path(smr_t *s, char *out, size_t cap, const char *fmt, ...)
     vsnprintf(out + n, cap - (size_t)n, fmt, ap);
     va_end(ap);
 }
+/* Who wrote a file: every control file ends with its writer's stamp {pid, start time of that process (field 22 of
+ * /proc/<pid>/stat)}.  A directory that still holds the files of an EARLIER run (INTEGRATION.md used a fixed /dev/shm path)
+ * satisfies nobody: a hello file counts only while the process it names is alive with that start time, every other file only
+ * when it carries the stamp its expected writer's hello gave (stale replica_N.ipc / ready_* / leader_* files made a
+ * restarted server import dead IPC handles and follow a leader of the run before). */
+static int proc_look(pid_t pid, char *state, uint64_t *start)
+{
+    char pth[64], buf[1024];
+    snprintf(pth, sizeof pth, "/proc/%d/stat", (int)pid);
+    FILE *f = fopen(pth, "r");
+    if (!f) return -1;
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    char *p = strrchr(buf, ')');                         /* (the command name may hold anything, blanks and brackets included) */
+    if (!p || !p[1] || !p[2]) return -1;
+    *state = p[2];
+    p += 2;                                              /* field 3 (state) */
+    for (int field = 3; field < 22 && p; field++) { p = strchr(p, ' '); if (p) p++; }
+    if (!p) return -1;
+    *start = strtoull(p, NULL, 10);
+    return 0;
+}
+static g_stamp_t g_my_stamp(void)
+{
+    g_stamp_t st = { (int64_t)getpid(), 0 };
+    char c;
+    proc_look(getpid(), &c, &st.start);
+    return st;
+}
+/* a process that exists, is not a zombie (kill(pid, 0) still succeeds on an unreaped one: a launcher that never wait()s would
+ * hide a dead leader for ever) and is the SAME process the stamp was taken from */
+static int g_stamp_alive(const g_stamp_t *st)
+{
+    char state = 0; uint64_t start = 0;
+    if (st->pid <= 0 || proc_look((pid_t)st->pid, &state, &start)) return 0;
+    return state != 'Z' && state != 'X' && start == st->start;
+}
 static int g_write(smr_t *s, const void *buf, size_t len, const char *name)
 {
     char tmp[480], dst[400];
@@ -356,34 +395,46 @@ static int g_write(smr_t *s, const void *buf, size_t len, const char *name)
     snprintf(tmp, sizeof tmp, "%s.tmp.%d", dst, (int)getpid());
     FILE *f = fopen(tmp, "wb");
     if (!f) return -1;
-    const int ok = fwrite(buf, 1, len, f) == len;
+    const g_stamp_t me = g_my_stamp();
+    const int ok = fwrite(buf, 1, len, f) == len && fwrite(&me, 1, sizeof me, f) == sizeof me;
     fclose(f);
     if (!ok || rename(tmp, dst)) { unlink(tmp); return -1; }
     return 0;
 }
-static int g_read(smr_t *s, void *buf, size_t len, const char *name)
+/* the file's `len` bytes and the stamp behind them */
+static int g_read(smr_t *s, void *buf, size_t len, const char *name, g_stamp_t *who)
 {
     char src[400];
     g_path(s, src, sizeof src, "%s", name);
     FILE *f = fopen(src, "rb");
     if (!f) return -1;
-    const int ok = fread(buf, 1, len, f) == len;
+    g_stamp_t st;
+    const int ok = fread(buf, 1, len, f) == len && fread(&st, 1, sizeof st, f) == sizeof st;
     fclose(f);
+    if (ok && who) *who = st;
     return ok ? 0 : -1;
 }
-static int g_exists(smr_t *s, const char *name) { char pth[400]; struct stat st; g_path(s, pth, sizeof pth, "%s", name); return stat(pth, &st) == 0; }
-static int g_wait(smr_t *s, const char *name, double seconds)
+/* waits for `name` AS WRITTEN BY server `writer` of this run (its stamp from the hello exchange; writer == group_size: any
+ * live process -- the hello files themselves) */
+static int g_wait_from(smr_t *s, const char *name, uint32_t writer, size_t len, void *out, double seconds)
 {
     const double t0 = now_s();
-    while (!g_exists(s, name)) {
+    uint8_t tmp[sizeof(apus_ipc_replica_t) + 64];        /* (the largest file: a hello) */
+    if (len > sizeof tmp) return -1;
+    for (;;) {
+        g_stamp_t st;
+        if (!g_read(s, tmp, len, name, &st)) {
+            const int good = writer < s->group_size ? (st.pid == s->peer_stamp[writer].pid && st.start == s->peer_stamp[writer].start)
+                                                    : g_stamp_alive(&st);
+            if (good) { if (out) memcpy(out, tmp, len); return 0; }
+        }
         if (s->terminate || now_s() - t0 > seconds) return -1;
         struct timespec ts = {0, 2000000}; nanosleep(&ts, NULL);
     }
-    return 0;
 }
-static int g_alive(smr_t *s, uint32_t i) { return s->peer_pid[i] > 0 && (kill(s->peer_pid[i], 0) == 0 || errno == EPERM); }
+static int g_alive(smr_t *s, uint32_t i) { return g_stamp_alive(&s->peer_stamp[i]); }
 
-typedef struct { apus_ipc_replica_t ipc; int32_t pid; int32_t pad; } g_hello_t;
+typedef struct { apus_ipc_replica_t ipc; } g_hello_t;
 
 /* RC_SYN / SYNACK once: export the replica this process hosts, map everybody else's */
 static int group_connect(smr_t *s)
@@ -391,19 +442,18 @@ static int group_connect(smr_t *s)
     g_hello_t me;
     memset(&me, 0, sizeof me);
     if (apus_gpu_export_replica(s->eng, s->idx, &me.ipc)) return -1;
-    me.pid = (int32_t)getpid();
     char name[64];
     snprintf(name, sizeof name, "replica_%u.ipc", s->idx);
     if (g_write(s, &me, sizeof me, name)) return -1;
-    s->peer_pid[s->idx] = getpid();
+    s->peer_stamp[s->idx] = g_my_stamp();
     for (uint32_t i = 0; i < s->group_size; i++) {
         if (i == s->idx) continue;
         snprintf(name, sizeof name, "replica_%u.ipc", i);
-        if (g_wait(s, name, 120.0)) { fprintf(stderr, "[apus] server %u: server %u never showed up in %s\n", s->idx, i, s->group_dir); return -1; }
         g_hello_t h;
-        if (g_read(s, &h, sizeof h, name) || h.ipc.replica != i) return -1;
+        /* (the hello of a LIVE process: a file an earlier run left behind names a process that is gone, or another one) */
+        if (g_wait_from(s, name, s->group_size, sizeof h, &h, 120.0)) { fprintf(stderr, "[apus] server %u: server %u never showed up in %s\n", s->idx, i, s->group_dir); return -1; }
+        if (g_read(s, &h, sizeof h, name, &s->peer_stamp[i]) || h.ipc.replica != i || !g_stamp_alive(&s->peer_stamp[i])) return -1;
         if (apus_gpu_import_replica(s->eng, &h.ipc)) { fprintf(stderr, "[apus] server %u: cannot map server %u's replica\n", s->idx, i); return -1; }
-        s->peer_pid[i] = (pid_t)h.pid;
     }
     s->alive_mask = s->bitmask = (1u << s->group_size) - 1;
     return 0;
@@ -424,7 +474,8 @@ static int group_start_term(smr_t *s)
     for (uint32_t i = 0; i < s->group_size; i++) {
         if (i == s->idx || !((s->alive_mask >> i) & 1u) || !((s->bitmask >> i) & 1u)) continue;
         snprintf(name, sizeof name, "ready_%llu_%u", (unsigned long long)s->term, i);
-        if (g_wait(s, name, 30.0)) fprintf(stderr, "[apus] leader %u: follower %u did not start its workgroups for term %llu\n", s->idx, i, (unsigned long long)s->term);
+        char one;
+        if (g_wait_from(s, name, i, 1, &one, 30.0)) fprintf(stderr, "[apus] leader %u: follower %u did not start its workgroups for term %llu\n", s->idx, i, (unsigned long long)s->term);
     }
     if (apus_gpu_rep_start(s->eng, 24u * 3600u * 1000u, 500, na, nf)) return -1;
     s->dev_hr = apus_gpu_rep_highest_rec_ptr(s->eng);
@@ -441,17 +492,32 @@ static void follower_upcalls(smr_t *s)
     static apus_apply_t recs[512];
     static uint8_t *bytes;
     if (!bytes) bytes = malloc(65536u + 64u);             /* one record's payload at a time */
-    while (s->replayed < pr[0]) {
+    while (s->replayed < pr[0] && !s->failed) {
         uint64_t n = pr[0] - s->replayed;
         if (n > 512) n = 512;
-        if (apus_gpu_apply_records(s->eng, s->idx, s->replayed, n, recs)) return;
-        for (uint64_t i = 0; i < n; i++) {
+        if (apus_gpu_apply_records(s->eng, s->idx, s->replayed, n, recs)) { s->failed = 1; break; }
+        uint64_t done = 0;
+        for (uint64_t i = 0; i < n; i++, done++) {
+            /* the record must be the one of the slot asked for: a replay that fell a lap of the apply ring behind would be fed
+             * another entry's record (the kernel reports min(device apply, host replay) as applied, so the head cannot pass an
+             * entry that is not replayed -- this is the check behind that) -- fail-stop, never a wrong upcall */
+            if (recs[i].slot != s->replayed + i) {
+                fprintf(stderr, "[apus] server %u: apply record of slot %llu reads as slot %llu: the replay fell behind its ring -- stopping\n",
+                        s->idx, (unsigned long long)(s->replayed + i), (unsigned long long)recs[i].slot);
+                s->failed = 1;
+                break;
+            }
             if (recs[i].kind == 2 && s->in.do_action) {
-                if (recs[i].len) apus_gpu_read_ring(s->eng, s->idx, recs[i].off + 50, recs[i].len, bytes);
+                if (recs[i].len && apus_gpu_read_ring(s->eng, s->idx, recs[i].off + 50, recs[i].len, bytes)) {
+                    fprintf(stderr, "[apus] server %u: cannot read the payload of slot %llu -- stopping\n", s->idx, (unsigned long long)recs[i].slot);
+                    s->failed = 1;
+                    break;
+                }
                 s->in.do_action(recs[i].clt_id, recs[i].type, recs[i].len, bytes, s->in.up_para);
             }
         }
-        s->replayed += n;
+        s->replayed += done;
+        apus_gpu_rep_follower_replayed(s->eng, s->idx, s->replayed);     /* what "applied" means on this server: carried out by its application */
     }
 }
 
@@ -476,7 +542,8 @@ static int group_failover(smr_t *s)
         for (uint32_t i = 0; i < s->group_size; i++) {
             if (i == s->idx || !((s->alive_mask >> i) & 1u)) continue;
             snprintf(name, sizeof name, "parked_%llu_%u", (unsigned long long)term, i);
-            if (g_wait(s, name, 20.0)) s->alive_mask &= ~(1u << i);           /* it does not answer: cut off */
+            char one;
+            if (g_wait_from(s, name, i, 1, &one, 20.0)) s->alive_mask &= ~(1u << i);           /* it does not answer: cut off */
         }
         uint64_t out[8] = {0};
         const uint32_t live = s->alive_mask & s->bitmask;
@@ -495,9 +562,8 @@ static int group_failover(smr_t *s)
         fflush(s->log);
     } else {
         snprintf(name, sizeof name, "leader_%llu", (unsigned long long)term);
-        if (g_wait(s, name, 60.0)) return -1;
         uint32_t cfg[2];
-        if (g_read(s, cfg, sizeof cfg, name)) return -1;
+        if (g_wait_from(s, name, winner, sizeof cfg, cfg, 60.0)) return -1;     /* (written by the server the same rule makes the winner HERE) */
         s->term = term; s->leader = cfg[0]; s->bitmask = cfg[1];
         apus_gpu_set_reachable(s->eng, s->alive_mask & s->bitmask);
         if (!((s->bitmask >> s->idx) & 1u)) return -1;                   /* this server was removed */
@@ -599,7 +665,7 @@ void *dare_server_init(void *arg)
             if (apus_gpu_become_leader(s->eng, 0, s->term, s->bitmask) || apus_gpu_sync(s->eng)) { fprintf(stderr, "[apus] election failed\n"); s->ready = -1; return NULL; }
             uint32_t cfg2[2] = { 0, s->bitmask };
             g_write(s, cfg2, sizeof cfg2, "leader_2");
-        } else if (g_wait(s, "leader_2", 120.0)) { s->ready = -1; return NULL; }
+        } else { uint32_t cfg2[2]; if (g_wait_from(s, "leader_2", 0, sizeof cfg2, cfg2, 120.0)) { s->ready = -1; return NULL; } }
         if (group_start_term(s)) { fprintf(stderr, "[apus] server %u: cannot start the replica kernels\n", s->idx); s->ready = -1; return NULL; }
         if (s->idx == 0) { fprintf(s->log, "[T%lu] LEADER\n", (unsigned long)s->term); fflush(s->log); }
         (void)name;

@@ -155,13 +155,20 @@ class PeerMember:
                 cfg = torch.tensor([e.bitmask, e.group_size, e.epoch, e.machines, 1], dtype=torch.int64)
             except EngineError as exc:      # (the other ranks wait in the broadcast: they must hear about it)
                 err = exc
-                cfg = torch.zeros(5, dtype=torch.int64)
+                # a refusal behind the CONFIG entries (APUS_E_NOANSWER): the leader's engine has adopted the configuration the
+                # device holds -- the other ranks adopt it too (flag 2), THEN everybody raises
+                cfg = torch.tensor([e.bitmask, e.group_size, e.epoch, e.machines, 2 if getattr(e, "join_refused_with_config", False) else 0], dtype=torch.int64)
+                e.join_refused_with_config = False
         else:
             cfg = torch.zeros(5, dtype=torch.int64)
         if dist.get_backend() == "nccl":
             cfg = cfg.to(self.device)
         dist.broadcast(cfg, src=self.leader)
         if int(cfg.cpu()[4]) != 1:
+            if int(cfg.cpu()[4]) == 2 and not self.is_leader:
+                bitmask, size, epoch, machines = (int(v) for v in cfg.cpu().tolist()[:4])
+                e._chk(e.L.apus_gpu_set_config(e.h, size, epoch), "set_config")
+                e.bitmask, e.group_size, e.epoch, e.machines = bitmask, size, epoch, machines
             raise err if err is not None else EngineError(f"rank {self.rank}: the leader could not carry out JOIN({r})")
         if not self.is_leader:
             bitmask, size, epoch, machines = (int(v) for v in cfg.cpu().tolist()[:4])

@@ -230,7 +230,8 @@ int  apus_gpu_set_config(apus_engine_t *e, uint32_t group_size, uint64_t epoch);
  * ignores every CONFIG entry whose idx is not above the idx of the one that admitted it (all of them once the index
  * sequence has restarted at an exact-fit wrap); what each member holds is derived from the engine's journal of CONFIG
  * entries and votes (apus_amd/csrc/apus_members.h).  In the second case the CONFIG entries of the attempt are in the
- * log, as they are in the reference's.  What the caller still decides (apus_amd/engine.py:Engine.join): no follower
+ * log, as they are in the reference's, AND THE CONFIGURATION ON THE DEVICE HAS MOVED ON: out[0..2] carry it (out[1] != 0) and
+ * the caller must adopt it for its later calls (elect, set_reachable, ...) although the call returned the refusal.  What the caller still decides (apus_amd/engine.py:Engine.join): no follower
  * is asked for its state machine twice without a committed <HEAD> entry in between (the reference answers from an
  * uninitialised pointer there, dare_server.c:604-651). */
 int  apus_gpu_join(apus_engine_t *e, uint32_t r, uint16_t lid, uint32_t bitmask, uint32_t reachable, uint64_t out[4]);
@@ -358,6 +359,9 @@ int  apus_gpu_rep_feed(apus_engine_t *e, const apus_req_t *reqs, uint32_t n, con
  * application (proxy.c:341-439); and, when the leader is gone and nobody will ring the park doorbell: leave */
 int  apus_gpu_rep_follower_progress(apus_engine_t *e, uint32_t replica, uint64_t out[4]);
 int  apus_gpu_rep_follower_stop(apus_engine_t *e, uint32_t replica);
+/* a host consumer replays the follower's apply stream: `slots` entry slots carried out so far.  From the first call on the
+ * follower tells the leader min(device apply, host replay) as applied: pruning cannot outrun the application */
+int  apus_gpu_rep_follower_replayed(apus_engine_t *e, uint32_t replica, uint64_t slots);
 int  apus_gpu_rep_req_ring_kind(apus_engine_t *e);                            /* 1: the request ring is device memory behind the BAR, 0: pinned host memory, -1: no run yet */
 int  apus_gpu_rep_launch_ms(apus_engine_t *e, double *ms);                    /* duration of the last (parked) run's resident launch, HIP events on its stream */
 int  apus_gpu_rep_role_stats(apus_engine_t *e, uint64_t out[20][8]);          /* diagnostics: passes / rounds / time of the serial roles of the last run */

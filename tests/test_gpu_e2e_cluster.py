@@ -80,7 +80,8 @@ def test_three_redis_processes_replicate_and_fail_over():
                                           cwd=d, env=env, stdout=open(os.path.join(d, "redis.out"), "w"), stderr=subprocess.STDOUT))
         for i in range(n):
             assert _wait_port(ports[i], procs[i], timeout=150), f"redis-server {i} did not come up\n" + open(os.path.join(tmp, f"r{i}", "redis.out")).read()[-3000:]
-        assert _wait_log(logs[0], "[T2] LEADER", 60), "server 0 did not announce itself as the leader"
+        assert _wait_log(logs[0], "[T2] LEADER", 60), "server 0 did not announce itself as the leader\n" + \
+            "\n".join(f"--- server {i}:\n" + open(os.path.join(tmp, f"r{i}", "redis.out"), errors="replace").read()[-1500:] for i in range(n))
 
         def bench(port, n_req):
             b = subprocess.run([os.path.join(REF, "redis-benchmark"), "-p", str(port), "-t", "set", "-d", "16", "-r", "5000", "-n", str(n_req), "-c", "4", "-q"],

@@ -10,12 +10,12 @@ mkdir -p gpurun_out
 for c in ${CONFIGS:-c2}; do
   d=$PWD/gpurun_out/prof_$c
   rm -rf $d; mkdir -p $d
-  ARGS="--config $c --steps 5 --warmup 2 --no-cpu --no-latency --no-ack-path --no-replica"
+  ARGS="--config $c --steps 5 --warmup 2 --no-cpu --no-latency --no-ack-path --no-replica --no-other --no-configs0"
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $d/kt -o kt -- python $OLDPWD/bench.py $ARGS > $d/kt_run.log 2>&1)
   f=$(find $d/kt -name "*.db" | head -1)
   { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS"; python tools/kstats.py $f; echo; python tools/kgrid.py $f k_step; } > $d/${R}_${c}_kernel_stats.txt
   tail -1 $d/kt_run.log > $d/${R}_${c}_bench_line_under_rocprof.json
-  PARGS="--config $c --steps 2 --warmup 1 --no-cpu --eager --no-latency --no-ack-path --no-replica"
+  PARGS="--config $c --steps 2 --warmup 1 --no-cpu --eager --no-latency --no-ack-path --no-replica --no-other --no-configs0"
   for ctr in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d $d/pmc_$ctr -o pmc -- python $OLDPWD/bench.py $PARGS > $d/pmc_$ctr.log 2>&1)
     echo "pmc $c $ctr exit: $?"
@@ -29,7 +29,7 @@ done
 if [ -n "$REPLICA" ]; then
   d=$PWD/gpurun_out/prof_rep
   rm -rf $d; mkdir -p $d
-  RARGS="--grid ${REP_GRID:-192:96} --steps 3 --no-hostfed --brief"
+  RARGS="--grid ${REP_GRID:-192:128} --steps 3 --no-hostfed --brief"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $d/kt -o kt -- python $OLDPWD/tools/rep_bench.py $RARGS > $d/kt_run.log 2>&1)
   f=$(find $d/kt -name "*.db" | head -1)
   { echo "# rocprofv3 --kernel-trace --stats -- python tools/rep_bench.py $RARGS"; python tools/kstats.py $f; echo; tail -1 $d/kt_run.log | cut -c1-600; } > $d/${R}_replica_kernel_stats.txt
