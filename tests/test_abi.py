@@ -126,3 +126,18 @@ def test_pmc_traffic_file_belongs_to_this_build():
     assert doc.get("kernel_source_sha256") == bench.kernel_source_hash(), \
         "apus_device.h / apus_kernels.h changed after the PMC passes: re-run tools/gpu_profile.sh and commit profiles/r03_pmc_traffic.json"
     assert doc["configs"]["c2"]["kernel"] == "k_step" and 400 < doc["configs"]["c2"]["bytes_per_entry"] < 1088
+
+
+def test_replica_pmc_traffic_file_belongs_to_this_build():
+    """the headline's roofline.traffic (k_replica) is quoted only for the build the PMC passes were taken on:
+    profiles/r04_replica_pmc_traffic.json must carry the hash of apus_device.h + apus_persistent.h + apus_replica.h as they are now"""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    path = os.path.join(ROOT, "profiles", bench.REP_PMC_FILE)
+    assert os.path.exists(path), f"{path} is missing"
+    doc = json.load(open(path))
+    assert doc.get("kernel_source_sha256") == bench.replica_source_hash(), \
+        "the replica kernels' sources changed after the PMC passes: re-run REPLICA=1 tools/gpu_profile.sh and commit profiles/r04_replica_pmc_traffic.json"
+    assert doc["kernel"] == "k_replica" and doc["replicas"] == 3 and 384 < doc["bytes_per_entry"] < 1088
