@@ -161,6 +161,8 @@ enum { TK_E0 = 0, TK_IDX0, TK_SLOT0, TK_SRC, TK_END, TK_D0, TK_D1, TK_META };
  * (E.round_prefix / E.round_first: read-only during a run).  Everything else -- pinned rounds, control entries, the round at
  * a wrap, short passes -- keeps its eight words. */
 #define TK_BULK   (1ull << 13)          /* TK_META: [11:0] pass number (low bits)  [13] 1  [47:16] staged round; TK_SRC: [31:0] first request  [38:32] n */
+#define TK_BULK_PIN (1ull << 14)        /* ... a pass of FULL, equally long rounds from the request ring: [47:16] = the round's number within the pass,
+                                         * PR_BPF = the entries' size, PR_BRF_N = the pass's first request slot (low half) | rounds << 32 */
 #define PR_CAP    512u                  /* pass records (a bulk pass has >= 64 tickets, RS_CAP tickets are in flight at most) */
 enum { PR_T0 = 0, PR_RC0, PR_END0, PR_IDX0, PR_SLOT0, PR_BPF, PR_BRF_N, PR_PUSH_STAMP };   /* words {low 16 bits of pass + 1 : 48-bit value} */
 #define TK_VAL 0x0000FFFFFFFFFFFFull
@@ -978,6 +980,52 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
          *      the whole tailq, dare_ibv_ud.c:780-790) ---- */
         const uint64_t limit = have_cmd ? cmd_after : ~0ull;
         bool any = false;
+        /* ---- several FULL windows of equally long requests (producers that keep the ring filled): one pass record for all of
+         *      them, two words per round -- the rounds are the same rounds of 64 the loop below would make one by one, at ~1 us
+         *      of the sequencer each (round 3 / 4: the host-fed ceiling, 46 M entries/s whatever the number of producers) ---- */
+        if (!(A.dbg & 32) && budget >= 2) {
+            uint32_t Wn = 0;
+            const uint32_t len0 = rl32u(v[0] & 0xFFFFu, 0);
+#pragma unroll
+            for (int wdw = 0; wdw < R_WIN; wdw++) {
+                if (Wn != (uint32_t)wdw) break;
+                const uint64_t slot = req_head + (uint64_t)wdw * WAVE + lane;
+                const bool ok = slot < limit && (v[wdw] >> 16) == rep_slot_tag(slot) && (v[wdw] & 0xFFFFu) == len0;
+                if (__ballot(ok) == ~0ull) Wn++;
+            }
+            if ((uint64_t)Wn > budget) Wn = (uint32_t)budget;
+            const uint64_t T = APUS_HDR + (uint64_t)len0, tot = (uint64_t)Wn * WAVE * T;
+            const uint64_t used = S.end >= S.head_safe ? S.end - S.head_safe : L - (S.head_safe - S.end);
+            if (Wn >= 2 && S.end != L && S.end + tot < L && S.end != S.head_safe && tot + APUS_HDR <= L - used) {
+                const uint64_t pn = S.pass_seq++;
+                const uint64_t stamp = wall_clock64() & 0xFFFFFFFFull;
+                uint64_t pv = 0;
+                switch (lane) {
+                case PR_T0: pv = S.t; break;
+                case PR_RC0: pv = 0; break;
+                case PR_END0: pv = S.end; break;
+                case PR_IDX0: pv = S.last_idx + 1; break;
+                case PR_SLOT0: pv = S.n_end; break;
+                case PR_BPF: pv = T; break;
+                case PR_BRF_N: pv = (req_head & 0xFFFFFFFFull) | ((uint64_t)Wn << 32); break;
+                case PR_PUSH_STAMP: pv = stamp | ((uint64_t)S.push_mask << 32); break;
+                default: break;
+                }
+                if (lane < 8) st_agent(&LS->prec[pn % PR_CAP][lane], rep_tk(pn, pv));
+                if (lane < Wn) {
+                    const uint64_t tk = S.t + lane;
+                    st_agent(&LS->tkw[TK_SRC][tk % RS_CAP], rep_tk(tk, ((req_head + (uint64_t)lane * WAVE) & 0xFFFFFFFFull) | ((uint64_t)WAVE << 32)));
+                    st_agent(&LS->tkw[TK_META][tk % RS_CAP], rep_tk(tk, TK_BULK | TK_BULK_PIN | (pn & 0xFFFull) | ((uint64_t)lane << 16)));
+                }
+                const uint64_t ne = (uint64_t)Wn * WAVE;
+                S.end += tot; S.tail = S.end - T; S.tail_known = true; S.last_idx += ne; S.n_end += ne; S.store_count += ne; S.prev_head = 0;
+                if (S.can_commit) { S.c_off = S.end; S.c_slot = S.n_end; }
+                S.t += Wn; req_head += ne; budget -= Wn;
+                rep_seq_publish(LS, s_m, S, cmd_head + req_head);
+                idle = 0;
+                continue;
+            }
+        }
 #pragma unroll
         for (int wdw = 0; wdw < R_WIN; wdw++) {
             if (budget == 0) break;
@@ -1438,12 +1486,15 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
              * round's four prefix values are asked for together) */
             const uint64_t mv = rdl64(wv, TK_META);
             const uint64_t r = mv >> 16, p12 = mv & 0xFFFull;
+            const bool bpin = (mv & TK_BULK_PIN) != 0;          /* a pass of full rounds from the request ring: r = the round's number within it */
             const uint64_t sv = rdl64(wv, TK_SRC);
             const uint64_t bfirst = sv & 0xFFFFFFFFull;
             const uint32_t bn = (uint32_t)(sv >> 32) & 0x7F;
             uint64_t pfv = 0;
-            if (lane == 8) pfv = E.round_prefix[r]; else if (lane == 9) pfv = E.round_prefix[r + 1];
-            if (lane < bn) dbulk = E.req[bfirst + lane];          /* (the round's descriptors: the same round trip) */
+            if (!bpin) {
+                if (lane == 8) pfv = E.round_prefix[r]; else if (lane == 9) pfv = E.round_prefix[r + 1];
+                if (lane < bn) dbulk = E.req[bfirst + lane];      /* (the round's descriptors: the same round trip) */
+            }
             uint64_t pw = 0;
             for (uint64_t i = 0;; i++) {
                 if (lane < 8) pw = ld_agent(&LS->prec[p12 % PR_CAP][lane]);
@@ -1461,10 +1512,18 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             const uint64_t bpf = rdl64(pw, PR_BPF), brfn = rdl64(pw, PR_BRF_N), ps = rdl64(pw, PR_PUSH_STAMP);
             const uint64_t pf0 = rdl64(pfv, 8), pf1 = rdl64(pfv, 9), rf0 = bfirst, rf1 = bfirst + bn;
             const uint64_t brf = brfn & 0xFFFFFFFFull;
+            if (bpin) {
+                /* equally long entries, full rounds: everything is arithmetic on the round's number (bpf = the entries' size) */
+                e0 = end0 + r * WAVE * bpf; idx0 = pidx0 + r * WAVE; slot0 = pslot0 + r * WAVE; first = bfirst;
+                end_after = e0 + (uint64_t)WAVE * bpf; d0 = 0; d1 = ps & 0xFFFFFFFFull;
+                meta = (uint64_t)WAVE | ((uint64_t)R_SRC_PINNED << 8) | ((ps >> 32) << 32);
+                if (lane == 0 && (k - t0 != r || bfirst != ((brf + r * WAVE) & 0xFFFFFFFFull)) && !(atomicOr(E.status, 1u << 3) & (1u << 3))) { E.status[3] = (uint32_t)k; E.status[4] = (uint32_t)r; E.status[5] = (uint32_t)(k - t0); E.status[6] = 0xB01Du; }
+            } else {
             e0 = end0 + (pf0 - bpf); idx0 = pidx0 + (rf0 - brf); slot0 = pslot0 + (rf0 - brf); first = rf0;
             end_after = end0 + (pf1 - bpf); d0 = 0; d1 = ps & 0xFFFFFFFFull;
             meta = (rf1 - rf0) | ((uint64_t)R_SRC_STAGED << 8) | ((ps >> 32) << 32);
             if (lane == 0 && rc0 + (k - t0) != r && !(atomicOr(E.status, 1u << 3) & (1u << 3))) { E.status[3] = (uint32_t)k; E.status[4] = (uint32_t)r; E.status[5] = (uint32_t)(rc0 + (k - t0)); E.status[6] = 0xB01Cu; }
+            }
         } else {
             e0 = rdl64(wv, TK_E0); idx0 = rdl64(wv, TK_IDX0); slot0 = rdl64(wv, TK_SLOT0); first = rdl64(wv, TK_SRC);
             end_after = rdl64(wv, TK_END); d0 = rdl64(wv, TK_D0); d1 = rdl64(wv, TK_D1); meta = rdl64(wv, TK_META);
