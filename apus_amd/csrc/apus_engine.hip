@@ -2413,12 +2413,19 @@ static int rep_push_cmd(apus_engine *e, uint32_t op, uint64_t a, uint64_t b)
  * are consumed in order, so a producer only ever waits for producers in front of it).  What the slot remembers of the
  * payload arena is its tail as read BEFORE the fetch-and-add: an arena allocation takes its slot number first and its
  * bytes second (below), so no allocation of a LATER slot is included and the arena is never freed too early. */
+/* Request slots that may be reserved and not yet consumed.  Smaller than the ring on purpose: a pass of full rounds from
+ * the request ring is ONE pass record for 2..8 rounds (pinned bulk passes, apus_replica.h), and the ring of pass records
+ * (PR_CAP = 512) is sized for passes of >= 64 tickets -- with at most 16384 slots whose bytes have not been read there are at
+ * most 256 such rounds, hence at most 128 such passes, not yet appended: a record is never overwritten under an append
+ * wavefront that still needs it, however far the followers fall behind.  (120 us of requests at the host-fed rate.) */
+#define R_SLOTS_INFLIGHT 16384u
+static_assert(R_SLOTS_INFLIGHT <= RQ_CAP && R_SLOTS_INFLIGHT / WAVE / 2 + RS_CAP / WAVE < PR_CAP, "pass records: pinned bulk passes + staged bulk passes in flight");
 static inline int rep_reserve_inline(apus_engine *e, uint32_t n, uint64_t *first)
 {
     const uint64_t atail = __atomic_load_n(&e->r_arena_tail, __ATOMIC_ACQUIRE);
     const uint64_t s0 = __atomic_fetch_add(&e->r_slot_tail, (uint64_t)n, __ATOMIC_ACQ_REL);
     const double t0 = mono_s();
-    while (s0 + n - e->rh->slots_done > RQ_CAP) {
+    while (s0 + n - e->rh->slots_done > R_SLOTS_INFLIGHT) {
         if (e->rh->alive == 2) return APUS_E_STATE;
         if (mono_s() - t0 > 5.0) return -1;
     }
@@ -2441,7 +2448,7 @@ static inline int rep_reserve_arena(apus_engine *e, uint32_t len, uint64_t *slot
         if (phys + need + 16 > RA_CAP) { pos += RA_CAP - phys; phys = 0; }      /* the payload does not straddle the end */
         if (phys == 0) { pos += 16; phys = 16; }                                 /* bytes -2, -1 of a payload must exist */
         const uint64_t freed = done ? e->r_slot_aend[(done - 1) % RQ_CAP] : 0;
-        if (s0 + 1 - done <= RQ_CAP && pos + need - freed <= RA_CAP) {
+        if (s0 + 1 - done <= R_SLOTS_INFLIGHT && pos + need - freed <= RA_CAP) {
             __atomic_store_n(&e->r_arena_tail, pos + need, __ATOMIC_RELEASE);
             e->r_slot_aend[s0 % RQ_CAP] = pos + need;
             *slot = s0;
