@@ -316,9 +316,13 @@ int  apus_gpu_device_arch(int device, char *out, int cap);
  * many rounds in flight) and push ONLY the log bytes + one 32-byte doorbell per round to every follower;
  * each follower's workgroups -- on the follower's own device, in its own process when the replica is
  * peer-mapped -- poll their doorbells, build directory and apply records locally from the landed bytes,
- * persist, write the reply byte into the sender's log (R3) and their ACK byte into the sender's map, and
- * apply on the commit doorbell; the leader commits by majority over the per-replica ACK maps (popcount +
- * wave ballot), so a dead follower costs its ACK, not the round.
+ * persist, acknowledge (R3) and apply on the commit doorbell.  R3 since round 4: the reply bytes ride with the entries
+ * (the leader's header stores carry reply[f] for follower f's copy and for its own; a follower that declines an entry
+ * clears them), and what the leader commits on is each follower's CUMULATIVE, in-order count of the entry slots it
+ * holds and has persisted -- an entry is acknowledged by f only when f holds everything in front of it; committed =
+ * below the (quorum - 1)-th largest count (dare_ibv_rc.c:1738-1741), so a dead follower costs its ACK, not the round.
+ * apus_gpu_rep_reserve hands out `payload_dst` in the request ring, which is DEVICE memory where the host can store into
+ * it (large BAR; apus_gpu_rep_req_ring_kind) -- write-only for the caller: copy the payload there, never read it back.
  *
  * apus_gpu_rep_start launches the workgroups of every replica HOSTED by this engine (the leader's when it
  * is hosted here, and those of every hosted follower); in a peer-mapped group every process calls it.  While
