@@ -112,6 +112,9 @@ SIGNATURES = {
     "apus_gpu_rep_launch_ms": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "apus_gpu_rep_req_ring_kind": (C.c_int, [vp]),
     "apus_gpu_rep_roundtrip": (C.c_int, [vp, vp, u32, vp, u64, u32, vp]),
+    "apus_gpu_unmap_replica": (C.c_int, [vp, u32]),
+    "apus_gpu_last_entry": (C.c_int, [vp, u32, C.POINTER(u64)]),
+    "apus_gpu_rep_box_words": (C.c_int, [vp, u32, u32, C.POINTER(u64)]),
 }
 
 

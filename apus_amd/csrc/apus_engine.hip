@@ -434,6 +434,62 @@ extern "C" int apus_gpu_unmap_peers(apus_engine_t *e)
     return 0;
 }
 
+/* One peer's mapping alone: a server whose PROCESS is gone and whose slot a new machine takes over (JOIN into an empty
+ * place, dare_ibv_ud.c:995-1021) -- the members drop the mapping of the dead process's memory before they map the
+ * newcomer's.  The mappings are closed in the order they were opened (APUS_IPC_BUFFERS per replica). */
+extern "C" int apus_gpu_unmap_replica(apus_engine_t *e, uint32_t replica)
+{
+    if (!e || replica >= e->cfg.group_size) return APUS_E_ARG;
+    if (!((e->imported_mask >> replica) & 1u)) return APUS_E_STATE;
+    if (e->r_running || e->p_running || e->batching) return APUS_E_STATE;
+    if (e->d.leader == replica) return APUS_E_STATE;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const RepDev &r = e->d.rep[replica];
+    void *mine[APUS_IPC_BUFFERS] = { r.ring, r.hdr, r.dir_off, r.dir_len, r.ack, r.apply, e->d.box[replica], e->d.ackb[replica] };
+    for (void *m : mine)
+        for (size_t k = 0; k < e->ipc_ptrs.size(); k++)
+            if (e->ipc_ptrs[k] == m) { hipIpcCloseMemHandle(m); e->ipc_ptrs.erase(e->ipc_ptrs.begin() + (long)k); break; }
+    e->d.rep[replica] = RepDev{};
+    e->d.box[replica] = nullptr; e->d.ackb[replica] = nullptr;
+    e->local_mask &= ~(1u << replica);
+    e->imported_mask &= ~(1u << replica);
+    e->reachable &= ~(1u << replica); e->d.reachable = e->reachable;
+    return 0;
+}
+
+/* The last entry of a replica's log -- what a vote is decided on (poll_vote_requests, dare_server.c:1661-1673: the
+ * candidate's last (term, idx) must be at least as good as the voter's): out[0] = term, out[1] = idx (both 0: the log reads
+ * as empty), out[2] = entry slots it holds, out[3] = its end offset.  Synchronises; between runs of the replica kernels. */
+extern "C" int apus_gpu_last_entry(apus_engine_t *e, uint32_t replica, uint64_t out[4])
+{
+    if (!e || !out || replica >= e->cfg.group_size || !e->d.rep[replica].ring) return APUS_E_ARG;
+    if (e->batching) return APUS_E_STATE;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    uint64_t h[16];
+    HIPCHK(hipMemcpy(h, e->d.rep[replica].hdr, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = out[1] = 0; out[2] = h[H_N_END]; out[3] = h[H_END];
+    if (h[H_END] != e->d.log_len && h[H_N_END] > 0) {
+        uint64_t off = 0, w[2] = {0, 0};
+        HIPCHK(hipMemcpy(&off, &e->d.rep[replica].dir_off[(uint32_t)(h[H_N_END] - 1) & e->d.dir_mask], sizeof off, hipMemcpyDeviceToHost));
+        if (off + 16 <= e->d.log_len) HIPCHK(hipMemcpy(w, e->d.rep[replica].ring + off, sizeof w, hipMemcpyDeviceToHost));
+        out[1] = w[0]; out[0] = w[1];
+    }
+    return 0;
+}
+
+/* diagnostics / tests: words of a replica's mailbox between runs -- out[0] the commit doorbell (R4: entry slots the
+ * leader told it are committed, as rung: NOT clipped to what it holds), [1] ctrl, [2] f_seq_next, [3] f_runs, [4] f_exit,
+ * [5] persisted_by[who], [6] applied_by[who], [7] seqdone_by[who] (what follower `who` told this replica while it led) */
+extern "C" int apus_gpu_rep_box_words(apus_engine_t *e, uint32_t replica, uint32_t who, uint64_t out[8])
+{
+    if (!e || !out || replica >= e->cfg.group_size || who >= 16 || !e->d.box[replica]) return APUS_E_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    RepBox *b = e->d.box[replica];
+    uint64_t *src[8] = { &b->commit_bell, &b->ctrl, &b->f_seq_next, &b->f_runs, &b->f_exit, &b->persisted_by[who], &b->applied_by[who], &b->seqdone_by[who] };
+    for (int k = 0; k < 8; k++) HIPCHK(hipMemcpy(&out[k], src[k], sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int apus_gpu_import_replica(apus_engine_t *e, const apus_ipc_replica_t *in)
 {
     if (!e || !in || in->replica >= e->cfg.group_size) return APUS_E_ARG;
@@ -1054,13 +1110,15 @@ __global__ void k_set_roles(const EngDev E, uint64_t sid, uint32_t bitmask, uint
     for (uint32_t i = 0; i < E.group_size; i++) lh[H_APPLY_OFFSETS + i] = lh[H_HEAD];  /* dare_server.c:1504-1507 */
     /* A term fence raised against this engine while it led an OLDER term (k_fence_check) ends here only if no server of the
      * configuration that this engine can see holds a NEWER term than the one it has just won -- looked at BEFORE the
-     * followers below are given the new SID (round 3 looked afterwards: always false), and over every configured
-     * server that is mapped here, reachable or not: a follower that is ahead and cut off keeps the fence up and the
-     * sticky APUS_ST_TERM_FENCE bit set.  (rc_restore_log_access, dare_ibv_rc.c:2245-2290: the voters restore the log
-     * access of the server they vote for.) */
+     * followers below are given the new SID (round 3 looked afterwards: always false), and over the configured
+     * servers this leader can REACH (rc_restore_log_access, dare_ibv_rc.c:2245-2290: the voters restore the log access of
+     * the server they vote for -- a server that died holding a higher term, e.g. after a failed candidacy of its own, takes
+     * no part in that; round 4 scanned the unreachable ones too and such a server kept every launch of a legitimately
+     * elected leader fenced for ever: ADVICE r4).  A follower that is ahead and cut off raises the fence again through
+     * k_fence_check in front of the first launch that pushes to it once it is released. */
     bool ahead = false;
     for (uint32_t i = 0; i < E.group_size; i++)
-        if (i != E.leader && ((bitmask >> i) & 1u) && E.rep[i].ring && (E.rep[i].hdr[H_SID] >> 9) > (sid >> 9)) ahead = true;
+        if (i != E.leader && ((bitmask >> i) & 1u) && ((follow_mask >> i) & 1u) && E.rep[i].ring && (E.rep[i].hdr[H_SID] >> 9) > (sid >> 9)) ahead = true;
     for (uint32_t i = 0; i < E.group_size; i++) {
         if (i == E.leader || !((follow_mask >> i) & 1u) || !E.rep[i].ring) continue;
         uint64_t *fh = E.rep[i].hdr;
@@ -2262,7 +2320,7 @@ static int rep_in_step(apus_engine *e, uint32_t cand, uint32_t *out_mask, uint64
             const uint64_t cap = (uint64_t)e->d.dir_mask + 1;
             const uint64_t s0 = lh[H_N_END] - n_end > cap ? lh[H_N_END] - cap : n_end;
             hipLaunchKernelGGL(k_rep_clear_reply, dim3((unsigned)std::min<uint64_t>(256, (lh[H_N_END] - s0 + 255) / 256)), dim3(256), 0, e->stream,
-                               e->d, e->d.leader, f, s0, lh[H_N_END]);
+                               e->d, e->d.leader, f, s0, lh[H_N_END], lh[H_HEAD], lh[H_END], lh[H_LAST_IDX]);
             HIPCHK(hipGetLastError());
         }
     }
@@ -2494,8 +2552,12 @@ extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uin
 {
     if (!e || !reqs) return APUS_E_ARG;
     if (!e->r_running || !e->r_lead) return APUS_E_STATE;
-    for (uint32_t g = 0; g < n; g++)
+    /* everything that can be refused is refused HERE, before any slot is reserved: a block of reserved slots that is never
+     * published wedges the sequencer, which takes slots strictly in order */
+    for (uint32_t g = 0; g < n; g++) {
         if (reqs[g].payload_off + reqs[g].len > arena_bytes) return APUS_E_ARG;
+        if (reqs[g].type == APUS_NOOP || reqs[g].type == APUS_CONFIG || reqs[g].type == APUS_HEAD || reqs[g].type > 15) return APUS_E_ARG;
+    }
     constexpr uint32_t BLK = 64;
     uint32_t g = 0;
     while (g < n) {
@@ -2517,7 +2579,6 @@ extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uin
          * the write-combining buffers to drain (~0.35 us; two per slot made a round of 64 cost 50 us) */
         for (uint32_t i = 0; i < run; i++) {
             const apus_req_t &q = reqs[g + i];
-            if (q.type == APUS_NOOP || q.type == APUS_CONFIG || q.type == APUS_HEAD || q.type > 15) return APUS_E_ARG;
             RepSlot &sl = e->rq->slot[(s0 + i) % RQ_CAP];
             if (q.len) memcpy((void *)sl.pay, arena + q.payload_off, q.len);
             ReqDev d;

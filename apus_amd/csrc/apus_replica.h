@@ -2047,7 +2047,11 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
     const uint64_t hash0 = mh[H_APPLY_HASH], cnt0 = mh[H_APPLY_COUNT], my_sid = mh[H_SID];
     uint64_t hash = 0, ncl = 0;
     uint64_t q_app = q0;
-    const bool has_consumer = A.FH[me] && ld_sys(&A.FH[me]->consumer) != 0;
+    /* (latched: a host consumer may register while the run is resident -- apus_gpu_rep_follower_replayed promises "before and
+     * during a run" -- so the word is looked at again on every 256th pass (busy or idle: a look at pinned host memory is a PCIe round trip)
+     * until it reads non-zero; round 4
+     * read it once at the start, and a follower's FIRST term published the device's apply count alone: ADVICE r4) */
+    bool has_consumer = A.FH[me] && ld_sys(&A.FH[me]->consumer) != 0;
     uint64_t applied_pub = n_apply;
     if (has_consumer) { const uint64_t hr = ld_sys(&A.FH[me]->replayed); if (hr < applied_pub) applied_pub = hr; }
     if (lane == 0) { st_sys(&lbox->seqdone_by[me], q_app); st_sys(&lbox->applied_by[me], applied_pub); st_sys(&lbox->apply_off_by[me], a_off0); }
@@ -2112,6 +2116,10 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
                 if (A.FH[me] && !(A.dbg & 2048)) st_sys(&A.FH[me]->n_apply, n_apply);
             }
         }
+        if (!has_consumer && A.FH[me] && (st_pass & 255) == 0 && ld_sys(&A.FH[me]->consumer) != 0) {
+            /* from here on the leader hears min(device apply, host replay); what it was told before stands (the head never moves back) */
+            has_consumer = true;
+        }
         /* a host consumer: applied = what the device has applied AND the host has replayed (a look at pinned host memory, only
          * while the two differ from what the leader was last told) */
         if (has_consumer && applied_pub < n_apply) {
@@ -2155,12 +2163,26 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
     }
 }
 
-/* reply[f] = 0 in replica `lead`'s copy of the entry slots [s0, s1): follower f does not hold them (see R_BELL_REPLY) */
-__global__ __launch_bounds__(256) void k_rep_clear_reply(const EngDev E, uint32_t lead, uint32_t f, uint64_t s0, uint64_t s1)
+/* reply[f] = 0 in replica `lead`'s copy of the entry slots [s0, s1): follower f does not hold them (see R_BELL_REPLY).
+ * Only where the slot is still a LIVE entry of the leader's log: the directory is sized for minimum-size entries and is
+ * never invalidated by pruning, so a slot behind the head still resolves to a position -- one the ring may have lapped.
+ * A slot counts as live when its position lies in [head, end) and the entry there carries the idx the slot must have
+ * (idx runs back from the last entry's; a restart of the numbering at an exact fit in between leaves the bytes alone:
+ * they are diagnostic state, the commit never looks at them).  ADVICE r4. */
+__global__ __launch_bounds__(256) void k_rep_clear_reply(const EngDev E, uint32_t lead, uint32_t f, uint64_t s0, uint64_t s1,
+                                                         uint64_t head, uint64_t end, uint64_t last_idx)
 {
     const RepDev &Md = E.rep[lead];
+    const uint64_t L = E.log_len;
+    if (end == L) return;                                  /* the log reads as empty */
+    const uint64_t d_head = apus_end_distance(end, L, head);
     for (uint64_t s = s0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < s1; s += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t pos = Md.dir_off[(uint32_t)s & E.dir_mask];
+        if (pos + APUS_HDR > L) continue;
+        const uint64_t d = apus_end_distance(end, L, pos);
+        if (d == 0 || d > d_head) continue;                /* behind the head (or the end itself) */
+        const uint64_t want = last_idx - (s1 - 1 - s);
+        if (last_idx < s1 - 1 - s || ld8u(Md.ring + pos) != want) continue;
         st_sys8(Md.ring + pos + 28 + f, 0);
     }
 }

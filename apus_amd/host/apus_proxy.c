@@ -152,6 +152,15 @@ typedef struct {
     /* one PROCESS per server (APUS_GROUP_DIR): this process hosts replica `idx` only, the others are peer-mapped */
     int group;                                 /* 1: group mode */
     char group_dir[256];
+    uint32_t capacity;                         /* replicas that can exist (APUS_GROUP_CAPACITY >= group_size: room for machines that JOIN) */
+    uint32_t mapped_mask;                      /* peers whose replica is mapped here */
+    uint64_t seq;                              /* the newest announcement (cfg_<seq>) this server has acted on */
+    uint64_t epoch;                            /* config.cid.epoch */
+    uint32_t machines;                         /* LIDs handed out (a joiner is a new machine) */
+    int pending_transfer;                      /* a joined machine: its application has not been given the recovered log yet (it may not be listening yet) */
+    uint64_t xfer_head, xfer_apply;            /* ... the part of the log that stands for its snapshot: [head, apply) as recovered */
+    volatile int serving;                      /* group mode: this server leads AND its run is resident -- the hooks admit requests (a client that
+                                                * reaches a server between its election and the start of its workgroups is not replicated yet) */
     g_stamp_t peer_stamp[APUS_MAX_SERVERS];    /* every server's process of THIS run */
     uint32_t alive_mask, bitmask;              /* servers whose process answers; cid.bitmask as this process knows it */
     uint64_t replayed;                         /* follower: apply-stream slots handed to do_action so far */
@@ -178,7 +187,7 @@ static int submit_one(uint8_t type, uint16_t connection_id, uint64_t req_id, con
     return apus_tailq_push(type, connection_id, req_id, buf, len);
 }
 
-int is_leader(void) { return g_smr.ready && g_smr.leader == g_smr.idx; }        /* dare_server.c:2299 */
+int is_leader(void) { return g_smr.ready > 0 && g_smr.leader == g_smr.idx && (!g_smr.group || g_smr.serving); }        /* dare_server.c:2299 */
 uint8_t get_node_id(void) { return (uint8_t)g_smr.idx; }                         /* dare_server.c:2304 */
 
 static double now_s(void)
@@ -315,18 +324,19 @@ static void dump_replicas(smr_t *s, const char *path)
     apus_gpu_sync(s->eng);
     const uint32_t st = apus_gpu_status(s->eng);
     uint64_t len = 0;
-    for (uint32_t i = 0; i < s->group_size; i++) {
+    const uint32_t nrep = s->group ? s->capacity : s->group_size;      /* (group mode: every place a machine can hold; a place nobody is mapped in reads as zeros) */
+    for (uint32_t i = 0; i < nrep; i++) {
         uint64_t o[8] = {0}, c[8] = {0};
         apus_gpu_offsets(s->eng, i, o);
         apus_gpu_counters(s->eng, i, c);
-        len = o[7];
+        if (o[7]) len = o[7];
         fprintf(f, "replica %u head %llu apply %llu commit %llu end %llu tail %llu len %llu highest_rec %llu status %u\n", i,
                 (unsigned long long)o[0], (unsigned long long)o[1], (unsigned long long)o[2], (unsigned long long)o[3],
                 (unsigned long long)o[4], (unsigned long long)o[7], (unsigned long long)c[6], st);
     }
     fprintf(f, "rings\n");
     uint8_t *buf = malloc(len ? len : 1);
-    for (uint32_t i = 0; buf && i < s->group_size; i++) {
+    for (uint32_t i = 0; buf && i < nrep; i++) {
         if (apus_gpu_read_ring(s->eng, i, 0, len, buf)) memset(buf, 0xEE, len);
         fwrite(buf, 1, len, f);
     }
@@ -337,11 +347,28 @@ static void dump_replicas(smr_t *s, const char *path)
 /* ------------------------------------------------------------------------- */
 /* One process per server (benchmarks/run.sh starts one redis + interposer per node; here: per GPU).  The control plane
  * between the processes is a directory (APUS_GROUP_DIR): what the reference exchanges in UD messages -- MR addresses and
- * rkeys (RC_SYN / SYNACK, dare_ibv_ud.c:1098-1380), "I follow you", "I lead term t" -- are small files written with
- * rename(); any other transport would do.  The data plane is the replica kernels: every
- * process runs the workgroups of the replica it hosts.  Election schedule: start-up = server 0 (the start-up ELECT of the
- * pinned traces); after the leader's PROCESS is gone = the live server with the lowest index (the reference draws random
- * timeouts, dare_server.c:1237-1250; a trace's ELECT(w) names the winner -- this is one legal schedule). */
+ * rkeys (RC_SYN / SYNACK, dare_ibv_ud.c:1098-1380), vote requests, "I lead term t with this configuration", JOIN
+ * requests (dare_ibv_ud.c:973-1068) -- are small files written with rename(); any other transport would do
+ * (INTEGRATION.md section 6).  The data plane is the replica kernels: every process runs the workgroups of the replica
+ * it hosts.
+ *
+ *   replica_<i>.ipc    server i's hello: the HIP-IPC handles of its replica (RC_SYN)
+ *   cfg_<seq>          an ANNOUNCEMENT by whoever leads: {seq, term, leader, bitmask, size, epoch} -- one per run of the
+ *                      replica kernels (start-up, fail-over, removal of a dead follower, JOIN); cfg_latest names the newest
+ *   ready_<seq>_<i>    follower i's workgroups for announcement seq are resident
+ *   parked_<term>_<i>  election of `term`: server i has parked and this is its last entry (term, idx) -- its vote request
+ *   join_<i>           a new machine asks for slot i (server_type=join)
+ *
+ * Election schedule: start-up = server 0 (the start-up ELECT of the pinned traces).  After the leader's PROCESS is gone:
+ * the live server whose log is the most up to date -- last entry's (term, idx), ties to the lowest index -- is the one
+ * whose timeout "fires first".  (The reference draws random timeouts, dare_server.c:1237-1250, and a candidate whose log
+ * is behind a voter's is refused, :1661-1673, and tries again later; a trace's ELECT(w) names the winner.  Round 4 took
+ * the lowest live index: with a leader killed MID-FLIGHT the followers' logs differ, the lowest index may be the shorter
+ * one, its election fails on the device -- and the group stopped.  The rule here is the schedule in which the first
+ * candidate is one that can win.) */
+typedef struct { uint64_t seq, term; uint32_t leader, bitmask, size, kind; uint64_t epoch; } g_cfg_t;
+enum { G_KIND_START = 0, G_KIND_FAILOVER, G_KIND_REMOVE, G_KIND_JOIN };
+
 static void g_path(smr_t *s, char *out, size_t cap, const char *fmt, ...)
 {
     va_list ap;
@@ -414,21 +441,27 @@ static int g_read(smr_t *s, void *buf, size_t len, const char *name, g_stamp_t *
     if (ok && who) *who = st;
     return ok ? 0 : -1;
 }
-/* waits for `name` AS WRITTEN BY server `writer` of this run (its stamp from the hello exchange; writer == group_size: any
- * live process -- the hello files themselves) */
+static int g_same(const g_stamp_t *a, const g_stamp_t *b) { return a->pid == b->pid && a->start == b->start; }
+/* `name` as written by server `writer` of this run (its stamp from the hello exchange; writer >= capacity: any live
+ * process -- the hello files themselves); 0 when it is there */
+static int g_have_from(smr_t *s, const char *name, uint32_t writer, size_t len, void *out)
+{
+    uint8_t tmp[sizeof(apus_ipc_replica_t) + 64];        /* (the largest file: a hello) */
+    g_stamp_t st;
+    if (len > sizeof tmp || g_read(s, tmp, len, name, &st)) return -1;
+    const int good = writer < s->capacity ? g_same(&st, &s->peer_stamp[writer]) : g_stamp_alive(&st);
+    if (!good) return -1;
+    if (out) memcpy(out, tmp, len);
+    return 0;
+}
+/* waits for it; gives up when `seconds` are over, at shutdown, or -- writer < capacity -- when the writer's process is gone */
 static int g_wait_from(smr_t *s, const char *name, uint32_t writer, size_t len, void *out, double seconds)
 {
     const double t0 = now_s();
-    uint8_t tmp[sizeof(apus_ipc_replica_t) + 64];        /* (the largest file: a hello) */
-    if (len > sizeof tmp) return -1;
-    for (;;) {
-        g_stamp_t st;
-        if (!g_read(s, tmp, len, name, &st)) {
-            const int good = writer < s->group_size ? (st.pid == s->peer_stamp[writer].pid && st.start == s->peer_stamp[writer].start)
-                                                    : g_stamp_alive(&st);
-            if (good) { if (out) memcpy(out, tmp, len); return 0; }
-        }
+    for (unsigned i = 0;; i++) {
+        if (!g_have_from(s, name, writer, len, out)) return 0;
         if (s->terminate || now_s() - t0 > seconds) return -1;
+        if (writer < s->capacity && (i & 15) == 15 && !g_stamp_alive(&s->peer_stamp[writer])) return -1;
         struct timespec ts = {0, 2000000}; nanosleep(&ts, NULL);
     }
 }
@@ -436,8 +469,30 @@ static int g_alive(smr_t *s, uint32_t i) { return g_stamp_alive(&s->peer_stamp[i
 
 typedef struct { apus_ipc_replica_t ipc; } g_hello_t;
 
-/* RC_SYN / SYNACK once: export the replica this process hosts, map everybody else's */
-static int group_connect(smr_t *s)
+/* RC_SYN / SYNACK with server i: map the replica its LIVE process exports (dropping the mapping of a former holder of the
+ * slot whose process is gone) */
+static int group_map_peer(smr_t *s, uint32_t i, double seconds)
+{
+    char name[64];
+    snprintf(name, sizeof name, "replica_%u.ipc", i);
+    g_hello_t h;
+    g_stamp_t st;
+    /* (the hello of a LIVE process: a file an earlier run left behind names a process that is gone, or another one) */
+    if (g_wait_from(s, name, s->capacity, sizeof h, &h, seconds)) { fprintf(stderr, "[apus] server %u: server %u never showed up in %s\n", s->idx, i, s->group_dir); return -1; }
+    if (g_read(s, &h, sizeof h, name, &st) || h.ipc.replica != i || !g_stamp_alive(&st)) return -1;
+    if ((s->mapped_mask >> i) & 1u) {
+        if (g_same(&st, &s->peer_stamp[i])) return 0;                         /* mapped already: the same process */
+        if (apus_gpu_unmap_replica(s->eng, i)) { fprintf(stderr, "[apus] server %u: cannot drop the mapping of server %u's former process\n", s->idx, i); return -1; }
+        s->mapped_mask &= ~(1u << i);
+    }
+    if (apus_gpu_import_replica(s->eng, &h.ipc)) { fprintf(stderr, "[apus] server %u: cannot map server %u's replica\n", s->idx, i); return -1; }
+    s->peer_stamp[i] = st;
+    s->mapped_mask |= 1u << i;
+    return 0;
+}
+
+/* export the replica this process hosts, map the members of `members` */
+static int group_connect(smr_t *s, uint32_t members)
 {
     g_hello_t me;
     memset(&me, 0, sizeof me);
@@ -446,54 +501,65 @@ static int group_connect(smr_t *s)
     snprintf(name, sizeof name, "replica_%u.ipc", s->idx);
     if (g_write(s, &me, sizeof me, name)) return -1;
     s->peer_stamp[s->idx] = g_my_stamp();
-    for (uint32_t i = 0; i < s->group_size; i++) {
-        if (i == s->idx) continue;
-        snprintf(name, sizeof name, "replica_%u.ipc", i);
-        g_hello_t h;
-        /* (the hello of a LIVE process: a file an earlier run left behind names a process that is gone, or another one) */
-        if (g_wait_from(s, name, s->group_size, sizeof h, &h, 120.0)) { fprintf(stderr, "[apus] server %u: server %u never showed up in %s\n", s->idx, i, s->group_dir); return -1; }
-        if (g_read(s, &h, sizeof h, name, &s->peer_stamp[i]) || h.ipc.replica != i || !g_stamp_alive(&s->peer_stamp[i])) return -1;
-        if (apus_gpu_import_replica(s->eng, &h.ipc)) { fprintf(stderr, "[apus] server %u: cannot map server %u's replica\n", s->idx, i); return -1; }
-    }
-    s->alive_mask = s->bitmask = (1u << s->group_size) - 1;
+    for (uint32_t i = 0; i < s->capacity; i++)
+        if (i != s->idx && ((members >> i) & 1u) && group_map_peer(s, i, 120.0)) return -1;
     return 0;
 }
 
 static uint32_t rep_grid_env(const char *name, uint32_t dflt) { const char *v = getenv(name); return v ? (uint32_t)atoi(v) : dflt; }
 
-/* the replica kernels of a term: followers first (their workgroups poll their mailboxes), then the leader */
-static int group_start_term(smr_t *s)
+static int g_announce(smr_t *s, uint32_t kind)
+{
+    char name[64];
+    g_cfg_t c = { ++s->seq, s->term, s->leader, s->bitmask, s->group_size, kind, s->epoch };
+    snprintf(name, sizeof name, "cfg_%llu", (unsigned long long)c.seq);
+    if (g_write(s, &c, sizeof c, name) || g_write(s, &c, sizeof c, "cfg_latest")) return -1;
+    return 0;
+}
+
+static void proxy_align_cur_rec(uint64_t v);
+
+/* the replica kernels of one announcement: followers first (their workgroups poll their mailboxes), then the leader */
+static int group_start_run(smr_t *s)
 {
     char name[64];
     const uint32_t na = rep_grid_env("APUS_REP_APPEND", 16), nf = rep_grid_env("APUS_REP_FWORK", 8);
     if (s->leader != s->idx) {
+        /* what "applied" means on this server from the first round on: carried out by its application (the first
+         * term used to publish the device's apply count alone) */
+        apus_gpu_rep_follower_replayed(s->eng, s->idx, s->replayed);
         if (apus_gpu_set_leader(s->eng, s->leader) || apus_gpu_rep_start(s->eng, 24u * 3600u * 1000u, 2000, na, nf)) return -1;
-        snprintf(name, sizeof name, "ready_%llu_%u", (unsigned long long)s->term, s->idx);
+        snprintf(name, sizeof name, "ready_%llu_%u", (unsigned long long)s->seq, s->idx);
         return g_write(s, "1", 1, name);
     }
-    for (uint32_t i = 0; i < s->group_size; i++) {
+    for (uint32_t i = 0; i < s->capacity; i++) {
         if (i == s->idx || !((s->alive_mask >> i) & 1u) || !((s->bitmask >> i) & 1u)) continue;
-        snprintf(name, sizeof name, "ready_%llu_%u", (unsigned long long)s->term, i);
+        snprintf(name, sizeof name, "ready_%llu_%u", (unsigned long long)s->seq, i);
         char one;
-        if (g_wait_from(s, name, i, 1, &one, 30.0)) fprintf(stderr, "[apus] leader %u: follower %u did not start its workgroups for term %llu\n", s->idx, i, (unsigned long long)s->term);
+        if (g_wait_from(s, name, i, 1, &one, 30.0)) fprintf(stderr, "[apus] leader %u: follower %u did not start its workgroups for announcement %llu\n", s->idx, i, (unsigned long long)s->seq);
     }
     if (apus_gpu_rep_start(s->eng, 24u * 3600u * 1000u, 500, na, nf)) return -1;
     s->dev_hr = apus_gpu_rep_highest_rec_ptr(s->eng);
     s->upcalled = *s->dev_hr;
+    /* a request's place in the order of upcalls starts where the device's count stands: a new leader's applier has counted the
+     * entries it found in its log (update_state, dare_server.c:1952-1955) -- with the reference's cur_rec = 0 the first that
+     * many requests of the new term would return before they are committed (proxy.c:160 compares the two counters) */
+    proxy_align_cur_rec(*s->dev_hr);
+    __sync_synchronize();
+    s->serving = 1;
     return 0;
 }
 
-/* a follower's apply_committed_entries upcalls (dare_server.c:1941-1955 -> proxy_do_action, proxy.c:341-439): what its
- * own kernel has applied since the last look, replayed into the local application in log order */
-static void follower_upcalls(smr_t *s)
+/* apply_committed_entries' upcalls on a server that does not lead (dare_server.c:1941-1955 -> proxy_do_action,
+ * proxy.c:341-439): the apply-stream records of entry slots [s->replayed, upto) replayed into the local application in
+ * log order.  any_kind: records the device applied as the LEADER count too (below) */
+static void replay_upto(smr_t *s, uint64_t upto, int any_kind)
 {
-    uint64_t pr[4];
-    if (apus_gpu_rep_follower_progress(s->eng, s->idx, pr)) return;
     static apus_apply_t recs[512];
     static uint8_t *bytes;
     if (!bytes) bytes = malloc(65536u + 64u);             /* one record's payload at a time */
-    while (s->replayed < pr[0] && !s->failed) {
-        uint64_t n = pr[0] - s->replayed;
+    while (s->replayed < upto && !s->failed) {
+        uint64_t n = upto - s->replayed;
         if (n > 512) n = 512;
         if (apus_gpu_apply_records(s->eng, s->idx, s->replayed, n, recs)) { s->failed = 1; break; }
         uint64_t done = 0;
@@ -507,7 +573,7 @@ static void follower_upcalls(smr_t *s)
                 s->failed = 1;
                 break;
             }
-            if (recs[i].kind == 2 && s->in.do_action) {
+            if ((recs[i].kind == 2 || (any_kind && recs[i].kind == 1)) && s->in.do_action) {
                 if (recs[i].len && apus_gpu_read_ring(s->eng, s->idx, recs[i].off + 50, recs[i].len, bytes)) {
                     fprintf(stderr, "[apus] server %u: cannot read the payload of slot %llu -- stopping\n", s->idx, (unsigned long long)recs[i].slot);
                     s->failed = 1;
@@ -520,31 +586,56 @@ static void follower_upcalls(smr_t *s)
         apus_gpu_rep_follower_replayed(s->eng, s->idx, s->replayed);     /* what "applied" means on this server: carried out by its application */
     }
 }
+/* what the follower's own kernel has applied since the last look */
+static void joiner_state_transfer(smr_t *s);
+static int proxy_app_listening(void);
+static void follower_upcalls(smr_t *s)
+{
+    uint64_t pr[4];
+    if (s->pending_transfer) {                              /* a joined machine: first the part of the log that stands for its snapshot */
+        if (!proxy_app_listening()) return;
+        joiner_state_transfer(s);
+        s->pending_transfer = 0;
+    }
+    if (apus_gpu_rep_follower_progress(s->eng, s->idx, pr)) return;
+    replay_upto(s, pr[0], 0);
+}
 
-/* the leader's process is gone: park, agree on the survivors, the lowest live index wins the next term */
+/* the leader's process is gone: park, tell the others where this log ends, the most up-to-date survivor wins the next term */
 static int group_failover(smr_t *s)
 {
     char name[64];
     const uint32_t old_leader = s->leader;
+    s->serving = 0;
     apus_gpu_rep_follower_stop(s->eng, s->idx);
     apus_gpu_rep_park(s->eng);
     follower_upcalls(s);
     s->alive_mask &= ~(1u << old_leader);
-    for (uint32_t i = 0; i < s->group_size; i++) if (i != s->idx && !g_alive(s, i)) s->alive_mask &= ~(1u << i);
+    for (uint32_t i = 0; i < s->capacity; i++) if (i != s->idx && ((s->alive_mask >> i) & 1u) && !g_alive(s, i)) s->alive_mask &= ~(1u << i);
     const uint64_t term = s->term + 2;
+    /* the vote request: this server's last entry (start_election, dare_server.c:1264-1322) */
+    uint64_t mine[4] = {0}, theirs[APUS_MAX_SERVERS][4];
+    if (apus_gpu_last_entry(s->eng, s->idx, mine)) return -1;
     snprintf(name, sizeof name, "parked_%llu_%u", (unsigned long long)term, s->idx);
-    g_write(s, "1", 1, name);
-    uint32_t winner = s->group_size;
-    for (uint32_t i = 0; i < s->group_size; i++) if ((s->alive_mask >> i) & 1u && (s->bitmask >> i) & 1u) { winner = i; break; }
-    if (winner >= s->group_size) return -1;
+    g_write(s, mine, sizeof mine, name);
+    memset(theirs, 0, sizeof theirs);
+    memcpy(theirs[s->idx], mine, sizeof mine);
+    /* nothing of the old term may still be running on a survivor when the votes are cast through the mappings: every live
+     * member's word is waited for (a process that dies meanwhile, or never answers, is cut off) */
+    for (uint32_t i = 0; i < s->capacity; i++) {
+        if (i == s->idx || !((s->alive_mask >> i) & 1u) || !((s->bitmask >> i) & 1u)) continue;
+        snprintf(name, sizeof name, "parked_%llu_%u", (unsigned long long)term, i);
+        if (g_wait_from(s, name, i, sizeof theirs[i], theirs[i], 20.0)) s->alive_mask &= ~(1u << i);
+    }
+    uint32_t winner = s->capacity;
+    for (uint32_t i = 0; i < s->capacity; i++) {
+        if (!((s->alive_mask >> i) & 1u) || !((s->bitmask >> i) & 1u)) continue;
+        if (winner >= s->capacity || theirs[i][0] > theirs[winner][0] || (theirs[i][0] == theirs[winner][0] && theirs[i][1] > theirs[winner][1])) winner = i;
+    }
+    if (winner >= s->capacity) return -1;
+    fprintf(s->log, "[T%lu] election of term %llu: server %u has the newest log (term %llu, idx %llu)\n", (unsigned long)s->term, (unsigned long long)term, winner,
+            (unsigned long long)theirs[winner][0], (unsigned long long)theirs[winner][1]);
     if (winner == s->idx) {
-        /* nothing of the old term may still be running on a survivor when the votes are cast through the mappings */
-        for (uint32_t i = 0; i < s->group_size; i++) {
-            if (i == s->idx || !((s->alive_mask >> i) & 1u)) continue;
-            snprintf(name, sizeof name, "parked_%llu_%u", (unsigned long long)term, i);
-            char one;
-            if (g_wait_from(s, name, i, 1, &one, 20.0)) s->alive_mask &= ~(1u << i);           /* it does not answer: cut off */
-        }
         uint64_t out[8] = {0};
         const uint32_t live = s->alive_mask & s->bitmask;
         if (apus_gpu_set_reachable(s->eng, live) || apus_gpu_elect(s->eng, winner, live, s->bitmask, out) || !out[0]) {
@@ -555,20 +646,158 @@ static int group_failover(smr_t *s)
         if (apus_gpu_become_leader_ex(s->eng, winner, term, s->bitmask, dead) || apus_gpu_sync(s->eng)) return -1;
         s->bitmask &= ~dead;
         s->term = term; s->leader = winner;
-        uint32_t cfg[2] = { winner, s->bitmask };
-        snprintf(name, sizeof name, "leader_%llu", (unsigned long long)term);
-        g_write(s, cfg, sizeof cfg, name);
-        fprintf(s->log, "[T%lu] LEADER\n", (unsigned long)s->term);
-        fflush(s->log);
+        /* What this server held but had not carried out when it stopped following: the new leader's first pass has committed
+         * it (blank CONFIG + removal commit everything in front of them) and its applier has COUNTED it -- the reference's
+         * leader applies a client entry with proxy_update_state alone (dare_server.c:1952-1955), so its application never
+         * executes the commands it inherits and differs from its followers' from then on.  Here they are replayed into the
+         * local application (proxy_do_action) before the first client of the new term is admitted: the log, the offsets and
+         * the counters are the reference's, the application is a replica.  (Deviation 3) */
+        uint64_t cnt[8];
+        if (!apus_gpu_counters(s->eng, s->idx, cnt)) replay_upto(s, cnt[3], 1);
+        if (g_announce(s, G_KIND_FAILOVER)) return -1;
     } else {
-        snprintf(name, sizeof name, "leader_%llu", (unsigned long long)term);
-        uint32_t cfg[2];
-        if (g_wait_from(s, name, winner, sizeof cfg, cfg, 60.0)) return -1;     /* (written by the server the same rule makes the winner HERE) */
-        s->term = term; s->leader = cfg[0]; s->bitmask = cfg[1];
+        g_cfg_t c;
+        snprintf(name, sizeof name, "cfg_%llu", (unsigned long long)(s->seq + 1));
+        if (g_wait_from(s, name, winner, sizeof c, &c, 60.0)) return -1;     /* (written by the server the same rule makes the winner HERE) */
+        s->seq = c.seq; s->term = c.term; s->leader = c.leader; s->bitmask = c.bitmask;
         apus_gpu_set_reachable(s->eng, s->alive_mask & s->bitmask);
         if (!((s->bitmask >> s->idx) & 1u)) return -1;                   /* this server was removed */
     }
-    return group_start_term(s);
+    const int rc = group_start_run(s);
+    if (!rc && winner == s->idx) { fprintf(s->log, "[T%lu] LEADER\n", (unsigned long)s->term); fflush(s->log); }   /* dare_server.c:1396, grepped by run.sh */
+    return rc;
+}
+
+/* ---- the leader changes the configuration between two runs: the application's threads wait at the admission lock ---- */
+static void leader_pause(smr_t *s)
+{
+    pthread_spin_lock(&g_q.lock);
+    if (apus_gpu_rep_drain(s->eng, 5000)) fprintf(stderr, "[apus] leader %u: the run did not drain before the reconfiguration\n", s->idx);
+    leader_upcalls(*s->dev_hr);
+    apus_gpu_rep_park(s->eng);
+}
+static int leader_resume(smr_t *s, uint32_t kind)
+{
+    int rc = apus_gpu_sync(s->eng) || g_announce(s, kind) || group_start_run(s);
+    pthread_spin_unlock(&g_q.lock);
+    return rc;
+}
+
+/* check_failure_count (dare_server.c:1190-1230): servers whose process is gone are removed from the configuration with a
+ * CONFIG entry -- the rounds in between had their majority without them (a dead follower costs its ACK, not the round) */
+static int leader_remove_dead(smr_t *s, uint32_t dead)
+{
+    fprintf(s->log, "[T%lu] removing the servers whose process is gone: mask %#x\n", (unsigned long)s->term, dead);
+    leader_pause(s);
+    s->alive_mask &= ~dead;
+    s->bitmask &= ~dead;
+    uint8_t cid[16] = {0};
+    memcpy(cid, &s->epoch, 8);
+    cid[8] = (uint8_t)s->group_size;
+    memcpy(cid + 12, &s->bitmask, 4);
+    int rc = apus_gpu_set_reachable(s->eng, s->alive_mask & s->bitmask) || apus_gpu_append_control(s->eng, APUS_CONFIG, cid);
+    if (rc) fprintf(stderr, "[apus] leader %u: cannot append the CONFIG entry of the removal\n", s->idx);
+    const int rr = leader_resume(s, G_KIND_REMOVE);
+    return rc ? rc : rr;
+}
+
+/* handle_server_join_request (dare_ibv_ud.c:973-1068) for a machine that asked through join_<r>: map its replica, let the
+ * device carry the JOIN out (CONFIG entries incl. the 3-phase extension, the joiner's recovery as a bulk transfer into ITS
+ * memory, its first persist / apply passes: apus_gpu_join), announce the new configuration */
+static int leader_join(smr_t *s, uint32_t r)
+{
+    fprintf(s->log, "[T%lu] JOIN request for slot %u\n", (unsigned long)s->term, r);
+    leader_pause(s);
+    int rc = group_map_peer(s, r, 10.0);
+    uint64_t out[4] = {0};
+    if (!rc) {
+        rc = apus_gpu_join(s->eng, r, (uint16_t)(++s->machines), s->bitmask, s->alive_mask & s->bitmask, out);
+        if (rc) fprintf(stderr, "[apus] leader %u: JOIN of slot %u refused (rc %d)\n", s->idx, r, rc);
+        if (!rc || (rc == APUS_E_NOANSWER && out[1])) { s->bitmask = (uint32_t)out[0]; s->group_size = (uint32_t)out[1]; s->epoch = out[2]; }
+        if (!rc) s->alive_mask |= 1u << r;
+    }
+    char name[64];
+    snprintf(name, sizeof name, "join_%u", r);
+    char pth[400];
+    g_path(s, pth, sizeof pth, "%s", name);
+    unlink(pth);                                           /* (answered, one way or the other) */
+    const int rr = leader_resume(s, G_KIND_JOIN);
+    return rc ? rc : rr;
+}
+
+/* a follower whose kernel has parked although its leader lives: the next announcement (a removal, a JOIN) */
+static int follower_next_run(smr_t *s)
+{
+    char name[64];
+    g_cfg_t c;
+    snprintf(name, sizeof name, "cfg_%llu", (unsigned long long)(s->seq + 1));
+    if (g_have_from(s, name, s->leader, sizeof c, &c)) return 1;            /* not yet */
+    {   /* its leader's park word ends the run; a follower the leader no longer counted in (dropped from the push set and from
+         * the park set) is asked to leave by its own process */
+        uint64_t pr[4] = {0};
+        const double t0 = now_s();
+        while (!apus_gpu_rep_follower_progress(s->eng, s->idx, pr) && pr[2] == 1 && now_s() - t0 < 5.0) { struct timespec ts = {0, 200000}; nanosleep(&ts, NULL); }
+        if (pr[2] == 1) apus_gpu_rep_follower_stop(s->eng, s->idx);
+    }
+    apus_gpu_rep_park(s->eng);
+    follower_upcalls(s);
+    s->seq = c.seq; s->term = c.term; s->leader = c.leader; s->bitmask = c.bitmask;
+    if (!((s->bitmask >> s->idx) & 1u)) { fprintf(s->log, "[T%lu] this server was removed from the configuration\n", (unsigned long)s->term); return -1; }
+    for (uint32_t i = 0; i < s->capacity; i++) {
+        if (i == s->idx || !((c.bitmask >> i) & 1u)) continue;
+        if (group_map_peer(s, i, 30.0)) return -1;                         /* a machine that joined (or took over a slot) */
+        s->alive_mask |= 1u << i;
+    }
+    s->alive_mask &= c.bitmask | (1u << s->idx);
+    if (c.size != s->group_size || c.epoch != s->epoch) {
+        if (apus_gpu_set_config(s->eng, c.size, c.epoch)) return -1;
+        s->group_size = c.size; s->epoch = c.epoch;
+    }
+    apus_gpu_set_reachable(s->eng, s->alive_mask & s->bitmask);
+    return group_start_run(s);
+}
+
+/* What a joined machine's application is given.  The reference ships the donor's BerkeleyDB records (rc_recover_sm,
+ * dare_ibv_rc.c:597-705 -> stablestorage_load_records, proxy.c:306-339) -- records that do not hold the commands (SURVEY Q1:
+ * the length word read for a SEND record is reply[4..5], the stored bytes are the entry's header), so a joined redis
+ * starts EMPTY whatever was written before.  Here the application is brought up to date from the log this server has just
+ * recovered: every client entry in [head, apply) is carried out (proxy_do_action) in log order.  What was pruned before
+ * the join (in front of head) is not available either way; that is said in the log. */
+/* right after the JOIN, before this server's workgroups start: what its log holds as applied is the snapshot's part */
+static void joiner_mark(smr_t *s)
+{
+    uint64_t o[8] = {0}, c[8] = {0};
+    if (apus_gpu_offsets(s->eng, s->idx, o) || apus_gpu_counters(s->eng, s->idx, c)) return;
+    s->xfer_head = o[0]; s->xfer_apply = o[1];
+    s->replayed = c[3];
+    s->pending_transfer = s->in.do_action && o[3] != o[7] && o[0] != o[1];
+}
+static void joiner_state_transfer(smr_t *s)
+{
+    uint64_t o[8] = {0};
+    if (apus_gpu_offsets(s->eng, s->idx, o)) return;
+    const uint64_t L = o[7], head = s->xfer_head, apply = s->xfer_apply;
+    uint8_t *ring = malloc(L);
+    if (!ring || apus_gpu_read_ring(s->eng, s->idx, 0, L, ring)) { free(ring); return; }
+    uint64_t off = head, n = 0, first_idx = 0;
+    for (uint64_t guard = 0; off != apply && guard < 2 * (L / 64) + 16; guard++) {
+        if (L - off < 64) { off = 0; continue; }                                  /* log_get_entry, dare_log.h:300-337 */
+        const uint8_t type = ring[off + 26];
+        uint16_t len = 0;
+        if (type != APUS_NOOP && type != APUS_CONFIG && type != APUS_HEAD) memcpy(&len, ring + off + 48, 2);
+        if (L - off < 64u + len) { off = 0; continue; }                           /* log_fit_entry: the entry sits at 0 */
+        if (!n) memcpy(&first_idx, ring + off, 8);
+        if (type != APUS_NOOP && type != APUS_CONFIG && type != APUS_HEAD) {
+            uint16_t clt; memcpy(&clt, ring + off + 24, 2);
+            s->in.do_action(clt, type, len, ring + off + 50, s->in.up_para);
+        }
+        off += 64u + len;
+        n++;
+    }
+    fprintf(s->log, "[T%lu] state transfer: %llu entries of the recovered log replayed into the application (the log starts at idx %llu%s)\n",
+            (unsigned long)s->term, (unsigned long long)n, (unsigned long long)first_idx, first_idx > 1 ? ": entries pruned before the join are NOT part of it" : "");
+    fflush(s->log);
+    free(ring);
 }
 
 static void group_loop(smr_t *s)
@@ -584,6 +813,20 @@ static void group_loop(smr_t *s)
             }
             const double t = now_s();
             if (!s->failed && t - last_prune >= s->prune_period_s) { apus_gpu_rep_prune(s->eng); last_prune = t; }
+            if (!s->failed && t - last_look > 0.01) {     /* the heartbeat timer: are the followers there?  does a machine want to join? */
+                last_look = t;
+                uint32_t dead = 0;
+                for (uint32_t i = 0; i < s->capacity; i++)
+                    if (i != s->idx && ((s->alive_mask >> i) & 1u) && ((s->bitmask >> i) & 1u) && !g_alive(s, i)) dead |= 1u << i;
+                if (dead && leader_remove_dead(s, dead)) { s->failed = 1; continue; }
+                uint32_t r = s->group_size;                /* dare_ibv_ud.c:995-1021: the lowest empty place, else the group grows */
+                for (int i = (int)s->group_size - 1; i >= 0; i--) if (!((s->bitmask >> i) & 1u)) r = (uint32_t)i;
+                if (r < s->capacity) {
+                    char name[64], one;
+                    snprintf(name, sizeof name, "join_%u", r);
+                    if (!g_have_from(s, name, s->capacity, 1, &one)) leader_join(s, r);
+                }
+            }
             struct timespec ts = {0, 100000}; nanosleep(&ts, NULL);
             continue;
         }
@@ -593,7 +836,10 @@ static void group_loop(smr_t *s)
             last_look = t;
             if (!g_alive(s, s->leader)) {
                 fprintf(s->log, "[T%lu] the leader p%u is gone\n", (unsigned long)s->term, s->leader);
-                if (group_failover(s)) { fprintf(stderr, "[apus] server %u: fail-over failed, the hooks are inert from here on\n", s->idx); s->failed = 1; s->leader = s->group_size; break; }
+                if (group_failover(s)) { fprintf(stderr, "[apus] server %u: fail-over failed, the hooks are inert from here on\n", s->idx); s->failed = 1; s->leader = s->capacity; break; }
+            } else {
+                const int x = follower_next_run(s);
+                if (x < 0) { fprintf(stderr, "[apus] server %u: cannot follow the new configuration, the hooks are inert from here on\n", s->idx); s->failed = 1; s->leader = s->capacity; break; }
             }
         }
         struct timespec ts = {0, 50000}; nanosleep(&ts, NULL);
@@ -615,23 +861,47 @@ void *dare_server_init(void *arg)
     const char *pp = getenv("APUS_PRUNE_PERIOD_MS");
     s->prune_period_s = pp ? atof(pp) * 1e-3 : 0.05;   /* log_pruning_period, nodes.local.cfg:35 */
 
-    /* This host layer runs ONE process: the group's replicas are logical replicas on this process's
-     * GPU and this server leads them.  A process per server -- what
-     * benchmarks/run.sh starts on three nodes -- is the peer-mapped group of apus_amd/peers.py, which
-     * this C layer does not drive yet: refuse instead of starting a second, independent leader. */
+    /* Without APUS_GROUP_DIR this host layer runs ONE process: the group's replicas are logical replicas on this process's
+     * GPU and this server leads them.  A process per server -- what benchmarks/run.sh starts on
+     * three nodes -- is group mode (APUS_GROUP_DIR); a second, independent leader is refused. */
     const char *gdir = getenv("APUS_GROUP_DIR");
     s->group = gdir && *gdir;
     if (s->group) snprintf(s->group_dir, sizeof s->group_dir, "%s", gdir);
     if (!s->group && (s->in.srv_type == SRV_TYPE_JOIN || (s->idx != 0 && !getenv("APUS_ALLOW_ANY_SERVER_IDX")))) {
-        fprintf(stderr, "[apus] server_idx=%u server_type=%s: this build replicates inside ONE process (logical replicas on one GPU, "
-                        "server_idx 0 leads); a process per server needs the peer-mapped group (apus_amd/peers.py, INTEGRATION.md section 6)\n",
+        fprintf(stderr, "[apus] server_idx=%u server_type=%s: without APUS_GROUP_DIR this build replicates inside ONE process (logical replicas on one "
+                        "GPU, server_idx 0 leads); a process per server needs the group directory (INTEGRATION.md section 2)\n",
                 s->idx, s->in.srv_type == SRV_TYPE_JOIN ? "join" : "start");
         s->ready = -1;
         return NULL;
     }
+    s->capacity = s->group_size;
+    const char *cap_env = getenv("APUS_GROUP_CAPACITY");
+    if (s->group && cap_env && (uint32_t)atoi(cap_env) > s->capacity) s->capacity = (uint32_t)atoi(cap_env);
+    if (s->capacity > APUS_MAX_SERVERS) s->capacity = APUS_MAX_SERVERS;
+    g_cfg_t jc;
+    memset(&jc, 0, sizeof jc);
+    if (s->group && s->in.srv_type == SRV_TYPE_JOIN) {
+        /* join_cluster_cb (dare_server.c:445-530): a new machine asks the group for a place.  The newest announcement says who
+         * leads and which places are taken; the place is the leader's to give (handle_server_join_request,
+         * dare_ibv_ud.c:995-1021: the lowest empty one, else the group grows) -- worked out here with the same rule because
+         * the replica this process exports must sit in that slot before the request goes out. */
+        s->peer_stamp[0].pid = 0;
+        const double t0 = now_s();
+        for (;;) {
+            g_stamp_t st;
+            if (!g_read(s, &jc, sizeof jc, "cfg_latest", &st) && g_stamp_alive(&st)) break;
+            if (now_s() - t0 > 120.0) { fprintf(stderr, "[apus] join: no live group in %s\n", s->group_dir); s->ready = -1; return NULL; }
+            struct timespec ts = {0, 5000000}; nanosleep(&ts, NULL);
+        }
+        uint32_t r = jc.size;
+        for (int i = (int)jc.size - 1; i >= 0; i--) if (!((jc.bitmask >> i) & 1u)) r = (uint32_t)i;
+        if (r >= s->capacity) { fprintf(stderr, "[apus] join: the group of %u is full and has no room to grow (APUS_GROUP_CAPACITY=%u)\n", jc.size, s->capacity); s->ready = -1; return NULL; }
+        s->idx = r;
+        s->group_size = jc.size;
+    }
     apus_cfg_t cfg;
     memset(&cfg, 0, sizeof cfg);
-    cfg.group_size = s->group_size;
+    cfg.group_size = s->group ? s->capacity : s->group_size;
     if (s->group) { cfg.n_local = 1; cfg.local_ids[0] = (uint8_t)s->idx; }      /* one process per server: this one hosts replica idx */
     else {
         cfg.n_local = s->group_size;               /* logical replicas on one device */
@@ -650,25 +920,49 @@ void *dare_server_init(void *arg)
     apus_gpu_bind_global(s->eng);
     if (s->group) {
         /* ---- one process per server ---- */
-        if (s->in.srv_type == SRV_TYPE_JOIN) {
-            fprintf(stderr, "[apus] server_type=join: a machine that joins a running group is driven through apus_gpu_join by the leader's process "
-                            "(apus_amd/peers.py:PeerMember.join); this host layer starts groups and fails over\n");
-            s->ready = -1;
-            return NULL;
-        }
-        if (group_connect(s)) { s->ready = -1; return NULL; }
-        s->term = 2; s->leader = 0;
         s->live_replica = 1; s->live_persist = 0;
-        char name[64];
-        if (s->idx == 0) {
-            /* start-up election (dare_server.c:1169, 1264-1518): server 0's timeout fires first */
-            if (apus_gpu_become_leader(s->eng, 0, s->term, s->bitmask) || apus_gpu_sync(s->eng)) { fprintf(stderr, "[apus] election failed\n"); s->ready = -1; return NULL; }
-            uint32_t cfg2[2] = { 0, s->bitmask };
-            g_write(s, cfg2, sizeof cfg2, "leader_2");
-        } else { uint32_t cfg2[2]; if (g_wait_from(s, "leader_2", 0, sizeof cfg2, cfg2, 120.0)) { s->ready = -1; return NULL; } }
-        if (group_start_term(s)) { fprintf(stderr, "[apus] server %u: cannot start the replica kernels\n", s->idx); s->ready = -1; return NULL; }
-        if (s->idx == 0) { fprintf(s->log, "[T%lu] LEADER\n", (unsigned long)s->term); fflush(s->log); }
-        (void)name;
+        s->machines = s->group_size;
+        if (s->capacity > s->group_size && apus_gpu_set_group_size(s->eng, s->group_size)) { s->ready = -1; return NULL; }
+        if (s->in.srv_type == SRV_TYPE_JOIN) {
+            if (apus_gpu_clear_replica(s->eng, s->idx) || group_connect(s, jc.bitmask)) { s->ready = -1; return NULL; }
+            char name[64];
+            snprintf(name, sizeof name, "join_%u", s->idx);
+            if (g_write(s, "1", 1, name)) { s->ready = -1; return NULL; }
+            /* the join reply (dare_ibv_ud.c:1071-1088): the first announcement whose configuration shows this server */
+            const double t0 = now_s();
+            for (;;) {
+                g_stamp_t st;
+                g_cfg_t c;
+                if (!g_read(s, &c, sizeof c, "cfg_latest", &st) && g_stamp_alive(&st) && c.seq > jc.seq && ((c.bitmask >> s->idx) & 1u) &&
+                    c.leader < s->capacity && g_same(&st, &s->peer_stamp[c.leader])) { jc = c; break; }
+                if (s->terminate || now_s() - t0 > 120.0) { fprintf(stderr, "[apus] join: the group did not admit server %u\n", s->idx); s->ready = -1; return NULL; }
+                struct timespec ts = {0, 2000000}; nanosleep(&ts, NULL);
+            }
+            s->seq = jc.seq; s->term = jc.term; s->leader = jc.leader; s->bitmask = jc.bitmask; s->group_size = jc.size; s->epoch = jc.epoch;
+            s->alive_mask = jc.bitmask;
+            for (uint32_t i = 0; i < s->capacity; i++)
+                if (i != s->idx && ((jc.bitmask >> i) & 1u) && group_map_peer(s, i, 30.0)) { s->ready = -1; return NULL; }
+            if (apus_gpu_set_config(s->eng, jc.size, jc.epoch) || apus_gpu_set_reachable(s->eng, jc.bitmask)) { s->ready = -1; return NULL; }
+            joiner_mark(s);                  /* (the application is brought up to date by the DARE loop, once it listens) */
+            if (group_start_run(s)) { fprintf(stderr, "[apus] server %u: cannot start the replica kernels\n", s->idx); s->ready = -1; return NULL; }
+            fprintf(s->log, "[T%lu] joined as server %u\n", (unsigned long)s->term, s->idx); fflush(s->log);
+        } else {
+            const uint32_t all = (1u << s->group_size) - 1;
+            if (group_connect(s, all)) { s->ready = -1; return NULL; }
+            s->alive_mask = s->bitmask = all;
+            s->term = 2; s->leader = 0;
+            if (s->idx == 0) {
+                /* start-up election (dare_server.c:1169, 1264-1518): server 0's timeout fires first */
+                if (apus_gpu_become_leader(s->eng, 0, s->term, s->bitmask) || apus_gpu_sync(s->eng)) { fprintf(stderr, "[apus] election failed\n"); s->ready = -1; return NULL; }
+                if (g_announce(s, G_KIND_START)) { s->ready = -1; return NULL; }
+            } else {
+                g_cfg_t c;
+                if (g_wait_from(s, "cfg_1", 0, sizeof c, &c, 120.0)) { s->ready = -1; return NULL; }
+                s->seq = c.seq;
+            }
+            if (group_start_run(s)) { fprintf(stderr, "[apus] server %u: cannot start the replica kernels\n", s->idx); s->ready = -1; return NULL; }
+            if (s->idx == 0) { fprintf(s->log, "[T%lu] LEADER\n", (unsigned long)s->term); fflush(s->log); }
+        }
         signal(SIGINT, on_sigint);
         s->running = 1;
         __sync_synchronize();
@@ -676,7 +970,7 @@ void *dare_server_init(void *arg)
         group_loop(s);
         /* shutdown: the leader drains and parks everybody; a follower waits for its workgroups (or asks them to leave) */
         if (s->leader == s->idx) { apus_gpu_rep_drain(s->eng, 5000); leader_upcalls(*s->dev_hr); s->dev_hr = NULL; apus_gpu_rep_park(s->eng); }
-        else if (s->leader < s->group_size) { apus_gpu_rep_follower_stop(s->eng, s->idx); apus_gpu_rep_park(s->eng); follower_upcalls(s); }
+        else if (s->leader < s->capacity) { apus_gpu_rep_follower_stop(s->eng, s->idx); apus_gpu_rep_park(s->eng); follower_upcalls(s); }
         apus_gpu_sync(s->eng);
         const char *dump_g = getenv("APUS_PROXY_DUMP");
         if (dump_g && *dump_g) dump_replicas(s, dump_g);
@@ -847,6 +1141,17 @@ struct proxy_node_t {
 static struct proxy_node_t *g_proxy;
 
 static void proxy_mirror_highest_rec(uint64_t v) { if (g_proxy) g_proxy->highest_rec = v; }
+/* does the local application accept connections yet?  (the interposer initialises from an ELF constructor: main() has not run) */
+static int proxy_app_listening(void)
+{
+    if (!g_proxy) return 1;
+    int fd = socket(AF_INET, SOCK_STREAM, 0);
+    if (fd < 0) return 0;
+    const int ok = connect(fd, (struct sockaddr *)&g_proxy->sys_addr, sizeof g_proxy->sys_addr) == 0;
+    close(fd);
+    return ok;
+}
+static void proxy_align_cur_rec(uint64_t v) { if (g_proxy && g_proxy->cur_rec < v) g_proxy->cur_rec = v; }
 
 static void update_highest_rec(void *arg)                        /* proxy.c:263-267 */
 {

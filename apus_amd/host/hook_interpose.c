@@ -23,6 +23,7 @@
 #include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <sys/socket.h>
 #include <sys/stat.h>
 #include <sys/types.h>
@@ -48,7 +49,8 @@ __attribute__((constructor)) static void apus_hook_init(void)
 {
     if (getenv("APUS_DEBUG")) signal(SIGSEGV, on_segv);
     const char *cfg = getenv("config_path");
-    if (!getenv("server_idx")) return;              /* not an APUS-managed process */
+    const char *st = getenv("server_type");
+    if (!getenv("server_idx") && !(st && !strcmp(st, "join"))) return;      /* not an APUS-managed process (a joiner has no index yet) */
     initialising = 1;
     guard = 1;
     proxy = proxy_init(cfg ? cfg : "", NULL);       /* tern_init_func, spec_hooks.cpp:22-45 */

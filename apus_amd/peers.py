@@ -93,6 +93,11 @@ class PeerMember:
         self.led = []                       # (first pass, passes) of the round record for every term this rank led
         self.rep_running = False            # a run of the replica kernels is resident (rep_begin .. rep_end)
         self.rep_here = False               # ... and this process carries workgroups of it
+        self.pg = None                      # the process group the control-plane barriers run on (None: everybody; the
+                                            # survivors' group once a rank has DIED -- tests/_peer_kill_worker.py)
+
+    def _barrier(self):
+        dist.barrier(group=self.pg)
 
     @property
     def is_leader(self) -> bool:
@@ -106,7 +111,7 @@ class PeerMember:
         e = self.eng
         if self.is_leader:
             e.sync()
-        dist.barrier()
+        self._barrier()
         if self.rank == winner:
             first = len(e.round_record()[0])
             e.elect(winner)                 # term += 2, blank CONFIG (+ removal of the dead) on the device
@@ -146,7 +151,7 @@ class PeerMember:
             e.sync()
         if self.rank == r:
             e._chk(e.L.apus_gpu_clear_replica(e.h, r), "clear_replica")
-        dist.barrier()
+        self._barrier()
         err = None
         if self.is_leader:
             try:
@@ -163,7 +168,7 @@ class PeerMember:
             cfg = torch.zeros(5, dtype=torch.int64)
         if dist.get_backend() == "nccl":
             cfg = cfg.to(self.device)
-        dist.broadcast(cfg, src=self.leader)
+        dist.broadcast(cfg, src=self.leader, group=self.pg)
         if int(cfg.cpu()[4]) != 1:
             if int(cfg.cpu()[4]) == 2 and not self.is_leader:
                 bitmask, size, epoch, machines = (int(v) for v in cfg.cpu().tolist()[:4])
@@ -188,14 +193,14 @@ class PeerMember:
             return
         if self.is_leader:
             e.sync()
-        dist.barrier()                      # the control plane's last words are in everybody's control blocks
+        self._barrier()                      # the control plane's last words are in everybody's control blocks
         alive = self.leader >= 0 and (e.reachable >> self.rank) & 1 and (e.bitmask >> self.rank) & 1
         self.rep_here = False
         if alive and not self.is_leader:
             e._chk(e.L.apus_gpu_set_leader(e.h, self.leader), "set_leader")
             e.rep_start(idle_ms, peer_ms, n_append, n_fwork)
             self.rep_here = True
-        dist.barrier()                      # every follower's workgroups are resident
+        self._barrier()                      # every follower's workgroups are resident
         if self.is_leader:
             e.rep_start(idle_ms, peer_ms, n_append, n_fwork)
             self.rep_here = True
@@ -213,7 +218,7 @@ class PeerMember:
                 e.rep_drain(timeout_ms=60000)
             code = e.rep_park()
         self.rep_running = self.rep_here = False
-        dist.barrier()
+        self._barrier()
         if code != 0:
             raise EngineError(f"rank {self.rank}: the replica kernels left with code {code}, status {e.status_names()}")
 
@@ -242,7 +247,7 @@ class PeerMember:
         """Check point: the leader's stream has drained, everybody may look at its own replica."""
         if self.is_leader:
             self.eng.sync()
-        dist.barrier()
+        self._barrier()
 
     def check_done(self):
         """Closes a check point: nobody moves on before EVERY rank has finished looking at its replica.  (Without it
@@ -252,16 +257,16 @@ class PeerMember:
         slowest comparison, five rounds of ten entries before the next check point.)"""
         if os.environ.get("APUS_PEER_NO_CHECK_BARRIER"):        # diagnostic only: reproduces that failure (tests/test_gpu_peers.py)
             return
-        dist.barrier()
+        self._barrier()
 
     def close(self):
         try:
             self.eng.sync()
         except EngineError:
             pass
-        dist.barrier()                      # nobody unmaps / frees while a peer may still write
+        self._barrier()                      # nobody unmaps / frees while a peer may still write
         self.eng.L.apus_gpu_unmap_peers(self.eng.h)
-        dist.barrier()                      # nobody frees what a peer still has mapped
+        self._barrier()                      # nobody frees what a peer still has mapped
         self.eng.close()
 
 

@@ -184,6 +184,8 @@ int  apus_gpu_export_replica(apus_engine_t *e, uint32_t replica, apus_ipc_replic
 /* maps a peer process's replica; from then on this engine can lead a group that contains it.
  * The memory stays owned by the exporter (never reset or freed here). */
 int  apus_gpu_import_replica(apus_engine_t *e, const apus_ipc_replica_t *in);
+/* one peer's mapping alone: the members drop a dead process's replica before they map the machine that takes its slot */
+int  apus_gpu_unmap_replica(apus_engine_t *e, uint32_t replica);
 /* Orderly shutdown of a peer-mapped group, first half: close every imported mapping, free nothing.  (Every process
  * unmaps, a barrier, then every process destroys: an owner that frees a buffer a peer still has open cannot export
  * the memory it allocates next.)  APUS_E_STATE while a resident kernel or a batch is open. */
@@ -206,6 +208,9 @@ int  apus_gpu_become_leader(apus_engine_t *e, uint32_t leader, uint64_t term, ui
 int  apus_gpu_elect(apus_engine_t *e, uint32_t winner, uint32_t live_mask, uint32_t bitmask, uint64_t out[8]);
 int  apus_gpu_become_leader_ex(apus_engine_t *e, uint32_t leader, uint64_t term, uint32_t bitmask,
                                uint32_t removed);
+/* the last entry of a replica's log, what a vote is decided on (dare_server.c:1661-1673): out[0] term, [1] idx (0, 0: the
+ * log reads as empty), [2] entry slots held, [3] end offset.  Synchronises; not while a run of the replica kernels is resident. */
+int  apus_gpu_last_entry(apus_engine_t *e, uint32_t replica, uint64_t out[4]);
 /* cfg.group_size is the number of replicas that EXIST (the capacity); this sets the size of the
  * configuration the leader decides with (cid.size[0]: quorum = n/2+1, the servers a prune tick looks
  * at).  Default = the capacity; a group that is meant to grow starts smaller (apus_gpu_join extends it). */
@@ -366,6 +371,9 @@ int  apus_gpu_rep_follower_stop(apus_engine_t *e, uint32_t replica);
 /* a host consumer replays the follower's apply stream: `slots` entry slots carried out so far.  From the first call on the
  * follower tells the leader min(device apply, host replay) as applied: pruning cannot outrun the application */
 int  apus_gpu_rep_follower_replayed(apus_engine_t *e, uint32_t replica, uint64_t slots);
+/* diagnostics / tests, between runs: out[0] the commit doorbell of `replica` as rung (R4, not clipped to what it holds), [1] ctrl,
+ * [2] f_seq_next, [3] f_runs, [4] f_exit, [5..7] persisted_by / applied_by / seqdone_by[who] as follower `who` left them */
+int  apus_gpu_rep_box_words(apus_engine_t *e, uint32_t replica, uint32_t who, uint64_t out[8]);
 int  apus_gpu_rep_req_ring_kind(apus_engine_t *e);                            /* 1: the request ring is device memory behind the BAR, 0: pinned host memory, -1: no run yet */
 int  apus_gpu_rep_launch_ms(apus_engine_t *e, double *ms);                    /* duration of the last (parked) run's resident launch, HIP events on its stream */
 int  apus_gpu_rep_role_stats(apus_engine_t *e, uint64_t out[20][8]);          /* diagnostics: passes / rounds / time of the serial roles of the last run */

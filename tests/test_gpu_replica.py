@@ -122,3 +122,61 @@ def test_rep_a_dead_follower_costs_its_ack_not_the_round():
         assert eng.offsets(4)["end"] != o["end"]              # nobody persisted there
     finally:
         eng.close()
+
+
+def test_rep_a_host_consumer_that_registers_during_the_first_run_holds_the_head_back():
+    """apus_gpu_rep_follower_replayed is "callable before and during a run" -- a follower whose host replay lags
+    tells the leader min(device apply, host replay) as applied, also when the consumer registers while the FIRST run is
+    already resident (round 4 read the word once at the start: the first term published the device's count alone and the
+    leader could prune and lap what the host had not carried out).  A consumer that has replayed nothing: applied_by stays 0
+    in the leader's mailbox, no prune tick moves the verified head over it (the ring is protected), and once the host says
+    it has caught up the leader hears it."""
+    import ctypes as C
+    import time
+    from apus_amd.engine import Engine
+    tr = T.steady_trace(3, 64 * 96, 64, 8, 64, log_len=1 << 20, prune_bytes=1 << 17)
+    eng = Engine(3, tr.log_len)
+    try:
+        eng.stage_trace(tr)
+        eng.elect(0)
+        eng.sync()
+        eng.rep_start(idle_ms=5000, peer_ms=3000)
+        L = eng.L
+        assert L.apus_gpu_rep_follower_replayed(eng.h, 1, 0) == 0          # registers DURING the first run: nothing replayed yet
+        time.sleep(0.05)                                                   # (the apply wavefront looks at the word every 256 passes)
+        ev = [e for e in tr.events if e[0] in ("ROUND", "PRUNE")]
+        i, ticks = 0, 0
+        while i < len(ev) and ticks < 5:                                   # fewer ticks than head moves may stay unverified (8)
+            if ev[i][0] == "PRUNE":
+                eng.rep_prune(); ticks += 1; i += 1
+                continue
+            j = i
+            while j < len(ev) and ev[j][0] == "ROUND":
+                j += 1
+            eng.rep_run(eng.round_of_g0[ev[i][1]], j - i)
+            i = j
+        pr = (C.c_uint64 * 4)()
+        t0 = time.time()
+        while time.time() - t0 < 10:
+            L.apus_gpu_rep_follower_progress(eng.h, 1, pr)
+            if pr[0] > 64 * 40:
+                break
+            time.sleep(0.001)
+        assert pr[0] > 64 * 40, f"follower 1's kernel applied only {pr[0]} entry slots"
+        w = (C.c_uint64 * 8)()
+        # (the mailbox is uncached device memory: readable while the run is resident)
+        assert L.apus_gpu_rep_box_words(eng.h, 0, 1, w) == 0
+        assert w[6] == 0, f"the leader was told follower 1 applied {w[6]} entry slots although its host has replayed none"
+        assert L.apus_gpu_rep_box_words(eng.h, 0, 2, w) == 0 and w[6] > 0          # (follower 2 has no host consumer: the device count)
+        # the host catches up: the leader hears it, the run drains, everything is applied everywhere
+        applied = int(pr[0])
+        L.apus_gpu_rep_follower_replayed(eng.h, 1, 1 << 40)
+        eng.rep_drain(timeout_ms=20000)
+        L.apus_gpu_rep_box_words(eng.h, 0, 1, w)
+        assert w[6] >= applied
+        assert eng.rep_park() == 0
+        o = eng.offsets(0)
+        assert o["commit"] == o["end"] == o["apply"]
+        assert eng.offsets(1)["apply"] == o["end"]
+    finally:
+        eng.close()
