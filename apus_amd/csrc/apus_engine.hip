@@ -1230,6 +1230,70 @@ __global__ void k_adjust(const EngDev E, uint32_t mask, uint32_t alive_mask)
     fh[H_STORE_COUNT] += count;
 }
 
+/* poll_vote_count (dare_server.c:1327-1518) + the first steps of log_adjustment (dare_ibv_rc.c:1357-1368): every vote ACK
+ * carries the voter's commit offset and the new leader's commit moves up to the largest of them -- what a voter knows to
+ * be committed IS committed, and an elected leader holds it.  In the pinned schedules every server learns a commit in the
+ * pass that made it, so the voters' commits equal the winner's; with a leader killed MID-FLIGHT the commit doorbells have
+ * reached the survivors at different times. */
+__global__ void k_inherit(const EngDev E, uint32_t voters)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const RepDev &Ld = E.rep[E.leader];
+    uint64_t *lh = Ld.hdr;
+    if (lh[H_END] == E.log_len) return;
+    uint64_t nc = lh[H_N_COMMIT];
+    for (uint32_t m = voters & ~(1u << E.leader); m; m &= m - 1) {
+        const uint32_t f = (uint32_t)__builtin_ctz(m);
+        if (f >= APUS_DEV_MAX_SERVERS || !E.rep[f].ring) continue;
+        const uint64_t c = E.rep[f].hdr[H_N_COMMIT];
+        if (c > nc) nc = c;
+    }
+    if (nc > lh[H_N_END]) nc = lh[H_N_END];
+    if (nc > lh[H_N_COMMIT]) {
+        lh[H_COMMIT] = nc == lh[H_N_END] ? lh[H_END] : Ld.dir_off[(uint32_t)nc & E.dir_mask];
+        lh[H_N_COMMIT] = nc;
+    }
+}
+
+/* INHERITED entries (deviation 4, DESIGN.md section 6: liveness where the reference has none).  A follower acknowledges
+ * an entry to the server that SENT it (entry->sender, dare_server.c:1806) and the commit scan counts the reply bytes in
+ * the leader's own copy (dare_ibv_rc.c:1725-1758).  An entry a new leader holds from its predecessor -- in its own log
+ * since before the election, or shipped to a follower that lagged by the new leader's catch-up -- was and is acknowledged
+ * to the DEAD sender: the new leader's copy never shows a majority, the scan stops in front of it for good, and nothing
+ * behind it commits either.  (The median-of-end-offsets rule of DARE that would cover it is dead code in the reference:
+ * its result is overwritten at :1725.)  The pinned schedules never get there -- every server has learnt every commit when
+ * the leader dies -- a leader killed with rounds in flight does: the followers hold rounds whose commit doorbell they
+ * have not seen.
+ * Here: once the new term's own entry (the blank CONFIG the leader has just appended) is held and acknowledged by a
+ * majority -- the condition under which a leader may count replicas of older terms' entries at all -- every follower the
+ * leader pushes to counts as having acknowledged what it holds of the leader's log (its log IS a prefix of the leader's:
+ * log adjustment cut what differed, the catch-up wrote the rest).  Only the derived ACK words are set, never the reply
+ * bytes in a ring: the logs stay what the reference's would be had the old leader lived one pass longer.
+ * flag[0] != 0: bits were set, a commit pass must follow. */
+__global__ __launch_bounds__(256) void k_reack(const EngDev E, uint32_t fmask, uint32_t *flag)
+{
+    const RepDev &Ld = E.rep[E.leader];
+    const uint64_t *lh = Ld.hdr;
+    if (lh[H_END] == E.log_len) return;
+    const uint64_t n_end = lh[H_N_END], nc = lh[H_N_COMMIT];
+    if (nc >= n_end) return;
+    const uint32_t size = E.group_size, size_mask = (1u << size) - 1;
+    const uint32_t last = __hip_atomic_load(&Ld.ack[(uint32_t)(n_end - 1) & E.dir_mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)__popc((last | (1u << E.leader)) & size_mask) < size / 2 + 1) return;
+    bool any = false;
+    for (uint32_t m = fmask & ~(1u << E.leader); m; m &= m - 1) {
+        const uint32_t f = (uint32_t)__builtin_ctz(m);
+        if (f >= APUS_DEV_MAX_SERVERS || !E.rep[f].ring) continue;
+        uint64_t upto = E.rep[f].hdr[H_N_PERSIST];
+        if (upto > n_end) upto = n_end;
+        for (uint64_t sl = nc + threadIdx.x; sl < upto; sl += blockDim.x) {
+            const uint32_t di = (uint32_t)sl & E.dir_mask;
+            if (!((__hip_atomic_load(&Ld.ack[di], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> f) & 1u)) { atomicOr(&Ld.ack[di], 1u << f); any = true; }
+        }
+    }
+    if (any) atomicOr(flag, 1u);
+}
+
 extern "C" int apus_gpu_elect(apus_engine_t *e, uint32_t winner, uint32_t live_mask, uint32_t bitmask, uint64_t out[8])
 {
     if (!e || !out || winner >= e->d.group_size) return APUS_E_ARG;
@@ -1271,6 +1335,8 @@ extern "C" int apus_gpu_become_leader_ex(apus_engine_t *e, uint32_t leader, uint
         const uint32_t am = e->adjust_mask & e->local_mask & e->reachable & ~(1u << leader);
         /* ... and they took this candidate's configuration with their vote (dare_server.c:1697) */
         hipLaunchKernelGGL(k_cfg_note, dim3(1), dim3(64), 0, e->stream, e->d_cfgj, e->adjust_mask & ~(1u << leader), bitmask);
+        /* ... and told it how far they know the log to be committed */
+        if (am) hipLaunchKernelGGL(k_inherit, dim3(1), dim3(64), 0, e->stream, e->d, am);
         e->adjust_mask = 0;
         if (am) {
             hipLaunchKernelGGL(k_adjust, dim3(popc(am)), dim3(64), 0, e->stream, e->d, am, e->reachable);
@@ -1284,14 +1350,31 @@ extern "C" int apus_gpu_become_leader_ex(apus_engine_t *e, uint32_t leader, uint
     cid[8] = (uint8_t)e->d.group_size;
     memcpy(cid + 12, &bitmask, 4);
     removed &= bitmask & ~(1u << leader);
-    if (!removed) return apus_gpu_append_control(e, APUS_CONFIG, cid);
-    uint64_t d0, d1;
-    memcpy(&d0, cid, 8); memcpy(&d1, cid + 8, 8);
-    int rc = launch_control_round(e, 3, APUS_CONFIG, d0, d1);        /* append only */
+    int rc;
+    if (!removed) rc = apus_gpu_append_control(e, APUS_CONFIG, cid);
+    else {
+        uint64_t d0, d1;
+        memcpy(&d0, cid, 8); memcpy(&d1, cid + 8, 8);
+        rc = launch_control_round(e, 3, APUS_CONFIG, d0, d1);        /* append only */
+        if (rc) return rc;
+        const uint32_t left = bitmask & ~removed;
+        memcpy(cid + 12, &left, 4);
+        rc = apus_gpu_append_control(e, APUS_CONFIG, cid);            /* second entry + the pass */
+    }
     if (rc) return rc;
-    const uint32_t left = bitmask & ~removed;
-    memcpy(cid + 12, &left, 4);
-    return apus_gpu_append_control(e, APUS_CONFIG, cid);            /* second entry + the pass */
+    /* what this leader INHERITED and could not commit in that pass (k_reack above): one look, and only when there was
+     * something -- never in a pinned schedule -- one more pass that commits and applies it */
+    {
+        uint32_t *flag = (uint32_t *)(e->d_elect + 24);
+        HIPCHK(hipMemsetAsync(flag, 0, sizeof(uint32_t), e->stream));
+        hipLaunchKernelGGL(k_reack, dim3(1), dim3(256), 0, e->stream, e->d, sync_mask(e), flag);
+        HIPCHK(hipGetLastError());
+        uint32_t h = 0;
+        HIPCHK(hipMemcpyAsync(&h, flag, sizeof h, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (h) rc = launch_control_round(e, 2, 0, 0, 0);
+    }
+    return rc;
 }
 
 extern "C" int apus_gpu_become_leader(apus_engine_t *e, uint32_t leader, uint64_t term, uint32_t bitmask)

@@ -27,6 +27,7 @@
 #include <fcntl.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <pthread.h>
 #include <signal.h>
 #include <stdarg.h>
@@ -1178,7 +1179,28 @@ static void do_action_to_server(uint16_t clt_id, uint8_t type, size_t data_size,
         }
         break;
     case PROXY_SEND:
-        if (fp->used && write(fp->sock, data, data_size) < 0) fprintf(stderr, "ERROR writing to socket!\n");
+        /* The reference writes once into its non-blocking socket (proxy.c:417-424): whatever the socket buffer does not
+         * take -- a replay that runs ahead of the application, e.g. a joined machine's state transfer or a follower behind a
+         * fast leader -- is LOST and the replica's application silently differs from then on.  Here the DARE thread waits
+         * for the application instead (back-pressure: what it has not replayed is not reported as applied, so the leader's
+         * head cannot pass it). */
+        if (fp->used) {
+            const uint8_t *b = data;
+            size_t left = data_size;
+            int stalls = 0;
+            while (left) {
+                const ssize_t w = write(fp->sock, b, left);
+                if (w > 0) { b += w; left -= (size_t)w; stalls = 0; continue; }
+                if (w < 0 && (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) && !g_smr.terminate && stalls < 30000) {
+                    struct pollfd pf = { fp->sock, POLLOUT, 0 };
+                    poll(&pf, 1, 10);
+                    stalls++;
+                    continue;
+                }
+                fprintf(stderr, "ERROR writing to socket!\n");
+                break;
+            }
+        }
         break;
     case PROXY_CLOSE:
         if (fp->used) { if (close(fp->sock)) fprintf(stderr, "ERROR closing socket!\n"); fp->used = 0; }
