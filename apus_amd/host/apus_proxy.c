@@ -1203,7 +1203,26 @@ static void do_action_to_server(uint16_t clt_id, uint8_t type, size_t data_size,
         }
         break;
     case PROXY_CLOSE:
-        if (fp->used) { if (close(fp->sock)) fprintf(stderr, "ERROR closing socket!\n"); fp->used = 0; }
+        if (fp->used) {
+            /* The replies the application wrote on this connection were never read (proxy.c:341-439 does not read them
+             * either): close() on a socket with unread data sends a RESET, and a reset makes the peer drop what it has not
+             * read yet -- a replay that runs ahead of the application (a joined machine's state transfer) lost the last
+             * commands of every connection that way.  So: half-close, let the application read to the end and close its
+             * side, THEN close.  Bounded; the DARE thread waits for the application here as it does in PROXY_SEND. */
+            shutdown(fp->sock, SHUT_WR);
+            char sink[4096];
+            for (int waits = 0; waits < 500 && !g_smr.terminate; ) {
+                const ssize_t r = read(fp->sock, sink, sizeof sink);
+                if (r == 0) break;                                         /* the application has closed its side */
+                if (r > 0) continue;
+                if (errno != EAGAIN && errno != EWOULDBLOCK && errno != EINTR) break;
+                struct pollfd pf = { fp->sock, POLLIN, 0 };
+                poll(&pf, 1, 10);
+                waits++;
+            }
+            if (close(fp->sock)) fprintf(stderr, "ERROR closing socket!\n");
+            fp->used = 0;
+        }
         break;
     default: break;
     }
