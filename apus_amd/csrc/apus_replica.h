@@ -49,6 +49,18 @@
 #pragma once
 #include "apus_persistent.h"
 
+/* Round 5: no per-entry ACK byte.  Rounds 3 and 4 had every follower store one byte per entry into a map in the leader's
+ * (uncached) memory next to its cumulative in-order count -- a system-scope one-byte store per entry and follower: a
+ * read-modify-write of a memory line each, and across GPUs one xGMI write transaction per entry, which is exactly what the
+ * reference does badly (rc_send_entries_reply posts one RDMA WRITE of one byte per entry, dare_ibv_rc.c:1828-1863).  The
+ * map told the leader nothing the count does not: a follower acknowledges in order or not at all (a round it declines ends
+ * its run in front of that round), so "f acknowledged entry s" IS "s < f's count" -- for the entries of a run, for what was
+ * appended before it (an exact-fit round held back, entries that had no majority), and for the ACK words the control-plane
+ * kernels read when a run ends without a majority.  -DREP_ACK_BYTES=1 keeps the byte map (A/B measurements). */
+#ifndef REP_ACK_BYTES
+#define REP_ACK_BYTES 0
+#endif
+
 #define RB_CAP    8192u          /* round doorbells in flight per follower                    */
 #define RS_CAP    16384u         /* leader: tickets in flight                                 */
 #define RQ_CAP    (1u << 16)     /* pinned request slots                                      */
@@ -1190,7 +1202,9 @@ __device__ static inline void rep_commit_pass(const EngDev &E, RepLead *LS, RepC
         C.progress = true;
         if (pr < WAVE) break;
     }
+#if REP_ACK_BYTES
     if (C.cs < C.pre_end) return;                                    /* (what was appended before this run commits first: rep_commit_pre) */
+#endif
     /* ---- the ACKs: the (quorum - 1)-th largest of the followers' in-order counts ---- */
     uint64_t acked = ~0ull;
     if (quorum > 1) {
@@ -1255,7 +1269,9 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, l
         const uint64_t st_p0 = (A.dbg & 512) ? wall_clock64() : 0;
         const uint64_t prog = s_m[M_PROG];
         const uint64_t tail = s_m[M_TAIL], fin = s_m[M_FINAL];
+#if REP_ACK_BYTES
         if (C.cs < C.pre_end) rep_commit_pre(E, C, ackb, cap, members, quorum);
+#endif
         rep_commit_pass(E, LS, C, tail, mybox, members, quorum, my_tag);
         if (lane == 0) { s_m[M_T_DONE] = C.t_done; s_m[M_CS] = C.cs; }      /* (the applier reads M_CS first) */
         if (C.slots_done != sd_pub) { sd_pub = C.slots_done; if (lane == 0) st_sys(&H->slots_done, C.slots_done + s_m[M_DROPPED]); }
@@ -1308,7 +1324,11 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, l
         for (uint32_t m = members; m; m &= m - 1) {
             const uint32_t f = (uint32_t)__builtin_ctz(m);
             const uint64_t hf = rl64u(held, (int)f);
+#if REP_ACK_BYTES
             if (in && s < hf && ld_sys8(ackb + (uint64_t)f * cap + di) == want) bits |= 1u << f;
+#else
+            if (in && s < hf) bits |= 1u << f;
+#endif
         }
         if (!in) continue;
         __hip_atomic_store((APUS_GLOBAL uint32_t *)(uintptr_t)&Md.ack[di], bits, RLX_AGENT);
@@ -1879,7 +1899,9 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
              * moved on to a newer term than the one the round comes from (the term fence, receiver side).
              * (The ACK goes first: the entry IS in this log; what follows is this server's own bookkeeping.) */
             if (sender == leader && lring && (my_sid >> 9) <= (uint64_t)u0.z + ((uint64_t)u0.w << 32)) {
+#if REP_ACK_BYTES
                 st_sys8(lack + (uint64_t)me * cap + di, rep_ack_tag(slot, E.dir_mask));
+#endif
                 if (!preset && !(A.dbg & 1)) st_sys8(lring + pos + 28 + me, 1);
                 acked = true;
             }
@@ -2187,14 +2209,23 @@ __global__ __launch_bounds__(256) void k_rep_clear_reply(const EngDev E, uint32_
     }
 }
 
-/* ===================================================================================== the launch */
-/* One launch carries every role this process hosts: [leader control, n_append append workgroups,] then
- * n_fwork workgroups per hosted follower (the first two wavefronts of a follower's first workgroup are its
- * retire and apply wavefronts).  All workgroups must be resident together: the host sizes the grid for that. */
+/* ===================================================================================== the launches */
+/* ONE RESIDENT KERNEL PER REPLICA (BASELINE configs[1] read literally; round 5).  The leader's launch is its control
+ * workgroup (sequencer, committer, applier) + n_append append workgroups; every hosted follower has a launch of its own
+ * (n_fwork workgroups: the first two wavefronts of the first workgroup are its retire and apply wavefronts) on its own
+ * stream.  Rounds 3 and 4 carried every hosted replica in one launch: one register budget for all roles -- the 165-190
+ * VGPRs of the sequencer and the append wavefronts -- so a follower's simple wavefronts ran at two per SIMD too, and the
+ * followers' workgroups took slots the append workgroups could have had (at 5 and 7 replicas most of them).  A follower's
+ * kernel is compiled for >= 4 wavefronts per SIMD now and shares compute units with the leader's workgroups.
+ * All workgroups of all launches of a run must be resident together (they wait for each other, bounded): the host sizes
+ * the grids for that (apus_gpu_rep_start). */
 #ifndef R_MIN_WG_PER_CU
 #define R_MIN_WG_PER_CU 2
 #endif
-__global__ __launch_bounds__(256, R_MIN_WG_PER_CU) void k_replica(const EngDev E, const RepArgs A)
+#ifndef R_FOLLOW_WAVES_PER_EU
+#define R_FOLLOW_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(256, R_MIN_WG_PER_CU) void k_replica_leader(const EngDev E, const RepArgs A)
 {
     __shared__ RepAppLds s_lds[4];
     __shared__ uint64_t s_h[64];
@@ -2203,48 +2234,44 @@ __global__ __launch_bounds__(256, R_MIN_WG_PER_CU) void k_replica(const EngDev E
     __shared__ uint64_t s_m[M_WORDS];
     __shared__ RepPtrLds s_pt;
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
-    uint32_t b = blockIdx.x;
-    if (A.lead_here) {
-        if (b == 0) {
-            RepHost *H = A.H;
-            if (tid < 64) s_h[tid] = E.rep[E.leader].hdr[tid];
-            if (tid < 16) s_x[tid] = 0;
-            if (tid < M_WORDS) s_m[tid] = tid == M_FINAL ? ~0ull : (tid == M_N_APPLY ? E.rep[E.leader].hdr[H_N_APPLY] : 0ull);
-            __syncthreads();
-            if (wave == 0) rep_sequencer(E, A, APUS_LDS64(s_h), APUS_LDS64(s_ao), APUS_LDS64(s_m), APUS_LDS64(s_x), (uint4 *)&s_lds[0]);   /* (the append stage's LDS is free in this workgroup) */
-            else if (wave == 1) rep_committer(E, A, APUS_LDS64(s_h), APUS_LDS64(s_m), APUS_LDS64(s_x));
-            else if (wave == 2) rep_applier(E, A, APUS_LDS64(s_h), APUS_LDS64(s_m));
-            __syncthreads();
-            if (tid == 0) {
-                /* park the followers: every round they were sent is in their doorbell ring */
-                const uint64_t t_fin = s_x[1];
-                for (uint32_t m = A.park_mask; m; m &= m - 1) {
-                    const uint32_t f = (uint32_t)__builtin_ctz(m);
-                    uint64_t sent = 0;
-                    if ((A.push_mask >> f) & 1u) { const uint64_t td = ld_agent(&A.LS->t_drop[f]); sent = td == ~0ull ? t_fin : td; }
-                    st_sys(&E.box[f]->ctrl, ((A.fruns[f] + 1) << 40) | (sent + 1));
-                }
-                st_sys(&H->exit_code, s_x[0]);
-                st_sys(&H->rounds, t_fin);
-                if (s_x[0] == R_EXIT_TIMEOUT) atomicOr(E.status, 1u << 4);
-                __threadfence_system();
-                st_sys(&H->alive, 2);
+    const uint32_t b = blockIdx.x;
+    if (b == 0) {
+        RepHost *H = A.H;
+        if (tid < 64) s_h[tid] = E.rep[E.leader].hdr[tid];
+        if (tid < 16) s_x[tid] = 0;
+        if (tid < M_WORDS) s_m[tid] = tid == M_FINAL ? ~0ull : (tid == M_N_APPLY ? E.rep[E.leader].hdr[H_N_APPLY] : 0ull);
+        __syncthreads();
+        if (wave == 0) rep_sequencer(E, A, APUS_LDS64(s_h), APUS_LDS64(s_ao), APUS_LDS64(s_m), APUS_LDS64(s_x), (uint4 *)&s_lds[0]);   /* (the append stage's LDS is free in this workgroup) */
+        else if (wave == 1) rep_committer(E, A, APUS_LDS64(s_h), APUS_LDS64(s_m), APUS_LDS64(s_x));
+        else if (wave == 2) rep_applier(E, A, APUS_LDS64(s_h), APUS_LDS64(s_m));
+        __syncthreads();
+        if (tid == 0) {
+            /* park the followers: every round they were sent is in their doorbell ring */
+            const uint64_t t_fin = s_x[1];
+            for (uint32_t m = A.park_mask; m; m &= m - 1) {
+                const uint32_t f = (uint32_t)__builtin_ctz(m);
+                uint64_t sent = 0;
+                if ((A.push_mask >> f) & 1u) { const uint64_t td = ld_agent(&A.LS->t_drop[f]); sent = td == ~0ull ? t_fin : td; }
+                st_sys(&E.box[f]->ctrl, ((A.fruns[f] + 1) << 40) | (sent + 1));
             }
-            return;
+            st_sys(&H->exit_code, s_x[0]);
+            st_sys(&H->rounds, t_fin);
+            if (s_x[0] == R_EXIT_TIMEOUT) atomicOr(E.status, 1u << 4);
+            __threadfence_system();
+            st_sys(&H->alive, 2);
         }
-        if (b <= A.n_append) {
-            if (tid < APUS_DEV_MAX_SERVERS) { s_pt.ring[tid] = E.rep[tid].ring; s_pt.box[tid] = E.box[tid]; s_pt.qbase[tid] = A.qbase[tid]; }
-            __syncthreads();
-            rep_append_wave(E, A, s_lds[wave], s_pt, (b - 1) * 4 + wave, A.n_append * 4);
-            return;
-        }
-        b -= 1 + A.n_append;
+        return;
     }
-    const uint32_t ord = b / A.n_fwork, fb = b % A.n_fwork;
-    int me = -1;
-    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
-        if (A.follow_mask & (1u << i)) { if (k == (int)ord) { me = i; break; } k++; }
-    if (me < 0) return;
+    if (tid < APUS_DEV_MAX_SERVERS) { s_pt.ring[tid] = E.rep[tid].ring; s_pt.box[tid] = E.box[tid]; s_pt.qbase[tid] = A.qbase[tid]; }
+    __syncthreads();
+    rep_append_wave(E, A, s_lds[wave], s_pt, (b - 1) * 4 + wave, A.n_append * 4);
+}
+
+__global__ __launch_bounds__(256, R_FOLLOW_WAVES_PER_EU) void k_replica_follower(const EngDev E, const RepArgs A, uint32_t me)
+{
+    __shared__ uint64_t s_m[F_WORDS];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t fb = blockIdx.x;
     const uint32_t G = A.n_fwork * 4 - 2;
     if (fb == 0) {
         if (tid < F_WORDS) {
@@ -2252,12 +2279,12 @@ __global__ __launch_bounds__(256, R_MIN_WG_PER_CU) void k_replica(const EngDev E
             s_m[tid] = tid == F_END ? mh[H_END] : tid == F_N_END ? mh[H_N_END] : tid == F_Q_RET ? ld_sys(&E.box[me]->f_seq_next) : 0ull;
         }
         __syncthreads();
-        if (wave == 0) { rep_follow_retire(E, A, (uint32_t)me, APUS_LDS64(s_m)); return; }
-        if (wave == 1) { rep_follow_apply(E, A, (uint32_t)me, APUS_LDS64(s_m)); return; }
-        rep_follow_wave(E, A, (uint32_t)me, wave - 2, G);
+        if (wave == 0) { rep_follow_retire(E, A, me, APUS_LDS64(s_m)); return; }
+        if (wave == 1) { rep_follow_apply(E, A, me, APUS_LDS64(s_m)); return; }
+        rep_follow_wave(E, A, me, wave - 2, G);
         return;
     }
-    rep_follow_wave(E, A, (uint32_t)me, fb * 4 + wave - 2, G);
+    rep_follow_wave(E, A, me, fb * 4 + wave - 2, G);
 }
 
 
