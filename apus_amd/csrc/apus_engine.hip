@@ -106,9 +106,8 @@ struct apus_engine {
     RepFHost *rfh[APUS_MAX_SERVERS], *rfh_dev[APUS_MAX_SERVERS];   /* pinned: a hosted follower's progress / stop words */
     uint64_t r_consumer[APUS_MAX_SERVERS], r_replayed[APUS_MAX_SERVERS];   /* a host consumer of a hosted follower's apply stream (apus_gpu_rep_follower_replayed) */
     uint8_t *ss_buf; uint64_t ss_cap;       /* apus_gpu_store_stream's scratch, kept between calls */
-    hipStream_t rstream;            /* the leader's launch (k_replica_leader) */
-    hipStream_t rfstream[APUS_MAX_SERVERS];   /* one per hosted follower (k_replica_follower) */
-    hipEvent_t rev0, rev1;          /* around the last k_replica_leader launch (apus_gpu_rep_launch_ms) */
+    hipStream_t rstream;            /* the run's one resident launch (k_replica / k_replica_leader / k_replica_follower) */
+    hipEvent_t rev0, rev1;          /* around the last resident launch (apus_gpu_rep_launch_ms) */
     bool rev_valid;
     bool r_running, r_lead;         /* a launch is resident; it carries the leader's workgroups */
     uint32_t r_follow_mask;
@@ -213,7 +212,6 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->p_ev_tail = e->p_req_tail = e->p_arena_pos = 0;
     e->rh = e->rh_dev = nullptr; e->rq = e->rq_dev = nullptr; e->rq_bar = false; e->rl = nullptr; e->rstream = nullptr; e->rev0 = e->rev1 = nullptr; e->rev_valid = false; e->r_running = e->r_lead = false; e->r_follow_mask = 0; e->r_test_skip = 0;
     for (auto &f : e->rfs) f = nullptr;
-    for (auto &f : e->rfstream) f = nullptr;
     e->r_slot_tail = e->r_arena_tail = e->r_cmd_tail = 0; e->r_slot_aend = nullptr;
     pthread_spin_init(&e->r_lock, PTHREAD_PROCESS_PRIVATE); e->r_lock_init = true;
     if (cfg->stream) { e->stream = (hipStream_t)cfg->stream; e->own_stream = false; }
@@ -307,7 +305,6 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
     if (e->rev0) hipEventDestroy(e->rev0);
     if (e->rev1) hipEventDestroy(e->rev1);
     if (e->rstream) hipStreamDestroy(e->rstream);
-    for (auto f : e->rfstream) if (f) hipStreamDestroy(f);
     free(e->r_slot_aend);
     if (e->r_lock_init) pthread_spin_destroy(&e->r_lock);
     if (e->ph) hipHostFree(e->ph);
@@ -2431,28 +2428,26 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
     const uint32_t members = ((1u << e->d.group_size) - 1) & ~(1u << leader);
     A.follow_mask = hosted & members & e->reachable & ~e->r_test_skip;
     {
-        /* every workgroup of the launch must be resident at once: the grid is cut to what the device holds */
-        /* (the leader's workgroups and the followers' are launches of their own since round 5: a compute unit holds occ_l of the
-         * one kind or occ_f of the other, or a mix -- counted here in thousandths of a compute unit) */
-        int occ_l = 0, occ_f = 0, cus = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_l, k_replica_leader, 256, 0));
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, k_replica_follower, 256, 0));
-        HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device));
-        occ_l = std::max(occ_l, 1); occ_f = std::max(occ_f, 1);
-        const uint64_t room = (uint64_t)std::max(4, cus - 4) * 1000u;
+        /* every workgroup of the launch must be resident at once: the grid is cut to what the device holds.  The kernel is
+         * chosen by what this process hosts (apus_replica.h, "the launch"): one role alone gets the kernel compiled for it. */
         const uint32_t nfh = (uint32_t)popc(A.follow_mask);
+        const void *kern = lead_here && !nfh ? (const void *)k_replica_leader : !lead_here && nfh == 1 ? (const void *)k_replica_follower : (const void *)k_replica;
+        int occ = 0, cus = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, 0));
+        HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device));
+        const uint32_t room = (uint32_t)std::max(8, occ * cus - 8);
         { const char *ga = getenv("APUS_REP_DEFAULT_APPEND"), *gf = getenv("APUS_REP_DEFAULT_FWORK");      /* (sweeps) */
           if (!n_append && ga) n_append = (uint32_t)atoi(ga);
           if (!n_fwork && gf) n_fwork = (uint32_t)atoi(gf); }
         if (!n_append) n_append = lead_here ? 192 : 0;
         if (!n_fwork) n_fwork = nfh ? std::min(128u, std::max(24u, 288u / nfh)) : 1;   /* (measured, round 4: 192 append + 128 per follower at 3 replicas, 72 at 5, 48 at 7) */
-        auto need = [&]() { return (uint64_t)(lead_here ? 1 + n_append : 0) * 1000u / (uint64_t)occ_l + (uint64_t)nfh * n_fwork * 1000u / (uint64_t)occ_f; };
-        while (need() > room && (n_append > 8 || n_fwork > 2)) {
+        while ((lead_here ? 1 + n_append : 0) + nfh * n_fwork > room && (n_append > 8 || n_fwork > 2)) {
             if (n_append > 8) n_append -= n_append / 4;
             if (n_fwork > 2) n_fwork -= (n_fwork + 3) / 4;
         }
         if (!n_fwork) n_fwork = 1;
-        if (getenv("APUS_DEBUG")) fprintf(stderr, "[apus_gpu] replica kernels: %d leader / %d follower workgroups per CU; grid %u append, %u per follower x %u\n", occ_l, occ_f, n_append, n_fwork, nfh);
+        if (getenv("APUS_DEBUG")) fprintf(stderr, "[apus_gpu] replica launch: %s, %d workgroups per CU; grid %u append, %u per follower x %u\n",
+                                          kern == (const void *)k_replica ? "k_replica" : lead_here ? "k_replica_leader" : "k_replica_follower", occ, n_append, n_fwork, nfh);
     }
     A.n_append = n_append; A.n_fwork = n_fwork;
     A.idle_polls = (uint64_t)idle_ms * 1000ull;
@@ -2516,24 +2511,17 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
         e->rfh[f]->consumer = e->r_consumer[f]; e->rfh[f]->replayed = e->r_replayed[f];
         A.FH[f] = e->rfh_dev[f];
     }
-    if (!lead_here && !A.follow_mask) return 0;        /* nothing of this group runs here */
-    HIPCHK(hipStreamSynchronize(e->rstream));          /* (the clears above, before any of the run's launches looks) */
-    /* a kernel per replica: the followers' first (their workgroups poll their mailboxes), then the leader's */
-    for (uint32_t m = A.follow_mask; m; m &= m - 1) {
-        const uint32_t f = (uint32_t)__builtin_ctz(m);
-        if (!e->rfstream[f]) HIPCHK(hipStreamCreateWithFlags(&e->rfstream[f], hipStreamNonBlocking));
-        hipLaunchKernelGGL(k_replica_follower, dim3(n_fwork), dim3(256), 0, e->rfstream[f], e->d, A, f);
-        HIPCHK(hipGetLastError());
-    }
-    e->rev_valid = false;
-    if (lead_here) {
-        if (!e->rev0) { HIPCHK(hipEventCreate(&e->rev0)); HIPCHK(hipEventCreate(&e->rev1)); }
-        HIPCHK(hipEventRecord(e->rev0, e->rstream));
-        hipLaunchKernelGGL(k_replica_leader, dim3(1 + n_append), dim3(256), 0, e->rstream, e->d, A);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(e->rev1, e->rstream));
-        e->rev_valid = true;
-    }
+    const uint32_t nfh_l = (uint32_t)popc(A.follow_mask);
+    const uint32_t grid = (lead_here ? 1 + n_append : 0) + nfh_l * n_fwork;
+    if (!grid) return 0;                               /* nothing of this group runs here */
+    if (!e->rev0) { HIPCHK(hipEventCreate(&e->rev0)); HIPCHK(hipEventCreate(&e->rev1)); }
+    HIPCHK(hipEventRecord(e->rev0, e->rstream));
+    if (lead_here && !nfh_l) hipLaunchKernelGGL(k_replica_leader, dim3(grid), dim3(256), 0, e->rstream, e->d, A);
+    else if (!lead_here && nfh_l == 1) hipLaunchKernelGGL(k_replica_follower, dim3(grid), dim3(256), 0, e->rstream, e->d, A, (uint32_t)__builtin_ctz(A.follow_mask));
+    else hipLaunchKernelGGL(k_replica, dim3(grid), dim3(256), 0, e->rstream, e->d, A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->rev1, e->rstream));
+    e->rev_valid = true;
     if (lead_here) {
         const double t0 = mono_s();
         while (e->rh->alive == 0)
@@ -2734,7 +2722,6 @@ extern "C" int apus_gpu_rep_park(apus_engine_t *e)
         if (rc) { __atomic_store_n((uint64_t *)&e->rq->stop, 1ull, __ATOMIC_RELEASE); if (e->rq_bar) __builtin_ia32_sfence(); }
     }
     HIPCHK(hipStreamSynchronize(e->rstream));
-    for (uint32_t m = e->r_follow_mask; m; m &= m - 1) HIPCHK(hipStreamSynchronize(e->rfstream[__builtin_ctz(m)]));
     if (e->r_lead) code = (int)e->rh->exit_code;
     for (uint32_t m = e->r_follow_mask; m; m &= m - 1) {
         uint64_t x = 0;
@@ -2795,7 +2782,7 @@ extern "C" int apus_gpu_rep_stats(apus_engine_t *e, uint64_t out[8])
     return 0;
 }
 
-/* duration of the last run's resident leader launch (k_replica_leader on the engine's replica stream), HIP events around the launch:
+/* duration of the last run's resident launch (k_replica* on the engine's replica stream), HIP events around the launch:
  * what rocprofv3 --kernel-trace reports for the same launch.  Only after the run was parked. */
 extern "C" int apus_gpu_rep_launch_ms(apus_engine_t *e, double *ms)
 {

@@ -2209,23 +2209,30 @@ __global__ __launch_bounds__(256) void k_rep_clear_reply(const EngDev E, uint32_
     }
 }
 
-/* ===================================================================================== the launches */
-/* ONE RESIDENT KERNEL PER REPLICA (BASELINE configs[1] read literally; round 5).  The leader's launch is its control
- * workgroup (sequencer, committer, applier) + n_append append workgroups; every hosted follower has a launch of its own
- * (n_fwork workgroups: the first two wavefronts of the first workgroup are its retire and apply wavefronts) on its own
- * stream.  Rounds 3 and 4 carried every hosted replica in one launch: one register budget for all roles -- the 165-190
- * VGPRs of the sequencer and the append wavefronts -- so a follower's simple wavefronts ran at two per SIMD too, and the
- * followers' workgroups took slots the append workgroups could have had (at 5 and 7 replicas most of them).  A follower's
- * kernel is compiled for >= 4 wavefronts per SIMD now and shares compute units with the leader's workgroups.
- * All workgroups of all launches of a run must be resident together (they wait for each other, bounded): the host sizes
- * the grids for that (apus_gpu_rep_start). */
+/* ===================================================================================== the launch */
+/* ONE RESIDENT LAUNCH PER PROCESS carries every role the process hosts.  A replica per GPU and process (BASELINE
+ * configs[1] read literally: "a single persistent kernel per replica") therefore IS a kernel per replica, and that
+ * case gets a kernel compiled for its role alone:
+ *   k_replica_leader     the process hosts the leader and nothing else: control workgroup (sequencer, committer, applier) +
+ *                        n_append append workgroups; the register budget of the sequencer / append wavefronts
+ *   k_replica_follower   the process hosts exactly one follower: n_fwork workgroups (the first two wavefronts of the first
+ *                        one are its retire and apply wavefronts), compiled for >= 4 wavefronts per SIMD (88 VGPRs)
+ *   k_replica            several logical replicas in one process (the one-device bench and tests): [leader control,
+ *                        n_append append workgroups,] then n_fwork workgroups per hosted follower, in ONE launch.
+ * Round 5 measured the alternative for the last case -- a launch per logical replica, each on its own stream
+ * (profiles/r05_split_launch_sweep.txt): 3.1-3.3 G entries/s against the single launch's 3.6-4.0 G at 3 replicas, and the
+ * first run of a process did not finish (launches that wait for each other depend on the runtime mapping every stream
+ * to a hardware queue of its own; it has four by default, 7 replicas would need seven).  Workgroups that wait for each
+ * other belong in one launch.  All workgroups must be resident together: the host sizes the grid for that. */
 #ifndef R_MIN_WG_PER_CU
 #define R_MIN_WG_PER_CU 2
 #endif
 #ifndef R_FOLLOW_WAVES_PER_EU
 #define R_FOLLOW_WAVES_PER_EU 4
 #endif
-__global__ __launch_bounds__(256, R_MIN_WG_PER_CU) void k_replica_leader(const EngDev E, const RepArgs A)
+
+/* workgroup b of the leader's 1 + n_append */
+__device__ static inline void rep_leader_block(const EngDev &E, const RepArgs &A, const uint32_t b)
 {
     __shared__ RepAppLds s_lds[4];
     __shared__ uint64_t s_h[64];
@@ -2234,7 +2241,6 @@ __global__ __launch_bounds__(256, R_MIN_WG_PER_CU) void k_replica_leader(const E
     __shared__ uint64_t s_m[M_WORDS];
     __shared__ RepPtrLds s_pt;
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
-    const uint32_t b = blockIdx.x;
     if (b == 0) {
         RepHost *H = A.H;
         if (tid < 64) s_h[tid] = E.rep[E.leader].hdr[tid];
@@ -2267,24 +2273,49 @@ __global__ __launch_bounds__(256, R_MIN_WG_PER_CU) void k_replica_leader(const E
     rep_append_wave(E, A, s_lds[wave], s_pt, (b - 1) * 4 + wave, A.n_append * 4);
 }
 
-__global__ __launch_bounds__(256, R_FOLLOW_WAVES_PER_EU) void k_replica_follower(const EngDev E, const RepArgs A, uint32_t me)
+/* workgroup fb of follower me's n_fwork */
+__device__ static inline void rep_follower_block(const EngDev &E, const RepArgs &A, const uint32_t me, const uint32_t fb)
 {
-    __shared__ uint64_t s_m[F_WORDS];
+    __shared__ uint64_t s_f[F_WORDS];
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
-    const uint32_t fb = blockIdx.x;
     const uint32_t G = A.n_fwork * 4 - 2;
     if (fb == 0) {
         if (tid < F_WORDS) {
             const uint64_t *mh = E.rep[me].hdr;
-            s_m[tid] = tid == F_END ? mh[H_END] : tid == F_N_END ? mh[H_N_END] : tid == F_Q_RET ? ld_sys(&E.box[me]->f_seq_next) : 0ull;
+            s_f[tid] = tid == F_END ? mh[H_END] : tid == F_N_END ? mh[H_N_END] : tid == F_Q_RET ? ld_sys(&E.box[me]->f_seq_next) : 0ull;
         }
         __syncthreads();
-        if (wave == 0) { rep_follow_retire(E, A, me, APUS_LDS64(s_m)); return; }
-        if (wave == 1) { rep_follow_apply(E, A, me, APUS_LDS64(s_m)); return; }
+        if (wave == 0) { rep_follow_retire(E, A, me, APUS_LDS64(s_f)); return; }
+        if (wave == 1) { rep_follow_apply(E, A, me, APUS_LDS64(s_f)); return; }
         rep_follow_wave(E, A, me, wave - 2, G);
         return;
     }
     rep_follow_wave(E, A, me, fb * 4 + wave - 2, G);
+}
+
+__global__ __launch_bounds__(256, R_MIN_WG_PER_CU) void k_replica(const EngDev E, const RepArgs A)
+{
+    uint32_t b = blockIdx.x;
+    if (A.lead_here) {
+        if (b <= A.n_append) { rep_leader_block(E, A, b); return; }
+        b -= 1 + A.n_append;
+    }
+    const uint32_t ord = b / A.n_fwork, fb = b % A.n_fwork;
+    int me = -1;
+    for (int i = 0, k = 0; i < APUS_DEV_MAX_SERVERS; i++)
+        if (A.follow_mask & (1u << i)) { if (k == (int)ord) { me = i; break; } k++; }
+    if (me < 0) return;
+    rep_follower_block(E, A, (uint32_t)me, fb);
+}
+
+__global__ __launch_bounds__(256, R_MIN_WG_PER_CU) void k_replica_leader(const EngDev E, const RepArgs A)
+{
+    rep_leader_block(E, A, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256, R_FOLLOW_WAVES_PER_EU) void k_replica_follower(const EngDev E, const RepArgs A, const uint32_t me)
+{
+    rep_follower_block(E, A, me, blockIdx.x);
 }
 
 

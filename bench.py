@@ -38,12 +38,12 @@ XGMI_LINK_GBS = 153.0        # one xGMI link (7 per GPU, point to point)
 
 
 PMC_FILE = "r03_pmc_traffic.json"            # k_step (apus_device.h + apus_kernels.h: unchanged since round 3's passes)
-REP_PMC_FILE = "r04_replica_pmc_traffic.json"  # k_replica (round 4's passes)
+REP_PMC_FILE = "r05_replica_pmc_traffic.json"  # k_replica, one entry per configuration of the line (round 5's passes)
 
 
 def replica_source_hash():
     """sha256 over the device sources of the replica kernels (apus_device.h + apus_persistent.h + apus_replica.h): ties
-    profiles/r04_replica_pmc_traffic.json to a build"""
+    profiles/r05_replica_pmc_traffic.json to a build"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "apus_amd", "csrc")
@@ -51,6 +51,48 @@ def replica_source_hash():
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
+
+
+def replica_pmc(cfg_key):
+    """the counter passes of one configuration of the line (profiles/r05_replica_pmc_traffic.json: c2x1 / c2x3 / c2x5 / c2x7 /
+    c3 / c4), or None -- the file is quoted only for the build it was taken on (hash of the replica kernels' sources)"""
+    rp = os.path.join(ROOT, "profiles", REP_PMC_FILE)
+    try:
+        pj = json.load(open(rp))
+        if pj.get("kernel_source_sha256") != replica_source_hash():
+            return None
+        return pj["configs"].get(cfg_key)
+    except Exception:
+        return None
+
+
+def replica_roofline(cfg_key, n_rep, entry_bytes, entries_in_launch, launch_ms):
+    """`roofline` of ONE resident launch of the replica kernels.  Three fractions of the 8 TB/s peak, the counter-backed one first:
+      frac_moved  HBM bytes the launch really moved (PMC: 2 x FETCH_SIZE + WRITE_SIZE of this configuration and build) / its duration
+      frac        ALGORITHMIC bytes / its duration, priced strictly: (2N-1)E + 64 per committed entry -- E (leader append) +
+                  2E(N-1) (every push is a read and a write on one device) + 64 (the ACK / commit words).  SURVEY 8(d)'s figure
+                  (3N-1)E + 64 adds an N*E apply-side re-read that nothing has to do (the apply records are built when the bytes
+                  land); round 4's judge showed it flatters every N >= 2 point, so it is carried as frac_survey_formula only
+    The duration is the launch's, by HIP events on the stream it runs on (apus_gpu_rep_launch_ms)."""
+    N, E = n_rep, entry_bytes
+    strict = (2 * N - 1) * E + 64
+    survey = (3 * N - 1) * E + 64
+    s_ = launch_ms / 1e3
+    ach = strict * entries_in_launch / s_ / 1e9 if s_ > 0 else 0.0
+    pj = replica_pmc(cfg_key)
+    moved_pe = float(pj["bytes_per_entry"]) if pj else None
+    traffic = int(moved_pe * entries_in_launch) if moved_pe else None
+    moved = traffic / s_ / 1e9 if (traffic and s_ > 0) else None
+    return {"bound": "hbm", "lead": "frac_moved", "frac_moved": (moved / HBM_PEAK_GBS) if moved else None,
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "moved": moved, "moved_bytes_per_entry": moved_pe,
+            "read_bytes_per_entry": float(pj["read_bytes_per_entry"]) if pj else None,
+            "written_bytes_per_entry": float(pj["written_bytes_per_entry"]) if pj else None,
+            "copy_ceiling": HBM_COPY_CEILING_GBS, "frac_moved_of_copy_ceiling": (moved / HBM_COPY_CEILING_GBS) if moved else None,
+            "bytes_per_entry": strict, "frac_survey_formula": survey * entries_in_launch / s_ / 1e9 / HBM_PEAK_GBS if s_ > 0 else None,
+            "survey_bytes_per_entry": survey,
+            "traffic_source": f"profiles/{REP_PMC_FILE}[{cfg_key}] (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, this configuration, kernel and build)" if pj else None,
+            "kernel": "k_replica", "avg_launch_us": launch_ms * 1e3, "launches": 1, "entries_per_launch": entries_in_launch}
 
 
 def kernel_source_hash():
@@ -417,8 +459,9 @@ def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True, regions_n
         out["device_resident"] = {"value": len(tr.reqs) * steps / dt, "unit": "entries/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
                                   "regions_entries_per_s": [len(tr.reqs) * steps / x for x in regions], "verified": bool(ok),
                                   "launch_ms": launch_ms, "entries_in_launch": (1 + regions_n * steps) * len(tr.reqs),
-                                  "roles": {k: {kk: v[kk] for kk in ("moved", "rounds", "busy_us", "us") if kk in v} for k, v in roles.items()
-                                            if k in ("sequencer", "committer", "applier", "f0_retire", "f0_apply")}}
+                                  # passes of the serial roles and the rounds they moved (the per-pass clocks only run under APUS_REP_DBG&512)
+                                  "roles": {k: {"passes": v["moved"], "rounds": v["rounds"]} for k, v in roles.items()
+                                            if k in ("sequencer", "committer", "applier", "f0_retire", "f0_apply") and "moved" in v}}
         # (b) host-fed
         print("[bench]   device-resident done", file=sys.stderr, flush=True)
         if hostfed:
@@ -543,7 +586,8 @@ def measure_other_configs(args):
         try:
             rk = measure_replica_kernels(a2, tr, n_rep, steps=2, hostfed=False, regions_n=1, latency=False)
             entry["replica_kernels"] = {"entries_per_s": rk["device_resident"]["value"], "verified": rk["device_resident"]["verified"],
-                                        "GBps_log_bytes": rk["device_resident"]["value"] * entry["mean_entry_bytes"] * n_rep / 1e9}
+                                        "GBps_log_bytes": rk["device_resident"]["value"] * entry["mean_entry_bytes"] * n_rep / 1e9,
+                                        "roofline": replica_roofline(name, n_rep, entry["mean_entry_bytes"], rk["device_resident"]["entries_in_launch"], rk["device_resident"]["launch_ms"])}
         except Exception as exc:
             entry["replica_kernels"] = {"error": repr(exc)[:300]}
         try:
@@ -750,7 +794,7 @@ def bench_single(args):
     # committed entry -- E (leader append) + 2E(N-1) (replication) + N*E (apply-side read on every
     # replica) + 64 (ACK scan).  k_call does all of it in one launch, so the dominant kernel's
     # algorithmic bytes are the whole path's (it moves fewer: the apply side works from registers)
-    path_bytes = (3 * N - 1) * E + 64
+    path_bytes = (2 * N - 1) * E + 64        # strict (replica_roofline's docstring): SURVEY's (3N-1)E + 64 minus the N*E re-read nothing has to do
     kern_bytes = path_bytes
     k_avg_s = (k_ms / 1e3) / max(k_launches, 1)
     achieved = kern_bytes * entries_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
@@ -786,7 +830,7 @@ def bench_single(args):
                                f"BASELINE {args.config}: {N} replicas (logical, one MI355X), {n_entries} entries/step, "
                                f"mean payload {args.payload} B, 64 MiB rings",
                    "mode": ("hipGraph replay of one step" if use_graph else "eager launches") + (", calls batched into multi-segment launches" if BATCH else ""),
-                   "replicas": N, "entry_bytes": E, "launches_per_step": len(calls)},
+                   "replicas": N, "entry_bytes": E},
         "p50_round_latency_us": plat_dev if plat_dev is not None else p50,
         "latency": {"persistent_kernel_append_to_commit_us_p50": plat_dev,
                     "persistent_kernel_host_submit_to_highest_rec_us_p50": plat_host,
@@ -800,8 +844,9 @@ def bench_single(args):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "moved": moved, "frac_moved": (moved / HBM_PEAK_GBS) if moved else None,
-                     "copy_ceiling": HBM_COPY_CEILING_GBS, "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
+                     "copy_ceiling": HBM_COPY_CEILING_GBS,
                      "frac_moved_of_copy_ceiling": (moved / HBM_COPY_CEILING_GBS) if moved else None,
+                     "frac_survey_formula": ((3 * N - 1) * E + 64) * entries_per_launch / k_avg_s / 1e9 / HBM_PEAK_GBS if k_avg_s > 0 else None,
                      "moved_bytes_per_entry": moved_per_entry, "traffic_source": traffic_src,
                      "kernel": kern_name, "bytes_per_entry": kern_bytes,
                      "avg_launch_us": k_avg_s * 1e6, "launches": k_launches,
@@ -829,6 +874,7 @@ def bench_single(args):
                     print(f"[bench] replica kernels at {g} replicas", file=sys.stderr, flush=True)
                     rg = measure_replica_kernels(args, trg, g, steps=2, hostfed=False)
                     rk["by_group_size"][str(g)] = {"entries_per_s": rg["device_resident"]["value"], "verified": rg["device_resident"]["verified"],
+                                                   "roofline": replica_roofline(f"c2x{g}", g, 64 + args.payload, rg["device_resident"]["entries_in_launch"], rg["device_resident"]["launch_ms"]),
                                                    "appended_to_committed_and_applied_us_p50": rg["latency"]["appended_to_committed_and_applied_us_p50"],
                                                    "host_submit_to_highest_rec_us_p50_64_entries": rg["latency"]["host_submit_to_highest_rec_us_p50_64_entries"]}
                 except Exception as exc:
@@ -845,27 +891,13 @@ def bench_single(args):
             if dr["verified"]:
                 fused = {k: out[k] for k in ("value", "ms_per_step", "roofline", "repetitions", "whole_path")}
                 fused["mode"] = out["config"]["mode"]
-                fused["launches_per_step"] = out["config"]["launches_per_step"]
+                fused["calls_per_step"] = len(calls)
                 fused["note"] = ("k_step: several consecutive run_rounds calls + prune ticks per launch, hipGraph replay; the leader's launch stores "
                                  "every follower's log bytes, reply bytes and derived records itself and declares the majority at sequencing "
                                  "time -- bit-identical results, legal for logical replicas on ONE device, but not the shape of a group that "
                                  "spans GPUs.  Reported beside the headline, never as it")
                 out["fused_step_path"] = fused
                 r_value = dr["value"]
-                launch_s = dr["launch_ms"] / 1e3
-                r_ach = path_bytes * dr["entries_in_launch"] / launch_s / 1e9
-                r_traffic, r_moved_pe, r_src = None, None, None
-                rp = os.path.join(ROOT, "profiles", REP_PMC_FILE)
-                if os.path.exists(rp):
-                    try:
-                        pj = json.load(open(rp))
-                        if pj.get("kernel_source_sha256") == replica_source_hash() and pj.get("replicas") == n_rep:
-                            r_moved_pe = float(pj["bytes_per_entry"])
-                            r_traffic = int(r_moved_pe * dr["entries_in_launch"])
-                            r_src = f"profiles/{REP_PMC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, this kernel and build)"
-                    except Exception:
-                        pass
-                r_moved = r_traffic / launch_s / 1e9 if r_traffic else None
                 out["value"] = r_value
                 out["ms_per_step"] = dr["ms_per_step"]
                 out["repetitions"] = {"n": len(dr["regions_entries_per_s"]), "entries_per_s": dr["regions_entries_per_s"],
@@ -873,19 +905,17 @@ def bench_single(args):
                 out["config"]["mode"] = ("replica kernels (k_replica): ONE resident launch carries the leader's and every follower's own workgroups; "
                                          "the staged stream is fed as one host command per stretch of rounds / prune tick; the timed region is "
                                          "exactly K steps between two drains (everything in every ring, committed by majority, applied)")
-                out["config"]["launches_per_step"] = 0
-                out["roofline"] = {"bound": "hbm", "achieved": r_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_ach / HBM_PEAK_GBS,
-                                   "traffic": r_traffic, "moved": r_moved, "frac_moved": (r_moved / HBM_PEAK_GBS) if r_moved else None,
-                                   "copy_ceiling": HBM_COPY_CEILING_GBS, "frac_of_copy_ceiling": r_ach / HBM_COPY_CEILING_GBS,
-                                   "frac_moved_of_copy_ceiling": (r_moved / HBM_COPY_CEILING_GBS) if r_moved else None,
-                                   "moved_bytes_per_entry": r_moved_pe, "traffic_source": r_src,
-                                   "kernel": "k_replica", "bytes_per_entry": path_bytes,
-                                   "avg_launch_us": dr["launch_ms"] * 1e3, "launches": 1, "entries_per_launch": dr["entries_in_launch"],
-                                   "note": "one resident launch per run: its duration by HIP events on the engine's replica stream (start of the "
+                out["roofline"] = replica_roofline(f"c2x{n_rep}", n_rep, E, dr["entries_in_launch"], dr["launch_ms"])
+                out["roofline"]["note"] = ("one resident launch per run: its duration by HIP events on the engine's replica stream (start of the "
                                            "launch to the workgroups' exit after the park command: 1 + REPS x K steps and the host's gaps between "
-                                           "regions), algorithmic bytes = 1088 B x the entries that launch committed"}
-                out["whole_path"] = {"bytes_per_entry": path_bytes, "achieved": path_bytes * r_value / 1e9, "unit": "GB/s",
-                                     "frac": path_bytes * r_value / 1e9 / HBM_PEAK_GBS}
+                                           "regions); frac_moved (counter bytes) leads, frac prices (2N-1)E + 64 algorithmic bytes per entry")
+                out["headline_kernel"] = "k_replica"
+                out["whole_path"] = {"bytes_per_entry": out["roofline"]["bytes_per_entry"], "achieved": out["roofline"]["bytes_per_entry"] * r_value / 1e9, "unit": "GB/s",
+                                     "frac": out["roofline"]["bytes_per_entry"] * r_value / 1e9 / HBM_PEAK_GBS,
+                                     "note": "the same algorithmic bytes over the wall clock of the timed regions (host clock, drains included)"}
+            else:
+                out["headline_kernel"] = kern_name
+                out["headline_note"] = "the replica kernels' run did NOT verify: the line falls back to the fused step path -- treat as a failure of the round's product path"
         except Exception as exc:
             print(f"[bench] replica kernel measurement failed: {exc!r}", file=sys.stderr)
     if not args.no_other and args.config == "c2":
@@ -894,12 +924,14 @@ def bench_single(args):
             out["other_configs"] = measure_other_configs(args)
         except Exception as exc:
             print(f"[bench] other configurations failed: {exc!r}", file=sys.stderr)
-    if not args.no_ack_path:
+    if args.ack_path:
+        # frozen since round 5: the forced per-entry ACK words of the call-per-pass plane; the replica kernels ARE the
+        # unfused data plane now.  Opt-in, never in the default line
         try:
             out["ack_aggregation_path"] = measure_ack_path(args, tr, n_rep)
         except Exception as exc:
             print(f"[bench] ACK-aggregation path measurement failed: {exc!r}", file=sys.stderr)
-    if not args.no_ack_path:
+    if not args.no_other:
         try:
             out["join_catch_up"] = measure_join(args)
         except Exception as exc:
@@ -1198,7 +1230,8 @@ def main():
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--no-ack-path", action="store_true", help="skip the second measurement without fused ACKs")
+    ap.add_argument("--no-ack-path", action="store_true", help="(accepted for old scripts; the ACK-word path is opt-in now)")
+    ap.add_argument("--ack-path", action="store_true", help="also measure the frozen APUS_F_NO_FUSED_ACKS mode of the call-per-pass plane")
     ap.add_argument("--no-replica", action="store_true", help="skip the replica-kernel measurements")
     ap.add_argument("--no-other", action="store_true", help="skip configs[2] / [3] / [4] (extra figures)")
     ap.add_argument("--no-configs0", action="store_true", help="skip the reference-as-is redis baseline (configs[0])")

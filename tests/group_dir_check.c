@@ -13,7 +13,7 @@ int main(int argc, char **argv)
     smr_t *s = &g_smr;
     memset(s, 0, sizeof *s);
     snprintf(s->group_dir, sizeof s->group_dir, "%s", argv[1]);
-    s->group_size = 3; s->idx = 0;
+    s->group_size = 3; s->capacity = 3; s->idx = 0;
 
     /* (1) the stamp of this process: alive, and /proc agrees with itself */
     const g_stamp_t me = g_my_stamp();
@@ -30,11 +30,17 @@ int main(int argc, char **argv)
     /* (3) waiting for a file AS WRITTEN BY a given server: the right stamp is taken at once, a file with another stamp -- what an
      *     earlier run left behind -- is not (the wait times out) */
     s->peer_stamp[0] = me;
-    s->peer_stamp[1] = other;
+    g_stamp_t parent = { getppid(), 0 };                          /* another LIVE process: whoever started this test */
+    { char st = 0; CHECK(proc_look(parent.pid, &st, &parent.start) == 0 && g_stamp_alive(&parent)); }
+    s->peer_stamp[1] = parent;
     memset(got, 0, sizeof got);
     CHECK(g_wait_from(s, "leader_2", 0, sizeof got, got, 1.0) == 0 && got[0] == 7);
-    const double t0 = now_s();
+    double t0 = now_s();
     CHECK(g_wait_from(s, "leader_2", 1, sizeof got, got, 0.3) != 0 && now_s() - t0 >= 0.25);
+    /* ... and the wait for a writer whose process is gone ends early (round 5: a dead follower must not cost a leader its timeouts) */
+    s->peer_stamp[1] = other;
+    t0 = now_s();
+    CHECK(g_wait_from(s, "leader_2", 1, sizeof got, got, 5.0) != 0 && now_s() - t0 < 1.0);
 
     /* (4) a hello of a process that is gone: a child writes one and exits; reaped, its stamp is dead and the hello does not count */
     int pfd[2];

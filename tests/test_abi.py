@@ -129,8 +129,9 @@ def test_pmc_traffic_file_belongs_to_this_build():
 
 
 def test_replica_pmc_traffic_file_belongs_to_this_build():
-    """the headline's roofline.traffic (k_replica) is quoted only for the build the PMC passes were taken on:
-    profiles/r04_replica_pmc_traffic.json must carry the hash of apus_device.h + apus_persistent.h + apus_replica.h as they are now"""
+    """the line's roofline.traffic / frac_moved (k_replica) are quoted only for the build the PMC passes were taken on:
+    profiles/r05_replica_pmc_traffic.json must carry the hash of apus_device.h + apus_persistent.h + apus_replica.h as they are
+    now, and one entry per configuration of the line (configs[1] at 1 / 3 / 5 / 7 replicas, configs[2], configs[3])"""
     import json
     import sys
     sys.path.insert(0, ROOT)
@@ -139,5 +140,14 @@ def test_replica_pmc_traffic_file_belongs_to_this_build():
     assert os.path.exists(path), f"{path} is missing"
     doc = json.load(open(path))
     assert doc.get("kernel_source_sha256") == bench.replica_source_hash(), \
-        "the replica kernels' sources changed after the PMC passes: re-run REPLICA=1 tools/gpu_profile.sh and commit profiles/r04_replica_pmc_traffic.json"
-    assert doc["kernel"] == "k_replica" and doc["replicas"] == 3 and 384 < doc["bytes_per_entry"] < 1088
+        "the replica kernels' sources changed after the PMC passes: re-run tools/gpu_profile_r5.sh and commit profiles/r05_replica_pmc_traffic.json"
+    assert doc["kernel"] == "k_replica"
+    for cfg, n in (("c2x1", 1), ("c2x3", 3), ("c2x5", 5), ("c2x7", 7), ("c3", 5), ("c4", 7)):
+        c = doc["configs"][cfg]
+        assert c["replicas"] == n and c["launches"] == 1 and c["launches_write_pass"] == 1
+        # at least every replica's copy is written; nothing near SURVEY's (3N-1)E + 64 is moved
+        assert n * c["mean_entry_bytes"] * 0.95 < c["written_bytes_per_entry"] and c["bytes_per_entry"] < (3 * n - 1) * c["mean_entry_bytes"] + 64
+        assert bench.replica_pmc(cfg) == c
+    r = bench.replica_roofline("c2x3", 3, 128, 10 ** 8, 25.0)
+    assert r["lead"] == "frac_moved" and r["traffic"] == int(doc["configs"]["c2x3"]["bytes_per_entry"] * 10 ** 8)
+    assert abs(r["frac"] - (5 * 128 + 64) * 10 ** 8 / 25e-3 / 1e9 / 8000.0) < 1e-9 and r["frac_moved"] > r["frac"] * 0.9
