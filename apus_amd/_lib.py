@@ -13,7 +13,7 @@ vp = C.c_void_p
 class IpcReplica(C.Structure):
     """apus_ipc_replica_t (include/apus_gpu.h)"""
     _fields_ = [("handle", (u8 * 64) * 8), ("log_len", u64), ("dir_cap", u32), ("replica", u32),
-                ("device", C.c_int32), ("pad", u32)]
+                ("device", C.c_int32), ("fences", u32)]
 
 
 class Cfg(C.Structure):
@@ -113,6 +113,11 @@ SIGNATURES = {
     "apus_gpu_rep_req_ring_kind": (C.c_int, [vp]),
     "apus_gpu_rep_roundtrip": (C.c_int, [vp, vp, u32, vp, u64, u32, vp]),
     "apus_gpu_unmap_replica": (C.c_int, [vp, u32]),
+    "apus_gpu_selftest": (C.c_int, [vp, u32, u32, u32, u64, u32, u32, C.POINTER(u64)]),
+    "apus_gpu_ring_alloc_kind": (C.c_int, [vp]),
+    "apus_gpu_fence_replica": (C.c_int, [vp, u32, C.POINTER(IpcReplica)]),
+    "apus_gpu_remap_fenced": (C.c_int, [vp, C.POINTER(IpcReplica)]),
+    "apus_gpu_read_retired_ring": (C.c_int, [vp, u32, u32, u64, u64, vp]),
     "apus_gpu_last_entry": (C.c_int, [vp, u32, C.POINTER(u64)]),
     "apus_gpu_rep_box_words": (C.c_int, [vp, u32, u32, C.POINTER(u64)]),
 }

@@ -19,6 +19,7 @@
 #include "apus_persistent.h"
 #include "apus_replica.h"
 #include "apus_quirks.h"
+#include "apus_selftest.h"
 #include "apus_members.h"
 #include <pthread.h>
 #include <time.h>
@@ -107,6 +108,12 @@ struct apus_engine {
     uint64_t r_consumer[APUS_MAX_SERVERS], r_replayed[APUS_MAX_SERVERS];   /* a host consumer of a hosted follower's apply stream (apus_gpu_rep_follower_replayed) */
     uint8_t *ss_buf; uint64_t ss_cap;       /* apus_gpu_store_stream's scratch, kept between calls */
     hipStream_t rstream;            /* the run's one resident launch (k_replica / k_replica_leader / k_replica_follower) */
+    /* apus_gpu_fence_replica: the allocations a hosted replica's ring and mailbox have LEFT (a deposed leader's mapping still
+     * leads there; kept so that its stores hit memory that exists and nobody reads), oldest first */
+    std::vector<uint8_t *> retired_ring[APUS_MAX_SERVERS];
+    std::vector<RepBox *> retired_box[APUS_MAX_SERVERS];
+    int ring_alloc;                 /* 0 hipMalloc, 1 fine-grained, 2 uncached (APUS_RING_ALLOC) */
+    uint32_t fences[APUS_MAX_SERVERS];          /* hosted: fences so far; imported: the exporter's count as mapped here */
     hipEvent_t rev0, rev1;          /* around the last resident launch (apus_gpu_rep_launch_ms) */
     bool rev_valid;
     bool r_running, r_lead;         /* a launch is resident; it carries the leader's workgroups */
@@ -212,6 +219,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->p_ev_tail = e->p_req_tail = e->p_arena_pos = 0;
     e->rh = e->rh_dev = nullptr; e->rq = e->rq_dev = nullptr; e->rq_bar = false; e->rl = nullptr; e->rstream = nullptr; e->rev0 = e->rev1 = nullptr; e->rev_valid = false; e->r_running = e->r_lead = false; e->r_follow_mask = 0; e->r_test_skip = 0;
     for (auto &f : e->rfs) f = nullptr;
+    for (auto &f : e->fences) f = 0;
     e->r_slot_tail = e->r_arena_tail = e->r_cmd_tail = 0; e->r_slot_aend = nullptr;
     pthread_spin_init(&e->r_lock, PTHREAD_PROCESS_PRIVATE); e->r_lock_init = true;
     if (cfg->stream) { e->stream = (hipStream_t)cfg->stream; e->own_stream = false; }
@@ -228,6 +236,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     if (cfg->flags & APUS_F_REF_QUIRKS) { if (dev_alloc(e, &e->d_quirk, 16)) { delete e; return APUS_E_NOMEM; } }
     if (dev_alloc(e, &e->d_cfgj, sizeof(CfgJournal))) { delete e; return APUS_E_NOMEM; }
     e->local_mask = 0; e->imported_mask = 0;
+    { const char *ra = getenv("APUS_RING_ALLOC"); e->ring_alloc = (ra && !strcmp(ra, "finegrained")) ? 1 : (ra && !strcmp(ra, "uncached")) ? 2 : 0; }
     e->reachable = (1u << cfg->group_size) - 1;
     e->d.reachable = e->reachable;
     int rc = 0;
@@ -237,7 +246,9 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
         e->local_mask |= 1u << i;
         RepDev &r = e->d.rep[i];
         r.idx = i;
-        if ((rc = dev_alloc(e, &r.ring, L + 4096))) break;
+        /* the log ring: ordinary device memory -- unless first contact between two devices showed that a peer's stores are not
+         * what the owner's resident kernel reads (apus_selftest.h; bench.py then sets APUS_RING_ALLOC and starts again) */
+        if ((rc = dev_alloc(e, &r.ring, L + 4096, true, e->ring_alloc == 1 ? hipDeviceMallocFinegrained : e->ring_alloc == 2 ? hipDeviceMallocUncached : 0u))) break;
         /* control blocks live in uncached device memory: stores reach memory without a release, so
          * that blocks of a LATER segment of the same launch (k_step) can read them with bypassing loads */
         if ((rc = dev_alloc(e, &r.hdr, sizeof(uint64_t) * 64, true, hipDeviceMallocUncached))) break;
@@ -410,7 +421,7 @@ extern "C" int apus_gpu_export_replica(apus_engine_t *e, uint32_t replica, apus_
         HIPCHK(hipIpcGetMemHandle(&h, bufs[k]));
         memcpy(out->handle[k], &h, sizeof h);
     }
-    out->log_len = e->d.log_len; out->dir_cap = e->dir_cap; out->replica = replica; out->device = e->cfg.device;
+    out->log_len = e->d.log_len; out->dir_cap = e->dir_cap; out->replica = replica; out->device = e->cfg.device; out->fences = e->fences[replica];
     return 0;
 }
 
@@ -490,6 +501,91 @@ extern "C" int apus_gpu_rep_box_words(apus_engine_t *e, uint32_t replica, uint32
     return 0;
 }
 
+/* ---- the receiver's fence (rc_revoke_log_access, dare_ibv_rc.c:2156-2243) for peer-mapped groups --------------------
+ * The reference's voters reset the QPs of the old leader: its WRITEs bounce.  A buffer another process has mapped cannot be
+ * taken back, but it can be LEFT: the replica this engine hosts moves the two buffers peers store into during a run -- its
+ * log ring and its mailbox (doorbells, commit bell, cumulative ACKs) -- to fresh allocations (device copies of the old
+ * ones).  Every mapping another process holds of the old ones, a deposed leader's first of all, leads to memory nobody
+ * reads any more; its kernel may go on storing for as long as it likes.  `out` = the replica's handles with the two new
+ * buffers (the other six unchanged): the members of the new term map them with apus_gpu_remap_fenced.  The old
+ * allocations stay allocated (a stale writer must hit memory that exists); from the fifth fence on the oldest pair is
+ * reused -- a leader deposed four terms ago that still stores is outside the failure model.
+ * The buffers peers write only from control-plane launches (control block, directory, apply stream: log adjustment, JOIN)
+ * stay where they are: those launches sit behind the sender's term check (k_fence_check).
+ * Not while a resident kernel or a batch is open; graphs captured before the fence hold the old pointers (peer-mapped groups
+ * capture none). */
+#define APUS_FENCE_KEEP 4u
+extern "C" int apus_gpu_fence_replica(apus_engine_t *e, uint32_t replica, apus_ipc_replica_t *out)
+{
+    if (!e || replica >= e->cfg.group_size) return APUS_E_ARG;
+    if (!((e->local_mask >> replica) & 1u) || ((e->imported_mask >> replica) & 1u) || !e->d.rep[replica].ring || !e->d.box[replica]) return APUS_E_STATE;
+    if (e->r_running || e->p_running || e->batching || !e->graphs.empty()) return APUS_E_STATE;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const uint64_t ring_bytes = e->d.log_len + 4096;
+    uint8_t *nring = nullptr; RepBox *nbox = nullptr;
+    if (e->retired_ring[replica].size() >= APUS_FENCE_KEEP) {
+        nring = e->retired_ring[replica].front(); e->retired_ring[replica].erase(e->retired_ring[replica].begin());
+        nbox = e->retired_box[replica].front(); e->retired_box[replica].erase(e->retired_box[replica].begin());
+    } else {
+        int rc;
+        if ((rc = dev_alloc(e, &nring, ring_bytes, false, e->ring_alloc == 1 ? hipDeviceMallocFinegrained : e->ring_alloc == 2 ? hipDeviceMallocUncached : 0u))) return rc;
+        if ((rc = dev_alloc(e, &nbox, sizeof(RepBox), false, hipDeviceMallocUncached))) return rc;
+    }
+    uint8_t *oring = e->d.rep[replica].ring; RepBox *obox = e->d.box[replica];
+    HIPCHK(hipMemcpyAsync(nring, oring, ring_bytes, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(nbox, obox, sizeof(RepBox), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->retired_ring[replica].push_back(oring); e->retired_box[replica].push_back(obox);
+    e->d.rep[replica].ring = nring; e->d.box[replica] = nbox;
+    e->fences[replica]++;
+    return out ? apus_gpu_export_replica(e, replica, out) : 0;
+}
+
+/* a member of the new term maps the two buffers a peer's fence moved (handles 0 and 6 of `in`), and drops its mappings of the
+ * ones the peer left.  The replica must be imported already (apus_gpu_import_replica). */
+extern "C" int apus_gpu_remap_fenced(apus_engine_t *e, const apus_ipc_replica_t *in)
+{
+    if (!e || !in || in->replica >= e->cfg.group_size) return APUS_E_ARG;
+    if (in->log_len != e->d.log_len || in->dir_cap != e->dir_cap) return APUS_E_ARG;
+    if (!((e->imported_mask >> in->replica) & 1u)) return APUS_E_STATE;
+    if (in->fences == e->fences[in->replica]) return 0;            /* nothing moved since these buffers were mapped */
+    if (e->r_running || e->p_running || e->batching) return APUS_E_STATE;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const uint32_t which[2] = { 0, 6 };
+    void *np[2] = { nullptr, nullptr };
+    for (int k = 0; k < 2; k++) {
+        hipIpcMemHandle_t h;
+        memcpy(&h, in->handle[which[k]], sizeof h);
+        if (hipIpcOpenMemHandle(&np[k], h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            fprintf(stderr, "[apus_gpu] hipIpcOpenMemHandle failed for replica %u's fenced buffer %u: %s\n", in->replica, which[k], hipGetErrorString(hipGetLastError()));
+            if (k) hipIpcCloseMemHandle(np[0]);
+            return APUS_E_HIP;
+        }
+    }
+    void *old[2] = { e->d.rep[in->replica].ring, e->d.box[in->replica] };
+    for (int k = 0; k < 2; k++) {
+        if (old[k] == np[k]) { continue; }                       /* (the runtime hands an open mapping out again: nothing moved) */
+        for (size_t j = 0; j < e->ipc_ptrs.size(); j++)
+            if (e->ipc_ptrs[j] == old[k]) { hipIpcCloseMemHandle(old[k]); e->ipc_ptrs.erase(e->ipc_ptrs.begin() + (long)j); break; }
+        e->ipc_ptrs.push_back(np[k]);
+    }
+    e->d.rep[in->replica].ring = (uint8_t *)np[0];
+    e->d.box[in->replica] = (RepBox *)np[1];
+    e->fences[in->replica] = in->fences;
+    return 0;
+}
+
+/* tests: `n` bytes at `off` of the ring replica `replica` left `back` fences ago (1 = the last one) -- where a deposed
+ * leader's stores went */
+extern "C" int apus_gpu_read_retired_ring(apus_engine_t *e, uint32_t replica, uint32_t back, uint64_t off, uint64_t n, void *dst)
+{
+    if (!e || replica >= e->cfg.group_size || !dst || back == 0 || back > e->retired_ring[replica].size() || off + n > e->d.log_len) return APUS_E_ARG;
+    HIPCHK(hipMemcpy(dst, e->retired_ring[replica][e->retired_ring[replica].size() - back] + off, n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int apus_gpu_import_replica(apus_engine_t *e, const apus_ipc_replica_t *in)
 {
     if (!e || !in || in->replica >= e->cfg.group_size) return APUS_E_ARG;
@@ -513,6 +609,7 @@ extern "C" int apus_gpu_import_replica(apus_engine_t *e, const apus_ipc_replica_
     e->d.box[in->replica] = (RepBox *)p[6]; e->d.ackb[in->replica] = (uint8_t *)p[7];
     e->local_mask |= 1u << in->replica;
     e->imported_mask |= 1u << in->replica;
+    e->fences[in->replica] = in->fences;
     return 0;
 }
 
@@ -2651,15 +2748,23 @@ extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uin
         if (reqs[g].payload_off + reqs[g].len > arena_bytes) return APUS_E_ARG;
         if (reqs[g].type == APUS_NOOP || reqs[g].type == APUS_CONFIG || reqs[g].type == APUS_HEAD || reqs[g].type > 15) return APUS_E_ARG;
     }
-    constexpr uint32_t BLK = 64;
+    /* A block = the slots one fetch-and-add hands out and ONE fence covers.  Through the BAR every fence waits for the
+     * write-combining buffers to drain (~0.35 us): at 64 slots per block and two fences per block a producer thread spent
+     * 0.7 of its 0.83 us per block in fences (round 4: 77 M entries/s with one producer).  Round 5: 256 slots per block,
+     * and the fence behind a block's publish words is the NEXT block's payload fence (the words leave with it at the
+     * latest; the last block of the call has its own) -- one fence per 256 entries.  A block's publish words never leave
+     * before its payloads: the fence between them stays.  APUS_REP_SUBMIT_BLOCK: measurements. */
+    static const uint32_t BLK = []() { const char *v = getenv("APUS_REP_SUBMIT_BLOCK"); const int x = v ? atoi(v) : 0; return (uint32_t)(x >= 1 && x <= 1024 ? x : 256); }();
     uint32_t g = 0;
+    bool words_pending = false;
     while (g < n) {
         if (reqs[g].len > R_INLINE) {
             uint64_t slot; void *dst;
             int rc = rep_reserve_arena(e, reqs[g].len, &slot, &dst);
-            if (rc) return rc;
+            if (rc) { if (words_pending && e->rq_bar) __builtin_ia32_sfence(); return rc; }
             memcpy(dst, arena + reqs[g].payload_off, reqs[g].len);
             if ((rc = apus_gpu_rep_publish(e, slot, dst, reqs[g].req_id, reqs[g].clt_id, reqs[g].type, reqs[g].len))) return rc;
+            words_pending = false;                         /* (publish fences) */
             g++;
             continue;
         }
@@ -2667,9 +2772,7 @@ extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uin
         while (run < BLK && g + run < n && reqs[g + run].len <= R_INLINE) run++;
         uint64_t s0;
         int rc = rep_reserve_inline(e, run, &s0);
-        if (rc) return rc;
-        /* the whole block's descriptors and payloads, ONE fence, then its publish words: through the BAR every fence waits for
-         * the write-combining buffers to drain (~0.35 us; two per slot made a round of 64 cost 50 us) */
+        if (rc) { if (words_pending && e->rq_bar) __builtin_ia32_sfence(); return rc; }
         for (uint32_t i = 0; i < run; i++) {
             const apus_req_t &q = reqs[g + i];
             RepSlot &sl = e->rq->slot[(s0 + i) % RQ_CAP];
@@ -2678,12 +2781,13 @@ extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uin
             d.req_id = q.req_id; d.pay16_type = R_PAY_INLINE | ((uint32_t)q.type << 28); d.len = q.len; d.clt_id = q.clt_id;
             sl.d = d;
         }
-        if (e->rq_bar) __builtin_ia32_sfence();
+        if (e->rq_bar) __builtin_ia32_sfence();            /* the payloads and descriptors (and the block before's publish words) */
         for (uint32_t i = 0; i < run; i++)
             __atomic_store_n((uint32_t *)&e->rq->ready_len[(s0 + i) % RQ_CAP], (rep_slot_tag(s0 + i) << 16) | reqs[g + i].len, __ATOMIC_RELEASE);
-        if (e->rq_bar) __builtin_ia32_sfence();
+        words_pending = true;
         g += run;
     }
+    if (words_pending && e->rq_bar) __builtin_ia32_sfence();
     return 0;
 }
 
@@ -2894,6 +2998,50 @@ extern "C" int apus_gpu_calib_pingpong(apus_engine_t *e, uint32_t me, uint32_t p
     }
     return 0;
 }
+
+/* First contact between two devices (apus_selftest.h): roles bit 0 = this process pushes `rounds` rounds of 8 KiB into
+ * replica `owner`'s ring + doorbells into its mailbox, bit 1 = this process's RESIDENT kernel checks them (both: one launch on
+ * one device).  The two processes call it at the same time.  out: [0] rounds checked, [1] 16-byte units that differed,
+ * [2] first round that differed + 1 (0: none), [3] waits that timed out.  What the test touched (the first regions x 8 KiB of
+ * the owner's ring, both mailboxes' doorbell lines) is cleared afterwards: run it before the group starts. */
+extern "C" int apus_gpu_selftest(apus_engine_t *e, uint32_t pusher, uint32_t owner, uint32_t roles, uint64_t rounds, uint32_t regions,
+                                 uint32_t timeout_ms, uint64_t out[4])
+{
+    const uint32_t mode = roles & ~3u;                     /* (experiments: 16 = a release behind the pusher's stores, 32 = an invalidate in front of the checker's loads) */
+    roles &= 3u;
+    if (!e || !out || pusher >= e->cfg.group_size || owner >= e->cfg.group_size || pusher == owner || !roles || !rounds) return APUS_E_ARG;
+    if (!e->d.rep[owner].ring || !e->d.box[owner] || !e->d.box[pusher]) return APUS_E_ARG;
+    if (regions < 64 || regions > RB_CAP || (uint64_t)regions * ST_ROUND_BYTES > e->d.log_len) return APUS_E_ARG;
+    if (e->r_running || e->p_running || e->batching) return APUS_E_STATE;
+    unsigned long long *d_res = nullptr;
+    HIPCHK(hipMalloc((void **)&d_res, 16 * sizeof(unsigned long long)));
+    const unsigned long long init[16] = { 0, 0, ~0ull, 0 };
+    HIPCHK(hipMemcpyAsync(d_res, init, sizeof init, hipMemcpyHostToDevice, e->stream));
+    const uint32_t wgs = 16;                              /* 64 wavefronts per role */
+    hipLaunchKernelGGL(k_selftest, dim3(roles == 3 ? 2 * wgs : wgs), dim3(256), 0, e->stream, e->d, pusher, owner, roles | mode, rounds, regions,
+                       0xA905000500000000ull ^ rounds, (uint64_t)timeout_ms * 1500ull, d_res);
+    hipError_t er = hipStreamSynchronize(e->stream);
+    unsigned long long h[16] = { 0 };
+    if (er == hipSuccess) er = hipMemcpy(h, d_res, sizeof h, hipMemcpyDeviceToHost);
+    hipFree(d_res);
+    if (er != hipSuccess) return APUS_E_HIP;
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2] == ~0ull ? 0 : h[2]; out[3] = h[3];
+    if (h[1] && getenv("APUS_DEBUG"))
+        fprintf(stderr, "[apus_gpu] selftest %u -> %u: first difference seen in round %llu unit %llu: there %016llx %016llx, pushed %016llx %016llx\n", pusher, owner,
+                h[4] - 1, h[5], h[6], h[7], h[8], h[9]);
+    /* leave no granule behind that a run's doorbell numbering could meet: whoever OWNS a buffer clears it */
+    const bool own_owner = ((e->local_mask >> owner) & 1u) && !((e->imported_mask >> owner) & 1u);
+    const bool own_pusher = ((e->local_mask >> pusher) & 1u) && !((e->imported_mask >> pusher) & 1u);
+    if ((roles & 2u) && own_owner) {
+        HIPCHK(hipMemsetAsync(e->d.rep[owner].ring, 0, (size_t)regions * ST_ROUND_BYTES, e->stream));
+        HIPCHK(hipMemsetAsync(e->d.box[owner]->rnd, 0, sizeof e->d.box[owner]->rnd, e->stream));
+    }
+    if ((roles & 1u) && own_pusher) HIPCHK(hipMemsetAsync(e->d.box[pusher]->rnd, 0, sizeof e->d.box[pusher]->rnd, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+/* how this engine's log rings are allocated: 0 ordinary device memory, 1 fine-grained, 2 uncached (APUS_RING_ALLOC at create) */
+extern "C" int apus_gpu_ring_alloc_kind(apus_engine_t *e) { return e ? e->ring_alloc : APUS_E_ARG; }
 
 /* write-through 16-byte stores of `bytes` into replica `peer`'s ring, `iters` times, HIP events around each pass:
  * out_gbps[i] = GB/s of pass i.  The ring's contents are destroyed: calibrate before the group starts (or reset). */

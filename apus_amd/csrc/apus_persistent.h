@@ -97,7 +97,7 @@ __device__ static inline void st16_agent(uint8_t *p, uint4 v)
 {
     if ((((uintptr_t)p) & 3) == 0) {
         v4u_t d = {v.x, v.y, v.z, v.w};
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(d) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
     } else {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         for (int i = 0; i < 16; i++)

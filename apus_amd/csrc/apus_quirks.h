@@ -19,6 +19,10 @@
  * passes need nothing special: they commit by slot number, and apply from the leader's own apply slot.
  * A CONFIG entry in that position is left alone (the leader's apply of a CONFIG entry appends the next one,
  * dare_server.c:1859-1932: that belongs to the control rounds). */
+#ifndef APUS_F_REF_QUIRKS
+#define APUS_F_REF_QUIRKS 4u      /* apus_cfg_t.flags: the parity harness's diagnostic, not part of the public ABI (include/apus_gpu.h) */
+#endif
+
 #pragma once
 #include "apus_kernels.h"
 

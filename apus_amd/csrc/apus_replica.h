@@ -66,7 +66,13 @@
 #define RQ_CAP    (1u << 16)     /* pinned request slots                                      */
 #define RA_CAP    (64u << 20)    /* pinned payload arena (bytes)                              */
 #define RC_CAP    256u           /* host command ring                                         */
-#define R_WIN     8              /* 64-slot windows of the request ring read per PCIe round trip */
+#ifndef R_WIN
+#define R_WIN     32             /* 64-slot windows of the request ring the sequencer reads per round trip.  Round 5, four producers, M entries/s
+                                  * host-fed: 8 windows 167, 16 windows 242, 32 windows 300 (a pass costs ~1.8 us + ~0.17 us per window; the next
+                                  * pass's words are asked for while this pass's record and tickets are stored).  The two 32-word register
+                                  * arrays take the leader's kernels to 219 VGPRs: two wavefronts per SIMD, which is what a launch of at most two
+                                  * workgroups per compute unit has anyway (staged throughput unchanged: profiles/r05_host_fed_windows.txt) */
+#endif
 #ifndef R_SUB
 #define R_SUB     4              /* 64-round chunks a serial role handles per memory round trip  */
 #endif
@@ -298,18 +304,23 @@ __device__ static inline uint4 payload_mask(uint4 v, uint32_t so, uint32_t P, ui
     else if (so == 49) lo |= (uint64_t)((len16 >> 8) & 0xFFu);
     return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
-/* 16 bytes, dword aligned, written through (system scope): st16_agent without its byte-wise path for unaligned addresses */
+/* 16 bytes, dword aligned, written through (system scope): st16_agent without its byte-wise path for unaligned addresses.
+ * (s_nop 1 INSIDE the string: a VMEM store of more than 64 bits reads its data registers a wait state after it issues, and the
+ * compiler pads nothing around an asm statement -- a VALU write of those registers straight behind the store changes what is
+ * stored.  cdna_hip_programming.md 5.7 item 1 says so; round 5's first-contact test (apus_selftest.h) showed it: its unrolled
+ * pattern loop had the first two words of unit u + 64 in unit u, one unit in five.  The data path's own loops never put a VALU
+ * write of the data registers there -- parity at full size says so -- but nothing kept the compiler from doing it.) */
 __device__ static inline void st16_wt(uint8_t *p, uint4 v)
 {
     v4u_t d = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
 }
 /* 16 bytes as a streaming store: acknowledged by the L2, on its way to memory behind that -- visible to others only
  * behind rep_release() */
 __device__ static inline void st16_nt(uint8_t *p, uint4 v)
 {
     v4u_t d = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
 }
 /* everything this wavefront has stored is in memory (system scope): write-back of the L2's dirty lines + drain */
 __device__ static inline void rep_release()
@@ -320,7 +331,7 @@ __device__ static inline void rep_release()
 __device__ static inline void st16_dev(uint8_t *p, uint4 v)
 {
     v4u_t d = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
 }
 __device__ static inline void ld32_dev(const uint8_t *p, uint4 &a, uint4 &b)
 {
@@ -710,6 +721,12 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
     for (int s = 0; s < R_SUB; s++) { npf0[s] = 0; npf1[s] = 0; nrf0[s] = 0; nrf1[s] = 0; }
     bool fl_pending = false, pk_pending = false;
     uint64_t fl_t = 0, fl_v = 0, pk_cg = 0, pk_next = 0;
+    /* the request-ring passes' pipeline registers (host-fed input) */
+    uint32_t pf_v[R_WIN];
+    uint64_t pf_cg = 0, pf_stop = 0, pf_head = 0, pf_cmd = 0;
+    bool pf_on = false;
+#pragma unroll
+    for (int wdw = 0; wdw < R_WIN; wdw++) pf_v[wdw] = 0;
     auto take_peek = [&]() {
         const unsigned long long okb = __ballot(lane < 8 && rep_gran_ok(pk_cg, pk_next + (lane >> 2)));
         if (have_cmd || have_cmd2 || (okb & 0xFull) != 0xFull) return;
@@ -960,15 +977,25 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
             idle = 0;
             continue;
         }
-        /* ---- one PCIe round trip: the next host command and R_WIN windows of the request ring ---- */
+        /* ---- one round trip: the next host command, the stop word and R_WIN windows of the request ring -- unless the pass
+         *      before asked for exactly these words already (a pass of full windows knows where the next one starts: its loads
+         *      are in flight while its record and tickets are stored; round 5) ---- */
         const uint64_t tq0 = stats ? wall_clock64() : 0;
         st_pcie_n++;
         uint32_t v[R_WIN];
+        uint64_t cg = 0, stopw = 0;
+        if (pf_on && pf_head == req_head && pf_cmd == cmd_head) {
 #pragma unroll
-        for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = ld_sys32(&RQ->ready_len[(req_head + (uint64_t)wdw * WAVE + lane) % RQ_CAP]);
-        if (!have_cmd) {
-            uint64_t cg = 0;
+            for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = pf_v[wdw];
+            cg = pf_cg; stopw = pf_stop;
+        } else {
+#pragma unroll
+            for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = ld_sys32(&RQ->ready_len[(req_head + (uint64_t)wdw * WAVE + lane) % RQ_CAP]);
             if (lane < 8) cg = ld_sys(&RQ->cmd[(cmd_head + (lane >> 2)) % RC_CAP].g[lane & 3]);
+            stopw = ld_sys(&RQ->stop);                   /* (with the rings: a look at host memory would be the one PCIe round trip of the pass) */
+        }
+        pf_on = false;
+        if (!have_cmd) {
             const unsigned long long okb = __ballot(lane < 8 && rep_gran_ok(cg, cmd_head + (lane >> 2)));
             if ((okb & 0xFull) == 0xFull) {
                 have_cmd = true;
@@ -981,7 +1008,6 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                 }
             }
         }
-        const uint64_t stopw = ld_sys(&RQ->stop);        /* (with the rings: a look at host memory would be the one PCIe round trip of the pass) */
         if (stats) st_pcie += wall_clock64() - tq0;
         {
             const int x = exec_cmd();
@@ -1009,6 +1035,15 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
             const uint64_t T = APUS_HDR + (uint64_t)len0, tot = (uint64_t)Wn * WAVE * T;
             const uint64_t used = S.end >= S.head_safe ? S.end - S.head_safe : L - (S.head_safe - S.end);
             if (Wn >= 2 && S.end != L && S.end + tot < L && S.end != S.head_safe && tot + APUS_HDR <= L - used) {
+                {   /* what the next pass will look at: asked for now, looked at then (words published later are seen a pass later) */
+                    const uint64_t nh = req_head + (uint64_t)Wn * WAVE;
+#pragma unroll
+                    for (int wdw = 0; wdw < R_WIN; wdw++) pf_v[wdw] = ld_sys32(&RQ->ready_len[(nh + (uint64_t)wdw * WAVE + lane) % RQ_CAP]);
+                    pf_cg = 0;
+                    if (lane < 8) pf_cg = ld_sys(&RQ->cmd[(cmd_head + (lane >> 2)) % RC_CAP].g[lane & 3]);
+                    pf_stop = ld_sys(&RQ->stop);
+                    pf_on = true; pf_head = nh; pf_cmd = cmd_head;
+                }
                 const uint64_t pn = S.pass_seq++;
                 const uint64_t stamp = wall_clock64() & 0xFFFFFFFFull;
                 uint64_t pv = 0;

@@ -327,77 +327,90 @@ def run_trace_group(member: GroupMember, trace):
     member.leader_stop()
 
 
-def bench_group(args, initialised=None):
-    """bench.py --gpus N with APUS_GROUP_TRANSPORT=p2p (or where the devices cannot map each
-    other's memory): N replicas, one per GPU, ranges shipped over RCCL point-to-point."""
+def bench_group(args, initialised=None, n_rep=None, keep_group=False, entries=None, steps=None, warmup=None):
+    """The message-passing twin of the peer-mapped data plane: N replicas, one per GPU, R1 / R2 as RCCL send / recv of the ring
+    range a follower lacks, R3 as one cumulative word back (module docstring).  Two uses:
+      * bench.py --gpus N with APUS_GROUP_TRANSPORT=p2p, or where the devices cannot map each other's memory: the line;
+      * inside bench.py --gpus N's normal run (keep_group=True, a shorter workload): the `rccl_transport` object next to the
+        peer-mapped headline -- north_star names both ways of carrying a round between GPUs.
+    n_rep < world: the ranks behind n_rep are spare machines; they only stand in the barriers and reductions."""
     from . import trace as T
     if initialised is None:
         from .peers import init_process_group_from_env
         initialised = init_process_group_from_env(args.gpus)
     rank, world, local, backend = initialised
-    n = world
-    tr = T.steady_trace(n, args.entries, args.payload, 16, args.batch, log_len=T.DEFAULT_LOG, name="C2")
-    m = GroupMember(n, rank, 0, local, backend, tr.log_len)
-    calls = None
-    if m.is_leader:
-        m.eng.stage_trace(tr)
-        ev, i, calls = tr.events, 0, []
-        while i < len(ev):
-            if ev[i][0] == "ROUND":
-                j = i
-                while j < len(ev) and ev[j][0] == "ROUND":
-                    j += 1
-                calls.append(("rounds", m.eng.round_of_g0[ev[i][1]], j - i))
-                i = j
-                continue
-            if ev[i][0] == "PRUNE":
-                calls.append(("prune",))
-            i += 1
-    m.elect()
-
-    def leader_step():
-        for c in calls:
-            if c[0] == "rounds":
-                m.leader_rounds(c[1], c[2])
-            else:
-                m.leader_prune()
-        m.leader_quiesce()
-
-    if m.is_leader:
-        m.sync_followers()
-        m.eng.quiesce()
-        for _ in range(args.warmup):
-            leader_step()
-        # exactly K steps between two marks; a mark = device sync + barrier on every rank
-        m.mark()
-        for _ in range(args.steps):
-            leader_step()
-        m.mark()
-        m.leader_stop()
+    n = n_rep or world
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    entries = entries or args.entries
+    spare = rank >= n
+    red_dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
+    tr = T.steady_trace(n, entries, args.payload, 16, args.batch, log_len=T.DEFAULT_LOG, name="C2")
+    n_entries = len(tr.reqs)
+    good, dt = True, 0.0
+    m = None
+    if spare:
+        dist.barrier()                      # (the two marks of the timed region)
+        dist.barrier()
     else:
-        m.follower_serve()
-    dt = m.marks[1] - m.marks[0]
+        m = GroupMember(n, rank, 0, local, backend, tr.log_len)
+        calls = None
+        if m.is_leader:
+            m.eng.stage_trace(tr)
+            ev, i, calls = tr.events, 0, []
+            while i < len(ev):
+                if ev[i][0] == "ROUND":
+                    j = i
+                    while j < len(ev) and ev[j][0] == "ROUND":
+                        j += 1
+                    calls.append(("rounds", m.eng.round_of_g0[ev[i][1]], j - i))
+                    i = j
+                    continue
+                if ev[i][0] == "PRUNE":
+                    calls.append(("prune",))
+                i += 1
+        m.elect()
+
+        def leader_step():
+            for c in calls:
+                if c[0] == "rounds":
+                    m.leader_rounds(c[1], c[2])
+                else:
+                    m.leader_prune()
+            m.leader_quiesce()
+
+        if m.is_leader:
+            m.sync_followers()
+            m.eng.quiesce()
+            for _ in range(warmup):
+                leader_step()
+            # exactly K steps between two marks; a mark = device sync + barrier on every rank
+            m.mark()
+            for _ in range(steps):
+                leader_step()
+            m.mark()
+            m.leader_stop()
+        else:
+            m.follower_serve()
+        dt = m.marks[1] - m.marks[0]
+        o = m.eng.offsets(rank)
+        total = (warmup + steps) * n_entries
+        applied = m.eng.counters(rank)["highest_rec"] if m.is_leader else int(m.eng.hdr_words(rank)[16])
+        good = (o["commit"] == o["end"] == o["apply"]) and applied == total and not m.eng.status()
     # max over ranks
-    red_dev = m.device if backend == "nccl" else torch.device("cpu")
     t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    n_entries = len(tr.reqs)
-    ok = torch.ones(1, device=red_dev)
-    o = m.eng.offsets(rank)
-    total = (args.warmup + args.steps) * n_entries
-    applied = m.eng.counters(rank)["highest_rec"] if m.is_leader else int(m.eng.hdr_words(rank)[16])
-    if not (o["commit"] == o["end"] == o["apply"]) or applied != total or m.eng.status():
-        ok.zero_()
+    ok = torch.tensor([1.0 if good else 0.0], device=red_dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     out = None
     if rank == 0:
         E = 64 + args.payload
-        value = n_entries * args.steps / dt
+        value = n_entries * steps / dt
         out = {
             "metric": "committed entries/sec", "value": value, "unit": "entries/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{n} replicas, one per GPU ({'RCCL p2p over xGMI' if backend == 'nccl' else backend + ' staging (test mode)'}), {n_entries} entries/step "
                                    f"of {args.payload} B, rounds of {args.batch}, prune tick every 8 MiB",
@@ -407,6 +420,8 @@ def bench_group(args, initialised=None):
                          "frac": value * E / 1e9 / 153.0, "traffic": None,
                          "note": "per leader->follower link: entries/s x E against one xGMI link (SURVEY.md 8d)"},
         }
-    m.close()
-    dist.destroy_process_group()
+    if m is not None:
+        m.close()
+    if not keep_group:
+        dist.destroy_process_group()
     return out

@@ -29,15 +29,15 @@ from .engine import Engine, EngineError
 from .trace import DEFAULT_LOG
 
 
-def _gather_bytes(blob: bytes, device) -> list[bytes]:
+def _gather_bytes(blob: bytes, device, group=None) -> list[bytes]:
     """all_gather of equal-sized byte strings (device tensors on RCCL, host tensors on gloo)."""
-    world = dist.get_world_size()
+    world = dist.get_world_size(group=group)
     on_dev = dist.get_backend() == "nccl"
     t = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
     if on_dev:
         t = t.to(device)
     outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t)
+    dist.all_gather(outs, t, group=group)
     return [bytes(o.cpu().numpy().tobytes()) for o in outs]
 
 
@@ -93,6 +93,9 @@ class PeerMember:
         self.led = []                       # (first pass, passes) of the round record for every term this rank led
         self.rep_running = False            # a run of the replica kernels is resident (rep_begin .. rep_end)
         self.rep_here = False               # ... and this process carries workgroups of it
+        self.fence_on_elect = not os.environ.get("APUS_PEER_NO_RING_FENCE")     # (diagnostic: tests/test_gpu_peers_deposed.py shows what happens without it)
+        self.had_leader = False
+        self.fenced = 0
         self.pg = None                      # the process group the control-plane barriers run on (None: everybody; the
                                             # survivors' group once a rank has DIED -- tests/_peer_kill_worker.py)
 
@@ -107,11 +110,18 @@ class PeerMember:
     def elect(self, winner: int):
         """ELECT(winner).  The barrier stands for the vote exchange; the previous leader's stream
         has drained before it (kill / the end of its last call), so the control blocks the winner
-        starts from (k_set_roles) are final."""
+        starts from (k_set_roles) are final.
+        The receiver's fence (rc_revoke_log_access, dare_ibv_rc.c:2156-2243): every server that takes part adopts the
+        new term by LEAVING the log ring and the mailbox the old leader has mapped (apus_gpu_fence_replica), and the
+        members of the new term map the new ones -- a deposed leader that was not part of the election (a partition; its
+        resident kernel may still be pushing) stores into memory nobody reads from then on.  The first election of a
+        group has nobody to fence off."""
         e = self.eng
         if self.is_leader:
             e.sync()
         self._barrier()
+        if self.fence_on_elect and (self.leader >= 0 or self.had_leader):
+            self._fence_and_remap()
         if self.rank == winner:
             first = len(e.round_record()[0])
             e.elect(winner)                 # term += 2, blank CONFIG (+ removal of the dead) on the device
@@ -123,6 +133,21 @@ class PeerMember:
             e.leader = winner
             e.bitmask &= ~(e.bitmask & ~e.reachable & ~(1 << winner))
         self.leader = winner
+        self.had_leader = True
+
+    def _fence_and_remap(self):
+        """every rank of the control plane's group (self.pg) moves its replica's ring + mailbox, the handles go round, everybody
+        maps what the others moved.  Collective over self.pg; ranks outside it keep their (now stale) mappings."""
+        e, L = self.eng, self.eng.L
+        mine = _lib.IpcReplica()
+        e._chk(L.apus_gpu_fence_replica(e.h, self.rank, C.byref(mine)), "fence_replica")
+        blobs = _gather_bytes(bytes(mine), self.device, group=self.pg)
+        for b in blobs:
+            h = _lib.IpcReplica.from_buffer_copy(b)
+            if h.replica != self.rank:
+                e._chk(L.apus_gpu_remap_fenced(e.h, C.byref(h)), f"remap_fenced({h.replica})")
+        self.fenced += 1
+        self._barrier()                      # every mapping of the new term exists before anybody leads
 
     def kill(self, r: int):
         e = self.eng

@@ -127,21 +127,13 @@ typedef struct {
  *    instead, like the reference: a follower's own workgroups do not acknowledge a round of a term older than their
  *    SID's -- no reply byte, no ACK: nothing of it can commit. */
 #define APUS_F_TERM_FENCE 2u
-/* Strict reference behaviour where the engine is deliberately safer by default: with the commit pointer parked on
- * a wrap position and no majority for the entry that wrapped to offset 0, the reference's leader sets commit = 0
- * (src/dare/dare_ibv_rc.c:1725-1758) and, at a case-1 wrap, APPLIES that entry although it is not committed
- * (log_get_entry redirects log->apply in place, src/include/dare/dare_log.h:327-330) -- one upcall, highest_rec + 1,
- * apply ahead of commit.  With this flag a one-thread kernel behind every pass (k_ref_quirk_wrap,
- * apus_amd/csrc/apus_quirks.h) brings the leader's control block, apply stream and counters to exactly that state.
- * Covers the call-per-pass path (apus_gpu_run_rounds outside a batch, the live calls, control rounds, quiesce);
- * apus_gpu_batch_begin, apus_gpu_persist_start and apus_gpu_rep_start return APUS_E_STATE under it.
- * STATUS, FINAL: this flag is a DIAGNOSTIC of the call-per-pass path -- it exists so that a test can exhibit the
- * reference's state bit for bit (tests/test_gpu_parity.py::test_ref_quirks_flag_closes_the_deviation).  It is not
- * and will not be accepted by the batch, persistent or replica kernels: what it reproduces is a client released by
- * an entry that only the leader holds, i.e. a safety violation of the reference that no deployment wants, and the
- * resident kernels (the product's live loop) never apply an uncommitted entry.  Deviation 1 in DESIGN.md section 6
- * states the bound (apply, one upcall, <= 8 per-pass records, only while the quorum is gone). */
-#define APUS_F_REF_QUIRKS 4u
+/* (flags bit 4u is NOT part of this ABI.  It is the parity harness's diagnostic APUS_F_REF_QUIRKS, defined with its kernel in
+ * apus_amd/csrc/apus_quirks.h: on the call-per-pass path it reproduces, bit for bit, the reference's state at a commit pointer
+ * parked on a wrap position without a majority -- commit = 0 and, at a case-1 wrap, the entry at offset 0 APPLIED although it
+ * is not committed (src/dare/dare_ibv_rc.c:1725-1758 + src/include/dare/dare_log.h:327-330): a client released by an entry only
+ * the leader holds.  DECIDED, round 5: that is a safety violation of the reference, the deviation from it is permanent on every
+ * data plane that carries traffic (the replica kernels, batches, the persistent kernel never apply an uncommitted entry and
+ * return APUS_E_STATE under the bit); DESIGN.md section 6, Deviation 1, states the bound and the tests that hold it.) */
 
 typedef struct apus_engine apus_engine_t;
 
@@ -177,7 +169,7 @@ typedef struct {
     uint32_t dir_cap;
     uint32_t replica;                         /* group index of the replica */
     int32_t  device;                          /* HIP device ordinal in the exporting process */
-    uint32_t pad;
+    uint32_t fences;                          /* how often the replica's ring and mailbox have moved (apus_gpu_fence_replica) */
 } apus_ipc_replica_t;
 /* replica must be hosted (allocated) by this engine */
 int  apus_gpu_export_replica(apus_engine_t *e, uint32_t replica, apus_ipc_replica_t *out);
@@ -190,6 +182,17 @@ int  apus_gpu_unmap_replica(apus_engine_t *e, uint32_t replica);
  * unmaps, a barrier, then every process destroys: an owner that frees a buffer a peer still has open cannot export
  * the memory it allocates next.)  APUS_E_STATE while a resident kernel or a batch is open. */
 int  apus_gpu_unmap_peers(apus_engine_t *e);
+/* The receiver's fence against a deposed leader (rc_revoke_log_access, src/dare/dare_ibv_rc.c:2156-2243: the voters reset
+ * the old leader's QPs, its WRITEs bounce).  A mapped buffer cannot be taken back, but it can be left: the hosted replica
+ * moves the two buffers peers store into during a run -- log ring and mailbox -- to fresh allocations (device copies);
+ * whoever still holds the old mappings stores into memory nobody reads.  out (may be NULL) = the handles with the two new
+ * buffers, fences + 1.  A server calls it when it adopts a newer term (apus_amd/peers.py: elect), the members of the new
+ * term then call apus_gpu_remap_fenced with its handles (a no-op for a replica whose `fences` they already know).
+ * APUS_E_STATE while a resident kernel or a batch is open, and for an engine that has captured graphs. */
+int  apus_gpu_fence_replica(apus_engine_t *e, uint32_t replica, apus_ipc_replica_t *out);
+int  apus_gpu_remap_fenced(apus_engine_t *e, const apus_ipc_replica_t *in);
+/* tests: n bytes at off of the ring `replica` left `back` fences ago (1 = the last): where a deposed leader's stores went */
+int  apus_gpu_read_retired_ring(apus_engine_t *e, uint32_t replica, uint32_t back, uint64_t off, uint64_t n, void *dst);
 
 /* ---- control plane (host-driven, ms-scale in the reference) ---------------- */
 /* Role/term change: the caller (host election logic) decided that `leader` won
@@ -345,6 +348,17 @@ int  apus_gpu_device_arch(int device, char *out, int cap);
 int  apus_gpu_calib_pingpong(apus_engine_t *e, uint32_t me, uint32_t peer, uint32_t role, uint32_t iters, uint64_t base,
                              uint32_t *out_ns, uint32_t timeout_ms);
 int  apus_gpu_calib_store_bw(apus_engine_t *e, uint32_t peer, uint64_t bytes, uint32_t iters, float *out_gbps);
+/* First contact between two devices, before anything is measured (apus_amd/csrc/apus_selftest.h): a peer's kernel pushes
+ * `rounds` rounds of 8 KiB (write-through stores + a doorbell, the data path's own instructions) into replica `owner`'s ring
+ * and mailbox, the owner's RESIDENT kernel checks every byte and frees the region (regions: 64 .. 8192, reused every
+ * `regions` rounds).  roles: 1 = this process pushes (it has `owner` mapped), 2 = this process checks (it hosts `owner`),
+ * 3 = both in one launch (one device).  The two processes call it together.  out: [0] rounds checked, [1] 16-byte units that
+ * differed, [2] first round that differed + 1, [3] waits that timed out.  Clears what it touched.
+ * APUS_RING_ALLOC=finegrained | uncached (read by apus_gpu_create) puts the log rings into fine-grained / uncached device
+ * memory: what bench.py --gpus N falls back to when the test finds a difference; apus_gpu_ring_alloc_kind: 0 / 1 / 2. */
+int  apus_gpu_selftest(apus_engine_t *e, uint32_t pusher, uint32_t owner, uint32_t roles, uint64_t rounds, uint32_t regions,
+                       uint32_t timeout_ms, uint64_t out[4]);
+int  apus_gpu_ring_alloc_kind(apus_engine_t *e);
 int  apus_gpu_set_leader(apus_engine_t *e, uint32_t leader);    /* a follower-only process: who leads (host mirror only, nothing is launched) */
 int  apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t peer_ms, uint32_t n_append, uint32_t n_fwork);
 int  apus_gpu_rep_park(apus_engine_t *e);     /* exit code of the run: 0 stop, 1 idle, 2 a wait timed out, 3 a follower had a gap */

@@ -146,8 +146,12 @@ def test_replica_pmc_traffic_file_belongs_to_this_build():
         c = doc["configs"][cfg]
         assert c["replicas"] == n and c["launches"] == 1 and c["launches_write_pass"] == 1
         # at least every replica's copy is written; nothing near SURVEY's (3N-1)E + 64 is moved
-        assert n * c["mean_entry_bytes"] * 0.95 < c["written_bytes_per_entry"] and c["bytes_per_entry"] < (3 * n - 1) * c["mean_entry_bytes"] + 64
+        assert n * c["mean_entry_bytes"] < c["written_bytes_per_entry"] * 1.02 and c["bytes_per_entry"] < (3 * n - 1) * c["mean_entry_bytes"] + 64
         assert bench.replica_pmc(cfg) == c
     r = bench.replica_roofline("c2x3", 3, 128, 10 ** 8, 25.0)
     assert r["lead"] == "frac_moved" and r["traffic"] == int(doc["configs"]["c2x3"]["bytes_per_entry"] * 10 ** 8)
-    assert abs(r["frac"] - (5 * 128 + 64) * 10 ** 8 / 25e-3 / 1e9 / 8000.0) < 1e-9 and r["frac_moved"] > r["frac"] * 0.9
+    assert r["bytes_per_entry"] == 3 * 128 + 80 + 2 * 64 and abs(r["frac"] - 592 * 10 ** 8 / 25e-3 / 1e9 / 8000.0) < 1e-9
+    # what is moved is never less than what has to move -- for every configuration
+    for cfg, n in (("c2x1", 1), ("c2x3", 3), ("c2x5", 5), ("c2x7", 7), ("c3", 5), ("c4", 7)):
+        c = doc["configs"][cfg]
+        assert c["bytes_per_entry"] >= bench.algorithmic_bytes(n, c["mean_entry_bytes"]), cfg

@@ -51,12 +51,24 @@ def test_bench_gpus_n_dry_run_full_schema(n):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--entries", "131072", "--cpu-seconds", "1",
            "--watchdog", "240"]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", APUS_DIST_BACKEND="gloo", APUS_DIST_ONE_DEVICE="1")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", APUS_DIST_BACKEND="gloo", APUS_DIST_ONE_DEVICE="1", APUS_SELFTEST_ROUNDS="100000")
+    if n == 4:
+        env["APUS_SELFTEST_FORCE_FALLBACK"] = "1"          # one size walks the fall-back: the group starts again with fine-grained rings
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert p.returncode == 0 and len(lines) == 1, f"rc={p.returncode}\n{p.stdout[-1500:]}\n{p.stderr[-4000:]}"
     d = json.loads(lines[0])
     replicas = n if n % 2 else n - 1
+    st = d["ring_visibility_selftest"]
+    if replicas >= 2:
+        # first contact: every follower's resident kernel checked every round its leader's device pushed, nothing differed
+        assert st["verdict"] == "ok" and len(st["by_follower"]) == replicas - 1
+        assert all(v["rounds"] == 100000 and v["bad_units"] == 0 and not v["timeouts"] and not v["pusher_timeouts"] for v in st["by_follower"].values()), st
+        assert st["retested"] == (n == 4) and ("fine-grained" in st["allocation"]) == (n == 4) and st["allocation"].split(" (")[0] in d["config"]["mode"]
+        # the same group over send / recv (gloo staging here, RCCL on the real node), verified
+        assert d["rccl_transport"]["verified"] is True and d["rccl_transport"]["value"] > 0
+    else:
+        assert st is None and "rccl_transport" not in d
     assert d["n_gpus"] == n and d["config"]["replicas"] == replicas and d["config"]["spare_machines"] == n - replicas
     assert d["verified"] is True and d["value"] > 0 and d["metric"] == "committed entries/sec" and d["scaling"] == "weak"
     assert d["roofline"]["bound"] == "xgmi" and d["roofline"]["kernel"] == "k_replica" and 0 < d["roofline"]["bytes_per_entry"] < 64 + 64 + 2

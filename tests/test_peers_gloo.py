@@ -45,6 +45,24 @@ class _FakeLib:
         self.eng.calls.append(("unmap_peers",))
         return 0
 
+    # the receiver's fence: a replica's ring + mailbox move (handles 0 and 6 change, `fences` counts), the others map them
+    def apus_gpu_fence_replica(self, h, replica, out):
+        self.eng.fence_n += 1
+        self.eng.calls.append(("fence", replica, self.eng.fence_n))
+        self.apus_gpu_export_replica(h, replica, out)
+        o = out._obj
+        o.fences = self.eng.fence_n
+        for k in (0, 6):
+            o.handle[k][0] = (o.handle[k][0] + self.eng.fence_n) & 0xFF
+        return 0
+
+    def apus_gpu_remap_fenced(self, h, inp):
+        o = inp._obj
+        assert o.replica in self.eng.imported, "remap of a replica that was never imported"
+        self.eng.calls.append(("remap", o.replica, o.fences))
+        self.eng.imported[o.replica] = bytes(o)
+        return 0
+
 
 class _FakeEngine:
     """records what the host asks of the device; control-plane bookkeeping as in apus_amd/engine.py"""
@@ -58,6 +76,7 @@ class _FakeEngine:
         self.h = None
         self.L = _FakeLib(self)
         self.imported = {}
+        self.fence_n = 0
         self.calls = []
         self.leader, self.term = -1, 0
         self.bitmask = self.reachable = (1 << group_size) - 1
@@ -177,8 +196,19 @@ def _worker(rank, world, port, name, q, replica=False):
             data = [c for c in mm.eng.calls if c[0] in ("rounds", "prune", "quiesce", "control", "lead")]
             led_calls[i] = (mm.is_leader, len(data))
 
+        def check_fences(mm):
+            # every election but the first: this rank's replica left its ring + mailbox once, and it mapped what every other
+            # rank moved -- with that rank's count, in the same election
+            n_el = sum(1 for e in tr.events if e[0] == "ELECT")
+            fences = [c for c in mm.eng.calls if c[0] == "fence"]
+            assert [c[1:] for c in fences] == [(rank, k + 1) for k in range(n_el - 1)], f"rank {rank}: {fences} for {n_el} elections"
+            remaps = [c for c in mm.eng.calls if c[0] == "remap"]
+            assert sorted(remaps) == sorted(("remap", r, k + 1) for k in range(n_el - 1) for r in range(world) if r != rank), f"rank {rank}: {remaps}"
+            assert mm.fenced == n_el - 1
+
         if replica:
             peers.walk_trace(m, tr, on_check=check, check_at=("QUIESCE", "ELECT", "KILL", "JOIN"), replica=True)
+            check_fences(m)
             calls = m.eng.calls
             starts = [k for k, c in enumerate(calls) if c[0] == "rep_start"]
             parks = [k for k, c in enumerate(calls) if c[0] == "rep_park"]
@@ -199,6 +229,7 @@ def _worker(rank, world, port, name, q, replica=False):
             m.close()
             return
         peers.walk_trace(m, tr, on_check=check, check_at=("QUIESCE", "PRUNE", "ELECT", "KILL", "JOIN"))
+        check_fences(m)
         data = [c for c in m.eng.calls if c[0] in ("rounds", "prune", "quiesce", "control", "join")]
         joins = [e[1] for e in tr.events if e[0] == "JOIN"]
         # a machine that joins clears the replica it hosts; nobody else's is cleared from here
