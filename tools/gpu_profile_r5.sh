@@ -12,7 +12,7 @@ d=$PWD/gpurun_out/prof_$R
 rm -rf $d; mkdir -p $d
 HERE=$PWD
 if [ -z "$NO_KT" ]; then
-  ARGS="--steps ${KT_STEPS:-20} --warmup 5 --no-cpu --no-latency --no-ack-path --no-other --no-configs0 --no-hostfed"
+  ARGS="--steps ${KT_STEPS:-20} --warmup 5 --no-cpu --no-latency --no-ack-path --no-other --no-configs0"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $d/kt -o kt -- python $HERE/bench.py $ARGS > $d/kt_run.log 2> $d/kt_run.err)
   f=$(find $d/kt -name "*.db" | head -1)
   { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS"; python tools/kstats.py $f | head -14; echo; echo "# every resident launch of that run"; python tools/klaunches.py $f k_replica; echo; echo "# the line that run printed (roofline of the headline launch)";
