@@ -724,7 +724,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
     /* the request-ring passes' pipeline registers (host-fed input) */
     uint32_t pf_v[R_WIN];
     uint64_t pf_cg = 0, pf_stop = 0, pf_head = 0, pf_cmd = 0;
-    bool pf_on = false;
+    bool pf_on = false, rq_hot = false;
 #pragma unroll
     for (int wdw = 0; wdw < R_WIN; wdw++) pf_v[wdw] = 0;
     auto take_peek = [&]() {
@@ -989,8 +989,11 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
             for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = pf_v[wdw];
             cg = pf_cg; stopw = pf_stop;
         } else {
+            /* (a ring that had no full window last time is looked at one window at a time: a lone request does not wait for
+             * R_WIN windows of words nobody has written -- a pass over 32 empty windows is ~7 us) */
+            const int nw = rq_hot ? R_WIN : 1;
 #pragma unroll
-            for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = ld_sys32(&RQ->ready_len[(req_head + (uint64_t)wdw * WAVE + lane) % RQ_CAP]);
+            for (int wdw = 0; wdw < R_WIN; wdw++) { if (wdw < nw) v[wdw] = ld_sys32(&RQ->ready_len[(req_head + (uint64_t)wdw * WAVE + lane) % RQ_CAP]); else v[wdw] = 0u; }   /* (0: no slot's tag) */
             if (lane < 8) cg = ld_sys(&RQ->cmd[(cmd_head + (lane >> 2)) % RC_CAP].g[lane & 3]);
             stopw = ld_sys(&RQ->stop);                   /* (with the rings: a look at host memory would be the one PCIe round trip of the pass) */
         }
@@ -1043,6 +1046,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                     if (lane < 8) pf_cg = ld_sys(&RQ->cmd[(cmd_head + (lane >> 2)) % RC_CAP].g[lane & 3]);
                     pf_stop = ld_sys(&RQ->stop);
                     pf_on = true; pf_head = nh; pf_cmd = cmd_head;
+                    rq_hot = true;
                 }
                 const uint64_t pn = S.pass_seq++;
                 const uint64_t stamp = wall_clock64() & 0xFFFFFFFFull;
@@ -1089,9 +1093,11 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                 dropped += n;                                                        /* slots consumed without a ticket */
             } else budget--;
             req_head += n;
+            rq_hot = n == WAVE;
             if (n < WAVE) break;
         }
         if (any) { if (lane == 0) s_m[M_DROPPED] = dropped; rep_seq_publish(LS, s_m, S, cmd_head + req_head); idle = 0; continue; }
+        rq_hot = false;
         /* ---- nothing to do ---- */
         if (stopw) { exit_code = R_EXIT_STOP; break; }
         if (++idle > A.idle_polls) { exit_code = R_EXIT_IDLE; break; }

@@ -921,7 +921,7 @@ def bench_single(args):
                 out["roofline"] = replica_roofline(f"c2x{n_rep}", n_rep, E, dr["entries_in_launch"], dr["launch_ms"])
                 out["roofline"]["note"] = ("one resident launch per run: its duration by HIP events on the engine's replica stream (start of the "
                                            "launch to the workgroups' exit after the park command: 1 + REPS x K steps and the host's gaps between "
-                                           "regions); frac_moved (counter bytes) leads, frac prices (2N-1)E + 64 algorithmic bytes per entry")
+                                           "regions); frac_moved (counter bytes) leads, frac prices N E + (E - 48) + 64 (N - 1) algorithmic bytes per entry")
                 out["headline_kernel"] = "k_replica"
                 out["whole_path"] = {"bytes_per_entry": out["roofline"]["bytes_per_entry"], "achieved": out["roofline"]["bytes_per_entry"] * r_value / 1e9, "unit": "GB/s",
                                      "frac": out["roofline"]["bytes_per_entry"] * r_value / 1e9 / HBM_PEAK_GBS,

@@ -26,7 +26,8 @@ PY
   tail -1 $d/kt_run.log > $d/${R}_bench_line_under_rocprof.json
   head -30 $d/${R}_replica_kernel_stats.txt | cut -c1-200
 fi
-for c in ${CFGS:-c2x3 c2x1 c2x5 c2x7 c3 c4}; do
+[ -n "$NO_PMC" ] && CFGS=" "
+for c in ${CFGS-c2x3 c2x1 c2x5 c2x7 c3 c4}; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $ctr -d $d/pmc_${c}_$ctr -o pmc -- python $HERE/tools/rep_profile_run.py $c > $d/pmc_${c}_$ctr.log 2>&1)
     echo "pmc $c $ctr exit: $?"
