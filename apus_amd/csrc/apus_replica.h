@@ -136,6 +136,11 @@ struct RepBox {
      * (written as a whole 64-byte line: a partial line is a read-modify-write in the memory that receives it) */
     uint64_t rnd[RB_CAP][8];
     uint16_t lens[RB_CAP][WAVE];         /* cmd.len of every entry of a round of mixed sizes (2 B per entry) */
+    /* Round 5: what a follower needs to know of every entry of a client round beyond what the doorbell says -- clt_id, type,
+     * sender: the third word of the header's second half, 4 B per entry -- so that it does not have to READ the headers that
+     * landed in its ring (a 32-byte read costs the 128-byte line: 256 B of the 884 an entry moved at three replicas, and
+     * the launch is bound by the bytes it moves).  Doorbell granules 4..7 carry idx0 and the term (R_BELL_META). */
+    uint32_t emeta[RB_CAP][WAVE];
     uint64_t commit_bell;                /* R4: committed slots                                 */
     uint64_t ctrl;                       /* (f_runs + 1) << 40 | rounds of this run to consume + 1: park */
     uint64_t ping, pong;                 /* link calibration (k_calib_pingpong): the word the peer writes, the word it answers in */
@@ -1479,6 +1484,7 @@ __device__ static inline uint32_t rep_spread4(uint32_t mask4) { return (mask4 & 
  * starts (it died, or was dropped from the push set mid-run) has its byte cleared in the leader's copy of everything it
  * does not hold (k_rep_clear_reply, from apus_gpu_rep_start) before anything is caught up. */
 #define R_BELL_REPLY (1u << 31)
+#define R_BELL_META  (1u << 30)          /* granules 4..7 = idx of the round's first entry (lo, hi), its term (lo, hi); emeta[][] = the entries' clt_id / type / sender */
 
 /* one append wavefront: ticket k, k + G, ... */
 __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A, RepAppLds &lds, const RepPtrLds &PT, uint32_t g, uint32_t G)
@@ -1631,6 +1637,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         /* every entry of the same size?  (the followers then place the round from one number) */
         const uint32_t T0 = rl32u(T, 0);
         const bool uniform = !__ballot(active && T != T0);
+        const bool bell_meta = kind != R_SRC_CONTROL && !(A.dbg & 16384);      /* client rounds: the followers need not read the headers back */
         uint64_t mix = 0;
         uint32_t client = 0;
         uint4 ar0 = make_uint4(0, 0, 0, 0), ar1 = ar0;
@@ -1660,6 +1667,10 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             if (!uniform) for (uint32_t m = push; m; m &= m - 1) {
                 const uint32_t f = (uint32_t)__builtin_ctz(m);
                 __hip_atomic_store((APUS_GLOBAL uint16_t *)(uintptr_t)&PT.box[f]->lens[(PT.qbase[f] + k) % RB_CAP][lane], (uint16_t)d.len, RLX_SYSTEM);
+            }
+            if (bell_meta) for (uint32_t m = push; m; m &= m - 1) {
+                const uint32_t f = (uint32_t)__builtin_ctz(m);
+                __hip_atomic_store((APUS_GLOBAL uint32_t *)(uintptr_t)&PT.box[f]->emeta[(PT.qbase[f] + k) % RB_CAP][lane], h1.z, RLX_SYSTEM);
             }
         }
         if (!(A.dbg & 8192)) rep_store_rows32(ar0, ar1, n, [&](uint32_t r) { return (uint8_t *)&Md.apply[(uint32_t)(slot0 + r) & E.dir_mask]; });
@@ -1825,7 +1836,11 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             }
         }
         const uint64_t t_stores = timed ? wall_clock64() : 0;
-        /* the next ticket's words are asked for now: their round trip runs under the drain of this round's stores */
+        /* the next ticket's words are asked for now: their round trip runs under the drain of this round's stores.
+         * (Round 5 also asked for the next round's pass record, prefix sums and descriptors a round early, with this round's payload
+         * loads -- 2.4 us of a round's 10.7 by the phase timers: the wait moved into the next phase, the throughput did not move
+         * (3.62 / 3.49 against 3.73 / 3.55 G at three replicas): the launch is bound by the bytes it moves, not by a wavefront's
+         * chain of round trips.  Taken out again.) */
         if (lane < 8) wv_next = ld_agent(&LS->tkw[lane][(k + G) % RS_CAP]);
         have_next = true;
         if (nt_ring) rep_release(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1835,7 +1850,8 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         const uint32_t t_now = (uint32_t)wall_clock64();
         if (lane < 8) {
             const uint32_t val = lane == 0 ? (uint32_t)end_after : lane == 1 ? (uint32_t)(slot0 + n) : lane == 2 ? (uint32_t)e0
-                                                                             : lane == 3 ? ((n << 17) | (uniform ? T0 : 0u) | (preset ? R_BELL_REPLY : 0u)) : 0u;
+                                 : lane == 3 ? ((n << 17) | (uniform ? T0 : 0u) | (preset ? R_BELL_REPLY : 0u) | (bell_meta ? R_BELL_META : 0u))
+                                 : !bell_meta ? 0u : lane == 4 ? (uint32_t)idx0 : lane == 5 ? (uint32_t)(idx0 >> 32) : lane == 6 ? (uint32_t)term : (uint32_t)(term >> 32);
             for (uint32_t m = push; m; m &= m - 1) {
                 const uint32_t f = (uint32_t)__builtin_ctz(m);
                 const uint64_t q = PT.qbase[f] + k;
@@ -1888,8 +1904,8 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
         uint64_t wv = bell_next;                     /* (looked at under the previous round's store drain) */
         uint32_t go = 0;
         for (uint64_t i = 0;; i++) {
-            if (i || !have_bell) { if (lane < 4) wv = ld_sys(&box->rnd[r][lane]); }
-            if (__ballot(lane < 4 && (wv >> 32) == ((q + 1) & 0xFFFFFFFFull)) == 0xFull) { go = 1; break; }
+            if (i || !have_bell) { if (lane < 8) wv = ld_sys(&box->rnd[r][lane]); }
+            if (__ballot(lane < 8 && (wv >> 32) == ((q + 1) & 0xFFFFFFFFull)) == 0xFFull) { go = 1; break; }      /* (the leader stores the whole 64-byte line) */
             if ((i & 15) == 15) {
                 const uint64_t ctrl = ld_sys(&box->ctrl);
                 if ((ctrl >> 40) == my_run + 1 && q0 + (ctrl & 0xFFFFFFFFFFull) - 1 <= q) break;   /* parked: round q never comes */
@@ -1911,6 +1927,9 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
         const uint32_t end_after = (uint32_t)rdl64(wv, 0), slot_lo = (uint32_t)rdl64(wv, 1), e0 = (uint32_t)rdl64(wv, 2), w3 = (uint32_t)rdl64(wv, 3);
         const uint32_t n = (w3 >> 17) & 0x7Fu, Tu = w3 & 0x1FFFF;
         const bool preset = (w3 & R_BELL_REPLY) != 0;              /* the reply bytes came with the entries */
+        const bool bmeta = (w3 & R_BELL_META) != 0 && !(A.dbg & 16);   /* ... and what the headers say came with the doorbell */
+        const uint64_t b_idx0 = (uint64_t)(uint32_t)rdl64(wv, 4) | ((uint64_t)(uint32_t)rdl64(wv, 5) << 32);
+        const uint64_t b_term = (uint64_t)(uint32_t)rdl64(wv, 6) | ((uint64_t)(uint32_t)rdl64(wv, 7) << 32);
         /* the slot count's high half: this run stays within 2^31 slots of where it began */
         uint64_t slot_end = (n_end0 & ~0xFFFFFFFFull) | slot_lo;
         if (slot_end + (1ull << 31) < n_end0) slot_end += 1ull << 32;
@@ -1928,7 +1947,21 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
         bool acked = false;
         uint64_t t_hdr = 0;
         if (active) {
-            if (A.dbg & 16) ld32_dev(Md.ring + pos, u0, u1); else ld32_sys(Md.ring + pos, u0, u1);
+            if (bmeta) {
+                /* the header words this wavefront uses, from the doorbell and the round's 4 bytes per entry: idx (rep_idx over the
+                 * same placement the leader made), term, clt_id / type / sender */
+                const uint64_t ix = rep_idx(pl, (int)lane, b_idx0);
+                u0 = make_uint4((uint32_t)ix, (uint32_t)(ix >> 32), (uint32_t)b_term, (uint32_t)(b_term >> 32));
+                u1.z = __hip_atomic_load((const APUS_GLOBAL uint32_t *)(uintptr_t)&box->emeta[r][lane], RLX_SYSTEM);
+                if (A.dbg & 32768) {
+                    /* verification mode (tests): the headers are read as well and must say the same */
+                    uint4 c0, c1;
+                    ld32_sys(Md.ring + pos, c0, c1);
+                    if ((c0.x != u0.x || c0.y != u0.y || c0.z != u0.z || c0.w != u0.w || c1.z != u1.z) && !(atomicOr(E.status, 1u << 3) & (1u << 3))) {
+                        E.status[3] = (uint32_t)q; E.status[4] = c0.x; E.status[5] = u0.x; E.status[6] = 0xBE11u; E.status[7] = c1.z ^ u1.z;
+                    }
+                }
+            } else if (A.dbg & 16) ld32_dev(Md.ring + pos, u0, u1); else ld32_sys(Md.ring + pos, u0, u1);
             if (timed) t_hdr = wall_clock64();
             const uint64_t idx = (uint64_t)u0.x | ((uint64_t)u0.y << 32);
             const uint32_t type = (u1.z >> 16) & 0xFF, sender = u1.z >> 24;
@@ -1970,7 +2003,7 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
             st_agent(&FS->fr[lane][r], rep_gran(q, val));
         }
         const uint64_t t_st = timed ? wall_clock64() : 0;
-        if (lane < 4) bell_next = ld_sys(&box->rnd[(q + G) % RB_CAP][lane]);     /* the next doorbell: its round trip runs under this drain */
+        if (lane < 8) bell_next = ld_sys(&box->rnd[(q + G) % RB_CAP][lane]);     /* the next doorbell: its round trip runs under this drain */
         have_bell = true;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (timed) { const uint64_t t_dr = wall_clock64(); w_rounds++; w_total += t_dr - t_bell; w_hdr += rdl64(t_hdr, 0) - t_bell; w_st += t_st - rdl64(t_hdr, 0); w_drain += t_dr - t_st; }

@@ -182,3 +182,15 @@ def test_rep_a_host_consumer_that_registers_during_the_first_run_holds_the_head_
         assert eng.offsets(1)["apply"] == o["end"]
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("name,source", [("steady5_unaligned", "staged"), ("exact_fit", "staged"), ("c4_small", "staged"), ("c2_small", "pinned")])
+def test_rep_doorbell_metadata_says_what_the_headers_say(name, source, monkeypatch):
+    """Round 5: a follower no longer READS the headers that landed in its ring -- idx and term come with the doorbell, clt_id /
+    type / sender as 4 bytes per entry beside it (R_BELL_META).  Verification mode (APUS_REP_DBG & 32768): the follower's
+    wavefronts read the headers as well and raise a status bit where they differ -- wraps, exact fit, mixed sizes, rounds from
+    the request ring.  And the old way (APUS_REP_DBG & 16384: no metadata, headers read back) still walks the same traces."""
+    monkeypatch.setenv("APUS_REP_DBG", "32768")
+    run_and_compare(traces.CATALOGUE[name](), source)
+    monkeypatch.setenv("APUS_REP_DBG", "16384")
+    run_and_compare(traces.CATALOGUE[name](), source)
