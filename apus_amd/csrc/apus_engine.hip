@@ -145,11 +145,18 @@ template <typename T>
 static int dev_alloc(apus_engine *e, T **out, size_t bytes, bool zero = true, unsigned ext_flags = 0)
 {
     void *p = nullptr;
+    /* Whole 2 MiB blocks for everything that is not tiny.  The runtime carves allocations that are not a multiple of its
+     * 2 MiB block out of shared blocks (a ring of 1 MiB + 4 KiB came back 28 KiB into a block), and hipIpcGetMemHandle on such
+     * a fragment fails with "invalid argument" once the process has exported, freed and re-allocated a few of them: round 5's
+     * 50-fold soak of the cross-process JOIN traces died at the fifth engine of one process group, on round 4's tree as well
+     * (tools/gpu_soak.sh; the suite's three repetitions never got there).  A buffer that owns its blocks exports every time. */
+    const size_t asked = bytes;
+    if (bytes > (64u << 10)) bytes = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
     if (ext_flags) { if (hipExtMallocWithFlags(&p, bytes, ext_flags) != hipSuccess) return APUS_E_NOMEM; }
     else if (hipMalloc(&p, bytes) != hipSuccess) return APUS_E_NOMEM;
     /* (on the engine's stream: a hipMemset on the null stream may still be in flight when the first kernel of the
      * non-blocking engine stream runs -- k_reset's words were seen zeroed again by a late memset) */
-    if (zero && hipMemsetAsync(p, 0, bytes, e->stream) != hipSuccess) return APUS_E_HIP;
+    if (zero && hipMemsetAsync(p, 0, asked, e->stream) != hipSuccess) return APUS_E_HIP;
     e->allocs.push_back(p);
     *out = (T *)p;
     return 0;
@@ -300,6 +307,7 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
     for (auto &t : e->timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (e->p_running) apus_gpu_persist_stop(e);       /* before anything it reads is freed */
     if (e->r_running) apus_gpu_rep_park(e);
+    if (!e->ipc_ptrs.empty() && getenv("APUS_DEBUG")) fprintf(stderr, "[apus_gpu] destroy: %zu peer mappings still open (closed now)\n", e->ipc_ptrs.size());
     for (void *p : e->ipc_ptrs) hipIpcCloseMemHandle(p);
     for (void *p : e->allocs) hipFree(p);
     if (e->d_req) hipFree(e->d_req);
@@ -418,7 +426,12 @@ extern "C" int apus_gpu_export_replica(apus_engine_t *e, uint32_t replica, apus_
     memset(out, 0, sizeof *out);
     for (uint32_t k = 0; k < APUS_IPC_BUFFERS; k++) {
         hipIpcMemHandle_t h;
-        HIPCHK(hipIpcGetMemHandle(&h, bufs[k]));
+        const hipError_t er = hipIpcGetMemHandle(&h, bufs[k]);
+        if (er != hipSuccess) {
+            fprintf(stderr, "[apus_gpu] hipIpcGetMemHandle failed for replica %u buffer %u (%p): %s\n", replica, k, bufs[k], hipGetErrorString(er));
+            (void)hipGetLastError();
+            return APUS_E_HIP;
+        }
         memcpy(out->handle[k], &h, sizeof h);
     }
     out->log_len = e->d.log_len; out->dir_cap = e->dir_cap; out->replica = replica; out->device = e->cfg.device; out->fences = e->fences[replica];
@@ -431,7 +444,10 @@ extern "C" int apus_gpu_export_replica(apus_engine_t *e, uint32_t replica, apus_
 extern "C" int apus_gpu_unmap_peers(apus_engine_t *e)
 {
     if (!e) return APUS_E_ARG;
-    if (e->r_running || e->p_running || e->batching) return APUS_E_STATE;
+    if (e->r_running || e->p_running || e->batching) {
+        fprintf(stderr, "[apus_gpu] unmap_peers refused (replica kernels %d, persistent kernel %d, batch %d): the mappings stay open\n", (int)e->r_running, (int)e->p_running, (int)e->batching);
+        return APUS_E_STATE;
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
     for (uint32_t r = 0; r < APUS_MAX_SERVERS; r++)
         if ((e->imported_mask >> r) & 1u) {
@@ -440,9 +456,14 @@ extern "C" int apus_gpu_unmap_peers(apus_engine_t *e)
         }
     e->local_mask &= ~e->imported_mask;
     e->imported_mask = 0;
-    for (void *p : e->ipc_ptrs) hipIpcCloseMemHandle(p);
+    int bad = 0;
+    for (void *p : e->ipc_ptrs) {
+        const hipError_t er = hipIpcCloseMemHandle(p);
+        if (er != hipSuccess) { bad++; fprintf(stderr, "[apus_gpu] hipIpcCloseMemHandle(%p) failed: %s\n", p, hipGetErrorString(er)); (void)hipGetLastError(); }
+    }
+    if (getenv("APUS_DEBUG")) fprintf(stderr, "[apus_gpu] unmap_peers: %zu mappings closed, %d refused\n", e->ipc_ptrs.size(), bad);
     e->ipc_ptrs.clear();
-    return 0;
+    return bad ? APUS_E_HIP : 0;
 }
 
 /* One peer's mapping alone: a server whose PROCESS is gone and whose slot a new machine takes over (JOIN into an empty

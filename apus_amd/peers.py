@@ -290,8 +290,10 @@ class PeerMember:
         except EngineError:
             pass
         self._barrier()                      # nobody unmaps / frees while a peer may still write
-        self.eng.L.apus_gpu_unmap_peers(self.eng.h)
+        rc = self.eng.L.apus_gpu_unmap_peers(self.eng.h)
         self._barrier()                      # nobody frees what a peer still has mapped
+        if rc:
+            raise EngineError(f"rank {self.rank}: unmap_peers rc={rc}: a peer's buffers stay mapped here (a kernel of this group is still resident?)")
         self.eng.close()
 
 
