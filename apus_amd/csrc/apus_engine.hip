@@ -2557,8 +2557,13 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
         { const char *ga = getenv("APUS_REP_DEFAULT_APPEND"), *gf = getenv("APUS_REP_DEFAULT_FWORK");      /* (sweeps) */
           if (!n_append && ga) n_append = (uint32_t)atoi(ga);
           if (!n_fwork && gf) n_fwork = (uint32_t)atoi(gf); }
-        if (!n_append) n_append = lead_here ? 192 : 0;
-        if (!n_fwork) n_fwork = nfh ? std::min(128u, std::max(24u, 288u / nfh)) : 1;   /* (measured, round 4: 192 append + 128 per follower at 3 replicas, 72 at 5, 48 at 7) */
+        /* (measured, round 4: 192 append + 128 per follower at 3 replicas, 72 at 5, 48 at 7 for configs[1]'s 128-byte entries.
+         *  Round 5: with entries of 512 bytes and more -- configs[2], configs[3] -- an append wavefront is bound by the rate at
+         *  which it issues its own stores (170 per round of 32 x 1 KiB at five replicas, ~240 ns each), and the followers, who no
+         *  longer read headers back, need few workgroups: 352 append + ~150 for all followers: +19 % / +6 %) */
+        const bool big = e->n_rounds_staged && e->stage_max_T >= 512;
+        if (!n_append) n_append = lead_here ? (big ? 352u : 192u) : 0;
+        if (!n_fwork) n_fwork = nfh ? (big ? std::min(128u, std::max(16u, 150u / nfh)) : std::min(128u, std::max(24u, 288u / nfh))) : 1;
         while ((lead_here ? 1 + n_append : 0) + nfh * n_fwork > room && (n_append > 8 || n_fwork > 2)) {
             if (n_append > 8) n_append -= n_append / 4;
             if (n_fwork > 2) n_fwork -= (n_fwork + 3) / 4;

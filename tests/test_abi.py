@@ -150,7 +150,7 @@ def test_replica_pmc_traffic_file_belongs_to_this_build():
         assert bench.replica_pmc(cfg) == c
     r = bench.replica_roofline("c2x3", 3, 128, 10 ** 8, 25.0)
     assert r["lead"] == "frac_moved" and r["traffic"] == int(doc["configs"]["c2x3"]["bytes_per_entry"] * 10 ** 8)
-    assert r["bytes_per_entry"] == 3 * 128 + 80 + 2 * 64 and abs(r["frac"] - 592 * 10 ** 8 / 25e-3 / 1e9 / 8000.0) < 1e-9
+    assert r["bytes_per_entry"] == 3 * 128 + 80 + 2 * 8 and abs(r["frac"] - 480 * 10 ** 8 / 25e-3 / 1e9 / 8000.0) < 1e-9
     # what is moved is never less than what has to move -- for every configuration
     for cfg, n in (("c2x1", 1), ("c2x3", 3), ("c2x5", 5), ("c2x7", 7), ("c3", 5), ("c4", 7)):
         c = doc["configs"][cfg]
