@@ -115,6 +115,7 @@ SIGNATURES = {
     "apus_gpu_unmap_replica": (C.c_int, [vp, u32]),
     "apus_gpu_selftest": (C.c_int, [vp, u32, u32, u32, u64, u32, u32, C.POINTER(u64)]),
     "apus_gpu_ring_alloc_kind": (C.c_int, [vp]),
+    "apus_gpu_calib_store_multi": (C.c_int, [vp, u32, u32, u32, C.POINTER(C.c_float)]),
     "apus_gpu_fence_replica": (C.c_int, [vp, u32, C.POINTER(IpcReplica)]),
     "apus_gpu_remap_fenced": (C.c_int, [vp, C.POINTER(IpcReplica)]),
     "apus_gpu_read_retired_ring": (C.c_int, [vp, u32, u32, u64, u64, vp]),

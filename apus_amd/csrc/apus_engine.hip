@@ -3066,6 +3066,33 @@ extern "C" int apus_gpu_selftest(apus_engine_t *e, uint32_t pusher, uint32_t own
     HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
+/* The write-through store ceiling of the data path's pattern (apus_selftest.h: k_calib_store_multi): 8 KiB chunks written at
+ * the same offset into every hosted ring of `mask`, the whole ring, `passes` times, `wgs` workgroups of four wavefronts;
+ * *gbps = bytes written / the launch's duration (HIP events).  Destroys the rings' contents. */
+extern "C" int apus_gpu_calib_store_multi(apus_engine_t *e, uint32_t mask, uint32_t passes, uint32_t wgs, float *gbps)
+{
+    if (!e || !gbps || !passes || !wgs || wgs > 4096) return APUS_E_ARG;
+    if (e->r_running || e->p_running || e->batching) return APUS_E_STATE;
+    const uint32_t skew = (passes >> 16) & 0x70u;          /* (passes bits 16..22: the chunks' offset within a 128-byte line, a multiple of 16) */
+    passes &= 0xFFFFu;
+    CalibRings R; R.n = 0;
+    for (uint32_t i = 0; i < e->cfg.group_size && i < APUS_DEV_MAX_SERVERS; i++)
+        if (((mask >> i) & 1u) && e->d.rep[i].ring && !((e->imported_mask >> i) & 1u)) R.r[R.n++] = e->d.rep[i].ring;
+    if (!R.n) return APUS_E_ARG;
+    const uint64_t bytes = e->d.log_len & ~(uint64_t)(ST_ROUND_BYTES - 1);
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    hipLaunchKernelGGL(k_calib_store_multi, dim3(wgs), dim3(256), 0, e->stream, R, bytes, 1u, 7u, skew);      /* (warm: page tables, clocks) */
+    hipEventRecord(a, e->stream);
+    hipLaunchKernelGGL(k_calib_store_multi, dim3(wgs), dim3(256), 0, e->stream, R, bytes, passes, 11u, skew);
+    hipEventRecord(b, e->stream);
+    int rc = hipEventSynchronize(b) == hipSuccess ? 0 : APUS_E_HIP;
+    float ms = 0.f;
+    if (!rc) hipEventElapsedTime(&ms, a, b);
+    hipEventDestroy(a); hipEventDestroy(b);
+    *gbps = ms > 0.f ? (float)((double)bytes * R.n * passes / (ms * 1e-3) / 1e9) : 0.f;
+    return rc;
+}
 /* how this engine's log rings are allocated: 0 ordinary device memory, 1 fine-grained, 2 uncached (APUS_RING_ALLOC at create) */
 extern "C" int apus_gpu_ring_alloc_kind(apus_engine_t *e) { return e ? e->ring_alloc : APUS_E_ARG; }
 

@@ -107,3 +107,27 @@ __global__ __launch_bounds__(256) void k_selftest(const EngDev E, uint32_t pushe
     if (lane == 0) { atomicAdd(&res[0], checked); atomicAdd(&res[1], bad); if (first_bad) atomicMin(&res[2], first_bad); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+
+
+/* The data path's store pattern with nothing around it (round 5, DESIGN 9 "what bounds it"): every wavefront takes 8 KiB chunks
+ * -- a round of 64 entries of 128 bytes -- and writes each chunk, write-through (st16_wt), at the same offset into EVERY ring of
+ * `rings`, chunk after chunk through the whole ring, `passes` times.  With three or more 64 MiB rings the footprint is past the
+ * 256 MiB of memory-side cache: what comes out is the rate at which this device takes write-through stores in this pattern --
+ * the ceiling the replica kernels' ring stores sit under, whatever else they do. */
+struct CalibRings { uint8_t *r[APUS_DEV_MAX_SERVERS]; uint32_t n; };
+__global__ __launch_bounds__(256) void k_calib_store_multi(const CalibRings R, uint64_t bytes, uint32_t passes, uint32_t seed, uint32_t skew)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), G = (uint64_t)gridDim.x * 4;
+    const uint64_t chunks = bytes / ST_ROUND_BYTES - 1;
+    for (uint32_t p = 0; p < passes; p++)
+        for (uint64_t c = g; c < chunks; c += G) {
+            const uint4 v = make_uint4(seed + p, (uint32_t)c, lane, 0x9E3779B9u);
+            for (uint32_t i = 0; i < R.n; i++) {
+                uint8_t *dst = R.r[i] + c * ST_ROUND_BYTES + 16u * lane + skew;          /* (skew: where a round really starts within a 128-byte line) */
+#pragma unroll
+                for (uint32_t k = 0; k < ST_UNITS / WAVE; k++) st16_wt(dst + 1024u * k, v);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          /* (a round's drain in front of its doorbell) */
+        }
+}

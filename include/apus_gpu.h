@@ -359,6 +359,10 @@ int  apus_gpu_calib_store_bw(apus_engine_t *e, uint32_t peer, uint64_t bytes, ui
 int  apus_gpu_selftest(apus_engine_t *e, uint32_t pusher, uint32_t owner, uint32_t roles, uint64_t rounds, uint32_t regions,
                        uint32_t timeout_ms, uint64_t out[4]);
 int  apus_gpu_ring_alloc_kind(apus_engine_t *e);
+/* The write-through store ceiling of the data path's own pattern: 8 KiB chunks (a round of 64 x 128 B) written at the same offset
+ * into every hosted ring of `mask`, through the whole ring, `passes` times, by `wgs` workgroups of four wavefronts, nothing else
+ * in the launch.  *gbps = bytes written / the launch's duration.  Destroys the rings' contents (calibration, before a group starts). */
+int  apus_gpu_calib_store_multi(apus_engine_t *e, uint32_t mask, uint32_t passes, uint32_t wgs, float *gbps);
 int  apus_gpu_set_leader(apus_engine_t *e, uint32_t leader);    /* a follower-only process: who leads (host mirror only, nothing is launched) */
 int  apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t peer_ms, uint32_t n_append, uint32_t n_fwork);
 int  apus_gpu_rep_park(apus_engine_t *e);     /* exit code of the run: 0 stop, 1 idle, 2 a wait timed out, 3 a follower had a gap */
