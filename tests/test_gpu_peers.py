@@ -158,6 +158,8 @@ def test_a_check_point_needs_its_closing_barrier():
     barrier that closes a check point (PeerMember.check_done) the leader goes on with the next stretch of rounds while
     a slower rank is still reading its own replica; with it the same slow rank passes."""
     slow = {"APUS_PEER_SLOW_RANK": "4"}
-    with pytest.raises(AssertionError, match="rank 4"):
+    # (which rank sees the leader's next stretch first is a race: usually the slow rank 4 itself -- "apply_count 50 vs 0" --
+    #  once in a while a rank that was simply still reading when the leader moved on; any rank's comparison failing is the point)
+    with pytest.raises(AssertionError, match=r"rank \d+: AssertionError"):
         run_group(5, "join_upsize_3_to_5", env_extra=dict(slow, APUS_PEER_NO_CHECK_BARRIER="1"), attempts=1)
     run_group(5, "join_upsize_3_to_5", env_extra=slow)
