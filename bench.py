@@ -1049,6 +1049,79 @@ def _selftest_verdict(res, rounds_wanted):
     return "mismatch" if any(v["bad_units"] for v in res.values()) else "ok"
 
 
+def _smaller_group(args, peers, k, world, rank, local, backend, grid, one_dev):
+    """BASELINE asks for 1 / 3 / 5 / 7 replica GPUs: the groups smaller than the one the line's headline ran on, in the SAME run and
+    on the same process group -- the first k ranks host the replicas, the others sit the measurement out (they are machines that
+    could JOIN).  A shorter workload (2^18 entries per step, one warm step + two timed steps), lone rounds first, verified like the
+    headline.  Collective; -> {entries_per_s, latency, verified} on rank 0."""
+    import copy
+    import torch
+    import torch.distributed as dist
+    a2 = copy.copy(args)
+    a2.entries = min(args.entries, 1 << 18)
+    tr = build_trace(a2, k)
+    red_dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
+    m = peers.PeerMember(world, rank, local, tr.log_len, configured=k)
+    eng = m.eng
+    try:
+        m.elect(0)
+        eng.stage_trace(tr)
+        cmds = _rep_step_cmds(tr, eng)
+        n_entries = len(tr.reqs)
+
+        def step():
+            for c in cmds:
+                if c[0] == "run":
+                    eng.rep_run(c[1], c[2])
+                else:
+                    eng.rep_prune()
+
+        def mark():
+            if m.is_leader:
+                eng.rep_drain(timeout_ms=120000)
+            dist.barrier()
+            return time.perf_counter()
+
+        lat, lone = None, 0
+        m.rep_begin(*grid)
+        if m.is_leader and not args.no_latency:
+            eng.rep_roundtrip_ns(np.ascontiguousarray(tr.reqs[16:16 + 64]), tr.arena, 200)
+            eng.rep_drain()
+            lone = 200 * 64
+        m.rep_end()
+        if m.is_leader and not args.no_latency:
+            la = eng.rep_latency_appended_ns()
+            lat = float(np.percentile(la[20:], 50)) / 1e3 if len(la) > 20 else None
+        lone_t = torch.tensor([float(lone)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(lone_t, op=dist.ReduceOp.MAX)
+        lone = int(lone_t.item())
+        m.rep_begin(*grid)
+        if m.is_leader:
+            step()
+        t0 = mark()
+        if m.is_leader:
+            step(); step()
+        t1 = mark()
+        m.rep_end()
+        t = torch.tensor([t1 - t0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if m.is_leader:
+            eng.quiesce()
+        m.settle()
+        good = True
+        if rank < k:
+            o = eng.offsets(rank)
+            applied = eng.counters(rank)["highest_rec"] if m.is_leader else int(eng.hdr_words(rank)[16])
+            good = (o["commit"] == o["end"] == o["apply"]) and applied == lone + 3 * n_entries and (not m.is_leader or eng.status() == 0)
+        ok = torch.tensor([1.0 if good else 0.0], device=red_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return {"replicas": k, "entries_per_s": 2 * n_entries / float(t.item()), "entries_per_step": n_entries, "steps": 2,
+                "appended_to_committed_and_applied_us_p50": lat, "verified": bool(ok.item() == 1),
+                "link_GBps_per_follower": (2 * n_entries / float(t.item())) * (64 + args.payload + 1.0) / 1e9 if k > 1 else 0.0}
+    finally:
+        m.close()
+
+
 def bench_multi(args):
     """--gpus N (N >= 2): one replica per GPU and process, logs peer-mapped over HIP IPC (apus_amd/peers.py), the
     consensus round carried by the replica kernels (apus_amd/csrc/apus_replica.h): EVERY process runs the workgroups
@@ -1285,6 +1358,24 @@ def bench_multi(args):
             except Exception as exc:
                 print(f"[bench] cpu baseline failed: {exc!r}", file=sys.stderr)
     m.close()
+    # ---- the smaller groups BASELINE names, in the same run: 1 / 3 / 5 replicas below the headline's (each its own group on the
+    #      same processes and devices; the other ranks sit it out)
+    if not args.no_smaller_groups:
+        smaller = {}
+        for k in (5, 3, 1):
+            if k >= n_rep:
+                continue
+            try:
+                r_k = _smaller_group(args, peers, k, world, rank, local, backend, grid, one_dev)
+                smaller[str(k)] = r_k
+            except Exception as exc:
+                print(f"[bench] rank {rank}: the {k}-replica group's measurement failed: {exc!r}", file=sys.stderr)
+                break                                   # (the ranks may be out of step now: nothing collective after this but the teardown)
+        if rank == 0 and out is not None:
+            out["by_group_size"] = dict(smaller, **{str(n_rep): {"replicas": n_rep, "entries_per_s": out["value"], "verified": out["verified"],
+                                                                 "appended_to_committed_and_applied_us_p50": out["p50_round_latency_us"]}})
+            if calib and calib.get("doorbell_one_way_us"):
+                out["by_group_size"]["floor_two_doorbell_hops_us"] = 2 * calib["doorbell_one_way_us"]
     # ---- the same group over RCCL send / recv (apus_amd/distributed.py: R1 / R2 as a message per follower and batch, R3 as one
     #      cumulative word back): north_star names both ways of carrying a round between GPUs; a shorter workload, same checks
     if n_rep >= 2 and not args.no_rccl_transport:
@@ -1328,6 +1419,7 @@ def main():
     ap.add_argument("--no-calibration", action="store_true", help="--gpus N: skip the link calibration")
     ap.add_argument("--no-join", action="store_true", help="--gpus N (even): do not let the spare machine join")
     ap.add_argument("--no-selftest", action="store_true", help="--gpus N: skip the first-contact test of the peer-mapped rings")
+    ap.add_argument("--no-smaller-groups", action="store_true", help="--gpus N: skip the 1 / 3 / 5-replica groups below the headline's")
     ap.add_argument("--no-rccl-transport", action="store_true", help="--gpus N: skip the second measurement over send / recv (apus_amd/distributed.py)")
     ap.add_argument("--rep-append", type=int, default=0, help="--gpus N: append workgroups of the leader (0 = default)")
     ap.add_argument("--rep-fwork", type=int, default=0, help="--gpus N: workgroups per follower (0 = default)")

@@ -65,6 +65,9 @@ def test_bench_gpus_n_dry_run_full_schema(n):
         assert st["verdict"] == "ok" and len(st["by_follower"]) == replicas - 1
         assert all(v["rounds"] == 100000 and v["bad_units"] == 0 and not v["timeouts"] and not v["pusher_timeouts"] for v in st["by_follower"].values()), st
         assert st["retested"] == (n == 4) and ("fine-grained" in st["allocation"]) == (n == 4) and st["allocation"].split(" (")[0] in d["config"]["mode"]
+        # the smaller groups BASELINE names, in the same run (1 / 3 / 5 replicas below the headline's), every one verified
+        want = {str(k) for k in (1, 3, 5, 7) if k <= replicas}
+        assert want <= set(d["by_group_size"]) and all(d["by_group_size"][k]["verified"] and d["by_group_size"][k]["entries_per_s"] > 0 for k in want), d["by_group_size"]
         # the same group over send / recv (gloo staging here, RCCL on the real node), verified
         assert d["rccl_transport"]["verified"] is True and d["rccl_transport"]["value"] > 0
     else:
