@@ -66,3 +66,30 @@ def test_every_configuration_of_the_line_has_a_counter_backed_roofline():
     # host-fed: monotonic in producers
     hf = d["replica_kernels"]["host_fed"]["by_producer_threads"]
     assert all(v["verified"] for v in hf.values()) and hf["1"]["entries_per_s"] <= hf["2"]["entries_per_s"] <= hf["4"]["entries_per_s"]
+
+
+def test_first_contact_verdicts():
+    """bench.py --gpus N: how the self-test's per-follower results are read (no GPU): ok / mismatch (the fall-back is worth a try) /
+    stuck (nothing to fall back to)"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    good = {"rounds": 1000, "bad_units": 0, "first_bad_round": 0, "timeouts": 0, "pusher_timeouts": 0, "rc": [0, 0]}
+    assert bench._selftest_verdict({"1": dict(good), "2": dict(good)}, 1000) == "ok"
+    assert bench._selftest_verdict({"1": dict(good), "2": dict(good, bad_units=3, first_bad_round=17)}, 1000) == "mismatch"
+    assert bench._selftest_verdict({"1": dict(good, rounds=400, timeouts=1)}, 1000) == "stuck"
+    assert bench._selftest_verdict({"1": dict(good, rc=[0, -6])}, 1000) == "stuck"
+    # a side that timed out AND saw differences: the differences decide (fine-grained rings may cure both)
+    assert bench._selftest_verdict({"1": dict(good, rounds=400, timeouts=1, bad_units=9)}, 1000) == "mismatch"
+
+
+def test_algorithmic_bytes():
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.algorithmic_bytes(3, 128) == 3 * 128 + 80 + 16 and bench.algorithmic_bytes(1, 128) == 208
+    assert bench.algorithmic_bytes(3, 128, followers_look=False) == 464
+    # always below SURVEY's (3N-1)E + 64 for N >= 2, and never below what the N rings alone take
+    for n in (2, 3, 5, 7):
+        for e in (104, 128, 1088, 4160):
+            assert n * e < bench.algorithmic_bytes(n, e) < (3 * n - 1) * e + 64
