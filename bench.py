@@ -1187,7 +1187,9 @@ def bench_multi(args):
             selftest.update(retested=True, allocation="fine-grained device memory (hipExtMallocWithFlags, APUS_RING_ALLOC=finegrained)",
                             verdict=verdict, by_follower_first_attempt=first, by_follower=second)
         if verdict != "ok":
-            raise RuntimeError(f"--gpus {world}: first contact between the devices failed ({verdict}): {selftest}")
+            # the run goes on -- a line that says what happened is worth more to whoever reads it than a traceback -- but nothing it
+            # measures counts as verified: the data path rests on exactly what this test checks
+            print(f"[bench] rank {rank}: first contact between the devices FAILED ({verdict}): {selftest}", file=sys.stderr)
     eng = m.eng
     n_entries = len(tr.reqs)
     # ---- calibrate the links first (the reference's LogGP probes), then start from a clean slate
@@ -1328,7 +1330,7 @@ def bench_multi(args):
                                 + (" -- TEST MODE, every rank on device 0 (no xGMI hop)" if one_dev else " over xGMI")
                                 + ("; log rings in " + selftest["allocation"] + " (first contact: " + selftest["verdict"] + ")" if selftest else "")),
                        "replicas": n_rep, "spare_machines": spare, "entry_bytes": E, "workgroups": {"leader_append": grid[0], "per_follower": grid[1]}},
-            "verified": bool(ok.item() == 1),
+            "verified": bool(ok.item() == 1) and (selftest is None or selftest["verdict"] == "ok"),
             "placement": {"ranks": place, "distinct_devices": distinct, "visible_devices": nvis, "peer_access_matrix": peer_matrix,
                           "collective_backend": backend, "ranks_in_group": world},
             "link_calibration": calib,
@@ -1358,6 +1360,20 @@ def bench_multi(args):
             except Exception as exc:
                 print(f"[bench] cpu baseline failed: {exc!r}", file=sys.stderr)
     m.close()
+    # ---- from here on: extras.  The headline exists; nothing below may cost the driver its line.  Every rank arms a timer: if the
+    #      extras are not through in time (a collective of the send / recv transport that never completes on a fabric it has never
+    #      seen, say), rank 0 prints the line as it stands and every rank leaves with status 0.
+    import threading
+    extras_done = threading.Event()
+
+    def _bail():
+        if extras_done.wait(timeout=args.extras_timeout):
+            return
+        if rank == 0 and out is not None:
+            out["extras"] = f"cut off after {args.extras_timeout} s: what is missing below the headline did not finish"
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    threading.Thread(target=_bail, daemon=True).start()
     # ---- the smaller groups BASELINE names, in the same run: 1 / 3 / 5 replicas below the headline's (each its own group on the
     #      same processes and devices; the other ranks sit it out)
     if not args.no_smaller_groups:
@@ -1392,6 +1408,7 @@ def bench_multi(args):
                                                  "the peer-mapped replica kernels above are the product path"}
         except Exception as exc:
             print(f"[bench] rank {rank}: the send / recv transport's measurement failed: {exc!r}", file=sys.stderr)
+    extras_done.set()
     dist.destroy_process_group()
     faulthandler.cancel_dump_traceback_later()
     return out
@@ -1420,6 +1437,7 @@ def main():
     ap.add_argument("--no-join", action="store_true", help="--gpus N (even): do not let the spare machine join")
     ap.add_argument("--no-selftest", action="store_true", help="--gpus N: skip the first-contact test of the peer-mapped rings")
     ap.add_argument("--no-smaller-groups", action="store_true", help="--gpus N: skip the 1 / 3 / 5-replica groups below the headline's")
+    ap.add_argument("--extras-timeout", type=int, default=150, help="--gpus N: seconds the measurements below the headline (smaller groups, send / recv transport) may take before the line is printed without them")
     ap.add_argument("--no-rccl-transport", action="store_true", help="--gpus N: skip the second measurement over send / recv (apus_amd/distributed.py)")
     ap.add_argument("--rep-append", type=int, default=0, help="--gpus N: append workgroups of the leader (0 = default)")
     ap.add_argument("--rep-fwork", type=int, default=0, help="--gpus N: workgroups per follower (0 = default)")

@@ -86,3 +86,20 @@ def test_bench_gpus_n_dry_run_full_schema(n):
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
     print(f"--gpus {n}: {d['value'] / 1e6:.0f} M entries/s, p50 {d['p50_round_latency_us']} us, doorbell rt {cal['doorbell_round_trip_us_p50']}, "
           f"peer store peak {cal['peer_store_peak_GBps']:.0f} GB/s, join {d['join_catch_up']}")
+
+
+def test_bench_gpus_extras_are_cut_off_not_the_line():
+    """`bench.py --gpus N`: what is measured below the headline (smaller groups, the send / recv transport) may never cost the
+    driver its line -- with a budget they cannot meet, rank 0 prints the line as it stands, says so, and every rank leaves with
+    status 0."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=5",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "5", "--steps", "2", "--warmup", "1", "--entries", "131072", "--cpu-seconds", "1",
+           "--watchdog", "240", "--extras-timeout", "0"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", APUS_DIST_BACKEND="gloo", APUS_DIST_ONE_DEVICE="1", APUS_SELFTEST_ROUNDS="100000")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, f"rc={p.returncode}\n{p.stdout[-1500:]}\n{p.stderr[-3000:]}"
+    d = json.loads(lines[0])
+    assert d["verified"] is True and d["value"] > 0 and d["config"]["replicas"] == 5 and "cut off" in d["extras"]
+    assert "rccl_transport" not in d
