@@ -138,8 +138,8 @@ struct RepBox {
     uint16_t lens[RB_CAP][WAVE];         /* cmd.len of every entry of a round of mixed sizes (2 B per entry) */
     /* Round 5: what a follower needs to know of every entry of a client round beyond what the doorbell says -- clt_id, type,
      * sender: the third word of the header's second half, 4 B per entry -- so that it does not have to READ the headers that
-     * landed in its ring (a 32-byte read costs the 128-byte line: 256 B of the 884 an entry moved at three replicas, and
-     * the launch is bound by the bytes it moves).  Doorbell granules 4..7 carry idx0 and the term (R_BELL_META). */
+     * landed in its ring (a 32-byte read costs the 128-byte line: 256 B of the 884 an entry moved at three replicas; without
+     * it +13 % / +15 % at five / seven replicas).  Doorbell granules 4..7 carry idx0 and the term (R_BELL_META). */
     uint32_t emeta[RB_CAP][WAVE];
     uint64_t commit_bell;                /* R4: committed slots                                 */
     uint64_t ctrl;                       /* (f_runs + 1) << 40 | rounds of this run to consume + 1: park */
@@ -1839,8 +1839,9 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         /* the next ticket's words are asked for now: their round trip runs under the drain of this round's stores.
          * (Round 5 also asked for the next round's pass record, prefix sums and descriptors a round early, with this round's payload
          * loads -- 2.4 us of a round's 10.7 by the phase timers: the wait moved into the next phase, the throughput did not move
-         * (3.62 / 3.49 against 3.73 / 3.55 G at three replicas): the launch is bound by the bytes it moves, not by a wavefront's
-         * chain of round trips.  Taken out again.) */
+         * (3.62 / 3.49 against 3.73 / 3.55 G at three replicas): the sequencer hands out tickets at 14.8 ns per round, the append
+         * wavefronts' capacity sits within 10 % of that -- shortening one of the two alone shows nothing.  Taken out
+         * again.) */
         if (lane < 8) wv_next = ld_agent(&LS->tkw[lane][(k + G) % RS_CAP]);
         have_next = true;
         if (nt_ring) rep_release(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
