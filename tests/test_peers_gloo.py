@@ -299,3 +299,59 @@ def test_peer_group_replica_kernels_host_logic(name, world):
     if name == "hold_release":
         held = [e[1] for e in tr.events if e[0] == "HOLD"]
         assert all(runs[h] < max(runs.values()) for h in held)      # a held server's process sits runs out
+
+
+def _deposed_worker(rank, world, port, q):
+    """host logic of tests/test_gpu_peers_deposed.py (stand-in engine): ranks 1 and 2 hold an election among themselves, rank 0 -- the
+    deposed leader behind a partition -- is not part of it"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from apus_amd import _lib, peers
+
+        def factory(n, log_len, local_ids=None, device=0, flags=0, capacity=None):
+            e = _FakeEngine(n, log_len, local_ids=local_ids, device=device, flags=flags, capacity=capacity)
+            e._elect = lambda self, w: (setattr(self, "term", getattr(self, "term", 0) + 2), setattr(self, "leader", w), self.calls.append(("elect", w)))
+            return e
+        sub = dist.new_group(ranks=[1, 2])
+        m = peers.PeerMember(world, rank, 0, 1 << 16, engine_factory=factory)
+        first = {r: m.eng.imported[r] for r in m.eng.imported}
+        m.elect(0)                                           # a group's first election: nobody to fence off
+        assert m.fenced == 0 and not any(c[0] in ("fence", "remap") for c in m.eng.calls)
+        dist.barrier()
+        if rank != 0:
+            m.pg = sub
+            m.kill(0)
+            m.elect(1)                                       # the survivors' election: both leave their ring + mailbox, map each other's
+            other = 3 - rank
+            assert m.fenced == 1 and ("fence", rank, 1) in m.eng.calls and ("remap", other, 1) in m.eng.calls
+            assert not any(c[0] == "remap" and c[1] == 0 for c in m.eng.calls)          # nothing of the deposed leader's moved
+            assert m.eng.imported[other] != first[other] and _lib.IpcReplica.from_buffer_copy(m.eng.imported[other]).fences == 1
+            assert m.leader == 1
+        else:
+            # the deposed leader took no part: what it has mapped of ranks 1 and 2 is what they have LEFT
+            assert m.fenced == 0 and all(m.eng.imported[r] == first[r] for r in (1, 2)) and m.leader == 0
+        dist.barrier()
+        q.put((rank, True, ""))
+    except BaseException as exc:      # noqa: BLE001
+        import traceback
+        q.put((rank, False, repr(exc) + traceback.format_exc()[-1200:]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_deposed_leader_keeps_the_mappings_the_others_left():
+    """the receiver's fence at the level of the host logic (CPU, gloo, stand-in engine): an election on a sub-group moves and
+    re-maps only its members' buffers; the rank outside keeps handles of allocations nobody reads any more"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_deposed_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    for r in sorted(res):
+        assert r[1], f"rank {r[0]}: {r[2]}"
