@@ -43,6 +43,8 @@ enum {
     H_N_VISIBLE,      /* leader: entries visible to followers / the ACK scan */
     H_APPLY_OFFSETS,  /* 13 words: ctrl_data->apply_offsets[], dare_server.h:137 */
     H_JOINED_AT = H_APPLY_OFFSETS + APUS_DEV_MAX_SERVERS,   /* a joined server: the entries below this slot were appended by other machines (a former holder of its slot included) */
+    H_TERM_SLOT0,     /* a leader: the slot of the first entry it appended in ITS term (the blank CONFIG entry of become_leader): entries
+                       * below it are inherited from older terms and commit only behind it (apus_replica.h: rep_commit_pass) */
     H_WORDS = H_APPLY_OFFSETS + APUS_DEV_MAX_SERVERS + 3   /* 38 -> padded */
 };
 

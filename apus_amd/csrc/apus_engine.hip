@@ -1223,6 +1223,7 @@ __global__ void k_set_roles(const EngDev E, uint64_t sid, uint32_t bitmask, uint
     lh[H_N_VISIBLE] = n_end;
     lh[H_OLD_END] = lh[H_END];
     lh[H_N_PERSIST] = n_end;
+    lh[H_TERM_SLOT0] = n_end;                 /* the blank CONFIG entry of this term goes here (become_leader appends it next) */
     /* ACK words of entries this server did not append itself start empty */
     for (uint64_t s2 = lh[H_N_COMMIT]; s2 < n_end; s2++) Ld.ack[(uint32_t)s2 & E.dir_mask] = 0;
     for (uint32_t i = 0; i < E.group_size; i++) lh[H_APPLY_OFFSETS + i] = lh[H_HEAD];  /* dare_server.c:1504-1507 */
@@ -2895,6 +2896,14 @@ extern "C" int apus_gpu_rep_follower_stop(apus_engine_t *e, uint32_t replica)
 
 /* tests only: a hosted follower whose workgroups are not launched -- a dead follower process that the leader still pushes to */
 extern "C" int apus_gpu_rep_test_skip_follower(apus_engine_t *e, uint32_t mask) { if (!e) return APUS_E_ARG; e->r_test_skip = mask; return 0; }
+/* tests only: where the leader's own term begins in its log (H_TERM_SLOT0; set by become_leader) -- the gate of rep_commit_pass */
+extern "C" int apus_gpu_rep_test_term_slot0(apus_engine_t *e, uint64_t slot)
+{
+    if (!e || e->d.leader >= e->d.group_size || e->r_running) return APUS_E_STATE;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(&e->d.rep[e->d.leader].hdr[H_TERM_SLOT0], &slot, sizeof slot, hipMemcpyHostToDevice));
+    return 0;
+}
 
 extern "C" uint64_t apus_gpu_rep_highest_rec(apus_engine_t *e) { return (e && e->rh) ? e->rh->highest_rec : 0; }
 extern "C" const volatile uint64_t *apus_gpu_rep_highest_rec_ptr(apus_engine_t *e) { return (e && e->rh) ? &e->rh->highest_rec : nullptr; }

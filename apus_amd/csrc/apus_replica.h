@@ -315,17 +315,20 @@ __device__ static inline uint4 payload_mask(uint4 v, uint32_t so, uint32_t P, ui
  * stored.  cdna_hip_programming.md 5.7 item 1 says so; round 5's first-contact test (apus_selftest.h) showed it: its unrolled
  * pattern loop had the first two words of unit u + 64 in unit u, one unit in five.  The data path's own loops never put a VALU
  * write of the data registers there -- parity at full size says so -- but nothing kept the compiler from doing it.) */
+#ifndef REP_ST_PAD
+#define REP_ST_PAD "\n\ts_nop 1"      /* (-DREP_ST_PAD='""': A/B measurements of the pad only -- never a product build) */
+#endif
 __device__ static inline void st16_wt(uint8_t *p, uint4 v)
 {
     v4u_t d = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" REP_ST_PAD :: "v"(p), "v"(d) : "memory");
 }
 /* 16 bytes as a streaming store: acknowledged by the L2, on its way to memory behind that -- visible to others only
  * behind rep_release() */
 __device__ static inline void st16_nt(uint8_t *p, uint4 v)
 {
     v4u_t d = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off nt" REP_ST_PAD :: "v"(p), "v"(d) : "memory");
 }
 /* everything this wavefront has stored is in memory (system scope): write-back of the L2's dirty lines + drain */
 __device__ static inline void rep_release()
@@ -336,7 +339,7 @@ __device__ static inline void rep_release()
 __device__ static inline void st16_dev(uint8_t *p, uint4 v)
 {
     v4u_t d = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" REP_ST_PAD :: "v"(p), "v"(d) : "memory");
 }
 __device__ static inline void ld32_dev(const uint8_t *p, uint4 &a, uint4 &b)
 {
@@ -1209,7 +1212,7 @@ struct RepCommitState {
  * largest of the followers' counts; the scan stops at the first entry that lacks its majority (:1741) = at that count.
  * Granules may be looked at before they are there: one that is not this round's does not count. */
 __device__ static inline void rep_commit_pass(const EngDev &E, RepLead *LS, RepCommitState &C, uint64_t tail,
-                                              const RepBox *mybox, uint32_t members, uint32_t quorum, uint64_t my_tag)
+                                              const RepBox *mybox, uint32_t members, uint32_t quorum, uint64_t my_tag, uint64_t term_slot0)
 {
     const uint32_t lane = lane_id();
     const uint64_t base = C.t_done;
@@ -1265,7 +1268,15 @@ __device__ static inline void rep_commit_pass(const EngDev &E, RepLead *LS, RepC
         const unsigned long long sel = __ballot(lane < 16 && rank == quorum - 2);
         acked = sel ? rl64u(val, __builtin_ctzll(sel)) : 0ull;
     }
-    const uint64_t upto = acked < C.vis ? acked : C.vis;
+    uint64_t upto = acked < C.vis ? acked : C.vis;
+    /* Entries this leader INHERITED (slots below the first entry of its own term, H_TERM_SLOT0 = the blank CONFIG entry of
+     * become_leader) commit only BEHIND that entry: a follower's count says how much of the log it holds in order, not in
+     * which term it came to hold it -- a voter that lags can hold the older entries without the CONFIG, and a majority by
+     * count among such voters would commit older-term entries while this term's own entry sits on a minority: a later
+     * leader may still overwrite them (the leader-completeness argument of Raft, figure 8; the reference never commits them
+     * at all: its followers acknowledge to the dead sender, DESIGN 6 deviation 4).  So the commit does not move below
+     * term_slot0 until the (quorum - 1)-th largest count covers the slot itself.   */
+    if (C.cs < term_slot0 && acked <= term_slot0) upto = C.cs;
     if (upto > C.cs) { C.cs = upto; C.progress = true; }
 }
 
@@ -1303,6 +1314,7 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, l
     C.cs = s_h[H_N_COMMIT];
     C.slots_done = ld_sys(&H->slots_done);
     C.push_live = A.push_mask;
+    const uint64_t term_slot0 = s_h[H_TERM_SLOT0];
     if (s_h[H_END] != E.log_len) C.vis = C.n_end_seen;   /* (an exact-fit round left hidden stays so until the next round is in) */
     else if (C.vis < C.n_end_seen) C.vis_off = Md.dir_off[(uint32_t)C.vis & E.dir_mask];
     uint64_t settled = ~0ull, cs_pub = C.cs, sd_pub = C.slots_done;
@@ -1318,7 +1330,7 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, l
 #if REP_ACK_BYTES
         if (C.cs < C.pre_end) rep_commit_pre(E, C, ackb, cap, members, quorum);
 #endif
-        rep_commit_pass(E, LS, C, tail, mybox, members, quorum, my_tag);
+        rep_commit_pass(E, LS, C, tail, mybox, members, quorum, my_tag, term_slot0);
         if (lane == 0) { s_m[M_T_DONE] = C.t_done; s_m[M_CS] = C.cs; }      /* (the applier reads M_CS first) */
         if (C.slots_done != sd_pub) { sd_pub = C.slots_done; if (lane == 0) st_sys(&H->slots_done, C.slots_done + s_m[M_DROPPED]); }
         if (C.cs > cs_pub) {
@@ -1373,7 +1385,8 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, l
 #if REP_ACK_BYTES
             if (in && s < hf && ld_sys8(ackb + (uint64_t)f * cap + di) == want) bits |= 1u << f;
 #else
-            if (in && s < hf) bits |= 1u << f;
+            /* (an inherited entry counts as acknowledged by f only when f holds this term's first entry as well: above) */
+            if (in && s < hf && (s >= term_slot0 || hf > term_slot0)) bits |= 1u << f;
 #endif
         }
         if (!in) continue;

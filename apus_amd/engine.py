@@ -463,12 +463,13 @@ class Engine:
         return out
 
     def run_trace_rep(self, trace: Trace, source: str = "pinned", idle_ms: int = 3000, peer_ms: int = 500,
-                      n_append: int = 0, n_fwork: int = 0, drain_each: bool = False):
+                      n_append: int = 0, n_fwork: int = 0, drain_each: bool = False, on_event=None):
         """The trace with its ROUND / PRUNE events going through the replica kernels: the leader's and every
         follower's own workgroups.  source = "pinned": the requests cross the pinned multi-producer ring one
         ROUND event at a time (drained per event when drain_each, so that round boundaries are the trace's);
         "staged": stretches of ROUND events run from the staged, device-resident input.  Control-plane events
-        (ELECT, HOLD, RELEASE, KILL, JOIN, QUIESCE) park the run and use the control-plane kernels."""
+        (ELECT, HOLD, RELEASE, KILL, JOIN, QUIESCE) park the run and use the control-plane kernels.
+        on_event(i, event, engine) is called behind every control-plane event (the run is parked then)."""
         reqs = np.ascontiguousarray(trace.reqs, dtype=REQ_DTYPE)
         arena = np.ascontiguousarray(trace.arena, dtype=np.uint8)
         if source == "staged":
@@ -521,6 +522,8 @@ class Engine:
                     self.join(ev[i][1])
                 else:
                     raise EngineError(f"trace event {ev[i]} is not supported")
+                if on_event is not None:
+                    on_event(i, ev[i], self)
                 i += 1
             park()
         finally:

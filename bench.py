@@ -398,7 +398,7 @@ def _rep_step_cmds(tr, eng):
     return out
 
 
-def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True, regions_n=3, latency=True):
+def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True, regions_n=3, latency=True, oracle_check=True):
     """BASELINE configs[1] read literally -- "single persistent kernel per replica": every replica runs its OWN
     resident workgroups (apus_amd/csrc/apus_replica.h).  The leader's pipelined workgroups push only log bytes and
     a doorbell per round; each follower's workgroups build directory / apply records from the landed bytes, persist,
@@ -426,7 +426,59 @@ def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True, regions_n
                     eng.rep_run(c[1], c[2])
                 else:
                     eng.rep_prune()
-        # (c) first, on an otherwise idle device
+        hr_base = eng.counters(0)["highest_rec"]
+        # (a) device-resident input -- first, on the engine as the election left it: the whole run is replayed by the oracle below
+        eng.rep_start(idle_ms=5000, peer_ms=1000)
+        step()
+        eng.rep_drain(timeout_ms=60000)
+        regions = []
+        for _ in range(regions_n):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            eng.rep_drain(timeout_ms=120000)
+            regions.append(time.perf_counter() - t0)
+        code = eng.rep_park()
+        roles = eng.rep_role_stats()
+        launch_ms = eng.rep_launch_ms()          # HIP events around the resident launch: 1 + regions_n * steps steps + the host's gaps
+        eng.quiesce()
+        total = hr_base + (1 + regions_n * steps) * len(tr.reqs)
+        ok = eng.status() == 0 and code == 0 and eng.counters(0)["highest_rec"] == total
+        for r in range(n_rep):
+            o = eng.offsets(r)
+            ok = ok and (o["commit"] == o["end"] == o["apply"])
+        # ---- bit-exact, not just "caught up": the run that was TIMED against the oracle (outside every timed region).  The
+        #      oracle (the checker: oracle/liboracle.so, pinned on the reference) replays the same commands -- ELECT, then
+        #      1 + regions_n x steps passes over the stream's rounds and prune ticks on the same logs -- and every replica is
+        #      compared: all 8 offsets, every defined ring byte, the canonical digest, highest_rec, apply count and stream hash
+        #      over all steps, store count, the newest apply records one by one; and the replicas' rings among each other.
+        bit_exact, bit_note = None, None
+        if oracle_check and ok:
+            try:
+                t_o = time.perf_counter()
+                from tests.parity import compare_replica, compare_apply_tail, oracle_replay_steps
+                cl = oracle_replay_steps(tr, 1 + regions_n * steps)
+                for r in range(n_rep):
+                    compare_replica(eng, cl, r, tag="the timed run")
+                    compare_apply_tail(eng, cl, r)
+                bit_exact = True
+                bit_note = (f"oracle replay of all {1 + regions_n * steps} steps ({(1 + regions_n * steps) * len(tr.reqs)} entries) + "
+                            f"full comparison of {n_rep} replicas: {time.perf_counter() - t_o:.1f} s, outside the timed regions")
+            except AssertionError as exc:
+                bit_exact, bit_note = False, str(exc)[:400]
+            except Exception as exc:           # (no oracle library on this box: the check is reported as not made, never as passed)
+                bit_exact, bit_note = None, "oracle check not made: " + repr(exc)[:300]
+        ok = ok and bit_exact is not False
+        dt = float(np.median(regions))
+        out["device_resident"] = {"value": len(tr.reqs) * steps / dt, "unit": "entries/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                                  "regions_entries_per_s": [len(tr.reqs) * steps / x for x in regions], "verified": bool(ok),
+                                  "bit_exact_vs_oracle": bit_exact, "oracle_check": bit_note,
+                                  "launch_ms": launch_ms, "entries_in_launch": (1 + regions_n * steps) * len(tr.reqs),
+                                  # passes of the serial roles and the rounds they moved (the per-pass clocks only run under APUS_REP_DBG&512)
+                                  "roles": {k: {"passes": v["moved"], "rounds": v["rounds"]} for k, v in roles.items()
+                                            if k in ("sequencer", "committer", "applier", "f0_retire", "f0_apply") and "moved" in v}}
+        print("[bench]   device-resident done", file=sys.stderr, flush=True)
+        # (c) lone rounds, on an otherwise idle device (a fresh resident launch behind the parked one)
         if latency:
             reqs64 = np.ascontiguousarray(tr.reqs[16:16 + 64])
             eng.rep_start(idle_ms=5000, peer_ms=1000)
@@ -447,37 +499,7 @@ def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True, regions_n
                     "host_publish_to_sequenced_plus_highest_rec_back_to_host": lh_ - ls_,     # two PCIe crossings: the sequencer's poll, the applier's store
                     "sequenced_to_bytes_in_every_ring": ls_ - la_,                            # ticket, descriptor + payload over PCIe, stores + drain
                     "bytes_in_every_ring_to_committed_and_applied": la_}                      # doorbell, follower persist + ACK, committer, applier
-        hr_base = eng.counters(0)["highest_rec"]
-        # (a) device-resident input
-        print("[bench]   latency done; device-resident run", file=sys.stderr, flush=True)
-        eng.rep_start(idle_ms=5000, peer_ms=1000)
-        step()
-        eng.rep_drain(timeout_ms=60000)
-        regions = []
-        for _ in range(regions_n):
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                step()
-            eng.rep_drain(timeout_ms=120000)
-            regions.append(time.perf_counter() - t0)
-        code = eng.rep_park()
-        roles = eng.rep_role_stats()
-        launch_ms = eng.rep_launch_ms()          # HIP events around the resident launch: 1 + regions_n * steps steps + the host's gaps
-        eng.quiesce()
-        total = hr_base + (1 + regions_n * steps) * len(tr.reqs)
-        ok = eng.status() == 0 and code == 0 and eng.counters(0)["highest_rec"] == total
-        for r in range(n_rep):
-            o = eng.offsets(r)
-            ok = ok and (o["commit"] == o["end"] == o["apply"])
-        dt = float(np.median(regions))
-        out["device_resident"] = {"value": len(tr.reqs) * steps / dt, "unit": "entries/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-                                  "regions_entries_per_s": [len(tr.reqs) * steps / x for x in regions], "verified": bool(ok),
-                                  "launch_ms": launch_ms, "entries_in_launch": (1 + regions_n * steps) * len(tr.reqs),
-                                  # passes of the serial roles and the rounds they moved (the per-pass clocks only run under APUS_REP_DBG&512)
-                                  "roles": {k: {"passes": v["moved"], "rounds": v["rounds"]} for k, v in roles.items()
-                                            if k in ("sequencer", "committer", "applier", "f0_retire", "f0_apply") and "moved" in v}}
         # (b) host-fed
-        print("[bench]   device-resident done", file=sys.stderr, flush=True)
         if hostfed:
             blk = np.ascontiguousarray(tr.reqs[16:16 + 4096])
             hf = {}

@@ -286,7 +286,7 @@ typedef struct {
     /* upcall bookkeeping (what the proxy callbacks would observe) */
     uint64_t highest_rec;                       /* proxy.c:263 */
     uint64_t store_count;                       /* proxy_store_cmd calls */
-    uint64_t apply_count, apply_hash;
+    uint64_t apply_count, apply_hash, apply_rec_base;
     uint64_t apply_slot;                        /* entries walked by apply_committed_entries */
     orc_apply_t *apply_log; uint64_t apply_cap;
     orc_det_t last_applied;                     /* dare_server.c:73 */
@@ -361,11 +361,12 @@ static void record_apply(orc_cluster_t *c, replica_t *p, uint64_t off, const orc
 {
     p->apply_hash += orc_apply_mix(p->apply_slot, off, e->idx, e->data.cmd.len, e->clt_id, e->type, kind);
     if (c->record_apply) {
-        if (p->apply_count == p->apply_cap) {
+        const uint64_t k = p->apply_count - p->apply_rec_base;     /* (records are kept from where recording was last switched on) */
+        if (k == p->apply_cap) {
             p->apply_cap = p->apply_cap ? p->apply_cap * 2 : 1024;
             p->apply_log = realloc(p->apply_log, p->apply_cap * sizeof(orc_apply_t));
         }
-        orc_apply_t *a = &p->apply_log[p->apply_count];
+        orc_apply_t *a = &p->apply_log[k];
         a->slot = p->apply_slot; a->off = off; a->idx = e->idx; a->len = e->data.cmd.len;
         a->clt_id = e->clt_id; a->type = e->type; a->kind = kind;
     }
@@ -409,7 +410,12 @@ void orc_cluster_free(orc_cluster_t *c)
     free(c);
 }
 
-void orc_cluster_record_apply(orc_cluster_t *c, int on) { c->record_apply = on; }
+void orc_cluster_record_apply(orc_cluster_t *c, int on)
+{
+    /* switched on in mid-run (a long replay that keeps the upcalls of its last stretch only): the record starts here */
+    if (on && !c->record_apply) for (int i = 0; i < ORC_MAX_SERVERS; i++) c->r[i].apply_rec_base = c->r[i].apply_count;
+    c->record_apply = on;
+}
 void orc_cluster_record_store(orc_cluster_t *c, int on) { c->record_store = on; }
 const uint8_t *orc_replica_store_stream(const orc_cluster_t *c, int r, uint64_t *n) { *n = c->r[r].store_len; return c->r[r].store_buf; }
 uint32_t orc_replica_records_len(const orc_cluster_t *c, int r) { return c->r[r].records_len; }
@@ -428,7 +434,7 @@ uint64_t orc_replica_apply_count(const orc_cluster_t *c, int r) { return c->r[r]
 uint64_t orc_replica_apply_hash(const orc_cluster_t *c, int r) { return c->r[r].apply_hash; }
 uint64_t orc_replica_store_count(const orc_cluster_t *c, int r) { return c->r[r].store_count; }
 const orc_apply_t *orc_replica_apply_log(const orc_cluster_t *c, int r, uint64_t *n)
-{ *n = c->record_apply ? c->r[r].apply_count : 0; return c->r[r].apply_log; }
+{ *n = c->record_apply ? c->r[r].apply_count - c->r[r].apply_rec_base : 0; return c->r[r].apply_log; }
 uint64_t orc_round_count(const orc_cluster_t *c) { return c->n_rounds; }
 const uint64_t *orc_round_commit(const orc_cluster_t *c) { return c->round_commit; }
 const uint64_t *orc_round_end(const orc_cluster_t *c) { return c->round_end; }

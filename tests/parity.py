@@ -131,3 +131,84 @@ def lockstep(trace, eng, check_at=("PRUNE", "QUIESCE"), coalesce=True, allow_exa
     assert cl.force_prunes == 0, ("the trace fills the log to 75 %: the reference's force_log_pruning "
                                   "(dare_server.c:2069, follower eviction) is modelled by the oracle only")
     return cl
+
+
+def step_commands(trace, round_of_g0):
+    """the commands of ONE step of a steady trace, as bench.py issues them to the replica kernels: a stretch of consecutive
+    ROUND events = ("run", first staged round, rounds), a PRUNE event = ("prune",)"""
+    out, ev, i = [], trace.events, 0
+    while i < len(ev):
+        if ev[i][0] == "ROUND":
+            j = i
+            while j < len(ev) and ev[j][0] == "ROUND":
+                j += 1
+            out.append(("run", round_of_g0[ev[i][1]], j - i))
+            i = j
+            continue
+        if ev[i][0] == "PRUNE":
+            out.append(("prune",))
+        i += 1
+    return out
+
+
+def oracle_replay_steps(trace, steps, record_last=True):
+    """The oracle's side of a bench-shaped run (bench.py: measure_replica_kernels, dare_server.c:1012-1125 is the loop it
+    stands for): ELECT, then `steps` passes over the trace's ROUND / PRUNE events on the same logs, then QUIESCE.  The apply
+    upcalls are recorded for the last step only (a hundred steps of configs[1] are 10^8 upcalls).  -> the cluster"""
+    rounds = [(e[1], e[2]) for e in trace.events if e[0] == "ROUND"]
+    round_of_g0 = {g0: i for i, (g0, _) in enumerate(rounds)}
+    round_n = np.array([n for _, n in rounds], dtype=np.uint32)
+    first = np.concatenate([[0], np.cumsum(round_n)]).astype(np.int64)
+    reqs = np.ascontiguousarray(trace.reqs, dtype=orc.REQ_DTYPE)
+    arena = np.ascontiguousarray(trace.arena, dtype=np.uint8)
+    cmds = step_commands(trace, round_of_g0)
+    cl = orc.Cluster(trace.group_size, trace.log_len, record_apply=False)
+    cl.elect(trace.leader)
+    for s in range(steps):
+        if record_last and s == steps - 1:
+            cl.L.orc_cluster_record_apply(cl.h, 1)
+        for c in cmds:
+            if c[0] == "run":
+                r0, n = c[1], c[2]
+                cl.run_rounds(reqs[first[r0]:first[r0 + n]], round_n[r0:r0 + n], arena, 0)
+            else:
+                cl.tick_prune()
+    cl.quiesce()
+    return cl
+
+
+def lockstep_rep(trace, eng, source="staged", **kw):
+    """The trace through the replica kernels (Engine.run_trace_rep) with the oracle in lock step: behind every QUIESCE
+    event -- the run is parked there -- every reachable replica is compared bit for bit.  Returns the oracle cluster."""
+    cl = orc.Cluster(trace.group_size, trace.log_len, record_apply=True)
+    reqs = np.ascontiguousarray(trace.reqs, dtype=orc.REQ_DTYPE)
+    arena = np.ascontiguousarray(trace.arena, dtype=np.uint8)
+    ev = trace.events
+    done = [0]                      # oracle: events carried out
+
+    def catch_up(upto):
+        while done[0] <= upto:
+            e = ev[done[0]]
+            op = e[0]
+            if op == "ROUND": cl.round(reqs[e[1]:e[1] + e[2]], arena)
+            elif op == "ELECT": cl.elect(e[1])
+            elif op == "PRUNE": cl.tick_prune()
+            elif op == "QUIESCE": cl.quiesce()
+            elif op == "KILL": cl.kill(e[1])
+            elif op == "HOLD": cl.hold(e[1])
+            elif op == "RELEASE": cl.release(e[1])
+            elif op == "JOIN": cl.join(e[1])
+            else: raise ValueError(e)
+            done[0] += 1
+
+    def on_event(i, e, engine):
+        catch_up(i)
+        if e[0] == "QUIESCE":
+            engine.check_status()
+            for r in range(engine.group_size):
+                if (engine.reachable >> r) & 1:
+                    compare_replica(engine, cl, r, tag=f"replica kernels ({source}), event {i} {e}")
+    eng.run_trace_rep(trace, source=source, on_event=on_event, **kw)
+    catch_up(len(ev) - 1)
+    assert cl.force_prunes == 0
+    return cl

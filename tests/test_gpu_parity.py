@@ -597,47 +597,10 @@ def test_random_traces_through_batched_launches(eng_factory, seed):
     workgroups first / segment by segment, one or two rounds per wavefront, wraps inside a launch,
     followers cut off and released, prune ticks at random places), lock step against the oracle."""
     from tests.parity import lockstep
-    rng = np.random.default_rng(1000 + seed)
-    n = int(rng.choice([3, 5, 7]))
-    L = int(rng.choice([1 << 18, 1 << 20, 1 << 22]))
-    sizes = [(64,), (64, 107), (40, 64, 300, 1024), (1, 17, 64)][int(rng.integers(0, 4))]
-    batch = [64, (1, 64), 16, (8, 32)][int(rng.integers(0, 4))]
-    n_send = int(rng.integers(3000, 30000))
-    picks = rng.random(4 * n_send + 64)          # the same decisions for every ring size tried below
-    who = rng.integers(1, n, 4 * n_send + 64)
-    while True:
-        base = _random_trace(n, n_send, sizes, batch, L, seed, picks, who)
-        # a follower that is cut off for long holds the head back; at 75 % fill the reference evicts it
-        # (force_log_pruning, dare_server.c:2069 -- SURVEY.md 8 f2, not in the engine): a bigger ring then
-        if orc.run_trace(base).force_prunes == 0 or L >= (1 << 26):
-            break
-        L *= 4
-    eng = eng_factory(n, L)
+    from tests import traces
+    base = traces.random_hold_release(seed, orc.run_trace)
+    eng = eng_factory(base.group_size, base.log_len)
     lockstep(base, eng, batch=True, check_at=("QUIESCE",))
-
-
-def _random_trace(n, n_send, sizes, batch, L, seed, picks, who):
-    base = T.steady_trace(n, n_send, sizes, 8, batch, log_len=L, prune_bytes=max(L // 8, 4096), seed=seed)
-    ev, held, k = [], [], 0
-    rng = None
-    for e in base.events:
-        k += 1
-        ev.append(e)
-        p = picks[2 * (k % (len(picks) // 2))]
-        if e[0] == "ROUND" and p < 0.01:
-            if held and picks[2 * (k % (len(picks) // 2)) + 1] < 0.6:
-                ev += [("RELEASE", held.pop()), ("QUIESCE",)]
-            elif len(held) < (n - 1) // 2:                      # the majority stays reachable
-                f = int(who[k % len(who)])
-                if f not in held:
-                    held.append(f); ev.append(("HOLD", f))
-        elif e[0] == "ROUND" and p > 0.996:
-            ev.append(("QUIESCE",))
-    for f in held:
-        ev.append(("RELEASE", f))
-    ev.append(("QUIESCE",))
-    base.events = ev
-    return base
 
 
 JOIN_TRACES = ["join_empty_slot", "join_upsize_3_to_5", "join_wrapped", "join_then_failover", "c5_rejoin"]

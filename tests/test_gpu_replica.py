@@ -194,3 +194,132 @@ def test_rep_doorbell_metadata_says_what_the_headers_say(name, source, monkeypat
     run_and_compare(traces.CATALOGUE[name](), source)
     monkeypatch.setenv("APUS_REP_DBG", "16384")
     run_and_compare(traces.CATALOGUE[name](), source)
+
+
+# ---- round 6: the configurations nobody ran -------------------------------------------------------
+
+@pytest.mark.parametrize("g", [1, 5, 7])
+def test_rep_full_size_c2_stream_at_every_group_size(g):
+    """The metric names 1, 3, 5 and 7 replicas on the 64-B stream: configs[1]'s stream at FULL size through the replica
+    kernels at the three sizes test_rep_full_size_staged[c2] does not cover -- bit for bit on every replica.  One replica:
+    the quorum of one (dare_ibv_rc.c:1725-1758 with size = 1: every entry has its majority the moment the leader holds it)
+    and the leader-only launch (k_replica_leader).  Reference loops: dare_server.c:1012-1125, :1751-1790."""
+    run_and_compare(T.config_c2(group_size=g), "staged", idle_ms=20000, peer_ms=5000)
+
+
+def test_rep_full_size_c2_single_replica_host_fed():
+    """... and the single replica with every request crossing the request ring (proxy_on_read's admission)"""
+    run_and_compare(T.config_c2(group_size=1), "pinned", idle_ms=20000, peer_ms=5000)
+
+
+@pytest.mark.parametrize("g,steps", [(3, 101), (1, 24)])
+def test_rep_bench_shaped_run_is_bit_exact(g, steps):
+    """What bench.py times, digested: ONE resident launch, `steps` passes over configs[1]'s stream on the same rings (101
+    steps = 250 laps of the 64 MiB ring, 1616 prune ticks, 10^8 entries) -- then every replica against an oracle that
+    replayed the same commands: all 8 offsets, every defined ring byte, the canonical digest, highest_rec, apply count +
+    stream hash over ALL steps, store count, and the apply records of the last step's newest entries one by one.
+    The loop this replaces: dare_server.c:1012-1125."""
+    from apus_amd.engine import Engine
+    from tests.parity import compare_replica, compare_apply_tail, oracle_replay_steps, step_commands
+    tr = T.config_c2(group_size=g)
+    eng = Engine(g, tr.log_len)
+    try:
+        eng.stage_trace(tr)
+        eng.elect(0)
+        eng.sync()
+        cmds = step_commands(tr, eng.round_of_g0)
+        eng.rep_start(idle_ms=20000, peer_ms=5000)
+        for _ in range(steps):
+            for c in cmds:
+                if c[0] == "run":
+                    eng.rep_run(c[1], c[2])
+                else:
+                    eng.rep_prune()
+        eng.rep_drain(timeout_ms=120000)
+        assert eng.rep_park() == 0
+        eng.quiesce()
+        assert eng.status() == 0, eng.status_names()
+        cl = oracle_replay_steps(tr, steps)
+        assert eng.counters(0)["highest_rec"] == steps * len(tr.reqs)
+        for r in range(g):
+            compare_replica(eng, cl, r, tag=f"{steps} steps in one resident launch")
+            compare_apply_tail(eng, cl, r)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_rep_random_traces(seed):
+    """The seeded random workloads of test_random_traces_through_batched_launches (3 / 5 / 7 replicas, mixed entry and round
+    sizes, followers cut off and released, QUIESCE events and prune ticks at random places) through the replica kernels,
+    the oracle in lock step: compared at every QUIESCE."""
+    from apus_amd.engine import Engine
+    from oracle import oracle as orc
+    from tests.parity import lockstep_rep, compare_apply_tail
+    tr = traces.random_hold_release(seed, orc.run_trace)
+    eng = Engine(tr.group_size, tr.log_len)
+    try:
+        cl = lockstep_rep(tr, eng, "staged")
+        eng.quiesce()
+        for r in range(tr.group_size):
+            compare_apply_tail(eng, cl, r)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
+def test_rep_full_size_doorbell_metadata_against_the_headers(cfg, monkeypatch):
+    """R_BELL_META at full size: the followers build their directory / apply records from what the LEADER says about an entry
+    (4 bytes beside the doorbell); here every follower wavefront reads the headers that landed as well and raises a status
+    bit where the two differ (APUS_REP_DBG & 32768) -- configs[1..3] at full size, then the usual bit-exact comparison."""
+    monkeypatch.setenv("APUS_REP_DBG", "32768")
+    run_and_compare(FULL[cfg](), "staged", idle_ms=20000, peer_ms=5000)
+
+
+def test_rep_inherited_entries_commit_only_behind_the_terms_first_entry():
+    """a follower's cumulative count says how much of the log it holds in order, not in which term it came to hold
+    it.  Entries below the slot of the leader's first entry of its OWN term (H_TERM_SLOT0, the blank CONFIG entry) commit
+    only once the (quorum - 1)-th largest count covers that slot.  Here the slot is moved far ahead of the log (test hook):
+    two of three replicas hold and acknowledge every round, and nothing commits; with the slot where become_leader put it
+    the same rounds commit."""
+    import ctypes as C
+    from apus_amd.engine import Engine
+    tr = T.steady_trace(3, 64 * 20, 64, 8, 64, log_len=1 << 20, prune_bytes=1 << 40)
+    eng = Engine(3, tr.log_len)
+    try:
+        eng.stage_trace(tr)
+        eng.elect(0)
+        eng.sync()
+        L = eng.L
+        L.apus_gpu_rep_test_term_slot0.argtypes = [C.c_void_p, C.c_uint64]
+        w = eng.hdr_words(0)
+        slot0 = int(w[37])                                       # H_TERM_SLOT0
+        assert slot0 == eng.counters(0)["n_end"] - 1             # the blank CONFIG entry of the election
+        c0 = eng.counters(0)["n_commit"]
+        assert L.apus_gpu_rep_test_term_slot0(eng.h, 1 << 40) == 0
+        n_rounds = sum(1 for e in tr.events if e[0] == "ROUND")
+        eng.rep_start(idle_ms=3000, peer_ms=100)
+        eng.rep_run(0, n_rounds)
+        with pytest.raises(Exception):
+            eng.rep_drain(timeout_ms=300)                        # every round is in every ring and acknowledged; nothing may commit
+        assert eng.rep_stats()["commit_slot"] == c0
+        eng.rep_park()
+        L.apus_gpu_clear_status(eng.h)
+        assert eng.counters(0)["n_commit"] == c0 and eng.counters(1)["n_end"] == eng.counters(0)["n_end"]
+        # the term's first entry where it really is: the next run commits everything
+        assert L.apus_gpu_rep_test_term_slot0(eng.h, slot0) == 0
+        import time
+        n_end = eng.counters(0)["n_end"]
+        eng.rep_start(idle_ms=3000, peer_ms=500)
+        t0 = time.time()
+        while eng.rep_stats()["commit_slot"] < n_end and time.time() - t0 < 5:
+            time.sleep(0.001)
+        assert eng.rep_stats()["commit_slot"] == n_end           # by the followers' counts, no new round needed
+        assert eng.rep_park() == 0
+        eng.quiesce()                                            # (entries without a ticket are applied by the control-plane pass)
+        assert eng.status() == 0, eng.status_names()
+        o = eng.offsets(0)
+        assert o["commit"] == o["end"] == o["apply"], o
+        assert eng.counters(0)["highest_rec"] == len(tr.reqs)
+    finally:
+        eng.close()

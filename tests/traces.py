@@ -225,3 +225,48 @@ def no_quorum_wide():
 
 # traces for the GPU tests only (not part of the golden records written from the reference)
 EXTRA = {f.__name__: f for f in (no_quorum_wide,)}
+
+
+def random_hold_release(seed: int, oracle_run=None):
+    """Seeded random workload: group size, ring size, entry sizes and round sizes drawn per seed; followers cut off and
+    released, QUIESCE events and prune ticks at random places (the majority always stays reachable).  A follower that is
+    cut off for long holds the head back; at 75 % fill the reference evicts it (force_log_pruning, dare_server.c:2069 --
+    modelled by the oracle only): the ring is then quadrupled until the trace stays clear of it.
+    oracle_run(trace) -> cluster (oracle.oracle.run_trace) decides that; the events do not depend on the ring size."""
+    import numpy as np
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([3, 5, 7]))
+    L = int(rng.choice([1 << 18, 1 << 20, 1 << 22]))
+    sizes = [(64,), (64, 107), (40, 64, 300, 1024), (1, 17, 64)][int(rng.integers(0, 4))]
+    batch = [64, (1, 64), 16, (8, 32)][int(rng.integers(0, 4))]
+    n_send = int(rng.integers(3000, 30000))
+    picks = rng.random(4 * n_send + 64)          # the same decisions for every ring size tried below
+    who = rng.integers(1, n, 4 * n_send + 64)
+    while True:
+        base = _random_events(n, n_send, sizes, batch, L, seed, picks, who)
+        if oracle_run is None or oracle_run(base).force_prunes == 0 or L >= (1 << 26):
+            return base
+        L *= 4
+
+
+def _random_events(n, n_send, sizes, batch, L, seed, picks, who):
+    base = T.steady_trace(n, n_send, sizes, 8, batch, log_len=L, prune_bytes=max(L // 8, 4096), seed=seed)
+    ev, held, k = [], [], 0
+    for e in base.events:
+        k += 1
+        ev.append(e)
+        p = picks[2 * (k % (len(picks) // 2))]
+        if e[0] == "ROUND" and p < 0.01:
+            if held and picks[2 * (k % (len(picks) // 2)) + 1] < 0.6:
+                ev += [("RELEASE", held.pop()), ("QUIESCE",)]
+            elif len(held) < (n - 1) // 2:                      # the majority stays reachable
+                f = int(who[k % len(who)])
+                if f not in held:
+                    held.append(f); ev.append(("HOLD", f))
+        elif e[0] == "ROUND" and p > 0.996:
+            ev.append(("QUIESCE",))
+    for f in held:
+        ev.append(("RELEASE", f))
+    ev.append(("QUIESCE",))
+    base.events = ev
+    return base
