@@ -67,7 +67,7 @@
 #define RA_CAP    (64u << 20)    /* pinned payload arena (bytes)                              */
 #define RC_CAP    256u           /* host command ring                                         */
 #ifndef R_WIN
-#define R_WIN     32             /* 64-slot windows of the request ring the sequencer reads per round trip.  Round 5, four producers, M entries/s
+#define R_WIN     8              /* 64-slot windows of the request ring the sequencer reads per round trip.  Round 5, four producers, M entries/s
                                   * host-fed: 8 windows 167, 16 windows 242, 32 windows 300 (a pass costs ~1.8 us + ~0.17 us per window; the next
                                   * pass's words are asked for while this pass's record and tickets are stored).  The two 32-word register
                                   * arrays take the leader's kernels to 219 VGPRs: two wavefronts per SIMD, which is what a launch of at most two
@@ -76,6 +76,9 @@
 #ifndef R_SUB
 #define R_SUB     4              /* 64-round chunks a serial role handles per memory round trip  */
 #endif
+#define GP_MAX    4096u          /* staged rounds ONE pass of the sequencer may take (one record, two words per ticket) */
+#define GP_GOAL   1024u          /* ... and the room it waits for when the rings run full: tickets are handed out this many at a time */
+#define GP_GRP    8              /* 64-ticket chunks of a pass whose words are loaded together */
 #define R_LAT_CAP (1u << 16)
 #define R_SLACK   (3u * WAVE)    /* head room kept in the ticket / doorbell rings             */
 #define R_INLINE  96u            /* payload bytes that fit into the request slot itself       */
@@ -721,14 +724,8 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
     const bool stats = A.dbg & 512;      /* per-pass clocks: every look at the wall clock is a scalar memory round trip */
     const uint64_t st_t0 = wall_clock64();
 
-    /* the staged passes' pipeline registers: the next pass's rounds, the flow-control words and the next host commands
-     * as the last pass asked for them */
-    uint64_t npf0[R_SUB], npf1[R_SUB], pre_rc = ~0ull, pre_end = 0;
-    uint32_t nrf0[R_SUB], nrf1[R_SUB];
-#pragma unroll
-    for (int s = 0; s < R_SUB; s++) { npf0[s] = 0; npf1[s] = 0; nrf0[s] = 0; nrf1[s] = 0; }
-    bool fl_pending = false, pk_pending = false;
-    uint64_t fl_t = 0, fl_v = 0, pk_cg = 0, pk_next = 0;
+    bool pk_pending = false;                     /* the next host commands, asked for by a staged pass that may end its run */
+    uint64_t pk_cg = 0, pk_next = 0;
     /* the request-ring passes' pipeline registers (host-fed input) */
     uint32_t pf_v[R_WIN];
     uint64_t pf_cg = 0, pf_stop = 0, pf_head = 0, pf_cmd = 0;
@@ -771,6 +768,37 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
         return 1;
     };
 
+    /* Flow control: room in the ticket ring and in every pushed follower's doorbell ring.  Waits until every ring has room for
+     * `need` rounds (a short while when at least one round's room is there: the rest of a big pass can wait for the next look)
+     * -> budget.  A follower that leaves less than a round's room for peer_polls looks in a row leaves the push set; false: the
+     * leader's own ticket ring does not drain -- its commit does not move, no majority: the run ends (R_EXIT_TIMEOUT). */
+    auto flow_wait = [&](uint32_t need) -> bool {
+        uint64_t spins = 0, soft = 0;
+        st_flow++;
+        const uint64_t tf0 = stats ? wall_clock64() : 0;
+        for (;;) {
+            uint64_t room = ~0ull;
+            if (lane == 0) {
+                const uint64_t inflight = S.t - s_m[M_T_RETIRED];
+                room = inflight + R_SLACK >= RS_CAP ? 0 : RS_CAP - R_SLACK - inflight;
+            } else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) {
+                const uint64_t inflight = my_qbase + S.t - ld_sys(&mybox->seqdone_by[lane - 1]);
+                room = inflight + R_SLACK >= RB_CAP ? 0 : RB_CAP - R_SLACK - inflight;
+            }
+            const unsigned long long tight = __ballot(room < WAVE);
+            const uint32_t r0 = wmin32((uint32_t)min(room, (uint64_t)0xFFFFFFFFu));
+            if (r0 >= need || (!tight && ++soft > 64)) { budget = r0; break; }
+            if (tight && ++spins > A.peer_polls) {
+                if (tight >> 1) { rep_seq_drop(E, S, LS, (uint32_t)(tight >> 1), 7102); spins = 0; continue; }
+                exit_code = R_EXIT_TIMEOUT;                     /* the leader's own commit does not move: no majority */
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (stats) st_flowt += wall_clock64() - tf0;
+        return true;
+    };
+
     for (;;) {
         st_pass++;
         /* ---- a host command that is already here runs at once: no look at the rings in front of it (round 3 paid a
@@ -781,128 +809,63 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
             if (x == 1) { idle = 0; continue; }
         }
         /* ---- flow control: room in the ticket ring and in every pushed follower's doorbell ring ---- */
-        if ((budget < WAVE * R_SUB && run_next == run_end) || budget < WAVE) {
-            fl_pending = false;
-            uint64_t spins = 0;
-            st_flow++;
-            const uint64_t tf0 = stats ? wall_clock64() : 0;
-            for (;;) {
-                uint64_t room = ~0ull;
-                if (lane == 0) {
-                    const uint64_t inflight = S.t - s_m[M_T_RETIRED];
-                    room = inflight + R_SLACK >= RS_CAP ? 0 : RS_CAP - R_SLACK - inflight;
-                } else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) {
-                    const uint64_t inflight = my_qbase + S.t - ld_sys(&mybox->seqdone_by[lane - 1]);
-                    room = inflight + R_SLACK >= RB_CAP ? 0 : RB_CAP - R_SLACK - inflight;
-                }
-                const unsigned long long tight = __ballot(room < WAVE);
-                if (!tight) {
-                    budget = wmin32((uint32_t)min(room, (uint64_t)0xFFFFFFFFu));
-                    break;
-                }
-                if (++spins > A.peer_polls) {
-                    if (tight >> 1) { rep_seq_drop(E, S, LS, (uint32_t)(tight >> 1), 7102); spins = 0; continue; }
-                    exit_code = R_EXIT_TIMEOUT;                     /* the leader's own commit does not move: no majority */
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            if (exit_code == R_EXIT_TIMEOUT) { if (lane == 0) spin_timeout(E, 7103); break; }
-            if (stats) st_flowt += wall_clock64() - tf0;
+        if ((budget < 4 * WAVE && run_next == run_end) || budget < WAVE) {
+            if (!flow_wait(WAVE)) { if (lane == 0) spin_timeout(E, 7103); break; }
         }
         if (run_next < run_end) {
-            /* ---- staged (device-resident) rounds: one lane per round, R_SUB x 64 rounds per pass.  The pass is software
-             *      pipelined: EVERYTHING a pass needs from memory was asked for by the pass before it -- the rounds'
-             *      prefix sums, the flow-control words when room runs low, the next host commands near the end of the run
-             *      (their PCIe round trip) -- and everything this pass asks for is looked at by the next one: no pass
-             *      waits for a load of its own (round 3 / early round 4: one exposed round trip per pass, 4 us per 256
-             *      rounds, the whole kernel's ceiling at 28 ns per round).  The ticket stores are never waited for. ---- */
+            /* ---- staged (device-resident) rounds.  Round 6: the cost of a pass does not depend on the rounds it takes.  Rounds
+             *      4 and 5 gave every round of a pass a lane (256 per pass: four prefix loads per lane, the pipeline registers to hide
+             *      them, 2.1-2.5 us per pass = 14.8 ns per round with the prune ticks -- the kernel's ceiling at one and three
+             *      replicas, and the reason why two launches of one binary differed by 10 %: the sequencer's pass time sat right at
+             *      the append wavefronts' capacity, and whoever shared its SIMD decided which of the two bound).  Now a pass takes up
+             *      to GP_MAX rounds -- what is left of the run, what the rings have room for -- and needs of them only (a) the
+             *      byte / request prefix at 64 CUTS of the stretch (lane l: the first avail (l + 1) / 64 rounds; the conditions
+             *      under which rounds are "plain" -- no wrap, no exact fit, room in the ring -- grow with the round, so the lanes
+             *      that hold form a prefix: __ballot, count trailing ones = the longest plain stretch at 1/64 granularity) and (b)
+             *      two words per ticket, 64 tickets per store instruction, worked out in closed form when every round is a full
+             *      one.  ONE pass record stands for all of them (TK_BULK); the append wavefronts place themselves (rep_append_wave).
+             *      What is left in front of a wrap -- fewer than 64 rounds -- and the round AT the wrap go one lane per round /
+             *      through the general placement, as before.  One memory round trip per pass, whatever its size. ---- */
             while (run_next < run_end) {
                 const uint64_t rc = run_next;
                 const uint64_t st_p0 = stats ? wall_clock64() : 0;
                 st_staged++;
-                const uint32_t want = (uint32_t)min((uint64_t)(WAVE * R_SUB), run_end - rc);
-                /* ---- what the last pass asked for ---- */
-                if (!(pre_rc == rc && pre_end == run_end)) {
-                    st_reload++;
-                    /* (the first pass of a run nobody saw coming, a pass behind one that took fewer rounds than it looked at) */
-#pragma unroll
-                    for (int s = 0; s < R_SUB; s++) {
-                        const uint32_t j = (uint32_t)s * WAVE + lane;
-                        const uint64_t r = rc + (j < want ? j : 0);
-                        npf0[s] = E.round_prefix[r]; npf1[s] = E.round_prefix[r + 1];
-                        nrf0[s] = E.round_first[r];  nrf1[s] = E.round_first[r + 1];
-                    }
+                const uint32_t want = (uint32_t)min((uint64_t)GP_MAX, run_end - rc);
+                if (budget < want && budget < GP_GOAL) {
+                    /* (room for a good part of the pass: tickets are handed out GP_GOAL at a time while >= RB_CAP - GP_GOAL rounds are queued) */
+                    if (!flow_wait(min(want, (uint32_t)GP_GOAL))) break;
                 }
-                uint64_t pf0[R_SUB], pf1[R_SUB];
-                uint32_t rf0[R_SUB], rf1[R_SUB];
-#pragma unroll
-                for (int s = 0; s < R_SUB; s++) { pf0[s] = npf0[s]; pf1[s] = npf1[s]; rf0[s] = nrf0[s]; rf1[s] = nrf1[s]; }
-                if (pk_pending) { take_peek(); pk_pending = false; }
-                if (fl_pending) {
-                    fl_pending = false;
-                    uint64_t room = ~0ull;
-                    if (lane == 0) {
-                        const uint64_t inflight = fl_t - fl_v;
-                        room = inflight + R_SLACK >= RS_CAP ? 0 : RS_CAP - R_SLACK - inflight;
-                    } else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) {
-                        const uint64_t inflight = my_qbase + fl_t - fl_v;
-                        room = inflight + R_SLACK >= RB_CAP ? 0 : RB_CAP - R_SLACK - inflight;
-                    }
-                    const uint64_t since = S.t - fl_t;                /* (tickets issued since the words were asked for) */
-                    const uint64_t r0 = (uint64_t)wmin32((uint32_t)min(room, (uint64_t)0xFFFFFFFFu));
-                    budget = r0 > since ? r0 - since : 0;
-                }
-                /* ---- what the next pass will need ---- */
-                {
-                    uint64_t nrc = ~0ull, nend = 0;
-                    if (rc + WAVE * R_SUB < run_end) { nrc = rc + WAVE * R_SUB; nend = run_end; }
-                    else if (have_cmd && cmd_op == R_OP_RUN && cmd_b) { nrc = cmd_a; nend = cmd_a + cmd_b; }
-                    else if (have_cmd && cmd_op == R_OP_PRUNE && have_cmd2 && cmd2_op == R_OP_RUN && cmd2_b) { nrc = cmd2_a; nend = cmd2_a + cmd2_b; }
-                    pre_rc = nrc; pre_end = nend;
-                    if (nrc != ~0ull) {
-                        const uint32_t nwant = (uint32_t)min((uint64_t)(WAVE * R_SUB), nend - nrc);
-#pragma unroll
-                        for (int s = 0; s < R_SUB; s++) {
-                            const uint32_t j = (uint32_t)s * WAVE + lane;
-                            const uint64_t r = nrc + (j < nwant ? j : 0);
-                            npf0[s] = E.round_prefix[r]; npf1[s] = E.round_prefix[r + 1];
-                            nrf0[s] = E.round_first[r];  nrf1[s] = E.round_first[r + 1];
-                        }
-                    }
-                }
-                /* flow control: the ticket ring and every pushed follower's doorbell ring, asked for while room for a few passes is left */
-                if (budget < 4 * WAVE * R_SUB) {
-                    fl_pending = true; fl_t = S.t; fl_v = 0;
-                    if (lane == 0) fl_v = s_m[M_T_RETIRED];
-                    else if (lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) fl_v = ld_sys(&mybox->seqdone_by[lane - 1]);
-                }
-                /* the next host commands, near the end of the run -- and only when NEITHER command register holds one: a command
-                 * fetched together with this RUN sits in the second register until the run is over; a peek that found only ONE
-                 * command used to leave that register as it was, and the command in it -- the same prune tick -- was carried out
-                 * a second time (seen only when the host pushes its commands slowly: test_rep_full_size_staged) */
-                if (!have_cmd && !have_cmd2 && run_end - rc <= 3 * WAVE * R_SUB) {
+                const uint32_t avail = (uint32_t)min((uint64_t)want, budget);
+                if (!avail) break;
+                /* ---- everything the pass needs from memory: one round trip ---- */
+                const uint32_t j0 = lane < avail ? lane : 0u;                            /* lane j: round rc + j (the first 64) */
+                const uint64_t pf0 = E.round_prefix[rc + j0], pf1 = E.round_prefix[rc + j0 + 1];
+                const uint32_t rf0 = E.round_first[rc + j0], rf1 = E.round_first[rc + j0 + 1];
+                const uint32_t cut = (uint32_t)(((uint64_t)avail * (lane + 1)) >> 6);     /* lane l: the first `cut` rounds (lane 63: all) */
+                const uint64_t spf = E.round_prefix[rc + cut];
+                const uint32_t srf = E.round_first[rc + cut];
+                /* the next host commands, when this pass may end the run -- and only when NEITHER command register holds one: a
+                 * command fetched together with this RUN sits in the second register until the run is over */
+                if (!have_cmd && !have_cmd2 && run_end - rc <= avail) {
                     pk_pending = true; pk_next = cmd_head + 1;            /* (cmd_head is the RUN in progress) */
                     pk_cg = 0;
                     if (lane < 8) pk_cg = ld_sys(&RQ->cmd[(pk_next + (lane >> 2)) % RC_CAP].g[lane & 3]);
                 }
-                if (budget < WAVE) break;                             /* (no room: the blocking look at the rings, above) */
-                const uint32_t avail = (uint32_t)min((uint64_t)want, budget);
                 const uint64_t stamp = wall_clock64() & 0xFFFFFFFFull;
+                const uint64_t bpf = rl64u(pf0, 0);
+                const uint32_t brf = rl32u(rf0, 0);
+                const uint64_t used = S.end >= S.head_safe ? S.end - S.head_safe : L - (S.head_safe - S.end);      /* (the VERIFIED head: rep_seq_prune) */
                 uint32_t taken = 0;
-                /* ---- a whole pass of plain rounds: one record + one word per ticket (TK_BULK) ---- */
-                if (avail >= WAVE && !(A.dbg & 32)) {
-                    const uint32_t last = avail - 1;
-                    uint64_t pf1_l = 0; uint32_t rf1_l = 0;
-#pragma unroll
-                    for (int s = 0; s < R_SUB; s++)
-                        if ((uint32_t)s == last / WAVE) { pf1_l = rl64u(pf1[s], (int)(last % WAVE)); rf1_l = rl32u(rf1[s], (int)(last % WAVE)); }
-                    const uint64_t bpf = rl64u(pf0[0], 0);
-                    const uint32_t brf = rl32u(rf0[0], 0);
-                    const uint64_t used = S.end >= S.head_safe ? S.end - S.head_safe : L - (S.head_safe - S.end);
-                    const uint64_t tot = pf1_l - bpf;
-                    /* (the conditions of `plain` below grow with the round: they hold for every round of the pass when they hold for its last) */
-                    if (S.end != L && S.end + tot < L && S.end != S.head_safe && tot + APUS_HDR <= L - used && rc + avail < (1ull << 32)) {
+                /* ---- the longest plain stretch as ONE pass: a record + two words per ticket (TK_BULK) ---- */
+                if (avail >= WAVE && !(A.dbg & 32) && rc + avail < (1ull << 32)) {
+                    const uint64_t tot_c = spf - bpf;
+                    const bool okc = S.end != L && S.end + tot_c < L && S.end != S.head_safe && tot_c + APUS_HDR <= L - used;
+                    const unsigned long long bm = __ballot(okc);
+                    const uint32_t nb = (~bm) ? (uint32_t)__builtin_ctzll(~bm) : WAVE;
+                    const uint32_t N = nb ? rl32u(cut, (int)nb - 1) : 0u;
+                    if (N >= WAVE) {
+                        const uint64_t tot = rl64u(spf, (int)nb - 1) - bpf;
+                        const uint32_t ntot = rl32u(srf, (int)nb - 1) - brf;
                         const uint64_t pn = S.pass_seq++;
                         uint64_t v = 0;
                         switch (lane) {
@@ -912,76 +875,95 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                         case PR_IDX0: v = S.last_idx + 1; break;
                         case PR_SLOT0: v = S.n_end; break;
                         case PR_BPF: v = bpf; break;
-                        case PR_BRF_N: v = (uint64_t)brf | ((uint64_t)avail << 32); break;
+                        case PR_BRF_N: v = (uint64_t)brf | ((uint64_t)N << 32); break;
                         case PR_PUSH_STAMP: v = (uint64_t)(uint32_t)stamp | ((uint64_t)S.push_mask << 32); break;
                         default: break;
                         }
                         if (lane < 8) st_agent(&LS->prec[pn % PR_CAP][lane], rep_tk(pn, v));
+                        /* the tickets' two words: ticket S.t + j = round rc + j.  (the tag of ticket t is t % 65535 + 1: worked out
+                         * from the pass's first ticket with 32-bit arithmetic -- a 64-bit modulo per word was a third of the old pass) */
+                        const uint32_t tbase = (uint32_t)(S.t % 65535ull), t_lo = (uint32_t)S.t;
+                        const uint64_t metab = TK_BULK | (pn & 0xFFFull);
+                        auto put = [&](uint32_t j, uint32_t a, uint32_t b) {
+                            const uint32_t x = tbase + j;                                /* (j < GP_MAX: below 2 x 65535) */
+                            const uint64_t tag = (uint64_t)((x >= 65535u ? x - 65535u : x) + 1u) << 48;
+                            const uint32_t ix = (t_lo + j) & (RS_CAP - 1u);
+                            st_agent(&LS->tkw[TK_SRC][ix], tag | (uint64_t)a | ((uint64_t)(b - a) << 32));
+                            st_agent(&LS->tkw[TK_META][ix], tag | metab | ((rc + j) << 16));
+                        };
+                        put(lane, rf0, rf1);                                             /* (N >= 64: every lane) */
+                        /* every round a full one (a staged round never has more than 64 requests, apus_gpu_stage): the first request of
+                         * round rc + j is brf + 64 j -- no loads at all (configs[1]) */
+                        const bool all64 = ntot == N * WAVE;
+                        for (uint32_t c0 = 1; c0 * WAVE < N; c0 += GP_GRP) {
+                            uint32_t a[GP_GRP], b[GP_GRP];
+                            if (all64) {
 #pragma unroll
-                        for (int s = 0; s < R_SUB; s++) {
-                            const uint32_t j = (uint32_t)s * WAVE + lane;
-                            if (j < avail) {
-                                const uint64_t tk = S.t + j;
-                                st_agent(&LS->tkw[TK_SRC][tk % RS_CAP], rep_tk(tk, (uint64_t)rf0[s] | ((uint64_t)(rf1[s] - rf0[s]) << 32)));
-                                st_agent(&LS->tkw[TK_META][tk % RS_CAP], rep_tk(tk, TK_BULK | (pn & 0xFFFull) | ((rc + j) << 16)));
+                                for (int g = 0; g < GP_GRP; g++) { a[g] = brf + ((c0 + (uint32_t)g) * WAVE + lane) * WAVE; b[g] = a[g] + WAVE; }
+                            } else {
+#pragma unroll
+                                for (int g = 0; g < GP_GRP; g++) {
+                                    const uint32_t j = (c0 + (uint32_t)g) * WAVE + lane;
+                                    const uint64_t r = rc + (j < N ? j : 0u);
+                                    a[g] = E.round_first[r]; b[g] = E.round_first[r + 1];
+                                }
+                            }
+#pragma unroll
+                            for (int g = 0; g < GP_GRP; g++) {
+                                const uint32_t j = (c0 + (uint32_t)g) * WAVE + lane;
+                                if (j < N) put(j, a[g], b[g]);
                             }
                         }
-                        const uint32_t ntot = rf1_l - brf;
                         S.end += tot; S.last_idx += ntot; S.n_end += ntot; S.store_count += ntot; S.prev_head = 0;
-                        S.tail_known = false; S.tail_round = rc + avail - 1;
+                        S.tail_known = false; S.tail_round = rc + N - 1;
                         if (S.can_commit) { S.c_off = S.end; S.c_slot = S.n_end; }
-                        S.t += avail; taken = avail;
+                        S.t += N; taken = N;
                     }
                 }
-#pragma unroll
-                for (int s = 0; s < R_SUB; s++) {
-                    if (taken >= avail) break;
-                    if ((uint32_t)s * WAVE >= avail || taken != (uint32_t)s * WAVE) break;
-                    const uint32_t nch = min((uint32_t)WAVE, avail - (uint32_t)s * WAVE);
+                if (!taken) {
+                    /* ---- fewer than 64 rounds, or the stretch in front of / at a wrap: one lane per round of the first 64 ---- */
+                    const uint32_t nch = min((uint32_t)WAVE, avail);
                     const bool on = lane < nch;
-                    const uint64_t bpf = rl64u(pf0[s], 0);
-                    const uint32_t brf = rl32u(rf0[s], 0);
-                    const uint64_t used = S.end >= S.head_safe ? S.end - S.head_safe : L - (S.head_safe - S.end);      /* (the VERIFIED head: rep_seq_prune) */
                     /* lanes that can go without the general code: the log does not read as empty, no entry of rounds
                      * 0..j crosses or touches len, everything fits into the free part of the ring */
-                    const bool plain = on && S.end != L && S.end + (pf1[s] - bpf) < L && S.end != S.head_safe && (pf1[s] - bpf) + APUS_HDR <= L - used;
+                    const bool plain = on && S.end != L && S.end + (pf1 - bpf) < L && S.end != S.head_safe && (pf1 - bpf) + APUS_HDR <= L - used;
                     const unsigned long long pm = __ballot(plain);
                     const uint32_t np = (~pm) ? (uint32_t)__builtin_ctzll(~pm) : WAVE;      /* prefix of plain rounds */
                     if (np) {
                         if (lane < np) {
                             const uint64_t tk = S.t + lane, ix = tk % RS_CAP;
-                            st_agent(&LS->tkw[TK_E0][ix], rep_tk(tk, S.end + (pf0[s] - bpf)));
-                            st_agent(&LS->tkw[TK_IDX0][ix], rep_tk(tk, S.last_idx + 1 + (rf0[s] - brf)));
-                            st_agent(&LS->tkw[TK_SLOT0][ix], rep_tk(tk, S.n_end + (rf0[s] - brf)));
-                            st_agent(&LS->tkw[TK_SRC][ix], rep_tk(tk, (uint64_t)rf0[s]));
-                            st_agent(&LS->tkw[TK_END][ix], rep_tk(tk, S.end + (pf1[s] - bpf)));
+                            st_agent(&LS->tkw[TK_E0][ix], rep_tk(tk, S.end + (pf0 - bpf)));
+                            st_agent(&LS->tkw[TK_IDX0][ix], rep_tk(tk, S.last_idx + 1 + (rf0 - brf)));
+                            st_agent(&LS->tkw[TK_SLOT0][ix], rep_tk(tk, S.n_end + (rf0 - brf)));
+                            st_agent(&LS->tkw[TK_SRC][ix], rep_tk(tk, (uint64_t)rf0));
+                            st_agent(&LS->tkw[TK_END][ix], rep_tk(tk, S.end + (pf1 - bpf)));
                             st_agent(&LS->tkw[TK_D0][ix], rep_tk(tk, 0ull));
                             st_agent(&LS->tkw[TK_D1][ix], rep_tk(tk, stamp));
-                            st_agent(&LS->tkw[TK_META][ix], rep_tk(tk, (uint64_t)(rf1[s] - rf0[s]) | ((uint64_t)R_SRC_STAGED << 8) | ((uint64_t)S.push_mask << 32)));
+                            st_agent(&LS->tkw[TK_META][ix], rep_tk(tk, (uint64_t)(rf1 - rf0) | ((uint64_t)R_SRC_STAGED << 8) | ((uint64_t)S.push_mask << 32)));
                         }
-                        const uint64_t tot = rl64u(pf1[s], (int)np - 1) - bpf;
-                        const uint32_t ntot = rl32u(rf1[s], (int)np - 1) - brf;
+                        const uint64_t tot = rl64u(pf1, (int)np - 1) - bpf;
+                        const uint32_t ntot = rl32u(rf1, (int)np - 1) - brf;
                         S.end += tot; S.last_idx += ntot; S.n_end += ntot; S.store_count += ntot; S.prev_head = 0;
-                        S.tail_known = false; S.tail_round = rc + taken + np - 1;
+                        S.tail_known = false; S.tail_round = rc + np - 1;
                         if (S.can_commit) { S.c_off = S.end; S.c_slot = S.n_end; }
-                        S.t += np; taken += np;
-                    } else if (s == 0) {
+                        S.t += np; taken = np;
+                    } else {
                         /* the round at the head of the pass needs the general code (wrap, exact fit, nearly full) */
-                        const uint32_t n = rl32u(rf1[0] - rf0[0], 0);
+                        const uint32_t n = rl32u(rf1 - rf0, 0);
                         const uint32_t T = lane < n ? APUS_HDR + (uint32_t)E.req_len[brf + lane] : 0u;
                         if (!rep_seq_round(E, X, S, LS, T, n, R_SRC_STAGED, brf, 0, 0, 0)) {
                             if (lane == 0) { set_status(E, 1u << 1); st_sys(&H->full, ld_sys(&H->full) + 1); }
                         }
                         taken = 1;
-                        break;
                     }
                 }
                 run_next += taken; budget -= min((uint64_t)taken, budget);
                 if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); }
                 rep_seq_publish(LS, s_m, S, cmd_head + req_head);
+                if (pk_pending) { take_peek(); pk_pending = false; }
                 if (stats) st_busy += wall_clock64() - st_p0;
             }
-            if (run_next == run_end && pk_pending) { take_peek(); pk_pending = false; }
+            if (exit_code == R_EXIT_TIMEOUT) { if (lane == 0) spin_timeout(E, 7103); break; }
             idle = 0;
             continue;
         }
@@ -1341,8 +1323,11 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, l
         /* ---- done? ---- */
         const uint64_t n_apply = s_m[M_N_APPLY];
         const bool can = (uint32_t)__popc((C.push_live | (1u << me)) & size_mask) >= quorum;
-        if (C.t_done == tail && ((C.cs == C.vis && n_apply == C.cs) || !can) && settled != prog) { settled = prog; if (lane == 0) st_sys(&H->settled, prog); }
-        if (fin != ~0ull && C.t_done >= fin && C.cs == C.vis && n_apply == C.cs) break;
+        /* (applied: everything committed -- or every TICKET, when entries from before the run committed in it: no ticket stands for
+         *  those, the control-plane pass behind the run applies them) */
+        const bool applied = n_apply == C.cs || (n_apply < C.pre_end && s_m[M_T_RETIRED] == C.t_done);
+        if (C.t_done == tail && ((C.cs == C.vis && applied) || !can) && settled != prog) { settled = prog; if (lane == 0) st_sys(&H->settled, prog); }
+        if (fin != ~0ull && C.t_done >= fin && C.cs == C.vis && applied) break;
         if (fin != ~0ull && C.t_done >= fin) {
             /* nothing more will be appended; ACKs may still be on their way -- unless no majority can answer */
             if (!can || ++patience > A.peer_polls) { if (can && lane == 0) spin_timeout(E, 7201); break; }
