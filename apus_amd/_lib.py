@@ -98,6 +98,7 @@ SIGNATURES = {
     "apus_gpu_rep_submit": (C.c_int, [vp, vp, u32, vp, u64]),
     "apus_gpu_rep_run": (C.c_int, [vp, u64, u64]),
     "apus_gpu_rep_prune": (C.c_int, [vp]),
+    "apus_gpu_rep_cmds": (C.c_int, [vp, C.POINTER(u64), u32, u32]),
     "apus_gpu_rep_drain": (C.c_int, [vp, u32]),
     "apus_gpu_rep_full": (C.c_int, [vp]),
     "apus_gpu_rep_highest_rec": (u64, [vp]),

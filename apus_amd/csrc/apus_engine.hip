@@ -2562,9 +2562,13 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
          *  Round 5: with entries of 512 bytes and more -- configs[2], configs[3] -- an append wavefront is bound by the rate at
          *  which it issues its own stores (170 per round of 32 x 1 KiB at five replicas, ~240 ns each), and the followers, who no
          *  longer read headers back, need few workgroups: 352 append + ~150 for all followers: +19 % / +6 %) */
+        /*  Round 6, three workgroups per compute unit (760 slots): one replica 320 append workgroups (8.1 G entries/s; 256: 7.8, 448: 7.1 --
+         *  the serial roles' passes get longer with every wavefront that shares their SIMDs); three replicas 384 + 96 per follower
+         *  (4.6 G; 320 + 128: 4.6, 256 + 128: 4.2, 448 + 64: 3.9 -- too few follower workgroups and the doorbell rings run full); five
+         *  384 + 64 (3.1 G; 320 + 96: 2.9); seven 384 + 48 (2.2 G; 320 + 64: 1.9).  profiles/r06_grid_sweeps.txt) */
         const bool big = e->n_rounds_staged && e->stage_max_T >= 512;
-        if (!n_append) n_append = lead_here ? (big ? 352u : 192u) : 0;
-        if (!n_fwork) n_fwork = nfh ? (big ? std::min(128u, std::max(16u, 150u / nfh)) : std::min(128u, std::max(24u, 288u / nfh))) : 1;
+        if (!n_append) n_append = lead_here ? (big ? 352u : (nfh ? 384u : 320u)) : 0;
+        if (!n_fwork) n_fwork = nfh ? (big ? std::min(128u, std::max(16u, 150u / nfh)) : std::min(96u, std::max(48u, 288u / nfh))) : 1;
         while ((lead_here ? 1 + n_append : 0) + nfh * n_fwork > room && (n_append > 8 || n_fwork > 2)) {
             if (n_append > 8) n_append -= n_append / 4;
             if (n_fwork > 2) n_fwork -= (n_fwork + 3) / 4;
@@ -2826,6 +2830,23 @@ extern "C" int apus_gpu_rep_run(apus_engine_t *e, uint64_t r0, uint64_t n_rounds
     return rep_push_cmd(e, R_OP_RUN, r0, n_rounds);
 }
 extern "C" int apus_gpu_rep_prune(apus_engine_t *e) { return rep_push_cmd(e, R_OP_PRUNE, 0, 0); }
+/* a whole list of commands in one call -- cmds[3 i] = 1 (a prune tick) or 2 (rounds [cmds[3 i + 1], + cmds[3 i + 2]) of the staged
+ * input) -- `repeat` times over: what a host that feeds a step's commands from a loop of its own would issue one by one (a step
+ * of configs[1] is 33 commands; from Python that is ~80 us of call overhead per step, next to 130 us of work at one replica) */
+extern "C" int apus_gpu_rep_cmds(apus_engine_t *e, const uint64_t *cmds, uint32_t n, uint32_t repeat)
+{
+    if (!e || (n && !cmds)) return APUS_E_ARG;
+    for (uint32_t i = 0; i < n; i++) {
+        if (cmds[3 * i] != R_OP_PRUNE && cmds[3 * i] != R_OP_RUN) return APUS_E_ARG;
+        if (cmds[3 * i] == R_OP_RUN && cmds[3 * i + 1] + cmds[3 * i + 2] > e->n_rounds_staged) return APUS_E_ARG;
+    }
+    for (uint32_t r = 0; r < repeat; r++)
+        for (uint32_t i = 0; i < n; i++) {
+            const int rc = rep_push_cmd(e, (uint32_t)cmds[3 * i], cmds[3 * i + 1], cmds[3 * i + 2]);
+            if (rc) return rc;
+        }
+    return 0;
+}
 
 /* everything submitted so far is appended everywhere, and committed + applied as far as a majority allows */
 extern "C" int apus_gpu_rep_drain(apus_engine_t *e, uint32_t timeout_ms)

@@ -74,9 +74,12 @@
                                   * workgroups per compute unit has anyway (staged throughput unchanged: profiles/r05_host_fed_windows.txt) */
 #endif
 #ifndef R_SUB
-#define R_SUB     4              /* 64-round chunks a serial role handles per memory round trip  */
+#define R_SUB     8              /* 64-round chunks a serial role handles per memory round trip (round 6: 4 -> 8, the committer and the applier
+                                  * took 250 of 256 rounds per look at 7 G entries/s) */
 #endif
-#define GP_MAX    4096u          /* staged rounds ONE pass of the sequencer may take (one record, two words per ticket) */
+#define GP_MIN    256u           /* a pass of at least this many plain staged rounds is its record ALONE: no word per ticket (below) */
+#define GR_CAP    128u           /* such records in flight: RS_CAP / GP_MIN = 64 passes' tickets fill the ticket ring */
+#define GP_MAX    4096u          /* staged rounds ONE pass of the sequencer may take (one record; two words per ticket below GP_MIN) */
 #define GP_GOAL   1024u          /* ... and the room it waits for when the rings run full: tickets are handed out this many at a time */
 #define GP_GRP    8              /* 64-ticket chunks of a pass whose words are loaded together */
 #define R_LAT_CAP (1u << 16)
@@ -168,6 +171,13 @@ struct RepBox {
     uint64_t pad1[2];
 };
 
+/* A serial role is ONE wavefront that hundreds wait for, on a SIMD it shares with one or two append / work wavefronts: its
+ * instructions go first (s_setprio: the arbiter picks the wavefront with the highest priority that is ready).  -DREP_NO_PRIO: A/B. */
+#ifndef REP_NO_PRIO
+#define REP_SERIAL_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define REP_SERIAL_PRIO() ((void)0)
+#endif
 /* one round, sequencer -> append wavefront: eight words {low 16 bits of ticket + 1 : 48-bit value}, valid the
  * moment all eight carry the ticket's tag -- the sequencer never waits for its stores.  Kept word-major
  * (RepLead.tkw[word][ticket]): the sequencer holds one ticket per lane, so word w of 64 consecutive tickets is ONE
@@ -189,6 +199,17 @@ enum { TK_E0 = 0, TK_IDX0, TK_SLOT0, TK_SRC, TK_END, TK_D0, TK_D1, TK_META };
 #define TK_BULK   (1ull << 13)          /* TK_META: [11:0] pass number (low bits)  [13] 1  [47:16] staged round; TK_SRC: [31:0] first request  [38:32] n */
 #define TK_BULK_PIN (1ull << 14)        /* ... a pass of FULL, equally long rounds from the request ring: [47:16] = the round's number within the pass,
                                          * PR_BPF = the entries' size, PR_BRF_N = the pass's first request slot (low half) | rounds << 32 */
+/* WORDLESS passes (round 6).  A pass of >= GP_MIN plain staged rounds -- configs[1]: the 1024 rounds between two prune ticks -- is
+ * its record and nothing else: the record goes into a ring of its own (RepLead.grec, numbered by S.g_seq), and an append
+ * wavefront FINDS the pass that holds its ticket: it keeps the number of the first such pass it has not left behind, asks for
+ * that record and the three after it together with its ticket's words (one load instruction: lanes 0..7 the words, lanes 8..39
+ * four records) and steps over the passes whose tickets lie below its own.  A pass has >= GP_MIN tickets, a wavefront's tickets are
+ * 4 n_append apart: it never falls more than a few records behind, and never GR_CAP.  With no word written per ticket a slot of
+ * tkw[] would keep an OLD ticket's words -- and their tag comes round again after 16384 x 65535 tickets -- so a wavefront that
+ * has taken a ticket with words clears the slot's TK_META.  PR_BRF_N of such a record: [31:0] first request  [44:32] rounds
+ * [47] every round has 64 requests (a staged round never has more: the first request of round r is then first + 64 (r - rc0),
+ * no look at round_first[]).  The sequencer's pass costs the same whatever it takes: one round trip + ~300 instructions. */
+#define PR_ALL64  (1ull << 47)
 #define PR_CAP    512u                  /* pass records (a bulk pass has >= 64 tickets, RS_CAP tickets are in flight at most) */
 enum { PR_T0 = 0, PR_RC0, PR_END0, PR_IDX0, PR_SLOT0, PR_BPF, PR_BRF_N, PR_PUSH_STAMP };   /* words {low 16 bits of pass + 1 : 48-bit value} */
 #define TK_VAL 0x0000FFFFFFFFFFFFull
@@ -213,6 +234,7 @@ struct RepLead {
     uint32_t lat_app[R_LAT_CAP];                /* bytes in every pushed ring -> committed and applied   */
     uint64_t  tkw[8][RS_CAP];
     uint64_t  prec[PR_CAP][8];
+    uint64_t  grec[GR_CAP][8];                  /* the records of the passes without ticket words, by their own sequence number */
     uint64_t  dn[8][RS_CAP];                     /* granule-major: the committer / applier read 64 consecutive tickets' granules in whole lines */
 };
 /* the leader's first workgroup: its wavefronts' words in LDS */
@@ -504,6 +526,7 @@ struct RepSeqState {                    /* the sequencer's registers: the leader
     uint64_t sample_slot;               /* slots the servers sampled by the last tick are taken to have applied */
     uint64_t t;                         /* tickets issued                                      */
     uint64_t pass_seq;                  /* bulk passes issued                                  */
+    uint64_t g_seq;                     /* ... and passes without ticket words                 */
     /* Head moves that are not verified yet (rep_seq_prune): a small queue in LDS of {the slot count every sampled server
      * must have applied, the head that then holds}, and the head as it stands with the verified moves only -- what
      * protects the ring (rep_refuse) until the rest is verified. */
@@ -620,10 +643,11 @@ __device__ static inline uint64_t rep_seq_applied(const RepSeqState &S, lds_u64 
 }
 /* retires the head moves that have become true (one look at the applied counts); -> the lanes (0: the leader's own
  * applier, f + 1: follower f) that are still behind the oldest one left, 0 when nothing is left */
-__device__ static inline unsigned long long rep_seq_verify(RepSeqState &S, lds_u64 s_m, RepBox *mybox)
+__device__ static inline unsigned long long rep_seq_verify(RepSeqState &S, lds_u64 s_m, RepBox *mybox, const uint64_t *pre = nullptr)
 {
     if (!S.pv_n) return 0;
-    const uint64_t v = rep_seq_applied(S, s_m, mybox);
+    /* (pre: the followers' counts as a pass asked for them a moment ago -- older counts retire fewer moves, never a wrong one) */
+    const uint64_t v = pre ? (lane_id() == 0 ? (uint64_t)s_m[M_N_APPLY] : *pre) : rep_seq_applied(S, s_m, mybox);
     for (;;) {
         if (!S.pv_n) return 0;
         const uint32_t ix = 2 * (S.pv_r % R_PV);
@@ -652,14 +676,14 @@ __device__ static inline bool rep_seq_wait_verified(const EngDev &E, const RepSe
 }
 
 __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, const RepSeqCtx &X, RepSeqState &S, lds_u64 s_ao /*[16] LDS*/,
-                                            lds_u64 s_m, uint32_t bitmask, RepBox *mybox, uint64_t progress)
+                                            lds_u64 s_m, uint32_t bitmask, RepBox *mybox, uint64_t progress, const uint64_t *pre = nullptr)
 {
     RepLead *LS = A.LS;
     const uint64_t L = E.log_len;
     const uint32_t lane = lane_id();
     /* (0) the earlier ticks' samples: what has become true is retired; with the queue full the oldest is waited for */
     bool late = false;
-    rep_seq_verify(S, s_m, mybox);
+    rep_seq_verify(S, s_m, mybox, pre);
     if (S.pv_n >= R_PV) late = !rep_seq_wait_verified(E, X, S, LS, R_PV - 1);
     const uint32_t size = E.group_size;
     const uint64_t c_before = S.c_off, cs_before = S.c_slot;
@@ -696,6 +720,7 @@ __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, c
 __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, lds_u64 s_h, lds_u64 s_ao,
                                             lds_u64 s_m, lds_u64 s_x, uint4 *s_tr /* 4 KiB of LDS: the queue of unverified head moves */)
 {
+    REP_SERIAL_PRIO();
     RepHost *H = A.H;
     RepReq *RQ = A.RQ;
     RepLead *LS = A.LS;
@@ -705,7 +730,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
     RepSeqState S;
     S.end = s_h[H_END]; S.tail = s_h[H_TAIL]; S.last_idx = s_h[H_LAST_IDX]; S.n_end = s_h[H_N_END]; S.head = s_h[H_HEAD];
     S.prev_head = s_h[H_PREV_HEAD]; S.store_count = s_h[H_STORE_COUNT];
-    S.c_off = s_h[H_COMMIT]; S.c_slot = s_h[H_N_COMMIT]; S.sample_slot = 0; S.t = 0; S.pass_seq = 0; S.tail_known = true; S.tail_round = 0;
+    S.c_off = s_h[H_COMMIT]; S.c_slot = s_h[H_N_COMMIT]; S.sample_slot = 0; S.t = 0; S.pass_seq = 0; S.g_seq = 0; S.tail_known = true; S.tail_round = 0;
     S.push_mask = A.push_mask; S.can_commit = rep_quorum(E, S.push_mask);
     S.pv = APUS_LDS64(s_tr); S.head_safe = S.head; S.pv_r = 0; S.pv_n = 0;
     const RepSeqCtx X = {&A, s_m, mybox};
@@ -724,6 +749,8 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
     const bool stats = A.dbg & 512;      /* per-pass clocks: every look at the wall clock is a scalar memory round trip */
     const uint64_t st_t0 = wall_clock64();
 
+    uint64_t ap_v = ~0ull;                       /* the followers' applied counts as the last staged pass asked for them (the next prune tick's first look) */
+    bool ap_have = false;
     bool pk_pending = false;                     /* the next host commands, asked for by a staged pass that may end its run */
     uint64_t pk_cg = 0, pk_next = 0;
     /* the request-ring passes' pipeline registers (host-fed input) */
@@ -763,7 +790,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
         }
         cmd_head++;
         if (lane == 0) st_sys(&H->cmd_head, cmd_head);
-        if (cmd_op == R_OP_PRUNE) { const uint64_t tp0 = stats ? wall_clock64() : 0; rep_seq_prune(E, A, X, S, s_ao, s_m, bitmask, mybox, cmd_head + req_head); budget--; if (stats) st_prune += wall_clock64() - tp0; }
+        if (cmd_op == R_OP_PRUNE) { const uint64_t tp0 = stats ? wall_clock64() : 0; rep_seq_prune(E, A, X, S, s_ao, s_m, bitmask, mybox, cmd_head + req_head, ap_have ? &ap_v : nullptr); ap_have = false; budget--; if (stats) st_prune += wall_clock64() - tp0; }
         else rep_seq_publish(LS, s_m, S, cmd_head + req_head);
         return 1;
     };
@@ -851,6 +878,9 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                     pk_cg = 0;
                     if (lane < 8) pk_cg = ld_sys(&RQ->cmd[(pk_next + (lane >> 2)) % RC_CAP].g[lane & 3]);
                 }
+                /* ... and what the prune tick behind the run will want to know first: how far the followers have applied */
+                ap_v = (lane >= 1 && lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) ? ld_sys(&mybox->applied_by[lane - 1]) : ~0ull;
+                ap_have = true;
                 const uint64_t stamp = wall_clock64() & 0xFFFFFFFFull;
                 const uint64_t bpf = rl64u(pf0, 0);
                 const uint32_t brf = rl32u(rf0, 0);
@@ -866,7 +896,11 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                     if (N >= WAVE) {
                         const uint64_t tot = rl64u(spf, (int)nb - 1) - bpf;
                         const uint32_t ntot = rl32u(srf, (int)nb - 1) - brf;
-                        const uint64_t pn = S.pass_seq++;
+                        /* every round a full one (a staged round never has more than 64 requests, apus_gpu_stage): the first request of
+                         * round rc + j is brf + 64 j -- nobody needs round_first[] (configs[1]) */
+                        const bool all64 = ntot == N * WAVE;
+                        const bool wordless = N >= GP_MIN && !(A.dbg & 128);
+                        const uint64_t pn = wordless ? S.g_seq++ : S.pass_seq++;
                         uint64_t v = 0;
                         switch (lane) {
                         case PR_T0: v = S.t; break;
@@ -875,11 +909,12 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                         case PR_IDX0: v = S.last_idx + 1; break;
                         case PR_SLOT0: v = S.n_end; break;
                         case PR_BPF: v = bpf; break;
-                        case PR_BRF_N: v = (uint64_t)brf | ((uint64_t)N << 32); break;
+                        case PR_BRF_N: v = (uint64_t)brf | ((uint64_t)N << 32) | (all64 ? PR_ALL64 : 0ull); break;
                         case PR_PUSH_STAMP: v = (uint64_t)(uint32_t)stamp | ((uint64_t)S.push_mask << 32); break;
                         default: break;
                         }
-                        if (lane < 8) st_agent(&LS->prec[pn % PR_CAP][lane], rep_tk(pn, v));
+                        if (lane < 8) st_agent(wordless ? &LS->grec[pn % GR_CAP][lane] : &LS->prec[pn % PR_CAP][lane], rep_tk(pn, v));
+                        if (!wordless) {
                         /* the tickets' two words: ticket S.t + j = round rc + j.  (the tag of ticket t is t % 65535 + 1: worked out
                          * from the pass's first ticket with 32-bit arithmetic -- a 64-bit modulo per word was a third of the old pass) */
                         const uint32_t tbase = (uint32_t)(S.t % 65535ull), t_lo = (uint32_t)S.t;
@@ -892,9 +927,6 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                             st_agent(&LS->tkw[TK_META][ix], tag | metab | ((rc + j) << 16));
                         };
                         put(lane, rf0, rf1);                                             /* (N >= 64: every lane) */
-                        /* every round a full one (a staged round never has more than 64 requests, apus_gpu_stage): the first request of
-                         * round rc + j is brf + 64 j -- no loads at all (configs[1]) */
-                        const bool all64 = ntot == N * WAVE;
                         for (uint32_t c0 = 1; c0 * WAVE < N; c0 += GP_GRP) {
                             uint32_t a[GP_GRP], b[GP_GRP];
                             if (all64) {
@@ -913,6 +945,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                                 const uint32_t j = (c0 + (uint32_t)g) * WAVE + lane;
                                 if (j < N) put(j, a[g], b[g]);
                             }
+                        }
                         }
                         S.end += tot; S.last_idx += ntot; S.n_end += ntot; S.store_count += ntot; S.prev_head = 0;
                         S.tail_known = false; S.tail_round = rc + N - 1;
@@ -1276,6 +1309,7 @@ __device__ static inline void rep_commit_pre(const EngDev &E, RepCommitState &C,
 
 __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, lds_u64 s_h, lds_u64 s_m, lds_u64 s_x)
 {
+    REP_SERIAL_PRIO();
     RepHost *H = A.H;
     RepLead *LS = A.LS;
     const RepDev &Md = E.rep[E.leader];
@@ -1387,6 +1421,7 @@ __device__ static inline void rep_committer(const EngDev &E, const RepArgs &A, l
  * round is committed */
 __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, lds_u64 s_h, lds_u64 s_m)
 {
+    REP_SERIAL_PRIO();
     RepHost *H = A.H;
     RepLead *LS = A.LS;
     const uint32_t lane = lane_id();
@@ -1496,29 +1531,58 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
     uint64_t a_rounds = 0, a_total = 0, a_drain = 0, a_desc = 0, a_pay = 0, a_pre = 0, a_it1 = 0, a_wait = 0, a_ldw = 0, a_iss = 0, a_sel = 0;
     uint64_t wv_next = 0;
     bool have_next = false;
+    /* the passes without ticket words (PR_ALL64 ...: "wordless passes" above): the first one this wavefront has not left behind,
+     * and its number modulo 65535 (the records' tags, kept up by addition: no 64-bit modulo per look) */
+    uint64_t g_next = 0;
+    uint32_t g_tag = 0;
+    const uint32_t rj = lane >= 8 ? (lane - 8) >> 3 : 0u;               /* lanes 8..39: word (lane & 7) of record g_next + rj */
+    /* one look: lanes 0..7 ticket kk's words, lanes 8..39 four records from g_next on -- ONE load instruction */
+    auto look = [&](uint64_t kk) -> uint64_t {
+        const uint64_t *p = lane < 8 ? &LS->tkw[lane][kk % RS_CAP] : &LS->grec[(g_next + rj) % GR_CAP][lane & 7];
+        return lane < 40 ? ld_agent(p) : 0ull;
+    };
     for (uint64_t k = g;; k += G) {
-        /* ---- wait for ticket k: its eight words carry its tag ---- */
+        /* ---- wait for ticket k: its eight words carry its tag, or a wordless pass holds it ---- */
         const uint64_t kx = k % RS_CAP;
         uint64_t wv = wv_next;                       /* (looked at under the previous round's store drain) */
-        bool go = false, bulk = false;
+        bool go = false, bulk = false, giant = false;
+        int gfound = 0;
         const uint64_t t_top = (A.dbg & 256) ? wall_clock64() : 0;
         for (uint64_t i = 0;; i++) {
-            /* the eight words of a ticket sit in eight lines (word-major): after two looks that missed, only the word
-             * that is stored last is polled until it carries the tag */
-            bool look = true;
+            /* after two looks that missed, only the word that is stored last and the first record are polled until one of
+             * them carries its tag (a ticket's words sit in eight lines, the records in four more) */
+            bool full = true;
             if (i >= 2) {
                 uint64_t m = 0;
                 if (lane == 0) m = ld_agent(&LS->tkw[TK_META][kx]);
-                look = rep_tk_ok(rl64u(m, 0), k);
+                else if (lane == 8) m = ld_agent(&LS->grec[g_next % GR_CAP][0]);
+                full = rep_tk_ok(rl64u(m, 0), k) || (rl64u(m, 8) >> 48) == (uint64_t)g_tag + 1;
             }
-            if (look && (i || !have_next)) { if (lane < 8) wv = ld_agent(&LS->tkw[lane][kx]); }
-            if (look) {
+            if (full && (i || !have_next)) wv = look(k);
+            if (full) {
                 const unsigned long long okb = __ballot(lane < 8 && rep_tk_ok(wv, k));
                 /* a ticket of a bulk pass is its TK_META and TK_SRC words alone (looked at FIRST: the slot's other six words
                  * are whatever the last ticket that had eight left there) */
                 const bool isb = ((okb >> TK_META) & 1ull) && (rdl64(wv, TK_META) & TK_BULK);
                 if (isb && ((okb >> TK_SRC) & 1ull)) { go = true; bulk = true; break; }
                 if (!isb && okb == 0xFFull) { go = true; break; }
+                /* the wordless passes: the records whose every word carries the record's tag, in order; a pass whose tickets lie
+                 * below k is left behind, the first one that does not decides */
+                const uint32_t tg = g_tag + rj;
+                const unsigned long long rb = __ballot(lane >= 8 && lane < 40 && (wv >> 48) == (uint64_t)((tg >= 65535u ? tg - 65535u : tg) + 1u));
+                uint32_t adv = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (adv != (uint32_t)j || ((rb >> (8 + 8 * j)) & 0xFFull) != 0xFFull) break;
+                    const uint64_t t0v = rdl64(wv, 8 + 8 * j + PR_T0) & TK_VAL, nv = (rdl64(wv, 8 + 8 * j + PR_BRF_N) >> 32) & 0x1FFFull;
+                    if (k >= t0v + nv) { adv = (uint32_t)j + 1; continue; }
+                    if (k >= t0v) { giant = true; gfound = j; }
+                    break;
+                }
+                if (giant) { adv = (uint32_t)gfound; }
+                g_next += adv; g_tag += adv; if (g_tag >= 65535u) g_tag -= 65535u;
+                if (giant) { go = true; break; }
+                if (adv == 4) { have_next = false; continue; }           /* (four passes left behind: the next four at once) */
             }
             if ((i & 7) == 7 && ld_agent(&LS->seq_final) <= k) break;      /* (one word for everybody: looked at now and then) */
             rep_nap(i < 256);
@@ -1543,36 +1607,56 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         const bool nt_ring = A.dbg & 1024;            /* measurement: streaming ring stores + one release per round */
         const uint64_t t_seen = timed ? wall_clock64() : 0;
         a_wait += t_seen - t_top;
+        /* a ticket that came with words: the slot does not keep them (their tag comes round again: "wordless passes" above) */
+        if (!giant && lane == 0) st_agent(&LS->tkw[TK_META][kx], 0ull);
         wv &= TK_VAL;
         uint64_t e0, idx0, slot0, first, end_after, d0, d1, meta;
         ReqDev dbulk; dbulk.req_id = 0; dbulk.pay16_type = 0; dbulk.len = 0; dbulk.clt_id = 0;
-        if (bulk) {
-            /* the other seven words from the pass record and the staged prefix sums: one round trip (the record's words and the
-             * round's four prefix values are asked for together) */
-            const uint64_t mv = rdl64(wv, TK_META);
-            const uint64_t r = mv >> 16, p12 = mv & 0xFFFull;
-            const bool bpin = (mv & TK_BULK_PIN) != 0;          /* a pass of full rounds from the request ring: r = the round's number within it */
-            const uint64_t sv = rdl64(wv, TK_SRC);
-            const uint64_t bfirst = sv & 0xFFFFFFFFull;
-            const uint32_t bn = (uint32_t)(sv >> 32) & 0x7F;
-            uint64_t pfv = 0;
-            if (!bpin) {
+        if (bulk || giant) {
+            /* the ticket's eight words from the pass record and the staged prefix sums */
+            uint64_t r = 0, bfirst = 0, pw = 0, pfv = 0;
+            uint32_t bn = 0;
+            bool bpin = false;
+            if (giant) {
+                /* the record is here (lanes 8 + 8 gfound ...): the round's number is the ticket's place in the pass */
+                pw = rl64v(wv, (int)((lane & 7) + 8 + 8 * (uint32_t)gfound));            /* (lanes 0..7: the record's words, like a polled record) */
+                const uint64_t t0 = rdl64(pw, PR_T0), rc0 = rdl64(pw, PR_RC0), brfn = rdl64(pw, PR_BRF_N);
+                r = rc0 + (k - t0);
+                if (brfn & PR_ALL64) { bfirst = (brfn & 0xFFFFFFFFull) + (k - t0) * WAVE; bn = WAVE; }
+                else {
+                    /* rounds of different sizes: the round's first request is one more look (configs[3]) */
+                    uint32_t fv = 0;
+                    if (lane < 2) fv = E.round_first[r + lane];
+                    bfirst = rl32u(fv, 0); bn = rl32u(fv, 1) - rl32u(fv, 0);
+                }
                 if (lane == 8) pfv = E.round_prefix[r]; else if (lane == 9) pfv = E.round_prefix[r + 1];
                 if (lane < bn) dbulk = E.req[bfirst + lane];      /* (the round's descriptors: the same round trip) */
-            }
-            uint64_t pw = 0;
-            for (uint64_t i = 0;; i++) {
-                if (lane < 8) pw = ld_agent(&LS->prec[p12 % PR_CAP][lane]);
-                /* (the record was stored before the pass's tickets, but nothing orders their arrival) */
-                /* (valid: all eight words of ONE pass -- the same non-zero tag -- and that pass holds ticket k) */
-                {
-                    const uint64_t tg = rdl64(pw, 0) >> 48, t0v = rdl64(pw, PR_T0) & TK_VAL, nv = ((rdl64(pw, PR_BRF_N) & TK_VAL) >> 32);
-                    if (tg != 0 && __ballot(lane < 8 && (pw >> 48) == tg) == 0xFFull && k >= t0v && k - t0v < nv) break;
+            } else {
+                /* one round trip: the record's words and the round's four prefix values are asked for together */
+                const uint64_t mv = rdl64(wv, TK_META);
+                r = mv >> 16;
+                const uint64_t p12 = mv & 0xFFFull;
+                bpin = (mv & TK_BULK_PIN) != 0;                 /* a pass of full rounds from the request ring: r = the round's number within it */
+                const uint64_t sv = rdl64(wv, TK_SRC);
+                bfirst = sv & 0xFFFFFFFFull;
+                bn = (uint32_t)(sv >> 32) & 0x7F;
+                if (!bpin) {
+                    if (lane == 8) pfv = E.round_prefix[r]; else if (lane == 9) pfv = E.round_prefix[r + 1];
+                    if (lane < bn) dbulk = E.req[bfirst + lane];      /* (the round's descriptors: the same round trip) */
                 }
-                if (i > A.peer_polls) { if (lane == 0) spin_timeout(E, 7401); break; }
-                rep_nap(true);
+                for (uint64_t i = 0;; i++) {
+                    if (lane < 8) pw = ld_agent(&LS->prec[p12 % PR_CAP][lane]);
+                    /* (the record was stored before the pass's tickets, but nothing orders their arrival) */
+                    /* (valid: all eight words of ONE pass -- the same non-zero tag -- and that pass holds ticket k) */
+                    {
+                        const uint64_t tg = rdl64(pw, 0) >> 48, t0v = rdl64(pw, PR_T0) & TK_VAL, nv = ((rdl64(pw, PR_BRF_N) & TK_VAL) >> 32) & 0x1FFFull;
+                        if (tg != 0 && __ballot(lane < 8 && (pw >> 48) == tg) == 0xFFull && k >= t0v && k - t0v < nv) break;
+                    }
+                    if (i > A.peer_polls) { if (lane == 0) spin_timeout(E, 7401); break; }
+                    rep_nap(true);
+                }
+                pw &= TK_VAL;
             }
-            pw &= TK_VAL;
             const uint64_t t0 = rdl64(pw, PR_T0), rc0 = rdl64(pw, PR_RC0), end0 = rdl64(pw, PR_END0), pidx0 = rdl64(pw, PR_IDX0), pslot0 = rdl64(pw, PR_SLOT0);
             const uint64_t bpf = rdl64(pw, PR_BPF), brfn = rdl64(pw, PR_BRF_N), ps = rdl64(pw, PR_PUSH_STAMP);
             const uint64_t pf0 = rdl64(pfv, 8), pf1 = rdl64(pfv, 9), rf0 = bfirst, rf1 = bfirst + bn;
@@ -1840,7 +1924,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
          * (3.62 / 3.49 against 3.73 / 3.55 G at three replicas): the sequencer hands out tickets at 14.8 ns per round, the append
          * wavefronts' capacity sits within 10 % of that -- shortening one of the two alone shows nothing.  Taken out
          * again.) */
-        if (lane < 8) wv_next = ld_agent(&LS->tkw[lane][(k + G) % RS_CAP]);
+        wv_next = look(k + G);
         have_next = true;
         if (nt_ring) rep_release(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint64_t t_drained = timed ? wall_clock64() : 0;
@@ -2017,6 +2101,7 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
 /* the follower's retire wavefront: rounds in order -- persist_new_entries' bookkeeping */
 __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &A, uint32_t me, lds_u64 s_f)
 {
+    REP_SERIAL_PRIO();
     RepBox *box = E.box[me];
     RepBox *lbox = E.box[E.leader];
     RepFollow *FS = A.FS[me];
@@ -2127,6 +2212,7 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
 /* the follower's apply wavefront: the commit doorbell (R4), apply_committed_entries round by round */
 __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A, uint32_t me, lds_u64 s_f)
 {
+    REP_SERIAL_PRIO();
     RepBox *box = E.box[me];
     RepBox *lbox = E.box[E.leader];
     RepFollow *FS = A.FS[me];
@@ -2298,7 +2384,8 @@ __global__ __launch_bounds__(256) void k_rep_clear_reply(const EngDev E, uint32_
  * to a hardware queue of its own; it has four by default, 7 replicas would need seven).  Workgroups that wait for each
  * other belong in one launch.  All workgroups must be resident together: the host sizes the grid for that. */
 #ifndef R_MIN_WG_PER_CU
-#define R_MIN_WG_PER_CU 2
+#define R_MIN_WG_PER_CU 3      /* round 6: the sequencer's pass no longer holds a lane's worth of registers per round (233 -> 168 VGPRs): three
+                                * workgroups per compute unit, 384 append workgroups instead of 192 (profiles/r06_grid_sweeps.txt) */
 #endif
 #ifndef R_FOLLOW_WAVES_PER_EU
 #define R_FOLLOW_WAVES_PER_EU 4

@@ -387,6 +387,14 @@ class Engine:
 
     def rep_prune(self): self._chk(self.L.apus_gpu_rep_prune(self.h), "rep_prune")
 
+    def rep_cmds(self, cmds, repeat: int = 1):
+        """a step's commands -- ("run", first staged round, rounds) / ("prune",) -- pushed by ONE call, `repeat` times over"""
+        flat = []
+        for c in cmds:
+            flat += [2, c[1], c[2]] if c[0] == "run" else [1, 0, 0]
+        arr = (C.c_uint64 * len(flat))(*flat)
+        self._chk(self.L.apus_gpu_rep_cmds(self.h, arr, len(cmds), repeat), "rep_cmds")
+
     def rep_drain(self, timeout_ms: int = 10000):
         rc = self.L.apus_gpu_rep_drain(self.h, timeout_ms)
         if rc != 0:

@@ -420,12 +420,8 @@ def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True, regions_n
         eng.sync()
         cmds = _rep_step_cmds(tr, eng)
 
-        def step():
-            for c in cmds:
-                if c[0] == "run":
-                    eng.rep_run(c[1], c[2])
-                else:
-                    eng.rep_prune()
+        def step(times=1):
+            eng.rep_cmds(cmds, times)             # (one C call pushes the step's 33 commands: apus_gpu_rep_cmds)
         hr_base = eng.counters(0)["highest_rec"]
         # (a) device-resident input -- first, on the engine as the election left it: the whole run is replayed by the oracle below
         eng.rep_start(idle_ms=5000, peer_ms=1000)
@@ -434,8 +430,7 @@ def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True, regions_n
         regions = []
         for _ in range(regions_n):
             t0 = time.perf_counter()
-            for _ in range(steps):
-                step()
+            step(steps)
             eng.rep_drain(timeout_ms=120000)
             regions.append(time.perf_counter() - t0)
         code = eng.rep_park()

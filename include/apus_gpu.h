@@ -372,6 +372,9 @@ int  apus_gpu_rep_publish(apus_engine_t *e, uint64_t slot, const void *payload_d
 int  apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uint32_t n, const uint8_t *arena, uint64_t arena_bytes);
 int  apus_gpu_rep_run(apus_engine_t *e, uint64_t r0, uint64_t n_rounds);     /* staged (device-resident) rounds */
 int  apus_gpu_rep_prune(apus_engine_t *e);                                   /* log_pruning tick */
+/* a list of such commands in one call: cmds[3 i] = 1 (prune tick) | 2 (rounds [cmds[3 i + 1], + cmds[3 i + 2]) of the staged input),
+ * the whole list `repeat` times over */
+int  apus_gpu_rep_cmds(apus_engine_t *e, const uint64_t *cmds, uint32_t n, uint32_t repeat);
 int  apus_gpu_rep_drain(apus_engine_t *e, uint32_t timeout_ms);
 int  apus_gpu_rep_full(apus_engine_t *e);                                    /* rounds refused because the log was full */
 uint64_t apus_gpu_rep_highest_rec(apus_engine_t *e);

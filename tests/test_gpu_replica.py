@@ -229,12 +229,7 @@ def test_rep_bench_shaped_run_is_bit_exact(g, steps):
         eng.sync()
         cmds = step_commands(tr, eng.round_of_g0)
         eng.rep_start(idle_ms=20000, peer_ms=5000)
-        for _ in range(steps):
-            for c in cmds:
-                if c[0] == "run":
-                    eng.rep_run(c[1], c[2])
-                else:
-                    eng.rep_prune()
+        eng.rep_cmds(cmds, steps)                     # (what bench.py does: apus_gpu_rep_cmds pushes the steps' commands)
         eng.rep_drain(timeout_ms=120000)
         assert eng.rep_park() == 0
         eng.quiesce()

@@ -42,18 +42,23 @@ def staged(n_rep, entries, payload, batch, steps, n_append, n_fwork, warmup=1):
         cmds = step_cmds(tr, eng)
         eng.rep_start(idle_ms=5000, peer_ms=1000, n_append=n_append, n_fwork=n_fwork)
 
-        def step():
-            for c in cmds:
-                if c[0] == "run":
-                    eng.rep_run(c[1], c[2])
-                else:
-                    eng.rep_prune()
-        for _ in range(warmup):
-            step()
+        one_by_one = bool(os.environ.get("SWEEP_ONE_BY_ONE"))
+
+        def step(times=1):
+            if not one_by_one:
+                eng.rep_cmds(cmds, times)
+                return
+            for _ in range(times):
+                for c in cmds:
+                    if c[0] == "run":
+                        eng.rep_run(c[1], c[2])
+                    else:
+                        eng.rep_prune()
+        step(warmup)
         eng.rep_drain(timeout_ms=60000)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        step(steps)
+        t_issue = time.perf_counter() - t0
         eng.rep_drain(timeout_ms=120000)
         dt = time.perf_counter() - t0
         st = eng.rep_stats()
@@ -69,7 +74,7 @@ def staged(n_rep, entries, payload, batch, steps, n_append, n_fwork, warmup=1):
             ok = ok and (o["commit"] == o["end"] == o["apply"])
         ok = ok and eng.counters(0)["highest_rec"] == total
         return {"mode": "staged", "replicas": n_rep, "payload": payload, "n_append": n_append, "n_fwork": n_fwork,
-                "entries_per_s": len(tr.reqs) * steps / dt, "ms_per_step": dt / steps * 1e3, "verified": bool(ok),
+                "entries_per_s": len(tr.reqs) * steps / dt, "ms_per_step": dt / steps * 1e3, "verified": bool(ok), "host_issue_frac": t_issue / dt,
                 "entries_total": total, "launch_ms": eng.rep_launch_ms(),
                 "exit": code, "status": eng.status_names(), "stats": st,
                 "lat_us_p50": float(np.percentile(lat, 50)) / 1e3 if len(lat) else None,

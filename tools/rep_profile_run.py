@@ -38,17 +38,12 @@ def run(cfg, steps):
         cmds = step_cmds(tr, eng)
         eng.rep_start(idle_ms=5000, peer_ms=1000)
 
-        def step():
-            for c in cmds:
-                if c[0] == "run":
-                    eng.rep_run(c[1], c[2])
-                else:
-                    eng.rep_prune()
+        def step(times=1):
+            eng.rep_cmds(cmds, times)
         step()
         eng.rep_drain(timeout_ms=60000)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        step(steps)
         eng.rep_drain(timeout_ms=120000)
         dt = time.perf_counter() - t0
         code = eng.rep_park()
