@@ -134,6 +134,7 @@ struct EngDev {
     const uint32_t *round_first;          /* prefix of round sizes, n_rounds + 1 entries */
     const uint32_t *round_bytes;          /* bytes each round appends (64 + len per request), n_rounds entries */
     const uint64_t *round_prefix;         /* staged rounds only: bytes appended by rounds [0, r), n_rounds + 1 entries */
+    const uint32_t *round_change;         /* ... and how often the number of requests per round has changed up to round r (n_rounds + 1 entries) */
     /* per-call scratch */
     SeqOut   *seq;
     uint64_t *round_virt;                 /* [max_rounds + 1] exclusive scan of round bytes */

@@ -49,7 +49,7 @@ struct apus_engine {
     bool tick_pending;              /* a prune tick waits to be fused into the next batch's sequencer */
     uint64_t max_rounds;
     /* staging */
-    void *d_req, *d_req_len, *d_arena, *d_round_first, *d_round_prefix;
+    void *d_req, *d_req_len, *d_arena, *d_round_first, *d_round_prefix, *d_round_change;
     uint64_t n_reqs, n_rounds_staged;
     std::vector<uint32_t> h_round_first;
     std::vector<uint64_t> h_round_prefix;      /* byte prefix of the staged rounds */
@@ -121,6 +121,8 @@ struct apus_engine {
     uint32_t r_test_skip;           /* tests: followers whose workgroups are NOT launched although they are pushed to (a dead process) */
     uint64_t r_slot_tail, r_arena_tail, r_cmd_tail;   /* producer side of the pinned rings (under r_lock) */
     uint64_t *r_slot_aend;          /* [RQ_CAP] logical arena position behind every slot's payload */
+    uint32_t *r_win_cnt, *r_win_len;/* [RQ_CAP / 64] per aligned window of 64 request slots: how many are published, and the one length they
+                                     * all have (rep_win_note: whoever brings a window to 64 writes its word, RepReq.ready_win) */
     pthread_spinlock_t r_lock;
     bool r_lock_init;
 };
@@ -171,6 +173,8 @@ static inline uint32_t sync_mask(const apus_engine *e)
     return e->local_mask & e->reachable & ~e->no_access & ~(1u << e->d.leader);
 }
 static inline int popc(uint32_t v) { return __builtin_popcount(v); }
+#define R_WIN_UNSET 0xFFFFFFFFu      /* rep_win_note: the window's account has no length yet / lengths that differ */
+#define R_WIN_MIXED 0xFFFFFFFEu
 
 /* the term fence (k_fence_check): in front of every launch that stores into followers, where another
  * process can move a follower to a newer term behind this leader's back */
@@ -219,7 +223,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->free_lb = 0; e->stage_max_T = APUS_HDR; e->host_status = 0;
     e->no_access = 0; e->adjust_mask = 0; e->d_elect = nullptr; e->cid_epoch = 0;
     e->n_reqs = 0; e->n_rounds_staged = 0;
-    e->d_req = e->d_req_len = e->d_arena = e->d_round_first = e->d_round_prefix = nullptr;
+    e->d_req = e->d_req_len = e->d_arena = e->d_round_first = e->d_round_prefix = e->d_round_change = nullptr;
     e->h_live = nullptr; e->d_live = nullptr; e->live_pending = false; e->live_copied = nullptr;
     e->live_r0 = e->live_R = e->live_n = 0;
     e->ph = e->ph_dev = nullptr; e->pd = nullptr; e->pstream = nullptr; e->p_running = false;
@@ -227,7 +231,7 @@ extern "C" int apus_gpu_create(const apus_cfg_t *cfg, apus_engine_t **out)
     e->rh = e->rh_dev = nullptr; e->rq = e->rq_dev = nullptr; e->rq_bar = false; e->rl = nullptr; e->rstream = nullptr; e->rev0 = e->rev1 = nullptr; e->rev_valid = false; e->r_running = e->r_lead = false; e->r_follow_mask = 0; e->r_test_skip = 0;
     for (auto &f : e->rfs) f = nullptr;
     for (auto &f : e->fences) f = 0;
-    e->r_slot_tail = e->r_arena_tail = e->r_cmd_tail = 0; e->r_slot_aend = nullptr;
+    e->r_slot_tail = e->r_arena_tail = e->r_cmd_tail = 0; e->r_slot_aend = nullptr; e->r_win_cnt = e->r_win_len = nullptr;
     pthread_spin_init(&e->r_lock, PTHREAD_PROCESS_PRIVATE); e->r_lock_init = true;
     if (cfg->stream) { e->stream = (hipStream_t)cfg->stream; e->own_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
@@ -315,6 +319,7 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
     if (e->d_arena) hipFree(e->d_arena);
     if (e->d_round_first) hipFree(e->d_round_first);
     if (e->d_round_prefix) hipFree(e->d_round_prefix);
+    if (e->d_round_change) hipFree(e->d_round_change);
     if (e->rq) { if (e->rq_bar) hipFree(e->rq); else hipHostFree(e->rq); }
     if (e->rh) hipHostFree(e->rh);
     if (e->rl) hipFree(e->rl);
@@ -324,7 +329,7 @@ extern "C" void apus_gpu_destroy(apus_engine_t *e)
     if (e->rev0) hipEventDestroy(e->rev0);
     if (e->rev1) hipEventDestroy(e->rev1);
     if (e->rstream) hipStreamDestroy(e->rstream);
-    free(e->r_slot_aend);
+    free(e->r_slot_aend); free(e->r_win_cnt); free(e->r_win_len);
     if (e->r_lock_init) pthread_spin_destroy(&e->r_lock);
     if (e->ph) hipHostFree(e->ph);
     if (e->pd) hipFree(e->pd);
@@ -693,6 +698,16 @@ extern "C" int apus_gpu_stage(apus_engine_t *e, const apus_req_t *reqs, uint64_t
         if ((rc = renew(&e->d_round_prefix, sizeof(uint64_t) * (n_rounds + 1)))) return rc;
         HIPCHK(hipMemcpy(e->d_round_prefix, pfx.data(), sizeof(uint64_t) * (n_rounds + 1), hipMemcpyHostToDevice));
     }
+    {
+        /* change points of the round size: chg[r] = #{i in [1, r]: round i has another number of requests than round i - 1} --
+         * rounds [a, a + n) are all of one size iff chg[a + n - 1] == chg[a] (the sequencer's passes without ticket words) */
+        std::vector<uint32_t> chg(n_rounds + 1, 0);
+        for (uint64_t r = 1; r < n_rounds; r++) chg[r] = chg[r - 1] + (round_n[r] != round_n[r - 1] ? 1u : 0u);
+        if (n_rounds) chg[n_rounds] = chg[n_rounds - 1];
+        if ((rc = renew(&e->d_round_change, sizeof(uint32_t) * (n_rounds + 1)))) return rc;
+        HIPCHK(hipMemcpy(e->d_round_change, chg.data(), sizeof(uint32_t) * (n_rounds + 1), hipMemcpyHostToDevice));
+    }
+    e->d.round_change = (const uint32_t *)e->d_round_change;
     e->d.req = (const ReqDev *)e->d_req;
     e->d.req_len = (const uint16_t *)e->d_req_len;
     e->d.arena = (const uint8_t *)e->d_arena;
@@ -2605,7 +2620,9 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
             }
             HIPCHK(hipMalloc((void **)&e->rl, sizeof(RepLead)));
             e->r_slot_aend = (uint64_t *)calloc(RQ_CAP, sizeof(uint64_t));
-            if (!e->r_slot_aend) return APUS_E_NOMEM;
+            e->r_win_cnt = (uint32_t *)calloc(RQ_CAP / WAVE, sizeof(uint32_t));
+            e->r_win_len = (uint32_t *)calloc(RQ_CAP / WAVE, sizeof(uint32_t));
+            if (!e->r_slot_aend || !e->r_win_cnt || !e->r_win_len) return APUS_E_NOMEM;
         }
         const uint32_t cand = sync_mask(e);
         uint32_t push = 0;
@@ -2620,6 +2637,10 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
         HIPCHK(hipMemcpy(h, e->d.rep[leader].hdr, sizeof h, hipMemcpyDeviceToHost));
         /* (a run that ended abnormally may have left commands or slots behind: they are dropped) */
         e->rh->cmd_head = e->r_cmd_tail; e->rh->slots_done = e->r_slot_tail;
+        /* the windows' accounts start empty; the window the ring's tail stands in is charged with the slots in front of the tail
+         * (used up by earlier runs) and never gets a word: its count still comes to 64 and is cleared for the next lap */
+        for (uint32_t w = 0; w < RQ_CAP / WAVE; w++) { e->r_win_cnt[w] = 0; e->r_win_len[w] = R_WIN_UNSET; }
+        if (e->r_slot_tail % WAVE) { e->r_win_cnt[(e->r_slot_tail / WAVE) % (RQ_CAP / WAVE)] = (uint32_t)(e->r_slot_tail % WAVE); e->r_win_len[(e->r_slot_tail / WAVE) % (RQ_CAP / WAVE)] = R_WIN_MIXED; }
         e->rh->settled = e->r_cmd_tail + e->r_slot_tail;
         e->rq->stop = 0; e->rh->alive = 0; e->rh->exit_code = 0; e->rh->full = 0; e->rh->rounds = 0;
         e->rh->highest_rec = h[H_HIGHEST_REC];
@@ -2693,11 +2714,48 @@ static int rep_push_cmd(apus_engine *e, uint32_t op, uint64_t a, uint64_t b)
  * payload arena is its tail as read BEFORE the fetch-and-add: an arena allocation takes its slot number first and its
  * bytes second (below), so no allocation of a LATER slot is included and the arena is never freed too early. */
 /* Request slots that may be reserved and not yet consumed.  Smaller than the ring on purpose: a pass of full rounds from
- * the request ring is ONE pass record for 2..8 rounds (pinned bulk passes, apus_replica.h), and the ring of pass records
- * (PR_CAP = 512) is sized for passes of >= 64 tickets -- with at most 16384 slots whose bytes have not been read there are at
- * most 256 such rounds, hence at most 128 such passes, not yet appended: a record is never overwritten under an append
- * wavefront that still needs it, however far the followers fall behind.  (120 us of requests at the host-fed rate.) */
-#define R_SLOTS_INFLIGHT 16384u
+ * the request ring is ONE pass record for >= 2 rounds (pinned bulk passes, apus_replica.h), and the ring of pass records
+ * (PR_CAP = 1024) also holds the staged passes' (>= 64 tickets each) -- with at most 49152 slots whose bytes have not been read there
+ * are at most 768 such rounds, hence at most 384 such passes, not yet appended: a record is never overwritten under an append
+ * wavefront that still needs it, however far the followers fall behind.  Round 6: 16384 -> 49152 -- the producers ran into the
+ * limit at 16384 / (sequenced -> read latency of ~50 us) = 300 M entries/s. */
+/* Window words (RepReq.ready_win).  Slots [s0, s0 + n) have just been published (their payloads fenced, their own words stored):
+ * every aligned window of 64 they touch is told so -- how many of its slots, and whether they all have ONE length so far --
+ * and the caller that brings a window to 64 writes the window's word for the sequencer (none when the lengths differ).  Several
+ * producers can share a window (a block does not start on a window boundary once anybody has submitted a number of requests
+ * that is not a multiple of 64); the counts live in host memory.  lens == nullptr: n slots of length len1. */
+static inline void rep_win_note(apus_engine *e, uint64_t s0, uint32_t n, const apus_req_t *reqs, uint32_t len1, bool all_same = false)
+{
+    const uint32_t NW = RQ_CAP / WAVE;
+    for (uint64_t w = s0 / WAVE; w * WAVE < s0 + n; w++) {
+        const uint64_t a = std::max<uint64_t>(s0, w * WAVE), b = std::min<uint64_t>(s0 + n, (w + 1) * WAVE);
+        const uint32_t len = reqs ? reqs[a - s0].len : len1;
+        bool same = true;
+        if (reqs && !all_same) for (uint64_t i = a + 1; i < b && same; i++) same = reqs[i - s0].len == len;
+        const uint32_t ix = (uint32_t)(w % NW);
+        if (b - a == WAVE) {
+            /* the whole window is this caller's: nobody else has an account to settle for it */
+            if (same) __atomic_store_n((uint32_t *)&e->rq->ready_win[ix], (rep_slot_tag(w * WAVE) << 16) | len, __ATOMIC_RELEASE);
+            continue;
+        }
+        if (!same) __atomic_store_n(&e->r_win_len[ix], R_WIN_MIXED, __ATOMIC_RELAXED);
+        else {
+            uint32_t seen = R_WIN_UNSET;
+            if (!__atomic_compare_exchange_n(&e->r_win_len[ix], &seen, len, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED) && seen != len)
+                __atomic_store_n(&e->r_win_len[ix], R_WIN_MIXED, __ATOMIC_RELAXED);
+        }
+        const uint32_t had = __atomic_fetch_add(&e->r_win_cnt[ix], (uint32_t)(b - a), __ATOMIC_ACQ_REL);
+        if (had + (uint32_t)(b - a) == WAVE) {
+            const uint32_t l = __atomic_load_n(&e->r_win_len[ix], __ATOMIC_RELAXED);
+            __atomic_store_n(&e->r_win_len[ix], R_WIN_UNSET, __ATOMIC_RELAXED);
+            __atomic_store_n(&e->r_win_cnt[ix], 0u, __ATOMIC_RELEASE);        /* (the window's next lap starts only when these slots are consumed) */
+            if (l != R_WIN_MIXED && l != R_WIN_UNSET)
+                __atomic_store_n((uint32_t *)&e->rq->ready_win[ix], (rep_slot_tag(w * WAVE) << 16) | l, __ATOMIC_RELEASE);
+        }
+    }
+}
+
+#define R_SLOTS_INFLIGHT 49152u
 static_assert(R_SLOTS_INFLIGHT <= RQ_CAP && R_SLOTS_INFLIGHT / WAVE / 2 + RS_CAP / WAVE < PR_CAP, "pass records: pinned bulk passes + staged bulk passes in flight");
 static inline int rep_reserve_inline(apus_engine *e, uint32_t n, uint64_t *first)
 {
@@ -2763,6 +2821,7 @@ extern "C" int apus_gpu_rep_publish(apus_engine_t *e, uint64_t slot, const void 
      * and the publish word leaves at once */
     if (e->rq_bar) __builtin_ia32_sfence();
     __atomic_store_n((uint32_t *)&e->rq->ready_len[slot % RQ_CAP], (rep_slot_tag(slot) << 16) | len, __ATOMIC_RELEASE);
+    rep_win_note(e, slot, 1, nullptr, len);
     if (e->rq_bar) __builtin_ia32_sfence();
     return 0;
 }
@@ -2775,9 +2834,11 @@ extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uin
     if (!e->r_running || !e->r_lead) return APUS_E_STATE;
     /* everything that can be refused is refused HERE, before any slot is reserved: a block of reserved slots that is never
      * published wedges the sequencer, which takes slots strictly in order */
+    bool all_same = true;                          /* (one length all the way: the windows' words need no second look at the lengths) */
     for (uint32_t g = 0; g < n; g++) {
         if (reqs[g].payload_off + reqs[g].len > arena_bytes) return APUS_E_ARG;
         if (reqs[g].type == APUS_NOOP || reqs[g].type == APUS_CONFIG || reqs[g].type == APUS_HEAD || reqs[g].type > 15) return APUS_E_ARG;
+        all_same = all_same && reqs[g].len == reqs[0].len;
     }
     /* A block = the slots one fetch-and-add hands out and ONE fence covers.  Through the BAR every fence waits for the
      * write-combining buffers to drain (~0.35 us): at 64 slots per block and two fences per block a producer thread spent
@@ -2815,6 +2876,7 @@ extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uin
         if (e->rq_bar) __builtin_ia32_sfence();            /* the payloads and descriptors (and the block before's publish words) */
         for (uint32_t i = 0; i < run; i++)
             __atomic_store_n((uint32_t *)&e->rq->ready_len[(s0 + i) % RQ_CAP], (rep_slot_tag(s0 + i) << 16) | reqs[g + i].len, __ATOMIC_RELEASE);
+        rep_win_note(e, s0, run, reqs + g, 0, all_same);   /* the windows these slots lie in: whoever completes one writes its word */
         words_pending = true;
         g += run;
     }

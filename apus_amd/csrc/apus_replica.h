@@ -67,11 +67,9 @@
 #define RA_CAP    (64u << 20)    /* pinned payload arena (bytes)                              */
 #define RC_CAP    256u           /* host command ring                                         */
 #ifndef R_WIN
-#define R_WIN     8              /* 64-slot windows of the request ring the sequencer reads per round trip.  Round 5, four producers, M entries/s
-                                  * host-fed: 8 windows 167, 16 windows 242, 32 windows 300 (a pass costs ~1.8 us + ~0.17 us per window; the next
-                                  * pass's words are asked for while this pass's record and tickets are stored).  The two 32-word register
-                                  * arrays take the leader's kernels to 219 VGPRs: two wavefronts per SIMD, which is what a launch of at most two
-                                  * workgroups per compute unit has anyway (staged throughput unchanged: profiles/r05_host_fed_windows.txt) */
+#define R_WIN     2              /* 64-slot windows of the request ring whose SLOT words the sequencer reads per round trip: what is not a full window
+                                  * of equally long requests (RepReq.ready_win) goes one round of <= 64 at a time, as many per look.  (Rounds 4 / 5
+                                  * read 8 / 32 windows of slot words for the bulk passes: two 32-word register arrays, 219 VGPRs) */
 #endif
 #ifndef R_SUB
 #define R_SUB     8              /* 64-round chunks a serial role handles per memory round trip (round 6: 4 -> 8, the committer and the applier
@@ -128,6 +126,11 @@ struct RepReq {
     /* multi-producer request ring: a producer reserves slot (+ arena range for a long payload), copies
      * the payload, fills slot[].d, then publishes ready_len[slot] = tag << 16 | len (release) */
     volatile uint32_t ready_len[RQ_CAP];
+    /* Round 6: one word per aligned WINDOW of 64 slots, tag << 16 | len like the slots' own, written by a producer that has
+     * published all 64 of them itself with one length (apus_gpu_rep_submit: a block of 256 slots = four windows).  The
+     * sequencer looks at 64 of these per round trip -- 4096 slots, one lane per window -- where rounds 4 and 5 looked at R_WIN
+     * windows' 64 slot words each (8 -> 32 windows per look bought 167 -> 300 M entries/s and 64 VGPRs of the leader's kernels) */
+    volatile uint32_t ready_win[RQ_CAP / WAVE];
     RepSlot  slot[RQ_CAP];
     uint8_t  arena[RA_CAP + 64];
 };
@@ -207,10 +210,11 @@ enum { TK_E0 = 0, TK_IDX0, TK_SLOT0, TK_SRC, TK_END, TK_D0, TK_D1, TK_META };
  * 4 n_append apart: it never falls more than a few records behind, and never GR_CAP.  With no word written per ticket a slot of
  * tkw[] would keep an OLD ticket's words -- and their tag comes round again after 16384 x 65535 tickets -- so a wavefront that
  * has taken a ticket with words clears the slot's TK_META.  PR_BRF_N of such a record: [31:0] first request  [44:32] rounds
- * [47] every round has 64 requests (a staged round never has more: the first request of round r is then first + 64 (r - rc0),
- * no look at round_first[]).  The sequencer's pass costs the same whatever it takes: one round trip + ~300 instructions. */
-#define PR_ALL64  (1ull << 47)
-#define PR_CAP    512u                  /* pass records (a bulk pass has >= 64 tickets, RS_CAP tickets are in flight at most) */
+ * [47] every round of the pass has the same number of requests, PR_RC0[39:32] (EngDev.round_change says so: the first request
+ * of round r is then first + n (r - rc0), no look at round_first[]).  The sequencer's pass costs the same whatever it takes:
+ * one round trip + ~300 instructions. */
+#define PR_UNIFORM (1ull << 47)
+#define PR_CAP    1024u                 /* pass records (a bulk pass has >= 64 tickets, RS_CAP tickets are in flight at most) */
 enum { PR_T0 = 0, PR_RC0, PR_END0, PR_IDX0, PR_SLOT0, PR_BPF, PR_BRF_N, PR_PUSH_STAMP };   /* words {low 16 bits of pass + 1 : 48-bit value} */
 #define TK_VAL 0x0000FFFFFFFFFFFFull
 /* (the tag is never 0: a word nobody has written yet never reads as valid.  Round 4: the words of a slot that bulk passes
@@ -754,7 +758,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
     bool pk_pending = false;                     /* the next host commands, asked for by a staged pass that may end its run */
     uint64_t pk_cg = 0, pk_next = 0;
     /* the request-ring passes' pipeline registers (host-fed input) */
-    uint32_t pf_v[R_WIN];
+    uint32_t pf_v[R_WIN], pf_ww = 0;
     uint64_t pf_cg = 0, pf_stop = 0, pf_head = 0, pf_cmd = 0;
     bool pf_on = false, rq_hot = false;
 #pragma unroll
@@ -871,6 +875,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                 const uint32_t cut = (uint32_t)(((uint64_t)avail * (lane + 1)) >> 6);     /* lane l: the first `cut` rounds (lane 63: all) */
                 const uint64_t spf = E.round_prefix[rc + cut];
                 const uint32_t srf = E.round_first[rc + cut];
+                const uint32_t scg = E.round_change[rc + (cut ? cut - 1 : 0u)], cg0 = E.round_change[rc];      /* (one size all the way?) */
                 /* the next host commands, when this pass may end the run -- and only when NEITHER command register holds one: a
                  * command fetched together with this RUN sits in the second register until the run is over */
                 if (!have_cmd && !have_cmd2 && run_end - rc <= avail) {
@@ -896,20 +901,20 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                     if (N >= WAVE) {
                         const uint64_t tot = rl64u(spf, (int)nb - 1) - bpf;
                         const uint32_t ntot = rl32u(srf, (int)nb - 1) - brf;
-                        /* every round a full one (a staged round never has more than 64 requests, apus_gpu_stage): the first request of
-                         * round rc + j is brf + 64 j -- nobody needs round_first[] (configs[1]) */
-                        const bool all64 = ntot == N * WAVE;
+                        /* every round of the same size: the first request of round rc + j is brf + n_u j -- nobody needs round_first[] */
+                        const uint32_t n_u = rl32u(rf1 - rf0, 0);
+                        const bool all64 = rl32u(scg, (int)nb - 1) == rl32u(cg0, 0);
                         const bool wordless = N >= GP_MIN && !(A.dbg & 128);
                         const uint64_t pn = wordless ? S.g_seq++ : S.pass_seq++;
                         uint64_t v = 0;
                         switch (lane) {
                         case PR_T0: v = S.t; break;
-                        case PR_RC0: v = rc; break;
+                        case PR_RC0: v = rc | ((uint64_t)n_u << 32); break;
                         case PR_END0: v = S.end; break;
                         case PR_IDX0: v = S.last_idx + 1; break;
                         case PR_SLOT0: v = S.n_end; break;
                         case PR_BPF: v = bpf; break;
-                        case PR_BRF_N: v = (uint64_t)brf | ((uint64_t)N << 32) | (all64 ? PR_ALL64 : 0ull); break;
+                        case PR_BRF_N: v = (uint64_t)brf | ((uint64_t)N << 32) | (all64 ? PR_UNIFORM : 0ull); break;
                         case PR_PUSH_STAMP: v = (uint64_t)(uint32_t)stamp | ((uint64_t)S.push_mask << 32); break;
                         default: break;
                         }
@@ -931,7 +936,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                             uint32_t a[GP_GRP], b[GP_GRP];
                             if (all64) {
 #pragma unroll
-                                for (int g = 0; g < GP_GRP; g++) { a[g] = brf + ((c0 + (uint32_t)g) * WAVE + lane) * WAVE; b[g] = a[g] + WAVE; }
+                                for (int g = 0; g < GP_GRP; g++) { a[g] = brf + ((c0 + (uint32_t)g) * WAVE + lane) * n_u; b[g] = a[g] + n_u; }
                             } else {
 #pragma unroll
                                 for (int g = 0; g < GP_GRP; g++) {
@@ -1005,13 +1010,15 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
          *      are in flight while its record and tickets are stored; round 5) ---- */
         const uint64_t tq0 = stats ? wall_clock64() : 0;
         st_pcie_n++;
-        uint32_t v[R_WIN];
+        uint32_t v[R_WIN], ww = 0;
         uint64_t cg = 0, stopw = 0;
         if (pf_on && pf_head == req_head && pf_cmd == cmd_head) {
 #pragma unroll
             for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = pf_v[wdw];
-            cg = pf_cg; stopw = pf_stop;
+            cg = pf_cg; stopw = pf_stop; ww = pf_ww;
         } else {
+            /* the window words of the next 64 windows, one lane each (when the ring's head stands on a window boundary) */
+            if (!(req_head & (WAVE - 1))) ww = ld_sys32(&RQ->ready_win[(req_head / WAVE + lane) % (RQ_CAP / WAVE)]);
             /* (a ring that had no full window last time is looked at one window at a time: a lone request does not wait for
              * R_WIN windows of words nobody has written -- a pass over 32 empty windows is ~7 us) */
             const int nw = rq_hot ? R_WIN : 1;
@@ -1048,21 +1055,27 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
          *      them, two words per round -- the rounds are the same rounds of 64 the loop below would make one by one, at ~1 us
          *      of the sequencer each (round 3 / 4: the host-fed ceiling, 46 M entries/s whatever the number of producers) ---- */
         if (!(A.dbg & 32) && budget >= 2) {
-            uint32_t Wn = 0;
-            const uint32_t len0 = rl32u(v[0] & 0xFFFFu, 0);
-#pragma unroll
-            for (int wdw = 0; wdw < R_WIN; wdw++) {
-                if (Wn != (uint32_t)wdw) break;
-                const uint64_t slot = req_head + (uint64_t)wdw * WAVE + lane;
-                const bool ok = slot < limit && (v[wdw] >> 16) == rep_slot_tag(slot) && (v[wdw] & 0xFFFFu) == len0;
-                if (__ballot(ok) == ~0ull) Wn++;
-            }
+            /* lane l: window l from the head on is all there, every request as long as the first window's */
+            const uint32_t len0 = rl32u(ww & 0xFFFFu, 0);
+            const uint64_t slot0 = req_head + (uint64_t)lane * WAVE;
+            const bool okw = !(req_head & (WAVE - 1)) && slot0 + WAVE <= limit && (ww >> 16) == rep_slot_tag(slot0) && (ww & 0xFFFFu) == len0;
+            const unsigned long long bw = __ballot(okw);
+            uint32_t Wn = (~bw) ? (uint32_t)__builtin_ctzll(~bw) : WAVE;
             if ((uint64_t)Wn > budget) Wn = (uint32_t)budget;
-            const uint64_t T = APUS_HDR + (uint64_t)len0, tot = (uint64_t)Wn * WAVE * T;
+            const uint64_t T = APUS_HDR + (uint64_t)len0;
             const uint64_t used = S.end >= S.head_safe ? S.end - S.head_safe : L - (S.head_safe - S.end);
+            if (Wn >= 2 && S.end != L && S.end != S.head_safe) {
+                /* as many of them as go in front of len and into the free part of the ring (the rest, and the round at the wrap, later) */
+                const uint64_t per = (uint64_t)WAVE * T;
+                const uint64_t r1 = (L - 1 - S.end) / per, r2 = L - used >= APUS_HDR ? (L - used - APUS_HDR) / per : 0;
+                if (r1 < Wn) Wn = (uint32_t)r1;
+                if (r2 < Wn) Wn = (uint32_t)r2;
+            }
+            const uint64_t tot = (uint64_t)Wn * WAVE * T;
             if (Wn >= 2 && S.end != L && S.end + tot < L && S.end != S.head_safe && tot + APUS_HDR <= L - used) {
                 {   /* what the next pass will look at: asked for now, looked at then (words published later are seen a pass later) */
                     const uint64_t nh = req_head + (uint64_t)Wn * WAVE;
+                    pf_ww = ld_sys32(&RQ->ready_win[(nh / WAVE + lane) % (RQ_CAP / WAVE)]);
 #pragma unroll
                     for (int wdw = 0; wdw < R_WIN; wdw++) pf_v[wdw] = ld_sys32(&RQ->ready_len[(nh + (uint64_t)wdw * WAVE + lane) % RQ_CAP]);
                     pf_cg = 0;
@@ -1104,7 +1117,10 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
         for (int wdw = 0; wdw < R_WIN; wdw++) {
             if (budget == 0) break;
             const uint64_t slot = req_head + lane;
-            const bool ok = slot < limit && (v[wdw] >> 16) == rep_slot_tag(slot);
+            /* (while full windows are coming in, a round that starts inside a window ends on its boundary: the windows behind it
+             *  then go 64 at a look by their words -- the ring's head only stands inside a window after a submit whose size is not a
+             *  multiple of 64) */
+            const bool ok = slot < limit && (v[wdw] >> 16) == rep_slot_tag(slot) && (!rq_hot || !(req_head & (WAVE - 1)) || (slot & ~(uint64_t)(WAVE - 1)) == (req_head & ~(uint64_t)(WAVE - 1)));
             const unsigned long long bal = __ballot(ok);
             const uint32_t n = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
             if (n == 0) break;
@@ -1232,15 +1248,21 @@ __device__ static inline void rep_commit_pass(const EngDev &E, RepLead *LS, RepC
     const uint32_t lane = lane_id();
     const uint64_t base = C.t_done;
     uint64_t g0[R_SUB], g1[R_SUB], g2[R_SUB];
+    /* (as many chunks of 64 as tickets are out: a lone round is one chunk's loads, not R_SUB chunks' -- the issue time of 24
+     *  loads nobody needs sat in every hop of a lone round's latency) */
+    const uint32_t nsub = (uint32_t)min((uint64_t)R_SUB, tail > base ? (tail - base + WAVE - 1) / WAVE : 1ull);
 #pragma unroll
     for (int s = 0; s < R_SUB; s++) {
-        const uint64_t ix = (base + (uint64_t)s * WAVE + lane) % RS_CAP;
-        g0[s] = ld_agent(&LS->dn[DN_META][ix]); g1[s] = ld_agent(&LS->dn[DN_SLOT_END][ix]); g2[s] = ld_agent(&LS->dn[DN_END][ix]);
+        g0[s] = 0; g1[s] = 0; g2[s] = 0;
+        if ((uint32_t)s < nsub) {
+            const uint64_t ix = (base + (uint64_t)s * WAVE + lane) % RS_CAP;
+            g0[s] = ld_agent(&LS->dn[DN_META][ix]); g1[s] = ld_agent(&LS->dn[DN_SLOT_END][ix]); g2[s] = ld_agent(&LS->dn[DN_END][ix]);
+        }
     }
     const uint64_t pbw = lane < 16 ? ld_sys(&mybox->persisted_by[lane]) : 0ull;
 #pragma unroll
     for (int s = 0; s < R_SUB; s++) {
-        if (C.t_done != base + (uint64_t)s * WAVE) break;           /* (chunk s is looked at only when every chunk before it is in whole) */
+        if (C.t_done != base + (uint64_t)s * WAVE || (uint32_t)s >= nsub) break;           /* (chunk s is looked at only when every chunk before it is in whole) */
         const uint64_t k = base + (uint64_t)s * WAVE + lane;
         const bool ret = k < tail && rep_gran_ok(g0[s], k) && rep_gran_ok(g1[s], k) && rep_gran_ok(g2[s], k);
         const unsigned long long balr = __ballot(ret);
@@ -1438,18 +1460,22 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, lds
         bool progress = false;
         if (t_app < t_done) {
             uint64_t g1[R_SUB], g3[R_SUB], g4[R_SUB], g5[R_SUB], g6[R_SUB], g7[R_SUB];
+            const uint32_t nsub = (uint32_t)min((uint64_t)R_SUB, (t_done - t_app + WAVE - 1) / WAVE);       /* (as many chunks as rounds are done) */
 #pragma unroll
             for (int s = 0; s < R_SUB; s++) {
-                const uint64_t ix = (t_app + (uint64_t)s * WAVE + lane) % RS_CAP;
-                g1[s] = ld_agent(&LS->dn[DN_SLOT_END][ix]); g3[s] = ld_agent(&LS->dn[DN_HASH_LO][ix]); g4[s] = ld_agent(&LS->dn[DN_HASH_HI][ix]);
-                g5[s] = ld_agent(&LS->dn[DN_NCLIENT][ix]); g6[s] = ld_agent(&LS->dn[DN_T_APPENDED][ix]); g7[s] = ld_agent(&LS->dn[DN_T_SEQUENCED][ix]);
+                g1[s] = 0; g3[s] = 0; g4[s] = 0; g5[s] = 0; g6[s] = 0; g7[s] = 0;
+                if ((uint32_t)s < nsub) {
+                    const uint64_t ix = (t_app + (uint64_t)s * WAVE + lane) % RS_CAP;
+                    g1[s] = ld_agent(&LS->dn[DN_SLOT_END][ix]); g3[s] = ld_agent(&LS->dn[DN_HASH_LO][ix]); g4[s] = ld_agent(&LS->dn[DN_HASH_HI][ix]);
+                    g5[s] = ld_agent(&LS->dn[DN_NCLIENT][ix]); g6[s] = ld_agent(&LS->dn[DN_T_APPENDED][ix]); g7[s] = ld_agent(&LS->dn[DN_T_SEQUENCED][ix]);
+                }
             }
             const uint64_t t0 = t_app;
             uint64_t nc_pass = 0;
             const uint32_t now = (uint32_t)wall_clock64();             /* (once per pass: the latency samples' end) */
 #pragma unroll
             for (int s = 0; s < R_SUB; s++) {
-                if (t_app != t0 + (uint64_t)s * WAVE) break;
+                if (t_app != t0 + (uint64_t)s * WAVE || (uint32_t)s >= nsub) break;
                 const uint64_t k = t_app + lane;
                 const uint64_t slot_end = rep_extend(n_apply, (uint32_t)g1[s]);
                 const bool okk = k < t_done && rep_gran_ok(g1[s], k) && rep_gran_ok(g3[s], k) && rep_gran_ok(g4[s], k) && rep_gran_ok(g5[s], k)
@@ -1620,9 +1646,9 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             if (giant) {
                 /* the record is here (lanes 8 + 8 gfound ...): the round's number is the ticket's place in the pass */
                 pw = rl64v(wv, (int)((lane & 7) + 8 + 8 * (uint32_t)gfound));            /* (lanes 0..7: the record's words, like a polled record) */
-                const uint64_t t0 = rdl64(pw, PR_T0), rc0 = rdl64(pw, PR_RC0), brfn = rdl64(pw, PR_BRF_N);
+                const uint64_t t0 = rdl64(pw, PR_T0), rc0 = rdl64(pw, PR_RC0) & 0xFFFFFFFFull, brfn = rdl64(pw, PR_BRF_N);
                 r = rc0 + (k - t0);
-                if (brfn & PR_ALL64) { bfirst = (brfn & 0xFFFFFFFFull) + (k - t0) * WAVE; bn = WAVE; }
+                if (brfn & PR_UNIFORM) { bn = (uint32_t)(rdl64(pw, PR_RC0) >> 32) & 0xFFu; bfirst = (brfn & 0xFFFFFFFFull) + (k - t0) * bn; }
                 else {
                     /* rounds of different sizes: the round's first request is one more look (configs[3]) */
                     uint32_t fv = 0;
@@ -1657,7 +1683,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                 }
                 pw &= TK_VAL;
             }
-            const uint64_t t0 = rdl64(pw, PR_T0), rc0 = rdl64(pw, PR_RC0), end0 = rdl64(pw, PR_END0), pidx0 = rdl64(pw, PR_IDX0), pslot0 = rdl64(pw, PR_SLOT0);
+            const uint64_t t0 = rdl64(pw, PR_T0), rc0 = rdl64(pw, PR_RC0) & 0xFFFFFFFFull, end0 = rdl64(pw, PR_END0), pidx0 = rdl64(pw, PR_IDX0), pslot0 = rdl64(pw, PR_SLOT0);
             const uint64_t bpf = rdl64(pw, PR_BPF), brfn = rdl64(pw, PR_BRF_N), ps = rdl64(pw, PR_PUSH_STAMP);
             const uint64_t pf0 = rdl64(pfv, 8), pf1 = rdl64(pfv, 9), rf0 = bfirst, rf1 = bfirst + bn;
             const uint64_t brf = brfn & 0xFFFFFFFFull;
@@ -2124,7 +2150,7 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
     const uint64_t pb_tag = ((my_run + 1) & 0xFFFFFFull) << 40;
     if (lane == 0) st_sys(&lbox->persisted_by[me], pb_tag | n_end);
     uint64_t idle = 0;
-    uint32_t exit_code = R_EXIT_STOP;
+    uint32_t exit_code = R_EXIT_STOP, last_p = 0;
     uint64_t final_q = ~0ull;
     uint64_t st_pass = 0, st_prog = 0, st_busy = 0;
     const uint64_t st_t0 = wall_clock64();
@@ -2136,17 +2162,22 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
         const uint64_t st_p0 = (A.dbg & 512) ? wall_clock64() : 0;
         const uint64_t ctrl = ld_sys(&box->ctrl);
         uint64_t f0[R_SUB], f1[R_SUB], f2[R_SUB], f3[R_SUB];
+        /* (one chunk of 64 while the rounds trickle in, as many as the last look retired and two more once they come in bulk) */
+        const uint32_t nsub = last_p < WAVE / 2 ? 1u : min((uint32_t)R_SUB, last_p / WAVE + 2);
 #pragma unroll
         for (int s = 0; s < R_SUB; s++) {
-            const uint64_t ix = (q_ret + (uint64_t)s * WAVE + lane) % RB_CAP;
-            f0[s] = ld_agent(&FS->fr[FR_END][ix]); f1[s] = ld_agent(&FS->fr[FR_E0][ix]); f2[s] = ld_agent(&FS->fr[FR_SLOT_END][ix]); f3[s] = ld_agent(&FS->fr[FR_N][ix]);
+            f0[s] = 0; f1[s] = 0; f2[s] = 0; f3[s] = 0;
+            if ((uint32_t)s < nsub) {
+                const uint64_t ix = (q_ret + (uint64_t)s * WAVE + lane) % RB_CAP;
+                f0[s] = ld_agent(&FS->fr[FR_END][ix]); f1[s] = ld_agent(&FS->fr[FR_E0][ix]); f2[s] = ld_agent(&FS->fr[FR_SLOT_END][ix]); f3[s] = ld_agent(&FS->fr[FR_N][ix]);
+            }
         }
         if (final_q == ~0ull && (ctrl >> 40) == my_run + 1) final_q = q0 + (ctrl & 0xFFFFFFFFFFull) - 1;
         const uint64_t t0 = q_ret;
         bool gap = false, fenced = false;
 #pragma unroll
         for (int s = 0; s < R_SUB; s++) {
-            if (q_ret != t0 + (uint64_t)s * WAVE || fenced) break;
+            if (q_ret != t0 + (uint64_t)s * WAVE || fenced || (uint32_t)s >= nsub) break;
             const uint64_t q = q_ret + lane;
             const bool okq = q < final_q && rep_gran_ok(f0[s], q) && rep_gran_ok(f1[s], q) && rep_gran_ok(f2[s], q) && rep_gran_ok(f3[s], q);
             const unsigned long long bal = __ballot(okq);
@@ -2183,6 +2214,7 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
             q_ret += p;
             progress = true;
         }
+        last_p = (uint32_t)(q_ret - t0);
         if (gap) { exit_code = R_EXIT_GAP; if (lane == 0) spin_timeout(E, 7301); break; }
         if (progress && lane == 0) {
             s_f[F_END] = end; s_f[F_N_END] = n_end;
@@ -2248,13 +2280,17 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
         q_ret = s_f[F_Q_RET]; n_end = s_f[F_N_END]; end = s_f[F_END];
         uint64_t cs = ld_sys(&box->commit_bell);
         uint64_t f0[R_SUB], f2[R_SUB], f3[R_SUB], f4[R_SUB], f5[R_SUB], f6[R_SUB];
+        const uint32_t nsub = (uint32_t)min((uint64_t)R_SUB, (q_ret - q_app + WAVE - 1) / WAVE);       /* (as many chunks as rounds are retired) */
         if (q_app < q_ret) {
 #pragma unroll
             for (int s = 0; s < R_SUB; s++) {
-                const uint64_t ix = (q_app + (uint64_t)s * WAVE + lane) % RB_CAP;
-                f0[s] = ld_agent(&FS->fr[FR_END][ix]);
-                f2[s] = ld_agent(&FS->fr[FR_SLOT_END][ix]); f3[s] = ld_agent(&FS->fr[FR_N][ix]); f4[s] = ld_agent(&FS->fr[FR_HASH_LO][ix]);
-                f5[s] = ld_agent(&FS->fr[FR_HASH_HI][ix]); f6[s] = ld_agent(&FS->fr[FR_HEAD][ix]);
+                f0[s] = 0; f2[s] = 0; f3[s] = 0; f4[s] = 0; f5[s] = 0; f6[s] = 0;
+                if ((uint32_t)s < nsub) {
+                    const uint64_t ix = (q_app + (uint64_t)s * WAVE + lane) % RB_CAP;
+                    f0[s] = ld_agent(&FS->fr[FR_END][ix]);
+                    f2[s] = ld_agent(&FS->fr[FR_SLOT_END][ix]); f3[s] = ld_agent(&FS->fr[FR_N][ix]); f4[s] = ld_agent(&FS->fr[FR_HASH_LO][ix]);
+                    f5[s] = ld_agent(&FS->fr[FR_HASH_HI][ix]); f6[s] = ld_agent(&FS->fr[FR_HEAD][ix]);
+                }
             }
         }
         if (cs > n_end) cs = n_end;
@@ -2263,7 +2299,7 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
             const uint64_t t0 = q_app;
 #pragma unroll
             for (int s = 0; s < R_SUB; s++) {
-                if (q_app != t0 + (uint64_t)s * WAVE) break;
+                if (q_app != t0 + (uint64_t)s * WAVE || (uint32_t)s >= nsub) break;
                 const uint64_t q = q_app + lane;
                 const uint64_t se = rep_extend(n_apply, (uint32_t)f2[s]);
                 const bool okq = q < q_ret && rep_gran_ok(f0[s], q) && rep_gran_ok(f2[s], q) && rep_gran_ok(f3[s], q) && rep_gran_ok(f4[s], q) && rep_gran_ok(f5[s], q)

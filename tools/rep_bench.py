@@ -83,7 +83,7 @@ def staged(n_rep, entries, payload, batch, steps, n_append, n_fwork, warmup=1):
         eng.close()
 
 
-def hostfed(n_rep, payload, seconds, n_append, n_fwork, blk=4096, threads=(1, 4, 8)):
+def hostfed(n_rep, payload, seconds, n_append, n_fwork, blk=4096, threads=(1, 2, 4, 8)):
     tr = T.steady_trace(n_rep, 1 << 16, payload, 16, 64, log_len=T.DEFAULT_LOG)
     eng = Engine(n_rep, tr.log_len)
     try:
@@ -110,6 +110,9 @@ def hostfed(n_rep, payload, seconds, n_append, n_fwork, blk=4096, threads=(1, 4,
             good = eng.rep_highest_rec() == hr0 + n
             code = eng.rep_park()
             out["by_threads"][str(nt)] = {"entries_per_s": n / dt, "verified": bool(good and code == 0)}
+            if os.environ.get("APUS_REP_DBG"):
+                rs = eng.rep_role_stats()
+                out["by_threads"][str(nt)]["seq"] = {k: rs.get("sequencer", {}).get(k) for k in ("passes", "moved", "rounds", "us", "busy_us", "pcie_us", "pcie_polls", "flow_us")}
             ok = ok and good and code == 0
         eng.quiesce()
         for r in range(n_rep):
