@@ -3006,6 +3006,15 @@ extern "C" int apus_gpu_rep_stats(apus_engine_t *e, uint64_t out[8])
 
 /* duration of the last run's resident launch (k_replica* on the engine's replica stream), HIP events around the launch:
  * what rocprofv3 --kernel-trace reports for the same launch.  Only after the run was parked. */
+/* diagnostics: the XCD (1..8; 0 = no such workgroup) every workgroup of the last resident launch ran on, by block index */
+extern "C" int apus_gpu_rep_xcc_map(apus_engine_t *e, uint8_t out[1024])
+{
+    if (!e || !out || !e->rl) return APUS_E_STATE;
+    if (e->r_running) return APUS_E_STATE;
+    HIPCHK(hipMemcpy(out, e->rl->xcc, 1024, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int apus_gpu_rep_launch_ms(apus_engine_t *e, double *ms)
 {
     if (!e || !ms || e->r_running || !e->rev_valid) return APUS_E_STATE;

@@ -239,6 +239,7 @@ struct RepLead {
     uint64_t  tkw[8][RS_CAP];
     uint64_t  prec[PR_CAP][8];
     uint64_t  grec[GR_CAP][8];                  /* the records of the passes without ticket words, by their own sequence number */
+    uint8_t   xcc[1024];                        /* which XCD (XCC_ID) every workgroup of the launch ran on: diagnostics (apus_gpu_rep_xcc_map) */
     uint64_t  dn[8][RS_CAP];                     /* granule-major: the committer / applier read 64 consecutive tickets' granules in whole lines */
 };
 /* the leader's first workgroup: its wavefronts' words in LDS */
@@ -2489,8 +2490,16 @@ __device__ static inline void rep_follower_block(const EngDev &E, const RepArgs 
     rep_follow_wave(E, A, me, fb * 4 + wave - 2, G);
 }
 
+/* the XCD this workgroup runs on (HW_REG_XCC_ID = hwreg 20, bits [3:0]) */
+__device__ static inline uint32_t rep_xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); }
+__device__ static inline void rep_note_xcc(const RepArgs &A)
+{
+    if (A.LS && threadIdx.x == 0 && blockIdx.x < 1024) A.LS->xcc[blockIdx.x] = (uint8_t)(rep_xcc_id() + 1);
+}
+
 __global__ __launch_bounds__(256, R_MIN_WG_PER_CU) void k_replica(const EngDev E, const RepArgs A)
 {
+    rep_note_xcc(A);
     uint32_t b = blockIdx.x;
     if (A.lead_here) {
         if (b <= A.n_append) { rep_leader_block(E, A, b); return; }
@@ -2506,6 +2515,7 @@ __global__ __launch_bounds__(256, R_MIN_WG_PER_CU) void k_replica(const EngDev E
 
 __global__ __launch_bounds__(256, R_MIN_WG_PER_CU) void k_replica_leader(const EngDev E, const RepArgs A)
 {
+    rep_note_xcc(A);
     rep_leader_block(E, A, blockIdx.x);
 }
 
