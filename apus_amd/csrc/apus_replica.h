@@ -532,10 +532,12 @@ struct RepSeqState {                    /* the sequencer's registers: the leader
     uint64_t t;                         /* tickets issued                                      */
     uint64_t pass_seq;                  /* bulk passes issued                                  */
     uint64_t g_seq;                     /* ... and passes without ticket words                 */
-    /* Head moves that are not verified yet (rep_seq_prune): a small queue in LDS of {the slot count every sampled server
-     * must have applied, the head that then holds}, and the head as it stands with the verified moves only -- what
-     * protects the ring (rep_refuse) until the rest is verified. */
-    lds_u64 pv;
+    /* Head moves that are not verified yet (rep_seq_prune): a small queue {the slot count every sampled server must have
+     * applied, the head that then holds} -- entry j in lane j of two registers (round 6: in LDS until then, like the sampled
+     * apply offsets: a dozen LDS round trips per prune tick on a compute unit whose append wavefronts live in LDS) -- and the
+     * head as it stands with the verified moves only: what protects the ring (rep_refuse) until the rest is verified. */
+    uint64_t pv_need, pv_head;
+    uint64_t ao;                        /* lane i: ctrl_data->apply_offsets[i], what the last tick sampled for server i */
     uint64_t head_safe;
     uint32_t pv_r, pv_n;
     uint64_t tail_round;                /* staged round whose last entry is the tail (tail worked out when somebody asks) */
@@ -655,11 +657,11 @@ __device__ static inline unsigned long long rep_seq_verify(RepSeqState &S, lds_u
     const uint64_t v = pre ? (lane_id() == 0 ? (uint64_t)s_m[M_N_APPLY] : *pre) : rep_seq_applied(S, s_m, mybox);
     for (;;) {
         if (!S.pv_n) return 0;
-        const uint32_t ix = 2 * (S.pv_r % R_PV);
-        const uint64_t need = S.pv[ix];
+        const int ix = (int)(S.pv_r % R_PV);
+        const uint64_t need = rl64u(S.pv_need, ix);
         const unsigned long long late = __ballot(v < need);
         if (late) return late;
-        S.head_safe = S.pv[ix + 1];
+        S.head_safe = rl64u(S.pv_head, ix);
         S.pv_r++; S.pv_n--;
     }
 }
@@ -680,7 +682,7 @@ __device__ static inline bool rep_seq_wait_verified(const EngDev &E, const RepSe
     return true;
 }
 
-__device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, const RepSeqCtx &X, RepSeqState &S, lds_u64 s_ao /*[16] LDS*/,
+__device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, const RepSeqCtx &X, RepSeqState &S,
                                             lds_u64 s_m, uint32_t bitmask, RepBox *mybox, uint64_t progress, const uint64_t *pre = nullptr)
 {
     RepLead *LS = A.LS;
@@ -695,9 +697,10 @@ __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, c
     if (!late) {
         /* (a) + (b) */
         uint64_t min_off = S.c_off;                                    /* the leader's own apply offset */
+        if (lane < size && !((bitmask >> lane) & 1u)) S.ao = S.c_off;
         for (uint32_t i = 0; i < size; i++) {
-            if (!((bitmask >> i) & 1u)) s_ao[i] = S.c_off;
-            if (apus_is_larger(S.end, L, min_off, s_ao[i])) min_off = s_ao[i];
+            const uint64_t ao_i = rl64u(S.ao, (int)i);
+            if (apus_is_larger(S.end, L, min_off, ao_i)) min_off = ao_i;
         }
         if (apus_end_distance(S.end, L, min_off) == 0) { rep_seq_fix_tail(E, S); min_off = S.tail; }      /* leave one entry, :2038-2041 */
         if (apus_is_larger(S.end, L, min_off, S.head) && !S.prev_head) {
@@ -706,17 +709,14 @@ __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, c
             if (rep_seq_round(E, X, S, LS, lane == 0 ? APUS_HDR : 0u, 1, R_SRC_CONTROL, 0, 3, min_off, 0)) {
                 S.prev_head = 1;
                 /* the move holds once every sampled server has applied what the LAST tick took it to have applied */
-                const uint32_t ix = 2 * ((S.pv_r + S.pv_n) % R_PV);
-                if (lane == 0) { S.pv[ix] = S.sample_slot; S.pv[ix + 1] = S.head; }
+                const uint32_t ix = (S.pv_r + S.pv_n) % R_PV;
+                if (lane == ix) { S.pv_need = S.sample_slot; S.pv_head = S.head; }
                 S.pv_n++;
             } else { S.head = head_before; if (lane == 0) { set_status(E, 1u << 1); st_sys(&A.H->full, ld_sys(&A.H->full) + 1); } }
         }
     }
     /* (c): what the servers will have applied when the timer's pass is over = the commit before <HEAD> */
-    for (uint32_t i = 0; i < size; i++) {
-        if (i == E.leader || !((bitmask >> i) & 1u)) s_ao[i] = c_before;
-        else if ((S.push_mask >> i) & 1u) s_ao[i] = c_before;
-    }
+    if (lane < size && (lane == E.leader || !((bitmask >> lane) & 1u) || ((S.push_mask >> lane) & 1u))) S.ao = c_before;
     S.sample_slot = cs_before;
     rep_seq_publish(LS, s_m, S, progress);
 }
@@ -737,14 +737,34 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
     S.prev_head = s_h[H_PREV_HEAD]; S.store_count = s_h[H_STORE_COUNT];
     S.c_off = s_h[H_COMMIT]; S.c_slot = s_h[H_N_COMMIT]; S.sample_slot = 0; S.t = 0; S.pass_seq = 0; S.g_seq = 0; S.tail_known = true; S.tail_round = 0;
     S.push_mask = A.push_mask; S.can_commit = rep_quorum(E, S.push_mask);
-    S.pv = APUS_LDS64(s_tr); S.head_safe = S.head; S.pv_r = 0; S.pv_n = 0;
+    S.pv_need = 0; S.pv_head = 0; S.head_safe = S.head; S.pv_r = 0; S.pv_n = 0;
+    S.ao = lane < APUS_DEV_MAX_SERVERS ? (uint64_t)s_h[H_APPLY_OFFSETS + lane] : 0ull;
     const RepSeqCtx X = {&A, s_m, mybox};
     const uint32_t bitmask = (uint32_t)s_h[H_CID_BITMASK];
-    if (lane < 16) s_ao[lane] = (lane < APUS_DEV_MAX_SERVERS) ? s_h[H_APPLY_OFFSETS + lane] : 0;
     uint64_t req_head = ld_sys(&H->slots_done), cmd_head = ld_sys(&H->cmd_head);
-    bool have_cmd = false, have_cmd2 = false;            /* the next host command, and the one behind it (fetched in the same PCIe round trip) */
+    /* The host's next commands: up to SIXTEEN per look at the command ring, held in one register -- lane l: granule l & 3 of command
+     * cq_base + (l >> 2) -- and taken from there (round 5 fetched two per look: one round trip through the mailbox's memory per RUN +
+     * PRUNE pair, 1.3 us of the ~10 us the sequencer spent per pair at three replicas).  cq_n of them are all there, cq_i are carried out. */
+    uint64_t cq = 0, cq_base = 0;
+    uint32_t cq_n = 0, cq_i = 0;
+    bool have_cmd = false;
     uint32_t cmd_op = 0; uint64_t cmd_after = 0, cmd_a = 0, cmd_b = 0;
-    uint32_t cmd2_op = 0; uint64_t cmd2_after = 0, cmd2_a = 0, cmd2_b = 0;
+    /* granules just loaded for commands `base` ...: how many commands in a row are complete */
+    auto cq_take = [&](uint64_t w, uint64_t base) {
+        if (cq_i < cq_n) return;                       /* (what is queued goes first; the words are asked for again when it is used up) */
+        unsigned long long m = __ballot(rep_gran_ok(w, base + (lane >> 2)));
+        m &= m >> 1; m &= m >> 2; m &= 0x1111111111111111ull;
+        const unsigned long long y = ~m & 0x1111111111111111ull;
+        cq = w; cq_base = base; cq_i = 0; cq_n = y ? (uint32_t)__builtin_ctzll(y) >> 2 : 16u;
+    };
+    /* the next command into the first register */
+    auto cq_front = [&]() {
+        if (have_cmd || cq_i >= cq_n) return;
+        const int l = (int)(4 * cq_i);
+        have_cmd = true; cq_i++;
+        cmd_op = (uint32_t)rl64u(cq, l); cmd_after = rep_extend(req_head, (uint32_t)rl64u(cq, l + 1));
+        cmd_a = (uint32_t)rl64u(cq, l + 2); cmd_b = (uint32_t)rl64u(cq, l + 3);
+    };
     uint64_t run_next = 0, run_end = 0;
     uint64_t idle = 0, budget = 0, dropped = 0;
     uint32_t exit_code = R_EXIT_STOP;
@@ -764,26 +784,12 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
     bool pf_on = false, rq_hot = false;
 #pragma unroll
     for (int wdw = 0; wdw < R_WIN; wdw++) pf_v[wdw] = 0;
-    auto take_peek = [&]() {
-        const unsigned long long okb = __ballot(lane < 8 && rep_gran_ok(pk_cg, pk_next + (lane >> 2)));
-        if (have_cmd || have_cmd2 || (okb & 0xFull) != 0xFull) return;
-        have_cmd = true;
-        cmd_op = (uint32_t)rl64u(pk_cg, 0); cmd_after = rep_extend(req_head, (uint32_t)rl64u(pk_cg, 1));
-        cmd_a = (uint32_t)rl64u(pk_cg, 2); cmd_b = (uint32_t)rl64u(pk_cg, 3);
-        have_cmd2 = (okb & 0xF0ull) == 0xF0ull;
-        if (have_cmd2) {
-            cmd2_op = (uint32_t)rl64u(pk_cg, 4); cmd2_after = rep_extend(req_head, (uint32_t)rl64u(pk_cg, 5));
-            cmd2_a = (uint32_t)rl64u(pk_cg, 6); cmd2_b = (uint32_t)rl64u(pk_cg, 7);
-        }
-    };
+    auto take_peek = [&]() { cq_take(pk_cg, pk_next); };
 
     /* the host command in the first register, once every request slot in front of it is taken: 0 not yet, 1 carried
      * out, 2 the run ends (STOP) */
     auto exec_cmd = [&]() -> int {
-        if (!have_cmd && have_cmd2) {                  /* (fetched with the command before it) */
-            have_cmd = true; have_cmd2 = false;
-            cmd_op = cmd2_op; cmd_after = cmd2_after; cmd_a = cmd2_a; cmd_b = cmd2_b;
-        }
+        cq_front();
         if (!have_cmd || cmd_after > req_head) return 0;
         if (cmd_op == R_OP_PRUNE && budget == 0) return 0;          /* (a tick may append a <HEAD> entry: room first) */
         have_cmd = false;
@@ -795,7 +801,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
         }
         cmd_head++;
         if (lane == 0) st_sys(&H->cmd_head, cmd_head);
-        if (cmd_op == R_OP_PRUNE) { const uint64_t tp0 = stats ? wall_clock64() : 0; rep_seq_prune(E, A, X, S, s_ao, s_m, bitmask, mybox, cmd_head + req_head, ap_have ? &ap_v : nullptr); ap_have = false; budget--; if (stats) st_prune += wall_clock64() - tp0; }
+        if (cmd_op == R_OP_PRUNE) { const uint64_t tp0 = stats ? wall_clock64() : 0; rep_seq_prune(E, A, X, S, s_m, bitmask, mybox, cmd_head + req_head, ap_have ? &ap_v : nullptr); ap_have = false; budget--; if (stats) st_prune += wall_clock64() - tp0; }
         else rep_seq_publish(LS, s_m, S, cmd_head + req_head);
         return 1;
     };
@@ -877,12 +883,10 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                 const uint64_t spf = E.round_prefix[rc + cut];
                 const uint32_t srf = E.round_first[rc + cut];
                 const uint32_t scg = E.round_change[rc + (cut ? cut - 1 : 0u)], cg0 = E.round_change[rc];      /* (one size all the way?) */
-                /* the next host commands, when this pass may end the run -- and only when NEITHER command register holds one: a
-                 * command fetched together with this RUN sits in the second register until the run is over */
-                if (!have_cmd && !have_cmd2 && run_end - rc <= avail) {
+                /* the next host commands, when this pass may end the run and none is queued */
+                if (!have_cmd && cq_i >= cq_n && run_end - rc <= avail) {
                     pk_pending = true; pk_next = cmd_head + 1;            /* (cmd_head is the RUN in progress) */
-                    pk_cg = 0;
-                    if (lane < 8) pk_cg = ld_sys(&RQ->cmd[(pk_next + (lane >> 2)) % RC_CAP].g[lane & 3]);
+                    pk_cg = ld_sys(&RQ->cmd[(pk_next + (lane >> 2)) % RC_CAP].g[lane & 3]);
                 }
                 /* ... and what the prune tick behind the run will want to know first: how far the followers have applied */
                 ap_v = (lane >= 1 && lane <= APUS_DEV_MAX_SERVERS && ((S.push_mask >> (lane - 1)) & 1u)) ? ld_sys(&mybox->applied_by[lane - 1]) : ~0ull;
@@ -1013,7 +1017,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
         st_pcie_n++;
         uint32_t v[R_WIN], ww = 0;
         uint64_t cg = 0, stopw = 0;
-        if (pf_on && pf_head == req_head && pf_cmd == cmd_head) {
+        if (pf_on && pf_head == req_head && pf_cmd == cmd_head + (uint64_t)have_cmd) {
 #pragma unroll
             for (int wdw = 0; wdw < R_WIN; wdw++) v[wdw] = pf_v[wdw];
             cg = pf_cg; stopw = pf_stop; ww = pf_ww;
@@ -1025,23 +1029,12 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
             const int nw = rq_hot ? R_WIN : 1;
 #pragma unroll
             for (int wdw = 0; wdw < R_WIN; wdw++) { if (wdw < nw) v[wdw] = ld_sys32(&RQ->ready_len[(req_head + (uint64_t)wdw * WAVE + lane) % RQ_CAP]); else v[wdw] = 0u; }   /* (0: no slot's tag) */
-            if (lane < 8) cg = ld_sys(&RQ->cmd[(cmd_head + (lane >> 2)) % RC_CAP].g[lane & 3]);
+            cg = ld_sys(&RQ->cmd[(cmd_head + (uint64_t)have_cmd + (lane >> 2)) % RC_CAP].g[lane & 3]);      /* (the commands behind the one in the first register) */
             stopw = ld_sys(&RQ->stop);                   /* (with the rings: a look at host memory would be the one PCIe round trip of the pass) */
+            pf_cmd = cmd_head + (uint64_t)have_cmd;
         }
         pf_on = false;
-        if (!have_cmd) {
-            const unsigned long long okb = __ballot(lane < 8 && rep_gran_ok(cg, cmd_head + (lane >> 2)));
-            if ((okb & 0xFull) == 0xFull) {
-                have_cmd = true;
-                cmd_op = (uint32_t)rl64u(cg, 0); cmd_after = rep_extend(req_head, (uint32_t)rl64u(cg, 1));
-                cmd_a = (uint32_t)rl64u(cg, 2); cmd_b = (uint32_t)rl64u(cg, 3);
-                have_cmd2 = (okb & 0xF0ull) == 0xF0ull;
-                if (have_cmd2) {
-                    cmd2_op = (uint32_t)rl64u(cg, 4); cmd2_after = rep_extend(req_head, (uint32_t)rl64u(cg, 5));
-                    cmd2_a = (uint32_t)rl64u(cg, 6); cmd2_b = (uint32_t)rl64u(cg, 7);
-                }
-            }
-        }
+        cq_take(cg, pf_cmd);
         if (stats) st_pcie += wall_clock64() - tq0;
         {
             const int x = exec_cmd();
@@ -1079,10 +1072,10 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                     pf_ww = ld_sys32(&RQ->ready_win[(nh / WAVE + lane) % (RQ_CAP / WAVE)]);
 #pragma unroll
                     for (int wdw = 0; wdw < R_WIN; wdw++) pf_v[wdw] = ld_sys32(&RQ->ready_len[(nh + (uint64_t)wdw * WAVE + lane) % RQ_CAP]);
-                    pf_cg = 0;
-                    if (lane < 8) pf_cg = ld_sys(&RQ->cmd[(cmd_head + (lane >> 2)) % RC_CAP].g[lane & 3]);
+                    pf_cmd = cmd_head + (uint64_t)have_cmd;
+                    pf_cg = ld_sys(&RQ->cmd[(pf_cmd + (lane >> 2)) % RC_CAP].g[lane & 3]);
                     pf_stop = ld_sys(&RQ->stop);
-                    pf_on = true; pf_head = nh; pf_cmd = cmd_head;
+                    pf_on = true; pf_head = nh;
                     rq_hot = true;
                 }
                 const uint64_t pn = S.pass_seq++;
@@ -1145,6 +1138,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
     }
     rep_seq_publish(LS, s_m, S, cmd_head + req_head);
     rep_seq_fix_tail(E, S);
+    if (lane < APUS_DEV_MAX_SERVERS) E.rep[E.leader].hdr[H_APPLY_OFFSETS + lane] = S.ao;
     if (lane == 0) {
         st_agent(&LS->seq_final, S.t);
         s_m[M_FINAL] = S.t;
@@ -1154,7 +1148,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
         uint64_t *mh = E.rep[E.leader].hdr;
         mh[H_END] = S.end; mh[H_TAIL] = S.tail; mh[H_LAST_IDX] = S.last_idx; mh[H_N_END] = S.n_end; mh[H_HEAD] = S.head;
         mh[H_PREV_HEAD] = S.prev_head; mh[H_STORE_COUNT] = S.store_count; mh[H_OLD_END] = S.end; mh[H_N_PERSIST] = S.n_end;
-        for (uint32_t i = 0; i < APUS_DEV_MAX_SERVERS; i++) mh[H_APPLY_OFFSETS + i] = s_ao[i];
+
         s_x[0] = exit_code; s_x[1] = S.t; s_x[2] = S.push_mask; s_x[3] = S.end; s_x[4] = S.n_end;
     }
 }
