@@ -1456,17 +1456,20 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, lds
         if (t_app < t_done) {
             uint64_t g1[R_SUB], g3[R_SUB], g4[R_SUB], g5[R_SUB], g6[R_SUB], g7[R_SUB];
             const uint32_t nsub = (uint32_t)min((uint64_t)R_SUB, (t_done - t_app + WAVE - 1) / WAVE);       /* (as many chunks as rounds are done) */
+            const bool want_lat = lat_n < R_LAT_CAP && !(A.dbg & 2048);         /* (the two time stamps only while latency samples are still being kept) */
 #pragma unroll
             for (int s = 0; s < R_SUB; s++) {
                 g1[s] = 0; g3[s] = 0; g4[s] = 0; g5[s] = 0; g6[s] = 0; g7[s] = 0;
                 if ((uint32_t)s < nsub) {
                     const uint64_t ix = (t_app + (uint64_t)s * WAVE + lane) % RS_CAP;
                     g1[s] = ld_agent(&LS->dn[DN_SLOT_END][ix]); g3[s] = ld_agent(&LS->dn[DN_HASH_LO][ix]); g4[s] = ld_agent(&LS->dn[DN_HASH_HI][ix]);
-                    g5[s] = ld_agent(&LS->dn[DN_NCLIENT][ix]); g6[s] = ld_agent(&LS->dn[DN_T_APPENDED][ix]); g7[s] = ld_agent(&LS->dn[DN_T_SEQUENCED][ix]);
+                    g5[s] = ld_agent(&LS->dn[DN_NCLIENT][ix]);
+                    if (want_lat) { g6[s] = ld_agent(&LS->dn[DN_T_APPENDED][ix]); g7[s] = ld_agent(&LS->dn[DN_T_SEQUENCED][ix]); }
                 }
             }
             const uint64_t t0 = t_app;
-            uint64_t nc_pass = 0;
+            uint64_t nc_pass = 0, h_lane = 0;                          /* (summed over the lanes ONCE per pass, not once per chunk: three scans per chunk were a third of the pass) */
+            uint32_t nc_lane = 0;
             const uint32_t now = (uint32_t)wall_clock64();             /* (once per pass: the latency samples' end) */
 #pragma unroll
             for (int s = 0; s < R_SUB; s++) {
@@ -1474,21 +1477,21 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, lds
                 const uint64_t k = t_app + lane;
                 const uint64_t slot_end = rep_extend(n_apply, (uint32_t)g1[s]);
                 const bool okk = k < t_done && rep_gran_ok(g1[s], k) && rep_gran_ok(g3[s], k) && rep_gran_ok(g4[s], k) && rep_gran_ok(g5[s], k)
-                                 && rep_gran_ok(g6[s], k) && rep_gran_ok(g7[s], k) && slot_end <= cs;
+                                 && (!want_lat || (rep_gran_ok(g6[s], k) && rep_gran_ok(g7[s], k))) && slot_end <= cs;
                 const unsigned long long bal = __ballot(okk);
                 const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
                 if (!p) break;
                 const bool mine = lane < p;
-                hash += wsum64(mine ? ((uint64_t)(uint32_t)g3[s] | (g4[s] << 32)) : 0ull);
-                nc_pass += wsum32(mine ? (uint32_t)g5[s] : 0u);
+                if (mine) { h_lane += (uint64_t)(uint32_t)g3[s] | (g4[s] << 32); nc_lane += (uint32_t)g5[s]; }
                 n_apply = rl64u(slot_end, (int)p - 1);
                 const uint32_t t_seq = (uint32_t)g7[s], t_apd = (uint32_t)g6[s];
-                if (mine && t_seq && lat_n + lane < R_LAT_CAP && !(A.dbg & 2048)) { LS->lat_ticks[lat_n + lane] = now - t_seq; LS->lat_app[lat_n + lane] = now - t_apd; }
-                lat_n = min(lat_n + p, R_LAT_CAP);
+                if (want_lat && mine && t_seq && lat_n + lane < R_LAT_CAP) { LS->lat_ticks[lat_n + lane] = now - t_seq; LS->lat_app[lat_n + lane] = now - t_apd; }
+                if (want_lat) lat_n = min(lat_n + p, R_LAT_CAP);
                 t_app += p;
                 progress = true;
             }
             if (progress) {
+                hash += wsum64(h_lane); nc_pass = wsum32(nc_lane);
                 ncl += nc_pass;
                 if (lane == 0) {
                     s_m[M_N_APPLY] = n_apply; s_m[M_T_RETIRED] = t_app;
@@ -2292,6 +2295,8 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
         if (cs > n_commit) { n_commit = cs; progress = true; }
         if (q_app < q_ret) {
             const uint64_t t0 = q_app;
+            uint64_t h_lane = 0;
+            uint32_t nc_lane = 0;
 #pragma unroll
             for (int s = 0; s < R_SUB; s++) {
                 if (q_app != t0 + (uint64_t)s * WAVE || (uint32_t)s >= nsub) break;
@@ -2303,8 +2308,7 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
                 const uint32_t p = (~bal) ? (uint32_t)__builtin_ctzll(~bal) : WAVE;
                 if (!p) break;
                 const bool mine = lane < p;
-                hash += wsum64(mine ? ((uint64_t)(uint32_t)f4[s] | (f5[s] << 32)) : 0ull);
-                ncl += wsum32(mine ? (((uint32_t)f3[s] >> 8) & 0xFF) : 0u);
+                if (mine) { h_lane += (uint64_t)(uint32_t)f4[s] | (f5[s] << 32); nc_lane += ((uint32_t)f3[s] >> 8) & 0xFF; }
                 /* poll_config_entries: a committed <HEAD> entry moves the head (dare_server.c:2164) */
                 const uint32_t hv = mine ? (uint32_t)f6[s] : 0xFFFFFFFFu;
                 const unsigned long long hb = __ballot(hv != 0xFFFFFFFFu);
@@ -2322,6 +2326,7 @@ __device__ static inline void rep_follow_apply(const EngDev &E, const RepArgs &A
                 q_app += p;
                 progress = true;
             }
+            if (q_app != t0) { hash += wsum64(h_lane); ncl += wsum32(nc_lane); }
             if (q_app != t0 && lane == 0) {
                 if (!has_consumer) { st_sys(&lbox->applied_by[me], n_apply); applied_pub = n_apply; }
                 st_sys(&lbox->seqdone_by[me], q_app);
