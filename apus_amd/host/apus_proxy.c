@@ -168,6 +168,13 @@ typedef struct {
     pthread_t thread;
     uint64_t applied_slot[APUS_MAX_SERVERS];   /* next apply-stream slot to hand to the upcalls */
     double prune_period_s;
+    /* group mode, a leader that lives but does not answer (a partition, a process that hangs): the leader's process writes a
+     * heartbeat word into the group directory from a thread of its own, a follower that sees none for hb_timeout_s starts the
+     * election although the leader's process exists (hb_receive_cb / the election timeout, dare_server.c:822-920, 1237-1250).
+     * Off (0) unless APUS_HB_TIMEOUT_MS is set: process liveness alone decides, as in rounds 3-5. */
+    double hb_timeout_s, hb_seen_t;
+    uint64_t hb_seen;
+    pthread_t hb_thread; int hb_running;
     /* drained batch kept between poll_tailq and write_remote_logs */
     apus_req_t *batch; uint8_t *batch_arena; uint32_t batch_n; uint64_t batch_bytes;
     FILE *log;
@@ -447,7 +454,7 @@ static int g_same(const g_stamp_t *a, const g_stamp_t *b) { return a->pid == b->
  * process -- the hello files themselves); 0 when it is there */
 static int g_have_from(smr_t *s, const char *name, uint32_t writer, size_t len, void *out)
 {
-    uint8_t tmp[sizeof(apus_ipc_replica_t) + 64];        /* (the largest file: a hello) */
+    uint8_t tmp[sizeof(apus_ipc_replica_t) + 64];        /* (the largest file: a vote request = 32 bytes + a hello) */
     g_stamp_t st;
     if (len > sizeof tmp || g_read(s, tmp, len, name, &st)) return -1;
     const int good = writer < s->capacity ? g_same(&st, &s->peer_stamp[writer]) : g_stamp_alive(&st);
@@ -469,6 +476,9 @@ static int g_wait_from(smr_t *s, const char *name, uint32_t writer, size_t len, 
 static int g_alive(smr_t *s, uint32_t i) { return g_stamp_alive(&s->peer_stamp[i]); }
 
 typedef struct { apus_ipc_replica_t ipc; } g_hello_t;
+/* a vote request: the server's last entry {term, idx, entry slots, end} and the handles of its replica as it stands behind the
+ * election's fence (the harness reads the first 32 bytes: tests/_cluster.py) */
+typedef struct { uint64_t last[4]; apus_ipc_replica_t ipc; } g_parked_t;
 
 /* RC_SYN / SYNACK with server i: map the replica its LIVE process exports (dropping the mapping of a former holder of the
  * slot whose process is gone) */
@@ -529,6 +539,7 @@ static int group_start_run(smr_t *s)
         /* what "applied" means on this server from the first round on: carried out by its application (the first
          * term used to publish the device's apply count alone) */
         apus_gpu_rep_follower_replayed(s->eng, s->idx, s->replayed);
+        s->hb_seen_t = 0; s->hb_seen = 0;                    /* (another leader's heartbeat from here on) */
         if (apus_gpu_set_leader(s->eng, s->leader) || apus_gpu_rep_start(s->eng, 24u * 3600u * 1000u, 2000, na, nf)) return -1;
         snprintf(name, sizeof name, "ready_%llu_%u", (unsigned long long)s->seq, s->idx);
         return g_write(s, "1", 1, name);
@@ -602,7 +613,35 @@ static void follower_upcalls(smr_t *s)
     replay_upto(s, pr[0], 0);
 }
 
-/* the leader's process is gone: park, tell the others where this log ends, the most up-to-date survivor wins the next term */
+/* the leader's heartbeat: a word in the group directory, from a thread of its own (the DARE thread blocks for seconds in a JOIN) */
+static void *hb_main(void *arg)
+{
+    smr_t *s = arg;
+    uint64_t n = 0;
+    char name[64];
+    snprintf(name, sizeof name, "hb_%u", s->idx);
+    while (!s->terminate && s->hb_running) {
+        if (s->leader == s->idx && !s->failed) { n++; g_write(s, &n, sizeof n, name); }
+        struct timespec ts = {0, 20000000}; nanosleep(&ts, NULL);
+    }
+    return NULL;
+}
+/* does the leader answer?  Its process exists -- and, when a heartbeat timeout is configured, its heartbeat word has moved within it */
+static int leader_answers(smr_t *s)
+{
+    if (!g_alive(s, s->leader)) return 0;
+    if (s->hb_timeout_s <= 0) return 1;
+    char name[64];
+    uint64_t n = 0;
+    snprintf(name, sizeof name, "hb_%u", s->leader);
+    const double t = now_s();
+    if (s->hb_seen_t == 0) s->hb_seen_t = t;                 /* (the first look at this leader: the timeout starts here) */
+    if (!g_have_from(s, name, s->leader, sizeof n, &n) && n != s->hb_seen) { s->hb_seen = n; s->hb_seen_t = t; }
+    return t - s->hb_seen_t <= s->hb_timeout_s;
+}
+
+/* the leader's process is gone (or does not answer): park, LEAVE what it has mapped, tell the others where this log ends, the most
+ * up-to-date survivor wins the next term */
 static int group_failover(smr_t *s)
 {
     char name[64];
@@ -614,28 +653,50 @@ static int group_failover(smr_t *s)
     s->alive_mask &= ~(1u << old_leader);
     for (uint32_t i = 0; i < s->capacity; i++) if (i != s->idx && ((s->alive_mask >> i) & 1u) && !g_alive(s, i)) s->alive_mask &= ~(1u << i);
     const uint64_t term = s->term + 2;
-    /* the vote request: this server's last entry (start_election, dare_server.c:1264-1322) */
-    uint64_t mine[4] = {0}, theirs[APUS_MAX_SERVERS][4];
-    if (apus_gpu_last_entry(s->eng, s->idx, mine)) return -1;
+    /* the vote request: this server's last entry (start_election, dare_server.c:1264-1322) -- and, round 6, the RECEIVER'S FENCE
+     * of every election, not only of one that follows a death (rc_revoke_log_access, dare_ibv_rc.c:2156-2243: a voter resets the
+     * QPs of the leader it leaves, the old leader's WRITEs bounce): this server LEAVES the log ring and the mailbox the old
+     * leader has mapped (apus_gpu_fence_replica: fresh allocations, device copies) before it takes part in the new term, and
+     * hands the new handles out with its vote request; every member of the new term maps them (apus_gpu_remap_fenced) before
+     * anything is voted on, adjusted or replicated.  An old leader that is not dead -- stopped, partitioned, slow -- keeps the
+     * old mappings: whatever its resident kernel still pushes lands in memory nobody reads.  (APUS_GROUP_NO_RING_FENCE: the
+     * control experiment.) */
+    static g_parked_t mine, theirs[APUS_MAX_SERVERS];
+    memset(&mine, 0, sizeof mine);
+    if (apus_gpu_last_entry(s->eng, s->idx, mine.last)) return -1;
+    if (!getenv("APUS_GROUP_NO_RING_FENCE")) {
+        if (apus_gpu_fence_replica(s->eng, s->idx, &mine.ipc)) { fprintf(stderr, "[apus] server %u: cannot leave the old leader's ring (fence)\n", s->idx); return -1; }
+        fprintf(s->log, "[T%lu] election of term %llu: left the log ring and the mailbox server %u has mapped (fence %u)\n", (unsigned long)s->term, (unsigned long long)term, old_leader, mine.ipc.fences);
+        fflush(s->log);
+        {   /* (a machine that maps this server from now on -- a joiner -- must find the buffers it has moved to) */
+            g_hello_t me; me.ipc = mine.ipc;
+            snprintf(name, sizeof name, "replica_%u.ipc", s->idx);
+            g_write(s, &me, sizeof me, name);
+        }
+    } else if (apus_gpu_export_replica(s->eng, s->idx, &mine.ipc)) return -1;
     snprintf(name, sizeof name, "parked_%llu_%u", (unsigned long long)term, s->idx);
-    g_write(s, mine, sizeof mine, name);
+    g_write(s, &mine, sizeof mine, name);
     memset(theirs, 0, sizeof theirs);
-    memcpy(theirs[s->idx], mine, sizeof mine);
+    theirs[s->idx] = mine;
     /* nothing of the old term may still be running on a survivor when the votes are cast through the mappings: every live
      * member's word is waited for (a process that dies meanwhile, or never answers, is cut off) */
     for (uint32_t i = 0; i < s->capacity; i++) {
         if (i == s->idx || !((s->alive_mask >> i) & 1u) || !((s->bitmask >> i) & 1u)) continue;
         snprintf(name, sizeof name, "parked_%llu_%u", (unsigned long long)term, i);
-        if (g_wait_from(s, name, i, sizeof theirs[i], theirs[i], 20.0)) s->alive_mask &= ~(1u << i);
+        if (g_wait_from(s, name, i, sizeof theirs[i], &theirs[i], 20.0)) { s->alive_mask &= ~(1u << i); continue; }
+        if (((s->mapped_mask >> i) & 1u) && apus_gpu_remap_fenced(s->eng, &theirs[i].ipc)) {
+            fprintf(stderr, "[apus] server %u: cannot map the ring server %u moved to\n", s->idx, i);
+            s->alive_mask &= ~(1u << i);
+        }
     }
     uint32_t winner = s->capacity;
     for (uint32_t i = 0; i < s->capacity; i++) {
         if (!((s->alive_mask >> i) & 1u) || !((s->bitmask >> i) & 1u)) continue;
-        if (winner >= s->capacity || theirs[i][0] > theirs[winner][0] || (theirs[i][0] == theirs[winner][0] && theirs[i][1] > theirs[winner][1])) winner = i;
+        if (winner >= s->capacity || theirs[i].last[0] > theirs[winner].last[0] || (theirs[i].last[0] == theirs[winner].last[0] && theirs[i].last[1] > theirs[winner].last[1])) winner = i;
     }
     if (winner >= s->capacity) return -1;
     fprintf(s->log, "[T%lu] election of term %llu: server %u has the newest log (term %llu, idx %llu)\n", (unsigned long)s->term, (unsigned long long)term, winner,
-            (unsigned long long)theirs[winner][0], (unsigned long long)theirs[winner][1]);
+            (unsigned long long)theirs[winner].last[0], (unsigned long long)theirs[winner].last[1]);
     if (winner == s->idx) {
         uint64_t out[8] = {0};
         const uint32_t live = s->alive_mask & s->bitmask;
@@ -816,6 +877,21 @@ static void group_loop(smr_t *s)
             if (!s->failed && t - last_prune >= s->prune_period_s) { apus_gpu_rep_prune(s->eng); last_prune = t; }
             if (!s->failed && t - last_look > 0.01) {     /* the heartbeat timer: are the followers there?  does a machine want to join? */
                 last_look = t;
+                {   /* somebody else leads a newer term (this process was stopped or cut off, the others elected): step down.  The
+                     * followers have LEFT what this server has mapped (the receiver's fence): whatever its kernel pushed meanwhile
+                     * went nowhere; the hooks are inert from here on, like a removed server's (update_cid, dare_server.c:2216) */
+                    char cname[64];
+                    g_cfg_t c;
+                    snprintf(cname, sizeof cname, "cfg_%llu", (unsigned long long)(s->seq + 1));
+                    if (!g_have_from(s, cname, s->capacity, sizeof c, &c) && c.leader != s->idx && c.term > s->term) {
+                        fprintf(s->log, "[T%lu] deposed: server %u leads term %llu -- stepping down\n", (unsigned long)s->term, c.leader, (unsigned long long)c.term);
+                        fflush(s->log);
+                        s->serving = 0;
+                        apus_gpu_rep_park(s->eng);
+                        s->failed = 1; s->leader = s->capacity;
+                        continue;
+                    }
+                }
                 uint32_t dead = 0;
                 for (uint32_t i = 0; i < s->capacity; i++)
                     if (i != s->idx && ((s->alive_mask >> i) & 1u) && ((s->bitmask >> i) & 1u) && !g_alive(s, i)) dead |= 1u << i;
@@ -835,8 +911,9 @@ static void group_loop(smr_t *s)
         const double t = now_s();
         if (t - last_look > 0.01) {                       /* the heartbeat timer (hb_period, nodes.local.cfg): is the leader there? */
             last_look = t;
-            if (!g_alive(s, s->leader)) {
-                fprintf(s->log, "[T%lu] the leader p%u is gone\n", (unsigned long)s->term, s->leader);
+            if (!leader_answers(s)) {
+                fprintf(s->log, "[T%lu] the leader p%u is gone%s\n", (unsigned long)s->term, s->leader, g_alive(s, s->leader) ? " (its process exists: no heartbeat)" : "");
+                fflush(s->log);
                 if (group_failover(s)) { fprintf(stderr, "[apus] server %u: fail-over failed, the hooks are inert from here on\n", s->idx); s->failed = 1; s->leader = s->capacity; break; }
             } else {
                 const int x = follower_next_run(s);
@@ -968,7 +1045,12 @@ void *dare_server_init(void *arg)
         s->running = 1;
         __sync_synchronize();
         s->ready = 1;
+        {   const char *hb = getenv("APUS_HB_TIMEOUT_MS");
+            s->hb_timeout_s = hb ? atof(hb) * 1e-3 : 0.0;
+            s->hb_running = 1;
+            if (pthread_create(&s->hb_thread, NULL, hb_main, s)) s->hb_running = 0; }
         group_loop(s);
+        if (s->hb_running) { s->hb_running = 0; pthread_join(s->hb_thread, NULL); }
         /* shutdown: the leader drains and parks everybody; a follower waits for its workgroups (or asks them to leave) */
         if (s->leader == s->idx) { apus_gpu_rep_drain(s->eng, 5000); leader_upcalls(*s->dev_hr); s->dev_hr = NULL; apus_gpu_rep_park(s->eng); }
         else if (s->leader < s->capacity) { apus_gpu_rep_follower_stop(s->eng, s->idx); apus_gpu_rep_park(s->eng); follower_upcalls(s); }
