@@ -534,13 +534,15 @@ extern "C" int apus_gpu_rep_box_words(apus_engine_t *e, uint32_t replica, uint32
  * ones).  Every mapping another process holds of the old ones, a deposed leader's first of all, leads to memory nobody
  * reads any more; its kernel may go on storing for as long as it likes.  `out` = the replica's handles with the two new
  * buffers (the other six unchanged): the members of the new term map them with apus_gpu_remap_fenced.  The old
- * allocations stay allocated (a stale writer must hit memory that exists); from the fifth fence on the oldest pair is
- * reused -- a leader deposed four terms ago that still stores is outside the failure model.
+ * allocations stay allocated (a stale writer must hit memory that exists); from the ninth fence on the oldest pair is
+ * reused -- a leader deposed EIGHT terms ago whose kernel still stores would write into the live ring again: outside the failure
+ * model, and said so in include/apus_gpu.h (a deposed leader's process steps down when it sees a newer term's announcement, its
+ * kernel parks within peer_ms; eight elections take seconds).
  * The buffers peers write only from control-plane launches (control block, directory, apply stream: log adjustment, JOIN)
  * stay where they are: those launches sit behind the sender's term check (k_fence_check).
  * Not while a resident kernel or a batch is open; graphs captured before the fence hold the old pointers (peer-mapped groups
  * capture none). */
-#define APUS_FENCE_KEEP 4u
+#define APUS_FENCE_KEEP 8u
 extern "C" int apus_gpu_fence_replica(apus_engine_t *e, uint32_t replica, apus_ipc_replica_t *out)
 {
     if (!e || replica >= e->cfg.group_size) return APUS_E_ARG;
@@ -2862,6 +2864,9 @@ extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uin
         }
         uint32_t run = 1;
         while (run < BLK && g + run < n && reqs[g + run].len <= R_INLINE) run++;
+        /* (a reserve that has to wait for the ring: the block before's publish words leave first -- the sequencer takes slots in
+         *  order, words that sat in the write-combining buffers meanwhile would stall every other producer) */
+        if (words_pending && e->rq_bar && __atomic_load_n(&e->r_slot_tail, __ATOMIC_RELAXED) + run - e->rh->slots_done > R_SLOTS_INFLIGHT) { __builtin_ia32_sfence(); words_pending = false; }
         uint64_t s0;
         int rc = rep_reserve_inline(e, run, &s0);
         if (rc) { if (words_pending && e->rq_bar) __builtin_ia32_sfence(); return rc; }

@@ -58,6 +58,7 @@ typedef struct {
 } subq_t;
 
 static subq_t g_q;
+static volatile int g_admission_closed;          /* the leader is between two runs (leader_pause): no request is admitted */
 static pthread_once_t g_q_once = PTHREAD_ONCE_INIT;
 
 extern pthread_spinlock_t tailq_lock;          /* message.h:22 -- defined below, with the reference's queue */
@@ -730,18 +731,28 @@ static int group_failover(smr_t *s)
     return rc;
 }
 
-/* ---- the leader changes the configuration between two runs: the application's threads wait at the admission lock ---- */
+/* ---- the leader changes the configuration between two runs: admission is CLOSED meanwhile -- a flag the application's threads
+ *      look at under the admission lock and wait for outside it (round 5 held the spin lock itself across the drain, the
+ *      mapping of a joiner and the start of the next run: seconds of every application thread spinning at 100 %).
+ *      What was reserved before the flag went up is published by its own thread and drained with the run; a run that does
+ *      not drain is a failure of this server (slots reserved and never published would leave their callers waiting). ---- */
 static void leader_pause(smr_t *s)
 {
     pthread_spin_lock(&g_q.lock);
-    if (apus_gpu_rep_drain(s->eng, 5000)) fprintf(stderr, "[apus] leader %u: the run did not drain before the reconfiguration\n", s->idx);
+    g_admission_closed = 1;
+    pthread_spin_unlock(&g_q.lock);
+    if (apus_gpu_rep_drain(s->eng, 5000)) {
+        fprintf(stderr, "[apus] leader %u: the run did not drain before the reconfiguration -- the hooks are inert from here on\n", s->idx);
+        s->failed = 1;
+    }
     leader_upcalls(*s->dev_hr);
     apus_gpu_rep_park(s->eng);
 }
 static int leader_resume(smr_t *s, uint32_t kind)
 {
     int rc = apus_gpu_sync(s->eng) || g_announce(s, kind) || group_start_run(s);
-    pthread_spin_unlock(&g_q.lock);
+    __sync_synchronize();
+    g_admission_closed = 0;
     return rc;
 }
 
@@ -1331,8 +1342,8 @@ static void leader_handle_submit_req(uint8_t type, ssize_t data_size, void *buf,
     const int replica = g_smr.live_replica;
     for (;;) {
         pthread_spin_lock(&g_q.lock);
-        if (replica || (g_q.n < Q_CAP && g_q.arena_used + (uint64_t)data_size + 16 <= Q_ARENA)) break;
-        pthread_spin_unlock(&g_q.lock);              /* queue full: wait for the DARE thread to drain */
+        if (!g_admission_closed && (replica || (g_q.n < Q_CAP && g_q.arena_used + (uint64_t)data_size + 16 <= Q_ARENA))) break;
+        pthread_spin_unlock(&g_q.lock);              /* queue full, or the leader is between two runs (leader_pause): wait OUTSIDE the lock */
         if (g_smr.failed || g_smr.terminate || g_smr.ready < 0) return;
         sched_yield();
     }

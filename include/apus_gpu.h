@@ -186,8 +186,12 @@ int  apus_gpu_unmap_peers(apus_engine_t *e);
  * the old leader's QPs, its WRITEs bounce).  A mapped buffer cannot be taken back, but it can be left: the hosted replica
  * moves the two buffers peers store into during a run -- log ring and mailbox -- to fresh allocations (device copies);
  * whoever still holds the old mappings stores into memory nobody reads.  out (may be NULL) = the handles with the two new
- * buffers, fences + 1.  A server calls it when it adopts a newer term (apus_amd/peers.py: elect), the members of the new
- * term then call apus_gpu_remap_fenced with its handles (a no-op for a replica whose `fences` they already know).
+ * buffers, fences + 1.  A server calls it when it adopts a newer term (apus_amd/peers.py: elect; apus_amd/host/apus_proxy.c:
+ * group_failover -- at EVERY election), the members of the new term then call apus_gpu_remap_fenced with its handles (a no-op
+ * for a replica whose `fences` they already know).  BOUND: the buffers a replica has left stay allocated -- a stale writer
+ * hits memory that exists -- and the oldest pair is taken into use again at the ninth fence: a leader deposed eight terms ago
+ * whose kernel is STILL storing is outside the failure model (its process steps down at the first newer announcement it sees
+ * and parks its kernel).
  * APUS_E_STATE while a resident kernel or a batch is open, and for an engine that has captured graphs. */
 int  apus_gpu_fence_replica(apus_engine_t *e, uint32_t replica, apus_ipc_replica_t *out);
 int  apus_gpu_remap_fenced(apus_engine_t *e, const apus_ipc_replica_t *in);
