@@ -871,9 +871,7 @@ static int flush_batch(apus_engine *e)
          * per wavefront as still fit (more wavefronts in flight for a small launch). */
         auto grouped_blocks = [](const CallArgs &a, uint32_t gd) { return a.GP > 1 ? (a.R + APUS_GP * gd - 1) / (APUS_GP * gd) : a.R * a.SP; };
         auto svc_of = [](const apus_engine::BatchSeg &g) { return g.blocks - 2 - call_append_blocks(g.a); };
-        /* (with APUS_F_NO_FUSED_ACKS no segment is sequenced ahead: every one waits for its ACK scan, the
-         * segments run one after the other and the order of the grid follows them) */
-        const bool fit_ok = !e->p_running && e->step_slots > 0 && !(e->d.flags & 1u);
+        const bool fit_ok = !e->p_running && e->step_slots > 0;
         uint32_t fit_app = 0, fit_svc = 0, consumed = 0, seg_svc[APUS_STEP_SEGS];
         apus_engine::BatchSeg split_rest;
         bool have_rest = false;

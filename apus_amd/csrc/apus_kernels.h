@@ -284,7 +284,6 @@ __device__ static inline void seq_in_step(const EngDev &E, const uint64_t *lh, c
     const uint64_t L = E.log_len;
     const uint64_t e_pre = lh[H_END], n_pre = lh[H_N_END];
     fuse_mask = 0;
-    if (!(E.flags & 1u))            /* APUS_F_NO_FUSED_ACKS: every ACK goes through the reply byte, the ACK word and the scan */
     for (uint32_t m = push_mask; m; m &= m - 1)
         if (fw[__builtin_ctz(m)][3] == n_pre && e_pre != L) fuse_mask |= 1u << __builtin_ctz(m);
     const uint32_t size = E.group_size, size_mask = (1u << size) - 1;

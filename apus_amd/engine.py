@@ -47,7 +47,7 @@ class Engine:
             cfg.local_ids[k] = i
         cfg.log_len = log_len
         cfg.device = device
-        cfg.flags = flags          # include/apus_gpu.h APUS_F_*: 1 = no fused ACKs (per-entry ACK words + quorum scan), 2 = term fence, 4 = strict reference quirks
+        cfg.flags = flags          # include/apus_gpu.h APUS_F_*: 2 = term fence, 4 = strict reference quirks (the parity harness's diagnostic)
         cfg.stream = stream
         h = C.c_void_p()
         rc = self.L.apus_gpu_create(C.byref(cfg), C.byref(h))

@@ -37,8 +37,8 @@ HBM_COPY_CEILING_GBS = 6290.0   # the measured-copy ceiling SURVEY.md 8(d) asks 
 XGMI_LINK_GBS = 153.0        # one xGMI link (7 per GPU, point to point)
 
 
-PMC_FILE = "r03_pmc_traffic.json"            # k_step (apus_device.h + apus_kernels.h: unchanged since round 3's passes)
-REP_PMC_FILE = "r05_replica_pmc_traffic.json"  # k_replica, one entry per configuration of the line (round 5's passes)
+PMC_FILE = "r06_pmc_traffic.json"            # k_step (apus_device.h + apus_kernels.h: round 6's passes -- apus_device.h gained two words)
+REP_PMC_FILE = "r06_replica_pmc_traffic.json"  # k_replica, one entry per configuration of the line (round 6's passes)
 
 
 def replica_source_hash():
@@ -341,47 +341,6 @@ def cpu_baseline(args, seconds=12.0):
     return out
 
 
-def measure_ack_path(args, tr, n_rep):
-    """The same step with APUS_F_NO_FUSED_ACKS: per-entry ACK words written by the followers'
-    persist pass, commit decided by the popcount / ballot scan (the path a group that spans GPUs
-    must take).  Same verification as the main measurement."""
-    import torch
-    from apus_amd.engine import Engine
-    eng = Engine(n_rep, tr.log_len, device=0, flags=1)
-    try:
-        eng.stage_trace(tr)
-        eng.elect(0)
-        calls = step_calls(tr, eng)
-        issue(eng, calls)
-        eng.sync(); eng.check_status()
-        eng.capture_begin(); issue(eng, calls); gid = eng.capture_end()
-        for _ in range(args.warmup):
-            eng.graph_launch(gid)
-        eng.sync(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.graph_launch(gid)
-        eng.sync(); torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        eng.check_status()
-        total = (1 + args.warmup + args.steps) * len(tr.reqs)
-        for r in range(n_rep):
-            o = eng.offsets(r)
-            assert o["commit"] == o["end"] == o["apply"], f"ack path: replica {r} not caught up: {o}"
-        assert eng.counters(0)["highest_rec"] == total
-        eng.set_timing(True)
-        for _ in range(args.steps):
-            issue(eng, calls)
-        eng.sync()
-        k_ms, k_launches = eng.kernel_time(0)
-        eng.set_timing(False)
-        return {"value": len(tr.reqs) * args.steps / dt, "unit": "entries/s", "ms_per_step": dt / args.steps * 1e3,
-                "kernel": "k_step" if BATCH else "k_call", "avg_launch_us": k_ms * 1e3 / max(k_launches, 1), "launches": k_launches,
-                "note": "APUS_F_NO_FUSED_ACKS: follower persist + reply byte + ACK word per entry, quorum by popcount/ballot scan"}
-    finally:
-        eng.close()
-
-
 def _rep_step_cmds(tr, eng):
     out, ev, i = [], tr.events, 0
     while i < len(ev):
@@ -498,7 +457,7 @@ def measure_replica_kernels(args, tr, n_rep, steps=None, hostfed=True, regions_n
         if hostfed:
             blk = np.ascontiguousarray(tr.reqs[16:16 + 4096])
             hf = {}
-            for nt in (1, 2, 4):
+            for nt in (1, 2, 4, 8):
                 eng.rep_start(idle_ms=5000, peer_ms=1000)
                 hr0 = eng.rep_highest_rec()
                 n, sec = eng.rep_feed(blk, tr.arena, nt, 0.4, prune_every_reqs=(8 << 20) // (64 + args.payload))
@@ -955,13 +914,6 @@ def bench_single(args):
             out["other_configs"] = measure_other_configs(args)
         except Exception as exc:
             print(f"[bench] other configurations failed: {exc!r}", file=sys.stderr)
-    if args.ack_path:
-        # frozen since round 5: the forced per-entry ACK words of the call-per-pass plane; the replica kernels ARE the
-        # unfused data plane now.  Opt-in, never in the default line
-        try:
-            out["ack_aggregation_path"] = measure_ack_path(args, tr, n_rep)
-        except Exception as exc:
-            print(f"[bench] ACK-aggregation path measurement failed: {exc!r}", file=sys.stderr)
     if not args.no_other:
         try:
             out["join_catch_up"] = measure_join(args)
@@ -1445,8 +1397,7 @@ def main():
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--no-ack-path", action="store_true", help="(accepted for old scripts; the ACK-word path is opt-in now)")
-    ap.add_argument("--ack-path", action="store_true", help="also measure the frozen APUS_F_NO_FUSED_ACKS mode of the call-per-pass plane")
+    ap.add_argument("--no-ack-path", action="store_true", help="(accepted for old scripts; the ACK-word mode of the call-per-pass plane is retired)")
     ap.add_argument("--no-replica", action="store_true", help="skip the replica-kernel measurements")
     ap.add_argument("--no-other", action="store_true", help="skip configs[2] / [3] / [4] (extra figures)")
     ap.add_argument("--no-configs0", action="store_true", help="skip the reference-as-is redis baseline (configs[0])")

@@ -105,12 +105,8 @@ typedef struct {
 } apus_cfg_t;
 
 /* apus_cfg_t.flags */
-/* Followers never persist + ACK as part of the leader's push: every entry goes the way it has to
- * go between GPUs -- follower persist_new_entries + rc_send_entries_reply write the reply byte and
- * the per-entry ACK word, the leader's scan decides the commit with popcount / wave ballot
- * (update_remote_logs, src/dare/dare_ibv_rc.c:1725-1758).  Results are identical; only the
- * schedule inside a call differs (bench.py reports this path as `ack_aggregation_path`). */
-#define APUS_F_NO_FUSED_ACKS 1u
+/* (bit 1u, APUS_F_NO_FUSED_ACKS of rounds 1-5 -- the call-per-pass plane with every ACK forced through reply byte, ACK word and scan --
+ * is retired: the replica kernels (apus_gpu_rep_*) ARE the data plane whose followers acknowledge for themselves.) */
 /* The term fence in front of every launch that stores into followers (k_fence_check): a follower whose
  * control block shows a SID of a NEWER term than the leader's -- it voted for, or heard from, a leader
  * driven by another engine -- fences this leader off: APUS_ST_TERM_FENCE is raised and the launches behind

@@ -1,4 +1,4 @@
-"""The bench line's contract (CPU): the committed line of the round's build (profiles/r05_bench_line.json, written by
+"""The bench line's contract (CPU): the committed line of the round's build (profiles/r06_bench_line.json, written by
 `python bench.py --gpus 1 --steps 20 --warmup 5` on one MI355X right after the PMC passes of the same build) carries every key the
 driver and the judge read, the headline is the replica kernels' figure and is consistent with its own parts, and EVERY
 configuration in it has a counter-backed roofline."""
@@ -6,7 +6,7 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = "r05_bench_line.json"
+LINE = "r06_bench_line.json"
 
 
 def _line():
@@ -49,7 +49,9 @@ def test_committed_bench_line_has_the_contract_keys():
     assert "fused_step_path" in d and d["fused_step_path"]["roofline"]["kernel"] == "k_step"
     # no dead fields (round 4's busy_us = 0.0 / launches_per_step = 0)
     assert "launches_per_step" not in d["config"] and "busy_us" not in json.dumps(d["replica_kernels"]["device_resident"])
-    assert "ack_aggregation_path" not in d                      # frozen, opt-in
+    assert "ack_aggregation_path" not in d                      # retired (round 6)
+    # "verified" means bit-exact: the timed run itself was replayed by the oracle and compared, outside the timed regions
+    assert d["replica_kernels"]["device_resident"]["bit_exact_vs_oracle"] is True
 
 
 def test_every_configuration_of_the_line_has_a_counter_backed_roofline():

@@ -243,22 +243,6 @@ def test_exact_fit_wrap_restarts_index(eng_factory, mode):
     assert eng.counters(0)["last_idx"] < 1024
 
 
-@pytest.mark.parametrize("batch", [False, True])
-def test_ack_aggregation_path_matches_oracle(batch):
-    """APUS_F_NO_FUSED_ACKS: no follower persists + ACKs with the leader's push; every entry goes
-    through the reply byte, the per-entry ACK word and the popcount / ballot scan -- the path a
-    group that spans GPUs has to take.  Same results, bit for bit (BASELINE configs[1] shape,
-    reduced size, and a small ring with wraps)."""
-    from apus_amd.engine import Engine
-    from tests.parity import lockstep
-    for tr in (T.config_c2(n_send=1 << 15, log_len=1 << 22), T.steady_trace(5, 3000, 100, 8, 32, log_len=1 << 16)):
-        eng = Engine(tr.group_size, tr.log_len, flags=1)
-        try:
-            lockstep(tr, eng, check_at=("QUIESCE",), batch=batch)
-        finally:
-            eng.close()
-
-
 def test_known_deviation_uncommitted_apply_at_wrap(eng_factory):
     """The one place where the engine does NOT follow the reference, shown with its bound.
 

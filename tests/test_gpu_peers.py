@@ -101,9 +101,6 @@ def test_peer_mapped_leader_process_fails_over():
     assert [r["led"] for r in res] == [1, 1, 0, 0, 0]
 
 
-def test_peer_mapped_ack_aggregation_path():
-    """per-entry ACK words + quorum scan (APUS_F_NO_FUSED_ACKS) across processes"""
-    run_group(3, "steady3", flags=1)
 
 
 def test_peer_mapped_two_failovers_truncate_a_divergent_log():
