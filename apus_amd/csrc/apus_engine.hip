@@ -3039,6 +3039,7 @@ extern "C" int apus_gpu_rep_role_stats(apus_engine_t *e, uint64_t out[20][8])
     if (e->rl) HIPCHK(hipMemcpy(out, e->rl->stat, sizeof(uint64_t) * 3 * 8, hipMemcpyDeviceToHost));
     if (e->rl) HIPCHK(hipMemcpy(out[15], e->rl->stat[3], sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
     if (e->rl) HIPCHK(hipMemcpy(out[17], e->rl->stat[4], sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
+    if (e->rl) HIPCHK(hipMemcpy(out[18], e->rl->stat[5], sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));       /* the sequencer's pass / prune tick by phase (APUS_REP_DBG & 512) */
     int k = 0;
     for (uint32_t m = e->r_follow_mask; m && k < 6; m &= m - 1, k++) {
         RepFollow *fs = e->rfs[__builtin_ctz(m)];

@@ -538,6 +538,8 @@ struct RepSeqState {                    /* the sequencer's registers: the leader
      * head as it stands with the verified moves only: what protects the ring (rep_refuse) until the rest is verified. */
     uint64_t pv_need, pv_head;
     uint64_t ao;                        /* lane i: ctrl_data->apply_offsets[i], what the last tick sampled for server i */
+    uint64_t st_pr[4];                  /* diagnostics (APUS_REP_DBG & 512): prune ticks, and their time by phase */
+    bool stats;
     uint64_t head_safe;
     uint32_t pv_r, pv_n;
     uint64_t tail_round;                /* staged round whose last entry is the tail (tail worked out when somebody asks) */
@@ -682,6 +684,37 @@ __device__ static inline bool rep_seq_wait_verified(const EngDev &E, const RepSe
     return true;
 }
 
+/* The <HEAD> entry of a prune tick in closed form: 64 bytes at the log's end, no wrap, no exact fit, room in front of both heads
+ * -- every tick but the one per lap whose entry meets len.  What rep_seq_round does for such a round, without the wave-scan
+ * placement and its two kilobytes of code: the kernel is 114 KB against an instruction cache of 64 KB per two compute units,
+ * and a tick runs once per 1024 rounds -- every line of code it touches is fetched from memory again (round 6: the tick's
+ * <HEAD> round was 3.6 of its 4.7 us at three replicas).  False: not such a round, nothing done. */
+__device__ static inline bool rep_seq_head_plain(const EngDev &E, RepSeqState &S, RepLead *LS, uint64_t new_head)
+{
+    const uint64_t L = E.log_len, e0 = S.end;
+    if (e0 == L || e0 + APUS_HDR >= L) return false;
+    const uint64_t used = e0 >= S.head ? e0 - S.head : L - (S.head - e0);
+    const uint64_t used_s = e0 >= S.head_safe ? e0 - S.head_safe : L - (S.head_safe - e0);
+    if (e0 == S.head || APUS_HDR > L - used) return false;
+    if (S.pv_n && (e0 == S.head_safe || APUS_HDR > L - used_s)) return false;          /* (the general path waits for the verification) */
+    const uint32_t lane = lane_id();
+    uint64_t v = 0;
+    switch (lane) {
+    case TK_E0: v = e0; break;
+    case TK_IDX0: v = S.last_idx + 1; break;
+    case TK_SLOT0: v = S.n_end; break;
+    case TK_END: v = e0 + APUS_HDR; break;
+    case TK_D0: v = new_head; break;
+    case TK_META: v = 1ull | ((uint64_t)R_SRC_CONTROL << 8) | (3ull << 16) | ((uint64_t)S.push_mask << 32); break;
+    default: break;
+    }
+    if (lane < 8) st_agent(&LS->tkw[lane][S.t % RS_CAP], rep_tk(S.t, v));
+    S.t++;
+    S.tail = e0; S.tail_known = true; S.end = e0 + APUS_HDR; S.last_idx++; S.n_end++; S.store_count++;
+    if (S.can_commit) { S.c_off = S.end; S.c_slot = S.n_end; }
+    return true;
+}
+
 __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, const RepSeqCtx &X, RepSeqState &S,
                                             lds_u64 s_m, uint32_t bitmask, RepBox *mybox, uint64_t progress, const uint64_t *pre = nullptr)
 {
@@ -690,8 +723,10 @@ __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, c
     const uint32_t lane = lane_id();
     /* (0) the earlier ticks' samples: what has become true is retired; with the queue full the oldest is waited for */
     bool late = false;
+    const uint64_t tq0 = S.stats ? wall_clock64() : 0;
     rep_seq_verify(S, s_m, mybox, pre);
     if (S.pv_n >= R_PV) late = !rep_seq_wait_verified(E, X, S, LS, R_PV - 1);
+    const uint64_t tq1 = S.stats ? wall_clock64() : 0;
     const uint32_t size = E.group_size;
     const uint64_t c_before = S.c_off, cs_before = S.c_slot;
     if (!late) {
@@ -706,7 +741,7 @@ __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, c
         if (apus_is_larger(S.end, L, min_off, S.head) && !S.prev_head) {
             const uint64_t head_before = S.head;
             S.head = min_off;
-            if (rep_seq_round(E, X, S, LS, lane == 0 ? APUS_HDR : 0u, 1, R_SRC_CONTROL, 0, 3, min_off, 0)) {
+            if (rep_seq_head_plain(E, S, LS, min_off) || rep_seq_round(E, X, S, LS, lane == 0 ? APUS_HDR : 0u, 1, R_SRC_CONTROL, 0, 3, min_off, 0)) {
                 S.prev_head = 1;
                 /* the move holds once every sampled server has applied what the LAST tick took it to have applied */
                 const uint32_t ix = (S.pv_r + S.pv_n) % R_PV;
@@ -715,10 +750,12 @@ __device__ static inline void rep_seq_prune(const EngDev &E, const RepArgs &A, c
             } else { S.head = head_before; if (lane == 0) { set_status(E, 1u << 1); st_sys(&A.H->full, ld_sys(&A.H->full) + 1); } }
         }
     }
+    const uint64_t tq2 = S.stats ? wall_clock64() : 0;
     /* (c): what the servers will have applied when the timer's pass is over = the commit before <HEAD> */
     if (lane < size && (lane == E.leader || !((bitmask >> lane) & 1u) || ((S.push_mask >> lane) & 1u))) S.ao = c_before;
     S.sample_slot = cs_before;
     rep_seq_publish(LS, s_m, S, progress);
+    if (S.stats) { S.st_pr[0]++; S.st_pr[1] += tq1 - tq0; S.st_pr[2] += tq2 - tq1; S.st_pr[3] += wall_clock64() - tq2; }
 }
 
 /* the leader's first workgroup: wavefront 0 sequences, wavefront 1 commits, wavefront 2 applies */
@@ -738,6 +775,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
     S.c_off = s_h[H_COMMIT]; S.c_slot = s_h[H_N_COMMIT]; S.sample_slot = 0; S.t = 0; S.pass_seq = 0; S.g_seq = 0; S.tail_known = true; S.tail_round = 0;
     S.push_mask = A.push_mask; S.can_commit = rep_quorum(E, S.push_mask);
     S.pv_need = 0; S.pv_head = 0; S.head_safe = S.head; S.pv_r = 0; S.pv_n = 0;
+    S.st_pr[0] = S.st_pr[1] = S.st_pr[2] = S.st_pr[3] = 0; S.stats = (A.dbg & 512) != 0;
     S.ao = lane < APUS_DEV_MAX_SERVERS ? (uint64_t)s_h[H_APPLY_OFFSETS + lane] : 0ull;
     const RepSeqCtx X = {&A, s_m, mybox};
     const uint32_t bitmask = (uint32_t)s_h[H_CID_BITMASK];
@@ -771,9 +809,12 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
     if (lane == 0) st_sys(&H->alive, 1);
     const uint64_t my_qbase = (lane >= 1 && lane <= APUS_DEV_MAX_SERVERS) ? A.qbase[lane - 1] : 0;    /* (lane f + 1 looks after follower f) */
     uint64_t st_pass = 0, st_staged = 0, st_flow = 0, st_busy = 0, st_prune = 0, st_flowt = 0, st_pcie = 0, st_pcie_n = 0, st_reload = 0;
+    uint64_t st_ph[4] = {0, 0, 0, 0};
     const bool stats = A.dbg & 512;      /* per-pass clocks: every look at the wall clock is a scalar memory round trip */
     const uint64_t st_t0 = wall_clock64();
 
+    uint64_t n_pf0 = 0, n_pf1 = 0, n_spf = 0, pre_rc = ~0ull;      /* the next RUN's words as the pass before asked for them (rounds from pre_rc on, pre_avail of them) */
+    uint32_t n_rf0 = 0, n_rf1 = 0, n_srf = 0, n_scg = 0, n_cg0 = 0, pre_avail = 0;
     uint64_t ap_v = ~0ull;                       /* the followers' applied counts as the last staged pass asked for them (the next prune tick's first look) */
     bool ap_have = false;
     bool pk_pending = false;                     /* the next host commands, asked for by a staged pass that may end its run */
@@ -869,20 +910,31 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                 const uint64_t st_p0 = stats ? wall_clock64() : 0;
                 st_staged++;
                 const uint32_t want = (uint32_t)min((uint64_t)GP_MAX, run_end - rc);
+                if (stats) st_ph[0]++;
                 if (budget < want && budget < GP_GOAL) {
                     /* (room for a good part of the pass: tickets are handed out GP_GOAL at a time while >= RB_CAP - GP_GOAL rounds are queued) */
                     if (!flow_wait(min(want, (uint32_t)GP_GOAL))) break;
                 }
                 const uint32_t avail = (uint32_t)min((uint64_t)want, budget);
                 if (!avail) break;
-                /* ---- everything the pass needs from memory: one round trip ---- */
+                const uint64_t tpa = stats ? wall_clock64() : 0;
+                /* ---- everything the pass needs from memory: one round trip -- or none: the pass that ended the RUN before this one
+                 *      asked for these words already when the command ring showed this RUN behind it (the round trip ran under the
+                 *      prune tick in between: 1.8 of the pass's 3.6 us at three replicas) ---- */
                 const uint32_t j0 = lane < avail ? lane : 0u;                            /* lane j: round rc + j (the first 64) */
-                const uint64_t pf0 = E.round_prefix[rc + j0], pf1 = E.round_prefix[rc + j0 + 1];
-                const uint32_t rf0 = E.round_first[rc + j0], rf1 = E.round_first[rc + j0 + 1];
                 const uint32_t cut = (uint32_t)(((uint64_t)avail * (lane + 1)) >> 6);     /* lane l: the first `cut` rounds (lane 63: all) */
-                const uint64_t spf = E.round_prefix[rc + cut];
-                const uint32_t srf = E.round_first[rc + cut];
-                const uint32_t scg = E.round_change[rc + (cut ? cut - 1 : 0u)], cg0 = E.round_change[rc];      /* (one size all the way?) */
+                uint64_t pf0, pf1, spf;
+                uint32_t rf0, rf1, srf, scg, cg0;
+                if (pre_rc == rc && pre_avail == avail) {
+                    pf0 = n_pf0; pf1 = n_pf1; spf = n_spf; rf0 = n_rf0; rf1 = n_rf1; srf = n_srf; scg = n_scg; cg0 = n_cg0;
+                } else {
+                    pf0 = E.round_prefix[rc + j0]; pf1 = E.round_prefix[rc + j0 + 1];
+                    rf0 = E.round_first[rc + j0]; rf1 = E.round_first[rc + j0 + 1];
+                    spf = E.round_prefix[rc + cut];
+                    srf = E.round_first[rc + cut];
+                    scg = E.round_change[rc + (cut ? cut - 1 : 0u)]; cg0 = E.round_change[rc];      /* (one size all the way?) */
+                }
+                pre_rc = ~0ull;
                 /* the next host commands, when this pass may end the run and none is queued */
                 if (!have_cmd && cq_i >= cq_n && run_end - rc <= avail) {
                     pk_pending = true; pk_next = cmd_head + 1;            /* (cmd_head is the RUN in progress) */
@@ -896,6 +948,7 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                 const uint32_t brf = rl32u(rf0, 0);
                 const uint64_t used = S.end >= S.head_safe ? S.end - S.head_safe : L - (S.head_safe - S.end);      /* (the VERIFIED head: rep_seq_prune) */
                 uint32_t taken = 0;
+                const uint64_t tpb = stats ? (wall_clock64() + 0 * (uint64_t)rl32u(srf, 0)) : 0;      /* (behind the loads' arrival) */
                 /* ---- the longest plain stretch as ONE pass: a record + two words per ticket (TK_BULK) ---- */
                 if (avail >= WAVE && !(A.dbg & 32) && rc + avail < (1ull << 32)) {
                     const uint64_t tot_c = spf - bpf;
@@ -1004,7 +1057,28 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
                 if (run_next == run_end) { cmd_head++; if (lane == 0) st_sys(&H->cmd_head, cmd_head); }
                 rep_seq_publish(LS, s_m, S, cmd_head + req_head);
                 if (pk_pending) { take_peek(); pk_pending = false; }
-                if (stats) st_busy += wall_clock64() - st_p0;
+                {
+                    /* the RUN behind this one (behind the prune tick, as a rule): its words are asked for now.  Straight-line code: a
+                     * load inside a branch is waited for where the branch ends, whoever needs it (the pass would pay the round trip it
+                     * is meant to hide); a pass that has no RUN to look forward to asks for its own first words again, and drops them */
+                    const bool q0 = cq_i < cq_n, q1 = cq_i + 1 < cq_n;
+                    const int l0 = (int)min(4u * cq_i, 56u), l1 = l0 + 4;
+                    const uint32_t op0 = (uint32_t)rl64u(cq, l0), op1 = (uint32_t)rl64u(cq, l1);
+                    const uint64_t a0 = (uint32_t)rl64u(cq, l0 + 2), b0 = (uint32_t)rl64u(cq, l0 + 3), a1 = (uint32_t)rl64u(cq, l1 + 2), b1 = (uint32_t)rl64u(cq, l1 + 3);
+                    const bool use0 = q0 && op0 == R_OP_RUN && b0 != 0, use1 = !use0 && q0 && op0 == R_OP_PRUNE && q1 && op1 == R_OP_RUN && b1 != 0;
+                    const bool fwd = run_next == run_end && !have_cmd && (use0 || use1);
+                    const uint64_t na = fwd ? (use0 ? a0 : a1) : rc;
+                    const uint32_t nav = fwd ? (uint32_t)min((uint64_t)GP_MAX, use0 ? b0 : b1) : 1u;
+                    const uint32_t nj0 = lane < nav ? lane : 0u;
+                    const uint32_t ncut = (uint32_t)(((uint64_t)nav * (lane + 1)) >> 6);
+                    n_pf0 = E.round_prefix[na + nj0]; n_pf1 = E.round_prefix[na + nj0 + 1];
+                    n_rf0 = E.round_first[na + nj0]; n_rf1 = E.round_first[na + nj0 + 1];
+                    n_spf = E.round_prefix[na + ncut];
+                    n_srf = E.round_first[na + ncut];
+                    n_scg = E.round_change[na + (ncut ? ncut - 1 : 0u)]; n_cg0 = E.round_change[na];
+                    pre_rc = fwd ? na : ~0ull; pre_avail = nav;
+                }
+                if (stats) { const uint64_t tpc = wall_clock64(); st_busy += tpc - st_p0; st_ph[1] += tpa - st_p0; st_ph[2] += tpb - tpa; st_ph[3] += tpc - tpb; }
             }
             if (exit_code == R_EXIT_TIMEOUT) { if (lane == 0) spin_timeout(E, 7103); break; }
             idle = 0;
@@ -1144,6 +1218,8 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
         s_m[M_FINAL] = S.t;
         LS->stat[0][0] = st_pass; LS->stat[0][1] = st_staged; LS->stat[0][2] = S.t; LS->stat[0][3] = wall_clock64() - st_t0; LS->stat[0][4] = st_flow; LS->stat[0][5] = st_busy; LS->stat[0][6] = st_prune;
         LS->stat[4][0] = st_flowt; LS->stat[4][1] = st_pcie; LS->stat[4][2] = st_pcie_n; LS->stat[4][3] = st_reload;
+        LS->stat[5][0] = st_ph[0]; LS->stat[5][1] = st_ph[1]; LS->stat[5][2] = st_ph[2]; LS->stat[5][3] = st_ph[3];
+        LS->stat[5][4] = S.st_pr[0]; LS->stat[5][5] = S.st_pr[1]; LS->stat[5][6] = S.st_pr[2]; LS->stat[5][7] = S.st_pr[3];
         /* the leader's append-side words (log_append_entry's bookkeeping, persist_new_entries' own part) */
         uint64_t *mh = E.rep[E.leader].hdr;
         mh[H_END] = S.end; mh[H_TAIL] = S.tail; mh[H_LAST_IDX] = S.last_idx; mh[H_N_END] = S.n_end; mh[H_HEAD] = S.head;

@@ -450,6 +450,10 @@ class Engine:
         if "sequencer" in d:
             d["sequencer"].update({"outer_passes": int(out[0][0]), "flow_us": int(out[17][0]) / 100.0, "pcie_us": int(out[17][1]) / 100.0,
                                    "pcie_polls": int(out[17][2]), "reloads": int(out[17][3])})
+        if "sequencer" in d and out[18][0]:
+            n_p, n_t = max(1, int(out[18][0])), max(1, int(out[18][4]))
+            d["sequencer"]["pass_phases_us"] = {"flow": int(out[18][1]) / 100.0 / n_p, "loads": int(out[18][2]) / 100.0 / n_p, "record_and_words": int(out[18][3]) / 100.0 / n_p}
+            d["sequencer"]["prune_phases_us"] = {"verify": int(out[18][5]) / 100.0 / n_t, "head_round": int(out[18][6]) / 100.0 / n_t, "rest": int(out[18][7]) / 100.0 / n_t}
         a = out[15]
         if a[0]:
             d["append"] = {"rounds": int(a[0]), "us_per_round": int(a[1]) / 100.0 / int(a[0]), "drain_us": int(a[2]) / 100.0 / int(a[0]),

@@ -20,7 +20,7 @@ def brief(d):
         return (x["moved"], round(x["rounds"] / max(1, x["moved"])), round(x["busy_us"] / max(1, x["moved"]), 2), round(x["busy_us"] / max(1e-9, x["us"]), 2))
     out = {"Meps": round(d["entries_per_s"] / 1e6), "ok": d["verified"], "host": round(d.get("host_issue_frac", 0), 2), "lat": d["lat_us_p50"], "lat_app": d["lat_appended_us_p50"],
            "seq_prune_us": r.get("sequencer", {}).get("y_us"), "seq_x": r.get("sequencer", {}).get("x"), "seq_us": r.get("sequencer", {}).get("us"),
-           "seq_more": {k: r.get("sequencer", {}).get(k) for k in ("outer_passes", "flow_us", "pcie_us", "pcie_polls", "reloads")},
+           "seq_more": {k: r.get("sequencer", {}).get(k) for k in ("outer_passes", "flow_us", "pcie_us", "pcie_polls", "reloads", "pass_phases_us", "prune_phases_us")},
            "seq": f("sequencer"), "com": f("committer"), "app": f("applier"), "f0r": f("f0_retire"), "f0a": f("f0_apply")}
     for k in ("append", "f0_work"):
         if k in r:
