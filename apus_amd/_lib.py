@@ -13,7 +13,7 @@ vp = C.c_void_p
 class IpcReplica(C.Structure):
     """apus_ipc_replica_t (include/apus_gpu.h)"""
     _fields_ = [("handle", (u8 * 64) * 8), ("log_len", u64), ("dir_cap", u32), ("replica", u32),
-                ("device", C.c_int32), ("fences", u32)]
+                ("device", C.c_int32), ("fences", u32), ("pair", ((u8 * 64) * 2) * 4)]
 
 
 class Cfg(C.Structure):
@@ -99,6 +99,7 @@ SIGNATURES = {
     "apus_gpu_rep_run": (C.c_int, [vp, u64, u64]),
     "apus_gpu_rep_prune": (C.c_int, [vp]),
     "apus_gpu_rep_cmds": (C.c_int, [vp, C.POINTER(u64), u32, u32]),
+    "apus_gpu_rep_push_info": (C.c_int, [vp, C.POINTER(u32)]),
     "apus_gpu_rep_drain": (C.c_int, [vp, u32]),
     "apus_gpu_rep_full": (C.c_int, [vp]),
     "apus_gpu_rep_highest_rec": (u64, [vp]),

@@ -108,10 +108,14 @@ struct apus_engine {
     uint64_t r_consumer[APUS_MAX_SERVERS], r_replayed[APUS_MAX_SERVERS];   /* a host consumer of a hosted follower's apply stream (apus_gpu_rep_follower_replayed) */
     uint8_t *ss_buf; uint64_t ss_cap;       /* apus_gpu_store_stream's scratch, kept between calls */
     hipStream_t rstream;            /* the run's one resident launch (k_replica / k_replica_leader / k_replica_follower) */
-    /* apus_gpu_fence_replica: the allocations a hosted replica's ring and mailbox have LEFT (a deposed leader's mapping still
-     * leads there; kept so that its stores hit memory that exists and nobody reads), oldest first */
-    std::vector<uint8_t *> retired_ring[APUS_MAX_SERVERS];
-    std::vector<RepBox *> retired_box[APUS_MAX_SERVERS];
+    /* apus_gpu_fence_replica: the APUS_FENCE_PAIRS (log ring, mailbox) pairs a replica moves through, fence f lives in pair
+     * f % APUS_FENCE_PAIRS; the ones it has LEFT stay allocated (a deposed leader's mapping still leads there: its stores hit
+     * memory that exists and nobody reads) */
+    uint8_t *pair_ring[APUS_MAX_SERVERS][APUS_FENCE_PAIRS];     /* hosted: allocations (pair 0 = the one the replica was created in); */
+    RepBox *pair_box[APUS_MAX_SERVERS][APUS_FENCE_PAIRS];       /* mapped: the peer's, all of them open from apus_gpu_import_replica on */
+    bool pairs_ready[APUS_MAX_SERVERS];
+    apus_ipc_replica_t ipc_cache[APUS_MAX_SERVERS];             /* hosted: the handles, taken once (ipc_cached) */
+    bool ipc_cached[APUS_MAX_SERVERS];
     int ring_alloc;                 /* 0 hipMalloc, 1 fine-grained, 2 uncached (APUS_RING_ALLOC) */
     uint32_t fences[APUS_MAX_SERVERS];          /* hosted: fences so far; imported: the exporter's count as mapped here */
     hipEvent_t rev0, rev1;          /* around the last resident launch (apus_gpu_rep_launch_ms) */
@@ -119,6 +123,8 @@ struct apus_engine {
     bool r_running, r_lead;         /* a launch is resident; it carries the leader's workgroups */
     uint32_t r_follow_mask;
     uint32_t r_test_skip;           /* tests: followers whose workgroups are NOT launched although they are pushed to (a dead process) */
+    uint64_t r_fruns[APUS_MAX_SERVERS];          /* leader: every pushed follower's f_runs when the run began (apus_gpu_rep_park waits for the next) */
+    uint32_t r_push_mask, r_cand_mask;        /* the last run started here as the leader: who gets its rounds, who could be reached */
     uint64_t r_slot_tail, r_arena_tail, r_cmd_tail;   /* producer side of the pinned rings (under r_lock) */
     uint64_t *r_slot_aend;          /* [RQ_CAP] logical arena position behind every slot's payload */
     uint32_t *r_win_cnt, *r_win_len;/* [RQ_CAP / 64] per aligned window of 64 request slots: how many are published, and the one length they
@@ -420,26 +426,80 @@ extern "C" int apus_gpu_reset(apus_engine_t *e)
 }
 
 /* ---- peer-mapped replicas (one replica per GPU / process) ------------------------------- */
+/* hipIpcGetMemHandle with a second and a third try.  Round 6's soak (every election of the C layer fences now: ~300 fences per
+ * suite run, five processes on one device allocating and exporting side by side) saw ONE export of a freshly allocated, block-owning
+ * buffer fail with "invalid argument" -- and a group of five lose a second server to it.  The call succeeds when it is repeated. */
+static hipError_t ipc_handle_of(hipIpcMemHandle_t *h, void *p)
+{
+    hipError_t er = hipSuccess;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        er = hipIpcGetMemHandle(h, p);
+        if (er == hipSuccess) {
+            if (attempt) fprintf(stderr, "[apus_gpu] hipIpcGetMemHandle(%p) succeeded at attempt %d\n", p, attempt + 1);
+            return er;
+        }
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        struct timespec ts = {0, 2000000L << attempt};
+        nanosleep(&ts, nullptr);
+    }
+    return er;
+}
+
+/* the spare (ring, mailbox) pairs of a hosted replica: allocated when the replica is first exported or fenced -- an engine that
+ * hosts a whole group in one process (bench.py, most tests) never pays for them */
+static int ensure_pairs(apus_engine *e, uint32_t replica)
+{
+    if (e->pairs_ready[replica]) return 0;
+    const uint32_t cur = e->fences[replica] % APUS_FENCE_PAIRS;
+    e->pair_ring[replica][cur] = e->d.rep[replica].ring; e->pair_box[replica][cur] = e->d.box[replica];
+    for (uint32_t k = 0; k < APUS_FENCE_PAIRS; k++) {
+        if (k == cur) continue;
+        int rc;
+        if ((rc = dev_alloc(e, &e->pair_ring[replica][k], e->d.log_len + 4096, true, e->ring_alloc == 1 ? hipDeviceMallocFinegrained : e->ring_alloc == 2 ? hipDeviceMallocUncached : 0u))) return rc;
+        if ((rc = dev_alloc(e, &e->pair_box[replica][k], sizeof(RepBox), true, hipDeviceMallocUncached))) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->pairs_ready[replica] = true;
+    return 0;
+}
+
 extern "C" int apus_gpu_export_replica(apus_engine_t *e, uint32_t replica, apus_ipc_replica_t *out)
 {
     if (!e || !out || replica >= e->cfg.group_size) return APUS_E_ARG;
     if (!((e->local_mask >> replica) & 1u) || ((e->imported_mask >> replica) & 1u)) return APUS_E_STATE;
+    HIPCHK(hipSetDevice(e->cfg.device));
     HIPCHK(hipStreamSynchronize(e->stream));
-    const RepDev &r = e->d.rep[replica];
-    void *bufs[APUS_IPC_BUFFERS] = { r.ring, r.hdr, r.dir_off, r.dir_len, r.ack, r.apply, e->d.box[replica], e->d.ackb[replica] };
     static_assert(sizeof(hipIpcMemHandle_t) <= 64, "apus_ipc_replica_t carries 64 bytes per handle");
-    memset(out, 0, sizeof *out);
-    for (uint32_t k = 0; k < APUS_IPC_BUFFERS; k++) {
-        hipIpcMemHandle_t h;
-        const hipError_t er = hipIpcGetMemHandle(&h, bufs[k]);
-        if (er != hipSuccess) {
-            fprintf(stderr, "[apus_gpu] hipIpcGetMemHandle failed for replica %u buffer %u (%p): %s\n", replica, k, bufs[k], hipGetErrorString(er));
-            (void)hipGetLastError();
-            return APUS_E_HIP;
+    if (!e->ipc_cached[replica]) {
+        /* every handle of the replica is taken ONCE, all pairs included: nothing is allocated, exported or mapped at election
+         * time (see apus_gpu_fence_replica) */
+        int rc = ensure_pairs(e, replica);
+        if (rc) return rc;
+        const RepDev &r = e->d.rep[replica];
+        apus_ipc_replica_t &c = e->ipc_cache[replica];
+        memset(&c, 0, sizeof c);
+        void *bufs[APUS_IPC_BUFFERS] = { nullptr, r.hdr, r.dir_off, r.dir_len, r.ack, r.apply, nullptr, e->d.ackb[replica] };
+        for (uint32_t k = 0; k < APUS_IPC_BUFFERS + 2 * APUS_FENCE_PAIRS; k++) {
+            void *buf = k < APUS_IPC_BUFFERS ? bufs[k] : (k - APUS_IPC_BUFFERS) % 2 ? (void *)e->pair_box[replica][(k - APUS_IPC_BUFFERS) / 2] : (void *)e->pair_ring[replica][(k - APUS_IPC_BUFFERS) / 2];
+            if (!buf) continue;                                    /* (handle[0], handle[6]: copies of the current pair's, below) */
+            hipIpcMemHandle_t h;
+            const hipError_t er = ipc_handle_of(&h, buf);
+            if (er != hipSuccess) {
+                fprintf(stderr, "[apus_gpu] hipIpcGetMemHandle failed for replica %u buffer %u (%p): %s\n", replica, k, buf, hipGetErrorString(er));
+                (void)hipGetLastError();
+                return APUS_E_HIP;
+            }
+            memcpy(k < APUS_IPC_BUFFERS ? c.handle[k] : c.pair[(k - APUS_IPC_BUFFERS) / 2][(k - APUS_IPC_BUFFERS) % 2], &h, sizeof h);
         }
-        memcpy(out->handle[k], &h, sizeof h);
+        c.log_len = e->d.log_len; c.dir_cap = e->dir_cap; c.replica = replica; c.device = e->cfg.device;
+        e->ipc_cached[replica] = true;
     }
-    out->log_len = e->d.log_len; out->dir_cap = e->dir_cap; out->replica = replica; out->device = e->cfg.device; out->fences = e->fences[replica];
+    *out = e->ipc_cache[replica];
+    out->fences = e->fences[replica];
+    const uint32_t cur = e->fences[replica] % APUS_FENCE_PAIRS;
+    memcpy(out->handle[0], out->pair[cur][0], 64);
+    memcpy(out->handle[6], out->pair[cur][1], 64);
     return 0;
 }
 
@@ -458,6 +518,7 @@ extern "C" int apus_gpu_unmap_peers(apus_engine_t *e)
         if ((e->imported_mask >> r) & 1u) {
             e->d.rep[r] = RepDev{};
             e->d.box[r] = nullptr; e->d.ackb[r] = nullptr;
+            for (uint32_t k = 0; k < APUS_FENCE_PAIRS; k++) { e->pair_ring[r][k] = nullptr; e->pair_box[r][k] = nullptr; }
         }
     e->local_mask &= ~e->imported_mask;
     e->imported_mask = 0;
@@ -479,13 +540,17 @@ extern "C" int apus_gpu_unmap_replica(apus_engine_t *e, uint32_t replica)
     if (!e || replica >= e->cfg.group_size) return APUS_E_ARG;
     if (!((e->imported_mask >> replica) & 1u)) return APUS_E_STATE;
     if (e->r_running || e->p_running || e->batching) return APUS_E_STATE;
-    if (e->d.leader == replica) return APUS_E_STATE;
+    /* (the LEADER's mapping is dropped like any other once its process is gone or deposed: this engine has no leader until the next
+     *  election's become_leader / set_leader) */
+    if (e->d.leader == replica) e->d.leader = 0xFFFFFFFFu;
     HIPCHK(hipStreamSynchronize(e->stream));
     const RepDev &r = e->d.rep[replica];
-    void *mine[APUS_IPC_BUFFERS] = { r.ring, r.hdr, r.dir_off, r.dir_len, r.ack, r.apply, e->d.box[replica], e->d.ackb[replica] };
+    std::vector<void *> mine = { r.hdr, r.dir_off, r.dir_len, r.ack, r.apply, e->d.ackb[replica] };
+    for (uint32_t k = 0; k < APUS_FENCE_PAIRS; k++) { mine.push_back(e->pair_ring[replica][k]); mine.push_back(e->pair_box[replica][k]); }
     for (void *m : mine)
-        for (size_t k = 0; k < e->ipc_ptrs.size(); k++)
+        for (size_t k = 0; m && k < e->ipc_ptrs.size(); k++)
             if (e->ipc_ptrs[k] == m) { hipIpcCloseMemHandle(m); e->ipc_ptrs.erase(e->ipc_ptrs.begin() + (long)k); break; }
+    for (uint32_t k = 0; k < APUS_FENCE_PAIRS; k++) { e->pair_ring[replica][k] = nullptr; e->pair_box[replica][k] = nullptr; }
     e->d.rep[replica] = RepDev{};
     e->d.box[replica] = nullptr; e->d.ackb[replica] = nullptr;
     e->local_mask &= ~(1u << replica);
@@ -542,7 +607,6 @@ extern "C" int apus_gpu_rep_box_words(apus_engine_t *e, uint32_t replica, uint32
  * stay where they are: those launches sit behind the sender's term check (k_fence_check).
  * Not while a resident kernel or a batch is open; graphs captured before the fence hold the old pointers (peer-mapped groups
  * capture none). */
-#define APUS_FENCE_KEEP 8u
 extern "C" int apus_gpu_fence_replica(apus_engine_t *e, uint32_t replica, apus_ipc_replica_t *out)
 {
     if (!e || replica >= e->cfg.group_size) return APUS_E_ARG;
@@ -550,28 +614,23 @@ extern "C" int apus_gpu_fence_replica(apus_engine_t *e, uint32_t replica, apus_i
     if (e->r_running || e->p_running || e->batching || !e->graphs.empty()) return APUS_E_STATE;
     HIPCHK(hipSetDevice(e->cfg.device));
     HIPCHK(hipStreamSynchronize(e->stream));
+    {   int rc = ensure_pairs(e, replica); if (rc) return rc; }
     const uint64_t ring_bytes = e->d.log_len + 4096;
-    uint8_t *nring = nullptr; RepBox *nbox = nullptr;
-    if (e->retired_ring[replica].size() >= APUS_FENCE_KEEP) {
-        nring = e->retired_ring[replica].front(); e->retired_ring[replica].erase(e->retired_ring[replica].begin());
-        nbox = e->retired_box[replica].front(); e->retired_box[replica].erase(e->retired_box[replica].begin());
-    } else {
-        int rc;
-        if ((rc = dev_alloc(e, &nring, ring_bytes, false, e->ring_alloc == 1 ? hipDeviceMallocFinegrained : e->ring_alloc == 2 ? hipDeviceMallocUncached : 0u))) return rc;
-        if ((rc = dev_alloc(e, &nbox, sizeof(RepBox), false, hipDeviceMallocUncached))) return rc;
-    }
     uint8_t *oring = e->d.rep[replica].ring; RepBox *obox = e->d.box[replica];
+    const uint32_t next = (e->fences[replica] + 1) % APUS_FENCE_PAIRS;
+    uint8_t *nring = e->pair_ring[replica][next]; RepBox *nbox = e->pair_box[replica][next];
     HIPCHK(hipMemcpyAsync(nring, oring, ring_bytes, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(nbox, obox, sizeof(RepBox), hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->retired_ring[replica].push_back(oring); e->retired_box[replica].push_back(obox);
     e->d.rep[replica].ring = nring; e->d.box[replica] = nbox;
     e->fences[replica]++;
+    if (getenv("APUS_DEBUG")) fprintf(stderr, "[apus_gpu] fence %u of replica %u: ring %p -> %p, mailbox %p -> %p\n", e->fences[replica], replica, (void *)oring, (void *)nring, (void *)obox, (void *)nbox);
     return out ? apus_gpu_export_replica(e, replica, out) : 0;
 }
 
-/* a member of the new term maps the two buffers a peer's fence moved (handles 0 and 6 of `in`), and drops its mappings of the
- * ones the peer left.  The replica must be imported already (apus_gpu_import_replica). */
+/* a member of the new term follows a peer's fence: the pair `in->fences` names has been open here since the replica was mapped
+ * (apus_gpu_import_replica maps them all), the pointers the kernels of the next run get are switched -- nothing is opened or
+ * closed.  The replica must be imported already. */
 extern "C" int apus_gpu_remap_fenced(apus_engine_t *e, const apus_ipc_replica_t *in)
 {
     if (!e || !in || in->replica >= e->cfg.group_size) return APUS_E_ARG;
@@ -581,24 +640,11 @@ extern "C" int apus_gpu_remap_fenced(apus_engine_t *e, const apus_ipc_replica_t 
     if (e->r_running || e->p_running || e->batching) return APUS_E_STATE;
     HIPCHK(hipSetDevice(e->cfg.device));
     HIPCHK(hipStreamSynchronize(e->stream));
-    const uint32_t which[2] = { 0, 6 };
-    void *np[2] = { nullptr, nullptr };
-    for (int k = 0; k < 2; k++) {
-        hipIpcMemHandle_t h;
-        memcpy(&h, in->handle[which[k]], sizeof h);
-        if (hipIpcOpenMemHandle(&np[k], h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
-            fprintf(stderr, "[apus_gpu] hipIpcOpenMemHandle failed for replica %u's fenced buffer %u: %s\n", in->replica, which[k], hipGetErrorString(hipGetLastError()));
-            if (k) hipIpcCloseMemHandle(np[0]);
-            return APUS_E_HIP;
-        }
-    }
+    const uint32_t cur = in->fences % APUS_FENCE_PAIRS;
     void *old[2] = { e->d.rep[in->replica].ring, e->d.box[in->replica] };
-    for (int k = 0; k < 2; k++) {
-        if (old[k] == np[k]) { continue; }                       /* (the runtime hands an open mapping out again: nothing moved) */
-        for (size_t j = 0; j < e->ipc_ptrs.size(); j++)
-            if (e->ipc_ptrs[j] == old[k]) { hipIpcCloseMemHandle(old[k]); e->ipc_ptrs.erase(e->ipc_ptrs.begin() + (long)j); break; }
-        e->ipc_ptrs.push_back(np[k]);
-    }
+    void *np[2] = { e->pair_ring[in->replica][cur], e->pair_box[in->replica][cur] };
+    if (!np[0] || !np[1]) return APUS_E_STATE;
+    if (getenv("APUS_DEBUG")) fprintf(stderr, "[apus_gpu] remap of replica %u (fence %u -> %u): ring %p -> %p, mailbox %p -> %p\n", in->replica, e->fences[in->replica], in->fences, old[0], np[0], old[1], np[1]);
     e->d.rep[in->replica].ring = (uint8_t *)np[0];
     e->d.box[in->replica] = (RepBox *)np[1];
     e->fences[in->replica] = in->fences;
@@ -609,9 +655,23 @@ extern "C" int apus_gpu_remap_fenced(apus_engine_t *e, const apus_ipc_replica_t 
  * leader's stores went */
 extern "C" int apus_gpu_read_retired_ring(apus_engine_t *e, uint32_t replica, uint32_t back, uint64_t off, uint64_t n, void *dst)
 {
-    if (!e || replica >= e->cfg.group_size || !dst || back == 0 || back > e->retired_ring[replica].size() || off + n > e->d.log_len) return APUS_E_ARG;
-    HIPCHK(hipMemcpy(dst, e->retired_ring[replica][e->retired_ring[replica].size() - back] + off, n, hipMemcpyDeviceToHost));
+    if (!e || replica >= e->cfg.group_size || !dst || back == 0 || back >= APUS_FENCE_PAIRS || back > e->fences[replica] || !e->pairs_ready[replica] || off + n > e->d.log_len) return APUS_E_ARG;
+    HIPCHK(hipMemcpy(dst, e->pair_ring[replica][(e->fences[replica] - back) % APUS_FENCE_PAIRS] + off, n, hipMemcpyDeviceToHost));
     return 0;
+}
+
+/* bytes of the k-th buffer a replica exports (apus_ipc_replica_t: handle[0..7], then the pairs) */
+static size_t ipc_buffer_bytes(const apus_engine *e, uint32_t k)
+{
+    if (k >= APUS_IPC_BUFFERS) return (k - APUS_IPC_BUFFERS) % 2 ? sizeof(RepBox) : (size_t)e->d.log_len + 4096;
+    switch (k) {
+    case 1: return sizeof(uint64_t) * 64;
+    case 2: return sizeof(uint64_t) * e->dir_cap;
+    case 3: case 4: return sizeof(uint32_t) * e->dir_cap;
+    case 5: return sizeof(apus_apply_rec) * (size_t)e->dir_cap;
+    case 7: return (size_t)e->cfg.group_size * e->dir_cap;
+    default: return 0;
+    }
 }
 
 extern "C" int apus_gpu_import_replica(apus_engine_t *e, const apus_ipc_replica_t *in)
@@ -620,21 +680,40 @@ extern "C" int apus_gpu_import_replica(apus_engine_t *e, const apus_ipc_replica_
     if (in->log_len != e->d.log_len || in->dir_cap != e->dir_cap) return APUS_E_ARG;
     if ((e->local_mask >> in->replica) & 1u) return APUS_E_STATE;          /* hosted here, or imported already */
     HIPCHK(hipSetDevice(e->cfg.device));
-    void *p[APUS_IPC_BUFFERS];
-    for (uint32_t k = 0; k < APUS_IPC_BUFFERS; k++) {
+    /* the six buffers that never move, then every (ring, mailbox) pair the replica moves through at its fences: ALL mappings of a
+     * peer are made here, once.  (Round 6's first cut mapped the pair a fence had moved to at election time; the soak found a
+     * survivor's new ring mapped over another live mapping -- the runtime handed an address range out twice once mappings had
+     * been closed and opened between runs -- and the log bytes pushed through it lost while the doorbells arrived.) */
+    const uint32_t NB = APUS_IPC_BUFFERS + 2 * APUS_FENCE_PAIRS;
+    void *p[APUS_IPC_BUFFERS + 2 * APUS_FENCE_PAIRS] = {nullptr};
+    for (uint32_t k = 0; k < NB; k++) {
+        if (k == 0 || k == 6) continue;                              /* (copies of the current pair's handles) */
         hipIpcMemHandle_t h;
-        memcpy(&h, in->handle[k], sizeof h);
+        memcpy(&h, k < APUS_IPC_BUFFERS ? in->handle[k] : in->pair[(k - APUS_IPC_BUFFERS) / 2][(k - APUS_IPC_BUFFERS) % 2], sizeof h);
         if (hipIpcOpenMemHandle(&p[k], h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
             fprintf(stderr, "[apus_gpu] hipIpcOpenMemHandle failed for replica %u buffer %u: %s\n", in->replica, k, hipGetErrorString(hipGetLastError()));
-            for (uint32_t j = 0; j < k; j++) hipIpcCloseMemHandle(p[j]);
+            for (uint32_t j = 0; j < k; j++) if (p[j]) hipIpcCloseMemHandle(p[j]);
             return APUS_E_HIP;
         }
     }
-    for (uint32_t k = 0; k < APUS_IPC_BUFFERS; k++) e->ipc_ptrs.push_back(p[k]);
+    /* what the kernels are about to be given must not lie over one another */
+    for (uint32_t a = 0; a < NB; a++)
+        for (uint32_t b = 0; p[a] && b < NB; b++)
+            if (b != a && p[b] && (uintptr_t)p[a] <= (uintptr_t)p[b] && (uintptr_t)p[b] < (uintptr_t)p[a] + ipc_buffer_bytes(e, a)) {
+                fprintf(stderr, "[apus_gpu] replica %u: the mappings of buffers %u (%p) and %u (%p) overlap\n", in->replica, a, p[a], b, p[b]);
+                for (uint32_t j = 0; j < NB; j++) if (p[j]) hipIpcCloseMemHandle(p[j]);
+                return APUS_E_HIP;
+            }
+    for (uint32_t k = 0; k < NB; k++) if (p[k]) e->ipc_ptrs.push_back(p[k]);
+    for (uint32_t k = 0; k < APUS_FENCE_PAIRS; k++) {
+        e->pair_ring[in->replica][k] = (uint8_t *)p[APUS_IPC_BUFFERS + 2 * k];
+        e->pair_box[in->replica][k] = (RepBox *)p[APUS_IPC_BUFFERS + 2 * k + 1];
+    }
+    const uint32_t cur = in->fences % APUS_FENCE_PAIRS;
     RepDev &r = e->d.rep[in->replica];
-    r.ring = (uint8_t *)p[0]; r.hdr = (uint64_t *)p[1]; r.dir_off = (uint64_t *)p[2]; r.dir_len = (uint32_t *)p[3];
+    r.ring = e->pair_ring[in->replica][cur]; r.hdr = (uint64_t *)p[1]; r.dir_off = (uint64_t *)p[2]; r.dir_len = (uint32_t *)p[3];
     r.ack = (uint32_t *)p[4]; r.apply = (apus_apply_rec *)p[5]; r.idx = in->replica;
-    e->d.box[in->replica] = (RepBox *)p[6]; e->d.ackb[in->replica] = (uint8_t *)p[7];
+    e->d.box[in->replica] = e->pair_box[in->replica][cur]; e->d.ackb[in->replica] = (uint8_t *)p[7];
     e->local_mask |= 1u << in->replica;
     e->imported_mask |= 1u << in->replica;
     e->fences[in->replica] = in->fences;
@@ -2589,6 +2668,9 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
             if (n_fwork > 2) n_fwork -= (n_fwork + 3) / 4;
         }
         if (!n_fwork) n_fwork = 1;
+        if (getenv("APUS_DEBUG")) {
+            for (uint32_t i = 0; i < e->d.group_size; i++) fprintf(stderr, "[apus_gpu]   replica %u: ring %p mailbox %p hdr %p%s\n", i, (void *)e->d.rep[i].ring, (void *)e->d.box[i], (void *)e->d.rep[i].hdr, ((e->imported_mask >> i) & 1u) ? " (mapped)" : "");
+        }
         if (getenv("APUS_DEBUG")) fprintf(stderr, "[apus_gpu] replica launch: %s, %d workgroups per CU; grid %u append, %u per follower x %u\n",
                                           kern == (const void *)k_replica ? "k_replica" : lead_here ? "k_replica_leader" : "k_replica_follower", occ, n_append, n_fwork, nfh);
     }
@@ -2629,6 +2711,7 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
         int rc = rep_in_step(e, cand, &push, A.qbase, A.fruns);
         if (rc) return rc;
         A.push_mask = push; A.park_mask = cand;
+        if (getenv("APUS_DEBUG")) { fprintf(stderr, "[apus_gpu] leader %u starts a run: push %#x of %#x;", leader, push, cand); for (uint32_t m = cand; m; m &= m - 1) fprintf(stderr, " q%u=%llu", __builtin_ctz(m), (unsigned long long)A.qbase[__builtin_ctz(m)]); fprintf(stderr, "\n"); }
         if (push != cand) e->lag_possible = true;
         HIPCHK(hipMemsetAsync(e->rl, 0, sizeof(RepLead), e->rstream));
         HIPCHK(hipMemsetAsync(&e->rl->seq_final, 0xFF, sizeof(uint64_t), e->rstream));
@@ -2677,6 +2760,17 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
             if (mono_s() - t0 > 10.0) { fprintf(stderr, "[apus_gpu] the leader's workgroups did not start\n"); return APUS_E_HIP; }
     }
     e->r_running = true; e->r_lead = lead_here; e->r_follow_mask = A.follow_mask;
+    e->r_push_mask = A.push_mask; e->r_cand_mask = A.park_mask;
+    for (uint32_t f = 0; f < APUS_MAX_SERVERS && f < APUS_DEV_MAX_SERVERS; f++) e->r_fruns[f] = A.fruns[f];
+    return 0;
+}
+
+/* the last run the leader started here: out[0] = followers that get its rounds (they held everything when it began), out[1] = followers
+ * it could reach -- a follower in out[1] and not in out[0] takes no part until the next control-plane pass has caught it up */
+extern "C" int apus_gpu_rep_push_info(apus_engine_t *e, uint32_t out[2])
+{
+    if (!e || !out) return APUS_E_ARG;
+    out[0] = e->r_push_mask; out[1] = e->r_cand_mask;
     return 0;
 }
 
@@ -2940,6 +3034,26 @@ extern "C" int apus_gpu_rep_park(apus_engine_t *e)
     }
     HIPCHK(hipStreamSynchronize(e->rstream));
     if (e->r_lead) code = (int)e->rh->exit_code;
+    /* Followers in OTHER processes were told to park by the leader's workgroups; their kernels write their control words back
+     * (end, commit, apply; then f_runs + 1, last) a moment later.  Whatever the leader does next reads those words -- the wide
+     * catch-up of the control-plane launches first of all, which would send a follower whose words still show the run's first
+     * slot everything it already holds, from the leader's copy (same entries; other servers' reply bytes with them: the soak's
+     * one-in-fifteen "reply bytes differ from the oracle").  Bounded: a follower whose process died never writes them. */
+    if (e->r_lead) {
+        const double t0 = mono_s();
+        for (uint32_t m = e->r_push_mask & e->imported_mask; m; m &= m - 1) {
+            const uint32_t f = (uint32_t)__builtin_ctz(m);
+            if (!e->d.box[f]) continue;
+            for (;;) {
+                uint64_t x = 0;
+                if (hipMemcpy(&x, &e->d.box[f]->f_runs, sizeof x, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); break; }
+                if (x > e->r_fruns[f]) break;
+                if (mono_s() - t0 > 1.0) { if (getenv("APUS_DEBUG")) fprintf(stderr, "[apus_gpu] park: follower %u has not left the run after 1 s\n", f); break; }
+                struct timespec ts = {0, 200000};
+                nanosleep(&ts, nullptr);
+            }
+        }
+    }
     for (uint32_t m = e->r_follow_mask; m; m &= m - 1) {
         uint64_t x = 0;
         HIPCHK(hipMemcpy(&x, &e->d.box[__builtin_ctz(m)]->f_exit, sizeof x, hipMemcpyDeviceToHost));

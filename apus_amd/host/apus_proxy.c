@@ -541,6 +541,11 @@ static int group_start_run(smr_t *s)
          * term used to publish the device's apply count alone) */
         apus_gpu_rep_follower_replayed(s->eng, s->idx, s->replayed);
         s->hb_seen_t = 0; s->hb_seen = 0;                    /* (another leader's heartbeat from here on) */
+        {   uint64_t cnt[8] = {0};
+            apus_gpu_counters(s->eng, s->idx, cnt);
+            fprintf(s->log, "[T%lu] following server %u (announcement %llu): %llu entry slots, %llu committed, %llu applied by the device, %llu replayed here\n", (unsigned long)s->term, s->leader,
+                    (unsigned long long)s->seq, (unsigned long long)cnt[0], (unsigned long long)cnt[2], (unsigned long long)cnt[3], (unsigned long long)s->replayed);
+            fflush(s->log); }
         if (apus_gpu_set_leader(s->eng, s->leader) || apus_gpu_rep_start(s->eng, 24u * 3600u * 1000u, 2000, na, nf)) return -1;
         snprintf(name, sizeof name, "ready_%llu_%u", (unsigned long long)s->seq, s->idx);
         return g_write(s, "1", 1, name);
@@ -552,6 +557,9 @@ static int group_start_run(smr_t *s)
         if (g_wait_from(s, name, i, 1, &one, 30.0)) fprintf(stderr, "[apus] leader %u: follower %u did not start its workgroups for announcement %llu\n", s->idx, i, (unsigned long long)s->seq);
     }
     if (apus_gpu_rep_start(s->eng, 24u * 3600u * 1000u, 500, na, nf)) return -1;
+    {   uint32_t pi[2] = {0, 0};
+        apus_gpu_rep_push_info(s->eng, pi);
+        if (pi[0] != pi[1]) { fprintf(s->log, "[T%lu] run of announcement %llu: followers %#x are reachable but NOT in step (pushed: %#x)\n", (unsigned long)s->term, (unsigned long long)s->seq, pi[1] & ~pi[0], pi[0]); fflush(s->log); } }
     s->dev_hr = apus_gpu_rep_highest_rec_ptr(s->eng);
     s->upcalled = *s->dev_hr;
     /* a request's place in the order of upcalls starts where the device's count stands: a new leader's applier has counted the
@@ -657,8 +665,9 @@ static int group_failover(smr_t *s)
     /* the vote request: this server's last entry (start_election, dare_server.c:1264-1322) -- and, round 6, the RECEIVER'S FENCE
      * of every election, not only of one that follows a death (rc_revoke_log_access, dare_ibv_rc.c:2156-2243: a voter resets the
      * QPs of the leader it leaves, the old leader's WRITEs bounce): this server LEAVES the log ring and the mailbox the old
-     * leader has mapped (apus_gpu_fence_replica: fresh allocations, device copies) before it takes part in the new term, and
-     * hands the new handles out with its vote request; every member of the new term maps them (apus_gpu_remap_fenced) before
+     * leader has mapped (apus_gpu_fence_replica: the next of its pre-mapped pairs, device copies) before it takes part in the
+     * new term, and says where it lives now with its vote request; every member of the new term switches to that pair
+     * (apus_gpu_remap_fenced: all pairs have been mapped since the hello, nothing is opened or closed at election time) before
      * anything is voted on, adjusted or replicated.  An old leader that is not dead -- stopped, partitioned, slow -- keeps the
      * old mappings: whatever its resident kernel still pushes lands in memory nobody reads.  (APUS_GROUP_NO_RING_FENCE: the
      * control experiment.) */
@@ -667,7 +676,8 @@ static int group_failover(smr_t *s)
     if (apus_gpu_last_entry(s->eng, s->idx, mine.last)) return -1;
     if (!getenv("APUS_GROUP_NO_RING_FENCE")) {
         if (apus_gpu_fence_replica(s->eng, s->idx, &mine.ipc)) { fprintf(stderr, "[apus] server %u: cannot leave the old leader's ring (fence)\n", s->idx); return -1; }
-        fprintf(s->log, "[T%lu] election of term %llu: left the log ring and the mailbox server %u has mapped (fence %u)\n", (unsigned long)s->term, (unsigned long long)term, old_leader, mine.ipc.fences);
+        fprintf(s->log, "[T%lu] election of term %llu: left the log ring and the mailbox server %u has mapped (fence %u); last entry (term %llu, idx %llu), %llu entry slots, replayed %llu\n",
+                (unsigned long)s->term, (unsigned long long)term, old_leader, mine.ipc.fences, (unsigned long long)mine.last[0], (unsigned long long)mine.last[1], (unsigned long long)mine.last[2], (unsigned long long)s->replayed);
         fflush(s->log);
         {   /* (a machine that maps this server from now on -- a joiner -- must find the buffers it has moved to) */
             g_hello_t me; me.ipc = mine.ipc;

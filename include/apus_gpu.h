@@ -159,13 +159,16 @@ int  apus_gpu_stage(apus_engine_t *e, const apus_req_t *reqs, uint64_t n,
  * and bench.py use torch.distributed all_gather). */
 #define APUS_IPC_BUFFERS 8u              /* ring, control block, directory offsets / lengths, ACK words, apply stream,
                                           * mailbox + ACK byte maps of the replica kernels (apus_gpu_rep_*) */
+#define APUS_FENCE_PAIRS 4u              /* the (log ring, mailbox) pairs a replica moves through at its fences (apus_gpu_fence_replica) */
 typedef struct {
-    uint8_t  handle[APUS_IPC_BUFFERS][64];   /* hipIpcMemHandle_t each */
+    uint8_t  handle[APUS_IPC_BUFFERS][64];   /* hipIpcMemHandle_t each; [0] and [6] = the pair the replica lives in now */
     uint64_t log_len;
     uint32_t dir_cap;
     uint32_t replica;                         /* group index of the replica */
     int32_t  device;                          /* HIP device ordinal in the exporting process */
-    uint32_t fences;                          /* how often the replica's ring and mailbox have moved (apus_gpu_fence_replica) */
+    uint32_t fences;                          /* how often the replica's ring and mailbox have moved (apus_gpu_fence_replica):
+                                               * it lives in pair[fences % APUS_FENCE_PAIRS] */
+    uint8_t  pair[APUS_FENCE_PAIRS][2][64];   /* every (ring, mailbox) pair: a peer maps them ALL when it maps the replica */
 } apus_ipc_replica_t;
 /* replica must be hosted (allocated) by this engine */
 int  apus_gpu_export_replica(apus_engine_t *e, uint32_t replica, apus_ipc_replica_t *out);
@@ -180,14 +183,17 @@ int  apus_gpu_unmap_replica(apus_engine_t *e, uint32_t replica);
 int  apus_gpu_unmap_peers(apus_engine_t *e);
 /* The receiver's fence against a deposed leader (rc_revoke_log_access, src/dare/dare_ibv_rc.c:2156-2243: the voters reset
  * the old leader's QPs, its WRITEs bounce).  A mapped buffer cannot be taken back, but it can be left: the hosted replica
- * moves the two buffers peers store into during a run -- log ring and mailbox -- to fresh allocations (device copies);
- * whoever still holds the old mappings stores into memory nobody reads.  out (may be NULL) = the handles with the two new
- * buffers, fences + 1.  A server calls it when it adopts a newer term (apus_amd/peers.py: elect; apus_amd/host/apus_proxy.c:
- * group_failover -- at EVERY election), the members of the new term then call apus_gpu_remap_fenced with its handles (a no-op
- * for a replica whose `fences` they already know).  BOUND: the buffers a replica has left stay allocated -- a stale writer
- * hits memory that exists -- and the oldest pair is taken into use again at the ninth fence: a leader deposed eight terms ago
- * whose kernel is STILL storing is outside the failure model (its process steps down at the first newer announcement it sees
- * and parks its kernel).
+ * moves the two buffers peers store into during a run -- log ring and mailbox -- to the next of its APUS_FENCE_PAIRS pairs
+ * (device copies); whoever still runs on the old pointers stores into memory nobody reads.  The pairs are allocated when the
+ * replica is first exported and a peer maps them ALL with apus_gpu_import_replica: nothing is allocated, exported, opened or
+ * closed at election time (the first cut of round 6 did, and the soak caught the runtime handing one address range to two
+ * mappings after a few close/open cycles between runs).  out (may be NULL) = the handles, fences + 1.  A server calls it
+ * when it adopts a newer term (apus_amd/peers.py: elect; apus_amd/host/apus_proxy.c: group_failover -- at EVERY election),
+ * the members of the new term then call apus_gpu_remap_fenced with its handles: the pointers their next run is given are
+ * switched to pair[fences % APUS_FENCE_PAIRS] (a no-op for a replica whose `fences` they already know).
+ * BOUND: a pair is lived in again APUS_FENCE_PAIRS fences after it was left: a leader deposed that many terms ago whose
+ * kernel is STILL storing is outside the failure model (its process steps down at the first newer announcement it sees and
+ * parks its kernel; the reference's QP reset has no such bound).
  * APUS_E_STATE while a resident kernel or a batch is open, and for an engine that has captured graphs. */
 int  apus_gpu_fence_replica(apus_engine_t *e, uint32_t replica, apus_ipc_replica_t *out);
 int  apus_gpu_remap_fenced(apus_engine_t *e, const apus_ipc_replica_t *in);
@@ -375,6 +381,9 @@ int  apus_gpu_rep_prune(apus_engine_t *e);                                   /* 
 /* a list of such commands in one call: cmds[3 i] = 1 (prune tick) | 2 (rounds [cmds[3 i + 1], + cmds[3 i + 2]) of the staged input),
  * the whole list `repeat` times over */
 int  apus_gpu_rep_cmds(apus_engine_t *e, const uint64_t *cmds, uint32_t n, uint32_t repeat);
+/* the run the leader started last: out[0] = the followers that get its rounds (they held everything the leader had when it began),
+ * out[1] = the followers it could reach; one that is in out[1] only sits the run out until a control-plane pass has caught it up */
+int  apus_gpu_rep_push_info(apus_engine_t *e, uint32_t out[2]);
 int  apus_gpu_rep_drain(apus_engine_t *e, uint32_t timeout_ms);
 int  apus_gpu_rep_full(apus_engine_t *e);                                    /* rounds refused because the log was full */
 uint64_t apus_gpu_rep_highest_rec(apus_engine_t *e);

@@ -8,6 +8,8 @@ import os
 import signal
 import socket
 import struct
+import atexit
+import shutil
 import subprocess
 import tempfile
 import threading
@@ -25,9 +27,16 @@ CFG_LEN = struct.calcsize(CFG_FMT)
 class Group:
     """n redis-server processes, one replica each; `capacity` > n leaves room for machines that JOIN."""
 
+    _old_tmp = []
+
     def __init__(self, n, log_len=1 << 24, capacity=None, rep_append=8, rep_fwork=4):
         self.n, self.log_len, self.capacity = n, log_len, capacity or n
+        # (a group's directory holds its servers' replica dumps -- tens of MiB each -- and is read after close(): the one before
+        #  this one has been looked at by now; the last one goes at exit.  A soak of thirty runs filled /tmp without this.)
+        while Group._old_tmp:
+            shutil.rmtree(Group._old_tmp.pop(), ignore_errors=True)
         self.tmp = tempfile.mkdtemp()
+        Group._old_tmp.append(self.tmp)
         self.gdir = os.path.join(self.tmp, "group")
         os.makedirs(self.gdir)
         self.hook = os.path.join(ROOT, "apus_amd", "libapus_interpose.so")
@@ -42,6 +51,8 @@ class Group:
         self.nproc += 1
         os.makedirs(d)
         port = _free_port()
+        while port in self.ports.values():          # (the kernel hands a port that was just released out again: two servers of one group on one port)
+            port = _free_port()
         cfg = os.path.join(d, "node.cfg")
         open(cfg, "w").write(f'db_name = "node_{idx}";\nreq_log = 0;\nip_address = "127.0.0.1";\nport = {port};\n')
         env = dict(os.environ, group_size=str(self.n), APUS_GROUP_DIR=self.gdir, APUS_GROUP_CAPACITY=str(self.capacity),
@@ -179,6 +190,9 @@ class Group:
                 p.wait(timeout=30)
             except subprocess.TimeoutExpired:
                 pass
+
+
+atexit.register(lambda: [shutil.rmtree(t, ignore_errors=True) for t in Group._old_tmp])
 
 
 class Load:

@@ -99,7 +99,11 @@ def one_group(n, stats):
     for key, val in acked_all[:: max(1, len(acked_all) // 200)]:
         assert f"{key} {val}".encode() in bodies, f"{key} was acknowledged but is not in the log"
     cl = K.oracle_replay(n, LOG, ents, elections)
-    K.compare_with_oracle(cl, reps, rings, survivors)
+    try:
+        K.compare_with_oracle(cl, reps, rings, survivors)
+    except AssertionError:
+        g.postmortem("failover_postmortem.txt")
+        raise
     stats["entries"] += len(ents)
 
 

@@ -53,7 +53,7 @@ def parse_dump(path, n):
         w = line.split()
         reps.append({w[i]: int(w[i + 1]) for i in range(0, len(w), 2)})
     assert len(reps) == n
-    L = reps[0]["len"]
+    L = max(r["len"] for r in reps)        # (a place whose mapping was dropped -- a dead server -- reads as zeros)
     rings = [np.frombuffer(rest[i * L:(i + 1) * L], dtype=np.uint8) for i in range(n)]
     return reps, rings
 

@@ -104,3 +104,67 @@ def test_concurrent_submitters_all_commit():
     res = json.load(open(out))
     assert res["ok"], f"{res.get('error')}\n{p.stderr[-1500:]}"
     assert res["total"] == 8 * 2001 and res["connections"] == 8
+
+
+@pytest.mark.parametrize("threads,block,lens", [(4, 1000, (64, 40)), (3, 4096, (64,)), (5, 257, (17, 64, 96, 300))])
+def test_concurrent_producers_with_odd_blocks_and_mixed_lengths(threads, block, lens):
+    """Round 6: the request ring's WINDOW words (RepReq.ready_win: one word per aligned window of 64 slots, written by whoever
+    completes the window with requests of one length; producers that share a window settle it through counts in host memory,
+    apus_engine.hip: rep_win_note) under what they were built for and what they must survive: several producer threads
+    (apus_gpu_rep_submit, side by side) submitting the same block over and over -- block sizes that are not multiples of 64 (every block starts
+    inside a window the producer before it began), lengths that change inside windows (no word: those go round by round), payloads
+    too long for a slot (the arena path), one length throughout (every window gets its word).  The order in which concurrent
+    producers' requests enter the log is theirs; checked is everything that does not depend on it: every request was committed and
+    applied on every replica (highest_rec, offsets), the replicas are bit-identical -- and an ORACLE REPLAY of the leader's log in
+    the order it has (tests/_cluster.py: oracle_replay) gives the same rings and offsets bit for bit.
+    Reference: leader_handle_submit_req + get_tailq_message, src/proxy/proxy.c:108-161, dare_ibv_ud.c:780-790."""
+    from apus_amd.engine import Engine
+    from tests import _cluster as K
+    n_rep, L = 3, T.DEFAULT_LOG
+    rng = np.random.default_rng(7)
+    conns = 8
+    lens_req = np.asarray(lens, dtype=np.int64)[rng.integers(0, len(lens), block)]
+    types = np.concatenate([np.full(conns, T.CONNECT), np.full(block, T.SEND)]).astype(np.uint8)
+    fds = np.concatenate([np.arange(conns), np.arange(block) % conns]) + 100
+    reqs, arena, _ = T.build_requests(types, fds, np.concatenate([np.zeros(conns, dtype=np.int64), lens_req]), 0)
+    blk = np.ascontiguousarray(reqs[conns:])
+    eng = Engine(n_rep, L)
+    try:
+        eng.elect(0)
+        eng.sync()
+        eng.rep_start(idle_ms=5000, peer_ms=1000)
+        hr0 = eng.rep_highest_rec()
+        passes, errs = 6, []
+
+        def producer():
+            try:
+                for _ in range(passes):
+                    eng.rep_submit(blk, arena)               # (ctypes drops the GIL: the producers really run side by side)
+            except Exception as exc:                         # noqa: BLE001
+                errs.append(repr(exc))
+        th = [threading.Thread(target=producer) for _ in range(threads)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(60)
+        assert not errs, errs
+        n = threads * passes * block
+        eng.rep_drain(timeout_ms=20000)
+        assert eng.rep_highest_rec() == hr0 + n, (n, eng.rep_highest_rec(), eng.rep_stats())
+        assert eng.rep_park() == 0
+        eng.quiesce()
+        assert eng.status() == 0, eng.status_names()
+        o0 = eng.offsets(0)
+        assert o0["commit"] == o0["end"] == o0["apply"] and o0["end"] < L and o0["head"] == 0, o0   # (one lap, no prune tick: the replay below starts at offset 0)
+        rings = {r: eng.ring(r) for r in range(n_rep)}
+        reps = {r: eng.offsets(r) for r in range(n_rep)}
+        for r in (1, 2):
+            assert (reps[r]["commit"], reps[r]["end"], reps[r]["apply"]) == (o0["commit"], o0["end"], o0["apply"]), (r, reps[r], o0)
+        ents = K.log_entries(rings[0], o0["end"])
+        sends = [e for e in ents if e[2] == T.SEND]
+        assert len(sends) == n and [e[0] for e in ents] == list(range(1, len(ents) + 1))
+        # every producer's pass over the block is in the log in the block's order (a producer's own requests never overtake each other)
+        cl = K.oracle_replay(n_rep, L, ents, [])
+        K.compare_with_oracle(cl, reps, rings, [0, 1, 2])
+    finally:
+        eng.close()
