@@ -595,14 +595,16 @@ extern "C" int apus_gpu_rep_box_words(apus_engine_t *e, uint32_t replica, uint32
 /* ---- the receiver's fence (rc_revoke_log_access, dare_ibv_rc.c:2156-2243) for peer-mapped groups --------------------
  * The reference's voters reset the QPs of the old leader: its WRITEs bounce.  A buffer another process has mapped cannot be
  * taken back, but it can be LEFT: the replica this engine hosts moves the two buffers peers store into during a run -- its
- * log ring and its mailbox (doorbells, commit bell, cumulative ACKs) -- to fresh allocations (device copies of the old
- * ones).  Every mapping another process holds of the old ones, a deposed leader's first of all, leads to memory nobody
- * reads any more; its kernel may go on storing for as long as it likes.  `out` = the replica's handles with the two new
- * buffers (the other six unchanged): the members of the new term map them with apus_gpu_remap_fenced.  The old
- * allocations stay allocated (a stale writer must hit memory that exists); from the ninth fence on the oldest pair is
- * reused -- a leader deposed EIGHT terms ago whose kernel still stores would write into the live ring again: outside the failure
- * model, and said so in include/apus_gpu.h (a deposed leader's process steps down when it sees a newer term's announcement, its
- * kernel parks within peer_ms; eight elections take seconds).
+ * log ring and its mailbox (doorbells, commit bell, cumulative ACKs) -- to the next of its APUS_FENCE_PAIRS pairs (device
+ * copies of the old ones).  Every pointer another process still runs on, a deposed leader's first of all, leads to memory
+ * nobody reads any more; its kernel may go on storing for as long as it likes.  `out` = the replica's handles, fences + 1:
+ * the members of the new term follow with apus_gpu_remap_fenced.  All pairs are allocated at the first export, their handles
+ * taken once, and mapped by a peer together with the replica: a fence allocates, exports, opens and closes NOTHING (the first
+ * cut of round 6 did all four between two runs, and the soak found the runtime handing one address range to two mappings:
+ * DESIGN.md 8.1).  A pair is lived in again APUS_FENCE_PAIRS fences after it was left -- a leader deposed that many terms
+ * ago whose kernel still stores would write into the live ring again: outside the failure model, and said so in
+ * include/apus_gpu.h (a deposed leader's process steps down when it sees a newer term's announcement, its kernel parks within
+ * peer_ms).
  * The buffers peers write only from control-plane launches (control block, directory, apply stream: log adjustment, JOIN)
  * stay where they are: those launches sit behind the sender's term check (k_fence_check).
  * Not while a resident kernel or a batch is open; graphs captured before the fence hold the old pointers (peer-mapped groups
