@@ -35,4 +35,4 @@ for g in (3,):
 print(json.dumps(out))
 PY
 done
-timeout 400 python -m pytest tests/test_gpu_replica.py tests/test_gpu_e2e_redis.py tests/test_gpu_host_path.py -m gpu -q -x --timeout 300 -s 2>&1 | grep -v "^W0\|amdgpu.ids" | grep -i "passed\|failed\|error\|SET\|req/s\|k/s" | tail -12 | cut -c1-300
+[ -n "$LAT_ONLY" ] || timeout 400 python -m pytest tests/test_gpu_replica.py tests/test_gpu_e2e_redis.py tests/test_gpu_host_path.py -m gpu -q -x --timeout 300 -s 2>&1 | grep -v "^W0\|amdgpu.ids" | grep -i "passed\|failed\|error\|SET\|req/s\|k/s" | tail -12 | cut -c1-300
