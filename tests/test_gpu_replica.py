@@ -318,3 +318,46 @@ def test_rep_inherited_entries_commit_only_behind_the_terms_first_entry():
         assert eng.counters(0)["highest_rec"] == len(tr.reqs)
     finally:
         eng.close()
+
+
+def test_rep_a_replica_moves_through_its_fence_pairs_and_round_again():
+    """apus_gpu_fence_replica (include/apus_gpu.h): a replica lives in pair fences % APUS_FENCE_PAIRS of its (log ring, mailbox)
+    pairs; the pairs are allocated once, a fence copies the replica into the NEXT one -- which, from the fourth fence on, holds
+    what the replica looked like four fences ago.  Here every replica of a group of three (the leader's too) is fenced between
+    the runs of a trace, nine times each -- twice round the pairs -- and the logs, offsets and apply streams are the oracle's
+    at the end; the ring a replica left one fence ago still reads as it stood then; a ring left APUS_FENCE_PAIRS fences ago is
+    the live one again and is refused."""
+    import ctypes as C
+    from apus_amd import _lib
+    base = T.steady_trace(3, 9000, (64, 107, 300), 8, (8, 64), log_len=1 << 20, prune_bytes=1 << 17, seed=11)
+    ev, k = [], 0
+    for e in base.events:
+        ev.append(e)
+        if e[0] == "ROUND":
+            k += 1
+            if k % 8 == 0:
+                ev.append(("QUIESCE",))
+    ev.append(("QUIESCE",))
+    base.events = ev
+    seen = {"fences": 0, "checked": 0}
+
+    def on_event(i, event, eng):
+        if event[0] != "QUIESCE":
+            return
+        L = eng.L
+        for r in range(3):
+            before = np.empty(4096, dtype=np.uint8)
+            eng._chk(L.apus_gpu_read_ring(eng.h, r, 0, 4096, before.ctypes.data), "read_ring")
+            out = _lib.IpcReplica()
+            eng._chk(L.apus_gpu_fence_replica(eng.h, r, C.byref(out)), "fence_replica")
+            seen["fences"] += 1
+            assert out.fences == seen["fences"] // 3 + (1 if seen["fences"] % 3 else 0), (out.fences, seen)
+            after, left = np.empty(4096, dtype=np.uint8), np.empty(4096, dtype=np.uint8)
+            eng._chk(L.apus_gpu_read_ring(eng.h, r, 0, 4096, after.ctypes.data), "read_ring")
+            eng._chk(L.apus_gpu_read_retired_ring(eng.h, r, 1, 0, 4096, left.ctypes.data), "read_retired_ring")
+            assert (after == before).all() and (left == before).all()
+            assert L.apus_gpu_read_retired_ring(eng.h, r, 4, 0, 4096, left.ctypes.data) != 0      # (that pair is lived in again)
+            seen["checked"] += 1
+
+    run_and_compare(base, "staged", on_event=on_event)
+    assert seen["fences"] >= 27, seen
