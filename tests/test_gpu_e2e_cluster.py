@@ -62,7 +62,11 @@ def test_three_redis_processes_replicate_and_fail_over():
     gdir = os.path.join(tmp, "group")
     os.makedirs(gdir)
     hook = os.path.join(ROOT, "apus_amd", "libapus_interpose.so")
-    ports = [_free_port() for _ in range(n)]
+    ports = []
+    while len(ports) < n:                     # (distinct: the kernel hands a port that was just released out again)
+        p = _free_port()
+        if p not in ports:
+            ports.append(p)
     clean = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
     procs, logs, dumps = [], [], []
     try:
