@@ -22,6 +22,8 @@
 #include "apus_selftest.h"
 #include "apus_members.h"
 #include <pthread.h>
+#include <sched.h>
+#include <dirent.h>
 #include <time.h>
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { \
@@ -3345,18 +3347,110 @@ extern "C" int apus_gpu_calib_store_bw(apus_engine_t *e, uint32_t peer, uint64_t
  * over and over for `seconds`; thread 0 also plays the prune timer (one tick per prune_bytes of log).  Then
  * everything is drained.  out[0] = requests submitted, out[1] = nanoseconds from the first submit to the
  * drain's end. */
+/* Where the device hangs: the NUMA node of its PCIe root (sysfs), -1 when the platform does not say.  On a two-socket host a
+ * producer on the OTHER socket writes the request ring through the inter-socket link as well: round 6 measured 130 against 166 M
+ * entries/s for one producer, 280 against 346 for four (profiles/r06_numa.txt). */
+extern "C" int apus_gpu_numa_node(int device)
+{
+    char bus[64] = {0}, path[160];
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+/* the CPUs of a NUMA node this process may run on, in the order of the node's cpulist (physical cores first, their sibling
+ * threads behind them on the hosts seen here); returns how many */
+static int node_cpus(int node, int *out, int cap)
+{
+    char path[96], buf[1024] = {0};
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return 0;
+    const bool ok = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!ok) return 0;
+    cpu_set_t all;
+    if (sched_getaffinity(0, sizeof all, &all)) return 0;
+    int n = 0;
+    for (char *p = buf; *p && *p != '\n';) {
+        char *q; long a = strtol(p, &q, 10), b = a;
+        if (q == p) break;
+        if (*q == '-') { p = q + 1; b = strtol(p, &q, 10); }
+        for (long c = a; c <= b && n < cap; c++) if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET((int)c, &all)) out[n++] = (int)c;
+        p = *q == ',' ? q + 1 : q;
+    }
+    return n;
+}
+/* Binds the calling thread (who = 0) or the whole process as it stands (who = 1: every thread that exists now, and what they
+ * start later) to the CPUs of the device's NUMA node.  0: done; 1: nothing to do (one node, or the platform does not say). */
+extern "C" int apus_gpu_bind_near(apus_engine_t *e, int who)
+{
+    if (!e) return APUS_E_ARG;
+    const int node = apus_gpu_numa_node(e->cfg.device);
+    if (node < 0) return 1;
+    static int cpus[CPU_SETSIZE];
+    const int n = node_cpus(node, cpus, CPU_SETSIZE);
+    cpu_set_t all;
+    if (n <= 0 || sched_getaffinity(0, sizeof all, &all) || n >= CPU_COUNT(&all)) return 1;
+    cpu_set_t set; CPU_ZERO(&set);
+    for (int i = 0; i < n; i++) CPU_SET(cpus[i], &set);
+    if (!who) return pthread_setaffinity_np(pthread_self(), sizeof set, &set) ? APUS_E_STATE : 0;
+    /* every thread of the process: /proc/self/task */
+    int rc = 0;
+    if (DIR *d = opendir("/proc/self/task")) {
+        while (struct dirent *de = readdir(d)) {
+            const int tid = atoi(de->d_name);
+            if (tid > 0 && sched_setaffinity(tid, sizeof set, &set)) rc = APUS_E_STATE;
+        }
+        closedir(d);
+    } else rc = APUS_E_STATE;
+    return rc;
+}
+
 struct RepFeedArg { apus_engine *e; const apus_req_t *reqs; uint32_t n; const uint8_t *arena; uint64_t arena_bytes;
-                    double t_end; uint64_t prune_every; int tid; uint64_t done; int rc; };
+                    double t_end; uint64_t prune_every; int tid; uint64_t done; int rc; uint64_t *total; };
 static void *rep_feed_thread(void *p)
 {
     RepFeedArg *a = (RepFeedArg *)p;
-    uint64_t since = 0;
+    {   /* Where the producers run.  Default: producer i on a CPU of its own on the DEVICE'S NUMA node (the node's third CPU onwards:
+         * the first ones take the host's interrupts) -- on the two-socket hosts of the pool a producer on the other socket writes the
+         * ring through the inter-socket link as well, and two producers on sibling threads share a core's write-combining buffers:
+         * 131-162 / 201-231 / 284-291 / 391-402 M entries/s wherever the scheduler put 1 / 2 / 4 / 8 of them, 166 / 280 / 367 / 425
+         * like this (profiles/r06_numa.txt).  APUS_FEED_PIN=0: the scheduler's choice; =<stride>: the (i x stride)-th CPU the
+         * process may run on, whatever its node. */
+        const char *pin = getenv("APUS_FEED_PIN");
+        const int stride = pin && strcmp(pin, "node") ? atoi(pin) : -1;
+        static int cpus[CPU_SETSIZE];
+        cpu_set_t all;
+        if (stride < 0) {
+            const int node = apus_gpu_numa_node(a->e->cfg.device);
+            const int n = node >= 0 ? node_cpus(node, cpus, CPU_SETSIZE) : 0;
+            if (n > 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[(a->tid + (n > 8 ? 2 : 0)) % n], &one); pthread_setaffinity_np(pthread_self(), sizeof one, &one); }
+        } else if (stride > 0 && sched_getaffinity(0, sizeof all, &all) == 0) {
+            int want = a->tid * stride, seen = 0, n_all = CPU_COUNT(&all);
+            if (n_all > 0) want %= n_all;
+            for (int c = 0; c < CPU_SETSIZE; c++) {
+                if (!CPU_ISSET(c, &all)) continue;
+                if (seen++ == want) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(c, &one); pthread_setaffinity_np(pthread_self(), sizeof one, &one); break; }
+            }
+        }
+    }
     while (mono_s() < a->t_end) {
         int rc = apus_gpu_rep_submit(a->e, a->reqs, a->n, a->arena, a->arena_bytes);
         if (rc) { a->rc = rc; break; }
         a->done += a->n;
-        since += a->n;
-        if (a->tid == 0 && a->prune_every && since >= a->prune_every) { apus_gpu_rep_prune(a->e); since = 0; }
+        /* the prune tick belongs to the producers' TOTAL: whoever carries it over a multiple of prune_every issues it (round 5 let
+         * producer 0 count its own share -- with the producers on CPUs of their own they no longer run at one rate, producer 0
+         * fell behind once and the log ran full) */
+        if (a->prune_every) {
+            const uint64_t before = __atomic_fetch_add(a->total, (uint64_t)a->n, __ATOMIC_RELAXED);
+            if (before / a->prune_every != (before + a->n) / a->prune_every) apus_gpu_rep_prune(a->e);
+        }
     }
     return nullptr;
 }
@@ -3366,9 +3460,10 @@ extern "C" int apus_gpu_rep_feed(apus_engine_t *e, const apus_req_t *reqs, uint3
     if (!e || !e->r_running || !e->r_lead || !reqs || !n || n_threads == 0 || n_threads > 64 || !out) return APUS_E_ARG;
     RepFeedArg args[64];
     pthread_t th[64];
+    uint64_t shared_total = 0;
     const double t0 = mono_s();
     for (uint32_t i = 0; i < n_threads; i++) {
-        args[i] = RepFeedArg{ e, reqs, n, arena, arena_bytes, t0 + seconds, prune_every_reqs / n_threads, (int)i, 0, 0 };
+        args[i] = RepFeedArg{ e, reqs, n, arena, arena_bytes, t0 + seconds, prune_every_reqs, (int)i, 0, 0, &shared_total };
         if (pthread_create(&th[i], nullptr, rep_feed_thread, &args[i])) return APUS_E_STATE;
     }
     uint64_t total = 0; int rc = 0;

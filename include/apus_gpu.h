@@ -200,6 +200,16 @@ int  apus_gpu_remap_fenced(apus_engine_t *e, const apus_ipc_replica_t *in);
 /* tests: n bytes at off of the ring `replica` left `back` fences ago (1 = the last): where a deposed leader's stores went */
 int  apus_gpu_read_retired_ring(apus_engine_t *e, uint32_t replica, uint32_t back, uint64_t off, uint64_t n, void *dst);
 
+/* ---- where the device hangs (two-socket hosts) ---------------------------- */
+/* The NUMA node of the device's PCIe root (-1: the platform does not say).  A thread on the other socket reaches the request
+ * ring and the device's answers through the inter-socket link as well: one producer 130 against 166 M entries/s, four 280
+ * against 330-370 (round 6, profiles/r06_numa.txt).  apus_gpu_bind_near binds the calling thread (who = 0) or every thread of
+ * the process as it stands (who = 1) to that node's CPUs: 0 done, 1 nothing to do (one node / unknown).  A lone request's
+ * round trip does not change with it (17.5 us either way); nothing binds an application behind its back -- the producers of
+ * apus_gpu_rep_feed (bench.py's host-fed leg) are placed on the device's node, one CPU each (APUS_FEED_PIN). */
+int  apus_gpu_numa_node(int device);
+int  apus_gpu_bind_near(apus_engine_t *e, int who);
+
 /* ---- control plane (host-driven, ms-scale in the reference) ---------------- */
 /* Role/term change: the caller (host election logic) decided that `leader` won
  * term `term`; appends the blank CONFIG entry a new leader always writes
