@@ -75,6 +75,33 @@
 #define R_SUB     8              /* 64-round chunks a serial role handles per memory round trip (round 6: 4 -> 8, the committer and the applier
                                   * took 250 of 256 rounds per look at 7 G entries/s) */
 #endif
+/* Round 6, the lone request's path (host submit -> highest_rec): every hop below is one dependent memory round trip taken out.
+ *   REP_SPEC_PAY   a round from the request ring whose entries have ONE size carries it in its ticket (TK_D0; a pinned bulk pass: the
+ *                  record's PR_BPF): the append wavefront asks for the slots' inline payload TOGETHER with their descriptors and
+ *                  loads nothing a second time when the descriptors say what the ticket said
+ *   REP_APPLY_PRE  the leader's applier, idle, holds the done granules of the next ticket before the commit reaches it
+ *   REP_BELL16     a round doorbell is one 128-byte line: granules 8..15 = what emeta[] says of the round's first eight entries
+ *                  (a round of <= 8 entries: no second look by the follower's work wavefront)
+ *   REP_POLL_WIDE  an append wavefront that has waited this many polls looks at its ticket's eight words at once
+ * -D...=0: A/B measurements (profiles/r06_latency_ab.txt). */
+#ifndef REP_SPEC_PAY
+#define REP_SPEC_PAY 1
+#endif
+#ifndef REP_APPLY_PRE
+#define REP_APPLY_PRE 1
+#endif
+#ifndef REP_BELL16
+#define REP_BELL16 1
+#endif
+#ifndef REP_FAST_ACK
+#define REP_FAST_ACK 1              /* a follower's work wavefront that holds the very round its retire wavefront is waiting for acknowledges it itself */
+#endif
+#ifndef REP_POLL_WIDE
+#define REP_POLL_WIDE 0             /* (measured: 1536 idle wavefronts looking at twelve lines each instead of two cost the lone request 0.2-0.6 us) */
+#endif
+#define R_HOLD_MAX 2u                /* REP_APPLY_PRE: done tickets in front of the applier up to which it takes them one by one, holding their granules */
+#define R_QUIET    32u               /* ... and the idle passes in a row that say "rounds come one by one" */
+#define R_BELL_W  (REP_BELL16 ? 16 : 8)      /* granules per round doorbell */
 #define GP_MIN    256u           /* a pass of at least this many plain staged rounds is its record ALONE: no word per ticket (below) */
 #define GR_CAP    128u           /* such records in flight: RS_CAP / GP_MIN = 64 passes' tickets fill the ticket ring */
 #define GP_MAX    4096u          /* staged rounds ONE pass of the sequencer may take (one record; two words per ticket below GP_MIN) */
@@ -143,7 +170,7 @@ struct RepBox {
      *   [2] end offset before the round (len: the log read as empty)
      *   [3] n << 17 | T when all n entries are T bytes long, n << 17 when the sizes differ (lens[])
      * (written as a whole 64-byte line: a partial line is a read-modify-write in the memory that receives it) */
-    uint64_t rnd[RB_CAP][8];
+    uint64_t rnd[RB_CAP][R_BELL_W];      /* (round 6: sixteen granules, one 128-byte line; [8..15]: the first eight entries' emeta words) */
     uint16_t lens[RB_CAP][WAVE];         /* cmd.len of every entry of a round of mixed sizes (2 B per entry) */
     /* Round 5: what a follower needs to know of every entry of a client round beyond what the doorbell says -- clt_id, type,
      * sender: the third word of the header's second half, 4 B per entry -- so that it does not have to READ the headers that
@@ -166,6 +193,12 @@ struct RepBox {
     uint64_t applied_by[16];             /* entry slots applied                                 */
     uint64_t apply_off_by[16];           /* ... and the apply offset that goes with it (when the run ends) */
     uint64_t sid_by[16];                 /* a follower that moved on to a newer SID says so here: the term fence */
+    /* Round 6 (REP_FAST_ACK): the same count as persisted_by[], raised (atomic max, system scope) by the follower's WORK wavefront
+     * when the round it has just taken in is the one its retire wavefront stands in front of -- every round before it retired in
+     * order, this one continues them (RepFollow.ret_pub), every entry acknowledged, not an exact fit: what the retire wavefront
+     * will say one hand-off through memory later (~1 us of a lone round's commit latency).  The leader commits on the larger of
+     * the two words; persisted_by[] alone still carries every ACK. */
+    uint64_t persisted_fast_by[16];
     /* this replica's own notes, kept across runs of its follower workgroups */
     uint64_t f_seq_next;                 /* next round it expects                               */
     uint64_t f_pend_slot0, f_pend_slot_end, f_pend_sid;   /* an exact-fit round it holds back (its end == len) */
@@ -258,6 +291,9 @@ struct RepFollow {                       /* follower-local (device memory, agent
     uint64_t stat[3][8];                 /* retire / apply wavefront: passes, passes that moved something, rounds, wall-clock ticks; [2]: the work
                                           * wavefronts' phase timers (APUS_REP_DBG & 256): rounds, total, bell -> headers, headers -> stores issued, drain */
     uint64_t fr[FR_WORDS][RB_CAP];          /* granule-major, like the leader's done granules */
+    /* where the retire wavefront stands, for the work wavefronts (REP_FAST_ACK): granules {q_ret + 1 : low half of the end offset /
+     * of the slot count every round before q_ret left} -- not valid (0) while an exact-fit round is held back */
+    uint64_t ret_pub[8];
 };
 /* a follower's first workgroup: its retire / apply wavefronts' words in LDS */
 enum { F_END = 0, F_N_END, F_Q_RET, F_R_FINAL, F_STORE_COUNT, F_PEND_N, F_PEND_SLOT_END, F_EXIT, F_WORDS = 8 };
@@ -1194,7 +1230,10 @@ __device__ static inline void rep_sequencer(const EngDev &E, const RepArgs &A, l
             if (n == 0) break;
             any = true;
             const uint32_t T = lane < n ? APUS_HDR + (v[wdw] & 0xFFFFu) : 0u;
-            if (!rep_seq_round(E, X, S, LS, T, n, R_SRC_PINNED, req_head, 0, 0, 0)) {
+            /* (TK_D0 of a round from the request ring: its entries' one size, 0 when they differ -- REP_SPEC_PAY) */
+            const uint32_t T0s = rl32u(T, 0);
+            const uint64_t d0u = (REP_SPEC_PAY && !__ballot(lane < n && T != T0s)) ? (uint64_t)T0s : 0ull;
+            if (!rep_seq_round(E, X, S, LS, T, n, R_SRC_PINNED, req_head, 0, d0u, 0)) {
                 /* refused: the requests are dropped (get_tailq_message frees the node anyway), the host is told */
                 if (lane == 0) { set_status(E, 1u << 1); st_sys(&H->full, ld_sys(&H->full) + 1); }
                 dropped += n;                                                        /* slots consumed without a ticket */
@@ -1331,6 +1370,9 @@ __device__ static inline void rep_commit_pass(const EngDev &E, RepLead *LS, RepC
         }
     }
     const uint64_t pbw = lane < 16 ? ld_sys(&mybox->persisted_by[lane]) : 0ull;
+#if REP_FAST_ACK
+    const uint64_t pbf = lane < 16 ? ld_sys(&mybox->persisted_fast_by[lane]) : 0ull;
+#endif
 #pragma unroll
     for (int s = 0; s < R_SUB; s++) {
         if (C.t_done != base + (uint64_t)s * WAVE || (uint32_t)s >= nsub) break;           /* (chunk s is looked at only when every chunk before it is in whole) */
@@ -1366,7 +1408,10 @@ __device__ static inline void rep_commit_pass(const EngDev &E, RepLead *LS, RepC
     uint64_t acked = ~0ull;
     if (quorum > 1) {
         const bool mem = lane < 16 && ((members >> lane) & 1u) && (pbw >> 40) == my_tag;
-        const uint64_t val = mem ? (pbw & PB_VAL) : 0ull;
+        uint64_t val = mem ? (pbw & PB_VAL) : 0ull;
+#if REP_FAST_ACK
+        if (lane < 16 && ((members >> lane) & 1u) && (pbf >> 40) == my_tag && (pbf & PB_VAL) > val) val = pbf & PB_VAL;
+#endif
         uint32_t rank = 0;                                           /* values above this lane's (ties: the lower lane first) */
 #pragma unroll
         for (int j = 0; j < 16; j++) {
@@ -1523,16 +1568,81 @@ __device__ static inline void rep_applier(const EngDev &E, const RepArgs &A, lds
     uint32_t lat_n = 0;
     uint64_t st_pass = 0, st_prog = 0, st_busy = 0;
     const uint64_t st_t0 = wall_clock64();
+#if REP_APPLY_PRE
+    bool pre_have = false, pre_lat = false, lone_ok = false;             /* the lone-round path's held granules: ticket pre_t's */
+    uint32_t quiet = 0;
+    uint64_t pre_t = 0, p1 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0, p7 = 0;
+#endif
     for (;;) {
         st_pass++;
         const uint64_t st_p0 = (A.dbg & 512) ? wall_clock64() : 0;
-        const uint64_t cfin = s_m[M_C_FINAL];
-        const uint64_t cs = s_m[M_CS], t_done = s_m[M_T_DONE];
+        /* (the committer's words as SCALARS: a value read from LDS is a vector value to the compiler, and every branch below that
+         *  depends on one is compiled as a divergent one -- with the lone-round path in front of it the general path's loads ended
+         *  up under exec masks, 3.2 -> 3.8 us per pass) */
+        const uint64_t cfin = rl64u(s_m[M_C_FINAL], 0);
+        const uint64_t cs = rl64u(s_m[M_CS], 0), t_done = rl64u(s_m[M_T_DONE], 0);
         bool progress = false;
+#if REP_APPLY_PRE
+        /* ---- rounds that come one by one (at most R_HOLD_MAX done tickets in front of the applier).  The commit is the last
+         *      thing a lone round waits for, and its done granules were in memory long before (the append wavefront stored them
+         *      when the bytes were in every ring; the committer counted the ticket as done then): this path asks for the next
+         *      ticket's chunk of granules ONCE, holds it when that ticket's own are there, and from then on watches the
+         *      committer's words in LDS alone -- when the commit comes the round is applied without another round trip (the
+         *      general path below reads the commit first and loads second: a pass in flight fails on the commit it read before
+         *      its loads and the next one loads again, 1.5 round trips behind the commit on average).  Granules are valid the
+         *      moment they carry their ticket's tag and never change afterwards; lanes whose tickets were not done when the
+         *      chunk was loaded fail their tag as they would have then, and are asked for again.  A path of its own, the general
+         *      one untouched: with a queue of done tickets a held chunk is 64 rounds' worth of a pass that can take 512, and a
+         *      branch inside the general path's loads cost it 0.8 us per pass (8.6 -> 7.9 G entries/s at one replica). ---- */
+        /* (quiet: the applier found nothing to do R_QUIET passes in a row before this round came -- under load it never does, and there a
+         *  catch-up of a few tickets taken one by one here, a round trip each, cost the general path 7 % at one replica) */
+        if (t_app >= t_done) { if (++quiet >= R_QUIET) lone_ok = true; } else quiet = 0;
+        if (lone_ok && t_app < t_done && t_done - t_app <= R_HOLD_MAX) {
+            if (!(pre_have && pre_t == t_app)) {
+                /* (the next ticket's granules alone, kept as scalars: six more vector registers alive across the general path's
+                 *  96 cost it 0.6 us per pass) */
+                const uint64_t ix = t_app % RS_CAP;
+                uint64_t v1 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0;
+                pre_lat = lat_n < R_LAT_CAP && !(A.dbg & 2048);
+                if (lane == 0) {
+                    v1 = ld_agent(&LS->dn[DN_SLOT_END][ix]); v3 = ld_agent(&LS->dn[DN_HASH_LO][ix]); v4 = ld_agent(&LS->dn[DN_HASH_HI][ix]);
+                    v5 = ld_agent(&LS->dn[DN_NCLIENT][ix]);
+                    if (pre_lat) { v6 = ld_agent(&LS->dn[DN_T_APPENDED][ix]); v7 = ld_agent(&LS->dn[DN_T_SEQUENCED][ix]); }
+                }
+                p1 = rl64u(v1, 0); p3 = rl64u(v3, 0); p4 = rl64u(v4, 0); p5 = rl64u(v5, 0); p6 = rl64u(v6, 0); p7 = rl64u(v7, 0);
+                pre_have = rep_gran_ok(p1, t_app) && rep_gran_ok(p3, t_app) && rep_gran_ok(p4, t_app) && rep_gran_ok(p5, t_app)
+                           && (!pre_lat || (rep_gran_ok(p6, t_app) && rep_gran_ok(p7, t_app)));
+                pre_t = t_app;
+            }
+            const uint64_t slot_end = rep_extend(n_apply, (uint32_t)p1);
+            if (pre_have && slot_end <= cs) {
+                const uint32_t nc = (uint32_t)p5;
+                hash += (uint64_t)(uint32_t)p3 | (p4 << 32);
+                ncl += nc;
+                n_apply = slot_end;
+                if (pre_lat) {
+                    const uint32_t now = (uint32_t)wall_clock64(), t_seq = (uint32_t)p7, t_apd = (uint32_t)p6;
+                    if (lane == 0 && t_seq && lat_n < R_LAT_CAP) { LS->lat_ticks[lat_n] = now - t_seq; LS->lat_app[lat_n] = now - t_apd; }
+                    lat_n = min(lat_n + 1u, R_LAT_CAP);
+                }
+                t_app += 1;
+                progress = true;
+                pre_have = false;
+                if (lane == 0) {
+                    s_m[M_N_APPLY] = n_apply; s_m[M_T_RETIRED] = t_app;
+                    if (nc && !(A.dbg & 2048)) st_sys(&H->highest_rec, hr0 + ncl);
+                }
+            }
+        } else
+#endif
         if (t_app < t_done) {
+#if REP_APPLY_PRE
+            lone_ok = false;
+            t_app = rl64u(t_app, 0); n_apply = rl64u(n_apply, 0);      /* (scalars for the compiler: the lone-round path above updates them under a branch) */
+#endif
             uint64_t g1[R_SUB], g3[R_SUB], g4[R_SUB], g5[R_SUB], g6[R_SUB], g7[R_SUB];
-            const uint32_t nsub = (uint32_t)min((uint64_t)R_SUB, (t_done - t_app + WAVE - 1) / WAVE);       /* (as many chunks as rounds are done) */
-            const bool want_lat = lat_n < R_LAT_CAP && !(A.dbg & 2048);         /* (the two time stamps only while latency samples are still being kept) */
+            const uint32_t nsub = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint64_t)R_SUB, (t_done - t_app + WAVE - 1) / WAVE));       /* (as many chunks as rounds are done) */
+            const bool want_lat = __builtin_amdgcn_readfirstlane((int)(lat_n < R_LAT_CAP && !(A.dbg & 2048))) != 0;         /* (the two time stamps only while latency samples are still being kept) */
 #pragma unroll
             for (int s = 0; s < R_SUB; s++) {
                 g1[s] = 0; g3[s] = 0; g4[s] = 0; g5[s] = 0; g6[s] = 0; g7[s] = 0;
@@ -1601,6 +1711,9 @@ struct RepAppLds {
     uint32_t ubase[WAVE + 1];
     uint4    h0[WAVE];
     uint4    h1[WAVE];
+#if REP_SPEC_PAY
+    uint4    spec[WAVE];                 /* unit `lane`'s payload bytes as they came with the descriptors (kept here, not in registers, across the placement) */
+#endif
 };
 
 /* reply bytes (dare_log_entry_t.reply[i] at byte 28 + i) of the servers in `mask4` (four of them) as the bytes of one word */
@@ -1652,7 +1765,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             /* after two looks that missed, only the word that is stored last and the first record are polled until one of
              * them carries its tag (a ticket's words sit in eight lines, the records in four more) */
             bool full = true;
-            if (i >= 2) {
+            if (i >= 2 && (REP_POLL_WIDE == 0 || i < REP_POLL_WIDE)) {      /* (a wavefront that has waited long is waiting for a lone round: one look) */
                 uint64_t m = 0;
                 if (lane == 0) m = ld_agent(&LS->tkw[TK_META][kx]);
                 else if (lane == 8) m = ld_agent(&LS->grec[g_next % GR_CAP][0]);
@@ -1711,6 +1824,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         if (!giant && lane == 0) st_agent(&LS->tkw[TK_META][kx], 0ull);
         wv &= TK_VAL;
         uint64_t e0, idx0, slot0, first, end_after, d0, d1, meta;
+        uint32_t spec_T = 0;                          /* REP_SPEC_PAY: the one size of a round from the request ring, as its ticket / record says */
         ReqDev dbulk; dbulk.req_id = 0; dbulk.pay16_type = 0; dbulk.len = 0; dbulk.clt_id = 0;
         if (bulk || giant) {
             /* the ticket's eight words from the pass record and the staged prefix sums */
@@ -1766,6 +1880,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                 e0 = end0 + r * WAVE * bpf; idx0 = pidx0 + r * WAVE; slot0 = pslot0 + r * WAVE; first = bfirst;
                 end_after = e0 + (uint64_t)WAVE * bpf; d0 = 0; d1 = ps & 0xFFFFFFFFull;
                 meta = (uint64_t)WAVE | ((uint64_t)R_SRC_PINNED << 8) | ((ps >> 32) << 32);
+                spec_T = (uint32_t)bpf;
                 if (lane == 0 && (k - t0 != r || bfirst != ((brf + r * WAVE) & 0xFFFFFFFFull)) && !(atomicOr(E.status, 1u << 3) & (1u << 3))) { E.status[3] = (uint32_t)k; E.status[4] = (uint32_t)r; E.status[5] = (uint32_t)(k - t0); E.status[6] = 0xB01Du; }
             } else {
             e0 = end0 + (pf0 - bpf); idx0 = pidx0 + (rf0 - brf); slot0 = pslot0 + (rf0 - brf); first = rf0;
@@ -1776,6 +1891,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         } else {
             e0 = rdl64(wv, TK_E0); idx0 = rdl64(wv, TK_IDX0); slot0 = rdl64(wv, TK_SLOT0); first = rdl64(wv, TK_SRC);
             end_after = rdl64(wv, TK_END); d0 = rdl64(wv, TK_D0); d1 = rdl64(wv, TK_D1); meta = rdl64(wv, TK_META);
+            if (((meta >> 8) & 0xF) == R_SRC_PINNED) spec_T = (uint32_t)d0;
         }
         const uint32_t n = (uint32_t)(meta & 0xFF), kind = (uint32_t)(meta >> 8) & 0xF, ctype = (uint32_t)(meta >> 16) & 0xFF;
         const uint32_t hidden = (uint32_t)(meta >> 12) & 1u;
@@ -1785,16 +1901,30 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         /* ---- get_tailq_message: the requests of the round ---- */
         ReqDev d; d.req_id = 0; d.pay16_type = 0; d.len = 0; d.clt_id = 0;
         const uint8_t *src = nullptr;
+        uint4 spec_v = make_uint4(0, 0, 0, 0);
+        const bool spec_try = REP_SPEC_PAY && kind == R_SRC_PINNED && spec_T > APUS_HDR && spec_T - APUS_HDR <= R_INLINE && !(spec_T & 15u)
+                              && ((spec_T >> 4) & ((spec_T >> 4) - 1)) == 0 && n * (spec_T >> 4) <= WAVE;      /* (a small round: <= 64 units of 16 bytes) */
         if (kind == R_SRC_PINNED) {
             /* descriptors and payload sit in host memory whose lines this CU may hold from an earlier, partly
              * filled state (a vector L1 is never refreshed by anybody's stores): drop them */
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+#if REP_SPEC_PAY
+            /* the first 64 units' payload bytes, asked for with the descriptors: unit `lane` of a round whose entries are all spec_T
+             * bytes long with their payload in the slot (what the loop below asks for in its first pass, when the descriptors agree) */
+            if (spec_try) {
+                const uint32_t s_upe = spec_T >> 4, s_so = 16u * (lane & (s_upe - 1)), s_e = lane >> __builtin_ctz(s_upe);
+                if (s_so >= 48 && s_e < n) spec_v = ld16u((const uint8_t *)A.RQ->slot[(first + s_e) % RQ_CAP].pay + s_so - 50);
+            }
+#endif
             if (active) {
                 const RepSlot *sl = &A.RQ->slot[(first + lane) % RQ_CAP];
                 const uint4 q = *(const uint4 *)&sl->d;
                 d.req_id = (uint64_t)q.x | ((uint64_t)q.y << 32); d.pay16_type = q.z; d.len = (uint16_t)(q.w & 0xFFFF); d.clt_id = (uint16_t)(q.w >> 16);
                 src = (d.pay16_type & 0x0FFFFFFFu) == R_PAY_INLINE ? sl->pay : A.RQ->arena + (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16;
             }
+#if REP_SPEC_PAY
+            if (spec_try) lds.spec[lane] = spec_v;          /* (loads return in order: it is here when the descriptors are) */
+#endif
         } else if (kind == R_SRC_STAGED) {
             if (active) { if (bulk) d = dbulk; else d = E.req[first + lane]; src = E.arena + (uint64_t)(d.pay16_type & 0x0FFFFFFFu) * 16; }
         } else {
@@ -1820,6 +1950,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         const uint32_t T0 = rl32u(T, 0);
         const bool uniform = !__ballot(active && T != T0);
         const bool bell_meta = kind != R_SRC_CONTROL && !(A.dbg & 16384);      /* client rounds: the followers need not read the headers back */
+        const bool spec_ok = spec_try && uniform && T0 == spec_T && !__ballot(active && (d.pay16_type & 0x0FFFFFFFu) != R_PAY_INLINE);
         uint64_t mix = 0;
         uint32_t client = 0;
         uint4 ar0 = make_uint4(0, 0, 0, 0), ar1 = ar0;
@@ -1850,7 +1981,7 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
                 const uint32_t f = (uint32_t)__builtin_ctz(m);
                 __hip_atomic_store((APUS_GLOBAL uint16_t *)(uintptr_t)&PT.box[f]->lens[(PT.qbase[f] + k) % RB_CAP][lane], (uint16_t)d.len, RLX_SYSTEM);
             }
-            if (bell_meta) for (uint32_t m = push; m; m &= m - 1) {
+            if (bell_meta && (!REP_BELL16 || n > 8)) for (uint32_t m = push; m; m &= m - 1) {       /* (<= 8 entries: the words ride in the doorbell) */
                 const uint32_t f = (uint32_t)__builtin_ctz(m);
                 __hip_atomic_store((APUS_GLOBAL uint32_t *)(uintptr_t)&PT.box[f]->emeta[(PT.qbase[f] + k) % RB_CAP][lane], h1.z, RLX_SYSTEM);
             }
@@ -1895,6 +2026,31 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
             }
             if (so == 48 && !is_ctl) ins = (uint64_t)(P & 0xFFFFu);
             const uint4 ctlv = make_uint4((uint32_t)d0, (uint32_t)(d0 >> 32), (uint32_t)d1, (uint32_t)(d1 >> 32));
+#if REP_SPEC_PAY
+            if (spec_ok) {
+                /* a small round from the request ring (<= 64 units: spec_try) whose payload bytes came with its descriptors: unit
+                 * `lane`, nothing to load, nothing to wait for */
+                const uint32_t e = min(lane >> sh, n - 1);
+                uint4 vv;
+                if (so == 0) vv = lds.h0[e];
+                else if (so == 16) vv = lds.h1[e];
+                else if (so == 32) vv = make_uint4(0, 0, 0, 0);
+                else {
+                    const uint4 sv = lds.spec[lane];
+                    const uint64_t lo = (((uint64_t)sv.x | ((uint64_t)sv.y << 32)) & mlo) | ins;
+                    const uint64_t hi = ((uint64_t)sv.z | ((uint64_t)sv.w << 32)) & mhi;
+                    vv = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+                }
+                for (uint32_t m = rings; m; m &= m - 1) {
+                    const uint32_t ri = (uint32_t)__builtin_ctz(m);
+                    const uint32_t rmask = preset ? (ri == me ? push : (1u << ri)) : 0u;
+                    uint4 rb = make_uint4(0, 0, 0, 0);
+                    if (so == 16) rb.w = rep_spread4(rmask & 0xFu);
+                    else if (so == 32) { rb.x = rep_spread4((rmask >> 4) & 0xFu); rb.y = rep_spread4((rmask >> 8) & 0xFu); rb.z = (rmask >> 12) & 1u; }
+                    if (lane < utotal) st16_wt(PT.ring[ri] + e0 + 16ull * lane, make_uint4(vv.x | rb.x, vv.y | rb.y, vv.z | rb.z, vv.w | rb.w));
+                }
+            } else
+#endif
             for (uint32_t u0 = lane; u0 < utotal; u0 += WAVE * ILP) {
                 if (timed && u0 >= WAVE * ILP && !t_it1) t_it1 = wall_clock64();
                 uint4 v[ILP], hv[ILP];
@@ -2031,10 +2187,16 @@ __device__ static inline void rep_append_wave(const EngDev &E, const RepArgs &A,
         /* ---- the bytes are in every pushed ring.  R2: the round's doorbell in every pushed follower's mailbox;
          *      the round's done granules for the committer and the applier -- one batch of stores, no second drain ---- */
         const uint32_t t_now = (uint32_t)wall_clock64();
-        if (lane < 8) {
+#if REP_BELL16
+        const uint32_t em8 = (uint32_t)__shfl((int)h1.z, (int)((lane - 8) & 7u));     /* lanes 8..15: the emeta word of entry lane - 8 */
+#else
+        const uint32_t em8 = 0;
+#endif
+        if (lane < R_BELL_W) {
             const uint32_t val = lane == 0 ? (uint32_t)end_after : lane == 1 ? (uint32_t)(slot0 + n) : lane == 2 ? (uint32_t)e0
                                  : lane == 3 ? ((n << 17) | (uniform ? T0 : 0u) | (preset ? R_BELL_REPLY : 0u) | (bell_meta ? R_BELL_META : 0u))
-                                 : !bell_meta ? 0u : lane == 4 ? (uint32_t)idx0 : lane == 5 ? (uint32_t)(idx0 >> 32) : lane == 6 ? (uint32_t)term : (uint32_t)(term >> 32);
+                                 : !bell_meta ? 0u : lane == 4 ? (uint32_t)idx0 : lane == 5 ? (uint32_t)(idx0 >> 32) : lane == 6 ? (uint32_t)term
+                                 : lane == 7 ? (uint32_t)(term >> 32) : em8;
             for (uint32_t m = push; m; m &= m - 1) {
                 const uint32_t f = (uint32_t)__builtin_ctz(m);
                 const uint64_t q = PT.qbase[f] + k;
@@ -2079,6 +2241,10 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
     RepBox *const lbox = leader < APUS_DEV_MAX_SERVERS ? E.box[leader] : nullptr;
     uint64_t bell_next = 0;
     bool have_bell = false;
+#if REP_FAST_ACK
+    uint64_t rp = 0;                          /* lanes 16, 17: the retire wavefront's two words as the doorbell's look saw them */
+    const uint64_t pb_tag = ((my_run + 1) & 0xFFFFFFull) << 40;
+#endif
     const bool timed = A.dbg & 256;
     uint64_t w_rounds = 0, w_total = 0, w_hdr = 0, w_st = 0, w_drain = 0;
     for (uint64_t q = q0 + g;; q += G) {
@@ -2086,9 +2252,19 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
         /* ---- wait for the doorbell of round q ---- */
         uint64_t wv = bell_next;                     /* (looked at under the previous round's store drain) */
         uint32_t go = 0;
+#if REP_FAST_ACK
+        rp = 0;                                      /* (no granule carries tag 0) */
+#endif
         for (uint64_t i = 0;; i++) {
-            if (i || !have_bell) { if (lane < 8) wv = ld_sys(&box->rnd[r][lane]); }
-            if (__ballot(lane < 8 && (wv >> 32) == ((q + 1) & 0xFFFFFFFFull)) == 0xFFull) { go = 1; break; }      /* (the leader stores the whole 64-byte line) */
+            if (i || !have_bell) {
+                if (lane < R_BELL_W) wv = ld_sys(&box->rnd[r][lane]);
+#if REP_FAST_ACK
+                /* (only by a wavefront that has been waiting: rounds that come one by one.  Under load the retire wavefront is
+                 *  hundreds of rounds behind the doorbells and the second load per look cost 2-3 % at five and seven replicas) */
+                if (i >= 2 && lane >= 16 && lane < 18) rp = ld_agent(&FS->ret_pub[lane - 16]);      /* (issued BEHIND the doorbell's load: at least as new) */
+#endif
+            }
+            if (__ballot(lane < R_BELL_W && (wv >> 32) == ((q + 1) & 0xFFFFFFFFull)) == (1ull << R_BELL_W) - 1) { go = 1; break; }      /* (the leader stores the whole line) */
             if ((i & 15) == 15) {
                 const uint64_t ctrl = ld_sys(&box->ctrl);
                 if ((ctrl >> 40) == my_run + 1 && q0 + (ctrl & 0xFFFFFFFFFFull) - 1 <= q) break;   /* parked: round q never comes */
@@ -2113,6 +2289,9 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
         const bool bmeta = (w3 & R_BELL_META) != 0 && !(A.dbg & 16);   /* ... and what the headers say came with the doorbell */
         const uint64_t b_idx0 = (uint64_t)(uint32_t)rdl64(wv, 4) | ((uint64_t)(uint32_t)rdl64(wv, 5) << 32);
         const uint64_t b_term = (uint64_t)(uint32_t)rdl64(wv, 6) | ((uint64_t)(uint32_t)rdl64(wv, 7) << 32);
+#if REP_BELL16
+        const uint32_t em_bell = (uint32_t)__shfl((int)(uint32_t)wv, (int)(8u + (lane & 7u)));      /* (every lane active here: the crossbar reads live lanes only) */
+#endif
         /* the slot count's high half: this run stays within 2^31 slots of where it began */
         uint64_t slot_end = (n_end0 & ~0xFFFFFFFFull) | slot_lo;
         if (slot_end + (1ull << 31) < n_end0) slot_end += 1ull << 32;
@@ -2135,6 +2314,10 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
                  * same placement the leader made), term, clt_id / type / sender */
                 const uint64_t ix = rep_idx(pl, (int)lane, b_idx0);
                 u0 = make_uint4((uint32_t)ix, (uint32_t)(ix >> 32), (uint32_t)b_term, (uint32_t)(b_term >> 32));
+#if REP_BELL16
+                if (n <= 8) u1.z = em_bell;                                            /* (the doorbell's granules 8..15) */
+                else
+#endif
                 u1.z = __hip_atomic_load((const APUS_GLOBAL uint32_t *)(uintptr_t)&box->emeta[r][lane], RLX_SYSTEM);
                 if (A.dbg & 32768) {
                     /* verification mode (tests): the headers are read as well and must say the same */
@@ -2175,6 +2358,16 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
             if (type == APUS_HEAD) { uint4 x0, x1; ld32_sys(Md.ring + pos + 32, x0, x1); head_val = x1.x; }
         }
         const uint32_t acked_all = __ballot(active && !acked) ? 0u : 1u;
+#if REP_FAST_ACK
+        {
+            /* the retire wavefront stands in front of THIS round, and the round continues what it has retired: the cumulative
+             * ACK it will send when the granules below reach it, sent now */
+            const uint64_t rp0 = rdl64(rp, 16), rp1 = rdl64(rp, 17);
+            if (lane == 0 && acked_all && lbox && rep_gran_ok(rp0, q) && rep_gran_ok(rp1, q) && (uint32_t)rp0 == e0 && (uint32_t)rp1 == (uint32_t)slot0
+                && end_after != (uint32_t)L && n != 0)
+                __hip_atomic_fetch_max((APUS_GLOBAL uint64_t *)(uintptr_t)&lbox->persisted_fast_by[me], pb_tag | (slot_end & PB_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+#endif
         if (!(A.dbg & 2)) rep_store_rows32(ar0, ar1, n, [&](uint32_t r) { return (uint8_t *)&Md.apply[(uint32_t)(slot0 + r) & E.dir_mask]; });
         const uint64_t hsum = wsum64(mix);
         const uint32_t nclient = wsum32(client);
@@ -2186,7 +2379,7 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
             st_agent(&FS->fr[lane][r], rep_gran(q, val));
         }
         const uint64_t t_st = timed ? wall_clock64() : 0;
-        if (lane < 8) bell_next = ld_sys(&box->rnd[(q + G) % RB_CAP][lane]);     /* the next doorbell: its round trip runs under this drain */
+        if (lane < R_BELL_W) bell_next = ld_sys(&box->rnd[(q + G) % RB_CAP][lane]);     /* the next doorbell: its round trip runs under this drain */
         have_bell = true;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (timed) { const uint64_t t_dr = wall_clock64(); w_rounds++; w_total += t_dr - t_bell; w_hdr += rdl64(t_hdr, 0) - t_bell; w_st += t_st - rdl64(t_hdr, 0); w_drain += t_dr - t_st; }
@@ -2223,6 +2416,10 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
     uint64_t real_end = pend_n ? L : end;
     const uint64_t pb_tag = ((my_run + 1) & 0xFFFFFFull) << 40;
     if (lane == 0) st_sys(&lbox->persisted_by[me], pb_tag | n_end);
+#if REP_FAST_ACK
+    if (lane == 0) st_sys(&lbox->persisted_fast_by[me], pb_tag | n_end);      /* (this run's tag; the work wavefronts only ever raise it) */
+    if (lane < 2) st_agent(&FS->ret_pub[lane], pend_n ? 0ull : rep_gran(q_ret, lane == 0 ? (uint32_t)real_end : (uint32_t)real_n_end));
+#endif
     uint64_t idle = 0;
     uint32_t exit_code = R_EXIT_STOP, last_p = 0;
     uint64_t final_q = ~0ull;
@@ -2290,6 +2487,9 @@ __device__ static inline void rep_follow_retire(const EngDev &E, const RepArgs &
         }
         last_p = (uint32_t)(q_ret - t0);
         if (gap) { exit_code = R_EXIT_GAP; if (lane == 0) spin_timeout(E, 7301); break; }
+#if REP_FAST_ACK
+        if (progress && lane < 2) st_agent(&FS->ret_pub[lane], (pend_n || fenced) ? 0ull : rep_gran(q_ret, lane == 0 ? (uint32_t)real_end : (uint32_t)real_n_end));
+#endif
         if (progress && lane == 0) {
             s_f[F_END] = end; s_f[F_N_END] = n_end;
             s_f[F_Q_RET] = q_ret;                       /* (the apply wavefront reads F_Q_RET first) */

@@ -361,3 +361,29 @@ def test_rep_a_replica_moves_through_its_fence_pairs_and_round_again():
 
     run_and_compare(base, "staged", on_event=on_event)
     assert seen["fences"] >= 27, seen
+
+
+# ---- round 6: the lone round's path (REP_SPEC_PAY / REP_BELL16 / REP_FAST_ACK / REP_APPLY_PRE, apus_replica.h) ------------------
+
+@pytest.mark.parametrize("g,payload,batch,drain", [
+    (3, 64, 1, True),                                   # one request at a time, each waited for: proxy_on_read with one client
+    (3, 64, (1, 8), True),                              # <= 64 units: the payload comes with the descriptors
+    (3, 64, (1, 12), False),                            # ... back to back: rounds the retire wavefront is and is not standing at
+    (5, (16, 64, 192), (1, 4), True),                   # sizes that differ inside a round: no size in the ticket
+    (3, (0, 14, 48, 64, 80, 96, 97, 200), (1, 9), True),    # header-only entries, sizes that are no multiple of 16, payloads in the arena
+    (3, 448, 1, True),                                  # one size, but not in the slot
+    (7, 64, (1, 2), False),
+    (1, 64, (1, 3), True),
+])
+def test_rep_rounds_that_come_one_by_one(g, payload, batch, drain, monkeypatch):
+    """Round 6 took four dependent memory round trips out of a lone round's way (host submit -> highest_rec 17 -> 14 us): the
+    append wavefront asks for the slots' payload together with their descriptors when the ticket names the entries' one size
+    (leader_handle_submit_req + get_tailq_message + log_append_entry, src/proxy/proxy.c:108-161, dare_ibv_ud.c:780-790); the
+    doorbell carries the first eight entries' clt_id / type / sender; the follower's work wavefront sends the cumulative ACK
+    itself when its retire wavefront stands at its round (rc_send_entries_reply, dare_ibv_rc.c:1828-1863); the leader's applier
+    holds the round's done granules until the commit comes (dare_server.c:1815-1974).  Small rounds over a small ring -- wraps,
+    prune ticks, header-only entries, payloads in the arena -- with every follower wavefront comparing what the doorbell said
+    with the headers that landed (APUS_REP_DBG & 32768): every replica bit for bit the oracle's."""
+    monkeypatch.setenv("APUS_REP_DBG", "32768")
+    tr = T.steady_trace(g, 700, payload, 8, batch, log_len=1 << 16, seed=11)
+    run_and_compare(tr, "pinned", drain_each=drain)
