@@ -337,7 +337,7 @@ int  apus_gpu_device_arch(int device, char *out, int cap);
 /* ---- replica kernels: every replica runs its OWN resident workgroups ---------------------
  * The one-server-per-machine structure of the reference on GPUs (apus_amd/csrc/apus_replica.h).  The
  * leader's workgroups run the leader's polling() loop pipelined (sequencer -> append wavefronts -> committer:
- * many rounds in flight) and push ONLY the log bytes + one 32-byte doorbell per round to every follower;
+ * many rounds in flight) and push ONLY the log bytes + one doorbell line (128 bytes since round 6) per round to every follower;
  * each follower's workgroups -- on the follower's own device, in its own process when the replica is
  * peer-mapped -- poll their doorbells, build directory and apply records locally from the landed bytes,
  * persist, acknowledge (R3) and apply on the commit doorbell.  R3 since round 4: the reply bytes ride with the entries
