@@ -123,6 +123,7 @@ SIGNATURES = {
     "apus_gpu_read_retired_ring": (C.c_int, [vp, u32, u32, u64, u64, vp]),
     "apus_gpu_last_entry": (C.c_int, [vp, u32, C.POINTER(u64)]),
     "apus_gpu_rep_box_words": (C.c_int, [vp, u32, u32, C.POINTER(u64)]),
+    "apus_gpu_selftest_atomic_misses": (C.c_int, [vp, C.POINTER(u64)]),
     "apus_gpu_numa_node": (C.c_int, [C.c_int]),
     "apus_gpu_bind_near": (C.c_int, [vp, C.c_int]),
 }

@@ -48,6 +48,7 @@ struct apus_engine {
     std::vector<void *> ipc_ptrs;    /* hipIpcOpenMemHandle results, closed at destroy */
     uint32_t reachable;             /* peers the leader can post to (trace KILL/HOLD/RELEASE) */
     bool lag_possible;              /* a follower may be far behind: run the wide catch-up first */
+    uint64_t st_atomic_misses = 0;  /* apus_gpu_selftest, pushing side: system-scope atomics that had not landed in front of the store behind them */
     bool tick_pending;              /* a prune tick waits to be fused into the next batch's sequencer */
     uint64_t max_rounds;
     /* staging */
@@ -3275,6 +3276,7 @@ extern "C" int apus_gpu_selftest(apus_engine_t *e, uint32_t pusher, uint32_t own
     hipFree(d_res);
     if (er != hipSuccess) return APUS_E_HIP;
     out[0] = h[0]; out[1] = h[1]; out[2] = h[2] == ~0ull ? 0 : h[2]; out[3] = h[3];
+    e->st_atomic_misses += h[10];
     if (h[1] && getenv("APUS_DEBUG"))
         fprintf(stderr, "[apus_gpu] selftest %u -> %u: first difference seen in round %llu unit %llu: there %016llx %016llx, pushed %016llx %016llx\n", pusher, owner,
                 h[4] - 1, h[5], h[6], h[7], h[8], h[9]);
@@ -3286,7 +3288,16 @@ extern "C" int apus_gpu_selftest(apus_engine_t *e, uint32_t pusher, uint32_t own
         HIPCHK(hipMemsetAsync(e->d.box[owner]->rnd, 0, sizeof e->d.box[owner]->rnd, e->stream));
     }
     if ((roles & 1u) && own_pusher) HIPCHK(hipMemsetAsync(e->d.box[pusher]->rnd, 0, sizeof e->d.box[pusher]->rnd, e->stream));
+    if ((roles & 1u) && own_pusher) HIPCHK(hipMemsetAsync(&e->d.box[pusher]->persisted_fast_by[15], 0, sizeof(uint64_t), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+/* the pushing side's count, over this engine's self-tests so far, of regions it found freed before the checker's system-scope
+ * atomic max (issued and drained in front of the freeing word) had reached its mailbox: 0 is what REP_FAST_ACK rests on */
+extern "C" int apus_gpu_selftest_atomic_misses(apus_engine_t *e, uint64_t *misses)
+{
+    if (!e || !misses) return APUS_E_ARG;
+    *misses = e->st_atomic_misses;
     return 0;
 }
 /* The write-through store ceiling of the data path's pattern (apus_selftest.h: k_calib_store_multi): 8 KiB chunks written at

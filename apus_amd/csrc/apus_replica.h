@@ -2243,6 +2243,8 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
     bool have_bell = false;
 #if REP_FAST_ACK
     uint64_t rp = 0;                          /* lanes 16, 17: the retire wavefront's two words as the doorbell's look saw them */
+    const bool fast_on = !(A.dbg & 65536);    /* (APUS_REP_DBG & 65536: off at run time -- bench.py --gpus N sets it when first contact finds that a
+                                               *  system-scope atomic into the peer's mailbox does not land before the store behind it, apus_selftest.h) */
     const uint64_t pb_tag = ((my_run + 1) & 0xFFFFFFull) << 40;
 #endif
     const bool timed = A.dbg & 256;
@@ -2261,7 +2263,7 @@ __device__ static inline void rep_follow_wave(const EngDev &E, const RepArgs &A,
 #if REP_FAST_ACK
                 /* (only by a wavefront that has been waiting: rounds that come one by one.  Under load the retire wavefront is
                  *  hundreds of rounds behind the doorbells and the second load per look cost 2-3 % at five and seven replicas) */
-                if (i >= 2 && lane >= 16 && lane < 18) rp = ld_agent(&FS->ret_pub[lane - 16]);      /* (issued BEHIND the doorbell's load: at least as new) */
+                if (fast_on && i >= 2 && lane >= 16 && lane < 18) rp = ld_agent(&FS->ret_pub[lane - 16]);      /* (issued BEHIND the doorbell's load: at least as new) */
 #endif
             }
             if (__ballot(lane < R_BELL_W && (wv >> 32) == ((q + 1) & 0xFFFFFFFFull)) == (1ull << R_BELL_W) - 1) { go = 1; break; }      /* (the leader stores the whole line) */

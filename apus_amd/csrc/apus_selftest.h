@@ -14,6 +14,11 @@
  *
  * Regions are reused every `regions` rounds, so a stale line of an earlier lap is a mismatch.  Both roles can run in one
  * launch (roles = 3: the one-device unit test) or in two processes (roles = 1 on the pusher's, 2 on the owner's).
+ * Round 6: the cumulative ACK a follower's work wavefront sends itself (REP_FAST_ACK) is a system-scope ATOMIC MAX into the
+ * leader's mailbox through the mapping; the checker does the same -- round + 1 into the pusher's persisted_fast_by[15], a
+ * drain, then the word that frees the region -- and the pusher, when it finds a region free, expects the atomic's word to
+ * have got at least that far ([10]: times it had not: bench.py then runs the group with APUS_REP_DBG & 65536, the ACKs
+ * through the retire wavefronts' plain stores alone).
  * Result words: [0] rounds checked, [1] units that differed, [2] first round that differed + 1, [3] waits that timed out.
  * A mismatch is not the end: bench.py re-creates the group with the rings in fine-grained memory (APUS_RING_ALLOC) and
  * tests again; the line says which allocation the numbers were taken on. */
@@ -51,6 +56,8 @@ __global__ __launch_bounds__(256) void k_selftest(const EngDev E, uint32_t pushe
                     if (++polls > max_polls) { if (lane == 0) atomicAdd(&res[3], 1ull); return; }
                     __builtin_amdgcn_s_sleep(2);
                 }
+                /* (the checker's atomic max went out, and was drained, in front of that word) */
+                if (lane == 0 && ld_sys(&pbox->persisted_fast_by[15]) < r - regions + 1) atomicAdd(&res[10], 1ull);
             }
             uint8_t *dst = ring + (uint64_t)s * ST_ROUND_BYTES;
 #pragma unroll
@@ -102,7 +109,11 @@ __global__ __launch_bounds__(256) void k_selftest(const EngDev E, uint32_t pushe
                 res[8] = (unsigned long long)w.x | ((unsigned long long)w.y << 32); res[9] = (unsigned long long)w.z | ((unsigned long long)w.w << 32);
             }
         }
-        if (lane == 0) st_sys(&pbox->rnd[s][7], r + 1);
+        if (lane == 0) {
+            __hip_atomic_fetch_max((APUS_GLOBAL uint64_t *)(uintptr_t)&pbox->persisted_fast_by[15], (uint64_t)(r + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_sys(&pbox->rnd[s][7], r + 1);
+        }
     }
     if (lane == 0) { atomicAdd(&res[0], checked); atomicAdd(&res[1], bad); if (first_bad) atomicMin(&res[2], first_bad); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

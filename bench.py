@@ -1002,11 +1002,16 @@ def _ring_visibility_selftest(m, world, rank, n_rep):
         elif rank == f:
             rc = L.apus_gpu_selftest(h, 0, f, 2, rounds, 1024, 20000, out)
             mine = {"role": "check", "rc": int(rc), "rounds": int(out[0]), "bad_units": int(out[1]), "first_bad_round": int(out[2]), "timeouts": int(out[3])}
+        if rank == 0:
+            miss = C.c_uint64(0)
+            L.apus_gpu_selftest_atomic_misses(h, C.byref(miss))      # (cumulative over the followers tested so far)
+            mine["atomic_misses"] = int(miss.value)
         got = [None] * world
         dist.all_gather_object(got, mine)
         chk, psh = got[f] or {}, got[0] or {}
         res[str(f)] = {"rounds": chk.get("rounds"), "bad_units": chk.get("bad_units"), "first_bad_round": chk.get("first_bad_round"),
-                       "timeouts": chk.get("timeouts"), "pusher_timeouts": psh.get("timeouts"), "rc": [psh.get("rc"), chk.get("rc")]}
+                       "timeouts": chk.get("timeouts"), "pusher_timeouts": psh.get("timeouts"), "rc": [psh.get("rc"), chk.get("rc")],
+                       "atomic_misses_so_far": psh.get("atomic_misses")}
     return res
 
 
@@ -1155,6 +1160,14 @@ def bench_multi(args):
             verdict = _selftest_verdict(second, rounds_wanted)
             selftest.update(retested=True, allocation="fine-grained device memory (hipExtMallocWithFlags, APUS_RING_ALLOC=finegrained)",
                             verdict=verdict, by_follower_first_attempt=first, by_follower=second)
+        # the follower's own cumulative ACK of a lone round (REP_FAST_ACK) is a system-scope atomic max into the leader's mailbox:
+        # if first contact saw one arrive behind the store issued after its drain, every rank runs without it (the ACKs then go
+        # through the retire wavefronts' plain stores alone, as in round 5) and the line says so
+        misses = max([int(v.get("atomic_misses_so_far") or 0) for v in selftest["by_follower"].values()] + [0])
+        selftest["fast_ack"] = "on"
+        if misses or os.environ.get("APUS_SELFTEST_FORCE_NO_FAST_ACK"):
+            os.environ["APUS_REP_DBG"] = str(int(os.environ.get("APUS_REP_DBG", "0") or 0) | 65536)
+            selftest["fast_ack"] = f"off (APUS_REP_DBG & 65536): {misses} system-scope atomics into the leader's mailbox had not landed in front of the store behind them"
         if verdict != "ok":
             # the run goes on -- a line that says what happened is worth more to whoever reads it than a traceback -- but nothing it
             # measures counts as verified: the data path rests on exactly what this test checks
@@ -1285,7 +1298,7 @@ def bench_multi(args):
         E = 64 + args.payload
         value = n_entries * args.steps / dt
         rounds_per_step = sum(c[2] for c in cmds if c[0] == "run")
-        link_bytes_per_entry = E + 64.0 * rounds_per_step / n_entries           # log bytes + one 64-byte doorbell per round
+        link_bytes_per_entry = E + 128.0 * rounds_per_step / n_entries          # log bytes + one 128-byte doorbell line per round (round 6: apus_replica.h, REP_BELL16)
         link = value * link_bytes_per_entry / 1e9
         out = {
             "metric": "committed entries/sec", "value": value, "unit": "entries/s",
@@ -1307,7 +1320,7 @@ def bench_multi(args):
             "roofline": {"bound": "xgmi", "achieved": link, "peak": XGMI_LINK_GBS, "unit": "GB/s", "frac": link / XGMI_LINK_GBS,
                          "traffic": None, "kernel": "k_replica", "bytes_per_entry": link_bytes_per_entry,
                          "bytes_per_link_per_step": link_bytes_per_entry * n_entries,
-                         "note": "per leader->follower link: E log bytes per entry + one 64-byte doorbell per round (nothing derived crosses: directory, "
+                         "note": "per leader->follower link: E log bytes per entry + one 128-byte doorbell line per round (nothing derived crosses: directory, "
                                  "apply records and ACK bookkeeping are built by the follower's own kernel); against ONE xGMI link (153 GB/s), "
                                  "each follower sits on its own link; back: 1 reply byte per entry + 1 round ACK granule and the commit doorbell"
                                  + ("; TEST MODE: nothing crossed a link" if one_dev else ""),

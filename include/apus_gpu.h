@@ -375,6 +375,12 @@ int  apus_gpu_calib_store_bw(apus_engine_t *e, uint32_t peer, uint64_t bytes, ui
 int  apus_gpu_selftest(apus_engine_t *e, uint32_t pusher, uint32_t owner, uint32_t roles, uint64_t rounds, uint32_t regions,
                        uint32_t timeout_ms, uint64_t out[4]);
 int  apus_gpu_ring_alloc_kind(apus_engine_t *e);
+/* Round 6: the checker of apus_gpu_selftest also sends what a follower's work wavefront sends when it acknowledges a lone round
+ * itself (apus_replica.h, REP_FAST_ACK): a system-scope atomic max into the PUSHER's mailbox, drained, in front of the word that
+ * frees the region.  *misses = on the pushing side, over this engine's self-tests: regions found free before the atomic's word
+ * had got that far.  Not 0: run the group with APUS_REP_DBG & 65536 (every ACK through the retire wavefronts' plain stores, as
+ * in round 5) -- bench.py --gpus N does. */
+int  apus_gpu_selftest_atomic_misses(apus_engine_t *e, uint64_t *misses);
 /* The write-through store ceiling of the data path's own pattern: 8 KiB chunks (a round of 64 x 128 B) written at the same offset
  * into every hosted ring of `mask`, through the whole ring, `passes` times, by `wgs` workgroups of four wavefronts, nothing else
  * in the launch.  *gbps = bytes written / the launch's duration.  Destroys the rings' contents (calibration, before a group starts). */

@@ -52,6 +52,8 @@ def test_bench_gpus_n_dry_run_full_schema(n):
            os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--entries", "131072", "--cpu-seconds", "1",
            "--watchdog", "240"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", APUS_DIST_BACKEND="gloo", APUS_DIST_ONE_DEVICE="1", APUS_SELFTEST_ROUNDS="100000")
+    if n == 5:
+        env["APUS_SELFTEST_FORCE_NO_FAST_ACK"] = "1"       # one size walks the group without REP_FAST_ACK
     if n == 4:
         env["APUS_SELFTEST_FORCE_FALLBACK"] = "1"          # one size walks the fall-back: the group starts again with fine-grained rings
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
@@ -64,6 +66,9 @@ def test_bench_gpus_n_dry_run_full_schema(n):
         # first contact: every follower's resident kernel checked every round its leader's device pushed, nothing differed
         assert st["verdict"] == "ok" and len(st["by_follower"]) == replicas - 1
         assert all(v["rounds"] == 100000 and v["bad_units"] == 0 and not v["timeouts"] and not v["pusher_timeouts"] for v in st["by_follower"].values()), st
+        # ... and the follower's own ACK of a lone round (a system-scope atomic max into the leader's mailbox) is on when the
+        # atomics of first contact all landed in order, off for the whole group when told they did not
+        assert st["fast_ack"] == "on" if n != 5 else st["fast_ack"].startswith("off (APUS_REP_DBG & 65536)"), st["fast_ack"]
         assert st["retested"] == (n == 4) and ("fine-grained" in st["allocation"]) == (n == 4) and st["allocation"].split(" (")[0] in d["config"]["mode"]
         # the smaller groups BASELINE names, in the same run (1 / 3 / 5 replicas below the headline's), every one verified
         want = {str(k) for k in (1, 3, 5, 7) if k <= replicas}
@@ -74,7 +79,7 @@ def test_bench_gpus_n_dry_run_full_schema(n):
         assert st is None and "rccl_transport" not in d
     assert d["n_gpus"] == n and d["config"]["replicas"] == replicas and d["config"]["spare_machines"] == n - replicas
     assert d["verified"] is True and d["value"] > 0 and d["metric"] == "committed entries/sec" and d["scaling"] == "weak"
-    assert d["roofline"]["bound"] == "xgmi" and d["roofline"]["kernel"] == "k_replica" and 0 < d["roofline"]["bytes_per_entry"] < 64 + 64 + 2
+    assert d["roofline"]["bound"] == "xgmi" and d["roofline"]["kernel"] == "k_replica" and 0 < d["roofline"]["bytes_per_entry"] < 64 + 64 + 3
     assert d["placement"]["ranks_in_group"] == n and len(d["placement"]["ranks"]) == n and d["placement"]["peer_access_matrix"]
     cal = d["link_calibration"]
     assert cal and all(v and v > 0 for v in cal["doorbell_round_trip_us_p50"].values()) and len(cal["doorbell_round_trip_us_p50"]) == n - 1

@@ -22,6 +22,10 @@ def test_pusher_and_resident_checker_agree_on_every_byte():
             rc = eng.L.apus_gpu_selftest(eng.h, pusher, owner, 3, 300000, regions, 20000, out)
             assert rc == 0 and list(out) == [300000, 0, 0, 0], (pusher, owner, regions, rc, list(out))
         assert eng.L.apus_gpu_ring_alloc_kind(eng.h) == 0
+        # round 6: the checker's system-scope atomic max into the pusher's mailbox (what REP_FAST_ACK sends) always got there in
+        # front of the store issued behind its drain
+        miss = C.c_uint64(7)
+        assert eng.L.apus_gpu_selftest_atomic_misses(eng.h, C.byref(miss)) == 0 and miss.value == 0, miss.value
         # what the test touched is cleared: the engine still walks a trace bit for bit
         assert not eng.ring(1, 0, 1 << 16).any() and not eng.ring(0, 0, 1 << 16).any()
     finally:
