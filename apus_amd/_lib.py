@@ -124,6 +124,7 @@ SIGNATURES = {
     "apus_gpu_last_entry": (C.c_int, [vp, u32, C.POINTER(u64)]),
     "apus_gpu_rep_box_words": (C.c_int, [vp, u32, u32, C.POINTER(u64)]),
     "apus_gpu_selftest_atomic_misses": (C.c_int, [vp, C.POINTER(u64)]),
+    "apus_gpu_rep_feed_profile": (C.c_int, [vp, C.POINTER(u64)]),
     "apus_gpu_numa_node": (C.c_int, [C.c_int]),
     "apus_gpu_bind_near": (C.c_int, [vp, C.c_int]),
 }

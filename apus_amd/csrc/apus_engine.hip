@@ -48,6 +48,11 @@ struct apus_engine {
     std::vector<void *> ipc_ptrs;    /* hipIpcOpenMemHandle results, closed at destroy */
     uint32_t reachable;             /* peers the leader can post to (trace KILL/HOLD/RELEASE) */
     bool lag_possible;              /* a follower may be far behind: run the wide catch-up first */
+    /* APUS_FEED_PROF=1: where a producer's time goes in apus_gpu_rep_submit, by phase, summed over the producers (TSC ticks):
+     * [0] blocks [1] slots [2] reserve (the fetch-and-add + waiting for room in the ring) [3] payload + descriptor stores (write-combined,
+     * through the BAR) [4] the fence behind them [5] the slots' publish words [6] the windows' accounts + words [7] the call's last fence */
+    uint64_t feed_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int feed_prof_on = -1;
     uint64_t st_atomic_misses = 0;  /* apus_gpu_selftest, pushing side: system-scope atomics that had not landed in front of the store behind them */
     bool tick_pending;              /* a prune tick waits to be fused into the next batch's sequencer */
     uint64_t max_rounds;
@@ -129,6 +134,7 @@ struct apus_engine {
     uint64_t r_fruns[APUS_MAX_SERVERS];          /* leader: every pushed follower's f_runs when the run began (apus_gpu_rep_park waits for the next) */
     uint32_t r_push_mask, r_cand_mask;        /* the last run started here as the leader: who gets its rounds, who could be reached */
     uint64_t r_slot_tail, r_arena_tail, r_cmd_tail;   /* producer side of the pinned rings (under r_lock) */
+    uint64_t r_done_seen = 0;       /* rh->slots_done as a producer last read it (rep_reserve_inline) */
     uint64_t *r_slot_aend;          /* [RQ_CAP] logical arena position behind every slot's payload */
     uint32_t *r_win_cnt, *r_win_len;/* [RQ_CAP / 64] per aligned window of 64 request slots: how many are published, and the one length they
                                      * all have (rep_win_note: whoever brings a window to 64 writes its word, RepReq.ready_win) */
@@ -2724,7 +2730,7 @@ extern "C" int apus_gpu_rep_start(apus_engine_t *e, uint32_t idle_ms, uint32_t p
         uint64_t h[64];
         HIPCHK(hipMemcpy(h, e->d.rep[leader].hdr, sizeof h, hipMemcpyDeviceToHost));
         /* (a run that ended abnormally may have left commands or slots behind: they are dropped) */
-        e->rh->cmd_head = e->r_cmd_tail; e->rh->slots_done = e->r_slot_tail;
+        e->rh->cmd_head = e->r_cmd_tail; e->rh->slots_done = e->r_slot_tail; e->r_done_seen = e->r_slot_tail;
         /* the windows' accounts start empty; the window the ring's tail stands in is charged with the slots in front of the tail
          * (used up by earlier runs) and never gets a word: its count still comes to 64 and is cleared for the next lap */
         for (uint32_t w = 0; w < RQ_CAP / WAVE; w++) { e->r_win_cnt[w] = 0; e->r_win_len[w] = R_WIN_UNSET; }
@@ -2860,10 +2866,19 @@ static inline int rep_reserve_inline(apus_engine *e, uint32_t n, uint64_t *first
 {
     const uint64_t atail = __atomic_load_n(&e->r_arena_tail, __ATOMIC_ACQUIRE);
     const uint64_t s0 = __atomic_fetch_add(&e->r_slot_tail, (uint64_t)n, __ATOMIC_ACQ_REL);
-    const double t0 = mono_s();
-    while (s0 + n - e->rh->slots_done > R_SLOTS_INFLIGHT) {
-        if (e->rh->alive == 2) return APUS_E_STATE;
-        if (mono_s() - t0 > 5.0) return -1;
+    /* room in the ring: by what some producer last READ of the device's count first -- slots_done is a line of pinned host memory
+     * the device keeps writing, and every look at it is a miss that crosses to the device's side of the fabric (0.3 of a lone
+     * producer's 1.2 us per block of 256 slots went into this look: profiles/r06_feed_profile.txt); the count only grows, an old
+     * value errs on the side of waiting */
+    if (s0 + n - __atomic_load_n(&e->r_done_seen, __ATOMIC_RELAXED) > R_SLOTS_INFLIGHT) {
+        const double t0 = mono_s();
+        for (;;) {
+            const uint64_t done = e->rh->slots_done;
+            __atomic_store_n(&e->r_done_seen, done, __ATOMIC_RELAXED);
+            if (s0 + n - done <= R_SLOTS_INFLIGHT) break;
+            if (e->rh->alive == 2) return APUS_E_STATE;
+            if (mono_s() - t0 > 5.0) return -1;
+        }
     }
     for (uint32_t i = 0; i < n; i++) e->r_slot_aend[(s0 + i) % RQ_CAP] = atail;
     *first = s0;
@@ -2948,6 +2963,10 @@ extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uin
     static const uint32_t BLK = []() { const char *v = getenv("APUS_REP_SUBMIT_BLOCK"); const int x = v ? atoi(v) : 0; return (uint32_t)(x >= 1 && x <= 1024 ? x : 256); }();
     uint32_t g = 0;
     bool words_pending = false;
+    if (e->feed_prof_on < 0) { const char *v = getenv("APUS_FEED_PROF"); e->feed_prof_on = v && atoi(v) ? 1 : 0; }
+    const bool prof = e->feed_prof_on == 1;
+    uint64_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = 0;
+#define FEED_T(i) do { if (prof) { const uint64_t t_ = __builtin_ia32_rdtsc(); pf[i] += t_ - tp; tp = t_; } } while (0)
     while (g < n) {
         if (reqs[g].len > R_INLINE) {
             uint64_t slot; void *dst;
@@ -2965,8 +2984,10 @@ extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uin
          *  order, words that sat in the write-combining buffers meanwhile would stall every other producer) */
         if (words_pending && e->rq_bar && __atomic_load_n(&e->r_slot_tail, __ATOMIC_RELAXED) + run - e->rh->slots_done > R_SLOTS_INFLIGHT) { __builtin_ia32_sfence(); words_pending = false; }
         uint64_t s0;
+        if (prof) tp = __builtin_ia32_rdtsc();
         int rc = rep_reserve_inline(e, run, &s0);
         if (rc) { if (words_pending && e->rq_bar) __builtin_ia32_sfence(); return rc; }
+        FEED_T(2);
         for (uint32_t i = 0; i < run; i++) {
             const apus_req_t &q = reqs[g + i];
             RepSlot &sl = e->rq->slot[(s0 + i) % RQ_CAP];
@@ -2975,14 +2996,34 @@ extern "C" int apus_gpu_rep_submit(apus_engine_t *e, const apus_req_t *reqs, uin
             d.req_id = q.req_id; d.pay16_type = R_PAY_INLINE | ((uint32_t)q.type << 28); d.len = q.len; d.clt_id = q.clt_id;
             sl.d = d;
         }
+        FEED_T(3);
         if (e->rq_bar) __builtin_ia32_sfence();            /* the payloads and descriptors (and the block before's publish words) */
+        FEED_T(4);
         for (uint32_t i = 0; i < run; i++)
             __atomic_store_n((uint32_t *)&e->rq->ready_len[(s0 + i) % RQ_CAP], (rep_slot_tag(s0 + i) << 16) | reqs[g + i].len, __ATOMIC_RELEASE);
+        FEED_T(5);
         rep_win_note(e, s0, run, reqs + g, 0, all_same);   /* the windows these slots lie in: whoever completes one writes its word */
+        FEED_T(6);
+        pf[0]++; pf[1] += run;
         words_pending = true;
         g += run;
     }
+    if (prof) tp = __builtin_ia32_rdtsc();
     if (words_pending && e->rq_bar) __builtin_ia32_sfence();
+    FEED_T(7);
+    if (prof) for (int i = 0; i < 8; i++) __atomic_fetch_add(&e->feed_prof[i], pf[i], __ATOMIC_RELAXED);
+#undef FEED_T
+    return 0;
+}
+/* APUS_FEED_PROF=1: out[0..7] = the producers' phase counters so far (apus_engine.feed_prof: TSC ticks), out[8] = TSC ticks per
+ * microsecond as measured here over 20 ms; the counters are cleared */
+extern "C" int apus_gpu_rep_feed_profile(apus_engine_t *e, uint64_t out[9])
+{
+    if (!e || !out) return APUS_E_ARG;
+    for (int i = 0; i < 8; i++) out[i] = __atomic_exchange_n(&e->feed_prof[i], 0ull, __ATOMIC_RELAXED);
+    const double t0 = mono_s(); const uint64_t c0 = __builtin_ia32_rdtsc();
+    while (mono_s() - t0 < 0.02) { }
+    out[8] = (uint64_t)((double)(__builtin_ia32_rdtsc() - c0) / ((mono_s() - t0) * 1e6));
     return 0;
 }
 

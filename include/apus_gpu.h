@@ -200,6 +200,13 @@ int  apus_gpu_remap_fenced(apus_engine_t *e, const apus_ipc_replica_t *in);
 /* tests: n bytes at off of the ring `replica` left `back` fences ago (1 = the last): where a deposed leader's stores went */
 int  apus_gpu_read_retired_ring(apus_engine_t *e, uint32_t replica, uint32_t back, uint64_t off, uint64_t n, void *dst);
 
+/* Host-side profile of the request ring's producers (APUS_FEED_PROF=1 in the environment, read at the first submit): TSC ticks
+ * summed over the producers, by phase of apus_gpu_rep_submit -- out[0] blocks, [1] slots, [2] reserve (fetch-and-add + waiting for
+ * room), [3] payload + descriptor stores (write-combined, through the BAR), [4] the fence behind them, [5] the slots' publish words,
+ * [6] the windows' accounts and words, [7] the call's last fence; out[8] = TSC ticks per microsecond.  Clears the counters.
+ * (profiles/r06_feed_profile.txt: what `perf stat` would have been asked about, from inside.) */
+int  apus_gpu_rep_feed_profile(apus_engine_t *e, uint64_t out[9]);
+
 /* ---- where the device hangs (two-socket hosts) ---------------------------- */
 /* The NUMA node of the device's PCIe root (-1: the platform does not say).  A thread on the other socket reaches the request
  * ring and the device's answers through the inter-socket link as well: one producer 130 against 166 M entries/s, four 280
