@@ -95,3 +95,29 @@ def test_algorithmic_bytes():
     for n in (2, 3, 5, 7):
         for e in (104, 128, 1088, 4160):
             assert n * e < bench.algorithmic_bytes(n, e) < (3 * n - 1) * e + 64
+
+
+def test_independent_groups_fallback_line():
+    """`bench.py --gpus N`, last resort (the cross-GPU group raised on a fabric it has never met): the line of N independent
+    single-GPU groups is the contract's -- the entries ALL reporting ranks committed over the SLOWEST rank's region -- and
+    cannot be taken for the one-replica-per-GPU group's: marked in workload, mode, `fallback`, `verified_cross_gpu`."""
+    import argparse
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    args = argparse.Namespace(replicas=3, payload=64, batch=64, warmup=5, gpus=4)
+    parts = [{"rank": r, "device": r, "entries": 1000, "steps": 20, "seconds": 0.004 + 0.001 * r, "entries_per_s": 1000 * 20 / (0.004 + 0.001 * r),
+              "verified": True, "bit_exact_vs_oracle": True if r == 0 else None} for r in (2, 0, 3, 1)]
+    d = bench.independent_groups_line(args, 4, parts, "RuntimeError: hipIpcOpenMemHandle: invalid argument")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["metric"] == "committed entries/sec" and d["n_gpus"] == 4 and d["steps"] == 20 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert abs(d["value"] - 4 * 1000 * 20 / 0.007) < 1e-6 and abs(d["ms_per_step"] - 0.007 / 20 * 1e3) < 1e-12
+    assert d["value"] <= sum(p["entries_per_s"] for p in parts)           # never more than the ranks' own figures add up to
+    assert d["fallback"] is True and d["verified_cross_gpu"] is False and d["verified"] is True
+    assert d["config"]["workload"].startswith("FALLBACK") and d["config"]["mode"].startswith("FALLBACK") and "hipIpcOpenMemHandle" in d["config"]["mode"]
+    assert d["config"]["ranks_reporting"] == [0, 1, 2, 3] and [p["rank"] for p in d["by_rank"]] == [0, 1, 2, 3] and "model" not in d["config"]
+    # a rank that did not report: the line exists, and is not verified
+    d3 = bench.independent_groups_line(args, 4, parts[:3], "x")
+    assert d3["verified"] is False and d3["config"]["groups"] == 3 and d3["n_gpus"] == 4
+    json.dumps(d)
