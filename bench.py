@@ -1114,12 +1114,15 @@ def bench_multi(args):
     import torch
     import torch.distributed as dist
     from apus_amd import peers
-    faulthandler.dump_traceback_later(args.watchdog, exit=True)          # nothing here may hang the driver
+    faulthandler.dump_traceback_later(args.watchdog, exit=False)         # nothing here may hang the driver: the stacks first ...
+    _arm_group_watchdog(args)                                            # ... then the rank starts again as main()'s last resort
     if os.environ.get("APUS_GROUP_TRANSPORT") == "p2p":
         from apus_amd.distributed import bench_group
         return bench_group(args)
     rank, world, local, backend = peers.init_process_group_from_env(args.gpus, timeout=datetime.timedelta(seconds=min(args.watchdog, 300)))
     one_dev = bool(os.environ.get("APUS_DIST_ONE_DEVICE"))
+    if os.environ.get("APUS_BENCH_FORCE_GROUP_HANG"):             # (tests: a rank that sits somewhere for good)
+        time.sleep(10 ** 6)
     if os.environ.get("APUS_BENCH_FORCE_GROUP_FAILURE"):          # (tests: walk main()'s last resort on a box where the group works)
         raise RuntimeError("APUS_BENCH_FORCE_GROUP_FAILURE: the cross-GPU group was told to fail")
     n_rep = world if world % 2 == 1 else world - 1
@@ -1348,6 +1351,7 @@ def bench_multi(args):
     #      extras are not through in time (a collective of the send / recv transport that never completes on a fabric it has never
     #      seen, say), rank 0 prints the line as it stands and every rank leaves with status 0.
     import threading
+    _WATCH["phase"], _WATCH["out"] = "extras", out      # (the watchdog: from here on there is a line to print, not a group to give up)
     extras_done = threading.Event()
 
     def _bail():
@@ -1396,6 +1400,35 @@ def bench_multi(args):
     dist.destroy_process_group()
     faulthandler.cancel_dump_traceback_later()
     return out
+
+
+_WATCH = {"done": None, "phase": "headline", "out": None}
+
+
+def _arm_group_watchdog(args):
+    """--gpus N: a rank that has not left bench_multi after --watchdog seconds.  With the headline measured (the extras hang): rank 0
+    prints the line as it stands, every rank leaves with status 0.  Without: the rank REPLACES itself (exec: the old process image,
+    its HIP context, its resident workgroups and its peer mappings go the way a killed process's do) by one that goes straight to
+    independent_groups_fallback -- a hang on a fabric nobody has seen costs the driver the group's figure, not its line."""
+    import threading
+    _WATCH["done"] = threading.Event()
+
+    def run():
+        if _WATCH["done"].wait(args.watchdog + 2):
+            return
+        rank = os.environ.get("RANK", "0")
+        if _WATCH["phase"] == "extras":
+            if _WATCH["out"] is not None:
+                _WATCH["out"]["extras"] = f"cut off by the watchdog after {args.watchdog} s: what is missing below the headline did not finish"
+                print(json.dumps(_WATCH["out"]), flush=True)
+            os._exit(0)
+        print(f"[bench] rank {rank}: watchdog: the cross-GPU group had not finished after {args.watchdog} s; this rank starts again as an "
+              "independent single-GPU group", file=sys.stderr, flush=True)
+        os.environ["APUS_BENCH_FALLBACK_REASON"] = (f"watchdog: the cross-GPU group had not finished after {args.watchdog} s on rank {rank} "
+                                                    "(every rank's stacks are on stderr)")
+        sys.stdout.flush()
+        os.execv(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+    threading.Thread(target=run, daemon=True).start()
 
 
 def independent_groups_line(args, world, parts, reason, one_dev=False):
@@ -1449,6 +1482,14 @@ def independent_groups_fallback(args, exc):
     part = {"rank": rank, "device": local, "error": None}
     try:
         torch.cuda.set_device(local)
+        # what the failed group left on this device -- a resident launch ends by itself once its host says nothing (idle_ms) or its
+        # peers go quiet (peer_ms): give it that long, bounded, before a launch that needs every one of its workgroups resident
+        import threading
+        th = threading.Thread(target=lambda: torch.cuda.synchronize(local), daemon=True)
+        th.start()
+        th.join(timeout=20.0)
+        if th.is_alive():
+            print(f"[bench] rank {rank}: device {local} still busy with what the failed group left there; measuring beside it", file=sys.stderr, flush=True)
         tr = build_trace(args, args.replicas)
         lock = None
         if one_dev:            # (two resident launches cannot share one device's workgroup slots: the test mode takes turns)
@@ -1553,9 +1594,15 @@ def main():
         sys.exit(subprocess.call(cmd, env=env))
     else:
         try:
+            if os.environ.get("APUS_BENCH_FALLBACK_REASON"):       # (this rank was started again by its watchdog: _arm_group_watchdog)
+                raise RuntimeError(os.environ["APUS_BENCH_FALLBACK_REASON"])
             out = bench_multi(args)
-        except Exception as exc:      # (a hang is the watchdog's: it ends the rank)
+            if _WATCH["done"] is not None:
+                _WATCH["done"].set()
+        except Exception as exc:      # (a hang is the watchdog's: it starts the rank again, and the rank comes here)
             import traceback
+            if _WATCH["done"] is not None:
+                _WATCH["done"].set()
             traceback.print_exc()
             out = independent_groups_fallback(args, exc)
             if out is not None:
