@@ -1475,8 +1475,12 @@ def independent_groups_fallback(args, exc):
     one_dev = bool(os.environ.get("APUS_DIST_ONE_DEVICE"))
     local = 0 if one_dev else int(os.environ.get("LOCAL_RANK", str(rank)))
     print(f"[bench] rank {rank}: the cross-GPU group failed ({reason}); falling back to independent single-GPU groups", file=sys.stderr, flush=True)
+    # how long rank 0 waits for the others: a rank that sat in the group until its watchdog started it again reports about a minute
+    # after T0 + watchdog -- whenever THIS rank got here
+    t_start = float(os.environ.get("APUS_BENCH_T0", str(time.time())))
+    wait_until = max(time.time() + 60.0, t_start + args.watchdog + 120.0)
     faulthandler.cancel_dump_traceback_later()
-    faulthandler.dump_traceback_later(max(args.watchdog, 120), exit=True)
+    faulthandler.dump_traceback_later(max(wait_until - time.time() + 120.0, 180.0), exit=True)
     d = os.path.join(tempfile.gettempdir(), f"apus_bench_fallback_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")      # (every rank is a child of the one launcher)
     os.makedirs(d, exist_ok=True)
     part = {"rank": rank, "device": local, "error": None}
@@ -1515,7 +1519,7 @@ def independent_groups_fallback(args, exc):
     if rank == 0:
         t0 = time.time()
         parts = {}
-        while time.time() - t0 < max(60, args.watchdog - 60):
+        while time.time() < max(wait_until, t0 + 30.0):
             for r in range(world):
                 fp = os.path.join(d, f"rank{r}.json")
                 if r not in parts and os.path.exists(fp):
@@ -1593,6 +1597,7 @@ def main():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         sys.exit(subprocess.call(cmd, env=env))
     else:
+        os.environ.setdefault("APUS_BENCH_T0", str(time.time()))      # (kept across the watchdog's exec)
         try:
             if os.environ.get("APUS_BENCH_FALLBACK_REASON"):       # (this rank was started again by its watchdog: _arm_group_watchdog)
                 raise RuntimeError(os.environ["APUS_BENCH_FALLBACK_REASON"])
