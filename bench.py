@@ -1121,7 +1121,7 @@ def bench_multi(args):
         return bench_group(args)
     rank, world, local, backend = peers.init_process_group_from_env(args.gpus, timeout=datetime.timedelta(seconds=min(args.watchdog, 300)))
     one_dev = bool(os.environ.get("APUS_DIST_ONE_DEVICE"))
-    if os.environ.get("APUS_BENCH_FORCE_GROUP_HANG"):             # (tests: a rank that sits somewhere for good)
+    if os.environ.get("APUS_BENCH_FORCE_GROUP_HANG", "") not in ("", "resident"):      # (tests: a rank that sits somewhere for good)
         time.sleep(10 ** 6)
     if os.environ.get("APUS_BENCH_FORCE_GROUP_FAILURE"):          # (tests: walk main()'s last resort on a box where the group works)
         raise RuntimeError("APUS_BENCH_FORCE_GROUP_FAILURE: the cross-GPU group was told to fail")
@@ -1235,6 +1235,8 @@ def bench_multi(args):
         step()                                  # one untimed step: pages in, validates
         for _ in range(args.warmup):
             step()
+    if os.environ.get("APUS_BENCH_FORCE_GROUP_HANG") == "resident":    # (tests: ... with every rank's workgroups resident and its peers' rings mapped)
+        time.sleep(10 ** 6)
     t0 = mark()
     if m.is_leader:
         for _ in range(args.steps):

@@ -131,18 +131,21 @@ def test_bench_gpus_group_failure_falls_back_to_independent_groups():
     assert d["config"]["workload"].startswith("FALLBACK") and d["cpu_baseline"]["value"] > 0
 
 
-def test_bench_gpus_group_hang_falls_back_to_independent_groups():
-    """... and when the cross-GPU group HANGS (every rank told to sit in bench_multi for good): at --watchdog seconds every rank
+@pytest.mark.parametrize("where,n", [("1", 2), ("resident", 3)])
+def test_bench_gpus_group_hang_falls_back_to_independent_groups(where, n):
+    """... and when the cross-GPU group HANGS (every rank told to sit in bench_multi for good -- right behind the process group's
+    start, or with a three-replica group's workgroups resident and every peer's rings mapped): at --watchdog seconds every rank
     dumps its stacks and replaces itself (exec) by a process that goes straight to the same last resort -- one line, status 0."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--entries", "131072", "--cpu-seconds", "1",
-           "--watchdog", "12"]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", APUS_DIST_BACKEND="gloo", APUS_DIST_ONE_DEVICE="1", APUS_BENCH_FORCE_GROUP_HANG="1")
+           os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--entries", "131072", "--cpu-seconds", "1",
+           "--watchdog", "12" if where == "1" else "30", "--no-calibration"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", APUS_DIST_BACKEND="gloo", APUS_DIST_ONE_DEVICE="1", APUS_BENCH_FORCE_GROUP_HANG=where,
+               APUS_SELFTEST_ROUNDS="100000")
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert p.returncode == 0 and len(lines) == 1, f"rc={p.returncode}\n{p.stdout[-1500:]}\n{p.stderr[-4000:]}"
     d = json.loads(lines[0])
     assert d["fallback"] is True and d["verified_cross_gpu"] is False and d["group_failure"].startswith("RuntimeError: watchdog")
-    assert d["n_gpus"] == 2 and d["config"]["ranks_reporting"] == [0, 1] and d["verified"] is True and d["value"] > 0
+    assert d["n_gpus"] == n and d["config"]["ranks_reporting"] == list(range(n)) and d["verified"] is True and d["value"] > 0
     assert d["by_rank"][0]["bit_exact_vs_oracle"] is True
