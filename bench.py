@@ -925,7 +925,11 @@ def bench_single(args):
         except Exception as exc:
             print(f"[bench] configs[0] (redis under LD_PRELOAD) failed: {exc!r}", file=sys.stderr)
     if not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        try:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        except Exception as exc:          # (no checker library on this box: the GPU's line is printed without the CPU's figure, and says why)
+            print(f"[bench] cpu baseline failed: {exc!r}", file=sys.stderr)
+            out["cpu_baseline"] = {"value": None, "unit": "committed entries/s", "cores": 0, "kind": "port", "sample": None, "error": repr(exc)[:300]}
     return out
 
 
