@@ -121,3 +121,20 @@ def test_independent_groups_fallback_line():
     d3 = bench.independent_groups_line(args, 4, parts[:3], "x")
     assert d3["verified"] is False and d3["config"]["groups"] == 3 and d3["n_gpus"] == 4
     json.dumps(d)
+
+
+def test_group_watchdog_prints_the_line_once_the_headline_exists():
+    """`bench.py --gpus N`: a rank still inside the group's measurement at --watchdog seconds.  With the headline measured (the
+    phase is "extras"), rank 0's watchdog prints the line as it stands and the rank leaves with status 0 -- it never gives a
+    measured group up for the fallback."""
+    import subprocess
+    import sys
+    code = ("import sys, time, argparse; sys.path.insert(0, %r); import bench\n"
+            "bench._WATCH['phase'], bench._WATCH['out'] = 'extras', {'metric': 'committed entries/sec', 'value': 1.0, 'n_gpus': 3}\n"
+            "bench._arm_group_watchdog(argparse.Namespace(watchdog=-1))\n"
+            "time.sleep(30)\nsys.exit(7)\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout, p.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["value"] == 1.0 and d["n_gpus"] == 3 and "cut off by the watchdog" in d["extras"]
