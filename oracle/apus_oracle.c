@@ -25,8 +25,12 @@
 /* ================================================================== */
 /* Part 1: the log (dare_log.h)                                        */
 
-/* dare_log_entry_t, dare_log.h:33-47; offsets probed in SURVEY.md section 10 */
-typedef struct {
+/* dare_log_entry_t, dare_log.h:33-47; offsets probed in SURVEY.md section 10.
+ * Entries lie at ANY byte offset of the ring (an entry is 64 B + its payload's length, nothing is rounded up), and the reference
+ * reads them through a plain struct pointer -- fine on x86, undefined in C.  Here the type is packed (alignment 1, the padding in
+ * front of `data` spelled out), so every access is an unaligned-safe one and the checker runs clean under UBSan
+ * (tools/oracle_sanitize.sh); the asserts below hold the reference's offsets. */
+typedef struct __attribute__((packed)) {
     uint64_t idx;                       /*  0 */
     uint64_t term;                      /*  8 */
     uint64_t req_id;                    /* 16 */
@@ -34,8 +38,9 @@ typedef struct {
     uint8_t  type;                      /* 26 */
     uint8_t  sender;                    /* 27 */
     uint8_t  reply[ORC_MAX_SERVERS];    /* 28 */
-    union {
-        struct { uint16_t len; uint8_t cmd[]; } cmd;   /* 48 ; payload @50 */
+    uint8_t  pad_[48 - 28 - ORC_MAX_SERVERS];          /* 41 (the reference's struct has this padding implicitly) */
+    union __attribute__((packed)) {
+        struct __attribute__((packed)) { uint16_t len; uint8_t cmd[]; } cmd;   /* 48 ; payload @50 */
         orc_cid_t cid;
         uint64_t  head;
     } data;
@@ -518,7 +523,7 @@ static void poll_config_entries(replica_t *p)
         orc_entry_t *e = get_entry(log, &off);
         if (!fits_entry(log, off, e)) { off = 0; continue; }
         if (e->type == ORC_CONFIG) {
-            if (e->idx > p->cid_idx) update_cid(p, &e->data.cid);
+            if (e->idx > p->cid_idx) { const orc_cid_t cid = e->data.cid; update_cid(p, &cid); }    /* (a copy: the entry is not aligned) */
         } else if (e->type == ORC_HEAD) {
             if (!orc_log_is_larger(log, off, commit)) {     /* committed HEAD entries only */
                 head_offset = e->data.head;
