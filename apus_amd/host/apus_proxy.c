@@ -1465,6 +1465,7 @@ struct proxy_node_t *proxy_init(const char *config_path, const char *proxy_log_p
     }
     p->leader_map = calloc(MAX_FDS, sizeof(lead_pair_t));
     p->follower_map = calloc(65536, sizeof(foll_pair_t));
+    if (!p->leader_map || !p->follower_map) { free(p->leader_map); free(p->follower_map); free(p); return NULL; }
     if (p->req_log) {
         char path[512];
         snprintf(path, sizeof path, "%s/node-proxy-req.log", proxy_log_path ? proxy_log_path : ".");
@@ -1474,6 +1475,7 @@ struct proxy_node_t *proxy_init(const char *config_path, const char *proxy_log_p
 
     /* dare_main, proxy.c:22-89: same environment variables, same defaults */
     dare_server_input_t *in = calloc(1, sizeof *in);
+    if (!in) { free(p->leader_map); free(p->follower_map); free(p); return NULL; }      /* (the hooks stay inert: proxy != NULL guards) */
     in->log = stdout;
     in->name = "";
     in->output = "dare_servers.out";
