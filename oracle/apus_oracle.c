@@ -1340,6 +1340,11 @@ static orc_entry_t *mt_next(orc_log_t *log, uint64_t *off, uint64_t lim)
     }
 }
 
+/* Under ThreadSanitizer this port still reports races of two kinds, both the reference's own and on purpose: the circular comparison
+ * of a HEAD entry's offset reads the live `end` word its leader's thread stores (dare_log.h:255-280 reads the word the NIC writes), and
+ * a follower's thread stores its reply byte into the leader's copy of an entry (the RDMA WRITE of rc_send_entries_reply, dare_ibv_rc.c:1828-1863) while the leader's thread memcpy's a range
+ * of its ring into another follower (its NIC reading host memory under update_remote_logs): which reply bytes of OTHER servers a
+ * follower's copy holds depends on that timing in the reference too, and tests/test_trace_oracle.py compares everything but them. */
 static void *mt_follower(void *arg)
 {
     mt_ctx_t *x = arg;
@@ -1373,7 +1378,7 @@ static void *mt_follower(void *arg)
             while ((e = mt_next(log, &apply, commit))) {
                 if (e->type == ORC_HEAD) { if (orc_log_is_larger(log, e->data.head, log->head)) log->head = e->data.head; }
                 else if (e->type != ORC_CONFIG && e->type != ORC_NOOP) {
-                    log->apply = apply;
+                    __atomic_store_n(&log->apply, apply, __ATOMIC_RELAXED);      /* (the leader's prune tick reads it from its own thread) */
                     record_apply(c, p, apply, e, 2);
                     p->last_applied.idx = e->idx; p->last_applied.term = e->term; p->last_applied.offset = apply + entry_len(e);
                 }
