@@ -1517,10 +1517,13 @@ def independent_groups_fallback(args, exc):
     except Exception as exc2:
         part["error"] = repr(exc2)[:500]
         print(f"[bench] rank {rank}: the fallback's measurement failed too: {exc2!r}", file=sys.stderr, flush=True)
-    tmp = os.path.join(d, f".rank{rank}.tmp")
-    with open(tmp, "w") as f:
-        json.dump(part, f)
-    os.replace(tmp, os.path.join(d, f"rank{rank}.json"))
+    try:
+        tmp = os.path.join(d, f".rank{rank}.tmp")
+        with open(tmp, "w") as f:
+            json.dump(part, f)
+        os.replace(tmp, os.path.join(d, f"rank{rank}.json"))
+    except OSError as exc4:            # (rank 0 gave up waiting and is gone: nobody reads this rank's figure any more)
+        print(f"[bench] rank {rank}: could not leave its figure in {d}: {exc4!r}", file=sys.stderr, flush=True)
     out = None
     if rank == 0:
         t0 = time.time()
@@ -1533,6 +1536,9 @@ def independent_groups_fallback(args, exc):
             if len(parts) == world:
                 break
             time.sleep(0.2)
+        if len(parts) == world:            # (everybody has reported: nothing more will be written there)
+            import shutil
+            shutil.rmtree(d, ignore_errors=True)
         good = [p for p in parts.values() if not p.get("error")]
         if good:
             out = independent_groups_line(args, world, good, reason, one_dev)

@@ -138,3 +138,42 @@ def test_group_watchdog_prints_the_line_once_the_headline_exists():
     assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout, p.stderr[-2000:])
     d = json.loads(lines[0])
     assert d["value"] == 1.0 and d["n_gpus"] == 3 and "cut off by the watchdog" in d["extras"]
+
+
+def test_independent_groups_fallback_two_ranks_meet_without_a_process_group():
+    """The last resort's exchange, world size 2, on CPU: two ranks (children of one launcher, no process group between them) each
+    "measure" their own device -- the measurement itself is replaced here, it needs an MI355X and has its GPU test -- leave their
+    figures in the launcher-keyed directory, and rank 0 alone prints the one line: both ranks in it, the slower rank's time."""
+    import subprocess
+    import sys
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = ("import sys, json, argparse; sys.path.insert(0, %r); import bench, torch, os\n"
+            "torch.cuda.set_device = lambda d: None\n"
+            "torch.cuda.synchronize = lambda d=None: None\n"
+            "rank = int(os.environ['RANK'])\n"
+            "def fake(args, tr, n_rep, steps=None, device=0, **kw):\n"
+            "    assert device == rank and n_rep == 3\n"
+            "    return {'device_resident': {'value': len(tr.reqs) * steps / (0.01 * (rank + 1)), 'ms_per_step': 10.0 * (rank + 1) / steps, 'steps': steps,\n"
+            "                                'verified': True, 'bit_exact_vs_oracle': True if kw.get('oracle_check') else None}}\n"
+            "bench.measure_replica_kernels = fake\n"
+            "args = argparse.Namespace(replicas=3, payload=64, batch=64, warmup=1, steps=4, gpus=2, entries=4096, watchdog=60, no_cpu=True, cpu_seconds=1.0, config='c2')\n"
+            "out = bench.independent_groups_fallback(args, RuntimeError('the group fell apart'))\n"
+            "if out is not None: print(json.dumps(out))\n" % ROOT)
+    procs = []
+    for r in (1, 0):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_PORT=str(port))
+        env.pop("APUS_DIST_ONE_DEVICE", None)
+        procs.append((r, subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    outs = {r: p.communicate(timeout=120) + (p.returncode,) for r, p in procs}
+    assert outs[0][2] == 0 and outs[1][2] == 0, outs
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]            # rank 1 prints nothing
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1, outs[0]
+    d = json.loads(lines[0])
+    assert d["fallback"] is True and d["n_gpus"] == 2 and d["config"]["ranks_reporting"] == [0, 1] and d["verified"] is True
+    n = d["by_rank"][0]["entries"]
+    assert abs(d["value"] - 2 * n * 4 / 0.02) < 1e-6 * d["value"] and "the group fell apart" in d["group_failure"]
+    assert [p["device"] for p in d["by_rank"]] == [0, 1] and d["by_rank"][0]["bit_exact_vs_oracle"] is True and d["by_rank"][1]["bit_exact_vs_oracle"] is None
